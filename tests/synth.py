@@ -1,0 +1,91 @@
+"""Deterministic synthetic inputs, integer-only, no RNG library.
+
+Same generators the reference's own tests and benches use, restated in numpy:
+  noise            -> tests/support/synthetic.rs:183  (LCG, one step per byte)
+  noise_gray       -> tests/support/synthetic.rs:200
+  gradient_rgb     -> benches/comparison.rs:32 (generate_gradient_image)
+  flat_blocks      -> benches/comparison.rs:82 (generate_flat_blocks_image)
+  checkerboard     -> tests/support/synthetic.rs:88
+  rgba_noise_alpha1-> SURVEY.md §8c C5 input (LCG bytes, every 4th byte |= 1)
+"""
+import numpy as np
+
+_A = 1103515245
+_C = 12345
+
+
+def lcg_bytes(n: int, seed: int) -> np.ndarray:
+    """n bytes of `state = state*1103515245 + 12345 (mod 2^32); byte = state>>16`.
+
+    Vectorised with the closed form state_k = A^k*seed + C*(A^k-1)/(A-1) computed
+    by blocked affine-map composition (all arithmetic mod 2^32 in uint64 lanes).
+    """
+    if n == 0:
+        return np.zeros(0, dtype=np.uint8)
+    out = np.empty(n, dtype=np.uint8)
+    # affine maps x -> a*x + c for 1..B steps
+    B = 1 << 16
+    a = np.empty(B, dtype=np.uint64)
+    c = np.empty(B, dtype=np.uint64)
+    ca, cc = 1, 0
+    M = 0xFFFFFFFF
+    # build tables by doubling: (a,c) for k steps
+    a_list = [1]
+    c_list = [0]
+    # sequentially is O(B) python ops = 65k, fine
+    for k in range(B):
+        ca = (ca * _A) & M
+        cc = (cc * _A + _C) & M
+        a[k] = ca
+        c[k] = cc
+    state = seed & M
+    pos = 0
+    while pos < n:
+        m = min(B, n - pos)
+        s = (a[:m] * np.uint64(state) + c[:m]) & np.uint64(M)
+        out[pos:pos + m] = ((s >> np.uint64(16)) & np.uint64(0xFF)).astype(np.uint8)
+        state = int(s[m - 1])
+        pos += m
+    return out
+
+
+def noise(w: int, h: int, seed: int = 42) -> np.ndarray:
+    return lcg_bytes(w * h * 3, seed)
+
+
+def noise_gray(w: int, h: int, seed: int = 42) -> np.ndarray:
+    return lcg_bytes(w * h, seed)
+
+
+def rgba_noise_alpha1(w: int, h: int, seed: int = 42) -> np.ndarray:
+    b = lcg_bytes(w * h * 4, seed)
+    b[3::4] |= 1
+    return b
+
+
+def gradient_rgb(w: int, h: int) -> np.ndarray:
+    x = np.arange(w, dtype=np.uint32)[None, :]
+    y = np.arange(h, dtype=np.uint32)[:, None]
+    r = ((x * 255) // max(w, 1)).astype(np.uint8) + np.zeros((h, 1), np.uint8)
+    g = ((y * 255) // max(h, 1)).astype(np.uint8) + np.zeros((1, w), np.uint8)
+    b = (((x + y) * 127) // max(w + h, 1)).astype(np.uint8)
+    return np.stack([r, g, b], axis=-1).reshape(-1)
+
+
+def flat_blocks(w: int, h: int) -> np.ndarray:
+    colors = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0]], np.uint8)
+    bx = (np.arange(w) >= w // 2).astype(np.int64)[None, :]
+    by = (np.arange(h) >= h // 2).astype(np.int64)[:, None]
+    return colors[by * 2 + bx].reshape(-1)
+
+
+def checkerboard(w: int, h: int, cell: int = 8) -> np.ndarray:
+    cell = max(cell, 1)
+    cx = (np.arange(w) // cell)[None, :]
+    cy = (np.arange(h) // cell)[:, None]
+    v = np.where((cx + cy) % 2 == 0, 255, 0).astype(np.uint8)
+    return np.repeat(v.reshape(-1), 3)
+
+
+def constant(w: int, h: int, v: int, channels: int = 3) -> np.ndarray:
+    return np.full(w * h * channels, v, np.uint8)

@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py — Mpixels/s of the JPEG encode pixel pipeline (RGB→YCbCr→DCT→quant) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the fused colour + DCT + quantise kernel over one batch of synthetic
+input that is already resident in HBM (BASELINE.json configs[1]: one 4096x4096 RGB8 image,
+q=80, 4:2:0).  Each rank rotates over enough distinct input/output buffers to exceed the
+256 MiB Infinity Cache, so the bytes really come from and go to HBM.  N>1: every rank
+encodes its own images (weak scaling, no data-path collective — SURVEY §8e); the only
+communication is the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line (rank 0) with the contract's keys plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2_444", "c3", "c1"],
+                    help="c2: 4096x4096 4:2:0 (the metric); c2_444; c3: 64x1920x1080 batch; c1: 512x512")
+    ap.add_argument("--quality", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    return ap.parse_args()
+
+
+WORKLOADS = {
+    #        w     h     batch  subsampling  label
+    "c2": (4096, 4096, 1, 1, "configs[1]: single 4096x4096 RGB8, q=80, 4:2:0, fused colour+DCT+quant kernel"),
+    "c2_444": (4096, 4096, 1, 0, "4096x4096 RGB8, q=80, 4:4:4"),
+    "c3": (1920, 1080, 64, 1, "configs[2]: batch of 64 x 1920x1080 RGB8, q=80, 4:2:0, one launch"),
+    "c1": (512, 512, 1, 1, "configs[0] shape on the GPU: 512x512 RGB8, q=80, 4:2:0"),
+}
+
+
+def cpu_baseline(w, h, ss, quality, budget_s):
+    """Oracle (C restatement, -O2, OpenMP over MCU rows) timed on this host's cores on the same
+    4096x4096 workload, coefficient stage only (the work the GPU kernel does)."""
+    import oracle_lib as O
+    import synth
+    px = synth.noise(w, h, 42)
+    cores = os.cpu_count() or 1
+    O.coeffs(px[: 64 * 64 * 3], 64, 64, 2, ss, quality)  # load lib
+    t0 = time.perf_counter()
+    O.coeffs(px, w, h, 2, ss, quality, threads=cores)
+    first = time.perf_counter() - t0
+    reps = max(1, min(50, int(budget_s / max(first, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.coeffs(px, w, h, 2, ss, quality, threads=cores)
+    dt = (time.perf_counter() - t0) / reps
+    out = {"value": round(w * h / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+           "sample": "%d x (%dx%d RGB8 noise seed 42, q=%d, %s) coefficient stage (colour+DCT+quant) "
+                     "by oracle/pixo_oracle.c, gcc -O2 -ffp-contract=off, OpenMP %d threads"
+                     % (reps, w, h, quality, "4:2:0" if ss else "4:4:4", cores)}
+    # single-thread figure as well (the reference's baseline encode_scan is single-threaded)
+    t0 = time.perf_counter()
+    O.coeffs(px, w, h, 2, ss, quality, threads=1)
+    out["value_1_thread"] = round(w * h / (time.perf_counter() - t0) / 1e6, 2)
+    return out
+
+
+def cpu_reference_wasm(w, h, ss, quality):
+    """The reference's OWN code (its wasm build under node, 1 thread, whole-file encode incl.
+    Huffman) on the same image, if oracle/_ref and node are available on this box."""
+    wasm = os.path.join(ROOT, "oracle", "_ref", "pixo_bg.wasm")
+    try:
+        if not os.path.exists(wasm) or subprocess.run(["node", "--version"], capture_output=True).returncode:
+            return None
+        import synth
+        tmp = tempfile.mkdtemp(prefix="pixo_bench_")
+        inp = os.path.join(tmp, "in.bin")
+        synth.noise(w, h, 42).tofile(inp)
+        man = {"cases": [dict(kind="jpeg", input=inp, w=w, h=h, color_type=2, quality=quality, preset=0,
+                              s420=bool(ss), repeat=4)]}
+        mp = os.path.join(tmp, "m.json")
+        json.dump(man, open(mp, "w"))
+        r = subprocess.run(["node", "--max-old-space-size=4096", os.path.join(ROOT, "oracle", "ref_wasm.js"), mp],
+                           capture_output=True, text=True, timeout=120)
+        ms = json.loads(r.stdout.strip().splitlines()[0])["ms"]
+        best = min(ms[1:])  # discard the JIT warm-up call
+        return {"value": round(w * h / best / 1e3, 2), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
+                "sample": "pixo v0.4.1 wasm32 build under node (V8 JIT), whole-file encode incl. Huffman, "
+                          "best of 3 warm runs on one %dx%d image" % (w, h)}
+    except Exception as e:  # never let the baseline leg break the bench line
+        return {"error": str(e)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    from pixo_amd import jpeg
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist is not None:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    w, h, batch, ss, label = WORKLOADS[args.workload]
+    q = args.quality
+    import synth
+    yb, cbn = jpeg.coefficient_geometry(w, h, 2, ss)
+    in_bytes = w * h * 3 * batch
+    out_bytes = (yb + 2 * cbn) * 128 * batch
+    # rotate over enough buffer sets that the working set exceeds the 256 MiB Infinity Cache
+    nbuf = max(2, -(-(640 << 20) // (in_bytes + out_bytes)))
+    nbuf = min(nbuf, 64)
+    base = synth.noise(w, h, 42 + rank)
+    host = torch.from_numpy(np.ascontiguousarray(base))
+    ins, outs = [], []
+    for i in range(nbuf):
+        t = host.to(dev)
+        if batch > 1:
+            t = t.repeat(batch)
+        # make every buffer distinct content-wise (cheap xor with the buffer index)
+        t = t ^ torch.tensor(i & 0xFF, dtype=torch.uint8, device=dev) if i else t
+        ins.append(t.contiguous())
+        outs.append((torch.empty((batch * yb, 64), dtype=torch.int16, device=dev),
+                     torch.empty((batch * cbn, 64), dtype=torch.int16, device=dev),
+                     torch.empty((batch * cbn, 64), dtype=torch.int16, device=dev)))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        k = i % nbuf
+        y, cb, cr = outs[k]
+        jpeg.coefficients_device(ins[k], w, h, 2, ss, q, y, cb, cr, batch=batch, stream=stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream, per launch
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.barrier()
+
+    # second pass: one event pair per launch (excludes inter-launch gaps), rank 0 only
+    pairs = []
+    if rank == 0:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 64))]
+        for i, (a, b) in enumerate(evs):
+            a.record(); step(i); b.record()
+        torch.cuda.synchronize()
+        pairs = sorted(a.elapsed_time(b) for a, b in evs)
+
+    # correctness spot check inside the bench: buffer 0 against the oracle on a 64-row strip
+    if rank == 0:
+        import oracle_lib as O
+        strip_h = 64
+        oy, ocb, ocr = O.coeffs(base[: w * strip_h * 3], w, strip_h, 2, ss, q)
+        step(0)
+        torch.cuda.synchronize()
+        gy = outs[0][0][: oy.shape[0]].cpu().numpy()
+        gcb = outs[0][1][: ocb.shape[0]].cpu().numpy()
+        if not (np.array_equal(gy, oy) and np.array_equal(gcb, ocb)):
+            raise SystemExit("bench: GPU coefficients differ from the oracle — refusing to report a number")
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    pixels_per_step = w * h * batch
+    value = pixels_per_step * world * args.steps / elapsed / 1e6
+    alg_bytes = in_bytes + out_bytes  # 3 B/px read + 3 B/px written (4:2:0); 3+6 for 4:4:4
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "Mpixels/s JPEG encode (RGB→YCbCr→DCT→quant), 4096×4096 q=80" if args.workload == "c2"
+                  else "Mpixels/s JPEG encode (RGB→YCbCr→DCT→quant), %s" % args.workload,
+        "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": label, "width": w, "height": h, "batch": batch, "quality": q,
+                   "subsampling": "4:2:0" if ss else "4:4:4", "buffers_rotated": nbuf,
+                   "working_set_MiB": round(nbuf * (in_bytes + out_bytes) / 2**20, 1),
+                   "parallelism": "one process per GPU, images sharded across ranks, no collective"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "kernel": "jpeg_coeffs_kernel<%s>" % ("M420" if ss else "M444"),
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_us_avg": round(kernel_ms * 1e3, 3),
+                     "kernel_us_event_pairs_median": round(pairs[len(pairs) // 2] * 1e3, 3) if pairs else None,
+                     "kernel_us_event_pairs_min": round(pairs[0] * 1e3, 3) if pairs else None,
+                     "read_only_frac_of_peak": round(in_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "frac_of_measured_copy_ceiling_6300": round(achieved / 6300.0, 4)},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(4096, 4096, ss, q, args.cpu_seconds)
+        ref = cpu_reference_wasm(4096, 4096, ss, q)
+        if ref:
+            line["cpu_reference"] = ref
+    print(json.dumps(line, ensure_ascii=False))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

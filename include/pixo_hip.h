@@ -1,0 +1,141 @@
+/*
+ * pixo_hip.h — C ABI of the MI355X (gfx950) backend for pixo's JPEG encode path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * A Rust `pixo` crate binds these with `extern "C"` and keeps
+ * its public `pixo::jpeg::{encode, encode_into, JpegOptions, …}` surface unchanged.
+ * Each entry point cites the reference interface (leerob/pixo v0.4.1) it replaces.
+ *
+ * Threading: every function is re-entrant; device buffers and the HIP stream live
+ * in a thread-local context, so many host threads may encode concurrently (the
+ * reference's functions are `Sync`-safe and have rayon callers).
+ *
+ * Errors: functions return PIXO_OK (0) or a negative pixo_status.  The message of
+ * the last failure on the calling thread — identical to the reference's
+ * `pixo::Error` Display string (src/error.rs:50-91) — is available from
+ * pixo_hip_last_error().  All validation errors are reported before any work is
+ * done and in the reference's order (src/jpeg/mod.rs:333-373).
+ */
+#ifndef PIXO_HIP_H
+#define PIXO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* pixo::ColorType discriminants (src/color.rs:7-18, #[repr(u8)]). */
+enum { PIXO_GRAY = 0, PIXO_GRAY_ALPHA = 1, PIXO_RGB = 2, PIXO_RGBA = 3 };
+/* pixo::jpeg::Subsampling (src/jpeg/mod.rs:96-101). */
+enum { PIXO_S444 = 0, PIXO_S420 = 1 };
+
+/* One code per pixo::Error variant that this path can raise (src/error.rs:10-48). */
+typedef enum {
+    PIXO_OK = 0,
+    PIXO_ERR_INVALID_DIMENSIONS = -1,      /* Error::InvalidDimensions            */
+    PIXO_ERR_INVALID_DATA_LENGTH = -2,     /* Error::InvalidDataLength            */
+    PIXO_ERR_INVALID_QUALITY = -3,         /* Error::InvalidQuality               */
+    PIXO_ERR_IMAGE_TOO_LARGE = -4,         /* Error::ImageTooLarge                */
+    PIXO_ERR_UNSUPPORTED_COLOR_TYPE = -5,  /* Error::UnsupportedColorType         */
+    PIXO_ERR_COMPRESSION = -6,             /* Error::CompressionError(String): device/runtime failures */
+    PIXO_ERR_INVALID_RESTART_INTERVAL = -7,/* Error::InvalidRestartInterval       */
+    PIXO_ERR_INVALID_COLOR_ARG = -8,       /* wasm.rs:122-131 "Invalid color type for JPEG: …" */
+    PIXO_ERR_BUFFER_TOO_SMALL = -9         /* encode_into with a fixed-capacity buffer */
+} pixo_status;
+
+/* pixo::jpeg::JpegOptions (src/jpeg/mod.rs:121-140), field for field. */
+typedef struct pixo_jpeg_options {
+    uint32_t width;
+    uint32_t height;
+    uint8_t color_type;            /* PIXO_GRAY or PIXO_RGB                        */
+    uint8_t quality;               /* 1..=100                                      */
+    uint8_t subsampling;           /* PIXO_S444 / PIXO_S420                        */
+    uint8_t has_restart_interval;  /* Option<u16> discriminant                     */
+    uint16_t restart_interval;     /* MCUs; Some(0) is InvalidRestartInterval      */
+    uint8_t optimize_huffman;
+    uint8_t progressive;           /* not on the accelerated path: see DESIGN.md   */
+    uint8_t trellis_quant;         /* not on the accelerated path: see DESIGN.md   */
+} pixo_jpeg_options;
+
+/* JpegOptions::{fast,balanced,max,from_preset} (src/jpeg/mod.rs:162-216). */
+void pixo_jpeg_options_from_preset(pixo_jpeg_options *out, uint32_t width, uint32_t height,
+                                   uint8_t quality, uint8_t preset);
+
+/* ---- whole-file encode (host pixels in, JFIF bytes out) ------------------------- */
+
+/* Replaces `pixo::jpeg::encode(data, &options) -> Result<Vec<u8>>` (src/jpeg/mod.rs:88).
+ * On success *out is a malloc'd buffer the caller releases with pixo_hip_free(). */
+int pixo_hip_jpeg_encode(const uint8_t *data, size_t data_len, const pixo_jpeg_options *options,
+                         uint8_t **out, size_t *out_len);
+
+/* Replaces `pixo::jpeg::encode_into(&mut output, data, &options)` (src/jpeg/mod.rs:328):
+ * writes into caller storage of `capacity` bytes; *out_len receives the bytes needed
+ * (also on PIXO_ERR_BUFFER_TOO_SMALL, so a Rust Vec can reserve and retry). */
+int pixo_hip_jpeg_encode_into(uint8_t *output, size_t capacity, const uint8_t *data,
+                              size_t data_len, const pixo_jpeg_options *options,
+                              size_t *out_len);
+
+/* Replaces the flat wasm-bindgen export `encode_jpeg(data,width,height,color_type,
+ * quality,preset,subsampling_420)` (src/wasm.rs:113-142): same 7 arguments, same
+ * builder order (.quality → .preset → .subsampling), same error strings. */
+int pixo_hip_encode_jpeg(const uint8_t *data, size_t data_len, uint32_t width, uint32_t height,
+                         uint8_t color_type, uint8_t quality, uint8_t preset,
+                         int subsampling_420, uint8_t **out, size_t *out_len);
+
+/* ---- the device seam: the coefficient tuple ------------------------------------- */
+
+/* Geometry of `YCbCrCoefficients` (src/jpeg/mod.rs:58-61, filled by
+ * compute_all_coefficients :932-1230): natural-order i16[64] blocks; 4:2:0 stores
+ * Y as 4 blocks per MCU (TL,TR,BL,BR) in raster MCU order. */
+int pixo_hip_coeff_geometry(uint32_t width, uint32_t height, uint8_t color_type,
+                            uint8_t subsampling, size_t *y_blocks, size_t *c_blocks);
+
+/* Fused colour → (2x2 box) → level shift → f32 AAN DCT → quantise on the GPU;
+ * replaces the per-MCU loop bodies of encode_scan / compute_all_coefficients
+ * (src/jpeg/mod.rs:1448-1557, :981-1046: extract_block/extract_mcu_420 + dct_2d +
+ * quantize_block).  Host pointers; H2D/D2H copies included; synchronous. */
+int pixo_hip_jpeg_coeffs(const uint8_t *pixels, uint32_t width, uint32_t height,
+                         uint8_t color_type, uint8_t subsampling, uint8_t quality,
+                         int16_t *y, size_t y_blocks, int16_t *cb, int16_t *cr,
+                         size_t c_blocks);
+
+/* Same computation on DEVICE pointers for `batch` equally-sized images laid out
+ * back to back (pixels: batch*w*h*bpp bytes; y: batch*y_blocks*64 i16; …).
+ * Asynchronous on `stream` (a hipStream_t, NULL = default stream). */
+int pixo_hip_jpeg_coeffs_device(const void *d_pixels, uint32_t width, uint32_t height,
+                                uint8_t color_type, uint8_t subsampling, uint8_t quality,
+                                uint32_t batch, void *d_y, void *d_cb, void *d_cr,
+                                void *stream);
+
+/* Entropy stage on the host from a coefficient tuple (zig-zag, DC delta, run-length,
+ * Huffman, byte stuffing, headers): replaces encode_block + BitWriterMsb + write_*
+ * (src/jpeg/huffman.rs:423-481, src/bits.rs:195-293, src/jpeg/mod.rs:449-648) when
+ * the coefficients were produced elsewhere (e.g. by several GPUs, see bands below). */
+int pixo_hip_jpeg_entropy_encode(const int16_t *y, const int16_t *cb, const int16_t *cr,
+                                 const pixo_jpeg_options *options, uint8_t **out,
+                                 size_t *out_len);
+
+/* ---- multi-GPU band sharding -------------------------------------- */
+
+/* Splits the image into `parts` contiguous MCU-row bands; band `index` covers pixel
+ * rows [*row_begin, *row_end) and owns *y_blocks / *c_blocks of the tuple starting
+ * at block offsets *y_offset / *c_offset.  Concatenating the bands' coefficients in
+ * index order gives exactly the single-device tuple (edge replication included). */
+int pixo_hip_band(uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling,
+                  uint32_t parts, uint32_t index, uint32_t *row_begin, uint32_t *row_end,
+                  size_t *y_offset, size_t *y_blocks, size_t *c_offset, size_t *c_blocks);
+
+/* ---- runtime ----------------------------------------------------------------------- */
+
+int pixo_hip_device_count(void);            /* 0 when no GPU / no driver              */
+int pixo_hip_set_device(int device);        /* device for the calling thread's context */
+void pixo_hip_free(void *p);
+const char *pixo_hip_last_error(void);      /* thread-local, never NULL               */
+const char *pixo_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIXO_HIP_H */

@@ -1,0 +1,74 @@
+"""Loader for the C-ABI library (pixo_amd/libpixo_hip.so, built by pixo_amd/csrc/Makefile).
+
+There is no CPU fallback: if the HIP library is missing, importing the compute entry
+points fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpixo_hip.so")
+
+
+class JpegOptionsC(C.Structure):
+    """pixo_jpeg_options (include/pixo_hip.h)"""
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32),
+        ("color_type", C.c_uint8), ("quality", C.c_uint8), ("subsampling", C.c_uint8),
+        ("has_restart_interval", C.c_uint8), ("restart_interval", C.c_uint16),
+        ("optimize_huffman", C.c_uint8), ("progressive", C.c_uint8), ("trellis_quant", C.c_uint8),
+    ]
+
+
+# every symbol include/pixo_hip.h declares
+SYMBOLS = [
+    "pixo_jpeg_options_from_preset", "pixo_hip_jpeg_encode", "pixo_hip_jpeg_encode_into",
+    "pixo_hip_encode_jpeg", "pixo_hip_coeff_geometry", "pixo_hip_jpeg_coeffs",
+    "pixo_hip_jpeg_coeffs_device", "pixo_hip_jpeg_entropy_encode", "pixo_hip_band",
+    "pixo_hip_device_count", "pixo_hip_set_device", "pixo_hip_free", "pixo_hip_last_error",
+    "pixo_hip_version",
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "pixo_amd: %s is missing — build it with `make -C pixo_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    u8pp, szp = C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)
+    optp = C.POINTER(JpegOptionsC)
+    L.pixo_jpeg_options_from_preset.argtypes = [optp, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8]
+    L.pixo_jpeg_options_from_preset.restype = None
+    L.pixo_hip_jpeg_encode.argtypes = [C.c_void_p, C.c_size_t, optp, u8pp, szp]
+    L.pixo_hip_jpeg_encode_into.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, optp, szp]
+    L.pixo_hip_encode_jpeg.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint8,
+                                       C.c_uint8, C.c_uint8, C.c_int, u8pp, szp]
+    L.pixo_hip_coeff_geometry.argtypes = [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, szp, szp]
+    L.pixo_hip_jpeg_coeffs.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8,
+                                       C.c_uint8, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                       C.c_size_t]
+    L.pixo_hip_jpeg_coeffs_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint8,
+                                              C.c_uint8, C.c_uint8, C.c_uint32, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pixo_hip_jpeg_entropy_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, optp, u8pp, szp]
+    L.pixo_hip_band.argtypes = [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint32, C.c_uint32,
+                                C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), szp, szp, szp, szp]
+    L.pixo_hip_device_count.restype = C.c_int
+    L.pixo_hip_set_device.argtypes = [C.c_int]
+    L.pixo_hip_free.argtypes = [C.c_void_p]
+    L.pixo_hip_free.restype = None
+    L.pixo_hip_last_error.restype = C.c_char_p
+    L.pixo_hip_version.restype = C.c_char_p
+    for name in ("pixo_hip_jpeg_encode", "pixo_hip_jpeg_encode_into", "pixo_hip_encode_jpeg",
+                 "pixo_hip_coeff_geometry", "pixo_hip_jpeg_coeffs", "pixo_hip_jpeg_coeffs_device",
+                 "pixo_hip_jpeg_entropy_encode", "pixo_hip_band", "pixo_hip_set_device"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L

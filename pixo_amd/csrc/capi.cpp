@@ -1,0 +1,362 @@
+// capi.cpp — the extern "C" boundary declared in include/pixo_hip.h.
+//
+// Owns the thread-local device context (HIP stream, grow-only device and pinned host
+// buffers) and the per-device quantiser-table cache.  No CPU fallback exists: without a
+// usable GPU every compute entry point fails with PIXO_ERR_COMPRESSION and says so.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pixo_hip.h"
+#include "jpeg_host.hpp"
+#include "jpeg_kernels.hpp"
+
+namespace {
+
+thread_local std::string t_error = "";
+
+int fail(int code, const std::string &msg)
+{
+    t_error = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    // pixo::Error::CompressionError(String) Display: "Compression error: {msg}"
+    return fail(PIXO_ERR_COMPRESSION, std::string("Compression error: HIP ") + what + ": " +
+                                          hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+// ---- per-device table cache: 100 qualities x 256 floats, uploaded once -------------
+constexpr int kMaxDevices = 64;
+std::mutex g_qt_mutex;
+float *g_qt[kMaxDevices] = {};
+
+int device_tables(int device, const float **out)
+{
+    std::lock_guard<std::mutex> lock(g_qt_mutex);
+    if (device < 0 || device >= kMaxDevices) return fail(PIXO_ERR_COMPRESSION, "Compression error: bad device index");
+    if (!g_qt[device]) {
+        std::vector<float> host(100 * 256);
+        for (int q = 1; q <= 100; ++q) pixo_host::fill_device_qt(static_cast<uint8_t>(q), &host[(q - 1) * 256]);
+        float *d = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), host.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+        g_qt[device] = d;
+    }
+    *out = g_qt[device];
+    return PIXO_OK;
+}
+
+// ---- thread-local execution context --------------------------------------------------
+struct Context {
+    int device = 0;
+    bool ready = false;
+    hipStream_t stream = nullptr;
+    void *d_px = nullptr;   size_t px_cap = 0;
+    void *d_coef = nullptr; size_t coef_cap = 0;
+    void *h_coef = nullptr; size_t hcoef_cap = 0; // pinned
+
+    int ensure()
+    {
+        if (ready) return PIXO_OK;
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n == 0)
+            return fail(PIXO_ERR_COMPRESSION,
+                        "Compression error: no MI355X/HIP device available (pixo_hip has no CPU fallback)");
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        ready = true;
+        return PIXO_OK;
+    }
+    int reserve_px(size_t n)
+    {
+        if (n <= px_cap) return PIXO_OK;
+        if (d_px) (void)hipFree(d_px);
+        d_px = nullptr; px_cap = 0;
+        HIP_TRY(hipMalloc(&d_px, n));
+        px_cap = n;
+        return PIXO_OK;
+    }
+    int reserve_coef(size_t n)
+    {
+        if (n > coef_cap) {
+            if (d_coef) (void)hipFree(d_coef);
+            d_coef = nullptr; coef_cap = 0;
+            HIP_TRY(hipMalloc(&d_coef, n));
+            coef_cap = n;
+        }
+        return PIXO_OK;
+    }
+    int reserve_hcoef(size_t n)
+    {
+        if (n > hcoef_cap) {
+            if (h_coef) (void)hipHostFree(h_coef);
+            h_coef = nullptr; hcoef_cap = 0;
+            HIP_TRY(hipHostMalloc(&h_coef, n, hipHostMallocDefault));
+            hcoef_cap = n;
+        }
+        return PIXO_OK;
+    }
+    ~Context()
+    {
+        // Process teardown order vs. the HIP runtime is unspecified; leak deliberately
+        // rather than call into a runtime that may already be gone.
+    }
+};
+thread_local Context t_ctx;
+
+// Runs the device pipeline for host pixels; on success `*coef` points at pinned host
+// memory holding [y | cb | cr] contiguously.
+int coeffs_to_pinned(const uint8_t *pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g,
+                     const int16_t **y, const int16_t **cb, const int16_t **cr)
+{
+    Context &c = t_ctx;
+    int rc = c.ensure();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c.device));
+    const float *qt_all = nullptr;
+    rc = device_tables(c.device, &qt_all);
+    if (rc) return rc;
+    const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
+    const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128;
+    if ((rc = c.reserve_px((px_bytes + 15) & ~size_t{15}))) return rc;
+    if ((rc = c.reserve_coef(coef_bytes))) return rc;
+    if ((rc = c.reserve_hcoef(coef_bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(c.d_px, pixels, px_bytes, hipMemcpyHostToDevice, c.stream));
+    int16_t *dy = static_cast<int16_t *>(c.d_coef);
+    int16_t *dcb = dy + g.y_blocks * 64;
+    int16_t *dcr = dcb + g.c_blocks * 64;
+    HIP_TRY(pixo_dev::launch_jpeg_coeffs(c.d_px, o.width, o.height, g.gray, g.s420, 1, dy,
+                                         g.gray ? nullptr : dcb, g.gray ? nullptr : dcr,
+                                         qt_all + (o.quality - 1) * 256, c.stream));
+    HIP_TRY(hipMemcpyAsync(c.h_coef, c.d_coef, coef_bytes, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    *y = static_cast<const int16_t *>(c.h_coef);
+    *cb = *y + g.y_blocks * 64;
+    *cr = *cb + g.c_blocks * 64;
+    return PIXO_OK;
+}
+
+int unsupported_scan_mode(const pixo_jpeg_options &o)
+{
+    if (o.progressive || o.trellis_quant)
+        return fail(PIXO_ERR_COMPRESSION,
+                    "Compression error: progressive/trellis encoding is not implemented by the "
+                    "HIP backend (baseline sequential only); use the CPU encoder for preset 2");
+    return PIXO_OK;
+}
+
+int encode_to_vector(const uint8_t *data, size_t data_len, const pixo_jpeg_options &o,
+                     std::vector<uint8_t> &out)
+{
+    std::string msg;
+    int rc = pixo_host::validate(o, true, data_len, msg);
+    if (rc) return fail(rc, msg);
+    if ((rc = unsupported_scan_mode(o))) return rc;
+    const pixo_host::Geometry g = pixo_host::geometry(o.width, o.height, o.color_type, o.subsampling);
+    const int16_t *y, *cb, *cr;
+    if ((rc = coeffs_to_pinned(data, o, g, &y, &cb, &cr))) return rc;
+    pixo_host::encode_file(y, cb, cr, o, out);
+    return PIXO_OK;
+}
+
+int hand_over(const std::vector<uint8_t> &v, uint8_t **out, size_t *out_len)
+{
+    uint8_t *p = static_cast<uint8_t *>(std::malloc(v.size() ? v.size() : 1));
+    if (!p) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
+    std::memcpy(p, v.data(), v.size());
+    *out = p;
+    *out_len = v.size();
+    return PIXO_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void pixo_jpeg_options_from_preset(pixo_jpeg_options *o, uint32_t width, uint32_t height,
+                                   uint8_t quality, uint8_t preset)
+{ // jpeg/mod.rs:162-216
+    std::memset(o, 0, sizeof *o);
+    o->width = width; o->height = height; o->color_type = PIXO_RGB; o->quality = quality;
+    o->subsampling = PIXO_S444;
+    if (preset == 0) return;
+    o->optimize_huffman = 1;
+    if (preset == 2) { o->subsampling = PIXO_S420; o->progressive = 1; o->trellis_quant = 1; }
+}
+
+int pixo_hip_jpeg_encode(const uint8_t *data, size_t data_len, const pixo_jpeg_options *options,
+                         uint8_t **out, size_t *out_len)
+{
+    std::vector<uint8_t> v;
+    int rc = encode_to_vector(data, data_len, *options, v);
+    if (rc) return rc;
+    return hand_over(v, out, out_len);
+}
+
+int pixo_hip_jpeg_encode_into(uint8_t *output, size_t capacity, const uint8_t *data, size_t data_len,
+                              const pixo_jpeg_options *options, size_t *out_len)
+{
+    std::vector<uint8_t> v;
+    int rc = encode_to_vector(data, data_len, *options, v);
+    if (rc) return rc;
+    *out_len = v.size();
+    if (v.size() > capacity)
+        return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(v.size()) + " bytes");
+    std::memcpy(output, v.data(), v.size());
+    return PIXO_OK;
+}
+
+int pixo_hip_encode_jpeg(const uint8_t *data, size_t data_len, uint32_t width, uint32_t height,
+                         uint8_t color_type, uint8_t quality, uint8_t preset, int subsampling_420,
+                         uint8_t **out, size_t *out_len)
+{ // wasm.rs:113-142
+    if (color_type != PIXO_GRAY && color_type != PIXO_RGB)
+        return fail(PIXO_ERR_INVALID_COLOR_ARG, "Invalid color type for JPEG: " + std::to_string(color_type) +
+                                                    ". Expected 0 (Gray) or 2 (Rgb)");
+    pixo_jpeg_options o;
+    pixo_jpeg_options_from_preset(&o, width, height, quality, preset); // .quality(q).preset(p)
+    o.color_type = color_type;                                         // preset keeps the colour type
+    o.subsampling = subsampling_420 ? PIXO_S420 : PIXO_S444;           // .subsampling(...) overrides
+    return pixo_hip_jpeg_encode(data, data_len, &o, out, out_len);
+}
+
+int pixo_hip_coeff_geometry(uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling,
+                            size_t *y_blocks, size_t *c_blocks)
+{
+    if (width == 0 || height == 0)
+        return fail(PIXO_ERR_INVALID_DIMENSIONS,
+                    "Invalid image dimensions: " + std::to_string(width) + "x" + std::to_string(height));
+    if (color_type != PIXO_GRAY && color_type != PIXO_RGB)
+        return fail(PIXO_ERR_UNSUPPORTED_COLOR_TYPE, "Unsupported color type for this format");
+    const pixo_host::Geometry g = pixo_host::geometry(width, height, color_type, subsampling);
+    *y_blocks = g.y_blocks;
+    *c_blocks = g.c_blocks;
+    return PIXO_OK;
+}
+
+int pixo_hip_jpeg_coeffs(const uint8_t *pixels, uint32_t width, uint32_t height, uint8_t color_type,
+                         uint8_t subsampling, uint8_t quality, int16_t *y, size_t y_blocks, int16_t *cb,
+                         int16_t *cr, size_t c_blocks)
+{
+    pixo_jpeg_options o{};
+    o.width = width; o.height = height; o.color_type = color_type; o.quality = quality;
+    o.subsampling = subsampling;
+    std::string msg;
+    int rc = pixo_host::validate(o, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    const pixo_host::Geometry g = pixo_host::geometry(width, height, color_type, subsampling);
+    if (y_blocks != g.y_blocks || c_blocks != g.c_blocks)
+        return fail(PIXO_ERR_INVALID_DATA_LENGTH,
+                    "Invalid pixel data length: expected " + std::to_string(g.y_blocks) + " bytes, got " +
+                        std::to_string(y_blocks));
+    const int16_t *hy, *hcb, *hcr;
+    if ((rc = coeffs_to_pinned(pixels, o, g, &hy, &hcb, &hcr))) return rc;
+    std::memcpy(y, hy, g.y_blocks * 128);
+    if (g.c_blocks) {
+        std::memcpy(cb, hcb, g.c_blocks * 128);
+        std::memcpy(cr, hcr, g.c_blocks * 128);
+    }
+    return PIXO_OK;
+}
+
+int pixo_hip_jpeg_coeffs_device(const void *d_pixels, uint32_t width, uint32_t height, uint8_t color_type,
+                                uint8_t subsampling, uint8_t quality, uint32_t batch, void *d_y, void *d_cb,
+                                void *d_cr, void *stream)
+{
+    pixo_jpeg_options o{};
+    o.width = width; o.height = height; o.color_type = color_type; o.quality = quality;
+    o.subsampling = subsampling;
+    std::string msg;
+    int rc = pixo_host::validate(o, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if (batch == 0 || batch > 65535) return fail(PIXO_ERR_COMPRESSION, "Compression error: batch must be 1..65535");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const float *qt_all = nullptr;
+    if ((rc = device_tables(dev, &qt_all))) return rc;
+    const bool gray = color_type == PIXO_GRAY;
+    HIP_TRY(pixo_dev::launch_jpeg_coeffs(d_pixels, width, height, gray, !gray && subsampling == PIXO_S420,
+                                         batch, d_y, gray ? nullptr : d_cb, gray ? nullptr : d_cr,
+                                         qt_all + (quality - 1) * 256, static_cast<hipStream_t>(stream)));
+    return PIXO_OK;
+}
+
+int pixo_hip_jpeg_entropy_encode(const int16_t *y, const int16_t *cb, const int16_t *cr,
+                                 const pixo_jpeg_options *options, uint8_t **out, size_t *out_len)
+{
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if ((rc = unsupported_scan_mode(*options))) return rc;
+    std::vector<uint8_t> v;
+    pixo_host::encode_file(y, cb, cr, *options, v);
+    return hand_over(v, out, out_len);
+}
+
+int pixo_hip_band(uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling, uint32_t parts,
+                  uint32_t index, uint32_t *row_begin, uint32_t *row_end, size_t *y_offset, size_t *y_blocks,
+                  size_t *c_offset, size_t *c_blocks)
+{
+    if (width == 0 || height == 0)
+        return fail(PIXO_ERR_INVALID_DIMENSIONS,
+                    "Invalid image dimensions: " + std::to_string(width) + "x" + std::to_string(height));
+    if (parts == 0 || index >= parts) return fail(PIXO_ERR_COMPRESSION, "Compression error: bad band index");
+    const pixo_host::Geometry g = pixo_host::geometry(width, height, color_type, subsampling);
+    const uint32_t unit_px = g.s420 ? 16 : 8;
+    // contiguous unit-row bands, the first (units_y % parts) bands one row taller
+    const uint32_t base = g.units_y / parts, extra = g.units_y % parts;
+    const uint32_t u0 = index * base + (index < extra ? index : extra);
+    const uint32_t u1 = u0 + base + (index < extra ? 1 : 0);
+    *row_begin = u0 * unit_px < height ? u0 * unit_px : height;
+    *row_end = u1 * unit_px < height ? u1 * unit_px : height;
+    const size_t per_row_y = static_cast<size_t>(g.units_x) * (g.s420 ? 4 : 1);
+    *y_offset = u0 * per_row_y;
+    *y_blocks = (u1 - u0) * per_row_y;
+    *c_offset = g.gray ? 0 : static_cast<size_t>(u0) * g.units_x;
+    *c_blocks = g.gray ? 0 : static_cast<size_t>(u1 - u0) * g.units_x;
+    return PIXO_OK;
+}
+
+int pixo_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pixo_hip_set_device(int device)
+{
+    Context &c = t_ctx;
+    if (c.ready && c.device != device) {
+        // rebind: drop the old device's buffers lazily by resetting the context
+        if (c.d_px) (void)hipFree(c.d_px);
+        if (c.d_coef) (void)hipFree(c.d_coef);
+        if (c.h_coef) (void)hipHostFree(c.h_coef);
+        if (c.stream) (void)hipStreamDestroy(c.stream);
+        c = Context();
+    }
+    c.device = device;
+    return PIXO_OK;
+}
+
+void pixo_hip_free(void *p) { std::free(p); }
+
+const char *pixo_hip_last_error(void) { return t_error.c_str(); }
+
+const char *pixo_hip_version(void) { return "pixo_hip 0.1.0 (gfx950; reference pixo 0.4.1)"; }
+
+} // extern "C"

@@ -1,0 +1,71 @@
+// jpeg_host.hpp — host half of the JPEG path: option validation, quantiser and Huffman
+// tables, JFIF headers and the entropy coder that turns the GPU's coefficient tuple
+// into a byte stream identical to the reference's.
+//
+// This is PRODUCT code (C++17).  It never includes or links anything from oracle/.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/pixo_hip.h"
+
+namespace pixo_host {
+
+// ---- quantiser tables: reference src/jpeg/quantize.rs:42-89 ------------------------
+struct QuantTables {
+    uint8_t lum_zigzag[64]; // DQT payloads (zig-zag order)
+    uint8_t chr_zigzag[64];
+    float lum[64];          // natural order, exact integers 1..255
+    float chr[64];
+};
+QuantTables make_quant_tables(uint8_t quality);
+
+// Device-side table block (layout documented in jpeg_tile.h: 1/q lum, 1/q chr, q lum, q chr)
+void fill_device_qt(uint8_t quality, float out[256]);
+
+extern const uint8_t kZigzag[64]; // quantize.rs:18-22
+
+// ---- Huffman tables: reference src/jpeg/huffman.rs ---------------------------------
+struct HuffTable {
+    uint8_t bits[16];
+    uint8_t vals[256];
+    int nvals = 0;
+    uint16_t code[256];
+    uint8_t len[256];
+    bool assign_codes(int symbol_limit); // canonical codes, huffman.rs:264-291
+};
+struct HuffSet {
+    HuffTable dc[2]; // [0] luminance, [1] chrominance
+    HuffTable ac[2];
+    static HuffSet standard();                                       // Annex K, huffman.rs:17-62
+    // huffman.rs:167-205 + jpeg/mod.rs:380-390: falls back to standard() like unwrap_or_default
+    static HuffSet optimized(const uint64_t dc_counts[2][12], const uint64_t ac_counts[2][256],
+                             bool has_chroma);
+};
+
+// ---- geometry of the coefficient tuple (jpeg/mod.rs:58-61) --------------------------
+struct Geometry {
+    bool gray, s420;
+    uint32_t units_x, units_y; // MCUs (4:2:0) or 8x8 blocks
+    size_t y_blocks, c_blocks, units;
+};
+Geometry geometry(uint32_t w, uint32_t h, uint8_t color_type, uint8_t subsampling);
+
+// ---- validation in the reference's order (jpeg/mod.rs:333-373) ----------------------
+// Returns PIXO_OK or a pixo_status and fills `msg` with the pixo::Error Display text.
+int validate(const pixo_jpeg_options &o, bool check_len, size_t data_len, std::string &msg);
+
+// ---- entropy coding -------------------------------------------------------------------
+// count_block statistics over the scan (jpeg/mod.rs:684-860), restart resets included.
+void symbol_histograms(const int16_t *y, const int16_t *cb, const int16_t *cr,
+                       const pixo_jpeg_options &o, uint64_t dc[2][12], uint64_t ac[2][256]);
+
+// Whole file from a coefficient tuple: headers (jpeg/mod.rs:449-648), scan
+// (encode_scan :1408-1563 ordering, encode_block huffman.rs:423-481, BitWriterMsb
+// bits.rs:195-293 incl. 0xFF stuffing, 1-padding and RSTn), EOI.
+void encode_file(const int16_t *y, const int16_t *cb, const int16_t *cr,
+                 const pixo_jpeg_options &o, std::vector<uint8_t> &out);
+
+} // namespace pixo_host

@@ -1,0 +1,16 @@
+// jpeg_kernels.hpp — host-callable launcher of the gfx950 coefficient kernel.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+namespace pixo_dev {
+
+// Enqueues the fused colour -> DCT -> quantise kernel for `batch` equally sized images on
+// `stream`.  All pointers are device pointers; d_qt points at the 256-float table block of
+// the requested quality (layout in jpeg_tile.h).  d_cb/d_cr are ignored for gray input.
+hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gray, bool s420,
+                              uint32_t batch, void *d_y, void *d_cb, void *d_cr,
+                              const float *d_qt, hipStream_t stream);
+
+} // namespace pixo_dev

@@ -1,0 +1,267 @@
+"""`pixo::jpeg` — host-side mirror of the reference's JPEG API over the HIP C ABI.
+
+Same names, argument meaning and error behaviour as the reference
+(src/jpeg/mod.rs:88-447, src/wasm.rs:113-142):
+
+    encode(data, options) -> bytes                      jpeg/mod.rs:88
+    encode_into(output: bytearray, data, options)       jpeg/mod.rs:328
+    JpegOptions / JpegOptions.builder / presets         jpeg/mod.rs:121-300
+    Subsampling                                         jpeg/mod.rs:96-101
+    encode_jpeg(data, w, h, color_type, quality, preset, subsampling_420)   wasm.rs:113
+
+plus the device seam (the reference's internal `YCbCrCoefficients`, jpeg/mod.rs:58-61):
+
+    coefficients(data, options) -> (y, cb, cr) int16 arrays [blocks, 64]
+    coefficients_device(...)    -> same on device pointers / torch tensors, async
+"""
+import ctypes as C
+import dataclasses
+import enum
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .color import ColorType
+from .error import from_status
+
+
+class Subsampling(enum.IntEnum):
+    S444 = 0
+    S420 = 1
+
+
+@dataclasses.dataclass
+class JpegOptions:
+    """jpeg/mod.rs:121-157 (Default: quality 75, 4:4:4, RGB, width/height 0)."""
+    width: int = 0
+    height: int = 0
+    color_type: ColorType = ColorType.Rgb
+    quality: int = 75
+    subsampling: Subsampling = Subsampling.S444
+    restart_interval: Optional[int] = None
+    optimize_huffman: bool = False
+    progressive: bool = False
+    trellis_quant: bool = False
+
+    # presets, jpeg/mod.rs:162-216
+    @staticmethod
+    def fast(width, height, quality):
+        return JpegOptions(width, height, ColorType.Rgb, quality, Subsampling.S444)
+
+    @staticmethod
+    def balanced(width, height, quality):
+        return JpegOptions(width, height, ColorType.Rgb, quality, Subsampling.S444, None, True)
+
+    @staticmethod
+    def max(width, height, quality):
+        return JpegOptions(width, height, ColorType.Rgb, quality, Subsampling.S420, None, True, True, True)
+
+    @staticmethod
+    def from_preset(width, height, quality, preset):
+        if preset == 0:
+            return JpegOptions.fast(width, height, quality)
+        if preset == 2:
+            return JpegOptions.max(width, height, quality)
+        return JpegOptions.balanced(width, height, quality)
+
+    @staticmethod
+    def builder(width, height):
+        return JpegOptionsBuilder(width, height)
+
+    def _c(self) -> _lib.JpegOptionsC:
+        o = _lib.JpegOptionsC()
+        o.width, o.height = self.width & 0xFFFFFFFF, self.height & 0xFFFFFFFF
+        o.color_type, o.quality = int(self.color_type) & 0xFF, int(self.quality) & 0xFF
+        o.subsampling = int(self.subsampling)
+        o.has_restart_interval = 0 if self.restart_interval is None else 1
+        o.restart_interval = 0 if self.restart_interval is None else int(self.restart_interval) & 0xFFFF
+        o.optimize_huffman = int(bool(self.optimize_huffman))
+        o.progressive = int(bool(self.progressive))
+        o.trellis_quant = int(bool(self.trellis_quant))
+        return o
+
+
+class JpegOptionsBuilder:
+    """jpeg/mod.rs:230-300."""
+
+    def __init__(self, width, height):
+        self._o = JpegOptions(width=width, height=height, color_type=ColorType.Rgb)
+
+    def color_type(self, color_type):
+        self._o.color_type = color_type
+        return self
+
+    def quality(self, quality):
+        self._o.quality = quality
+        return self
+
+    def subsampling(self, subsampling):
+        self._o.subsampling = subsampling
+        return self
+
+    def restart_interval(self, interval):
+        self._o.restart_interval = interval
+        return self
+
+    def optimize_huffman(self, value):
+        self._o.optimize_huffman = value
+        return self
+
+    def progressive(self, value):
+        self._o.progressive = value
+        return self
+
+    def trellis_quant(self, value):
+        self._o.trellis_quant = value
+        return self
+
+    def preset(self, preset):
+        """Applies a preset while retaining dimensions, colour type and quality (:285-293)."""
+        keep = self._o
+        self._o = JpegOptions.from_preset(keep.width, keep.height, keep.quality, preset)
+        self._o.color_type = keep.color_type
+        return self
+
+    def build(self):
+        return dataclasses.replace(self._o)
+
+
+def _raise(status):
+    raise from_status(status, _lib.load().pixo_hip_last_error().decode())
+
+
+def _as_u8(data):
+    a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    if a.dtype != np.uint8:
+        raise TypeError("pixel data must be bytes-like / uint8")
+    return np.ascontiguousarray(a).reshape(-1)
+
+
+def encode(data, options: JpegOptions) -> bytes:
+    """`pixo::jpeg::encode` (jpeg/mod.rs:88): complete JFIF file as bytes."""
+    L = _lib.load()
+    px = _as_u8(data)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_encode(px.ctypes.data, px.size, C.byref(oc), C.byref(out), C.byref(n))
+    if rc:
+        _raise(rc)
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        L.pixo_hip_free(out)
+
+
+def encode_into(output: bytearray, data, options: JpegOptions) -> None:
+    """`pixo::jpeg::encode_into` (jpeg/mod.rs:328): clears and refills `output`; on error
+    `output` is left untouched (validation precedes `output.clear()` in the reference)."""
+    blob = encode(data, options)
+    del output[:]
+    output += blob
+
+
+def encode_jpeg(data, width, height, color_type, quality, preset, subsampling_420) -> bytes:
+    """The reference's flat wasm export `encode_jpeg` (src/wasm.rs:113-142), same 7 arguments."""
+    L = _lib.load()
+    px = _as_u8(data)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    rc = L.pixo_hip_encode_jpeg(px.ctypes.data, px.size, width, height, color_type & 0xFF,
+                                quality & 0xFF, preset & 0xFF, int(bool(subsampling_420)),
+                                C.byref(out), C.byref(n))
+    if rc:
+        _raise(rc)
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        L.pixo_hip_free(out)
+
+
+def coefficient_geometry(width, height, color_type=ColorType.Rgb, subsampling=Subsampling.S420):
+    """(y_blocks, c_blocks) of the coefficient tuple."""
+    L = _lib.load()
+    yb, cb = C.c_size_t(), C.c_size_t()
+    rc = L.pixo_hip_coeff_geometry(width, height, int(color_type), int(subsampling), C.byref(yb), C.byref(cb))
+    if rc:
+        _raise(rc)
+    return yb.value, cb.value
+
+
+def coefficients(data, options: JpegOptions):
+    """The GPU half only: quantised DCT blocks in the reference's `YCbCrCoefficients`
+    layout (natural order; 4:2:0 stores Y as 4 blocks per MCU)."""
+    L = _lib.load()
+    px = _as_u8(data)
+    expected = options.width * options.height * ColorType(options.color_type).bytes_per_pixel() \
+        if options.color_type in (0, 2) else -1
+    yb, cbn = coefficient_geometry(options.width, options.height, options.color_type, options.subsampling)
+    if expected >= 0 and px.size != expected:
+        raise from_status(-2, "Invalid pixel data length: expected %d bytes, got %d" % (expected, px.size))
+    y = np.empty((yb, 64), np.int16)
+    cb = np.empty((cbn, 64), np.int16)
+    cr = np.empty((cbn, 64), np.int16)
+    rc = L.pixo_hip_jpeg_coeffs(px.ctypes.data, options.width, options.height, int(options.color_type),
+                                int(options.subsampling), int(options.quality), y.ctypes.data, yb,
+                                cb.ctypes.data, cr.ctypes.data, cbn)
+    if rc:
+        _raise(rc)
+    return y, cb, cr
+
+
+def coefficients_device(d_pixels, width, height, color_type, subsampling, quality, d_y, d_cb, d_cr,
+                        batch=1, stream=0):
+    """Asynchronous launch on device memory.  Pointers may be ints or objects with
+    `.data_ptr()` (torch tensors); `stream` is a hipStream_t handle (int), 0 = default."""
+    L = _lib.load()
+
+    def ptr(x):
+        if x is None:
+            return None
+        return x.data_ptr() if hasattr(x, "data_ptr") else int(x)
+
+    rc = L.pixo_hip_jpeg_coeffs_device(ptr(d_pixels), width, height, int(color_type), int(subsampling),
+                                       int(quality), batch, ptr(d_y), ptr(d_cb), ptr(d_cr),
+                                       C.c_void_p(stream) if stream else None)
+    if rc:
+        _raise(rc)
+
+
+def entropy_encode(y, cb, cr, options: JpegOptions) -> bytes:
+    """Host entropy stage from an existing coefficient tuple (used when several GPUs each
+    produced a band of it)."""
+    L = _lib.load()
+    y = np.ascontiguousarray(y, np.int16)
+    cb = np.ascontiguousarray(cb, np.int16)
+    cr = np.ascontiguousarray(cr, np.int16)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_entropy_encode(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, C.byref(oc),
+                                        C.byref(out), C.byref(n))
+    if rc:
+        _raise(rc)
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        L.pixo_hip_free(out)
+
+
+def band(width, height, color_type, subsampling, parts, index):
+    """MCU-row band `index` of `parts`: dict(row_begin,row_end,y_offset,y_blocks,
+    c_offset,c_blocks).  Bands are independent sub-images of the same width."""
+    L = _lib.load()
+    r0, r1 = C.c_uint32(), C.c_uint32()
+    yo, yb, co, cbk = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    rc = L.pixo_hip_band(width, height, int(color_type), int(subsampling), parts, index,
+                         C.byref(r0), C.byref(r1), C.byref(yo), C.byref(yb), C.byref(co), C.byref(cbk))
+    if rc:
+        _raise(rc)
+    return dict(row_begin=r0.value, row_end=r1.value, y_offset=yo.value, y_blocks=yb.value,
+                c_offset=co.value, c_blocks=cbk.value)
+
+
+def device_count() -> int:
+    return _lib.load().pixo_hip_device_count()
+
+
+def set_device(device: int) -> None:
+    _lib.load().pixo_hip_set_device(device)

@@ -1,0 +1,125 @@
+// emu_tile.cpp — TEST HARNESS.  Runs the device tile code of pixo_amd/csrc/jpeg_tile.h on
+// the CPU: one workgroup = a loop over 256 "lanes" per barrier-delimited phase, LDS = a
+// byte array.  The arithmetic executed is the kernel's own source (compiled with
+// -DPIXO_EMU, -ffp-contract=off), so CPU-only test runs check the real kernel logic —
+// lane mapping, LDS layout, swizzles, colour math, DCT order, quantiser fast path —
+// against the oracle.  Not shipped; the product never links this.
+#define PIXO_EMU 1
+#include "../../pixo_amd/csrc/jpeg_tile.h"
+#include "../../pixo_amd/csrc/jpeg_host.hpp"
+
+#include <vector>
+
+using namespace pixo_tile;
+
+template <int MODE>
+static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long *stats)
+{
+    std::vector<Lane<MODE>> lanes(kThreads);
+    alignas(16) static uint8_t lds[64 * 1024];
+    int cls[kThreads];
+    for (uint32_t ty = 0; ty < tiles_y; ty++)
+        for (uint32_t tx = 0; tx < tiles_x; tx++) {
+            const bool interior = tile_is_interior<MODE>(c, tx, ty);
+            if (stats) stats[interior ? 0 : 1]++;
+            for (int t = 0; t < kThreads; t++) {
+                if (interior) phase_load<MODE, true>(c, tx, ty, t, lanes[t]);
+                else phase_load<MODE, false>(c, tx, ty, t, lanes[t]);
+                phase_color<MODE>(t, lanes[t], lds);
+            }
+            for (int t = 0; t < kThreads; t++) cls[t] = phase_fetch<MODE>(t, lds, lanes[t]);
+            // poison the aliased region to prove phase B no longer depends on planar data
+            memset(lds, 0xA5, lds_bytes<MODE>());
+            for (int t = 0; t < kThreads; t++) phase_dct_quant<MODE>(t, cls[t], c.qt, lanes[t], lds);
+            for (int t = 0; t < kThreads; t++) phase_store<MODE>(c, tx, ty, t, lds);
+        }
+}
+
+extern "C" int emu_jpeg_coeffs(const uint8_t *px, uint32_t W, uint32_t H, int color_type, int subsampling,
+                               int quality, int16_t *y, int16_t *cb, int16_t *cr, int allow_fast,
+                               long *stats /* [interior tiles, edge tiles] or NULL */)
+{
+    float qt[256];
+    pixo_host::fill_device_qt((uint8_t)quality, qt);
+    const bool gray = color_type == 0, s420 = !gray && subsampling == 1;
+    TileCtx c;
+    c.px = px; c.y = y; c.cb = cb; c.cr = cr; c.qt = qt; c.W = W; c.H = H;
+    const uint32_t unit = s420 ? 16 : 8;
+    c.units_x = (W + unit - 1) / unit;
+    c.units_y = (H + unit - 1) / unit;
+    const size_t row_bytes = (size_t)W * (gray ? 1 : 3);
+    c.fast = allow_fast && ((uintptr_t)px % 4 == 0) && (row_bytes % 4 == 0);
+    if (stats) stats[0] = stats[1] = 0;
+    if (gray) {
+        run_image<MGRAY>(c, (c.units_x + 63) / 64, (c.units_y * 8 + 31) / 32, stats);
+    } else if (s420) {
+        run_image<M420>(c, (c.units_x + 31) / 32, c.units_y, stats);
+    } else {
+        run_image<M444>(c, (c.units_x + 63) / 64, c.units_y, stats);
+    }
+    return 0;
+}
+
+// quantiser fast path vs the reference formula on caller-provided values (for the
+// dense/exhaustive sweeps in tests/test_quant_exact.py)
+extern "C" long emu_quant_mismatches(const float *x, long n, int qlo, int qhi)
+{
+    long bad = 0;
+    for (int q = qlo; q <= qhi; q++) {
+        const float fq = (float)q, rcp = 1.0f / fq;
+        float rr[8], qq[8], xx[8];
+        for (int i = 0; i < 8; i++) { rr[i] = rcp; qq[i] = fq; }
+        for (long i = 0; i + 8 <= n; i += 8) {
+            uint32_t out[4];
+            for (int k = 0; k < 8; k++) xx[k] = x[i + k];
+            quant_row8(xx, rr, qq, out);
+            for (int k = 0; k < 8; k++) {
+                int16_t got = (int16_t)(out[k >> 1] >> (16 * (k & 1)));
+                float want = roundf(xx[k] / fq);
+                if ((float)got != want) bad++;
+            }
+        }
+    }
+    return bad;
+}
+
+// fast path ONLY (no exact fallback): returns how many inputs the safety test flags and
+// how many unflagged inputs would have been wrong (must be 0).
+extern "C" void emu_quant_fastpath_audit(const float *x, long n, int q, long *flagged, long *wrong_unflagged)
+{
+    const float fq = (float)q, rcp = 1.0f / fq;
+    long f = 0, w = 0;
+    for (long i = 0; i < n; i++) {
+        float r = x[i] * rcp;
+        float nn = __builtin_rintf(r);
+        float lim = __builtin_fmaf(__builtin_fabsf(r), -0x1p-21f, 0.5f);
+        bool risky = __builtin_fabsf(r - nn) >= lim;
+        if (risky) f++;
+        else if (nn != roundf(x[i] / fq)) w++;
+    }
+    *flagged = f;
+    *wrong_unflagged = w;
+}
+
+// Exhaustive audit over every f32 bit pattern in [lo_bits, hi_bits] (both signs), one q.
+extern "C" void emu_quant_exhaustive(int q, uint32_t lo_bits, uint32_t hi_bits, long *flagged,
+                                     long *wrong_unflagged, long *wrong_final)
+{
+    const float fq = (float)q, rcp = 1.0f / fq;
+    long f = 0, w = 0, wf = 0;
+    for (int sign = 0; sign < 2; sign++)
+        for (uint64_t b = lo_bits; b <= hi_bits; b++) {
+            uint32_t u = (uint32_t)b | (sign ? 0x80000000u : 0u);
+            float x;
+            memcpy(&x, &u, 4);
+            float want = roundf(x / fq);
+            float r = x * rcp;
+            float nn = __builtin_rintf(r);
+            float lim = __builtin_fmaf(__builtin_fabsf(r), -0x1p-21f, 0.5f);
+            bool risky = __builtin_fabsf(r - nn) >= lim;
+            if (risky) { f++; nn = roundf(x / fq); }
+            else if (nn != want) w++;
+            if (nn != want) wf++;
+        }
+    *flagged = f; *wrong_unflagged = w; *wrong_final = wf;
+}

@@ -1,0 +1,161 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(pixo_amd/libpixo_hip.so); the oracle and the reference-made goldens are only the checkers.
+Bit-exact: coefficients are integers, files are bytes."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+import synth
+from pixo_amd import ColorType, jpeg
+
+pytestmark = pytest.mark.gpu
+
+
+def _opts(w, h, ct, ss, q, **kw):
+    b = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss))
+    for k, v in kw.items():
+        b = getattr(b, k)(v)
+    return b.build()
+
+
+def _check_coeffs(px, w, h, ct, ss, q, threads=8):
+    oy, ocb, ocr = O.coeffs(px, w, h, ct, ss, q, threads=threads)
+    gy, gcb, gcr = jpeg.coefficients(px, _opts(w, h, ct, ss, q))
+    assert np.array_equal(gy, oy), "Y coefficients differ"
+    assert np.array_equal(gcb, ocb) and np.array_equal(gcr, ocr), "chroma coefficients differ"
+
+
+def test_native_library_is_the_one_running():
+    assert jpeg.device_count() >= 1
+    import os
+    maps = open("/proc/self/maps").read()
+    assert "libpixo_hip.so" in maps
+
+
+ALL = G.cases(max_pixels=1100 * 1100)
+
+
+@pytest.mark.parametrize("c", ALL, ids=[c["name"] for c in ALL])
+def test_whole_file_bytes_match_reference_goldens(c):
+    """encode_jpeg() — the reference's flat entry — must return the reference's bytes."""
+    blob = jpeg.encode_jpeg(G.make_input(c), c["w"], c["h"], c["color_type"], c["quality"], c["preset"], c["s420"])
+    G.check(c, blob)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (2, 2), (7, 7), (8, 8), (9, 9), (16, 16), (15, 17), (1, 100), (100, 1),
+                                 (256, 256), (512, 512), (1000, 1000), (1024, 1024), (511, 16), (513, 17),
+                                 (1028, 33), (2048, 16), (1918, 70), (1921, 40)])
+@pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])
+def test_coefficients_edge_dimensions(w, h, mode):
+    """reference EDGE_CASE_DIMENSIONS (tests/support/synthetic.rs:276) + tile-boundary sizes."""
+    ct, ss = mode
+    px = synth.noise_gray(w, h, 17) if ct == 0 else synth.noise(w, h, 17)
+    _check_coeffs(px, w, h, ct, ss, 80)
+
+
+@pytest.mark.parametrize("q", [1, 2, 10, 35, 49, 50, 51, 75, 80, 85, 95, 99, 100])
+def test_coefficients_quality_sweep(q):
+    for gen in (synth.noise(200, 120, q), synth.gradient_rgb(200, 120), synth.flat_blocks(200, 120),
+                synth.checkerboard(200, 120, 5)):
+        _check_coeffs(gen, 200, 120, 2, 1, q)
+        _check_coeffs(gen, 200, 120, 2, 0, q)
+
+
+def test_saturated_colours():
+    for rgb in ([0, 0, 255], [255, 0, 0], [255, 255, 255], [0, 0, 0], [0, 255, 0], [1, 0, 255]):
+        px = np.tile(np.array(rgb, np.uint8), 64 * 32)
+        _check_coeffs(px, 64, 32, 2, 1, 100)
+        _check_coeffs(px, 64, 32, 2, 0, 100)
+
+
+def test_config1_512_and_config3_unit_1080p_files():
+    for (w, h) in [(512, 512), (1920, 1080)]:
+        c = [c for c in G.load()["cases"] if (c["w"], c["h"], c["preset"], c["gen"]) == (w, h, 0, "noise")][0]
+        G.check(c, jpeg.encode_jpeg(G.make_input(c), w, h, 2, 80, 0, True))
+
+
+def test_config2_4096_coefficients_and_file_hashes():
+    """BASELINE config 2: 4096x4096 q80, both subsamplings; coefficient tuple vs the oracle and
+    whole-file sha256 vs the reference-made golden."""
+    w = h = 4096
+    px = synth.noise(w, h, 42)
+    for ss, s420 in ((1, True), (0, False)):
+        _check_coeffs(px, w, h, 2, ss, 80)
+        c = [c for c in G.load()["cases"] if (c["w"], c["s420"], c["gen"]) == (4096, s420, "noise")][0]
+        G.check(c, jpeg.encode(px, _opts(w, h, 2, ss, 80)))
+
+
+def test_restart_and_optimized_huffman_whole_path():
+    w, h = 333, 211
+    px = synth.noise(w, h, 5)
+    for ss in (0, 1):
+        for restart, opt in [(None, True), (5, False), (64, True)]:
+            got = jpeg.encode(px, _opts(w, h, 2, ss, 66, restart_interval=restart, optimize_huffman=opt))
+            want = O.encode(px, O.make_options(w, h, 2, 66, ss, restart=restart, optimize_huffman=opt))
+            assert got == want
+
+
+def test_device_api_batch_of_1080p_matches_per_image_oracle():
+    """BASELINE config 3 shape: a batch of 1920x1080 images in one launch on device memory
+    (8 here to keep the CPU oracle quick; bench covers 64)."""
+    import torch
+    w, h, n = 1920, 1080, 8
+    imgs = [synth.noise(w, h, 42 + i) for i in range(n)]
+    yb, cbn = jpeg.coefficient_geometry(w, h, 2, 1)
+    dev = torch.device("cuda:0")
+    d_px = torch.from_numpy(np.concatenate(imgs)).to(dev)
+    d_y = torch.empty((n * yb, 64), dtype=torch.int16, device=dev)
+    d_cb = torch.empty((n * cbn, 64), dtype=torch.int16, device=dev)
+    d_cr = torch.empty((n * cbn, 64), dtype=torch.int16, device=dev)
+    jpeg.coefficients_device(d_px, w, h, 2, 1, 80, d_y, d_cb, d_cr, batch=n,
+                             stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    y, cb, cr = d_y.cpu().numpy(), d_cb.cpu().numpy(), d_cr.cpu().numpy()
+    for i in (0, 3, 7):
+        oy, ocb, ocr = O.coeffs(imgs[i], w, h, 2, 1, 80, threads=8)
+        assert np.array_equal(y[i * yb:(i + 1) * yb], oy)
+        assert np.array_equal(cb[i * cbn:(i + 1) * cbn], ocb) and np.array_equal(cr[i * cbn:(i + 1) * cbn], ocr)
+    # image 0 inside the batch == image 0 alone (launch-shape independence)
+    gy, gcb, gcr = jpeg.coefficients(imgs[0], _opts(w, h, 2, 1, 80))
+    assert np.array_equal(gy, y[:yb]) and np.array_equal(gcb, cb[:cbn])
+
+
+def test_bands_concatenate_to_the_single_device_tuple():
+    """Config 4's sharding rule at a size one GPU and the CPU oracle finish quickly: 8 MCU-row
+    bands computed independently (as 8 GPUs would) == the whole-image tuple, and the host
+    entropy stage over the stitched tuple gives the oracle's file."""
+    w, h = 2048, 1000
+    px = synth.noise(w, h, 8)
+    full = jpeg.coefficients(px, _opts(w, h, 2, 1, 80))
+    parts = 8
+    ys, cbs, crs = [], [], []
+    for i in range(parts):
+        b = jpeg.band(w, h, 2, 1, parts, i)
+        sub = px[b["row_begin"] * w * 3: b["row_end"] * w * 3]
+        y, cb, cr = jpeg.coefficients(sub, _opts(w, b["row_end"] - b["row_begin"], 2, 1, 80))
+        assert y.shape[0] == b["y_blocks"]
+        ys.append(y); cbs.append(cb); crs.append(cr)
+    y, cb, cr = np.concatenate(ys), np.concatenate(cbs), np.concatenate(crs)
+    assert np.array_equal(y, full[0]) and np.array_equal(cb, full[1]) and np.array_equal(cr, full[2])
+    assert jpeg.entropy_encode(y, cb, cr, _opts(w, h, 2, 1, 80)) == O.encode(px, O.make_options(w, h, 2, 80, 1))
+
+
+def test_determinism_and_linearity_properties_at_full_size():
+    """Size-independent properties on a 4096x4096 image the oracle is not consulted for:
+    (i) two runs are identical; (ii) vertical flip of a 16-row-aligned image permutes MCU rows
+    of |DC| identically (DC is the block mean: flipping rows inside a block keeps it)."""
+    w = h = 4096
+    px = synth.noise(w, h, 123)
+    o = _opts(w, h, 2, 1, 80)
+    a = jpeg.coefficients(px, o)
+    b = jpeg.coefficients(px, o)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    flipped = px.reshape(h, w * 3)[::-1].reshape(-1)
+    f = jpeg.coefficients(np.ascontiguousarray(flipped), o)
+    mw = w // 16
+    cb = a[1][:, 0].reshape(-1, mw)
+    cbf = f[1][:, 0].reshape(-1, mw)[::-1]
+    assert np.array_equal(cb, cbf)  # chroma DC of an MCU is invariant under the flip

@@ -56,19 +56,32 @@ def cpu_baseline(w, h, ss, quality, budget_s):
     import oracle_lib as O
     import synth
     px = synth.noise(w, h, 42)
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
     O.coeffs(px[: 64 * 64 * 3], 64, 64, 2, ss, quality)  # load lib
-    t0 = time.perf_counter()
-    O.coeffs(px, w, h, 2, ss, quality, threads=cores)
-    first = time.perf_counter() - t0
-    reps = max(1, min(50, int(budget_s / max(first, 1e-3)) - 1))
+    # pick the thread count that is actually fastest on this box (SMT / cgroup quotas can make
+    # "all logical CPUs" slower than fewer threads); `cores` reports the count used
+    best_dt, cores = None, 1
+    tried = {}
+    for th in sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 64), min(avail, 32), min(avail, 16)}):
+        O.coeffs(px, w, h, 2, ss, quality, threads=th)
+        t0 = time.perf_counter()
+        O.coeffs(px, w, h, 2, ss, quality, threads=th)
+        dt = time.perf_counter() - t0
+        tried[th] = round(w * h / dt / 1e6, 1)
+        if best_dt is None or dt < best_dt:
+            best_dt, cores = dt, th
+    reps = max(1, min(50, int(budget_s / max(best_dt, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(reps):
         O.coeffs(px, w, h, 2, ss, quality, threads=cores)
     dt = (time.perf_counter() - t0) / reps
     out = {"value": round(w * h / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+           "logical_cpus": avail, "threads_tried_Mpx_s": tried,
            "sample": "%d x (%dx%d RGB8 noise seed 42, q=%d, %s) coefficient stage (colour+DCT+quant) "
-                     "by oracle/pixo_oracle.c, gcc -O2 -ffp-contract=off, OpenMP %d threads"
+                     "by oracle/pixo_oracle.c, gcc -O2 -ffp-contract=off, OpenMP %d threads over MCU rows"
                      % (reps, w, h, quality, "4:2:0" if ss else "4:4:4", cores)}
     # single-thread figure as well (the reference's baseline encode_scan is single-threaded)
     t0 = time.perf_counter()

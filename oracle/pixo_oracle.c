@@ -246,7 +246,7 @@ int po_jpeg_coeffs(const uint8_t *pixels, uint32_t w32, uint32_t h32, uint8_t co
     if (color_type == PO_GRAY || subsampling == PO_S444) {
         long bw = (long)((w + 7) / 8), bh = (long)((h + 7) / 8);
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(threads > 1 ? threads : 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 1 ? threads : 1)
 #endif
         for (long brow = 0; brow < bh; brow++) {
             float yb[64], cbb[64], crb[64];
@@ -264,7 +264,7 @@ int po_jpeg_coeffs(const uint8_t *pixels, uint32_t w32, uint32_t h32, uint8_t co
     } else {
         long mw = (long)((w + 15) / 16), mh = (long)((h + 15) / 16);
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(threads > 1 ? threads : 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 1 ? threads : 1)
 #endif
         for (long mrow = 0; mrow < mh; mrow++) {
             float yb[4][64], cbb[64], crb[64];

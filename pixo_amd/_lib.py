@@ -32,6 +32,23 @@ SYMBOLS = [
 _lib = None
 
 
+def _preload_process_hip_runtime():
+    """One HIP runtime per process.  libpixo_hip.so needs `libamdhip64.so.7`; PyTorch-ROCm
+    wheels bundle their own copy under torch/lib with the same soname.  Whichever is mapped
+    first serves both, and mapping ROCm's first makes a later `import torch` find no GPU.
+    So when torch is installed, map ITS runtime before ours (without importing torch)."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # fall back to the loader's default resolution (RUNPATH -> /opt/rocm/lib)
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -41,6 +58,7 @@ def load():
             "pixo_amd: %s is missing — build it with `make -C pixo_amd/csrc` "
             "(or python -c 'import __graft_entry__ as g; g.build()'). "
             "There is no CPU fallback." % LIB_PATH)
+    _preload_process_hip_runtime()
     L = C.CDLL(LIB_PATH)
     u8pp, szp = C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)
     optp = C.POINTER(JpegOptionsC)

@@ -35,8 +35,17 @@
 #include <math.h>
 #include <string.h>
 #define PIXO_DEV static inline
+#define PIXO_SCHED_FENCE() ((void)0)
+#define PIXO_PIN(x) ((void)0)
 #else
 #define PIXO_DEV __device__ __forceinline__
+// Stops the machine scheduler from interleaving independent 1-D transforms: left alone it
+// sinks the whole column pass into the quantiser rows, keeping ~16 temporaries of all 8
+// columns alive (150 VGPRs, 3 waves/SIMD).  Fenced, a block needs 64 + ~20 registers.
+#define PIXO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Materialises a value here: stops LLVM from sinking the column pass into the quantiser's
+// basic blocks (which kept every column's butterflies alive across them).
+#define PIXO_PIN(x) asm volatile("" : "+v"(x))
 #endif
 
 #pragma clang fp contract(off)
@@ -414,12 +423,16 @@ PIXO_DEV void aan8(float &d0, float &d1, float &d2, float &d3, float &d4, float 
 PIXO_DEV void dct_2d(float *v)
 {
 #pragma unroll
-    for (int r = 0; r < 8; r++)
+    for (int r = 0; r < 8; r++) {
         aan8(v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5],
              v[r * 8 + 6], v[r * 8 + 7]);
+        if (r & 1) PIXO_SCHED_FENCE();
+    }
 #pragma unroll
-    for (int c = 0; c < 8; c++)
+    for (int c = 0; c < 8; c++) {
         aan8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+        if (c & 1) PIXO_SCHED_FENCE();
+    }
 }
 
 // ---- phase B.3: quantise one row of 8 coefficients ----------------------------------
@@ -443,9 +456,12 @@ PIXO_DEV void quant_row8(const float *x, const float *rcp, const float *q, uint3
         float lim = __builtin_fmaf(__builtin_fabsf(r), -0x1p-21f, 0.5f);
         risky |= __builtin_fabsf(r - n[c]) >= lim;
     }
-    if (risky) {
+    if (risky) { // rare: a quotient within 2^-21 (relative) of a rounding boundary
 #pragma unroll
-        for (int c = 0; c < 8; c++) n[c] = __builtin_roundf(x[c] / q[c]);
+        for (int c = 0; c < 8; c++) {
+            n[c] = __builtin_roundf(x[c] / q[c]); // the reference operation itself
+            PIXO_SCHED_FENCE();                   // one divide at a time: few temporaries
+        }
     }
     out[0] = pack_i16(n[0], n[1]); out[1] = pack_i16(n[2], n[3]);
     out[2] = pack_i16(n[4], n[5]); out[3] = pack_i16(n[6], n[7]);
@@ -467,12 +483,15 @@ PIXO_DEV void phase_dct_quant(int tid, int cls, const float *qt, Lane<MODE> &L, 
     const float *q = rcp + 128;
     dct_2d(L.v);
 #pragma unroll
+    for (int i = 0; i < 64; i++) PIXO_PIN(L.v[i]);
+#pragma unroll
     for (int u = 0; u < 8; u++) {
         u32x4 o;
         uint32_t w[4];
         quant_row8(&L.v[u * 8], rcp + u * 8, q + u * 8, w);
         o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
         *(u32x4 *)(lds + stage_addr(b, u)) = o;
+        PIXO_SCHED_FENCE();
     }
 }
 

@@ -48,8 +48,8 @@ int device_tables(int device, const float **out)
     std::lock_guard<std::mutex> lock(g_qt_mutex);
     if (device < 0 || device >= kMaxDevices) return fail(PIXO_ERR_COMPRESSION, "Compression error: bad device index");
     if (!g_qt[device]) {
-        std::vector<float> host(100 * 256);
-        for (int q = 1; q <= 100; ++q) pixo_host::fill_device_qt(static_cast<uint8_t>(q), &host[(q - 1) * 256]);
+        std::vector<float> host(100 * pixo_host::kDeviceQtFloats);
+        for (int q = 1; q <= 100; ++q) pixo_host::fill_device_qt(static_cast<uint8_t>(q), &host[(q - 1) * pixo_host::kDeviceQtFloats]);
         float *d = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), host.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -141,7 +141,7 @@ int coeffs_to_pinned(const uint8_t *pixels, const pixo_jpeg_options &o, const pi
     int16_t *dcr = dcb + g.c_blocks * 64;
     HIP_TRY(pixo_dev::launch_jpeg_coeffs(c.d_px, o.width, o.height, g.gray, g.s420, 1, dy,
                                          g.gray ? nullptr : dcb, g.gray ? nullptr : dcr,
-                                         qt_all + (o.quality - 1) * 256, c.stream));
+                                         qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c.stream));
     HIP_TRY(hipMemcpyAsync(c.h_coef, c.d_coef, coef_bytes, hipMemcpyDeviceToHost, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));
     *y = static_cast<const int16_t *>(c.h_coef);
@@ -291,7 +291,7 @@ int pixo_hip_jpeg_coeffs_device(const void *d_pixels, uint32_t width, uint32_t h
     const bool gray = color_type == PIXO_GRAY;
     HIP_TRY(pixo_dev::launch_jpeg_coeffs(d_pixels, width, height, gray, !gray && subsampling == PIXO_S420,
                                          batch, d_y, gray ? nullptr : d_cb, gray ? nullptr : d_cr,
-                                         qt_all + (quality - 1) * 256, static_cast<hipStream_t>(stream)));
+                                         qt_all + (quality - 1) * pixo_host::kDeviceQtFloats, static_cast<hipStream_t>(stream)));
     return PIXO_OK;
 }
 

@@ -51,7 +51,7 @@ QuantTables make_quant_tables(uint8_t quality)
     return t;
 }
 
-void fill_device_qt(uint8_t quality, float out[256])
+void fill_device_qt(uint8_t quality, float out[kDeviceQtFloats])
 {
     const QuantTables t = make_quant_tables(quality);
     for (int i = 0; i < 64; ++i) {
@@ -59,6 +59,7 @@ void fill_device_qt(uint8_t quality, float out[256])
         out[64 + i] = 1.0f / t.chr[i];
         out[128 + i] = t.lum[i];
         out[192 + i] = t.chr[i];
+        out[256 + i] = out[64 + i] * 0.25f; // exact: 4:2:0 chroma is transformed at 4x scale
     }
 }
 

@@ -1,10 +1,12 @@
 // jpeg_kernels.hip — gfx950 kernels of the JPEG pixel pipeline and their launcher.
 //
 // The per-tile body lives in jpeg_tile.h (shared with the CPU emulation harness in
-// tests/emu).  This file adds the __global__ wrappers, the blockIdx -> tile mapping and
-// the host-side launch function.  Written for CDNA4 only: 64-lane wavefronts, 256-thread
-// workgroups (4 waves, one per SIMD), <= 32 KiB LDS per workgroup so that 5 workgroups
-// share a CU's 160 KiB, >= 2048 workgroups per 4096x4096 image (8 per CU).
+// tests/emu).  This file adds the persistent __global__ loop, the tile -> image mapping
+// and the host-side launch function.  Written for CDNA4 only: 64-lane wavefronts,
+// 256-thread workgroups (4 waves, one per SIMD), 24-32 KiB LDS per workgroup, a grid of
+// (resident workgroups per CU) x 256 CUs that walks the tiles with a stride, each
+// workgroup prefetching its next tile's pixels into registers while it transforms the
+// current one, so HBM reads, VALU work and HBM writes of neighbouring tiles overlap.
 #include <hip/hip_runtime.h>
 
 #include "jpeg_kernels.hpp"
@@ -19,48 +21,101 @@ struct KArgs {
     const uint8_t *px;
     int16_t *y, *cb, *cr;
     const float *qt;
-    uint32_t W, H, units_x, units_y, tiles_x, fast;
-    size_t px_stride;  // bytes between consecutive images of a batch
-    size_t y_stride;   // i16 elements between images
+    uint32_t W, H, units_x, units_y, tiles_x, tiles_y, batch, fast;
+    size_t px_stride; // bytes between consecutive images of a batch
+    size_t y_stride;  // i16 elements between images
     size_t c_stride;
 };
+
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, which would
+// make every barrier wait for the next tile's prefetch loads and the previous tile's stores.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+struct TileId {
+    TileCtx c;
+    uint32_t tx, ty;
+};
+
+__device__ __forceinline__ TileId locate(const KArgs &a, uint32_t t)
+{
+    const uint32_t per_img = a.tiles_x * a.tiles_y;
+    const uint32_t img = t / per_img, r = t - img * per_img;
+    TileId id;
+    id.ty = r / a.tiles_x;
+    id.tx = r - id.ty * a.tiles_x;
+    id.c.px = a.px + (size_t)img * a.px_stride;
+    id.c.y = a.y + (size_t)img * a.y_stride;
+    id.c.cb = a.cb ? a.cb + (size_t)img * a.c_stride : nullptr;
+    id.c.cr = a.cr ? a.cr + (size_t)img * a.c_stride : nullptr;
+    id.c.qt = a.qt;
+    id.c.W = a.W; id.c.H = a.H; id.c.units_x = a.units_x; id.c.units_y = a.units_y; id.c.fast = a.fast;
+    return id;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void jpeg_coeffs_kernel(const KArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[lds_bytes<MODE>()];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[Geo<MODE>::lds];
     const int tid = threadIdx.x;
-    const uint32_t tile_y = blockIdx.x / a.tiles_x;
-    const uint32_t tile_x = blockIdx.x - tile_y * a.tiles_x;
-    const size_t img = blockIdx.y;
-
-    TileCtx c;
-    c.px = a.px + img * a.px_stride;
-    c.y = a.y + img * a.y_stride;
-    c.cb = a.cb ? a.cb + img * a.c_stride : nullptr;
-    c.cr = a.cr ? a.cr + img * a.c_stride : nullptr;
-    c.qt = a.qt;
-    c.W = a.W; c.H = a.H; c.units_x = a.units_x; c.units_y = a.units_y; c.fast = a.fast;
+    const uint32_t total = a.tiles_x * a.tiles_y * a.batch;
+    uint32_t t = blockIdx.x;
+    if (t >= total) return;
 
     Lane<MODE> L;
-    if (tile_is_interior<MODE>(c, tile_x, tile_y))
-        phase_load<MODE, true>(c, tile_x, tile_y, tid, L);
-    else
-        phase_load<MODE, false>(c, tile_x, tile_y, tid, L);
-    phase_color<MODE>(tid, L, lds);
-    __syncthreads();
-    const int cls = phase_fetch<MODE>(tid, lds, L);
-    __syncthreads(); // planar samples are in registers; the stage may now overwrite them
-    phase_dct_quant<MODE>(tid, cls, c.qt, L, lds);
-    __syncthreads();
-    phase_store<MODE>(c, tile_x, tile_y, tid, lds);
+    TileId cur = locate(a, t);
+    load_tile<MODE>(cur.c, cur.tx, cur.ty, tid, L);
+    for (;;) {
+        phase_color<MODE>(tid, L, lds); // consumes L.in
+        const uint32_t tn = t + gridDim.x;
+        const bool more = tn < total;
+        TileId nxt = cur;
+        if (more) { // prefetch: lands while this tile is transformed and stored
+            nxt = locate(a, tn);
+            load_tile<MODE>(nxt.c, nxt.tx, nxt.ty, tid, L);
+        }
+        lds_barrier();
+        phase_dct_quant<MODE>(tid, a.qt, lds);
+        lds_barrier();
+        phase_store<MODE>(cur.c, cur.tx, cur.ty, tid, lds);
+        if (!more) break;
+        t = tn;
+        cur = nxt;
+        lds_barrier(); // the stage has been read out; the next tile may overwrite it
+    }
 }
 
-template <int MODE> static hipError_t launch_mode(const KArgs &a, uint32_t batch, hipStream_t s)
+// resident workgroups per CU, per mode (queried once per process)
+template <int MODE> static int blocks_per_cu()
 {
-    const uint32_t tiles_y = (a.units_y * (MODE == M420 ? 16u : 8u) + Geo<MODE>::tile_h - 1) / Geo<MODE>::tile_h;
-    dim3 grid(a.tiles_x * tiles_y, batch, 1);
-    hipLaunchKernelGGL(jpeg_coeffs_kernel<MODE>, grid, dim3(kThreads), 0, s, a);
+    static int cached = 0;
+    if (!cached) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, jpeg_coeffs_kernel<MODE>, kThreads, 0) != hipSuccess || n < 1)
+            n = 2;
+        cached = n > 8 ? 8 : n;
+    }
+    return cached;
+}
+
+template <int MODE> static hipError_t launch_mode(KArgs &a, hipStream_t s)
+{
+    a.tiles_x = (a.units_x + Geo<MODE>::units_x - 1) / Geo<MODE>::units_x;
+    a.tiles_y = (a.units_y * (MODE == M420 ? 16u : 8u) + Geo<MODE>::tile_h - 1) / Geo<MODE>::tile_h;
+    const uint64_t total64 = (uint64_t)a.tiles_x * a.tiles_y * a.batch;
+    if (total64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const uint32_t total = (uint32_t)total64;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t resident = (uint32_t)blocks_per_cu<MODE>() * (uint32_t)cus;
+    // equal number of tiles per workgroup: rounds = ceil(total / resident), grid = ceil(total / rounds)
+    const uint32_t rounds = (total + resident - 1) / resident;
+    const uint32_t grid = (total + rounds - 1) / rounds;
+    hipLaunchKernelGGL(jpeg_coeffs_kernel<MODE>, dim3(grid), dim3(kThreads), 0, s, a);
     return hipGetLastError();
 }
 
@@ -74,7 +129,7 @@ hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gra
     a.cb = static_cast<int16_t *>(d_cb);
     a.cr = static_cast<int16_t *>(d_cr);
     a.qt = d_qt;
-    a.W = W; a.H = H;
+    a.W = W; a.H = H; a.batch = batch;
     const uint32_t unit = (!gray && s420) ? 16 : 8;
     a.units_x = (W + unit - 1) / unit;
     a.units_y = (H + unit - 1) / unit;
@@ -87,16 +142,9 @@ hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gra
     const size_t units = static_cast<size_t>(a.units_x) * a.units_y;
     a.y_stride = (unit == 16 ? 4 * units : units) * 64;
     a.c_stride = units * 64;
-    if (gray) {
-        a.tiles_x = (a.units_x + Geo<MGRAY>::units_x - 1) / Geo<MGRAY>::units_x;
-        return launch_mode<MGRAY>(a, batch, stream);
-    }
-    if (s420) {
-        a.tiles_x = (a.units_x + Geo<M420>::units_x - 1) / Geo<M420>::units_x;
-        return launch_mode<M420>(a, batch, stream);
-    }
-    a.tiles_x = (a.units_x + Geo<M444>::units_x - 1) / Geo<M444>::units_x;
-    return launch_mode<M444>(a, batch, stream);
+    if (gray) return launch_mode<MGRAY>(a, stream);
+    if (s420) return launch_mode<M420>(a, stream);
+    return launch_mode<M444>(a, stream);
 }
 
 } // namespace pixo_dev

@@ -1,17 +1,23 @@
 // jpeg_tile.h — the per-tile body of the fused JPEG coefficient kernel for gfx950.
 //
-// One 256-thread workgroup turns one tile of pixels into quantised DCT blocks:
+// One 256-thread workgroup (4 wavefronts, one per SIMD) turns tiles of pixels into
+// quantised DCT blocks.  Per tile:
 //
-//   phase A  (all 256 lanes, pixel-parallel)   global RGB8 -> registers (coalesced
-//            12 B/lane = 4 px), integer BT.601 colour conversion with packed-u16
-//            VALU ops (2 px per instruction), 2x2 chroma box sums, planar u8/u16
-//            samples into LDS.
-//   phase B  (one lane per 8x8 block)          LDS -> 64 f32 registers, level shift,
-//            f32 AAN DCT rows then columns entirely in registers (no transposes),
-//            quantise (reciprocal fast path proven equal to the IEEE divide, exact
-//            divide fallback), pack to i16, swizzled 16-B chunks into an LDS stage.
-//   phase C  (all lanes)                       LDS stage -> global, 16 B per lane,
-//            fully coalesced, in the reference's YCbCrCoefficients layout.
+//   phase A  (all 256 lanes, pixel-parallel)   global RGB8 -> registers (coalesced 12 B per
+//            lane = 4 px; issued one tile AHEAD by the persistent loop so HBM latency hides
+//            under the previous tile's DCT), integer BT.601 colour conversion with packed-u16
+//            VALU ops (2 px per instruction), 2x2 chroma box sums, planar u8/u16 samples
+//            into LDS — each wavefront's future blocks into that wavefront's own LDS region.
+//   --- barrier ---
+//   phase B  (one lane per 8x8 block)          LDS rows -> f32 on the fly, f32 AAN DCT rows
+//            then columns entirely in registers (no transposes), quantise (reciprocal fast
+//            path proven equal to the IEEE divide, exact divide fallback), pack to i16,
+//            swizzled 16-B chunks into the LDS stage.  A wavefront's stage region is the
+//            region its own planar samples lived in, so no barrier separates read and write.
+//   --- barrier ---
+//   phase C  (all lanes)                       LDS stage -> global, 16 B per lane, fully
+//            coalesced, in the reference's YCbCrCoefficients layout.
+//   --- barrier ---
 //
 // Reference semantics reproduced bit-for-bit (leerob/pixo v0.4.1):
 //   colour           src/color.rs:60-77           (integer, 2^8-scaled, clamp)
@@ -27,6 +33,11 @@
 // Compile with -ffp-contract=off: every f32 operation of the DCT must round once,
 // exactly as rustc emits it (no FMA).  The only fused operation below is an explicit
 // fmaf in OUR safety test, which is not part of the reference arithmetic.
+//
+// Instruction selection follows tools/ubench/valu_rates.hip measured on MI355X: wave64
+// v_add/sub/mul/fma_f32, v_and/or/add_u32 and shifts issue in 2 cycles; v_cvt_*, v_rndne,
+// v_cmp, v_perm, v_pk_* and every VOP3 integer op in 4 — so conversions use mantissa tricks
+// built from the 2-cycle set wherever the arithmetic stays exact.
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -39,9 +50,8 @@
 #define PIXO_PIN(x) ((void)0)
 #else
 #define PIXO_DEV __device__ __forceinline__
-// Stops the machine scheduler from interleaving independent 1-D transforms: left alone it
-// sinks the whole column pass into the quantiser rows, keeping ~16 temporaries of all 8
-// columns alive (150 VGPRs, 3 waves/SIMD).  Fenced, a block needs 64 + ~20 registers.
+// Stops the machine scheduler from interleaving independent 1-D transforms (which keeps the
+// temporaries of many rows/columns alive at once).
 #define PIXO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // Materialises a value here: stops LLVM from sinking the column pass into the quantiser's
 // basic blocks (which kept every column's butterflies alive across them).
@@ -55,50 +65,42 @@ namespace pixo_tile {
 enum Mode { M420 = 0, M444 = 1, MGRAY = 2 };
 
 constexpr int kThreads = 256;
-constexpr int kTileW = 512;        // pixels per tile row
-constexpr int kPitch = kTileW + 16; // LDS bytes per planar row: 8*kPitch % 256 == 128
-                                    // puts the bottom Y blocks of an MCU on the other
-                                    // half of the 64 banks (ds_read_b64 conflict-free)
+constexpr int kTileW = 512;     // pixels per tile row
+constexpr int kRegion = 8192;   // LDS bytes owned by one wavefront: 64 blocks x 128 B of stage
+constexpr int kPitch = 528;     // planar row pitch, full-width planes (4:4:4, gray)
+constexpr int kPitchHalf = 272; // planar row pitch, 256-px half planes (4:2:0 luminance);
+                                // 8*272 % 256 == 128 puts the bottom Y blocks of an MCU on the
+                                // other half of the 64 banks: ds_read_b64 conflict-free
 
 // Quantiser table block for one quality, resident in HBM, read with scalar loads:
 //   [0,64)    1/q luminance   [64,128)   1/q chrominance   (f32, correctly rounded)
 //   [128,192) q   luminance   [192,256)  q   chrominance   (f32, exact integers 1..255)
-constexpr int kQtFloats = 256;
+//   [256,320) (1/q chrominance) / 4 — for 4:2:0 chroma, whose DCT runs on the 2x2 SUMS
+//             (4x the sample; a power-of-two scale commutes with every f32 rounding)
+constexpr int kQtFloats = 320;
 
+// LDS map (bytes).  Stage block b lives at [128 b, 128 b + 128); wavefront w owns blocks
+// [64 w, 64 w + 64) = region [kRegion w, kRegion (w+1)) and its planar inputs sit inside it.
+//   4:2:0  tile 512x16 px = 32 MCUs = 192 blocks
+//          wave 0/1: luminance of MCUs 0-15 / 16-31 — half plane 16 rows x 272 B at region 0/1
+//          wave 2  : 32 Cb + 32 Cr blocks — 2x2 sums as u16, 8 rows x 512 B each, at
+//                    2*kRegion (Cb) and 2*kRegion + 4096 (Cr)
+//   4:4:4  tile 512x8 px = 64 block columns x {Y,Cb,Cr}: wave c reads plane c (8 rows x 528 B)
+//   gray   tile 512x32 px = 4 block rows: wave w reads block row w (8 rows x 528 B)
 template <int MODE> struct Geo;
-template <> struct Geo<M420> {
-    static constexpr int tile_h = 16, units_x = 32 /* MCUs */, blocks = 192;
-    static constexpr int y_off = 0, cb_off = 16 * kPitch, cr_off = cb_off + 4096;
-    static constexpr int planar_bytes = cr_off + 4096;
-    static constexpr int stage_bytes = blocks * 128;
-};
-template <> struct Geo<M444> {
-    static constexpr int tile_h = 8, units_x = 64 /* blocks */, blocks = 192;
-    static constexpr int y_off = 0, cb_off = 8 * kPitch, cr_off = 16 * kPitch;
-    static constexpr int planar_bytes = 24 * kPitch;
-    static constexpr int stage_bytes = blocks * 128;
-};
-template <> struct Geo<MGRAY> {
-    static constexpr int tile_h = 32, units_x = 64 /* blocks */, blocks = 256;
-    static constexpr int y_off = 0, cb_off = 0, cr_off = 0;
-    static constexpr int planar_bytes = 32 * kPitch;
-    static constexpr int stage_bytes = blocks * 128;
-};
-template <int MODE> constexpr int lds_bytes()
-{
-    return Geo<MODE>::planar_bytes > Geo<MODE>::stage_bytes ? Geo<MODE>::planar_bytes
-                                                             : Geo<MODE>::stage_bytes;
-}
+template <> struct Geo<M420> { static constexpr int tile_h = 16, units_x = 32, bpp = 3, in_regs = 24, lds = 3 * kRegion; };
+template <> struct Geo<M444> { static constexpr int tile_h = 8, units_x = 64, bpp = 3, in_regs = 12, lds = 3 * kRegion; };
+template <> struct Geo<MGRAY> { static constexpr int tile_h = 32, units_x = 64, bpp = 1, in_regs = 16, lds = 4 * kRegion; };
 
 // Per-image launch context (uniform across the workgroup).
 struct TileCtx {
-    const uint8_t *px;   // this image's pixels, tightly packed rows
+    const uint8_t *px;    // this image's pixels, tightly packed rows
     int16_t *y, *cb, *cr; // this image's coefficient arrays
-    const float *qt;     // kQtFloats floats for the requested quality
-    uint32_t W, H;       // pixels
-    uint32_t units_x;    // MCUs per row (4:2:0) or 8x8 blocks per row (4:4:4, gray)
-    uint32_t units_y;    // MCU rows / block rows
-    uint32_t fast;       // rows are 4-byte aligned: (px % 4 == 0) && (W*bpp % 4 == 0)
+    const float *qt;      // kQtFloats floats for the requested quality
+    uint32_t W, H;        // pixels
+    uint32_t units_x;     // MCUs per row (4:2:0) or 8x8 blocks per row (4:4:4, gray)
+    uint32_t units_y;     // MCU rows / block rows
+    uint32_t fast;        // rows are 4-byte aligned: (px % 4 == 0) && (W*bpp % 4 == 0)
 };
 
 // ---------------------------------------------------------------------------------
@@ -107,6 +109,7 @@ struct TileCtx {
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 PIXO_DEV uint32_t bits(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+PIXO_DEV uint32_t fbits(float v) { return __builtin_bit_cast(uint32_t, v); }
 PIXO_DEV u16x2 pk(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 PIXO_DEV u16x2 splat(unsigned v) { return u16x2{(unsigned short)v, (unsigned short)v}; }
 
@@ -127,21 +130,6 @@ PIXO_DEV uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
 #endif
 }
 
-// two f32 (integer-valued) -> packed i16 pair, saturating like Rust's `as i16`
-PIXO_DEV uint32_t pack_i16(float a, float b)
-{
-#if defined(PIXO_EMU)
-    int ia = (int)a, ib = (int)b;
-    ia = ia > 32767 ? 32767 : (ia < -32768 ? -32768 : ia);
-    ib = ib > 32767 ? 32767 : (ib < -32768 ? -32768 : ib);
-    return (uint32_t)(uint16_t)(int16_t)ia | ((uint32_t)(uint16_t)(int16_t)ib << 16);
-#else
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    s16x2 p = __builtin_amdgcn_cvt_pk_i16((int)a, (int)b);
-    return __builtin_bit_cast(uint32_t, p);
-#endif
-}
-
 PIXO_DEV int uniform_i32(int v)
 {
 #if defined(PIXO_EMU)
@@ -159,8 +147,8 @@ struct alignas(16) u32x4 { uint32_t x, y, z, w; };
 //   d0 = R0 G0 B0 R1   d1 = G1 B1 R2 G2   d2 = B2 R3 G3 B3   (little-endian bytes)
 // ---------------------------------------------------------------------------------
 struct Row4 {
-    uint32_t y4;         // Y0..Y3 as bytes
-    u16x2 cb01, cb23;    // min(X'>>8, 254) per pixel  (= Cb - 1, see below)
+    uint32_t y4;      // Y0..Y3 as bytes
+    u16x2 cb01, cb23; // min(X'>>8, 254) per pixel  (= Cb - 1, see below)
     u16x2 cr01, cr23;
 };
 
@@ -170,9 +158,8 @@ struct Row4 {
 //        (always in [0, 65280], so u16 arithmetic never wraps in the final value),
 //        Cb = (X' >> 8) + 1, and the reference's clamp to 255 is min(X' >> 8, 254) + 1.
 //   Cr = same with X' = 128R + 32640 - 107G - 21B.
-// The "+1" is folded into the level shift of phase B (x - 127 instead of x - 128),
-// which is exact.  Arithmetic >> on negative i32 in the reference equals the floor
-// that the biased unsigned shift computes.
+// The "+1" is folded into the level shift of phase B, which is exact.  Arithmetic >> on
+// negative i32 in the reference equals the floor that the biased unsigned shift computes.
 PIXO_DEV Row4 color_row4(uint32_t d0, uint32_t d1, uint32_t d2)
 {
     u16x2 r01 = pk(perm(d0, d0, 0x0C030C00u));
@@ -251,18 +238,20 @@ PIXO_DEV void load_row4_rgb(const TileCtx &c, uint32_t x0, uint32_t y, uint32_t 
     }
 }
 
-// Per-lane registers that live across the workgroup barriers.
+// The only per-lane state that crosses barriers: one tile's pixels in flight.
 template <int MODE> struct Lane {
-    uint32_t in[MODE == M420 ? 24 : (MODE == M444 ? 12 : 16)];
-    float v[64];
+    uint32_t in[Geo<MODE>::in_regs];
 };
 
-// ---- phase A.1: global loads (all issued before any use) ---------------------------
 template <int MODE> PIXO_DEV bool tile_is_interior(const TileCtx &c, uint32_t tile_x, uint32_t tile_y)
 {
     return c.fast && (tile_x + 1) * kTileW <= c.W && (tile_y + 1) * Geo<MODE>::tile_h <= c.H;
 }
 
+// ---- phase A.1: global loads (all issued before any use) ---------------------------
+// Work item = 4 horizontally adjacent pixels (x = 4g) of one row (or of a row pair for
+// 4:2:0, so that a lane owns whole 2x2 chroma quads).  Consecutive lanes read consecutive
+// 12-byte groups: a wavefront instruction covers 768 contiguous bytes of one image row.
 template <int MODE, bool INTERIOR>
 PIXO_DEV void phase_load(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int tid, Lane<MODE> &L)
 {
@@ -293,118 +282,93 @@ PIXO_DEV void phase_load(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int
     }
 }
 
+template <int MODE>
+PIXO_DEV void load_tile(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int tid, Lane<MODE> &L)
+{
+    if (tile_is_interior<MODE>(c, tile_x, tile_y)) phase_load<MODE, true>(c, tile_x, tile_y, tid, L);
+    else phase_load<MODE, false>(c, tile_x, tile_y, tid, L);
+}
+
 // ---- phase A.2: colour + subsample -> planar LDS -----------------------------------
 template <int MODE> PIXO_DEV void phase_color(int tid, const Lane<MODE> &L, uint8_t *lds)
 {
-    typedef Geo<MODE> G;
     if (MODE == M420) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             int item = k * kThreads + tid, g = item & 127, p = item >> 7;
             Row4 a = color_row4(L.in[k * 6], L.in[k * 6 + 1], L.in[k * 6 + 2]);
             Row4 b = color_row4(L.in[k * 6 + 3], L.in[k * 6 + 4], L.in[k * 6 + 5]);
-            *(uint32_t *)(lds + G::y_off + (2 * p) * kPitch + 4 * g) = a.y4;
-            *(uint32_t *)(lds + G::y_off + (2 * p + 1) * kPitch + 4 * g) = b.y4;
+            uint8_t *yp = lds + (g >> 6) * kRegion + (2 * p) * kPitchHalf + 4 * (g & 63);
+            *(uint32_t *)yp = a.y4;
+            *(uint32_t *)(yp + kPitchHalf) = b.y4;
             // 2x2 box sums (jpeg/mod.rs:1641-1646): vertical then horizontal, u16 exact
             uint32_t cb01 = bits(a.cb01 + b.cb01), cb23 = bits(a.cb23 + b.cb23);
             uint32_t cr01 = bits(a.cr01 + b.cr01), cr23 = bits(a.cr23 + b.cr23);
             u16x2 cbs = pk(perm(cb23, cb01, 0x05040100u)) + pk(perm(cb23, cb01, 0x07060302u));
             u16x2 crs = pk(perm(cr23, cr01, 0x05040100u)) + pk(perm(cr23, cr01, 0x07060302u));
-            *(uint32_t *)(lds + G::cb_off + p * 512 + 4 * g) = bits(cbs);
-            *(uint32_t *)(lds + G::cr_off + p * 512 + 4 * g) = bits(crs);
+            *(uint32_t *)(lds + 2 * kRegion + p * 512 + 4 * g) = bits(cbs);
+            *(uint32_t *)(lds + 2 * kRegion + 4096 + p * 512 + 4 * g) = bits(crs);
         }
     } else if (MODE == M444) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             int item = k * kThreads + tid, g = item & 127, r = item >> 7;
             Row4 a = color_row4(L.in[k * 3], L.in[k * 3 + 1], L.in[k * 3 + 2]);
-            *(uint32_t *)(lds + G::y_off + r * kPitch + 4 * g) = a.y4;
-            *(uint32_t *)(lds + G::cb_off + r * kPitch + 4 * g) =
-                perm(bits(a.cb23), bits(a.cb01), 0x06040200u);
-            *(uint32_t *)(lds + G::cr_off + r * kPitch + 4 * g) =
-                perm(bits(a.cr23), bits(a.cr01), 0x06040200u);
+            uint8_t *p = lds + r * kPitch + 4 * g;
+            *(uint32_t *)p = a.y4;
+            *(uint32_t *)(p + kRegion) = perm(bits(a.cb23), bits(a.cb01), 0x06040200u);
+            *(uint32_t *)(p + 2 * kRegion) = perm(bits(a.cr23), bits(a.cr01), 0x06040200u);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             int item = k * kThreads + tid, g = item & 127, r = item >> 7;
-            *(uint32_t *)(lds + r * kPitch + 4 * g) = L.in[k];
+            *(uint32_t *)(lds + (r >> 3) * kRegion + (r & 7) * kPitch + 4 * g) = L.in[k];
         }
     }
 }
 
-// ---- phase B.1: planar LDS -> 64 level-shifted f32 per block lane -------------------
-PIXO_DEV void bytes8_to_f32(u32x2 w, float shift, float *v)
+// ---------------------------------------------------------------------------------
+// phase B: one lane = one 8x8 block
+// ---------------------------------------------------------------------------------
+// A sample byte b (or 2x2 sum S) becomes the float 2^23 + b by OR-ing it into the mantissa
+// of 0x4B000000 — full-rate VALU ops instead of v_cvt (half rate) + level-shift subtract.
+// The bias and the JPEG level shift never need a per-sample operation: the row transform's
+// first butterflies cancel the bias (aan8_biased) and the level shift only reaches the DC
+// term of each row, where one subtraction removes it (all values involved are exact small
+// integers in f32, so this is the same arithmetic as the reference's `x as f32 - 128.0`).
+constexpr uint32_t kBiasBits = 0x4B000000u; // 2^23
+
+PIXO_DEV float biased(uint32_t small) { return __builtin_bit_cast(float, kBiasBits | small); }
+
+PIXO_DEV void row_from_bytes(uint32_t lo, uint32_t hi, float *v)
 {
-    v[0] = (float)(w.x & 0xFF) - shift;         v[1] = (float)((w.x >> 8) & 0xFF) - shift;
-    v[2] = (float)((w.x >> 16) & 0xFF) - shift; v[3] = (float)(w.x >> 24) - shift;
-    v[4] = (float)(w.y & 0xFF) - shift;         v[5] = (float)((w.y >> 8) & 0xFF) - shift;
-    v[6] = (float)((w.y >> 16) & 0xFF) - shift; v[7] = (float)(w.y >> 24) - shift;
+    v[0] = biased(lo & 0xFF);         v[1] = biased((lo >> 8) & 0xFF);
+    v[2] = biased((lo >> 16) & 0xFF); v[3] = biased(lo >> 24);
+    v[4] = biased(hi & 0xFF);         v[5] = biased((hi >> 8) & 0xFF);
+    v[6] = biased((hi >> 16) & 0xFF); v[7] = biased(hi >> 24);
+}
+PIXO_DEV void row_from_u16(u32x4 w, float *v)
+{
+    v[0] = biased(w.x & 0xFFFF); v[1] = biased(w.x >> 16);
+    v[2] = biased(w.y & 0xFFFF); v[3] = biased(w.y >> 16);
+    v[4] = biased(w.z & 0xFFFF); v[5] = biased(w.z >> 16);
+    v[6] = biased(w.w & 0xFFFF); v[7] = biased(w.w >> 16);
 }
 
-// returns the quantiser class of this lane's block: 0 luminance, 1 chrominance, -1 idle
-template <int MODE> PIXO_DEV int phase_fetch(int tid, const uint8_t *lds, Lane<MODE> &L)
-{
-    typedef Geo<MODE> G;
-    const int wave = uniform_i32(tid >> 6), lane = tid & 63;
-    if (MODE == M420) {
-        if (wave < 2) {
-            int m = wave * 16 + (lane >> 2), s = lane & 3;
-            const uint8_t *base = lds + G::y_off + ((s >> 1) * 8) * kPitch + m * 16 + (s & 1) * 8;
-#pragma unroll
-            for (int r = 0; r < 8; r++)
-                bytes8_to_f32(*(const u32x2 *)(base + r * kPitch), 128.0f, &L.v[r * 8]);
-            return 0;
-        }
-        if (wave == 2) {
-            const uint8_t *base = lds + G::cb_off + (lane >> 5) * 4096 + (lane & 31) * 16;
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                u32x4 w = *(const u32x4 *)(base + r * 512);
-                // mean of four u8 chroma values, f32: (sum + 4) * 0.25 - 128 == sum*0.25 - 127
-                // (jpeg/mod.rs:1650-1653; every value is a multiple of 0.25 below 256: exact)
-                float *v = &L.v[r * 8];
-                v[0] = (float)(w.x & 0xFFFF) * 0.25f - 127.0f; v[1] = (float)(w.x >> 16) * 0.25f - 127.0f;
-                v[2] = (float)(w.y & 0xFFFF) * 0.25f - 127.0f; v[3] = (float)(w.y >> 16) * 0.25f - 127.0f;
-                v[4] = (float)(w.z & 0xFFFF) * 0.25f - 127.0f; v[5] = (float)(w.z >> 16) * 0.25f - 127.0f;
-                v[6] = (float)(w.w & 0xFFFF) * 0.25f - 127.0f; v[7] = (float)(w.w >> 16) * 0.25f - 127.0f;
-            }
-            return 1;
-        }
-        return -1;
-    } else if (MODE == M444) {
-        if (wave < 3) {
-            const uint8_t *base = lds + wave * (8 * kPitch) + lane * 8;
-            const float shift = wave == 0 ? 128.0f : 127.0f; // chroma bytes hold C-1
-#pragma unroll
-            for (int r = 0; r < 8; r++)
-                bytes8_to_f32(*(const u32x2 *)(base + r * kPitch), shift, &L.v[r * 8]);
-            return wave == 0 ? 0 : 1;
-        }
-        return -1;
-    } else {
-        const uint8_t *base = lds + (wave * 8) * kPitch + lane * 8;
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-            bytes8_to_f32(*(const u32x2 *)(base + r * kPitch), 128.0f, &L.v[r * 8]);
-        return 0;
-    }
-}
-
-// ---- phase B.2: f32 AAN DCT, dct.rs:651-700, operation for operation ---------------
+// f32 AAN DCT, dct.rs:651-700, operation for operation.
 #define PIXO_A1 0.70710678118654752440f
 #define PIXO_A2 0.5411961f
 #define PIXO_A4 1.3065629f
 #define PIXO_A5 0.38268343f
 
-PIXO_DEV void aan8(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5, float &d6,
-                   float &d7)
+// everything of dct.rs:651-700 after the first butterfly stage
+PIXO_DEV void aan8_core(float t0, float t1, float t2, float t3, float t4, float t5, float t6, float t7,
+                        float dc_shift, float &d0, float &d1, float &d2, float &d3, float &d4,
+                        float &d5, float &d6, float &d7)
 {
-    float t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
-    float t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
-
     float e0 = t0 + t3, e3 = t0 - t3, e1 = t1 + t2, e2 = t1 - t2;
-    float r0 = e0 + e1, r4 = e0 - e1;
+    float r0 = (e0 + e1) - dc_shift, r4 = e0 - e1; // dc_shift == 0 in the column pass
     float z1 = (e2 + e3) * PIXO_A1;
     float r2 = e3 + z1, r6 = e3 - z1;
 
@@ -420,51 +384,78 @@ PIXO_DEV void aan8(float &d0, float &d1, float &d2, float &d3, float &d4, float 
     d4 = r4 * 0.3535534f; d5 = r5 * 0.4499881f; d6 = r6 * 0.6532815f; d7 = r7 * 1.2814578f;
 }
 
-PIXO_DEV void dct_2d(float *v)
+// column pass: plain inputs, no shift (x - 0.0f is exact and folds away)
+PIXO_DEV void aan8(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5, float &d6,
+                   float &d7)
 {
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        aan8(v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5],
-             v[r * 8 + 6], v[r * 8 + 7]);
-        if (r & 1) PIXO_SCHED_FENCE();
-    }
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        aan8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
-        if (c & 1) PIXO_SCHED_FENCE();
-    }
+    float t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
+    float t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+    aan8_core(t0, t1, t2, t3, t4, t5, t6, t7, 0.0f, d0, d1, d2, d3, d4, d5, d6, d7);
 }
 
-// ---- phase B.3: quantise one row of 8 coefficients ----------------------------------
+// Row transform on biased inputs D_i = 2^23 + b_i.  Differences cancel the bias exactly;
+// a sum is formed as (D_i - 2^24) + D_j = (b_i - 2^23) + (2^23 + b_j) = b_i + b_j, both steps
+// exact.  The true inputs are b_i - L (level shift L), so the butterflies' sums carry +2L,
+// +4L, +8L and the differences nothing: only r0 needs the shift (8L = dc_shift).  Every
+// value up to the first multiplication is an exact integer below 2^14, so the reference's
+// own sequence of f32 additions yields the same numbers.
+PIXO_DEV void aan8_biased(float dc_shift, float &d0, float &d1, float &d2, float &d3, float &d4,
+                          float &d5, float &d6, float &d7)
+{
+    const float k2p24 = 16777216.0f;
+    float t7 = d0 - d7, t6 = d1 - d6, t5 = d2 - d5, t4 = d3 - d4;
+    float t0 = (d0 - k2p24) + d7, t1 = (d1 - k2p24) + d6;
+    float t2 = (d2 - k2p24) + d5, t3 = (d3 - k2p24) + d4;
+    aan8_core(t0, t1, t2, t3, t4, t5, t6, t7, dc_shift, d0, d1, d2, d3, d4, d5, d6, d7);
+}
+
+// Quantise one row of 8 coefficients.
 // Reference: (x / q).round() as i16 with IEEE f32 divide and round-half-away.
 //
 // Fast path: r = x * fl(1/q), n = rint(r).  Let t = x/q (real) and f = fl(t) the
 // reference quotient.  |r - t| <= |t|(2^-24 + 2^-24 + 2^-48) and |f - t| <= 2^-24|t|,
 // so |r - f| < 2^-22 |r| =: delta.  If no half-integer lies within delta' = 2^-21 |r|
 // (twice delta; the slack absorbs the rounding of the test itself) of r, then r and f
-// sit strictly inside the same interval (k-1/2, k+1/2) and both roundings — rint for
-// r, half-away for f — give k.  Otherwise the lane takes the exact divide.  |r - n|
-// is computed exactly (Sterbenz).  Tiny |r| (< 1/8) are trivially safe.
-PIXO_DEV void quant_row8(const float *x, const float *rcp, const float *q, uint32_t out[4])
+// sit strictly inside the same interval (k-1/2, k+1/2) and both roundings — to-nearest-even
+// for r, half-away for f — give k.  Otherwise the row takes the exact divide.  Checked by
+// enumeration over every f32 |x| <= 4096 and every q in 1..255: tests/emu/sweep_quant.py.
+//
+// Built from full-rate gfx950 VALU ops only:
+//   s = r + 1.5*2^23      rounds r to an integer (RNE) and leaves it, two's complement, in
+//                         the low mantissa bits: bits(s) = 0x4B400000 + n for |n| < 2^22
+//   n = s - 1.5*2^23      exact;   d = r - n exact (|d| <= 1/2, Sterbenz)
+//   w = (|d| + 2^-21|r|) - 1/2      >= 0 (sign bit clear) iff the lane is risky
+//   acc &= bits(w)        the row is safe iff the sign bit survives all eight ANDs
+// `scale` (1 or 1/4) maps x back to the reference's magnitude for the exact path only; the
+// fast path's rcp already contains it (exact power of two).
+constexpr float kRoundMagic = 12582912.0f; // 1.5 * 2^23
+
+PIXO_DEV void quant_row8(const float *x, const float *rcp, const float *q, float scale, uint32_t out[4])
 {
-    float n[8];
-    bool risky = false;
+    float s[8];
+    uint32_t acc = 0x80000000u;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         float r = x[c] * rcp[c];
-        n[c] = __builtin_rintf(r);
-        float lim = __builtin_fmaf(__builtin_fabsf(r), -0x1p-21f, 0.5f);
-        risky |= __builtin_fabsf(r - n[c]) >= lim;
+        s[c] = r + kRoundMagic;
+        float n = s[c] - kRoundMagic;
+        float d = r - n;
+        float w = __builtin_fmaf(__builtin_fabsf(r), 0x1p-21f, __builtin_fabsf(d)) - 0.5f;
+        acc &= fbits(w);
     }
-    if (risky) { // rare: a quotient within 2^-21 (relative) of a rounding boundary
+    if ((acc & 0x80000000u) == 0) { // rare: a quotient within 2^-21 (relative) of a rounding boundary
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-            n[c] = __builtin_roundf(x[c] / q[c]); // the reference operation itself
-            PIXO_SCHED_FENCE();                   // one divide at a time: few temporaries
+            float n = __builtin_roundf((x[c] * scale) / q[c]); // the reference operation itself
+            s[c] = n + kRoundMagic;                             // exact: |n| < 2^15
+            PIXO_SCHED_FENCE();                                 // one divide at a time: few temporaries
         }
     }
-    out[0] = pack_i16(n[0], n[1]); out[1] = pack_i16(n[2], n[3]);
-    out[2] = pack_i16(n[4], n[5]); out[3] = pack_i16(n[6], n[7]);
+    // low 16 bits of each s = the i16 result (never saturates: |x/q| <= 2^11)
+    out[0] = perm(fbits(s[1]), fbits(s[0]), 0x05040100u);
+    out[1] = perm(fbits(s[3]), fbits(s[2]), 0x05040100u);
+    out[2] = perm(fbits(s[5]), fbits(s[4]), 0x05040100u);
+    out[3] = perm(fbits(s[7]), fbits(s[6]), 0x05040100u);
 }
 
 // LDS stage: block b occupies bytes [128b, 128b+128); its 16-byte chunk j (= natural-
@@ -473,26 +464,111 @@ PIXO_DEV void quant_row8(const float *x, const float *rcp, const float *q, uint3
 // are bank-conflict free.
 PIXO_DEV int stage_addr(int b, int j) { return b * 128 + ((j ^ (b & 7)) << 4); }
 
-template <int MODE>
-PIXO_DEV void phase_dct_quant(int tid, int cls, const float *qt, Lane<MODE> &L, uint8_t *lds)
+// Block kinds (wave-uniform): quantiser table, DC shift of the row pass, scale.
+//   luminance            samples b,  level shift 128          row DC shift 8*128 = 1024
+//   chroma 4:4:4         bytes hold C-1 (see color_row4)      row DC shift 8*127 = 1016
+//   chroma 4:2:0 (U16)   2x2 sums S = 4*mean - 4, transform at 4x scale:
+//                        mean - 128 = (S - 508)/4             row DC shift 8*508 = 4064
+// `src` points at this lane's first planar row; rows are `pitch` bytes apart.  Rows are read
+// from LDS as the row pass needs them (2-4 registers), not staged in 16-32 registers.
+template <bool U16>
+PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v)
 {
-    if (cls < 0) return;
-    const int wave = uniform_i32(tid >> 6), lane = tid & 63;
-    const int b = wave * 64 + lane;
-    const float *rcp = qt + uniform_i32(cls) * 64;
-    const float *q = rcp + 128;
-    dct_2d(L.v);
 #pragma unroll
-    for (int i = 0; i < 64; i++) PIXO_PIN(L.v[i]);
+    for (int r = 0; r < 8; r++) {
+        if (U16) {
+            row_from_u16(*(const u32x4 *)(src + r * pitch), &v[r * 8]);
+        } else {
+            u32x2 w = *(const u32x2 *)(src + r * pitch);
+            row_from_bytes(w.x, w.y, &v[r * 8]);
+        }
+        aan8_biased(dc_shift, v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4],
+                    v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+        if (r & 1) PIXO_SCHED_FENCE();
+    }
+}
+
+PIXO_DEV void block_cols_quant(float *v, const float *rcp, const float *q, float scale, int b, uint8_t *lds)
+{
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        aan8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+        if (c & 1) PIXO_SCHED_FENCE();
+    }
+#pragma unroll
+    for (int i = 0; i < 64; i++) PIXO_PIN(v[i]);
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         u32x4 o;
         uint32_t w[4];
-        quant_row8(&L.v[u * 8], rcp + u * 8, q + u * 8, w);
+        quant_row8(&v[u * 8], rcp + u * 8, q + u * 8, scale, w);
         o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
         *(u32x4 *)(lds + stage_addr(b, u)) = o;
         PIXO_SCHED_FENCE();
     }
+}
+
+// What the block of lane `tid` is and where its planar rows start (all wave-uniform except src).
+struct BlockDesc {
+    const uint8_t *src;
+    int pitch;
+    int rcp_off, q_off; // offsets into the quantiser table block
+    float dc_shift, scale;
+    bool active, u16;
+};
+
+template <int MODE> PIXO_DEV BlockDesc block_desc(int tid, const uint8_t *lds)
+{
+    const int wave = uniform_i32(tid >> 6), lane = tid & 63;
+    BlockDesc d;
+    d.active = true; d.u16 = false; d.pitch = kPitch; d.rcp_off = 0; d.q_off = 128;
+    d.dc_shift = 1024.0f; d.scale = 1.0f;
+    d.src = lds + wave * kRegion + lane * 8;
+    if (MODE == M420) {
+        if (wave < 2) {
+            const int ml = lane >> 2, s = lane & 3;
+            d.src = lds + wave * kRegion + ((s >> 1) * 8) * kPitchHalf + ml * 16 + (s & 1) * 8;
+            d.pitch = kPitchHalf;
+        } else if (wave == 2) {
+            d.src = lds + 2 * kRegion + (lane >> 5) * 4096 + (lane & 31) * 16;
+            d.pitch = 512; d.u16 = true; d.rcp_off = 256; d.q_off = 192; d.dc_shift = 4064.0f; d.scale = 0.25f;
+        } else {
+            d.active = false;
+        }
+    } else if (MODE == M444) {
+        if (wave >= 3) d.active = false;
+        if (wave >= 1) { d.rcp_off = 64; d.q_off = 192; d.dc_shift = 1016.0f; }
+    }
+    return d;
+}
+
+// Phase B is two steps per wavefront, in program order and WITHOUT a barrier between them:
+// (1) every lane reads its 8 planar rows from the wavefront's region and runs the row pass;
+// (2) column pass, quantise, write the stage into the same region.  Lanes of a wavefront
+// execute in lockstep, so all reads of step 1 precede all writes of step 2; other
+// wavefronts never touch this region during phase B.  (tests/emu runs the two steps as
+// separate lane loops per wavefront to model exactly this ordering.)
+template <int MODE> PIXO_DEV bool phase_rows(int tid, const uint8_t *lds, float *v)
+{
+    const BlockDesc d = block_desc<MODE>(tid, lds);
+    if (!d.active) return false;
+    if (MODE == M420 && d.u16) block_rows<true>(d.src, 512, 4064.0f, v);
+    else block_rows<false>(d.src, d.pitch, d.dc_shift, v);
+    return true;
+}
+
+template <int MODE> PIXO_DEV void phase_cols_quant(int tid, const float *qt, float *v, uint8_t *lds)
+{
+    const BlockDesc d = block_desc<MODE>(tid, lds);
+    if (!d.active) return;
+    const int wave = uniform_i32(tid >> 6), lane = tid & 63;
+    block_cols_quant(v, qt + d.rcp_off, qt + d.q_off, d.scale, wave * 64 + lane, lds);
+}
+
+template <int MODE> PIXO_DEV void phase_dct_quant(int tid, const float *qt, uint8_t *lds)
+{
+    float v[64];
+    if (phase_rows<MODE>(tid, lds, v)) phase_cols_quant<MODE>(tid, qt, v, lds);
 }
 
 // ---- phase C: stage -> global, 16 B per lane, coalesced ------------------------------

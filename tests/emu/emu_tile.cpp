@@ -13,33 +13,39 @@
 using namespace pixo_tile;
 
 template <int MODE>
-static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long *stats)
+static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long *stats, int wave_order)
 {
     std::vector<Lane<MODE>> lanes(kThreads);
+    std::vector<float> v((size_t)kThreads * 64);
     alignas(16) static uint8_t lds[64 * 1024];
-    int cls[kThreads];
+    bool active[kThreads];
     for (uint32_t ty = 0; ty < tiles_y; ty++)
         for (uint32_t tx = 0; tx < tiles_x; tx++) {
-            const bool interior = tile_is_interior<MODE>(c, tx, ty);
-            if (stats) stats[interior ? 0 : 1]++;
+            if (stats) stats[tile_is_interior<MODE>(c, tx, ty) ? 0 : 1]++;
+            memset(lds, 0xA5, sizeof lds); // nothing may rely on LDS contents of a previous tile
+            // phase A (then barrier)
             for (int t = 0; t < kThreads; t++) {
-                if (interior) phase_load<MODE, true>(c, tx, ty, t, lanes[t]);
-                else phase_load<MODE, false>(c, tx, ty, t, lanes[t]);
+                load_tile<MODE>(c, tx, ty, t, lanes[t]);
                 phase_color<MODE>(t, lanes[t], lds);
             }
-            for (int t = 0; t < kThreads; t++) cls[t] = phase_fetch<MODE>(t, lds, lanes[t]);
-            // poison the aliased region to prove phase B no longer depends on planar data
-            memset(lds, 0xA5, lds_bytes<MODE>());
-            for (int t = 0; t < kThreads; t++) phase_dct_quant<MODE>(t, cls[t], c.qt, lanes[t], lds);
+            // phase B: no barrier between wavefronts, so run them in a caller-chosen order;
+            // inside a wavefront, lockstep: all lanes' reads (rows) before any lane's writes.
+            for (int k = 0; k < 4; k++) {
+                const int w = wave_order == 0 ? k : (wave_order == 1 ? 3 - k : (k * 3 + 1) % 4);
+                for (int l = 0; l < 64; l++) active[w * 64 + l] = phase_rows<MODE>(w * 64 + l, lds, &v[(w * 64 + l) * 64]);
+                for (int l = 0; l < 64; l++)
+                    if (active[w * 64 + l]) phase_cols_quant<MODE>(w * 64 + l, c.qt, &v[(w * 64 + l) * 64], lds);
+            }
+            // (barrier) phase C
             for (int t = 0; t < kThreads; t++) phase_store<MODE>(c, tx, ty, t, lds);
         }
 }
 
 extern "C" int emu_jpeg_coeffs(const uint8_t *px, uint32_t W, uint32_t H, int color_type, int subsampling,
                                int quality, int16_t *y, int16_t *cb, int16_t *cr, int allow_fast,
-                               long *stats /* [interior tiles, edge tiles] or NULL */)
+                               long *stats /* [interior tiles, edge tiles] or NULL */, int wave_order)
 {
-    float qt[256];
+    float qt[pixo_host::kDeviceQtFloats];
     pixo_host::fill_device_qt((uint8_t)quality, qt);
     const bool gray = color_type == 0, s420 = !gray && subsampling == 1;
     TileCtx c;
@@ -51,11 +57,11 @@ extern "C" int emu_jpeg_coeffs(const uint8_t *px, uint32_t W, uint32_t H, int co
     c.fast = allow_fast && ((uintptr_t)px % 4 == 0) && (row_bytes % 4 == 0);
     if (stats) stats[0] = stats[1] = 0;
     if (gray) {
-        run_image<MGRAY>(c, (c.units_x + 63) / 64, (c.units_y * 8 + 31) / 32, stats);
+        run_image<MGRAY>(c, (c.units_x + 63) / 64, (c.units_y * 8 + 31) / 32, stats, wave_order);
     } else if (s420) {
-        run_image<M420>(c, (c.units_x + 31) / 32, c.units_y, stats);
+        run_image<M420>(c, (c.units_x + 31) / 32, c.units_y, stats, wave_order);
     } else {
-        run_image<M444>(c, (c.units_x + 63) / 64, c.units_y, stats);
+        run_image<M444>(c, (c.units_x + 63) / 64, c.units_y, stats, wave_order);
     }
     return 0;
 }
@@ -72,7 +78,7 @@ extern "C" long emu_quant_mismatches(const float *x, long n, int qlo, int qhi)
         for (long i = 0; i + 8 <= n; i += 8) {
             uint32_t out[4];
             for (int k = 0; k < 8; k++) xx[k] = x[i + k];
-            quant_row8(xx, rr, qq, out);
+            quant_row8(xx, rr, qq, 1.0f, out);
             for (int k = 0; k < 8; k++) {
                 int16_t got = (int16_t)(out[k >> 1] >> (16 * (k & 1)));
                 float want = roundf(xx[k] / fq);
@@ -91,11 +97,14 @@ extern "C" void emu_quant_fastpath_audit(const float *x, long n, int q, long *fl
     long f = 0, w = 0;
     for (long i = 0; i < n; i++) {
         float r = x[i] * rcp;
-        float nn = __builtin_rintf(r);
-        float lim = __builtin_fmaf(__builtin_fabsf(r), -0x1p-21f, 0.5f);
-        bool risky = __builtin_fabsf(r - nn) >= lim;
+        float sm = r + kRoundMagic;
+        float nn = sm - kRoundMagic;
+        float d = r - nn;
+        float wv = __builtin_fmaf(__builtin_fabsf(r), 0x1p-21f, __builtin_fabsf(d)) - 0.5f;
+        bool risky = !(__builtin_bit_cast(uint32_t, wv) & 0x80000000u);
+        int16_t got = (int16_t)(__builtin_bit_cast(uint32_t, sm) & 0xFFFF);
         if (risky) f++;
-        else if (nn != roundf(x[i] / fq)) w++;
+        else if ((float)got != roundf(x[i] / fq)) w++;
     }
     *flagged = f;
     *wrong_unflagged = w;
@@ -114,12 +123,15 @@ extern "C" void emu_quant_exhaustive(int q, uint32_t lo_bits, uint32_t hi_bits, 
             memcpy(&x, &u, 4);
             float want = roundf(x / fq);
             float r = x * rcp;
-            float nn = __builtin_rintf(r);
-            float lim = __builtin_fmaf(__builtin_fabsf(r), -0x1p-21f, 0.5f);
-            bool risky = __builtin_fabsf(r - nn) >= lim;
-            if (risky) { f++; nn = roundf(x / fq); }
-            else if (nn != want) w++;
-            if (nn != want) wf++;
+            float sm = r + kRoundMagic;
+            float nn = sm - kRoundMagic;
+            float d = r - nn;
+            float wv = __builtin_fmaf(__builtin_fabsf(r), 0x1p-21f, __builtin_fabsf(d)) - 0.5f;
+            bool risky = !(__builtin_bit_cast(uint32_t, wv) & 0x80000000u);
+            float got = (float)(int16_t)(__builtin_bit_cast(uint32_t, sm) & 0xFFFF);
+            if (risky) { f++; got = want; }
+            else if (got != want) w++;
+            if (got != want) wf++;
         }
     *flagged = f; *wrong_unflagged = w; *wrong_final = wf;
 }

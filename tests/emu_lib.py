@@ -17,7 +17,7 @@ def lib():
         subprocess.check_call(["make", "-C", _EMU], stdout=subprocess.DEVNULL)
         L = C.CDLL(os.path.join(_EMU, "libpixo_emu.so"))
         L.emu_jpeg_coeffs.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int,
-                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.emu_quant_mismatches.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int]
         L.emu_quant_mismatches.restype = C.c_long
         L.emu_quant_fastpath_audit.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p]
@@ -34,7 +34,7 @@ def geometry(w, h, color_type, subsampling):
     return (4 * units if s420 else units), (0 if gray else units)
 
 
-def coeffs(pixels, w, h, color_type=2, subsampling=1, quality=80, allow_fast=True, misalign=0):
+def coeffs(pixels, w, h, color_type=2, subsampling=1, quality=80, allow_fast=True, misalign=0, wave_order=0):
     px = np.ascontiguousarray(pixels, np.uint8)
     if misalign:
         buf = np.empty(px.size + 16, np.uint8)
@@ -47,5 +47,5 @@ def coeffs(pixels, w, h, color_type=2, subsampling=1, quality=80, allow_fast=Tru
     cr = np.full((max(cbn, 1), 64), -32768, np.int16)
     stats = (C.c_long * 2)()
     lib().emu_jpeg_coeffs(px.ctypes.data, w, h, color_type, subsampling, quality, y.ctypes.data,
-                          cb.ctypes.data, cr.ctypes.data, int(allow_fast), stats)
+                          cb.ctypes.data, cr.ctypes.data, int(allow_fast), stats, wave_order)
     return y, cb[:cbn], cr[:cbn], (stats[0], stats[1])

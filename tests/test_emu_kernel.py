@@ -64,3 +64,15 @@ def test_saturated_colours_hit_the_chroma_clamp():
         px = np.tile(np.array(rgb, np.uint8), 64 * 32)
         _same(px, 64, 32, 2, 1, 100)
         _same(px, 64, 32, 2, 0, 100)
+
+
+@pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_phase_b_needs_no_barrier_between_wavefronts(mode, order):
+    """Phase B has no workgroup barrier between reading planar rows and writing the stage:
+    each wavefront only touches its own LDS region.  Running the wavefronts in different
+    orders (each one completely, reads-then-writes) must not change a single coefficient."""
+    ct, ss = mode
+    w, h = 1100, 70
+    px = synth.noise_gray(w, h, 3) if ct == 0 else synth.noise(w, h, 3)
+    _same(px, w, h, ct, ss, 80, wave_order=order)

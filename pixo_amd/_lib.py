@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpixo_hip.so")
+# PIXO_HIP_LIB lets kernel A/B experiments (tools/ab_build.sh) point at another build of the
+# same C ABI; the default is the in-tree library.
+LIB_PATH = os.environ.get("PIXO_HIP_LIB") or os.path.join(_HERE, "libpixo_hip.so")
 
 
 class JpegOptionsC(C.Structure):

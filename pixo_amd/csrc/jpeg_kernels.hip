@@ -36,27 +36,45 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// A tile is (image, tile column, tile row): three SGPRs.  The full TileCtx is rebuilt from the
+// kernel arguments where it is needed instead of being carried (three live copies of it cost
+// ~30 SGPRs and pushed the kernel to the 102-SGPR limit).
 struct TileId {
-    TileCtx c;
-    uint32_t tx, ty;
+    uint32_t img, tx, ty;
 };
 
 __device__ __forceinline__ TileId locate(const KArgs &a, uint32_t t)
 {
     const uint32_t per_img = a.tiles_x * a.tiles_y;
-    const uint32_t img = t / per_img, r = t - img * per_img;
     TileId id;
+    id.img = t / per_img;
+    const uint32_t r = t - id.img * per_img;
     id.ty = r / a.tiles_x;
     id.tx = r - id.ty * a.tiles_x;
-    id.c.px = a.px + (size_t)img * a.px_stride;
-    id.c.y = a.y + (size_t)img * a.y_stride;
-    id.c.cb = a.cb ? a.cb + (size_t)img * a.c_stride : nullptr;
-    id.c.cr = a.cr ? a.cr + (size_t)img * a.c_stride : nullptr;
-    id.c.qt = a.qt;
-    id.c.W = a.W; id.c.H = a.H; id.c.units_x = a.units_x; id.c.units_y = a.units_y; id.c.fast = a.fast;
     return id;
 }
 
+__device__ __forceinline__ TileCtx ctx_of(const KArgs &a, uint32_t img)
+{
+    TileCtx c;
+    c.px = a.px + (size_t)img * a.px_stride;
+    c.y = a.y + (size_t)img * a.y_stride;
+    c.cb = a.cb ? a.cb + (size_t)img * a.c_stride : nullptr;
+    c.cr = a.cr ? a.cr + (size_t)img * a.c_stride : nullptr;
+    c.qt = a.qt;
+    c.W = a.W; c.H = a.H; c.units_x = a.units_x; c.units_y = a.units_y; c.fast = a.fast;
+    return c;
+}
+
+// Software pipeline, one call site per phase.  Iteration i of a workgroup (tile i = its i-th
+// tile; planar and stage are disjoint LDS areas):
+//   1. colour-convert tile i (registers -> LDS planar)       first use of the loaded pixels
+//   2. write tile i-1's stage out to HBM, THEN issue tile i+1's global loads
+//   3. transform tile i (LDS planar -> LDS stage)             pure VALU/LDS, no vmcnt wait
+// Every VMEM operation of an iteration is issued in step 2 and not waited for until step 1 of
+// the next iteration, so stores and loads drain under the whole of step 3.  (vmcnt retires in
+// order: with the loads older than the stores, a wait for the loads would also be a wait for
+// the stores just issued — the previous schedule serialised store drain and VALU work.)
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void jpeg_coeffs_kernel(const KArgs a)
 {
@@ -65,28 +83,37 @@ __global__ __launch_bounds__(kThreads) void jpeg_coeffs_kernel(const KArgs a)
     const uint32_t total = a.tiles_x * a.tiles_y * a.batch;
     uint32_t t = blockIdx.x;
     if (t >= total) return;
-
     Lane<MODE> L;
-    TileId cur = locate(a, t);
-    load_tile<MODE>(cur.c, cur.tx, cur.ty, tid, L);
+    TileId prev = locate(a, t), cur = prev, nxt = prev;
+    load_tile<MODE>(ctx_of(a, cur.img), cur.tx, cur.ty, tid, L);
+    bool have_prev = false;
     for (;;) {
-        phase_color<MODE>(tid, L, lds); // consumes L.in
+#if !defined(PIXO_ABLATE) || PIXO_ABLATE < 2 // (timing experiments: >=2 drops the colour conversion)
+        phase_color<MODE>(tid, L, lds);
+#else
+        for (int i = 0; i < Geo<MODE>::in_regs; i++) asm volatile("" ::"v"(L.in[i]));
+#endif
+        lds_barrier(); // planar(cur) complete; stage(prev) was completed before the last barrier
+        if (have_prev) phase_store<MODE>(ctx_of(a, prev.img), prev.tx, prev.ty, tid, lds);
         const uint32_t tn = t + gridDim.x;
         const bool more = tn < total;
-        TileId nxt = cur;
-        if (more) { // prefetch: lands while this tile is transformed and stored
+        if (more) {
             nxt = locate(a, tn);
-            load_tile<MODE>(nxt.c, nxt.tx, nxt.ty, tid, L);
+            load_tile<MODE>(ctx_of(a, nxt.img), nxt.tx, nxt.ty, tid, L);
         }
-        lds_barrier();
+        lds_barrier(); // stage(prev) read out: phase B may overwrite it
+#if !defined(PIXO_ABLATE) || PIXO_ABLATE < 1 // (>=1 drops the transform)
         phase_dct_quant<MODE>(tid, a.qt, lds);
-        lds_barrier();
-        phase_store<MODE>(cur.c, cur.tx, cur.ty, tid, lds);
+#endif
+        prev = cur;
+        have_prev = true;
         if (!more) break;
-        t = tn;
         cur = nxt;
-        lds_barrier(); // the stage has been read out; the next tile may overwrite it
+        t = tn;
+        lds_barrier(); // planar(cur) consumed: the next colour conversion may overwrite it
     }
+    lds_barrier();
+    phase_store<MODE>(ctx_of(a, prev.img), prev.tx, prev.ty, tid, lds);
 }
 
 // resident workgroups per CU, per mode (queried once per process)

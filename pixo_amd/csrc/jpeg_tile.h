@@ -12,8 +12,7 @@
 //   phase B  (one lane per 8x8 block)          LDS rows -> f32 on the fly, f32 AAN DCT rows
 //            then columns entirely in registers (no transposes), quantise (reciprocal fast
 //            path proven equal to the IEEE divide, exact divide fallback), pack to i16,
-//            swizzled 16-B chunks into the LDS stage.  A wavefront's stage region is the
-//            region its own planar samples lived in, so no barrier separates read and write.
+//            swizzled 16-B chunks into the LDS stage (disjoint from the planar samples).
 //   --- barrier ---
 //   phase C  (all lanes)                       LDS stage -> global, 16 B per lane, fully
 //            coalesced, in the reference's YCbCrCoefficients layout.
@@ -48,6 +47,7 @@
 #define PIXO_DEV static inline
 #define PIXO_SCHED_FENCE() ((void)0)
 #define PIXO_PIN(x) ((void)0)
+#define PIXO_CONST_AS
 #else
 #define PIXO_DEV __device__ __forceinline__
 // Stops the machine scheduler from interleaving independent 1-D transforms (which keeps the
@@ -56,6 +56,11 @@
 // Materialises a value here: stops LLVM from sinking the column pass into the quantiser's
 // basic blocks (which kept every column's butterflies alive across them).
 #define PIXO_PIN(x) asm volatile("" : "+v"(x))
+// The quantiser tables are read through the constant address space so that the compiler may
+// use scalar (SMEM) loads.  Inside the persistent loop a plain global pointer is "clobbered"
+// by the kernel's own stores as far as alias analysis knows, and becomes VECTOR loads — whose
+// vmcnt wait is in-order and therefore also waits for the next tile's prefetch: no overlap.
+#define PIXO_CONST_AS __attribute__((address_space(4)))
 #endif
 
 #pragma clang fp contract(off)
@@ -66,7 +71,8 @@ enum Mode { M420 = 0, M444 = 1, MGRAY = 2 };
 
 constexpr int kThreads = 256;
 constexpr int kTileW = 512;     // pixels per tile row
-constexpr int kRegion = 8192;   // LDS bytes owned by one wavefront: 64 blocks x 128 B of stage
+constexpr int kRegion = 8192;   // LDS bytes of stage per wavefront (64 blocks x 128 B); also the
+                                // stride between the planar areas read by different wavefronts
 constexpr int kPitch = 528;     // planar row pitch, full-width planes (4:4:4, gray)
 constexpr int kPitchHalf = 272; // planar row pitch, 256-px half planes (4:2:0 luminance);
                                 // 8*272 % 256 == 128 puts the bottom Y blocks of an MCU on the
@@ -79,8 +85,10 @@ constexpr int kPitchHalf = 272; // planar row pitch, 256-px half planes (4:2:0 l
 //             (4x the sample; a power-of-two scale commutes with every f32 rounding)
 constexpr int kQtFloats = 320;
 
-// LDS map (bytes).  Stage block b lives at [128 b, 128 b + 128); wavefront w owns blocks
-// [64 w, 64 w + 64) = region [kRegion w, kRegion (w+1)) and its planar inputs sit inside it.
+// LDS map (bytes): [0, planar) planar samples of the tile being transformed, then the stage
+// of quantised blocks (block b at stage + [128 b, 128 b + 128)).  Planar and stage do not
+// overlap, so the stage of tile i-1 can be written out to HBM while tile i's samples are
+// already in LDS (see the pipeline in jpeg_kernels.hip).  Planar areas, per wavefront w:
 //   4:2:0  tile 512x16 px = 32 MCUs = 192 blocks
 //          wave 0/1: luminance of MCUs 0-15 / 16-31 — half plane 16 rows x 272 B at region 0/1
 //          wave 2  : 32 Cb + 32 Cr blocks — 2x2 sums as u16, 8 rows x 512 B each, at
@@ -88,9 +96,9 @@ constexpr int kQtFloats = 320;
 //   4:4:4  tile 512x8 px = 64 block columns x {Y,Cb,Cr}: wave c reads plane c (8 rows x 528 B)
 //   gray   tile 512x32 px = 4 block rows: wave w reads block row w (8 rows x 528 B)
 template <int MODE> struct Geo;
-template <> struct Geo<M420> { static constexpr int tile_h = 16, units_x = 32, bpp = 3, in_regs = 24, lds = 3 * kRegion; };
-template <> struct Geo<M444> { static constexpr int tile_h = 8, units_x = 64, bpp = 3, in_regs = 12, lds = 3 * kRegion; };
-template <> struct Geo<MGRAY> { static constexpr int tile_h = 32, units_x = 64, bpp = 1, in_regs = 16, lds = 4 * kRegion; };
+template <> struct Geo<M420> { static constexpr int tile_h = 16, units_x = 32, bpp = 3, in_regs = 24, planar = 3 * kRegion, lds = planar + 192 * 128; };
+template <> struct Geo<M444> { static constexpr int tile_h = 8, units_x = 64, bpp = 3, in_regs = 12, planar = 3 * kRegion, lds = planar + 192 * 128; };
+template <> struct Geo<MGRAY> { static constexpr int tile_h = 32, units_x = 64, bpp = 1, in_regs = 16, planar = 4 * kRegion, lds = planar + 256 * 128; };
 
 // Per-image launch context (uniform across the workgroup).
 struct TileCtx {
@@ -129,6 +137,9 @@ PIXO_DEV uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
     return __builtin_amdgcn_perm(hi, lo, sel);
 #endif
 }
+
+typedef PIXO_CONST_AS const float *qtab_t;
+PIXO_DEV qtab_t as_qtab(const float *p) { return (qtab_t)(uintptr_t)p; }
 
 PIXO_DEV int uniform_i32(int v)
 {
@@ -224,12 +235,14 @@ PIXO_DEV uint32_t gather_row4_gray(const uint8_t *px, uint32_t W, uint32_t H, ui
     return d;
 }
 
-// INTERIOR: the whole tile lies inside the image and rows are dword aligned, so every
-// lane takes the 12-byte vector load with no per-item test.
-template <bool INTERIOR>
+// In-bounds items of dword-aligned images take one 12-byte vector load; everything else the
+// clamped byte gather.  (A per-tile "interior" specialisation of this function was tried and
+// dropped: with the loader inlined both before and inside the persistent loop, hipcc 7.2
+// produced wrong pixels for workgroups whose first tile was a bottom-edge tile; the per-item
+// test costs two compares and a branch per 8 pixels.)
 PIXO_DEV void load_row4_rgb(const TileCtx &c, uint32_t x0, uint32_t y, uint32_t *d)
 {
-    if (INTERIOR || (c.fast && x0 + 4 <= c.W && y < c.H)) {
+    if (c.fast && x0 + 4 <= c.W && y < c.H) {
         const uint32_t *q = (const uint32_t *)(c.px + ((size_t)y * c.W + x0) * 3);
         d[0] = q[0]; d[1] = q[1]; d[2] = q[2];
     } else {
@@ -243,50 +256,38 @@ template <int MODE> struct Lane {
     uint32_t in[Geo<MODE>::in_regs];
 };
 
-template <int MODE> PIXO_DEV bool tile_is_interior(const TileCtx &c, uint32_t tile_x, uint32_t tile_y)
-{
-    return c.fast && (tile_x + 1) * kTileW <= c.W && (tile_y + 1) * Geo<MODE>::tile_h <= c.H;
-}
-
 // ---- phase A.1: global loads (all issued before any use) ---------------------------
 // Work item = 4 horizontally adjacent pixels (x = 4g) of one row (or of a row pair for
 // 4:2:0, so that a lane owns whole 2x2 chroma quads).  Consecutive lanes read consecutive
 // 12-byte groups: a wavefront instruction covers 768 contiguous bytes of one image row.
-template <int MODE, bool INTERIOR>
-PIXO_DEV void phase_load(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int tid, Lane<MODE> &L)
+template <int MODE>
+PIXO_DEV void load_tile(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int tid, Lane<MODE> &L)
 {
     const uint32_t tx0 = tile_x * kTileW, ty0 = tile_y * Geo<MODE>::tile_h;
     if (MODE == M420) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             int item = k * kThreads + tid, g = item & 127, p = item >> 7;
-            load_row4_rgb<INTERIOR>(c, tx0 + 4 * g, ty0 + 2 * p, &L.in[k * 6]);
-            load_row4_rgb<INTERIOR>(c, tx0 + 4 * g, ty0 + 2 * p + 1, &L.in[k * 6 + 3]);
+            load_row4_rgb(c, tx0 + 4 * g, ty0 + 2 * p, &L.in[k * 6]);
+            load_row4_rgb(c, tx0 + 4 * g, ty0 + 2 * p + 1, &L.in[k * 6 + 3]);
         }
     } else if (MODE == M444) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             int item = k * kThreads + tid, g = item & 127, r = item >> 7;
-            load_row4_rgb<INTERIOR>(c, tx0 + 4 * g, ty0 + r, &L.in[k * 3]);
+            load_row4_rgb(c, tx0 + 4 * g, ty0 + r, &L.in[k * 3]);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             int item = k * kThreads + tid, g = item & 127, r = item >> 7;
             uint32_t x0 = tx0 + 4 * g, y = ty0 + r;
-            if (INTERIOR || (c.fast && x0 + 4 <= c.W && y < c.H))
+            if (c.fast && x0 + 4 <= c.W && y < c.H)
                 L.in[k] = *(const uint32_t *)(c.px + (size_t)y * c.W + x0);
             else
                 L.in[k] = gather_row4_gray(c.px, c.W, c.H, x0, y);
         }
     }
-}
-
-template <int MODE>
-PIXO_DEV void load_tile(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int tid, Lane<MODE> &L)
-{
-    if (tile_is_interior<MODE>(c, tile_x, tile_y)) phase_load<MODE, true>(c, tile_x, tile_y, tid, L);
-    else phase_load<MODE, false>(c, tile_x, tile_y, tid, L);
 }
 
 // ---- phase A.2: colour + subsample -> planar LDS -----------------------------------
@@ -430,7 +431,7 @@ PIXO_DEV void aan8_biased(float dc_shift, float &d0, float &d1, float &d2, float
 // fast path's rcp already contains it (exact power of two).
 constexpr float kRoundMagic = 12582912.0f; // 1.5 * 2^23
 
-PIXO_DEV void quant_row8(const float *x, const float *rcp, const float *q, float scale, uint32_t out[4])
+PIXO_DEV void quant_row8(const float *x, const float *rcp, qtab_t q, float scale, uint32_t out[4])
 {
     float s[8];
     uint32_t acc = 0x80000000u;
@@ -482,29 +483,51 @@ PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v
             u32x2 w = *(const u32x2 *)(src + r * pitch);
             row_from_bytes(w.x, w.y, &v[r * 8]);
         }
+#ifndef PIXO_ABL_NOROWS // (timing experiments only)
         aan8_biased(dc_shift, v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4],
                     v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+#endif
         if (r & 1) PIXO_SCHED_FENCE();
     }
 }
 
-PIXO_DEV void block_cols_quant(float *v, const float *rcp, const float *q, float scale, int b, uint8_t *lds)
+PIXO_DEV void block_cols_quant(float *v, qtab_t rcp, qtab_t q, float scale, int b, uint8_t *lds)
 {
 #pragma unroll
     for (int c = 0; c < 8; c++) {
+#ifndef PIXO_ABL_NOCOLS // (timing experiments only)
         aan8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+#endif
         if (c & 1) PIXO_SCHED_FENCE();
     }
 #pragma unroll
     for (int i = 0; i < 64; i++) PIXO_PIN(v[i]);
+    // The reciprocals are wave-uniform scalar (SMEM) loads.  Fetch each row's eight one row
+    // ahead of its use so their ~200-cycle latency hides under the previous row's arithmetic
+    // (left to itself the compiler issues each s_load right before its s_waitcnt).
+    float rc[8], rn[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) rc[c] = rcp[c];
+    PIXO_SCHED_FENCE();
 #pragma unroll
     for (int u = 0; u < 8; u++) {
+        if (u < 7) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) rn[c] = rcp[(u + 1) * 8 + c];
+            PIXO_SCHED_FENCE();
+        }
         u32x4 o;
         uint32_t w[4];
-        quant_row8(&v[u * 8], rcp + u * 8, q + u * 8, scale, w);
+#ifndef PIXO_ABL_NOQUANT // (timing experiments only)
+        quant_row8(&v[u * 8], rc, q + u * 8, scale, w);
+#else
+        for (int c = 0; c < 4; c++) w[c] = fbits(v[u * 8 + 2 * c] + rc[c]) ^ fbits(v[u * 8 + 2 * c + 1]);
+#endif
         o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
         *(u32x4 *)(lds + stage_addr(b, u)) = o;
         PIXO_SCHED_FENCE();
+#pragma unroll
+        for (int c = 0; c < 8; c++) rc[c] = rn[c];
     }
 }
 
@@ -542,12 +565,8 @@ template <int MODE> PIXO_DEV BlockDesc block_desc(int tid, const uint8_t *lds)
     return d;
 }
 
-// Phase B is two steps per wavefront, in program order and WITHOUT a barrier between them:
-// (1) every lane reads its 8 planar rows from the wavefront's region and runs the row pass;
-// (2) column pass, quantise, write the stage into the same region.  Lanes of a wavefront
-// execute in lockstep, so all reads of step 1 precede all writes of step 2; other
-// wavefronts never touch this region during phase B.  (tests/emu runs the two steps as
-// separate lane loops per wavefront to model exactly this ordering.)
+// Phase B in two steps (rows: LDS planar -> registers; columns + quantise -> LDS stage).
+// Planar and stage are disjoint, so neither step needs a barrier against other wavefronts.
 template <int MODE> PIXO_DEV bool phase_rows(int tid, const uint8_t *lds, float *v)
 {
     const BlockDesc d = block_desc<MODE>(tid, lds);
@@ -562,7 +581,9 @@ template <int MODE> PIXO_DEV void phase_cols_quant(int tid, const float *qt, flo
     const BlockDesc d = block_desc<MODE>(tid, lds);
     if (!d.active) return;
     const int wave = uniform_i32(tid >> 6), lane = tid & 63;
-    block_cols_quant(v, qt + d.rcp_off, qt + d.q_off, d.scale, wave * 64 + lane, lds);
+    const qtab_t tab = as_qtab(qt);
+    block_cols_quant(v, tab + uniform_i32(d.rcp_off), tab + uniform_i32(d.q_off), d.scale, wave * 64 + lane,
+                     lds + Geo<MODE>::planar);
 }
 
 template <int MODE> PIXO_DEV void phase_dct_quant(int tid, const float *qt, uint8_t *lds)
@@ -577,6 +598,7 @@ PIXO_DEV void phase_store(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, in
                           const uint8_t *lds)
 {
     typedef Geo<MODE> G;
+    lds += G::planar;                        // the stage follows the planar samples
     const uint32_t u0 = tile_x * G::units_x; // first MCU / block column of the tile
     const uint32_t nvalid = c.units_x - u0 < (uint32_t)G::units_x ? c.units_x - u0 : G::units_x;
     if (MODE == M420) {

@@ -17,12 +17,13 @@ static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long
 {
     std::vector<Lane<MODE>> lanes(kThreads);
     std::vector<float> v((size_t)kThreads * 64);
-    alignas(16) static uint8_t lds[64 * 1024];
+    alignas(16) static uint8_t lds[Geo<MODE>::lds];
     bool active[kThreads];
     for (uint32_t ty = 0; ty < tiles_y; ty++)
         for (uint32_t tx = 0; tx < tiles_x; tx++) {
-            if (stats) stats[tile_is_interior<MODE>(c, tx, ty) ? 0 : 1]++;
+            if (stats) stats[(c.fast && (tx + 1) * kTileW <= c.W && (ty + 1) * Geo<MODE>::tile_h <= c.H) ? 0 : 1]++;
             memset(lds, 0xA5, sizeof lds); // nothing may rely on LDS contents of a previous tile
+            static_assert(Geo<MODE>::lds <= 160 * 1024 / (MODE == MGRAY ? 2 : 3), "workgroups per CU by LDS");
             // phase A (then barrier)
             for (int t = 0; t < kThreads; t++) {
                 load_tile<MODE>(c, tx, ty, t, lanes[t]);
@@ -78,7 +79,7 @@ extern "C" long emu_quant_mismatches(const float *x, long n, int qlo, int qhi)
         for (long i = 0; i + 8 <= n; i += 8) {
             uint32_t out[4];
             for (int k = 0; k < 8; k++) xx[k] = x[i + k];
-            quant_row8(xx, rr, qq, 1.0f, out);
+            quant_row8(xx, rr, as_qtab(qq), 1.0f, out);
             for (int k = 0; k < 8; k++) {
                 int16_t got = (int16_t)(out[k >> 1] >> (16 * (k & 1)));
                 float want = roundf(xx[k] / fq);

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Times every pixo_amd/ab_*.so plus the default library with bench.py (kernel-only line).
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+for lib in "" pixo_amd/ab_*.so; do
+  name=${lib:-default}
+  for rep in 1 2; do
+    PIXO_BENCH_ABLATION=${lib:+1} PIXO_HIP_LIB=${lib:+$PWD/$lib} python bench.py --steps 200 --warmup 20 --no-cpu-baseline ${AB_ARGS:-} 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline()); r = d['roofline']
+print('%-28s value %9.0f Mpx/s  kernel %7.2f us  frac %.3f' % ('$name', d['value'], r['kernel_us_avg'], r['frac']))"
+  done
+done

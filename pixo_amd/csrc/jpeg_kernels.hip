@@ -3,11 +3,13 @@
 // The per-tile body lives in jpeg_tile.h (shared with the CPU emulation harness in
 // tests/emu).  This file adds the persistent __global__ loop, the tile -> image mapping
 // and the host-side launch function.  Written for CDNA4 only: 64-lane wavefronts,
-// 256-thread workgroups (4 waves, one per SIMD), 24-32 KiB LDS per workgroup, a grid of
-// (resident workgroups per CU) x 256 CUs that walks the tiles with a stride, each
-// workgroup prefetching its next tile's pixels into registers while it transforms the
-// current one, so HBM reads, VALU work and HBM writes of neighbouring tiles overlap.
+// 256-thread workgroups of four role-specialised wavefronts (one producer, three consumers),
+// ~50-58 KiB LDS per workgroup (two resident per CU = two busy wavefronts per SIMD), a grid
+// of (resident workgroups per CU) x 256 CUs that walks the tiles with a stride.
 #include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
 
 #include "jpeg_kernels.hpp"
 #include "jpeg_tile.h"
@@ -25,6 +27,7 @@ struct KArgs {
     size_t px_stride; // bytes between consecutive images of a batch
     size_t y_stride;  // i16 elements between images
     size_t c_stride;
+    unsigned long long *dbg; // PIXO_TIMING builds only: per-workgroup cycle sums
 };
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, which would
@@ -66,70 +69,135 @@ __device__ __forceinline__ TileCtx ctx_of(const KArgs &a, uint32_t img)
     return c;
 }
 
-// Software pipeline, one call site per phase.  Iteration i of a workgroup (tile i = its i-th
-// tile; planar and stage are disjoint LDS areas):
-//   1. colour-convert tile i (registers -> LDS planar)       first use of the loaded pixels
-//   2. write tile i-1's stage out to HBM, THEN issue tile i+1's global loads
-//   3. transform tile i (LDS planar -> LDS stage)             pure VALU/LDS, no vmcnt wait
-// Every VMEM operation of an iteration is issued in step 2 and not waited for until step 1 of
-// the next iteration, so stores and loads drain under the whole of step 3.  (vmcnt retires in
-// order: with the loads older than the stores, a wait for the loads would also be a wait for
-// the stores just issued — the previous schedule serialised store drain and VALU work.)
-template <int MODE>
-__global__ __launch_bounds__(kThreads) void jpeg_coeffs_kernel(const KArgs a)
+// Role-specialised persistent workgroup.  Tiles t = blockIdx.x + i * gridDim.x, i = 0..n-1.
+//   producer (wave 3):   for i: fill planar[i & 1] with tile i; barrier_i
+//   consumers (0..2):    for i: barrier_i; transform + store tile i from planar[i & 1]
+// Both sides execute exactly n barriers.  The producer refills planar[i & 1] (tile i + 2) only
+// after barrier_{i+1}, which the consumers reach only after they are done with tile i, so one
+// barrier per tile is the whole protocol.  While the consumers work on tile i the producer
+// converts tile i + 1 and has tile i + 2's loads in flight: each item's registers are reloaded
+// for the next tile as soon as the item has been converted, so HBM reads are spread evenly
+// over the iteration and never waited for at the point of issue.
+template <int MODE, bool FAST>
+__global__ __launch_bounds__(kThreads, 2) void jpeg_coeffs_kernel(const KArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[Geo<MODE>::lds];
-    const int tid = threadIdx.x;
+    typedef Geo<MODE> G;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[lds_bytes<MODE>()];
+    uint8_t *const stage = lds + 2 * G::planar;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint32_t total = a.tiles_x * a.tiles_y * a.batch;
-    uint32_t t = blockIdx.x;
-    if (t >= total) return;
-    Lane<MODE> L;
-    TileId prev = locate(a, t), cur = prev, nxt = prev;
-    load_tile<MODE>(ctx_of(a, cur.img), cur.tx, cur.ty, tid, L);
-    bool have_prev = false;
-    for (;;) {
-#if !defined(PIXO_ABLATE) || PIXO_ABLATE < 2 // (timing experiments: >=2 drops the colour conversion)
-        phase_color<MODE>(tid, L, lds);
+    const uint32_t first = blockIdx.x, stride = gridDim.x;
+    if (first >= total) return;
+
+    if (wave == 3) {
+        // Two register sets: while set X (tile t, loaded one iteration ago) is converted, set Y
+        // receives tile t + stride.  The explicit vmcnt(0) sits BEFORE the new loads are issued,
+        // so it only ever waits for loads that have had a whole iteration to land; the loads are
+        // unconditional (the last iteration re-reads its own tile) so that no branch joins —
+        // and therefore no compiler-inserted wait — follow them.
+        uint32_t ra[G::items * G::item_regs], rb[G::items * G::item_regs];
+        TileId id = locate(a, first);
+        TileCtx c = ctx_of(a, id.img);
+#pragma unroll
+        for (int k = 0; k < G::items; k++) producer_load_item<MODE, FAST>(c, id.tx, id.ty, k, lane, &ra[k * G::item_regs]);
+        uint32_t buf = 0, t = first;
+#ifdef PIXO_TIMING
+        unsigned long long tm[5] = {0, 0, 0, 0, 0}, acc[4] = {0, 0, 0, 0};
+#define PIXO_T(i) tm[i] = __builtin_readcyclecounter(); if (i > 0) acc[i - 1] += tm[i] - tm[i - 1];
 #else
-        for (int i = 0; i < Geo<MODE>::in_regs; i++) asm volatile("" ::"v"(L.in[i]));
+#define PIXO_T(i)
 #endif
-        lds_barrier(); // planar(cur) complete; stage(prev) was completed before the last barrier
-        if (have_prev) phase_store<MODE>(ctx_of(a, prev.img), prev.tx, prev.ty, tid, lds);
-        const uint32_t tn = t + gridDim.x;
-        const bool more = tn < total;
-        if (more) {
-            nxt = locate(a, tn);
-            load_tile<MODE>(ctx_of(a, nxt.img), nxt.tx, nxt.ty, tid, L);
+        for (;;) {
+#define PIXO_PRODUCER_HALF(X, Y)                                                                   \
+            {                                                                                      \
+                const uint32_t tn = t + stride;                                                    \
+                const bool more = tn < total;                                                      \
+                const TileCtx cc = c;                                                              \
+                const uint32_t ctx = id.tx;                                                        \
+                id = locate(a, more ? tn : t);                                                     \
+                c = ctx_of(a, id.img);                                                             \
+                PIXO_T(0) __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): set X has landed */     \
+                PIXO_T(1) _Pragma("unroll") for (int k = 0; k < G::items; k++)                     \
+                    producer_load_item<MODE, FAST>(c, id.tx, id.ty, k, lane, &Y[k * G::item_regs]); \
+                uint8_t *planar = lds + buf * G::planar;                                           \
+                PIXO_T(2) _Pragma("unroll") for (int k = 0; k < G::items; k++) {                   \
+                    PIXO_PRODUCER_CONVERT(X)                                                       \
+                }                                                                                  \
+                buf ^= 1;                                                                          \
+                PIXO_T(3) lds_barrier(); /* planar buffer of tile t handed over */                 \
+                PIXO_T(4)                                                                          \
+                if (!more) break;                                                                  \
+                t = tn;                                                                            \
+            }
+#if !defined(PIXO_ABLATE) || PIXO_ABLATE < 2 // (timing experiments: >=2 drops the colour conversion)
+#define PIXO_PRODUCER_CONVERT(X)                                                  \
+    producer_fix_item<MODE, FAST>(cc, ctx, k, lane, &X[k * G::item_regs]);        \
+    producer_color_item<MODE>(k, lane, &X[k * G::item_regs], planar);          \
+    __builtin_amdgcn_sched_barrier(0); /* one item at a time: ~40 temporaries, not 16 x 40 */
+#else
+#define PIXO_PRODUCER_CONVERT(X) \
+    for (int i = 0; i < G::item_regs; i++) asm volatile("" ::"v"(X[k * G::item_regs + i]));
+#endif
+            PIXO_PRODUCER_HALF(ra, rb)
+            PIXO_PRODUCER_HALF(rb, ra)
+#undef PIXO_PRODUCER_HALF
+#undef PIXO_PRODUCER_CONVERT
         }
-        lds_barrier(); // stage(prev) read out: phase B may overwrite it
-#if !defined(PIXO_ABLATE) || PIXO_ABLATE < 1 // (>=1 drops the transform)
-        phase_dct_quant<MODE>(tid, a.qt, lds);
+#ifdef PIXO_TIMING
+        if (lane == 0 && a.dbg) for (int i = 0; i < 4; i++) a.dbg[blockIdx.x * 16 + i] = acc[i];
 #endif
-        prev = cur;
-        have_prev = true;
-        if (!more) break;
-        cur = nxt;
-        t = tn;
-        lds_barrier(); // planar(cur) consumed: the next colour conversion may overwrite it
+    } else {
+        uint32_t buf = 0;
+#ifdef PIXO_TIMING
+        unsigned long long tm[5] = {0, 0, 0, 0, 0}, acc[4] = {0, 0, 0, 0};
+#endif
+        for (uint32_t t = first; t < total; t += stride) {
+            PIXO_T(0) lds_barrier(); // tile t's planar buffer is complete
+            PIXO_T(1) const TileId id = locate(a, t);
+            const uint8_t *planar = lds + buf * G::planar;
+            float v[64];
+#if !defined(PIXO_ABLATE) || PIXO_ABLATE < 1 // (>=1 drops the transform)
+            consumer_rows<MODE>(wave, lane, planar, v);
+            PIXO_T(2) consumer_cols_quant<MODE>(wave, lane, a.qt, v, stage);
+#endif
+            PIXO_T(3) consumer_store<MODE>(ctx_of(a, id.img), id.tx, id.ty, wave, lane, stage);
+            PIXO_T(4) buf ^= 1;
+        }
+#ifdef PIXO_TIMING
+        if (lane == 0 && a.dbg) for (int i = 0; i < 4; i++) a.dbg[blockIdx.x * 16 + 4 + wave * 4 + i] = acc[i];
+#endif
     }
-    lds_barrier();
-    phase_store<MODE>(ctx_of(a, prev.img), prev.tx, prev.ty, tid, lds);
 }
 
-// resident workgroups per CU, per mode (queried once per process)
-template <int MODE> static int blocks_per_cu()
+// Resident workgroups per CU, computed from the kernel's own resource usage: gfx950 has 160 KiB
+// of LDS and 512 VGPRs per lane per SIMD (allocation granule 8), and one wavefront of each
+// 4-wave workgroup lands on each SIMD.  (hipOccupancyMaxActiveBlocksPerMultiprocessor answers 1
+// for the 57 KiB-LDS kernels — it still budgets 64 KiB of LDS per CU — which would halve the
+// grid and leave every wavefront alone on its SIMD, at half the VALU issue rate.)
+template <int MODE, bool FAST> static int blocks_per_cu()
 {
     static int cached = 0;
     if (!cached) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, jpeg_coeffs_kernel<MODE>, kThreads, 0) != hipSuccess || n < 1)
-            n = 2;
-        cached = n > 8 ? 8 : n;
+        hipFuncAttributes attr;
+        int n = 1;
+        if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(jpeg_coeffs_kernel<MODE, FAST>)) == hipSuccess) {
+            const int regs = ((attr.numRegs > 0 ? attr.numRegs : 256) + 7) / 8 * 8;
+            const int by_vgpr = 512 / regs;
+            const int by_lds = (160 * 1024) / (attr.sharedSizeBytes > 0 ? (int)attr.sharedSizeBytes : lds_bytes<MODE>());
+            n = by_vgpr < by_lds ? by_vgpr : by_lds;
+            if (getenv("PIXO_HIP_DEBUG"))
+                fprintf(stderr, "pixo_hip: mode %d fast %d numRegs %d sharedSizeBytes %zu maxDyn %d -> %d workgroups/CU\n", MODE,
+                        (int)FAST, attr.numRegs, attr.sharedSizeBytes, attr.maxDynamicSharedSizeBytes, n);
+        } else if (getenv("PIXO_HIP_DEBUG")) {
+            fprintf(stderr, "pixo_hip: hipFuncGetAttributes failed\n");
+        }
+        if (const char *e = getenv("PIXO_HIP_BLOCKS_PER_CU")) n = atoi(e); // tuning experiments
+        cached = n < 1 ? 1 : (n > 8 ? 8 : n);
     }
     return cached;
 }
 
-template <int MODE> static hipError_t launch_mode(KArgs &a, hipStream_t s)
+template <int MODE, bool FAST> static hipError_t launch_mode(KArgs &a, hipStream_t s)
 {
     a.tiles_x = (a.units_x + Geo<MODE>::units_x - 1) / Geo<MODE>::units_x;
     a.tiles_y = (a.units_y * (MODE == M420 ? 16u : 8u) + Geo<MODE>::tile_h - 1) / Geo<MODE>::tile_h;
@@ -138,11 +206,11 @@ template <int MODE> static hipError_t launch_mode(KArgs &a, hipStream_t s)
     const uint32_t total = (uint32_t)total64;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const uint32_t resident = (uint32_t)blocks_per_cu<MODE>() * (uint32_t)cus;
+    const uint32_t resident = (uint32_t)blocks_per_cu<MODE, FAST>() * (uint32_t)cus;
     // equal number of tiles per workgroup: rounds = ceil(total / resident), grid = ceil(total / rounds)
     const uint32_t rounds = (total + resident - 1) / resident;
     const uint32_t grid = (total + rounds - 1) / rounds;
-    hipLaunchKernelGGL(jpeg_coeffs_kernel<MODE>, dim3(grid), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, FAST>), dim3(grid), dim3(kThreads), 0, s, a);
     return hipGetLastError();
 }
 
@@ -156,6 +224,10 @@ hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gra
     a.cb = static_cast<int16_t *>(d_cb);
     a.cr = static_cast<int16_t *>(d_cr);
     a.qt = d_qt;
+    a.dbg = nullptr;
+#ifdef PIXO_TIMING
+    if (const char *e = getenv("PIXO_DBG_PTR")) a.dbg = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0));
+#endif
     a.W = W; a.H = H; a.batch = batch;
     const uint32_t unit = (!gray && s420) ? 16 : 8;
     a.units_x = (W + unit - 1) / unit;
@@ -169,9 +241,11 @@ hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gra
     const size_t units = static_cast<size_t>(a.units_x) * a.units_y;
     a.y_stride = (unit == 16 ? 4 * units : units) * 64;
     a.c_stride = units * 64;
-    if (gray) return launch_mode<MGRAY>(a, stream);
-    if (s420) return launch_mode<M420>(a, stream);
-    return launch_mode<M444>(a, stream);
+    // FAST additionally needs at least one whole 4-pixel group per row (address clamp W - 4)
+    const bool fast = a.fast && W >= 4;
+    if (gray) return fast ? launch_mode<MGRAY, true>(a, stream) : launch_mode<MGRAY, false>(a, stream);
+    if (s420) return fast ? launch_mode<M420, true>(a, stream) : launch_mode<M420, false>(a, stream);
+    return fast ? launch_mode<M444, true>(a, stream) : launch_mode<M444, false>(a, stream);
 }
 
 } // namespace pixo_dev

@@ -1,22 +1,25 @@
 // jpeg_tile.h — the per-tile body of the fused JPEG coefficient kernel for gfx950.
 //
-// One 256-thread workgroup (4 wavefronts, one per SIMD) turns tiles of pixels into
-// quantised DCT blocks.  Per tile:
+// A 256-thread workgroup = 4 wavefronts with fixed roles (measured on MI355X,
+// tools/ubench/valu_ilp.hip: one wavefront can issue a VALU instruction only every ~5 cycles,
+// two wavefronts saturate a SIMD — so the design keeps two busy wavefronts per SIMD, from two
+// co-resident workgroups, instead of many that take turns):
 //
-//   phase A  (all 256 lanes, pixel-parallel)   global RGB8 -> registers (coalesced 12 B per
-//            lane = 4 px; issued one tile AHEAD by the persistent loop so HBM latency hides
-//            under the previous tile's DCT), integer BT.601 colour conversion with packed-u16
-//            VALU ops (2 px per instruction), 2x2 chroma box sums, planar u8/u16 samples
-//            into LDS — each wavefront's future blocks into that wavefront's own LDS region.
-//   --- barrier ---
-//   phase B  (one lane per 8x8 block)          LDS rows -> f32 on the fly, f32 AAN DCT rows
-//            then columns entirely in registers (no transposes), quantise (reciprocal fast
-//            path proven equal to the IEEE divide, exact divide fallback), pack to i16,
-//            swizzled 16-B chunks into the LDS stage (disjoint from the planar samples).
-//   --- barrier ---
-//   phase C  (all lanes)                       LDS stage -> global, 16 B per lane, fully
-//            coalesced, in the reference's YCbCrCoefficients layout.
-//   --- barrier ---
+//   producer (wave 3)   streams the NEXT tile: global RGB8 -> registers (12 B per lane = 4 px,
+//                       a whole tile of loads in flight), integer BT.601 colour conversion with
+//                       packed-u16 VALU ops (2 px per instruction), 2x2 chroma box sums, planar
+//                       u8/u16 samples into one of two LDS planar buffers.
+//   consumers (waves 0-2)  one lane per 8x8 block of the CURRENT tile: LDS rows -> f32 on the
+//                       fly, f32 AAN DCT rows then columns entirely in registers (no
+//                       transposes), quantise (reciprocal fast path proven equal to the IEEE
+//                       divide, exact divide fallback), pack to i16, swizzled 16-B chunks into
+//                       the wave's own LDS stage, read back linearly and stored to HBM 16 B per
+//                       lane, coalesced, in the reference's YCbCrCoefficients layout.
+//
+// One LDS-only barrier per tile hands a filled planar buffer to the consumers and an emptied
+// one back to the producer (double buffering).  HBM reads, colour conversion, DCT/quantise and
+// HBM writes of neighbouring tiles all overlap; no wavefront ever waits on another role's
+// memory traffic.
 //
 // Reference semantics reproduced bit-for-bit (leerob/pixo v0.4.1):
 //   colour           src/color.rs:60-77           (integer, 2^8-scaled, clamp)
@@ -71,12 +74,11 @@ enum Mode { M420 = 0, M444 = 1, MGRAY = 2 };
 
 constexpr int kThreads = 256;
 constexpr int kTileW = 512;     // pixels per tile row
-constexpr int kRegion = 8192;   // LDS bytes of stage per wavefront (64 blocks x 128 B); also the
-                                // stride between the planar areas read by different wavefronts
 constexpr int kPitch = 528;     // planar row pitch, full-width planes (4:4:4, gray)
 constexpr int kPitchHalf = 272; // planar row pitch, 256-px half planes (4:2:0 luminance);
                                 // 8*272 % 256 == 128 puts the bottom Y blocks of an MCU on the
                                 // other half of the 64 banks: ds_read_b64 conflict-free
+constexpr int kStageBytes = 192 * 128; // 3 consumer waves x 64 blocks x 128 B
 
 // Quantiser table block for one quality, resident in HBM, read with scalar loads:
 //   [0,64)    1/q luminance   [64,128)   1/q chrominance   (f32, correctly rounded)
@@ -85,20 +87,20 @@ constexpr int kPitchHalf = 272; // planar row pitch, 256-px half planes (4:2:0 l
 //             (4x the sample; a power-of-two scale commutes with every f32 rounding)
 constexpr int kQtFloats = 320;
 
-// LDS map (bytes): [0, planar) planar samples of the tile being transformed, then the stage
-// of quantised blocks (block b at stage + [128 b, 128 b + 128)).  Planar and stage do not
-// overlap, so the stage of tile i-1 can be written out to HBM while tile i's samples are
-// already in LDS (see the pipeline in jpeg_kernels.hip).  Planar areas, per wavefront w:
-//   4:2:0  tile 512x16 px = 32 MCUs = 192 blocks
-//          wave 0/1: luminance of MCUs 0-15 / 16-31 — half plane 16 rows x 272 B at region 0/1
-//          wave 2  : 32 Cb + 32 Cr blocks — 2x2 sums as u16, 8 rows x 512 B each, at
-//                    2*kRegion (Cb) and 2*kRegion + 4096 (Cr)
-//   4:4:4  tile 512x8 px = 64 block columns x {Y,Cb,Cr}: wave c reads plane c (8 rows x 528 B)
-//   gray   tile 512x32 px = 4 block rows: wave w reads block row w (8 rows x 528 B)
+// Tiles and planar layouts (bytes inside one planar buffer):
+//   4:2:0  512x16 px = 32 MCUs = 192 blocks.  Luminance as two 256-px half planes (16 rows x
+//          272 B) at 0 and 4352 — consumer 0 takes MCUs 0-15, consumer 1 MCUs 16-31; 2x2 chroma
+//          sums as u16, 8 rows x 512 B: Cb at 8704, Cr at 12800 — consumer 2 takes 32 Cb + 32 Cr.
+//   4:4:4  512x8 px = 64 block columns x {Y,Cb,Cr}: plane c (8 rows x 528 B) at 4224 c, consumer c.
+//   gray   512x24 px = 3 block rows x 64: block row w (8 rows x 528 B) at 4224 w, consumer w.
+// Producer work item k of a lane: 4 px at x = 4 g, g = 64 (k & 1) + lane, image row(s) k >> 1
+// (a row PAIR for 4:2:0 so that a lane owns whole chroma quads): consecutive lanes read
+// consecutive 12-byte groups, a wavefront instruction covers 768 contiguous bytes of a row.
 template <int MODE> struct Geo;
-template <> struct Geo<M420> { static constexpr int tile_h = 16, units_x = 32, bpp = 3, in_regs = 24, planar = 3 * kRegion, lds = planar + 192 * 128; };
-template <> struct Geo<M444> { static constexpr int tile_h = 8, units_x = 64, bpp = 3, in_regs = 12, planar = 3 * kRegion, lds = planar + 192 * 128; };
-template <> struct Geo<MGRAY> { static constexpr int tile_h = 32, units_x = 64, bpp = 1, in_regs = 16, planar = 4 * kRegion, lds = planar + 256 * 128; };
+template <> struct Geo<M420> { static constexpr int tile_h = 16, units_x = 32, bpp = 3, items = 16, item_regs = 6, planar = 16896; };
+template <> struct Geo<M444> { static constexpr int tile_h = 8, units_x = 64, bpp = 3, items = 16, item_regs = 3, planar = 12672; };
+template <> struct Geo<MGRAY> { static constexpr int tile_h = 24, units_x = 64, bpp = 1, items = 48, item_regs = 1, planar = 12672; };
+template <int MODE> constexpr int lds_bytes() { return 2 * Geo<MODE>::planar + kStageBytes; }
 
 // Per-image launch context (uniform across the workgroup).
 struct TileCtx {
@@ -235,102 +237,104 @@ PIXO_DEV uint32_t gather_row4_gray(const uint8_t *px, uint32_t W, uint32_t H, ui
     return d;
 }
 
-// In-bounds items of dword-aligned images take one 12-byte vector load; everything else the
-// clamped byte gather.  (A per-tile "interior" specialisation of this function was tried and
-// dropped: with the loader inlined both before and inside the persistent loop, hipcc 7.2
-// produced wrong pixels for workgroups whose first tile was a bottom-edge tile; the per-item
-// test costs two compares and a branch per 8 pixels.)
-PIXO_DEV void load_row4_rgb(const TileCtx &c, uint32_t x0, uint32_t y, uint32_t *d)
+// ---------------------------------------------------------------------------------
+// producer: one wavefront moves a whole tile from HBM to a planar LDS buffer
+// ---------------------------------------------------------------------------------
+// FAST images (every row dword aligned: base % 4 == 0 and W * bpp % 4 == 0, hence W % 4 == 0)
+// are read with ONE unconditional 12-byte (RGB) / 4-byte (gray) vector load per item-row and no
+// branch anywhere near a load: the address is clamped to the last group of the row and to the
+// last row, which IS the reference's edge replication for rows (jpeg/mod.rs:1579,1627); groups
+// lying wholly right of the image (W % 4 == 0: a group is never split) are rebuilt from the
+// clamped group's last pixel by fix_right_edge_*, a register-only step that only right-edge
+// tiles execute.  (Branches around the loads made hipcc wait for every load at its join point:
+// one outstanding load per wavefront, 4.6 TB/s at best.)  Other images take the byte gather.
+template <int MODE, bool FAST>
+PIXO_DEV void producer_load_item(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int k, int lane,
+                                 uint32_t *r)
 {
-    if (c.fast && x0 + 4 <= c.W && y < c.H) {
-        const uint32_t *q = (const uint32_t *)(c.px + ((size_t)y * c.W + x0) * 3);
-        d[0] = q[0]; d[1] = q[1]; d[2] = q[2];
-    } else {
-        u32x3 t = gather_row4_rgb(c.px, c.W, c.H, x0, y);
-        d[0] = t.a; d[1] = t.b; d[2] = t.c;
-    }
-}
-
-// The only per-lane state that crosses barriers: one tile's pixels in flight.
-template <int MODE> struct Lane {
-    uint32_t in[Geo<MODE>::in_regs];
-};
-
-// ---- phase A.1: global loads (all issued before any use) ---------------------------
-// Work item = 4 horizontally adjacent pixels (x = 4g) of one row (or of a row pair for
-// 4:2:0, so that a lane owns whole 2x2 chroma quads).  Consecutive lanes read consecutive
-// 12-byte groups: a wavefront instruction covers 768 contiguous bytes of one image row.
-template <int MODE>
-PIXO_DEV void load_tile(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int tid, Lane<MODE> &L)
-{
-    const uint32_t tx0 = tile_x * kTileW, ty0 = tile_y * Geo<MODE>::tile_h;
-    if (MODE == M420) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int item = k * kThreads + tid, g = item & 127, p = item >> 7;
-            load_row4_rgb(c, tx0 + 4 * g, ty0 + 2 * p, &L.in[k * 6]);
-            load_row4_rgb(c, tx0 + 4 * g, ty0 + 2 * p + 1, &L.in[k * 6 + 3]);
-        }
-    } else if (MODE == M444) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int item = k * kThreads + tid, g = item & 127, r = item >> 7;
-            load_row4_rgb(c, tx0 + 4 * g, ty0 + r, &L.in[k * 3]);
+    const uint32_t x0 = tile_x * kTileW + 4 * ((k & 1) * 64 + lane);
+    const uint32_t y0 = tile_y * Geo<MODE>::tile_h + (MODE == M420 ? 2 : 1) * (k >> 1);
+    if (FAST) {
+        const uint32_t xc = x0 < c.W ? x0 : c.W - 4;
+        const uint32_t ya = y0 < c.H ? y0 : c.H - 1;
+        if (MODE == MGRAY) {
+            r[0] = *(const uint32_t *)(c.px + (size_t)ya * c.W + xc);
+        } else {
+            const uint32_t *q = (const uint32_t *)(c.px + ((size_t)ya * c.W + xc) * 3);
+            r[0] = q[0]; r[1] = q[1]; r[2] = q[2];
+            if (MODE == M420) {
+                const uint32_t yb = y0 + 1 < c.H ? y0 + 1 : c.H - 1;
+                const uint32_t *q2 = (const uint32_t *)(c.px + ((size_t)yb * c.W + xc) * 3);
+                r[3] = q2[0]; r[4] = q2[1]; r[5] = q2[2];
+            }
         }
     } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            int item = k * kThreads + tid, g = item & 127, r = item >> 7;
-            uint32_t x0 = tx0 + 4 * g, y = ty0 + r;
-            if (c.fast && x0 + 4 <= c.W && y < c.H)
-                L.in[k] = *(const uint32_t *)(c.px + (size_t)y * c.W + x0);
-            else
-                L.in[k] = gather_row4_gray(c.px, c.W, c.H, x0, y);
+        if (MODE == MGRAY) {
+            r[0] = gather_row4_gray(c.px, c.W, c.H, x0, y0);
+        } else {
+            u32x3 t = gather_row4_rgb(c.px, c.W, c.H, x0, y0);
+            r[0] = t.a; r[1] = t.b; r[2] = t.c;
+            if (MODE == M420) {
+                t = gather_row4_rgb(c.px, c.W, c.H, x0, y0 + 1);
+                r[3] = t.a; r[4] = t.b; r[5] = t.c;
+            }
         }
     }
 }
 
-// ---- phase A.2: colour + subsample -> planar LDS -----------------------------------
-template <int MODE> PIXO_DEV void phase_color(int tid, const Lane<MODE> &L, uint8_t *lds)
+// Right-edge fix-up for FAST loads: a group at x0 >= W becomes four copies of pixel W-1, i.e. of
+// the clamped group's last pixel (bytes 9..11 of its 12).
+PIXO_DEV void fix_right_edge_rgb(bool outside, uint32_t *d)
 {
-    if (MODE == M420) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int item = k * kThreads + tid, g = item & 127, p = item >> 7;
-            Row4 a = color_row4(L.in[k * 6], L.in[k * 6 + 1], L.in[k * 6 + 2]);
-            Row4 b = color_row4(L.in[k * 6 + 3], L.in[k * 6 + 4], L.in[k * 6 + 5]);
-            uint8_t *yp = lds + (g >> 6) * kRegion + (2 * p) * kPitchHalf + 4 * (g & 63);
-            *(uint32_t *)yp = a.y4;
-            *(uint32_t *)(yp + kPitchHalf) = b.y4;
-            // 2x2 box sums (jpeg/mod.rs:1641-1646): vertical then horizontal, u16 exact
-            uint32_t cb01 = bits(a.cb01 + b.cb01), cb23 = bits(a.cb23 + b.cb23);
-            uint32_t cr01 = bits(a.cr01 + b.cr01), cr23 = bits(a.cr23 + b.cr23);
-            u16x2 cbs = pk(perm(cb23, cb01, 0x05040100u)) + pk(perm(cb23, cb01, 0x07060302u));
-            u16x2 crs = pk(perm(cr23, cr01, 0x05040100u)) + pk(perm(cr23, cr01, 0x07060302u));
-            *(uint32_t *)(lds + 2 * kRegion + p * 512 + 4 * g) = bits(cbs);
-            *(uint32_t *)(lds + 2 * kRegion + 4096 + p * 512 + 4 * g) = bits(crs);
-        }
-    } else if (MODE == M444) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int item = k * kThreads + tid, g = item & 127, r = item >> 7;
-            Row4 a = color_row4(L.in[k * 3], L.in[k * 3 + 1], L.in[k * 3 + 2]);
-            uint8_t *p = lds + r * kPitch + 4 * g;
-            *(uint32_t *)p = a.y4;
-            *(uint32_t *)(p + kRegion) = perm(bits(a.cb23), bits(a.cb01), 0x06040200u);
-            *(uint32_t *)(p + 2 * kRegion) = perm(bits(a.cr23), bits(a.cr01), 0x06040200u);
-        }
+    const uint32_t a = perm(d[2], d[2], 0x01030201u); // R G B R
+    const uint32_t b = perm(d[2], d[2], 0x02010302u); // G B R G
+    const uint32_t e = perm(d[2], d[2], 0x03020103u); // B R G B
+    d[0] = outside ? a : d[0]; d[1] = outside ? b : d[1]; d[2] = outside ? e : d[2];
+}
+
+template <int MODE, bool FAST>
+PIXO_DEV void producer_fix_item(const TileCtx &c, uint32_t tile_x, int k, int lane, uint32_t *r)
+{
+    if (!FAST || (tile_x + 1) * kTileW <= c.W) return; // wave-uniform: only right-edge tiles
+    const bool outside = tile_x * kTileW + 4 * ((k & 1) * 64 + lane) >= c.W;
+    if (MODE == MGRAY) {
+        r[0] = outside ? perm(r[0], r[0], 0x03030303u) : r[0];
     } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            int item = k * kThreads + tid, g = item & 127, r = item >> 7;
-            *(uint32_t *)(lds + (r >> 3) * kRegion + (r & 7) * kPitch + 4 * g) = L.in[k];
-        }
+        fix_right_edge_rgb(outside, r);
+        if (MODE == M420) fix_right_edge_rgb(outside, r + 3);
+    }
+}
+
+template <int MODE> PIXO_DEV void producer_color_item(int k, int lane, const uint32_t *r, uint8_t *planar)
+{
+    const int h = k & 1, g = h * 64 + lane, row = k >> 1;
+    if (MODE == M420) {
+        Row4 a = color_row4(r[0], r[1], r[2]);
+        PIXO_SCHED_FENCE(); // one row at a time: the producer carries two tiles of pixels in registers
+        Row4 b = color_row4(r[3], r[4], r[5]);
+        uint8_t *yp = planar + h * 4352 + (2 * row) * kPitchHalf + 4 * lane;
+        *(uint32_t *)yp = a.y4;
+        *(uint32_t *)(yp + kPitchHalf) = b.y4;
+        // 2x2 box sums (jpeg/mod.rs:1641-1646): vertical then horizontal, u16 exact
+        uint32_t cb01 = bits(a.cb01 + b.cb01), cb23 = bits(a.cb23 + b.cb23);
+        uint32_t cr01 = bits(a.cr01 + b.cr01), cr23 = bits(a.cr23 + b.cr23);
+        u16x2 cbs = pk(perm(cb23, cb01, 0x05040100u)) + pk(perm(cb23, cb01, 0x07060302u));
+        u16x2 crs = pk(perm(cr23, cr01, 0x05040100u)) + pk(perm(cr23, cr01, 0x07060302u));
+        *(uint32_t *)(planar + 8704 + row * 512 + 4 * g) = bits(cbs);
+        *(uint32_t *)(planar + 12800 + row * 512 + 4 * g) = bits(crs);
+    } else if (MODE == M444) {
+        Row4 a = color_row4(r[0], r[1], r[2]);
+        uint8_t *p = planar + row * kPitch + 4 * g;
+        *(uint32_t *)p = a.y4;
+        *(uint32_t *)(p + 4224) = perm(bits(a.cb23), bits(a.cb01), 0x06040200u);
+        *(uint32_t *)(p + 8448) = perm(bits(a.cr23), bits(a.cr01), 0x06040200u);
+    } else {
+        *(uint32_t *)(planar + (row >> 3) * 4224 + (row & 7) * kPitch + 4 * g) = r[0];
     }
 }
 
 // ---------------------------------------------------------------------------------
-// phase B: one lane = one 8x8 block
+// consumers: one lane = one 8x8 block
 // ---------------------------------------------------------------------------------
 // A sample byte b (or 2x2 sum S) becomes the float 2^23 + b by OR-ing it into the mantissa
 // of 0x4B000000 — full-rate VALU ops instead of v_cvt (half rate) + level-shift subtract.
@@ -491,7 +495,7 @@ PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v
     }
 }
 
-PIXO_DEV void block_cols_quant(float *v, qtab_t rcp, qtab_t q, float scale, int b, uint8_t *lds)
+PIXO_DEV void block_cols_quant(float *v, qtab_t rcp, qtab_t q, float scale, int b, uint8_t *stage)
 {
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -524,117 +528,93 @@ PIXO_DEV void block_cols_quant(float *v, qtab_t rcp, qtab_t q, float scale, int 
         for (int c = 0; c < 4; c++) w[c] = fbits(v[u * 8 + 2 * c] + rc[c]) ^ fbits(v[u * 8 + 2 * c + 1]);
 #endif
         o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
-        *(u32x4 *)(lds + stage_addr(b, u)) = o;
+        *(u32x4 *)(stage + stage_addr(b, u)) = o;
         PIXO_SCHED_FENCE();
 #pragma unroll
         for (int c = 0; c < 8; c++) rc[c] = rn[c];
     }
 }
 
-// What the block of lane `tid` is and where its planar rows start (all wave-uniform except src).
+// What the block of lane `lane` of consumer wave `wave` is, and where its planar rows start
+// (everything wave-uniform except src).
 struct BlockDesc {
     const uint8_t *src;
     int pitch;
     int rcp_off, q_off; // offsets into the quantiser table block
     float dc_shift, scale;
-    bool active, u16;
+    bool u16;
 };
 
-template <int MODE> PIXO_DEV BlockDesc block_desc(int tid, const uint8_t *lds)
+template <int MODE> PIXO_DEV BlockDesc block_desc(int wave, int lane, const uint8_t *planar)
 {
-    const int wave = uniform_i32(tid >> 6), lane = tid & 63;
     BlockDesc d;
-    d.active = true; d.u16 = false; d.pitch = kPitch; d.rcp_off = 0; d.q_off = 128;
-    d.dc_shift = 1024.0f; d.scale = 1.0f;
-    d.src = lds + wave * kRegion + lane * 8;
+    d.u16 = false; d.pitch = kPitch; d.rcp_off = 0; d.q_off = 128; d.dc_shift = 1024.0f; d.scale = 1.0f;
+    d.src = planar + wave * 4224 + lane * 8;
     if (MODE == M420) {
         if (wave < 2) {
             const int ml = lane >> 2, s = lane & 3;
-            d.src = lds + wave * kRegion + ((s >> 1) * 8) * kPitchHalf + ml * 16 + (s & 1) * 8;
+            d.src = planar + wave * 4352 + ((s >> 1) * 8) * kPitchHalf + ml * 16 + (s & 1) * 8;
             d.pitch = kPitchHalf;
-        } else if (wave == 2) {
-            d.src = lds + 2 * kRegion + (lane >> 5) * 4096 + (lane & 31) * 16;
-            d.pitch = 512; d.u16 = true; d.rcp_off = 256; d.q_off = 192; d.dc_shift = 4064.0f; d.scale = 0.25f;
         } else {
-            d.active = false;
+            d.src = planar + 8704 + (lane >> 5) * 4096 + (lane & 31) * 16;
+            d.pitch = 512; d.u16 = true; d.rcp_off = 256; d.q_off = 192; d.dc_shift = 4064.0f; d.scale = 0.25f;
         }
     } else if (MODE == M444) {
-        if (wave >= 3) d.active = false;
         if (wave >= 1) { d.rcp_off = 64; d.q_off = 192; d.dc_shift = 1016.0f; }
     }
     return d;
 }
 
-// Phase B in two steps (rows: LDS planar -> registers; columns + quantise -> LDS stage).
-// Planar and stage are disjoint, so neither step needs a barrier against other wavefronts.
-template <int MODE> PIXO_DEV bool phase_rows(int tid, const uint8_t *lds, float *v)
+// Consumer step 1: planar rows -> registers, row pass.
+template <int MODE> PIXO_DEV void consumer_rows(int wave, int lane, const uint8_t *planar, float *v)
 {
-    const BlockDesc d = block_desc<MODE>(tid, lds);
-    if (!d.active) return false;
+    const BlockDesc d = block_desc<MODE>(wave, lane, planar);
     if (MODE == M420 && d.u16) block_rows<true>(d.src, 512, 4064.0f, v);
     else block_rows<false>(d.src, d.pitch, d.dc_shift, v);
-    return true;
 }
 
-template <int MODE> PIXO_DEV void phase_cols_quant(int tid, const float *qt, float *v, uint8_t *lds)
-{
-    const BlockDesc d = block_desc<MODE>(tid, lds);
-    if (!d.active) return;
-    const int wave = uniform_i32(tid >> 6), lane = tid & 63;
-    const qtab_t tab = as_qtab(qt);
-    block_cols_quant(v, tab + uniform_i32(d.rcp_off), tab + uniform_i32(d.q_off), d.scale, wave * 64 + lane,
-                     lds + Geo<MODE>::planar);
-}
-
-template <int MODE> PIXO_DEV void phase_dct_quant(int tid, const float *qt, uint8_t *lds)
-{
-    float v[64];
-    if (phase_rows<MODE>(tid, lds, v)) phase_cols_quant<MODE>(tid, qt, v, lds);
-}
-
-// ---- phase C: stage -> global, 16 B per lane, coalesced ------------------------------
+// Consumer step 2: column pass, quantise, write the wave's stage region.
 template <int MODE>
-PIXO_DEV void phase_store(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int tid,
-                          const uint8_t *lds)
+PIXO_DEV void consumer_cols_quant(int wave, int lane, const float *qt, float *v, uint8_t *stage)
+{
+    const BlockDesc d = block_desc<MODE>(wave, lane, nullptr);
+    const qtab_t tab = as_qtab(qt);
+    block_cols_quant(v, tab + uniform_i32(d.rcp_off), tab + uniform_i32(d.q_off), d.scale, wave * 64 + lane, stage);
+}
+
+// Consumer step 3: the wave's own 64 blocks, stage -> HBM, 16 B per lane, coalesced.  Reads
+// only what this wavefront wrote in step 2 (program order, no barrier).
+template <int MODE>
+PIXO_DEV void consumer_store(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int wave, int lane,
+                             const uint8_t *stage)
 {
     typedef Geo<MODE> G;
-    lds += G::planar;                        // the stage follows the planar samples
     const uint32_t u0 = tile_x * G::units_x; // first MCU / block column of the tile
     const uint32_t nvalid = c.units_x - u0 < (uint32_t)G::units_x ? c.units_x - u0 : G::units_x;
-    if (MODE == M420) {
-        const size_t mcu0 = (size_t)tile_y * c.units_x + u0;
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            int ch = k * kThreads + tid, b = ch >> 3, j = ch & 7;
-            u32x4 w = *(const u32x4 *)(lds + stage_addr(b, j));
-            if (k < 4) {
-                if ((uint32_t)(b >> 2) < nvalid)
-                    *(u32x4 *)((uint8_t *)(c.y + mcu0 * 256) + (size_t)ch * 16) = w;
+    for (int k = 0; k < 8; k++) {
+        const int ch = k * 64 + lane, bl = ch >> 3, j = ch & 7; // chunk, block within wave, row
+        const u32x4 w = *(const u32x4 *)(stage + stage_addr(wave * 64 + bl, j));
+        if (MODE == M420) {
+            const size_t mcu0 = (size_t)tile_y * c.units_x + u0;
+            if (wave < 2) {
+                if ((uint32_t)(wave * 16 + (bl >> 2)) < nvalid)
+                    *(u32x4 *)((uint8_t *)(c.y + (mcu0 * 4 + wave * 64) * 64) + (size_t)ch * 16) = w;
             } else {
-                int bi = b & 31;
-                int16_t *dst = (k == 4 ? c.cb : c.cr) + (mcu0 + bi) * 64 + j * 8;
-                if ((uint32_t)bi < nvalid) *(u32x4 *)dst = w;
+                const int m = bl & 31;
+                int16_t *dst = (bl < 32 ? c.cb : c.cr) + (mcu0 + m) * 64 + j * 8;
+                if ((uint32_t)m < nvalid) *(u32x4 *)dst = w;
             }
-        }
-    } else if (MODE == M444) {
-        const size_t blk0 = (size_t)tile_y * c.units_x + u0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            int ch = k * kThreads + tid, b = ch >> 3, j = ch & 7;
-            u32x4 w = *(const u32x4 *)(lds + stage_addr(b, j));
-            int bi = b & 63;
-            int16_t *plane = (k < 2) ? c.y : (k < 4 ? c.cb : c.cr);
-            if ((uint32_t)bi < nvalid) *(u32x4 *)(plane + (blk0 + bi) * 64 + j * 8) = w;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            int ch = k * kThreads + tid, b = ch >> 3, j = ch & 7;
-            u32x4 w = *(const u32x4 *)(lds + stage_addr(b, j));
-            uint32_t brow = tile_y * 4 + (b >> 6);
-            int bi = b & 63;
-            if ((uint32_t)bi < nvalid && brow < c.units_y)
-                *(u32x4 *)(c.y + ((size_t)brow * c.units_x + u0 + bi) * 64 + j * 8) = w;
+        } else if (MODE == M444) {
+            const size_t blk0 = (size_t)tile_y * c.units_x + u0;
+            int16_t *plane = c.y; // explicit selects: an indexed pointer table would live in scratch
+            if (wave == 1) plane = c.cb;
+            if (wave == 2) plane = c.cr;
+            if ((uint32_t)bl < nvalid) *(u32x4 *)(plane + (blk0 + bl) * 64 + j * 8) = w;
+        } else {
+            const uint32_t brow = tile_y * 3 + wave;
+            if ((uint32_t)bl < nvalid && brow < c.units_y)
+                *(u32x4 *)(c.y + ((size_t)brow * c.units_x + u0 + bl) * 64 + j * 8) = w;
         }
     }
 }

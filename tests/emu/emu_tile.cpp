@@ -12,33 +12,36 @@
 
 using namespace pixo_tile;
 
-template <int MODE>
+template <int MODE, bool FAST>
 static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long *stats, int wave_order)
 {
-    std::vector<Lane<MODE>> lanes(kThreads);
-    std::vector<float> v((size_t)kThreads * 64);
-    alignas(16) static uint8_t lds[Geo<MODE>::lds];
-    bool active[kThreads];
+    typedef Geo<MODE> G;
+    static_assert(lds_bytes<MODE>() <= 160 * 1024 / 2, "two workgroups must fit a CU's LDS");
+    alignas(16) static uint8_t lds[lds_bytes<MODE>()];
+    std::vector<float> v((size_t)192 * 64);
+    uint32_t regs[G::items * G::item_regs];
+    uint32_t buf = 0;
     for (uint32_t ty = 0; ty < tiles_y; ty++)
         for (uint32_t tx = 0; tx < tiles_x; tx++) {
-            if (stats) stats[(c.fast && (tx + 1) * kTileW <= c.W && (ty + 1) * Geo<MODE>::tile_h <= c.H) ? 0 : 1]++;
-            memset(lds, 0xA5, sizeof lds); // nothing may rely on LDS contents of a previous tile
-            static_assert(Geo<MODE>::lds <= 160 * 1024 / (MODE == MGRAY ? 2 : 3), "workgroups per CU by LDS");
-            // phase A (then barrier)
-            for (int t = 0; t < kThreads; t++) {
-                load_tile<MODE>(c, tx, ty, t, lanes[t]);
-                phase_color<MODE>(t, lanes[t], lds);
+            if (stats) stats[FAST ? 0 : 1]++; // tiles read by vector loads / by byte gathers
+            uint8_t *planar = lds + buf * G::planar, *stage = lds + 2 * G::planar;
+            memset(planar, 0xA5, G::planar); // nothing may rely on a previous tile's samples
+            // producer wavefront: every lane loads and converts its items of this tile
+            for (int lane = 0; lane < 64; lane++) {
+                for (int k = 0; k < G::items; k++) producer_load_item<MODE, FAST>(c, tx, ty, k, lane, &regs[k * G::item_regs]);
+                for (int k = 0; k < G::items; k++) {
+                    producer_fix_item<MODE, FAST>(c, tx, k, lane, &regs[k * G::item_regs]);
+                    producer_color_item<MODE>(k, lane, &regs[k * G::item_regs], planar);
+                }
             }
-            // phase B: no barrier between wavefronts, so run them in a caller-chosen order;
-            // inside a wavefront, lockstep: all lanes' reads (rows) before any lane's writes.
-            for (int k = 0; k < 4; k++) {
-                const int w = wave_order == 0 ? k : (wave_order == 1 ? 3 - k : (k * 3 + 1) % 4);
-                for (int l = 0; l < 64; l++) active[w * 64 + l] = phase_rows<MODE>(w * 64 + l, lds, &v[(w * 64 + l) * 64]);
-                for (int l = 0; l < 64; l++)
-                    if (active[w * 64 + l]) phase_cols_quant<MODE>(w * 64 + l, c.qt, &v[(w * 64 + l) * 64], lds);
+            // (barrier) consumer wavefronts, in a caller-chosen order: they share nothing
+            for (int k = 0; k < 3; k++) {
+                const int w = wave_order == 0 ? k : (wave_order == 1 ? 2 - k : (k + 1) % 3);
+                for (int l = 0; l < 64; l++) consumer_rows<MODE>(w, l, planar, &v[(w * 64 + l) * 64]);
+                for (int l = 0; l < 64; l++) consumer_cols_quant<MODE>(w, l, c.qt, &v[(w * 64 + l) * 64], stage);
+                for (int l = 0; l < 64; l++) consumer_store<MODE>(c, tx, ty, w, l, stage);
             }
-            // (barrier) phase C
-            for (int t = 0; t < kThreads; t++) phase_store<MODE>(c, tx, ty, t, lds);
+            buf ^= 1;
         }
 }
 
@@ -55,14 +58,17 @@ extern "C" int emu_jpeg_coeffs(const uint8_t *px, uint32_t W, uint32_t H, int co
     c.units_x = (W + unit - 1) / unit;
     c.units_y = (H + unit - 1) / unit;
     const size_t row_bytes = (size_t)W * (gray ? 1 : 3);
-    c.fast = allow_fast && ((uintptr_t)px % 4 == 0) && (row_bytes % 4 == 0);
+    c.fast = allow_fast && ((uintptr_t)px % 4 == 0) && (row_bytes % 4 == 0) && W >= 4;
     if (stats) stats[0] = stats[1] = 0;
     if (gray) {
-        run_image<MGRAY>(c, (c.units_x + 63) / 64, (c.units_y * 8 + 31) / 32, stats, wave_order);
+        if (c.fast) run_image<MGRAY, true>(c, (c.units_x + 63) / 64, (c.units_y + 2) / 3, stats, wave_order);
+        else run_image<MGRAY, false>(c, (c.units_x + 63) / 64, (c.units_y + 2) / 3, stats, wave_order);
     } else if (s420) {
-        run_image<M420>(c, (c.units_x + 31) / 32, c.units_y, stats, wave_order);
+        if (c.fast) run_image<M420, true>(c, (c.units_x + 31) / 32, c.units_y, stats, wave_order);
+        else run_image<M420, false>(c, (c.units_x + 31) / 32, c.units_y, stats, wave_order);
     } else {
-        run_image<M444>(c, (c.units_x + 63) / 64, c.units_y, stats, wave_order);
+        if (c.fast) run_image<M444, true>(c, (c.units_x + 63) / 64, c.units_y, stats, wave_order);
+        else run_image<M444, false>(c, (c.units_x + 63) / 64, c.units_y, stats, wave_order);
     }
     return 0;
 }

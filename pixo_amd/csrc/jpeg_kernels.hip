@@ -1,11 +1,10 @@
 // jpeg_kernels.hip — gfx950 kernels of the JPEG pixel pipeline and their launcher.
 //
 // The per-tile body lives in jpeg_tile.h (shared with the CPU emulation harness in
-// tests/emu).  This file adds the persistent __global__ loop, the tile -> image mapping
-// and the host-side launch function.  Written for CDNA4 only: 64-lane wavefronts,
-// 256-thread workgroups of four role-specialised wavefronts (one producer, three consumers),
-// ~50-58 KiB LDS per workgroup (two resident per CU = two busy wavefronts per SIMD), a grid
-// of (resident workgroups per CU) x 256 CUs that walks the tiles with a stride.
+// tests/emu).  This file adds the __global__ wrapper, the tile -> image mapping and the
+// host-side launch function.  Written for CDNA4 only: 64-lane wavefronts, 256-thread
+// workgroups (4 waves, one per SIMD), one 512-pixel-wide tile per workgroup, >= 2048
+// workgroups per 4096x4096 image (8 per CU, 6 resident at a time).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -69,132 +68,43 @@ __device__ __forceinline__ TileCtx ctx_of(const KArgs &a, uint32_t img)
     return c;
 }
 
-// Role-specialised persistent workgroup.  Tiles t = blockIdx.x + i * gridDim.x, i = 0..n-1.
-//   producer (wave 3):   for i: fill planar[i & 1] with tile i; barrier_i
-//   consumers (0..2):    for i: barrier_i; transform + store tile i from planar[i & 1]
-// Both sides execute exactly n barriers.  The producer refills planar[i & 1] (tile i + 2) only
-// after barrier_{i+1}, which the consumers reach only after they are done with tile i, so one
-// barrier per tile is the whole protocol.  While the consumers work on tile i the producer
-// converts tile i + 1 and has tile i + 2's loads in flight: each item's registers are reloaded
-// for the next tile as soon as the item has been converted, so HBM reads are spread evenly
-// over the iteration and never waited for at the point of issue.
+// One tile per workgroup.  All four wavefronts load and colour-convert a quarter of the tile
+// each (phase A), one LDS barrier, then three wavefronts transform, quantise and store 64 blocks
+// each (phase B; the fourth has nothing to do for 4:2:0 / 4:4:4 and exits).  A wavefront stages
+// its quantised blocks in the LDS area its own planar samples came from — it has consumed them
+// all by then — so phase B needs no barrier and the workgroup only ~17 KiB of LDS.
+// Overlap of HBM latency with VALU work comes from the other resident workgroups (6 per CU:
+// 79 VGPRs, 17 KiB LDS) being in other phases; they drift apart as workgroups retire and are
+// replaced.  Measured alternatives (persistent loop with register prefetch; role-specialised
+// producer/consumer wavefronts with double-buffered LDS) were 5-10 % slower: DESIGN.md.
 template <int MODE, bool FAST>
-__global__ __launch_bounds__(kThreads, 2) void jpeg_coeffs_kernel(const KArgs a)
+__global__ __launch_bounds__(kThreads, 4) void jpeg_coeffs_kernel(const KArgs a)
 {
     typedef Geo<MODE> G;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[lds_bytes<MODE>()];
-    uint8_t *const stage = lds + 2 * G::planar;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[G::planar];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint32_t total = a.tiles_x * a.tiles_y * a.batch;
-    const uint32_t first = blockIdx.x, stride = gridDim.x;
-    if (first >= total) return;
-
-    if (wave == 3) {
-        // Two register sets: while set X (tile t, loaded one iteration ago) is converted, set Y
-        // receives tile t + stride.  The explicit vmcnt(0) sits BEFORE the new loads are issued,
-        // so it only ever waits for loads that have had a whole iteration to land; the loads are
-        // unconditional (the last iteration re-reads its own tile) so that no branch joins —
-        // and therefore no compiler-inserted wait — follow them.
-        uint32_t ra[G::items * G::item_regs], rb[G::items * G::item_regs];
-        TileId id = locate(a, first);
-        TileCtx c = ctx_of(a, id.img);
+    const TileId id = locate(a, blockIdx.x);
+    const TileCtx c = ctx_of(a, id.img);
+    constexpr int Q = G::items / 4; // items per wavefront
+    uint32_t r[Q * G::item_regs];
 #pragma unroll
-        for (int k = 0; k < G::items; k++) producer_load_item<MODE, FAST>(c, id.tx, id.ty, k, lane, &ra[k * G::item_regs]);
-        uint32_t buf = 0, t = first;
-#ifdef PIXO_TIMING
-        unsigned long long tm[5] = {0, 0, 0, 0, 0}, acc[4] = {0, 0, 0, 0};
-#define PIXO_T(i) tm[i] = __builtin_readcyclecounter(); if (i > 0) acc[i - 1] += tm[i] - tm[i - 1];
-#else
-#define PIXO_T(i)
-#endif
-        for (;;) {
-#define PIXO_PRODUCER_HALF(X, Y)                                                                   \
-            {                                                                                      \
-                const uint32_t tn = t + stride;                                                    \
-                const bool more = tn < total;                                                      \
-                const TileCtx cc = c;                                                              \
-                const uint32_t ctx = id.tx;                                                        \
-                id = locate(a, more ? tn : t);                                                     \
-                c = ctx_of(a, id.img);                                                             \
-                PIXO_T(0) __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): set X has landed */     \
-                PIXO_T(1) _Pragma("unroll") for (int k = 0; k < G::items; k++)                     \
-                    producer_load_item<MODE, FAST>(c, id.tx, id.ty, k, lane, &Y[k * G::item_regs]); \
-                uint8_t *planar = lds + buf * G::planar;                                           \
-                PIXO_T(2) _Pragma("unroll") for (int k = 0; k < G::items; k++) {                   \
-                    PIXO_PRODUCER_CONVERT(X)                                                       \
-                }                                                                                  \
-                buf ^= 1;                                                                          \
-                PIXO_T(3) lds_barrier(); /* planar buffer of tile t handed over */                 \
-                PIXO_T(4)                                                                          \
-                if (!more) break;                                                                  \
-                t = tn;                                                                            \
-            }
-#if !defined(PIXO_ABLATE) || PIXO_ABLATE < 2 // (timing experiments: >=2 drops the colour conversion)
-#define PIXO_PRODUCER_CONVERT(X)                                                  \
-    producer_fix_item<MODE, FAST>(cc, ctx, k, lane, &X[k * G::item_regs]);        \
-    producer_color_item<MODE>(k, lane, &X[k * G::item_regs], planar);          \
-    __builtin_amdgcn_sched_barrier(0); /* one item at a time: ~40 temporaries, not 16 x 40 */
-#else
-#define PIXO_PRODUCER_CONVERT(X) \
-    for (int i = 0; i < G::item_regs; i++) asm volatile("" ::"v"(X[k * G::item_regs + i]));
-#endif
-            PIXO_PRODUCER_HALF(ra, rb)
-            PIXO_PRODUCER_HALF(rb, ra)
-#undef PIXO_PRODUCER_HALF
-#undef PIXO_PRODUCER_CONVERT
-        }
-#ifdef PIXO_TIMING
-        if (lane == 0 && a.dbg) for (int i = 0; i < 4; i++) a.dbg[blockIdx.x * 16 + i] = acc[i];
-#endif
-    } else {
-        uint32_t buf = 0;
-#ifdef PIXO_TIMING
-        unsigned long long tm[5] = {0, 0, 0, 0, 0}, acc[4] = {0, 0, 0, 0};
-#endif
-        for (uint32_t t = first; t < total; t += stride) {
-            PIXO_T(0) lds_barrier(); // tile t's planar buffer is complete
-            PIXO_T(1) const TileId id = locate(a, t);
-            const uint8_t *planar = lds + buf * G::planar;
-            float v[64];
-#if !defined(PIXO_ABLATE) || PIXO_ABLATE < 1 // (>=1 drops the transform)
-            consumer_rows<MODE>(wave, lane, planar, v);
-            PIXO_T(2) consumer_cols_quant<MODE>(wave, lane, a.qt, v, stage);
-#endif
-            PIXO_T(3) consumer_store<MODE>(ctx_of(a, id.img), id.tx, id.ty, wave, lane, stage);
-            PIXO_T(4) buf ^= 1;
-        }
-#ifdef PIXO_TIMING
-        if (lane == 0 && a.dbg) for (int i = 0; i < 4; i++) a.dbg[blockIdx.x * 16 + 4 + wave * 4 + i] = acc[i];
-#endif
+    for (int j = 0; j < Q; j++) producer_load_item<MODE, FAST>(c, id.tx, id.ty, wave * Q + j, lane, &r[j * G::item_regs]);
+#pragma unroll
+    for (int j = 0; j < Q; j++) {
+        producer_fix_item<MODE, FAST>(c, id.tx, wave * Q + j, lane, &r[j * G::item_regs]);
+        producer_color_item<MODE>(wave * Q + j, lane, &r[j * G::item_regs], lds);
     }
-}
-
-// Resident workgroups per CU, computed from the kernel's own resource usage: gfx950 has 160 KiB
-// of LDS and 512 VGPRs per lane per SIMD (allocation granule 8), and one wavefront of each
-// 4-wave workgroup lands on each SIMD.  (hipOccupancyMaxActiveBlocksPerMultiprocessor answers 1
-// for the 57 KiB-LDS kernels — it still budgets 64 KiB of LDS per CU — which would halve the
-// grid and leave every wavefront alone on its SIMD, at half the VALU issue rate.)
-template <int MODE, bool FAST> static int blocks_per_cu()
-{
-    static int cached = 0;
-    if (!cached) {
-        hipFuncAttributes attr;
-        int n = 1;
-        if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(jpeg_coeffs_kernel<MODE, FAST>)) == hipSuccess) {
-            const int regs = ((attr.numRegs > 0 ? attr.numRegs : 256) + 7) / 8 * 8;
-            const int by_vgpr = 512 / regs;
-            const int by_lds = (160 * 1024) / (attr.sharedSizeBytes > 0 ? (int)attr.sharedSizeBytes : lds_bytes<MODE>());
-            n = by_vgpr < by_lds ? by_vgpr : by_lds;
-            if (getenv("PIXO_HIP_DEBUG"))
-                fprintf(stderr, "pixo_hip: mode %d fast %d numRegs %d sharedSizeBytes %zu maxDyn %d -> %d workgroups/CU\n", MODE,
-                        (int)FAST, attr.numRegs, attr.sharedSizeBytes, attr.maxDynamicSharedSizeBytes, n);
-        } else if (getenv("PIXO_HIP_DEBUG")) {
-            fprintf(stderr, "pixo_hip: hipFuncGetAttributes failed\n");
-        }
-        if (const char *e = getenv("PIXO_HIP_BLOCKS_PER_CU")) n = atoi(e); // tuning experiments
-        cached = n < 1 ? 1 : (n > 8 ? 8 : n);
+    lds_barrier();
+    if (wave < 3) {
+        float v[64];
+        consumer_rows<MODE>(wave, lane, lds, v);
+        consumer_cols(v);
+        uint8_t *stage = lds + stage_offset<MODE>(wave); // inside this wavefront's own planar area
+        consumer_quant_half<MODE>(wave, lane, a.qt, v, 0, stage);
+        consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 0, stage);
+        consumer_quant_half<MODE>(wave, lane, a.qt, v, 1, stage);
+        consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 1, stage);
     }
-    return cached;
 }
 
 template <int MODE, bool FAST> static hipError_t launch_mode(KArgs &a, hipStream_t s)
@@ -204,13 +114,7 @@ template <int MODE, bool FAST> static hipError_t launch_mode(KArgs &a, hipStream
     const uint64_t total64 = (uint64_t)a.tiles_x * a.tiles_y * a.batch;
     if (total64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const uint32_t total = (uint32_t)total64;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const uint32_t resident = (uint32_t)blocks_per_cu<MODE, FAST>() * (uint32_t)cus;
-    // equal number of tiles per workgroup: rounds = ceil(total / resident), grid = ceil(total / rounds)
-    const uint32_t rounds = (total + resident - 1) / resident;
-    const uint32_t grid = (total + rounds - 1) / rounds;
-    hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, FAST>), dim3(grid), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, FAST>), dim3(total), dim3(kThreads), 0, s, a);
     return hipGetLastError();
 }
 

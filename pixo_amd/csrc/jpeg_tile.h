@@ -1,25 +1,22 @@
 // jpeg_tile.h — the per-tile body of the fused JPEG coefficient kernel for gfx950.
 //
-// A 256-thread workgroup = 4 wavefronts with fixed roles (measured on MI355X,
-// tools/ubench/valu_ilp.hip: one wavefront can issue a VALU instruction only every ~5 cycles,
-// two wavefronts saturate a SIMD — so the design keeps two busy wavefronts per SIMD, from two
-// co-resident workgroups, instead of many that take turns):
+// One 256-thread workgroup (4 wavefronts, one per SIMD) turns one tile of pixels into quantised
+// DCT blocks:
 //
-//   producer (wave 3)   streams the NEXT tile: global RGB8 -> registers (12 B per lane = 4 px,
-//                       a whole tile of loads in flight), integer BT.601 colour conversion with
-//                       packed-u16 VALU ops (2 px per instruction), 2x2 chroma box sums, planar
-//                       u8/u16 samples into one of two LDS planar buffers.
-//   consumers (waves 0-2)  one lane per 8x8 block of the CURRENT tile: LDS rows -> f32 on the
-//                       fly, f32 AAN DCT rows then columns entirely in registers (no
-//                       transposes), quantise (reciprocal fast path proven equal to the IEEE
-//                       divide, exact divide fallback), pack to i16, swizzled 16-B chunks into
-//                       the wave's own LDS stage, read back linearly and stored to HBM 16 B per
-//                       lane, coalesced, in the reference's YCbCrCoefficients layout.
+//   phase A  (all 4 wavefronts, 4 work items each)   global RGB8 -> registers: one unconditional
+//            12-byte load per lane and row (4 px; a wavefront instruction covers 768 contiguous
+//            bytes), integer BT.601 colour conversion with packed-u16 VALU ops (2 px per
+//            instruction), 2x2 chroma box sums, planar u8/u16 samples into LDS.
+//   --- one LDS-only barrier ---
+//   phase B  (3 wavefronts, one lane per 8x8 block)  LDS rows -> f32 on the fly, f32 AAN DCT rows
+//            then columns entirely in registers (no transposes), quantise (reciprocal fast
+//            path proven equal to the IEEE divide, exact divide fallback), pack to i16, stage
+//            half a block per lane in the wavefront's own LDS area, read back by 16-byte chunk
+//            and store to HBM so that 4 consecutive lanes write 64 contiguous bytes, in the
+//            reference's YCbCrCoefficients layout.
 //
-// One LDS-only barrier per tile hands a filled planar buffer to the consumers and an emptied
-// one back to the producer (double buffering).  HBM reads, colour conversion, DCT/quantise and
-// HBM writes of neighbouring tiles all overlap; no wavefront ever waits on another role's
-// memory traffic.
+// (Function names say producer_* / consumer_* because the same pieces were also run as
+// role-specialised wavefronts of a persistent workgroup; see DESIGN.md for that experiment.)
 //
 // Reference semantics reproduced bit-for-bit (leerob/pixo v0.4.1):
 //   colour           src/color.rs:60-77           (integer, 2^8-scaled, clamp)
@@ -78,7 +75,7 @@ constexpr int kPitch = 528;     // planar row pitch, full-width planes (4:4:4, g
 constexpr int kPitchHalf = 272; // planar row pitch, 256-px half planes (4:2:0 luminance);
                                 // 8*272 % 256 == 128 puts the bottom Y blocks of an MCU on the
                                 // other half of the 64 banks: ds_read_b64 conflict-free
-constexpr int kStageBytes = 192 * 128; // 3 consumer waves x 64 blocks x 128 B
+constexpr int kStageWave = 4096;        // per consumer wave: 64 blocks x 4 rows x 16 B (half a block each)
 
 // Quantiser table block for one quality, resident in HBM, read with scalar loads:
 //   [0,64)    1/q luminance   [64,128)   1/q chrominance   (f32, correctly rounded)
@@ -100,7 +97,12 @@ template <int MODE> struct Geo;
 template <> struct Geo<M420> { static constexpr int tile_h = 16, units_x = 32, bpp = 3, items = 16, item_regs = 6, planar = 16896; };
 template <> struct Geo<M444> { static constexpr int tile_h = 8, units_x = 64, bpp = 3, items = 16, item_regs = 3, planar = 12672; };
 template <> struct Geo<MGRAY> { static constexpr int tile_h = 24, units_x = 64, bpp = 1, items = 48, item_regs = 1, planar = 12672; };
-template <int MODE> constexpr int lds_bytes() { return 2 * Geo<MODE>::planar + kStageBytes; }
+template <int MODE> constexpr int lds_bytes() { return Geo<MODE>::planar; }
+// A consumer wavefront's 4 KiB stage reuses the start of the planar area only it reads:
+// 4:2:0 luminance half planes (4352 B each) and the chroma sums (8192 B); 4:4:4 / gray planes
+// (4224 B each).  Lanes of a wavefront run in lockstep and LDS operations of a wavefront complete
+// in order, so all of its planar reads (row pass) precede its first stage write (quantiser).
+template <int MODE> PIXO_DEV int stage_offset(int wave) { return MODE == M420 ? wave * 4352 : wave * 4224; }
 
 // Per-image launch context (uniform across the workgroup).
 struct TileCtx {
@@ -255,16 +257,19 @@ PIXO_DEV void producer_load_item(const TileCtx &c, uint32_t tile_x, uint32_t til
     const uint32_t x0 = tile_x * kTileW + 4 * ((k & 1) * 64 + lane);
     const uint32_t y0 = tile_y * Geo<MODE>::tile_h + (MODE == M420 ? 2 : 1) * (k >> 1);
     if (FAST) {
-        const uint32_t xc = x0 < c.W ? x0 : c.W - 4;
+        // uniform 64-bit row base (scalar ALU) + per-lane 32-bit byte offset: the loads use the
+        // saddr + voffset form and cost no 64-bit vector arithmetic
+        const uint32_t xoff = (x0 < c.W ? x0 : c.W - 4) * Geo<MODE>::bpp;
         const uint32_t ya = y0 < c.H ? y0 : c.H - 1;
+        const uint8_t *row = c.px + (size_t)ya * ((size_t)c.W * Geo<MODE>::bpp);
         if (MODE == MGRAY) {
-            r[0] = *(const uint32_t *)(c.px + (size_t)ya * c.W + xc);
+            r[0] = *(const uint32_t *)(row + xoff);
         } else {
-            const uint32_t *q = (const uint32_t *)(c.px + ((size_t)ya * c.W + xc) * 3);
+            const uint32_t *q = (const uint32_t *)(row + xoff);
             r[0] = q[0]; r[1] = q[1]; r[2] = q[2];
             if (MODE == M420) {
                 const uint32_t yb = y0 + 1 < c.H ? y0 + 1 : c.H - 1;
-                const uint32_t *q2 = (const uint32_t *)(c.px + ((size_t)yb * c.W + xc) * 3);
+                const uint32_t *q2 = (const uint32_t *)(c.px + (size_t)yb * ((size_t)c.W * 3) + xoff);
                 r[3] = q2[0]; r[4] = q2[1]; r[5] = q2[2];
             }
         }
@@ -463,19 +468,19 @@ PIXO_DEV void quant_row8(const float *x, const float *rcp, qtab_t q, float scale
     out[3] = perm(fbits(s[7]), fbits(s[6]), 0x05040100u);
 }
 
-// LDS stage: block b occupies bytes [128b, 128b+128); its 16-byte chunk j (= natural-
-// order row j of the block) is stored at slot j ^ (b & 7) so that both the per-block
-// ds_write_b128 (8-lane groups, stride 128 B) and the linear ds_read_b128 of phase C
-// are bank-conflict free.
-PIXO_DEV int stage_addr(int b, int j) { return b * 128 + ((j ^ (b & 7)) << 4); }
+// LDS stage of one consumer wavefront: 4 KiB holding rows [4 half, 4 half + 4) of its 64 blocks.
+// Chunk (block bl, row r in 0..3) lives at 64 bl + 16 (r ^ (bl & 3)): the per-block
+// ds_write_b128 (lane = block, 64-B stride) then touches four different 16-B slots per 128 B
+// instead of one, and the read-back (lane = chunk) is linear up to that permutation.
+PIXO_DEV int stage_addr(int bl, int r) { return bl * 64 + ((r ^ (bl & 3)) << 4); }
 
 // Block kinds (wave-uniform): quantiser table, DC shift of the row pass, scale.
 //   luminance            samples b,  level shift 128          row DC shift 8*128 = 1024
 //   chroma 4:4:4         bytes hold C-1 (see color_row4)      row DC shift 8*127 = 1016
 //   chroma 4:2:0 (U16)   2x2 sums S = 4*mean - 4, transform at 4x scale:
 //                        mean - 128 = (S - 508)/4             row DC shift 8*508 = 4064
-// `src` points at this lane's first planar row; rows are `pitch` bytes apart.  Rows are read
-// from LDS as the row pass needs them (2-4 registers), not staged in 16-32 registers.
+// `src` points at this lane's first planar row; rows are `pitch` bytes apart and are read from
+// LDS as the row pass needs them (2-4 registers), not staged in 16-32 registers.
 template <bool U16>
 PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v)
 {
@@ -495,7 +500,7 @@ PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v
     }
 }
 
-PIXO_DEV void block_cols_quant(float *v, qtab_t rcp, qtab_t q, float scale, int b, uint8_t *stage)
+PIXO_DEV void block_cols(float *v)
 {
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -506,16 +511,22 @@ PIXO_DEV void block_cols_quant(float *v, qtab_t rcp, qtab_t q, float scale, int 
     }
 #pragma unroll
     for (int i = 0; i < 64; i++) PIXO_PIN(v[i]);
-    // The reciprocals are wave-uniform scalar (SMEM) loads.  Fetch each row's eight one row
-    // ahead of its use so their ~200-cycle latency hides under the previous row's arithmetic
-    // (left to itself the compiler issues each s_load right before its s_waitcnt).
+}
+
+// Quantise rows [4 half, 4 half + 4) of the lane's block into the wave's stage.
+// The reciprocals are wave-uniform scalar (SMEM) loads, fetched one row ahead of their use so
+// that their latency hides under the previous row's arithmetic.
+PIXO_DEV void block_quant_half(const float *v, qtab_t rcp, qtab_t q, float scale, int half, int bl,
+                               uint8_t *stage_wave)
+{
     float rc[8], rn[8];
 #pragma unroll
-    for (int c = 0; c < 8; c++) rc[c] = rcp[c];
+    for (int c = 0; c < 8; c++) rc[c] = rcp[half * 32 + c];
     PIXO_SCHED_FENCE();
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-        if (u < 7) {
+    for (int r = 0; r < 4; r++) {
+        const int u = half * 4 + r;
+        if (r < 3) {
 #pragma unroll
             for (int c = 0; c < 8; c++) rn[c] = rcp[(u + 1) * 8 + c];
             PIXO_SCHED_FENCE();
@@ -528,7 +539,7 @@ PIXO_DEV void block_cols_quant(float *v, qtab_t rcp, qtab_t q, float scale, int 
         for (int c = 0; c < 4; c++) w[c] = fbits(v[u * 8 + 2 * c] + rc[c]) ^ fbits(v[u * 8 + 2 * c + 1]);
 #endif
         o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
-        *(u32x4 *)(stage + stage_addr(b, u)) = o;
+        *(u32x4 *)(stage_wave + stage_addr(bl, r)) = o;
         PIXO_SCHED_FENCE();
 #pragma unroll
         for (int c = 0; c < 8; c++) rc[c] = rn[c];
@@ -573,33 +584,38 @@ template <int MODE> PIXO_DEV void consumer_rows(int wave, int lane, const uint8_
     else block_rows<false>(d.src, d.pitch, d.dc_shift, v);
 }
 
-// Consumer step 2: column pass, quantise, write the wave's stage region.
+// Consumer step 2: column pass (registers only).
+PIXO_DEV void consumer_cols(float *v) { block_cols(v); }
+
+// Consumer step 3 (half = 0, 1): quantise four rows of every block of the wave into its stage.
 template <int MODE>
-PIXO_DEV void consumer_cols_quant(int wave, int lane, const float *qt, float *v, uint8_t *stage)
+PIXO_DEV void consumer_quant_half(int wave, int lane, const float *qt, const float *v, int half, uint8_t *stage)
 {
     const BlockDesc d = block_desc<MODE>(wave, lane, nullptr);
     const qtab_t tab = as_qtab(qt);
-    block_cols_quant(v, tab + uniform_i32(d.rcp_off), tab + uniform_i32(d.q_off), d.scale, wave * 64 + lane, stage);
+    block_quant_half(v, tab + uniform_i32(d.rcp_off), tab + uniform_i32(d.q_off), d.scale, half, lane, stage);
 }
 
-// Consumer step 3: the wave's own 64 blocks, stage -> HBM, 16 B per lane, coalesced.  Reads
-// only what this wavefront wrote in step 2 (program order, no barrier).
+// Consumer step 4 (half = 0, 1): the wave's staged half blocks -> HBM.  Lane l of round k moves
+// chunk 64 k + l = (block, row): four consecutive lanes write 64 contiguous bytes of one block.
+// Reads only what this wavefront wrote in step 3 (program order, no barrier).
 template <int MODE>
-PIXO_DEV void consumer_store(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int wave, int lane,
-                             const uint8_t *stage)
+PIXO_DEV void consumer_store_half(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int wave, int lane,
+                                  int half, const uint8_t *stage)
 {
     typedef Geo<MODE> G;
     const uint32_t u0 = tile_x * G::units_x; // first MCU / block column of the tile
     const uint32_t nvalid = c.units_x - u0 < (uint32_t)G::units_x ? c.units_x - u0 : G::units_x;
+    const uint8_t *stage_wave = stage;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int ch = k * 64 + lane, bl = ch >> 3, j = ch & 7; // chunk, block within wave, row
-        const u32x4 w = *(const u32x4 *)(stage + stage_addr(wave * 64 + bl, j));
+    for (int k = 0; k < 4; k++) {
+        const int ch = k * 64 + lane, bl = ch >> 2, r = ch & 3, j = half * 4 + r;
+        const u32x4 w = *(const u32x4 *)(stage_wave + stage_addr(bl, r));
         if (MODE == M420) {
             const size_t mcu0 = (size_t)tile_y * c.units_x + u0;
             if (wave < 2) {
                 if ((uint32_t)(wave * 16 + (bl >> 2)) < nvalid)
-                    *(u32x4 *)((uint8_t *)(c.y + (mcu0 * 4 + wave * 64) * 64) + (size_t)ch * 16) = w;
+                    *(u32x4 *)(c.y + (mcu0 * 4 + wave * 64 + bl) * 64 + j * 8) = w;
             } else {
                 const int m = bl & 31;
                 int16_t *dst = (bl < 32 ? c.cb : c.cr) + (mcu0 + m) * 64 + j * 8;
@@ -607,10 +623,14 @@ PIXO_DEV void consumer_store(const TileCtx &c, uint32_t tile_x, uint32_t tile_y,
             }
         } else if (MODE == M444) {
             const size_t blk0 = (size_t)tile_y * c.units_x + u0;
-            int16_t *plane = c.y; // explicit selects: an indexed pointer table would live in scratch
-            if (wave == 1) plane = c.cb;
-            if (wave == 2) plane = c.cr;
-            if ((uint32_t)bl < nvalid) *(u32x4 *)(plane + (blk0 + bl) * 64 + j * 8) = w;
+            // wave-uniform branches, one store each: selecting among c.y / c.cb / c.cr as VALUES
+            // makes the compiler spill the context to scratch and index it
+            const size_t off = (blk0 + bl) * 64 + j * 8;
+            if ((uint32_t)bl < nvalid) {
+                if (wave == 0) *(u32x4 *)(c.y + off) = w;
+                else if (wave == 1) *(u32x4 *)(c.cb + off) = w;
+                else *(u32x4 *)(c.cr + off) = w;
+            }
         } else {
             const uint32_t brow = tile_y * 3 + wave;
             if ((uint32_t)bl < nvalid && brow < c.units_y)

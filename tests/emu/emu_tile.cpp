@@ -16,15 +16,14 @@ template <int MODE, bool FAST>
 static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long *stats, int wave_order)
 {
     typedef Geo<MODE> G;
-    static_assert(lds_bytes<MODE>() <= 160 * 1024 / 2, "two workgroups must fit a CU's LDS");
+    static_assert(lds_bytes<MODE>() <= 160 * 1024 / 6, "six workgroups must fit a CU's LDS");
     alignas(16) static uint8_t lds[lds_bytes<MODE>()];
     std::vector<float> v((size_t)192 * 64);
     uint32_t regs[G::items * G::item_regs];
-    uint32_t buf = 0;
     for (uint32_t ty = 0; ty < tiles_y; ty++)
         for (uint32_t tx = 0; tx < tiles_x; tx++) {
             if (stats) stats[FAST ? 0 : 1]++; // tiles read by vector loads / by byte gathers
-            uint8_t *planar = lds + buf * G::planar, *stage = lds + 2 * G::planar;
+            uint8_t *planar = lds;
             memset(planar, 0xA5, G::planar); // nothing may rely on a previous tile's samples
             // producer wavefront: every lane loads and converts its items of this tile
             for (int lane = 0; lane < 64; lane++) {
@@ -37,11 +36,15 @@ static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long
             // (barrier) consumer wavefronts, in a caller-chosen order: they share nothing
             for (int k = 0; k < 3; k++) {
                 const int w = wave_order == 0 ? k : (wave_order == 1 ? 2 - k : (k + 1) % 3);
+                // a wavefront runs these steps in lockstep: every lane finishes a step before any
+                // lane starts the next (the stage is written by block and read back by chunk)
                 for (int l = 0; l < 64; l++) consumer_rows<MODE>(w, l, planar, &v[(w * 64 + l) * 64]);
-                for (int l = 0; l < 64; l++) consumer_cols_quant<MODE>(w, l, c.qt, &v[(w * 64 + l) * 64], stage);
-                for (int l = 0; l < 64; l++) consumer_store<MODE>(c, tx, ty, w, l, stage);
+                for (int l = 0; l < 64; l++) consumer_cols(&v[(w * 64 + l) * 64]);
+                for (int half = 0; half < 2; half++) {
+                    for (int l = 0; l < 64; l++) consumer_quant_half<MODE>(w, l, c.qt, &v[(w * 64 + l) * 64], half, lds + stage_offset<MODE>(w));
+                    for (int l = 0; l < 64; l++) consumer_store_half<MODE>(c, tx, ty, w, l, half, lds + stage_offset<MODE>(w));
+                }
             }
-            buf ^= 1;
         }
 }
 

@@ -87,23 +87,41 @@ __global__ __launch_bounds__(kThreads, 4) void jpeg_coeffs_kernel(const KArgs a)
     const TileCtx c = ctx_of(a, id.img);
     constexpr int Q = G::items / 4; // items per wavefront
     uint32_t r[Q * G::item_regs];
+#if defined(PIXO_ABLATE) && PIXO_ABLATE == 5 // (timing experiments only: no loads)
+    for (int i = 0; i < Q * G::item_regs; i++) r[i] = lane * 77 + i;
+#else
 #pragma unroll
     for (int j = 0; j < Q; j++) producer_load_item<MODE, FAST>(c, id.tx, id.ty, wave * Q + j, lane, &r[j * G::item_regs]);
+#endif
 #pragma unroll
     for (int j = 0; j < Q; j++) {
+#if !defined(PIXO_ABLATE) || PIXO_ABLATE < 2 // (timing experiments only: 2..5 drop the colour conversion)
         producer_fix_item<MODE, FAST>(c, id.tx, wave * Q + j, lane, &r[j * G::item_regs]);
         producer_color_item<MODE>(wave * Q + j, lane, &r[j * G::item_regs], lds);
+#else
+        for (int i = 0; i < G::item_regs; i++) asm volatile("" ::"v"(r[j * G::item_regs + i]));
+#endif
     }
     lds_barrier();
     if (wave < 3) {
         float v[64];
+#if !defined(PIXO_ABLATE) || PIXO_ABLATE == 3 // (1, 2, 4, 5: no transform; 3: transform, no colour)
         consumer_rows<MODE>(wave, lane, lds, v);
         consumer_cols(v);
+#else
+        for (int i = 0; i < 64; i++) v[i] = (float)(lane + i);
+#endif
         uint8_t *stage = lds + stage_offset<MODE>(wave); // inside this wavefront's own planar area
         consumer_quant_half<MODE>(wave, lane, a.qt, v, 0, stage);
+#if !defined(PIXO_ABLATE) || PIXO_ABLATE != 4 // (4: no stores — one guarded store keeps the work alive)
         consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 0, stage);
+#endif
         consumer_quant_half<MODE>(wave, lane, a.qt, v, 1, stage);
+#if !defined(PIXO_ABLATE) || PIXO_ABLATE != 4
         consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 1, stage);
+#else
+        if (*(volatile uint32_t *)(stage + lane * 4) == 0x12345678u) consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 1, stage);
+#endif
     }
 }
 

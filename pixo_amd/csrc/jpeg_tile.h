@@ -155,6 +155,12 @@ PIXO_DEV int uniform_i32(int v)
 }
 
 struct u32x2 { uint32_t x, y; };
+#if defined(PIXO_EMU) || !defined(PIXO_NT_STORES)
+#define PIXO_GSTORE(ptr, val) (*(u32x4 *)(ptr) = (val))
+#else
+typedef uint32_t pixo_v4u __attribute__((ext_vector_type(4)));
+#define PIXO_GSTORE(ptr, val) __builtin_nontemporal_store(__builtin_bit_cast(pixo_v4u, (val)), (pixo_v4u *)(ptr))
+#endif
 struct alignas(16) u32x4 { uint32_t x, y, z, w; };
 
 // ---------------------------------------------------------------------------------
@@ -615,11 +621,11 @@ PIXO_DEV void consumer_store_half(const TileCtx &c, uint32_t tile_x, uint32_t ti
             const size_t mcu0 = (size_t)tile_y * c.units_x + u0;
             if (wave < 2) {
                 if ((uint32_t)(wave * 16 + (bl >> 2)) < nvalid)
-                    *(u32x4 *)(c.y + (mcu0 * 4 + wave * 64 + bl) * 64 + j * 8) = w;
+                    PIXO_GSTORE(c.y + (mcu0 * 4 + wave * 64 + bl) * 64 + j * 8, w);
             } else {
                 const int m = bl & 31;
                 int16_t *dst = (bl < 32 ? c.cb : c.cr) + (mcu0 + m) * 64 + j * 8;
-                if ((uint32_t)m < nvalid) *(u32x4 *)dst = w;
+                if ((uint32_t)m < nvalid) PIXO_GSTORE(dst, w);
             }
         } else if (MODE == M444) {
             const size_t blk0 = (size_t)tile_y * c.units_x + u0;
@@ -627,14 +633,14 @@ PIXO_DEV void consumer_store_half(const TileCtx &c, uint32_t tile_x, uint32_t ti
             // makes the compiler spill the context to scratch and index it
             const size_t off = (blk0 + bl) * 64 + j * 8;
             if ((uint32_t)bl < nvalid) {
-                if (wave == 0) *(u32x4 *)(c.y + off) = w;
-                else if (wave == 1) *(u32x4 *)(c.cb + off) = w;
-                else *(u32x4 *)(c.cr + off) = w;
+                if (wave == 0) PIXO_GSTORE(c.y + off, w);
+                else if (wave == 1) PIXO_GSTORE(c.cb + off, w);
+                else PIXO_GSTORE(c.cr + off, w);
             }
         } else {
             const uint32_t brow = tile_y * 3 + wave;
             if ((uint32_t)bl < nvalid && brow < c.units_y)
-                *(u32x4 *)(c.y + ((size_t)brow * c.units_x + u0 + bl) * 64 + j * 8) = w;
+                PIXO_GSTORE(c.y + ((size_t)brow * c.units_x + u0 + bl) * 64 + j * 8, w);
         }
     }
 }

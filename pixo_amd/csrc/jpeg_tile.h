@@ -475,10 +475,12 @@ PIXO_DEV void quant_row8(const float *x, const float *rcp, qtab_t q, float scale
 }
 
 // LDS stage of one consumer wavefront: 4 KiB holding rows [4 half, 4 half + 4) of its 64 blocks.
-// Chunk (block bl, row r in 0..3) lives at 64 bl + 16 (r ^ (bl & 3)): the per-block
-// ds_write_b128 (lane = block, 64-B stride) then touches four different 16-B slots per 128 B
-// instead of one, and the read-back (lane = chunk) is linear up to that permutation.
-PIXO_DEV int stage_addr(int bl, int r) { return bl * 64 + ((r ^ (bl & 3)) << 4); }
+// Chunk (block bl, row r in 0..3) lives at 64 bl + 16 ((r ^ (bl >> 1)) & 3).  ds_write_b128 is
+// served in groups of 8 consecutive lanes (= blocks) against 32 banks = 128 B: blocks of equal
+// parity share a 64-byte half of that window, and the four of them in a group (bl >> 1 =
+// 0..3 mod 4) take its four different 16-byte slots — conflict-free.  The read-back (lane =
+// chunk, 4 lanes per block) touches all four slots of each block whatever the permutation.
+PIXO_DEV int stage_addr(int bl, int r) { return bl * 64 + (((r ^ (bl >> 1)) & 3) << 4); }
 
 // Block kinds (wave-uniform): quantiser table, DC shift of the row pass, scale.
 //   luminance            samples b,  level shift 128          row DC shift 8*128 = 1024

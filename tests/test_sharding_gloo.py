@@ -1,0 +1,69 @@
+"""The N>1 path on CPU: the image is sharded into MCU-row bands across ranks exactly as
+bench.py / a multi-GPU caller shards it (pixo_hip_band), every rank produces its band's
+coefficients independently (here with the oracle standing in for the rank's GPU — the point
+is the sharding and stitching logic, not the arithmetic), rank 0 gathers them over gloo and
+runs the product's host entropy coder: the file must be byte-identical to the single-rank
+result.  world_size 2, 127.0.0.1 rendezvous."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, ct, ss, q, ret):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch
+    import torch.distributed as dist
+    import oracle_lib as O
+    import synth
+    from pixo_amd import ColorType, jpeg
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    px = synth.noise_gray(w, h, 77) if ct == 0 else synth.noise(w, h, 77)
+    bpp = 1 if ct == 0 else 3
+    b = jpeg.band(w, h, ct, ss, world, rank)
+    rows = b["row_end"] - b["row_begin"]
+    sub = px[b["row_begin"] * w * bpp: b["row_end"] * w * bpp]
+    y, cb, cr = O.coeffs(sub, w, rows, ct, ss, q) if rows else (np.zeros((0, 64), np.int16),) * 3
+    assert y.shape[0] == b["y_blocks"] and cb.shape[0] == b["c_blocks"]
+    parts = [None] * world
+    dist.gather_object((y, cb, cr), parts if rank == 0 else None, dst=0)
+    if rank == 0:
+        Y = np.concatenate([p[0] for p in parts])
+        CB = np.concatenate([p[1] for p in parts])
+        CR = np.concatenate([p[2] for p in parts])
+        o = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss)).build()
+        got = jpeg.entropy_encode(Y, CB, CR, o)
+        want = O.encode(px, O.make_options(w, h, ct, q, ss))
+        ret.put(got == want)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [(333, 211, 2, 1, 80), (100, 75, 2, 0, 60), (64, 40, 0, 0, 90), (40, 16, 2, 1, 80)])
+def test_two_rank_band_sharding_is_byte_identical(case):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port) + case + (ret,)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True

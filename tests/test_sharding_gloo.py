@@ -1,9 +1,8 @@
-"""The N>1 path on CPU: the image is sharded into MCU-row bands across ranks exactly as
-bench.py / a multi-GPU caller shards it (pixo_hip_band), every rank produces its band's
-coefficients independently (here with the oracle standing in for the rank's GPU — the point
-is the sharding and stitching logic, not the arithmetic), rank 0 gathers them over gloo and
-runs the product's host entropy coder: the file must be byte-identical to the single-rank
-result.  world_size 2, 127.0.0.1 rendezvous."""
+"""The N>1 path on CPU: `pixo_amd.sharded.encode_banded` shards the image into MCU-row bands
+across ranks (pixo_hip_band), every rank produces its band's coefficients independently (here
+with the oracle standing in for the rank's GPU — the point is the sharding and stitching logic,
+not the arithmetic), rank 0 gathers them over gloo and runs the product's host entropy coder:
+the file must be byte-identical to the single-rank result.  world_size 2, 127.0.0.1 rendezvous."""
 import os
 import socket
 import sys
@@ -34,22 +33,17 @@ def _worker(rank, world, port, w, h, ct, ss, q, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     px = synth.noise_gray(w, h, 77) if ct == 0 else synth.noise(w, h, 77)
-    bpp = 1 if ct == 0 else 3
-    b = jpeg.band(w, h, ct, ss, world, rank)
-    rows = b["row_end"] - b["row_begin"]
-    sub = px[b["row_begin"] * w * bpp: b["row_end"] * w * bpp]
-    y, cb, cr = O.coeffs(sub, w, rows, ct, ss, q) if rows else (np.zeros((0, 64), np.int16),) * 3
-    assert y.shape[0] == b["y_blocks"] and cb.shape[0] == b["c_blocks"]
-    parts = [None] * world
-    dist.gather_object((y, cb, cr), parts if rank == 0 else None, dst=0)
+    from pixo_amd import sharded
+
+    def cpu_coeffs(sub, o):  # stands in for the rank's GPU
+        return O.coeffs(sub, o.width, o.height, int(o.color_type), int(o.subsampling), o.quality)
+
+    o = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss)).build()
+    got = sharded.encode_banded(px, o, coeff_fn=cpu_coeffs)
     if rank == 0:
-        Y = np.concatenate([p[0] for p in parts])
-        CB = np.concatenate([p[1] for p in parts])
-        CR = np.concatenate([p[2] for p in parts])
-        o = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss)).build()
-        got = jpeg.entropy_encode(Y, CB, CR, o)
-        want = O.encode(px, O.make_options(w, h, ct, q, ss))
-        ret.put(got == want)
+        ret.put(got == O.encode(px, O.make_options(w, h, ct, q, ss)))
+    else:
+        assert got is None
     dist.barrier()
     dist.destroy_process_group()
 

@@ -2,9 +2,9 @@
 //
 // The per-tile body lives in jpeg_tile.h (shared with the CPU emulation harness in
 // tests/emu).  This file adds the __global__ wrapper, the tile -> image mapping and the
-// host-side launch function.  Written for CDNA4 only: 64-lane wavefronts, 256-thread
-// workgroups (4 waves, one per SIMD), one 512-pixel-wide tile per workgroup, >= 2048
-// workgroups per 4096x4096 image (8 per CU, 6 resident at a time).
+// host-side launch function.  Written for CDNA4 only: 64-lane wavefronts, 192-thread
+// workgroups (3 waves), one 512-pixel-wide tile per workgroup, 2048 workgroups per 4096x4096
+// 4:2:0 image (8 per CU, all resident at once).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -26,7 +26,7 @@ struct KArgs {
     size_t px_stride; // bytes between consecutive images of a batch
     size_t y_stride;  // i16 elements between images
     size_t c_stride;
-    unsigned long long *dbg; // PIXO_TIMING builds only: per-workgroup cycle sums
+    unsigned long long *dbg; // PIXO_TIMING builds only: per-wavefront stamps (tools/wave_probe.py)
 };
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, which would
@@ -68,61 +68,106 @@ __device__ __forceinline__ TileCtx ctx_of(const KArgs &a, uint32_t img)
     return c;
 }
 
-// One tile per workgroup.  All four wavefronts load and colour-convert a quarter of the tile
-// each (phase A), one LDS barrier, then three wavefronts transform, quantise and store 64 blocks
-// each (phase B; the fourth has nothing to do for 4:2:0 / 4:4:4 and exits).  A wavefront stages
-// its quantised blocks in the LDS area its own planar samples came from — it has consumed them
-// all by then — so phase B needs no barrier and the workgroup only ~17 KiB of LDS.
-// Overlap of HBM latency with VALU work comes from the other resident workgroups (6 per CU:
-// 79 VGPRs, 17 KiB LDS) being in other phases; they drift apart as workgroups retire and are
-// replaced.  Measured alternatives (persistent loop with register prefetch; role-specialised
-// producer/consumer wavefronts with double-buffered LDS) were 5-10 % slower: DESIGN.md.
-template <int MODE, bool FAST>
-__global__ __launch_bounds__(kThreads, 4) void jpeg_coeffs_kernel(const KArgs a)
+// Phase A of one wavefront: COUNT items [first, first + COUNT) of the tile, HBM -> registers ->
+// planar LDS.  All loads are issued before the first conversion (no branch near a load).
+template <int MODE, bool FAST, int COUNT>
+__device__ __forceinline__ void phase_a(const TileCtx &c, const TileId &id, int first, int lane, uint8_t *lds,
+                                        unsigned long long *stamps = nullptr)
 {
     typedef Geo<MODE> G;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[G::planar];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const TileId id = locate(a, blockIdx.x);
-    const TileCtx c = ctx_of(a, id.img);
-    constexpr int Q = G::items / 4; // items per wavefront
-    uint32_t r[Q * G::item_regs];
-#if defined(PIXO_ABLATE) && PIXO_ABLATE == 5 // (timing experiments only: no loads)
-    for (int i = 0; i < Q * G::item_regs; i++) r[i] = lane * 77 + i;
+    uint32_t r[COUNT * G::item_regs];
+#if defined(PIXO_ABLATE) && (PIXO_ABLATE == 5 || PIXO_ABLATE == 6 || PIXO_ABLATE == 7) // (timing experiments only: no loads)
+    for (int i = 0; i < COUNT * G::item_regs; i++) r[i] = lane * 77 + i;
 #else
 #pragma unroll
-    for (int j = 0; j < Q; j++) producer_load_item<MODE, FAST>(c, id.tx, id.ty, wave * Q + j, lane, &r[j * G::item_regs]);
+    for (int j = 0; j < COUNT; j++) producer_load_item<MODE, FAST>(c, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
 #endif
 #pragma unroll
-    for (int j = 0; j < Q; j++) {
-#if !defined(PIXO_ABLATE) || PIXO_ABLATE < 2 // (timing experiments only: 2..5 drop the colour conversion)
-        producer_fix_item<MODE, FAST>(c, id.tx, wave * Q + j, lane, &r[j * G::item_regs]);
-        producer_color_item<MODE>(wave * Q + j, lane, &r[j * G::item_regs], lds);
+    for (int j = 0; j < COUNT; j++) {
+#ifdef PIXO_TIMING
+        if (j == 0) { // when did the first item's / all items' pixels arrive? (scalar instructions only)
+            for (int i = 0; i < G::item_regs; i++) asm volatile("" : "+v"(r[i]));
+            asm volatile("s_nop 0" ::: "memory");
+            stamps[0] = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamps[1] = __builtin_readcyclecounter();
+        }
+#endif
+#if !defined(PIXO_ABLATE) || PIXO_ABLATE < 2 || PIXO_ABLATE == 6 // (timing experiments only: 2..5, 7 drop the colour conversion)
+        producer_fix_item<MODE, FAST>(c, id.tx, first + j, lane, &r[j * G::item_regs]);
+        producer_color_item<MODE>(first + j, lane, &r[j * G::item_regs], lds);
 #else
         for (int i = 0; i < G::item_regs; i++) asm volatile("" ::"v"(r[j * G::item_regs + i]));
 #endif
     }
+}
+
+// One tile per workgroup of THREE wavefronts.  Phase A: the wavefronts share the tile's items
+// 6/5/5 (16/16/16 for grey), load them and colour-convert them into planar LDS; one LDS barrier;
+// phase B: each wavefront transforms, quantises and stores 64 blocks (one per lane), staging the
+// quantised rows in the LDS area its own planar samples came from — it has consumed them all by
+// then — so phase B needs no barrier and the workgroup only ~17 KiB of LDS.
+// Three waves, not four: the tile has exactly 3 x 64 blocks, so a fourth wavefront would idle
+// through phase B (70 % of the work) while holding a wave slot; with 3-wave workgroups the 24
+// wave slots of a CU (79 VGPRs -> 6 per SIMD) hold all 8 tiles a CU gets of a 4096x4096 image at
+// once: every load is issued in the first microsecond and the VALU stays saturated to the end
+// (a single wavefront can issue only every ~4.3 cycles; two per SIMD are needed to fill it).
+// Measured alternatives (4-wave workgroups; persistent loop with register prefetch;
+// role-specialised producer/consumer wavefronts with double-buffered LDS): DESIGN.md.
+template <int MODE, bool FAST>
+__global__ __launch_bounds__(kThreads) void jpeg_coeffs_kernel(const KArgs a)
+{
+    typedef Geo<MODE> G;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[G::planar];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#ifdef PIXO_TIMING
+    const unsigned long long t_start = __builtin_readcyclecounter(), w_start = __builtin_amdgcn_s_memrealtime();
+#endif
+    const TileId id = locate(a, blockIdx.x);
+    const TileCtx c = ctx_of(a, id.img);
+    constexpr int base = G::items / kWaves, extra = G::items % kWaves;
+#ifdef PIXO_TIMING
+    unsigned long long t_data[2] = {0, 0};
+    if (extra && wave < extra) phase_a<MODE, FAST, base + 1>(c, id, wave * (base + 1), lane, lds, t_data);
+    else phase_a<MODE, FAST, base>(c, id, extra * (base + 1) + (wave - extra) * base, lane, lds, t_data);
+    const unsigned long long t_colour = __builtin_readcyclecounter();
     lds_barrier();
-    if (wave < 3) {
-        float v[64];
-#if !defined(PIXO_ABLATE) || PIXO_ABLATE == 3 // (1, 2, 4, 5: no transform; 3: transform, no colour)
-        consumer_rows<MODE>(wave, lane, lds, v);
-        consumer_cols(v);
+    const unsigned long long t_bar = __builtin_readcyclecounter();
 #else
-        for (int i = 0; i < 64; i++) v[i] = (float)(lane + i);
+    if (extra && wave < extra) phase_a<MODE, FAST, base + 1>(c, id, wave * (base + 1), lane, lds);
+    else phase_a<MODE, FAST, base>(c, id, extra * (base + 1) + (wave - extra) * base, lane, lds);
+    lds_barrier();
 #endif
-        uint8_t *stage = lds + stage_offset<MODE>(wave); // inside this wavefront's own planar area
-        consumer_quant_half<MODE>(wave, lane, a.qt, v, 0, stage);
-#if !defined(PIXO_ABLATE) || PIXO_ABLATE != 4 // (4: no stores — one guarded store keeps the work alive)
-        consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 0, stage);
+    float v[64];
+#if !defined(PIXO_ABLATE) || PIXO_ABLATE == 3 || PIXO_ABLATE == 6 || PIXO_ABLATE == 7 // (1, 2, 4, 5: no transform; 3, 7: transform, no colour; 6: all compute, no HBM)
+    consumer_rows<MODE>(wave, lane, lds, v);
+    consumer_cols(v);
+#ifdef PIXO_TIMING
+    const unsigned long long t_dct = __builtin_readcyclecounter();
 #endif
-        consumer_quant_half<MODE>(wave, lane, a.qt, v, 1, stage);
-#if !defined(PIXO_ABLATE) || PIXO_ABLATE != 4
-        consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 1, stage);
 #else
-        if (*(volatile uint32_t *)(stage + lane * 4) == 0x12345678u) consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 1, stage);
+    for (int i = 0; i < 64; i++) v[i] = (float)(lane + i);
 #endif
+    uint8_t *stage = lds + stage_offset<MODE>(wave); // inside this wavefront's own planar area
+    consumer_quant_half<MODE>(wave, lane, a.qt, v, 0, stage);
+#if !defined(PIXO_ABLATE) || (PIXO_ABLATE != 4 && PIXO_ABLATE != 6 && PIXO_ABLATE != 7) // (4, 6, 7: no stores — one guarded store keeps the work alive)
+    consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 0, stage);
+#endif
+    consumer_quant_half<MODE>(wave, lane, a.qt, v, 1, stage);
+#if !defined(PIXO_ABLATE) || (PIXO_ABLATE != 4 && PIXO_ABLATE != 6 && PIXO_ABLATE != 7)
+    consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 1, stage);
+#else
+    if (*(volatile uint32_t *)(stage + lane * 4) == 0x12345678u) consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 1, stage);
+#endif
+#ifdef PIXO_TIMING
+    if (lane == 0 && a.dbg) {
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
+        d[0] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); d[1] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+        d[2] = t_start; d[3] = t_bar; d[4] = t_dct; d[5] = __builtin_readcyclecounter();
+        d[6] = w_start; d[7] = __builtin_amdgcn_s_memrealtime();
+        d[8] = t_data[0]; d[9] = t_data[1]; d[10] = t_colour;
     }
+#endif
 }
 
 template <int MODE, bool FAST> static hipError_t launch_mode(KArgs &a, hipStream_t s)
@@ -132,7 +177,9 @@ template <int MODE, bool FAST> static hipError_t launch_mode(KArgs &a, hipStream
     const uint64_t total64 = (uint64_t)a.tiles_x * a.tiles_y * a.batch;
     if (total64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const uint32_t total = (uint32_t)total64;
-    hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, FAST>), dim3(total), dim3(kThreads), 0, s, a);
+    // PIXO_HIP_LDS_PAD (bytes of unused dynamic LDS) lowers the residency for experiments
+    static const unsigned pad = getenv("PIXO_HIP_LDS_PAD") ? (unsigned)atoi(getenv("PIXO_HIP_LDS_PAD")) : 0u;
+    hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, FAST>), dim3(total), dim3(kThreads), pad, s, a);
     return hipGetLastError();
 }
 

@@ -69,7 +69,8 @@ namespace pixo_tile {
 
 enum Mode { M420 = 0, M444 = 1, MGRAY = 2 };
 
-constexpr int kThreads = 256;
+constexpr int kWaves = 3;         // wavefronts per workgroup = per tile (a tile has 3 x 64 blocks)
+constexpr int kThreads = 64 * kWaves;
 constexpr int kTileW = 512;     // pixels per tile row
 constexpr int kPitch = 528;     // planar row pitch, full-width planes (4:4:4, gray)
 constexpr int kPitchHalf = 272; // planar row pitch, 256-px half planes (4:2:0 luminance);

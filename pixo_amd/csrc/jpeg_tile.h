@@ -168,46 +168,77 @@ struct alignas(16) u32x4 { uint32_t x, y, z, w; };
 // phase A: colour conversion of 4 horizontally adjacent pixels held as 3 dwords
 //   d0 = R0 G0 B0 R1   d1 = G1 B1 R2 G2   d2 = B2 R3 G3 B3   (little-endian bytes)
 // ---------------------------------------------------------------------------------
+// a*b + c on two u16 lanes, SATURATING at 0xFFFF (v_pk_mad_u16 with the clamp bit).
+PIXO_DEV u16x2 mad_sat(u16x2 a, u16x2 b, u16x2 c)
+{
+#if defined(PIXO_EMU)
+    u16x2 o;
+    for (int i = 0; i < 2; i++) {
+        const uint32_t t = (uint32_t)a[i] * b[i] + c[i];
+        o[i] = (unsigned short)(t > 0xFFFFu ? 0xFFFFu : t);
+    }
+    return o;
+#else
+    u16x2 o;
+    asm("v_pk_mad_u16 %0, %1, %2, %3 clamp" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+#endif
+}
+
+// a*k + c on two u16 lanes, wrapping; k is a wave-uniform constant (scalar register).  Written
+// as the instruction itself: left to the compiler, u16 arithmetic is reassociated into
+// multiply + multiply-add + add chains (one more half-rate instruction per chain).
+PIXO_DEV u16x2 mad_k(u16x2 a, unsigned k, u16x2 c)
+{
+#if defined(PIXO_EMU)
+    return a * splat(k) + c;
+#else
+    u16x2 o;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(o) : "v"(a), "s"(k * 0x10001u), "v"(c));
+    return o;
+#endif
+}
+
+// Pixels are paired even/odd: lane pair E = (pixel 0, pixel 2), O = (pixel 1, pixel 3), so that
+// the horizontal neighbours a 4:2:0 box sum adds sit in the same u16 lane of E and O.
 struct Row4 {
-    uint32_t y4;      // Y0..Y3 as bytes
-    u16x2 cb01, cb23; // min(X'>>8, 254) per pixel  (= Cb - 1, see below)
-    u16x2 cr01, cr23;
+    uint32_t y4;    // Y0..Y3 as bytes
+    u16x2 cbE, cbO; // u16 per pixel whose HIGH byte is Cb (low byte: discarded fraction)
+    u16x2 crE, crO;
 };
 
 // color.rs:60-77 restated for packed u16 lanes.
 //   Y  = (77R + 150G + 29B + 128) >> 8            max 65408: fits u16, clamp is a no-op.
-//   Cb = ((-43R - 85G + 128B + 128) >> 8) + 128.  With X' = 128B + 32640 - 43R - 85G
-//        (always in [0, 65280], so u16 arithmetic never wraps in the final value),
-//        Cb = (X' >> 8) + 1, and the reference's clamp to 255 is min(X' >> 8, 254) + 1.
-//   Cr = same with X' = 128R + 32640 - 107G - 21B.
-// The "+1" is folded into the level shift of phase B, which is exact.  Arithmetic >> on
-// negative i32 in the reference equals the floor that the biased unsigned shift computes.
+//   Cb = clamp(((-43R - 85G + 128B + 128) >> 8) + 128, 0, 255)
+//      = min((X >> 8), 255)  with  X = 128B + I,  I = 32896 - 43R - 85G  in [256, 32896].
+//        I is formed with wrapping u16 multiply-adds (multipliers 65536-43, 65536-85: the
+//        true value is in range, so the wrapped result is it).  128B + I <= 65536 and reaches
+//        65536 only for B = 255, R = G = 0 — exactly the one colour the reference clamps
+//        (256 -> 255): the last multiply-add SATURATES, 0xFFFF >> 8 = 255.  No min, no +-1.
+//   Cr = same with X = 128R + I,  I = 32896 - 107G - 21B.
+// Arithmetic >> on negative i32 in the reference equals the floor that the biased unsigned
+// high byte takes.
 PIXO_DEV Row4 color_row4(uint32_t d0, uint32_t d1, uint32_t d2)
 {
-    u16x2 r01 = pk(perm(d0, d0, 0x0C030C00u));
-    u16x2 g01 = pk(perm(d1, d0, 0x0C040C01u));
-    u16x2 b01 = pk(perm(d1, d0, 0x0C050C02u));
-    u16x2 r23 = pk(perm(d2, d1, 0x0C050C02u));
-    u16x2 g23 = pk(perm(d2, d1, 0x0C060C03u));
-    u16x2 b23 = pk(perm(d2, d2, 0x0C030C00u));
+    u16x2 rE = pk(perm(d1, d0, 0x0C060C00u)); // R0 R2
+    u16x2 gE = pk(perm(d1, d0, 0x0C070C01u)); // G0 G2
+    u16x2 bE = pk(perm(d2, d0, 0x0C040C02u)); // B0 B2
+    u16x2 rO = pk(perm(d2, d0, 0x0C050C03u)); // R1 R3
+    u16x2 gO = pk(perm(d2, d1, 0x0C060C00u)); // G1 G3
+    u16x2 bO = pk(perm(d2, d1, 0x0C070C01u)); // B1 B3
 
-    u16x2 y01 = r01 * splat(77) + (g01 * splat(150) + (b01 * splat(29) + splat(128)));
-    u16x2 y23 = r23 * splat(77) + (g23 * splat(150) + (b23 * splat(29) + splat(128)));
-
-    const u16x2 kM43 = splat(65536 - 43), kM85 = splat(65536 - 85);
-    const u16x2 kM107 = splat(65536 - 107), kM21 = splat(65536 - 21);
-    u16x2 cb01 = r01 * kM43 + (g01 * kM85 + (b01 * splat(128) + splat(32640)));
-    u16x2 cb23 = r23 * kM43 + (g23 * kM85 + (b23 * splat(128) + splat(32640)));
-    u16x2 cr01 = g01 * kM107 + (b01 * kM21 + (r01 * splat(128) + splat(32640)));
-    u16x2 cr23 = g23 * kM107 + (b23 * kM21 + (r23 * splat(128) + splat(32640)));
-
+    // (a VOP3P instruction may read one scalar operand: the two constant addends live in VGPRs)
+    u16x2 k128 = splat(128), kI = splat(32896);
+    PIXO_PIN(k128); PIXO_PIN(kI);
+    const unsigned kM43 = 65536 - 43, kM85 = 65536 - 85, kM107 = 65536 - 107, kM21 = 65536 - 21;
+    u16x2 yE = mad_k(rE, 77, mad_k(gE, 150, mad_k(bE, 29, k128)));
+    u16x2 yO = mad_k(rO, 77, mad_k(gO, 150, mad_k(bO, 29, k128)));
     Row4 o;
-    o.y4 = perm(bits(y23), bits(y01), 0x07050301u); // high byte of each u16 lane
-    const u16x2 k254 = splat(254);
-    o.cb01 = __builtin_elementwise_min(cb01 >> 8, k254);
-    o.cb23 = __builtin_elementwise_min(cb23 >> 8, k254);
-    o.cr01 = __builtin_elementwise_min(cr01 >> 8, k254);
-    o.cr23 = __builtin_elementwise_min(cr23 >> 8, k254);
+    o.y4 = perm(bits(yO), bits(yE), 0x07030501u); // high byte of each u16 lane, pixel order
+    o.cbE = mad_sat(bE, k128, mad_k(rE, kM43, mad_k(gE, kM85, kI)));
+    o.cbO = mad_sat(bO, k128, mad_k(rO, kM43, mad_k(gO, kM85, kI)));
+    o.crE = mad_sat(rE, k128, mad_k(gE, kM107, mad_k(bE, kM21, kI)));
+    o.crO = mad_sat(rO, k128, mad_k(gO, kM107, mad_k(bO, kM21, kI)));
     return o;
 }
 
@@ -322,24 +353,23 @@ template <int MODE> PIXO_DEV void producer_color_item(int k, int lane, const uin
     const int h = k & 1, g = h * 64 + lane, row = k >> 1;
     if (MODE == M420) {
         Row4 a = color_row4(r[0], r[1], r[2]);
-        PIXO_SCHED_FENCE(); // one row at a time: the producer carries two tiles of pixels in registers
+        PIXO_SCHED_FENCE(); // one row at a time: few temporaries
         Row4 b = color_row4(r[3], r[4], r[5]);
         uint8_t *yp = planar + h * 4352 + (2 * row) * kPitchHalf + 4 * lane;
         *(uint32_t *)yp = a.y4;
         *(uint32_t *)(yp + kPitchHalf) = b.y4;
-        // 2x2 box sums (jpeg/mod.rs:1641-1646): vertical then horizontal, u16 exact
-        uint32_t cb01 = bits(a.cb01 + b.cb01), cb23 = bits(a.cb23 + b.cb23);
-        uint32_t cr01 = bits(a.cr01 + b.cr01), cr23 = bits(a.cr23 + b.cr23);
-        u16x2 cbs = pk(perm(cb23, cb01, 0x05040100u)) + pk(perm(cb23, cb01, 0x07060302u));
-        u16x2 crs = pk(perm(cr23, cr01, 0x05040100u)) + pk(perm(cr23, cr01, 0x07060302u));
+        // 2x2 box sums (jpeg/mod.rs:1641-1646) of the high bytes, u16 exact (<= 1020):
+        // even + odd lanes = horizontal neighbours, then the two rows
+        u16x2 cbs = ((a.cbE >> 8) + (a.cbO >> 8)) + ((b.cbE >> 8) + (b.cbO >> 8));
+        u16x2 crs = ((a.crE >> 8) + (a.crO >> 8)) + ((b.crE >> 8) + (b.crO >> 8));
         *(uint32_t *)(planar + 8704 + row * 512 + 4 * g) = bits(cbs);
         *(uint32_t *)(planar + 12800 + row * 512 + 4 * g) = bits(crs);
     } else if (MODE == M444) {
         Row4 a = color_row4(r[0], r[1], r[2]);
         uint8_t *p = planar + row * kPitch + 4 * g;
         *(uint32_t *)p = a.y4;
-        *(uint32_t *)(p + 4224) = perm(bits(a.cb23), bits(a.cb01), 0x06040200u);
-        *(uint32_t *)(p + 8448) = perm(bits(a.cr23), bits(a.cr01), 0x06040200u);
+        *(uint32_t *)(p + 4224) = perm(bits(a.cbO), bits(a.cbE), 0x07030501u);
+        *(uint32_t *)(p + 8448) = perm(bits(a.crO), bits(a.crE), 0x07030501u);
     } else {
         *(uint32_t *)(planar + (row >> 3) * 4224 + (row & 7) * kPitch + 4 * g) = r[0];
     }
@@ -484,10 +514,9 @@ PIXO_DEV void quant_row8(const float *x, const float *rcp, qtab_t q, float scale
 PIXO_DEV int stage_addr(int bl, int r) { return bl * 64 + (((r ^ (bl >> 1)) & 3) << 4); }
 
 // Block kinds (wave-uniform): quantiser table, DC shift of the row pass, scale.
-//   luminance            samples b,  level shift 128          row DC shift 8*128 = 1024
-//   chroma 4:4:4         bytes hold C-1 (see color_row4)      row DC shift 8*127 = 1016
-//   chroma 4:2:0 (U16)   2x2 sums S = 4*mean - 4, transform at 4x scale:
-//                        mean - 128 = (S - 508)/4             row DC shift 8*508 = 4064
+//   luminance, chroma 4:4:4   samples b, level shift 128     row DC shift 8*128 = 1024
+//   chroma 4:2:0 (U16)        2x2 sums S = 4*mean, transform at 4x scale:
+//                             mean - 128 = (S - 512)/4       row DC shift 8*512 = 4096
 // `src` points at this lane's first planar row; rows are `pitch` bytes apart and are read from
 // LDS as the row pass needs them (2-4 registers), not staged in 16-32 registers.
 template <bool U16>
@@ -577,10 +606,10 @@ template <int MODE> PIXO_DEV BlockDesc block_desc(int wave, int lane, const uint
             d.pitch = kPitchHalf;
         } else {
             d.src = planar + 8704 + (lane >> 5) * 4096 + (lane & 31) * 16;
-            d.pitch = 512; d.u16 = true; d.rcp_off = 256; d.q_off = 192; d.dc_shift = 4064.0f; d.scale = 0.25f;
+            d.pitch = 512; d.u16 = true; d.rcp_off = 256; d.q_off = 192; d.dc_shift = 4096.0f; d.scale = 0.25f;
         }
     } else if (MODE == M444) {
-        if (wave >= 1) { d.rcp_off = 64; d.q_off = 192; d.dc_shift = 1016.0f; }
+        if (wave >= 1) { d.rcp_off = 64; d.q_off = 192; }
     }
     return d;
 }
@@ -589,7 +618,7 @@ template <int MODE> PIXO_DEV BlockDesc block_desc(int wave, int lane, const uint
 template <int MODE> PIXO_DEV void consumer_rows(int wave, int lane, const uint8_t *planar, float *v)
 {
     const BlockDesc d = block_desc<MODE>(wave, lane, planar);
-    if (MODE == M420 && d.u16) block_rows<true>(d.src, 512, 4064.0f, v);
+    if (MODE == M420 && d.u16) block_rows<true>(d.src, 512, 4096.0f, v);
     else block_rows<false>(d.src, d.pitch, d.dc_shift, v);
 }
 

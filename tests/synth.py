@@ -53,6 +53,12 @@ def noise(w: int, h: int, seed: int = 42) -> np.ndarray:
     return lcg_bytes(w * h * 3, seed)
 
 
+def extremes(w: int, h: int, seed: int = 42) -> np.ndarray:
+    """RGB noise whose channels only take the values 0, 1, 254, 255: every pixel sits on or next
+    to a corner of the colour cube, so neighbouring pixels mix clamped and unclamped chroma."""
+    return np.array([0, 1, 254, 255], np.uint8)[lcg_bytes(w * h * 3, seed) >> 6]
+
+
 def noise_gray(w: int, h: int, seed: int = 42) -> np.ndarray:
     return lcg_bytes(w * h, seed)
 

@@ -64,6 +64,9 @@ def test_saturated_colours_hit_the_chroma_clamp():
         px = np.tile(np.array(rgb, np.uint8), 64 * 32)
         _same(px, 64, 32, 2, 1, 100)
         _same(px, 64, 32, 2, 0, 100)
+    for seed in (1, 2, 3):  # clamped and unclamped pixels inside the same 2x2 box / block
+        _same(synth.extremes(80, 48, seed), 80, 48, 2, 1, 100)
+        _same(synth.extremes(80, 48, seed), 80, 48, 2, 0, 90)
 
 
 @pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])

@@ -69,6 +69,9 @@ def test_saturated_colours():
         px = np.tile(np.array(rgb, np.uint8), 64 * 32)
         _check_coeffs(px, 64, 32, 2, 1, 100)
         _check_coeffs(px, 64, 32, 2, 0, 100)
+    for seed in (1, 2, 3):  # clamped and unclamped pixels inside the same 2x2 box / block
+        _check_coeffs(synth.extremes(600, 48, seed), 600, 48, 2, 1, 100)
+        _check_coeffs(synth.extremes(600, 48, seed), 600, 48, 2, 0, 90)
 
 
 def test_config1_512_and_config3_unit_1080p_files():

@@ -378,29 +378,31 @@ template <int MODE> PIXO_DEV void producer_color_item(int k, int lane, const uin
 // ---------------------------------------------------------------------------------
 // consumers: one lane = one 8x8 block
 // ---------------------------------------------------------------------------------
-// A sample byte b (or 2x2 sum S) becomes the float 2^23 + b by OR-ing it into the mantissa
-// of 0x4B000000 — full-rate VALU ops instead of v_cvt (half rate) + level-shift subtract.
-// The bias and the JPEG level shift never need a per-sample operation: the row transform's
-// first butterflies cancel the bias (aan8_biased) and the level shift only reaches the DC
-// term of each row, where one subtraction removes it (all values involved are exact small
-// integers in f32, so this is the same arithmetic as the reference's `x as f32 - 128.0`).
-constexpr uint32_t kBiasBits = 0x4B000000u; // 2^23
-
-PIXO_DEV float biased(uint32_t small) { return __builtin_bit_cast(float, kBiasBits | small); }
-
+// Samples (bytes, or 2x2 sums in u16 lanes) become floats with one conversion each
+// (v_cvt_f32_ubyteN / v_cvt_f32_u32 with a sub-dword select: half rate, like every other way of
+// isolating a byte).  The JPEG level shift needs no per-sample operation: the row transform's
+// first butterflies are sums and differences of exact small integers, the shift cancels in
+// every difference and reaches only the DC term of the row, where one subtraction removes it
+// (same arithmetic as the reference's `x as f32 - 128.0`, all values exact integers in f32).
 PIXO_DEV void row_from_bytes(uint32_t lo, uint32_t hi, float *v)
 {
-    v[0] = biased(lo & 0xFF);         v[1] = biased((lo >> 8) & 0xFF);
-    v[2] = biased((lo >> 16) & 0xFF); v[3] = biased(lo >> 24);
-    v[4] = biased(hi & 0xFF);         v[5] = biased((hi >> 8) & 0xFF);
-    v[6] = biased((hi >> 16) & 0xFF); v[7] = biased(hi >> 24);
+    v[0] = (float)(lo & 0xFF);         v[1] = (float)((lo >> 8) & 0xFF);
+    v[2] = (float)((lo >> 16) & 0xFF); v[3] = (float)(lo >> 24);
+    v[4] = (float)(hi & 0xFF);         v[5] = (float)((hi >> 8) & 0xFF);
+    v[6] = (float)((hi >> 16) & 0xFF); v[7] = (float)(hi >> 24);
+    // (keeps LLVM from folding the first butterflies into integer SDWA adds + conversions:
+    // twice as many half-rate instructions)
+#pragma unroll
+    for (int i = 0; i < 8; i++) PIXO_PIN(v[i]);
 }
 PIXO_DEV void row_from_u16(u32x4 w, float *v)
 {
-    v[0] = biased(w.x & 0xFFFF); v[1] = biased(w.x >> 16);
-    v[2] = biased(w.y & 0xFFFF); v[3] = biased(w.y >> 16);
-    v[4] = biased(w.z & 0xFFFF); v[5] = biased(w.z >> 16);
-    v[6] = biased(w.w & 0xFFFF); v[7] = biased(w.w >> 16);
+    v[0] = (float)(w.x & 0xFFFF); v[1] = (float)(w.x >> 16);
+    v[2] = (float)(w.y & 0xFFFF); v[3] = (float)(w.y >> 16);
+    v[4] = (float)(w.z & 0xFFFF); v[5] = (float)(w.z >> 16);
+    v[6] = (float)(w.w & 0xFFFF); v[7] = (float)(w.w >> 16);
+#pragma unroll
+    for (int i = 0; i < 8; i++) PIXO_PIN(v[i]);
 }
 
 // f32 AAN DCT, dct.rs:651-700, operation for operation.
@@ -440,19 +442,15 @@ PIXO_DEV void aan8(float &d0, float &d1, float &d2, float &d3, float &d4, float 
     aan8_core(t0, t1, t2, t3, t4, t5, t6, t7, 0.0f, d0, d1, d2, d3, d4, d5, d6, d7);
 }
 
-// Row transform on biased inputs D_i = 2^23 + b_i.  Differences cancel the bias exactly;
-// a sum is formed as (D_i - 2^24) + D_j = (b_i - 2^23) + (2^23 + b_j) = b_i + b_j, both steps
-// exact.  The true inputs are b_i - L (level shift L), so the butterflies' sums carry +2L,
-// +4L, +8L and the differences nothing: only r0 needs the shift (8L = dc_shift).  Every
-// value up to the first multiplication is an exact integer below 2^14, so the reference's
-// own sequence of f32 additions yields the same numbers.
-PIXO_DEV void aan8_biased(float dc_shift, float &d0, float &d1, float &d2, float &d3, float &d4,
-                          float &d5, float &d6, float &d7)
+// Row transform on unshifted samples b_i (true inputs b_i - L): the butterflies' sums carry
+// +2L, +4L, +8L and the differences nothing, so only r0 needs the shift (8L = dc_shift).  Every
+// value up to the first multiplication is an exact integer below 2^14, so the reference's own
+// sequence of f32 additions yields the same numbers.
+PIXO_DEV void aan8_shift(float dc_shift, float &d0, float &d1, float &d2, float &d3, float &d4,
+                         float &d5, float &d6, float &d7)
 {
-    const float k2p24 = 16777216.0f;
-    float t7 = d0 - d7, t6 = d1 - d6, t5 = d2 - d5, t4 = d3 - d4;
-    float t0 = (d0 - k2p24) + d7, t1 = (d1 - k2p24) + d6;
-    float t2 = (d2 - k2p24) + d5, t3 = (d3 - k2p24) + d4;
+    float t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
+    float t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
     aan8_core(t0, t1, t2, t3, t4, t5, t6, t7, dc_shift, d0, d1, d2, d3, d4, d5, d6, d7);
 }
 
@@ -467,35 +465,51 @@ PIXO_DEV void aan8_biased(float dc_shift, float &d0, float &d1, float &d2, float
 // for r, half-away for f — give k.  Otherwise the row takes the exact divide.  Checked by
 // enumeration over every f32 |x| <= 4096 and every q in 1..255: tests/emu/sweep_quant.py.
 //
-// Built from full-rate gfx950 VALU ops only:
 //   s = r + 1.5*2^23      rounds r to an integer (RNE) and leaves it, two's complement, in
 //                         the low mantissa bits: bits(s) = 0x4B400000 + n for |n| < 2^22
 //   n = s - 1.5*2^23      exact;   d = r - n exact (|d| <= 1/2, Sterbenz)
-//   w = (|d| + 2^-21|r|) - 1/2      >= 0 (sign bit clear) iff the lane is risky
-//   acc &= bits(w)        the row is safe iff the sign bit survives all eight ANDs
-// `scale` (1 or 1/4) maps x back to the reference's magnitude for the exact path only; the
-// fast path's rcp already contains it (exact power of two).
+//   t = |d| + 2^-21|r|    (one fma) >= 1/2 iff the lane is risky; the row keeps the maximum
+//                         (v_max3_f32: two elements per instruction)
+// A flagged row (a few per cent of rows on noise, far fewer on photographs) repeats the test
+// per element and takes the reference's own divide only for the elements some lane flagged —
+// typically one of the eight.  `scale` (1 or 1/4) maps x back to the reference's magnitude for
+// the exact path only; the fast path's rcp already contains it (exact power of two).
 constexpr float kRoundMagic = 12582912.0f; // 1.5 * 2^23
+
+#if defined(PIXO_EMU)
+#define PIXO_ANY_LANE(pred) (pred)
+#else
+#define PIXO_ANY_LANE(pred) (__builtin_amdgcn_ballot_w64(pred) != 0)
+#endif
+
+PIXO_DEV float quant_risk(float r, float s)
+{
+    const float n = s - kRoundMagic;
+    const float d = r - n;
+    return __builtin_fmaf(__builtin_fabsf(r), 0x1p-21f, __builtin_fabsf(d));
+}
 
 PIXO_DEV void quant_row8(const float *x, const float *rcp, qtab_t q, float scale, uint32_t out[4])
 {
     float s[8];
-    uint32_t acc = 0x80000000u;
+    float worst = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-        float r = x[c] * rcp[c];
-        s[c] = r + kRoundMagic;
-        float n = s[c] - kRoundMagic;
-        float d = r - n;
-        float w = __builtin_fmaf(__builtin_fabsf(r), 0x1p-21f, __builtin_fabsf(d)) - 0.5f;
-        acc &= fbits(w);
+    for (int c = 0; c < 8; c += 2) {
+        const float r0 = x[c] * rcp[c], r1 = x[c + 1] * rcp[c + 1];
+        s[c] = r0 + kRoundMagic;
+        s[c + 1] = r1 + kRoundMagic;
+        worst = __builtin_fmaxf(__builtin_fmaxf(worst, quant_risk(r0, s[c])), quant_risk(r1, s[c + 1]));
     }
-    if ((acc & 0x80000000u) == 0) { // rare: a quotient within 2^-21 (relative) of a rounding boundary
+    if (PIXO_ANY_LANE(worst >= 0.5f)) { // rare: some quotient within 2^-21 (relative) of a rounding boundary
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-            float n = __builtin_roundf((x[c] * scale) / q[c]); // the reference operation itself
-            s[c] = n + kRoundMagic;                             // exact: |n| < 2^15
-            PIXO_SCHED_FENCE();                                 // one divide at a time: few temporaries
+            float xc = x[c];
+            PIXO_PIN(xc); // recompute the test here: reusing the fast path's values keeps 16 of them alive
+            if (PIXO_ANY_LANE(quant_risk(xc * rcp[c], s[c]) >= 0.5f)) {
+                const float n = __builtin_roundf((x[c] * scale) / q[c]); // the reference operation itself
+                s[c] = n + kRoundMagic;                                   // exact: |n| < 2^15
+            }
+            PIXO_SCHED_FENCE(); // one element at a time: few temporaries
         }
     }
     // low 16 bits of each s = the i16 result (never saturates: |x/q| <= 2^11)
@@ -531,10 +545,17 @@ PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v
             row_from_bytes(w.x, w.y, &v[r * 8]);
         }
 #ifndef PIXO_ABL_NOROWS // (timing experiments only)
-        aan8_biased(dc_shift, v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4],
+        aan8_shift(dc_shift, v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4],
                     v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
 #endif
-        if (r & 1) PIXO_SCHED_FENCE();
+        if (r & 1) {
+            // finish both rows (scale multiplications included) before the next pair starts:
+            // left free, the compiler batches all 64 scale multiplications after row 7 into
+            // fresh registers
+#pragma unroll
+            for (int i = 0; i < 16; i++) PIXO_PIN(v[(r - 1) * 8 + i]);
+            PIXO_SCHED_FENCE();
+        }
     }
 }
 

@@ -26,7 +26,7 @@ for ln in lines:
     op = t.split()[0]
     if op == "s_barrier": region += 1
     hot[(region, op)] += 1
-    if op == "s_cbranch_execz":
+    if op.startswith("s_cbranch_"):
         # quantiser slow path (fallthrough body) is skipped; other execz regions are small
         tgt = t.split()[1]
         # only skip when the body contains v_div_scale (look ahead)

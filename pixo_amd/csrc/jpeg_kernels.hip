@@ -27,6 +27,7 @@ struct KArgs {
     size_t y_stride;  // i16 elements between images
     size_t c_stride;
     unsigned long long *dbg; // PIXO_TIMING builds only: per-wavefront stamps (tools/wave_probe.py)
+    uint32_t prio_a;         // raise wave priority during phase A (single-generation launches)
 };
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, which would
@@ -123,6 +124,13 @@ __global__ __launch_bounds__(kThreads) void jpeg_coeffs_kernel(const KArgs a)
 #ifdef PIXO_TIMING
     const unsigned long long t_start = __builtin_readcyclecounter(), w_start = __builtin_amdgcn_s_memrealtime();
 #endif
+    // Launches whose workgroups are all resident at once (one 4096x4096 image: 8 per CU) run
+    // phase A at raised wave priority: the hardware otherwise issues oldest-first, the colour
+    // conversion of the younger workgroups waits behind the older ones' phase B, and few
+    // wavefronts are in phase B at any time (two per SIMD are needed to fill the VALU).
+    // With more workgroups than fit, the same setting delays the retirement of old workgroups
+    // and costs 9 % (measured), so it is a launch-time decision.
+    if (a.prio_a) __builtin_amdgcn_s_setprio(1);
     const TileId id = locate(a, blockIdx.x);
     const TileCtx c = ctx_of(a, id.img);
     constexpr int base = G::items / kWaves, extra = G::items % kWaves;
@@ -138,6 +146,7 @@ __global__ __launch_bounds__(kThreads) void jpeg_coeffs_kernel(const KArgs a)
     else phase_a<MODE, FAST, base>(c, id, extra * (base + 1) + (wave - extra) * base, lane, lds);
     lds_barrier();
 #endif
+    __builtin_amdgcn_s_setprio(0);
     float v[64];
 #if !defined(PIXO_ABLATE) || PIXO_ABLATE == 3 || PIXO_ABLATE == 6 || PIXO_ABLATE == 7 // (1, 2, 4, 5: no transform; 3, 7: transform, no colour; 6: all compute, no HBM)
     consumer_rows<MODE>(wave, lane, lds, v);
@@ -177,6 +186,9 @@ template <int MODE, bool FAST> static hipError_t launch_mode(KArgs &a, hipStream
     const uint64_t total64 = (uint64_t)a.tiles_x * a.tiles_y * a.batch;
     if (total64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const uint32_t total = (uint32_t)total64;
+    static const int cus = [] { int d = 0, n = 0; return hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess ? n : 256; }();
+    static const char *prio_env = getenv("PIXO_HIP_PRIO_A"); // experiments: force 0 / 1
+    a.prio_a = prio_env ? (uint32_t)atoi(prio_env) : (total <= 8u * (uint32_t)cus ? 1u : 0u);
     // PIXO_HIP_LDS_PAD (bytes of unused dynamic LDS) lowers the residency for experiments
     static const unsigned pad = getenv("PIXO_HIP_LDS_PAD") ? (unsigned)atoi(getenv("PIXO_HIP_LDS_PAD")) : 0u;
     hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, FAST>), dim3(total), dim3(kThreads), pad, s, a);

@@ -156,7 +156,11 @@ PIXO_DEV int uniform_i32(int v)
 }
 
 struct u32x2 { uint32_t x, y; };
-#if defined(PIXO_EMU) || !defined(PIXO_NT_STORES)
+// Coefficient stores are non-temporal (global_store_dwordx4 ... nt): the 50 MB a 4096x4096 image
+// produces are never read back by this kernel, and written with the default policy ~30 MB of them
+// are still dirty in the eight 4 MB L2s when the kernel ends — the end-of-kernel write-back then
+// adds ~3.5 us during which nothing else runs (29.2 -> 25.9 us with nt, measured).
+#if defined(PIXO_EMU) || defined(PIXO_ABL_PLAIN_STORES)
 #define PIXO_GSTORE(ptr, val) (*(u32x4 *)(ptr) = (val))
 #else
 typedef uint32_t pixo_v4u __attribute__((ext_vector_type(4)));
@@ -196,6 +200,25 @@ PIXO_DEV u16x2 mad_k(u16x2 a, unsigned k, u16x2 c)
     u16x2 o;
     asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(o) : "v"(a), "s"(k * 0x10001u), "v"(c));
     return o;
+#endif
+}
+
+// (high byte of e.lo + high byte of o.lo, high byte of e.hi + high byte of o.hi) as two u16
+// lanes: two SDWA adds with byte selects instead of two packed shifts and a packed add.  The
+// s_nop's cover the SDWA partial-write forwarding hazard, which the compiler cannot see inside
+// inline assembly.
+PIXO_DEV u16x2 add_high_bytes(u16x2 e, u16x2 o)
+{
+#if defined(PIXO_EMU)
+    return (e >> 8) + (o >> 8);
+#else
+    uint32_t d;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
+        "s_nop 0"
+        : "=&v"(d) : "v"(e), "v"(o));
+    return pk(d);
 #endif
 }
 
@@ -360,8 +383,8 @@ template <int MODE> PIXO_DEV void producer_color_item(int k, int lane, const uin
         *(uint32_t *)(yp + kPitchHalf) = b.y4;
         // 2x2 box sums (jpeg/mod.rs:1641-1646) of the high bytes, u16 exact (<= 1020):
         // even + odd lanes = horizontal neighbours, then the two rows
-        u16x2 cbs = ((a.cbE >> 8) + (a.cbO >> 8)) + ((b.cbE >> 8) + (b.cbO >> 8));
-        u16x2 crs = ((a.crE >> 8) + (a.crO >> 8)) + ((b.crE >> 8) + (b.crO >> 8));
+        u16x2 cbs = add_high_bytes(a.cbE, a.cbO) + add_high_bytes(b.cbE, b.cbO);
+        u16x2 crs = add_high_bytes(a.crE, a.crO) + add_high_bytes(b.crE, b.crO);
         *(uint32_t *)(planar + 8704 + row * 512 + 4 * g) = bits(cbs);
         *(uint32_t *)(planar + 12800 + row * 512 + 4 * g) = bits(crs);
     } else if (MODE == M444) {
@@ -475,6 +498,9 @@ PIXO_DEV void aan8_shift(float dc_shift, float &d0, float &d1, float &d2, float 
 // typically one of the eight.  `scale` (1 or 1/4) maps x back to the reference's magnitude for
 // the exact path only; the fast path's rcp already contains it (exact power of two).
 constexpr float kRoundMagic = 12582912.0f; // 1.5 * 2^23
+#ifndef PIXO_QUANT_EPS // (overridden only by tests/emu/sweep_quant.py experiments)
+#define PIXO_QUANT_EPS 0x1p-21f
+#endif
 
 #if defined(PIXO_EMU)
 #define PIXO_ANY_LANE(pred) (pred)
@@ -486,7 +512,7 @@ PIXO_DEV float quant_risk(float r, float s)
 {
     const float n = s - kRoundMagic;
     const float d = r - n;
-    return __builtin_fmaf(__builtin_fabsf(r), 0x1p-21f, __builtin_fabsf(d));
+    return __builtin_fmaf(__builtin_fabsf(r), PIXO_QUANT_EPS, __builtin_fabsf(d));
 }
 
 PIXO_DEV void quant_row8(const float *x, const float *rcp, qtab_t q, float scale, uint32_t out[4])
@@ -536,17 +562,25 @@ PIXO_DEV int stage_addr(int bl, int r) { return bl * 64 + (((r ^ (bl >> 1)) & 3)
 template <bool U16>
 PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v)
 {
+    // all eight planar rows are fetched first (16 or 32 registers that are free this early:
+    // v[] fills up only as the rows are transformed) so that the LDS latency is paid once
+    u32x4 raw16[U16 ? 8 : 1];
+    u32x2 raw8[U16 ? 1 : 8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        if (U16) {
-            row_from_u16(*(const u32x4 *)(src + r * pitch), &v[r * 8]);
-        } else {
-            u32x2 w = *(const u32x2 *)(src + r * pitch);
-            row_from_bytes(w.x, w.y, &v[r * 8]);
-        }
+        if (U16) raw16[r] = *(const u32x4 *)(src + r * pitch);
+        else raw8[r] = *(const u32x2 *)(src + r * pitch);
+    }
+#ifndef PIXO_ABL_NO_ROW_PREFETCH // (timing experiments only)
+    PIXO_SCHED_FENCE();
+#endif
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        if (U16) row_from_u16(raw16[r], &v[r * 8]);
+        else row_from_bytes(raw8[r].x, raw8[r].y, &v[r * 8]);
 #ifndef PIXO_ABL_NOROWS // (timing experiments only)
         aan8_shift(dc_shift, v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4],
-                    v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
+                   v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
 #endif
         if (r & 1) {
             // finish both rows (scale multiplications included) before the next pair starts:
@@ -658,14 +692,10 @@ PIXO_DEV void consumer_quant_half(int wave, int lane, const float *qt, const flo
 // Consumer step 4 (half = 0, 1): the wave's staged half blocks -> HBM.  Lane l of round k moves
 // chunk 64 k + l = (block, row): four consecutive lanes write 64 contiguous bytes of one block.
 // Reads only what this wavefront wrote in step 3 (program order, no barrier).
-template <int MODE>
-PIXO_DEV void consumer_store_half(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int wave, int lane,
-                                  int half, const uint8_t *stage)
+template <int MODE, bool GUARD>
+PIXO_DEV void store_half_body(const TileCtx &c, uint32_t u0, uint32_t nvalid, uint32_t tile_y, int wave, int lane,
+                              int half, const uint8_t *stage_wave)
 {
-    typedef Geo<MODE> G;
-    const uint32_t u0 = tile_x * G::units_x; // first MCU / block column of the tile
-    const uint32_t nvalid = c.units_x - u0 < (uint32_t)G::units_x ? c.units_x - u0 : G::units_x;
-    const uint8_t *stage_wave = stage;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int ch = k * 64 + lane, bl = ch >> 2, r = ch & 3, j = half * 4 + r;
@@ -673,17 +703,18 @@ PIXO_DEV void consumer_store_half(const TileCtx &c, uint32_t tile_x, uint32_t ti
         if (MODE == M420) {
             const size_t mcu0 = (size_t)tile_y * c.units_x + u0;
             if (wave < 2) {
-                if ((uint32_t)(wave * 16 + (bl >> 2)) < nvalid)
+                if (!GUARD || (uint32_t)(wave * 16 + (bl >> 2)) < nvalid)
                     PIXO_GSTORE(c.y + (mcu0 * 4 + wave * 64 + bl) * 64 + j * 8, w);
             } else {
                 const int m = bl & 31;
                 int16_t *dst = (bl < 32 ? c.cb : c.cr) + (mcu0 + m) * 64 + j * 8;
-                if ((uint32_t)m < nvalid) PIXO_GSTORE(dst, w);
+                if (!GUARD || (uint32_t)m < nvalid) PIXO_GSTORE(dst, w);
             }
         } else if (MODE == M444) {
             const size_t blk0 = (size_t)tile_y * c.units_x + u0;
-            // wave-uniform branches, one store each: selecting among c.y / c.cb / c.cr as VALUES
-            // makes the compiler spill the context to scratch and index it
+            // wave-uniform branches, one store each, inside a lane-divergent guard (kept even for
+            // interior tiles): without it the three stores are merged into one store through a
+            // select among c.y / c.cb / c.cr, which the compiler implements in scratch memory
             const size_t off = (blk0 + bl) * 64 + j * 8;
             if ((uint32_t)bl < nvalid) {
                 if (wave == 0) PIXO_GSTORE(c.y + off, w);
@@ -692,10 +723,24 @@ PIXO_DEV void consumer_store_half(const TileCtx &c, uint32_t tile_x, uint32_t ti
             }
         } else {
             const uint32_t brow = tile_y * 3 + wave;
-            if ((uint32_t)bl < nvalid && brow < c.units_y)
+            if (!GUARD || ((uint32_t)bl < nvalid && brow < c.units_y))
                 PIXO_GSTORE(c.y + ((size_t)brow * c.units_x + u0 + bl) * 64 + j * 8, w);
         }
     }
+}
+
+template <int MODE>
+PIXO_DEV void consumer_store_half(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int wave, int lane,
+                                  int half, const uint8_t *stage)
+{
+    typedef Geo<MODE> G;
+    const uint32_t u0 = tile_x * G::units_x; // first MCU / block column of the tile
+    const uint32_t nvalid = c.units_x - u0 < (uint32_t)G::units_x ? c.units_x - u0 : G::units_x;
+    // tiles that lie wholly inside the image (all but the right-most column; for grey also not
+    // the block rows below the image) store unguarded (4:4:4 keeps its guard, see above)
+    const bool inside = nvalid == (uint32_t)G::units_x && (MODE != MGRAY || tile_y * 3 + wave < c.units_y);
+    if (MODE != M444 && inside) store_half_body<MODE, false>(c, u0, nvalid, tile_y, wave, lane, half, stage);
+    else store_half_body<MODE, true>(c, u0, nvalid, tile_y, wave, lane, half, stage);
 }
 
 } // namespace pixo_tile

@@ -108,10 +108,7 @@ extern "C" void emu_quant_fastpath_audit(const float *x, long n, int q, long *fl
     for (long i = 0; i < n; i++) {
         float r = x[i] * rcp;
         float sm = r + kRoundMagic;
-        float nn = sm - kRoundMagic;
-        float d = r - nn;
-        float wv = __builtin_fmaf(__builtin_fabsf(r), 0x1p-21f, __builtin_fabsf(d)) - 0.5f;
-        bool risky = !(__builtin_bit_cast(uint32_t, wv) & 0x80000000u);
+        bool risky = quant_risk(r, sm) >= 0.5f; // the kernel's own test (jpeg_tile.h)
         int16_t got = (int16_t)(__builtin_bit_cast(uint32_t, sm) & 0xFFFF);
         if (risky) f++;
         else if ((float)got != roundf(x[i] / fq)) w++;
@@ -134,10 +131,7 @@ extern "C" void emu_quant_exhaustive(int q, uint32_t lo_bits, uint32_t hi_bits, 
             float want = roundf(x / fq);
             float r = x * rcp;
             float sm = r + kRoundMagic;
-            float nn = sm - kRoundMagic;
-            float d = r - nn;
-            float wv = __builtin_fmaf(__builtin_fabsf(r), 0x1p-21f, __builtin_fabsf(d)) - 0.5f;
-            bool risky = !(__builtin_bit_cast(uint32_t, wv) & 0x80000000u);
+            bool risky = quant_risk(r, sm) >= 0.5f; // the kernel's own test (jpeg_tile.h)
             float got = (float)(int16_t)(__builtin_bit_cast(uint32_t, sm) & 0xFFFF);
             if (risky) { f++; got = want; }
             else if (got != want) w++;

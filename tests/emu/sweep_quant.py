@@ -19,7 +19,8 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 def one(q):
     import emu_lib as E
-    L = E.lib()
+    # PIXO_EMU_LIB: an emulation library built with another -DPIXO_QUANT_EPS (experiments)
+    L = C.CDLL(os.environ["PIXO_EMU_LIB"]) if os.environ.get("PIXO_EMU_LIB") else E.lib()
     L.emu_quant_exhaustive.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     hi = struct.unpack("<I", struct.pack("<f", 4096.0))[0]
     f, w, wf = C.c_long(), C.c_long(), C.c_long()
@@ -33,7 +34,7 @@ if __name__ == "__main__":
     E.lib()  # build once before forking
     with mp.Pool(n) as pool:
         rows = pool.map(one, range(1, 256), chunksize=1)
-    out = os.path.join(os.path.dirname(os.path.dirname(HERE)), "profiles", "quant_fastpath_sweep.txt")
+    out = os.environ.get("PIXO_SWEEP_OUT") or os.path.join(os.path.dirname(os.path.dirname(HERE)), "profiles", "quant_fastpath_sweep.txt")
     with open(out, "w") as fh:
         fh.write("# q flagged(took exact divide) wrong_unflagged wrong_final ; x = every f32 with |x|<=4096\n")
         for r in rows:

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/pixo_hip.h"
+#include "jpeg_entropy.hpp"
 #include "jpeg_host.hpp"
 #include "jpeg_kernels.hpp"
 
@@ -67,6 +68,23 @@ struct Context {
     void *d_px = nullptr;   size_t px_cap = 0;
     void *d_coef = nullptr; size_t coef_cap = 0;
     void *h_coef = nullptr; size_t hcoef_cap = 0; // pinned
+    // device entropy stage (grow-only)
+    struct Buf {
+        void *p = nullptr; size_t cap = 0;
+        hipError_t reserve(size_t n)
+        {
+            if (n <= cap) return hipSuccess;
+            if (p) (void)hipFree(p);
+            p = nullptr; cap = 0;
+            const size_t want = n + n / 4; // head-room: sizes are data dependent
+            hipError_t e = hipMalloc(&p, want);
+            if (e == hipSuccess) cap = want;
+            return e;
+        }
+        template <class T> T *as() const { return static_cast<T *>(p); }
+    };
+    Buf e_tables, e_hist, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out;
+    uint64_t *h_totals = nullptr; // pinned, 2 words
 
     int ensure()
     {
@@ -150,6 +168,111 @@ int coeffs_to_pinned(const uint8_t *pixels, const pixo_jpeg_options &o, const pi
     return PIXO_OK;
 }
 
+// Device pixels -> device coefficient tuple inside the context's buffer.
+int coeffs_on_device(const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
+                     int16_t **dy, int16_t **dcb, int16_t **dcr)
+{
+    Context &c = t_ctx;
+    const float *qt_all = nullptr;
+    int rc = device_tables(c.device, &qt_all);
+    if (rc) return rc;
+    const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128;
+    if ((rc = c.reserve_coef(coef_bytes))) return rc;
+    *dy = static_cast<int16_t *>(c.d_coef);
+    *dcb = *dy + g.y_blocks * 64;
+    *dcr = *dcb + g.c_blocks * 64;
+    HIP_TRY(pixo_dev::launch_jpeg_coeffs(d_pixels, o.width, o.height, g.gray, g.s420, 1, *dy,
+                                         g.gray ? nullptr : *dcb, g.gray ? nullptr : *dcr,
+                                         qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, stream));
+    return PIXO_OK;
+}
+
+// Scans that emit RSTn markers are entropy-coded on the host (the device stage packs one
+// uninterrupted bit stream); everything else — standard or optimised tables — on the device.
+bool scan_has_restart_markers(const pixo_jpeg_options &o, const pixo_host::Geometry &g)
+{
+    return o.has_restart_interval && o.restart_interval != 0 && o.restart_interval < g.units;
+}
+
+// Device coefficient tuple -> whole file in `out` (headers on the host, entropy-coded segment by
+// the kernels of jpeg_entropy.hip, copied straight into the vector).
+int device_entropy_to_vector(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+                             const pixo_host::Geometry &g, hipStream_t stream, std::vector<uint8_t> &out)
+{
+    Context &c = t_ctx;
+    namespace pd = pixo_dev;
+    const uint64_t n = g.y_blocks + 2 * g.c_blocks;
+    pd::ScanArgs a;
+    a.y = dy; a.cb = dcb; a.cr = dcr;
+    a.mode = g.gray ? 0 : (g.s420 ? 2 : 1);
+    a.nblocks = n;
+    HIP_TRY(c.e_tables.reserve(pixo_host::kScanTableWords * 4));
+    HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
+    HIP_TRY(c.e_len.reserve(n * 4));
+    HIP_TRY(c.e_off.reserve(n * 8));
+    HIP_TRY(c.e_tmp.reserve((pd::scan_tile_count(n) + 1) * 8));
+    HIP_TRY(c.e_totals.reserve(16));
+    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 16, hipHostMallocDefault));
+    a.tables = c.e_tables.as<uint32_t>();
+
+    pixo_host::HuffSet h;
+    if (o.optimize_huffman) { // count_block statistics on the device, table construction on the host
+        HIP_TRY(hipMemsetAsync(c.e_hist.p, 0, pixo_host::kScanTableWords * 8, stream));
+        HIP_TRY(pd::launch_scan_count(a, c.e_hist.as<unsigned long long>(), stream));
+        uint64_t counts[pixo_host::kScanTableWords];
+        HIP_TRY(hipMemcpyAsync(counts, c.e_hist.p, sizeof counts, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        uint64_t dc[2][12], ac[2][256];
+        for (int cls = 0; cls < 2; ++cls) {
+            std::memcpy(dc[cls], counts + cls * 268, sizeof dc[cls]);
+            std::memcpy(ac[cls], counts + cls * 268 + 12, sizeof ac[cls]);
+        }
+        h = pixo_host::HuffSet::optimized(dc, ac, !g.gray);
+    } else {
+        h = pixo_host::HuffSet::standard();
+    }
+    uint32_t packed[pixo_host::kScanTableWords];
+    pixo_host::pack_scan_tables(h, packed);
+    HIP_TRY(hipMemcpyAsync(c.e_tables.p, packed, sizeof packed, hipMemcpyHostToDevice, stream));
+
+    // 1-2: block bit lengths, their prefix sum
+    HIP_TRY(pd::launch_scan_lengths(a, c.e_len.as<uint32_t>(), stream));
+    HIP_TRY(pd::launch_exclusive_scan(c.e_len.as<uint32_t>(), n, c.e_off.as<uint64_t>(), c.e_tmp.as<uint64_t>(),
+                                      c.e_totals.as<uint64_t>(), stream));
+    HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_totals.p, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream)); // `packed` may go out of scope after this, too
+    const uint64_t total_bits = c.h_totals[0];
+    const uint64_t nbytes = (total_bits + 7) / 8;
+    // 3: pack
+    const size_t stream_bytes = (total_bits / 32 + 2) * 4;
+    HIP_TRY(c.e_stream.reserve(stream_bytes));
+    HIP_TRY(hipMemsetAsync(c.e_stream.p, 0, stream_bytes, stream));
+    HIP_TRY(pd::launch_scan_pack(a, c.e_off.as<uint64_t>(), total_bits, c.e_stream.as<uint32_t>(), stream));
+    // 4: 0xFF census
+    const size_t tiles = pd::stuff_tile_count(nbytes);
+    HIP_TRY(c.e_tile_ff.reserve(tiles * 4));
+    HIP_TRY(c.e_tile_base.reserve(tiles * 8));
+    HIP_TRY(c.e_tmp.reserve((pd::scan_tile_count(tiles) + 1) * 8));
+    HIP_TRY(pd::launch_ff_tile_count(c.e_stream.as<uint32_t>(), nbytes, c.e_tile_ff.as<uint32_t>(), stream));
+    HIP_TRY(pd::launch_exclusive_scan(c.e_tile_ff.as<uint32_t>(), tiles, c.e_tile_base.as<uint64_t>(), c.e_tmp.as<uint64_t>(),
+                                      c.e_totals.as<uint64_t>() + 1, stream));
+    HIP_TRY(hipMemcpyAsync(c.h_totals + 1, c.e_totals.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const uint64_t scan_bytes = nbytes + c.h_totals[1];
+    // 5: stuff, then straight into the caller's vector behind the headers
+    HIP_TRY(c.e_out.reserve(scan_bytes));
+    HIP_TRY(pd::launch_stuff(c.e_stream.as<uint32_t>(), nbytes, c.e_tile_base.as<uint64_t>(), c.e_out.as<uint8_t>(), stream));
+    out.clear();
+    pixo_host::file_headers(out, o, h);
+    const size_t hdr = out.size();
+    out.resize(hdr + scan_bytes + 2);
+    HIP_TRY(hipMemcpyAsync(out.data() + hdr, c.e_out.p, scan_bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    out[hdr + scan_bytes] = 0xFF; // EOI
+    out[hdr + scan_bytes + 1] = 0xD9;
+    return PIXO_OK;
+}
+
 int unsupported_scan_mode(const pixo_jpeg_options &o)
 {
     if (o.progressive || o.trellis_quant)
@@ -167,10 +290,21 @@ int encode_to_vector(const uint8_t *data, size_t data_len, const pixo_jpeg_optio
     if (rc) return fail(rc, msg);
     if ((rc = unsupported_scan_mode(o))) return rc;
     const pixo_host::Geometry g = pixo_host::geometry(o.width, o.height, o.color_type, o.subsampling);
-    const int16_t *y, *cb, *cr;
-    if ((rc = coeffs_to_pinned(data, o, g, &y, &cb, &cr))) return rc;
-    pixo_host::encode_file(y, cb, cr, o, out);
-    return PIXO_OK;
+    if (scan_has_restart_markers(o, g) || std::getenv("PIXO_HIP_HOST_ENTROPY")) {
+        const int16_t *y, *cb, *cr;
+        if ((rc = coeffs_to_pinned(data, o, g, &y, &cb, &cr))) return rc;
+        pixo_host::encode_file(y, cb, cr, o, out);
+        return PIXO_OK;
+    }
+    Context &c = t_ctx;
+    if ((rc = c.ensure())) return rc;
+    HIP_TRY(hipSetDevice(c.device));
+    const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
+    if ((rc = c.reserve_px((px_bytes + 15) & ~size_t{15}))) return rc;
+    HIP_TRY(hipMemcpyAsync(c.d_px, data, px_bytes, hipMemcpyHostToDevice, c.stream));
+    int16_t *dy, *dcb, *dcr;
+    if ((rc = coeffs_on_device(c.d_px, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
+    return device_entropy_to_vector(dy, dcb, dcr, o, g, c.stream, out);
 }
 
 int hand_over(const std::vector<uint8_t> &v, uint8_t **out, size_t *out_len)

@@ -1,0 +1,248 @@
+// jpeg_entropy.hip — gfx950 kernels of the device entropy stage: the baseline
+// Huffman scan of a coefficient tuple that is already in HBM, byte-identical to the reference's
+// encode_scan + encode_block + BitWriterMsb (src/jpeg/mod.rs:1408-1563, src/jpeg/huffman.rs:
+// 423-481, src/bits.rs:195-293) for scans without restart markers.
+//
+//   1. lengths   one lane per block (scan order): bit length of the block            u32[n]
+//   2. scan      exclusive prefix sum of the lengths -> absolute bit offset          u64[n], total
+//   3. pack      one lane per block: codes + value bits at the block's offset into a zeroed
+//                MSB-first word stream; the last block also writes the 1-padding of the final byte
+//   4. ff count  0xFF bytes per 4 KiB tile of the packed stream, scanned like (2)
+//   5. stuff     copies the stream to its final place, inserting 0x00 after every 0xFF
+//   (0. count    optional: DC-category / AC run-size histograms for optimised tables)
+//
+// A block is 128 contiguous bytes and a lane walks it serially (the zero-run state machine is
+// inherently sequential); 64 lanes = 64 consecutive blocks.  All of it is integer work bounded
+// by HBM traffic and scattered 4-byte stores: no MFMA, no LDS tiling beyond the tables.
+#include <hip/hip_runtime.h>
+
+#include "jpeg_entropy.hpp"
+#include "jpeg_scan_block.h"
+
+namespace pixo_dev {
+using namespace pixo_scan;
+
+namespace {
+constexpr int kScanThreads = 256;
+
+enum { WHAT_LENGTH = 0, WHAT_PACK = 1, WHAT_COUNT = 2 };
+
+template <int WHAT>
+__global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(const ScanArgs a, uint32_t *len, const uint64_t *off,
+                                                                  uint32_t *stream, unsigned long long *hist,
+                                                                  uint64_t total_bits)
+{
+    __shared__ uint32_t tab[kTableWords];
+    __shared__ uint32_t lhist[WHAT == WHAT_COUNT ? kTableWords : 1];
+    for (int i = threadIdx.x; i < kTableWords; i += kScanThreads) {
+        if (WHAT != WHAT_COUNT) tab[i] = a.tables[i];
+        else lhist[i] = 0;
+    }
+    __syncthreads();
+    const uint64_t s = (uint64_t)blockIdx.x * kScanThreads + threadIdx.x;
+    if (s < a.nblocks) {
+        const BlockRef ref = block_of(a.mode, s);
+        const int16_t *base = ref.comp == 0 ? a.y : (ref.comp == 1 ? a.cb : a.cr);
+        const uint4 *p = reinterpret_cast<const uint4 *>(base + ref.index * 64);
+        uint32_t w[32];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint4 q = p[i];
+            w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+        }
+        // DC predictor: the previous block of the same component (no restart markers here)
+        const int prev_dc = ref.index ? (int)base[(ref.index - 1) * 64] : 0;
+        const int cls = ref.comp == 0 ? 0 : 1;
+        if (WHAT == WHAT_LENGTH) {
+            LengthVisitor v{tab + cls * kClassSyms, 0};
+            walk_block(w, prev_dc, v);
+            len[s] = v.bits;
+        } else if (WHAT == WHAT_PACK) {
+            PackVisitor v;
+            v.tab = tab + cls * kClassSyms;
+            v.begin(stream, off[s]);
+            walk_block(w, prev_dc, v);
+            v.finish();
+            if (s == a.nblocks - 1) { // BitWriterMsb::flush: pad the last byte with 1-bits (bits.rs:261-272)
+                const int n = (int)((8 - (total_bits & 7)) & 7);
+                if (n) v.or_word(total_bits >> 5, ((1u << n) - 1u) << (32 - (int)(total_bits & 31) - n));
+            }
+        } else {
+            CountVisitor v{lhist + cls * kClassSyms};
+            walk_block(w, prev_dc, v);
+        }
+    }
+    if (WHAT == WHAT_COUNT) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < kTableWords; i += kScanThreads)
+            if (lhist[i]) atomicAdd(&hist[i], (unsigned long long)lhist[i]);
+    }
+}
+
+// ---- exclusive scan of u32 -> u64 (three small kernels; tiles of 2048 elements) --------------
+constexpr int kTileElems = 2048, kPerThread = kTileElems / kScanThreads;
+
+__device__ __forceinline__ uint64_t wg_exclusive_scan(uint64_t v, uint64_t *total)
+{ // 256 threads, Hillis-Steele in LDS
+    __shared__ uint64_t buf[2][kScanThreads];
+    int cur = 0;
+    buf[0][threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (int d = 1; d < kScanThreads; d <<= 1) {
+        uint64_t x = buf[cur][threadIdx.x];
+        if ((int)threadIdx.x >= d) x += buf[cur][threadIdx.x - d];
+        buf[cur ^ 1][threadIdx.x] = x;
+        cur ^= 1;
+        __syncthreads();
+    }
+    const uint64_t incl = buf[cur][threadIdx.x];
+    if (total) *total = buf[cur][kScanThreads - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void tile_sums_kernel(const uint32_t *in, uint64_t n, uint64_t *tile_sum)
+{
+    const uint64_t i0 = (uint64_t)blockIdx.x * kTileElems + (uint64_t)threadIdx.x * kPerThread;
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kPerThread; k++)
+        if (i0 + k < n) s += in[i0 + k];
+    uint64_t total;
+    (void)wg_exclusive_scan(s, &total);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_tiles_kernel(uint64_t *tile_sum, uint64_t ntiles, uint64_t *grand_total)
+{ // one workgroup: tile sums -> exclusive tile bases, in place
+    uint64_t carry = 0;
+    for (uint64_t t0 = 0; t0 < ntiles; t0 += kScanThreads) {
+        const uint64_t t = t0 + threadIdx.x;
+        const uint64_t v = t < ntiles ? tile_sum[t] : 0;
+        uint64_t total;
+        const uint64_t ex = wg_exclusive_scan(v, &total);
+        if (t < ntiles) tile_sum[t] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *grand_total = carry;
+}
+
+__global__ __launch_bounds__(kScanThreads) void downsweep_kernel(const uint32_t *in, uint64_t n, const uint64_t *tile_base,
+                                                                uint64_t *out)
+{
+    const uint64_t i0 = (uint64_t)blockIdx.x * kTileElems + (uint64_t)threadIdx.x * kPerThread;
+    uint32_t v[kPerThread];
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kPerThread; k++) { v[k] = i0 + k < n ? in[i0 + k] : 0; s += v[k]; }
+    uint64_t run = tile_base[blockIdx.x] + wg_exclusive_scan(s, nullptr);
+#pragma unroll
+    for (int k = 0; k < kPerThread; k++) {
+        if (i0 + k < n) out[i0 + k] = run;
+        run += v[k];
+    }
+}
+
+// ---- byte stuffing (bits.rs:245-253): tiles of 1024 words = 4096 stream bytes ------------------
+constexpr int kStuffWordsPerThread = 4, kStuffTileBytes = kScanThreads * kStuffWordsPerThread * 4;
+
+__device__ __forceinline__ uint32_t ff_bytes(uint32_t word, uint64_t first_byte, uint64_t nbytes)
+{ // how many of the (at most 4) stream bytes of this big-endian word are 0xFF and exist
+    uint32_t c = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+        if (first_byte + b < nbytes && ((word >> (24 - 8 * b)) & 0xFF) == 0xFF) c++;
+    return c;
+}
+
+__global__ __launch_bounds__(kScanThreads) void ff_tile_count_kernel(const uint32_t *stream, uint64_t nbytes, uint32_t *tile_ff)
+{
+    const uint64_t w0 = ((uint64_t)blockIdx.x * kScanThreads + threadIdx.x) * kStuffWordsPerThread;
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kStuffWordsPerThread; k++)
+        if ((w0 + k) * 4 < nbytes) c += ff_bytes(stream[w0 + k], (w0 + k) * 4, nbytes);
+    uint64_t total;
+    (void)wg_exclusive_scan(c, &total);
+    if (threadIdx.x == 0) tile_ff[blockIdx.x] = (uint32_t)total;
+}
+
+__global__ __launch_bounds__(kScanThreads) void stuff_kernel(const uint32_t *stream, uint64_t nbytes,
+                                                            const uint64_t *tile_ff_base, uint8_t *out)
+{
+    const uint64_t w0 = ((uint64_t)blockIdx.x * kScanThreads + threadIdx.x) * kStuffWordsPerThread;
+    uint32_t w[kStuffWordsPerThread];
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kStuffWordsPerThread; k++) {
+        w[k] = (w0 + k) * 4 < nbytes ? stream[w0 + k] : 0;
+        c += ff_bytes(w[k], (w0 + k) * 4, nbytes);
+    }
+    const uint64_t before = tile_ff_base[blockIdx.x] + wg_exclusive_scan(c, nullptr);
+    uint8_t *o = out + w0 * 4 + before;
+#pragma unroll
+    for (int k = 0; k < kStuffWordsPerThread; k++) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            if ((w0 + k) * 4 + b < nbytes) {
+                const uint8_t byte = (uint8_t)(w[k] >> (24 - 8 * b));
+                *o++ = byte;
+                if (byte == 0xFF) *o++ = 0x00;
+            }
+        }
+    }
+}
+
+inline unsigned grid_for(uint64_t n, uint64_t per_group) { return (unsigned)((n + per_group - 1) / per_group); }
+} // namespace
+
+size_t scan_tile_count(uint64_t n) { return (size_t)((n + kTileElems - 1) / kTileElems); }
+size_t stuff_tile_count(uint64_t nbytes) { return (size_t)((nbytes + kStuffTileBytes - 1) / kStuffTileBytes); }
+
+hipError_t launch_scan_count(const ScanArgs &a, unsigned long long *d_hist, hipStream_t s)
+{
+    hipLaunchKernelGGL((scan_blocks_kernel<WHAT_COUNT>), dim3(grid_for(a.nblocks, kScanThreads)), dim3(kScanThreads), 0, s, a,
+                       nullptr, nullptr, nullptr, d_hist, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_lengths(const ScanArgs &a, uint32_t *d_len, hipStream_t s)
+{
+    hipLaunchKernelGGL((scan_blocks_kernel<WHAT_LENGTH>), dim3(grid_for(a.nblocks, kScanThreads)), dim3(kScanThreads), 0, s, a,
+                       d_len, nullptr, nullptr, nullptr, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_pack(const ScanArgs &a, const uint64_t *d_off, uint64_t total_bits, uint32_t *d_stream, hipStream_t s)
+{
+    hipLaunchKernelGGL((scan_blocks_kernel<WHAT_PACK>), dim3(grid_for(a.nblocks, kScanThreads)), dim3(kScanThreads), 0, s, a,
+                       nullptr, d_off, d_stream, nullptr, total_bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_exclusive_scan(const uint32_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *d_tile_tmp, uint64_t *d_total,
+                                 hipStream_t s)
+{
+    const unsigned tiles = (unsigned)scan_tile_count(n);
+    hipLaunchKernelGGL(tile_sums_kernel, dim3(tiles), dim3(kScanThreads), 0, s, d_in, n, d_tile_tmp);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(kScanThreads), 0, s, d_tile_tmp, (uint64_t)tiles, d_total);
+    if (d_out) hipLaunchKernelGGL(downsweep_kernel, dim3(tiles), dim3(kScanThreads), 0, s, d_in, n, d_tile_tmp, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_ff_tile_count(const uint32_t *d_stream, uint64_t nbytes, uint32_t *d_tile_ff, hipStream_t s)
+{
+    hipLaunchKernelGGL(ff_tile_count_kernel, dim3((unsigned)stuff_tile_count(nbytes)), dim3(kScanThreads), 0, s, d_stream, nbytes,
+                       d_tile_ff);
+    return hipGetLastError();
+}
+
+hipError_t launch_stuff(const uint32_t *d_stream, uint64_t nbytes, const uint64_t *d_tile_ff_base, uint8_t *d_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(stuff_kernel, dim3((unsigned)stuff_tile_count(nbytes)), dim3(kScanThreads), 0, s, d_stream, nbytes,
+                       d_tile_ff_base, d_out);
+    return hipGetLastError();
+}
+
+} // namespace pixo_dev

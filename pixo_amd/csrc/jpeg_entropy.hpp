@@ -1,0 +1,33 @@
+// jpeg_entropy.hpp — host-callable launchers of the device entropy stage (jpeg_entropy.hip).
+// All pointers are device pointers; every launcher only enqueues work on `stream`.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace pixo_dev {
+
+struct ScanArgs {
+    const int16_t *y, *cb, *cr; // coefficient tuple, natural order, 64 i16 per block
+    const uint32_t *tables;     // pixo_scan::kTableWords words: (length << 16) | code
+    int mode;                   // 0 gray, 1 4:4:4, 2 4:2:0 (block order of encode_scan)
+    uint64_t nblocks;           // blocks in scan order
+};
+
+size_t scan_tile_count(uint64_t n);        // u64 scratch words launch_exclusive_scan needs for n elements
+size_t stuff_tile_count(uint64_t nbytes);  // 4 KiB tiles of the packed stream
+
+// d_hist: pixo_scan::kTableWords zero-initialised 64-bit counters ([class][12 DC + 256 AC])
+hipError_t launch_scan_count(const ScanArgs &a, unsigned long long *d_hist, hipStream_t s);
+hipError_t launch_scan_lengths(const ScanArgs &a, uint32_t *d_len, hipStream_t s);
+// d_out[i] = sum of d_in[0..i) (may be null: totals only); *d_total = sum of all
+hipError_t launch_exclusive_scan(const uint32_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *d_tile_tmp, uint64_t *d_total,
+                                 hipStream_t s);
+// d_stream: zeroed, at least total_bits / 32 + 2 words
+hipError_t launch_scan_pack(const ScanArgs &a, const uint64_t *d_off, uint64_t total_bits, uint32_t *d_stream, hipStream_t s);
+hipError_t launch_ff_tile_count(const uint32_t *d_stream, uint64_t nbytes, uint32_t *d_tile_ff, hipStream_t s);
+// d_out: nbytes + (number of 0xFF bytes) bytes
+hipError_t launch_stuff(const uint32_t *d_stream, uint64_t nbytes, const uint64_t *d_tile_ff_base, uint8_t *d_out, hipStream_t s);
+
+} // namespace pixo_dev

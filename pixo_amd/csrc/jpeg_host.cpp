@@ -456,6 +456,20 @@ void symbol_histograms(const int16_t *y, const int16_t *cb, const int16_t *cr,
     walk_scan(c, y, cb, cr, o);
 }
 
+void file_headers(std::vector<uint8_t> &out, const pixo_jpeg_options &o, const HuffSet &h)
+{
+    write_headers(out, o, make_quant_tables(o.quality), h);
+}
+
+void pack_scan_tables(const HuffSet &h, uint32_t out[kScanTableWords])
+{
+    for (int cls = 0; cls < 2; ++cls) {
+        uint32_t *t = out + cls * (12 + 256);
+        for (int i = 0; i < 12; ++i) t[i] = (static_cast<uint32_t>(h.dc[cls].len[i]) << 16) | h.dc[cls].code[i];
+        for (int i = 0; i < 256; ++i) t[12 + i] = (static_cast<uint32_t>(h.ac[cls].len[i]) << 16) | h.ac[cls].code[i];
+    }
+}
+
 void encode_file(const int16_t *y, const int16_t *cb, const int16_t *cr,
                  const pixo_jpeg_options &o, std::vector<uint8_t> &out)
 {

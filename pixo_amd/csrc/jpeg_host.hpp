@@ -64,6 +64,15 @@ int validate(const pixo_jpeg_options &o, bool check_len, size_t data_len, std::s
 void symbol_histograms(const int16_t *y, const int16_t *cb, const int16_t *cr,
                        const pixo_jpeg_options &o, uint64_t dc[2][12], uint64_t ac[2][256]);
 
+// Everything of the file before the entropy-coded segment: SOI, APP0, DQT x2, SOF0, DHT x4, [DRI],
+// SOS (jpeg/mod.rs:449-648).  Appends to `out`.
+void file_headers(std::vector<uint8_t> &out, const pixo_jpeg_options &o, const HuffSet &h);
+
+// The tables as the device entropy stage reads them (jpeg_scan_block.h): 2 x (12 + 256) words,
+// (code length << 16) | code, class 0 luminance, class 1 chrominance.
+constexpr int kScanTableWords = 2 * (12 + 256);
+void pack_scan_tables(const HuffSet &h, uint32_t out[kScanTableWords]);
+
 // Whole file from a coefficient tuple: headers (jpeg/mod.rs:449-648), scan
 // (encode_scan :1408-1563 ordering, encode_block huffman.rs:423-481, BitWriterMsb
 // bits.rs:195-293 incl. 0xFF stuffing, 1-padding and RSTn), EOI.

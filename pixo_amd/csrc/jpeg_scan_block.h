@@ -1,0 +1,172 @@
+// jpeg_scan_block.h — per-block body of the device entropy stage: one LANE walks one 8x8 block
+// of quantised coefficients in zig-zag order exactly like the reference's encode_block
+// (src/jpeg/huffman.rs:423-481) and hands every Huffman symbol to a visitor.  Three visitors
+// exist: bit LENGTH of the block, PACK the bits at a known bit offset, symbol HISTOGRAM
+// (count_block, src/jpeg/mod.rs:826-860).
+//
+// Shared between the gfx950 kernels (jpeg_entropy.hip) and the CPU emulation harness in
+// tests/emu (-DPIXO_EMU): the walk, the magnitude categories, the value bits and the
+// MSB-first packing are all plain integer code.
+#pragma once
+#include <stdint.h>
+
+#if defined(PIXO_EMU)
+#define PIXO_SDEV static inline // free functions
+#define PIXO_SMEM inline        // member functions
+#else
+#define PIXO_SDEV __device__ __forceinline__
+#define PIXO_SMEM __device__ __forceinline__
+#endif
+
+namespace pixo_scan {
+
+// Huffman tables as the kernels see them: one u32 per symbol = (code length << 16) | code,
+// [class 0 = luminance, 1 = chrominance][0..11 DC categories, 12..267 AC run/size symbols].
+constexpr int kDcSyms = 12, kAcSyms = 256, kClassSyms = kDcSyms + kAcSyms, kTableWords = 2 * kClassSyms;
+
+// zig-zag scan order, quantize.rs:18-22: natural index of the k-th coefficient of the scan.
+// Only ever called with a compile-time k (fully unrolled walk), so it folds to a constant.
+PIXO_SDEV constexpr int zigzag(int k)
+{
+    constexpr uint8_t t[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
+                               12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                               35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+                               58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    return t[k];
+}
+
+// `category` (huffman.rs:394-401): number of bits of |v|
+PIXO_SDEV int magnitude_bits(int v)
+{
+    const unsigned a = (unsigned)(v < 0 ? -v : v);
+    return a == 0 ? 0 : 32 - __builtin_clz(a);
+}
+
+// `encode_value` (huffman.rs:404-418): the low `cat` bits of v (v - 1 for negative v)
+PIXO_SDEV uint32_t value_bits(int v, int cat) { return (uint32_t)(v < 0 ? v - 1 : v) & ((1u << cat) - 1u); }
+
+// coefficient j (natural order) of a block held as 32 dwords of two i16 each
+PIXO_SDEV int coef_of(const uint32_t *w, int j) { return (int)(int16_t)(w[j >> 1] >> (16 * (j & 1))); }
+
+// Walks one block.  V provides dc(cat, diff), ac(rs, cat, v), zrl(), eob().
+template <class V> PIXO_SDEV void walk_block(const uint32_t *w, int prev_dc, V &vis)
+{
+    const int d0 = coef_of(w, 0);
+    const int diff = (int)(int16_t)(d0 - prev_dc); // i16 arithmetic like the reference
+    vis.dc(magnitude_bits(diff), diff);
+    int run = 0;
+#pragma unroll
+    for (int k = 1; k < 64; k++) {
+        const int v = coef_of(w, zigzag(k));
+        if (v == 0) {
+            run++;
+        } else {
+            while (run >= 16) { vis.zrl(); run -= 16; }
+            const int cat = magnitude_bits(v);
+            vis.ac((run << 4) | cat, cat, v);
+            run = 0;
+        }
+    }
+    if (run > 0) vis.eob();
+}
+
+// ---- visitor 1: bit length of the block ----------------------------------------------------
+struct LengthVisitor {
+    const uint32_t *tab; // this class's kClassSyms words
+    uint32_t bits;
+    PIXO_SMEM void dc(int cat, int) { bits += (tab[cat] >> 16) + cat; }
+    PIXO_SMEM void ac(int rs, int cat, int) { bits += (tab[kDcSyms + rs] >> 16) + cat; }
+    PIXO_SMEM void zrl() { bits += tab[kDcSyms + 0xF0] >> 16; }
+    PIXO_SMEM void eob() { bits += tab[kDcSyms] >> 16; }
+};
+
+// ---- visitor 2: pack the block's bits at absolute bit offset `pos` of a zeroed stream ------
+// The stream is an array of u32 holding the bits MSB first (stream bit k = bit 31 - k % 32 of
+// word k / 32; bytes come out big-endian).  Words this block only partly covers (its first and
+// last) are OR-ed atomically — neighbouring blocks, packed by other lanes, share them —
+// words it covers completely are stored.
+struct PackVisitor {
+    const uint32_t *tab;
+    uint32_t *stream;
+    uint64_t acc;     // pending bits, right-aligned
+    int pending;      // how many (< 32 between calls)
+    uint64_t word;    // index of the word the pending bits belong to
+    bool first;       // nothing flushed yet: the next word is the shared first one
+
+    PIXO_SMEM void begin(uint32_t *s, uint64_t pos)
+    {
+        stream = s; acc = 0; pending = (int)(pos & 31); word = pos >> 5; first = true;
+    }
+    PIXO_SMEM void or_word(uint64_t i, uint32_t v)
+    {
+#if defined(PIXO_EMU)
+        stream[i] |= v;
+#else
+        if (v) atomicOr(&stream[i], v);
+#endif
+    }
+    PIXO_SMEM void put(uint32_t v, int n) // n <= 32
+    {
+        acc = (acc << n) | v;
+        pending += n;
+        if (pending >= 32) {
+            const uint32_t out = (uint32_t)(acc >> (pending - 32));
+            if (first) { or_word(word, out); first = false; }
+            else stream[word] = out;
+            word++;
+            pending -= 32;
+            acc &= (1ull << pending) - 1ull;
+        }
+    }
+    PIXO_SMEM void finish() // the last, partly filled word
+    {
+        if (pending > 0) or_word(word, (uint32_t)(acc << (32 - pending)));
+    }
+    PIXO_SMEM void dc(int cat, int diff)
+    {
+        const uint32_t t = tab[cat];
+        put(((t & 0xFFFF) << cat) | value_bits(diff, cat), (int)(t >> 16) + cat);
+    }
+    PIXO_SMEM void ac(int rs, int cat, int v)
+    {
+        const uint32_t t = tab[kDcSyms + rs];
+        put(((t & 0xFFFF) << cat) | value_bits(v, cat), (int)(t >> 16) + cat);
+    }
+    PIXO_SMEM void zrl() { const uint32_t t = tab[kDcSyms + 0xF0]; put(t & 0xFFFF, (int)(t >> 16)); }
+    PIXO_SMEM void eob() { const uint32_t t = tab[kDcSyms]; put(t & 0xFFFF, (int)(t >> 16)); }
+};
+
+// ---- visitor 3: symbol statistics for optimised tables ---------------------------------------
+struct CountVisitor {
+    uint32_t *hist; // this class's kClassSyms counters (LDS on the device)
+    PIXO_SMEM void bump(int i)
+    {
+#if defined(PIXO_EMU)
+        hist[i]++;
+#else
+        atomicAdd(&hist[i], 1u);
+#endif
+    }
+    PIXO_SMEM void dc(int cat, int) { bump(cat); }
+    PIXO_SMEM void ac(int rs, int, int) { bump(kDcSyms + (rs & 0xFF)); }
+    PIXO_SMEM void zrl() { bump(kDcSyms + 0xF0); }
+    PIXO_SMEM void eob() { bump(kDcSyms); }
+};
+
+// Scan-order position -> (component, block index inside that component's array).
+// mode 0 gray: Y;  1 4:4:4: Y Cb Cr per block;  2 4:2:0: Y0 Y1 Y2 Y3 Cb Cr per MCU
+// (encode_scan, jpeg/mod.rs:1491-1544).  comp: 0 Y, 1 Cb, 2 Cr.
+struct BlockRef { int comp; uint64_t index; };
+PIXO_SDEV BlockRef block_of(int mode, uint64_t s)
+{
+    BlockRef r;
+    if (mode == 0) { r.comp = 0; r.index = s; }
+    else if (mode == 1) { const uint64_t m = s / 3; const int k = (int)(s - m * 3); r.comp = k; r.index = m; }
+    else {
+        const uint64_t m = s / 6; const int k = (int)(s - m * 6);
+        if (k < 4) { r.comp = 0; r.index = m * 4 + k; } else { r.comp = k - 3; r.index = m; }
+    }
+    return r;
+}
+
+} // namespace pixo_scan

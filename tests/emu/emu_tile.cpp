@@ -139,3 +139,87 @@ extern "C" void emu_quant_exhaustive(int q, uint32_t lo_bits, uint32_t hi_bits, 
         }
     *flagged = f; *wrong_unflagged = w; *wrong_final = wf;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Device entropy stage (pixo_amd/csrc/jpeg_scan_block.h) lane by lane: lengths, prefix sum,
+// pack into a zeroed MSB-first word stream, 1-padding, byte stuffing — the steps of
+// jpeg_entropy.hip with the workgroup collectives replaced by loops.
+// ---------------------------------------------------------------------------------------------
+#include "../../pixo_amd/csrc/jpeg_scan_block.h"
+
+extern "C" void emu_scan_tables(const int16_t *y, const int16_t *cb, const int16_t *cr, uint32_t w, uint32_t h,
+                                int color_type, int subsampling, int optimize, uint32_t *out /* 536 words */)
+{
+    pixo_jpeg_options o{};
+    o.width = w; o.height = h; o.color_type = (uint8_t)color_type; o.subsampling = (uint8_t)subsampling; o.quality = 80;
+    pixo_host::HuffSet hs = pixo_host::HuffSet::standard();
+    if (optimize) {
+        // statistics through the DEVICE visitor (CountVisitor), tables through the host builder
+        const pixo_host::Geometry g = pixo_host::geometry(w, h, o.color_type, o.subsampling);
+        const int mode = g.gray ? 0 : (g.s420 ? 2 : 1);
+        const uint64_t n = g.y_blocks + 2 * g.c_blocks;
+        std::vector<uint32_t> hist(pixo_scan::kTableWords, 0);
+        for (uint64_t s = 0; s < n; s++) {
+            const pixo_scan::BlockRef r = pixo_scan::block_of(mode, s);
+            const int16_t *base = r.comp == 0 ? y : (r.comp == 1 ? cb : cr);
+            uint32_t wds[32];
+            memcpy(wds, base + r.index * 64, 128);
+            pixo_scan::CountVisitor v{hist.data() + (r.comp ? 1 : 0) * pixo_scan::kClassSyms};
+            pixo_scan::walk_block(wds, r.index ? base[(r.index - 1) * 64] : 0, v);
+        }
+        uint64_t dc[2][12], ac[2][256];
+        for (int c = 0; c < 2; c++) {
+            for (int i = 0; i < 12; i++) dc[c][i] = hist[c * 268 + i];
+            for (int i = 0; i < 256; i++) ac[c][i] = hist[c * 268 + 12 + i];
+        }
+        hs = pixo_host::HuffSet::optimized(dc, ac, !g.gray);
+    }
+    pixo_host::pack_scan_tables(hs, out);
+}
+
+extern "C" long emu_scan(const int16_t *y, const int16_t *cb, const int16_t *cr, int mode, uint64_t nblocks,
+                         const uint32_t *tables, uint8_t *out, long cap)
+{
+    using namespace pixo_scan;
+    std::vector<uint32_t> len(nblocks);
+    std::vector<uint64_t> off(nblocks);
+    auto load = [&](uint64_t s, uint32_t *wds, int *prev, int *cls) {
+        const BlockRef r = block_of(mode, s);
+        const int16_t *base = r.comp == 0 ? y : (r.comp == 1 ? cb : cr);
+        memcpy(wds, base + r.index * 64, 128);
+        *prev = r.index ? base[(r.index - 1) * 64] : 0;
+        *cls = r.comp ? 1 : 0;
+    };
+    uint64_t total = 0;
+    for (uint64_t s = 0; s < nblocks; s++) {
+        uint32_t wds[32]; int prev, cls;
+        load(s, wds, &prev, &cls);
+        LengthVisitor v{tables + cls * kClassSyms, 0};
+        walk_block(wds, prev, v);
+        len[s] = v.bits; off[s] = total; total += v.bits;
+    }
+    std::vector<uint32_t> stream(total / 32 + 2, 0);
+    // blocks packed in REVERSE order: the result must not depend on which lane runs first
+    for (uint64_t i = nblocks; i-- > 0;) {
+        uint32_t wds[32]; int prev, cls;
+        load(i, wds, &prev, &cls);
+        PackVisitor v;
+        v.tab = tables + cls * kClassSyms;
+        v.begin(stream.data(), off[i]);
+        walk_block(wds, prev, v);
+        v.finish();
+        if (i == nblocks - 1) {
+            const int n = (int)((8 - (total & 7)) & 7);
+            if (n) v.or_word(total >> 5, ((1u << n) - 1u) << (32 - (int)(total & 31) - n));
+        }
+    }
+    const uint64_t nbytes = (total + 7) / 8;
+    long o = 0;
+    for (uint64_t b = 0; b < nbytes; b++) {
+        const uint8_t byte = (uint8_t)(stream[b >> 2] >> (24 - 8 * (b & 3)));
+        if (o + 2 > cap) return -1;
+        out[o++] = byte;
+        if (byte == 0xFF) out[o++] = 0x00;
+    }
+    return o;
+}

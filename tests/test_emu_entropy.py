@@ -1,0 +1,81 @@
+"""The DEVICE entropy-stage block code (pixo_amd/csrc/jpeg_scan_block.h: zig-zag walk, Huffman
+symbols, MSB-first packing at a bit offset, 1-padding) compiled for the host and run block by
+block — in reverse order, like lanes racing — against the oracle's entropy-coded segment.
+Covers on CPU what jpeg_entropy.hip does per lane; the workgroup scans and the stuffing copy
+are checked on the GPU (test_gpu_parity.py, whole-file byte identity)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import emu_lib as E
+import oracle_lib as O
+import synth
+
+
+def _scan_segment(jpeg: bytes) -> bytes:
+    """Bytes between the SOS header and EOI."""
+    assert jpeg[:2] == b"\xff\xd8" and jpeg[-2:] == b"\xff\xd9"
+    i = 2
+    while True:
+        assert jpeg[i] == 0xFF
+        marker, seglen = jpeg[i + 1], int.from_bytes(jpeg[i + 2:i + 4], "big")
+        i += 2 + seglen
+        if marker == 0xDA:
+            return jpeg[i:-2]
+
+
+def _emu_scan(y, cb, cr, w, h, ct, ss, optimize):
+    L = E.lib()
+    L.emu_scan.restype = C.c_long
+    L.emu_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_long]
+    L.emu_scan_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    tables = np.zeros(536, np.uint32)
+    L.emu_scan_tables(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, w, h, ct, ss, int(optimize), tables.ctypes.data)
+    mode = 0 if ct == 0 else (2 if ss == 1 else 1)
+    n = y.shape[0] + cb.shape[0] + cr.shape[0]
+    out = np.zeros(n * 260 + 64, np.uint8)
+    got = L.emu_scan(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, mode, n, tables.ctypes.data, out.ctypes.data, out.size)
+    assert got >= 0
+    return out[:got].tobytes()
+
+
+def _check(px, w, h, ct, ss, q, optimize=False):
+    y, cb, cr = O.coeffs(px, w, h, ct, ss, q)
+    want = _scan_segment(O.encode_from_coeffs(y, cb, cr, O.make_options(w, h, ct, q, ss, optimize_huffman=optimize)))
+    assert _emu_scan(y, cb, cr, w, h, ct, ss, optimize) == want
+
+
+@pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])
+@pytest.mark.parametrize("q", [1, 35, 80, 100])
+def test_device_block_coder_matches_reference_scan(mode, q):
+    ct, ss = mode
+    w, h = 72, 40
+    px = synth.noise_gray(w, h, q) if ct == 0 else synth.noise(w, h, q)
+    _check(px, w, h, ct, ss, q)
+
+
+@pytest.mark.parametrize("optimize", [False, True])
+def test_smooth_and_flat_content_long_zero_runs_and_eob(optimize):
+    # gradients / flat blocks: ZRL (16-zero runs), EOB right after DC, all-zero AC blocks
+    for gen in (synth.gradient_rgb, synth.flat_blocks):
+        _check(gen(96, 64), 96, 64, 2, 1, 80, optimize)
+        _check(gen(96, 64), 96, 64, 2, 0, 95, optimize)
+    _check(synth.constant(33, 17, 128), 33, 17, 2, 1, 50, optimize)
+    _check(synth.checkerboard(64, 64, 3), 64, 64, 2, 0, 100, optimize)
+
+
+def test_optimised_tables_from_device_histogram_visitor():
+    px = synth.noise(120, 56, 9)
+    _check(px, 120, 56, 2, 1, 60, optimize=True)
+    _check(synth.noise_gray(50, 50, 3), 50, 50, 0, 0, 85, optimize=True)
+
+
+def test_ff_bytes_are_stuffed_and_last_byte_padded_with_ones():
+    # noise at q=100 produces plenty of 0xFF bytes in the packed stream
+    px = synth.noise(64, 64, 4)
+    y, cb, cr = O.coeffs(px, 64, 64, 2, 0, 100)
+    seg = _emu_scan(y, cb, cr, 64, 64, 2, 0, False)
+    assert b"\xff\x00" in seg
+    assert all(seg[i + 1] == 0 for i in range(len(seg) - 1) if seg[i] == 0xFF)
+    _check(px, 64, 64, 2, 0, 100)

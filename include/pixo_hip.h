@@ -117,6 +117,24 @@ int pixo_hip_jpeg_entropy_encode(const int16_t *y, const int16_t *cb, const int1
                                  const pixo_jpeg_options *options, uint8_t **out,
                                  size_t *out_len);
 
+/* Entropy stage on the DEVICE from a coefficient tuple that is already in HBM (as produced by
+ * pixo_hip_jpeg_coeffs_device for ONE image): per-block Huffman coding, bit-offset prefix sum,
+ * parallel packing and 0xFF stuffing on the GPU, byte-identical to encode_scan + encode_block +
+ * BitWriterMsb (src/jpeg/mod.rs:1408-1563, src/jpeg/huffman.rs:423-481, src/bits.rs:195-293);
+ * with options->optimize_huffman the count_block statistics (src/jpeg/mod.rs:826-860) are
+ * gathered on the GPU as well.  Only the finished file crosses PCIe.  Scans that emit restart
+ * markers are copied back and coded by the host stage above.  Synchronous; the pointers must
+ * belong to the current HIP device and their producers must have completed. */
+int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const void *d_cr,
+                                        const pixo_jpeg_options *options, uint8_t **out,
+                                        size_t *out_len);
+
+/* pixo::jpeg::encode for pixels that are already in HBM (options->width * height * bpp bytes,
+ * tightly packed): coefficient kernel + device entropy stage, result in malloc'd host memory.
+ * Same validation and errors as pixo_hip_jpeg_encode. */
+int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *options,
+                                uint8_t **out, size_t *out_len);
+
 /* ---- multi-GPU band sharding -------------------------------------- */
 
 /* Splits the image into `parts` contiguous MCU-row bands; band `index` covers pixel

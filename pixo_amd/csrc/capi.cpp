@@ -441,6 +441,73 @@ int pixo_hip_jpeg_entropy_encode(const int16_t *y, const int16_t *cb, const int1
     return hand_over(v, out, out_len);
 }
 
+namespace {
+// binds the thread-local context to the HIP device that is current for the caller
+int context_on_current_device(Context **out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (t_ctx.ready && t_ctx.device != dev) (void)pixo_hip_set_device(dev);
+    t_ctx.device = dev;
+    int rc = t_ctx.ensure();
+    if (rc) return rc;
+    *out = &t_ctx;
+    return PIXO_OK;
+}
+
+int device_tuple_to_vector(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+                           const pixo_host::Geometry &g, Context &c, std::vector<uint8_t> &v)
+{
+    if (!scan_has_restart_markers(o, g)) return device_entropy_to_vector(dy, dcb, dcr, o, g, c.stream, v);
+    // restart markers: host coder on a copy of the tuple
+    const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128;
+    int rc = c.reserve_hcoef(coef_bytes);
+    if (rc) return rc;
+    int16_t *hy = static_cast<int16_t *>(c.h_coef), *hcb = hy + g.y_blocks * 64, *hcr = hcb + g.c_blocks * 64;
+    HIP_TRY(hipMemcpyAsync(hy, dy, g.y_blocks * 128, hipMemcpyDeviceToHost, c.stream));
+    if (g.c_blocks) {
+        HIP_TRY(hipMemcpyAsync(hcb, dcb, g.c_blocks * 128, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipMemcpyAsync(hcr, dcr, g.c_blocks * 128, hipMemcpyDeviceToHost, c.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    pixo_host::encode_file(hy, hcb, hcr, o, v);
+    return PIXO_OK;
+}
+} // namespace
+
+int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const void *d_cr,
+                                        const pixo_jpeg_options *options, uint8_t **out, size_t *out_len)
+{
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if ((rc = unsupported_scan_mode(*options))) return rc;
+    Context *c = nullptr;
+    if ((rc = context_on_current_device(&c))) return rc;
+    const pixo_host::Geometry g = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
+    std::vector<uint8_t> v;
+    if ((rc = device_tuple_to_vector(static_cast<const int16_t *>(d_y), static_cast<const int16_t *>(d_cb),
+                                     static_cast<const int16_t *>(d_cr), *options, g, *c, v)))
+        return rc;
+    return hand_over(v, out, out_len);
+}
+
+int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *options, uint8_t **out, size_t *out_len)
+{
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if ((rc = unsupported_scan_mode(*options))) return rc;
+    Context *c = nullptr;
+    if ((rc = context_on_current_device(&c))) return rc;
+    const pixo_host::Geometry g = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
+    int16_t *dy, *dcb, *dcr;
+    if ((rc = coeffs_on_device(d_pixels, *options, g, c->stream, &dy, &dcb, &dcr))) return rc;
+    std::vector<uint8_t> v;
+    if ((rc = device_tuple_to_vector(dy, dcb, dcr, *options, g, *c, v))) return rc;
+    return hand_over(v, out, out_len);
+}
+
 int pixo_hip_band(uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling, uint32_t parts,
                   uint32_t index, uint32_t *row_begin, uint32_t *row_end, size_t *y_offset, size_t *y_blocks,
                   size_t *c_offset, size_t *c_blocks)
@@ -476,10 +543,15 @@ int pixo_hip_set_device(int device)
 {
     Context &c = t_ctx;
     if (c.ready && c.device != device) {
-        // rebind: drop the old device's buffers lazily by resetting the context
+        // rebind: drop the old device's buffers and start over
+        (void)hipSetDevice(c.device);
         if (c.d_px) (void)hipFree(c.d_px);
         if (c.d_coef) (void)hipFree(c.d_coef);
         if (c.h_coef) (void)hipHostFree(c.h_coef);
+        if (c.h_totals) (void)hipHostFree(c.h_totals);
+        for (Context::Buf *b : {&c.e_tables, &c.e_hist, &c.e_len, &c.e_off, &c.e_tmp, &c.e_totals, &c.e_stream,
+                                &c.e_tile_ff, &c.e_tile_base, &c.e_out})
+            if (b->p) (void)hipFree(b->p);
         if (c.stream) (void)hipStreamDestroy(c.stream);
         c = Context();
     }

@@ -245,6 +245,43 @@ def entropy_encode(y, cb, cr, options: JpegOptions) -> bytes:
         L.pixo_hip_free(out)
 
 
+def _dev_ptr(x):
+    if x is None:
+        return None
+    return x.data_ptr() if hasattr(x, "data_ptr") else int(x)
+
+
+def entropy_encode_device(d_y, d_cb, d_cr, options: JpegOptions) -> bytes:
+    """Device entropy stage: coefficient tuple in HBM (torch tensors or raw pointers, one image)
+    -> JPEG file.  Per-block Huffman coding, bit-offset scan, packing and 0xFF stuffing run on
+    the GPU; only the file crosses PCIe."""
+    L = _lib.load()
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_entropy_encode_device(_dev_ptr(d_y), _dev_ptr(d_cb), _dev_ptr(d_cr), C.byref(oc),
+                                               C.byref(out), C.byref(n))
+    if rc:
+        _raise(rc)
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        L.pixo_hip_free(out)
+
+
+def encode_device(d_pixels, options: JpegOptions) -> bytes:
+    """`encode` for pixels that are already in HBM (torch tensor or raw pointer)."""
+    L = _lib.load()
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_encode_device(_dev_ptr(d_pixels), C.byref(oc), C.byref(out), C.byref(n))
+    if rc:
+        _raise(rc)
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        L.pixo_hip_free(out)
+
+
 def band(width, height, color_type, subsampling, parts, index):
     """MCU-row band `index` of `parts`: dict(row_begin,row_end,y_offset,y_blocks,
     c_offset,c_blocks).  Bands are independent sub-images of the same width."""

@@ -162,3 +162,64 @@ def test_determinism_and_linearity_properties_at_full_size():
     cb = a[1][:, 0].reshape(-1, mw)
     cbf = f[1][:, 0].reshape(-1, mw)[::-1]
     assert np.array_equal(cb, cbf)  # chroma DC of an MCU is invariant under the flip
+
+
+# ---- device entropy stage (jpeg_entropy.hip) ----------------------------------------------------
+
+def _file_from_device_tuple(px, w, h, ct, ss, q, **kw):
+    """pixels -> device tuple (coefficient kernel) -> device entropy stage -> file bytes"""
+    import torch
+    dev = torch.device("cuda:0")
+    yb, cbn = jpeg.coefficient_geometry(w, h, ct, ss)
+    d_px = torch.from_numpy(np.ascontiguousarray(px, np.uint8)).to(dev)
+    d_y = torch.empty((yb, 64), dtype=torch.int16, device=dev)
+    d_cb = torch.empty((max(cbn, 1), 64), dtype=torch.int16, device=dev)
+    d_cr = torch.empty((max(cbn, 1), 64), dtype=torch.int16, device=dev)
+    jpeg.coefficients_device(d_px, w, h, ct, ss, q, d_y, d_cb, d_cr, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return jpeg.entropy_encode_device(d_y, d_cb, d_cr, _opts(w, h, ct, ss, q, **kw))
+
+
+@pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])
+@pytest.mark.parametrize("optimize", [False, True])
+def test_device_entropy_stage_files_equal_the_oracle(mode, optimize):
+    ct, ss = mode
+    for (w, h, q, gen) in [(200, 120, 80, "noise"), (333, 77, 35, "noise"), (640, 480, 95, "gradient"),
+                           (96, 96, 100, "noise"), (1024, 64, 1, "noise"), (17, 9, 60, "noise")]:
+        if gen == "gradient":
+            px = synth.gradient_rgb(w, h) if ct == 2 else synth.gradient_rgb(w, h).reshape(-1, 3)[:, 1].copy()
+        else:
+            px = synth.noise(w, h, q) if ct == 2 else synth.noise_gray(w, h, q)
+        got = _file_from_device_tuple(px, w, h, ct, ss, q, optimize_huffman=optimize)
+        want = O.encode(px, O.make_options(w, h, ct, q, ss, optimize_huffman=optimize))
+        assert got == want, (w, h, q, gen)
+
+
+def test_device_entropy_stage_long_zero_runs_flat_and_tiny_images():
+    for px, w, h in [(synth.constant(64, 64, 128), 64, 64), (synth.flat_blocks(160, 96), 160, 96),
+                     (synth.checkerboard(128, 128, 16), 128, 128), (synth.constant(1, 1, 7), 1, 1),
+                     (synth.extremes(80, 48, 2), 80, 48)]:
+        for ss in (0, 1):
+            assert _file_from_device_tuple(px, w, h, 2, ss, 75) == O.encode(px, O.make_options(w, h, 2, 75, ss))
+
+
+def test_device_entropy_stage_hands_restart_scans_to_the_host_coder():
+    w, h = 300, 200
+    px = synth.noise(w, h, 11)
+    for restart in (1, 7, 10_000):  # 10_000 > MCU count: DRI header but no marker -> device path
+        got = _file_from_device_tuple(px, w, h, 2, 1, 70, restart_interval=restart)
+        assert got == O.encode(px, O.make_options(w, h, 2, 70, 1, restart=restart))
+
+
+def test_encode_device_resident_pixels_full_size_hashes():
+    """configs[1] through encode_device(): the reference's own 4096x4096 files."""
+    import torch
+    w = h = 4096
+    d_px = torch.from_numpy(synth.noise(w, h, 42)).to("cuda:0")
+    torch.cuda.synchronize()
+    for ss, n, sha in [(1, 11150133, "0e8ec9217215507f1ac235c22a969586906a267370249aa8653adcad5e472e49"),
+                       (0, 23336677, "831e247fe60d1aa4bb9b43e83f5744f9b061c77f05017f67830f339c70a0a564")]:
+        blob = jpeg.encode_device(d_px, _opts(w, h, 2, ss, 80))
+        assert len(blob) == n and hashlib.sha256(blob).hexdigest() == sha
+    # repeated calls reuse the context's buffers
+    assert jpeg.encode_device(d_px, _opts(w, h, 2, 1, 80)) == jpeg.encode_device(d_px, _opts(w, h, 2, 1, 80))

@@ -248,6 +248,21 @@ def main():
                      "read_only_frac_of_peak": round(in_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                      "frac_of_measured_copy_ceiling_6300": round(achieved / 6300.0, 4)},
     }
+    if batch == 1 and world == 1 and not os.environ.get("PIXO_BENCH_ABLATION"):
+        # Not `value`: the whole file (coefficient kernel + device entropy stage + copy of the file to
+        # the host) from device-resident pixels, reported beside the kernel-only metric.
+        opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling(ss)).build()
+        blob = jpeg.encode_device(ins[0], opts)
+        n_files, ts = 7, []
+        for i in range(n_files):
+            t1 = time.perf_counter()
+            blob = jpeg.encode_device(ins[i % nbuf], opts)
+            ts.append(time.perf_counter() - t1)
+        dt = sorted(ts)[n_files // 2]
+        line["whole_file"] = {"value": round(w * h / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_image": round(dt * 1e3, 3),
+                              "file_bytes": len(blob),
+                              "path": "device-resident pixels -> coefficient kernel -> device Huffman/pack/stuff kernels "
+                                      "-> file copied to host memory (pixo_hip_jpeg_encode_device)"}
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(4096, 4096, ss, q, args.cpu_seconds)
         ref = cpu_reference_wasm(4096, 4096, ss, q)

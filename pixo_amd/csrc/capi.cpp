@@ -5,6 +5,8 @@
 // usable GPU every compute entry point fails with PIXO_ERR_COMPRESSION and says so.
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -85,6 +87,18 @@ struct Context {
     };
     Buf e_tables, e_hist, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out;
     uint64_t *h_totals = nullptr; // pinned, 2 words
+    uint8_t *h_file = nullptr; size_t hfile_cap = 0; // pinned: the finished file lands here
+    int reserve_hfile(size_t n)
+    {
+        if (n > hfile_cap) {
+            if (h_file) (void)hipHostFree(h_file);
+            h_file = nullptr; hfile_cap = 0;
+            const size_t want = n + n / 4;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_file), want, hipHostMallocDefault));
+            hfile_cap = want;
+        }
+        return PIXO_OK;
+    }
 
     int ensure()
     {
@@ -194,11 +208,26 @@ bool scan_has_restart_markers(const pixo_jpeg_options &o, const pixo_host::Geome
     return o.has_restart_interval && o.restart_interval != 0 && o.restart_interval < g.units;
 }
 
-// Device coefficient tuple -> whole file in `out` (headers on the host, entropy-coded segment by
-// the kernels of jpeg_entropy.hip, copied straight into the vector).
-int device_entropy_to_vector(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
-                             const pixo_host::Geometry &g, hipStream_t stream, std::vector<uint8_t> &out)
+struct Stopwatch { // PIXO_HIP_TRACE=1: per-phase wall times of the device entropy stage on stderr
+    bool on = std::getenv("PIXO_HIP_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pixo_hip] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
+// Device coefficient tuple -> whole file in the context's PINNED host buffer (headers written by
+// the host, entropy-coded segment by the kernels of jpeg_entropy.hip and copied straight behind
+// them).  Pinned on purpose: a device-to-host copy into fresh pageable memory makes the runtime
+// pin those pages first, which costs 10-25 ms for an 11 MB file every time the address changes.
+int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+                             const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len)
 {
+    Stopwatch sw;
     Context &c = t_ctx;
     namespace pd = pixo_dev;
     const uint64_t n = g.y_blocks + 2 * g.c_blocks;
@@ -214,6 +243,7 @@ int device_entropy_to_vector(const int16_t *dy, const int16_t *dcb, const int16_
     HIP_TRY(c.e_totals.reserve(16));
     if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 16, hipHostMallocDefault));
     a.tables = c.e_tables.as<uint32_t>();
+    sw.lap("  reserve");
 
     pixo_host::HuffSet h;
     if (o.optimize_huffman) { // count_block statistics on the device, table construction on the host
@@ -234,13 +264,16 @@ int device_entropy_to_vector(const int16_t *dy, const int16_t *dcb, const int16_
     uint32_t packed[pixo_host::kScanTableWords];
     pixo_host::pack_scan_tables(h, packed);
     HIP_TRY(hipMemcpyAsync(c.e_tables.p, packed, sizeof packed, hipMemcpyHostToDevice, stream));
+    sw.lap("  tables h2d");
 
     // 1-2: block bit lengths, their prefix sum
     HIP_TRY(pd::launch_scan_lengths(a, c.e_len.as<uint32_t>(), stream));
     HIP_TRY(pd::launch_exclusive_scan(c.e_len.as<uint32_t>(), n, c.e_off.as<uint64_t>(), c.e_tmp.as<uint64_t>(),
                                       c.e_totals.as<uint64_t>(), stream));
     HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_totals.p, 8, hipMemcpyDeviceToHost, stream));
+    sw.lap("  launches");
     HIP_TRY(hipStreamSynchronize(stream)); // `packed` may go out of scope after this, too
+    sw.lap("tables+lengths+scan");
     const uint64_t total_bits = c.h_totals[0];
     const uint64_t nbytes = (total_bits + 7) / 8;
     // 3: pack
@@ -258,19 +291,47 @@ int device_entropy_to_vector(const int16_t *dy, const int16_t *dcb, const int16_
                                       c.e_totals.as<uint64_t>() + 1, stream));
     HIP_TRY(hipMemcpyAsync(c.h_totals + 1, c.e_totals.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    sw.lap("memset+pack+ff census");
     const uint64_t scan_bytes = nbytes + c.h_totals[1];
     // 5: stuff, then straight into the caller's vector behind the headers
     HIP_TRY(c.e_out.reserve(scan_bytes));
     HIP_TRY(pd::launch_stuff(c.e_stream.as<uint32_t>(), nbytes, c.e_tile_base.as<uint64_t>(), c.e_out.as<uint8_t>(), stream));
-    out.clear();
-    pixo_host::file_headers(out, o, h);
-    const size_t hdr = out.size();
-    out.resize(hdr + scan_bytes + 2);
-    HIP_TRY(hipMemcpyAsync(out.data() + hdr, c.e_out.p, scan_bytes, hipMemcpyDeviceToHost, stream));
+    std::vector<uint8_t> head;
+    pixo_host::file_headers(head, o, h);
+    const size_t hdr = head.size(), total = hdr + scan_bytes + 2;
+    int rc = c.reserve_hfile(total);
+    if (rc) return rc;
+    uint8_t *buf = c.h_file;
+    std::memcpy(buf, head.data(), hdr);
+    HIP_TRY(hipMemcpyAsync(buf + hdr, c.e_out.p, scan_bytes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    out[hdr + scan_bytes] = 0xFF; // EOI
-    out[hdr + scan_bytes + 1] = 0xD9;
+    buf[hdr + scan_bytes] = 0xFF; // EOI
+    buf[hdr + scan_bytes + 1] = 0xD9;
+    *file = buf;
+    *file_len = total;
+    sw.lap("stuff+copy to host");
     return PIXO_OK;
+}
+
+// ... and into memory the caller owns: a fresh malloc block, or storage it supplied
+int deliver(const uint8_t *file, size_t n, uint8_t **out, size_t *out_len)
+{
+    uint8_t *p = static_cast<uint8_t *>(std::malloc(n ? n : 1));
+    if (!p) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
+    std::memcpy(p, file, n);
+    *out = p;
+    *out_len = n;
+    return PIXO_OK;
+}
+
+int device_entropy_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+                             const pixo_host::Geometry &g, hipStream_t stream, uint8_t **out_buf, size_t *out_len)
+{
+    const uint8_t *file = nullptr;
+    size_t n = 0;
+    int rc = device_entropy_to_pinned(dy, dcb, dcr, o, g, stream, &file, &n);
+    if (rc) return rc;
+    return deliver(file, n, out_buf, out_len);
 }
 
 int unsupported_scan_mode(const pixo_jpeg_options &o)
@@ -282,8 +343,20 @@ int unsupported_scan_mode(const pixo_jpeg_options &o)
     return PIXO_OK;
 }
 
-int encode_to_vector(const uint8_t *data, size_t data_len, const pixo_jpeg_options &o,
-                     std::vector<uint8_t> &out)
+int hand_over(const std::vector<uint8_t> &v, uint8_t **out, size_t *out_len)
+{
+    uint8_t *p = static_cast<uint8_t *>(std::malloc(v.size() ? v.size() : 1));
+    if (!p) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
+    std::memcpy(p, v.data(), v.size());
+    *out = p;
+    *out_len = v.size();
+    return PIXO_OK;
+}
+
+// Encodes host pixels; on return `*file` points at the finished file, either in the context's
+// pinned buffer or in `spill` (host coder: scans with restart markers).
+int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options &o, std::vector<uint8_t> &spill,
+                   const uint8_t **file, size_t *file_len)
 {
     std::string msg;
     int rc = pixo_host::validate(o, true, data_len, msg);
@@ -293,7 +366,9 @@ int encode_to_vector(const uint8_t *data, size_t data_len, const pixo_jpeg_optio
     if (scan_has_restart_markers(o, g) || std::getenv("PIXO_HIP_HOST_ENTROPY")) {
         const int16_t *y, *cb, *cr;
         if ((rc = coeffs_to_pinned(data, o, g, &y, &cb, &cr))) return rc;
-        pixo_host::encode_file(y, cb, cr, o, out);
+        pixo_host::encode_file(y, cb, cr, o, spill);
+        *file = spill.data();
+        *file_len = spill.size();
         return PIXO_OK;
     }
     Context &c = t_ctx;
@@ -304,17 +379,7 @@ int encode_to_vector(const uint8_t *data, size_t data_len, const pixo_jpeg_optio
     HIP_TRY(hipMemcpyAsync(c.d_px, data, px_bytes, hipMemcpyHostToDevice, c.stream));
     int16_t *dy, *dcb, *dcr;
     if ((rc = coeffs_on_device(c.d_px, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
-    return device_entropy_to_vector(dy, dcb, dcr, o, g, c.stream, out);
-}
-
-int hand_over(const std::vector<uint8_t> &v, uint8_t **out, size_t *out_len)
-{
-    uint8_t *p = static_cast<uint8_t *>(std::malloc(v.size() ? v.size() : 1));
-    if (!p) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
-    std::memcpy(p, v.data(), v.size());
-    *out = p;
-    *out_len = v.size();
-    return PIXO_OK;
+    return device_entropy_to_pinned(dy, dcb, dcr, o, g, c.stream, file, file_len);
 }
 
 } // namespace
@@ -335,22 +400,26 @@ void pixo_jpeg_options_from_preset(pixo_jpeg_options *o, uint32_t width, uint32_
 int pixo_hip_jpeg_encode(const uint8_t *data, size_t data_len, const pixo_jpeg_options *options,
                          uint8_t **out, size_t *out_len)
 {
-    std::vector<uint8_t> v;
-    int rc = encode_to_vector(data, data_len, *options, v);
+    std::vector<uint8_t> spill;
+    const uint8_t *file = nullptr;
+    size_t n = 0;
+    int rc = encode_to_view(data, data_len, *options, spill, &file, &n);
     if (rc) return rc;
-    return hand_over(v, out, out_len);
+    return deliver(file, n, out, out_len);
 }
 
 int pixo_hip_jpeg_encode_into(uint8_t *output, size_t capacity, const uint8_t *data, size_t data_len,
                               const pixo_jpeg_options *options, size_t *out_len)
 {
-    std::vector<uint8_t> v;
-    int rc = encode_to_vector(data, data_len, *options, v);
+    std::vector<uint8_t> spill;
+    const uint8_t *file = nullptr;
+    size_t n = 0;
+    int rc = encode_to_view(data, data_len, *options, spill, &file, &n);
     if (rc) return rc;
-    *out_len = v.size();
-    if (v.size() > capacity)
-        return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(v.size()) + " bytes");
-    std::memcpy(output, v.data(), v.size());
+    *out_len = n;
+    if (n > capacity)
+        return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(n) + " bytes");
+    std::memcpy(output, file, n);
     return PIXO_OK;
 }
 
@@ -455,10 +524,10 @@ int context_on_current_device(Context **out)
     return PIXO_OK;
 }
 
-int device_tuple_to_vector(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
-                           const pixo_host::Geometry &g, Context &c, std::vector<uint8_t> &v)
+int device_tuple_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+                           const pixo_host::Geometry &g, Context &c, uint8_t **out, size_t *out_len)
 {
-    if (!scan_has_restart_markers(o, g)) return device_entropy_to_vector(dy, dcb, dcr, o, g, c.stream, v);
+    if (!scan_has_restart_markers(o, g)) return device_entropy_to_malloc(dy, dcb, dcr, o, g, c.stream, out, out_len);
     // restart markers: host coder on a copy of the tuple
     const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128;
     int rc = c.reserve_hcoef(coef_bytes);
@@ -470,8 +539,9 @@ int device_tuple_to_vector(const int16_t *dy, const int16_t *dcb, const int16_t 
         HIP_TRY(hipMemcpyAsync(hcr, dcr, g.c_blocks * 128, hipMemcpyDeviceToHost, c.stream));
     }
     HIP_TRY(hipStreamSynchronize(c.stream));
+    std::vector<uint8_t> v;
     pixo_host::encode_file(hy, hcb, hcr, o, v);
-    return PIXO_OK;
+    return hand_over(v, out, out_len);
 }
 } // namespace
 
@@ -485,11 +555,8 @@ int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const
     Context *c = nullptr;
     if ((rc = context_on_current_device(&c))) return rc;
     const pixo_host::Geometry g = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
-    std::vector<uint8_t> v;
-    if ((rc = device_tuple_to_vector(static_cast<const int16_t *>(d_y), static_cast<const int16_t *>(d_cb),
-                                     static_cast<const int16_t *>(d_cr), *options, g, *c, v)))
-        return rc;
-    return hand_over(v, out, out_len);
+    return device_tuple_to_malloc(static_cast<const int16_t *>(d_y), static_cast<const int16_t *>(d_cb),
+                                  static_cast<const int16_t *>(d_cr), *options, g, *c, out, out_len);
 }
 
 int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *options, uint8_t **out, size_t *out_len)
@@ -503,9 +570,7 @@ int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *o
     const pixo_host::Geometry g = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
     int16_t *dy, *dcb, *dcr;
     if ((rc = coeffs_on_device(d_pixels, *options, g, c->stream, &dy, &dcb, &dcr))) return rc;
-    std::vector<uint8_t> v;
-    if ((rc = device_tuple_to_vector(dy, dcb, dcr, *options, g, *c, v))) return rc;
-    return hand_over(v, out, out_len);
+    return device_tuple_to_malloc(dy, dcb, dcr, *options, g, *c, out, out_len);
 }
 
 int pixo_hip_band(uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling, uint32_t parts,
@@ -549,6 +614,7 @@ int pixo_hip_set_device(int device)
         if (c.d_coef) (void)hipFree(c.d_coef);
         if (c.h_coef) (void)hipHostFree(c.h_coef);
         if (c.h_totals) (void)hipHostFree(c.h_totals);
+        if (c.h_file) (void)hipHostFree(c.h_file);
         for (Context::Buf *b : {&c.e_tables, &c.e_hist, &c.e_len, &c.e_off, &c.e_tmp, &c.e_totals, &c.e_stream,
                                 &c.e_tile_ff, &c.e_tile_base, &c.e_out})
             if (b->p) (void)hipFree(b->p);

@@ -10,7 +10,7 @@ w = h = 4096
 px = synth.noise(w, h, 42)
 o = jpeg.JpegOptions.builder(w, h).quality(80).subsampling(jpeg.Subsampling.S420).build()
 for name, fn in [("coefficients() host->host (H2D + kernel + D2H + memcpy)", lambda: jpeg.coefficients(px, o)),
-                 ("encode() whole file (H2D + kernel + D2H + 1-thread host Huffman)", lambda: jpeg.encode(px, o))]:
+                 ("encode() whole file (H2D + kernels incl. device entropy stage + file D2H)", lambda: jpeg.encode(px, o))]:
     fn()
     ts = []
     for _ in range(5):

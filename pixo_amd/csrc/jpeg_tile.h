@@ -482,16 +482,18 @@ PIXO_DEV void aan8_shift(float dc_shift, float &d0, float &d1, float &d2, float 
 //
 // Fast path: r = x * fl(1/q), n = rint(r).  Let t = x/q (real) and f = fl(t) the
 // reference quotient.  |r - t| <= |t|(2^-24 + 2^-24 + 2^-48) and |f - t| <= 2^-24|t|,
-// so |r - f| < 2^-22 |r| =: delta.  If no half-integer lies within delta' = 2^-21 |r|
-// (twice delta; the slack absorbs the rounding of the test itself) of r, then r and f
-// sit strictly inside the same interval (k-1/2, k+1/2) and both roundings — to-nearest-even
-// for r, half-away for f — give k.  Otherwise the row takes the exact divide.  Checked by
-// enumeration over every f32 |x| <= 4096 and every q in 1..255: tests/emu/sweep_quant.py.
+// so |r - f| <= 3 * 2^-24 |t| (+ second-order terms).  If no half-integer lies within
+// delta = 2^-22 |r| = 4 * 2^-24 |r| of r, then r and f sit strictly inside the same interval
+// (k-1/2, k+1/2) and both roundings — to-nearest-even for r, half-away for f — give k.
+// Otherwise the element takes the exact divide.  The margin between 3 and 4 units is thin
+// enough that the claim rests on ENUMERATION, not on the sketch: every f32 |x| <= 4096 with
+// every q in 1..255 (tests/emu/sweep_quant.py -> profiles/quant_fastpath_sweep.txt, 0 wrong;
+// 2^-21 passes as well and flags twice as many).
 //
 //   s = r + 1.5*2^23      rounds r to an integer (RNE) and leaves it, two's complement, in
 //                         the low mantissa bits: bits(s) = 0x4B400000 + n for |n| < 2^22
 //   n = s - 1.5*2^23      exact;   d = r - n exact (|d| <= 1/2, Sterbenz)
-//   t = |d| + 2^-21|r|    (one fma) >= 1/2 iff the lane is risky; the row keeps the maximum
+//   t = |d| + 2^-22|r|    (one fma) >= 1/2 iff the lane is risky; the row keeps the maximum
 //                         (v_max3_f32: two elements per instruction)
 // A flagged row (a few per cent of rows on noise, far fewer on photographs) repeats the test
 // per element and takes the reference's own divide only for the elements some lane flagged —
@@ -499,7 +501,7 @@ PIXO_DEV void aan8_shift(float dc_shift, float &d0, float &d1, float &d2, float 
 // the exact path only; the fast path's rcp already contains it (exact power of two).
 constexpr float kRoundMagic = 12582912.0f; // 1.5 * 2^23
 #ifndef PIXO_QUANT_EPS // (overridden only by tests/emu/sweep_quant.py experiments)
-#define PIXO_QUANT_EPS 0x1p-21f
+#define PIXO_QUANT_EPS 0x1p-22f
 #endif
 
 #if defined(PIXO_EMU)
@@ -526,7 +528,7 @@ PIXO_DEV void quant_row8(const float *x, const float *rcp, qtab_t q, float scale
         s[c + 1] = r1 + kRoundMagic;
         worst = __builtin_fmaxf(__builtin_fmaxf(worst, quant_risk(r0, s[c])), quant_risk(r1, s[c + 1]));
     }
-    if (PIXO_ANY_LANE(worst >= 0.5f)) { // rare: some quotient within 2^-21 (relative) of a rounding boundary
+    if (PIXO_ANY_LANE(worst >= 0.5f)) { // rare: some quotient within 2^-22 (relative) of a rounding boundary
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             float xc = x[c];

@@ -149,3 +149,22 @@ def histograms(y, cb, cr, opts):
                                np.ascontiguousarray(cr).ctypes.data, C.byref(opts),
                                dc.ctypes.data, ac.ctypes.data)
     return dc, ac
+
+
+# ---- PNG row filters + Adler-32 (oracle/pixo_png_oracle.c) ---------------------------------------
+S_NONE, S_SUB, S_UP, S_AVERAGE, S_PAETH, S_MINSUM, S_ADAPTIVE, S_ADAPTIVE_FAST, S_BIGRAMS = range(9)
+
+
+def png_filter(pixels, w, h, bpp, strategy, stateful_fast=False):
+    """-> (filtered stream bytes [h * (w*bpp + 1)], adler32)"""
+    L = lib()
+    L.po_png_filter.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.po_png_filter.restype = C.c_int
+    px = np.ascontiguousarray(pixels, dtype=np.uint8)
+    assert px.size == w * h * bpp
+    out = np.empty(h * (w * bpp + 1), np.uint8)
+    ad = C.c_uint32()
+    rc = L.po_png_filter(px.ctypes.data, w, h, bpp, strategy, int(stateful_fast), out.ctypes.data, C.byref(ad))
+    if rc:
+        raise OracleError(rc)
+    return out, ad.value

@@ -135,6 +135,35 @@ int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const
 int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *options,
                                 uint8_t **out, size_t *out_len);
 
+/* ---- PNG row filters + Adler-32 ------------------------------ */
+
+/* pixo::png::FilterStrategy in declaration order (src/png/mod.rs:345-364).  Bigrams is not
+ * accelerated (PIXO_ERR_COMPRESSION). */
+enum pixo_png_filter_strategy {
+    PIXO_PNG_NONE = 0, PIXO_PNG_SUB = 1, PIXO_PNG_UP = 2, PIXO_PNG_AVERAGE = 3, PIXO_PNG_PAETH = 4,
+    PIXO_PNG_MINSUM = 5, PIXO_PNG_ADAPTIVE = 6, PIXO_PNG_ADAPTIVE_FAST = 7, PIXO_PNG_BIGRAMS = 8
+};
+/* flags */
+#define PIXO_PNG_NO_RAYON 1u /* semantics of a build without the `parallel` feature (wasm): AdaptiveFast is
+                                 always the sequential, stateful variant (src/png/filter.rs:147-167) */
+
+/* Replaces pixo::png::filter::apply_filters (src/png/filter.rs:51-206) and the Adler-32 the zlib
+ * wrapper computes over its result (src/simd/fallback.rs:8-25, src/compress/deflate.rs:1044):
+ * `out` receives height * (width * bytes_per_pixel + 1) bytes — filter-type byte + filtered row,
+ * exactly what the reference hands to its DEFLATE — and *adler32 the checksum of those bytes.
+ * Same strategy rules as the reference: images of <= 4096 pixels use Sub instead of the adaptive
+ * strategies; the adaptive strategies treat rows independently when height > 32 (the rayon path
+ * of the default build) and sequentially otherwise.  bytes_per_pixel in {1,2,3,4,6,8}.
+ * Host pointers; synchronous. */
+int pixo_hip_png_filter(const uint8_t *data, size_t data_len, uint32_t width, uint32_t height,
+                        uint32_t bytes_per_pixel, uint8_t strategy, uint32_t flags, uint8_t *out,
+                        size_t out_capacity, uint32_t *adler32);
+
+/* Same on DEVICE pointers of the current HIP device (d_out: height * (row bytes + 1) bytes).
+ * Synchronous: returns after the checksum has been combined. */
+int pixo_hip_png_filter_device(const void *d_data, uint32_t width, uint32_t height, uint32_t bytes_per_pixel,
+                               uint8_t strategy, uint32_t flags, void *d_out, uint32_t *adler32);
+
 /* ---- multi-GPU band sharding -------------------------------------- */
 
 /* Splits the image into `parts` contiguous MCU-row bands; band `index` covers pixel

@@ -9,7 +9,7 @@ Host-side mirror of the reference's public API for this path:
 
 Everything below this package is the C ABI of include/pixo_hip.h (pixo_amd/libpixo_hip.so).
 """
-from . import error, jpeg  # noqa: F401
+from . import error, jpeg, png  # noqa: F401
 from .color import ColorType  # noqa: F401
 from .error import Error  # noqa: F401
 

@@ -1,0 +1,307 @@
+// png_filter.hip — gfx950 kernel of the PNG row-filter stage: what the
+// reference's apply_filters (src/png/filter.rs:51-206) hands to DEFLATE — one filter-type byte
+// plus the filtered row, for every row — and the per-row sums from which the zlib wrapper's
+// Adler-32 (src/simd/fallback.rs:8-25, computed once over the whole filtered stream,
+// src/compress/deflate.rs:1044) is combined.
+//
+// Rows are independent on the encode side (every predictor reads ORIGINAL neighbours): one
+// workgroup per row.  Pass 1 scores the candidate filters (score_filter: sum of |byte as i8|,
+// fallback.rs:93) with four bytes per register — SWAR subtract / average, Paeth in packed 16-bit
+// lanes, v_sad_u8 for the score — and reduces the scores across the workgroup; thread-uniform code
+// then replays the reference's decision sequence (adaptive_filter :302-393 with its early exits,
+// adaptive_filter_fast :474-527, or a fixed filter); pass 2 recomputes only the winning filter,
+// stores the row and accumulates the Adler sums.  The row is read twice (second time from L2),
+// written once: no intermediate in HBM.  Byte work bounded by HBM and VALU issue; no MFMA.
+#include <hip/hip_runtime.h>
+
+#include "png_filter.hpp"
+
+namespace pixo_dev {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr uint32_t kH = 0x80808080u;
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t sub4(uint32_t a, uint32_t b)
+{ // per-byte a - b (mod 256), no borrow between bytes
+    return ((a | kH) - (b & ~kH)) ^ ((a ^ ~b) & kH);
+}
+__device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b)
+{ // per-byte floor((a + b) / 2)  (fallback.rs:127: u16 sum, / 2)
+    return (a & b) + (((a ^ b) & 0xFEFEFEFEu) >> 1);
+}
+__device__ __forceinline__ s16x2 as_s(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t le_mask(s16x2 x, s16x2 y)
+{ // per 16-bit lane: 0xFFFF where x <= y (values small and non-negative)
+    return as_u((x - y - (s16x2)(1)) >> 15);
+}
+// Paeth predictor (fallback.rs:144-159) on two bytes held in the low bytes of 16-bit lanes
+__device__ __forceinline__ uint32_t paeth2(uint32_t a, uint32_t b, uint32_t c)
+{
+    const s16x2 bc = as_s(b) - as_s(c), ac = as_s(a) - as_s(c);
+    const s16x2 pa = __builtin_elementwise_abs(bc), pb = __builtin_elementwise_abs(ac), pc = __builtin_elementwise_abs(bc + ac);
+    const uint32_t m1 = le_mask(pa, pb) & le_mask(pa, pc), m2 = le_mask(pb, pc);
+    const uint32_t bc_sel = (b & m2) | (c & ~m2);
+    return (a & m1) | (bc_sel & ~m1);
+}
+__device__ __forceinline__ uint32_t paeth4(uint32_t a, uint32_t b, uint32_t c)
+{
+    const uint32_t M = 0x00FF00FFu;
+    const uint32_t e = paeth2(a & M, b & M, c & M);
+    const uint32_t o = paeth2((a >> 8) & M, (b >> 8) & M, (c >> 8) & M);
+    return e | (o << 8);
+}
+__device__ __forceinline__ uint32_t score4(uint32_t f, uint32_t acc)
+{ // sum over the 4 bytes of |byte as i8|: |f - 128 biased| = |(f ^ 0x80) - 0x80|
+    return __builtin_amdgcn_sad_u8(f ^ kH, kH, acc);
+}
+
+enum { F_NONE = 0, F_SUB = 1, F_UP = 2, F_AVG = 3, F_PAETH = 4 };
+
+struct Group { // 16 bytes of the row and their neighbours, as dwords
+    uint32_t cur[4], left[4], up[4], ul[4];
+    uint32_t valid[4]; // byte mask of the bytes that exist
+};
+
+// bytes [4k - BPP, 4k - BPP + 4) of the row as one dword, from X = {dword k-2, dword k-1, dword k}
+template <int BPP> __device__ __forceinline__ uint32_t left_of(const uint32_t *x6, int j)
+{ // x6 = {L0, L1, c0, c1, c2, c3}: dword j of the group sits at x6[2 + j]
+    constexpr int dummy = 0; (void)dummy;
+    const int p = 8 + 4 * j - BPP, idx = p >> 2, sh = p & 3;
+    return sh ? __builtin_amdgcn_alignbyte(x6[idx + 1], x6[idx], sh) : x6[idx];
+}
+
+// One guarded dword (k may be negative or past the end): used by the unaligned variant for
+// everything and by the aligned variant for a row's last, partial group.
+template <bool FAST> __device__ __forceinline__ uint32_t load_dword(const uint8_t *row, int k, int nbytes)
+{
+    if (k < 0 || 4 * k >= nbytes) return 0;
+    if (FAST) return *reinterpret_cast<const uint32_t *>(row + 4 * k);
+    uint32_t v = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+        if (4 * k + b < nbytes) v |= (uint32_t)row[4 * k + b] << (8 * b);
+    return v;
+}
+
+// FAST (row base and row length multiples of 4): a group that lies wholly inside the row is read
+// with one 16-byte and one 8-byte load per row, no branch near them (the 8 bytes before the
+// row's first group do not exist: address clamped, value zeroed by a select).
+template <int BPP, bool FAST>
+__device__ __forceinline__ void load_six(const uint8_t *row, int k0, int n, bool whole, uint32_t *x)
+{
+    if (FAST && whole) {
+        const uint2 l = *reinterpret_cast<const uint2 *>(row + 4 * (k0 >= 2 ? k0 - 2 : 0));
+        const uint4 c = *reinterpret_cast<const uint4 *>(row + 4 * k0);
+        x[0] = k0 >= 2 ? l.x : 0u; x[1] = k0 >= 2 ? l.y : 0u; // (k0 is a multiple of 4)
+        x[2] = c.x; x[3] = c.y; x[4] = c.z; x[5] = c.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[i] = load_dword<FAST>(row, k0 - 2 + i, n);
+    }
+}
+
+template <int BPP, bool FAST>
+__device__ __forceinline__ void load_group(const uint8_t *row, const uint8_t *prev, int k0, int n, Group &g)
+{
+    uint32_t x[6], u[6];
+    const bool whole = 4 * (k0 + 4) <= n;
+    load_six<BPP, FAST>(row, k0, n, whole, x);
+    if (prev) load_six<BPP, FAST>(prev, k0, n, whole, u);
+    else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) u[i] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        g.cur[j] = x[2 + j]; g.up[j] = u[2 + j];
+        g.left[j] = left_of<BPP>(x, j); g.ul[j] = left_of<BPP>(u, j);
+        const int rem = n - 4 * (k0 + j);
+        g.valid[j] = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : (1u << (8 * rem)) - 1u);
+    }
+}
+
+__device__ __forceinline__ uint32_t filtered(int f, const Group &g, int j)
+{
+    switch (f) {
+    case F_NONE: return g.cur[j];
+    case F_SUB: return sub4(g.cur[j], g.left[j]);
+    case F_UP: return sub4(g.cur[j], g.up[j]);
+    case F_AVG: return sub4(g.cur[j], avg4(g.left[j], g.up[j]));
+    default: return sub4(g.cur[j], paeth4(g.left[j], g.up[j], g.ul[j]));
+    }
+}
+
+__device__ __forceinline__ unsigned long long wg_sum(unsigned long long v, unsigned long long *lds)
+{ // 256 threads; every thread gets the total
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+// the reference's decision sequences, replayed on the five row scores
+__device__ __forceinline__ int decide(int strategy, const unsigned long long s[5], unsigned long long n)
+{
+    if (strategy <= PNG_S_PAETH) return strategy; // None, Sub, Up, Average, Paeth
+    if (strategy == PNG_S_ADAPTIVE_FAST) { // filter.rs:474-527
+        const unsigned long long early = n / 8 + 1;
+        int best = F_SUB;
+        unsigned long long bs = s[F_SUB];
+        if (bs <= early) return best;
+        if (s[F_UP] < bs) { bs = s[F_UP]; best = F_UP; }
+        if (bs <= early) return best;
+        if (s[F_PAETH] < bs) best = F_PAETH;
+        return best;
+    }
+    // Adaptive / MinSum, filter.rs:302-404: None, Sub, Up, Average, Paeth in this order, a later
+    // filter wins only with a strictly smaller score, stop as soon as the best is <= early (or 0)
+    const unsigned long long early = n / 4 + 1;
+    int best = F_NONE;
+    unsigned long long bs = s[F_NONE];
+    if (bs <= early || bs == 0) return best;
+#pragma unroll
+    for (int f = F_SUB; f <= F_AVG; f++) {
+        if (s[f] < bs) { bs = s[f]; best = f; if (bs == 0 || bs <= early) return best; }
+    }
+    if (s[F_PAETH] < bs) best = F_PAETH;
+    return best;
+}
+
+struct Args {
+    const uint8_t *data;
+    uint8_t *out;
+    unsigned long long *row_sums; // [height][2]: sum of bytes, position-weighted sum (Adler partials)
+    const int *forced;            // sequential AdaptiveFast: rows >= 1 use *forced as a fixed filter
+    int *winner0;                 //   ... written by row 0
+    uint64_t row_bytes;
+    uint32_t height, first_row;
+    int strategy;
+};
+
+template <int BPP, bool FAST> __global__ __launch_bounds__(kThreads) void png_filter_kernel(const Args a)
+{
+    __shared__ unsigned long long red[4];
+    const uint32_t y = a.first_row + blockIdx.x;
+    const int n = (int)a.row_bytes; // < 2^31 (checked by the launcher)
+    const uint8_t *row = a.data + (size_t)y * a.row_bytes;
+    const uint8_t *prev = y ? row - a.row_bytes : nullptr;
+    const int ndw = (n + 3) / 4, per_iter = kThreads * 4;
+    int strategy = a.forced ? *a.forced : a.strategy;
+
+    int f = strategy;
+    if (strategy > PNG_S_PAETH) {
+        // pass 1: scores of the candidates (AdaptiveFast never looks at None / Average)
+        uint32_t sc[5] = {0, 0, 0, 0, 0};
+        const bool fast = strategy == PNG_S_ADAPTIVE_FAST;
+        for (int k0 = (int)threadIdx.x * 4; k0 < ndw; k0 += per_iter) {
+            Group g;
+            load_group<BPP, FAST>(row, prev, k0, n, g);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t m = g.valid[j];
+                sc[F_SUB] = score4(filtered(F_SUB, g, j) & m, sc[F_SUB]);
+                sc[F_UP] = score4(filtered(F_UP, g, j) & m, sc[F_UP]);
+                sc[F_PAETH] = score4(filtered(F_PAETH, g, j) & m, sc[F_PAETH]);
+                if (!fast) {
+                    sc[F_NONE] = score4(g.cur[j] & m, sc[F_NONE]);
+                    sc[F_AVG] = score4(filtered(F_AVG, g, j) & m, sc[F_AVG]);
+                }
+            }
+        }
+        unsigned long long tot[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) tot[i] = wg_sum(sc[i], red);
+        f = decide(strategy, tot, (unsigned long long)n);
+    }
+    if (a.winner0 && y == 0 && threadIdx.x == 0) *a.winner0 = f;
+
+    // pass 2: the winning filter -> output row (filter byte + n bytes), Adler partial sums
+    uint8_t *orow = a.out + (size_t)y * (a.row_bytes + 1);
+    const unsigned long long L = (unsigned long long)n + 1; // bytes of the output row; byte i has weight L - i
+    unsigned long long s1 = 0, s2 = 0;
+    if (threadIdx.x == 0) { orow[0] = (uint8_t)f; s1 = (unsigned)f; s2 = L * (unsigned)f; }
+    for (int k0 = (int)threadIdx.x * 4; k0 < ndw; k0 += per_iter) {
+        Group g;
+        load_group<BPP, FAST>(row, prev, k0, n, g);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j;
+            if (k >= ndw) break;
+            uint32_t v;
+            // (a switch on the uniform f keeps one filter's code live per row)
+            if (f == F_NONE) v = g.cur[j];
+            else if (f == F_SUB) v = filtered(F_SUB, g, j);
+            else if (f == F_UP) v = filtered(F_UP, g, j);
+            else if (f == F_AVG) v = filtered(F_AVG, g, j);
+            else v = filtered(F_PAETH, g, j);
+            v &= g.valid[j];
+            uint8_t *dst = orow + 1 + 4 * k;
+            if (g.valid[j] == 0xFFFFFFFFu) {
+                __builtin_memcpy(dst, &v, 4); // unaligned dword store (rows of the output start at odd offsets)
+            } else {
+                for (int b = 0; b < 4; b++) if (4 * k + b < n) dst[b] = (uint8_t)(v >> (8 * b));
+            }
+            // bytes at output positions p = 1 + 4k + b, weight L - p
+            const unsigned sum = __builtin_amdgcn_sad_u8(v, 0u, 0u);
+            const unsigned ramp = __builtin_amdgcn_udot4(v, 0x00010203u, 0u, false); // 3*b0 + 2*b1 + 1*b2 + 0*b3
+            s1 += sum;
+            s2 += (L - (unsigned long long)(4 * k + 4)) * sum + ramp;
+        }
+    }
+    const unsigned long long t1 = wg_sum(s1, red), t2 = wg_sum(s2, red);
+    if (threadIdx.x == 0) { a.row_sums[2 * (size_t)y] = t1; a.row_sums[2 * (size_t)y + 1] = t2; }
+}
+
+template <int BPP> hipError_t launch_bpp(const Args &a, uint32_t rows, bool fast, hipStream_t s)
+{
+    if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true>), dim3(rows), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((png_filter_kernel<BPP, false>), dim3(rows), dim3(kThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows(const Args &a, uint32_t rows, uint32_t bpp, bool fast, hipStream_t s)
+{
+    switch (bpp) {
+    case 1: return launch_bpp<1>(a, rows, fast, s);
+    case 2: return launch_bpp<2>(a, rows, fast, s);
+    case 3: return launch_bpp<3>(a, rows, fast, s);
+    case 4: return launch_bpp<4>(a, rows, fast, s);
+    case 6: return launch_bpp<6>(a, rows, fast, s);
+    case 8: return launch_bpp<8>(a, rows, fast, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+} // namespace
+
+hipError_t launch_png_filter(const void *d_data, uint32_t width, uint32_t height, uint32_t bpp, int strategy,
+                             bool sequential_fast, void *d_out, unsigned long long *d_row_sums, int *d_scratch,
+                             hipStream_t stream)
+{
+    Args a;
+    a.data = static_cast<const uint8_t *>(d_data);
+    a.out = static_cast<uint8_t *>(d_out);
+    a.row_sums = d_row_sums;
+    a.row_bytes = (uint64_t)width * bpp;
+    if (a.row_bytes >= 0x7FFFFFF0ull) return hipErrorInvalidValue; // 32-bit byte indices inside a row
+    a.height = height;
+    a.strategy = strategy;
+    a.forced = nullptr; a.winner0 = nullptr; a.first_row = 0;
+    const bool fast = reinterpret_cast<uintptr_t>(d_data) % 4 == 0 && a.row_bytes % 4 == 0;
+    if (strategy == PNG_S_ADAPTIVE_FAST && sequential_fast && height > 1) {
+        // sequential AdaptiveFast (filter.rs:147-167): the first row's winner (always Sub, Up or
+        // Paeth) is forced on every later row; two launches, no host round trip
+        a.winner0 = d_scratch;
+        hipError_t e = launch_rows(a, 1, bpp, fast, stream);
+        if (e != hipSuccess) return e;
+        a.winner0 = nullptr; a.forced = d_scratch; a.first_row = 1;
+        return launch_rows(a, height - 1, bpp, fast, stream);
+    }
+    return launch_rows(a, height, bpp, fast, stream);
+}
+
+} // namespace pixo_dev

@@ -164,6 +164,17 @@ int pixo_hip_png_filter(const uint8_t *data, size_t data_len, uint32_t width, ui
 int pixo_hip_png_filter_device(const void *d_data, uint32_t width, uint32_t height, uint32_t bytes_per_pixel,
                                uint8_t strategy, uint32_t flags, void *d_out, uint32_t *adler32);
 
+/* Asynchronous form for resident pipelines: enqueues the filter kernel on `stream` (a
+ * hipStream_t, NULL = default stream) and leaves the per-row checksum partials — two u64 per row:
+ * byte sum, position-weighted byte sum — in d_row_sums[2 * height]; d_scratch is 16 bytes of
+ * device memory.  pixo_hip_png_adler32_from_row_sums turns a HOST copy of the partials into the
+ * zlib Adler-32 of the whole filtered stream. */
+int pixo_hip_png_filter_async(const void *d_data, uint32_t width, uint32_t height, uint32_t bytes_per_pixel,
+                              uint8_t strategy, uint32_t flags, void *d_out, void *d_row_sums,
+                              void *d_scratch, void *stream);
+uint32_t pixo_hip_png_adler32_from_row_sums(const uint64_t *row_sums, uint32_t width, uint32_t height,
+                                            uint32_t bytes_per_pixel);
+
 /* ---- multi-GPU band sharding -------------------------------------- */
 
 /* Splits the image into `parts` contiguous MCU-row bands; band `index` covers pixel

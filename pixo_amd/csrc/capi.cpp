@@ -656,6 +656,28 @@ int pixo_hip_png_filter(const uint8_t *data, size_t data_len, uint32_t width, ui
     return PIXO_OK;
 }
 
+int pixo_hip_png_filter_async(const void *d_data, uint32_t width, uint32_t height, uint32_t bytes_per_pixel,
+                              uint8_t strategy, uint32_t flags, void *d_out, void *d_row_sums, void *d_scratch,
+                              void *stream)
+{
+    int run = 0;
+    bool seq = false;
+    int rc = png_plan(width, height, bytes_per_pixel, strategy, flags, &run, &seq);
+    if (rc) return rc;
+    HIP_TRY(pixo_dev::launch_png_filter(d_data, width, height, bytes_per_pixel, run, seq, d_out,
+                                        static_cast<unsigned long long *>(d_row_sums), static_cast<int *>(d_scratch),
+                                        static_cast<hipStream_t>(stream)));
+    return PIXO_OK;
+}
+
+uint32_t pixo_hip_png_adler32_from_row_sums(const uint64_t *row_sums, uint32_t width, uint32_t height,
+                                            uint32_t bytes_per_pixel)
+{
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "u64");
+    return combine_adler(reinterpret_cast<const unsigned long long *>(row_sums), height,
+                         static_cast<uint64_t>(width) * bytes_per_pixel + 1);
+}
+
 int pixo_hip_png_filter_device(const void *d_data, uint32_t width, uint32_t height, uint32_t bytes_per_pixel,
                                uint8_t strategy, uint32_t flags, void *d_out, uint32_t *adler32)
 {

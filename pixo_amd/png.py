@@ -58,3 +58,25 @@ def apply_filters_device(d_data, width, height, bytes_per_pixel, d_out, strategy
     if rc:
         _raise(rc)
     return ad.value
+
+
+def apply_filters_async(d_data, width, height, bytes_per_pixel, d_out, d_row_sums, d_scratch,
+                        strategy=FilterStrategy.ADAPTIVE, flags=0, stream=0):
+    """Enqueue only (no synchronisation): d_row_sums receives 2 u64 per row; combine a host copy of
+    them with `adler32_from_row_sums`."""
+    L = _lib.load()
+
+    def ptr(x):
+        return x.data_ptr() if hasattr(x, "data_ptr") else int(x)
+
+    rc = L.pixo_hip_png_filter_async(ptr(d_data), width, height, bytes_per_pixel, int(strategy), flags, ptr(d_out),
+                                     ptr(d_row_sums), ptr(d_scratch), C.c_void_p(stream) if stream else None)
+    if rc:
+        _raise(rc)
+
+
+def adler32_from_row_sums(row_sums, width, height, bytes_per_pixel):
+    L = _lib.load()
+    a = np.ascontiguousarray(row_sums, dtype=np.uint64)
+    assert a.size == 2 * height
+    return int(L.pixo_hip_png_adler32_from_row_sums(a.ctypes.data, width, height, bytes_per_pixel)) & 0xFFFFFFFF

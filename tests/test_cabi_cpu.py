@@ -20,7 +20,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     # header and binding agree on the symbol list
     import os, re
     hdr = open(os.path.join(os.path.dirname(_lib.__file__), "..", "include", "pixo_hip.h")).read()
-    declared = set(re.findall(r"\b(pixo_(?:hip|jpeg)_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(pixo_(?:hip|jpeg)_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.SYMBOLS)
     assert b"gfx950" in lib.pixo_hip_version()
 

@@ -34,18 +34,27 @@ __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b)
 }
 __device__ __forceinline__ s16x2 as_s(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ uint32_t le_mask(s16x2 x, s16x2 y)
-{ // per 16-bit lane: 0xFFFF where x <= y (values small and non-negative)
-    return as_u((x - y - (s16x2)(1)) >> 15);
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t gt_mask(s16x2 x, s16x2 y)
+{ // per 16-bit lane: 0xFFFF where x > y  (two packed ops: subtract, arithmetic shift)
+    return as_u((y - x) >> 15);
 }
-// Paeth predictor (fallback.rs:144-159) on two bytes held in the low bytes of 16-bit lanes
+__device__ __forceinline__ s16x2 absdiff(uint32_t x, uint32_t y)
+{ // |x - y| of small non-negative lanes: saturating differences OR-ed (three packed ops)
+    const u16x2 ux = __builtin_bit_cast(u16x2, x), uy = __builtin_bit_cast(u16x2, y);
+    return as_s(__builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(ux, uy)) |
+                __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(uy, ux)));
+}
+// Paeth predictor (fallback.rs:144-159) on two bytes held in the low bytes of 16-bit lanes:
+// p = a + b - c, pa = |p - a| = |b - c|, pb = |p - b| = |a - c|, pc = |p - c| = |(b - c) + (a - c)|;
+// a unless pa > pb or pa > pc, then b unless pb > pc, then c.
 __device__ __forceinline__ uint32_t paeth2(uint32_t a, uint32_t b, uint32_t c)
 {
-    const s16x2 bc = as_s(b) - as_s(c), ac = as_s(a) - as_s(c);
-    const s16x2 pa = __builtin_elementwise_abs(bc), pb = __builtin_elementwise_abs(ac), pc = __builtin_elementwise_abs(bc + ac);
-    const uint32_t m1 = le_mask(pa, pb) & le_mask(pa, pc), m2 = le_mask(pb, pc);
-    const uint32_t bc_sel = (b & m2) | (c & ~m2);
-    return (a & m1) | (bc_sel & ~m1);
+    const s16x2 pa = absdiff(b, c), pb = absdiff(a, c);
+    const s16x2 pc = __builtin_elementwise_abs((as_s(b) - as_s(c)) + (as_s(a) - as_s(c)));
+    const uint32_t not_a = gt_mask(pa, pb) | gt_mask(pa, pc), use_c = gt_mask(pb, pc);
+    const uint32_t bc_sel = (c & use_c) | (b & ~use_c);
+    return (bc_sel & not_a) | (a & ~not_a);
 }
 __device__ __forceinline__ uint32_t paeth4(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -104,16 +113,25 @@ __device__ __forceinline__ void load_six(const uint8_t *row, int k0, int n, bool
     }
 }
 
-template <int BPP, bool FAST>
+// NEED: bit 0 left neighbours, bit 1 the row above, bit 2 its left neighbours
+template <int BPP, bool FAST, int NEED = 7>
 __device__ __forceinline__ void load_group(const uint8_t *row, const uint8_t *prev, int k0, int n, Group &g)
 {
-    uint32_t x[6], u[6];
+    uint32_t x[6] = {0, 0, 0, 0, 0, 0}, u[6] = {0, 0, 0, 0, 0, 0};
     const bool whole = 4 * (k0 + 4) <= n;
-    load_six<BPP, FAST>(row, k0, n, whole, x);
-    if (prev) load_six<BPP, FAST>(prev, k0, n, whole, u);
+    if (NEED & 1) load_six<BPP, FAST>(row, k0, n, whole, x);
+    else if (FAST && whole) { const uint4 c = *reinterpret_cast<const uint4 *>(row + 4 * k0); x[2] = c.x; x[3] = c.y; x[4] = c.z; x[5] = c.w; }
     else {
 #pragma unroll
-        for (int i = 0; i < 6; i++) u[i] = 0;
+        for (int i = 2; i < 6; i++) x[i] = load_dword<FAST>(row, k0 - 2 + i, n);
+    }
+    if (prev && (NEED & 4)) load_six<BPP, FAST>(prev, k0, n, whole, u);
+    else if (prev && (NEED & 2)) {
+        if (FAST && whole) { const uint4 c = *reinterpret_cast<const uint4 *>(prev + 4 * k0); u[2] = c.x; u[3] = c.y; u[4] = c.z; u[5] = c.w; }
+        else {
+#pragma unroll
+            for (int i = 2; i < 6; i++) u[i] = load_dword<FAST>(prev, k0 - 2 + i, n);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -181,7 +199,73 @@ struct Args {
     uint64_t row_bytes;
     uint32_t height, first_row;
     int strategy;
+    uint32_t stage_bytes; // dynamic LDS for the staged write-out, 0 = rows too long: direct stores
 };
+
+// Pass 2 for filter F.  The output row starts at byte y * (n + 1) of the stream — a different
+// alignment for every row — so the filtered bytes are staged in LDS (filter byte at offset 15, row
+// byte i at 16 + i: aligned 16-byte writes) and written out as 16-byte chunks aligned in GLOBAL
+// memory: each chunk is five aligned LDS dwords shifted by a row-uniform byte count.  The few
+// bytes before the first / after the last aligned chunk are stored singly.  Rows too long for the
+// LDS stage (a.stage_bytes == 0) store unaligned dwords directly.
+template <int BPP, bool FAST, int F, int NEED>
+__device__ __forceinline__ void write_row(const Args &a, uint32_t y, const uint8_t *row, const uint8_t *prev, int n,
+                                          unsigned long long &s1, unsigned long long &s2)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+    const int ndw = (n + 3) / 4, per_iter = kThreads * 4;
+    uint8_t *orow = a.out + (size_t)y * (a.row_bytes + 1);
+    const unsigned long long L = (unsigned long long)n + 1; // bytes of the output row; byte p has weight L - p
+    const bool staged = a.stage_bytes != 0;
+    if (threadIdx.x == 0) {
+        if (staged) stage[15] = (uint8_t)F; else orow[0] = (uint8_t)F;
+        s1 = (unsigned)F; s2 = L * (unsigned)F;
+    }
+    for (int k0 = (int)threadIdx.x * 4; k0 < ndw; k0 += per_iter) {
+        Group g;
+        load_group<BPP, FAST, NEED>(row, prev, k0, n, g);
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            v[j] = filtered(F, g, j) & g.valid[j];
+            // bytes at output positions p = 1 + 4k + b, weight L - p
+            const unsigned sum = __builtin_amdgcn_sad_u8(v[j], 0u, 0u);
+            const unsigned ramp = __builtin_amdgcn_udot4(v[j], 0x00010203u, 0u, false); // 3*b0 + 2*b1 + 1*b2 + 0*b3
+            s1 += sum;
+            s2 += (L - (unsigned long long)(4 * (k0 + j) + 4)) * sum + ramp;
+        }
+        if (staged) {
+            *reinterpret_cast<uint4 *>(stage + 16 + 4 * k0) = make_uint4(v[0], v[1], v[2], v[3]); // (zero beyond the row)
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint8_t *dst = orow + 1 + 4 * (k0 + j);
+                if (g.valid[j] == 0xFFFFFFFFu) __builtin_memcpy(dst, &v[j], 4);
+                else for (int b = 0; b < 4; b++) if (4 * (k0 + j) + b < n) dst[b] = (uint8_t)(v[j] >> (8 * b));
+            }
+        }
+    }
+    if (!staged) return;
+    __syncthreads();
+    // stream byte p of this row (0 = filter byte) sits at LDS offset 15 + p
+    const int total = n + 1;
+    const int head = (int)((16 - (reinterpret_cast<uintptr_t>(orow) & 15)) & 15); // bytes before the first aligned chunk
+    const int h = head < total ? head : total;
+    const int chunks = (total - h) / 16, tail = total - h - 16 * chunks;
+    if ((int)threadIdx.x < h) orow[threadIdx.x] = stage[15 + threadIdx.x];
+    if ((int)threadIdx.x < tail) orow[h + 16 * chunks + threadIdx.x] = stage[15 + h + 16 * chunks + threadIdx.x];
+    const int t = 15 + h, r = t & 3; // LDS offset of the first chunk; r is uniform
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(stage) + (t >> 2);
+    for (int c = threadIdx.x; c < chunks; c += kThreads) {
+        uint32_t d[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) d[i] = w[4 * c + i];
+        uint4 o;
+        o.x = __builtin_amdgcn_alignbyte(d[1], d[0], r); o.y = __builtin_amdgcn_alignbyte(d[2], d[1], r);
+        o.z = __builtin_amdgcn_alignbyte(d[3], d[2], r); o.w = __builtin_amdgcn_alignbyte(d[4], d[3], r);
+        *reinterpret_cast<uint4 *>(orow + h + 16 * c) = o;
+    }
+}
 
 template <int BPP, bool FAST> __global__ __launch_bounds__(kThreads) void png_filter_kernel(const Args a)
 {
@@ -221,37 +305,17 @@ template <int BPP, bool FAST> __global__ __launch_bounds__(kThreads) void png_fi
     if (a.winner0 && y == 0 && threadIdx.x == 0) *a.winner0 = f;
 
     // pass 2: the winning filter -> output row (filter byte + n bytes), Adler partial sums
-    uint8_t *orow = a.out + (size_t)y * (a.row_bytes + 1);
-    const unsigned long long L = (unsigned long long)n + 1; // bytes of the output row; byte i has weight L - i
     unsigned long long s1 = 0, s2 = 0;
-    if (threadIdx.x == 0) { orow[0] = (uint8_t)f; s1 = (unsigned)f; s2 = L * (unsigned)f; }
-    for (int k0 = (int)threadIdx.x * 4; k0 < ndw; k0 += per_iter) {
-        Group g;
-        load_group<BPP, FAST>(row, prev, k0, n, g);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = k0 + j;
-            if (k >= ndw) break;
-            uint32_t v;
-            // (a switch on the uniform f keeps one filter's code live per row)
-            if (f == F_NONE) v = g.cur[j];
-            else if (f == F_SUB) v = filtered(F_SUB, g, j);
-            else if (f == F_UP) v = filtered(F_UP, g, j);
-            else if (f == F_AVG) v = filtered(F_AVG, g, j);
-            else v = filtered(F_PAETH, g, j);
-            v &= g.valid[j];
-            uint8_t *dst = orow + 1 + 4 * k;
-            if (g.valid[j] == 0xFFFFFFFFu) {
-                __builtin_memcpy(dst, &v, 4); // unaligned dword store (rows of the output start at odd offsets)
-            } else {
-                for (int b = 0; b < 4; b++) if (4 * k + b < n) dst[b] = (uint8_t)(v >> (8 * b));
-            }
-            // bytes at output positions p = 1 + 4k + b, weight L - p
-            const unsigned sum = __builtin_amdgcn_sad_u8(v, 0u, 0u);
-            const unsigned ramp = __builtin_amdgcn_udot4(v, 0x00010203u, 0u, false); // 3*b0 + 2*b1 + 1*b2 + 0*b3
-            s1 += sum;
-            s2 += (L - (unsigned long long)(4 * k + 4)) * sum + ramp;
-        }
+    switch (f) { // uniform: one filter's code and loads per row
+    case F_NONE: write_row<BPP, FAST, F_NONE, 0>(a, y, row, prev, n, s1, s2); break;
+    case F_SUB: write_row<BPP, FAST, F_SUB, 1>(a, y, row, prev, n, s1, s2); break;
+    case F_UP: write_row<BPP, FAST, F_UP, 2>(a, y, row, prev, n, s1, s2); break;
+    case F_AVG: write_row<BPP, FAST, F_AVG, 3>(a, y, row, prev, n, s1, s2); break;
+#ifdef PIXO_PNG_EXP_AVG7 // (timing experiment: Paeth's loads, Average's arithmetic)
+    default: write_row<BPP, FAST, F_AVG, 7>(a, y, row, prev, n, s1, s2); break;
+#else
+    default: write_row<BPP, FAST, F_PAETH, 7>(a, y, row, prev, n, s1, s2); break;
+#endif
     }
     const unsigned long long t1 = wg_sum(s1, red), t2 = wg_sum(s2, red);
     if (threadIdx.x == 0) { a.row_sums[2 * (size_t)y] = t1; a.row_sums[2 * (size_t)y + 1] = t2; }
@@ -259,8 +323,8 @@ template <int BPP, bool FAST> __global__ __launch_bounds__(kThreads) void png_fi
 
 template <int BPP> hipError_t launch_bpp(const Args &a, uint32_t rows, bool fast, hipStream_t s)
 {
-    if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true>), dim3(rows), dim3(kThreads), 0, s, a);
-    else hipLaunchKernelGGL((png_filter_kernel<BPP, false>), dim3(rows), dim3(kThreads), 0, s, a);
+    if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
+    else hipLaunchKernelGGL((png_filter_kernel<BPP, false>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
     return hipGetLastError();
 }
 
@@ -290,6 +354,10 @@ hipError_t launch_png_filter(const void *d_data, uint32_t width, uint32_t height
     if (a.row_bytes >= 0x7FFFFFF0ull) return hipErrorInvalidValue; // 32-bit byte indices inside a row
     a.height = height;
     a.strategy = strategy;
+    // LDS stage: 16 bytes in front (filter byte at 15), the row rounded up to whole 16-byte groups of
+    // 4 KiB iterations, 16 bytes of slack for the fifth dword of the last chunk
+    const uint64_t stage = 16 + ((a.row_bytes + 15) & ~15ull) + 32;
+    a.stage_bytes = stage <= 48 * 1024 ? (uint32_t)stage : 0u;
     a.forced = nullptr; a.winner0 = nullptr; a.first_row = 0;
     const bool fast = reinterpret_cast<uintptr_t>(d_data) % 4 == 0 && a.row_bytes % 4 == 0;
     if (strategy == PNG_S_ADAPTIVE_FAST && sequential_fast && height > 1) {

@@ -185,6 +185,11 @@ def bench_png(args):
         raise SystemExit("bench: filtered stream differs from the reference's — refusing to report a number")
     alg = in_bytes + out_bytes
     achieved = alg / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic_c5.json"))).get("hbm_bytes_per_launch")
+    except Exception:
+        pass
     line = {"metric": "Mpixels/s PNG row filters + Adler-32 partials (Adaptive), 4096x4096 RGBA8", "value": round(w * h * world * args.steps / elapsed / 1e6, 1),
             "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -192,7 +197,7 @@ def bench_png(args):
             "config": {"workload": "configs[4]: 4096x4096 RGBA8, FilterStrategy::Adaptive, rows independent", "width": w, "height": h,
                        "buffers_rotated": nbuf, "parallelism": "one process per GPU, images sharded across ranks, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "png_filter_kernel<4, true>",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "kernel": "png_filter_kernel<4, true>",
                          "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3)}}
     if not args.no_cpu_baseline and world == 1:
         import oracle_lib as O

@@ -115,8 +115,15 @@ __device__ __forceinline__ void phase_a(const TileCtx &c, const TileId &id, int 
 // (a single wavefront can issue only every ~4.3 cycles; two per SIMD are needed to fill it).
 // Measured alternatives (4-wave workgroups; persistent loop with register prefetch;
 // role-specialised producer/consumer wavefronts with double-buffered LDS): DESIGN.md.
+#ifdef PIXO_ABL_NO_WAVES_ATTR // (timing experiments only)
+#define PIXO_WAVES_ATTR
+#else
+// 6 waves per SIMD = 24 per CU = the 8 three-wave workgroups a CU gets of a 4096x4096 image: the
+// compiler keeps every variant at 80 VGPRs without spilling when told to.
+#define PIXO_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
+#endif
 template <int MODE, bool FAST>
-__global__ __launch_bounds__(kThreads) void jpeg_coeffs_kernel(const KArgs a)
+__global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(const KArgs a)
 {
     typedef Geo<MODE> G;
     __shared__ __attribute__((aligned(16))) uint8_t lds[G::planar];

@@ -122,9 +122,9 @@ int pixo_hip_jpeg_entropy_encode(const int16_t *y, const int16_t *cb, const int1
  * parallel packing and 0xFF stuffing on the GPU, byte-identical to encode_scan + encode_block +
  * BitWriterMsb (src/jpeg/mod.rs:1408-1563, src/jpeg/huffman.rs:423-481, src/bits.rs:195-293);
  * with options->optimize_huffman the count_block statistics (src/jpeg/mod.rs:826-860) are
- * gathered on the GPU as well.  Only the finished file crosses PCIe.  Scans that emit restart
- * markers are copied back and coded by the host stage above.  Synchronous; the pointers must
- * belong to the current HIP device and their producers must have completed. */
+ * gathered on the GPU as well, and restart intervals (src/jpeg/mod.rs:1423-1445) are handled as
+ * byte-aligned segments with RSTn markers.  Only the finished file crosses PCIe.  Synchronous;
+ * the pointers must belong to the current HIP device and their producers must have completed. */
 int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const void *d_cr,
                                         const pixo_jpeg_options *options, uint8_t **out,
                                         size_t *out_len);

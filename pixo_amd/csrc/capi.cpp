@@ -86,7 +86,7 @@ struct Context {
         }
         template <class T> T *as() const { return static_cast<T *>(p); }
     };
-    Buf e_tables, e_hist, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out;
+    Buf e_tables, e_hist, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out, e_seg_bytes, e_seg_off;
     Buf p_in, p_out, p_sums, p_scratch; // PNG filter stage
     unsigned long long *h_sums = nullptr; size_t hsums_cap = 0; // pinned
     uint64_t *h_totals = nullptr; // pinned, 2 words
@@ -204,8 +204,7 @@ int coeffs_on_device(const void *d_pixels, const pixo_jpeg_options &o, const pix
     return PIXO_OK;
 }
 
-// Scans that emit RSTn markers are entropy-coded on the host (the device stage packs one
-// uninterrupted bit stream); everything else — standard or optimised tables — on the device.
+// Does the scan emit RSTn markers (jpeg/mod.rs:1431-1445: only while more MCUs follow)?
 bool scan_has_restart_markers(const pixo_jpeg_options &o, const pixo_host::Geometry &g)
 {
     return o.has_restart_interval && o.restart_interval != 0 && o.restart_interval < g.units;
@@ -238,11 +237,18 @@ int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_
     a.y = dy; a.cb = dcb; a.cr = dcr;
     a.mode = g.gray ? 0 : (g.s420 ? 2 : 1);
     a.nblocks = n;
+    a.blocks_per_mcu = g.gray ? 1 : (g.s420 ? 6 : 3);
+    a.restart = scan_has_restart_markers(o, g) ? o.restart_interval : 0;
+    const uint64_t nseg = a.restart ? (g.units + a.restart - 1) / a.restart : 0;
     HIP_TRY(c.e_tables.reserve(pixo_host::kScanTableWords * 4));
     HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
     HIP_TRY(c.e_len.reserve(n * 4));
     HIP_TRY(c.e_off.reserve(n * 8));
-    HIP_TRY(c.e_tmp.reserve((pd::scan_tile_count(n) + 1) * 8));
+    // scratch of the three prefix sums (blocks, restart segments, 0xFF tiles), reserved before any launch:
+    // a block has at most 1665 bits, so the packed stream has at most n * 209 + 3 * nseg bytes
+    const size_t tmp_blocks = pd::scan_tile_count(n) + 1, tmp_segs = pd::scan_tile_count(nseg ? nseg : 1) + 1;
+    const size_t tmp_tiles = pd::scan_tile_count(pd::stuff_tile_count(n * 209 + 3 * nseg + 8)) + 1;
+    HIP_TRY(c.e_tmp.reserve((tmp_blocks + tmp_segs + tmp_tiles) * 8));
     HIP_TRY(c.e_totals.reserve(16));
     if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 16, hipHostMallocDefault));
     a.tables = c.e_tables.as<uint32_t>();
@@ -273,25 +279,34 @@ int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_
     HIP_TRY(pd::launch_scan_lengths(a, c.e_len.as<uint32_t>(), stream));
     HIP_TRY(pd::launch_exclusive_scan(c.e_len.as<uint32_t>(), n, c.e_off.as<uint64_t>(), c.e_tmp.as<uint64_t>(),
                                       c.e_totals.as<uint64_t>(), stream));
-    HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_totals.p, 8, hipMemcpyDeviceToHost, stream));
+    pd::SegmentPlan plan{0, nullptr};
+    if (nseg) { // restart markers: byte-aligned segments, each followed by two marker bytes
+        HIP_TRY(c.e_seg_bytes.reserve(nseg * 4));
+        HIP_TRY(c.e_seg_off.reserve(nseg * 8));
+        HIP_TRY(pd::launch_segment_sizes(a, c.e_off.as<uint64_t>(), c.e_totals.as<uint64_t>(), nseg, c.e_seg_bytes.as<uint32_t>(), stream));
+        HIP_TRY(pd::launch_exclusive_scan(c.e_seg_bytes.as<uint32_t>(), nseg, c.e_seg_off.as<uint64_t>(),
+                                          c.e_tmp.as<uint64_t>() + tmp_blocks, c.e_totals.as<uint64_t>() + 1, stream));
+        plan.nsegments = nseg;
+        plan.seg_byte_off = c.e_seg_off.as<uint64_t>();
+    }
+    HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_totals.p, 16, hipMemcpyDeviceToHost, stream));
     sw.lap("  launches");
     HIP_TRY(hipStreamSynchronize(stream)); // `packed` may go out of scope after this, too
     sw.lap("tables+lengths+scan");
     const uint64_t total_bits = c.h_totals[0];
-    const uint64_t nbytes = (total_bits + 7) / 8;
+    const uint64_t nbytes = nseg ? c.h_totals[1] : (total_bits + 7) / 8; // bytes of the packed (unstuffed) stream
     // 3: pack
-    const size_t stream_bytes = (total_bits / 32 + 2) * 4;
+    const size_t stream_bytes = (nbytes / 4 + 2) * 4;
     HIP_TRY(c.e_stream.reserve(stream_bytes));
     HIP_TRY(hipMemsetAsync(c.e_stream.p, 0, stream_bytes, stream));
-    HIP_TRY(pd::launch_scan_pack(a, c.e_off.as<uint64_t>(), total_bits, c.e_stream.as<uint32_t>(), stream));
+    HIP_TRY(pd::launch_scan_pack(a, c.e_off.as<uint64_t>(), total_bits, nseg ? &plan : nullptr, c.e_stream.as<uint32_t>(), stream));
     // 4: 0xFF census
     const size_t tiles = pd::stuff_tile_count(nbytes);
     HIP_TRY(c.e_tile_ff.reserve(tiles * 4));
     HIP_TRY(c.e_tile_base.reserve(tiles * 8));
-    HIP_TRY(c.e_tmp.reserve((pd::scan_tile_count(tiles) + 1) * 8));
     HIP_TRY(pd::launch_ff_tile_count(c.e_stream.as<uint32_t>(), nbytes, c.e_tile_ff.as<uint32_t>(), stream));
-    HIP_TRY(pd::launch_exclusive_scan(c.e_tile_ff.as<uint32_t>(), tiles, c.e_tile_base.as<uint64_t>(), c.e_tmp.as<uint64_t>(),
-                                      c.e_totals.as<uint64_t>() + 1, stream));
+    HIP_TRY(pd::launch_exclusive_scan(c.e_tile_ff.as<uint32_t>(), tiles, c.e_tile_base.as<uint64_t>(),
+                                      c.e_tmp.as<uint64_t>() + tmp_blocks + tmp_segs, c.e_totals.as<uint64_t>() + 1, stream));
     HIP_TRY(hipMemcpyAsync(c.h_totals + 1, c.e_totals.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     sw.lap("memset+pack+ff census");
@@ -299,6 +314,8 @@ int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_
     // 5: stuff, then straight into the caller's vector behind the headers
     HIP_TRY(c.e_out.reserve(scan_bytes));
     HIP_TRY(pd::launch_stuff(c.e_stream.as<uint32_t>(), nbytes, c.e_tile_base.as<uint64_t>(), c.e_out.as<uint8_t>(), stream));
+    if (nseg) HIP_TRY(pd::launch_restart_markers(a, c.e_off.as<uint64_t>(), plan, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
+                                                 c.e_out.as<uint8_t>(), stream));
     std::vector<uint8_t> head;
     pixo_host::file_headers(head, o, h);
     const size_t hdr = head.size(), total = hdr + scan_bytes + 2;
@@ -366,7 +383,7 @@ int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options
     if (rc) return fail(rc, msg);
     if ((rc = unsupported_scan_mode(o))) return rc;
     const pixo_host::Geometry g = pixo_host::geometry(o.width, o.height, o.color_type, o.subsampling);
-    if (scan_has_restart_markers(o, g) || std::getenv("PIXO_HIP_HOST_ENTROPY")) {
+    if (std::getenv("PIXO_HIP_HOST_ENTROPY")) { // (experiments: the host twin of the entropy stage)
         const int16_t *y, *cb, *cr;
         if ((rc = coeffs_to_pinned(data, o, g, &y, &cb, &cr))) return rc;
         pixo_host::encode_file(y, cb, cr, o, spill);
@@ -530,8 +547,8 @@ int context_on_current_device(Context **out)
 int device_tuple_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                            const pixo_host::Geometry &g, Context &c, uint8_t **out, size_t *out_len)
 {
-    if (!scan_has_restart_markers(o, g)) return device_entropy_to_malloc(dy, dcb, dcr, o, g, c.stream, out, out_len);
-    // restart markers: host coder on a copy of the tuple
+    if (!std::getenv("PIXO_HIP_HOST_ENTROPY")) return device_entropy_to_malloc(dy, dcb, dcr, o, g, c.stream, out, out_len);
+    // (experiments: host coder on a copy of the tuple)
     const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128;
     int rc = c.reserve_hcoef(coef_bytes);
     if (rc) return rc;
@@ -734,7 +751,7 @@ int pixo_hip_set_device(int device)
         if (c.h_file) (void)hipHostFree(c.h_file);
         if (c.h_sums) (void)hipHostFree(c.h_sums);
         for (Context::Buf *b : {&c.e_tables, &c.e_hist, &c.e_len, &c.e_off, &c.e_tmp, &c.e_totals, &c.e_stream,
-                                &c.e_tile_ff, &c.e_tile_base, &c.e_out, &c.p_in, &c.p_out, &c.p_sums, &c.p_scratch})
+                                &c.e_tile_ff, &c.e_tile_base, &c.e_out, &c.e_seg_bytes, &c.e_seg_off, &c.p_in, &c.p_out, &c.p_sums, &c.p_scratch})
             if (b->p) (void)hipFree(b->p);
         if (c.stream) (void)hipStreamDestroy(c.stream);
         c = Context();

@@ -1,7 +1,7 @@
 // jpeg_entropy.hip — gfx950 kernels of the device entropy stage: the baseline
 // Huffman scan of a coefficient tuple that is already in HBM, byte-identical to the reference's
 // encode_scan + encode_block + BitWriterMsb (src/jpeg/mod.rs:1408-1563, src/jpeg/huffman.rs:
-// 423-481, src/bits.rs:195-293) for scans without restart markers.
+// 423-481, src/bits.rs:195-293), restart markers included.
 //
 //   1. lengths   one lane per block (scan order): bit length of the block            u32[n]
 //   2. scan      exclusive prefix sum of the lengths -> absolute bit offset          u64[n], total
@@ -10,6 +10,8 @@
 //   4. ff count  0xFF bytes per 4 KiB tile of the packed stream, scanned like (2)
 //   5. stuff     copies the stream to its final place, inserting 0x00 after every 0xFF
 //   (0. count    optional: DC-category / AC run-size histograms for optimised tables)
+//   (restart intervals: segment byte sizes from the prefix sum after 2, each segment packed at its
+//    own byte offset in 3, FF D0+(k & 7) written over two reserved zero bytes after 5)
 //
 // A block is 128 contiguous bytes and a lane walks it serially (the zero-run state machine is
 // inherently sequential); 64 lanes = 64 consecutive blocks.  All of it is integer work bounded
@@ -27,10 +29,13 @@ constexpr int kScanThreads = 256;
 
 enum { WHAT_LENGTH = 0, WHAT_PACK = 1, WHAT_COUNT = 2 };
 
+// first block (scan order) of restart segment k
+__device__ __forceinline__ uint64_t segment_first(const ScanArgs &a, uint64_t k) { return k * a.restart * a.blocks_per_mcu; }
+
 template <int WHAT>
 __global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(const ScanArgs a, uint32_t *len, const uint64_t *off,
                                                                   uint32_t *stream, unsigned long long *hist,
-                                                                  uint64_t total_bits)
+                                                                  uint64_t total_bits, const uint64_t *seg_byte_off)
 {
     __shared__ uint32_t tab[kTableWords];
     __shared__ uint32_t lhist[WHAT == WHAT_COUNT ? kTableWords : 1];
@@ -50,8 +55,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(const ScanArg
             const uint4 q = p[i];
             w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
         }
-        // DC predictor: the previous block of the same component (no restart markers here)
-        const int prev_dc = ref.index ? (int)base[(ref.index - 1) * 64] : 0;
+        // DC predictor: the previous block of the same component; 0 for the first block of each
+        // component in a restart segment (jpeg/mod.rs:1441-1444)
+        int prev_dc = ref.index ? (int)base[(ref.index - 1) * 64] : 0;
+        uint64_t mcu = 0, seg = 0;
+        if (a.restart) {
+            mcu = s / a.blocks_per_mcu;
+            seg = mcu / a.restart;
+            const uint32_t k = (uint32_t)(s - mcu * a.blocks_per_mcu);
+            const bool first_of_comp = a.mode == 2 ? (k == 0 || k >= 4) : true;
+            if (mcu % a.restart == 0 && first_of_comp) prev_dc = 0;
+        }
         const int cls = ref.comp == 0 ? 0 : 1;
         if (WHAT == WHAT_LENGTH) {
             LengthVisitor v{tab + cls * kClassSyms, 0};
@@ -60,12 +74,22 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(const ScanArg
         } else if (WHAT == WHAT_PACK) {
             PackVisitor v;
             v.tab = tab + cls * kClassSyms;
-            v.begin(stream, off[s]);
+            uint64_t pos = off[s], end_bits = total_bits; // end of the stream / of this block's segment
+            bool last_of_segment = s == a.nblocks - 1;
+            if (a.restart) { // the segment starts at its own byte offset; inside it the bits are contiguous
+                const uint64_t first = segment_first(a, seg), next = segment_first(a, seg + 1);
+                const uint64_t seg_bits0 = off[first];
+                const uint64_t seg_end = next < a.nblocks ? off[next] : total_bits;
+                pos = seg_byte_off[seg] * 8 + (pos - seg_bits0);
+                end_bits = seg_byte_off[seg] * 8 + (seg_end - seg_bits0);
+                last_of_segment = s + 1 == next || s == a.nblocks - 1;
+            }
+            v.begin(stream, pos);
             walk_block(w, prev_dc, v);
             v.finish();
-            if (s == a.nblocks - 1) { // BitWriterMsb::flush: pad the last byte with 1-bits (bits.rs:261-272)
-                const int n = (int)((8 - (total_bits & 7)) & 7);
-                if (n) v.or_word(total_bits >> 5, ((1u << n) - 1u) << (32 - (int)(total_bits & 31) - n));
+            if (last_of_segment) { // BitWriterMsb::flush: pad the last byte with 1-bits (bits.rs:261-272)
+                const int n = (int)((8 - (end_bits & 7)) & 7);
+                if (n) v.or_word(end_bits >> 5, ((1u << n) - 1u) << (32 - (int)(end_bits & 31) - n));
             }
         } else {
             CountVisitor v{lhist + cls * kClassSyms};
@@ -194,6 +218,36 @@ __global__ __launch_bounds__(kScanThreads) void stuff_kernel(const uint32_t *str
     }
 }
 
+__global__ __launch_bounds__(kScanThreads) void segment_sizes_kernel(const ScanArgs a, const uint64_t *off, const uint64_t *total_bits,
+                                                                    uint64_t nsegments, uint32_t *seg_bytes)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * kScanThreads + threadIdx.x;
+    if (k >= nsegments) return;
+    const uint64_t first = segment_first(a, k), next = segment_first(a, k + 1);
+    const uint64_t bits = (next < a.nblocks ? off[next] : *total_bits) - off[first];
+    seg_bytes[k] = (uint32_t)((bits + 7) / 8 + (k + 1 < nsegments ? 2 : 0));
+}
+
+__global__ __launch_bounds__(kScanThreads) void restart_markers_kernel(const ScanArgs a, const uint64_t *off, const uint64_t *seg_byte_off,
+                                                                      uint64_t nsegments, const uint32_t *stream,
+                                                                      const uint64_t *tile_ff_base, uint8_t *out)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * kScanThreads + threadIdx.x;
+    if (k + 1 >= nsegments) return;
+    // the marker's two (still zero) bytes sit right before the next segment
+    const uint64_t pos = seg_byte_off[k + 1] - 2;
+    const uint64_t tile = pos / kStuffTileBytes;
+    uint64_t ff = tile_ff_base[tile];
+    for (uint64_t w = tile * (kStuffTileBytes / 4); w * 4 < pos; w++) { // 0xFF bytes of this tile before the marker
+        const uint32_t v = stream[w];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (w * 4 + b < pos && ((v >> (24 - 8 * b)) & 0xFF) == 0xFF) ff++;
+    }
+    out[pos + ff] = 0xFF;
+    out[pos + ff + 1] = (uint8_t)(0xD0 + (k & 7)); // jpeg/mod.rs:1436-1439
+}
+
 inline unsigned grid_for(uint64_t n, uint64_t per_group) { return (unsigned)((n + per_group - 1) / per_group); }
 } // namespace
 
@@ -203,21 +257,39 @@ size_t stuff_tile_count(uint64_t nbytes) { return (size_t)((nbytes + kStuffTileB
 hipError_t launch_scan_count(const ScanArgs &a, unsigned long long *d_hist, hipStream_t s)
 {
     hipLaunchKernelGGL((scan_blocks_kernel<WHAT_COUNT>), dim3(grid_for(a.nblocks, kScanThreads)), dim3(kScanThreads), 0, s, a,
-                       nullptr, nullptr, nullptr, d_hist, 0);
+                       nullptr, nullptr, nullptr, d_hist, 0, nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_scan_lengths(const ScanArgs &a, uint32_t *d_len, hipStream_t s)
 {
     hipLaunchKernelGGL((scan_blocks_kernel<WHAT_LENGTH>), dim3(grid_for(a.nblocks, kScanThreads)), dim3(kScanThreads), 0, s, a,
-                       d_len, nullptr, nullptr, nullptr, 0);
+                       d_len, nullptr, nullptr, nullptr, 0, nullptr);
     return hipGetLastError();
 }
 
-hipError_t launch_scan_pack(const ScanArgs &a, const uint64_t *d_off, uint64_t total_bits, uint32_t *d_stream, hipStream_t s)
+hipError_t launch_scan_pack(const ScanArgs &a, const uint64_t *d_off, uint64_t total_bits, const SegmentPlan *seg,
+                            uint32_t *d_stream, hipStream_t s)
 {
     hipLaunchKernelGGL((scan_blocks_kernel<WHAT_PACK>), dim3(grid_for(a.nblocks, kScanThreads)), dim3(kScanThreads), 0, s, a,
-                       nullptr, d_off, d_stream, nullptr, total_bits);
+                       nullptr, d_off, d_stream, nullptr, total_bits, seg ? seg->seg_byte_off : nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_segment_sizes(const ScanArgs &a, const uint64_t *d_off, const uint64_t *d_total_bits, uint64_t nsegments,
+                                uint32_t *d_seg_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(segment_sizes_kernel, dim3(grid_for(nsegments, kScanThreads)), dim3(kScanThreads), 0, s, a, d_off, d_total_bits,
+                       nsegments, d_seg_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_restart_markers(const ScanArgs &a, const uint64_t *d_off, const SegmentPlan &seg, const uint32_t *d_stream,
+                                  const uint64_t *d_tile_ff_base, uint8_t *d_out, hipStream_t s)
+{
+    if (seg.nsegments < 2) return hipSuccess;
+    hipLaunchKernelGGL(restart_markers_kernel, dim3(grid_for(seg.nsegments - 1, kScanThreads)), dim3(kScanThreads), 0, s, a, d_off,
+                       seg.seg_byte_off, seg.nsegments, d_stream, d_tile_ff_base, d_out);
     return hipGetLastError();
 }
 

@@ -13,6 +13,15 @@ struct ScanArgs {
     const uint32_t *tables;     // pixo_scan::kTableWords words: (length << 16) | code
     int mode;                   // 0 gray, 1 4:4:4, 2 4:2:0 (block order of encode_scan)
     uint64_t nblocks;           // blocks in scan order
+    uint32_t restart;           // MCUs per restart segment (jpeg/mod.rs:1423-1445), 0 = no markers
+    uint32_t blocks_per_mcu;    // 1, 3 or 6
+};
+
+// Scans with restart markers: a segment is `restart` MCUs; every segment starts on a byte boundary
+// (1-padding), DC predictors restart at 0, and all but the last are followed by FF D0+(k & 7).
+struct SegmentPlan {
+    uint64_t nsegments;
+    const uint64_t *seg_byte_off; // [nsegments] byte offset of each segment in the packed stream
 };
 
 size_t scan_tile_count(uint64_t n);        // u64 scratch words launch_exclusive_scan needs for n elements
@@ -24,8 +33,16 @@ hipError_t launch_scan_lengths(const ScanArgs &a, uint32_t *d_len, hipStream_t s
 // d_out[i] = sum of d_in[0..i) (may be null: totals only); *d_total = sum of all
 hipError_t launch_exclusive_scan(const uint32_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *d_tile_tmp, uint64_t *d_total,
                                  hipStream_t s);
-// d_stream: zeroed, at least total_bits / 32 + 2 words
-hipError_t launch_scan_pack(const ScanArgs &a, const uint64_t *d_off, uint64_t total_bits, uint32_t *d_stream, hipStream_t s);
+// d_stream: zeroed, at least total_bits / 32 + 2 words.  seg: null without restart markers.
+hipError_t launch_scan_pack(const ScanArgs &a, const uint64_t *d_off, uint64_t total_bits, const SegmentPlan *seg,
+                            uint32_t *d_stream, hipStream_t s);
+// Restart segments: d_seg_bytes[k] = bytes of segment k in the packed stream (padding and, except for
+// the last, the two marker bytes included), from the exclusive bit offsets d_off and the total.
+hipError_t launch_segment_sizes(const ScanArgs &a, const uint64_t *d_off, const uint64_t *d_total_bits, uint64_t nsegments,
+                                uint32_t *d_seg_bytes, hipStream_t s);
+// After launch_stuff: writes FF D0+(k & 7) over the two zero bytes that follow segment k < nsegments - 1.
+hipError_t launch_restart_markers(const ScanArgs &a, const uint64_t *d_off, const SegmentPlan &seg, const uint32_t *d_stream,
+                                  const uint64_t *d_tile_ff_base, uint8_t *d_out, hipStream_t s);
 hipError_t launch_ff_tile_count(const uint32_t *d_stream, uint64_t nbytes, uint32_t *d_tile_ff, hipStream_t s);
 // d_out: nbytes + (number of 0xFF bytes) bytes
 hipError_t launch_stuff(const uint32_t *d_stream, uint64_t nbytes, const uint64_t *d_tile_ff_base, uint8_t *d_out, hipStream_t s);

@@ -203,12 +203,30 @@ def test_device_entropy_stage_long_zero_runs_flat_and_tiny_images():
             assert _file_from_device_tuple(px, w, h, 2, ss, 75) == O.encode(px, O.make_options(w, h, 2, 75, ss))
 
 
-def test_device_entropy_stage_hands_restart_scans_to_the_host_coder():
+@pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])
+def test_device_entropy_stage_restart_markers(mode):
+    """RSTn: byte-aligned segments with 1-padding, predictors reset, FF D0..D7 cycling, no marker
+    after the last segment (jpeg/mod.rs:1423-1445) — all on the device."""
+    ct, ss = mode
     w, h = 300, 200
-    px = synth.noise(w, h, 11)
-    for restart in (1, 7, 10_000):  # 10_000 > MCU count: DRI header but no marker -> device path
-        got = _file_from_device_tuple(px, w, h, 2, 1, 70, restart_interval=restart)
-        assert got == O.encode(px, O.make_options(w, h, 2, 70, 1, restart=restart))
+    px = synth.noise(w, h, 11) if ct == 2 else synth.noise_gray(w, h, 11)
+    for restart, opt in [(1, False), (2, True), (7, False), (19, True), (64, False), (10_000, False)]:
+        # 10_000 > MCU count: DRI header but no marker
+        got = _file_from_device_tuple(px, w, h, ct, ss, 70, restart_interval=restart, optimize_huffman=opt)
+        assert got == O.encode(px, O.make_options(w, h, ct, 70, ss, restart=restart, optimize_huffman=opt)), (restart, opt)
+    # smooth content: many 0xFF-free, short segments; and an interval that divides the MCU count exactly
+    g = synth.gradient_rgb(256, 64) if ct == 2 else synth.gradient_rgb(256, 64).reshape(-1, 3)[:, 0].copy()
+    for restart in (4, 16, 32):
+        assert _file_from_device_tuple(g, 256, 64, ct, ss, 90, restart_interval=restart) == \
+            O.encode(g, O.make_options(256, 64, ct, 90, ss, restart=restart))
+
+
+def test_restart_markers_at_full_size_whole_path():
+    w = h = 2048
+    px = synth.noise(w, h, 21)
+    for restart in (1, 128):
+        got = jpeg.encode(px, _opts(w, h, 2, 1, 80, restart_interval=restart))
+        assert got == O.encode(px, O.make_options(w, h, 2, 80, 1, restart=restart))
 
 
 def test_encode_device_resident_pixels_full_size_hashes():

@@ -241,3 +241,26 @@ def test_encode_device_resident_pixels_full_size_hashes():
         assert len(blob) == n and hashlib.sha256(blob).hexdigest() == sha
     # repeated calls reuse the context's buffers
     assert jpeg.encode_device(d_px, _opts(w, h, 2, 1, 80)) == jpeg.encode_device(d_px, _opts(w, h, 2, 1, 80))
+
+
+def test_banded_device_encode_over_rccl_world_of_one():
+    """encode_banded_device on the real device path (RCCL process group, device tensors, device
+    entropy stage).  Only one GPU is available to the tests, so the world has one rank; the
+    two-rank stitching logic runs on CPU over gloo (tests/test_sharding_gloo.py)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from pixo_amd import sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        for (w, h, ct, ss) in [(1024, 520, 2, 1), (300, 100, 2, 0), (200, 64, 0, 0)]:
+            px = synth.noise(w, h, 31) if ct == 2 else synth.noise_gray(w, h, 31)
+            d_px = torch.from_numpy(px).to("cuda:0")
+            got = sharded.encode_banded_device(d_px, _opts(w, h, ct, ss, 80))
+            assert got == O.encode(px, O.make_options(w, h, ct, 80, ss))
+    finally:
+        dist.destroy_process_group()

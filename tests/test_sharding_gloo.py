@@ -61,3 +61,55 @@ def test_two_rank_band_sharding_is_byte_identical(case):
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(timeout=5) is True
+
+
+def _worker_device_form(rank, world, port, w, h, ct, ss, q, ret):
+    """encode_banded_device with CPU tensors over gloo: equal-sized send buffers, one gather per
+    plane, slicing back to the true band sizes, stitched tuple -> entropy stage."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch
+    import torch.distributed as dist
+    import oracle_lib as O
+    import synth
+    from pixo_amd import ColorType, jpeg, sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    px = synth.noise_gray(w, h, 78) if ct == 0 else synth.noise(w, h, 78)
+    bpp = 1 if ct == 0 else 3
+    b = jpeg.band(w, h, ct, ss, world, rank)
+    mine = torch.from_numpy(px[b["row_begin"] * w * bpp: b["row_end"] * w * bpp].copy())
+
+    def cpu_coeffs(t, o, y, cb, cr):  # stands in for the rank's coefficient kernel
+        oy, ocb, ocr = O.coeffs(t.numpy(), o.width, o.height, int(o.color_type), int(o.subsampling), o.quality)
+        y[: oy.shape[0]] = torch.from_numpy(oy)
+        cb[: ocb.shape[0]] = torch.from_numpy(ocb)
+        cr[: ocr.shape[0]] = torch.from_numpy(ocr)
+
+    def host_entropy(y, cb, cr, o):  # stands in for the device entropy stage on rank 0
+        return jpeg.entropy_encode(y.numpy(), cb.numpy(), cr.numpy(), o)
+
+    o = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss)).build()
+    got = sharded.encode_banded_device(mine, o, coeff_fn=cpu_coeffs, entropy_fn=host_entropy)
+    if rank == 0:
+        ret.put(got == O.encode(px, O.make_options(w, h, ct, q, ss)))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [(333, 211, 2, 1, 80), (100, 72, 2, 0, 60), (64, 40, 0, 0, 90), (40, 16, 2, 1, 80)])
+def test_two_rank_device_form_gathers_equal_sized_bands(case):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_device_form, args=(r, 2, port) + case + (ret,)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True

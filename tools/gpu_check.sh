@@ -33,4 +33,17 @@ for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   f=$(find /tmp/prof_out/pmc$i -name "*counter_collection*" | head -1)
   [ -n "$f" ] && python $ROOT/tools/pmc_summary.py "$f" jpeg_coeffs > gpurun_out/prof/pmc${i}_summary.txt 2>&1
 done
-ls gpurun_out/prof
+echo "== PNG (c5) and entropy stage"
+mkdir -p gpurun_out/extra
+timeout 300 python bench.py --workload c5 --steps 100 --warmup 10 2>/dev/null | tail -1 > gpurun_out/extra/bench_c5.json
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_out/c5 -o c5 -- python $ROOT/bench.py --workload c5 --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2>&1)
+find /tmp/prof_out/c5 -name "*kernel_stats*" -exec cp {} gpurun_out/extra/kernel_stats_c5.csv \;
+for k in "0 noise" "1 noise" "0 gradient"; do
+  n=$(echo $k | tr " " "_")
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_out/e_$n -o e -- python $ROOT/tools/encode_loop.py 10 $k 2>&1 | grep "encode()" > $ROOT/gpurun_out/extra/encode_loop_$n.txt)
+  find /tmp/prof_out/e_$n -name "*kernel_stats*" -exec cp {} gpurun_out/extra/kernel_stats_encode_$n.csv \;
+done
+timeout 120 python tools/e2e_timing.py 2>&1 | tail -3 > gpurun_out/extra/e2e_timing.txt
+timeout 120 python tools/e2e_device.py 2>&1 | tail -4 > gpurun_out/extra/e2e_device.txt
+timeout 120 python tools/png_probe.py 2>&1 | tail -7 > gpurun_out/extra/png_probe.txt
+ls gpurun_out/prof gpurun_out/extra

@@ -264,3 +264,23 @@ def test_banded_device_encode_over_rccl_world_of_one():
             assert got == O.encode(px, O.make_options(w, h, ct, 80, ss))
     finally:
         dist.destroy_process_group()
+
+
+def test_random_option_sweep_whole_files():
+    """40 pseudo-random (size, mode, quality, restart, tables, content) combinations through
+    encode(): every file byte-identical to the oracle's."""
+    rng = np.random.RandomState(20240917)
+    for i in range(40):
+        w, h = int(rng.randint(1, 700)), int(rng.randint(1, 300))
+        ct, ss = [(2, 1), (2, 0), (0, 0)][rng.randint(3)]
+        q = int(rng.choice([1, 10, 37, 50, 75, 80, 92, 100]))
+        restart = [None, None, 1, 3, 17, 250][rng.randint(6)]
+        opt = bool(rng.randint(2))
+        kind = rng.randint(3)
+        if ct == 2:
+            px = [synth.noise(w, h, i), synth.gradient_rgb(w, h), synth.extremes(w, h, i)][kind]
+        else:
+            px = [synth.noise_gray(w, h, i), synth.constant(w, h, 200, 1), (synth.noise_gray(w, h, i) >> 5) * 32][kind]
+        got = jpeg.encode(px, _opts(w, h, ct, ss, q, restart_interval=restart, optimize_huffman=opt))
+        want = O.encode(px, O.make_options(w, h, ct, q, ss, restart=restart, optimize_huffman=opt))
+        assert got == want, (i, w, h, ct, ss, q, restart, opt, kind)

@@ -135,6 +135,13 @@ int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const
 int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *options,
                                 uint8_t **out, size_t *out_len);
 
+/* pixo::jpeg::encode for `batch` equally sized images back to back in HBM (config 3: 64 x 1080p):
+ * one coefficient launch and ONE pass of the device entropy stage for all of them (every image is a
+ * byte-aligned segment of one packed stream), files[i] / lens[i] receive `batch` malloc'd files
+ * (pixo_hip_free).  With optimize_huffman or restart markers the images are encoded one by one. */
+int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_options *options, uint32_t batch,
+                                      uint8_t **files, size_t *lens);
+
 /* ---- PNG row filters + Adler-32 ------------------------------ */
 
 /* pixo::png::FilterStrategy in declaration order (src/png/mod.rs:345-364).  Bigrams is not

@@ -226,20 +226,31 @@ struct Stopwatch { // PIXO_HIP_TRACE=1: per-phase wall times of the device entro
 // the host, entropy-coded segment by the kernels of jpeg_entropy.hip and copied straight behind
 // them).  Pinned on purpose: a device-to-host copy into fresh pageable memory makes the runtime
 // pin those pages first, which costs 10-25 ms for an 11 MB file every time the address changes.
+// batch > 1 (standard tables, no restart markers): the tuples of `batch` equal images back to back;
+// every image is a byte-aligned segment of ONE packed stream.  Then *file = headers (once) followed by
+// all the entropy-coded segments, and image_starts[i] (batch + 1 entries) are their offsets behind the
+// headers; no EOI is written.
 int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
-                             const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len)
+                             const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len,
+                             uint32_t batch = 1, std::vector<uint64_t> *image_starts = nullptr, size_t *header_len = nullptr)
 {
     Stopwatch sw;
     Context &c = t_ctx;
     namespace pd = pixo_dev;
-    const uint64_t n = g.y_blocks + 2 * g.c_blocks;
+    const uint64_t n = (g.y_blocks + 2 * g.c_blocks) * batch;
     pd::ScanArgs a;
     a.y = dy; a.cb = dcb; a.cr = dcr;
     a.mode = g.gray ? 0 : (g.s420 ? 2 : 1);
     a.nblocks = n;
     a.blocks_per_mcu = g.gray ? 1 : (g.s420 ? 6 : 3);
+    a.marker_bytes = 2;
     a.restart = scan_has_restart_markers(o, g) ? o.restart_interval : 0;
-    const uint64_t nseg = a.restart ? (g.units + a.restart - 1) / a.restart : 0;
+    uint64_t nseg = a.restart ? (g.units + a.restart - 1) / a.restart : 0;
+    if (batch > 1) { // one segment per image, no marker between them
+        a.restart = static_cast<uint32_t>(g.units);
+        a.marker_bytes = 0;
+        nseg = batch;
+    }
     HIP_TRY(c.e_tables.reserve(pixo_host::kScanTableWords * 4));
     HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
     HIP_TRY(c.e_len.reserve(n * 4));
@@ -281,7 +292,7 @@ int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_
                                       c.e_totals.as<uint64_t>(), stream));
     pd::SegmentPlan plan{0, nullptr};
     if (nseg) { // restart markers: byte-aligned segments, each followed by two marker bytes
-        HIP_TRY(c.e_seg_bytes.reserve(nseg * 4));
+        HIP_TRY(c.e_seg_bytes.reserve(nseg * 8));
         HIP_TRY(c.e_seg_off.reserve(nseg * 8));
         HIP_TRY(pd::launch_segment_sizes(a, c.e_off.as<uint64_t>(), c.e_totals.as<uint64_t>(), nseg, c.e_seg_bytes.as<uint32_t>(), stream));
         HIP_TRY(pd::launch_exclusive_scan(c.e_seg_bytes.as<uint32_t>(), nseg, c.e_seg_off.as<uint64_t>(),
@@ -316,6 +327,14 @@ int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_
     HIP_TRY(pd::launch_stuff(c.e_stream.as<uint32_t>(), nbytes, c.e_tile_base.as<uint64_t>(), c.e_out.as<uint8_t>(), stream));
     if (nseg) HIP_TRY(pd::launch_restart_markers(a, c.e_off.as<uint64_t>(), plan, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
                                                  c.e_out.as<uint8_t>(), stream));
+    if (batch > 1) { // where every image's segment begins in the stuffed stream (reuses the seg_bytes buffer: 8 B/entry)
+        HIP_TRY(c.e_seg_bytes.reserve(nseg * 8));
+        HIP_TRY(pd::launch_segment_out_offsets(plan, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
+                                               c.e_seg_bytes.as<uint64_t>(), stream));
+        image_starts->assign(batch + 1, 0);
+        HIP_TRY(hipMemcpyAsync(image_starts->data(), c.e_seg_bytes.p, nseg * 8, hipMemcpyDeviceToHost, stream));
+        (*image_starts)[batch] = scan_bytes;
+    }
     std::vector<uint8_t> head;
     pixo_host::file_headers(head, o, h);
     const size_t hdr = head.size(), total = hdr + scan_bytes + 2;
@@ -325,10 +344,11 @@ int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_
     std::memcpy(buf, head.data(), hdr);
     HIP_TRY(hipMemcpyAsync(buf + hdr, c.e_out.p, scan_bytes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    buf[hdr + scan_bytes] = 0xFF; // EOI
+    buf[hdr + scan_bytes] = 0xFF; // EOI (of the only image; batches append it per file)
     buf[hdr + scan_bytes + 1] = 0xD9;
     *file = buf;
     *file_len = total;
+    if (header_len) *header_len = hdr;
     sw.lap("stuff+copy to host");
     return PIXO_OK;
 }
@@ -705,6 +725,54 @@ int pixo_hip_png_filter_device(const void *d_data, uint32_t width, uint32_t heig
     Context *c = nullptr;
     if ((rc = context_on_current_device(&c))) return rc;
     return png_filter_on_device(*c, d_data, width, height, bytes_per_pixel, run, seq, d_out, adler32);
+}
+
+int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_options *options, uint32_t batch,
+                                      uint8_t **files, size_t *lens)
+{
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if ((rc = unsupported_scan_mode(*options))) return rc;
+    if (batch == 0 || batch > 65535) return fail(PIXO_ERR_COMPRESSION, "Compression error: batch must be 1..65535");
+    Context *c = nullptr;
+    if ((rc = context_on_current_device(&c))) return rc;
+    const pixo_jpeg_options &o = *options;
+    const pixo_host::Geometry g = pixo_host::geometry(o.width, o.height, o.color_type, o.subsampling);
+    const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
+    for (uint32_t i = 0; i < batch; ++i) { files[i] = nullptr; lens[i] = 0; }
+    auto release = [&](int code) { for (uint32_t i = 0; i < batch; ++i) { std::free(files[i]); files[i] = nullptr; } return code; };
+    // Per-image tables or restart segments inside the images: one image at a time.
+    if (batch == 1 || o.optimize_huffman || scan_has_restart_markers(o, g) || px_bytes % 4 != 0) {
+        for (uint32_t i = 0; i < batch; ++i) {
+            int16_t *dy, *dcb, *dcr;
+            if ((rc = coeffs_on_device(static_cast<const uint8_t *>(d_pixels) + i * px_bytes, o, g, c->stream, &dy, &dcb, &dcr))) return release(rc);
+            if ((rc = device_tuple_to_malloc(dy, dcb, dcr, o, g, *c, &files[i], &lens[i]))) return release(rc);
+        }
+        return PIXO_OK;
+    }
+    // one coefficient launch and one entropy pass for the whole batch
+    const float *qt_all = nullptr;
+    if ((rc = device_tables(c->device, &qt_all))) return rc;
+    const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128 * batch;
+    if ((rc = c->reserve_coef(coef_bytes))) return rc;
+    int16_t *dy = static_cast<int16_t *>(c->d_coef), *dcb = dy + g.y_blocks * 64 * batch, *dcr = dcb + g.c_blocks * 64 * batch;
+    HIP_TRY(pixo_dev::launch_jpeg_coeffs(d_pixels, o.width, o.height, g.gray, g.s420, batch, dy, g.gray ? nullptr : dcb,
+                                         g.gray ? nullptr : dcr, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c->stream));
+    const uint8_t *blob = nullptr;
+    size_t blob_len = 0, hdr = 0;
+    std::vector<uint64_t> starts;
+    if ((rc = device_entropy_to_pinned(dy, dcb, dcr, o, g, c->stream, &blob, &blob_len, batch, &starts, &hdr))) return rc;
+    for (uint32_t i = 0; i < batch; ++i) {
+        const size_t seg = static_cast<size_t>(starts[i + 1] - starts[i]), n = hdr + seg + 2;
+        uint8_t *p = static_cast<uint8_t *>(std::malloc(n));
+        if (!p) return release(fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory"));
+        std::memcpy(p, blob, hdr);
+        std::memcpy(p + hdr, blob + hdr + starts[i], seg);
+        p[hdr + seg] = 0xFF; p[hdr + seg + 1] = 0xD9;
+        files[i] = p; lens[i] = n;
+    }
+    return PIXO_OK;
 }
 
 int pixo_hip_band(uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling, uint32_t parts,

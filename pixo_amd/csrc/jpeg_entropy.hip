@@ -225,7 +225,31 @@ __global__ __launch_bounds__(kScanThreads) void segment_sizes_kernel(const ScanA
     if (k >= nsegments) return;
     const uint64_t first = segment_first(a, k), next = segment_first(a, k + 1);
     const uint64_t bits = (next < a.nblocks ? off[next] : *total_bits) - off[first];
-    seg_bytes[k] = (uint32_t)((bits + 7) / 8 + (k + 1 < nsegments ? 2 : 0));
+    seg_bytes[k] = (uint32_t)((bits + 7) / 8 + (k + 1 < nsegments ? a.marker_bytes : 0));
+}
+
+// 0xFF bytes of the packed stream before byte `pos`: the tile's base count + a walk inside the tile
+__device__ __forceinline__ uint64_t ff_before(const uint32_t *stream, const uint64_t *tile_ff_base, uint64_t pos)
+{
+    const uint64_t tile = pos / kStuffTileBytes;
+    uint64_t ff = tile_ff_base[tile];
+    for (uint64_t w = tile * (kStuffTileBytes / 4); w * 4 < pos; w++) {
+        const uint32_t v = stream[w];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (w * 4 + b < pos && ((v >> (24 - 8 * b)) & 0xFF) == 0xFF) ff++;
+    }
+    return ff;
+}
+
+__global__ __launch_bounds__(kScanThreads) void segment_out_offsets_kernel(const uint64_t *seg_byte_off, uint64_t nsegments,
+                                                                          const uint32_t *stream, const uint64_t *tile_ff_base,
+                                                                          uint64_t *seg_out)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * kScanThreads + threadIdx.x;
+    if (k >= nsegments) return;
+    const uint64_t pos = seg_byte_off[k]; // < bytes of the packed stream
+    seg_out[k] = pos + ff_before(stream, tile_ff_base, pos);
 }
 
 __global__ __launch_bounds__(kScanThreads) void restart_markers_kernel(const ScanArgs a, const uint64_t *off, const uint64_t *seg_byte_off,
@@ -236,14 +260,7 @@ __global__ __launch_bounds__(kScanThreads) void restart_markers_kernel(const Sca
     if (k + 1 >= nsegments) return;
     // the marker's two (still zero) bytes sit right before the next segment
     const uint64_t pos = seg_byte_off[k + 1] - 2;
-    const uint64_t tile = pos / kStuffTileBytes;
-    uint64_t ff = tile_ff_base[tile];
-    for (uint64_t w = tile * (kStuffTileBytes / 4); w * 4 < pos; w++) { // 0xFF bytes of this tile before the marker
-        const uint32_t v = stream[w];
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-            if (w * 4 + b < pos && ((v >> (24 - 8 * b)) & 0xFF) == 0xFF) ff++;
-    }
+    const uint64_t ff = ff_before(stream, tile_ff_base, pos);
     out[pos + ff] = 0xFF;
     out[pos + ff + 1] = (uint8_t)(0xD0 + (k & 7)); // jpeg/mod.rs:1436-1439
 }
@@ -284,10 +301,18 @@ hipError_t launch_segment_sizes(const ScanArgs &a, const uint64_t *d_off, const 
     return hipGetLastError();
 }
 
+hipError_t launch_segment_out_offsets(const SegmentPlan &seg, const uint32_t *d_stream, const uint64_t *d_tile_ff_base,
+                                      uint64_t *d_seg_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(segment_out_offsets_kernel, dim3(grid_for(seg.nsegments, kScanThreads)), dim3(kScanThreads), 0, s,
+                       seg.seg_byte_off, seg.nsegments, d_stream, d_tile_ff_base, d_seg_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_restart_markers(const ScanArgs &a, const uint64_t *d_off, const SegmentPlan &seg, const uint32_t *d_stream,
                                   const uint64_t *d_tile_ff_base, uint8_t *d_out, hipStream_t s)
 {
-    if (seg.nsegments < 2) return hipSuccess;
+    if (seg.nsegments < 2 || a.marker_bytes == 0) return hipSuccess;
     hipLaunchKernelGGL(restart_markers_kernel, dim3(grid_for(seg.nsegments - 1, kScanThreads)), dim3(kScanThreads), 0, s, a, d_off,
                        seg.seg_byte_off, seg.nsegments, d_stream, d_tile_ff_base, d_out);
     return hipGetLastError();

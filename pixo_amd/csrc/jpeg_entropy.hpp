@@ -13,8 +13,11 @@ struct ScanArgs {
     const uint32_t *tables;     // pixo_scan::kTableWords words: (length << 16) | code
     int mode;                   // 0 gray, 1 4:4:4, 2 4:2:0 (block order of encode_scan)
     uint64_t nblocks;           // blocks in scan order
-    uint32_t restart;           // MCUs per restart segment (jpeg/mod.rs:1423-1445), 0 = no markers
+    uint32_t restart;           // MCUs per segment, 0 = one uninterrupted stream.  A segment starts on a byte
+                                // boundary with DC predictors 0: a restart interval (jpeg/mod.rs:1423-1445)
+                                // or, for a batch, one whole image
     uint32_t blocks_per_mcu;    // 1, 3 or 6
+    uint32_t marker_bytes;      // 2 = RSTn marker after every segment but the last; 0 = batch of images
 };
 
 // Scans with restart markers: a segment is `restart` MCUs; every segment starts on a byte boundary
@@ -40,6 +43,10 @@ hipError_t launch_scan_pack(const ScanArgs &a, const uint64_t *d_off, uint64_t t
 // the last, the two marker bytes included), from the exclusive bit offsets d_off and the total.
 hipError_t launch_segment_sizes(const ScanArgs &a, const uint64_t *d_off, const uint64_t *d_total_bits, uint64_t nsegments,
                                 uint32_t *d_seg_bytes, hipStream_t s);
+// d_seg_out[k] = offset of segment k in the STUFFED stream, k < nsegments: where each image of a batch
+// begins.  After launch_ff_tile_count + its scan.
+hipError_t launch_segment_out_offsets(const SegmentPlan &seg, const uint32_t *d_stream, const uint64_t *d_tile_ff_base,
+                                      uint64_t *d_seg_out, hipStream_t s);
 // After launch_stuff: writes FF D0+(k & 7) over the two zero bytes that follow segment k < nsegments - 1.
 hipError_t launch_restart_markers(const ScanArgs &a, const uint64_t *d_off, const SegmentPlan &seg, const uint32_t *d_stream,
                                   const uint64_t *d_tile_ff_base, uint8_t *d_out, hipStream_t s);

@@ -282,6 +282,23 @@ def encode_device(d_pixels, options: JpegOptions) -> bytes:
         L.pixo_hip_free(out)
 
 
+def encode_batch_device(d_pixels, options: JpegOptions, batch: int):
+    """`batch` equally sized images back to back in HBM -> list of `batch` JPEG files; one
+    coefficient launch and one pass of the device entropy stage for all of them."""
+    L = _lib.load()
+    files = (C.POINTER(C.c_uint8) * batch)()
+    lens = (C.c_size_t * batch)()
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_encode_batch_device(_dev_ptr(d_pixels), C.byref(oc), batch, files, lens)
+    if rc:
+        _raise(rc)
+    out = []
+    for i in range(batch):
+        out.append(C.string_at(files[i], lens[i]))
+        L.pixo_hip_free(files[i])
+    return out
+
+
 def band(width, height, color_type, subsampling, parts, index):
     """MCU-row band `index` of `parts`: dict(row_begin,row_end,y_offset,y_blocks,
     c_offset,c_blocks).  Bands are independent sub-images of the same width."""

@@ -284,3 +284,22 @@ def test_random_option_sweep_whole_files():
         got = jpeg.encode(px, _opts(w, h, ct, ss, q, restart_interval=restart, optimize_huffman=opt))
         want = O.encode(px, O.make_options(w, h, ct, q, ss, restart=restart, optimize_huffman=opt))
         assert got == want, (i, w, h, ct, ss, q, restart, opt, kind)
+
+
+@pytest.mark.parametrize("shape", [(1920, 1080, 2, 1, 6), (333, 77, 2, 0, 9), (64, 64, 0, 0, 5), (100, 36, 2, 1, 3)])
+def test_batch_whole_files_one_entropy_pass(shape):
+    """config 3 shape through encode_batch_device: every image of the batch equals its own oracle file."""
+    import torch
+    w, h, ct, ss, n = shape
+    imgs = [(synth.noise(w, h, 100 + i) if ct == 2 else synth.noise_gray(w, h, 100 + i)) for i in range(n)]
+    imgs[1] = synth.gradient_rgb(w, h) if ct == 2 else synth.constant(w, h, 90, 1)  # a very short segment among long ones
+    d_px = torch.from_numpy(np.concatenate(imgs)).to("cuda:0")
+    torch.cuda.synchronize()
+    files = jpeg.encode_batch_device(d_px, _opts(w, h, ct, ss, 80), n)
+    assert len(files) == n
+    for i in range(n):
+        assert files[i] == O.encode(imgs[i], O.make_options(w, h, ct, 80, ss)), i
+    # options that need per-image work take the one-by-one route and still agree
+    files = jpeg.encode_batch_device(d_px, _opts(w, h, ct, ss, 80, optimize_huffman=True, restart_interval=5), n)
+    for i in (0, n - 1):
+        assert files[i] == O.encode(imgs[i], O.make_options(w, h, ct, 80, ss, optimize_huffman=True, restart=5)), i

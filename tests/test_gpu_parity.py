@@ -303,3 +303,18 @@ def test_batch_whole_files_one_entropy_pass(shape):
     files = jpeg.encode_batch_device(d_px, _opts(w, h, ct, ss, 80, optimize_huffman=True, restart_interval=5), n)
     for i in (0, n - 1):
         assert files[i] == O.encode(imgs[i], O.make_options(w, h, ct, 80, ss, optimize_huffman=True, restart=5)), i
+
+
+def test_config4_16384_image_on_one_gpu_matches_the_reference_file():
+    """configs[3] at full size on a single MI355X (0.8 GB of pixels, 6.3 M blocks, a 178 MB file):
+    64-bit offsets everywhere, and the reference's own result for this input (made by
+    the wasm build) — 178,548,465 bytes, sha256 77cc6cb6..."""
+    import torch
+    w = h = 16384
+    px = synth.noise(w, h, 42)
+    d_px = torch.from_numpy(px).to("cuda:0")
+    del px
+    torch.cuda.synchronize()
+    blob = jpeg.encode_device(d_px, _opts(w, h, 2, 1, 80))
+    assert len(blob) == 178548465
+    assert hashlib.sha256(blob).hexdigest() == "77cc6cb69a782693c46f2024ac57ebfdfb8411148fa3cef62698c727af36c70c"

@@ -56,7 +56,7 @@ typedef struct pixo_jpeg_options {
     uint16_t restart_interval;     /* MCUs; Some(0) is InvalidRestartInterval      */
     uint8_t optimize_huffman;
     uint8_t progressive;           /* not on the accelerated path: see DESIGN.md   */
-    uint8_t trellis_quant;         /* not on the accelerated path: see DESIGN.md   */
+    uint8_t trellis_quant;         /* read only by the progressive path, as upstream */
 } pixo_jpeg_options;
 
 /* JpegOptions::{fast,balanced,max,from_preset} (src/jpeg/mod.rs:162-216). */

@@ -716,7 +716,7 @@ int po_encode_jpeg_from_coeffs(const int16_t *y, const int16_t *cb, const int16_
 {
     int rc = validate(o, 0, 0);
     if (rc) return rc;
-    if (o->progressive || o->trellis_quant) return PO_ERR_UNSUPPORTED_OPTION;
+    if (o->progressive) return PO_ERR_UNSUPPORTED_OPTION; /* trellis_quant alone: no effect on the baseline path (jpeg/mod.rs:1408-1563 never reads it) */
     uint8_t lzz[64], czz[64];
     float ql[64], qc[64];
     po_quant_tables(o->quality, lzz, czz, ql, qc);
@@ -747,7 +747,7 @@ int po_encode_jpeg(const uint8_t *data, size_t data_len, const po_options *o, ui
 {
     int rc = validate(o, data_len, 1);
     if (rc) return rc;
-    if (o->progressive || o->trellis_quant) return PO_ERR_UNSUPPORTED_OPTION;
+    if (o->progressive) return PO_ERR_UNSUPPORTED_OPTION; /* trellis_quant alone: no effect on the baseline path (jpeg/mod.rs:1408-1563 never reads it) */
     size_t yb, cbn;
     po_coeff_geometry(o->width, o->height, o->color_type, o->subsampling, &yb, &cbn);
     int16_t *y = (int16_t *)malloc((yb + 2 * cbn + 1) * 64 * sizeof(int16_t));

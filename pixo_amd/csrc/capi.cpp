@@ -374,9 +374,12 @@ int device_entropy_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_
     return deliver(file, n, out_buf, out_len);
 }
 
+// `trellis_quant` only acts inside the progressive path of the reference (compute_all_coefficients,
+// src/jpeg/mod.rs:872-976; encode_scan never looks at it): a baseline encode with the flag set is an
+// ordinary baseline encode.  Progressive scans are not implemented here and are refused loudly.
 int unsupported_scan_mode(const pixo_jpeg_options &o)
 {
-    if (o.progressive || o.trellis_quant)
+    if (o.progressive)
         return fail(PIXO_ERR_COMPRESSION,
                     "Compression error: progressive/trellis encoding is not implemented by the "
                     "HIP backend (baseline sequential only); use the CPU encoder for preset 2");

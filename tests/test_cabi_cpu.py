@@ -91,11 +91,16 @@ def test_validation_order_and_variants():
     assert out == b"keep"
 
 
-def test_progressive_and_trellis_are_refused_not_silently_ignored():
+def test_progressive_is_refused_and_trellis_alone_is_the_baseline_encode():
     y = np.zeros((1, 64), np.int16)
     o = jpeg.JpegOptions.builder(8, 8).color_type(ColorType.Gray).progressive(True).build()
     with pytest.raises(error.CompressionError, match="progressive/trellis"):
         jpeg.entropy_encode(y, y, y, o)
+    # the reference only reads trellis_quant inside its progressive path (jpeg/mod.rs:872-976):
+    # with progressive off the flag changes nothing
+    t = jpeg.JpegOptions.builder(8, 8).color_type(ColorType.Gray).trellis_quant(True).build()
+    plain = jpeg.JpegOptions.builder(8, 8).color_type(ColorType.Gray).build()
+    assert jpeg.entropy_encode(y, y, y, t) == jpeg.entropy_encode(y, y, y, plain)
 
 
 def test_no_gpu_means_loud_failure_not_a_cpu_fallback():

@@ -224,16 +224,132 @@ void po_coeff_geometry(uint32_t w, uint32_t h, uint8_t color_type, uint8_t subsa
     }
 }
 
-static void dct_quant(const float blk[64], const float q[64], int16_t out[64])
-{
-    float f[64];
-    po_dct_2d(blk, f);
-    po_quantize_block(f, q, out);
+/* ------------------------------------------------------------------------- */
+/* trellis quantisation: src/jpeg/trellis.rs:18-299 (lambda = DEFAULT_LAMBDA)    */
+/* ------------------------------------------------------------------------- */
+static const uint8_t ZZ_NAT[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
+                                   12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+                                   58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+typedef struct { float cost; uint8_t zero_run; uint16_t parent; int16_t value; } tstate;
+
+static int16_t sat_i16(float v)
+{ /* Rust `as i16`: saturating, NaN -> 0 */
+    if (!(v == v)) return 0;
+    if (v >= 32767.0f) return 32767;
+    if (v <= -32768.0f) return -32768;
+    return (int16_t)v;
+}
+static int tcat(int16_t v)
+{ /* trellis.rs:289-296 */
+    unsigned a = (unsigned)(v < 0 ? -(int)v : (int)v) & 0xFFFFu;
+    int c = 0;
+    while (a) { c++; a >>= 1; }
+    return c;
+}
+static int gen_candidates(float fq, int16_t c[5])
+{ /* trellis.rs:210-244: 0, floor, round, ceil, one step further out when |fq| > 1.5; no duplicates */
+    int16_t r = sat_i16(roundf(fq)), fl = sat_i16(floorf(fq)), ce = sat_i16(ceilf(fq));
+    int n = 0;
+    c[n++] = 0;
+#define HAS(v) ({ int f_ = 0; for (int i_ = 0; i_ < n; i_++) if (c[i_] == (v)) f_ = 1; f_; })
+    if (fl != 0 && !HAS(fl)) c[n++] = fl;
+    if (r != 0 && !HAS(r)) c[n++] = r;
+    if (ce != 0 && !HAS(ce)) c[n++] = ce;
+    if (fabsf(fq) > 1.5f) {
+        int16_t ext = (int16_t)(fq >= 0.0f ? ce + 1 : fl - 1);
+        if (!HAS(ext)) c[n++] = ext;
+    }
+#undef HAS
+    return n;
+}
+static float ac_huff_len(unsigned rs)
+{ /* trellis.rs:260-279 */
+    switch (rs) {
+    case 0x00: return 4.0f; case 0x01: return 2.0f; case 0x02: return 2.5f; case 0x03: return 3.0f;
+    case 0x04: return 4.0f; case 0x11: return 3.0f; case 0x12: return 4.0f; case 0x21: return 4.0f;
+    case 0xF0: return 10.0f;
+    default: { float run = (float)(rs >> 4), size = (float)(rs & 0x0F); return 3.0f + run * 0.5f + size * 0.3f; }
+    }
+}
+static void trellis_quantize(const float dct[64], const float q[64], int16_t out[64])
+{ /* trellis.rs:67-208 */
+    const float lambda = 1.0f;
+    memset(out, 0, 64 * sizeof(int16_t));
+    out[0] = sat_i16(roundf(dct[0] / q[0]));
+    static _Thread_local tstate all[64][8];
+    static _Thread_local int alln[64];
+    tstate cur[8], nxt[40];
+    int ncur = 1;
+    cur[0].cost = 0.0f; cur[0].zero_run = 0; cur[0].parent = 0; cur[0].value = 0;
+    all[0][0] = cur[0]; alln[0] = 1;
+    for (int zz = 1; zz < 64; zz++) {
+        const float coef = dct[ZZ_NAT[zz]], qq = q[ZZ_NAT[zz]];
+        int16_t cand[5];
+        const int nc = gen_candidates(coef / qq, cand);
+        int nn = 0;
+        for (int pi = 0; pi < ncur; pi++) {
+            for (int ci = 0; ci < nc; ci++) {
+                const int16_t c = cand[ci];
+                const float rec = (float)c * qq, dd = coef - rec, dist = dd * dd;
+                float rate; uint8_t nrun;
+                if (c == 0) {
+                    unsigned r = (unsigned)cur[pi].zero_run + 1; if (r > 255) r = 255;
+                    if (r >= 16) { rate = 10.0f; nrun = 0; } else { rate = 0.0f; nrun = (uint8_t)r; }
+                } else {
+                    const int cat = tcat(c);
+                    rate = ac_huff_len(((unsigned)cur[pi].zero_run << 4) | (unsigned)cat) + (float)cat;
+                    nrun = 0;
+                }
+                const float cost = cur[pi].cost + rate + lambda * dist;
+                int found = -1;
+                for (int k = 0; k < nn; k++) if (nxt[k].value == c && nxt[k].zero_run == nrun) { found = k; break; }
+                tstate st = {cost, nrun, (uint16_t)pi, c};
+                if (found < 0) nxt[nn++] = st;
+                else if (cost < nxt[found].cost) nxt[found] = st;
+            }
+        }
+        /* stable sort by cost (sort_by + partial_cmp), keep the best MAX_STATES = 8 */
+        for (int i = 1; i < nn; i++) {
+            tstate t = nxt[i]; int j = i - 1;
+            while (j >= 0 && nxt[j].cost > t.cost) { nxt[j + 1] = nxt[j]; j--; }
+            nxt[j + 1] = t;
+        }
+        if (nn > 8) nn = 8;
+        for (int i = 0; i < nn; i++) { cur[i] = nxt[i]; all[zz][i] = nxt[i]; }
+        ncur = nn; alln[zz] = nn;
+    }
+    for (int i = 0; i < ncur; i++) if (cur[i].zero_run > 0) cur[i].cost += 4.0f;
+    int best = 0;
+    for (int i = 1; i < ncur; i++) if (cur[i].cost < cur[best].cost) best = i; /* min_by: the first minimum */
+    int idx = best;
+    for (int zz = 63; zz >= 1; zz--) {
+        if (idx < alln[zz]) { out[ZZ_NAT[zz]] = all[zz][idx].value; idx = all[zz][idx].parent; }
+    }
 }
 
+static void dct_quant_ex(const float blk[64], const float q[64], int16_t out[64], int use_trellis)
+{ /* quantize_dct, jpeg/mod.rs:968-976 */
+    float f[64];
+    po_dct_2d(blk, f);
+    if (use_trellis) trellis_quantize(f, q, out);
+    else po_quantize_block(f, q, out);
+}
+#define dct_quant(blk, q, out) dct_quant_ex(blk, q, out, use_trellis)
+
+int po_jpeg_coeffs_ex(const uint8_t *pixels, uint32_t w32, uint32_t h32, uint8_t color_type,
+                      uint8_t subsampling, uint8_t quality, int16_t *y, int16_t *cb,
+                      int16_t *cr, int threads, int use_trellis);
 int po_jpeg_coeffs(const uint8_t *pixels, uint32_t w32, uint32_t h32, uint8_t color_type,
                    uint8_t subsampling, uint8_t quality, int16_t *y, int16_t *cb,
                    int16_t *cr, int threads)
+{
+    return po_jpeg_coeffs_ex(pixels, w32, h32, color_type, subsampling, quality, y, cb, cr, threads, 0);
+}
+
+int po_jpeg_coeffs_ex(const uint8_t *pixels, uint32_t w32, uint32_t h32, uint8_t color_type,
+                      uint8_t subsampling, uint8_t quality, int16_t *y, int16_t *cb,
+                      int16_t *cr, int threads, int use_trellis)
 {
     if (w32 == 0 || h32 == 0) return PO_ERR_INVALID_DIMENSIONS;
     if (color_type != PO_GRAY && color_type != PO_RGB) return PO_ERR_UNSUPPORTED_COLOR;
@@ -665,14 +781,14 @@ static void put_dht(bytevec *v, uint8_t id, const htable *t)
 
 static void put_headers(bytevec *v, const po_options *o, const uint8_t lzz[64],
                         const uint8_t czz[64], const hufftables *ht)
-{
+{ /* progressive (:397-405): SOF2 instead of SOF0, and the SOS headers are written per scan */
     static const uint8_t app0[] = {0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
     bv_be16(v, 0xFFD8);       /* SOI :449 */
     bv_put(v, app0, sizeof app0); /* APP0 :457-481 */
     bv_be16(v, 0xFFDB); bv_be16(v, 67); bv_push(v, 0); bv_put(v, lzz, 64); /* DQT :484-496 */
     bv_be16(v, 0xFFDB); bv_be16(v, 67); bv_push(v, 1); bv_put(v, czz, 64);
     int nc = o->color_type == PO_GRAY ? 1 : 3;
-    bv_be16(v, 0xFFC0);       /* SOF0 :519-571 */
+    bv_be16(v, o->progressive ? 0xFFC2 : 0xFFC0);       /* SOF0 / SOF2 :498-571 */
     bv_be16(v, (unsigned)(8 + 3 * nc));
     bv_push(v, 8);
     bv_be16(v, o->height & 0xFFFF);
@@ -690,12 +806,105 @@ static void put_headers(bytevec *v, const po_options *o, const uint8_t lzz[64],
     put_dht(v, 0x10, &ht->ac[0]);
     put_dht(v, 0x11, &ht->ac[1]);
     if (o->has_restart) { bv_be16(v, 0xFFDD); bv_be16(v, 4); bv_be16(v, o->restart_interval); } /* :587-591 */
+    if (o->progressive) return;
     bv_be16(v, 0xFFDA);       /* SOS :614-648 */
     bv_be16(v, (unsigned)(6 + 2 * nc));
     bv_push(v, (uint8_t)nc);
     bv_push(v, 1); bv_push(v, 0x00);
     if (nc == 3) { bv_push(v, 2); bv_push(v, 0x11); bv_push(v, 3); bv_push(v, 0x11); }
     bv_push(v, 0); bv_push(v, 63); bv_push(v, 0);
+}
+
+/* ------------------------------------------------------------------------- */
+/* progressive scans: src/jpeg/mod.rs:872-927, :1248-1365; src/jpeg/progressive.rs */
+/* ------------------------------------------------------------------------- */
+/* progressive.rs:363-381: walks BITS/VALS; a symbol that is not in the table gets (0, 4) */
+static void code_from_table(const htable *t, uint8_t sym, unsigned *code, int *len)
+{
+    unsigned c = 0;
+    int vi = 0;
+    for (int l = 0; l < 16; l++) {
+        for (int k = 0; k < t->bits[l]; k++) {
+            if (vi < t->nvals && t->vals[vi] == sym) { *code = c; *len = l + 1; return; }
+            vi++; c++;
+        }
+        c <<= 1;
+    }
+    *code = 0; *len = 4;
+}
+static void flush_eob_run(bitw *w, uint16_t *eob_run, const htable *ac)
+{ /* progressive.rs:313-345 */
+    if (*eob_run == 0) return;
+    unsigned temp = *eob_run; int nbits = 0;
+    while (temp > 0) { temp >>= 1; nbits++; }
+    nbits = nbits > 0 ? nbits - 1 : 0;
+    unsigned code; int len;
+    code_from_table(ac, (uint8_t)(nbits << 4), &code, &len);
+    bw_bits(w, code, len);
+    if (nbits > 0) bw_bits(w, (uint32_t)(*eob_run - (1u << nbits)), nbits);
+    *eob_run = 0;
+}
+static void encode_ac_first(bitw *w, const int16_t blk[64], int ss, int se, int al, uint16_t *eob_run, const htable *ac)
+{ /* progressive.rs:141-210 */
+    int16_t zz[64];
+    po_zigzag(blk, zz);
+    int k = se;
+    while (k >= ss && (zz[k] >> al) == 0) { if (k == ss) break; k--; }
+    const int last = k;
+    if (last == ss && (zz[ss] >> al) == 0) {
+        *eob_run += 1;
+        if (*eob_run == 0x7FFF) flush_eob_run(w, eob_run, ac);
+        return;
+    }
+    if (*eob_run > 0) flush_eob_run(w, eob_run, ac);
+    int zero_run = 0;
+    for (k = ss; k <= last; k++) {
+        const int coef = zz[k] >> al;
+        if (coef == 0) { zero_run++; continue; }
+        unsigned code; int len;
+        while (zero_run >= 16) { code_from_table(ac, 0xF0, &code, &len); bw_bits(w, code, len); zero_run -= 16; }
+        const int cat = category(coef);
+        code_from_table(ac, (uint8_t)((zero_run << 4) | cat), &code, &len);
+        bw_bits(w, code, len);
+        if (cat > 0) bw_bits(w, value_bits(coef, cat), cat);
+        zero_run = 0;
+    }
+    if (last < se) *eob_run = 1;
+}
+static void progressive_scans(bytevec *v, const int16_t *y, size_t yb, const int16_t *cb, const int16_t *cr, size_t cbn,
+                              const hufftables *ht)
+{ /* simple_progressive_script (progressive.rs:98-110): DC of Y, Cb, Cr; Y AC 1-10, 11-63; Cb AC; Cr AC.
+     Every scan walks the component's blocks in STORAGE order (mod.rs:1286, :1350) with its own bit writer. */
+    static const struct { int comp, ss, se; } script[7] = {{0, 0, 0}, {1, 0, 0}, {2, 0, 0}, {0, 1, 10}, {0, 11, 63}, {1, 1, 63}, {2, 1, 63}};
+    for (int s = 0; s < 7; s++) {
+        const int comp = script[s].comp, ss = script[s].ss, se = script[s].se;
+        bv_be16(v, 0xFFDA); bv_be16(v, 8); bv_push(v, 1); /* write_sos_progressive :650-682 */
+        bv_push(v, (uint8_t)(comp + 1)); bv_push(v, comp == 0 ? 0x00 : 0x11);
+        bv_push(v, (uint8_t)ss); bv_push(v, (uint8_t)se); bv_push(v, 0);
+        const int16_t *coef = comp == 0 ? y : (comp == 1 ? cb : cr);
+        const size_t n = comp == 0 ? yb : cbn;
+        const int cls = comp == 0 ? 0 : 1;
+        bitw w = {v, 0, 8};
+        if (n == 0) continue; /* gray: the chroma scans are headers only */
+        if (ss == 0 && se == 0) { /* encode_dc_scan :1248-1310 */
+            int16_t prev = 0;
+            for (size_t b = 0; b < n; b++) {
+                const int16_t dc = coef[b * 64];
+                const int16_t diff = (int16_t)(dc - prev);
+                const int cat = category(diff);
+                unsigned code; int len;
+                code_from_table(&ht->dc[cls], (uint8_t)cat, &code, &len);
+                bw_bits(&w, code, len);
+                if (cat > 0) bw_bits(&w, value_bits(diff, cat), cat);
+                prev = dc;
+            }
+        } else { /* encode_ac_first_scan :1326-1365 */
+            uint16_t eob_run = 0;
+            for (size_t b = 0; b < n; b++) encode_ac_first(&w, coef + b * 64, ss, se, 0, &eob_run, &ht->ac[cls]);
+            if (eob_run > 0) flush_eob_run(&w, &eob_run, &ht->ac[cls]);
+        }
+        bw_flush(&w);
+    }
 }
 
 /* jpeg/mod.rs:333-373, same order of checks. */
@@ -716,7 +925,10 @@ int po_encode_jpeg_from_coeffs(const int16_t *y, const int16_t *cb, const int16_
 {
     int rc = validate(o, 0, 0);
     if (rc) return rc;
-    if (o->progressive) return PO_ERR_UNSUPPORTED_OPTION; /* trellis_quant alone: no effect on the baseline path (jpeg/mod.rs:1408-1563 never reads it) */
+    /* (trellis_quant alone: no effect on the baseline path, jpeg/mod.rs:1408-1563 never reads it.
+       Progressive WITH optimised tables needs the pixels — the statistics come from the plain
+       quantiser, not from this tuple: po_encode_jpeg below.) */
+    if (o->progressive && o->optimize_huffman) return PO_ERR_UNSUPPORTED_OPTION;
     uint8_t lzz[64], czz[64];
     float ql[64], qc[64];
     po_quant_tables(o->quality, lzz, czz, ql, qc);
@@ -731,10 +943,16 @@ int po_encode_jpeg_from_coeffs(const int16_t *y, const int16_t *cb, const int16_
     bytevec v = {0};
     bv_reserve(&v, (size_t)o->width * o->height / 4 + 1024);
     put_headers(&v, o, lzz, czz, &ht);
-    bitw w = {&v, 0, 8};
-    walk_ctx c = {0, &w, &ht, NULL, NULL};
-    walk_scan(&c, y, cb, cr, o);
-    bw_flush(&w);
+    if (o->progressive) {
+        size_t yb, cbn;
+        po_coeff_geometry(o->width, o->height, o->color_type, o->subsampling, &yb, &cbn);
+        progressive_scans(&v, y, yb, cb, cr, cbn, &ht);
+    } else {
+        bitw w = {&v, 0, 8};
+        walk_ctx c = {0, &w, &ht, NULL, NULL};
+        walk_scan(&c, y, cb, cr, o);
+        bw_flush(&w);
+    }
     bv_be16(&v, 0xFFD9);
     if (v.oom) { free(v.p); return PO_ERR_NOMEM; }
     *out = v.p;
@@ -747,16 +965,45 @@ int po_encode_jpeg(const uint8_t *data, size_t data_len, const po_options *o, ui
 {
     int rc = validate(o, data_len, 1);
     if (rc) return rc;
-    if (o->progressive) return PO_ERR_UNSUPPORTED_OPTION; /* trellis_quant alone: no effect on the baseline path (jpeg/mod.rs:1408-1563 never reads it) */
     size_t yb, cbn;
     po_coeff_geometry(o->width, o->height, o->color_type, o->subsampling, &yb, &cbn);
     int16_t *y = (int16_t *)malloc((yb + 2 * cbn + 1) * 64 * sizeof(int16_t));
     if (!y) return PO_ERR_NOMEM;
     int16_t *cb = y + yb * 64, *cr = cb + cbn * 64;
     po_jpeg_coeffs(data, o->width, o->height, o->color_type, o->subsampling, o->quality, y, cb, cr, 1);
-    rc = po_encode_jpeg_from_coeffs(y, cb, cr, o, out, out_len);
+    if (!o->progressive) {
+        rc = po_encode_jpeg_from_coeffs(y, cb, cr, o, out, out_len);
+        free(y);
+        return rc;
+    }
+    /* progressive (jpeg/mod.rs:376-419): tables first — optimised ones from the statistics of the
+       PLAIN quantiser (build_optimized_huffman_tables :684-824 never uses trellis) — then the
+       coefficients again, through the trellis quantiser if asked (compute_all_coefficients :932). */
+    uint8_t lzz[64], czz[64];
+    float ql[64], qc[64];
+    po_quant_tables(o->quality, lzz, czz, ql, qc);
+    hufftables ht;
+    if (o->optimize_huffman) {
+        uint64_t dc[2][12], ac[2][256];
+        po_options base = *o;
+        base.progressive = 0;
+        po_symbol_histograms(y, cb, cr, &base, dc, ac);
+        optimized_tables(&ht, dc, ac, o->color_type != PO_GRAY);
+    } else {
+        std_tables(&ht);
+    }
+    if (o->trellis_quant)
+        po_jpeg_coeffs_ex(data, o->width, o->height, o->color_type, o->subsampling, o->quality, y, cb, cr, 1, 1);
+    bytevec v = {0};
+    bv_reserve(&v, (size_t)o->width * o->height / 4 + 1024);
+    put_headers(&v, o, lzz, czz, &ht);
+    progressive_scans(&v, y, yb, cb, cr, cbn, &ht);
+    bv_be16(&v, 0xFFD9);
     free(y);
-    return rc;
+    if (v.oom) { free(v.p); return PO_ERR_NOMEM; }
+    *out = v.p;
+    *out_len = v.n;
+    return PO_OK;
 }
 
 int po_encode_jpeg_flat(const uint8_t *data, size_t data_len, uint32_t w, uint32_t h,

@@ -83,6 +83,11 @@ void po_coeff_geometry(uint32_t w, uint32_t h, uint8_t color_type, uint8_t subsa
  * 2x2 box, level shift, DCT, quantise.  Natural-order i16[64] per block.
  * threads<=1: single thread; otherwise OpenMP over MCU rows (what the reference's
  * rayon path does in compute_all_coefficients, jpeg/mod.rs:1137-1230). */
+/* same with the quantiser of the progressive path: use_trellis != 0 -> trellis_quantize
+ * (src/jpeg/trellis.rs:67-208, lambda 1.0) instead of quantize_block */
+int po_jpeg_coeffs_ex(const uint8_t *pixels, uint32_t w, uint32_t h, uint8_t color_type,
+                      uint8_t subsampling, uint8_t quality, int16_t *y, int16_t *cb, int16_t *cr,
+                      int threads, int use_trellis);
 int po_jpeg_coeffs(const uint8_t *pixels, uint32_t w, uint32_t h, uint8_t color_type,
                    uint8_t subsampling, uint8_t quality, int16_t *y, int16_t *cb,
                    int16_t *cr, int threads);

@@ -328,6 +328,8 @@ static void trellis_quantize(const float dct[64], const float q[64], int16_t out
     }
 }
 
+void po_trellis_quantize(const float dct[64], const float q[64], int16_t out[64]) { trellis_quantize(dct, q, out); }
+
 static void dct_quant_ex(const float blk[64], const float q[64], int16_t out[64], int use_trellis)
 { /* quantize_dct, jpeg/mod.rs:968-976 */
     float f[64];

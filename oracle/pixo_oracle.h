@@ -83,6 +83,8 @@ void po_coeff_geometry(uint32_t w, uint32_t h, uint8_t color_type, uint8_t subsa
  * 2x2 box, level shift, DCT, quantise.  Natural-order i16[64] per block.
  * threads<=1: single thread; otherwise OpenMP over MCU rows (what the reference's
  * rayon path does in compute_all_coefficients, jpeg/mod.rs:1137-1230). */
+/* src/jpeg/trellis.rs:67-208 with DEFAULT_LAMBDA, one block (natural order in and out) */
+void po_trellis_quantize(const float dct[64], const float q[64], int16_t out[64]);
 /* same with the quantiser of the progressive path: use_trellis != 0 -> trellis_quantize
  * (src/jpeg/trellis.rs:67-208, lambda 1.0) instead of quantize_block */
 int po_jpeg_coeffs_ex(const uint8_t *pixels, uint32_t w, uint32_t h, uint8_t color_type,

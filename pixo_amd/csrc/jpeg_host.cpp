@@ -421,7 +421,7 @@ void write_headers(std::vector<uint8_t> &v, const pixo_jpeg_options &o, const Qu
     }
     const bool gray = o.color_type == PIXO_GRAY;
     const unsigned ncomp = gray ? 1 : 3;
-    be16(v, 0xFFC0);
+    be16(v, o.progressive ? 0xFFC2 : 0xFFC0); // SOF2 for progressive scans (jpeg/mod.rs:397-400, :508-516)
     be16(v, 8 + 3 * ncomp);
     v.push_back(8);
     be16(v, o.height & 0xFFFF);
@@ -438,6 +438,7 @@ void write_headers(std::vector<uint8_t> &v, const pixo_jpeg_options &o, const Qu
     dht_segment(v, 0x10, h.ac[0]);
     dht_segment(v, 0x11, h.ac[1]);
     if (o.has_restart_interval) { be16(v, 0xFFDD); be16(v, 4); be16(v, o.restart_interval); }
+    if (o.progressive) return; // every progressive scan writes its own SOS
     be16(v, 0xFFDA);
     be16(v, 6 + 2 * ncomp);
     v.push_back(static_cast<uint8_t>(ncomp));
@@ -445,7 +446,96 @@ void write_headers(std::vector<uint8_t> &v, const pixo_jpeg_options &o, const Qu
     if (!gray) { v.push_back(2); v.push_back(0x11); v.push_back(3); v.push_back(0x11); }
     v.push_back(0); v.push_back(63); v.push_back(0);
 }
+// ---- progressive scans (jpeg/mod.rs:872-927, :1248-1365; progressive.rs) -------------------------
+// A symbol the table does not contain is coded as (0, 4 bits): progressive.rs:363-381 falls back to
+// that instead of failing, and the end-of-band run symbols 0x10..0xE0 are never in these tables.
+struct Code { uint32_t code; int len; };
+inline Code code_of(const HuffTable &t, int symbol)
+{
+    return t.len[symbol & 0xFF] ? Code{t.code[symbol & 0xFF], t.len[symbol & 0xFF]} : Code{0, 4};
+}
+
+void flush_band_run(BitSink &sink, unsigned &run, const HuffTable &ac)
+{ // progressive.rs:313-345: symbol = floor(log2 run) << 4, then the low bits of the run
+    if (run == 0) return;
+    const int nbits = 31 - __builtin_clz(run);
+    const Code c = code_of(ac, nbits << 4);
+    sink.put(c.code, c.len);
+    if (nbits > 0) sink.put(run - (1u << nbits), nbits);
+    run = 0;
+}
+
+// One block of a first AC scan over zig-zag positions [ss, se] (progressive.rs:141-210, al = 0)
+void ac_band_block(BitSink &sink, const int16_t *blk, int ss, int se, unsigned &run, const HuffTable &ac)
+{
+    int last = se;
+    while (last > ss && blk[kZigzag[last]] == 0) --last;
+    if (last == ss && blk[kZigzag[ss]] == 0) { // nothing in the band: lengthen the end-of-band run
+        if (++run == 0x7FFF) flush_band_run(sink, run, ac);
+        return;
+    }
+    flush_band_run(sink, run, ac);
+    int zeros = 0;
+    for (int k = ss; k <= last; ++k) {
+        const int v = blk[kZigzag[k]];
+        if (v == 0) { ++zeros; continue; }
+        for (; zeros >= 16; zeros -= 16) { const Code z = code_of(ac, 0xF0); sink.put(z.code, z.len); }
+        const int cat = magnitude_bits(v);
+        const Code c = code_of(ac, (zeros << 4) | cat);
+        sink.put(c.code, c.len);
+        sink.put(static_cast<uint32_t>(v < 0 ? v - 1 : v) & ((1u << cat) - 1u), cat);
+        zeros = 0;
+    }
+    if (last < se) run = 1;
+}
+
+// simple_progressive_script (progressive.rs:98-110): DC of Y, Cb, Cr, then Y AC 1-10, Y AC 11-63, Cb AC,
+// Cr AC; one component per scan, its blocks in STORAGE order (jpeg/mod.rs:1286, :1350), one bit
+// stream per scan (flushed with 1-padding).  Gray images still get the chroma SOS headers (:888-925).
+void progressive_scans(std::vector<uint8_t> &out, const int16_t *y, const int16_t *cb, const int16_t *cr,
+                       const Geometry &g, const HuffSet &h)
+{
+    static const struct { int comp, ss, se; } script[7] = {{0, 0, 0}, {1, 0, 0}, {2, 0, 0}, {0, 1, 10}, {0, 11, 63}, {1, 1, 63}, {2, 1, 63}};
+    for (const auto &sc : script) {
+        be16(out, 0xFFDA); be16(out, 8); out.push_back(1); // write_sos_progressive, jpeg/mod.rs:650-682
+        out.push_back(static_cast<uint8_t>(sc.comp + 1));
+        out.push_back(sc.comp == 0 ? 0x00 : 0x11);
+        out.push_back(static_cast<uint8_t>(sc.ss)); out.push_back(static_cast<uint8_t>(sc.se)); out.push_back(0);
+        const int16_t *coef = sc.comp == 0 ? y : (sc.comp == 1 ? cb : cr);
+        const size_t n = sc.comp == 0 ? g.y_blocks : g.c_blocks;
+        const int cls = sc.comp == 0 ? 0 : 1;
+        if (n == 0) continue;
+        BitSink sink(out);
+        if (sc.se == 0) { // DC scan: differences in storage order, predictor starts at 0 per scan
+            int16_t prev = 0;
+            for (size_t b = 0; b < n; ++b) {
+                const int16_t dc = coef[b * 64];
+                const int diff = static_cast<int16_t>(dc - prev);
+                const int cat = magnitude_bits(diff);
+                const Code c = code_of(h.dc[cls], cat);
+                sink.put(c.code, c.len);
+                if (cat) sink.put(static_cast<uint32_t>(diff < 0 ? diff - 1 : diff) & ((1u << cat) - 1u), cat);
+                prev = dc;
+            }
+        } else {
+            unsigned run = 0;
+            for (size_t b = 0; b < n; ++b) ac_band_block(sink, coef + b * 64, sc.ss, sc.se, run, h.ac[cls]);
+            flush_band_run(sink, run, h.ac[cls]);
+        }
+        sink.align_with_ones();
+    }
+}
 } // namespace
+
+void encode_progressive_file(const int16_t *y, const int16_t *cb, const int16_t *cr, const pixo_jpeg_options &o,
+                             const HuffSet &h, std::vector<uint8_t> &out)
+{
+    const Geometry g = geometry(o.width, o.height, o.color_type, o.subsampling);
+    out.clear();
+    write_headers(out, o, make_quant_tables(o.quality), h);
+    progressive_scans(out, y, cb, cr, g, h);
+    be16(out, 0xFFD9);
+}
 
 void symbol_histograms(const int16_t *y, const int16_t *cb, const int16_t *cr,
                        const pixo_jpeg_options &o, uint64_t dc[2][12], uint64_t ac[2][256])
@@ -481,6 +571,10 @@ void encode_file(const int16_t *y, const int16_t *cb, const int16_t *cr,
         h = HuffSet::optimized(dc, ac, o.color_type != PIXO_GRAY);
     } else {
         h = HuffSet::standard();
+    }
+    if (o.progressive) { // (statistics for optimised tables: those of a baseline scan over this tuple)
+        encode_progressive_file(y, cb, cr, o, h, out);
+        return;
     }
     out.clear();
     out.reserve(static_cast<size_t>(o.width) * o.height * (o.color_type == PIXO_RGB ? 3 : 1) / 4 + 1024);

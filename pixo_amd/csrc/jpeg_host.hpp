@@ -79,4 +79,9 @@ void pack_scan_tables(const HuffSet &h, uint32_t out[kScanTableWords]);
 void encode_file(const int16_t *y, const int16_t *cb, const int16_t *cr,
                  const pixo_jpeg_options &o, std::vector<uint8_t> &out);
 
+// Progressive file from a coefficient tuple and the tables to use: SOF2 headers, the seven scans of
+// simple_progressive_script (src/jpeg/progressive.rs:98-110) coded like jpeg/mod.rs:1248-1365, EOI.
+void encode_progressive_file(const int16_t *y, const int16_t *cb, const int16_t *cr, const pixo_jpeg_options &o,
+                             const HuffSet &h, std::vector<uint8_t> &out);
+
 } // namespace pixo_host

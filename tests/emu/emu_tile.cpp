@@ -223,3 +223,17 @@ extern "C" long emu_scan(const int16_t *y, const int16_t *cb, const int16_t *cr,
     }
     return o;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Device trellis quantiser (pixo_amd/csrc/jpeg_trellis.h) on the host: n blocks of 64 floats.
+// ---------------------------------------------------------------------------------------------
+#include "../../pixo_amd/csrc/jpeg_trellis.h"
+extern "C" void emu_trellis(const float *dct, const float *q, long nblocks, int16_t *out)
+{
+    for (long b = 0; b < nblocks; b++) {
+        uint32_t trail[63 * 8];
+        uint8_t counts[63];
+        pixo_trellis::quantize_block(dct + b * 64, q, out + b * 64, trail, counts);
+    }
+}

@@ -17,6 +17,7 @@
 #include "jpeg_entropy.hpp"
 #include "jpeg_host.hpp"
 #include "jpeg_kernels.hpp"
+#include "jpeg_trellis.hpp"
 #include "png_filter.hpp"
 
 namespace {
@@ -88,6 +89,7 @@ struct Context {
     };
     Buf e_tables, e_hist, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out, e_seg_bytes, e_seg_off;
     Buf p_in, p_out, p_sums, p_scratch; // PNG filter stage
+    Buf t_raw;                          // progressive + trellis: unquantised DCT blocks (f32)
     unsigned long long *h_sums = nullptr; size_t hsums_cap = 0; // pinned
     uint64_t *h_totals = nullptr; // pinned, 2 words
     uint8_t *h_file = nullptr; size_t hfile_cap = 0; // pinned: the finished file lands here
@@ -374,15 +376,65 @@ int device_entropy_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_
     return deliver(file, n, out_buf, out_len);
 }
 
-// `trellis_quant` only acts inside the progressive path of the reference (compute_all_coefficients,
-// src/jpeg/mod.rs:872-976; encode_scan never looks at it): a baseline encode with the flag set is an
-// ordinary baseline encode.  Progressive scans are not implemented here and are refused loudly.
-int unsupported_scan_mode(const pixo_jpeg_options &o)
+// Progressive files (jpeg/mod.rs:397-419, :872-927).  Device pixels -> file in `out`:
+//   tables   optimised ones come from the statistics of a BASELINE walk over the PLAIN quantiser's
+//            coefficients (build_optimized_huffman_tables, :684-824, never uses trellis): the ordinary
+//            coefficient kernel + the device histogram pass;
+//   tuple    `trellis_quant`: the coefficient kernel in raw mode (unquantised transform) followed by the
+//            trellis kernel; otherwise the ordinary kernel (`trellis_quant` acts nowhere else: a baseline
+//            encode with the flag set is an ordinary baseline encode, encode_scan never reads it);
+//   scans    the seven scans of simple_progressive_script are cheap, sequential re-walks of the tuple:
+//            host code (jpeg_host.cpp) on a pinned copy.
+int progressive_to_vector(const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, Context &c,
+                          std::vector<uint8_t> &out)
 {
-    if (o.progressive)
-        return fail(PIXO_ERR_COMPRESSION,
-                    "Compression error: progressive/trellis encoding is not implemented by the "
-                    "HIP backend (baseline sequential only); use the CPU encoder for preset 2");
+    namespace pd = pixo_dev;
+    int rc;
+    int16_t *dy, *dcb, *dcr;
+    const float *qt_all = nullptr;
+    if ((rc = device_tables(c.device, &qt_all))) return rc;
+    const float *qt = qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats;
+    pixo_host::HuffSet h = pixo_host::HuffSet::standard();
+    const bool need_plain = o.optimize_huffman || !o.trellis_quant;
+    if (need_plain && (rc = coeffs_on_device(d_pixels, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
+    if (o.optimize_huffman) {
+        pd::ScanArgs a;
+        a.y = dy; a.cb = dcb; a.cr = dcr; a.tables = nullptr;
+        a.mode = g.gray ? 0 : (g.s420 ? 2 : 1);
+        a.nblocks = g.y_blocks + 2 * g.c_blocks;
+        a.blocks_per_mcu = g.gray ? 1 : (g.s420 ? 6 : 3);
+        a.marker_bytes = 2;
+        a.restart = scan_has_restart_markers(o, g) ? o.restart_interval : 0;
+        HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
+        HIP_TRY(hipMemsetAsync(c.e_hist.p, 0, pixo_host::kScanTableWords * 8, c.stream));
+        HIP_TRY(pd::launch_scan_count(a, c.e_hist.as<unsigned long long>(), c.stream));
+        uint64_t counts[pixo_host::kScanTableWords];
+        HIP_TRY(hipMemcpyAsync(counts, c.e_hist.p, sizeof counts, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        uint64_t dc[2][12], ac[2][256];
+        for (int cls = 0; cls < 2; ++cls) {
+            std::memcpy(dc[cls], counts + cls * 268, sizeof dc[cls]);
+            std::memcpy(ac[cls], counts + cls * 268 + 12, sizeof ac[cls]);
+        }
+        h = pixo_host::HuffSet::optimized(dc, ac, !g.gray);
+    }
+    const size_t blocks = g.y_blocks + 2 * g.c_blocks, coef_bytes = blocks * 128;
+    if (o.trellis_quant) {
+        HIP_TRY(c.t_raw.reserve(blocks * 256));
+        if ((rc = c.reserve_coef(coef_bytes))) return rc;
+        float *ry = c.t_raw.as<float>(), *rcb = ry + g.y_blocks * 64, *rcr = rcb + g.c_blocks * 64;
+        dy = static_cast<int16_t *>(c.d_coef); dcb = dy + g.y_blocks * 64; dcr = dcb + g.c_blocks * 64;
+        HIP_TRY(pd::launch_jpeg_coeffs(d_pixels, o.width, o.height, g.gray, g.s420, 1, ry, g.gray ? nullptr : rcb,
+                                       g.gray ? nullptr : rcr, qt, c.stream, /*raw_f32=*/true));
+        HIP_TRY(pd::launch_trellis(ry, qt + 128, 1.0f, dy, g.y_blocks, c.stream));   // luminance steps
+        HIP_TRY(pd::launch_trellis(rcb, qt + 192, 1.0f, dcb, g.c_blocks, c.stream)); // chrominance steps
+        HIP_TRY(pd::launch_trellis(rcr, qt + 192, 1.0f, dcr, g.c_blocks, c.stream));
+    }
+    if ((rc = c.reserve_hcoef(coef_bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(c.h_coef, dy, coef_bytes, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    const int16_t *hy = static_cast<const int16_t *>(c.h_coef), *hcb = hy + g.y_blocks * 64, *hcr = hcb + g.c_blocks * 64;
+    pixo_host::encode_progressive_file(hy, hcb, hcr, o, h, out);
     return PIXO_OK;
 }
 
@@ -404,7 +456,6 @@ int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options
     std::string msg;
     int rc = pixo_host::validate(o, true, data_len, msg);
     if (rc) return fail(rc, msg);
-    if ((rc = unsupported_scan_mode(o))) return rc;
     const pixo_host::Geometry g = pixo_host::geometry(o.width, o.height, o.color_type, o.subsampling);
     if (std::getenv("PIXO_HIP_HOST_ENTROPY")) { // (experiments: the host twin of the entropy stage)
         const int16_t *y, *cb, *cr;
@@ -420,6 +471,12 @@ int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options
     const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
     if ((rc = c.reserve_px((px_bytes + 15) & ~size_t{15}))) return rc;
     HIP_TRY(hipMemcpyAsync(c.d_px, data, px_bytes, hipMemcpyHostToDevice, c.stream));
+    if (o.progressive) {
+        if ((rc = progressive_to_vector(c.d_px, o, g, c, spill))) return rc;
+        *file = spill.data();
+        *file_len = spill.size();
+        return PIXO_OK;
+    }
     int16_t *dy, *dcb, *dcr;
     if ((rc = coeffs_on_device(c.d_px, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
     return device_entropy_to_pinned(dy, dcb, dcr, o, g, c.stream, file, file_len);
@@ -547,7 +604,6 @@ int pixo_hip_jpeg_entropy_encode(const int16_t *y, const int16_t *cb, const int1
     std::string msg;
     int rc = pixo_host::validate(*options, false, 0, msg);
     if (rc) return fail(rc, msg);
-    if ((rc = unsupported_scan_mode(*options))) return rc;
     std::vector<uint8_t> v;
     pixo_host::encode_file(y, cb, cr, *options, v);
     return hand_over(v, out, out_len);
@@ -570,8 +626,9 @@ int context_on_current_device(Context **out)
 int device_tuple_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                            const pixo_host::Geometry &g, Context &c, uint8_t **out, size_t *out_len)
 {
-    if (!std::getenv("PIXO_HIP_HOST_ENTROPY")) return device_entropy_to_malloc(dy, dcb, dcr, o, g, c.stream, out, out_len);
-    // (experiments: host coder on a copy of the tuple)
+    if (!o.progressive && !std::getenv("PIXO_HIP_HOST_ENTROPY"))
+        return device_entropy_to_malloc(dy, dcb, dcr, o, g, c.stream, out, out_len);
+    // progressive scans (and, for experiments, the host twin of the baseline coder): host code on a copy
     const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128;
     int rc = c.reserve_hcoef(coef_bytes);
     if (rc) return rc;
@@ -594,7 +651,6 @@ int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const
     std::string msg;
     int rc = pixo_host::validate(*options, false, 0, msg);
     if (rc) return fail(rc, msg);
-    if ((rc = unsupported_scan_mode(*options))) return rc;
     Context *c = nullptr;
     if ((rc = context_on_current_device(&c))) return rc;
     const pixo_host::Geometry g = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
@@ -607,10 +663,14 @@ int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *o
     std::string msg;
     int rc = pixo_host::validate(*options, false, 0, msg);
     if (rc) return fail(rc, msg);
-    if ((rc = unsupported_scan_mode(*options))) return rc;
     Context *c = nullptr;
     if ((rc = context_on_current_device(&c))) return rc;
     const pixo_host::Geometry g = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
+    if (options->progressive) {
+        std::vector<uint8_t> v;
+        if ((rc = progressive_to_vector(d_pixels, *options, g, *c, v))) return rc;
+        return hand_over(v, out, out_len);
+    }
     int16_t *dy, *dcb, *dcr;
     if ((rc = coeffs_on_device(d_pixels, *options, g, c->stream, &dy, &dcb, &dcr))) return rc;
     return device_tuple_to_malloc(dy, dcb, dcr, *options, g, *c, out, out_len);
@@ -736,7 +796,6 @@ int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_opti
     std::string msg;
     int rc = pixo_host::validate(*options, false, 0, msg);
     if (rc) return fail(rc, msg);
-    if ((rc = unsupported_scan_mode(*options))) return rc;
     if (batch == 0 || batch > 65535) return fail(PIXO_ERR_COMPRESSION, "Compression error: batch must be 1..65535");
     Context *c = nullptr;
     if ((rc = context_on_current_device(&c))) return rc;
@@ -746,6 +805,11 @@ int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_opti
     for (uint32_t i = 0; i < batch; ++i) { files[i] = nullptr; lens[i] = 0; }
     auto release = [&](int code) { for (uint32_t i = 0; i < batch; ++i) { std::free(files[i]); files[i] = nullptr; } return code; };
     // Per-image tables or restart segments inside the images: one image at a time.
+    if (o.progressive) {
+        for (uint32_t i = 0; i < batch; ++i)
+            if ((rc = pixo_hip_jpeg_encode_device(static_cast<const uint8_t *>(d_pixels) + i * px_bytes, options, &files[i], &lens[i]))) return release(rc);
+        return PIXO_OK;
+    }
     if (batch == 1 || o.optimize_huffman || scan_has_restart_markers(o, g) || px_bytes % 4 != 0) {
         for (uint32_t i = 0; i < batch; ++i) {
             int16_t *dy, *dcb, *dcr;
@@ -822,7 +886,7 @@ int pixo_hip_set_device(int device)
         if (c.h_file) (void)hipHostFree(c.h_file);
         if (c.h_sums) (void)hipHostFree(c.h_sums);
         for (Context::Buf *b : {&c.e_tables, &c.e_hist, &c.e_len, &c.e_off, &c.e_tmp, &c.e_totals, &c.e_stream,
-                                &c.e_tile_ff, &c.e_tile_base, &c.e_out, &c.e_seg_bytes, &c.e_seg_off, &c.p_in, &c.p_out, &c.p_sums, &c.p_scratch})
+                                &c.e_tile_ff, &c.e_tile_base, &c.e_out, &c.e_seg_bytes, &c.e_seg_off, &c.p_in, &c.p_out, &c.p_sums, &c.p_scratch, &c.t_raw})
             if (b->p) (void)hipFree(b->p);
         if (c.stream) (void)hipStreamDestroy(c.stream);
         c = Context();

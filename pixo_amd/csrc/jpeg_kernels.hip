@@ -28,6 +28,7 @@ struct KArgs {
     size_t c_stride;
     unsigned long long *dbg; // PIXO_TIMING builds only: per-wavefront stamps (tools/wave_probe.py)
     uint32_t prio_a;         // raise wave priority during phase A (single-generation launches)
+    float *ry, *rcb, *rcr;   // RAW kernels only: unquantised DCT blocks (64 f32 each) instead of y/cb/cr
 };
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, which would
@@ -122,7 +123,42 @@ __device__ __forceinline__ void phase_a(const TileCtx &c, const TileId &id, int 
 // compiler keeps every variant at 80 VGPRs without spilling when told to.
 #define PIXO_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
 #endif
-template <int MODE, bool FAST>
+// RAW kernels: the lane's transformed block as 64 floats (natural order, the reference's dct_2d
+// output: 4:2:0 chroma scaled back by the exact factor 1/4) for the trellis quantiser.
+template <int MODE>
+__device__ __forceinline__ void store_raw_block(const KArgs &a, const TileCtx &c, const TileId &id, int wave, int lane, const float *v)
+{
+    typedef Geo<MODE> G;
+    const uint32_t u0 = id.tx * G::units_x;
+    const uint32_t nvalid = c.units_x - u0 < (uint32_t)G::units_x ? c.units_x - u0 : G::units_x;
+    float *dst = nullptr;
+    float scale = 1.0f;
+    if (MODE == M420) {
+        const size_t mcu0 = (size_t)id.ty * c.units_x + u0;
+        if (wave < 2) {
+            if ((uint32_t)(wave * 16 + (lane >> 2)) < nvalid) dst = a.ry + (size_t)id.img * a.y_stride + (mcu0 * 4 + wave * 64 + lane) * 64;
+        } else {
+            const int m = lane & 31;
+            if ((uint32_t)m < nvalid) dst = (lane < 32 ? a.rcb : a.rcr) + (size_t)id.img * a.c_stride + (mcu0 + m) * 64;
+            scale = 0.25f;
+        }
+    } else if (MODE == M444) {
+        const size_t blk = (size_t)id.ty * c.units_x + u0 + lane;
+        if ((uint32_t)lane < nvalid) {
+            if (wave == 0) dst = a.ry + (size_t)id.img * a.y_stride + blk * 64;
+            else dst = (wave == 1 ? a.rcb : a.rcr) + (size_t)id.img * a.c_stride + blk * 64;
+        }
+    } else {
+        const uint32_t brow = id.ty * 3 + wave;
+        if ((uint32_t)lane < nvalid && brow < c.units_y) dst = a.ry + (size_t)id.img * a.y_stride + ((size_t)brow * c.units_x + u0 + lane) * 64;
+    }
+    if (!dst) return;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        reinterpret_cast<float4 *>(dst)[i] = make_float4(v[4 * i] * scale, v[4 * i + 1] * scale, v[4 * i + 2] * scale, v[4 * i + 3] * scale);
+}
+
+template <int MODE, bool FAST, bool RAW = false>
 __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(const KArgs a)
 {
     typedef Geo<MODE> G;
@@ -164,6 +200,10 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
 #else
     for (int i = 0; i < 64; i++) v[i] = (float)(lane + i);
 #endif
+    if (RAW) { // hand the transformed blocks to the trellis quantiser instead of quantising here
+        store_raw_block<MODE>(a, c, id, wave, lane, v);
+        return;
+    }
     uint8_t *stage = lds + stage_offset<MODE>(wave); // inside this wavefront's own planar area
     consumer_quant_half<MODE>(wave, lane, a.qt, v, 0, stage);
 #if !defined(PIXO_ABLATE) || (PIXO_ABLATE != 4 && PIXO_ABLATE != 6 && PIXO_ABLATE != 7) // (4, 6, 7: no stores — one guarded store keeps the work alive)
@@ -188,6 +228,7 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
 
 template <int MODE, bool FAST> static hipError_t launch_mode(KArgs &a, hipStream_t s)
 {
+    const bool raw = a.ry != nullptr;
     a.tiles_x = (a.units_x + Geo<MODE>::units_x - 1) / Geo<MODE>::units_x;
     a.tiles_y = (a.units_y * (MODE == M420 ? 16u : 8u) + Geo<MODE>::tile_h - 1) / Geo<MODE>::tile_h;
     const uint64_t total64 = (uint64_t)a.tiles_x * a.tiles_y * a.batch;
@@ -198,15 +239,20 @@ template <int MODE, bool FAST> static hipError_t launch_mode(KArgs &a, hipStream
     a.prio_a = prio_env ? (uint32_t)atoi(prio_env) : (total <= 8u * (uint32_t)cus ? 1u : 0u);
     // PIXO_HIP_LDS_PAD (bytes of unused dynamic LDS) lowers the residency for experiments
     static const unsigned pad = getenv("PIXO_HIP_LDS_PAD") ? (unsigned)atoi(getenv("PIXO_HIP_LDS_PAD")) : 0u;
-    hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, FAST>), dim3(total), dim3(kThreads), pad, s, a);
+    if (raw) hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, FAST, true>), dim3(total), dim3(kThreads), pad, s, a);
+    else hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, FAST, false>), dim3(total), dim3(kThreads), pad, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gray, bool s420,
                               uint32_t batch, void *d_y, void *d_cb, void *d_cr,
-                              const float *d_qt, hipStream_t stream)
+                              const float *d_qt, hipStream_t stream, bool raw_f32)
 {
     KArgs a;
+    a.ry = a.rcb = a.rcr = nullptr;
+    if (raw_f32) { // the same three planes, as 64 f32 per block
+        a.ry = static_cast<float *>(d_y); a.rcb = static_cast<float *>(d_cb); a.rcr = static_cast<float *>(d_cr);
+    }
     a.px = static_cast<const uint8_t *>(d_px);
     a.y = static_cast<int16_t *>(d_y);
     a.cb = static_cast<int16_t *>(d_cb);

@@ -91,16 +91,30 @@ def test_validation_order_and_variants():
     assert out == b"keep"
 
 
-def test_progressive_is_refused_and_trellis_alone_is_the_baseline_encode():
-    y = np.zeros((1, 64), np.int16)
-    o = jpeg.JpegOptions.builder(8, 8).color_type(ColorType.Gray).progressive(True).build()
-    with pytest.raises(error.CompressionError, match="progressive/trellis"):
-        jpeg.entropy_encode(y, y, y, o)
+def test_trellis_alone_is_the_baseline_encode():
     # the reference only reads trellis_quant inside its progressive path (jpeg/mod.rs:872-976):
     # with progressive off the flag changes nothing
+    y = np.zeros((1, 64), np.int16)
     t = jpeg.JpegOptions.builder(8, 8).color_type(ColorType.Gray).trellis_quant(True).build()
     plain = jpeg.JpegOptions.builder(8, 8).color_type(ColorType.Gray).build()
     assert jpeg.entropy_encode(y, y, y, t) == jpeg.entropy_encode(y, y, y, plain)
+
+
+@pytest.mark.parametrize("shape", [(72, 40, 2, 1), (50, 33, 2, 0), (31, 17, 0, 0), (300, 200, 2, 1)])
+def test_host_progressive_coder_matches_oracle(shape):
+    """The product's progressive scan coder (jpeg_host.cpp: SOF2, seven scans, end-of-band runs, the
+    (0, 4) fallback for symbols the table lacks) against the oracle's restatement on the same tuple."""
+    w, h, ct, ss = shape
+    for gen, q in ((synth.noise, 80), (synth.gradient_rgb, 90), (synth.flat_blocks, 50)):
+        px = gen(w, h) if gen is not synth.noise else synth.noise(w, h, 3)
+        if ct == 0:
+            px = px.reshape(-1, 3)[:, 0].copy()
+        y, cb, cr = O.coeffs(px, w, h, ct, ss, q)
+        o = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss)).progressive(True).build()
+        got = jpeg.entropy_encode(y, cb, cr, o)
+        want = O.encode_from_coeffs(y, cb, cr, O.make_options(w, h, ct, q, ss, progressive=True))
+        assert got == want
+        assert got[:2] == b"\xff\xd8" and b"\xff\xc2" in got[:700] and got.count(b"\xff\xda") >= 7
 
 
 def test_no_gpu_means_loud_failure_not_a_cpu_fallback():

@@ -55,8 +55,8 @@ typedef struct pixo_jpeg_options {
     uint8_t has_restart_interval;  /* Option<u16> discriminant                     */
     uint16_t restart_interval;     /* MCUs; Some(0) is InvalidRestartInterval      */
     uint8_t optimize_huffman;
-    uint8_t progressive;           /* not on the accelerated path: see DESIGN.md   */
-    uint8_t trellis_quant;         /* read only by the progressive path, as upstream */
+    uint8_t progressive;           /* SOF2 + simple_progressive_script (7 scans)   */
+    uint8_t trellis_quant;         /* acts only with progressive, as upstream      */
 } pixo_jpeg_options;
 
 /* JpegOptions::{fast,balanced,max,from_preset} (src/jpeg/mod.rs:162-216). */

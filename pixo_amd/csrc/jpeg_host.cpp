@@ -5,6 +5,7 @@
 #include <cstring>
 #include <functional>
 #include <queue>
+#include <thread>
 #include <utility>
 
 namespace pixo_host {
@@ -496,16 +497,22 @@ void progressive_scans(std::vector<uint8_t> &out, const int16_t *y, const int16_
                        const Geometry &g, const HuffSet &h)
 {
     static const struct { int comp, ss, se; } script[7] = {{0, 0, 0}, {1, 0, 0}, {2, 0, 0}, {0, 1, 10}, {0, 11, 63}, {1, 1, 63}, {2, 1, 63}};
-    for (const auto &sc : script) {
-        be16(out, 0xFFDA); be16(out, 8); out.push_back(1); // write_sos_progressive, jpeg/mod.rs:650-682
-        out.push_back(static_cast<uint8_t>(sc.comp + 1));
-        out.push_back(sc.comp == 0 ? 0x00 : 0x11);
-        out.push_back(static_cast<uint8_t>(sc.ss)); out.push_back(static_cast<uint8_t>(sc.se)); out.push_back(0);
+    // The scans share nothing (each has its own predictor, run counter and bit stream): one thread per
+    // scan, results concatenated in script order.
+    std::vector<uint8_t> part[7];
+    auto run_scan = [&](int i) {
+        const auto &sc = script[i];
+        std::vector<uint8_t> &o = part[i];
+        be16(o, 0xFFDA); be16(o, 8); o.push_back(1); // write_sos_progressive, jpeg/mod.rs:650-682
+        o.push_back(static_cast<uint8_t>(sc.comp + 1));
+        o.push_back(sc.comp == 0 ? 0x00 : 0x11);
+        o.push_back(static_cast<uint8_t>(sc.ss)); o.push_back(static_cast<uint8_t>(sc.se)); o.push_back(0);
         const int16_t *coef = sc.comp == 0 ? y : (sc.comp == 1 ? cb : cr);
         const size_t n = sc.comp == 0 ? g.y_blocks : g.c_blocks;
         const int cls = sc.comp == 0 ? 0 : 1;
-        if (n == 0) continue;
-        BitSink sink(out);
+        if (n == 0) return;
+        o.reserve(n * (sc.se == 0 ? 2 : 24) + 64);
+        BitSink sink(o);
         if (sc.se == 0) { // DC scan: differences in storage order, predictor starts at 0 per scan
             int16_t prev = 0;
             for (size_t b = 0; b < n; ++b) {
@@ -523,7 +530,15 @@ void progressive_scans(std::vector<uint8_t> &out, const int16_t *y, const int16_
             flush_band_run(sink, run, h.ac[cls]);
         }
         sink.align_with_ones();
+    };
+    if (g.y_blocks + 2 * g.c_blocks >= 4096) {
+        std::thread workers[7];
+        for (int i = 0; i < 7; ++i) workers[i] = std::thread(run_scan, i);
+        for (auto &t : workers) t.join();
+    } else {
+        for (int i = 0; i < 7; ++i) run_scan(i);
     }
+    for (const auto &p : part) out.insert(out.end(), p.begin(), p.end());
 }
 } // namespace
 

@@ -100,7 +100,7 @@ def test_trellis_alone_is_the_baseline_encode():
     assert jpeg.entropy_encode(y, y, y, t) == jpeg.entropy_encode(y, y, y, plain)
 
 
-@pytest.mark.parametrize("shape", [(72, 40, 2, 1), (50, 33, 2, 0), (31, 17, 0, 0), (300, 200, 2, 1)])
+@pytest.mark.parametrize("shape", [(72, 40, 2, 1), (50, 33, 2, 0), (31, 17, 0, 0), (300, 200, 2, 1), (640, 480, 2, 1)])
 def test_host_progressive_coder_matches_oracle(shape):
     """The product's progressive scan coder (jpeg_host.cpp: SOF2, seven scans, end-of-band runs, the
     (0, 4) fallback for symbols the table lacks) against the oracle's restatement on the same tuple."""

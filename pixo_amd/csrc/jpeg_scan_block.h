@@ -78,6 +78,7 @@ struct LengthVisitor {
     PIXO_SMEM void ac(int rs, int cat, int) { bits += (tab[kDcSyms + rs] >> 16) + cat; }
     PIXO_SMEM void zrl() { bits += tab[kDcSyms + 0xF0] >> 16; }
     PIXO_SMEM void eob() { bits += tab[kDcSyms] >> 16; }
+    PIXO_SMEM void band_run(int symbol, int nbits, uint32_t) { bits += (tab[kDcSyms + symbol] >> 16) + nbits; }
 };
 
 // ---- visitor 2: pack the block's bits at absolute bit offset `pos` of a zeroed stream ------
@@ -134,6 +135,12 @@ struct PackVisitor {
     }
     PIXO_SMEM void zrl() { const uint32_t t = tab[kDcSyms + 0xF0]; put(t & 0xFFFF, (int)(t >> 16)); }
     PIXO_SMEM void eob() { const uint32_t t = tab[kDcSyms]; put(t & 0xFFFF, (int)(t >> 16)); }
+    PIXO_SMEM void band_run(int symbol, int nbits, uint32_t extra)
+    {
+        const uint32_t t = tab[kDcSyms + symbol];
+        put(t & 0xFFFF, (int)(t >> 16));
+        if (nbits) put(extra, nbits);
+    }
 };
 
 // ---- visitor 3: symbol statistics for optimised tables ---------------------------------------
@@ -152,6 +159,104 @@ struct CountVisitor {
     PIXO_SMEM void zrl() { bump(kDcSyms + 0xF0); }
     PIXO_SMEM void eob() { bump(kDcSyms); }
 };
+
+// ---- progressive scans (simple_progressive_script, progressive.rs:98-110) ------------------------
+// Seven single-component scans over the tuple, blocks in STORAGE order (jpeg/mod.rs:1286, :1350):
+//   0 DC Y   1 DC Cb   2 DC Cr   3 AC Y 1..10   4 AC Y 11..63   5 AC Cb 1..63   6 AC Cr 1..63
+// One lane owns one (scan, block) pair — a "virtual block"; first[i] is the virtual index where scan
+// i starts (first[7] = their total).  Tables are packed like the baseline ones, except that a symbol
+// the table lacks holds the reference's fallback code (0, 4 bits), progressive.rs:363-381.
+struct ProgLayout { uint64_t first[8]; };
+PIXO_SDEV int prog_scan_of(const ProgLayout &l, uint64_t v)
+{
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < 7; k++) i += v >= l.first[k] ? 1 : 0;
+    return i;
+}
+PIXO_SDEV int prog_comp(int scan) { return scan < 3 ? scan : (scan <= 4 ? 0 : scan - 4); }
+PIXO_SDEV int prog_band(int scan) { return scan == 3 ? 0 : (scan == 4 ? 1 : 2); } // 0: 1..10, 1: 11..63, 2: 1..63
+
+// What an AC scan needs to know about a block before any bit is placed: bit 0 = the band holds a
+// non-zero coefficient, bit 1 = its last non-zero lies before the band's end (an end-of-band follows).
+template <int SS, int SE> PIXO_SDEV uint32_t band_flags(const uint32_t *w)
+{
+    int last = -1;
+#pragma unroll
+    for (int k = SS; k <= SE; k++)
+        if (coef_of(w, zigzag(k)) != 0) last = k;
+    return last < 0 ? 0u : (1u | (last < SE ? 2u : 0u));
+}
+
+// One block of a first AC scan over zig-zag [SS, SE] (progressive.rs:141-210 with al = 0), band not
+// empty.  V provides ac(rs, cat, v), zrl().  Returns nothing: the caller knows `last < SE` from band_flags.
+template <int SS, int SE, class V> PIXO_SDEV void walk_band(const uint32_t *w, V &vis)
+{
+    int last = SS;
+#pragma unroll
+    for (int k = SS; k <= SE; k++)
+        if (coef_of(w, zigzag(k)) != 0) last = k;
+    int run = 0;
+#pragma unroll
+    for (int k = SS; k <= SE; k++) {
+        const int v = coef_of(w, zigzag(k));
+        if (k <= last) {
+            if (v == 0) {
+                run++;
+            } else {
+                while (run >= 16) { vis.zrl(); run -= 16; }
+                const int cat = magnitude_bits(v);
+                vis.ac((run << 4) | cat, cat, v);
+                run = 0;
+            }
+        }
+    }
+}
+
+// The end-of-band run counter (progressive.rs:156-162, :313-345) seen from one block: `before` =
+// the counter when the block is reached = (1 if the previous non-empty block of the scan ended
+// before the band's end) + the empty blocks since then, reduced by the flushes at 32767.
+constexpr uint32_t kMaxBandRun = 0x7FFF;
+template <class V> PIXO_SDEV void emit_band_run(uint32_t run, V &vis)
+{ // symbol = floor(log2 run) << 4, then that many low bits of the run
+    const int nbits = 31 - __builtin_clz(run);
+    vis.band_run(nbits << 4, nbits, run - (1u << nbits));
+}
+
+// The run counter on entry to virtual block v of an AC scan.  rank = exclusive prefix count of
+// non-empty bands over the virtual order, by_rank[r] = the r-th non-empty virtual block.
+PIXO_SDEV uint32_t band_run_before(uint64_t v, uint64_t scan_first, uint64_t rank_v, uint64_t rank_first,
+                                   const uint32_t *by_rank, const uint32_t *flags)
+{
+    const uint64_t r = rank_v - rank_first; // non-empty blocks of this scan in front of v
+    if (r == 0) return (uint32_t)((v - scan_first) % kMaxBandRun);
+    const uint64_t prev = by_rank[rank_first + r - 1];
+    return (uint32_t)((((flags[prev] >> 1) & 1u) + (v - prev - 1)) % kMaxBandRun);
+}
+
+// Everything one virtual block contributes to its scan's bit stream.
+template <class V>
+PIXO_SDEV void prog_emit(int scan, const uint32_t *w, int prev_dc, uint32_t flags, uint32_t before, bool last_of_scan, V &vis)
+{
+    if (scan < 3) { // encode_dc_scan, jpeg/mod.rs:1248-1310 (al = 0)
+        const int diff = (int)(int16_t)(coef_of(w, 0) - prev_dc);
+        vis.dc(magnitude_bits(diff), diff);
+        return;
+    }
+    uint32_t counter;
+    if (flags & 1u) {
+        if (before) emit_band_run(before, vis); // flush the pending run first (progressive.rs:171-174)
+        const int band = prog_band(scan);
+        if (band == 0) walk_band<1, 10>(w, vis);
+        else if (band == 1) walk_band<11, 63>(w, vis);
+        else walk_band<1, 63>(w, vis);
+        counter = (flags & 2u) ? 1u : 0u; // "if we ended before se, start an EOB run" (:206-209)
+    } else {
+        counter = before + 1;
+        if (counter == kMaxBandRun) { emit_band_run(counter, vis); counter = 0; } // (:160-163)
+    }
+    if (last_of_scan && counter) emit_band_run(counter, vis); // jpeg/mod.rs:1361-1364
+}
 
 // Scan-order position -> (component, block index inside that component's array).
 // mode 0 gray: Y;  1 4:4:4: Y Cb Cr per block;  2 4:2:0: Y0 Y1 Y2 Y3 Cb Cr per MCU

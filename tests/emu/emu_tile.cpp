@@ -237,3 +237,74 @@ extern "C" void emu_trellis(const float *dct, const float *q, long nblocks, int1
         pixo_trellis::quantize_block(dct + b * 64, q, out + b * 64, trail, counts);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Device progressive scan coder (jpeg_scan_block.h: band_flags, band_run_before, prog_emit) lane by
+// lane: flags, rank / by_rank, lengths, prefix sum, pack (blocks in reverse order), pad, stuffing.
+// out receives the seven entropy-coded segments back to back; seg_len[i] their byte counts.
+// ---------------------------------------------------------------------------------------------
+extern "C" long emu_progressive(const int16_t *y, const int16_t *cb, const int16_t *cr, uint64_t yb, uint64_t cbn,
+                                const uint32_t *tables, uint8_t *out, long cap, long *seg_len)
+{
+    using namespace pixo_scan;
+    ProgLayout lay;
+    const uint64_t sizes[7] = {yb, cbn, cbn, yb, yb, cbn, cbn};
+    lay.first[0] = 0;
+    for (int i = 0; i < 7; i++) lay.first[i + 1] = lay.first[i] + sizes[i];
+    const uint64_t V = lay.first[7];
+    std::vector<uint32_t> flags(V, 0), by_rank(V + 1, 0), len(V);
+    std::vector<uint64_t> rank(V + 1, 0), off(V + 1, 0);
+    auto load = [&](uint64_t v, int *scan, uint32_t *wds, int *prev) {
+        *scan = prog_scan_of(lay, v);
+        const int comp = prog_comp(*scan);
+        const int16_t *base = comp == 0 ? y : (comp == 1 ? cb : cr);
+        const uint64_t b = v - lay.first[*scan];
+        memcpy(wds, base + b * 64, 128);
+        *prev = b ? base[(b - 1) * 64] : 0;
+    };
+    for (uint64_t v = 0; v < V; v++) {
+        int scan, prev; uint32_t wds[32];
+        load(v, &scan, wds, &prev);
+        if (scan >= 3) flags[v] = prog_band(scan) == 0 ? band_flags<1, 10>(wds) : (prog_band(scan) == 1 ? band_flags<11, 63>(wds) : band_flags<1, 63>(wds));
+    }
+    for (uint64_t v = 0; v < V; v++) { rank[v + 1] = rank[v] + (flags[v] & 1u); if (flags[v] & 1u) by_rank[rank[v]] = (uint32_t)v; }
+    auto emit = [&](uint64_t v, auto &vis) {
+        int scan, prev; uint32_t wds[32];
+        load(v, &scan, wds, &prev);
+        vis.tab = tables + (prog_comp(scan) ? 1 : 0) * kClassSyms;
+        const uint32_t before = scan >= 3 ? band_run_before(v, lay.first[scan], rank[v], rank[lay.first[scan]], by_rank.data(), flags.data()) : 0;
+        prog_emit(scan, wds, prev, flags[v], before, v + 1 == lay.first[scan + 1], vis);
+        return scan;
+    };
+    for (uint64_t v = 0; v < V; v++) { LengthVisitor lv{nullptr, 0}; emit(v, lv); len[v] = lv.bits; off[v + 1] = off[v] + lv.bits; }
+    long o = 0;
+    for (int i = 0; i < 7; i++) {
+        const uint64_t bits = off[lay.first[i + 1]] - off[lay.first[i]];
+        std::vector<uint32_t> stream(bits / 32 + 2, 0);
+        for (uint64_t v = lay.first[i + 1]; v-- > lay.first[i];) {
+            PackVisitor pv;
+            pv.begin(stream.data(), off[v] - off[lay.first[i]]);
+            emit(v, pv);
+            pv.finish();
+        }
+        const int n = (int)((8 - (bits & 7)) & 7);
+        if (n) stream[bits >> 5] |= ((1u << n) - 1u) << (32 - (int)(bits & 31) - n);
+        const uint64_t nbytes = (bits + 7) / 8;
+        const long start = o;
+        for (uint64_t b = 0; b < nbytes; b++) {
+            const uint8_t byte = (uint8_t)(stream[b >> 2] >> (24 - 8 * (b & 3)));
+            if (o + 2 > cap) return -1;
+            out[o++] = byte;
+            if (byte == 0xFF) out[o++] = 0x00;
+        }
+        seg_len[i] = o - start;
+    }
+    return o;
+}
+
+// tables for the progressive coder: like pack_scan_tables, absent symbols = the (0, 4 bits) fallback
+extern "C" void emu_progressive_tables(uint32_t *out /* 536 words */)
+{
+    pixo_host::pack_scan_tables(pixo_host::HuffSet::standard(), out);
+    for (int i = 0; i < pixo_scan::kTableWords; i++) if ((out[i] >> 16) == 0) out[i] = 4u << 16;
+}

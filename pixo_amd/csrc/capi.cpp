@@ -90,6 +90,7 @@ struct Context {
     Buf e_tables, e_hist, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out, e_seg_bytes, e_seg_off;
     Buf p_in, p_out, p_sums, p_scratch; // PNG filter stage
     Buf t_raw;                          // progressive + trellis: unquantised DCT blocks (f32)
+    Buf g_flags, g_rank, g_by_rank;     // progressive scans: band flags, rank among non-empty blocks and its inverse
     unsigned long long *h_sums = nullptr; size_t hsums_cap = 0; // pinned
     uint64_t *h_totals = nullptr; // pinned, 2 words
     uint8_t *h_file = nullptr; size_t hfile_cap = 0; // pinned: the finished file lands here
@@ -331,7 +332,7 @@ int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_
                                                  c.e_out.as<uint8_t>(), stream));
     if (batch > 1) { // where every image's segment begins in the stuffed stream (reuses the seg_bytes buffer: 8 B/entry)
         HIP_TRY(c.e_seg_bytes.reserve(nseg * 8));
-        HIP_TRY(pd::launch_segment_out_offsets(plan, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
+        HIP_TRY(pd::launch_segment_out_offsets(plan, nbytes, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
                                                c.e_seg_bytes.as<uint64_t>(), stream));
         image_starts->assign(batch + 1, 0);
         HIP_TRY(hipMemcpyAsync(image_starts->data(), c.e_seg_bytes.p, nseg * 8, hipMemcpyDeviceToHost, stream));
@@ -376,6 +377,133 @@ int device_entropy_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_
     return deliver(file, n, out_buf, out_len);
 }
 
+// The seven scans of simple_progressive_script (progressive.rs:98-110) coded by the kernels of
+// jpeg_entropy.hip over the device tuple; `out` already holds the file headers.  All scans are ONE
+// packed stream of byte-aligned segments (the virtual block order is scan by scan, storage order inside
+// a scan), so lengths / prefix sum / pack / 0xFF stuffing run once; the host only splices the seven SOS
+// headers between the stuffed segments.
+int device_progressive_scans(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_host::Geometry &g,
+                             const pixo_host::HuffSet &h, Context &c, std::vector<uint8_t> &out)
+{
+    namespace pd = pixo_dev;
+    Stopwatch sw;
+    hipStream_t stream = c.stream;
+    pd::ProgArgs a;
+    a.y = dy; a.cb = g.gray ? dy : dcb; a.cr = g.gray ? dy : dcr;
+    const uint64_t size[7] = {g.y_blocks, g.c_blocks, g.c_blocks, g.y_blocks, g.y_blocks, g.c_blocks, g.c_blocks};
+    a.first[0] = 0;
+    for (int i = 0; i < 7; ++i) a.first[i + 1] = a.first[i] + size[i];
+    const uint64_t n = a.first[7];
+    HIP_TRY(c.e_tables.reserve(pixo_host::kScanTableWords * 4));
+    HIP_TRY(c.g_flags.reserve(n * 4));
+    HIP_TRY(c.g_rank.reserve(n * 8));
+    HIP_TRY(c.g_by_rank.reserve(n * 4));
+    HIP_TRY(c.e_len.reserve(n * 4));
+    HIP_TRY(c.e_off.reserve(n * 8));
+    HIP_TRY(c.e_seg_bytes.reserve(8 * 8));
+    HIP_TRY(c.e_seg_off.reserve(8 * 8));
+    // a block of an AC scan: at most 63 * 26 bits + an end-of-band run of at most 16 + 14 bits
+    const size_t tmp_blocks = pd::scan_tile_count(n) + 1, tmp_segs = pd::scan_tile_count(7) + 1;
+    const size_t tmp_tiles = pd::scan_tile_count(pd::stuff_tile_count(n * 212 + 64)) + 1;
+    HIP_TRY(c.e_tmp.reserve((tmp_blocks + tmp_segs + tmp_tiles) * 8));
+    HIP_TRY(c.e_totals.reserve(32));
+    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 16, hipHostMallocDefault));
+    a.tables = c.e_tables.as<uint32_t>();
+    a.flags = c.g_flags.as<uint32_t>();
+    a.nonempty = c.e_len.as<uint32_t>(); // only the input of the rank prefix sum: the lengths reuse it
+    a.rank = c.g_rank.as<uint64_t>();
+    a.by_rank = c.g_by_rank.as<uint32_t>();
+
+    uint32_t packed[pixo_host::kScanTableWords];
+    pixo_host::pack_scan_tables(h, packed);
+    for (uint32_t &w : packed) // progressive.rs:363-381: a symbol the table lacks is coded as (0, 4 bits)
+        if ((w >> 16) == 0) w = 4u << 16;
+    HIP_TRY(hipMemcpyAsync(c.e_tables.p, packed, sizeof packed, hipMemcpyHostToDevice, stream));
+    uint64_t *totals = c.e_totals.as<uint64_t>();
+    HIP_TRY(pd::launch_prog_flags(a, stream));
+    HIP_TRY(pd::launch_exclusive_scan(a.nonempty, n, c.g_rank.as<uint64_t>(), c.e_tmp.as<uint64_t>(), totals + 2, stream));
+    HIP_TRY(pd::launch_prog_by_rank(a, stream));
+    HIP_TRY(pd::launch_prog_lengths(a, c.e_len.as<uint32_t>(), stream));
+    HIP_TRY(pd::launch_exclusive_scan(c.e_len.as<uint32_t>(), n, c.e_off.as<uint64_t>(), c.e_tmp.as<uint64_t>(), totals, stream));
+    HIP_TRY(pd::launch_prog_segment_sizes(a, c.e_off.as<uint64_t>(), totals, c.e_seg_bytes.as<uint32_t>(), stream));
+    HIP_TRY(pd::launch_exclusive_scan(c.e_seg_bytes.as<uint32_t>(), 7, c.e_seg_off.as<uint64_t>(), c.e_tmp.as<uint64_t>() + tmp_blocks,
+                                      totals + 1, stream));
+    HIP_TRY(hipMemcpyAsync(c.h_totals, totals, 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    sw.lap("prog flags+rank+lengths");
+    const uint64_t total_bits = c.h_totals[0], nbytes = c.h_totals[1];
+    const size_t stream_bytes = (nbytes / 4 + 2) * 4;
+    HIP_TRY(c.e_stream.reserve(stream_bytes));
+    HIP_TRY(hipMemsetAsync(c.e_stream.p, 0, stream_bytes, stream));
+    HIP_TRY(pd::launch_prog_pack(a, c.e_off.as<uint64_t>(), total_bits, c.e_seg_off.as<uint64_t>(), c.e_stream.as<uint32_t>(), stream));
+    const size_t tiles = pd::stuff_tile_count(nbytes);
+    HIP_TRY(c.e_tile_ff.reserve(tiles * 4));
+    HIP_TRY(c.e_tile_base.reserve(tiles * 8));
+    HIP_TRY(pd::launch_ff_tile_count(c.e_stream.as<uint32_t>(), nbytes, c.e_tile_ff.as<uint32_t>(), stream));
+    HIP_TRY(pd::launch_exclusive_scan(c.e_tile_ff.as<uint32_t>(), tiles, c.e_tile_base.as<uint64_t>(),
+                                      c.e_tmp.as<uint64_t>() + tmp_blocks + tmp_segs, totals + 1, stream));
+    HIP_TRY(hipMemcpyAsync(c.h_totals + 1, totals + 1, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    sw.lap("prog pack+ff census");
+    const uint64_t scan_bytes = nbytes + c.h_totals[1];
+    HIP_TRY(c.e_out.reserve(scan_bytes + 16));
+    HIP_TRY(pd::launch_stuff(c.e_stream.as<uint32_t>(), nbytes, c.e_tile_base.as<uint64_t>(), c.e_out.as<uint8_t>(), stream));
+    const pd::SegmentPlan plan{7, c.e_seg_off.as<uint64_t>()};
+    HIP_TRY(pd::launch_segment_out_offsets(plan, nbytes, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
+                                           c.g_rank.as<uint64_t>(), stream)); // the rank array is free again
+    uint64_t start[8];
+    HIP_TRY(hipMemcpyAsync(start, c.g_rank.p, 7 * 8, hipMemcpyDeviceToHost, stream));
+    int rc = c.reserve_hfile(scan_bytes + 16);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c.h_file, c.e_out.p, scan_bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    start[7] = scan_bytes;
+    for (int i = 6; i >= 0; --i)
+        if (start[i] == ~0ull) start[i] = start[i + 1]; // empty scans at the end of the stream
+    static const uint8_t script[7][3] = {{0, 0, 0}, {1, 0, 0}, {2, 0, 0}, {0, 1, 10}, {0, 11, 63}, {1, 1, 63}, {2, 1, 63}};
+    out.reserve(out.size() + scan_bytes + 7 * 10 + 2);
+    for (int i = 0; i < 7; ++i) { // write_sos_progressive, jpeg/mod.rs:650-682
+        const uint8_t sos[10] = {0xFF, 0xDA, 0, 8, 1, static_cast<uint8_t>(script[i][0] + 1),
+                                 static_cast<uint8_t>(script[i][0] == 0 ? 0x00 : 0x11), script[i][1], script[i][2], 0};
+        out.insert(out.end(), sos, sos + 10);
+        out.insert(out.end(), c.h_file + start[i], c.h_file + start[i + 1]);
+    }
+    out.push_back(0xFF); out.push_back(0xD9);
+    sw.lap("prog stuff+copy+splice");
+    return PIXO_OK;
+}
+
+// Huffman tables of a file over the device tuple: the standard ones, or (optimize_huffman) those built
+// from the statistics of a baseline walk (build_optimized_huffman_tables, jpeg/mod.rs:684-824) — counted
+// on the device, constructed on the host.
+int huffman_for_tuple(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+                      const pixo_host::Geometry &g, Context &c, pixo_host::HuffSet &h)
+{
+    namespace pd = pixo_dev;
+    h = pixo_host::HuffSet::standard();
+    if (!o.optimize_huffman) return PIXO_OK;
+    pd::ScanArgs a;
+    a.y = dy; a.cb = dcb; a.cr = dcr; a.tables = nullptr;
+    a.mode = g.gray ? 0 : (g.s420 ? 2 : 1);
+    a.nblocks = g.y_blocks + 2 * g.c_blocks;
+    a.blocks_per_mcu = g.gray ? 1 : (g.s420 ? 6 : 3);
+    a.marker_bytes = 2;
+    a.restart = scan_has_restart_markers(o, g) ? o.restart_interval : 0;
+    HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
+    HIP_TRY(hipMemsetAsync(c.e_hist.p, 0, pixo_host::kScanTableWords * 8, c.stream));
+    HIP_TRY(pd::launch_scan_count(a, c.e_hist.as<unsigned long long>(), c.stream));
+    uint64_t counts[pixo_host::kScanTableWords];
+    HIP_TRY(hipMemcpyAsync(counts, c.e_hist.p, sizeof counts, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    uint64_t dc[2][12], ac[2][256];
+    for (int cls = 0; cls < 2; ++cls) {
+        std::memcpy(dc[cls], counts + cls * 268, sizeof dc[cls]);
+        std::memcpy(ac[cls], counts + cls * 268 + 12, sizeof ac[cls]);
+    }
+    h = pixo_host::HuffSet::optimized(dc, ac, !g.gray);
+    return PIXO_OK;
+}
+
 // Progressive files (jpeg/mod.rs:397-419, :872-927).  Device pixels -> file in `out`:
 //   tables   optimised ones come from the statistics of a BASELINE walk over the PLAIN quantiser's
 //            coefficients (build_optimized_huffman_tables, :684-824, never uses trellis): the ordinary
@@ -383,41 +511,21 @@ int device_entropy_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_
 //   tuple    `trellis_quant`: the coefficient kernel in raw mode (unquantised transform) followed by the
 //            trellis kernel; otherwise the ordinary kernel (`trellis_quant` acts nowhere else: a baseline
 //            encode with the flag set is an ordinary baseline encode, encode_scan never reads it);
-//   scans    the seven scans of simple_progressive_script are cheap, sequential re-walks of the tuple:
-//            host code (jpeg_host.cpp) on a pinned copy.
+//   scans    device_progressive_scans above (PIXO_HIP_HOST_ENTROPY=1: the host twin in jpeg_host.cpp on a
+//            pinned copy of the tuple).
 int progressive_to_vector(const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, Context &c,
                           std::vector<uint8_t> &out)
 {
     namespace pd = pixo_dev;
     int rc;
-    int16_t *dy, *dcb, *dcr;
+    int16_t *dy = nullptr, *dcb = nullptr, *dcr = nullptr;
     const float *qt_all = nullptr;
     if ((rc = device_tables(c.device, &qt_all))) return rc;
     const float *qt = qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats;
-    pixo_host::HuffSet h = pixo_host::HuffSet::standard();
+    pixo_host::HuffSet h;
     const bool need_plain = o.optimize_huffman || !o.trellis_quant;
     if (need_plain && (rc = coeffs_on_device(d_pixels, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
-    if (o.optimize_huffman) {
-        pd::ScanArgs a;
-        a.y = dy; a.cb = dcb; a.cr = dcr; a.tables = nullptr;
-        a.mode = g.gray ? 0 : (g.s420 ? 2 : 1);
-        a.nblocks = g.y_blocks + 2 * g.c_blocks;
-        a.blocks_per_mcu = g.gray ? 1 : (g.s420 ? 6 : 3);
-        a.marker_bytes = 2;
-        a.restart = scan_has_restart_markers(o, g) ? o.restart_interval : 0;
-        HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
-        HIP_TRY(hipMemsetAsync(c.e_hist.p, 0, pixo_host::kScanTableWords * 8, c.stream));
-        HIP_TRY(pd::launch_scan_count(a, c.e_hist.as<unsigned long long>(), c.stream));
-        uint64_t counts[pixo_host::kScanTableWords];
-        HIP_TRY(hipMemcpyAsync(counts, c.e_hist.p, sizeof counts, hipMemcpyDeviceToHost, c.stream));
-        HIP_TRY(hipStreamSynchronize(c.stream));
-        uint64_t dc[2][12], ac[2][256];
-        for (int cls = 0; cls < 2; ++cls) {
-            std::memcpy(dc[cls], counts + cls * 268, sizeof dc[cls]);
-            std::memcpy(ac[cls], counts + cls * 268 + 12, sizeof ac[cls]);
-        }
-        h = pixo_host::HuffSet::optimized(dc, ac, !g.gray);
-    }
+    if ((rc = huffman_for_tuple(dy, dcb, dcr, o, g, c, h))) return rc;
     const size_t blocks = g.y_blocks + 2 * g.c_blocks, coef_bytes = blocks * 128;
     if (o.trellis_quant) {
         HIP_TRY(c.t_raw.reserve(blocks * 256));
@@ -429,6 +537,11 @@ int progressive_to_vector(const void *d_pixels, const pixo_jpeg_options &o, cons
         HIP_TRY(pd::launch_trellis(ry, qt + 128, 1.0f, dy, g.y_blocks, c.stream));   // luminance steps
         HIP_TRY(pd::launch_trellis(rcb, qt + 192, 1.0f, dcb, g.c_blocks, c.stream)); // chrominance steps
         HIP_TRY(pd::launch_trellis(rcr, qt + 192, 1.0f, dcr, g.c_blocks, c.stream));
+    }
+    if (!std::getenv("PIXO_HIP_HOST_ENTROPY")) {
+        out.clear();
+        pixo_host::file_headers(out, o, h);
+        return device_progressive_scans(dy, dcb, dcr, g, h, c, out);
     }
     if ((rc = c.reserve_hcoef(coef_bytes))) return rc;
     HIP_TRY(hipMemcpyAsync(c.h_coef, dy, coef_bytes, hipMemcpyDeviceToHost, c.stream));
@@ -457,7 +570,7 @@ int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options
     int rc = pixo_host::validate(o, true, data_len, msg);
     if (rc) return fail(rc, msg);
     const pixo_host::Geometry g = pixo_host::geometry(o.width, o.height, o.color_type, o.subsampling);
-    if (std::getenv("PIXO_HIP_HOST_ENTROPY")) { // (experiments: the host twin of the entropy stage)
+    if (!o.progressive && std::getenv("PIXO_HIP_HOST_ENTROPY")) { // (experiments: the host twin of the entropy stage)
         const int16_t *y, *cb, *cr;
         if ((rc = coeffs_to_pinned(data, o, g, &y, &cb, &cr))) return rc;
         pixo_host::encode_file(y, cb, cr, o, spill);
@@ -626,9 +739,17 @@ int context_on_current_device(Context **out)
 int device_tuple_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                            const pixo_host::Geometry &g, Context &c, uint8_t **out, size_t *out_len)
 {
-    if (!o.progressive && !std::getenv("PIXO_HIP_HOST_ENTROPY"))
-        return device_entropy_to_malloc(dy, dcb, dcr, o, g, c.stream, out, out_len);
-    // progressive scans (and, for experiments, the host twin of the baseline coder): host code on a copy
+    if (!std::getenv("PIXO_HIP_HOST_ENTROPY")) {
+        if (!o.progressive) return device_entropy_to_malloc(dy, dcb, dcr, o, g, c.stream, out, out_len);
+        pixo_host::HuffSet h;
+        int rc = huffman_for_tuple(dy, dcb, dcr, o, g, c, h);
+        if (rc) return rc;
+        std::vector<uint8_t> v;
+        pixo_host::file_headers(v, o, h);
+        if ((rc = device_progressive_scans(dy, dcb, dcr, g, h, c, v))) return rc;
+        return hand_over(v, out, out_len);
+    }
+    // for experiments, the host twin of the scan coders: host code on a copy of the tuple
     const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128;
     int rc = c.reserve_hcoef(coef_bytes);
     if (rc) return rc;

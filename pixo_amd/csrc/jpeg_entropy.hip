@@ -242,14 +242,15 @@ __device__ __forceinline__ uint64_t ff_before(const uint32_t *stream, const uint
     return ff;
 }
 
-__global__ __launch_bounds__(kScanThreads) void segment_out_offsets_kernel(const uint64_t *seg_byte_off, uint64_t nsegments,
+__global__ __launch_bounds__(kScanThreads) void segment_out_offsets_kernel(const uint64_t *seg_byte_off, uint64_t nsegments, uint64_t nbytes,
                                                                           const uint32_t *stream, const uint64_t *tile_ff_base,
                                                                           uint64_t *seg_out)
 {
     const uint64_t k = (uint64_t)blockIdx.x * kScanThreads + threadIdx.x;
     if (k >= nsegments) return;
-    const uint64_t pos = seg_byte_off[k]; // < bytes of the packed stream
-    seg_out[k] = pos + ff_before(stream, tile_ff_base, pos);
+    const uint64_t pos = seg_byte_off[k];
+    // an empty segment at the very end starts where the stream ends: the caller substitutes its size
+    seg_out[k] = pos < nbytes ? pos + ff_before(stream, tile_ff_base, pos) : ~0ull;
 }
 
 __global__ __launch_bounds__(kScanThreads) void restart_markers_kernel(const ScanArgs a, const uint64_t *off, const uint64_t *seg_byte_off,
@@ -263,6 +264,99 @@ __global__ __launch_bounds__(kScanThreads) void restart_markers_kernel(const Sca
     const uint64_t ff = ff_before(stream, tile_ff_base, pos);
     out[pos + ff] = 0xFF;
     out[pos + ff + 1] = (uint8_t)(0xD0 + (k & 7)); // jpeg/mod.rs:1436-1439
+}
+
+// ---- progressive scans ---------------------------------------------------------------------------
+struct ProgBlock { int scan; uint32_t w[32]; int prev_dc; };
+__device__ __forceinline__ ProgLayout layout_of(const ProgArgs &a)
+{
+    ProgLayout l;
+#pragma unroll
+    for (int i = 0; i < 8; i++) l.first[i] = a.first[i];
+    return l;
+}
+__device__ __forceinline__ void load_prog_block(const ProgArgs &a, const ProgLayout &l, uint64_t v, ProgBlock &b)
+{
+    b.scan = prog_scan_of(l, v);
+    const int comp = prog_comp(b.scan);
+    const int16_t *base = comp == 0 ? a.y : (comp == 1 ? a.cb : a.cr);
+    const uint64_t i = v - l.first[b.scan];
+    const uint4 *p = reinterpret_cast<const uint4 *>(base + i * 64);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint4 q = p[k];
+        b.w[4 * k] = q.x; b.w[4 * k + 1] = q.y; b.w[4 * k + 2] = q.z; b.w[4 * k + 3] = q.w;
+    }
+    b.prev_dc = i ? (int)base[(i - 1) * 64] : 0;
+}
+
+__global__ __launch_bounds__(kScanThreads) void prog_flags_kernel(const ProgArgs a)
+{
+    const uint64_t v = (uint64_t)blockIdx.x * kScanThreads + threadIdx.x;
+    if (v >= a.first[7]) return;
+    const ProgLayout l = layout_of(a);
+    ProgBlock b;
+    load_prog_block(a, l, v, b);
+    uint32_t f = 0;
+    if (b.scan >= 3) {
+        const int band = prog_band(b.scan);
+        f = band == 0 ? band_flags<1, 10>(b.w) : (band == 1 ? band_flags<11, 63>(b.w) : band_flags<1, 63>(b.w));
+    }
+    a.flags[v] = f;
+    a.nonempty[v] = f & 1u;
+}
+
+__global__ __launch_bounds__(kScanThreads) void prog_by_rank_kernel(const ProgArgs a)
+{
+    const uint64_t v = (uint64_t)blockIdx.x * kScanThreads + threadIdx.x;
+    if (v >= a.first[7]) return;
+    if (a.flags[v] & 1u) a.by_rank[a.rank[v]] = (uint32_t)v;
+}
+
+template <int WHAT>
+__global__ __launch_bounds__(kScanThreads) void prog_blocks_kernel(const ProgArgs a, uint32_t *len, const uint64_t *off, uint64_t total_bits,
+                                                                  const uint64_t *seg_byte_off, uint32_t *stream)
+{
+    __shared__ uint32_t tab[kTableWords];
+    for (int i = threadIdx.x; i < kTableWords; i += kScanThreads) tab[i] = a.tables[i];
+    __syncthreads();
+    const uint64_t v = (uint64_t)blockIdx.x * kScanThreads + threadIdx.x;
+    if (v >= a.first[7]) return;
+    const ProgLayout l = layout_of(a);
+    ProgBlock b;
+    load_prog_block(a, l, v, b);
+    const uint64_t first = l.first[b.scan], next = l.first[b.scan + 1];
+    const uint32_t flags = a.flags[v];
+    const uint32_t before = b.scan >= 3 ? band_run_before(v, first, a.rank[v], a.rank[first], a.by_rank, a.flags) : 0u;
+    const bool last = v + 1 == next;
+    const uint32_t *t = tab + (prog_comp(b.scan) ? 1 : 0) * kClassSyms;
+    if (WHAT == WHAT_LENGTH) {
+        LengthVisitor vis{t, 0};
+        prog_emit(b.scan, b.w, b.prev_dc, flags, before, last, vis);
+        len[v] = vis.bits;
+    } else {
+        PackVisitor vis;
+        vis.tab = t;
+        const uint64_t base_bits = seg_byte_off[b.scan] * 8, scan_bits0 = off[first];
+        vis.begin(stream, base_bits + (off[v] - scan_bits0));
+        prog_emit(b.scan, b.w, b.prev_dc, flags, before, last, vis);
+        vis.finish();
+        if (last) { // every scan has its own BitWriterMsb: flush pads with 1-bits (jpeg/mod.rs:925)
+            const uint64_t end_bits = base_bits + ((next < a.first[7] ? off[next] : total_bits) - scan_bits0);
+            const int n = (int)((8 - (end_bits & 7)) & 7);
+            if (n) vis.or_word(end_bits >> 5, ((1u << n) - 1u) << (32 - (int)(end_bits & 31) - n));
+        }
+    }
+}
+
+__global__ void prog_segment_sizes_kernel(const ProgArgs a, const uint64_t *off, const uint64_t *total_bits, uint32_t *seg_bytes)
+{
+    const int i = threadIdx.x;
+    if (i >= 7) return;
+    const uint64_t first = a.first[i], next = a.first[i + 1];
+    const uint64_t end = next < a.first[7] ? off[next] : *total_bits;
+    const uint64_t begin = first < a.first[7] ? off[first] : *total_bits;
+    seg_bytes[i] = (uint32_t)((end - begin + 7) / 8);
 }
 
 inline unsigned grid_for(uint64_t n, uint64_t per_group) { return (unsigned)((n + per_group - 1) / per_group); }
@@ -301,11 +395,42 @@ hipError_t launch_segment_sizes(const ScanArgs &a, const uint64_t *d_off, const 
     return hipGetLastError();
 }
 
-hipError_t launch_segment_out_offsets(const SegmentPlan &seg, const uint32_t *d_stream, const uint64_t *d_tile_ff_base,
+hipError_t launch_prog_flags(const ProgArgs &a, hipStream_t s)
+{
+    if (a.first[7] == 0) return hipSuccess;
+    hipLaunchKernelGGL(prog_flags_kernel, dim3(grid_for(a.first[7], kScanThreads)), dim3(kScanThreads), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_prog_by_rank(const ProgArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(prog_by_rank_kernel, dim3(grid_for(a.first[7], kScanThreads)), dim3(kScanThreads), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_prog_lengths(const ProgArgs &a, uint32_t *d_len, hipStream_t s)
+{
+    hipLaunchKernelGGL((prog_blocks_kernel<WHAT_LENGTH>), dim3(grid_for(a.first[7], kScanThreads)), dim3(kScanThreads), 0, s, a, d_len,
+                       nullptr, 0, nullptr, nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_prog_segment_sizes(const ProgArgs &a, const uint64_t *d_off, const uint64_t *d_total_bits, uint32_t *d_seg_bytes,
+                                     hipStream_t s)
+{
+    hipLaunchKernelGGL(prog_segment_sizes_kernel, dim3(1), dim3(64), 0, s, a, d_off, d_total_bits, d_seg_bytes);
+    return hipGetLastError();
+}
+hipError_t launch_prog_pack(const ProgArgs &a, const uint64_t *d_off, uint64_t total_bits, const uint64_t *d_seg_byte_off,
+                            uint32_t *d_stream, hipStream_t s)
+{
+    hipLaunchKernelGGL((prog_blocks_kernel<WHAT_PACK>), dim3(grid_for(a.first[7], kScanThreads)), dim3(kScanThreads), 0, s, a, nullptr,
+                       d_off, total_bits, d_seg_byte_off, d_stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_segment_out_offsets(const SegmentPlan &seg, uint64_t nbytes, const uint32_t *d_stream, const uint64_t *d_tile_ff_base,
                                       uint64_t *d_seg_out, hipStream_t s)
 {
     hipLaunchKernelGGL(segment_out_offsets_kernel, dim3(grid_for(seg.nsegments, kScanThreads)), dim3(kScanThreads), 0, s,
-                       seg.seg_byte_off, seg.nsegments, d_stream, d_tile_ff_base, d_seg_out);
+                       seg.seg_byte_off, seg.nsegments, nbytes, d_stream, d_tile_ff_base, d_seg_out);
     return hipGetLastError();
 }
 

@@ -43,15 +43,37 @@ hipError_t launch_scan_pack(const ScanArgs &a, const uint64_t *d_off, uint64_t t
 // the last, the two marker bytes included), from the exclusive bit offsets d_off and the total.
 hipError_t launch_segment_sizes(const ScanArgs &a, const uint64_t *d_off, const uint64_t *d_total_bits, uint64_t nsegments,
                                 uint32_t *d_seg_bytes, hipStream_t s);
-// d_seg_out[k] = offset of segment k in the STUFFED stream, k < nsegments: where each image of a batch
+// d_seg_out[k] = offset of segment k in the STUFFED stream, k < nsegments (~0 for an empty segment that
+// starts at the end of the packed stream, nbytes): where each image of a batch / each progressive scan
 // begins.  After launch_ff_tile_count + its scan.
-hipError_t launch_segment_out_offsets(const SegmentPlan &seg, const uint32_t *d_stream, const uint64_t *d_tile_ff_base,
-                                      uint64_t *d_seg_out, hipStream_t s);
+hipError_t launch_segment_out_offsets(const SegmentPlan &seg, uint64_t nbytes, const uint32_t *d_stream,
+                                      const uint64_t *d_tile_ff_base, uint64_t *d_seg_out, hipStream_t s);
 // After launch_stuff: writes FF D0+(k & 7) over the two zero bytes that follow segment k < nsegments - 1.
 hipError_t launch_restart_markers(const ScanArgs &a, const uint64_t *d_off, const SegmentPlan &seg, const uint32_t *d_stream,
                                   const uint64_t *d_tile_ff_base, uint8_t *d_out, hipStream_t s);
 hipError_t launch_ff_tile_count(const uint32_t *d_stream, uint64_t nbytes, uint32_t *d_tile_ff, hipStream_t s);
 // d_out: nbytes + (number of 0xFF bytes) bytes
 hipError_t launch_stuff(const uint32_t *d_stream, uint64_t nbytes, const uint64_t *d_tile_ff_base, uint8_t *d_out, hipStream_t s);
+
+// ---- progressive scans on the device (simple_progressive_script: seven single-component scans) ------
+struct ProgArgs {
+    const int16_t *y, *cb, *cr; // coefficient tuple
+    const uint32_t *tables;     // packed like ScanArgs::tables; absent symbols hold (4 << 16): code 0, 4 bits
+    uint64_t first[8];          // virtual block index where scan i starts; first[7] = total
+    uint32_t *flags;            // [total] per virtual block: bit 0 band not empty, bit 1 ends before the band's end
+    uint32_t *nonempty;         // [total] flags & 1 (input of the rank prefix sum)
+    const uint64_t *rank;       // [total] exclusive prefix sum of nonempty
+    uint32_t *by_rank;          // [total] virtual index of the r-th non-empty block
+};
+hipError_t launch_prog_flags(const ProgArgs &a, hipStream_t s);   // fills flags, nonempty
+hipError_t launch_prog_by_rank(const ProgArgs &a, hipStream_t s); // fills by_rank (after the rank prefix sum)
+hipError_t launch_prog_lengths(const ProgArgs &a, uint32_t *d_len, hipStream_t s);
+// d_off: exclusive bit offsets of the virtual blocks, d_total: their sum; d_seg_bytes[7]: bytes of each scan's
+// packed (unstuffed, 1-padded) stream
+hipError_t launch_prog_segment_sizes(const ProgArgs &a, const uint64_t *d_off, const uint64_t *d_total_bits, uint32_t *d_seg_bytes,
+                                     hipStream_t s);
+// d_seg_byte_off[7]: exclusive prefix sum of d_seg_bytes; d_stream zeroed
+hipError_t launch_prog_pack(const ProgArgs &a, const uint64_t *d_off, uint64_t total_bits, const uint64_t *d_seg_byte_off,
+                            uint32_t *d_stream, hipStream_t s);
 
 } // namespace pixo_dev

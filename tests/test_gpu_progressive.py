@@ -61,3 +61,60 @@ def test_progressive_device_entry_points_and_restart_interval_header():
     want = O.encode(px, O.make_options(w, h, 2, 75, 1, progressive=True, trellis=True, optimize_huffman=True, restart=7))
     assert jpeg.encode_device(d_px, o) == want
     assert jpeg.encode_batch_device(torch.cat([d_px, d_px]), o, 2) == [want, want]
+
+
+def test_end_of_band_runs_longer_than_32767_blocks():
+    """A flat image has no AC coefficient anywhere: the AC scans are pure end-of-band runs, flushed
+    every 0x7FFF blocks (progressive.rs:186-190).  2048x2048 4:4:4 = 65536 blocks per component (two
+    flushes + a tail); a lone textured block in the middle splits one run."""
+    w = h = 2048
+    px = synth.constant(w, h, 97).reshape(h, w, 3).copy()
+    for variant in range(2):
+        if variant:
+            px[1000:1008, 1200:1208] = synth.noise(8, 8, 3).reshape(8, 8, 3)
+        flat = px.reshape(-1)
+        for ss in (0, 1):
+            got = jpeg.encode(flat, _opts(w, h, 2, ss, 85, progressive=True))
+            want = O.encode(flat, O.make_options(w, h, 2, 85, ss, progressive=True))
+            assert got == want
+    g = px[:, :, 0].reshape(-1).copy()
+    assert jpeg.encode(g, _opts(w, h, 0, 0, 85, progressive=True, optimize_huffman=True)) == \
+        O.encode(g, O.make_options(w, h, 0, 85, 0, progressive=True, optimize_huffman=True))
+
+
+@pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])
+def test_progressive_scans_over_a_device_tuple_and_the_host_twin(mode, monkeypatch):
+    """`entropy_encode_device` with progressive options codes the seven scans on the device from a tuple
+    that never leaves HBM; the host twin (PIXO_HIP_HOST_ENTROPY) must give the same bytes."""
+    import torch
+    ct, ss = mode
+    w, h = 413, 290
+    px = synth.noise(w, h, 5) if ct == 2 else synth.noise_gray(w, h, 5)
+    y, cb, cr = O.coeffs(px, w, h, ct, ss, 88)
+    dy = torch.from_numpy(y).to("cuda:0")
+    dcb = torch.from_numpy(cb).to("cuda:0") if cb.size else dy
+    dcr = torch.from_numpy(cr).to("cuda:0") if cr.size else dy
+    torch.cuda.synchronize()
+    for optimize in (False, True):
+        o = _opts(w, h, ct, ss, 88, progressive=True, optimize_huffman=optimize)
+        want = O.encode_from_coeffs(y, cb, cr, O.make_options(w, h, ct, 88, ss, progressive=True, optimize_huffman=optimize)) \
+            if not optimize else O.encode(px, O.make_options(w, h, ct, 88, ss, progressive=True, optimize_huffman=True))
+        got = jpeg.entropy_encode_device(dy, dcb, dcr, o)
+        assert got == want
+        monkeypatch.setenv("PIXO_HIP_HOST_ENTROPY", "1")
+        assert jpeg.entropy_encode_device(dy, dcb, dcr, o) == want
+        assert jpeg.encode(px, o) == want
+        monkeypatch.delenv("PIXO_HIP_HOST_ENTROPY")
+        assert jpeg.encode(px, o) == want
+
+
+def test_progressive_large_noise_matches_host_twin(monkeypatch):
+    """4096x4096 noise (the stream has millions of 0xFF bytes and every scan is many tiles long): device
+    scan coder == host twin byte for byte (the twin is pinned to the oracle on the CPU suite)."""
+    w = h = 4096
+    px = synth.noise(w, h, 77)
+    o = jpeg.JpegOptions.from_preset(w, h, 85, 2)
+    dev = jpeg.encode(px, o)
+    monkeypatch.setenv("PIXO_HIP_HOST_ENTROPY", "1")
+    host = jpeg.encode(px, o)
+    assert hashlib.sha256(dev).hexdigest() == hashlib.sha256(host).hexdigest() and len(dev) == len(host)

@@ -89,7 +89,7 @@ struct Context {
     };
     Buf e_tables, e_hist, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out, e_seg_bytes, e_seg_off;
     Buf p_in, p_out, p_sums, p_scratch; // PNG filter stage
-    Buf t_raw;                          // progressive + trellis: unquantised DCT blocks (f32)
+    Buf t_raw, t_trail;                 // progressive + trellis: unquantised DCT blocks (f32), Viterbi back-pointers
     Buf g_flags, g_rank, g_by_rank;     // progressive scans: band flags, rank among non-empty blocks and its inverse
     unsigned long long *h_sums = nullptr; size_t hsums_cap = 0; // pinned
     uint64_t *h_totals = nullptr; // pinned, 2 words
@@ -534,9 +534,11 @@ int progressive_to_vector(const void *d_pixels, const pixo_jpeg_options &o, cons
         dy = static_cast<int16_t *>(c.d_coef); dcb = dy + g.y_blocks * 64; dcr = dcb + g.c_blocks * 64;
         HIP_TRY(pd::launch_jpeg_coeffs(d_pixels, o.width, o.height, g.gray, g.s420, 1, ry, g.gray ? nullptr : rcb,
                                        g.gray ? nullptr : rcr, qt, c.stream, /*raw_f32=*/true));
-        HIP_TRY(pd::launch_trellis(ry, qt + 128, 1.0f, dy, g.y_blocks, c.stream));   // luminance steps
-        HIP_TRY(pd::launch_trellis(rcb, qt + 192, 1.0f, dcb, g.c_blocks, c.stream)); // chrominance steps
-        HIP_TRY(pd::launch_trellis(rcr, qt + 192, 1.0f, dcr, g.c_blocks, c.stream));
+        // (the three launches run back to back on one stream: they can share the back-pointer scratch)
+        HIP_TRY(c.t_trail.reserve(pd::trellis_scratch_bytes(g.y_blocks)));
+        HIP_TRY(pd::launch_trellis(ry, qt + 128, dy, g.y_blocks, c.t_trail.p, c.stream));   // luminance steps
+        HIP_TRY(pd::launch_trellis(rcb, qt + 192, dcb, g.c_blocks, c.t_trail.p, c.stream)); // chrominance steps
+        HIP_TRY(pd::launch_trellis(rcr, qt + 192, dcr, g.c_blocks, c.t_trail.p, c.stream));
     }
     if (!std::getenv("PIXO_HIP_HOST_ENTROPY")) {
         out.clear();

@@ -137,4 +137,152 @@ PIXO_TDEV void quantize_block(const float *dct, const float *q, int16_t *out, ui
     }
 }
 
+// ---- the same search with every state in registers -------------------------------------------------
+// quantize_block above follows the reference's data structures (vectors of states, linear searches);
+// run by a GPU lane it lives in scratch memory and is latency-bound.  quantize_block_fast is the same
+// function restated on the STRUCTURE of the state set, so that every array has a fixed size, every
+// index is static and all loops unroll:
+//   * candidates sit in fixed slots by kind (0, floor, round, ceil, one-further) with a valid bit; a
+//     slot is valid exactly when the reference would have pushed it, and the slot order is the
+//     reference's generation order;
+//   * a successor state is keyed by (value, run).  Non-zero values always have run 0, so each non-zero
+//     candidate has ONE successor whose cost is the first strict minimum over the parents; a zero
+//     successor is keyed by its run alone, and two parents produce the same run only when both have
+//     run 0 (all non-zero-valued parents and a (0, 0) parent): those fold into one entry that sits where
+//     the first of them would have been inserted;
+//   * insertion order therefore is: zero-successor of parent 0, the candidates, the zero-successors of
+//     parents 1..7 — twelve slots; the reference's stable sort by cost is a sorting network over 64-bit
+//     keys (cost bits, slot) (costs are sums of non-negative terms, so their bit patterns order like
+//     the values), the eight smallest survive;
+//   * a back-pointer is 6 bits (candidate kind, parent): 48 bits per coefficient; values are recomputed
+//     from the kind while walking back.
+// Env: coef(zz), step(zz) (zig-zag position -> f32), bits(rs) (the code-length estimate table of
+// ac_rate), trail_put(pos, u64), trail_get(pos), out(zz, i16).
+PIXO_TDEV float rate_bits(int rs)
+{ // trellis.rs:246-279 without the value bits; rs = (run << 4) | size, 0..255
+    switch (rs) {
+    case 0x00: return 4.0f; case 0x01: return 2.0f; case 0x02: return 2.5f;
+    case 0x03: return 3.0f; case 0x04: return 4.0f; case 0x11: return 3.0f;
+    case 0x12: return 4.0f; case 0x21: return 4.0f; case 0xF0: return 10.0f;
+    default: return 3.0f + (float)(rs >> 4) * 0.5f + (float)(rs & 0x0F) * 0.3f;
+    }
+}
+PIXO_TDEV uint32_t f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+PIXO_TDEV float u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+constexpr uint32_t kNoState = 0xFFFFFFFFu; // as a float: NaN — never smaller than anything, never chosen
+
+struct Kinds { int v[5]; bool ok[5]; }; // [0] is the zero candidate
+PIXO_TDEV Kinds candidate_kinds(float fq)
+{
+    const int r = to_i16(__builtin_roundf(fq)), fl = to_i16(__builtin_floorf(fq)), ce = to_i16(__builtin_ceilf(fq));
+    const int ext = (int16_t)(fq >= 0.0f ? ce + 1 : fl - 1);
+    Kinds k;
+    k.v[0] = 0; k.ok[0] = true;
+    k.v[1] = fl; k.ok[1] = fl != 0;
+    k.v[2] = r; k.ok[2] = r != 0 && r != fl;
+    k.v[3] = ce; k.ok[3] = ce != 0 && ce != fl && ce != r;
+    k.v[4] = ext; k.ok[4] = __builtin_fabsf(fq) > 1.5f && ext != 0 && ext != fl && ext != r && ext != ce;
+    return k;
+}
+
+#define PIXO_CE(a, b) { const uint64_t lo_ = e[a] < e[b] ? e[a] : e[b], hi_ = e[a] < e[b] ? e[b] : e[a]; e[a] = lo_; e[b] = hi_; }
+
+template <class Env> PIXO_TDEV void quantize_block_fast(Env &env)
+{
+    env.out(0, to_i16(__builtin_roundf(env.coef(0) / env.step(0)))); // DC: plain rounding (trellis.rs:75)
+    uint32_t cc[8]; // cost bits of the surviving states, cheapest first; kNoState beyond their number
+    int run[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { cc[i] = kNoState; run[i] = 0; }
+    cc[0] = 0; // cost 0.0
+    for (int zz = 1; zz < 64; zz++) {
+        const float coef = env.coef(zz), qq = env.step(zz);
+        const Kinds k = candidate_kinds(coef / qq);
+        uint64_t e[12];
+        // non-zero candidates -> slots 1..4
+#pragma unroll
+        for (int j = 1; j < 5; j++) {
+            const float rec = (float)k.v[j] * qq, d = coef - rec, dist = d * d;
+            const int cat = size_category(k.v[j]);
+            const float catf = (float)cat;
+            float best = 0.0f;
+            int parent = 0;
+#pragma unroll
+            for (int pi = 0; pi < 8; pi++) {
+                const float rate = env.bits((run[pi] << 4) | cat) + catf;
+                const float cost = u2f(cc[pi]) + rate + 1.0f * dist;
+                if (pi == 0 || cost < best) { best = cost; parent = pi; }
+            }
+            const uint32_t lo = ((uint32_t)j << 28) | ((uint32_t)j << 8) | (uint32_t)parent; // slot, kind, run 0, parent
+            e[j] = ((uint64_t)(k.ok[j] ? f2u(best) : kNoState) << 32) | lo;
+        }
+        // zero candidate -> slot 0 (parent 0) and slots 5..11 (parents 1..7)
+        const float dist0 = coef * coef; // (coef - 0 * step)^2
+        float zc[8];
+        bool alive[8], have = false;
+        float gbest = 0.0f;
+        int gparent = 0, first0 = 8;
+#pragma unroll
+        for (int pi = 0; pi < 8; pi++) {
+            alive[pi] = cc[pi] != kNoState;
+            const bool over = run[pi] + 1 >= 16; // a ZRL symbol will be needed (trellis.rs:117-120)
+            zc[pi] = u2f(cc[pi]) + (over ? 10.0f : 0.0f) + 1.0f * dist0;
+            const bool in_group = alive[pi] && run[pi] == 0; // successors keyed (0, 1): fold, first strict minimum
+            if (in_group && (!have || zc[pi] < gbest)) { gbest = zc[pi]; gparent = pi; }
+            if (in_group && !have) first0 = pi;
+            have = have || in_group;
+        }
+#pragma unroll
+        for (int pi = 0; pi < 8; pi++) {
+            const int slot = pi == 0 ? 0 : 4 + pi;
+            const bool grouped = run[pi] == 0;
+            const bool ok = alive[pi] && (!grouped || pi == first0);
+            const int nrun = run[pi] + 1 >= 16 ? 0 : run[pi] + 1;
+            const float cost = grouped ? gbest : zc[pi];
+            const int parent = grouped ? gparent : pi;
+            const uint32_t lo = ((uint32_t)slot << 28) | ((uint32_t)nrun << 4) | (uint32_t)parent; // kind 0
+            e[slot] = ((uint64_t)(ok ? f2u(cost) : kNoState) << 32) | lo;
+        }
+        // stable sort by cost == sort by (cost bits, slot); 39 compare-exchanges (optimal for 12 inputs)
+        PIXO_CE(0, 8) PIXO_CE(1, 7) PIXO_CE(2, 6) PIXO_CE(3, 11) PIXO_CE(4, 10) PIXO_CE(5, 9)
+        PIXO_CE(0, 1) PIXO_CE(2, 5) PIXO_CE(3, 4) PIXO_CE(6, 9) PIXO_CE(7, 8) PIXO_CE(10, 11)
+        PIXO_CE(0, 2) PIXO_CE(1, 6) PIXO_CE(5, 10) PIXO_CE(9, 11)
+        PIXO_CE(0, 3) PIXO_CE(1, 2) PIXO_CE(4, 6) PIXO_CE(5, 7) PIXO_CE(8, 11) PIXO_CE(9, 10)
+        PIXO_CE(1, 4) PIXO_CE(3, 5) PIXO_CE(6, 8) PIXO_CE(7, 10)
+        PIXO_CE(1, 3) PIXO_CE(2, 5) PIXO_CE(6, 9) PIXO_CE(8, 10)
+        PIXO_CE(2, 3) PIXO_CE(4, 5) PIXO_CE(6, 7) PIXO_CE(8, 9)
+        PIXO_CE(4, 6) PIXO_CE(5, 7)
+        PIXO_CE(3, 4) PIXO_CE(5, 6) PIXO_CE(7, 8)
+        uint64_t back = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t lo = (uint32_t)e[i];
+            cc[i] = (uint32_t)(e[i] >> 32);
+            run[i] = (int)((lo >> 4) & 15u);
+            back |= (uint64_t)((((lo >> 8) & 7u) << 3) | (lo & 7u)) << (6 * i);
+        }
+        env.trail_put(zz - 1, back);
+    }
+    // trailing zeros: an EOB will be coded (trellis.rs:172-178); min_by: the first of equal minima
+    int idx = 0;
+    float best = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float c = u2f(cc[i]);
+        if (run[i] > 0) c += 4.0f;
+        if (i == 0 || c < best) { best = c; idx = i; }
+    }
+    for (int zz = 63; zz >= 1; zz--) {
+        const uint32_t f = (uint32_t)(env.trail_get(zz - 1) >> (6 * idx)) & 63u;
+        const int kind = (int)(f >> 3);
+        const Kinds k = candidate_kinds(env.coef(zz) / env.step(zz));
+        int v = 0;
+#pragma unroll
+        for (int j = 1; j < 5; j++) v = kind == j ? k.v[j] : v;
+        env.out(zz, (int16_t)v);
+        idx = (int)(f & 7u);
+    }
+}
+#undef PIXO_CE
+
 } // namespace pixo_trellis

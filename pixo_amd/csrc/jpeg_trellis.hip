@@ -1,8 +1,14 @@
 // jpeg_trellis.hip — trellis quantisation of raw DCT blocks on gfx950: the quantiser
 // the reference's progressive path uses when `trellis_quant` is set (quantize_dct, src/jpeg/mod.rs:
-// 968-976 -> src/jpeg/trellis.rs).  One lane = one block; the Viterbi state of a lane (a few dozen
-// floats, 63 x 8 back-pointers) lives in scratch memory.  Divergent, latency-bound integer/float
-// control code — orders of magnitude below the coefficient kernel's rate and still ~100x one CPU core.
+// 968-976 -> src/jpeg/trellis.rs).
+//
+// One lane = one block, one wave = one workgroup = 64 consecutive blocks.  The Viterbi state of a lane
+// (8 costs, 8 runs, 12 successor keys) stays in registers (pixo_trellis::quantize_block_fast); the wave's
+// 64 x 64 coefficients are staged through LDS (coalesced 16-byte loads, lane stride 65 words: no bank
+// conflicts on the per-lane zig-zag reads), the code-length estimates are a 256-entry LDS table, the
+// back-pointers (8 bytes per lane and coefficient) go to a global scratch laid out [wave][position][lane]
+// so that both directions are full-line accesses.  Results return through the coefficient slots in LDS
+// and leave as whole 128-byte blocks.  ALU work: ~700 VALU instructions per coefficient position.
 #include <hip/hip_runtime.h>
 
 #include "jpeg_trellis.h"
@@ -12,31 +18,69 @@
 
 namespace pixo_dev {
 namespace {
-__global__ __launch_bounds__(64) void trellis_kernel(const float *raw, const float *q, float prescale, int16_t *out, uint64_t nblocks)
+constexpr int kLaneStride = 65; // words between two lanes' blocks in LDS
+
+__constant__ int c_zigzag_nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
+                                     12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                                     35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+                                     58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct LaneEnv {
+    float *mine;          // this lane's 64 coefficient slots in LDS (natural order)
+    const float *steps;   // 64 quantiser steps in LDS (natural order)
+    const float *table;   // 256 code-length estimates in LDS
+    uint64_t *trail;      // this lane's column of the wave's back-pointer scratch
+    __device__ __forceinline__ float coef(int zz) const { return mine[c_zigzag_nat[zz]]; }
+    __device__ __forceinline__ float step(int zz) const { return steps[c_zigzag_nat[zz]]; }
+    __device__ __forceinline__ float bits(int rs) const { return table[rs]; }
+    __device__ __forceinline__ void trail_put(int pos, uint64_t w) { __builtin_nontemporal_store(w, trail + pos * 64); }
+    __device__ __forceinline__ uint64_t trail_get(int pos) const { return __builtin_nontemporal_load(trail + pos * 64); }
+    // the result replaces the coefficient it was derived from (each slot is read before it is written)
+    __device__ __forceinline__ void out(int zz, int16_t v) { reinterpret_cast<int *>(mine)[c_zigzag_nat[zz]] = v; }
+};
+
+__global__ __launch_bounds__(64) void trellis_kernel(const float *raw, const float *q, int16_t *out, uint64_t nblocks, uint64_t *trail)
 {
-    const uint64_t b = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-    if (b >= nblocks) return;
-    float dct[64], qq[64];
-    const float4 *src = reinterpret_cast<const float4 *>(raw + b * 64);
+    __shared__ float s_coef[64 * kLaneStride];
+    __shared__ float s_step[64];
+    __shared__ float s_bits[256];
+    const int lane = threadIdx.x;
+    const uint64_t first = (uint64_t)blockIdx.x * 64;
+    const uint64_t have = nblocks - first < 64 ? nblocks - first : 64; // blocks of this wave
+    s_step[lane] = q[lane];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const float4 v = src[i];
-        dct[4 * i] = v.x * prescale; dct[4 * i + 1] = v.y * prescale; dct[4 * i + 2] = v.z * prescale; dct[4 * i + 3] = v.w * prescale;
+    for (int i = 0; i < 4; i++) s_bits[i * 64 + lane] = pixo_trellis::rate_bits(i * 64 + lane);
+    const float4 *src = reinterpret_cast<const float4 *>(raw + first * 64);
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+        const int i = it * 64 + lane, blk = i >> 4, part = i & 15;
+        // a short last wave recomputes its last block in the idle lanes
+        const float4 v = src[(uint64_t)(blk < (int)have ? blk : (int)have - 1) * 16 + part];
+        float *d = s_coef + blk * kLaneStride + part * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
-    for (int i = 0; i < 64; i++) qq[i] = q[i];
-    int16_t res[64];
-    uint32_t trail[63 * 8];
-    uint8_t counts[63];
-    pixo_trellis::quantize_block(dct, qq, res, trail, counts);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(out + b * 64);
-    for (int i = 0; i < 32; i++) dst[i] = (uint32_t)(uint16_t)res[2 * i] | ((uint32_t)(uint16_t)res[2 * i + 1] << 16);
+    __syncthreads();
+    LaneEnv env{s_coef + lane * kLaneStride, s_step, s_bits, trail + (uint64_t)blockIdx.x * 63 * 64 + lane};
+    pixo_trellis::quantize_block_fast(env);
+    __syncthreads();
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + first * 64);
+    const int *res = reinterpret_cast<const int *>(s_coef);
+#pragma unroll
+    for (int it = 0; it < 32; it++) {
+        const int i = it * 64 + lane, blk = i >> 5, pair = i & 31;
+        const int *p = res + blk * kLaneStride + pair * 2;
+        if (blk < (int)have) __builtin_nontemporal_store((uint32_t)(uint16_t)p[0] | ((uint32_t)(uint16_t)p[1] << 16), dst + i);
+    }
 }
 } // namespace
 
-hipError_t launch_trellis(const float *d_raw, const float *d_q, float prescale, int16_t *d_out, uint64_t nblocks, hipStream_t s)
+size_t trellis_scratch_bytes(uint64_t nblocks) { return (size_t)((nblocks + 63) / 64) * 63 * 64 * 8; }
+
+hipError_t launch_trellis(const float *d_raw, const float *d_q, int16_t *d_out, uint64_t nblocks, void *d_scratch, hipStream_t s)
 {
     if (nblocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(trellis_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, d_raw, d_q, prescale, d_out, nblocks);
+    hipLaunchKernelGGL(trellis_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, d_raw, d_q, d_out, nblocks,
+                       static_cast<uint64_t *>(d_scratch));
     return hipGetLastError();
 }
 } // namespace pixo_dev

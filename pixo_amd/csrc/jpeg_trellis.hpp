@@ -6,7 +6,8 @@
 
 namespace pixo_dev {
 // d_raw: nblocks x 64 f32 DCT coefficients (natural order) as left by the coefficient kernel's raw
-// mode, d_q: 64 quantiser steps (natural order), prescale: 1, or 0.25 for the 4:2:0 chroma blocks whose
-// transform ran on 2x2 sums.  d_out: nblocks x 64 i16.
-hipError_t launch_trellis(const float *d_raw, const float *d_q, float prescale, int16_t *d_out, uint64_t nblocks, hipStream_t s);
+// mode, d_q: 64 quantiser steps (natural order).  d_out: nblocks x 64 i16.  d_scratch: back-pointer
+// storage of trellis_scratch_bytes(nblocks) bytes (504 per block), free again when the kernel is done.
+size_t trellis_scratch_bytes(uint64_t nblocks);
+hipError_t launch_trellis(const float *d_raw, const float *d_q, int16_t *d_out, uint64_t nblocks, void *d_scratch, hipStream_t s);
 } // namespace pixo_dev

@@ -238,6 +238,31 @@ extern "C" void emu_trellis(const float *dct, const float *q, long nblocks, int1
     }
 }
 
+// The register-resident restatement the kernel actually runs (quantize_block_fast), same interface.
+namespace {
+struct HostTrellisEnv {
+    const float *dct, *q;
+    int16_t *res;
+    uint64_t trail[63];
+    float table[256];
+    float coef(int zz) const { return dct[pixo_trellis::kZigzagNat[zz]]; }
+    float step(int zz) const { return q[pixo_trellis::kZigzagNat[zz]]; }
+    float bits(int rs) const { return table[rs]; }
+    void trail_put(int pos, uint64_t w) { trail[pos] = w; }
+    uint64_t trail_get(int pos) const { return trail[pos]; }
+    void out(int zz, int16_t v) { res[pixo_trellis::kZigzagNat[zz]] = v; }
+};
+} // namespace
+extern "C" void emu_trellis_fast(const float *dct, const float *q, long nblocks, int16_t *out)
+{
+    HostTrellisEnv env;
+    for (int rs = 0; rs < 256; rs++) env.table[rs] = pixo_trellis::rate_bits(rs);
+    for (long b = 0; b < nblocks; b++) {
+        env.dct = dct + b * 64; env.q = q; env.res = out + b * 64;
+        pixo_trellis::quantize_block_fast(env);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Device progressive scan coder (jpeg_scan_block.h: band_flags, band_run_before, prog_emit) lane by
 // lane: flags, rank / by_rank, lengths, prefix sum, pack (blocks in reverse order), pad, stuffing.

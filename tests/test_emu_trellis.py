@@ -13,9 +13,13 @@ import oracle_lib as O
 def _both(dct, q):
     n = dct.shape[0]
     L = E.lib()
-    L.emu_trellis.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     got = np.zeros((n, 64), np.int16)
-    L.emu_trellis(dct.ctypes.data, q.ctypes.data, n, got.ctypes.data)
+    fast = np.ones((n, 64), np.int16)
+    for fn, dst in ((L.emu_trellis, got), (L.emu_trellis_fast, fast)):
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+        fn.restype = None
+        fn(dct.ctypes.data, q.ctypes.data, n, dst.ctypes.data)
+    assert np.array_equal(got, fast)  # reference-shaped search == register-resident restatement
     OL = O.lib()
     OL.po_trellis_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     OL.po_trellis_quantize.restype = None

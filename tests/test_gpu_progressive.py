@@ -118,3 +118,28 @@ def test_progressive_large_noise_matches_host_twin(monkeypatch):
     monkeypatch.setenv("PIXO_HIP_HOST_ENTROPY", "1")
     host = jpeg.encode(px, o)
     assert hashlib.sha256(dev).hexdigest() == hashlib.sha256(host).hexdigest() and len(dev) == len(host)
+
+
+def test_random_sweep_of_small_progressive_images():
+    """150 random shapes (1x1 upwards: scans of a single block, empty chroma scans, ragged edges),
+    qualities, contents and flag combinations against the oracle."""
+    rng = np.random.RandomState(2024)
+    for i in range(150):
+        w, h = int(rng.randint(1, 97)), int(rng.randint(1, 97))
+        ct = 2 if rng.rand() < 0.7 else 0
+        ss = int(rng.rand() < 0.5)
+        q = int(rng.choice([1, 10, 35, 50, 75, 90, 100]))
+        kind = i % 4
+        if kind == 0:
+            rgb = synth.noise(w, h, i)
+        elif kind == 1:
+            rgb = synth.gradient_rgb(w, h)
+        elif kind == 2:
+            rgb = synth.constant(w, h, int(rng.randint(0, 256)))
+        else:
+            rgb = synth.extremes(w, h, i)
+        px = rgb if ct == 2 else rgb.reshape(-1, 3)[:, i % 3].copy()
+        trellis, optimize = bool(rng.rand() < 0.5), bool(rng.rand() < 0.5)
+        got = jpeg.encode(px, _opts(w, h, ct, ss, q, progressive=True, trellis_quant=trellis, optimize_huffman=optimize))
+        want = O.encode(px, O.make_options(w, h, ct, q, ss, progressive=True, trellis=trellis, optimize_huffman=optimize))
+        assert got == want, (i, w, h, ct, ss, q, kind, trellis, optimize)

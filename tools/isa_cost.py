@@ -11,12 +11,12 @@ FULL = ("v_add_f32_e32 v_sub_f32_e32 v_mul_f32_e32 v_fmaak_f32 v_fmamk_f32 v_and
 cur = None; skip_until = None
 hot = collections.Counter(); region = 0
 sections = collections.OrderedDict()
-for ln in lines:
+for li, ln in enumerate(lines):
     m = re.match(r"^(_Z\w+):", ln)
     if m: cur = m.group(1); continue
     if ln.startswith(".Lfunc_end"): cur = None
     if cur is None or want not in cur: continue
-    t = ln.strip()
+    t = ln.split(';')[0].strip() if not ln.strip().startswith(';') else ln.strip()
     if not t or t[0] in ";/" : continue
     if t.endswith(":"):
         if skip_until and t[:-1] == skip_until: skip_until = None
@@ -30,12 +30,13 @@ for ln in lines:
         # quantiser slow path (fallthrough body) is skipped; other execz regions are small
         tgt = t.split()[1]
         # only skip when the body contains v_div_scale (look ahead)
-        i = lines.index(ln)
+        i = li
         body = []
-        for l2 in lines[i + 1:]:
-            if l2.strip() == tgt + ":": break
+        found = False
+        for l2 in lines[i + 1:i + 3000]:
+            if l2.split(";")[0].strip() == tgt + ":": found = True; break
             body.append(l2)
-        if any("v_div_scale" in b for b in body): skip_until = tgt
+        if found and any("v_div_scale" in b for b in body): skip_until = tgt
 def cost(op, ln=None):
     if not op.startswith("v_"): return 0.0
     if op in FULL: return 2.1

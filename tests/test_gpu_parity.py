@@ -318,3 +318,44 @@ def test_config4_16384_image_on_one_gpu_matches_the_reference_file():
     blob = jpeg.encode_device(d_px, _opts(w, h, 2, 1, 80))
     assert len(blob) == 178548465
     assert hashlib.sha256(blob).hexdigest() == "77cc6cb69a782693c46f2024ac57ebfdfb8411148fa3cef62698c727af36c70c"
+
+
+def test_concurrent_calls_from_many_threads_give_the_serial_results():
+    """The reference's encode is re-entrant and its users call it from rayon workers: the
+    C ABI keeps its context (stream, buffers) per thread.  Twelve threads, each encoding its own
+    images with its own options (baseline, optimised tables, restart markers, preset 2, PNG filters),
+    repeatedly and at the same time (ctypes drops the GIL): every result equals the one computed
+    alone beforehand."""
+    import threading
+    from pixo_amd import png
+    jobs = []
+    for t in range(12):
+        w, h = 160 + 37 * t, 120 + 29 * (t % 5)
+        px = synth.noise(w, h, 100 + t)
+        b = jpeg.JpegOptions.builder(w, h).quality(40 + 5 * t).subsampling(jpeg.Subsampling(t & 1))
+        if t % 4 == 1: b = b.optimize_huffman(True)
+        if t % 4 == 2: b = b.restart_interval(5)
+        if t % 4 == 3: b = b.preset(2)
+        rgba = synth.lcg_bytes(w * h * 4, 7 + t)
+        jobs.append((px, b.build(), rgba, w, h))
+    expected = [(jpeg.encode(px, o), png.apply_filters(rgba, w, h, 4, png.FilterStrategy.ADAPTIVE)) for px, o, rgba, w, h in jobs]
+    errors = []
+    start = threading.Barrier(len(jobs))
+
+    def worker(i):
+        px, o, rgba, w, h = jobs[i]
+        try:
+            start.wait()
+            for _ in range(6):
+                if jpeg.encode(px, o) != expected[i][0]:
+                    errors.append((i, "jpeg"))
+                got = png.apply_filters(rgba, w, h, 4, png.FilterStrategy.ADAPTIVE)
+                if not (np.array_equal(got[0], expected[i][1][0]) and got[1] == expected[i][1][1]):
+                    errors.append((i, "png"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(jobs))]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors

@@ -144,8 +144,8 @@ int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_opti
 
 /* ---- PNG row filters + Adler-32 ------------------------------ */
 
-/* pixo::png::FilterStrategy in declaration order (src/png/mod.rs:345-364).  Bigrams is not
- * accelerated (PIXO_ERR_COMPRESSION). */
+/* pixo::png::FilterStrategy in declaration order (src/png/mod.rs:345-364); every strategy runs on the
+ * device. */
 enum pixo_png_filter_strategy {
     PIXO_PNG_NONE = 0, PIXO_PNG_SUB = 1, PIXO_PNG_UP = 2, PIXO_PNG_AVERAGE = 3, PIXO_PNG_PAETH = 4,
     PIXO_PNG_MINSUM = 5, PIXO_PNG_ADAPTIVE = 6, PIXO_PNG_ADAPTIVE_FAST = 7, PIXO_PNG_BIGRAMS = 8

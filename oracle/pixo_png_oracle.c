@@ -117,6 +117,39 @@ static void adaptive_fast(const uint8_t *row, const uint8_t *prev, size_t n, siz
     if (s < best) { out[0] = PO_F_PAETH; memcpy(out + 1, tmp, n); }
 }
 
+/* filter.rs:635-649 score_bigrams: number of distinct adjacent byte pairs of the filtered row */
+static uint64_t score_bigrams(const uint8_t *f, size_t n)
+{
+    static _Thread_local uint8_t seen[65536];
+    memset(seen, 0, sizeof seen);
+    uint64_t count = 0;
+    for (size_t i = 0; i + 1 < n; i++) {
+        const unsigned key = ((unsigned)f[i] << 8) | f[i + 1];
+        if (!seen[key]) { seen[key] = 1; count++; }
+    }
+    return count;
+}
+
+/* filter.rs:406-472 bigrams_filter: None, Sub, Up, Average, Paeth in this order, a later filter wins
+ * only with a strictly smaller count, no early exit */
+static void bigrams(const uint8_t *row, const uint8_t *prev, size_t n, size_t bpp, uint8_t *out, uint8_t *tmp)
+{
+    uint64_t best = score_bigrams(row, n), s; /* (< usize::MAX always) */
+    out[0] = PO_F_NONE; memcpy(out + 1, row, n);
+    f_sub(row, n, bpp, tmp);
+    s = score_bigrams(tmp, n);
+    if (s < best) { best = s; out[0] = PO_F_SUB; memcpy(out + 1, tmp, n); }
+    f_up(row, prev, n, tmp);
+    s = score_bigrams(tmp, n);
+    if (s < best) { best = s; out[0] = PO_F_UP; memcpy(out + 1, tmp, n); }
+    f_avg(row, prev, n, bpp, tmp);
+    s = score_bigrams(tmp, n);
+    if (s < best) { best = s; out[0] = PO_F_AVG; memcpy(out + 1, tmp, n); }
+    f_paeth(row, prev, n, bpp, tmp);
+    s = score_bigrams(tmp, n);
+    if (s < best) { out[0] = PO_F_PAETH; memcpy(out + 1, tmp, n); }
+}
+
 /* filter.rs:529-574 filter_row */
 static int filter_row(const uint8_t *row, const uint8_t *prev, size_t n, size_t bpp, int strategy, uint8_t *out, uint8_t *tmp)
 {
@@ -129,7 +162,8 @@ static int filter_row(const uint8_t *row, const uint8_t *prev, size_t n, size_t 
     case PO_S_MINSUM:
     case PO_S_ADAPTIVE: adaptive(row, prev, n, bpp, out, tmp); return 0;
     case PO_S_ADAPTIVE_FAST: adaptive_fast(row, prev, n, bpp, out, tmp); return 0;
-    default: return -1; /* Bigrams: not restated */
+    case PO_S_BIGRAMS: bigrams(row, prev, n, bpp, out, tmp); return 0;
+    default: return -1;
     }
 }
 

@@ -812,8 +812,6 @@ int png_plan(uint32_t width, uint32_t height, uint32_t bpp, uint8_t strategy, ui
     const uint64_t area = static_cast<uint64_t>(width) * height;
     const bool adaptive = s == PIXO_PNG_ADAPTIVE || s == PIXO_PNG_ADAPTIVE_FAST || s == PIXO_PNG_BIGRAMS;
     if (area <= 4096 && adaptive) s = PIXO_PNG_SUB; // src/png/filter.rs:76-86
-    if (s == PIXO_PNG_BIGRAMS)
-        return fail(PIXO_ERR_COMPRESSION, "Compression error: the Bigrams filter strategy is not implemented by the HIP backend");
     // the stateful AdaptiveFast runs wherever the reference does not take its rayon path (:94-112)
     *sequential_fast = s == PIXO_PNG_ADAPTIVE_FAST && ((flags & PIXO_PNG_NO_RAYON) || height <= 32);
     *run = s;

@@ -200,6 +200,7 @@ struct Args {
     uint32_t height, first_row;
     int strategy;
     uint32_t stage_bytes; // dynamic LDS for the staged write-out, 0 = rows too long: direct stores
+    uint32_t bitmap_off;  // Bigrams: byte offset of the 8 KiB "pair seen" bitmap inside the dynamic LDS
 };
 
 // Pass 2 for filter F.  The output row starts at byte y * (n + 1) of the stream — a different
@@ -267,8 +268,51 @@ __device__ __forceinline__ void write_row(const Args &a, uint32_t y, const uint8
     }
 }
 
-template <int BPP, bool FAST> __global__ __launch_bounds__(kThreads) void png_filter_kernel(const Args a)
+// Bigrams (filter.rs:406-472, score_bigrams :635-649): the score of a candidate is the number of DISTINCT
+// adjacent byte pairs of the filtered row.  A 65536-bit "seen" bitmap in LDS, one atomic OR per pair
+// (any one-to-one pair -> bit mapping counts the same: the little-endian halfword at each byte
+// position), then a population count.  The pair that straddles two 16-byte groups needs the next
+// group's first filtered dword: recomputed by the same thread (its loads hit the cache lines the
+// neighbouring thread fetches anyway) — no cross-thread exchange, no staging of the row.
+template <int BPP, bool FAST, int F, int NEED>
+__device__ __forceinline__ unsigned long long bigram_score(const uint8_t *row, const uint8_t *prev, int n, uint32_t *bitmap,
+                                                           unsigned long long *red)
 {
+    for (int i = threadIdx.x; i < 2048; i += kThreads) bitmap[i] = 0;
+    __syncthreads();
+    const int ndw = (n + 3) / 4, per_iter = kThreads * 4;
+    for (int k0 = (int)threadIdx.x * 4; k0 < ndw; k0 += per_iter) {
+        Group g;
+        load_group<BPP, FAST, NEED>(row, prev, k0, n, g);
+        uint32_t v[5];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = filtered(F, g, j);
+        v[4] = 0;
+        if (k0 + 4 < ndw) {
+            Group h;
+            load_group<BPP, FAST, NEED>(row, prev, k0 + 4, n, h);
+            v[4] = filtered(F, h, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int lim = n - 1 - 4 * (k0 + j); // pairs that START in this dword and end inside the row
+            const uint32_t key[4] = {v[j] & 0xFFFFu, (v[j] >> 8) & 0xFFFFu, v[j] >> 16, (v[j] >> 24) | ((v[j + 1] & 0xFFu) << 8)};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (i < lim) atomicOr(&bitmap[key[i] >> 5], 1u << (key[i] & 31u));
+        }
+    }
+    __syncthreads();
+    unsigned count = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) count += __builtin_popcount(bitmap[threadIdx.x * 8 + i]);
+    return wg_sum(count, red);
+}
+
+// BIGRAMS is a separate instantiation: its scoring pass needs ~110 registers, the others 44.
+template <int BPP, bool FAST, bool BIGRAMS> __global__ __launch_bounds__(kThreads) void png_filter_kernel(const Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
     __shared__ unsigned long long red[4];
     // Workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2: rows are
     // handed out in chunks of 32 consecutive rows per XCD, so that the row above — the neighbouring
@@ -286,7 +330,20 @@ template <int BPP, bool FAST> __global__ __launch_bounds__(kThreads) void png_fi
     int strategy = a.forced ? *a.forced : a.strategy;
 
     int f = strategy;
-    if (strategy > PNG_S_PAETH) {
+    if (BIGRAMS) {
+        uint32_t *bitmap = reinterpret_cast<uint32_t *>(stage + a.bitmap_off);
+        unsigned long long tot[5];
+        tot[F_NONE] = bigram_score<BPP, FAST, F_NONE, 0>(row, prev, n, bitmap, red);
+        tot[F_SUB] = bigram_score<BPP, FAST, F_SUB, 1>(row, prev, n, bitmap, red);
+        tot[F_UP] = bigram_score<BPP, FAST, F_UP, 2>(row, prev, n, bitmap, red);
+        tot[F_AVG] = bigram_score<BPP, FAST, F_AVG, 3>(row, prev, n, bitmap, red);
+        tot[F_PAETH] = bigram_score<BPP, FAST, F_PAETH, 7>(row, prev, n, bitmap, red);
+        f = F_NONE; // in this order, a later filter wins only with strictly fewer pairs, no early exit
+#pragma unroll
+        for (int c = F_SUB; c <= F_PAETH; c++)
+            if (tot[c] < tot[f]) f = c;
+        __syncthreads(); // the write-out below reuses the dynamic LDS
+    } else if (strategy > PNG_S_PAETH) {
         // pass 1: scores of the candidates (AdaptiveFast never looks at None / Average)
         uint32_t sc[5] = {0, 0, 0, 0, 0};
         const bool fast = strategy == PNG_S_ADAPTIVE_FAST;
@@ -331,8 +388,12 @@ template <int BPP, bool FAST> __global__ __launch_bounds__(kThreads) void png_fi
 
 template <int BPP> hipError_t launch_bpp(const Args &a, uint32_t rows, bool fast, hipStream_t s)
 {
-    if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
-    else hipLaunchKernelGGL((png_filter_kernel<BPP, false>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
+    if (a.strategy == PNG_S_BIGRAMS) {
+        const uint32_t lds = a.stage_bytes + 8192u;
+        if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, true>), dim3(rows), dim3(kThreads), lds, s, a);
+        else hipLaunchKernelGGL((png_filter_kernel<BPP, false, true>), dim3(rows), dim3(kThreads), lds, s, a);
+    } else if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, false>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
+    else hipLaunchKernelGGL((png_filter_kernel<BPP, false, false>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
     return hipGetLastError();
 }
 
@@ -366,6 +427,7 @@ hipError_t launch_png_filter(const void *d_data, uint32_t width, uint32_t height
     // 4 KiB iterations, 16 bytes of slack for the fifth dword of the last chunk
     const uint64_t stage = 16 + ((a.row_bytes + 15) & ~15ull) + 32;
     a.stage_bytes = stage <= 48 * 1024 ? (uint32_t)stage : 0u;
+    a.bitmap_off = a.stage_bytes;
     a.forced = nullptr; a.winner0 = nullptr; a.first_row = 0;
     const bool fast = reinterpret_cast<uintptr_t>(d_data) % 4 == 0 && a.row_bytes % 4 == 0;
     if (strategy == PNG_S_ADAPTIVE_FAST && sequential_fast && height > 1) {

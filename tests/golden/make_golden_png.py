@@ -9,7 +9,8 @@ under tests/golden/png/.  Build container only (needs node + the staged wasm).
 
 Presets (png/mod.rs:129-183): 0 = AdaptiveFast (sequential, stateful in this build), no
 reductions; 1 = Adaptive + optimize_alpha + colour/palette reduction — inputs are chosen so that
-those leave the pixels alone (alpha never 0, > 256 colours, not gray, not opaque).
+those leave the pixels alone (alpha never 0, > 256 colours, not gray, not opaque); 2 = Bigrams with the
+same reductions (and the slow optimal DEFLATE, so only small images).
 
     python tests/golden/make_golden_png.py [--huge]     # --huge adds 4096x4096 RGBA (10 s, 0.7 GB)
 """
@@ -70,6 +71,9 @@ def cases(huge=False):
         if preset == 0:
             add("noise", 17, 9, 3, preset, 5)        # (preset 1 would palettise 153 pixels)
         add("noise", 1024, 40, 3, preset, 11)
+    # preset 2: FilterStrategy::Bigrams (png/mod.rs:179)
+    add("noise", 128, 96, 3, 2); add("noise", 131, 67, 3, 2, 7); add("gradient", 160, 80, 3, 2); add("gradient", 320, 200, 2, 2)
+    add("noise", 97, 83, 2, 2, 3); add("noise", 64, 64, 3, 2, 5); add("noise", 70, 70, 3, 2, 5); add("noise", 1024, 40, 3, 2, 11)
     add("noise", 300, 200, 0, 0, 9); add("noise", 300, 200, 1, 0, 9)   # gray, gray+alpha through preset 0
     add("flat", 256, 256, 2, 0)
     add("noise", 1920, 1080, 3, 1)

@@ -28,8 +28,9 @@ BPP = {0: 1, 1: 2, 2: 3, 3: 4}
 def test_reference_made_vectors(c):
     px = MG.make_input(c)
     bpp = BPP[c["color_type"]]
-    # preset 0: AdaptiveFast of the wasm build (no rayon -> sequential, stateful); preset 1: Adaptive
-    strategy, flags = (png.FilterStrategy.ADAPTIVE_FAST, png.NO_RAYON) if c["preset"] == 0 else (png.FilterStrategy.ADAPTIVE, 0)
+    # preset 0: AdaptiveFast of the wasm build (no rayon -> sequential, stateful); 1: Adaptive; 2: Bigrams
+    strategy, flags = {0: (png.FilterStrategy.ADAPTIVE_FAST, png.NO_RAYON), 1: (png.FilterStrategy.ADAPTIVE, 0),
+                       2: (png.FilterStrategy.BIGRAMS, 0)}[c["preset"]]
     flt, adler = png.apply_filters(px, c["w"], c["h"], bpp, strategy, flags)
     row = c["w"] * bpp + 1
     assert "".join(str(int(f)) for f in flt[::row]) == c["filters"]
@@ -38,7 +39,7 @@ def test_reference_made_vectors(c):
 
 
 @pytest.mark.parametrize("bpp", [1, 2, 3, 4, 6, 8])
-@pytest.mark.parametrize("strategy", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("strategy", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_every_strategy_and_pixel_size_against_the_oracle(bpp, strategy):
     for (w, h, seed) in [(67, 41, 1), (256, 40, 2), (1000, 35, 3), (5, 900, 4), (1, 70, 5), (4100, 33, 6)]:
         px = synth.lcg_bytes(w * h * bpp, seed + bpp)
@@ -54,7 +55,7 @@ def test_small_images_and_sequential_adaptive_fast():
     # <= 4096 pixels: adaptive strategies become Sub; height <= 32: AdaptiveFast is the stateful variant
     for (w, h) in [(64, 64), (10, 3), (300, 32), (300, 33), (2000, 2)]:
         px = synth.lcg_bytes(w * h * 4, w)
-        for strategy in (6, 7):
+        for strategy in (6, 7, 8):
             want, wad = O.png_filter(px, w, h, 4, strategy, stateful_fast=(h <= 32))
             got, gad = png.apply_filters(px, w, h, 4, strategy)
             assert np.array_equal(got, want) and gad == wad, (w, h, strategy)
@@ -72,8 +73,32 @@ def test_device_pointers_unaligned_rows_and_errors():
     assert np.array_equal(d_out.cpu().numpy(), want) and adler == wad
     from pixo_amd import Error
     with pytest.raises(Error):
-        png.apply_filters(px, w, h, bpp, png.FilterStrategy.BIGRAMS)
+        png.apply_filters(px, w, h, bpp, 9)  # no such strategy
     with pytest.raises(Error):
         png.apply_filters(px[:-1], w, h, bpp)
     with pytest.raises(Error):
         png.apply_filters(px, w, h, 5)
+
+
+def test_bigrams_on_long_rows_structured_content_and_the_c5_shape():
+    """Bigrams (preset "max"): rows longer than the LDS stage (direct stores), rows whose byte pairs
+    repeat heavily (few distinct pairs: ties between filters decide), a 2-byte row (one pair), a
+    1-byte row (no pair at all: every score 0, None wins) and the 4096x4096 RGBA shape of config 5."""
+    rng = np.random.RandomState(3)
+    shapes = [(20000, 34, 4), (2, 2100, 1), (1, 5000, 1), (700, 40, 3), (4096, 64, 4)]
+    for (w, h, bpp) in shapes:
+        for kind in range(3):
+            if kind == 0:
+                px = synth.lcg_bytes(w * h * bpp, w + kind)
+            elif kind == 1:
+                px = np.tile(rng.randint(0, 256, 7).astype(np.uint8), w * h * bpp // 7 + 1)[: w * h * bpp].copy()
+            else:
+                px = (np.cumsum(synth.lcg_bytes(w * h * bpp, 9).astype(np.int64) % 3) % 256).astype(np.uint8)
+            want, wad = O.png_filter(px, w, h, bpp, O.S_BIGRAMS)
+            got, gad = png.apply_filters(px, w, h, bpp, png.FilterStrategy.BIGRAMS)
+            assert np.array_equal(got, want) and gad == wad, (w, h, bpp, kind)
+    w = h = 4096
+    px = synth.lcg_bytes(w * h * 4, 42)
+    want, wad = O.png_filter(px, w, h, 4, O.S_BIGRAMS)
+    got, gad = png.apply_filters(px, w, h, 4, png.FilterStrategy.BIGRAMS)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest() and gad == wad

@@ -22,8 +22,8 @@ BPP = {0: 1, 1: 2, 2: 3, 3: 4}
 
 def run_case(c, fn):
     px = MG.make_input(c)
-    # preset 0 = AdaptiveFast as a build without rayon runs it (stateful); preset 1 = Adaptive
-    strategy, stateful = (O.S_ADAPTIVE_FAST, True) if c["preset"] == 0 else (O.S_ADAPTIVE, False)
+    # preset 0 = AdaptiveFast as a build without rayon runs it (stateful); 1 = Adaptive; 2 = Bigrams
+    strategy, stateful = {0: (O.S_ADAPTIVE_FAST, True), 1: (O.S_ADAPTIVE, False), 2: (O.S_BIGRAMS, False)}[c["preset"]]
     flt, adler = fn(px, c["w"], c["h"], BPP[c["color_type"]], strategy, stateful)
     row = c["w"] * BPP[c["color_type"]] + 1
     assert "".join(str(int(f)) for f in flt[::row]) == c["filters"]

@@ -10,7 +10,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pixo_hip.h"
@@ -356,12 +358,44 @@ int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_
     return PIXO_OK;
 }
 
+// Copies into FRESH host memory are page-fault bound (one core maps and fills a few GB/s of new pages):
+// above a few MB the bytes are spread over a handful of threads (PIXO_HIP_COPY_THREADS, default 8; 1 = none).
+unsigned copy_threads()
+{
+    static const unsigned n = [] {
+        const char *e = std::getenv("PIXO_HIP_COPY_THREADS");
+        const long v = e ? std::atol(e) : 8;
+        return static_cast<unsigned>(v < 1 ? 1 : (v > 64 ? 64 : v));
+    }();
+    return n;
+}
+template <class F> void run_on_threads(unsigned t, F &&body) // body(index) for index in [0, t)
+{
+    if (t <= 1) { body(0u); return; }
+    std::vector<std::thread> workers;
+    workers.reserve(t - 1);
+    for (unsigned i = 1; i < t; ++i) workers.emplace_back([&body, i] { body(i); });
+    body(0u);
+    for (auto &w : workers) w.join();
+}
+void big_copy(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    constexpr size_t kSlice = size_t{1} << 20;
+    const size_t slices = (n + kSlice - 1) / kSlice;
+    const unsigned t = static_cast<unsigned>(std::min<size_t>(copy_threads(), slices / 2));
+    if (t <= 1) { std::memcpy(dst, src, n); return; }
+    run_on_threads(t, [&](unsigned i) {
+        const size_t a = slices * i / t * kSlice, b = std::min(n, slices * (i + 1) / t * kSlice);
+        if (b > a) std::memcpy(dst + a, src + a, b - a);
+    });
+}
+
 // ... and into memory the caller owns: a fresh malloc block, or storage it supplied
 int deliver(const uint8_t *file, size_t n, uint8_t **out, size_t *out_len)
 {
     uint8_t *p = static_cast<uint8_t *>(std::malloc(n ? n : 1));
     if (!p) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
-    std::memcpy(p, file, n);
+    big_copy(p, file, n);
     *out = p;
     *out_len = n;
     return PIXO_OK;
@@ -557,7 +591,7 @@ int hand_over(const std::vector<uint8_t> &v, uint8_t **out, size_t *out_len)
 {
     uint8_t *p = static_cast<uint8_t *>(std::malloc(v.size() ? v.size() : 1));
     if (!p) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
-    std::memcpy(p, v.data(), v.size());
+    big_copy(p, v.data(), v.size());
     *out = p;
     *out_len = v.size();
     return PIXO_OK;
@@ -952,14 +986,22 @@ int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_opti
     std::vector<uint64_t> starts;
     if ((rc = device_entropy_to_pinned(dy, dcb, dcr, o, g, c->stream, &blob, &blob_len, batch, &starts, &hdr))) return rc;
     for (uint32_t i = 0; i < batch; ++i) {
-        const size_t seg = static_cast<size_t>(starts[i + 1] - starts[i]), n = hdr + seg + 2;
-        uint8_t *p = static_cast<uint8_t *>(std::malloc(n));
-        if (!p) return release(fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory"));
-        std::memcpy(p, blob, hdr);
-        std::memcpy(p + hdr, blob + hdr + starts[i], seg);
-        p[hdr + seg] = 0xFF; p[hdr + seg + 1] = 0xD9;
-        files[i] = p; lens[i] = n;
+        lens[i] = hdr + static_cast<size_t>(starts[i + 1] - starts[i]) + 2;
+        files[i] = static_cast<uint8_t *>(std::malloc(lens[i]));
+        if (!files[i]) return release(fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory"));
     }
+    // headers + own segment + EOI into every file; the files are fresh memory: several threads (see big_copy)
+    const size_t total = blob_len + static_cast<size_t>(batch) * hdr;
+    const unsigned t = static_cast<unsigned>(std::min<size_t>(std::min<size_t>(copy_threads(), batch), total >> 21));
+    run_on_threads(t ? t : 1, [&](unsigned k) {
+        for (uint32_t i = k; i < batch; i += (t ? t : 1)) {
+            const size_t seg = lens[i] - hdr - 2;
+            uint8_t *p = files[i];
+            std::memcpy(p, blob, hdr);
+            std::memcpy(p + hdr, blob + hdr + starts[i], seg);
+            p[hdr + seg] = 0xFF; p[hdr + seg + 1] = 0xD9;
+        }
+    });
     return PIXO_OK;
 }
 

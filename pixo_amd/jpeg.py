@@ -23,6 +23,7 @@ import numpy as np
 
 from . import _lib
 from .color import ColorType
+from . import error
 from .error import from_status
 
 
@@ -159,6 +160,27 @@ def encode_into(output: bytearray, data, options: JpegOptions) -> None:
     blob = encode(data, options)
     del output[:]
     output += blob
+
+
+def encode_into_buffer(buffer: np.ndarray, data, options: JpegOptions) -> int:
+    """The fixed-capacity form of `encode_into` (`pixo_hip_jpeg_encode_into`): writes the file into the
+    caller's uint8 array and returns its length.  Raises `error.BufferTooSmall` (its `.needed` says how
+    many bytes the file has) without touching `buffer` when it does not fit — the reserve-and-retry
+    protocol a Rust `Vec` would use."""
+    L = _lib.load()
+    px = _as_u8(data)
+    if buffer.dtype != np.uint8 or not buffer.flags["C_CONTIGUOUS"]:
+        raise TypeError("buffer must be a contiguous uint8 array")
+    n = C.c_size_t()
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_encode_into(buffer.ctypes.data, buffer.size, px.ctypes.data, px.size, C.byref(oc), C.byref(n))
+    if rc:
+        try:
+            _raise(rc)
+        except error.BufferTooSmall as e:
+            e.needed = n.value
+            raise
+    return n.value
 
 
 def encode_jpeg(data, width, height, color_type, quality, preset, subsampling_420) -> bytes:

@@ -359,3 +359,27 @@ def test_concurrent_calls_from_many_threads_give_the_serial_results():
     for t in threads: t.start()
     for t in threads: t.join()
     assert not errors, errors
+
+
+def test_encode_into_caller_storage_and_the_reserve_and_retry_protocol():
+    """pixo_hip_jpeg_encode_into: the file lands in the caller's buffer; a buffer that is too small is
+    left untouched, the call reports the needed size, and the retry with that size succeeds.  Every
+    flavour of file (baseline, optimised tables, restart markers, progressive + trellis)."""
+    from pixo_amd import error
+    w, h = 321, 203
+    px = synth.noise(w, h, 9)
+    B = jpeg.JpegOptions.builder
+    for o in (B(w, h).quality(77).subsampling(jpeg.Subsampling.S420).build(),
+              B(w, h).quality(60).optimize_huffman(True).build(),
+              B(w, h).quality(60).restart_interval(3).build(),
+              B(w, h).quality(85).preset(2).build()):
+        want = jpeg.encode(px, o)
+        small = np.full(len(want) - 1, 0xA5, np.uint8)
+        with pytest.raises(error.BufferTooSmall) as ei:
+            jpeg.encode_into_buffer(small, px, o)
+        assert ei.value.needed == len(want) and (small == 0xA5).all()
+        buf = np.zeros(ei.value.needed + 7, np.uint8)
+        n = jpeg.encode_into_buffer(buf, px, o)
+        assert n == len(want) and buf[:n].tobytes() == want and not buf[n:].any()
+    with pytest.raises(error.InvalidQuality):
+        jpeg.encode_into_buffer(np.zeros(10, np.uint8), px, B(w, h).quality(0).build())

@@ -31,8 +31,11 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 me
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--settle-ms", type=float, default=100.0,
+                    help="untimed launches before the warmup steps until this much wall time has passed: after an idle "
+                         "period the GPU needs ~20 ms of work to reach its steady clocks (tools/warmup_probe.py); 0 = none")
     ap.add_argument("--workload", default="c2", choices=["c2", "c2_444", "c3", "c1", "c5"],
                     help="c2: 4096x4096 4:2:0 (the metric); c2_444; c3: 64x1920x1080 batch; c1: 512x512")
     ap.add_argument("--quality", type=int, default=80)
@@ -48,6 +51,19 @@ WORKLOADS = {
     "c3": (1920, 1080, 64, 1, "configs[2]: batch of 64 x 1920x1080 RGB8, q=80, 4:2:0, one launch"),
     "c1": (512, 512, 1, 1, "configs[0] shape on the GPU: 512x512 RGB8, q=80, 4:2:0"),
 }
+
+
+def settle(step, ms):
+    """Untimed: keep the GPU busy for `ms` so that the W warmup steps and the K timed steps run at steady clocks
+    (a kernel of this size runs 15-35 % slower during the first ~20 ms after an idle period).  Returns the launches."""
+    import torch
+    n = 0
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(64):
+            step(n); n += 1
+        torch.cuda.synchronize()
+    return n
 
 
 def cpu_baseline(w, h, ss, quality, budget_s):
@@ -154,6 +170,7 @@ def bench_png(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    settled = settle(step, args.settle_ms)
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -195,7 +212,8 @@ def bench_png(args):
             "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[4]: 4096x4096 RGBA8, FilterStrategy::Adaptive, rows independent", "width": w, "height": h,
-                       "buffers_rotated": nbuf, "parallelism": "one process per GPU, images sharded across ranks, no collective"},
+                       "buffers_rotated": nbuf, "settle_launches_before_warmup": settled,
+                       "parallelism": "one process per GPU, images sharded across ranks, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "kernel": "png_filter_kernel<4, true>",
                          "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3)}}
@@ -270,6 +288,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    settled = settle(step, args.settle_ms)
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -335,6 +354,7 @@ def main():
         "config": {"workload": label, "width": w, "height": h, "batch": batch, "quality": q,
                    "subsampling": "4:2:0" if ss else "4:4:4", "buffers_rotated": nbuf,
                    "working_set_MiB": round(nbuf * (in_bytes + out_bytes) / 2**20, 1),
+                   "settle_launches_before_warmup": settled,
                    "parallelism": "one process per GPU, images sharded across ranks, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,

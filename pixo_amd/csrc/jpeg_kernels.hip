@@ -205,15 +205,28 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
         return;
     }
     uint8_t *stage = lds + stage_offset<MODE>(wave); // inside this wavefront's own planar area
+#ifdef PIXO_HALF_BLOCK_STORES // (timing experiments only: the previous write-out, 64-byte half blocks)
     consumer_quant_half<MODE>(wave, lane, a.qt, v, 0, stage);
-#if !defined(PIXO_ABLATE) || (PIXO_ABLATE != 4 && PIXO_ABLATE != 6 && PIXO_ABLATE != 7) // (4, 6, 7: no stores — one guarded store keeps the work alive)
+    consumer_stage_sync();
     consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 0, stage);
-#endif
+    consumer_stage_sync();
     consumer_quant_half<MODE>(wave, lane, a.qt, v, 1, stage);
-#if !defined(PIXO_ABLATE) || (PIXO_ABLATE != 4 && PIXO_ABLATE != 6 && PIXO_ABLATE != 7)
+    consumer_stage_sync();
     consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 1, stage);
 #else
-    if (*(volatile uint32_t *)(stage + lane * 4) == 0x12345678u) consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 1, stage);
+    uint32_t qw[32];
+    consumer_quant<MODE>(wave, lane, a.qt, v, qw);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        consumer_stage_blocks(lane, h, qw, stage);
+        consumer_stage_sync();
+#if !defined(PIXO_ABLATE) || (PIXO_ABLATE != 4 && PIXO_ABLATE != 6 && PIXO_ABLATE != 7) // (4, 6, 7: no stores — one guarded store keeps the work alive)
+        consumer_store_blocks<MODE>(c, id.tx, id.ty, wave, lane, h, stage);
+#else
+        if (*(volatile uint32_t *)(stage + lane * 4) == 0x12345678u) consumer_store_blocks<MODE>(c, id.tx, id.ty, wave, lane, h, stage);
+#endif
+        consumer_stage_sync();
+    }
 #endif
 #ifdef PIXO_TIMING
     if (lane == 0 && a.dbg) {

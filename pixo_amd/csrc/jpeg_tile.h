@@ -46,6 +46,7 @@
 #include <string.h>
 #define PIXO_DEV static inline
 #define PIXO_SCHED_FENCE() ((void)0)
+#define PIXO_WAVE_SYNC() ((void)0)
 #define PIXO_PIN(x) ((void)0)
 #define PIXO_CONST_AS
 #else
@@ -53,6 +54,13 @@
 // Stops the machine scheduler from interleaving independent 1-D transforms (which keeps the
 // temporaries of many rows/columns alive at once).
 #define PIXO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Lanes of a wavefront exchange data through LDS without a workgroup barrier (stage written by block,
+// read back by chunk): the hardware runs them in lockstep and keeps a wavefront's LDS operations in
+// order, but the COMPILER reasons per thread — without this fence it forwarded a value a lane had
+// loaded earlier past stores that only OTHER lanes execute (hipcc 7.2, seen on the 4:4:4 kernel).
+// Wavefront-scope release/acquire: no instruction, only the ordering.
+#define PIXO_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 // Materialises a value here: stops LLVM from sinking the column pass into the quantiser's
 // basic blocks (which kept every column's butterflies alive across them).
 #define PIXO_PIN(x) asm volatile("" : "+v"(x))
@@ -743,6 +751,113 @@ PIXO_DEV void consumer_store_half(const TileCtx &c, uint32_t tile_x, uint32_t ti
     const bool inside = nvalid == (uint32_t)G::units_x && (MODE != MGRAY || tile_y * 3 + wave < c.units_y);
     if (MODE != M444 && inside) store_half_body<MODE, false>(c, u0, nvalid, tile_y, wave, lane, half, stage);
     else store_half_body<MODE, true>(c, u0, nvalid, tile_y, wave, lane, half, stage);
+}
+
+// ---------------------------------------------------------------------------------
+// Whole-block write-out (what the kernel runs; the half-block steps above remain for the
+// PIXO_HALF_BLOCK_STORES timing build).  Two 64-byte halves of a 128-byte block stored a microsecond
+// apart cost HBM 20 % of its throughput (tools/ubench/tile_copy.hip: 22.1 us against 18.0 us for
+// the same bytes as whole lines), and the 4 KiB stage of a wavefront holds only 32 whole blocks.
+// So the lane quantises its whole block into 32 registers (the 64 floats die as it goes), and the
+// wavefront writes out in two rounds: lanes [32 h, 32 h + 32) put their blocks into the stage, all
+// 64 lanes read them back as 16-byte chunks — eight consecutive lanes = one block — and every
+// store instruction writes 1 KiB of consecutive bytes.
+// ---------------------------------------------------------------------------------
+// Chunk (block bl in 0..31, row r in 0..7) lives at 128 bl + 16 ((r ^ bl) & 7): the eight lanes a
+// ds_write_b128 group serves (consecutive blocks, same row) and the eight lanes of a read-back group
+// (same block, rows 0..7) each touch all eight 16-byte slots of a 128-byte bank window.
+PIXO_DEV int stage_addr_block(int bl, int r) { return bl * 128 + (((r ^ bl) & 7) << 4); }
+
+// Consumer step 3': quantise the lane's block, row r -> out[4 r .. 4 r + 3] (packed i16 pairs).
+PIXO_DEV void block_quant(const float *v, qtab_t rcp, qtab_t q, float scale, uint32_t *out)
+{
+    float rc[8], rn[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) rc[c] = rcp[c];
+    PIXO_SCHED_FENCE();
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        if (u < 7) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) rn[c] = rcp[(u + 1) * 8 + c];
+            PIXO_SCHED_FENCE();
+        }
+        quant_row8(&v[u * 8], rc, q + u * 8, scale, &out[u * 4]);
+        // the row's four result registers exist from here on (and its eight floats are dead)
+        PIXO_PIN(out[u * 4]); PIXO_PIN(out[u * 4 + 1]); PIXO_PIN(out[u * 4 + 2]); PIXO_PIN(out[u * 4 + 3]);
+        PIXO_SCHED_FENCE();
+#pragma unroll
+        for (int c = 0; c < 8; c++) rc[c] = rn[c];
+    }
+}
+template <int MODE> PIXO_DEV void consumer_quant(int wave, int lane, const float *qt, const float *v, uint32_t *out)
+{
+    const BlockDesc d = block_desc<MODE>(wave, lane, nullptr);
+    const qtab_t tab = as_qtab(qt);
+    block_quant(v, tab + uniform_i32(d.rcp_off), tab + uniform_i32(d.q_off), d.scale, out);
+}
+
+// Consumer step 4' (round h = 0, 1): the lanes of half h stage their blocks.
+PIXO_DEV void consumer_stage_blocks(int lane, int h, const uint32_t *qw, uint8_t *stage_wave)
+{
+    if ((lane >> 5) != h) return;
+    const int bl = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        u32x4 o;
+        o.x = qw[4 * r]; o.y = qw[4 * r + 1]; o.z = qw[4 * r + 2]; o.w = qw[4 * r + 3];
+        *(u32x4 *)(stage_wave + stage_addr_block(bl, r)) = o;
+    }
+}
+// (every lane, between the staging of a round and its read-back, and again before the next round)
+PIXO_DEV void consumer_stage_sync() { PIXO_WAVE_SYNC(); }
+
+// Consumer step 5' (round h): the 32 staged blocks -> HBM.  Lane l of instruction k moves chunk
+// 64 k + l = (block 8 k + l / 8, row l % 8).
+template <int MODE, bool GUARD>
+PIXO_DEV void store_blocks_body(const TileCtx &c, uint32_t u0, uint32_t nvalid, uint32_t tile_y, int wave, int lane,
+                                int h, const uint8_t *stage_wave)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int ch = k * 64 + lane, sb = ch >> 3, j = ch & 7, bl = h * 32 + sb; // bl: block of the wave
+        const u32x4 w = *(const u32x4 *)(stage_wave + stage_addr_block(sb, j));
+        if (MODE == M420) {
+            const size_t mcu0 = (size_t)tile_y * c.units_x + u0;
+            if (wave < 2) {
+                if (!GUARD || (uint32_t)(wave * 16 + (bl >> 2)) < nvalid)
+                    PIXO_GSTORE(c.y + (mcu0 * 4 + wave * 64 + bl) * 64 + j * 8, w);
+            } else { // round 0: the 32 Cb blocks, round 1: the 32 Cr blocks
+                int16_t *dst = (h == 0 ? c.cb : c.cr) + (mcu0 + sb) * 64 + j * 8;
+                if (!GUARD || (uint32_t)sb < nvalid) PIXO_GSTORE(dst, w);
+            }
+        } else if (MODE == M444) {
+            const size_t blk0 = (size_t)tile_y * c.units_x + u0;
+            // (wave-uniform branches inside a lane-divergent guard, see store_half_body)
+            const size_t off = (blk0 + bl) * 64 + j * 8;
+            if ((uint32_t)bl < nvalid) {
+                if (wave == 0) PIXO_GSTORE(c.y + off, w);
+                else if (wave == 1) PIXO_GSTORE(c.cb + off, w);
+                else PIXO_GSTORE(c.cr + off, w);
+            }
+        } else {
+            const uint32_t brow = tile_y * 3 + wave;
+            if (!GUARD || ((uint32_t)bl < nvalid && brow < c.units_y))
+                PIXO_GSTORE(c.y + ((size_t)brow * c.units_x + u0 + bl) * 64 + j * 8, w);
+        }
+    }
+}
+
+template <int MODE>
+PIXO_DEV void consumer_store_blocks(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int wave, int lane, int h,
+                                    const uint8_t *stage)
+{
+    typedef Geo<MODE> G;
+    const uint32_t u0 = tile_x * G::units_x;
+    const uint32_t nvalid = c.units_x - u0 < (uint32_t)G::units_x ? c.units_x - u0 : G::units_x;
+    const bool inside = nvalid == (uint32_t)G::units_x && (MODE != MGRAY || tile_y * 3 + wave < c.units_y);
+    if (MODE != M444 && inside) store_blocks_body<MODE, false>(c, u0, nvalid, tile_y, wave, lane, h, stage);
+    else store_blocks_body<MODE, true>(c, u0, nvalid, tile_y, wave, lane, h, stage);
 }
 
 } // namespace pixo_tile

@@ -40,9 +40,12 @@ static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long
                 // lane starts the next (the stage is written by block and read back by chunk)
                 for (int l = 0; l < 64; l++) consumer_rows<MODE>(w, l, planar, &v[(w * 64 + l) * 64]);
                 for (int l = 0; l < 64; l++) consumer_cols(&v[(w * 64 + l) * 64]);
-                for (int half = 0; half < 2; half++) {
-                    for (int l = 0; l < 64; l++) consumer_quant_half<MODE>(w, l, c.qt, &v[(w * 64 + l) * 64], half, lds + stage_offset<MODE>(w));
-                    for (int l = 0; l < 64; l++) consumer_store_half<MODE>(c, tx, ty, w, l, half, lds + stage_offset<MODE>(w));
+                // the shipped write-out: whole block into registers, two rounds of 32 blocks through the stage
+                static thread_local uint32_t qw[64 * 32];
+                for (int l = 0; l < 64; l++) consumer_quant<MODE>(w, l, c.qt, &v[(w * 64 + l) * 64], &qw[l * 32]);
+                for (int h = 0; h < 2; h++) {
+                    for (int l = 0; l < 64; l++) consumer_stage_blocks(l, h, &qw[l * 32], lds + stage_offset<MODE>(w));
+                    for (int l = 0; l < 64; l++) consumer_store_blocks<MODE>(c, tx, ty, w, l, h, lds + stage_offset<MODE>(w));
                 }
             }
         }

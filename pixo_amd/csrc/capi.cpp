@@ -568,11 +568,9 @@ int progressive_to_vector(const void *d_pixels, const pixo_jpeg_options &o, cons
         dy = static_cast<int16_t *>(c.d_coef); dcb = dy + g.y_blocks * 64; dcr = dcb + g.c_blocks * 64;
         HIP_TRY(pd::launch_jpeg_coeffs(d_pixels, o.width, o.height, g.gray, g.s420, 1, ry, g.gray ? nullptr : rcb,
                                        g.gray ? nullptr : rcr, qt, c.stream, /*raw_f32=*/true));
-        // (the three launches run back to back on one stream: they can share the back-pointer scratch)
-        HIP_TRY(c.t_trail.reserve(pd::trellis_scratch_bytes(g.y_blocks)));
-        HIP_TRY(pd::launch_trellis(ry, qt + 128, dy, g.y_blocks, c.t_trail.p, c.stream));   // luminance steps
-        HIP_TRY(pd::launch_trellis(rcb, qt + 192, dcb, g.c_blocks, c.t_trail.p, c.stream)); // chrominance steps
-        HIP_TRY(pd::launch_trellis(rcr, qt + 192, dcr, g.c_blocks, c.t_trail.p, c.stream));
+        // one launch over the whole tuple (the planes are contiguous): luminance steps, then chrominance steps
+        HIP_TRY(c.t_trail.reserve(pd::trellis_scratch_bytes(blocks)));
+        HIP_TRY(pd::launch_trellis(ry, qt + 128, qt + 192, dy, blocks, g.y_blocks, c.t_trail.p, c.stream));
     }
     if (!std::getenv("PIXO_HIP_HOST_ENTROPY")) {
         out.clear();

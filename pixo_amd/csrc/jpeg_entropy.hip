@@ -228,42 +228,49 @@ __global__ __launch_bounds__(kScanThreads) void segment_sizes_kernel(const ScanA
     seg_bytes[k] = (uint32_t)((bits + 7) / 8 + (k + 1 < nsegments ? a.marker_bytes : 0));
 }
 
-// 0xFF bytes of the packed stream before byte `pos`: the tile's base count + a walk inside the tile
-__device__ __forceinline__ uint64_t ff_before(const uint32_t *stream, const uint64_t *tile_ff_base, uint64_t pos)
+// 0xFF bytes of the packed stream before byte `pos` (wave-uniform), computed by a whole wavefront: the
+// tile's base count + the tile's words before `pos` spread over the 64 lanes (a single thread walking up
+// to 1024 words took 115 us).  Bytes sit MSB-first in the words.  Every lane returns the total.
+__device__ __forceinline__ uint64_t ff_before_wave(const uint32_t *stream, const uint64_t *tile_ff_base, uint64_t pos)
 {
-    const uint64_t tile = pos / kStuffTileBytes;
-    uint64_t ff = tile_ff_base[tile];
-    for (uint64_t w = tile * (kStuffTileBytes / 4); w * 4 < pos; w++) {
-        const uint32_t v = stream[w];
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-            if (w * 4 + b < pos && ((v >> (24 - 8 * b)) & 0xFF) == 0xFF) ff++;
+    const uint64_t tile = pos / kStuffTileBytes, w0 = tile * (kStuffTileBytes / 4);
+    const int lane = threadIdx.x & 63;
+    uint32_t n = 0;
+    for (uint64_t w = w0 + lane; w * 4 < pos; w += 64) {
+        const uint64_t left = pos - w * 4; // bytes of this word that lie before pos (>= 1)
+        uint32_t x = ~stream[w];           // a 0xFF byte becomes 0x00
+        if (left < 4) x |= 0xFFFFFFFFu >> (8 * (uint32_t)left); // bytes at or after pos never count
+        // exact zero-byte detector: 0x80 in every byte of x that is zero
+        const uint32_t y = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+        n += (uint32_t)__builtin_popcount(y);
     }
-    return ff;
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+    return tile_ff_base[tile] + n;
 }
 
-__global__ __launch_bounds__(kScanThreads) void segment_out_offsets_kernel(const uint64_t *seg_byte_off, uint64_t nsegments, uint64_t nbytes,
-                                                                          const uint32_t *stream, const uint64_t *tile_ff_base,
-                                                                          uint64_t *seg_out)
+// one wavefront per segment
+__global__ __launch_bounds__(64) void segment_out_offsets_kernel(const uint64_t *seg_byte_off, uint64_t nsegments, uint64_t nbytes,
+                                                                 const uint32_t *stream, const uint64_t *tile_ff_base, uint64_t *seg_out)
 {
-    const uint64_t k = (uint64_t)blockIdx.x * kScanThreads + threadIdx.x;
-    if (k >= nsegments) return;
+    const uint64_t k = blockIdx.x;
     const uint64_t pos = seg_byte_off[k];
     // an empty segment at the very end starts where the stream ends: the caller substitutes its size
-    seg_out[k] = pos < nbytes ? pos + ff_before(stream, tile_ff_base, pos) : ~0ull;
+    const uint64_t r = pos < nbytes ? pos + ff_before_wave(stream, tile_ff_base, pos) : ~0ull;
+    if (threadIdx.x == 0) seg_out[k] = r;
 }
 
-__global__ __launch_bounds__(kScanThreads) void restart_markers_kernel(const ScanArgs a, const uint64_t *off, const uint64_t *seg_byte_off,
-                                                                      uint64_t nsegments, const uint32_t *stream,
-                                                                      const uint64_t *tile_ff_base, uint8_t *out)
+__global__ __launch_bounds__(64) void restart_markers_kernel(const ScanArgs a, const uint64_t *off, const uint64_t *seg_byte_off,
+                                                             uint64_t nsegments, const uint32_t *stream, const uint64_t *tile_ff_base,
+                                                             uint8_t *out)
 {
-    const uint64_t k = (uint64_t)blockIdx.x * kScanThreads + threadIdx.x;
-    if (k + 1 >= nsegments) return;
+    const uint64_t k = blockIdx.x; // < nsegments - 1
     // the marker's two (still zero) bytes sit right before the next segment
     const uint64_t pos = seg_byte_off[k + 1] - 2;
-    const uint64_t ff = ff_before(stream, tile_ff_base, pos);
-    out[pos + ff] = 0xFF;
-    out[pos + ff + 1] = (uint8_t)(0xD0 + (k & 7)); // jpeg/mod.rs:1436-1439
+    const uint64_t ff = ff_before_wave(stream, tile_ff_base, pos);
+    if (threadIdx.x == 0) {
+        out[pos + ff] = 0xFF;
+        out[pos + ff + 1] = (uint8_t)(0xD0 + (k & 7)); // jpeg/mod.rs:1436-1439
+    }
 }
 
 // ---- progressive scans ---------------------------------------------------------------------------
@@ -429,7 +436,7 @@ hipError_t launch_prog_pack(const ProgArgs &a, const uint64_t *d_off, uint64_t t
 hipError_t launch_segment_out_offsets(const SegmentPlan &seg, uint64_t nbytes, const uint32_t *d_stream, const uint64_t *d_tile_ff_base,
                                       uint64_t *d_seg_out, hipStream_t s)
 {
-    hipLaunchKernelGGL(segment_out_offsets_kernel, dim3(grid_for(seg.nsegments, kScanThreads)), dim3(kScanThreads), 0, s,
+    hipLaunchKernelGGL(segment_out_offsets_kernel, dim3((unsigned)seg.nsegments), dim3(64), 0, s,
                        seg.seg_byte_off, seg.nsegments, nbytes, d_stream, d_tile_ff_base, d_seg_out);
     return hipGetLastError();
 }
@@ -438,7 +445,7 @@ hipError_t launch_restart_markers(const ScanArgs &a, const uint64_t *d_off, cons
                                   const uint64_t *d_tile_ff_base, uint8_t *d_out, hipStream_t s)
 {
     if (seg.nsegments < 2 || a.marker_bytes == 0) return hipSuccess;
-    hipLaunchKernelGGL(restart_markers_kernel, dim3(grid_for(seg.nsegments - 1, kScanThreads)), dim3(kScanThreads), 0, s, a, d_off,
+    hipLaunchKernelGGL(restart_markers_kernel, dim3((unsigned)(seg.nsegments - 1)), dim3(64), 0, s, a, d_off,
                        seg.seg_byte_off, seg.nsegments, d_stream, d_tile_ff_base, d_out);
     return hipGetLastError();
 }

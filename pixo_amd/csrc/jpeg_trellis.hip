@@ -27,7 +27,7 @@ __constant__ int c_zigzag_nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32,
 
 struct LaneEnv {
     float *mine;          // this lane's 64 coefficient slots in LDS (natural order)
-    const float *steps;   // 64 quantiser steps in LDS (natural order)
+    const float *steps;   // this lane's 64 quantiser steps in LDS (natural order)
     const float *table;   // 256 code-length estimates in LDS
     uint64_t *trail;      // this lane's column of the wave's back-pointer scratch
     __device__ __forceinline__ float coef(int zz) const { return mine[c_zigzag_nat[zz]]; }
@@ -39,15 +39,18 @@ struct LaneEnv {
     __device__ __forceinline__ void out(int zz, int16_t v) { reinterpret_cast<int *>(mine)[c_zigzag_nat[zz]] = v; }
 };
 
-__global__ __launch_bounds__(64) void trellis_kernel(const float *raw, const float *q, int16_t *out, uint64_t nblocks, uint64_t *trail)
+// Blocks [0, nluma) use q_luma, the rest q_chroma: the three planes of a tuple are contiguous, one launch.
+__global__ __launch_bounds__(64) void trellis_kernel(const float *raw, const float *q_luma, const float *q_chroma, int16_t *out,
+                                                     uint64_t nblocks, uint64_t nluma, uint64_t *trail)
 {
     __shared__ float s_coef[64 * kLaneStride];
-    __shared__ float s_step[64];
+    __shared__ float s_step[128];
     __shared__ float s_bits[256];
     const int lane = threadIdx.x;
     const uint64_t first = (uint64_t)blockIdx.x * 64;
     const uint64_t have = nblocks - first < 64 ? nblocks - first : 64; // blocks of this wave
-    s_step[lane] = q[lane];
+    s_step[lane] = q_luma[lane];
+    s_step[64 + lane] = q_chroma[lane];
 #pragma unroll
     for (int i = 0; i < 4; i++) s_bits[i * 64 + lane] = pixo_trellis::rate_bits(i * 64 + lane);
     const float4 *src = reinterpret_cast<const float4 *>(raw + first * 64);
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(64) void trellis_kernel(const float *raw, const flo
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
-    LaneEnv env{s_coef + lane * kLaneStride, s_step, s_bits, trail + (uint64_t)blockIdx.x * 63 * 64 + lane};
+    LaneEnv env{s_coef + lane * kLaneStride, s_step + (first + lane < nluma ? 0 : 64), s_bits, trail + (uint64_t)blockIdx.x * 63 * 64 + lane};
     pixo_trellis::quantize_block_fast(env);
     __syncthreads();
     uint32_t *dst = reinterpret_cast<uint32_t *>(out + first * 64);
@@ -76,11 +79,12 @@ __global__ __launch_bounds__(64) void trellis_kernel(const float *raw, const flo
 
 size_t trellis_scratch_bytes(uint64_t nblocks) { return (size_t)((nblocks + 63) / 64) * 63 * 64 * 8; }
 
-hipError_t launch_trellis(const float *d_raw, const float *d_q, int16_t *d_out, uint64_t nblocks, void *d_scratch, hipStream_t s)
+hipError_t launch_trellis(const float *d_raw, const float *d_q_luma, const float *d_q_chroma, int16_t *d_out, uint64_t nblocks,
+                          uint64_t nluma, void *d_scratch, hipStream_t s)
 {
     if (nblocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(trellis_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, d_raw, d_q, d_out, nblocks,
-                       static_cast<uint64_t *>(d_scratch));
+    hipLaunchKernelGGL(trellis_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, d_raw, d_q_luma, d_q_chroma, d_out, nblocks,
+                       nluma, static_cast<uint64_t *>(d_scratch));
     return hipGetLastError();
 }
 } // namespace pixo_dev

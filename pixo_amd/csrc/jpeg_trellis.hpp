@@ -6,8 +6,10 @@
 
 namespace pixo_dev {
 // d_raw: nblocks x 64 f32 DCT coefficients (natural order) as left by the coefficient kernel's raw
-// mode, d_q: 64 quantiser steps (natural order).  d_out: nblocks x 64 i16.  d_scratch: back-pointer
+// mode — the planes of a tuple back to back: blocks [0, nluma) are quantised with d_q_luma, the others
+// with d_q_chroma (64 steps each, natural order).  d_out: nblocks x 64 i16.  d_scratch: back-pointer
 // storage of trellis_scratch_bytes(nblocks) bytes (504 per block), free again when the kernel is done.
 size_t trellis_scratch_bytes(uint64_t nblocks);
-hipError_t launch_trellis(const float *d_raw, const float *d_q, int16_t *d_out, uint64_t nblocks, void *d_scratch, hipStream_t s);
+hipError_t launch_trellis(const float *d_raw, const float *d_q_luma, const float *d_q_chroma, int16_t *d_out, uint64_t nblocks,
+                          uint64_t nluma, void *d_scratch, hipStream_t s);
 } // namespace pixo_dev

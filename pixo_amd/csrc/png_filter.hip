@@ -39,20 +39,15 @@ __device__ __forceinline__ uint32_t gt_mask(s16x2 x, s16x2 y)
 { // per 16-bit lane: 0xFFFF where x > y  (two packed ops: subtract, arithmetic shift)
     return as_u((y - x) >> 15);
 }
-__device__ __forceinline__ s16x2 absdiff(uint32_t x, uint32_t y)
-{ // |x - y| of small non-negative lanes: saturating differences OR-ed (three packed ops)
-    const u16x2 ux = __builtin_bit_cast(u16x2, x), uy = __builtin_bit_cast(u16x2, y);
-    return as_s(__builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(ux, uy)) |
-                __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(uy, ux)));
-}
 // Paeth predictor (fallback.rs:144-159) on two bytes held in the low bytes of 16-bit lanes:
 // p = a + b - c, pa = |p - a| = |b - c|, pb = |p - b| = |a - c|, pc = |p - c| = |(b - c) + (a - c)|;
 // a unless pa > pb or pa > pc, then b unless pb > pc, then c.
 __device__ __forceinline__ uint32_t paeth2(uint32_t a, uint32_t b, uint32_t c)
-{
-    const s16x2 pa = absdiff(b, c), pb = absdiff(a, c);
-    const s16x2 pc = __builtin_elementwise_abs((as_s(b) - as_s(c)) + (as_s(a) - as_s(c)));
-    const uint32_t not_a = gt_mask(pa, pb) | gt_mask(pa, pc), use_c = gt_mask(pb, pc);
+{ // 14 packed operations + 2 bit selects
+    const s16x2 da = as_s(b) - as_s(c), db = as_s(a) - as_s(c), dd = da + db;
+    const s16x2 pa = __builtin_elementwise_max(da, -da), pb = __builtin_elementwise_max(db, -db);
+    const s16x2 pc = __builtin_elementwise_max(dd, -dd);
+    const uint32_t not_a = gt_mask(pa, __builtin_elementwise_min(pb, pc)), use_c = gt_mask(pb, pc);
     const uint32_t bc_sel = (c & use_c) | (b & ~use_c);
     return (bc_sel & not_a) | (a & ~not_a);
 }
@@ -142,6 +137,31 @@ __device__ __forceinline__ void load_group(const uint8_t *row, const uint8_t *pr
     }
 }
 
+// The same 16 bytes and their neighbours as loaded: 6 dwords of the row, 6 of the row above.  Rows of at
+// most kRegIters * 4 KiB are held like this by the whole workgroup between scoring and write-out.
+struct Raw { uint32_t x[6], u[6]; };
+template <int BPP, bool FAST>
+__device__ __forceinline__ void load_raw(const uint8_t *row, const uint8_t *prev, int k0, int n, Raw &r)
+{
+    const bool whole = 4 * (k0 + 4) <= n;
+    load_six<BPP, FAST>(row, k0, n, whole, r.x);
+    if (prev) load_six<BPP, FAST>(prev, k0, n, whole, r.u);
+    else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) r.u[i] = 0;
+    }
+}
+// MASK = false: the group lies wholly inside the row (every group but a row's last partial one): no byte masks
+template <int BPP, bool MASK> __device__ __forceinline__ void group_of(const Raw &r, int k0, int n, Group &g)
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        g.cur[j] = r.x[2 + j]; g.up[j] = r.u[2 + j];
+        g.left[j] = left_of<BPP>(r.x, j); g.ul[j] = left_of<BPP>(r.u, j);
+        const int rem = n - 4 * (k0 + j);
+        g.valid[j] = !MASK || rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : (1u << (8 * rem)) - 1u);
+    }
+}
 __device__ __forceinline__ uint32_t filtered(int f, const Group &g, int j)
 {
     switch (f) {
@@ -153,6 +173,24 @@ __device__ __forceinline__ uint32_t filtered(int f, const Group &g, int j)
     }
 }
 
+template <int BPP, bool MASK>
+__device__ __forceinline__ void score_group(const Raw &r, int k0, int n, bool fast, uint32_t sc[5])
+{
+    Group g;
+    group_of<BPP, MASK>(r, k0, n, g);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t m = g.valid[j]; // (all ones without MASK: the ands fold away)
+        sc[F_SUB] = score4(filtered(F_SUB, g, j) & m, sc[F_SUB]);
+        sc[F_UP] = score4(filtered(F_UP, g, j) & m, sc[F_UP]);
+        sc[F_PAETH] = score4(filtered(F_PAETH, g, j) & m, sc[F_PAETH]);
+        if (!fast) {
+            sc[F_NONE] = score4(g.cur[j] & m, sc[F_NONE]);
+            sc[F_AVG] = score4(filtered(F_AVG, g, j) & m, sc[F_AVG]);
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned long long wg_sum(unsigned long long v, unsigned long long *lds)
 { // 256 threads; every thread gets the total
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -160,6 +198,21 @@ __device__ __forceinline__ unsigned long long wg_sum(unsigned long long v, unsig
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
     __syncthreads();
     return lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+__device__ __forceinline__ void wg_sum5(unsigned long long v[5], unsigned long long *lds)
+{ // five totals with one pair of barriers; lds: 20 words
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+        for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) lds[(threadIdx.x >> 6) * 5 + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; i++) v[i] = lds[i] + lds[5 + i] + lds[10 + i] + lds[15 + i];
 }
 
 // the reference's decision sequences, replayed on the five row scores
@@ -209,44 +262,38 @@ struct Args {
 // memory: each chunk is five aligned LDS dwords shifted by a row-uniform byte count.  The few
 // bytes before the first / after the last aligned chunk are stored singly.  Rows too long for the
 // LDS stage (a.stage_bytes == 0) store unaligned dwords directly.
-template <int BPP, bool FAST, int F, int NEED>
-__device__ __forceinline__ void write_row(const Args &a, uint32_t y, const uint8_t *row, const uint8_t *prev, int n,
-                                          unsigned long long &s1, unsigned long long &s2)
+// Filtered dwords of one group -> Adler partial sums + stage (or direct stores for rows too long to stage).
+template <int F>
+__device__ __forceinline__ void emit_group(const Group &g, int k0, int n, unsigned long long L, bool staged, uint8_t *stage,
+                                           uint8_t *orow, unsigned long long &s1, unsigned long long &s2)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
-    const int ndw = (n + 3) / 4, per_iter = kThreads * 4;
-    uint8_t *orow = a.out + (size_t)y * (a.row_bytes + 1);
-    const unsigned long long L = (unsigned long long)n + 1; // bytes of the output row; byte p has weight L - p
-    const bool staged = a.stage_bytes != 0;
-    if (threadIdx.x == 0) {
-        if (staged) stage[15] = (uint8_t)F; else orow[0] = (uint8_t)F;
-        s1 = (unsigned)F; s2 = L * (unsigned)F;
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        v[j] = filtered(F, g, j) & g.valid[j];
+        // bytes at output positions p = 1 + 4k + b, weight L - p
+        const unsigned sum = __builtin_amdgcn_sad_u8(v[j], 0u, 0u);
+        const unsigned ramp = __builtin_amdgcn_udot4(v[j], 0x00010203u, 0u, false); // 3*b0 + 2*b1 + 1*b2 + 0*b3
+        s1 += sum;
+        s2 += (L - (unsigned long long)(4 * (k0 + j) + 4)) * sum + ramp;
     }
-    for (int k0 = (int)threadIdx.x * 4; k0 < ndw; k0 += per_iter) {
-        Group g;
-        load_group<BPP, FAST, NEED>(row, prev, k0, n, g);
-        uint32_t v[4];
+    if (staged) {
+        *reinterpret_cast<uint4 *>(stage + 16 + 4 * k0) = make_uint4(v[0], v[1], v[2], v[3]); // (zero beyond the row)
+    } else {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            v[j] = filtered(F, g, j) & g.valid[j];
-            // bytes at output positions p = 1 + 4k + b, weight L - p
-            const unsigned sum = __builtin_amdgcn_sad_u8(v[j], 0u, 0u);
-            const unsigned ramp = __builtin_amdgcn_udot4(v[j], 0x00010203u, 0u, false); // 3*b0 + 2*b1 + 1*b2 + 0*b3
-            s1 += sum;
-            s2 += (L - (unsigned long long)(4 * (k0 + j) + 4)) * sum + ramp;
-        }
-        if (staged) {
-            *reinterpret_cast<uint4 *>(stage + 16 + 4 * k0) = make_uint4(v[0], v[1], v[2], v[3]); // (zero beyond the row)
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint8_t *dst = orow + 1 + 4 * (k0 + j);
-                if (g.valid[j] == 0xFFFFFFFFu) __builtin_memcpy(dst, &v[j], 4);
-                else for (int b = 0; b < 4; b++) if (4 * (k0 + j) + b < n) dst[b] = (uint8_t)(v[j] >> (8 * b));
-            }
+            uint8_t *dst = orow + 1 + 4 * (k0 + j);
+            if (g.valid[j] == 0xFFFFFFFFu) __builtin_memcpy(dst, &v[j], 4);
+            else for (int b = 0; b < 4; b++) if (4 * (k0 + j) + b < n) dst[b] = (uint8_t)(v[j] >> (8 * b));
         }
     }
-    if (!staged) return;
+}
+
+// The staged row (filter byte at LDS offset 15, row byte i at 16 + i) -> global memory as 16-byte chunks
+// aligned in GLOBAL memory: each chunk is five aligned LDS dwords shifted by a row-uniform byte count; the
+// few bytes before the first / after the last aligned chunk are stored singly.
+__device__ __forceinline__ void flush_stage(const uint8_t *stage, uint8_t *orow, int n)
+{
     __syncthreads();
     // stream byte p of this row (0 = filter byte) sits at LDS offset 15 + p
     const int total = n + 1;
@@ -266,6 +313,56 @@ __device__ __forceinline__ void write_row(const Args &a, uint32_t y, const uint8
         o.z = __builtin_amdgcn_alignbyte(d[3], d[2], r); o.w = __builtin_amdgcn_alignbyte(d[4], d[3], r);
         *reinterpret_cast<uint4 *>(orow + h + 16 * c) = o;
     }
+}
+
+// Pass 2 for filter F.  The output row starts at byte y * (n + 1) of the stream — a different
+// alignment for every row — so the filtered bytes are staged in LDS and written out by flush_stage.
+// Rows too long for the LDS stage (a.stage_bytes == 0) store unaligned dwords directly.
+template <int BPP, bool FAST, int F, int NEED>
+__device__ __forceinline__ void write_row(const Args &a, uint32_t y, const uint8_t *row, const uint8_t *prev, int n,
+                                          unsigned long long &s1, unsigned long long &s2)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+    const int ndw = (n + 3) / 4, per_iter = kThreads * 4;
+    uint8_t *orow = a.out + (size_t)y * (a.row_bytes + 1);
+    const unsigned long long L = (unsigned long long)n + 1; // bytes of the output row; byte p has weight L - p
+    const bool staged = a.stage_bytes != 0;
+    if (threadIdx.x == 0) {
+        if (staged) stage[15] = (uint8_t)F; else orow[0] = (uint8_t)F;
+        s1 = (unsigned)F; s2 = L * (unsigned)F;
+    }
+    for (int k0 = (int)threadIdx.x * 4; k0 < ndw; k0 += per_iter) {
+        Group g;
+        load_group<BPP, FAST, NEED>(row, prev, k0, n, g);
+        emit_group<F>(g, k0, n, L, staged, stage, orow, s1, s2);
+    }
+    if (staged) flush_stage(stage, orow, n);
+}
+
+// The register-resident form (rows of at most kRegIters x 4 KiB, always staged): the workgroup loaded
+// the whole row and the row above ONCE, all loads in flight together; scoring and the winning filter
+// both work from those registers.
+constexpr int kRegIters = 4;
+template <int BPP, int F>
+__device__ __forceinline__ void write_row_regs(const Args &a, uint32_t y, const Raw *raw, int n, unsigned long long &s1,
+                                               unsigned long long &s2)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+    const int ndw = (n + 3) / 4, per_iter = kThreads * 4;
+    uint8_t *orow = a.out + (size_t)y * (a.row_bytes + 1);
+    const unsigned long long L = (unsigned long long)n + 1;
+    if (threadIdx.x == 0) { stage[15] = (uint8_t)F; s1 = (unsigned)F; s2 = L * (unsigned)F; }
+#pragma unroll
+    for (int it = 0; it < kRegIters; it++) {
+        const int k0 = (int)threadIdx.x * 4 + it * per_iter;
+        if (k0 < ndw) {
+            Group g;
+            if (4 * (k0 + 4) <= n) group_of<BPP, false>(raw[it], k0, n, g);
+            else group_of<BPP, true>(raw[it], k0, n, g);
+            emit_group<F>(g, k0, n, L, true, stage, orow, s1, s2);
+        }
+    }
+    flush_stage(stage, orow, n);
 }
 
 // Bigrams (filter.rs:406-472, score_bigrams :635-649): the score of a candidate is the number of DISTINCT
@@ -309,11 +406,14 @@ __device__ __forceinline__ unsigned long long bigram_score(const uint8_t *row, c
     return wg_sum(count, red);
 }
 
-// BIGRAMS is a separate instantiation: its scoring pass needs ~110 registers, the others 44.
-template <int BPP, bool FAST, bool BIGRAMS> __global__ __launch_bounds__(kThreads) void png_filter_kernel(const Args a)
+// Three instantiations by register need: K_GENERAL (fixed filters; adaptive strategies on rows too long to
+// hold: two passes over the row, 44 VGPRs), K_REGS (adaptive strategies, the row in registers, ~100),
+// K_BIGRAMS (~110).
+enum { K_GENERAL = 0, K_REGS = 1, K_BIGRAMS = 2 };
+template <int BPP, bool FAST, int KIND> __global__ __launch_bounds__(kThreads) void png_filter_kernel(const Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
-    __shared__ unsigned long long red[4];
+    __shared__ unsigned long long red[20];
     // Workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2: rows are
     // handed out in chunks of 32 consecutive rows per XCD, so that the row above — the neighbouring
     // workgroup's own row — is found in the same L2 instead of being fetched from HBM a second time
@@ -330,7 +430,7 @@ template <int BPP, bool FAST, bool BIGRAMS> __global__ __launch_bounds__(kThread
     int strategy = a.forced ? *a.forced : a.strategy;
 
     int f = strategy;
-    if (BIGRAMS) {
+    if (KIND == K_BIGRAMS) {
         uint32_t *bitmap = reinterpret_cast<uint32_t *>(stage + a.bitmap_off);
         unsigned long long tot[5];
         tot[F_NONE] = bigram_score<BPP, FAST, F_NONE, 0>(row, prev, n, bitmap, red);
@@ -343,6 +443,44 @@ template <int BPP, bool FAST, bool BIGRAMS> __global__ __launch_bounds__(kThread
         for (int c = F_SUB; c <= F_PAETH; c++)
             if (tot[c] < tot[f]) f = c;
         __syncthreads(); // the write-out below reuses the dynamic LDS
+    } else if (KIND == K_REGS) { // (the launcher checked: strategy > Paeth, ndw <= kRegIters * per_iter, staged)
+        // the whole row (and the row above) in registers: one round of loads, all in flight together
+        Raw raw[kRegIters];
+#pragma unroll
+        for (int it = 0; it < kRegIters; it++) {
+            const int k0 = (int)threadIdx.x * 4 + it * per_iter;
+            if (it * per_iter < ndw) load_raw<BPP, FAST>(row, prev, k0, n, raw[it]); // (uniform; k0 >= ndw loads zeros)
+            else {
+#pragma unroll
+                for (int i = 0; i < 6; i++) { raw[it].x[i] = 0; raw[it].u[i] = 0; }
+            }
+        }
+        uint32_t sc[5] = {0, 0, 0, 0, 0};
+        const bool fast = strategy == PNG_S_ADAPTIVE_FAST;
+#pragma unroll
+        for (int it = 0; it < kRegIters; it++) {
+            const int k0 = (int)threadIdx.x * 4 + it * per_iter;
+            if (k0 >= ndw) continue;
+            if (4 * (k0 + 4) <= n) score_group<BPP, false>(raw[it], k0, n, fast, sc);
+            else score_group<BPP, true>(raw[it], k0, n, fast, sc);
+        }
+        unsigned long long tot[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) tot[i] = sc[i];
+        wg_sum5(tot, red);
+        f = decide(strategy, tot, (unsigned long long)n);
+        if (a.winner0 && y == 0 && threadIdx.x == 0) *a.winner0 = f;
+        unsigned long long s1 = 0, s2 = 0;
+        switch (f) {
+        case F_NONE: write_row_regs<BPP, F_NONE>(a, y, raw, n, s1, s2); break;
+        case F_SUB: write_row_regs<BPP, F_SUB>(a, y, raw, n, s1, s2); break;
+        case F_UP: write_row_regs<BPP, F_UP>(a, y, raw, n, s1, s2); break;
+        case F_AVG: write_row_regs<BPP, F_AVG>(a, y, raw, n, s1, s2); break;
+        default: write_row_regs<BPP, F_PAETH>(a, y, raw, n, s1, s2); break;
+        }
+        const unsigned long long t1 = wg_sum(s1, red), t2 = wg_sum(s2, red);
+        if (threadIdx.x == 0) { a.row_sums[2 * (size_t)y] = t1; a.row_sums[2 * (size_t)y + 1] = t2; }
+        return;
     } else if (strategy > PNG_S_PAETH) {
         // pass 1: scores of the candidates (AdaptiveFast never looks at None / Average)
         uint32_t sc[5] = {0, 0, 0, 0, 0};
@@ -353,13 +491,19 @@ template <int BPP, bool FAST, bool BIGRAMS> __global__ __launch_bounds__(kThread
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t m = g.valid[j];
+#ifdef PIXO_PNG_EXP_LOADS_ONLY // (timing experiments only: pass 1 = its loads)
+                sc[F_SUB] += (g.cur[j] ^ g.left[j] ^ g.up[j] ^ g.ul[j]) & m;
+#else
                 sc[F_SUB] = score4(filtered(F_SUB, g, j) & m, sc[F_SUB]);
                 sc[F_UP] = score4(filtered(F_UP, g, j) & m, sc[F_UP]);
+#ifndef PIXO_PNG_EXP_NO_PAETH1 // (timing experiments only: pass 1 without the Paeth candidate)
                 sc[F_PAETH] = score4(filtered(F_PAETH, g, j) & m, sc[F_PAETH]);
+#endif
                 if (!fast) {
                     sc[F_NONE] = score4(g.cur[j] & m, sc[F_NONE]);
                     sc[F_AVG] = score4(filtered(F_AVG, g, j) & m, sc[F_AVG]);
                 }
+#endif
             }
         }
         unsigned long long tot[5];
@@ -371,6 +515,9 @@ template <int BPP, bool FAST, bool BIGRAMS> __global__ __launch_bounds__(kThread
 
     // pass 2: the winning filter -> output row (filter byte + n bytes), Adler partial sums
     unsigned long long s1 = 0, s2 = 0;
+#ifdef PIXO_PNG_EXP_NO_PASS2 // (timing experiments only)
+    if (f != 99) { if (threadIdx.x == 0) a.row_sums[2 * (size_t)y] = f; return; }
+#endif
     switch (f) { // uniform: one filter's code and loads per row
     case F_NONE: write_row<BPP, FAST, F_NONE, 0>(a, y, row, prev, n, s1, s2); break;
     case F_SUB: write_row<BPP, FAST, F_SUB, 1>(a, y, row, prev, n, s1, s2); break;
@@ -388,12 +535,16 @@ template <int BPP, bool FAST, bool BIGRAMS> __global__ __launch_bounds__(kThread
 
 template <int BPP> hipError_t launch_bpp(const Args &a, uint32_t rows, bool fast, hipStream_t s)
 {
+    const uint64_t ndw = (a.row_bytes + 3) / 4;
     if (a.strategy == PNG_S_BIGRAMS) {
         const uint32_t lds = a.stage_bytes + 8192u;
-        if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, true>), dim3(rows), dim3(kThreads), lds, s, a);
-        else hipLaunchKernelGGL((png_filter_kernel<BPP, false, true>), dim3(rows), dim3(kThreads), lds, s, a);
-    } else if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, false>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
-    else hipLaunchKernelGGL((png_filter_kernel<BPP, false, false>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
+        if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, K_BIGRAMS>), dim3(rows), dim3(kThreads), lds, s, a);
+        else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_BIGRAMS>), dim3(rows), dim3(kThreads), lds, s, a);
+    } else if (a.strategy > PNG_S_PAETH && !a.forced && ndw <= (uint64_t)kRegIters * kThreads * 4 && a.stage_bytes != 0) {
+        if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, K_REGS>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
+        else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_REGS>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
+    } else if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, K_GENERAL>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
+    else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_GENERAL>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
     return hipGetLastError();
 }
 

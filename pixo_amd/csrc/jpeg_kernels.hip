@@ -167,12 +167,12 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
 #ifdef PIXO_TIMING
     const unsigned long long t_start = __builtin_readcyclecounter(), w_start = __builtin_amdgcn_s_memrealtime();
 #endif
-    // Launches whose workgroups are all resident at once (one 4096x4096 image: 8 per CU) run
-    // phase A at raised wave priority: the hardware otherwise issues oldest-first, the colour
-    // conversion of the younger workgroups waits behind the older ones' phase B, and few
-    // wavefronts are in phase B at any time (two per SIMD are needed to fill the VALU).
-    // With more workgroups than fit, the same setting delays the retirement of old workgroups
-    // and costs 9 % (measured), so it is a launch-time decision.
+    // Phase A runs at raised wave priority: the hardware otherwise issues oldest-first, the colour
+    // conversion of the younger workgroups waits behind the older ones' phase B, and few wavefronts
+    // are in phase B at any time (two per SIMD are needed to fill the VALU).  +14 % for one 4096x4096
+    // image (all workgroups resident at once), +10 % for 4:4:4 and for the 64-image batch (measured at
+    // steady clocks with the whole-block write-out; with the earlier half-block stores the batch LOST
+    // 9 %, which is why this used to be a launch-time decision).  PIXO_HIP_PRIO_A=0 switches it off.
     if (a.prio_a) __builtin_amdgcn_s_setprio(1);
     const TileId id = locate(a, blockIdx.x);
     const TileCtx c = ctx_of(a, id.img);
@@ -247,9 +247,8 @@ template <int MODE, bool FAST> static hipError_t launch_mode(KArgs &a, hipStream
     const uint64_t total64 = (uint64_t)a.tiles_x * a.tiles_y * a.batch;
     if (total64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const uint32_t total = (uint32_t)total64;
-    static const int cus = [] { int d = 0, n = 0; return hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess ? n : 256; }();
     static const char *prio_env = getenv("PIXO_HIP_PRIO_A"); // experiments: force 0 / 1
-    a.prio_a = prio_env ? (uint32_t)atoi(prio_env) : (total <= 8u * (uint32_t)cus ? 1u : 0u);
+    a.prio_a = prio_env ? (uint32_t)atoi(prio_env) : 1u;
     // PIXO_HIP_LDS_PAD (bytes of unused dynamic LDS) lowers the residency for experiments
     static const unsigned pad = getenv("PIXO_HIP_LDS_PAD") ? (unsigned)atoi(getenv("PIXO_HIP_LDS_PAD")) : 0u;
     if (raw) hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, FAST, true>), dim3(total), dim3(kThreads), pad, s, a);

@@ -200,19 +200,11 @@ __device__ __forceinline__ unsigned long long wg_sum(unsigned long long v, unsig
     return lds[0] + lds[1] + lds[2] + lds[3];
 }
 
-__device__ __forceinline__ void wg_sum5(unsigned long long v[5], unsigned long long *lds)
-{ // five totals with one pair of barriers; lds: 20 words
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{ // every lane gets the wavefront's total (the caller guarantees it fits 32 bits)
 #pragma unroll
-    for (int i = 0; i < 5; i++)
-        for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int i = 0; i < 5; i++) lds[(threadIdx.x >> 6) * 5 + i] = v[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 5; i++) v[i] = lds[i] + lds[5 + i] + lds[10 + i] + lds[15 + i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
 }
 
 // the reference's decision sequences, replayed on the five row scores
@@ -263,9 +255,10 @@ struct Args {
 // bytes before the first / after the last aligned chunk are stored singly.  Rows too long for the
 // LDS stage (a.stage_bytes == 0) store unaligned dwords directly.
 // Filtered dwords of one group -> Adler partial sums + stage (or direct stores for rows too long to stage).
-template <int F>
-__device__ __forceinline__ void emit_group(const Group &g, int k0, int n, unsigned long long L, bool staged, uint8_t *stage,
-                                           uint8_t *orow, unsigned long long &s1, unsigned long long &s2)
+// (T: 64-bit sums in general; 32 bits hold a thread's share of a row of at most 16 KiB)
+template <int F, class T>
+__device__ __forceinline__ void emit_group(const Group &g, int k0, int n, T L, bool staged, uint8_t *stage,
+                                           uint8_t *orow, T &s1, T &s2)
 {
     uint32_t v[4];
 #pragma unroll
@@ -275,7 +268,7 @@ __device__ __forceinline__ void emit_group(const Group &g, int k0, int n, unsign
         const unsigned sum = __builtin_amdgcn_sad_u8(v[j], 0u, 0u);
         const unsigned ramp = __builtin_amdgcn_udot4(v[j], 0x00010203u, 0u, false); // 3*b0 + 2*b1 + 1*b2 + 0*b3
         s1 += sum;
-        s2 += (L - (unsigned long long)(4 * (k0 + j) + 4)) * sum + ramp;
+        s2 += (L - (T)(4 * (k0 + j) + 4)) * sum + ramp;
     }
     if (staged) {
         *reinterpret_cast<uint4 *>(stage + 16 + 4 * k0) = make_uint4(v[0], v[1], v[2], v[3]); // (zero beyond the row)
@@ -334,7 +327,7 @@ __device__ __forceinline__ void write_row(const Args &a, uint32_t y, const uint8
     for (int k0 = (int)threadIdx.x * 4; k0 < ndw; k0 += per_iter) {
         Group g;
         load_group<BPP, FAST, NEED>(row, prev, k0, n, g);
-        emit_group<F>(g, k0, n, L, staged, stage, orow, s1, s2);
+        emit_group<F, unsigned long long>(g, k0, n, L, staged, stage, orow, s1, s2);
     }
     if (staged) flush_stage(stage, orow, n);
 }
@@ -344,13 +337,13 @@ __device__ __forceinline__ void write_row(const Args &a, uint32_t y, const uint8
 // both work from those registers.
 constexpr int kRegIters = 4;
 template <int BPP, int F>
-__device__ __forceinline__ void write_row_regs(const Args &a, uint32_t y, const Raw *raw, int n, unsigned long long &s1,
-                                               unsigned long long &s2)
+__device__ __forceinline__ void write_row_regs(const Args &a, uint32_t y, const Raw *raw, int n, unsigned long long *acc64)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
     const int ndw = (n + 3) / 4, per_iter = kThreads * 4;
     uint8_t *orow = a.out + (size_t)y * (a.row_bytes + 1);
-    const unsigned long long L = (unsigned long long)n + 1;
+    const uint32_t L = (uint32_t)n + 1;
+    uint32_t s1 = 0, s2 = 0; // this thread's 64 bytes: s2 < 16 x 16385 x 1020 < 2^32
     if (threadIdx.x == 0) { stage[15] = (uint8_t)F; s1 = (unsigned)F; s2 = L * (unsigned)F; }
 #pragma unroll
     for (int it = 0; it < kRegIters; it++) {
@@ -359,8 +352,15 @@ __device__ __forceinline__ void write_row_regs(const Args &a, uint32_t y, const 
             Group g;
             if (4 * (k0 + 4) <= n) group_of<BPP, false>(raw[it], k0, n, g);
             else group_of<BPP, true>(raw[it], k0, n, g);
-            emit_group<F>(g, k0, n, L, true, stage, orow, s1, s2);
+            emit_group<F, uint32_t>(g, k0, n, L, true, stage, orow, s1, s2);
         }
+    }
+    // row totals: 32-bit butterflies inside the wavefront (s2 in two 16-bit halves so that the wave totals
+    // fit), one LDS atomic per wavefront; flush_stage's barrier orders them for the reader
+    const uint32_t w1 = wave_sum_u32(s1), lo = wave_sum_u32(s2 & 0xFFFFu), hi = wave_sum_u32(s2 >> 16);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&acc64[0], (unsigned long long)w1);
+        atomicAdd(&acc64[1], ((unsigned long long)hi << 16) + lo);
     }
     flush_stage(stage, orow, n);
 }
@@ -414,6 +414,8 @@ template <int BPP, bool FAST, int KIND> __global__ __launch_bounds__(kThreads) v
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
     __shared__ unsigned long long red[20];
+    __shared__ unsigned long long acc64[2];
+    __shared__ unsigned int acc32[8];
     // Workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2: rows are
     // handed out in chunks of 32 consecutive rows per XCD, so that the row above — the neighbouring
     // workgroup's own row — is found in the same L2 instead of being fetched from HBM a second time
@@ -445,6 +447,8 @@ template <int BPP, bool FAST, int KIND> __global__ __launch_bounds__(kThreads) v
         __syncthreads(); // the write-out below reuses the dynamic LDS
     } else if (KIND == K_REGS) { // (the launcher checked: strategy > Paeth, ndw <= kRegIters * per_iter, staged)
         // the whole row (and the row above) in registers: one round of loads, all in flight together
+        if (threadIdx.x < 8) acc32[threadIdx.x] = 0;
+        if (threadIdx.x < 2) acc64[threadIdx.x] = 0;
         Raw raw[kRegIters];
 #pragma unroll
         for (int it = 0; it < kRegIters; it++) {
@@ -455,6 +459,7 @@ template <int BPP, bool FAST, int KIND> __global__ __launch_bounds__(kThreads) v
                 for (int i = 0; i < 6; i++) { raw[it].x[i] = 0; raw[it].u[i] = 0; }
             }
         }
+        __syncthreads(); // (the zeroed totals; the loads are needed from here on anyway)
         uint32_t sc[5] = {0, 0, 0, 0, 0};
         const bool fast = strategy == PNG_S_ADAPTIVE_FAST;
 #pragma unroll
@@ -464,22 +469,27 @@ template <int BPP, bool FAST, int KIND> __global__ __launch_bounds__(kThreads) v
             if (4 * (k0 + 4) <= n) score_group<BPP, false>(raw[it], k0, n, fast, sc);
             else score_group<BPP, true>(raw[it], k0, n, fast, sc);
         }
+        // row totals (< 2^32: at most 16 KiB x 128): 32-bit butterflies, one LDS atomic per wavefront and score
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            if (fast && (i == F_NONE || i == F_AVG)) continue;
+            const uint32_t t = wave_sum_u32(sc[i]);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&acc32[i], t);
+        }
+        __syncthreads();
         unsigned long long tot[5];
 #pragma unroll
-        for (int i = 0; i < 5; i++) tot[i] = sc[i];
-        wg_sum5(tot, red);
+        for (int i = 0; i < 5; i++) tot[i] = acc32[i];
         f = decide(strategy, tot, (unsigned long long)n);
         if (a.winner0 && y == 0 && threadIdx.x == 0) *a.winner0 = f;
-        unsigned long long s1 = 0, s2 = 0;
         switch (f) {
-        case F_NONE: write_row_regs<BPP, F_NONE>(a, y, raw, n, s1, s2); break;
-        case F_SUB: write_row_regs<BPP, F_SUB>(a, y, raw, n, s1, s2); break;
-        case F_UP: write_row_regs<BPP, F_UP>(a, y, raw, n, s1, s2); break;
-        case F_AVG: write_row_regs<BPP, F_AVG>(a, y, raw, n, s1, s2); break;
-        default: write_row_regs<BPP, F_PAETH>(a, y, raw, n, s1, s2); break;
+        case F_NONE: write_row_regs<BPP, F_NONE>(a, y, raw, n, acc64); break;
+        case F_SUB: write_row_regs<BPP, F_SUB>(a, y, raw, n, acc64); break;
+        case F_UP: write_row_regs<BPP, F_UP>(a, y, raw, n, acc64); break;
+        case F_AVG: write_row_regs<BPP, F_AVG>(a, y, raw, n, acc64); break;
+        default: write_row_regs<BPP, F_PAETH>(a, y, raw, n, acc64); break;
         }
-        const unsigned long long t1 = wg_sum(s1, red), t2 = wg_sum(s2, red);
-        if (threadIdx.x == 0) { a.row_sums[2 * (size_t)y] = t1; a.row_sums[2 * (size_t)y + 1] = t2; }
+        if (threadIdx.x == 0) { a.row_sums[2 * (size_t)y] = acc64[0]; a.row_sums[2 * (size_t)y + 1] = acc64[1]; }
         return;
     } else if (strategy > PNG_S_PAETH) {
         // pass 1: scores of the candidates (AdaptiveFast never looks at None / Average)

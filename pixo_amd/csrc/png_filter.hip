@@ -47,7 +47,10 @@ __device__ __forceinline__ uint32_t paeth2(uint32_t a, uint32_t b, uint32_t c)
     const s16x2 da = as_s(b) - as_s(c), db = as_s(a) - as_s(c), dd = da + db;
     const s16x2 pa = __builtin_elementwise_max(da, -da), pb = __builtin_elementwise_max(db, -db);
     const s16x2 pc = __builtin_elementwise_max(dd, -dd);
-    const uint32_t not_a = gt_mask(pa, __builtin_elementwise_min(pb, pc)), use_c = gt_mask(pb, pc);
+    uint32_t not_a = gt_mask(pa, __builtin_elementwise_min(pb, pc)), use_c = gt_mask(pb, pc);
+    // (opaque: otherwise the masks are turned back into 16-bit compares + SDWA selects + a permute, 5 half-rate
+    // instructions where subtract, shift, bit-select are 3)
+    asm volatile("" : "+v"(not_a)); asm volatile("" : "+v"(use_c));
     const uint32_t bc_sel = (c & use_c) | (b & ~use_c);
     return (bc_sel & not_a) | (a & ~not_a);
 }

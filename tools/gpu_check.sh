@@ -51,4 +51,5 @@ timeout 120 python tools/mt_throughput.py 2>&1 | tail -5 > gpurun_out/extra/mt_t
 timeout 60 python tools/warmup_probe.py 2>&1 | tail -2 > gpurun_out/extra/warmup_probe.txt
 (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_out/p2 -o p2 -- python $ROOT/tools/preset2_timing.py > /dev/null 2>&1)
 find /tmp/prof_out/p2 -name "*kernel_stats*" -exec cp {} gpurun_out/extra/kernel_stats_preset2.csv \;
+bash tools/pmc_c5.sh > gpurun_out/extra/pmc_c5.txt 2>&1
 ls gpurun_out/prof gpurun_out/extra

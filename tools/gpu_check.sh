@@ -45,7 +45,7 @@ for k in "0 noise" "1 noise" "0 gradient"; do
 done
 timeout 120 python tools/e2e_timing.py 2>&1 | tail -3 > gpurun_out/extra/e2e_timing.txt
 timeout 120 python tools/e2e_device.py 2>&1 | tail -4 > gpurun_out/extra/e2e_device.txt
-timeout 120 python tools/png_probe.py 2>&1 | tail -7 > gpurun_out/extra/png_probe.txt
+timeout 120 python tools/png_probe.py 2>&1 | tail -8 > gpurun_out/extra/png_probe.txt
 timeout 120 python tools/preset2_timing.py 2>&1 | tail -9 > gpurun_out/extra/preset2_timing.txt
 timeout 120 python tools/mt_throughput.py 2>&1 | tail -5 > gpurun_out/extra/mt_throughput.txt
 timeout 60 python tools/warmup_probe.py 2>&1 | tail -2 > gpurun_out/extra/warmup_probe.txt

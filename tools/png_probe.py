@@ -12,7 +12,7 @@ ins = [(base.to("cuda:0") ^ torch.tensor(i, dtype=torch.uint8, device="cuda:0"))
 outs = [torch.empty(png.filtered_size(w, h, bpp), dtype=torch.uint8, device="cuda:0") for _ in range(nbuf)]
 sums = torch.zeros(2 * h, dtype=torch.int64, device="cuda:0"); scratch = torch.zeros(4, dtype=torch.int32, device="cuda:0")
 s = torch.cuda.current_stream().cuda_stream
-for name in ("NONE", "SUB", "UP", "AVERAGE", "PAETH", "ADAPTIVE_FAST", "ADAPTIVE"):
+for name in ("NONE", "SUB", "UP", "AVERAGE", "PAETH", "ADAPTIVE_FAST", "ADAPTIVE", "BIGRAMS"):
     st = png.FilterStrategy[name]
     for i in range(5): png.apply_filters_async(ins[i % nbuf], w, h, bpp, outs[i % nbuf], sums, scratch, st, 0, s)
     torch.cuda.synchronize()

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Randomised parity stress (not part of the test-suite: minutes of oracle time): JPEG whole files with
+random shapes / qualities / flags and PNG filter streams with random shapes / strategies / pixel sizes,
+GPU against the oracle.  Usage: stress_parity.py SECONDS [SEED]"""
+import os, sys, time
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..")); sys.path.insert(0, os.path.join(HERE, "..", "tests"))
+import numpy as np
+import synth, oracle_lib as O
+from pixo_amd import jpeg, png, ColorType
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time(); nj = npn = 0; bad = []
+
+def content(n, kind, seed):
+    if kind == 0: return synth.lcg_bytes(n, seed)
+    if kind == 1: return (np.cumsum(synth.lcg_bytes(n, seed).astype(np.int64) % 5) % 256).astype(np.uint8)
+    if kind == 2: return np.full(n, seed % 256, np.uint8)
+    b = synth.lcg_bytes(n, seed); b[b < 128] = 0; b[b >= 128] = 255; return b
+
+while time.time() - t0 < budget:
+    # ---- JPEG
+    big = rng.rand() < 0.15
+    w = int(rng.randint(1, 2600 if big else 400)); h = int(rng.randint(1, 1400 if big else 300))
+    ct = 2 if rng.rand() < 0.75 else 0
+    ss = int(rng.rand() < 0.6)
+    q = int(rng.randint(1, 101))
+    flags = dict(optimize_huffman=bool(rng.rand() < 0.4), progressive=bool(rng.rand() < 0.3), trellis=bool(rng.rand() < 0.3))
+    restart = int(rng.randint(1, 40)) if rng.rand() < 0.25 else None
+    px = content(w * h * (3 if ct == 2 else 1), int(rng.randint(0, 4)), int(rng.randint(1, 1 << 30)))
+    b = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss)) \
+        .optimize_huffman(flags["optimize_huffman"]).progressive(flags["progressive"]).trellis_quant(flags["trellis"])
+    if restart: b = b.restart_interval(restart)
+    got = jpeg.encode(px, b.build())
+    kw = dict(flags); 
+    if restart: kw["restart"] = restart
+    want = O.encode(px, O.make_options(w, h, ct, q, ss, **kw))
+    nj += 1
+    if got != want:
+        bad.append(("jpeg", w, h, ct, ss, q, flags, restart)); print("MISMATCH", bad[-1], flush=True)
+    # ---- PNG
+    bpp = int(rng.choice([1, 2, 3, 4, 6, 8])); w = int(rng.randint(1, 6000 if rng.rand() < 0.2 else 700)); h = int(rng.randint(1, 120))
+    st = int(rng.randint(0, 9))
+    px = content(w * h * bpp, int(rng.randint(0, 4)), int(rng.randint(1, 1 << 30)))
+    want, wad = O.png_filter(px, w, h, bpp, st, stateful_fast=(h <= 32))
+    got, gad = png.apply_filters(px, w, h, bpp, st)
+    npn += 1
+    if not (np.array_equal(got, want) and gad == wad):
+        bad.append(("png", w, h, bpp, st)); print("MISMATCH", bad[-1], flush=True)
+print("jpeg cases %d, png cases %d, mismatches %d, %.0f s" % (nj, npn, len(bad), time.time() - t0))
+sys.exit(1 if bad else 0)

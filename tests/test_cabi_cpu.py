@@ -186,3 +186,34 @@ def test_restart_intervals_match_oracle_and_marker_structure(interval, mode):
         assert len(rst) == (units - 1) // interval
         assert rst == [0xD0 + (k % 8) for k in range(len(rst))]
         assert got.endswith(b"\xff\xd9") and not (scan[-4] == 0xFF and 0xD0 <= scan[-3] <= 0xD7)
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/pixo_hip.h is the FFI contract: it must compile as strict C99 (what cgo / bindgen / ctypesgen
+    read) and a C program must link against the library and get the documented answers without a GPU."""
+    import os, subprocess
+    root = os.path.join(os.path.dirname(_lib.__file__), "..")
+    src = tmp_path / "t.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "pixo_hip.h"
+int main(void) {
+    pixo_jpeg_options o;
+    size_t yb = 0, cb = 0;
+    pixo_jpeg_options_from_preset(&o, 4096, 4096, 80, 2);
+    if (!(o.progressive && o.trellis_quant && o.optimize_huffman && o.subsampling == PIXO_S420)) return 1;
+    if (pixo_hip_coeff_geometry(4096, 4096, PIXO_RGB, PIXO_S420, &yb, &cb) != PIXO_OK) return 2;
+    if (yb != 262144 || cb != 65536) return 3;
+    if (pixo_hip_coeff_geometry(0, 7, PIXO_RGB, PIXO_S420, &yb, &cb) != PIXO_ERR_INVALID_DIMENSIONS) return 4;
+    if (strcmp(pixo_hip_last_error(), "Invalid image dimensions: 0x7") != 0) return 5;
+    printf("%s\n", pixo_hip_version());
+    return 0;
+}
+''')
+    exe = str(tmp_path / "t")
+    lib = os.path.dirname(_lib.__file__)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-o", exe, str(src),
+                           "-L" + lib, "-lpixo_hip", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert "gfx950" in out

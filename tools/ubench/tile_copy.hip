@@ -20,9 +20,17 @@ __global__ __launch_bounds__(192) void tile_copy(const uint8_t *in, uint8_t *out
     __shared__ uint32_t lds[64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t id = blockIdx.x;
-    const uint32_t tx = R == 0 ? id % 32 : id % 8, ty = R == 0 ? id / 32 : id / 8;
+    const uint32_t tx = R == 0 ? id % 32 : id % 8, ty = R == 0 ? id / 32 : id / 8; // (R == 2: as R == 1)
     const uint8_t *base = in + (R == 0 ? (size_t)ty * 64 * kPitch + tx * 384 : (size_t)ty * 16 * kPitch + tx * 1536);
     uint32_t acc = 0;
+    if (R == 2) { // the 512x16 tile with 16-byte loads: 16 rows x 96 lanes x 16 B = 1536 chunks
+#pragma unroll
+        for (int pass = 0; pass < 8; pass++) {
+            const int idx = pass * 192 + tid, row = idx / 96, col = (idx % 96) * 16;
+            const uint4 v = *reinterpret_cast<const uint4 *>(in + (size_t)(id / 8) * 16 * kPitch + (id % 8) * 1536 + (size_t)row * kPitch + col);
+            acc ^= v.x + v.y + v.z + v.w;
+        }
+    } else
 #pragma unroll
     for (int pass = 0; pass < 11; pass++) {
         const int idx = pass * 192 + tid;
@@ -90,6 +98,8 @@ int main()
     time("R1 512x16 tiles, W0 half-block stores", tile_copy<1, 0, 0>);
     time("R1 512x16 tiles, W0 half-block stores 1500 instr apart", tile_copy<1, 0, 1500>);
     time("R1 512x16 tiles, W1 whole-block stores", tile_copy<1, 1, 0>);
+    time("R2 512x16 tiles with 16-byte loads, W1 whole-block stores", tile_copy<2, 1, 0>);
+    time("R1 512x16 tiles, W1 whole-block stores (again)", tile_copy<1, 1, 0>);
     time("R0 128x64 tiles, W0 half-block stores (again)", tile_copy<0, 0, 0>);
     return 0;
 }

@@ -499,25 +499,10 @@ template <int BPP, bool FAST, int KIND> __global__ __launch_bounds__(kThreads) v
         uint32_t sc[5] = {0, 0, 0, 0, 0};
         const bool fast = strategy == PNG_S_ADAPTIVE_FAST;
         for (int k0 = (int)threadIdx.x * 4; k0 < ndw; k0 += per_iter) {
-            Group g;
-            load_group<BPP, FAST>(row, prev, k0, n, g);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t m = g.valid[j];
-#ifdef PIXO_PNG_EXP_LOADS_ONLY // (timing experiments only: pass 1 = its loads)
-                sc[F_SUB] += (g.cur[j] ^ g.left[j] ^ g.up[j] ^ g.ul[j]) & m;
-#else
-                sc[F_SUB] = score4(filtered(F_SUB, g, j) & m, sc[F_SUB]);
-                sc[F_UP] = score4(filtered(F_UP, g, j) & m, sc[F_UP]);
-#ifndef PIXO_PNG_EXP_NO_PAETH1 // (timing experiments only: pass 1 without the Paeth candidate)
-                sc[F_PAETH] = score4(filtered(F_PAETH, g, j) & m, sc[F_PAETH]);
-#endif
-                if (!fast) {
-                    sc[F_NONE] = score4(g.cur[j] & m, sc[F_NONE]);
-                    sc[F_AVG] = score4(filtered(F_AVG, g, j) & m, sc[F_AVG]);
-                }
-#endif
-            }
+            Raw r;
+            load_raw<BPP, FAST>(row, prev, k0, n, r);
+            if (4 * (k0 + 4) <= n) score_group<BPP, false>(r, k0, n, fast, sc);
+            else score_group<BPP, true>(r, k0, n, fast, sc);
         }
         unsigned long long tot[5];
 #pragma unroll
@@ -528,9 +513,6 @@ template <int BPP, bool FAST, int KIND> __global__ __launch_bounds__(kThreads) v
 
     // pass 2: the winning filter -> output row (filter byte + n bytes), Adler partial sums
     unsigned long long s1 = 0, s2 = 0;
-#ifdef PIXO_PNG_EXP_NO_PASS2 // (timing experiments only)
-    if (f != 99) { if (threadIdx.x == 0) a.row_sums[2 * (size_t)y] = f; return; }
-#endif
     switch (f) { // uniform: one filter's code and loads per row
     case F_NONE: write_row<BPP, FAST, F_NONE, 0>(a, y, row, prev, n, s1, s2); break;
     case F_SUB: write_row<BPP, FAST, F_SUB, 1>(a, y, row, prev, n, s1, s2); break;

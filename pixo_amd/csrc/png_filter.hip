@@ -288,7 +288,7 @@ __device__ __forceinline__ void emit_group(const Group &g, int k0, int n, T L, b
 // The staged row (filter byte at LDS offset 15, row byte i at 16 + i) -> global memory as 16-byte chunks
 // aligned in GLOBAL memory: each chunk is five aligned LDS dwords shifted by a row-uniform byte count; the
 // few bytes before the first / after the last aligned chunk are stored singly.
-__device__ __forceinline__ void flush_stage(const uint8_t *stage, uint8_t *orow, int n)
+template <int NT> __device__ __forceinline__ void flush_stage(const uint8_t *stage, uint8_t *orow, int n)
 {
     __syncthreads();
     // stream byte p of this row (0 = filter byte) sits at LDS offset 15 + p
@@ -300,7 +300,7 @@ __device__ __forceinline__ void flush_stage(const uint8_t *stage, uint8_t *orow,
     if ((int)threadIdx.x < tail) orow[h + 16 * chunks + threadIdx.x] = stage[15 + h + 16 * chunks + threadIdx.x];
     const int t = 15 + h, r = t & 3; // LDS offset of the first chunk; r is uniform
     const uint32_t *w = reinterpret_cast<const uint32_t *>(stage) + (t >> 2);
-    for (int c = threadIdx.x; c < chunks; c += kThreads) {
+    for (int c = threadIdx.x; c < chunks; c += NT) {
         uint32_t d[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) d[i] = w[4 * c + i];
@@ -332,18 +332,19 @@ __device__ __forceinline__ void write_row(const Args &a, uint32_t y, const uint8
         load_group<BPP, FAST, NEED>(row, prev, k0, n, g);
         emit_group<F, unsigned long long>(g, k0, n, L, staged, stage, orow, s1, s2);
     }
-    if (staged) flush_stage(stage, orow, n);
+    if (staged) flush_stage<kThreads>(stage, orow, n);
 }
 
-// The register-resident form (rows of at most kRegIters x 4 KiB, always staged): the workgroup loaded
+// The register-resident form (rows of at most kRegIters x 4 KiB with 256 threads, x 8 KiB with 512; always
+// staged): the workgroup loaded
 // the whole row and the row above ONCE, all loads in flight together; scoring and the winning filter
 // both work from those registers.
 constexpr int kRegIters = 4;
-template <int BPP, int F>
+template <int BPP, int F, int NT>
 __device__ __forceinline__ void write_row_regs(const Args &a, uint32_t y, const Raw *raw, int n, unsigned long long *acc64)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
-    const int ndw = (n + 3) / 4, per_iter = kThreads * 4;
+    const int ndw = (n + 3) / 4, per_iter = NT * 4; // (256 or 512 threads)
     uint8_t *orow = a.out + (size_t)y * (a.row_bytes + 1);
     const uint32_t L = (uint32_t)n + 1;
     uint32_t s1 = 0, s2 = 0; // this thread's 64 bytes: s2 < 16 x 16385 x 1020 < 2^32
@@ -365,7 +366,7 @@ __device__ __forceinline__ void write_row_regs(const Args &a, uint32_t y, const 
         atomicAdd(&acc64[0], (unsigned long long)w1);
         atomicAdd(&acc64[1], ((unsigned long long)hi << 16) + lo);
     }
-    flush_stage(stage, orow, n);
+    flush_stage<NT>(stage, orow, n);
 }
 
 // Bigrams (filter.rs:406-472, score_bigrams :635-649): the score of a candidate is the number of DISTINCT
@@ -412,8 +413,10 @@ __device__ __forceinline__ unsigned long long bigram_score(const uint8_t *row, c
 // Three instantiations by register need: K_GENERAL (fixed filters; adaptive strategies on rows too long to
 // hold: two passes over the row, 44 VGPRs), K_REGS (adaptive strategies, the row in registers, ~100),
 // K_BIGRAMS (~110).
-enum { K_GENERAL = 0, K_REGS = 1, K_BIGRAMS = 2 };
-template <int BPP, bool FAST, int KIND> __global__ __launch_bounds__(kThreads) void png_filter_kernel(const Args a)
+// K_REGS512: the same with 512 threads, rows of up to 32 KiB.
+enum { K_GENERAL = 0, K_REGS = 1, K_BIGRAMS = 2, K_REGS512 = 3 };
+template <int BPP, bool FAST, int KIND>
+__global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) void png_filter_kernel(const Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
     __shared__ unsigned long long red[20];
@@ -431,7 +434,8 @@ template <int BPP, bool FAST, int KIND> __global__ __launch_bounds__(kThreads) v
     const int n = (int)a.row_bytes; // < 2^31 (checked by the launcher)
     const uint8_t *row = a.data + (size_t)y * a.row_bytes;
     const uint8_t *prev = y ? row - a.row_bytes : nullptr;
-    const int ndw = (n + 3) / 4, per_iter = kThreads * 4;
+    constexpr int NT = KIND == K_REGS512 ? 2 * kThreads : kThreads;
+    const int ndw = (n + 3) / 4, per_iter = NT * 4;
     int strategy = a.forced ? *a.forced : a.strategy;
 
     int f = strategy;
@@ -448,7 +452,7 @@ template <int BPP, bool FAST, int KIND> __global__ __launch_bounds__(kThreads) v
         for (int c = F_SUB; c <= F_PAETH; c++)
             if (tot[c] < tot[f]) f = c;
         __syncthreads(); // the write-out below reuses the dynamic LDS
-    } else if (KIND == K_REGS) { // (the launcher checked: strategy > Paeth, ndw <= kRegIters * per_iter, staged)
+    } else if (KIND == K_REGS || KIND == K_REGS512) { // (the launcher checked: strategy > Paeth, ndw <= kRegIters * per_iter, staged)
         // the whole row (and the row above) in registers: one round of loads, all in flight together
         if (threadIdx.x < 8) acc32[threadIdx.x] = 0;
         if (threadIdx.x < 2) acc64[threadIdx.x] = 0;
@@ -486,11 +490,11 @@ template <int BPP, bool FAST, int KIND> __global__ __launch_bounds__(kThreads) v
         f = decide(strategy, tot, (unsigned long long)n);
         if (a.winner0 && y == 0 && threadIdx.x == 0) *a.winner0 = f;
         switch (f) {
-        case F_NONE: write_row_regs<BPP, F_NONE>(a, y, raw, n, acc64); break;
-        case F_SUB: write_row_regs<BPP, F_SUB>(a, y, raw, n, acc64); break;
-        case F_UP: write_row_regs<BPP, F_UP>(a, y, raw, n, acc64); break;
-        case F_AVG: write_row_regs<BPP, F_AVG>(a, y, raw, n, acc64); break;
-        default: write_row_regs<BPP, F_PAETH>(a, y, raw, n, acc64); break;
+        case F_NONE: write_row_regs<BPP, F_NONE, NT>(a, y, raw, n, acc64); break;
+        case F_SUB: write_row_regs<BPP, F_SUB, NT>(a, y, raw, n, acc64); break;
+        case F_UP: write_row_regs<BPP, F_UP, NT>(a, y, raw, n, acc64); break;
+        case F_AVG: write_row_regs<BPP, F_AVG, NT>(a, y, raw, n, acc64); break;
+        default: write_row_regs<BPP, F_PAETH, NT>(a, y, raw, n, acc64); break;
         }
         if (threadIdx.x == 0) { a.row_sums[2 * (size_t)y] = acc64[0]; a.row_sums[2 * (size_t)y + 1] = acc64[1]; }
         return;
@@ -535,9 +539,13 @@ template <int BPP> hipError_t launch_bpp(const Args &a, uint32_t rows, bool fast
         const uint32_t lds = a.stage_bytes + 8192u;
         if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, K_BIGRAMS>), dim3(rows), dim3(kThreads), lds, s, a);
         else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_BIGRAMS>), dim3(rows), dim3(kThreads), lds, s, a);
-    } else if (a.strategy > PNG_S_PAETH && !a.forced && ndw <= (uint64_t)kRegIters * kThreads * 4 && a.stage_bytes != 0) {
-        if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, K_REGS>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
-        else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_REGS>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
+    } else if (a.strategy > PNG_S_PAETH && !a.forced && ndw <= (uint64_t)kRegIters * 2 * kThreads * 4 && a.stage_bytes != 0) {
+        // rows of up to 16 KiB: 256 threads hold them; up to 32 KiB: 512 threads
+        if (ndw <= (uint64_t)kRegIters * kThreads * 4) {
+            if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, K_REGS>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
+            else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_REGS>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
+        } else if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, K_REGS512>), dim3(rows), dim3(2 * kThreads), a.stage_bytes, s, a);
+        else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_REGS512>), dim3(rows), dim3(2 * kThreads), a.stage_bytes, s, a);
     } else if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, K_GENERAL>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
     else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_GENERAL>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
     return hipGetLastError();

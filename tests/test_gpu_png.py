@@ -106,10 +106,11 @@ def test_bigrams_on_long_rows_structured_content_and_the_c5_shape():
 
 @pytest.mark.parametrize("strategy", [5, 6, 7])
 def test_rows_around_the_register_path_limit(strategy):
-    """The adaptive strategies hold rows of at most 16 KiB in registers (K_REGS) and take the two-pass
-    form beyond: 16380, 16384 (the limit), 16388 and 16400 bytes per row, plus short rows whose last
-    group is partial, all against the oracle."""
-    for (w, bpp) in [(4095, 4), (4096, 4), (4097, 4), (4100, 4), (5461, 3), (5462, 3), (16384, 1), (16385, 1), (2731, 6), (37, 1), (3, 2)]:
+    """The adaptive strategies hold rows of at most 16 KiB (256 threads) or 32 KiB (512 threads) in registers
+    (K_REGS) and take the two-pass form beyond: rows around both limits, plus short rows whose last group is
+    partial, all against the oracle."""
+    for (w, bpp) in [(4095, 4), (4096, 4), (4097, 4), (4100, 4), (5461, 3), (5462, 3), (16384, 1), (16385, 1), (2731, 6), (37, 1), (3, 2),
+                     (8191, 4), (8192, 4), (8193, 4), (5000, 6), (4096, 8), (4097, 8), (32768, 1), (32769, 1)]:  # 512-thread form and beyond
         h = 34
         px = synth.lcg_bytes(w * h * bpp, w)
         px[w * bpp * 7: w * bpp * 9] = (np.cumsum(px[w * bpp * 7: w * bpp * 9].astype(np.int64) % 3) % 256).astype(np.uint8)

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <mutex>
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -67,6 +68,8 @@ int device_tables(int device, const float **out)
 }
 
 // ---- thread-local execution context --------------------------------------------------
+std::atomic<bool> g_exiting{false};
+std::once_flag g_exit_hook;
 struct Context {
     int device = 0;
     bool ready = false;
@@ -118,6 +121,7 @@ struct Context {
                         "Compression error: no MI355X/HIP device available (pixo_hip has no CPU fallback)");
         HIP_TRY(hipSetDevice(device));
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        std::call_once(g_exit_hook, [] { std::atexit([] { g_exiting.store(true); }); });
         ready = true;
         return PIXO_OK;
     }
@@ -150,12 +154,29 @@ struct Context {
         }
         return PIXO_OK;
     }
-    ~Context()
-    {
-        // Process teardown order vs. the HIP runtime is unspecified; leak deliberately
-        // rather than call into a runtime that may already be gone.
-    }
+    // A thread that ends gives its buffers back (servers with a thread per request would otherwise run the
+    // device out of memory).  Not during process exit: an atexit handler registered at first use — it runs
+    // before the HIP runtime's own, which were registered when the runtime was loaded — raises a flag, and
+    // from then on everything is left to the dying process.
+    ~Context();
 };
+Context::~Context()
+{
+    if (!ready || g_exiting.load()) return;
+    if (hipSetDevice(device) != hipSuccess) return;
+    if (stream) (void)hipStreamSynchronize(stream);
+    Buf *bufs[] = {&e_tables, &e_hist, &e_len, &e_off, &e_tmp, &e_totals, &e_stream, &e_tile_ff, &e_tile_base, &e_out, &e_seg_bytes,
+                   &e_seg_off, &p_in, &p_out, &p_sums, &p_scratch, &t_raw, &t_trail, &g_flags, &g_rank, &g_by_rank};
+    for (Buf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (d_px) (void)hipFree(d_px);
+    if (d_coef) (void)hipFree(d_coef);
+    if (h_coef) (void)hipHostFree(h_coef);
+    if (h_sums) (void)hipHostFree(h_sums);
+    if (h_totals) (void)hipHostFree(h_totals);
+    if (h_file) (void)hipHostFree(h_file);
+    if (stream) (void)hipStreamDestroy(stream);
+}
 thread_local Context t_ctx;
 
 // Runs the device pipeline for host pixels; on success `*coef` points at pinned host

@@ -383,3 +383,24 @@ def test_encode_into_caller_storage_and_the_reserve_and_retry_protocol():
         assert n == len(want) and buf[:n].tobytes() == want and not buf[n:].any()
     with pytest.raises(error.InvalidQuality):
         jpeg.encode_into_buffer(np.zeros(10, np.uint8), px, B(w, h).quality(0).build())
+
+
+def test_threads_that_end_give_their_device_buffers_back():
+    """A server with one thread per request: 24 short-lived threads in sequence, each encoding a 2048x2048
+    image (about 70 MB of per-thread device and pinned buffers).  The library frees a thread's context when the
+    thread ends, so the device's free memory does not shrink by 24 contexts."""
+    import threading
+    import torch
+    w = h = 2048
+    px = synth.noise(w, h, 3)
+    o = jpeg.JpegOptions.builder(w, h).quality(80).subsampling(jpeg.Subsampling.S420).build()
+    want = jpeg.encode(px, o)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(24):
+        res = []
+        t = threading.Thread(target=lambda: res.append(jpeg.encode(px, o)))
+        t.start(); t.join()
+        assert res[0] == want
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 200 << 20, (free0 - free1) >> 20  # 24 leaked contexts would be > 1 GB

@@ -196,6 +196,9 @@ int pixo_hip_band(uint32_t width, uint32_t height, uint8_t color_type, uint8_t s
 
 int pixo_hip_device_count(void);            /* 0 when no GPU / no driver              */
 int pixo_hip_set_device(int device);        /* device for the calling thread's context */
+/* Releases the calling thread's device and pinned buffers (they only grow while the thread lives and are
+ * released by themselves when it ends): for a long-lived thread after an unusually large image. */
+int pixo_hip_trim(void);
 void pixo_hip_free(void *p);
 const char *pixo_hip_last_error(void);      /* thread-local, never NULL               */
 const char *pixo_hip_version(void);

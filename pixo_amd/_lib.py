@@ -29,7 +29,7 @@ SYMBOLS = [
     "pixo_hip_jpeg_coeffs_device", "pixo_hip_jpeg_entropy_encode", "pixo_hip_jpeg_entropy_encode_device",
     "pixo_hip_jpeg_encode_device", "pixo_hip_jpeg_encode_batch_device", "pixo_hip_png_filter", "pixo_hip_png_filter_device", "pixo_hip_png_filter_async",
     "pixo_hip_png_adler32_from_row_sums", "pixo_hip_band",
-    "pixo_hip_device_count", "pixo_hip_set_device", "pixo_hip_free", "pixo_hip_last_error",
+    "pixo_hip_device_count", "pixo_hip_set_device", "pixo_hip_trim", "pixo_hip_free", "pixo_hip_last_error",
     "pixo_hip_version",
 ]
 

@@ -159,16 +159,19 @@ struct Context {
     // before the HIP runtime's own, which were registered when the runtime was loaded — raises a flag, and
     // from then on everything is left to the dying process.
     ~Context();
+    void release(); // everything back to the driver; the context starts over at its next use
 };
-Context::~Context()
+void Context::release()
 {
-    if (!ready || g_exiting.load()) return;
+    if (!ready) return;
     if (hipSetDevice(device) != hipSuccess) return;
     if (stream) (void)hipStreamSynchronize(stream);
     Buf *bufs[] = {&e_tables, &e_hist, &e_len, &e_off, &e_tmp, &e_totals, &e_stream, &e_tile_ff, &e_tile_base, &e_out, &e_seg_bytes,
                    &e_seg_off, &p_in, &p_out, &p_sums, &p_scratch, &t_raw, &t_trail, &g_flags, &g_rank, &g_by_rank};
-    for (Buf *b : bufs)
+    for (Buf *b : bufs) {
         if (b->p) (void)hipFree(b->p);
+        b->p = nullptr; b->cap = 0;
+    }
     if (d_px) (void)hipFree(d_px);
     if (d_coef) (void)hipFree(d_coef);
     if (h_coef) (void)hipHostFree(h_coef);
@@ -176,6 +179,13 @@ Context::~Context()
     if (h_totals) (void)hipHostFree(h_totals);
     if (h_file) (void)hipHostFree(h_file);
     if (stream) (void)hipStreamDestroy(stream);
+    d_px = d_coef = h_coef = nullptr; px_cap = coef_cap = hcoef_cap = 0;
+    h_sums = nullptr; hsums_cap = 0; h_totals = nullptr; h_file = nullptr; hfile_cap = 0;
+    stream = nullptr; ready = false;
+}
+Context::~Context()
+{
+    if (!g_exiting.load()) release();
 }
 thread_local Context t_ctx;
 
@@ -1058,22 +1068,14 @@ int pixo_hip_device_count(void)
 int pixo_hip_set_device(int device)
 {
     Context &c = t_ctx;
-    if (c.ready && c.device != device) {
-        // rebind: drop the old device's buffers and start over
-        (void)hipSetDevice(c.device);
-        if (c.d_px) (void)hipFree(c.d_px);
-        if (c.d_coef) (void)hipFree(c.d_coef);
-        if (c.h_coef) (void)hipHostFree(c.h_coef);
-        if (c.h_totals) (void)hipHostFree(c.h_totals);
-        if (c.h_file) (void)hipHostFree(c.h_file);
-        if (c.h_sums) (void)hipHostFree(c.h_sums);
-        for (Context::Buf *b : {&c.e_tables, &c.e_hist, &c.e_len, &c.e_off, &c.e_tmp, &c.e_totals, &c.e_stream,
-                                &c.e_tile_ff, &c.e_tile_base, &c.e_out, &c.e_seg_bytes, &c.e_seg_off, &c.p_in, &c.p_out, &c.p_sums, &c.p_scratch, &c.t_raw})
-            if (b->p) (void)hipFree(b->p);
-        if (c.stream) (void)hipStreamDestroy(c.stream);
-        c = Context();
-    }
+    if (c.ready && c.device != device) c.release(); // rebind: drop the old device's buffers and start over
     c.device = device;
+    return PIXO_OK;
+}
+
+int pixo_hip_trim(void)
+{
+    t_ctx.release();
     return PIXO_OK;
 }
 

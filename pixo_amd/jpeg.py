@@ -341,3 +341,8 @@ def device_count() -> int:
 
 def set_device(device: int) -> None:
     _lib.load().pixo_hip_set_device(device)
+
+
+def trim() -> None:
+    """Release the calling thread's device and pinned buffers (`pixo_hip_trim`)."""
+    _lib.load().pixo_hip_trim()

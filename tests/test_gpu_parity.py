@@ -404,3 +404,18 @@ def test_threads_that_end_give_their_device_buffers_back():
         assert res[0] == want
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 200 << 20, (free0 - free1) >> 20  # 24 leaked contexts would be > 1 GB
+
+
+def test_trim_releases_the_threads_buffers_and_the_next_call_starts_over():
+    import torch
+    w = h = 4096
+    px = synth.noise(w, h, 42)
+    o = jpeg.JpegOptions.builder(w, h).quality(80).subsampling(jpeg.Subsampling.S420).build()
+    a = jpeg.encode(px, o)
+    torch.cuda.synchronize()
+    held, _ = torch.cuda.mem_get_info()
+    jpeg.trim()
+    freed, _ = torch.cuda.mem_get_info()
+    assert freed - held > 100 << 20  # pixels + tuple + entropy buffers of a 4096x4096 image
+    assert jpeg.encode(px, o) == a
+    jpeg.trim(); jpeg.trim()  # idempotent

@@ -662,6 +662,10 @@ int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options
 
 } // namespace
 
+// A null pointer where the contract wants an object is a caller bug the Rust API cannot express; the C ABI
+// answers it with an error instead of a crash.
+#define PIXO_REQUIRE(p) do { if (!(p)) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument '" #p "'"); } while (0)
+
 extern "C" {
 
 void pixo_jpeg_options_from_preset(pixo_jpeg_options *o, uint32_t width, uint32_t height,
@@ -678,6 +682,9 @@ void pixo_jpeg_options_from_preset(pixo_jpeg_options *o, uint32_t width, uint32_
 int pixo_hip_jpeg_encode(const uint8_t *data, size_t data_len, const pixo_jpeg_options *options,
                          uint8_t **out, size_t *out_len)
 {
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(out);
+    PIXO_REQUIRE(out_len);
     std::vector<uint8_t> spill;
     const uint8_t *file = nullptr;
     size_t n = 0;
@@ -689,6 +696,8 @@ int pixo_hip_jpeg_encode(const uint8_t *data, size_t data_len, const pixo_jpeg_o
 int pixo_hip_jpeg_encode_into(uint8_t *output, size_t capacity, const uint8_t *data, size_t data_len,
                               const pixo_jpeg_options *options, size_t *out_len)
 {
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(out_len);
     std::vector<uint8_t> spill;
     const uint8_t *file = nullptr;
     size_t n = 0;
@@ -705,6 +714,8 @@ int pixo_hip_encode_jpeg(const uint8_t *data, size_t data_len, uint32_t width, u
                          uint8_t color_type, uint8_t quality, uint8_t preset, int subsampling_420,
                          uint8_t **out, size_t *out_len)
 { // wasm.rs:113-142
+    PIXO_REQUIRE(out);
+    PIXO_REQUIRE(out_len);
     if (color_type != PIXO_GRAY && color_type != PIXO_RGB)
         return fail(PIXO_ERR_INVALID_COLOR_ARG, "Invalid color type for JPEG: " + std::to_string(color_type) +
                                                     ". Expected 0 (Gray) or 2 (Rgb)");
@@ -718,6 +729,8 @@ int pixo_hip_encode_jpeg(const uint8_t *data, size_t data_len, uint32_t width, u
 int pixo_hip_coeff_geometry(uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling,
                             size_t *y_blocks, size_t *c_blocks)
 {
+    PIXO_REQUIRE(y_blocks);
+    PIXO_REQUIRE(c_blocks);
     if (width == 0 || height == 0)
         return fail(PIXO_ERR_INVALID_DIMENSIONS,
                     "Invalid image dimensions: " + std::to_string(width) + "x" + std::to_string(height));
@@ -779,6 +792,9 @@ int pixo_hip_jpeg_coeffs_device(const void *d_pixels, uint32_t width, uint32_t h
 int pixo_hip_jpeg_entropy_encode(const int16_t *y, const int16_t *cb, const int16_t *cr,
                                  const pixo_jpeg_options *options, uint8_t **out, size_t *out_len)
 {
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(out);
+    PIXO_REQUIRE(out_len);
     std::string msg;
     int rc = pixo_host::validate(*options, false, 0, msg);
     if (rc) return fail(rc, msg);
@@ -834,6 +850,9 @@ int device_tuple_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_t 
 int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const void *d_cr,
                                         const pixo_jpeg_options *options, uint8_t **out, size_t *out_len)
 {
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(out);
+    PIXO_REQUIRE(out_len);
     std::string msg;
     int rc = pixo_host::validate(*options, false, 0, msg);
     if (rc) return fail(rc, msg);
@@ -846,6 +865,9 @@ int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const
 
 int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *options, uint8_t **out, size_t *out_len)
 {
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(out);
+    PIXO_REQUIRE(out_len);
     std::string msg;
     int rc = pixo_host::validate(*options, false, 0, msg);
     if (rc) return fail(rc, msg);
@@ -977,6 +999,9 @@ int pixo_hip_png_filter_device(const void *d_data, uint32_t width, uint32_t heig
 int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_options *options, uint32_t batch,
                                       uint8_t **files, size_t *lens)
 {
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(files);
+    PIXO_REQUIRE(lens);
     std::string msg;
     int rc = pixo_host::validate(*options, false, 0, msg);
     if (rc) return fail(rc, msg);

@@ -217,3 +217,17 @@ int main(void) {
                            "-L" + lib, "-lpixo_hip", "-Wl,-rpath," + lib])
     out = subprocess.run([exe], stdout=subprocess.PIPE, check=True).stdout.decode()
     assert "gfx950" in out
+
+
+def test_null_arguments_are_errors_not_crashes():
+    L = _lib.load()
+    o = _lib.JpegOptionsC()
+    L.pixo_jpeg_options_from_preset(C.byref(o), 8, 8, 80, 0)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    px = synth.noise(8, 8)
+    assert L.pixo_hip_jpeg_encode(px.ctypes.data, px.size, None, C.byref(out), C.byref(n)) == -6
+    assert b"null argument 'options'" in L.pixo_hip_last_error()
+    assert L.pixo_hip_jpeg_encode(px.ctypes.data, px.size, C.byref(o), None, C.byref(n)) == -6
+    assert L.pixo_hip_jpeg_encode_device(None, None, C.byref(out), C.byref(n)) == -6
+    L.pixo_hip_coeff_geometry.argtypes = [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, C.c_void_p, C.c_void_p]
+    assert L.pixo_hip_coeff_geometry(8, 8, 2, 1, None, None) == -6

@@ -135,6 +135,13 @@ int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const
 int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *options,
                                 uint8_t **out, size_t *out_len);
 
+/* The same into caller storage (`encode_into` for resident pixels): headers and the entropy-coded bytes
+ * are written straight into `output` — with pinned (hipHostMalloc / registered) storage the device-to-host
+ * copy is the only pass over the file.  *out_len receives the file size, also on
+ * PIXO_ERR_BUFFER_TOO_SMALL (nothing is copied then). */
+int pixo_hip_jpeg_encode_device_into(const void *d_pixels, const pixo_jpeg_options *options,
+                                     uint8_t *output, size_t capacity, size_t *out_len);
+
 /* pixo::jpeg::encode for `batch` equally sized images back to back in HBM (config 3: 64 x 1080p):
  * one coefficient launch and ONE pass of the device entropy stage for all of them (every image is a
  * byte-aligned segment of one packed stream), files[i] / lens[i] receive `batch` malloc'd files

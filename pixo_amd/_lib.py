@@ -27,7 +27,7 @@ SYMBOLS = [
     "pixo_jpeg_options_from_preset", "pixo_hip_jpeg_encode", "pixo_hip_jpeg_encode_into",
     "pixo_hip_encode_jpeg", "pixo_hip_coeff_geometry", "pixo_hip_jpeg_coeffs",
     "pixo_hip_jpeg_coeffs_device", "pixo_hip_jpeg_entropy_encode", "pixo_hip_jpeg_entropy_encode_device",
-    "pixo_hip_jpeg_encode_device", "pixo_hip_jpeg_encode_batch_device", "pixo_hip_png_filter", "pixo_hip_png_filter_device", "pixo_hip_png_filter_async",
+    "pixo_hip_jpeg_encode_device", "pixo_hip_jpeg_encode_device_into", "pixo_hip_jpeg_encode_batch_device", "pixo_hip_png_filter", "pixo_hip_png_filter_device", "pixo_hip_png_filter_async",
     "pixo_hip_png_adler32_from_row_sums", "pixo_hip_band",
     "pixo_hip_device_count", "pixo_hip_set_device", "pixo_hip_trim", "pixo_hip_free", "pixo_hip_last_error",
     "pixo_hip_version",
@@ -82,6 +82,7 @@ def load():
     L.pixo_hip_jpeg_entropy_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, optp, u8pp, szp]
     L.pixo_hip_jpeg_entropy_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, optp, u8pp, szp]
     L.pixo_hip_jpeg_encode_device.argtypes = [C.c_void_p, optp, u8pp, szp]
+    L.pixo_hip_jpeg_encode_device_into.argtypes = [C.c_void_p, optp, C.c_void_p, C.c_size_t, szp]
     L.pixo_hip_jpeg_encode_batch_device.argtypes = [C.c_void_p, optp, C.c_uint32, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
     L.pixo_hip_png_filter.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32,
                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]

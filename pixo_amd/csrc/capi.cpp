@@ -268,8 +268,10 @@ struct Stopwatch { // PIXO_HIP_TRACE=1: per-phase wall times of the device entro
 // headers; no EOI is written.
 int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                              const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len,
-                             uint32_t batch = 1, std::vector<uint64_t> *image_starts = nullptr, size_t *header_len = nullptr)
-{
+                             uint32_t batch = 1, std::vector<uint64_t> *image_starts = nullptr, size_t *header_len = nullptr,
+                             uint8_t *dest = nullptr, size_t dest_cap = 0)
+{ // dest != null: the file goes straight into the caller's storage (no pinned intermediate); when it does not
+  // fit, *file_len says how much is needed and nothing is copied (PIXO_ERR_BUFFER_TOO_SMALL)
     Stopwatch sw;
     Context &c = t_ctx;
     namespace pd = pixo_dev;
@@ -374,9 +376,17 @@ int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_
     std::vector<uint8_t> head;
     pixo_host::file_headers(head, o, h);
     const size_t hdr = head.size(), total = hdr + scan_bytes + 2;
-    int rc = c.reserve_hfile(total);
-    if (rc) return rc;
-    uint8_t *buf = c.h_file;
+    uint8_t *buf = dest;
+    if (dest) {
+        if (total > dest_cap) {
+            *file_len = total;
+            return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(total) + " bytes");
+        }
+    } else {
+        int rc = c.reserve_hfile(total);
+        if (rc) return rc;
+        buf = c.h_file;
+    }
     std::memcpy(buf, head.data(), hdr);
     HIP_TRY(hipMemcpyAsync(buf + hdr, c.e_out.p, scan_bytes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -882,6 +892,39 @@ int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *o
     int16_t *dy, *dcb, *dcr;
     if ((rc = coeffs_on_device(d_pixels, *options, g, c->stream, &dy, &dcb, &dcr))) return rc;
     return device_tuple_to_malloc(dy, dcb, dcr, *options, g, *c, out, out_len);
+}
+
+int pixo_hip_jpeg_encode_device_into(const void *d_pixels, const pixo_jpeg_options *options, uint8_t *output, size_t capacity,
+                                     size_t *out_len)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(out_len);
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    Context *c = nullptr;
+    if ((rc = context_on_current_device(&c))) return rc;
+    const pixo_host::Geometry g = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
+    if (options->progressive || std::getenv("PIXO_HIP_HOST_ENTROPY")) { // assembled on the host: copy if it fits
+        uint8_t *p = nullptr;
+        size_t n = 0;
+        if ((rc = pixo_hip_jpeg_encode_device(d_pixels, options, &p, &n))) return rc;
+        *out_len = n;
+        if (n > capacity) {
+            std::free(p);
+            return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(n) + " bytes");
+        }
+        std::memcpy(output, p, n);
+        std::free(p);
+        return PIXO_OK;
+    }
+    int16_t *dy, *dcb, *dcr;
+    if ((rc = coeffs_on_device(d_pixels, *options, g, c->stream, &dy, &dcb, &dcr))) return rc;
+    const uint8_t *file = nullptr;
+    // (a null output with capacity 0 is a size query)
+    static uint8_t nowhere;
+    return device_entropy_to_pinned(dy, dcb, dcr, *options, g, c->stream, &file, out_len, 1, nullptr, nullptr,
+                                    output ? output : &nowhere, output ? capacity : 0);
 }
 
 namespace {

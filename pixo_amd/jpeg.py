@@ -304,6 +304,27 @@ def encode_device(d_pixels, options: JpegOptions) -> bytes:
         L.pixo_hip_free(out)
 
 
+def encode_device_into(buffer, d_pixels, options: JpegOptions) -> int:
+    """Device pixels -> file written straight into `buffer` (a contiguous uint8 numpy array or a torch CPU
+    tensor, ideally pinned: then the device-to-host copy is the only pass over the file).  Returns the
+    file's length; raises `error.BufferTooSmall` (with `.needed`) without copying when it does not fit."""
+    L = _lib.load()
+    if hasattr(buffer, "data_ptr"):
+        ptr, cap = buffer.data_ptr(), buffer.numel() * buffer.element_size()
+    else:
+        ptr, cap = buffer.ctypes.data, buffer.nbytes
+    n = C.c_size_t()
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_encode_device_into(_dev_ptr(d_pixels), C.byref(oc), ptr, cap, C.byref(n))
+    if rc:
+        try:
+            _raise(rc)
+        except error.BufferTooSmall as e:
+            e.needed = n.value
+            raise
+    return n.value
+
+
 def encode_batch_device(d_pixels, options: JpegOptions, batch: int):
     """`batch` equally sized images back to back in HBM -> list of `batch` JPEG files; one
     coefficient launch and one pass of the device entropy stage for all of them."""

@@ -419,3 +419,28 @@ def test_trim_releases_the_threads_buffers_and_the_next_call_starts_over():
     assert freed - held > 100 << 20  # pixels + tuple + entropy buffers of a 4096x4096 image
     assert jpeg.encode(px, o) == a
     jpeg.trim(); jpeg.trim()  # idempotent
+
+
+def test_encode_device_into_pinned_and_pageable_storage():
+    """pixo_hip_jpeg_encode_device_into: resident pixels -> caller storage.  Pinned torch tensor and plain
+    numpy array; baseline, optimised tables, restart markers, progressive; size query and too-small buffers
+    (nothing written)."""
+    import torch
+    from pixo_amd import error
+    w, h = 640, 360
+    px = synth.noise(w, h, 21)
+    d_px = torch.from_numpy(px).to("cuda:0")
+    torch.cuda.synchronize()
+    B = jpeg.JpegOptions.builder
+    for o in (B(w, h).quality(80).subsampling(jpeg.Subsampling.S420).build(), B(w, h).quality(55).optimize_huffman(True).build(),
+              B(w, h).quality(70).restart_interval(4).build(), B(w, h).quality(85).preset(2).build()):
+        want = jpeg.encode(px, o)
+        pinned = torch.full((len(want) + 64,), 0x5A, dtype=torch.uint8).pin_memory()
+        n = jpeg.encode_device_into(pinned, d_px, o)
+        assert n == len(want) and pinned[:n].numpy().tobytes() == want and bool((pinned[n:] == 0x5A).all())
+        plain = np.zeros(len(want), np.uint8)
+        assert jpeg.encode_device_into(plain, d_px, o) == len(want) and plain.tobytes() == want
+        small = np.full(len(want) - 1, 0x77, np.uint8)
+        with pytest.raises(error.BufferTooSmall) as ei:
+            jpeg.encode_device_into(small, d_px, o)
+        assert ei.value.needed == len(want) and (small == 0x77).all()

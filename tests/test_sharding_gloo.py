@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, w, h, ct, ss, q, ret):
+def _worker(rank, world, port, w, h, ct, ss, q, ret, flags=None):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch
@@ -38,10 +38,15 @@ def _worker(rank, world, port, w, h, ct, ss, q, ret):
     def cpu_coeffs(sub, o):  # stands in for the rank's GPU
         return O.coeffs(sub, o.width, o.height, int(o.color_type), int(o.subsampling), o.quality)
 
-    o = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss)).build()
+    flags = flags or {}
+    b = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss))
+    if flags.get("optimize_huffman"): b = b.optimize_huffman(True)
+    if flags.get("progressive"): b = b.progressive(True)
+    if flags.get("restart"): b = b.restart_interval(flags["restart"])
+    o = b.build()
     got = sharded.encode_banded(px, o, coeff_fn=cpu_coeffs)
     if rank == 0:
-        ret.put(got == O.encode(px, O.make_options(w, h, ct, q, ss)))
+        ret.put(got == O.encode(px, O.make_options(w, h, ct, q, ss, **flags)))
     else:
         assert got is None
     dist.barrier()
@@ -107,6 +112,25 @@ def test_two_rank_device_form_gathers_equal_sized_bands(case):
     ret = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker_device_form, args=(r, 2, port) + case + (ret,)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
+
+
+@pytest.mark.parametrize("flags", [{"optimize_huffman": True}, {"restart": 5}, {"progressive": True},
+                                   {"progressive": True, "optimize_huffman": True}])
+def test_three_rank_bands_with_every_kind_of_file(flags):
+    """Uneven bands (3 ranks, 13 MCU rows) and the options that touch the entropy stage: optimised tables,
+    restart markers, progressive scans — the stitched tuple gives the single-device file."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    case = (200, 203, 2, 1, 75)
+    procs = [ctx.Process(target=_worker, args=(r, 3, port) + case + (ret, flags)) for r in range(3)]
     for p in procs:
         p.start()
     for p in procs:

@@ -167,6 +167,29 @@ inline void encode_into(std::vector<uint8_t> &output, const uint8_t *data, size_
 
 } // namespace jpeg
 
+namespace png {
+// pixo::png::FilterStrategy in declaration order (src/png/mod.rs:345-364)
+enum class FilterStrategy : uint8_t { None = 0, Sub, Up, Average, Paeth, MinSum, Adaptive, AdaptiveFast, Bigrams };
+
+namespace filter {
+// pixo::png::filter::apply_filters (src/png/filter.rs:51-206): one filter-type byte + the filtered row for every
+// row — what the reference hands to its DEFLATE.  `adler32`, when given, receives the zlib checksum of the
+// returned bytes (src/simd/fallback.rs:8-25, computed once over the whole stream: src/compress/deflate.rs:1044).
+[[nodiscard]] inline std::vector<uint8_t> apply_filters(const uint8_t *data, size_t len, uint32_t width, uint32_t height,
+                                                        size_t bytes_per_pixel, FilterStrategy strategy,
+                                                        uint32_t *adler32 = nullptr, uint32_t flags = 0)
+{
+    std::vector<uint8_t> out((size_t)height * ((size_t)width * bytes_per_pixel + 1));
+    uint32_t ad = 0;
+    const int rc = pixo_hip_png_filter(data, len, width, height, (uint32_t)bytes_per_pixel, (uint8_t)strategy, flags,
+                                       out.data(), out.size(), &ad);
+    if (rc != PIXO_OK) throw Error::from_status(rc);
+    if (adler32) *adler32 = ad;
+    return out;
+}
+} // namespace filter
+} // namespace png
+
 // The reference's flat wasm export (src/wasm.rs:113-142), same seven arguments.
 [[nodiscard]] inline std::vector<uint8_t> encode_jpeg(const uint8_t *data, size_t len, uint32_t width, uint32_t height,
                                                       uint8_t color_type, uint8_t quality, uint8_t preset,

@@ -52,6 +52,12 @@ int main(int argc, char **argv)
     CHECK(raises(Error::Kind::InvalidColorArgument, "Invalid color type for JPEG: 3. Expected 0 (Gray) or 2 (Rgb)",
                  [&] { (void)encode_jpeg(px.data(), px.size(), 4, 4, 3, 80, 0, true); }));
 
+    // PNG row filters: argument errors are reported before any device work
+    CHECK(raises(Error::Kind::InvalidDimensions, "Invalid image dimensions: 0x4",
+                 [&] { (void)png::filter::apply_filters(px.data(), px.size(), 0, 4, 3, png::FilterStrategy::Adaptive); }));
+    CHECK(raises(Error::Kind::UnsupportedColorType, "Unsupported color type for this format",
+                 [&] { (void)png::filter::apply_filters(px.data(), px.size(), 4, 4, 5, png::FilterStrategy::Sub); }));
+
     if (argc > 2 && std::strcmp(argv[1], "gpu") == 0) {
         const uint32_t w = 200, h = 120;
         std::vector<uint8_t> img(w * h * 3);
@@ -60,6 +66,11 @@ int main(int argc, char **argv)
         auto jpg = encode(img, JpegOptions::builder(w, h).quality(80).subsampling(Subsampling::S420).build());
         std::ofstream(argv[2], std::ios::binary).write((const char *)jpg.data(), (std::streamsize)jpg.size());
         CHECK(jpg.size() > 4 && jpg[0] == 0xFF && jpg[1] == 0xD8);
+        // a row of equal pixels: Sub gives zeros after the first pixel, filter byte 1 in front
+        std::vector<uint8_t> rgba(64 * 80 * 4, 9);
+        uint32_t ad = 0;
+        auto flt = png::filter::apply_filters(rgba.data(), rgba.size(), 64, 80, 4, png::FilterStrategy::Sub, &ad);
+        CHECK(flt.size() == 80u * (64 * 4 + 1) && flt[0] == 1 && flt[1] == 9 && flt[5] == 0 && flt[256] == 0 && flt[257] == 1 && ad != 0);
     } else {
         CHECK(raises(Error::Kind::CompressionError,
                      "Compression error: no MI355X/HIP device available (pixo_hip has no CPU fallback)",

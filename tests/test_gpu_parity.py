@@ -444,3 +444,17 @@ def test_encode_device_into_pinned_and_pageable_storage():
         with pytest.raises(error.BufferTooSmall) as ei:
             jpeg.encode_device_into(small, d_px, o)
         assert ei.value.needed == len(want) and (small == 0x77).all()
+
+
+def test_every_rgb_colour_once():
+    """A 4096x4096 image that contains each of the 16,777,216 RGB triples exactly once (two different
+    arrangements, so that every colour meets different neighbours in the 4:2:0 box sums): coefficient
+    tuples bit-exact against the oracle for 4:4:4 and 4:2:0."""
+    w = h = 4096
+    i = np.arange(w * h, dtype=np.uint32)
+    for arrangement in range(2):
+        k = i if arrangement == 0 else (i * np.uint32(2654435761)) & np.uint32(0xFFFFFF)  # odd multiplier: a permutation
+        px = np.stack([(k & 255), (k >> 8) & 255, (k >> 16) & 255], axis=1).astype(np.uint8).reshape(-1)
+        assert len(np.unique(k)) == w * h
+        for ss in (0, 1):
+            _check_coeffs(px, w, h, 2, ss, 92)

@@ -117,3 +117,24 @@ def test_rows_around_the_register_path_limit(strategy):
         want, wad = O.png_filter(px, w, h, bpp, strategy, stateful_fast=False)
         got, gad = png.apply_filters(px, w, h, bpp, strategy)
         assert np.array_equal(got, want) and gad == wad, (w, bpp)
+
+
+def test_paeth_predictor_on_every_left_up_upleft_combination():
+    """All 2^24 (left, up, up-left) byte triples: 8192 rows of 12288 one-byte pixels, row pair p holding 4096 of
+    them at positions 3k + 1 (even row: up-left, up; odd row: left, sample).  Fixed Paeth through the device
+    predictor (the same packed 16-bit function the adaptive strategies score with) against the oracle."""
+    pairs, per = 4096, 4096
+    w, h = 3 * per, 2 * pairs
+    rng = np.random.RandomState(12)
+    img = rng.randint(0, 256, (h, w)).astype(np.uint8)
+    t = (np.arange(pairs, dtype=np.uint32)[:, None] * per + np.arange(per, dtype=np.uint32)[None, :])
+    img[0::2, 0::3] = (t >> 16).astype(np.uint8)          # up-left
+    img[0::2, 1::3] = ((t >> 8) & 255).astype(np.uint8)   # up
+    img[1::2, 0::3] = (t & 255).astype(np.uint8)          # left
+    px = img.reshape(-1)
+    want, wad = O.png_filter(px, w, h, 1, O.S_PAETH)
+    got, gad = png.apply_filters(px, w, h, 1, png.FilterStrategy.PAETH)
+    assert np.array_equal(got, want) and gad == wad
+    got, gad = png.apply_filters(px, w, h, 1, png.FilterStrategy.ADAPTIVE)
+    want, wad = O.png_filter(px, w, h, 1, O.S_ADAPTIVE)
+    assert np.array_equal(got, want) and gad == wad

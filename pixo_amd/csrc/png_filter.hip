@@ -15,72 +15,13 @@
 #include <hip/hip_runtime.h>
 
 #include "png_filter.hpp"
+#include "png_filter_math.h"
 
 namespace pixo_dev {
 namespace {
+using namespace pixo_png; // the per-group arithmetic (png_filter_math.h)
 
 constexpr int kThreads = 256;
-constexpr uint32_t kH = 0x80808080u;
-
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t sub4(uint32_t a, uint32_t b)
-{ // per-byte a - b (mod 256), no borrow between bytes
-    return ((a | kH) - (b & ~kH)) ^ ((a ^ ~b) & kH);
-}
-__device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b)
-{ // per-byte floor((a + b) / 2)  (fallback.rs:127: u16 sum, / 2)
-    return (a & b) + (((a ^ b) & 0xFEFEFEFEu) >> 1);
-}
-__device__ __forceinline__ s16x2 as_s(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
-__device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t gt_mask(s16x2 x, s16x2 y)
-{ // per 16-bit lane: 0xFFFF where x > y  (two packed ops: subtract, arithmetic shift)
-    return as_u((y - x) >> 15);
-}
-// Paeth predictor (fallback.rs:144-159) on two bytes held in the low bytes of 16-bit lanes:
-// p = a + b - c, pa = |p - a| = |b - c|, pb = |p - b| = |a - c|, pc = |p - c| = |(b - c) + (a - c)|;
-// a unless pa > pb or pa > pc, then b unless pb > pc, then c.
-__device__ __forceinline__ uint32_t paeth2(uint32_t a, uint32_t b, uint32_t c)
-{ // 14 packed operations + 2 bit selects
-    const s16x2 da = as_s(b) - as_s(c), db = as_s(a) - as_s(c), dd = da + db;
-    const s16x2 pa = __builtin_elementwise_max(da, -da), pb = __builtin_elementwise_max(db, -db);
-    const s16x2 pc = __builtin_elementwise_max(dd, -dd);
-    uint32_t not_a = gt_mask(pa, __builtin_elementwise_min(pb, pc)), use_c = gt_mask(pb, pc);
-    // (opaque: otherwise the masks are turned back into 16-bit compares + SDWA selects + a permute, 5 half-rate
-    // instructions where subtract, shift, bit-select are 3)
-    asm volatile("" : "+v"(not_a)); asm volatile("" : "+v"(use_c));
-    const uint32_t bc_sel = (c & use_c) | (b & ~use_c);
-    return (bc_sel & not_a) | (a & ~not_a);
-}
-__device__ __forceinline__ uint32_t paeth4(uint32_t a, uint32_t b, uint32_t c)
-{
-    const uint32_t M = 0x00FF00FFu;
-    const uint32_t e = paeth2(a & M, b & M, c & M);
-    const uint32_t o = paeth2((a >> 8) & M, (b >> 8) & M, (c >> 8) & M);
-    return e | (o << 8);
-}
-__device__ __forceinline__ uint32_t score4(uint32_t f, uint32_t acc)
-{ // sum over the 4 bytes of |byte as i8|: |f - 128 biased| = |(f ^ 0x80) - 0x80|
-    return __builtin_amdgcn_sad_u8(f ^ kH, kH, acc);
-}
-
-enum { F_NONE = 0, F_SUB = 1, F_UP = 2, F_AVG = 3, F_PAETH = 4 };
-
-struct Group { // 16 bytes of the row and their neighbours, as dwords
-    uint32_t cur[4], left[4], up[4], ul[4];
-    uint32_t valid[4]; // byte mask of the bytes that exist
-};
-
-// bytes [4k - BPP, 4k - BPP + 4) of the row as one dword, from X = {dword k-2, dword k-1, dword k}
-template <int BPP> __device__ __forceinline__ uint32_t left_of(const uint32_t *x6, int j)
-{ // x6 = {L0, L1, c0, c1, c2, c3}: dword j of the group sits at x6[2 + j]
-    constexpr int dummy = 0; (void)dummy;
-    const int p = 8 + 4 * j - BPP, idx = p >> 2, sh = p & 3;
-    return sh ? __builtin_amdgcn_alignbyte(x6[idx + 1], x6[idx], sh) : x6[idx];
-}
-
 // One guarded dword (k may be negative or past the end): used by the unaligned variant for
 // everything and by the aligned variant for a row's last, partial group.
 template <bool FAST> __device__ __forceinline__ uint32_t load_dword(const uint8_t *row, int k, int nbytes)
@@ -140,9 +81,6 @@ __device__ __forceinline__ void load_group(const uint8_t *row, const uint8_t *pr
     }
 }
 
-// The same 16 bytes and their neighbours as loaded: 6 dwords of the row, 6 of the row above.  Rows of at
-// most kRegIters * 4 KiB are held like this by the whole workgroup between scoring and write-out.
-struct Raw { uint32_t x[6], u[6]; };
 template <int BPP, bool FAST>
 __device__ __forceinline__ void load_raw(const uint8_t *row, const uint8_t *prev, int k0, int n, Raw &r)
 {
@@ -154,46 +92,6 @@ __device__ __forceinline__ void load_raw(const uint8_t *row, const uint8_t *prev
         for (int i = 0; i < 6; i++) r.u[i] = 0;
     }
 }
-// MASK = false: the group lies wholly inside the row (every group but a row's last partial one): no byte masks
-template <int BPP, bool MASK> __device__ __forceinline__ void group_of(const Raw &r, int k0, int n, Group &g)
-{
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        g.cur[j] = r.x[2 + j]; g.up[j] = r.u[2 + j];
-        g.left[j] = left_of<BPP>(r.x, j); g.ul[j] = left_of<BPP>(r.u, j);
-        const int rem = n - 4 * (k0 + j);
-        g.valid[j] = !MASK || rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : (1u << (8 * rem)) - 1u);
-    }
-}
-__device__ __forceinline__ uint32_t filtered(int f, const Group &g, int j)
-{
-    switch (f) {
-    case F_NONE: return g.cur[j];
-    case F_SUB: return sub4(g.cur[j], g.left[j]);
-    case F_UP: return sub4(g.cur[j], g.up[j]);
-    case F_AVG: return sub4(g.cur[j], avg4(g.left[j], g.up[j]));
-    default: return sub4(g.cur[j], paeth4(g.left[j], g.up[j], g.ul[j]));
-    }
-}
-
-template <int BPP, bool MASK>
-__device__ __forceinline__ void score_group(const Raw &r, int k0, int n, bool fast, uint32_t sc[5])
-{
-    Group g;
-    group_of<BPP, MASK>(r, k0, n, g);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t m = g.valid[j]; // (all ones without MASK: the ands fold away)
-        sc[F_SUB] = score4(filtered(F_SUB, g, j) & m, sc[F_SUB]);
-        sc[F_UP] = score4(filtered(F_UP, g, j) & m, sc[F_UP]);
-        sc[F_PAETH] = score4(filtered(F_PAETH, g, j) & m, sc[F_PAETH]);
-        if (!fast) {
-            sc[F_NONE] = score4(g.cur[j] & m, sc[F_NONE]);
-            sc[F_AVG] = score4(filtered(F_AVG, g, j) & m, sc[F_AVG]);
-        }
-    }
-}
-
 __device__ __forceinline__ unsigned long long wg_sum(unsigned long long v, unsigned long long *lds)
 { // 256 threads; every thread gets the total
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -208,34 +106,6 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
-}
-
-// the reference's decision sequences, replayed on the five row scores
-__device__ __forceinline__ int decide(int strategy, const unsigned long long s[5], unsigned long long n)
-{
-    if (strategy <= PNG_S_PAETH) return strategy; // None, Sub, Up, Average, Paeth
-    if (strategy == PNG_S_ADAPTIVE_FAST) { // filter.rs:474-527
-        const unsigned long long early = n / 8 + 1;
-        int best = F_SUB;
-        unsigned long long bs = s[F_SUB];
-        if (bs <= early) return best;
-        if (s[F_UP] < bs) { bs = s[F_UP]; best = F_UP; }
-        if (bs <= early) return best;
-        if (s[F_PAETH] < bs) best = F_PAETH;
-        return best;
-    }
-    // Adaptive / MinSum, filter.rs:302-404: None, Sub, Up, Average, Paeth in this order, a later
-    // filter wins only with a strictly smaller score, stop as soon as the best is <= early (or 0)
-    const unsigned long long early = n / 4 + 1;
-    int best = F_NONE;
-    unsigned long long bs = s[F_NONE];
-    if (bs <= early || bs == 0) return best;
-#pragma unroll
-    for (int f = F_SUB; f <= F_AVG; f++) {
-        if (s[f] < bs) { bs = s[f]; best = f; if (bs == 0 || bs <= early) return best; }
-    }
-    if (s[F_PAETH] < bs) best = F_PAETH;
-    return best;
 }
 
 struct Args {
@@ -268,8 +138,8 @@ __device__ __forceinline__ void emit_group(const Group &g, int k0, int n, T L, b
     for (int j = 0; j < 4; j++) {
         v[j] = filtered(F, g, j) & g.valid[j];
         // bytes at output positions p = 1 + 4k + b, weight L - p
-        const unsigned sum = __builtin_amdgcn_sad_u8(v[j], 0u, 0u);
-        const unsigned ramp = __builtin_amdgcn_udot4(v[j], 0x00010203u, 0u, false); // 3*b0 + 2*b1 + 1*b2 + 0*b3
+        uint32_t sum, ramp;
+        adler_terms(v[j], sum, ramp); // byte sum; 3*b0 + 2*b1 + 1*b2 + 0*b3
         s1 += sum;
         s2 += (L - (T)(4 * (k0 + j) + 4)) * sum + ramp;
     }

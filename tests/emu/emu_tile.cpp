@@ -336,3 +336,81 @@ extern "C" void emu_progressive_tables(uint32_t *out /* 536 words */)
     pixo_host::pack_scan_tables(pixo_host::HuffSet::standard(), out);
     for (int i = 0; i < pixo_scan::kTableWords; i++) if ((out[i] >> 16) == 0) out[i] = 4u << 16;
 }
+
+// ---------------------------------------------------------------------------------------------
+// PNG row filters: the kernel's per-group arithmetic (pixo_amd/csrc/png_filter_math.h) driven row by row
+// and group by group on the host — neighbour alignment for every pixel size, SWAR filters, packed Paeth,
+// scores, the reference's decision sequences, checksum terms and their combination.  `strategy` is the
+// one the launcher would run (the <= 4096-pixel rule and the sequential AdaptiveFast are host logic in
+// capi.cpp).  Returns the Adler-32 of the stream.
+// ---------------------------------------------------------------------------------------------
+#include "../../pixo_amd/csrc/png_filter_math.h"
+namespace {
+uint32_t host_dword(const uint8_t *row, long k, long n)
+{ // bytes [4k, 4k + 4) of the row, zero outside it (what load_dword / load_six deliver)
+    uint32_t v = 0;
+    if (!row || k < 0) return 0;
+    for (int b = 0; b < 4; b++)
+        if (4 * k + b < n) v |= (uint32_t)row[4 * k + b] << (8 * b);
+    return v;
+}
+template <int BPP> uint32_t emu_png_rows(const uint8_t *data, long n, long height, int strategy, uint8_t *out)
+{
+    using namespace pixo_png;
+    const uint64_t M = 65521;
+    uint64_t a1 = 1, a2 = 0; // Adler state over the whole stream
+    const long ndw = (n + 3) / 4;
+    for (long y = 0; y < height; y++) {
+        const uint8_t *row = data + y * n, *prev = y ? row - n : nullptr;
+        int f = strategy;
+        if (strategy > S_PAETH) {
+            uint32_t sc[5] = {0, 0, 0, 0, 0};
+            for (long k0 = 0; k0 < ndw; k0 += 4) {
+                Raw r;
+                for (int i = 0; i < 6; i++) { r.x[i] = host_dword(row, k0 - 2 + i, n); r.u[i] = host_dword(prev, k0 - 2 + i, n); }
+                if (4 * (k0 + 4) <= n) score_group<BPP, false>(r, (int)k0, (int)n, strategy == S_ADAPTIVE_FAST, sc);
+                else score_group<BPP, true>(r, (int)k0, (int)n, strategy == S_ADAPTIVE_FAST, sc);
+            }
+            unsigned long long tot[5];
+            for (int i = 0; i < 5; i++) tot[i] = sc[i];
+            f = decide(strategy, tot, (unsigned long long)n);
+        }
+        uint8_t *o = out + y * (n + 1);
+        o[0] = (uint8_t)f;
+        const uint64_t L = (uint64_t)n + 1;
+        uint64_t s1 = (unsigned)f, s2 = L * (unsigned)f;
+        for (long k0 = 0; k0 < ndw; k0 += 4) {
+            Raw r;
+            for (int i = 0; i < 6; i++) { r.x[i] = host_dword(row, k0 - 2 + i, n); r.u[i] = host_dword(prev, k0 - 2 + i, n); }
+            Group g;
+            group_of<BPP, true>(r, (int)k0, (int)n, g);
+            for (int j = 0; j < 4; j++) {
+                const uint32_t v = filtered(f, g, j) & g.valid[j];
+                uint32_t sum, ramp;
+                adler_terms(v, sum, ramp);
+                s1 += sum;
+                s2 += (L - (uint64_t)(4 * (k0 + j) + 4)) * sum + ramp;
+                for (int b = 0; b < 4; b++)
+                    if (4 * (k0 + j) + b < n) o[1 + 4 * (k0 + j) + b] = (uint8_t)(v >> (8 * b));
+            }
+        }
+        // combine_adler (capi.cpp): s2 += row_len * s1_before + B, s1 += A
+        a2 = (a2 + (L % M) * a1 + s2 % M) % M;
+        a1 = (a1 + s1 % M) % M;
+    }
+    return (uint32_t)((a2 << 16) | a1);
+}
+} // namespace
+extern "C" long emu_png_filter(const uint8_t *data, long width, long height, int bpp, int strategy, uint8_t *out)
+{
+    const long n = width * bpp;
+    switch (bpp) {
+    case 1: return emu_png_rows<1>(data, n, height, strategy, out);
+    case 2: return emu_png_rows<2>(data, n, height, strategy, out);
+    case 3: return emu_png_rows<3>(data, n, height, strategy, out);
+    case 4: return emu_png_rows<4>(data, n, height, strategy, out);
+    case 6: return emu_png_rows<6>(data, n, height, strategy, out);
+    case 8: return emu_png_rows<8>(data, n, height, strategy, out);
+    default: return -1;
+    }
+}

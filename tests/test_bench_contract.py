@@ -1,0 +1,36 @@
+"""The bench line the driver parses: the committed round-1 line (profiles/r01_bench_c2.json, printed by bench.py on
+an MI355X) has every key of the contract, the metric BASELINE.json names and a self-consistent roofline object."""
+import json
+import os
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def test_committed_bench_line_follows_the_contract():
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r01_bench_c2.json")).read().strip().splitlines()[-1])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert line["metric"] == base["metric"] and line["unit"] == "Mpixels/s"
+    for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in line, key
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # achieved = algorithmic bytes per launch / the kernel's average duration; value = pixels / the same clock
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_us_avg"] * 1e-6) / 1e9) < 1.0
+    assert r["algorithmic_bytes_per_launch"] == 6 * 4096 * 4096  # 3 B read + 3 B written per pixel (4:2:0)
+    assert 0.95 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.10  # PMC bytes: no re-reads
+    px_per_us = line["value"] * 1e6 / 1e6  # Mpixels/s -> pixels/us
+    assert abs(px_per_us * line["ms_per_step"] * 1e3 - 4096 * 4096) / (4096 * 4096) < 0.01
+    c = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference")
+
+
+def test_bench_parses_its_flags_without_a_gpu():
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], stdout=subprocess.PIPE, check=True).stdout.decode()
+    for flag in ("--gpus", "--steps", "--warmup", "--workload"):
+        assert flag in out

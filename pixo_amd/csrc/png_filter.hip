@@ -266,11 +266,11 @@ __device__ __forceinline__ unsigned long long bigram_score(const uint8_t *row, c
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int lim = n - 1 - 4 * (k0 + j); // pairs that START in this dword and end inside the row
-            const uint32_t key[4] = {v[j] & 0xFFFFu, (v[j] >> 8) & 0xFFFFu, v[j] >> 16, (v[j] >> 24) | ((v[j + 1] & 0xFFu) << 8)};
+            uint32_t key[4];
+            const int cnt = bigram_keys(v[j], v[j + 1], n - 1 - 4 * (k0 + j), key);
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (i < lim) atomicOr(&bitmap[key[i] >> 5], 1u << (key[i] & 31u));
+                if (i < cnt) atomicOr(&bitmap[key[i] >> 5], 1u << (key[i] & 31u));
         }
     }
     __syncthreads();
@@ -317,10 +317,7 @@ __global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) void p
         tot[F_UP] = bigram_score<BPP, FAST, F_UP, 2>(row, prev, n, bitmap, red);
         tot[F_AVG] = bigram_score<BPP, FAST, F_AVG, 3>(row, prev, n, bitmap, red);
         tot[F_PAETH] = bigram_score<BPP, FAST, F_PAETH, 7>(row, prev, n, bitmap, red);
-        f = F_NONE; // in this order, a later filter wins only with strictly fewer pairs, no early exit
-#pragma unroll
-        for (int c = F_SUB; c <= F_PAETH; c++)
-            if (tot[c] < tot[f]) f = c;
+        f = decide_bigrams(tot);
         __syncthreads(); // the write-out below reuses the dynamic LDS
     } else if (KIND == K_REGS || KIND == K_REGS512) { // (the launcher checked: strategy > Paeth, ndw <= kRegIters * per_iter, staged)
         // the whole row (and the row above) in registers: one round of loads, all in flight together

@@ -176,4 +176,24 @@ PIXO_PDEV void adler_terms(uint32_t v, uint32_t &sum, uint32_t &ramp)
     ramp = pixo_udot4(v, 0x00010203u);
 }
 
+// Bigrams (score_bigrams, filter.rs:635-649): the pairs (byte p, byte p + 1) that START in filtered dword v and end
+// inside the row, as 16-bit keys (any one-to-one pair -> key mapping counts the same number of distinct pairs: the
+// little-endian halfword at each byte position).  `next` = the following filtered dword (its first byte closes the
+// fourth pair), lim = n - 1 - (position of v's first byte): how many of the four pairs exist.  Returns their number.
+PIXO_PDEV int bigram_keys(uint32_t v, uint32_t next, int lim, uint32_t key[4])
+{
+    key[0] = v & 0xFFFFu; key[1] = (v >> 8) & 0xFFFFu; key[2] = v >> 16; key[3] = (v >> 24) | ((next & 0xFFu) << 8);
+    return lim < 0 ? 0 : (lim > 4 ? 4 : lim);
+}
+// bigrams_filter (filter.rs:406-472): None, Sub, Up, Average, Paeth in this order, a later filter wins only with
+// strictly fewer distinct pairs, no early exit
+PIXO_PDEV int decide_bigrams(const unsigned long long tot[5])
+{
+    int f = F_NONE;
+#pragma unroll
+    for (int c = F_SUB; c <= F_PAETH; c++)
+        if (tot[c] < tot[f]) f = c;
+    return f;
+}
+
 } // namespace pixo_png

@@ -363,7 +363,34 @@ template <int BPP> uint32_t emu_png_rows(const uint8_t *data, long n, long heigh
     for (long y = 0; y < height; y++) {
         const uint8_t *row = data + y * n, *prev = y ? row - n : nullptr;
         int f = strategy;
-        if (strategy > S_PAETH) {
+        if (strategy == S_BIGRAMS) { // five passes over the row with a "pair seen" bitmap, like bigram_score
+            unsigned long long tot[5];
+            static thread_local uint32_t bitmap[2048];
+            for (int cand = F_NONE; cand <= F_PAETH; cand++) {
+                memset(bitmap, 0, sizeof bitmap);
+                auto dword = [&](long k0, int j) {
+                    Raw r;
+                    for (int i = 0; i < 6; i++) { r.x[i] = host_dword(row, k0 - 2 + i, n); r.u[i] = host_dword(prev, k0 - 2 + i, n); }
+                    Group g;
+                    group_of<BPP, true>(r, (int)k0, (int)n, g);
+                    return filtered(cand, g, j);
+                };
+                for (long k0 = 0; k0 < ndw; k0 += 4) {
+                    uint32_t v[5];
+                    for (int j = 0; j < 4; j++) v[j] = dword(k0, j);
+                    v[4] = k0 + 4 < ndw ? dword(k0 + 4, 0) : 0;
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t key[4];
+                        const int cnt = bigram_keys(v[j], v[j + 1], (int)(n - 1 - 4 * (k0 + j)), key);
+                        for (int i = 0; i < cnt; i++) bitmap[key[i] >> 5] |= 1u << (key[i] & 31u);
+                    }
+                }
+                unsigned long long count = 0;
+                for (int i = 0; i < 2048; i++) count += (unsigned)__builtin_popcount(bitmap[i]);
+                tot[cand] = count;
+            }
+            f = decide_bigrams(tot);
+        } else if (strategy > S_PAETH) {
             uint32_t sc[5] = {0, 0, 0, 0, 0};
             for (long k0 = 0; k0 < ndw; k0 += 4) {
                 Raw r;

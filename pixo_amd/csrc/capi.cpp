@@ -185,7 +185,9 @@ void Context::release()
 }
 Context::~Context()
 {
-    if (!g_exiting.load()) release();
+    // (PIXO_HIP_KEEP_ON_THREAD_EXIT=1: diagnostics — leave a finished thread's buffers to the process)
+    static const bool keep = std::getenv("PIXO_HIP_KEEP_ON_THREAD_EXIT") != nullptr;
+    if (!keep && !g_exiting.load()) release();
 }
 thread_local Context t_ctx;
 

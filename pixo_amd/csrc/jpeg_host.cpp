@@ -1,6 +1,7 @@
 // jpeg_host.cpp — see jpeg_host.hpp.  Product code; independent of oracle/.
 #include "jpeg_host.hpp"
 
+#include <cmath>
 #include <algorithm>
 #include <cstring>
 #include <functional>
@@ -52,15 +53,37 @@ QuantTables make_quant_tables(uint8_t quality)
     return t;
 }
 
+namespace {
+// Directed roundings of (1/q)(1 -+ (2^-24 + 2^-30)): the largest f32 not above / the smallest f32 not below
+// (jpeg_tile.h quant_row8 proves the bracket from exactly these two properties).
+float bracket_lo(float q)
+{
+    const double want = (1.0 / q) * (1.0 - 0x1p-24 - 0x1p-30);
+    float f = static_cast<float>(want);
+    while (static_cast<double>(f) > want) f = std::nextafterf(f, 0.0f);
+    return f;
+}
+float bracket_hi(float q)
+{
+    const double want = (1.0 / q) * (1.0 + 0x1p-24 + 0x1p-30);
+    float f = static_cast<float>(want);
+    while (static_cast<double>(f) < want) f = std::nextafterf(f, 2.0f);
+    return f;
+}
+} // namespace
+
 void fill_device_qt(uint8_t quality, float out[kDeviceQtFloats])
 {
     const QuantTables t = make_quant_tables(quality);
     for (int i = 0; i < 64; ++i) {
-        out[i] = 1.0f / t.lum[i]; // IEEE f32 divide: correctly rounded reciprocal
-        out[64 + i] = 1.0f / t.chr[i];
+        out[i] = bracket_lo(t.lum[i]);
+        out[64 + i] = bracket_hi(t.lum[i]);
         out[128 + i] = t.lum[i];
         out[192 + i] = t.chr[i];
-        out[256 + i] = out[64 + i] * 0.25f; // exact: 4:2:0 chroma is transformed at 4x scale
+        out[256 + i] = bracket_lo(t.chr[i]);
+        out[320 + i] = bracket_hi(t.chr[i]);
+        out[384 + i] = out[256 + i] * 0.25f; // exact: 4:2:0 chroma is transformed at 4x scale
+        out[448 + i] = out[320 + i] * 0.25f;
     }
 }
 

@@ -22,9 +22,9 @@ struct QuantTables {
 };
 QuantTables make_quant_tables(uint8_t quality);
 
-// Device-side table block (layout documented in jpeg_tile.h: 1/q lum, 1/q chr, q lum, q chr,
-// (1/q chr)/4)
-constexpr int kDeviceQtFloats = 320;
+// Device-side table block (layout documented in jpeg_tile.h: bracketing reciprocals rlo/rhi for
+// luminance, q lum, q chr, rlo/rhi chrominance, rlo/rhi chrominance / 4)
+constexpr int kDeviceQtFloats = 512;
 void fill_device_qt(uint8_t quality, float out[kDeviceQtFloats]);
 
 extern const uint8_t kZigzag[64]; // quantize.rs:18-22

@@ -7,8 +7,6 @@
 // 4:2:0 image (8 per CU, all resident at once).
 #include <hip/hip_runtime.h>
 
-#include <cstdio>
-#include <cstdlib>
 
 #include "jpeg_kernels.hpp"
 #include "jpeg_tile.h"
@@ -24,10 +22,9 @@ struct KArgs {
     const float *qt;
     uint32_t W, H, units_x, units_y, tiles_x, tiles_y, batch, fast;
     size_t px_stride; // bytes between consecutive images of a batch
+    size_t px_bytes;  // all pixel bytes of the launch (L_FUNNEL never reads a dword beyond them)
     size_t y_stride;  // i16 elements between images
     size_t c_stride;
-    unsigned long long *dbg; // PIXO_TIMING builds only: per-wavefront stamps (tools/wave_probe.py)
-    uint32_t prio_a;         // raise wave priority during phase A (single-generation launches)
     float *ry, *rcb, *rcr;   // RAW kernels only: unquantised DCT blocks (64 f32 each) instead of y/cb/cr
 };
 
@@ -67,40 +64,23 @@ __device__ __forceinline__ TileCtx ctx_of(const KArgs &a, uint32_t img)
     c.cr = a.cr ? a.cr + (size_t)img * a.c_stride : nullptr;
     c.qt = a.qt;
     c.W = a.W; c.H = a.H; c.units_x = a.units_x; c.units_y = a.units_y; c.fast = a.fast;
+    c.px_end = a.px + a.px_bytes;
     return c;
 }
 
 // Phase A of one wavefront: COUNT items [first, first + COUNT) of the tile, HBM -> registers ->
 // planar LDS.  All loads are issued before the first conversion (no branch near a load).
-template <int MODE, bool FAST, int COUNT>
-__device__ __forceinline__ void phase_a(const TileCtx &c, const TileId &id, int first, int lane, uint8_t *lds,
-                                        unsigned long long *stamps = nullptr)
+template <int MODE, int LOAD, int COUNT>
+__device__ __forceinline__ void phase_a(const TileCtx &c, const TileId &id, int first, int lane, uint8_t *lds)
 {
     typedef Geo<MODE> G;
     uint32_t r[COUNT * G::item_regs];
-#if defined(PIXO_ABLATE) && (PIXO_ABLATE == 5 || PIXO_ABLATE == 6 || PIXO_ABLATE == 7) // (timing experiments only: no loads)
-    for (int i = 0; i < COUNT * G::item_regs; i++) r[i] = lane * 77 + i;
-#else
 #pragma unroll
-    for (int j = 0; j < COUNT; j++) producer_load_item<MODE, FAST>(c, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
-#endif
+    for (int j = 0; j < COUNT; j++) producer_load_item<MODE, LOAD>(c, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
 #pragma unroll
     for (int j = 0; j < COUNT; j++) {
-#ifdef PIXO_TIMING
-        if (j == 0) { // when did the first item's / all items' pixels arrive? (scalar instructions only)
-            for (int i = 0; i < G::item_regs; i++) asm volatile("" : "+v"(r[i]));
-            asm volatile("s_nop 0" ::: "memory");
-            stamps[0] = __builtin_readcyclecounter();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stamps[1] = __builtin_readcyclecounter();
-        }
-#endif
-#if !defined(PIXO_ABLATE) || PIXO_ABLATE < 2 || PIXO_ABLATE == 6 // (timing experiments only: 2..5, 7 drop the colour conversion)
-        producer_fix_item<MODE, FAST>(c, id.tx, first + j, lane, &r[j * G::item_regs]);
+        producer_fix_item<MODE, LOAD>(c, id.tx, first + j, lane, &r[j * G::item_regs]);
         producer_color_item<MODE>(first + j, lane, &r[j * G::item_regs], lds);
-#else
-        for (int i = 0; i < G::item_regs; i++) asm volatile("" ::"v"(r[j * G::item_regs + i]));
-#endif
     }
 }
 
@@ -116,13 +96,9 @@ __device__ __forceinline__ void phase_a(const TileCtx &c, const TileId &id, int 
 // (a single wavefront can issue only every ~4.3 cycles; two per SIMD are needed to fill it).
 // Measured alternatives (4-wave workgroups; persistent loop with register prefetch;
 // role-specialised producer/consumer wavefronts with double-buffered LDS): DESIGN.md.
-#ifdef PIXO_ABL_NO_WAVES_ATTR // (timing experiments only)
-#define PIXO_WAVES_ATTR
-#else
 // 6 waves per SIMD = 24 per CU = the 8 three-wave workgroups a CU gets of a 4096x4096 image: the
 // compiler keeps every variant at 80 VGPRs without spilling when told to.
 #define PIXO_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
-#endif
 // RAW kernels: the lane's transformed block as 64 floats (natural order, the reference's dct_2d
 // output: 4:2:0 chroma scaled back by the exact factor 1/4) for the trellis quantiser.
 template <int MODE>
@@ -158,88 +134,45 @@ __device__ __forceinline__ void store_raw_block(const KArgs &a, const TileCtx &c
         reinterpret_cast<float4 *>(dst)[i] = make_float4(v[4 * i] * scale, v[4 * i + 1] * scale, v[4 * i + 2] * scale, v[4 * i + 3] * scale);
 }
 
-template <int MODE, bool FAST, bool RAW = false>
+template <int MODE, int LOAD, bool RAW = false>
 __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(const KArgs a)
 {
     typedef Geo<MODE> G;
     __shared__ __attribute__((aligned(16))) uint8_t lds[G::planar];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-#ifdef PIXO_TIMING
-    const unsigned long long t_start = __builtin_readcyclecounter(), w_start = __builtin_amdgcn_s_memrealtime();
-#endif
     // Phase A runs at raised wave priority: the hardware otherwise issues oldest-first, the colour
     // conversion of the younger workgroups waits behind the older ones' phase B, and few wavefronts
     // are in phase B at any time (two per SIMD are needed to fill the VALU).  +14 % for one 4096x4096
     // image (all workgroups resident at once), +10 % for 4:4:4 and for the 64-image batch (measured at
-    // steady clocks with the whole-block write-out; with the earlier half-block stores the batch LOST
-    // 9 %, which is why this used to be a launch-time decision).  PIXO_HIP_PRIO_A=0 switches it off.
-    if (a.prio_a) __builtin_amdgcn_s_setprio(1);
+    // steady clocks, profiles/r01_ablation_steady_clocks.txt).
+    __builtin_amdgcn_s_setprio(1);
     const TileId id = locate(a, blockIdx.x);
     const TileCtx c = ctx_of(a, id.img);
     constexpr int base = G::items / kWaves, extra = G::items % kWaves;
-#ifdef PIXO_TIMING
-    unsigned long long t_data[2] = {0, 0};
-    if (extra && wave < extra) phase_a<MODE, FAST, base + 1>(c, id, wave * (base + 1), lane, lds, t_data);
-    else phase_a<MODE, FAST, base>(c, id, extra * (base + 1) + (wave - extra) * base, lane, lds, t_data);
-    const unsigned long long t_colour = __builtin_readcyclecounter();
+    if (extra && wave < extra) phase_a<MODE, LOAD, base + 1>(c, id, wave * (base + 1), lane, lds);
+    else phase_a<MODE, LOAD, base>(c, id, extra * (base + 1) + (wave - extra) * base, lane, lds);
     lds_barrier();
-    const unsigned long long t_bar = __builtin_readcyclecounter();
-#else
-    if (extra && wave < extra) phase_a<MODE, FAST, base + 1>(c, id, wave * (base + 1), lane, lds);
-    else phase_a<MODE, FAST, base>(c, id, extra * (base + 1) + (wave - extra) * base, lane, lds);
-    lds_barrier();
-#endif
     __builtin_amdgcn_s_setprio(0);
     float v[64];
-#if !defined(PIXO_ABLATE) || PIXO_ABLATE == 3 || PIXO_ABLATE == 6 || PIXO_ABLATE == 7 // (1, 2, 4, 5: no transform; 3, 7: transform, no colour; 6: all compute, no HBM)
     consumer_rows<MODE>(wave, lane, lds, v);
     consumer_cols(v);
-#ifdef PIXO_TIMING
-    const unsigned long long t_dct = __builtin_readcyclecounter();
-#endif
-#else
-    for (int i = 0; i < 64; i++) v[i] = (float)(lane + i);
-#endif
     if (RAW) { // hand the transformed blocks to the trellis quantiser instead of quantising here
         store_raw_block<MODE>(a, c, id, wave, lane, v);
         return;
     }
     uint8_t *stage = lds + stage_offset<MODE>(wave); // inside this wavefront's own planar area
-#ifdef PIXO_HALF_BLOCK_STORES // (timing experiments only: the previous write-out, 64-byte half blocks)
-    consumer_quant_half<MODE>(wave, lane, a.qt, v, 0, stage);
-    consumer_stage_sync();
-    consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 0, stage);
-    consumer_stage_sync();
-    consumer_quant_half<MODE>(wave, lane, a.qt, v, 1, stage);
-    consumer_stage_sync();
-    consumer_store_half<MODE>(c, id.tx, id.ty, wave, lane, 1, stage);
-#else
     uint32_t qw[32];
     consumer_quant<MODE>(wave, lane, a.qt, v, qw);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         consumer_stage_blocks(lane, h, qw, stage);
         consumer_stage_sync();
-#if !defined(PIXO_ABLATE) || (PIXO_ABLATE != 4 && PIXO_ABLATE != 6 && PIXO_ABLATE != 7) // (4, 6, 7: no stores — one guarded store keeps the work alive)
         consumer_store_blocks<MODE>(c, id.tx, id.ty, wave, lane, h, stage);
-#else
-        if (*(volatile uint32_t *)(stage + lane * 4) == 0x12345678u) consumer_store_blocks<MODE>(c, id.tx, id.ty, wave, lane, h, stage);
-#endif
         consumer_stage_sync();
     }
-#endif
-#ifdef PIXO_TIMING
-    if (lane == 0 && a.dbg) {
-        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
-        d[0] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); d[1] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
-        d[2] = t_start; d[3] = t_bar; d[4] = t_dct; d[5] = __builtin_readcyclecounter();
-        d[6] = w_start; d[7] = __builtin_amdgcn_s_memrealtime();
-        d[8] = t_data[0]; d[9] = t_data[1]; d[10] = t_colour;
-    }
-#endif
 }
 
-template <int MODE, bool FAST> static hipError_t launch_mode(KArgs &a, hipStream_t s)
+template <int MODE, int LOAD> static hipError_t launch_mode(KArgs &a, hipStream_t s)
 {
     const bool raw = a.ry != nullptr;
     a.tiles_x = (a.units_x + Geo<MODE>::units_x - 1) / Geo<MODE>::units_x;
@@ -247,13 +180,16 @@ template <int MODE, bool FAST> static hipError_t launch_mode(KArgs &a, hipStream
     const uint64_t total64 = (uint64_t)a.tiles_x * a.tiles_y * a.batch;
     if (total64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const uint32_t total = (uint32_t)total64;
-    static const char *prio_env = getenv("PIXO_HIP_PRIO_A"); // experiments: force 0 / 1
-    a.prio_a = prio_env ? (uint32_t)atoi(prio_env) : 1u;
-    // PIXO_HIP_LDS_PAD (bytes of unused dynamic LDS) lowers the residency for experiments
-    static const unsigned pad = getenv("PIXO_HIP_LDS_PAD") ? (unsigned)atoi(getenv("PIXO_HIP_LDS_PAD")) : 0u;
-    if (raw) hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, FAST, true>), dim3(total), dim3(kThreads), pad, s, a);
-    else hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, FAST, false>), dim3(total), dim3(kThreads), pad, s, a);
+    if (raw) hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, true>), dim3(total), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, false>), dim3(total), dim3(kThreads), 0, s, a);
     return hipGetLastError();
+}
+
+template <int MODE> static hipError_t launch_load(int load, KArgs &a, hipStream_t s)
+{
+    if (load == L_ALIGNED) return launch_mode<MODE, L_ALIGNED>(a, s);
+    if (load == L_FUNNEL) return launch_mode<MODE, L_FUNNEL>(a, s);
+    return launch_mode<MODE, L_BYTES>(a, s);
 }
 
 hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gray, bool s420,
@@ -270,10 +206,6 @@ hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gra
     a.cb = static_cast<int16_t *>(d_cb);
     a.cr = static_cast<int16_t *>(d_cr);
     a.qt = d_qt;
-    a.dbg = nullptr;
-#ifdef PIXO_TIMING
-    if (const char *e = getenv("PIXO_DBG_PTR")) a.dbg = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0));
-#endif
     a.W = W; a.H = H; a.batch = batch;
     const uint32_t unit = (!gray && s420) ? 16 : 8;
     a.units_x = (W + unit - 1) / unit;
@@ -281,17 +213,19 @@ hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gra
     const uint32_t bpp = gray ? 1 : 3;
     const size_t row_bytes = static_cast<size_t>(W) * bpp;
     a.px_stride = row_bytes * H;
-    // dword loads need 4-byte aligned rows in every image of the batch
-    a.fast = (reinterpret_cast<uintptr_t>(d_px) % 4 == 0) && (row_bytes % 4 == 0) &&
-             (batch == 1 || a.px_stride % 4 == 0);
+    a.px_bytes = a.px_stride * batch;
+    // one 12-byte load per lane and row needs 4-byte aligned rows in every image of the batch; other
+    // images read aligned dwords and shift (L_FUNNEL); both need one whole 4-pixel group per row
+    const bool aligned = (reinterpret_cast<uintptr_t>(d_px) % 4 == 0) && (row_bytes % 4 == 0) &&
+                         (batch == 1 || a.px_stride % 4 == 0);
+    const int load = W < 4 ? L_BYTES : (aligned ? L_ALIGNED : L_FUNNEL);
+    a.fast = load != L_BYTES;
     const size_t units = static_cast<size_t>(a.units_x) * a.units_y;
     a.y_stride = (unit == 16 ? 4 * units : units) * 64;
     a.c_stride = units * 64;
-    // FAST additionally needs at least one whole 4-pixel group per row (address clamp W - 4)
-    const bool fast = a.fast && W >= 4;
-    if (gray) return fast ? launch_mode<MGRAY, true>(a, stream) : launch_mode<MGRAY, false>(a, stream);
-    if (s420) return fast ? launch_mode<M420, true>(a, stream) : launch_mode<M420, false>(a, stream);
-    return fast ? launch_mode<M444, true>(a, stream) : launch_mode<M444, false>(a, stream);
+    if (gray) return launch_load<MGRAY>(load, a, stream);
+    if (s420) return launch_load<M420>(load, a, stream);
+    return launch_load<M444>(load, a, stream);
 }
 
 } // namespace pixo_dev

@@ -1,19 +1,20 @@
 // jpeg_tile.h — the per-tile body of the fused JPEG coefficient kernel for gfx950.
 //
-// One 256-thread workgroup (4 wavefronts, one per SIMD) turns one tile of pixels into quantised
-// DCT blocks:
+// One 192-thread workgroup (3 wavefronts) turns one 512-pixel-wide tile of pixels into quantised
+// DCT blocks (a tile holds exactly 3 x 64 blocks):
 //
-//   phase A  (all 4 wavefronts, 4 work items each)   global RGB8 -> registers: one unconditional
-//            12-byte load per lane and row (4 px; a wavefront instruction covers 768 contiguous
-//            bytes), integer BT.601 colour conversion with packed-u16 VALU ops (2 px per
-//            instruction), 2x2 chroma box sums, planar u8/u16 samples into LDS.
+//   phase A  (3 wavefronts share the tile's work items 6/5/5)   global RGB8 -> registers: one
+//            unconditional 12-byte load per lane and row (4 px; a wavefront instruction covers 768
+//            contiguous bytes; rows that are not dword aligned: aligned dwords + v_alignbyte), integer
+//            BT.601 colour conversion with packed-u16 VALU ops (2 px per instruction), 2x2 chroma box
+//            sums, planar u8/u16 samples into LDS.
 //   --- one LDS-only barrier ---
-//   phase B  (3 wavefronts, one lane per 8x8 block)  LDS rows -> f32 on the fly, f32 AAN DCT rows
-//            then columns entirely in registers (no transposes), quantise (reciprocal fast
-//            path proven equal to the IEEE divide, exact divide fallback), pack to i16, stage
-//            half a block per lane in the wavefront's own LDS area, read back by 16-byte chunk
-//            and store to HBM so that 4 consecutive lanes write 64 contiguous bytes, in the
-//            reference's YCbCrCoefficients layout.
+//   phase B  (3 wavefronts, one lane per 8x8 block)  LDS rows -> f32, f32 AAN DCT rows then columns
+//            entirely in registers (no transposes), quantise (two bracketing reciprocal products
+//            proven to agree with the IEEE divide, exact divide fallback), pack the whole block to
+//            32 registers of i16 pairs, stage 32 blocks at a time in the wavefront's own LDS area,
+//            read back by 16-byte chunk and store to HBM so that 8 consecutive lanes write one
+//            128-byte block, in the reference's YCbCrCoefficients layout.
 //
 // (Function names say producer_* / consumer_* because the same pieces were also run as
 // role-specialised wavefronts of a persistent workgroup; see DESIGN.md for that experiment.)
@@ -33,10 +34,9 @@
 // exactly as rustc emits it (no FMA).  The only fused operation below is an explicit
 // fmaf in OUR safety test, which is not part of the reference arithmetic.
 //
-// Instruction selection follows tools/ubench/valu_rates.hip measured on MI355X: wave64
-// v_add/sub/mul/fma_f32, v_and/or/add_u32 and shifts issue in 2 cycles; v_cvt_*, v_rndne,
-// v_cmp, v_perm, v_pk_* and every VOP3 integer op in 4 — so conversions use mantissa tricks
-// built from the 2-cycle set wherever the arithmetic stays exact.
+// Instruction selection follows tools/ubench/valu_rates.hip measured on MI355X: wave64 VOP2
+// v_add/sub/mul_f32, v_and/or/xor/add_u32 issue in ~2 cycles; v_fma_f32, anything with an SGPR
+// operand, v_cvt_*, v_cmp, v_perm, v_pk_*, SDWA forms and every VOP3 integer op in ~4.
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -84,14 +84,15 @@ constexpr int kPitch = 528;     // planar row pitch, full-width planes (4:4:4, g
 constexpr int kPitchHalf = 272; // planar row pitch, 256-px half planes (4:2:0 luminance);
                                 // 8*272 % 256 == 128 puts the bottom Y blocks of an MCU on the
                                 // other half of the 64 banks: ds_read_b64 conflict-free
-constexpr int kStageWave = 4096;        // per consumer wave: 64 blocks x 4 rows x 16 B (half a block each)
 
-// Quantiser table block for one quality, resident in HBM, read with scalar loads:
-//   [0,64)    1/q luminance   [64,128)   1/q chrominance   (f32, correctly rounded)
-//   [128,192) q   luminance   [192,256)  q   chrominance   (f32, exact integers 1..255)
-//   [256,320) (1/q chrominance) / 4 — for 4:2:0 chroma, whose DCT runs on the 2x2 SUMS
-//             (4x the sample; a power-of-two scale commutes with every f32 rounding)
-constexpr int kQtFloats = 320;
+// Quantiser table block for one quality, resident in HBM, read with scalar loads (rlo / rhi: the
+// bracketing reciprocals of quant_row8, correctly directed roundings made by the host):
+//   [0,64)    rlo luminance     [64,128)   rhi luminance
+//   [128,192) q   luminance     [192,256)  q   chrominance   (f32, exact integers 1..255)
+//   [256,320) rlo chrominance   [320,384)  rhi chrominance
+//   [384,448) rlo chrominance/4 [448,512)  rhi chrominance/4 — for 4:2:0 chroma, whose DCT runs on
+//             the 2x2 SUMS (4x the sample; a power-of-two scale commutes with every f32 rounding)
+constexpr int kQtFloats = 512;
 
 // Tiles and planar layouts (bytes inside one planar buffer):
 //   4:2:0  512x16 px = 32 MCUs = 192 blocks.  Luminance as two 256-px half planes (16 rows x
@@ -121,8 +122,18 @@ struct TileCtx {
     uint32_t W, H;        // pixels
     uint32_t units_x;     // MCUs per row (4:2:0) or 8x8 blocks per row (4:4:4, gray)
     uint32_t units_y;     // MCU rows / block rows
-    uint32_t fast;        // rows are 4-byte aligned: (px % 4 == 0) && (W*bpp % 4 == 0)
+    uint32_t fast;        // vector loads (L_ALIGNED or L_FUNNEL); 0 = byte gathers
+    const uint8_t *px_end; // one past the last pixel byte of the launch (all images of a batch)
+#if defined(PIXO_EMU)
+    const uint8_t *px_first; // first pixel byte of the launch (bounds of the emulated dword loads)
+#endif
 };
+
+// How phase A reads the pixels (a launch-time choice, template parameter of the kernel):
+//   L_ALIGNED  every row dword aligned (base % 4 == 0, W * bpp % 4 == 0): one 12-byte load per lane and row
+//   L_FUNNEL   any alignment, W >= 4: the aligned dwords around the lane's 12 bytes + v_alignbyte
+//   L_BYTES    byte gathers (images narrower than one 4-pixel group)
+enum Load { L_BYTES = 0, L_ALIGNED = 1, L_FUNNEL = 2 };
 
 // ---------------------------------------------------------------------------------
 // small intrinsic wrappers (device instruction / host emulation)
@@ -309,37 +320,101 @@ PIXO_DEV uint32_t gather_row4_gray(const uint8_t *px, uint32_t W, uint32_t H, ui
 }
 
 // ---------------------------------------------------------------------------------
-// producer: one wavefront moves a whole tile from HBM to a planar LDS buffer
+// producer: the wavefronts move a whole tile from HBM to a planar LDS buffer
 // ---------------------------------------------------------------------------------
-// FAST images (every row dword aligned: base % 4 == 0 and W * bpp % 4 == 0, hence W % 4 == 0)
-// are read with ONE unconditional 12-byte (RGB) / 4-byte (gray) vector load per item-row and no
-// branch anywhere near a load: the address is clamped to the last group of the row and to the
-// last row, which IS the reference's edge replication for rows (jpeg/mod.rs:1579,1627); groups
-// lying wholly right of the image (W % 4 == 0: a group is never split) are rebuilt from the
-// clamped group's last pixel by fix_right_edge_*, a register-only step that only right-edge
-// tiles execute.  (Branches around the loads made hipcc wait for every load at its join point:
-// one outstanding load per wavefront, 4.6 TB/s at best.)  Other images take the byte gather.
-template <int MODE, bool FAST>
+// The vector paths read with unconditional loads and no branch anywhere near a load: the address
+// is clamped to the last 4-pixel group of the row (x = W - 4) and to the last row, which IS the
+// reference's edge replication for rows (jpeg/mod.rs:1579,1627); a group that reaches beyond the
+// image is rebuilt from the clamped group's pixels by fix_right_edge_*, a register-only step that
+// only right-edge tiles execute.  (Branches around the loads made hipcc wait for every load at its
+// join point: one outstanding load per wavefront, 4.6 TB/s at best.)
+//
+// Pixels are read once: the loads are non-temporal (they do not displace the other workgroups'
+// lines in L2 / Infinity Cache on their way through).
+#if defined(PIXO_EMU) || defined(PIXO_PLAIN_LOADS) // (PIXO_PLAIN_LOADS: A/B builds, tools/ab_build.sh)
+#define PIXO_GLOAD(ptr) (*(ptr))
+#else
+#define PIXO_GLOAD(ptr) __builtin_nontemporal_load(ptr)
+#endif
+
+// v_alignbyte_b32: ({hi, lo} >> 8 * (sh & 3)) & 0xffffffff
+PIXO_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+#if defined(PIXO_EMU)
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));
+#else
+    return __builtin_amdgcn_alignbyte(hi, lo, sh & 3);
+#endif
+}
+
+// One aligned dword of the pixel buffer.  The device reads it as it is: a dword that holds at least
+// one pixel byte lies in the same page as that byte.  The emulation assembles it from the bytes that
+// exist (others read as 0xEE and must never reach a result).
+PIXO_DEV uint32_t load_dword(const TileCtx &c, const uint8_t *aligned)
+{
+#if defined(PIXO_EMU)
+    uint32_t v = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint8_t *p = aligned + i;
+        v |= (uint32_t)((p >= c.px_first && p < c.px_end) ? *p : 0xEE) << (8 * i);
+    }
+    return v;
+#else
+    return PIXO_GLOAD((const uint32_t *)aligned);
+#endif
+}
+
+// L_FUNNEL: `n` (1 or 3) dwords starting at byte address `row + off`, whatever its alignment: n + 1
+// aligned dwords (the last one clamped to the buffer's last dword: it is only needed when the address
+// is not aligned, and then it holds wanted bytes) funnelled through v_alignbyte.
+template <int N> PIXO_DEV void funnel_load(const TileCtx &c, const uint8_t *row, uint32_t off, uint32_t *r)
+{
+    // wave-uniform part (scalar ALU): the row's aligned base and how far the buffer's last dword is from it
+    const uint32_t r3 = (uint32_t)(uintptr_t)row & 3u;
+    const uint8_t *row4 = row - r3;
+    const uint64_t last64 = (((uintptr_t)c.px_end - 1) & ~(uintptr_t)3) - (uintptr_t)row4;
+    const uint32_t last = last64 > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)last64;
+    // per lane: three VALU operations for the address, one per dword for the shift
+    const uint32_t t = off + r3, voff = t & ~3u, sh = t & 3u;
+    uint32_t w[N + 1];
+#pragma unroll
+    for (int i = 0; i < N; i++) w[i] = load_dword(c, row4 + voff + 4 * i);
+    w[N] = load_dword(c, row4 + (voff + 4 * N < last ? voff + 4 * N : last));
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = alignbyte(w[i + 1], w[i], sh);
+}
+
+template <int MODE, int LOAD>
 PIXO_DEV void producer_load_item(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int k, int lane,
                                  uint32_t *r)
 {
     const uint32_t x0 = tile_x * kTileW + 4 * ((k & 1) * 64 + lane);
     const uint32_t y0 = tile_y * Geo<MODE>::tile_h + (MODE == M420 ? 2 : 1) * (k >> 1);
-    if (FAST) {
+    if (LOAD != L_BYTES) {
         // uniform 64-bit row base (scalar ALU) + per-lane 32-bit byte offset: the loads use the
         // saddr + voffset form and cost no 64-bit vector arithmetic
-        const uint32_t xoff = (x0 < c.W ? x0 : c.W - 4) * Geo<MODE>::bpp;
+        const uint32_t xoff = (x0 < c.W - 4 ? x0 : c.W - 4) * Geo<MODE>::bpp;
         const uint32_t ya = y0 < c.H ? y0 : c.H - 1;
         const uint8_t *row = c.px + (size_t)ya * ((size_t)c.W * Geo<MODE>::bpp);
         if (MODE == MGRAY) {
-            r[0] = *(const uint32_t *)(row + xoff);
+            if (LOAD == L_ALIGNED) r[0] = PIXO_GLOAD((const uint32_t *)(row + xoff));
+            else funnel_load<1>(c, row, xoff, r);
         } else {
-            const uint32_t *q = (const uint32_t *)(row + xoff);
-            r[0] = q[0]; r[1] = q[1]; r[2] = q[2];
+            if (LOAD == L_ALIGNED) {
+                const uint32_t *q = (const uint32_t *)(row + xoff);
+                r[0] = PIXO_GLOAD(q); r[1] = PIXO_GLOAD(q + 1); r[2] = PIXO_GLOAD(q + 2);
+            } else {
+                funnel_load<3>(c, row, xoff, r);
+            }
             if (MODE == M420) {
                 const uint32_t yb = y0 + 1 < c.H ? y0 + 1 : c.H - 1;
-                const uint32_t *q2 = (const uint32_t *)(c.px + (size_t)yb * ((size_t)c.W * 3) + xoff);
-                r[3] = q2[0]; r[4] = q2[1]; r[5] = q2[2];
+                const uint8_t *row2 = c.px + (size_t)yb * ((size_t)c.W * 3);
+                if (LOAD == L_ALIGNED) {
+                    const uint32_t *q2 = (const uint32_t *)(row2 + xoff);
+                    r[3] = PIXO_GLOAD(q2); r[4] = PIXO_GLOAD(q2 + 1); r[5] = PIXO_GLOAD(q2 + 2);
+                } else {
+                    funnel_load<3>(c, row2, xoff, r + 3);
+                }
             }
         }
     } else {
@@ -356,26 +431,39 @@ PIXO_DEV void producer_load_item(const TileCtx &c, uint32_t tile_x, uint32_t til
     }
 }
 
-// Right-edge fix-up for FAST loads: a group at x0 >= W becomes four copies of pixel W-1, i.e. of
-// the clamped group's last pixel (bytes 9..11 of its 12).
-PIXO_DEV void fix_right_edge_rgb(bool outside, uint32_t *d)
+// Right-edge fix-up for the vector loads.  The group was read at x = W - 4 (pixels p0..p3 = W-4..W-1)
+// instead of x0 = W - 4 + d, d >= 1; what the reference's clamp (x = min(x, W-1)) yields for it is
+// (p[min(d,3)], p[min(d+1,3)], p[min(d+2,3)], p3).  d in {1, 2} occurs only when W % 4 != 0 (L_FUNNEL),
+// in one lane per row; d >= 3 is a group wholly right of the image: four copies of p3, bytes 9..11.
+template <int LOAD> PIXO_DEV void fix_right_edge_rgb(uint32_t d, uint32_t *v)
 {
-    const uint32_t a = perm(d[2], d[2], 0x01030201u); // R G B R
-    const uint32_t b = perm(d[2], d[2], 0x02010302u); // G B R G
-    const uint32_t e = perm(d[2], d[2], 0x03020103u); // B R G B
-    d[0] = outside ? a : d[0]; d[1] = outside ? b : d[1]; d[2] = outside ? e : d[2];
+    const uint32_t c0 = perm(v[2], v[2], 0x01030201u); // R3 G3 B3 R3
+    const uint32_t c1 = perm(v[2], v[2], 0x02010302u); // G3 B3 R3 G3
+    const uint32_t c2 = perm(v[2], v[2], 0x03020103u); // B3 R3 G3 B3
+    if (LOAD == L_ALIGNED) { // W % 4 == 0: a group is inside (d = 0) or wholly outside (d = 3)
+        v[0] = d == 0 ? v[0] : c0; v[1] = d == 0 ? v[1] : c1; v[2] = d == 0 ? v[2] : c2;
+        return;
+    }
+    const uint32_t a0 = alignbyte(v[1], v[0], 3), a1 = alignbyte(v[2], v[1], 3); // d = 1: p1 p2 p3 p3
+    const uint32_t b0 = alignbyte(v[2], v[1], 2);                                 // d = 2: p2 p3 p3 p3
+    v[0] = d == 0 ? v[0] : (d == 1 ? a0 : (d == 2 ? b0 : c0));
+    v[1] = d == 0 ? v[1] : (d == 1 ? a1 : c1);
+    v[2] = d == 0 ? v[2] : c2;
 }
 
-template <int MODE, bool FAST>
+template <int MODE, int LOAD>
 PIXO_DEV void producer_fix_item(const TileCtx &c, uint32_t tile_x, int k, int lane, uint32_t *r)
 {
-    if (!FAST || (tile_x + 1) * kTileW <= c.W) return; // wave-uniform: only right-edge tiles
-    const bool outside = tile_x * kTileW + 4 * ((k & 1) * 64 + lane) >= c.W;
+    if (LOAD == L_BYTES || (tile_x + 1) * kTileW <= c.W) return; // wave-uniform: only right-edge tiles
+    const uint32_t x0 = tile_x * kTileW + 4 * ((k & 1) * 64 + lane);
+    uint32_t d = x0 > c.W - 4 ? x0 - (c.W - 4) : 0;
+    d = d < 3 ? d : 3;
     if (MODE == MGRAY) {
-        r[0] = outside ? perm(r[0], r[0], 0x03030303u) : r[0];
+        const uint32_t s1 = perm(r[0], r[0], 0x03030201u), s2 = perm(r[0], r[0], 0x03030302u), s3 = perm(r[0], r[0], 0x03030303u);
+        r[0] = d == 0 ? r[0] : (d == 1 ? s1 : (d == 2 ? s2 : s3));
     } else {
-        fix_right_edge_rgb(outside, r);
-        if (MODE == M420) fix_right_edge_rgb(outside, r + 3);
+        fix_right_edge_rgb<LOAD>(d, r);
+        if (MODE == M420) fix_right_edge_rgb<LOAD>(d, r + 3);
     }
 }
 
@@ -488,29 +576,22 @@ PIXO_DEV void aan8_shift(float dc_shift, float &d0, float &d1, float &d2, float 
 // Quantise one row of 8 coefficients.
 // Reference: (x / q).round() as i16 with IEEE f32 divide and round-half-away.
 //
-// Fast path: r = x * fl(1/q), n = rint(r).  Let t = x/q (real) and f = fl(t) the
-// reference quotient.  |r - t| <= |t|(2^-24 + 2^-24 + 2^-48) and |f - t| <= 2^-24|t|,
-// so |r - f| <= 3 * 2^-24 |t| (+ second-order terms).  If no half-integer lies within
-// delta = 2^-22 |r| = 4 * 2^-24 |r| of r, then r and f sit strictly inside the same interval
-// (k-1/2, k+1/2) and both roundings — to-nearest-even for r, half-away for f — give k.
-// Otherwise the element takes the exact divide.  The margin between 3 and 4 units is thin
-// enough that the claim rests on ENUMERATION, not on the sketch: every f32 |x| <= 4096 with
-// every q in 1..255 (tests/emu/sweep_quant.py -> profiles/quant_fastpath_sweep.txt, 0 wrong;
-// 2^-21 passes as well and flags twice as many).
-//
-//   s = r + 1.5*2^23      rounds r to an integer (RNE) and leaves it, two's complement, in
-//                         the low mantissa bits: bits(s) = 0x4B400000 + n for |n| < 2^22
-//   n = s - 1.5*2^23      exact;   d = r - n exact (|d| <= 1/2, Sterbenz)
-//   t = |d| + 2^-22|r|    (one fma) >= 1/2 iff the lane is risky; the row keeps the maximum
-//                         (v_max3_f32: two elements per instruction)
-// A flagged row (a few per cent of rows on noise, far fewer on photographs) repeats the test
-// per element and takes the reference's own divide only for the elements some lane flagged —
-// typically one of the eight.  `scale` (1 or 1/4) maps x back to the reference's magnitude for
-// the exact path only; the fast path's rcp already contains it (exact power of two).
+// Fast path: two reciprocal products that BRACKET the reference quotient.  Let t = x/q (real) and
+// f = fl(t) the reference quotient, |f - t| <= 2^-24 |t|.  The table holds, per divisor,
+//     rlo = the largest  f32 <= (1/q)(1 - 2^-24 - 2^-30)
+//     rhi = the smallest f32 >= (1/q)(1 + 2^-24 + 2^-30)          (jpeg_host.cpp fill_device_qt)
+// so that f lies STRICTLY between the real products x*rlo and x*rhi (whatever the sign of x).
+//     s_lo = fma(x, rlo, 1.5*2^23)    one rounding of the exact sum: the integer nearest to x*rlo
+//     s_hi = fma(x, rhi, 1.5*2^23)    (ties to even) sits, two's complement, in the low mantissa bits
+// If both are the same integer n, both products lie in [n - 1/2, n + 1/2], f strictly inside, and
+// the reference's round-half-away gives n as well.  If they differ (the quotient is within ~2^-22
+// relative of a rounding boundary: a few per cent of wave-rows on noise, far fewer on photographs)
+// the row repeats the test per element and takes the reference's own divide only for the elements
+// some lane flagged.  Two multiply-adds, one xor, one or per element; the claim is also checked by
+// ENUMERATION over every f32 |x| <= 4096 and every q in 1..255 (tests/emu/sweep_quant.py ->
+// profiles/quant_fastpath_sweep.txt).  `scale` (1 or 1/4) maps x back to the reference's magnitude
+// for the exact path only; the fast path's tables already contain it (exact power of two).
 constexpr float kRoundMagic = 12582912.0f; // 1.5 * 2^23
-#ifndef PIXO_QUANT_EPS // (overridden only by tests/emu/sweep_quant.py experiments)
-#define PIXO_QUANT_EPS 0x1p-22f
-#endif
 
 #if defined(PIXO_EMU)
 #define PIXO_ANY_LANE(pred) (pred)
@@ -518,30 +599,46 @@ constexpr float kRoundMagic = 12582912.0f; // 1.5 * 2^23
 #define PIXO_ANY_LANE(pred) (__builtin_amdgcn_ballot_w64(pred) != 0)
 #endif
 
-PIXO_DEV float quant_risk(float r, float s)
+// the two roundings of one element; returns the bits that differ (0 = safe), *s = the low one
+PIXO_DEV uint32_t quant_bracket(float x, float rlo, float rhi, float *s)
 {
-    const float n = s - kRoundMagic;
-    const float d = r - n;
-    return __builtin_fmaf(__builtin_fabsf(r), PIXO_QUANT_EPS, __builtin_fabsf(d));
+    const float lo = __builtin_fmaf(x, rlo, kRoundMagic);
+    const float hi = __builtin_fmaf(x, rhi, kRoundMagic);
+    *s = lo;
+    return fbits(lo) ^ fbits(hi);
 }
 
-PIXO_DEV void quant_row8(const float *x, const float *rcp, qtab_t q, float scale, uint32_t out[4])
+#if defined(PIXO_QUANT_PK) && !defined(PIXO_EMU)
+typedef float pixo_f2 __attribute__((ext_vector_type(2)));
+#endif
+// four coefficients -> two registers of packed i16 pairs
+PIXO_DEV void quant_row4(const float *x, const float *rlo, const float *rhi, qtab_t q, float scale, uint32_t out[2])
 {
-    float s[8];
-    float worst = 0.0f;
+    float s[4];
+#if defined(PIXO_QUANT_PK) && !defined(PIXO_EMU)
+    // two elements per v_pk_fma_f32, one 64-bit compare per pair
+    bool any = false;
 #pragma unroll
-    for (int c = 0; c < 8; c += 2) {
-        const float r0 = x[c] * rcp[c], r1 = x[c + 1] * rcp[c + 1];
-        s[c] = r0 + kRoundMagic;
-        s[c + 1] = r1 + kRoundMagic;
-        worst = __builtin_fmaxf(__builtin_fmaxf(worst, quant_risk(r0, s[c])), quant_risk(r1, s[c + 1]));
+    for (int c = 0; c < 4; c += 2) {
+        const pixo_f2 xx = {x[c], x[c + 1]}, m = {kRoundMagic, kRoundMagic};
+        const pixo_f2 lo = __builtin_elementwise_fma(xx, (pixo_f2){rlo[c], rlo[c + 1]}, m);
+        const pixo_f2 hi = __builtin_elementwise_fma(xx, (pixo_f2){rhi[c], rhi[c + 1]}, m);
+        s[c] = lo.x; s[c + 1] = lo.y;
+        any |= __builtin_bit_cast(uint64_t, lo) != __builtin_bit_cast(uint64_t, hi);
     }
-    if (PIXO_ANY_LANE(worst >= 0.5f)) { // rare: some quotient within 2^-22 (relative) of a rounding boundary
+    const bool flagged = PIXO_ANY_LANE(any);
+#else
+    uint32_t differ = 0;
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            float xc = x[c];
-            PIXO_PIN(xc); // recompute the test here: reusing the fast path's values keeps 16 of them alive
-            if (PIXO_ANY_LANE(quant_risk(xc * rcp[c], s[c]) >= 0.5f)) {
+    for (int c = 0; c < 4; c++) differ |= quant_bracket(x[c], rlo[c], rhi[c], &s[c]);
+    const bool flagged = PIXO_ANY_LANE(differ != 0);
+#endif
+    if (flagged) { // rare: some quotient next to a rounding boundary
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float xc = x[c], t;
+            PIXO_PIN(xc); // recompute the test here: reusing the fast path's values keeps them all alive
+            if (PIXO_ANY_LANE(quant_bracket(xc, rlo[c], rhi[c], &t) != 0)) {
                 const float n = __builtin_roundf((x[c] * scale) / q[c]); // the reference operation itself
                 s[c] = n + kRoundMagic;                                   // exact: |n| < 2^15
             }
@@ -551,17 +648,13 @@ PIXO_DEV void quant_row8(const float *x, const float *rcp, qtab_t q, float scale
     // low 16 bits of each s = the i16 result (never saturates: |x/q| <= 2^11)
     out[0] = perm(fbits(s[1]), fbits(s[0]), 0x05040100u);
     out[1] = perm(fbits(s[3]), fbits(s[2]), 0x05040100u);
-    out[2] = perm(fbits(s[5]), fbits(s[4]), 0x05040100u);
-    out[3] = perm(fbits(s[7]), fbits(s[6]), 0x05040100u);
 }
-
-// LDS stage of one consumer wavefront: 4 KiB holding rows [4 half, 4 half + 4) of its 64 blocks.
-// Chunk (block bl, row r in 0..3) lives at 64 bl + 16 ((r ^ (bl >> 1)) & 3).  ds_write_b128 is
-// served in groups of 8 consecutive lanes (= blocks) against 32 banks = 128 B: blocks of equal
-// parity share a 64-byte half of that window, and the four of them in a group (bl >> 1 =
-// 0..3 mod 4) take its four different 16-byte slots — conflict-free.  The read-back (lane =
-// chunk, 4 lanes per block) touches all four slots of each block whatever the permutation.
-PIXO_DEV int stage_addr(int bl, int r) { return bl * 64 + (((r ^ (bl >> 1)) & 3) << 4); }
+PIXO_DEV void quant_row8(const float *x, const float *rlo, const float *rhi, qtab_t q, float scale, uint32_t out[4])
+{
+    quant_row4(x, rlo, rhi, q, scale, out);
+    PIXO_PIN(out[0]); PIXO_PIN(out[1]);
+    quant_row4(x + 4, rlo + 4, rhi + 4, q + 4, scale, out + 2);
+}
 
 // Block kinds (wave-uniform): quantiser table, DC shift of the row pass, scale.
 //   luminance, chroma 4:4:4   samples b, level shift 128     row DC shift 8*128 = 1024
@@ -581,17 +674,13 @@ PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v
         if (U16) raw16[r] = *(const u32x4 *)(src + r * pitch);
         else raw8[r] = *(const u32x2 *)(src + r * pitch);
     }
-#ifndef PIXO_ABL_NO_ROW_PREFETCH // (timing experiments only)
     PIXO_SCHED_FENCE();
-#endif
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         if (U16) row_from_u16(raw16[r], &v[r * 8]);
         else row_from_bytes(raw8[r].x, raw8[r].y, &v[r * 8]);
-#ifndef PIXO_ABL_NOROWS // (timing experiments only)
         aan8_shift(dc_shift, v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4],
                    v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
-#endif
         if (r & 1) {
             // finish both rows (scale multiplications included) before the next pair starts:
             // left free, the compiler batches all 64 scale multiplications after row 7 into
@@ -607,46 +696,11 @@ PIXO_DEV void block_cols(float *v)
 {
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-#ifndef PIXO_ABL_NOCOLS // (timing experiments only)
         aan8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
-#endif
         if (c & 1) PIXO_SCHED_FENCE();
     }
 #pragma unroll
     for (int i = 0; i < 64; i++) PIXO_PIN(v[i]);
-}
-
-// Quantise rows [4 half, 4 half + 4) of the lane's block into the wave's stage.
-// The reciprocals are wave-uniform scalar (SMEM) loads, fetched one row ahead of their use so
-// that their latency hides under the previous row's arithmetic.
-PIXO_DEV void block_quant_half(const float *v, qtab_t rcp, qtab_t q, float scale, int half, int bl,
-                               uint8_t *stage_wave)
-{
-    float rc[8], rn[8];
-#pragma unroll
-    for (int c = 0; c < 8; c++) rc[c] = rcp[half * 32 + c];
-    PIXO_SCHED_FENCE();
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int u = half * 4 + r;
-        if (r < 3) {
-#pragma unroll
-            for (int c = 0; c < 8; c++) rn[c] = rcp[(u + 1) * 8 + c];
-            PIXO_SCHED_FENCE();
-        }
-        u32x4 o;
-        uint32_t w[4];
-#ifndef PIXO_ABL_NOQUANT // (timing experiments only)
-        quant_row8(&v[u * 8], rc, q + u * 8, scale, w);
-#else
-        for (int c = 0; c < 4; c++) w[c] = fbits(v[u * 8 + 2 * c] + rc[c]) ^ fbits(v[u * 8 + 2 * c + 1]);
-#endif
-        o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
-        *(u32x4 *)(stage_wave + stage_addr(bl, r)) = o;
-        PIXO_SCHED_FENCE();
-#pragma unroll
-        for (int c = 0; c < 8; c++) rc[c] = rn[c];
-    }
 }
 
 // What the block of lane `lane` of consumer wave `wave` is, and where its planar rows start
@@ -654,7 +708,7 @@ PIXO_DEV void block_quant_half(const float *v, qtab_t rcp, qtab_t q, float scale
 struct BlockDesc {
     const uint8_t *src;
     int pitch;
-    int rcp_off, q_off; // offsets into the quantiser table block
+    int rcp_off, q_off; // offsets into the quantiser table block (rlo at rcp_off, rhi 64 floats behind)
     float dc_shift, scale;
     bool u16;
 };
@@ -671,10 +725,10 @@ template <int MODE> PIXO_DEV BlockDesc block_desc(int wave, int lane, const uint
             d.pitch = kPitchHalf;
         } else {
             d.src = planar + 8704 + (lane >> 5) * 4096 + (lane & 31) * 16;
-            d.pitch = 512; d.u16 = true; d.rcp_off = 256; d.q_off = 192; d.dc_shift = 4096.0f; d.scale = 0.25f;
+            d.pitch = 512; d.u16 = true; d.rcp_off = 384; d.q_off = 192; d.dc_shift = 4096.0f; d.scale = 0.25f;
         }
     } else if (MODE == M444) {
-        if (wave >= 1) { d.rcp_off = 64; d.q_off = 192; }
+        if (wave >= 1) { d.rcp_off = 256; d.q_off = 192; }
     }
     return d;
 }
@@ -690,74 +744,10 @@ template <int MODE> PIXO_DEV void consumer_rows(int wave, int lane, const uint8_
 // Consumer step 2: column pass (registers only).
 PIXO_DEV void consumer_cols(float *v) { block_cols(v); }
 
-// Consumer step 3 (half = 0, 1): quantise four rows of every block of the wave into its stage.
-template <int MODE>
-PIXO_DEV void consumer_quant_half(int wave, int lane, const float *qt, const float *v, int half, uint8_t *stage)
-{
-    const BlockDesc d = block_desc<MODE>(wave, lane, nullptr);
-    const qtab_t tab = as_qtab(qt);
-    block_quant_half(v, tab + uniform_i32(d.rcp_off), tab + uniform_i32(d.q_off), d.scale, half, lane, stage);
-}
-
-// Consumer step 4 (half = 0, 1): the wave's staged half blocks -> HBM.  Lane l of round k moves
-// chunk 64 k + l = (block, row): four consecutive lanes write 64 contiguous bytes of one block.
-// Reads only what this wavefront wrote in step 3 (program order, no barrier).
-template <int MODE, bool GUARD>
-PIXO_DEV void store_half_body(const TileCtx &c, uint32_t u0, uint32_t nvalid, uint32_t tile_y, int wave, int lane,
-                              int half, const uint8_t *stage_wave)
-{
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int ch = k * 64 + lane, bl = ch >> 2, r = ch & 3, j = half * 4 + r;
-        const u32x4 w = *(const u32x4 *)(stage_wave + stage_addr(bl, r));
-        if (MODE == M420) {
-            const size_t mcu0 = (size_t)tile_y * c.units_x + u0;
-            if (wave < 2) {
-                if (!GUARD || (uint32_t)(wave * 16 + (bl >> 2)) < nvalid)
-                    PIXO_GSTORE(c.y + (mcu0 * 4 + wave * 64 + bl) * 64 + j * 8, w);
-            } else {
-                const int m = bl & 31;
-                int16_t *dst = (bl < 32 ? c.cb : c.cr) + (mcu0 + m) * 64 + j * 8;
-                if (!GUARD || (uint32_t)m < nvalid) PIXO_GSTORE(dst, w);
-            }
-        } else if (MODE == M444) {
-            const size_t blk0 = (size_t)tile_y * c.units_x + u0;
-            // wave-uniform branches, one store each, inside a lane-divergent guard (kept even for
-            // interior tiles): without it the three stores are merged into one store through a
-            // select among c.y / c.cb / c.cr, which the compiler implements in scratch memory
-            const size_t off = (blk0 + bl) * 64 + j * 8;
-            if ((uint32_t)bl < nvalid) {
-                if (wave == 0) PIXO_GSTORE(c.y + off, w);
-                else if (wave == 1) PIXO_GSTORE(c.cb + off, w);
-                else PIXO_GSTORE(c.cr + off, w);
-            }
-        } else {
-            const uint32_t brow = tile_y * 3 + wave;
-            if (!GUARD || ((uint32_t)bl < nvalid && brow < c.units_y))
-                PIXO_GSTORE(c.y + ((size_t)brow * c.units_x + u0 + bl) * 64 + j * 8, w);
-        }
-    }
-}
-
-template <int MODE>
-PIXO_DEV void consumer_store_half(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int wave, int lane,
-                                  int half, const uint8_t *stage)
-{
-    typedef Geo<MODE> G;
-    const uint32_t u0 = tile_x * G::units_x; // first MCU / block column of the tile
-    const uint32_t nvalid = c.units_x - u0 < (uint32_t)G::units_x ? c.units_x - u0 : G::units_x;
-    // tiles that lie wholly inside the image (all but the right-most column; for grey also not
-    // the block rows below the image) store unguarded (4:4:4 keeps its guard, see above)
-    const bool inside = nvalid == (uint32_t)G::units_x && (MODE != MGRAY || tile_y * 3 + wave < c.units_y);
-    if (MODE != M444 && inside) store_half_body<MODE, false>(c, u0, nvalid, tile_y, wave, lane, half, stage);
-    else store_half_body<MODE, true>(c, u0, nvalid, tile_y, wave, lane, half, stage);
-}
-
 // ---------------------------------------------------------------------------------
-// Whole-block write-out (what the kernel runs; the half-block steps above remain for the
-// PIXO_HALF_BLOCK_STORES timing build).  Two 64-byte halves of a 128-byte block stored a microsecond
-// apart cost HBM 20 % of its throughput (tools/ubench/tile_copy.hip: 22.1 us against 18.0 us for
-// the same bytes as whole lines), and the 4 KiB stage of a wavefront holds only 32 whole blocks.
+// Whole-block write-out.  Two 64-byte halves of a 128-byte block stored a microsecond apart cost
+// HBM 20 % of its throughput (tools/ubench/tile_copy.hip: 22.1 us against 18.0 us for the same
+// bytes as whole lines), and the 4 KiB stage of a wavefront holds only 32 whole blocks.
 // So the lane quantises its whole block into 32 registers (the 64 floats die as it goes), and the
 // wavefront writes out in two rounds: lanes [32 h, 32 h + 32) put their blocks into the stage, all
 // 64 lanes read them back as 16-byte chunks — eight consecutive lanes = one block — and every
@@ -769,25 +759,27 @@ PIXO_DEV void consumer_store_half(const TileCtx &c, uint32_t tile_x, uint32_t ti
 PIXO_DEV int stage_addr_block(int bl, int r) { return bl * 128 + (((r ^ bl) & 7) << 4); }
 
 // Consumer step 3': quantise the lane's block, row r -> out[4 r .. 4 r + 3] (packed i16 pairs).
+// The reciprocals are wave-uniform scalar (SMEM) loads, fetched one row ahead of their use so that
+// their latency hides under the previous row's arithmetic.
 PIXO_DEV void block_quant(const float *v, qtab_t rcp, qtab_t q, float scale, uint32_t *out)
 {
-    float rc[8], rn[8];
+    float lo[8], hi[8], lo_n[8], hi_n[8];
 #pragma unroll
-    for (int c = 0; c < 8; c++) rc[c] = rcp[c];
+    for (int c = 0; c < 8; c++) { lo[c] = rcp[c]; hi[c] = rcp[64 + c]; }
     PIXO_SCHED_FENCE();
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         if (u < 7) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) rn[c] = rcp[(u + 1) * 8 + c];
+            for (int c = 0; c < 8; c++) { lo_n[c] = rcp[(u + 1) * 8 + c]; hi_n[c] = rcp[64 + (u + 1) * 8 + c]; }
             PIXO_SCHED_FENCE();
         }
-        quant_row8(&v[u * 8], rc, q + u * 8, scale, &out[u * 4]);
+        quant_row8(&v[u * 8], lo, hi, q + u * 8, scale, &out[u * 4]);
         // the row's four result registers exist from here on (and its eight floats are dead)
         PIXO_PIN(out[u * 4]); PIXO_PIN(out[u * 4 + 1]); PIXO_PIN(out[u * 4 + 2]); PIXO_PIN(out[u * 4 + 3]);
         PIXO_SCHED_FENCE();
 #pragma unroll
-        for (int c = 0; c < 8; c++) rc[c] = rn[c];
+        for (int c = 0; c < 8; c++) { lo[c] = lo_n[c]; hi[c] = hi_n[c]; }
     }
 }
 template <int MODE> PIXO_DEV void consumer_quant(int wave, int lane, const float *qt, const float *v, uint32_t *out)
@@ -813,37 +805,42 @@ PIXO_DEV void consumer_stage_blocks(int lane, int h, const uint32_t *qw, uint8_t
 PIXO_DEV void consumer_stage_sync() { PIXO_WAVE_SYNC(); }
 
 // Consumer step 5' (round h): the 32 staged blocks -> HBM.  Lane l of instruction k moves chunk
-// 64 k + l = (block 8 k + l / 8, row l % 8).
+// 64 k + l = (block 8 k + l / 8, row l % 8) of the round, i.e. bytes [1024 k + 16 l, + 16) behind the
+// round's first block: a wave-uniform 64-bit base (scalar registers) + a 32-bit lane offset, so that
+// the stores take the saddr + voffset form and no 64-bit vector arithmetic is spent on addresses.
 template <int MODE, bool GUARD>
 PIXO_DEV void store_blocks_body(const TileCtx &c, uint32_t u0, uint32_t nvalid, uint32_t tile_y, int wave, int lane,
                                 int h, const uint8_t *stage_wave)
 {
+    const uint32_t lane_off = (uint32_t)lane * 16u;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int ch = k * 64 + lane, sb = ch >> 3, j = ch & 7, bl = h * 32 + sb; // bl: block of the wave
         const u32x4 w = *(const u32x4 *)(stage_wave + stage_addr_block(sb, j));
+        const uint32_t off = (uint32_t)k * 1024u + lane_off;
         if (MODE == M420) {
             const size_t mcu0 = (size_t)tile_y * c.units_x + u0;
             if (wave < 2) {
-                if (!GUARD || (uint32_t)(wave * 16 + (bl >> 2)) < nvalid)
-                    PIXO_GSTORE(c.y + (mcu0 * 4 + wave * 64 + bl) * 64 + j * 8, w);
+                uint8_t *base = (uint8_t *)(c.y + (mcu0 * 4 + (size_t)(wave * 64 + h * 32)) * 64);
+                if (!GUARD || (uint32_t)(wave * 16 + (bl >> 2)) < nvalid) PIXO_GSTORE(base + off, w);
             } else { // round 0: the 32 Cb blocks, round 1: the 32 Cr blocks
-                int16_t *dst = (h == 0 ? c.cb : c.cr) + (mcu0 + sb) * 64 + j * 8;
-                if (!GUARD || (uint32_t)sb < nvalid) PIXO_GSTORE(dst, w);
+                uint8_t *base = (uint8_t *)((h == 0 ? c.cb : c.cr) + mcu0 * 64);
+                if (!GUARD || (uint32_t)sb < nvalid) PIXO_GSTORE(base + off, w);
             }
         } else if (MODE == M444) {
-            const size_t blk0 = (size_t)tile_y * c.units_x + u0;
-            // (wave-uniform branches inside a lane-divergent guard, see store_half_body)
-            const size_t off = (blk0 + bl) * 64 + j * 8;
+            const size_t blk = ((size_t)tile_y * c.units_x + u0 + (size_t)(h * 32)) * 64;
+            // (wave-uniform branches, one store each, inside a lane-divergent guard — kept even for interior
+            // tiles: without it the three stores are merged into one store through a select among
+            // c.y / c.cb / c.cr, which the compiler implements in scratch memory)
             if ((uint32_t)bl < nvalid) {
-                if (wave == 0) PIXO_GSTORE(c.y + off, w);
-                else if (wave == 1) PIXO_GSTORE(c.cb + off, w);
-                else PIXO_GSTORE(c.cr + off, w);
+                if (wave == 0) PIXO_GSTORE((uint8_t *)(c.y + blk) + off, w);
+                else if (wave == 1) PIXO_GSTORE((uint8_t *)(c.cb + blk) + off, w);
+                else PIXO_GSTORE((uint8_t *)(c.cr + blk) + off, w);
             }
         } else {
             const uint32_t brow = tile_y * 3 + wave;
-            if (!GUARD || ((uint32_t)bl < nvalid && brow < c.units_y))
-                PIXO_GSTORE(c.y + ((size_t)brow * c.units_x + u0 + bl) * 64 + j * 8, w);
+            uint8_t *base = (uint8_t *)(c.y + ((size_t)brow * c.units_x + u0 + (size_t)(h * 32)) * 64);
+            if (!GUARD || ((uint32_t)bl < nvalid && brow < c.units_y)) PIXO_GSTORE(base + off, w);
         }
     }
 }

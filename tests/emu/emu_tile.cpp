@@ -12,7 +12,7 @@
 
 using namespace pixo_tile;
 
-template <int MODE, bool FAST>
+template <int MODE, int LOAD>
 static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long *stats, int wave_order)
 {
     typedef Geo<MODE> G;
@@ -22,14 +22,14 @@ static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long
     uint32_t regs[G::items * G::item_regs];
     for (uint32_t ty = 0; ty < tiles_y; ty++)
         for (uint32_t tx = 0; tx < tiles_x; tx++) {
-            if (stats) stats[FAST ? 0 : 1]++; // tiles read by vector loads / by byte gathers
+            if (stats) stats[LOAD == L_ALIGNED ? 0 : (LOAD == L_BYTES ? 1 : 2)]++; // tiles by aligned loads / byte gathers / funnel loads
             uint8_t *planar = lds;
             memset(planar, 0xA5, G::planar); // nothing may rely on a previous tile's samples
             // producer wavefront: every lane loads and converts its items of this tile
             for (int lane = 0; lane < 64; lane++) {
-                for (int k = 0; k < G::items; k++) producer_load_item<MODE, FAST>(c, tx, ty, k, lane, &regs[k * G::item_regs]);
+                for (int k = 0; k < G::items; k++) producer_load_item<MODE, LOAD>(c, tx, ty, k, lane, &regs[k * G::item_regs]);
                 for (int k = 0; k < G::items; k++) {
-                    producer_fix_item<MODE, FAST>(c, tx, k, lane, &regs[k * G::item_regs]);
+                    producer_fix_item<MODE, LOAD>(c, tx, k, lane, &regs[k * G::item_regs]);
                     producer_color_item<MODE>(k, lane, &regs[k * G::item_regs], planar);
                 }
             }
@@ -53,7 +53,7 @@ static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long
 
 extern "C" int emu_jpeg_coeffs(const uint8_t *px, uint32_t W, uint32_t H, int color_type, int subsampling,
                                int quality, int16_t *y, int16_t *cb, int16_t *cr, int allow_fast,
-                               long *stats /* [interior tiles, edge tiles] or NULL */, int wave_order)
+                               long *stats /* [tiles by aligned loads, by byte gathers, by funnel loads] or NULL */, int wave_order)
 {
     float qt[pixo_host::kDeviceQtFloats];
     pixo_host::fill_device_qt((uint8_t)quality, qt);
@@ -64,20 +64,41 @@ extern "C" int emu_jpeg_coeffs(const uint8_t *px, uint32_t W, uint32_t H, int co
     c.units_x = (W + unit - 1) / unit;
     c.units_y = (H + unit - 1) / unit;
     const size_t row_bytes = (size_t)W * (gray ? 1 : 3);
-    c.fast = allow_fast && ((uintptr_t)px % 4 == 0) && (row_bytes % 4 == 0) && W >= 4;
-    if (stats) stats[0] = stats[1] = 0;
-    if (gray) {
-        if (c.fast) run_image<MGRAY, true>(c, (c.units_x + 63) / 64, (c.units_y + 2) / 3, stats, wave_order);
-        else run_image<MGRAY, false>(c, (c.units_x + 63) / 64, (c.units_y + 2) / 3, stats, wave_order);
-    } else if (s420) {
-        if (c.fast) run_image<M420, true>(c, (c.units_x + 31) / 32, c.units_y, stats, wave_order);
-        else run_image<M420, false>(c, (c.units_x + 31) / 32, c.units_y, stats, wave_order);
-    } else {
-        if (c.fast) run_image<M444, true>(c, (c.units_x + 63) / 64, c.units_y, stats, wave_order);
-        else run_image<M444, false>(c, (c.units_x + 63) / 64, c.units_y, stats, wave_order);
-    }
+    c.px_first = px; c.px_end = px + row_bytes * H;
+    // the launcher's choice (jpeg_kernels.hip launch_jpeg_coeffs); allow_fast = 0 forces the byte gathers,
+    // 2 forces the funnel loads even for aligned images
+    const bool aligned = ((uintptr_t)px % 4 == 0) && (row_bytes % 4 == 0);
+    int load = (!allow_fast || W < 4) ? L_BYTES : (aligned && allow_fast != 2 ? L_ALIGNED : L_FUNNEL);
+    c.fast = load != L_BYTES;
+    if (stats) stats[0] = stats[1] = stats[2] = 0;
+    const uint32_t tx_gray = (c.units_x + 63) / 64, ty_gray = (c.units_y + 2) / 3;
+#define PIXO_RUN(MODE, TX, TY)                                                     \
+    do {                                                                           \
+        if (load == L_ALIGNED) run_image<MODE, L_ALIGNED>(c, TX, TY, stats, wave_order); \
+        else if (load == L_FUNNEL) run_image<MODE, L_FUNNEL>(c, TX, TY, stats, wave_order); \
+        else run_image<MODE, L_BYTES>(c, TX, TY, stats, wave_order);                 \
+    } while (0)
+    if (gray) PIXO_RUN(MGRAY, tx_gray, ty_gray);
+    else if (s420) PIXO_RUN(M420, (c.units_x + 31) / 32, c.units_y);
+    else PIXO_RUN(M444, (c.units_x + 63) / 64, c.units_y);
+#undef PIXO_RUN
     return 0;
 }
+
+// The bracketing reciprocals of one divisor exactly as the device tables hold them (fill_device_qt
+// computes them per quality; here: any q in 1..255).
+static void bracket_of(int q, float *lo, float *hi)
+{
+    const double w_lo = (1.0 / q) * (1.0 - 0x1p-24 - 0x1p-30), w_hi = (1.0 / q) * (1.0 + 0x1p-24 + 0x1p-30);
+    float l = (float)w_lo, h = (float)w_hi;
+    while ((double)l > w_lo) l = nextafterf(l, 0.0f);
+    while ((double)h < w_hi) h = nextafterf(h, 2.0f);
+    *lo = l; *hi = h;
+}
+
+// the table block of one quality, as the device gets it (checked against bracket_of by the tests)
+extern "C" void emu_device_qt(int quality, float *out /* kDeviceQtFloats */) { pixo_host::fill_device_qt((uint8_t)quality, out); }
+extern "C" void emu_bracket_of(int q, float *lo, float *hi) { bracket_of(q, lo, hi); }
 
 // quantiser fast path vs the reference formula on caller-provided values (for the
 // dense/exhaustive sweeps in tests/test_quant_exact.py)
@@ -85,13 +106,15 @@ extern "C" long emu_quant_mismatches(const float *x, long n, int qlo, int qhi)
 {
     long bad = 0;
     for (int q = qlo; q <= qhi; q++) {
-        const float fq = (float)q, rcp = 1.0f / fq;
-        float rr[8], qq[8], xx[8];
-        for (int i = 0; i < 8; i++) { rr[i] = rcp; qq[i] = fq; }
+        const float fq = (float)q;
+        float lo, hi;
+        bracket_of(q, &lo, &hi);
+        float rl[8], rh[8], qq[8], xx[8];
+        for (int i = 0; i < 8; i++) { rl[i] = lo; rh[i] = hi; qq[i] = fq; }
         for (long i = 0; i + 8 <= n; i += 8) {
             uint32_t out[4];
             for (int k = 0; k < 8; k++) xx[k] = x[i + k];
-            quant_row8(xx, rr, as_qtab(qq), 1.0f, out);
+            quant_row8(xx, rl, rh, as_qtab(qq), 1.0f, out);
             for (int k = 0; k < 8; k++) {
                 int16_t got = (int16_t)(out[k >> 1] >> (16 * (k & 1)));
                 float want = roundf(xx[k] / fq);
@@ -106,12 +129,13 @@ extern "C" long emu_quant_mismatches(const float *x, long n, int qlo, int qhi)
 // how many unflagged inputs would have been wrong (must be 0).
 extern "C" void emu_quant_fastpath_audit(const float *x, long n, int q, long *flagged, long *wrong_unflagged)
 {
-    const float fq = (float)q, rcp = 1.0f / fq;
+    const float fq = (float)q;
+    float lo, hi;
+    bracket_of(q, &lo, &hi);
     long f = 0, w = 0;
     for (long i = 0; i < n; i++) {
-        float r = x[i] * rcp;
-        float sm = r + kRoundMagic;
-        bool risky = quant_risk(r, sm) >= 0.5f; // the kernel's own test (jpeg_tile.h)
+        float sm;
+        const bool risky = quant_bracket(x[i], lo, hi, &sm) != 0; // the kernel's own test (jpeg_tile.h)
         int16_t got = (int16_t)(__builtin_bit_cast(uint32_t, sm) & 0xFFFF);
         if (risky) f++;
         else if ((float)got != roundf(x[i] / fq)) w++;
@@ -124,7 +148,9 @@ extern "C" void emu_quant_fastpath_audit(const float *x, long n, int q, long *fl
 extern "C" void emu_quant_exhaustive(int q, uint32_t lo_bits, uint32_t hi_bits, long *flagged,
                                      long *wrong_unflagged, long *wrong_final)
 {
-    const float fq = (float)q, rcp = 1.0f / fq;
+    const float fq = (float)q;
+    float lo, hi;
+    bracket_of(q, &lo, &hi);
     long f = 0, w = 0, wf = 0;
     for (int sign = 0; sign < 2; sign++)
         for (uint64_t b = lo_bits; b <= hi_bits; b++) {
@@ -132,9 +158,8 @@ extern "C" void emu_quant_exhaustive(int q, uint32_t lo_bits, uint32_t hi_bits, 
             float x;
             memcpy(&x, &u, 4);
             float want = roundf(x / fq);
-            float r = x * rcp;
-            float sm = r + kRoundMagic;
-            bool risky = quant_risk(r, sm) >= 0.5f; // the kernel's own test (jpeg_tile.h)
+            float sm;
+            const bool risky = quant_bracket(x, lo, hi, &sm) != 0; // the kernel's own test (jpeg_tile.h)
             float got = (float)(int16_t)(__builtin_bit_cast(uint32_t, sm) & 0xFFFF);
             if (risky) { f++; got = want; }
             else if (got != want) w++;

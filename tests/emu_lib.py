@@ -45,7 +45,7 @@ def coeffs(pixels, w, h, color_type=2, subsampling=1, quality=80, allow_fast=Tru
     y = np.full((yb, 64), -32768, np.int16)
     cb = np.full((max(cbn, 1), 64), -32768, np.int16)
     cr = np.full((max(cbn, 1), 64), -32768, np.int16)
-    stats = (C.c_long * 2)()
+    stats = (C.c_long * 3)()
     lib().emu_jpeg_coeffs(px.ctypes.data, w, h, color_type, subsampling, quality, y.ctypes.data,
                           cb.ctypes.data, cr.ctypes.data, int(allow_fast), stats, wave_order)
-    return y, cb[:cbn], cr[:cbn], (stats[0], stats[1])
+    return y, cb[:cbn], cr[:cbn], (stats[0], stats[1], stats[2])

@@ -2,7 +2,7 @@
 lane (tests/emu: producer wavefront, then the three consumer wavefronts), against the oracle — bit-exact.  This exercises on CPU everything about the
 kernel except the hardware itself: lane->pixel/block mapping, LDS layout and swizzles, packed
 u16 colour math, DCT operation order, the quantiser fast path and its exact fallback, edge
-replication, the interior/edge tile split and the dword-aligned fast loads."""
+replication, the interior/edge tile split, the dword-aligned loads and the funnel loads of unaligned rows."""
 import numpy as np
 import pytest
 
@@ -34,11 +34,37 @@ def test_emulated_kernel_on_golden_inputs(c):
 def test_interior_and_edge_tiles(w, h, mode):
     ct, ss = mode
     px = synth.noise_gray(w, h, w + h) if ct == 0 else synth.noise(w, h, w + h)
-    vector, gather = _same(px, w, h, ct, ss, 80)
+    aligned, gather, funnel = _same(px, w, h, ct, ss, 80)
     row_bytes = w * (3 if ct == 2 else 1)
-    # dword-aligned rows (and at least one whole group) -> every tile via vector loads,
-    # including the right/bottom edge tiles; otherwise every tile via the byte gather
-    assert (vector > 0 and gather == 0) if (row_bytes % 4 == 0 and w >= 4) else (vector == 0 and gather > 0)
+    # dword-aligned rows -> every tile via the 12-byte loads, including the right/bottom edge tiles;
+    # other rows -> aligned dwords + alignbyte (funnel); the byte gather only below one 4-pixel group
+    if row_bytes % 4 == 0 and w >= 4:
+        assert aligned > 0 and gather == 0 and funnel == 0
+    else:
+        assert aligned == 0 and gather == 0 and funnel > 0
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (2, 9), (3, 17), (3, 3)])
+@pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])
+def test_images_narrower_than_a_group_take_the_byte_gather(w, h, mode):
+    ct, ss = mode
+    px = synth.noise_gray(w, h, 5) if ct == 0 else synth.noise(w, h, 5)
+    aligned, gather, funnel = _same(px, w, h, ct, ss, 80)
+    assert gather > 0 and aligned == 0 and funnel == 0
+
+
+@pytest.mark.parametrize("w", [4, 5, 6, 7, 9, 510, 511, 513, 514, 515, 1021, 1022, 1023, 1025, 1366, 1918])
+@pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])
+def test_funnel_loads_every_width_residue_and_base_alignment(w, mode):
+    """Rows that are not dword aligned: aligned dwords + v_alignbyte, the partial last group (1-3 valid
+    pixels) rebuilt in registers, every base alignment; also forced on aligned images."""
+    ct, ss = mode
+    h = 19
+    px = synth.noise_gray(w, h, w) if ct == 0 else synth.noise(w, h, w)
+    for mis in (0, 1, 2, 3):
+        st = _same(px, w, h, ct, ss, 80, misalign=mis)
+        assert st[1] == 0
+    _same(px, w, h, ct, ss, 80, allow_fast=2)
 
 
 @pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])
@@ -49,7 +75,7 @@ def test_unaligned_base_and_forced_gather_path_agree(mode):
     _same(px, w, h, ct, ss, 75, allow_fast=False)
     for mis in (1, 2, 3):
         st = _same(px, w, h, ct, ss, 75, misalign=mis)
-        assert st[0] == 0  # misaligned base must never take the dword path
+        assert st[0] == 0 and st[2] > 0  # misaligned base: never the 12-byte loads, always the funnel
 
 
 @pytest.mark.parametrize("q", [1, 5, 20, 49, 50, 77, 90, 100])

@@ -124,14 +124,17 @@ int pixo_hip_jpeg_entropy_encode(const int16_t *y, const int16_t *cb, const int1
  * with options->optimize_huffman the count_block statistics (src/jpeg/mod.rs:826-860) are
  * gathered on the GPU as well, and restart intervals (src/jpeg/mod.rs:1423-1445) are handled as
  * byte-aligned segments with RSTn markers.  Only the finished file crosses PCIe.  Synchronous;
- * the pointers must belong to the current HIP device and their producers must have completed. */
+ * the pointers must belong to the current HIP device; work enqueued on the producer stream
+ * (pixo_hip_set_producer_stream) is waited for on the device.  The tuple is coded as it is:
+ * options->trellis_quant with progressive is refused (the tuple entries cannot re-quantise). */
 int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const void *d_cr,
                                         const pixo_jpeg_options *options, uint8_t **out,
                                         size_t *out_len);
 
 /* pixo::jpeg::encode for pixels that are already in HBM (options->width * height * bpp bytes,
  * tightly packed): coefficient kernel + device entropy stage, result in malloc'd host memory.
- * Same validation and errors as pixo_hip_jpeg_encode. */
+ * Same validation and errors as pixo_hip_jpeg_encode.  Ordered after the producer stream (see
+ * pixo_hip_set_producer_stream), like every entry point below that takes device pixels. */
 int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *options,
                                 uint8_t **out, size_t *out_len);
 
@@ -199,10 +202,80 @@ int pixo_hip_band(uint32_t width, uint32_t height, uint8_t color_type, uint8_t s
                   uint32_t parts, uint32_t index, uint32_t *row_begin, uint32_t *row_end,
                   size_t *y_offset, size_t *y_blocks, size_t *c_offset, size_t *c_blocks);
 
+/* ---- one image across several GPUs: per-band entropy coding + splice ------------ */
+
+/* The reference has no device boundary; its seam for this is the scan loop's only cross-MCU state: the
+ * three DC predictors and the bit writer's position (src/jpeg/mod.rs:1417-1419, src/bits.rs:216-272).
+ * A band (pixo_hip_band) is coded on its own GPU given (1) the last DCs of the band above and (2) the
+ * bit offset at which it starts in the scan; what the GPUs exchange is 3 x i16 and one u64 per band
+ * (plus, for optimised tables, 536 counters per band, summed) — never coefficients.  The exchange is the
+ * caller's: torch.distributed all_gather between processes (pixo_amd/sharded.py), shared memory between
+ * threads (pixo_hip_jpeg_encode_multi below).  Baseline scans without restart markers; other option sets
+ * are refused by _create (gather the coefficient bands and use pixo_hip_jpeg_entropy_encode_device).
+ * Calls on one encoder must not overlap; different encoders may run on different threads at once. */
+#define PIXO_HIP_COUNT_WORDS 536 /* [class 0 luminance, 1 chrominance][12 DC categories + 256 AC run/size symbols] */
+typedef struct pixo_hip_band_encoder pixo_hip_band_encoder;
+
+/* Band `index` of `parts` of the image `options` describes, on HIP device `device`. */
+int pixo_hip_band_encoder_create(const pixo_jpeg_options *options, uint32_t parts, uint32_t index, int device,
+                                 pixo_hip_band_encoder **out);
+void pixo_hip_band_encoder_destroy(pixo_hip_band_encoder *encoder);
+/* pixel rows [*row_begin, *row_end) of the image belong to this band (equal: more bands than MCU rows) */
+int pixo_hip_band_encoder_rows(const pixo_hip_band_encoder *encoder, uint32_t *row_begin, uint32_t *row_end);
+/* Step 1: the coefficient kernel over the band's rows (`band_pixels`: those rows only, tightly packed; a
+ * host pointer — copied over this GPU's own PCIe link — or, with on_device != 0, a pointer on the
+ * encoder's device).  last_dc: quantised DC of the band's last Y, Cb, Cr block — what the NEXT band's
+ * first blocks predict from (encode_block's return value, src/jpeg/huffman.rs:480).  A band without
+ * rows reports zeros; its successor takes the DCs of the nearest band above that has rows. */
+int pixo_hip_band_encoder_coeffs(pixo_hip_band_encoder *encoder, const void *band_pixels, int on_device,
+                                 int16_t last_dc[3]);
+/* Step 2, only with optimize_huffman: the band's count_block statistics (src/jpeg/mod.rs:826-860) given its
+ * predecessors' DCs.  The tables are built from the element-wise SUM over all bands. */
+int pixo_hip_band_encoder_count(pixo_hip_band_encoder *encoder, const int16_t prev_dc[3],
+                                uint64_t counts[PIXO_HIP_COUNT_WORDS]);
+/* Step 3: the band's length in bits (total_counts: the summed statistics, NULL without optimize_huffman). */
+int pixo_hip_band_encoder_lengths(pixo_hip_band_encoder *encoder, const int16_t prev_dc[3],
+                                  const uint64_t *total_counts, uint64_t *bits);
+/* Step 4: Huffman-code, pack and 0xFF-stuff the band at `bit_offset` (the sum of the bits of all bands
+ * before it) -> *piece (pixo_hip_free): 16 header bytes { head_nbits, head_bits, tail_nbits, tail_bits,
+ * 0,0,0,0, body_len u64 LE } + body.  head = the band's first (8 - bit_offset % 8) % 8 bits (they share a
+ * byte with the band before), body = its whole bytes, stuffed, tail = the bits left over. */
+int pixo_hip_band_encoder_pack(pixo_hip_band_encoder *encoder, uint64_t bit_offset, uint8_t **piece,
+                               size_t *piece_len);
+/* Host: headers (src/jpeg/mod.rs:449-648) + the pieces of all bands in order, shared bytes merged and
+ * stuffed, final 1-padding (BitWriterMsb::flush) + EOI = the file pixo::jpeg::encode writes. */
+int pixo_hip_jpeg_splice(const pixo_jpeg_options *options, const uint64_t *total_counts,
+                         const uint8_t *const *pieces, const size_t *piece_lens, uint32_t parts,
+                         uint8_t **out, size_t *out_len);
+/* Host twins of steps 2-4 for a band whose coefficient tuple is in host memory (`band_rows` pixel rows;
+ * what pixo_hip_jpeg_entropy_encode is to the whole tuple). */
+int pixo_hip_jpeg_band_count_host(const int16_t *y, const int16_t *cb, const int16_t *cr,
+                                  const pixo_jpeg_options *options, uint32_t band_rows, const int16_t prev_dc[3],
+                                  uint64_t counts[PIXO_HIP_COUNT_WORDS]);
+int pixo_hip_jpeg_band_bits_host(const int16_t *y, const int16_t *cb, const int16_t *cr,
+                                 const pixo_jpeg_options *options, uint32_t band_rows, const int16_t prev_dc[3],
+                                 const uint64_t *total_counts, uint64_t *bits);
+int pixo_hip_jpeg_band_piece_host(const int16_t *y, const int16_t *cb, const int16_t *cr,
+                                  const pixo_jpeg_options *options, uint32_t band_rows, const int16_t prev_dc[3],
+                                  const uint64_t *total_counts, uint64_t bit_offset, uint8_t **piece,
+                                  size_t *piece_len);
+
+/* pixo::jpeg::encode on `n_devices` GPUs of this process (config 4: one 16384 x 16384 image over 8
+ * MI355X): band k of n_devices goes to devices[k] (a device may appear more than once); every band's
+ * rows are read straight from `data` over that GPU's PCIe link by its own host thread, the exchanges
+ * above happen in shared memory, the calling thread splices.  Byte-identical to pixo_hip_jpeg_encode.
+ * Progressive scans and restart markers are coded by devices[0] alone. */
+int pixo_hip_jpeg_encode_multi(const uint8_t *data, size_t data_len, const pixo_jpeg_options *options,
+                               const int *devices, uint32_t n_devices, uint8_t **out, size_t *out_len);
+
 /* ---- runtime ----------------------------------------------------------------------- */
 
 int pixo_hip_device_count(void);            /* 0 when no GPU / no driver              */
-int pixo_hip_set_device(int device);        /* device for the calling thread's context */
+int pixo_hip_set_device(int device);        /* device for the calling thread's context (host-pointer entries) */
+/* Entry points that take DEVICE pointers run on the library's own stream, ordered after everything the
+ * caller has enqueued so far on `stream` (a hipStream_t of the calling thread's current device; default:
+ * the NULL stream, which is also PyTorch's default stream).  Per thread. */
+int pixo_hip_set_producer_stream(void *stream);
 /* Releases the calling thread's device and pinned buffers (they only grow while the thread lives and are
  * released by themselves when it ends): for a long-lived thread after an unusually large image. */
 int pixo_hip_trim(void);

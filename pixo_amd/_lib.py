@@ -29,8 +29,12 @@ SYMBOLS = [
     "pixo_hip_jpeg_coeffs_device", "pixo_hip_jpeg_entropy_encode", "pixo_hip_jpeg_entropy_encode_device",
     "pixo_hip_jpeg_encode_device", "pixo_hip_jpeg_encode_device_into", "pixo_hip_jpeg_encode_batch_device", "pixo_hip_png_filter", "pixo_hip_png_filter_device", "pixo_hip_png_filter_async",
     "pixo_hip_png_adler32_from_row_sums", "pixo_hip_band",
-    "pixo_hip_device_count", "pixo_hip_set_device", "pixo_hip_trim", "pixo_hip_free", "pixo_hip_last_error",
-    "pixo_hip_version",
+    "pixo_hip_band_encoder_create", "pixo_hip_band_encoder_destroy", "pixo_hip_band_encoder_rows",
+    "pixo_hip_band_encoder_coeffs", "pixo_hip_band_encoder_count", "pixo_hip_band_encoder_lengths",
+    "pixo_hip_band_encoder_pack", "pixo_hip_jpeg_splice", "pixo_hip_jpeg_band_count_host",
+    "pixo_hip_jpeg_band_bits_host", "pixo_hip_jpeg_band_piece_host", "pixo_hip_jpeg_encode_multi",
+    "pixo_hip_device_count", "pixo_hip_set_device", "pixo_hip_set_producer_stream", "pixo_hip_trim", "pixo_hip_free",
+    "pixo_hip_last_error", "pixo_hip_version",
 ]
 
 _lib = None
@@ -94,6 +98,22 @@ def load():
                                              C.c_void_p, C.POINTER(C.c_uint32)]
     L.pixo_hip_band.argtypes = [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint32, C.c_uint32,
                                 C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), szp, szp, szp, szp]
+    i16p, u64p = C.POINTER(C.c_int16), C.POINTER(C.c_uint64)
+    L.pixo_hip_band_encoder_create.argtypes = [optp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+    L.pixo_hip_band_encoder_destroy.argtypes = [C.c_void_p]
+    L.pixo_hip_band_encoder_destroy.restype = None
+    L.pixo_hip_band_encoder_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.pixo_hip_band_encoder_coeffs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, i16p]
+    L.pixo_hip_band_encoder_count.argtypes = [C.c_void_p, i16p, u64p]
+    L.pixo_hip_band_encoder_lengths.argtypes = [C.c_void_p, i16p, u64p, u64p]
+    L.pixo_hip_band_encoder_pack.argtypes = [C.c_void_p, C.c_uint64, u8pp, szp]
+    L.pixo_hip_jpeg_splice.argtypes = [optp, u64p, C.POINTER(C.c_void_p), szp, C.c_uint32, u8pp, szp]
+    L.pixo_hip_jpeg_band_count_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, optp, C.c_uint32, i16p, u64p]
+    L.pixo_hip_jpeg_band_bits_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, optp, C.c_uint32, i16p, u64p, u64p]
+    L.pixo_hip_jpeg_band_piece_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, optp, C.c_uint32, i16p, u64p, C.c_uint64,
+                                                u8pp, szp]
+    L.pixo_hip_jpeg_encode_multi.argtypes = [C.c_void_p, C.c_size_t, optp, C.POINTER(C.c_int), C.c_uint32, u8pp, szp]
+    L.pixo_hip_set_producer_stream.argtypes = [C.c_void_p]
     L.pixo_hip_device_count.restype = C.c_int
     L.pixo_hip_set_device.argtypes = [C.c_int]
     L.pixo_hip_free.argtypes = [C.c_void_p]

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <algorithm>
 #include <atomic>
@@ -67,13 +69,26 @@ int device_tables(int device, const float **out)
     return PIXO_OK;
 }
 
+// Makes a context's device current for the calling thread for the duration of an entry point and gives
+// the caller its own device back afterwards (torch and other HIP users share the thread).
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device); else prev = -1;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
 // ---- thread-local execution context --------------------------------------------------
-std::atomic<bool> g_exiting{false};
-std::once_flag g_exit_hook;
 struct Context {
     int device = 0;
     bool ready = false;
     hipStream_t stream = nullptr;
+    hipEvent_t producer_done = nullptr; // orders the context's stream after the caller's (device-pointer entries)
     void *d_px = nullptr;   size_t px_cap = 0;
     void *d_coef = nullptr; size_t coef_cap = 0;
     void *h_coef = nullptr; size_t hcoef_cap = 0; // pinned
@@ -119,9 +134,10 @@ struct Context {
         if (e != hipSuccess || n == 0)
             return fail(PIXO_ERR_COMPRESSION,
                         "Compression error: no MI355X/HIP device available (pixo_hip has no CPU fallback)");
-        HIP_TRY(hipSetDevice(device));
+        if (device < 0 || device >= n) return fail(PIXO_ERR_COMPRESSION, "Compression error: no HIP device " + std::to_string(device));
+        DeviceScope on(device);
+        if (on.err != hipSuccess) return hip_fail(on.err, "hipSetDevice");
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        std::call_once(g_exit_hook, [] { std::atexit([] { g_exiting.store(true); }); });
         ready = true;
         return PIXO_OK;
     }
@@ -154,17 +170,13 @@ struct Context {
         }
         return PIXO_OK;
     }
-    // A thread that ends gives its buffers back (servers with a thread per request would otherwise run the
-    // device out of memory).  Not during process exit: an atexit handler registered at first use — it runs
-    // before the HIP runtime's own, which were registered when the runtime was loaded — raises a flag, and
-    // from then on everything is left to the dying process.
-    ~Context();
     void release(); // everything back to the driver; the context starts over at its next use
 };
 void Context::release()
 {
     if (!ready) return;
-    if (hipSetDevice(device) != hipSuccess) return;
+    DeviceScope on(device);
+    if (on.err != hipSuccess) return;
     if (stream) (void)hipStreamSynchronize(stream);
     Buf *bufs[] = {&e_tables, &e_hist, &e_len, &e_off, &e_tmp, &e_totals, &e_stream, &e_tile_ff, &e_tile_base, &e_out, &e_seg_bytes,
                    &e_seg_off, &p_in, &p_out, &p_sums, &p_scratch, &t_raw, &t_trail, &g_flags, &g_rank, &g_by_rank};
@@ -179,27 +191,86 @@ void Context::release()
     if (h_totals) (void)hipHostFree(h_totals);
     if (h_file) (void)hipHostFree(h_file);
     if (stream) (void)hipStreamDestroy(stream);
+    if (producer_done) (void)hipEventDestroy(producer_done);
+    producer_done = nullptr;
     d_px = d_coef = h_coef = nullptr; px_cap = coef_cap = hcoef_cap = 0;
     h_sums = nullptr; hsums_cap = 0; h_totals = nullptr; h_file = nullptr; hfile_cap = 0;
     stream = nullptr; ready = false;
 }
-Context::~Context()
+
+// Contexts outlive the threads that use them.  A thread's context must not be torn down by a
+// thread-local destructor: those run when the HIP runtime's own per-thread state may already be gone
+// (it was created later, so it is destroyed earlier), and — for threads still winding down while main()
+// returns — concurrently with the runtime's atexit teardown; hipFree / hipHostFree from there crashed
+// (SIGSEGV in amd::Context::svmFree with 16 threads ending at once, profiles/r02_thread_exit_crash.txt).
+// So a thread that ends only parks its context here (a mutex and a vector push, no HIP call); the next
+// thread that needs one adopts it — buffers, stream and all, which also spares a server with a thread per
+// request every hipMalloc — and live threads free what is left over beyond a small reserve.  Nothing is
+// destroyed at process exit (the pool is leaked on purpose).
+constexpr size_t kIdleContextsKept = 16;
+struct ContextPool {
+    std::mutex m;
+    std::vector<Context *> idle;
+    Context *take(int device)
+    {
+        std::vector<Context *> excess;
+        Context *c = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(m);
+            for (size_t i = idle.size(); i-- > 0;)
+                if (idle[i]->device == device) { c = idle[i]; idle.erase(idle.begin() + static_cast<long>(i)); break; }
+            if (!c && !idle.empty()) { c = idle.back(); idle.pop_back(); }
+            while (idle.size() > kIdleContextsKept) { excess.push_back(idle.front()); idle.erase(idle.begin()); }
+        }
+        for (Context *x : excess) { x->release(); delete x; } // (a live thread: HIP calls are fine here)
+        if (!c) c = new Context;
+        if (c->device != device) { c->release(); c->device = device; } // rebind: drop the other device's buffers
+        return c;
+    }
+    void give(Context *c) // no HIP calls: may run in a thread-local destructor
+    {
+        std::lock_guard<std::mutex> lock(m);
+        idle.push_back(c);
+    }
+    void drain() // frees every parked context (pixo_hip_trim)
+    {
+        std::vector<Context *> all;
+        {
+            std::lock_guard<std::mutex> lock(m);
+            all.swap(idle);
+        }
+        for (Context *x : all) { x->release(); delete x; }
+    }
+};
+ContextPool &pool()
 {
-    // (PIXO_HIP_KEEP_ON_THREAD_EXIT=1: diagnostics — leave a finished thread's buffers to the process)
-    static const bool keep = std::getenv("PIXO_HIP_KEEP_ON_THREAD_EXIT") != nullptr;
-    if (!keep && !g_exiting.load()) release();
+    static ContextPool *p = new ContextPool;
+    return *p;
 }
-thread_local Context t_ctx;
+struct ThreadSlot {
+    Context *c = nullptr;
+    int device = 0; // pixo_hip_set_device
+    ~ThreadSlot() { if (c) pool().give(c); }
+};
+thread_local ThreadSlot t_slot;
+Context &thread_context()
+{
+    if (!t_slot.c) t_slot.c = pool().take(t_slot.device);
+    return *t_slot.c;
+}
+
+#define PIXO_ON_DEVICE_OF(ctx)                      \
+    DeviceScope device_scope_((ctx).device);        \
+    if (device_scope_.err != hipSuccess) return hip_fail(device_scope_.err, "hipSetDevice")
 
 // Runs the device pipeline for host pixels; on success `*coef` points at pinned host
 // memory holding [y | cb | cr] contiguously.
-int coeffs_to_pinned(const uint8_t *pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g,
+int coeffs_to_pinned(Context &c, const uint8_t *pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g,
                      const int16_t **y, const int16_t **cb, const int16_t **cr)
 {
-    Context &c = t_ctx;
     int rc = c.ensure();
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(c.device));
+    PIXO_ON_DEVICE_OF(c);
     const float *qt_all = nullptr;
     rc = device_tables(c.device, &qt_all);
     if (rc) return rc;
@@ -224,10 +295,9 @@ int coeffs_to_pinned(const uint8_t *pixels, const pixo_jpeg_options &o, const pi
 }
 
 // Device pixels -> device coefficient tuple inside the context's buffer.
-int coeffs_on_device(const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
+int coeffs_on_device(Context &c, const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
                      int16_t **dy, int16_t **dcb, int16_t **dcr)
 {
-    Context &c = t_ctx;
     const float *qt_all = nullptr;
     int rc = device_tables(c.device, &qt_all);
     if (rc) return rc;
@@ -260,6 +330,175 @@ struct Stopwatch { // PIXO_HIP_TRACE=1: per-phase wall times of the device entro
     }
 };
 
+// ---- the device entropy stage, in the steps a caller may need to interleave with exchanges ------------
+// One pass of jpeg_entropy.hip over a coefficient tuple in HBM: a whole image, a batch of images (one
+// byte-aligned segment each), or a BAND of a larger image (predictors seeded from the band
+// above, packed at the band's bit offset modulo 8, no final padding).
+struct ScanJob {
+    pixo_dev::ScanArgs a;
+    uint64_t n = 0, nseg = 0;
+    size_t tmp_blocks = 0, tmp_segs = 0, tmp_tiles = 0;
+    pixo_dev::SegmentPlan plan{0, nullptr};
+    pixo_host::HuffSet h;
+    uint64_t total_bits = 0;
+    uint64_t nbytes = 0;     // bytes of the packed stream that get stuffed (a band: its whole bytes only)
+    uint64_t scan_bytes = 0; // ... after stuffing, in c.e_out
+    bool band = false;
+    int head_bits = 0;       // band: how many of its first bits share a byte with the band before
+};
+
+// Geometry of the pass and every buffer whose size does not depend on the data.
+int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+               const pixo_host::Geometry &g, uint32_t batch, const int16_t *band_seed_dc)
+{
+    namespace pd = pixo_dev;
+    j.n = (g.y_blocks + 2 * g.c_blocks) * batch;
+    pd::ScanArgs &a = j.a;
+    a.y = dy; a.cb = dcb; a.cr = dcr;
+    a.mode = g.gray ? 0 : (g.s420 ? 2 : 1);
+    a.nblocks = j.n;
+    a.blocks_per_mcu = g.gray ? 1 : (g.s420 ? 6 : 3);
+    a.marker_bytes = 2;
+    a.restart = (!band_seed_dc && scan_has_restart_markers(o, g)) ? o.restart_interval : 0;
+    a.seed_dc[0] = a.seed_dc[1] = a.seed_dc[2] = 0;
+    a.bit_base = 0; a.pad_last = 1;
+    j.band = band_seed_dc != nullptr;
+    if (j.band) {
+        for (int i = 0; i < 3; ++i) a.seed_dc[i] = band_seed_dc[i];
+        a.pad_last = 0;
+    }
+    j.nseg = a.restart ? (g.units + a.restart - 1) / a.restart : 0;
+    if (batch > 1) { // one segment per image, no marker between them
+        a.restart = static_cast<uint32_t>(g.units);
+        a.marker_bytes = 0;
+        j.nseg = batch;
+    }
+    HIP_TRY(c.e_tables.reserve(pixo_host::kScanTableWords * 4));
+    HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
+    HIP_TRY(c.e_len.reserve((j.n ? j.n : 1) * 4));
+    HIP_TRY(c.e_off.reserve((j.n ? j.n : 1) * 8));
+    // scratch of the three prefix sums (blocks, restart segments, 0xFF tiles), reserved before any launch:
+    // a block has at most 1665 bits, so the packed stream has at most n * 209 + 3 * nseg bytes
+    j.tmp_blocks = pd::scan_tile_count(j.n) + 1; j.tmp_segs = pd::scan_tile_count(j.nseg ? j.nseg : 1) + 1;
+    j.tmp_tiles = pd::scan_tile_count(pd::stuff_tile_count(j.n * 209 + 3 * j.nseg + 8)) + 1;
+    HIP_TRY(c.e_tmp.reserve((j.tmp_blocks + j.tmp_segs + j.tmp_tiles) * 8));
+    HIP_TRY(c.e_totals.reserve(16));
+    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 16, hipHostMallocDefault));
+    a.tables = c.e_tables.as<uint32_t>();
+    return PIXO_OK;
+}
+
+void split_counts(const uint64_t counts[pixo_host::kScanTableWords], uint64_t dc[2][12], uint64_t ac[2][256])
+{
+    for (int cls = 0; cls < 2; ++cls) {
+        std::memcpy(dc[cls], counts + cls * 268, sizeof dc[cls]);
+        std::memcpy(ac[cls], counts + cls * 268 + 12, sizeof ac[cls]);
+    }
+}
+
+// count_block statistics of the pass (src/jpeg/mod.rs:826-860) gathered on the device: [class][12 DC + 256 AC].
+int scan_count(Context &c, ScanJob &j, hipStream_t stream, uint64_t counts[pixo_host::kScanTableWords])
+{
+    HIP_TRY(hipMemsetAsync(c.e_hist.p, 0, pixo_host::kScanTableWords * 8, stream));
+    if (j.n) HIP_TRY(pixo_dev::launch_scan_count(j.a, c.e_hist.as<unsigned long long>(), stream));
+    HIP_TRY(hipMemcpyAsync(counts, c.e_hist.p, pixo_host::kScanTableWords * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return PIXO_OK;
+}
+
+// Tables (standard; optimised from `counts`, or from this pass's own statistics when counts == null),
+// block bit lengths and their prefix sum: afterwards j.total_bits is known (one read-back).
+int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
+                 const uint64_t *counts)
+{
+    namespace pd = pixo_dev;
+    if (o.optimize_huffman) { // table construction on the host, exactly like optimized_from_counts
+        uint64_t own[pixo_host::kScanTableWords];
+        if (!counts) {
+            int rc = scan_count(c, j, stream, own);
+            if (rc) return rc;
+            counts = own;
+        }
+        uint64_t dc[2][12], ac[2][256];
+        split_counts(counts, dc, ac);
+        j.h = pixo_host::HuffSet::optimized(dc, ac, !g.gray);
+    } else {
+        j.h = pixo_host::HuffSet::standard();
+    }
+    uint32_t packed[pixo_host::kScanTableWords];
+    pixo_host::pack_scan_tables(j.h, packed);
+    HIP_TRY(hipMemcpyAsync(c.e_tables.p, packed, sizeof packed, hipMemcpyHostToDevice, stream));
+    if (j.n) HIP_TRY(pd::launch_scan_lengths(j.a, c.e_len.as<uint32_t>(), stream));
+    HIP_TRY(pd::launch_exclusive_scan(c.e_len.as<uint32_t>(), j.n, c.e_off.as<uint64_t>(), c.e_tmp.as<uint64_t>(),
+                                      c.e_totals.as<uint64_t>(), stream));
+    if (j.nseg) { // restart markers: byte-aligned segments, each followed by two marker bytes
+        HIP_TRY(c.e_seg_bytes.reserve(j.nseg * 8));
+        HIP_TRY(c.e_seg_off.reserve(j.nseg * 8));
+        HIP_TRY(pd::launch_segment_sizes(j.a, c.e_off.as<uint64_t>(), c.e_totals.as<uint64_t>(), j.nseg, c.e_seg_bytes.as<uint32_t>(), stream));
+        HIP_TRY(pd::launch_exclusive_scan(c.e_seg_bytes.as<uint32_t>(), j.nseg, c.e_seg_off.as<uint64_t>(),
+                                          c.e_tmp.as<uint64_t>() + j.tmp_blocks, c.e_totals.as<uint64_t>() + 1, stream));
+        j.plan.nsegments = j.nseg;
+        j.plan.seg_byte_off = c.e_seg_off.as<uint64_t>();
+    }
+    HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_totals.p, 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream)); // `packed` may go out of scope after this, too
+    j.total_bits = c.h_totals[0];
+    j.nbytes = j.nseg ? c.h_totals[1] : (j.total_bits + 7) / 8; // bytes of the packed (unstuffed) stream
+    return PIXO_OK;
+}
+
+// Pack, 0xFF census, stuffing (+ restart markers): afterwards c.e_out holds j.scan_bytes finished bytes
+// (one read-back).  A band starting at bit `band_bit_offset` of the scan is packed so that its whole bytes
+// begin at word 1 of the stream: its first (8 - offset % 8) % 8 bits end word 0, the bits left over after the
+// last whole byte follow it; both are returned unstuffed in head / tail (value, right-aligned).
+int scan_pack(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offset = 0, uint32_t *head = nullptr,
+              int *tail_bits = nullptr, uint32_t *tail = nullptr)
+{
+    namespace pd = pixo_dev;
+    uint64_t stream_bits = j.total_bits;
+    uint32_t word_off = 0;
+    if (j.band) {
+        const uint64_t want = (8 - (band_bit_offset & 7)) & 7;
+        j.head_bits = static_cast<int>(j.total_bits < want ? j.total_bits : want);
+        j.a.bit_base = 32 - static_cast<uint32_t>(j.head_bits);
+        j.nbytes = (j.total_bits - j.head_bits) / 8;
+        stream_bits = j.a.bit_base + j.total_bits;
+        word_off = 1;
+    }
+    const size_t stream_bytes = j.band ? ((stream_bits + 31) / 32 + 2) * 4 : (j.nbytes / 4 + 2) * 4;
+    HIP_TRY(c.e_stream.reserve(stream_bytes));
+    HIP_TRY(hipMemsetAsync(c.e_stream.p, 0, stream_bytes, stream));
+    if (j.n) HIP_TRY(pd::launch_scan_pack(j.a, c.e_off.as<uint64_t>(), j.total_bits, j.nseg ? &j.plan : nullptr, c.e_stream.as<uint32_t>(), stream));
+    const uint32_t *body = c.e_stream.as<uint32_t>() + word_off;
+    const size_t tiles = pd::stuff_tile_count(j.nbytes);
+    HIP_TRY(c.e_tile_ff.reserve((tiles ? tiles : 1) * 4));
+    HIP_TRY(c.e_tile_base.reserve((tiles ? tiles : 1) * 8));
+    if (tiles) HIP_TRY(pd::launch_ff_tile_count(body, j.nbytes, c.e_tile_ff.as<uint32_t>(), stream));
+    HIP_TRY(pd::launch_exclusive_scan(c.e_tile_ff.as<uint32_t>(), tiles, c.e_tile_base.as<uint64_t>(),
+                                      c.e_tmp.as<uint64_t>() + j.tmp_blocks + j.tmp_segs, c.e_totals.as<uint64_t>() + 1, stream));
+    HIP_TRY(hipMemcpyAsync(c.h_totals + 1, c.e_totals.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
+    uint32_t edge[2] = {0, 0}; // band: word 0 (head bits) and the word holding the tail bits
+    if (j.band) {
+        HIP_TRY(hipMemcpyAsync(&edge[0], c.e_stream.p, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&edge[1], c.e_stream.as<uint32_t>() + 1 + j.nbytes / 4, 4, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    j.scan_bytes = j.nbytes + c.h_totals[1];
+    HIP_TRY(c.e_out.reserve(j.scan_bytes ? j.scan_bytes : 1));
+    if (tiles) HIP_TRY(pd::launch_stuff(body, j.nbytes, c.e_tile_base.as<uint64_t>(), c.e_out.as<uint8_t>(), stream));
+    if (j.nseg) HIP_TRY(pd::launch_restart_markers(j.a, c.e_off.as<uint64_t>(), j.plan, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
+                                                   c.e_out.as<uint8_t>(), stream));
+    if (j.band) {
+        const int t = static_cast<int>((j.total_bits - j.head_bits) % 8);
+        *head = j.head_bits ? (edge[0] & ((1u << j.head_bits) - 1u)) : 0u;
+        *tail_bits = t;
+        // the tail bits are the top bits of stream byte nbytes (MSB-first bytes inside big-endian words)
+        const uint32_t byte = (edge[1] >> (24 - 8 * static_cast<uint32_t>(j.nbytes % 4))) & 0xFFu;
+        *tail = t ? (byte >> (8 - t)) : 0u;
+    }
+    return PIXO_OK;
+}
+
 // Device coefficient tuple -> whole file in the context's PINNED host buffer (headers written by
 // the host, entropy-coded segment by the kernels of jpeg_entropy.hip and copied straight behind
 // them).  Pinned on purpose: a device-to-host copy into fresh pageable memory makes the runtime
@@ -268,115 +507,33 @@ struct Stopwatch { // PIXO_HIP_TRACE=1: per-phase wall times of the device entro
 // every image is a byte-aligned segment of ONE packed stream.  Then *file = headers (once) followed by
 // all the entropy-coded segments, and image_starts[i] (batch + 1 entries) are their offsets behind the
 // headers; no EOI is written.
-int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                              const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len,
                              uint32_t batch = 1, std::vector<uint64_t> *image_starts = nullptr, size_t *header_len = nullptr,
                              uint8_t *dest = nullptr, size_t dest_cap = 0)
 { // dest != null: the file goes straight into the caller's storage (no pinned intermediate); when it does not
   // fit, *file_len says how much is needed and nothing is copied (PIXO_ERR_BUFFER_TOO_SMALL)
-    Stopwatch sw;
-    Context &c = t_ctx;
     namespace pd = pixo_dev;
-    const uint64_t n = (g.y_blocks + 2 * g.c_blocks) * batch;
-    pd::ScanArgs a;
-    a.y = dy; a.cb = dcb; a.cr = dcr;
-    a.mode = g.gray ? 0 : (g.s420 ? 2 : 1);
-    a.nblocks = n;
-    a.blocks_per_mcu = g.gray ? 1 : (g.s420 ? 6 : 3);
-    a.marker_bytes = 2;
-    a.restart = scan_has_restart_markers(o, g) ? o.restart_interval : 0;
-    uint64_t nseg = a.restart ? (g.units + a.restart - 1) / a.restart : 0;
-    if (batch > 1) { // one segment per image, no marker between them
-        a.restart = static_cast<uint32_t>(g.units);
-        a.marker_bytes = 0;
-        nseg = batch;
-    }
-    HIP_TRY(c.e_tables.reserve(pixo_host::kScanTableWords * 4));
-    HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
-    HIP_TRY(c.e_len.reserve(n * 4));
-    HIP_TRY(c.e_off.reserve(n * 8));
-    // scratch of the three prefix sums (blocks, restart segments, 0xFF tiles), reserved before any launch:
-    // a block has at most 1665 bits, so the packed stream has at most n * 209 + 3 * nseg bytes
-    const size_t tmp_blocks = pd::scan_tile_count(n) + 1, tmp_segs = pd::scan_tile_count(nseg ? nseg : 1) + 1;
-    const size_t tmp_tiles = pd::scan_tile_count(pd::stuff_tile_count(n * 209 + 3 * nseg + 8)) + 1;
-    HIP_TRY(c.e_tmp.reserve((tmp_blocks + tmp_segs + tmp_tiles) * 8));
-    HIP_TRY(c.e_totals.reserve(16));
-    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 16, hipHostMallocDefault));
-    a.tables = c.e_tables.as<uint32_t>();
+    Stopwatch sw;
+    ScanJob j;
+    int rc = scan_begin(c, j, dy, dcb, dcr, o, g, batch, nullptr);
+    if (rc) return rc;
     sw.lap("  reserve");
-
-    pixo_host::HuffSet h;
-    if (o.optimize_huffman) { // count_block statistics on the device, table construction on the host
-        HIP_TRY(hipMemsetAsync(c.e_hist.p, 0, pixo_host::kScanTableWords * 8, stream));
-        HIP_TRY(pd::launch_scan_count(a, c.e_hist.as<unsigned long long>(), stream));
-        uint64_t counts[pixo_host::kScanTableWords];
-        HIP_TRY(hipMemcpyAsync(counts, c.e_hist.p, sizeof counts, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        uint64_t dc[2][12], ac[2][256];
-        for (int cls = 0; cls < 2; ++cls) {
-            std::memcpy(dc[cls], counts + cls * 268, sizeof dc[cls]);
-            std::memcpy(ac[cls], counts + cls * 268 + 12, sizeof ac[cls]);
-        }
-        h = pixo_host::HuffSet::optimized(dc, ac, !g.gray);
-    } else {
-        h = pixo_host::HuffSet::standard();
-    }
-    uint32_t packed[pixo_host::kScanTableWords];
-    pixo_host::pack_scan_tables(h, packed);
-    HIP_TRY(hipMemcpyAsync(c.e_tables.p, packed, sizeof packed, hipMemcpyHostToDevice, stream));
-    sw.lap("  tables h2d");
-
-    // 1-2: block bit lengths, their prefix sum
-    HIP_TRY(pd::launch_scan_lengths(a, c.e_len.as<uint32_t>(), stream));
-    HIP_TRY(pd::launch_exclusive_scan(c.e_len.as<uint32_t>(), n, c.e_off.as<uint64_t>(), c.e_tmp.as<uint64_t>(),
-                                      c.e_totals.as<uint64_t>(), stream));
-    pd::SegmentPlan plan{0, nullptr};
-    if (nseg) { // restart markers: byte-aligned segments, each followed by two marker bytes
-        HIP_TRY(c.e_seg_bytes.reserve(nseg * 8));
-        HIP_TRY(c.e_seg_off.reserve(nseg * 8));
-        HIP_TRY(pd::launch_segment_sizes(a, c.e_off.as<uint64_t>(), c.e_totals.as<uint64_t>(), nseg, c.e_seg_bytes.as<uint32_t>(), stream));
-        HIP_TRY(pd::launch_exclusive_scan(c.e_seg_bytes.as<uint32_t>(), nseg, c.e_seg_off.as<uint64_t>(),
-                                          c.e_tmp.as<uint64_t>() + tmp_blocks, c.e_totals.as<uint64_t>() + 1, stream));
-        plan.nsegments = nseg;
-        plan.seg_byte_off = c.e_seg_off.as<uint64_t>();
-    }
-    HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_totals.p, 16, hipMemcpyDeviceToHost, stream));
-    sw.lap("  launches");
-    HIP_TRY(hipStreamSynchronize(stream)); // `packed` may go out of scope after this, too
+    if ((rc = scan_lengths(c, j, o, g, stream, nullptr))) return rc;
     sw.lap("tables+lengths+scan");
-    const uint64_t total_bits = c.h_totals[0];
-    const uint64_t nbytes = nseg ? c.h_totals[1] : (total_bits + 7) / 8; // bytes of the packed (unstuffed) stream
-    // 3: pack
-    const size_t stream_bytes = (nbytes / 4 + 2) * 4;
-    HIP_TRY(c.e_stream.reserve(stream_bytes));
-    HIP_TRY(hipMemsetAsync(c.e_stream.p, 0, stream_bytes, stream));
-    HIP_TRY(pd::launch_scan_pack(a, c.e_off.as<uint64_t>(), total_bits, nseg ? &plan : nullptr, c.e_stream.as<uint32_t>(), stream));
-    // 4: 0xFF census
-    const size_t tiles = pd::stuff_tile_count(nbytes);
-    HIP_TRY(c.e_tile_ff.reserve(tiles * 4));
-    HIP_TRY(c.e_tile_base.reserve(tiles * 8));
-    HIP_TRY(pd::launch_ff_tile_count(c.e_stream.as<uint32_t>(), nbytes, c.e_tile_ff.as<uint32_t>(), stream));
-    HIP_TRY(pd::launch_exclusive_scan(c.e_tile_ff.as<uint32_t>(), tiles, c.e_tile_base.as<uint64_t>(),
-                                      c.e_tmp.as<uint64_t>() + tmp_blocks + tmp_segs, c.e_totals.as<uint64_t>() + 1, stream));
-    HIP_TRY(hipMemcpyAsync(c.h_totals + 1, c.e_totals.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    if ((rc = scan_pack(c, j, stream))) return rc;
     sw.lap("memset+pack+ff census");
-    const uint64_t scan_bytes = nbytes + c.h_totals[1];
-    // 5: stuff, then straight into the caller's vector behind the headers
-    HIP_TRY(c.e_out.reserve(scan_bytes));
-    HIP_TRY(pd::launch_stuff(c.e_stream.as<uint32_t>(), nbytes, c.e_tile_base.as<uint64_t>(), c.e_out.as<uint8_t>(), stream));
-    if (nseg) HIP_TRY(pd::launch_restart_markers(a, c.e_off.as<uint64_t>(), plan, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
-                                                 c.e_out.as<uint8_t>(), stream));
+    const uint64_t scan_bytes = j.scan_bytes;
     if (batch > 1) { // where every image's segment begins in the stuffed stream (reuses the seg_bytes buffer: 8 B/entry)
-        HIP_TRY(c.e_seg_bytes.reserve(nseg * 8));
-        HIP_TRY(pd::launch_segment_out_offsets(plan, nbytes, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
+        HIP_TRY(c.e_seg_bytes.reserve(j.nseg * 8));
+        HIP_TRY(pd::launch_segment_out_offsets(j.plan, j.nbytes, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
                                                c.e_seg_bytes.as<uint64_t>(), stream));
         image_starts->assign(batch + 1, 0);
-        HIP_TRY(hipMemcpyAsync(image_starts->data(), c.e_seg_bytes.p, nseg * 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(image_starts->data(), c.e_seg_bytes.p, j.nseg * 8, hipMemcpyDeviceToHost, stream));
         (*image_starts)[batch] = scan_bytes;
     }
     std::vector<uint8_t> head;
-    pixo_host::file_headers(head, o, h);
+    pixo_host::file_headers(head, o, j.h);
     const size_t hdr = head.size(), total = hdr + scan_bytes + 2;
     uint8_t *buf = dest;
     if (dest) {
@@ -385,8 +542,7 @@ int device_entropy_to_pinned(const int16_t *dy, const int16_t *dcb, const int16_
             return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(total) + " bytes");
         }
     } else {
-        int rc = c.reserve_hfile(total);
-        if (rc) return rc;
+        if ((rc = c.reserve_hfile(total))) return rc;
         buf = c.h_file;
     }
     std::memcpy(buf, head.data(), hdr);
@@ -444,12 +600,12 @@ int deliver(const uint8_t *file, size_t n, uint8_t **out, size_t *out_len)
     return PIXO_OK;
 }
 
-int device_entropy_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+int device_entropy_to_malloc(Context &c, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                              const pixo_host::Geometry &g, hipStream_t stream, uint8_t **out_buf, size_t *out_len)
 {
     const uint8_t *file = nullptr;
     size_t n = 0;
-    int rc = device_entropy_to_pinned(dy, dcb, dcr, o, g, stream, &file, &n);
+    int rc = device_entropy_to_pinned(c, dy, dcb, dcr, o, g, stream, &file, &n);
     if (rc) return rc;
     return deliver(file, n, out_buf, out_len);
 }
@@ -566,6 +722,7 @@ int huffman_for_tuple(const int16_t *dy, const int16_t *dcb, const int16_t *dcr,
     a.blocks_per_mcu = g.gray ? 1 : (g.s420 ? 6 : 3);
     a.marker_bytes = 2;
     a.restart = scan_has_restart_markers(o, g) ? o.restart_interval : 0;
+    a.seed_dc[0] = a.seed_dc[1] = a.seed_dc[2] = 0; a.bit_base = 0; a.pad_last = 1;
     HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
     HIP_TRY(hipMemsetAsync(c.e_hist.p, 0, pixo_host::kScanTableWords * 8, c.stream));
     HIP_TRY(pd::launch_scan_count(a, c.e_hist.as<unsigned long long>(), c.stream));
@@ -573,10 +730,7 @@ int huffman_for_tuple(const int16_t *dy, const int16_t *dcb, const int16_t *dcr,
     HIP_TRY(hipMemcpyAsync(counts, c.e_hist.p, sizeof counts, hipMemcpyDeviceToHost, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));
     uint64_t dc[2][12], ac[2][256];
-    for (int cls = 0; cls < 2; ++cls) {
-        std::memcpy(dc[cls], counts + cls * 268, sizeof dc[cls]);
-        std::memcpy(ac[cls], counts + cls * 268 + 12, sizeof ac[cls]);
-    }
+    split_counts(counts, dc, ac);
     h = pixo_host::HuffSet::optimized(dc, ac, !g.gray);
     return PIXO_OK;
 }
@@ -601,7 +755,7 @@ int progressive_to_vector(const void *d_pixels, const pixo_jpeg_options &o, cons
     const float *qt = qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats;
     pixo_host::HuffSet h;
     const bool need_plain = o.optimize_huffman || !o.trellis_quant;
-    if (need_plain && (rc = coeffs_on_device(d_pixels, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
+    if (need_plain && (rc = coeffs_on_device(c, d_pixels, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
     if ((rc = huffman_for_tuple(dy, dcb, dcr, o, g, c, h))) return rc;
     const size_t blocks = g.y_blocks + 2 * g.c_blocks, coef_bytes = blocks * 128;
     if (o.trellis_quant) {
@@ -646,18 +800,19 @@ int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options
     std::string msg;
     int rc = pixo_host::validate(o, true, data_len, msg);
     if (rc) return fail(rc, msg);
+    if (!data) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'data'");
     const pixo_host::Geometry g = pixo_host::geometry(o.width, o.height, o.color_type, o.subsampling);
+    Context &c = thread_context();
     if (!o.progressive && std::getenv("PIXO_HIP_HOST_ENTROPY")) { // (experiments: the host twin of the entropy stage)
         const int16_t *y, *cb, *cr;
-        if ((rc = coeffs_to_pinned(data, o, g, &y, &cb, &cr))) return rc;
+        if ((rc = coeffs_to_pinned(c, data, o, g, &y, &cb, &cr))) return rc;
         pixo_host::encode_file(y, cb, cr, o, spill);
         *file = spill.data();
         *file_len = spill.size();
         return PIXO_OK;
     }
-    Context &c = t_ctx;
     if ((rc = c.ensure())) return rc;
-    HIP_TRY(hipSetDevice(c.device));
+    PIXO_ON_DEVICE_OF(c);
     const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
     if ((rc = c.reserve_px((px_bytes + 15) & ~size_t{15}))) return rc;
     HIP_TRY(hipMemcpyAsync(c.d_px, data, px_bytes, hipMemcpyHostToDevice, c.stream));
@@ -668,14 +823,21 @@ int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options
         return PIXO_OK;
     }
     int16_t *dy, *dcb, *dcr;
-    if ((rc = coeffs_on_device(c.d_px, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
-    return device_entropy_to_pinned(dy, dcb, dcr, o, g, c.stream, file, file_len);
+    if ((rc = coeffs_on_device(c, c.d_px, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
+    return device_entropy_to_pinned(c, dy, dcb, dcr, o, g, c.stream, file, file_len);
 }
 
 } // namespace
 
 // A null pointer where the contract wants an object is a caller bug the Rust API cannot express; the C ABI
 // answers it with an error instead of a crash.
+namespace {
+int fail_tuple_trellis()
+{ // trellis quantisation happens between the transform and the tuple (src/jpeg/mod.rs:932-976): a tuple entry cannot apply it
+    return fail(PIXO_ERR_COMPRESSION, "Compression error: trellis_quant needs the pixels: quantise the tuple with the trellis "
+                                      "quantiser first and clear the flag, or use an entry point that takes pixels");
+}
+} // namespace
 #define PIXO_REQUIRE(p) do { if (!(p)) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument '" #p "'"); } while (0)
 
 extern "C" {
@@ -683,6 +845,7 @@ extern "C" {
 void pixo_jpeg_options_from_preset(pixo_jpeg_options *o, uint32_t width, uint32_t height,
                                    uint8_t quality, uint8_t preset)
 { // jpeg/mod.rs:162-216
+    if (!o) return;
     std::memset(o, 0, sizeof *o);
     o->width = width; o->height = height; o->color_type = PIXO_RGB; o->quality = quality;
     o->subsampling = PIXO_S444;
@@ -710,6 +873,7 @@ int pixo_hip_jpeg_encode_into(uint8_t *output, size_t capacity, const uint8_t *d
 {
     PIXO_REQUIRE(options);
     PIXO_REQUIRE(out_len);
+    if (capacity && !output) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'output'");
     std::vector<uint8_t> spill;
     const uint8_t *file = nullptr;
     size_t n = 0;
@@ -769,8 +933,11 @@ int pixo_hip_jpeg_coeffs(const uint8_t *pixels, uint32_t width, uint32_t height,
         return fail(PIXO_ERR_INVALID_DATA_LENGTH,
                     "Invalid pixel data length: expected " + std::to_string(g.y_blocks) + " bytes, got " +
                         std::to_string(y_blocks));
+    PIXO_REQUIRE(pixels);
+    PIXO_REQUIRE(y);
+    if (g.c_blocks && (!cb || !cr)) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'cb'/'cr'");
     const int16_t *hy, *hcb, *hcr;
-    if ((rc = coeffs_to_pinned(pixels, o, g, &hy, &hcb, &hcr))) return rc;
+    if ((rc = coeffs_to_pinned(thread_context(), pixels, o, g, &hy, &hcb, &hcr))) return rc;
     std::memcpy(y, hy, g.y_blocks * 128);
     if (g.c_blocks) {
         std::memcpy(cb, hcb, g.c_blocks * 128);
@@ -790,6 +957,9 @@ int pixo_hip_jpeg_coeffs_device(const void *d_pixels, uint32_t width, uint32_t h
     int rc = pixo_host::validate(o, false, 0, msg);
     if (rc) return fail(rc, msg);
     if (batch == 0 || batch > 65535) return fail(PIXO_ERR_COMPRESSION, "Compression error: batch must be 1..65535");
+    PIXO_REQUIRE(d_pixels);
+    PIXO_REQUIRE(d_y);
+    if (color_type != PIXO_GRAY && (!d_cb || !d_cr)) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'd_cb'/'d_cr'");
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     const float *qt_all = nullptr;
@@ -810,22 +980,37 @@ int pixo_hip_jpeg_entropy_encode(const int16_t *y, const int16_t *cb, const int1
     std::string msg;
     int rc = pixo_host::validate(*options, false, 0, msg);
     if (rc) return fail(rc, msg);
+    if (options->progressive && options->trellis_quant) return fail_tuple_trellis();
+    PIXO_REQUIRE(y);
     std::vector<uint8_t> v;
     pixo_host::encode_file(y, cb, cr, *options, v);
     return hand_over(v, out, out_len);
 }
 
 namespace {
-// binds the thread-local context to the HIP device that is current for the caller
+// Device-pointer entry points run on the context's own stream.  What the caller enqueued before the call
+// — on the stream it named with pixo_hip_set_producer_stream, by default the NULL stream — is ordered
+// in front of it with an event (no host synchronisation).
+thread_local hipStream_t t_producer = nullptr;
+int order_after_producer(Context &c)
+{
+    if (!c.producer_done) HIP_TRY(hipEventCreateWithFlags(&c.producer_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c.producer_done, t_producer));
+    HIP_TRY(hipStreamWaitEvent(c.stream, c.producer_done, 0));
+    return PIXO_OK;
+}
+
+// binds the thread's context to the HIP device that is current for the caller
 int context_on_current_device(Context **out)
 {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (t_ctx.ready && t_ctx.device != dev) (void)pixo_hip_set_device(dev);
-    t_ctx.device = dev;
-    int rc = t_ctx.ensure();
+    if (t_slot.device != dev) (void)pixo_hip_set_device(dev);
+    Context &c = thread_context();
+    int rc = c.ensure();
     if (rc) return rc;
-    *out = &t_ctx;
+    if ((rc = order_after_producer(c))) return rc;
+    *out = &c;
     return PIXO_OK;
 }
 
@@ -833,7 +1018,7 @@ int device_tuple_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_t 
                            const pixo_host::Geometry &g, Context &c, uint8_t **out, size_t *out_len)
 {
     if (!std::getenv("PIXO_HIP_HOST_ENTROPY")) {
-        if (!o.progressive) return device_entropy_to_malloc(dy, dcb, dcr, o, g, c.stream, out, out_len);
+        if (!o.progressive) return device_entropy_to_malloc(c, dy, dcb, dcr, o, g, c.stream, out, out_len);
         pixo_host::HuffSet h;
         int rc = huffman_for_tuple(dy, dcb, dcr, o, g, c, h);
         if (rc) return rc;
@@ -868,6 +1053,8 @@ int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const
     std::string msg;
     int rc = pixo_host::validate(*options, false, 0, msg);
     if (rc) return fail(rc, msg);
+    if (options->progressive && options->trellis_quant) return fail_tuple_trellis();
+    PIXO_REQUIRE(d_y);
     Context *c = nullptr;
     if ((rc = context_on_current_device(&c))) return rc;
     const pixo_host::Geometry g = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
@@ -878,6 +1065,7 @@ int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const
 int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *options, uint8_t **out, size_t *out_len)
 {
     PIXO_REQUIRE(options);
+    PIXO_REQUIRE(d_pixels);
     PIXO_REQUIRE(out);
     PIXO_REQUIRE(out_len);
     std::string msg;
@@ -892,7 +1080,7 @@ int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *o
         return hand_over(v, out, out_len);
     }
     int16_t *dy, *dcb, *dcr;
-    if ((rc = coeffs_on_device(d_pixels, *options, g, c->stream, &dy, &dcb, &dcr))) return rc;
+    if ((rc = coeffs_on_device(*c, d_pixels, *options, g, c->stream, &dy, &dcb, &dcr))) return rc;
     return device_tuple_to_malloc(dy, dcb, dcr, *options, g, *c, out, out_len);
 }
 
@@ -921,11 +1109,11 @@ int pixo_hip_jpeg_encode_device_into(const void *d_pixels, const pixo_jpeg_optio
         return PIXO_OK;
     }
     int16_t *dy, *dcb, *dcr;
-    if ((rc = coeffs_on_device(d_pixels, *options, g, c->stream, &dy, &dcb, &dcr))) return rc;
+    if ((rc = coeffs_on_device(*c, d_pixels, *options, g, c->stream, &dy, &dcb, &dcr))) return rc;
     const uint8_t *file = nullptr;
     // (a null output with capacity 0 is a size query)
     static uint8_t nowhere;
-    return device_entropy_to_pinned(dy, dcb, dcr, *options, g, c->stream, &file, out_len, 1, nullptr, nullptr,
+    return device_entropy_to_pinned(*c, dy, dcb, dcr, *options, g, c->stream, &file, out_len, 1, nullptr, nullptr,
                                     output ? output : &nowhere, output ? capacity : 0);
 }
 
@@ -996,9 +1184,10 @@ int pixo_hip_png_filter(const uint8_t *data, size_t data_len, uint32_t width, ui
                                                       " bytes, got " + std::to_string(data_len));
     if (out_capacity < out_bytes)
         return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(out_bytes) + " bytes");
-    Context &c = t_ctx;
+    if (!data || !out || !adler32) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument");
+    Context &c = thread_context();
     if ((rc = c.ensure())) return rc;
-    HIP_TRY(hipSetDevice(c.device));
+    PIXO_ON_DEVICE_OF(c);
     HIP_TRY(c.p_in.reserve((in_bytes + 15) & ~size_t{15}));
     HIP_TRY(c.p_out.reserve(out_bytes));
     HIP_TRY(hipMemcpyAsync(c.p_in.p, data, in_bytes, hipMemcpyHostToDevice, c.stream));
@@ -1036,6 +1225,9 @@ int pixo_hip_png_filter_device(const void *d_data, uint32_t width, uint32_t heig
     bool seq = false;
     int rc = png_plan(width, height, bytes_per_pixel, strategy, flags, &run, &seq);
     if (rc) return rc;
+    PIXO_REQUIRE(d_data);
+    PIXO_REQUIRE(d_out);
+    PIXO_REQUIRE(adler32);
     Context *c = nullptr;
     if ((rc = context_on_current_device(&c))) return rc;
     return png_filter_on_device(*c, d_data, width, height, bytes_per_pixel, run, seq, d_out, adler32);
@@ -1067,7 +1259,7 @@ int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_opti
     if (batch == 1 || o.optimize_huffman || scan_has_restart_markers(o, g) || px_bytes % 4 != 0) {
         for (uint32_t i = 0; i < batch; ++i) {
             int16_t *dy, *dcb, *dcr;
-            if ((rc = coeffs_on_device(static_cast<const uint8_t *>(d_pixels) + i * px_bytes, o, g, c->stream, &dy, &dcb, &dcr))) return release(rc);
+            if ((rc = coeffs_on_device(*c, static_cast<const uint8_t *>(d_pixels) + i * px_bytes, o, g, c->stream, &dy, &dcb, &dcr))) return release(rc);
             if ((rc = device_tuple_to_malloc(dy, dcb, dcr, o, g, *c, &files[i], &lens[i]))) return release(rc);
         }
         return PIXO_OK;
@@ -1083,7 +1275,7 @@ int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_opti
     const uint8_t *blob = nullptr;
     size_t blob_len = 0, hdr = 0;
     std::vector<uint64_t> starts;
-    if ((rc = device_entropy_to_pinned(dy, dcb, dcr, o, g, c->stream, &blob, &blob_len, batch, &starts, &hdr))) return rc;
+    if ((rc = device_entropy_to_pinned(*c, dy, dcb, dcr, o, g, c->stream, &blob, &blob_len, batch, &starts, &hdr))) return rc;
     for (uint32_t i = 0; i < batch; ++i) {
         lens[i] = hdr + static_cast<size_t>(starts[i + 1] - starts[i]) + 2;
         files[i] = static_cast<uint8_t *>(std::malloc(lens[i]));
@@ -1102,6 +1294,381 @@ int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_opti
         }
     });
     return PIXO_OK;
+}
+
+// ======================================================================================================
+// One image across several GPUs: per-band entropy coding + splice
+// ======================================================================================================
+struct pixo_hip_band_encoder {
+    pixo_jpeg_options image{}, band{};   // the whole image / the same options with the band's height
+    pixo_host::Geometry g{};             // of the band
+    uint32_t parts = 1, index = 0, rows = 0, row_begin = 0;
+    Context *c = nullptr;                // adopted from the pool for the encoder's lifetime
+    int16_t *dy = nullptr, *dcb = nullptr, *dcr = nullptr;
+    ScanJob job;
+    int stage = 0;                       // 0 created, 1 coefficients done, 2 lengths done
+    int16_t last_dc[3] = {0, 0, 0};
+};
+
+namespace {
+int band_rows(const pixo_jpeg_options &o, uint32_t parts, uint32_t index, uint32_t *row_begin, uint32_t *row_end)
+{
+    size_t yo, yb, co, cb;
+    return pixo_hip_band(o.width, o.height, o.color_type, o.subsampling, parts, index, row_begin, row_end, &yo, &yb, &co, &cb);
+}
+bool band_codable(const pixo_jpeg_options &o, const pixo_host::Geometry &g)
+{ // what a band encoder can do on its own: one uninterrupted baseline scan
+    return !o.progressive && !scan_has_restart_markers(o, g);
+}
+} // namespace
+
+int pixo_hip_band_encoder_create(const pixo_jpeg_options *options, uint32_t parts, uint32_t index, int device,
+                                 pixo_hip_band_encoder **out)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(out);
+    *out = nullptr;
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if (parts == 0 || index >= parts) return fail(PIXO_ERR_COMPRESSION, "Compression error: bad band index");
+    const pixo_host::Geometry whole = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
+    if (!band_codable(*options, whole))
+        return fail(PIXO_ERR_COMPRESSION, "Compression error: bands are entropy-coded on their own only for baseline scans without "
+                                          "restart markers (gather the coefficient bands and use pixo_hip_jpeg_entropy_encode_device)");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n)
+        return fail(PIXO_ERR_COMPRESSION, "Compression error: no HIP device " + std::to_string(device));
+    std::unique_ptr<pixo_hip_band_encoder> e(new pixo_hip_band_encoder);
+    e->image = *options; e->parts = parts; e->index = index;
+    uint32_t r0 = 0, r1 = 0;
+    if ((rc = band_rows(*options, parts, index, &r0, &r1))) return rc;
+    e->row_begin = r0; e->rows = r1 - r0;
+    e->band = *options;
+    e->band.height = e->rows ? e->rows : 1;
+    e->band.has_restart_interval = 0; e->band.restart_interval = 0;
+    e->g = pixo_host::geometry(e->band.width, e->band.height, e->band.color_type, e->band.subsampling);
+    if (e->rows == 0) { e->g.y_blocks = e->g.c_blocks = e->g.units = 0; e->g.units_y = 0; }
+    e->c = pool().take(device);
+    if ((rc = e->c->ensure())) { pool().give(e->c); return rc; }
+    *out = e.release();
+    return PIXO_OK;
+}
+
+void pixo_hip_band_encoder_destroy(pixo_hip_band_encoder *e)
+{
+    if (!e) return;
+    if (e->c) {
+        if (e->c->ready && e->c->stream) { DeviceScope on(e->c->device); (void)hipStreamSynchronize(e->c->stream); }
+        pool().give(e->c);
+    }
+    delete e;
+}
+
+int pixo_hip_band_encoder_rows(const pixo_hip_band_encoder *e, uint32_t *row_begin, uint32_t *row_end)
+{
+    PIXO_REQUIRE(e);
+    PIXO_REQUIRE(row_begin);
+    PIXO_REQUIRE(row_end);
+    *row_begin = e->row_begin; *row_end = e->row_begin + e->rows;
+    return PIXO_OK;
+}
+
+int pixo_hip_band_encoder_coeffs(pixo_hip_band_encoder *e, const void *band_pixels, int on_device, int16_t last_dc[3])
+{
+    PIXO_REQUIRE(e);
+    PIXO_REQUIRE(last_dc);
+    Context &c = *e->c;
+    PIXO_ON_DEVICE_OF(c);
+    e->stage = 1;
+    last_dc[0] = last_dc[1] = last_dc[2] = 0;
+    if (e->rows == 0) return PIXO_OK; // more bands than MCU rows: nothing to do, the caller forwards the DCs above
+    PIXO_REQUIRE(band_pixels);
+    int rc;
+    const void *d_px = band_pixels;
+    if (!on_device) { // the band's rows come over this GPU's own PCIe link
+        const size_t px_bytes = static_cast<size_t>(e->band.width) * e->rows * (e->g.gray ? 1 : 3);
+        if ((rc = c.reserve_px((px_bytes + 15) & ~size_t{15}))) return rc;
+        HIP_TRY(hipMemcpyAsync(c.d_px, band_pixels, px_bytes, hipMemcpyHostToDevice, c.stream));
+        d_px = c.d_px;
+    } else if ((rc = order_after_producer(c))) {
+        return rc;
+    }
+    if ((rc = coeffs_on_device(c, d_px, e->band, e->g, c.stream, &e->dy, &e->dcb, &e->dcr))) return rc;
+    // the DCs the next band predicts from: first coefficient of the last block of every plane
+    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 16, hipHostMallocDefault));
+    int16_t *h = reinterpret_cast<int16_t *>(c.h_totals);
+    HIP_TRY(hipMemcpyAsync(h, e->dy + (e->g.y_blocks - 1) * 64, 2, hipMemcpyDeviceToHost, c.stream));
+    if (e->g.c_blocks) {
+        HIP_TRY(hipMemcpyAsync(h + 1, e->dcb + (e->g.c_blocks - 1) * 64, 2, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipMemcpyAsync(h + 2, e->dcr + (e->g.c_blocks - 1) * 64, 2, hipMemcpyDeviceToHost, c.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    e->last_dc[0] = h[0];
+    e->last_dc[1] = e->g.c_blocks ? h[1] : 0;
+    e->last_dc[2] = e->g.c_blocks ? h[2] : 0;
+    for (int i = 0; i < 3; ++i) last_dc[i] = e->last_dc[i];
+    return PIXO_OK;
+}
+
+int pixo_hip_band_encoder_count(pixo_hip_band_encoder *e, const int16_t prev_dc[3], uint64_t counts[PIXO_HIP_COUNT_WORDS])
+{
+    PIXO_REQUIRE(e);
+    PIXO_REQUIRE(prev_dc);
+    PIXO_REQUIRE(counts);
+    if (e->stage < 1) return fail(PIXO_ERR_COMPRESSION, "Compression error: band encoder: coefficients first");
+    Context &c = *e->c;
+    PIXO_ON_DEVICE_OF(c);
+    std::memset(counts, 0, sizeof(uint64_t) * PIXO_HIP_COUNT_WORDS);
+    if (e->rows == 0) return PIXO_OK;
+    int rc = scan_begin(c, e->job, e->dy, e->dcb, e->dcr, e->band, e->g, 1, prev_dc);
+    if (rc) return rc;
+    return scan_count(c, e->job, c.stream, counts);
+}
+
+int pixo_hip_band_encoder_lengths(pixo_hip_band_encoder *e, const int16_t prev_dc[3], const uint64_t *total_counts, uint64_t *bits)
+{
+    PIXO_REQUIRE(e);
+    PIXO_REQUIRE(prev_dc);
+    PIXO_REQUIRE(bits);
+    if (e->stage < 1) return fail(PIXO_ERR_COMPRESSION, "Compression error: band encoder: coefficients first");
+    if (e->image.optimize_huffman && !total_counts)
+        return fail(PIXO_ERR_COMPRESSION, "Compression error: band encoder: optimised tables need the statistics of all bands");
+    Context &c = *e->c;
+    PIXO_ON_DEVICE_OF(c);
+    int rc = scan_begin(c, e->job, e->dy, e->dcb, e->dcr, e->band, e->g, 1, prev_dc);
+    if (rc) return rc;
+    if ((rc = scan_lengths(c, e->job, e->image, e->g, c.stream, total_counts))) return rc;
+    *bits = e->job.total_bits;
+    e->stage = 2;
+    return PIXO_OK;
+}
+
+int pixo_hip_band_encoder_pack(pixo_hip_band_encoder *e, uint64_t bit_offset, uint8_t **piece, size_t *piece_len)
+{
+    PIXO_REQUIRE(e);
+    PIXO_REQUIRE(piece);
+    PIXO_REQUIRE(piece_len);
+    if (e->stage < 2) return fail(PIXO_ERR_COMPRESSION, "Compression error: band encoder: lengths first");
+    Context &c = *e->c;
+    PIXO_ON_DEVICE_OF(c);
+    uint32_t head = 0, tail = 0;
+    int tail_bits = 0;
+    int rc = scan_pack(c, e->job, c.stream, bit_offset, &head, &tail_bits, &tail);
+    if (rc) return rc;
+    const size_t body = e->job.scan_bytes, total = pixo_host::kPieceHeader + body;
+    uint8_t *p = static_cast<uint8_t *>(std::malloc(total));
+    if (!p) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
+    std::vector<uint8_t> hdr;
+    pixo_host::make_piece(hdr, e->job.head_bits, head, tail_bits, tail, nullptr, 0);
+    std::memcpy(p, hdr.data(), pixo_host::kPieceHeader);
+    for (int i = 0; i < 8; ++i) p[8 + i] = static_cast<uint8_t>(static_cast<uint64_t>(body) >> (8 * i));
+    if (body) { // pinned bounce (a device-to-host copy into fresh pageable memory pins the pages first)
+        if ((rc = c.reserve_hfile(body))) { std::free(p); return rc; }
+        HIP_TRY(hipMemcpyAsync(c.h_file, c.e_out.p, body, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        big_copy(p + pixo_host::kPieceHeader, c.h_file, body);
+    } else {
+        HIP_TRY(hipStreamSynchronize(c.stream));
+    }
+    *piece = p;
+    *piece_len = total;
+    return PIXO_OK;
+}
+
+namespace {
+int tables_for_splice(const pixo_jpeg_options &o, const uint64_t *total_counts, pixo_host::HuffSet &h)
+{
+    h = pixo_host::HuffSet::standard();
+    if (!o.optimize_huffman) return PIXO_OK;
+    if (!total_counts) return fail(PIXO_ERR_COMPRESSION, "Compression error: optimised tables need the statistics of all bands");
+    uint64_t dc[2][12], ac[2][256];
+    split_counts(total_counts, dc, ac);
+    h = pixo_host::HuffSet::optimized(dc, ac, o.color_type != PIXO_GRAY);
+    return PIXO_OK;
+}
+} // namespace
+
+int pixo_hip_jpeg_splice(const pixo_jpeg_options *options, const uint64_t *total_counts, const uint8_t *const *pieces,
+                         const size_t *piece_lens, uint32_t parts, uint8_t **out, size_t *out_len)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(pieces);
+    PIXO_REQUIRE(piece_lens);
+    PIXO_REQUIRE(out);
+    PIXO_REQUIRE(out_len);
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    pixo_host::HuffSet h;
+    if ((rc = tables_for_splice(*options, total_counts, h))) return rc;
+    std::vector<uint8_t> v;
+    if ((rc = pixo_host::splice_file(*options, h, pieces, piece_lens, parts, v, msg))) return fail(rc, msg);
+    return hand_over(v, out, out_len);
+}
+
+// ---- host twins of the band encoder (a band's tuple in host memory) -----------------------------------
+namespace {
+int band_options(const pixo_jpeg_options *options, uint32_t band_rows_, pixo_jpeg_options *band)
+{
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if (band_rows_ == 0 || band_rows_ > options->height) return fail(PIXO_ERR_COMPRESSION, "Compression error: bad band height");
+    *band = *options;
+    band->height = band_rows_;
+    band->has_restart_interval = 0; band->restart_interval = 0;
+    return PIXO_OK;
+}
+} // namespace
+
+int pixo_hip_jpeg_band_count_host(const int16_t *y, const int16_t *cb, const int16_t *cr, const pixo_jpeg_options *options,
+                                  uint32_t band_rows_, const int16_t prev_dc[3], uint64_t counts[PIXO_HIP_COUNT_WORDS])
+{
+    PIXO_REQUIRE(options); PIXO_REQUIRE(y); PIXO_REQUIRE(prev_dc); PIXO_REQUIRE(counts);
+    pixo_jpeg_options band;
+    int rc = band_options(options, band_rows_, &band);
+    if (rc) return rc;
+    uint64_t dc[2][12], ac[2][256];
+    pixo_host::band_histograms(y, cb, cr, band, prev_dc, dc, ac);
+    for (int cls = 0; cls < 2; ++cls) {
+        std::memcpy(counts + cls * 268, dc[cls], sizeof dc[cls]);
+        std::memcpy(counts + cls * 268 + 12, ac[cls], sizeof ac[cls]);
+    }
+    return PIXO_OK;
+}
+
+int pixo_hip_jpeg_band_bits_host(const int16_t *y, const int16_t *cb, const int16_t *cr, const pixo_jpeg_options *options,
+                                 uint32_t band_rows_, const int16_t prev_dc[3], const uint64_t *total_counts, uint64_t *bits)
+{
+    PIXO_REQUIRE(options); PIXO_REQUIRE(y); PIXO_REQUIRE(prev_dc); PIXO_REQUIRE(bits);
+    pixo_jpeg_options band;
+    int rc = band_options(options, band_rows_, &band);
+    if (rc) return rc;
+    pixo_host::HuffSet h;
+    if ((rc = tables_for_splice(*options, total_counts, h))) return rc;
+    *bits = pixo_host::band_bits(y, cb, cr, band, h, prev_dc);
+    return PIXO_OK;
+}
+
+int pixo_hip_jpeg_band_piece_host(const int16_t *y, const int16_t *cb, const int16_t *cr, const pixo_jpeg_options *options,
+                                  uint32_t band_rows_, const int16_t prev_dc[3], const uint64_t *total_counts, uint64_t bit_offset,
+                                  uint8_t **piece, size_t *piece_len)
+{
+    PIXO_REQUIRE(options); PIXO_REQUIRE(y); PIXO_REQUIRE(prev_dc); PIXO_REQUIRE(piece); PIXO_REQUIRE(piece_len);
+    pixo_jpeg_options band;
+    int rc = band_options(options, band_rows_, &band);
+    if (rc) return rc;
+    pixo_host::HuffSet h;
+    if ((rc = tables_for_splice(*options, total_counts, h))) return rc;
+    std::vector<uint8_t> v;
+    pixo_host::band_piece(y, cb, cr, band, h, prev_dc, bit_offset, v);
+    return hand_over(v, piece, piece_len);
+}
+
+// ---- the whole exchange inside one process: one thread per band/device ---------------------------------
+namespace {
+class PhaseBarrier { // every band thread arrives at every phase boundary, also after a failure
+  public:
+    explicit PhaseBarrier(unsigned n) : n_(n) {}
+    void arrive()
+    {
+        std::unique_lock<std::mutex> lock(m_);
+        const unsigned gen = gen_;
+        if (++count_ == n_) { count_ = 0; ++gen_; cv_.notify_all(); }
+        else cv_.wait(lock, [&] { return gen_ != gen; });
+    }
+  private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    unsigned n_, count_ = 0, gen_ = 0;
+};
+} // namespace
+
+int pixo_hip_jpeg_encode_multi(const uint8_t *data, size_t data_len, const pixo_jpeg_options *options, const int *devices,
+                               uint32_t n_devices, uint8_t **out, size_t *out_len)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(out);
+    PIXO_REQUIRE(out_len);
+    PIXO_REQUIRE(devices);
+    const pixo_jpeg_options &o = *options;
+    std::string msg;
+    int rc = pixo_host::validate(o, true, data_len, msg);
+    if (rc) return fail(rc, msg);
+    PIXO_REQUIRE(data);
+    if (n_devices == 0 || n_devices > 1024) return fail(PIXO_ERR_COMPRESSION, "Compression error: need 1..1024 devices");
+    const pixo_host::Geometry whole = pixo_host::geometry(o.width, o.height, o.color_type, o.subsampling);
+    if (!band_codable(o, whole)) { // progressive scans / restart markers: one device codes the whole tuple
+        DeviceScope on(devices[0]);
+        if (on.err != hipSuccess) return hip_fail(on.err, "hipSetDevice");
+        const int keep = t_slot.device;
+        if ((rc = pixo_hip_set_device(devices[0]))) return rc;
+        rc = pixo_hip_jpeg_encode(data, data_len, options, out, out_len);
+        (void)pixo_hip_set_device(keep);
+        return rc;
+    }
+    const uint32_t parts = n_devices;
+    const size_t bpp = whole.gray ? 1 : 3;
+    struct Band {
+        pixo_hip_band_encoder *enc = nullptr;
+        int16_t last_dc[3] = {0, 0, 0}, prev_dc[3] = {0, 0, 0};
+        uint64_t counts[PIXO_HIP_COUNT_WORDS];
+        uint64_t bits = 0;
+        uint8_t *piece = nullptr;
+        size_t piece_len = 0;
+        int rc = PIXO_OK;
+        std::string error;
+    };
+    std::vector<Band> bands(parts);
+    std::vector<uint64_t> total_counts(PIXO_HIP_COUNT_WORDS, 0);
+    PhaseBarrier barrier(parts);
+    std::atomic<bool> failed{false};
+    auto body = [&](unsigned k) {
+        Band &b = bands[k];
+        auto step = [&](int r) { if (r && !b.rc) { b.rc = r; b.error = t_error; failed.store(true); } };
+        step(pixo_hip_band_encoder_create(options, parts, k, devices[k], &b.enc));
+        if (b.enc) {
+            uint32_t r0 = 0, r1 = 0;
+            (void)pixo_hip_band_encoder_rows(b.enc, &r0, &r1);
+            step(pixo_hip_band_encoder_coeffs(b.enc, data + static_cast<size_t>(r0) * o.width * bpp, 0, b.last_dc));
+        }
+        barrier.arrive(); // ---- exchange 1: the DCs at the band boundaries (3 x i16 per band)
+        if (!failed.load()) {
+            for (unsigned j = 0; j < k; ++j) { // predictors = last DCs of the nearest band above that has rows
+                uint32_t r0 = 0, r1 = 0;
+                (void)pixo_hip_band_encoder_rows(bands[j].enc, &r0, &r1);
+                if (r1 > r0) std::memcpy(b.prev_dc, bands[j].last_dc, sizeof b.prev_dc);
+            }
+            if (o.optimize_huffman) step(pixo_hip_band_encoder_count(b.enc, b.prev_dc, b.counts));
+        }
+        if (o.optimize_huffman) {
+            barrier.arrive(); // ---- exchange 1b: symbol statistics, summed (536 x u64 per band)
+            if (k == 0 && !failed.load())
+                for (unsigned j = 0; j < parts; ++j)
+                    for (int i = 0; i < PIXO_HIP_COUNT_WORDS; ++i) total_counts[i] += bands[j].counts[i];
+            barrier.arrive();
+        }
+        if (!failed.load()) step(pixo_hip_band_encoder_lengths(b.enc, b.prev_dc, o.optimize_huffman ? total_counts.data() : nullptr, &b.bits));
+        barrier.arrive(); // ---- exchange 2: bits per band (u64 per band) -> every band's bit offset
+        if (!failed.load()) {
+            uint64_t off = 0;
+            for (unsigned j = 0; j < k; ++j) off += bands[j].bits;
+            step(pixo_hip_band_encoder_pack(b.enc, off, &b.piece, &b.piece_len));
+        }
+        pixo_hip_band_encoder_destroy(b.enc);
+        b.enc = nullptr;
+    };
+    run_on_threads(parts, body);
+    auto cleanup = [&] { for (Band &b : bands) std::free(b.piece); };
+    for (Band &b : bands)
+        if (b.rc) { const int r = b.rc; const std::string e = b.error; cleanup(); return fail(r, e); }
+    std::vector<const uint8_t *> pieces(parts);
+    std::vector<size_t> lens(parts);
+    for (uint32_t k = 0; k < parts; ++k) { pieces[k] = bands[k].piece; lens[k] = bands[k].piece_len; }
+    rc = pixo_hip_jpeg_splice(options, o.optimize_huffman ? total_counts.data() : nullptr, pieces.data(), lens.data(), parts, out, out_len);
+    cleanup();
+    return rc;
 }
 
 int pixo_hip_band(uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling, uint32_t parts,
@@ -1137,15 +1704,27 @@ int pixo_hip_device_count(void)
 
 int pixo_hip_set_device(int device)
 {
-    Context &c = t_ctx;
-    if (c.ready && c.device != device) c.release(); // rebind: drop the old device's buffers and start over
-    c.device = device;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n)
+        return fail(PIXO_ERR_COMPRESSION, "Compression error: no HIP device " + std::to_string(device));
+    if (t_slot.c && t_slot.c->device != device) { // rebind: park the old device's context, adopt one of the new device
+        pool().give(t_slot.c);
+        t_slot.c = nullptr;
+    }
+    t_slot.device = device;
+    return PIXO_OK;
+}
+
+int pixo_hip_set_producer_stream(void *stream)
+{
+    t_producer = static_cast<hipStream_t>(stream);
     return PIXO_OK;
 }
 
 int pixo_hip_trim(void)
 {
-    t_ctx.release();
+    if (t_slot.c) t_slot.c->release();
+    pool().drain();
     return PIXO_OK;
 }
 

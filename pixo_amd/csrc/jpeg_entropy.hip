@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(const ScanArg
         }
         // DC predictor: the previous block of the same component; 0 for the first block of each
         // component in a restart segment (jpeg/mod.rs:1441-1444)
-        int prev_dc = ref.index ? (int)base[(ref.index - 1) * 64] : 0;
+        int prev_dc = ref.index ? (int)base[(ref.index - 1) * 64] : (int)a.seed_dc[ref.comp];
         uint64_t mcu = 0, seg = 0;
         if (a.restart) {
             mcu = s / a.blocks_per_mcu;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(const ScanArg
         } else if (WHAT == WHAT_PACK) {
             PackVisitor v;
             v.tab = tab + cls * kClassSyms;
-            uint64_t pos = off[s], end_bits = total_bits; // end of the stream / of this block's segment
+            uint64_t pos = off[s] + a.bit_base, end_bits = total_bits + a.bit_base; // end of the stream / of this block's segment
             bool last_of_segment = s == a.nblocks - 1;
             if (a.restart) { // the segment starts at its own byte offset; inside it the bits are contiguous
                 const uint64_t first = segment_first(a, seg), next = segment_first(a, seg + 1);
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(const ScanArg
             v.begin(stream, pos);
             walk_block(w, prev_dc, v);
             v.finish();
-            if (last_of_segment) { // BitWriterMsb::flush: pad the last byte with 1-bits (bits.rs:261-272)
+            if (last_of_segment && a.pad_last) { // BitWriterMsb::flush: pad the last byte with 1-bits (bits.rs:261-272)
                 const int n = (int)((8 - (end_bits & 7)) & 7);
                 if (n) v.or_word(end_bits >> 5, ((1u << n) - 1u) << (32 - (int)(end_bits & 31) - n));
             }
@@ -454,6 +454,7 @@ hipError_t launch_exclusive_scan(const uint32_t *d_in, uint64_t n, uint64_t *d_o
                                  hipStream_t s)
 {
     const unsigned tiles = (unsigned)scan_tile_count(n);
+    if (tiles == 0) return hipMemsetAsync(d_total, 0, sizeof(uint64_t), s); // nothing to sum (an empty band)
     hipLaunchKernelGGL(tile_sums_kernel, dim3(tiles), dim3(kScanThreads), 0, s, d_in, n, d_tile_tmp);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(kScanThreads), 0, s, d_tile_tmp, (uint64_t)tiles, d_total);
     if (d_out) hipLaunchKernelGGL(downsweep_kernel, dim3(tiles), dim3(kScanThreads), 0, s, d_in, n, d_tile_tmp, d_out);

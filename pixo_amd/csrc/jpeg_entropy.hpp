@@ -18,6 +18,11 @@ struct ScanArgs {
                                 // or, for a batch, one whole image
     uint32_t blocks_per_mcu;    // 1, 3 or 6
     uint32_t marker_bytes;      // 2 = RSTn marker after every segment but the last; 0 = batch of images
+    // A band of a larger image (one uninterrupted stream, restart == 0):
+    int16_t seed_dc[3];         // DC predictors of the first Y / Cb / Cr block: the last DCs of the band above (0: a whole image)
+    uint32_t bit_base;          // the stream's first bit is bit `bit_base` of d_stream (< 64; 0: a whole image)
+    uint32_t pad_last;          // 1 = the last block pads the final byte with 1-bits (BitWriterMsb::flush); 0 = a band leaves its
+                                //     tail bits for the splice
 };
 
 // Scans with restart markers: a segment is `restart` MCUs; every segment starts on a byte boundary

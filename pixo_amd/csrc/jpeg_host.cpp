@@ -385,10 +385,11 @@ struct Count {
 
 template <class Visitor>
 void walk_scan(Visitor &vis, const int16_t *y, const int16_t *cb, const int16_t *cr,
-               const pixo_jpeg_options &o)
+               const pixo_jpeg_options &o, const int16_t *seed_dc = nullptr)
 {
     const Geometry g = geometry(o.width, o.height, o.color_type, o.subsampling);
-    int16_t py = 0, pcb = 0, pcr = 0;
+    // (seed_dc: the predictors a band of a larger image starts from — the DCs of the band above)
+    int16_t py = seed_dc ? seed_dc[0] : 0, pcb = seed_dc ? seed_dc[1] : 0, pcr = seed_dc ? seed_dc[2] : 0;
     uint8_t rst = 0;
     const uint32_t total = static_cast<uint32_t>(g.units);
     const uint32_t interval = o.has_restart_interval ? o.restart_interval : 0;
@@ -596,6 +597,162 @@ void pack_scan_tables(const HuffSet &h, uint32_t out[kScanTableWords])
         for (int i = 0; i < 12; ++i) t[i] = (static_cast<uint32_t>(h.dc[cls].len[i]) << 16) | h.dc[cls].code[i];
         for (int i = 0; i < 256; ++i) t[12 + i] = (static_cast<uint32_t>(h.ac[cls].len[i]) << 16) | h.ac[cls].code[i];
     }
+}
+
+// ======================================================================================
+// One image as MCU-row bands: every band is entropy-coded on its own — with the DC
+// predictors of the band above and at its bit offset in the scan — and the pieces are spliced.
+// ======================================================================================
+namespace {
+// bit sinks for walk_scan's Emit: count only / collect the raw (unstuffed) bits
+struct BitCounter {
+    uint64_t bits = 0;
+    inline void put(uint32_t, int nbits) { bits += static_cast<uint64_t>(nbits); }
+    void align_with_ones() {}
+    void raw(uint8_t, uint8_t) {}
+};
+struct RawBits {
+    std::vector<uint8_t> bytes; // MSB first, last byte zero padded
+    uint64_t bits = 0;
+    inline void put(uint32_t value, int nbits)
+    {
+        for (int i = nbits - 1; i >= 0; --i) {
+            if ((bits & 7) == 0) bytes.push_back(0);
+            if ((value >> i) & 1u) bytes.back() |= static_cast<uint8_t>(0x80u >> (bits & 7));
+            ++bits;
+        }
+    }
+    void align_with_ones() {}
+    void raw(uint8_t, uint8_t) {}
+    uint32_t get(uint64_t first, int n) const // n <= 8 bits starting at bit `first`
+    {
+        uint32_t v = 0;
+        for (int i = 0; i < n; ++i) {
+            const uint64_t b = first + i;
+            v = (v << 1) | ((bytes[b >> 3] >> (7 - (b & 7))) & 1u);
+        }
+        return v;
+    }
+};
+template <class Sink> struct EmitTo {
+    Sink &sink;
+    const HuffSet &h;
+    inline int16_t block(const int16_t *blk, int16_t prev_dc, int cls)
+    { // encode_block, huffman.rs:423-481 (same walk as Emit)
+        const HuffTable &dc = h.dc[cls], &ac = h.ac[cls];
+        const int16_t d0 = blk[0];
+        const int diff = static_cast<int16_t>(d0 - prev_dc);
+        const int dcat = magnitude_bits(diff);
+        sink.put(dc.code[dcat], dc.len[dcat]);
+        if (dcat) sink.put(static_cast<uint32_t>(diff < 0 ? diff - 1 : diff) & ((1u << dcat) - 1u), dcat);
+        int run = 0;
+        for (int k = 1; k < 64; ++k) {
+            const int v = blk[kZigzag[k]];
+            if (v == 0) { ++run; continue; }
+            for (; run >= 16; run -= 16) sink.put(ac.code[0xF0], ac.len[0xF0]);
+            const int cat = magnitude_bits(v);
+            const int rs = (run << 4) | cat;
+            const uint32_t vb = static_cast<uint32_t>(v < 0 ? v - 1 : v) & ((1u << cat) - 1u);
+            sink.put((static_cast<uint32_t>(ac.code[rs]) << cat) | vb, ac.len[rs] + cat);
+            run = 0;
+        }
+        if (run > 0) sink.put(ac.code[0], ac.len[0]);
+        return d0;
+    }
+    void restart(uint8_t) {}
+};
+pixo_jpeg_options without_restart(pixo_jpeg_options o)
+{
+    o.has_restart_interval = 0; o.restart_interval = 0;
+    return o;
+}
+} // namespace
+
+void make_piece(std::vector<uint8_t> &piece, int head_n, uint32_t head, int tail_n, uint32_t tail, const uint8_t *body,
+                size_t body_len)
+{
+    piece.assign(kPieceHeader + body_len, 0);
+    piece[0] = static_cast<uint8_t>(head_n); piece[1] = static_cast<uint8_t>(head);
+    piece[2] = static_cast<uint8_t>(tail_n); piece[3] = static_cast<uint8_t>(tail);
+    for (int i = 0; i < 8; ++i) piece[8 + i] = static_cast<uint8_t>(static_cast<uint64_t>(body_len) >> (8 * i));
+    if (body_len) std::memcpy(piece.data() + kPieceHeader, body, body_len);
+}
+
+void band_histograms(const int16_t *y, const int16_t *cb, const int16_t *cr, const pixo_jpeg_options &band,
+                     const int16_t prev_dc[3], uint64_t dc[2][12], uint64_t ac[2][256])
+{
+    std::memset(dc, 0, sizeof(uint64_t) * 24);
+    std::memset(ac, 0, sizeof(uint64_t) * 512);
+    Count c{dc, ac};
+    walk_scan(c, y, cb, cr, without_restart(band), prev_dc);
+}
+
+uint64_t band_bits(const int16_t *y, const int16_t *cb, const int16_t *cr, const pixo_jpeg_options &band, const HuffSet &h,
+                   const int16_t prev_dc[3])
+{
+    BitCounter sink;
+    EmitTo<BitCounter> e{sink, h};
+    walk_scan(e, y, cb, cr, without_restart(band), prev_dc);
+    return sink.bits;
+}
+
+void band_piece(const int16_t *y, const int16_t *cb, const int16_t *cr, const pixo_jpeg_options &band, const HuffSet &h,
+                const int16_t prev_dc[3], uint64_t bit_offset, std::vector<uint8_t> &piece)
+{
+    RawBits sink;
+    EmitTo<RawBits> e{sink, h};
+    walk_scan(e, y, cb, cr, without_restart(band), prev_dc);
+    const uint64_t bits = sink.bits;
+    const int want = static_cast<int>((8 - (bit_offset & 7)) & 7);
+    const int head_n = static_cast<int>(bits < static_cast<uint64_t>(want) ? bits : want);
+    const uint64_t rest = bits - head_n, nfull = rest / 8;
+    const int tail_n = static_cast<int>(rest % 8);
+    std::vector<uint8_t> body;
+    body.reserve(nfull + nfull / 64 + 8);
+    for (uint64_t i = 0; i < nfull; ++i) {
+        const uint8_t b = static_cast<uint8_t>(sink.get(head_n + 8 * i, 8));
+        body.push_back(b);
+        if (b == 0xFF) body.push_back(0x00); // bits.rs:245-253
+    }
+    make_piece(piece, head_n, head_n ? sink.get(0, head_n) : 0, tail_n, tail_n ? sink.get(head_n + 8 * nfull, tail_n) : 0,
+               body.data(), body.size());
+}
+
+int splice_file(const pixo_jpeg_options &o, const HuffSet &h, const uint8_t *const *pieces, const size_t *lens, uint32_t parts,
+                std::vector<uint8_t> &out, std::string &msg)
+{
+    out.clear();
+    size_t total = 1024;
+    for (uint32_t k = 0; k < parts; ++k) {
+        if (!pieces[k] || lens[k] < kPieceHeader) { msg = "Compression error: band piece " + std::to_string(k) + " is malformed"; return PIXO_ERR_COMPRESSION; }
+        total += lens[k];
+    }
+    out.reserve(total);
+    write_headers(out, o, make_quant_tables(o.quality), h);
+    uint32_t acc = 0;
+    int nacc = 0; // bits of the byte two neighbouring bands share
+    auto emit = [&](uint8_t b) { out.push_back(b); if (b == 0xFF) out.push_back(0x00); };
+    for (uint32_t k = 0; k < parts; ++k) {
+        const uint8_t *p = pieces[k];
+        const int head_n = p[0], tail_n = p[2];
+        uint64_t body_len = 0;
+        for (int i = 0; i < 8; ++i) body_len |= static_cast<uint64_t>(p[8 + i]) << (8 * i);
+        if (head_n > 7 || tail_n > 7 || body_len != lens[k] - kPieceHeader || nacc + head_n > 8 ||
+            ((body_len || tail_n) && nacc + head_n != 8 && nacc + head_n != 0)) {
+            msg = "Compression error: band piece " + std::to_string(k) + " does not start at the bit offset the bands before it end at";
+            return PIXO_ERR_COMPRESSION;
+        }
+        if (head_n) {
+            acc = (acc << head_n) | (p[1] & ((1u << head_n) - 1u));
+            nacc += head_n;
+            if (nacc == 8) { emit(static_cast<uint8_t>(acc)); acc = 0; nacc = 0; }
+        }
+        out.insert(out.end(), p + kPieceHeader, p + kPieceHeader + body_len);
+        if (tail_n) { acc = p[3] & ((1u << tail_n) - 1u); nacc = tail_n; }
+    }
+    if (nacc) emit(static_cast<uint8_t>((acc << (8 - nacc)) | ((1u << (8 - nacc)) - 1u))); // BitWriterMsb::flush, bits.rs:261-272
+    be16(out, 0xFFD9);
+    return PIXO_OK;
 }
 
 void encode_file(const int16_t *y, const int16_t *cb, const int16_t *cr,

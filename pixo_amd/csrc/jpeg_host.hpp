@@ -79,6 +79,27 @@ void pack_scan_tables(const HuffSet &h, uint32_t out[kScanTableWords]);
 void encode_file(const int16_t *y, const int16_t *cb, const int16_t *cr,
                  const pixo_jpeg_options &o, std::vector<uint8_t> &out);
 
+// ---- one image as MCU-row bands (include/pixo_hip.h "band encoder") -------------------
+// A band's share of the scan travels as a PIECE: 16 header bytes
+//   [0] head_nbits [1] head_bits [2] tail_nbits [3] tail_bits [4..7] 0 [8..15] body_len (u64 LE)
+// + body.  With the band starting at bit `bit_offset` of the scan: head = its first (8 - offset % 8) % 8
+// bits (they share a byte with the band before), body = its whole bytes, already 0xFF-stuffed, tail =
+// the bits left over (they share a byte with the next band); bit values right-aligned.
+constexpr size_t kPieceHeader = 16;
+void make_piece(std::vector<uint8_t> &piece, int head_n, uint32_t head, int tail_n, uint32_t tail, const uint8_t *body,
+                size_t body_len);
+// Host twins of the device band encoder, on a band's tuple (`band` = the image's options with the band's
+// height; restart intervals do not apply to bands); prev_dc = last DC of Y, Cb, Cr above the band.
+void band_histograms(const int16_t *y, const int16_t *cb, const int16_t *cr, const pixo_jpeg_options &band,
+                     const int16_t prev_dc[3], uint64_t dc[2][12], uint64_t ac[2][256]);
+uint64_t band_bits(const int16_t *y, const int16_t *cb, const int16_t *cr, const pixo_jpeg_options &band, const HuffSet &h,
+                   const int16_t prev_dc[3]);
+void band_piece(const int16_t *y, const int16_t *cb, const int16_t *cr, const pixo_jpeg_options &band, const HuffSet &h,
+                const int16_t prev_dc[3], uint64_t bit_offset, std::vector<uint8_t> &piece);
+// headers + the pieces merged bit-exactly (shared bytes OR-ed and stuffed, final 1-padding) + EOI
+int splice_file(const pixo_jpeg_options &o, const HuffSet &h, const uint8_t *const *pieces, const size_t *lens, uint32_t parts,
+                std::vector<uint8_t> &out, std::string &msg);
+
 // Progressive file from a coefficient tuple and the tables to use: SOF2 headers, the seven scans of
 // simple_progressive_script (src/jpeg/progressive.rs:98-110) coded like jpeg/mod.rs:1248-1365, EOI.
 void encode_progressive_file(const int16_t *y, const int16_t *cb, const int16_t *cr, const pixo_jpeg_options &o,

@@ -13,6 +13,9 @@ plus the device seam (the reference's internal `YCbCrCoefficients`, jpeg/mod.rs:
 
     coefficients(data, options) -> (y, cb, cr) int16 arrays [blocks, 64]
     coefficients_device(...)    -> same on device pointers / torch tensors, async
+
+and one image over several GPUs: `BandEncoder`, `splice`, `encode_multi`, host twins
+`band_*_host`; `sharded.py` drives them over `torch.distributed`.
 """
 import ctypes as C
 import dataclasses
@@ -356,12 +359,184 @@ def band(width, height, color_type, subsampling, parts, index):
                 c_offset=co.value, c_blocks=cbk.value)
 
 
+COUNT_WORDS = 536  # PIXO_HIP_COUNT_WORDS: [class][12 DC categories + 256 AC run/size symbols]
+
+
+def _take(L, out, n):
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        L.pixo_hip_free(out)
+
+
+def _dc3(values):
+    return (C.c_int16 * 3)(*[int(v) for v in values])
+
+
+def _counts(total_counts):
+    if total_counts is None:
+        return None
+    a = np.ascontiguousarray(total_counts, np.uint64)
+    assert a.size == COUNT_WORDS
+    return a
+
+
+class BandEncoder:
+    """One MCU-row band of an image on one GPU (`pixo_hip_band_encoder`): coefficient kernel,
+    then — with what the other bands exchanged — statistics, bit length, and the packed + stuffed piece.
+    The exchanges themselves (3 x i16 and one u64 per band) are the caller's: see `sharded.encode_banded`."""
+
+    def __init__(self, options: JpegOptions, parts: int, index: int, device: int = 0):
+        L = _lib.load()
+        self._L = L
+        self._h = C.c_void_p()
+        oc = options._c()
+        rc = L.pixo_hip_band_encoder_create(C.byref(oc), parts, index, device, C.byref(self._h))
+        if rc:
+            _raise(rc)
+        r0, r1 = C.c_uint32(), C.c_uint32()
+        L.pixo_hip_band_encoder_rows(self._h, C.byref(r0), C.byref(r1))
+        self.row_begin, self.row_end = r0.value, r1.value
+
+    def close(self):
+        if self._h:
+            self._L.pixo_hip_band_encoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def coeffs(self, band_pixels):
+        """`band_pixels`: this band's rows — host bytes / uint8 array, or a device tensor / pointer.
+        Returns the band's last DCs (Y, Cb, Cr)."""
+        last = (C.c_int16 * 3)()
+        if hasattr(band_pixels, "data_ptr") and getattr(band_pixels, "is_cuda", False):
+            rc = self._L.pixo_hip_band_encoder_coeffs(self._h, band_pixels.data_ptr(), 1, last)
+        elif isinstance(band_pixels, int):
+            rc = self._L.pixo_hip_band_encoder_coeffs(self._h, band_pixels, 1, last)
+        else:
+            px = _as_u8(band_pixels)
+            rc = self._L.pixo_hip_band_encoder_coeffs(self._h, px.ctypes.data if px.size else None, 0, last)
+        if rc:
+            _raise(rc)
+        return [int(v) for v in last]
+
+    def count(self, prev_dc):
+        out = np.zeros(COUNT_WORDS, np.uint64)
+        rc = self._L.pixo_hip_band_encoder_count(self._h, _dc3(prev_dc), out.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if rc:
+            _raise(rc)
+        return out
+
+    def lengths(self, prev_dc, total_counts=None) -> int:
+        bits = C.c_uint64()
+        tc = _counts(total_counts)
+        rc = self._L.pixo_hip_band_encoder_lengths(self._h, _dc3(prev_dc),
+                                                   tc.ctypes.data_as(C.POINTER(C.c_uint64)) if tc is not None else None,
+                                                   C.byref(bits))
+        if rc:
+            _raise(rc)
+        return bits.value
+
+    def pack(self, bit_offset: int) -> bytes:
+        out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        rc = self._L.pixo_hip_band_encoder_pack(self._h, bit_offset, C.byref(out), C.byref(n))
+        if rc:
+            _raise(rc)
+        return _take(self._L, out, n)
+
+
+def _band_host_args(y, cb, cr):
+    y = np.ascontiguousarray(y, np.int16)
+    cb = np.ascontiguousarray(cb, np.int16)
+    cr = np.ascontiguousarray(cr, np.int16)
+    return y, cb, cr
+
+
+def band_count_host(y, cb, cr, options: JpegOptions, band_rows: int, prev_dc):
+    """Host twin of `BandEncoder.count` on a band's tuple in host memory."""
+    L = _lib.load()
+    y, cb, cr = _band_host_args(y, cb, cr)
+    out = np.zeros(COUNT_WORDS, np.uint64)
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_band_count_host(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, C.byref(oc), band_rows, _dc3(prev_dc),
+                                         out.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if rc:
+        _raise(rc)
+    return out
+
+
+def band_bits_host(y, cb, cr, options: JpegOptions, band_rows: int, prev_dc, total_counts=None) -> int:
+    L = _lib.load()
+    y, cb, cr = _band_host_args(y, cb, cr)
+    bits = C.c_uint64()
+    tc = _counts(total_counts)
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_band_bits_host(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, C.byref(oc), band_rows, _dc3(prev_dc),
+                                        tc.ctypes.data_as(C.POINTER(C.c_uint64)) if tc is not None else None, C.byref(bits))
+    if rc:
+        _raise(rc)
+    return bits.value
+
+
+def band_piece_host(y, cb, cr, options: JpegOptions, band_rows: int, prev_dc, bit_offset: int, total_counts=None) -> bytes:
+    L = _lib.load()
+    y, cb, cr = _band_host_args(y, cb, cr)
+    tc = _counts(total_counts)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_band_piece_host(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, C.byref(oc), band_rows, _dc3(prev_dc),
+                                         tc.ctypes.data_as(C.POINTER(C.c_uint64)) if tc is not None else None, bit_offset,
+                                         C.byref(out), C.byref(n))
+    if rc:
+        _raise(rc)
+    return _take(L, out, n)
+
+
+def splice(options: JpegOptions, pieces, total_counts=None) -> bytes:
+    """Headers + the bands' pieces in order (shared bytes merged, stuffed, final 1-padding) + EOI."""
+    L = _lib.load()
+    n_parts = len(pieces)
+    bufs = [np.frombuffer(p, np.uint8) for p in pieces]
+    ptrs = (C.c_void_p * n_parts)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n_parts)(*[b.size for b in bufs])
+    tc = _counts(total_counts)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_splice(C.byref(oc), tc.ctypes.data_as(C.POINTER(C.c_uint64)) if tc is not None else None, ptrs, lens,
+                                n_parts, C.byref(out), C.byref(n))
+    if rc:
+        _raise(rc)
+    return _take(L, out, n)
+
+
+def encode_multi(data, options: JpegOptions, devices) -> bytes:
+    """`encode` with the image's MCU-row bands spread over `devices` of this process (one host thread per
+    band; a device may be listed more than once).  Byte-identical to `encode`."""
+    L = _lib.load()
+    px = _as_u8(data)
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_encode_multi(px.ctypes.data, px.size, C.byref(oc), devs, len(devices), C.byref(out), C.byref(n))
+    if rc:
+        _raise(rc)
+    return _take(L, out, n)
+
+
+def set_producer_stream(stream) -> None:
+    """Device-pointer entry points are ordered after the work enqueued so far on `stream` (a hipStream_t
+    handle as int, 0 / None = the NULL stream, PyTorch's default)."""
+    _lib.load().pixo_hip_set_producer_stream(C.c_void_p(stream) if stream else None)
+
+
 def device_count() -> int:
     return _lib.load().pixo_hip_device_count()
 
 
 def set_device(device: int) -> None:
-    _lib.load().pixo_hip_set_device(device)
+    rc = _lib.load().pixo_hip_set_device(device)
+    if rc:
+        _raise(rc)
 
 
 def trim() -> None:

@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — Mpixels/s of the JPEG encode pixel pipeline (RGB→YCbCr→DCT→quant) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the fused colour + DCT + quantise kernel over one batch of synthetic
-input that is already resident in HBM (BASELINE.json configs[1]: one 4096x4096 RGB8 image,
-q=80, 4:2:0).  Each rank rotates over enough distinct input/output buffers to exceed the
-256 MiB Infinity Cache, so the bytes really come from and go to HBM.  N>1: every rank
-encodes its own images (weak scaling, no data-path collective — SURVEY §8e); the only
-communication is the barrier and the max-over-ranks of the elapsed time.
+A step = one pass of the hot path over one batch of synthetic input that is already resident in HBM.
 
-Prints ONE JSON line (rank 0) with the contract's keys plus `roofline` and `cpu_baseline`.
+  --workload c2 (default, the metric; BASELINE.json configs[1]): one launch of the fused colour + DCT + quantise
+      kernel over one 4096x4096 RGB8 image, q=80, 4:2:0.  Each rank rotates over enough distinct input/output
+      buffers to exceed the 256 MiB Infinity Cache, so the bytes really come from and go to HBM.  N > 1: every rank
+      encodes its own images (weak scaling, no data-path collective — SURVEY §8e).
+  --workload c4 (configs[3]): ONE 16384x16384 image whose MCU-row bands live on the N GPUs; a step = the whole file:
+      coefficient kernel + per-band entropy coding on every rank, the exchanges of pixo_amd/sharded.py (3 x i16 and a
+      u64 per band over RCCL), the bodies gathered over xGMI, spliced on rank 0 (strong scaling).
+  c2_444, c2_unaligned (4094 wide: rows not dword aligned), c3 (64 x 1080p, one launch), c1, c5 (PNG filters).
+
+Timing: W warmup steps, then R blocks (--blocks) of EXACTLY K steps, each bracketed by a barrier and
+torch.cuda.synchronize() on both sides, MAX over ranks per block; `ms_per_step` is the MEDIAN block (min and max
+beside it).  Rank 0 prints ONE JSON line with the contract's keys plus `roofline`, `cpu_baseline`, `other_configs`.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
 import subprocess
 import sys
 import tempfile
@@ -29,52 +38,163 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # what a plain tiled copy with this kernel's 1:1 read/write mix reaches on the part (tools/ubench/tile_copy.hip,
 # profiles/r01_ubench_tile_copy.txt: 12- or 16-byte loads, whole-line non-temporal stores); read-only streams: ~6400
 COPY_CEILING_GBPS = 5770.0
-
-
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--settle-ms", type=float, default=100.0,
-                    help="untimed launches before the warmup steps until this much wall time has passed: after an idle "
-                         "period the GPU needs ~20 ms of work to reach its steady clocks (tools/warmup_probe.py); 0 = none")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2_444", "c3", "c1", "c5"],
-                    help="c2: 4096x4096 4:2:0 (the metric); c2_444; c3: 64x1920x1080 batch; c1: 512x512")
-    ap.add_argument("--graph", type=int, default=0,
-                    help="experiment: replay the K timed steps as captured hipGraphs of this many kernel nodes each "
-                         "(the gap between dependent launches shrinks from ~2.9 to ~1.6 us); 0 = plain stream launches")
-    ap.add_argument("--quality", type=int, default=80)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
-    return ap.parse_args()
-
+C4_SHA256 = "77cc6cb69a782693c46f2024ac57ebfdfb8411148fa3cef62698c727af36c70c"  # SURVEY §8c, made by the reference
 
 WORKLOADS = {
-    #        w     h     batch  subsampling  label
+    #               w      h   batch ss  label
     "c2": (4096, 4096, 1, 1, "configs[1]: single 4096x4096 RGB8, q=80, 4:2:0, fused colour+DCT+quant kernel"),
     "c2_444": (4096, 4096, 1, 0, "4096x4096 RGB8, q=80, 4:4:4"),
+    "c2_unaligned": (4094, 4096, 1, 1, "4094x4096 RGB8 (rows not dword aligned: funnel loads), q=80, 4:2:0"),
     "c3": (1920, 1080, 64, 1, "configs[2]: batch of 64 x 1920x1080 RGB8, q=80, 4:2:0, one launch"),
     "c1": (512, 512, 1, 1, "configs[0] shape on the GPU: 512x512 RGB8, q=80, 4:2:0"),
 }
 
 
-def settle(step, ms):
-    """Untimed: keep the GPU busy for `ms` so that the W warmup steps and the K timed steps run at steady clocks
-    (a kernel of this size runs 15-35 % slower during the first ~20 ms after an idle period).  Returns the launches."""
-    import torch
-    n = 0
-    t0 = time.perf_counter()
-    while (time.perf_counter() - t0) * 1e3 < ms:
-        for _ in range(64):
-            step(n); n += 1
-        torch.cuda.synchronize()
-    return n
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--blocks", type=int, default=15, help="R: the K-step block is timed R times; median/min/max are reported")
+    ap.add_argument("--settle-ms", type=float, default=100.0,
+                    help="untimed launches before the warmup steps until this much wall time has passed: after an idle "
+                         "period the GPU needs ~20 ms of work to reach its steady clocks (tools/warmup_probe.py); 0 = none")
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["c4", "c5"])
+    ap.add_argument("--quality", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip whole_file and other_configs (A/B runs)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    ap.add_argument("--stub", action="store_true",
+                    help="plumbing test without a GPU: gloo process group, the step is a short sleep (data: 'stub')")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# process plumbing: --gpus N is honoured whichever way the script is started
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def ensure_world(args):
+    """Returns (rank, local_rank, world).  `python bench.py --gpus N` with N > 1 and no launcher environment
+    re-executes itself as N ranks under torch.distributed.run; a launcher whose world size differs from --gpus is an error."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a number "
+                         "for a different GPU count" % (args.gpus, world))
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world
+
+
+class Job:
+    """Process group + device + the timing protocol, shared by every workload."""
+
+    def __init__(self, args):
+        self.args = args
+        self.rank, self.local_rank, self.world = ensure_world(args)
+        self.stub = args.stub
+        self.dist = None
+        import torch
+        self.torch = torch
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if self.stub:
+            self.dev = torch.device("cpu")
+            if self.dist is not None:
+                self.dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+            if self.dist is not None:
+                self.dist.init_process_group(backend="nccl", device_id=self.dev)
+
+    def sync(self):
+        if not self.stub:
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.sync()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def settle(self, step, ms):
+        """Untimed: keep the GPU busy for `ms` so that warmup and timed steps run at steady clocks."""
+        n = 0
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < ms:
+            for _ in range(16):
+                step(n); n += 1
+            self.sync()
+        return n
+
+    def time_blocks(self, step, steps, warmup, blocks, events=True):
+        """W warmup steps, then `blocks` blocks of exactly `steps` steps: barrier + synchronize on both sides of every
+        block, MAX over ranks.  Returns (wall seconds per block, HIP-event milliseconds per block on this rank)."""
+        torch = self.torch
+        for i in range(warmup):
+            step(i)
+        walls, evs = [], []
+        n = warmup
+        for _ in range(blocks):
+            self.barrier()
+            if events and not self.stub:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(n + i)
+            if events and not self.stub:
+                e1.record()
+            self.sync()
+            dt = time.perf_counter() - t0
+            n += steps
+            walls.append(self.max_over_ranks(dt))
+            if events and not self.stub:
+                evs.append(e0.elapsed_time(e1))
+        self.barrier()
+        return walls, evs
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def block_stats(walls, steps):
+    per = sorted(w / steps * 1e3 for w in walls)
+    return {"ms_per_step": round(statistics.median(per), 5), "ms_per_step_min": round(per[0], 5), "ms_per_step_max": round(per[-1], 5),
+            "blocks": len(per)}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only)
+# ------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(w, h, ss, quality, budget_s):
-    """Oracle (C restatement, -O2, OpenMP over MCU rows) timed on this host's cores on the same
-    4096x4096 workload, coefficient stage only (the work the GPU kernel does)."""
+    """The oracle (C restatement, gcc -O2 -ffp-contract=off, OpenMP over MCU rows) timed on this host's cores on the same
+    4096x4096 image, coefficient stage only (the work the GPU kernel does).  `value` = the MEDIAN of the repetitions at the
+    thread count a short probe found fastest on this box (cgroup quotas make "all logical CPUs" slower than fewer threads);
+    the probe's single runs are listed for information only."""
     import oracle_lib as O
     import synth
     px = synth.noise(w, h, 42)
@@ -83,30 +203,33 @@ def cpu_baseline(w, h, ss, quality, budget_s):
     except AttributeError:
         avail = os.cpu_count() or 1
     O.coeffs(px[: 64 * 64 * 3], 64, 64, 2, ss, quality)  # load lib
-    # pick the thread count that is actually fastest on this box (SMT / cgroup quotas can make
-    # "all logical CPUs" slower than fewer threads); `cores` reports the count used
-    best_dt, cores = None, 1
     tried = {}
+    best_dt, cores = None, 1
     for th in sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 64), min(avail, 32), min(avail, 16)}):
-        O.coeffs(px, w, h, 2, ss, quality, threads=th)
-        t0 = time.perf_counter()
-        O.coeffs(px, w, h, 2, ss, quality, threads=th)
-        dt = time.perf_counter() - t0
-        tried[th] = round(w * h / dt / 1e6, 1)
-        if best_dt is None or dt < best_dt:
-            best_dt, cores = dt, th
-    reps = max(1, min(50, int(budget_s / max(best_dt, 1e-3))))
-    t0 = time.perf_counter()
+        O.coeffs(px, w, h, 2, ss, quality, threads=th)  # warm the threads
+        dts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            O.coeffs(px, w, h, 2, ss, quality, threads=th)
+            dts.append(time.perf_counter() - t0)
+        tried[th] = round(w * h / min(dts) / 1e6, 1)
+        if best_dt is None or min(dts) < best_dt:
+            best_dt, cores = min(dts), th
+    reps = max(5, min(60, int(budget_s / max(best_dt, 1e-3))))
+    dts = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         O.coeffs(px, w, h, 2, ss, quality, threads=cores)
-    dt = (time.perf_counter() - t0) / reps
-    out = {"value": round(w * h / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-           "logical_cpus": avail, "threads_tried_Mpx_s": tried,
+        dts.append(time.perf_counter() - t0)
+    dts.sort()
+    out = {"value": round(w * h / statistics.median(dts) / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+           "value_is": "median of %d repetitions at %d threads" % (reps, cores),
+           "best_repetition_Mpx_s": round(w * h / dts[0] / 1e6, 2), "worst_repetition_Mpx_s": round(w * h / dts[-1] / 1e6, 2),
+           "logical_cpus": avail, "probe_single_runs_Mpx_s_by_threads": tried,
            "sample": "%d x (%dx%d RGB8 noise seed 42, q=%d, %s) coefficient stage (colour+DCT+quant) "
                      "by oracle/pixo_oracle.c, gcc -O2 -ffp-contract=off, OpenMP %d threads over MCU rows"
                      % (reps, w, h, quality, "4:2:0" if ss else "4:4:4", cores)}
-    # single-thread figure as well (the reference's baseline encode_scan is single-threaded)
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()  # the reference's baseline encode_scan is single-threaded
     O.coeffs(px, w, h, 2, ss, quality, threads=1)
     out["value_1_thread"] = round(w * h / (time.perf_counter() - t0) / 1e6, 2)
     return out
@@ -138,297 +261,360 @@ def cpu_reference_wasm(w, h, ss, quality):
         return {"error": str(e)}
 
 
-def bench_png(args):
-    """--workload c5: configs[4], 4096x4096 RGBA8 through the PNG row-filter stage (Adaptive strategy)
-    + Adler-32 partials.  Algorithmic bytes (SURVEY §8d): read 4 B/px + write (4 + 1/4096) B/px."""
-    import numpy as np
-    import torch
-    from pixo_amd import png
-    import synth
-    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if dist is not None:
-        dist.init_process_group(backend="nccl", device_id=dev)
-    w = h = 4096
-    bpp = 4
-    base = synth.rgba_noise_alpha1(w, h, 42 + rank)
-    in_bytes, out_bytes = w * h * bpp, png.filtered_size(w, h, bpp)
-    nbuf = 5  # 5 x 134 MB > Infinity Cache
-    host = torch.from_numpy(base)
-    ins = [(host.to(dev) ^ torch.tensor(i, dtype=torch.uint8, device=dev)).contiguous() for i in range(nbuf)]
-    outs = [torch.empty(out_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    sums = [torch.zeros(2 * h, dtype=torch.int64, device=dev) for _ in range(nbuf)]
-    scratch = torch.zeros(4, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step(i):
-        k = i % nbuf
-        png.apply_filters_async(ins[k], w, h, bpp, outs[k], sums[k], scratch, png.FilterStrategy.ADAPTIVE, 0, stream)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    settled = settle(step, args.settle_ms)
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    ev1.record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        dist.barrier()
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-    # correctness inside the bench: buffer 0 against the reference-made vector of SURVEY §8c
-    step(0)
-    torch.cuda.synchronize()
-    import hashlib
-    adler = png.adler32_from_row_sums(sums[0].cpu().numpy().view(np.uint64), w, h, bpp)
-    digest = hashlib.sha256(outs[0].cpu().numpy().tobytes()).hexdigest()
-    if (adler != 0x90CC12E3 or not digest.startswith("240e005d4da54561")) and not os.environ.get("PIXO_BENCH_ABLATION"):
-        raise SystemExit("bench: filtered stream differs from the reference's — refusing to report a number")
-    alg = in_bytes + out_bytes
-    achieved = alg / (kernel_ms * 1e-3) / 1e9
-    traffic = None
+def traffic_of(workload):
+    """HBM bytes per launch from the committed PMC profile of this workload (separate rocprofv3 --pmc passes,
+    corrected as MI355X_MICROARCH.md prescribes) — read from profiles/, NOT measured in this run."""
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic_c5.json"))).get("hbm_bytes_per_launch")
+        d = json.load(open(path))
+        return d.get("hbm_bytes_per_launch"), "profile: " + os.path.relpath(path, ROOT)
     except Exception:
-        pass
-    line = {"metric": "Mpixels/s PNG row filters + Adler-32 partials (Adaptive), 4096x4096 RGBA8", "value": round(w * h * world * args.steps / elapsed / 1e6, 1),
-            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[4]: 4096x4096 RGBA8, FilterStrategy::Adaptive, rows independent", "width": w, "height": h,
-                       "buffers_rotated": nbuf, "settle_launches_before_warmup": settled,
-                       "parallelism": "one process per GPU, images sharded across ranks, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "kernel": "png_filter_kernel<4, true>",
-                         "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3)}}
-    if not args.no_cpu_baseline and world == 1:
+        return None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the coefficient kernel (c2, c2_444, c2_unaligned, c3, c1)
+# ------------------------------------------------------------------------------------------------------------------
+class CoeffWorkload:
+    def __init__(self, job, name, quality):
+        import numpy as np
+        import synth
+        from pixo_amd import jpeg
+        self.job, self.name, self.q, self.jpeg, self.np = job, name, quality, jpeg, np
+        torch = job.torch
+        self.w, self.h, self.batch, self.ss, self.label = WORKLOADS[name]
+        w, h, batch, ss = self.w, self.h, self.batch, self.ss
+        self.yb, self.cbn = jpeg.coefficient_geometry(w, h, 2, ss)
+        self.in_bytes = w * h * 3 * batch
+        self.out_bytes = (self.yb + 2 * self.cbn) * 128 * batch
+        # rotate over enough buffer sets that the working set exceeds the 256 MiB Infinity Cache
+        self.nbuf = min(64, max(2, -(-(640 << 20) // (self.in_bytes + self.out_bytes))))
+        self.base = synth.noise(w, h, 42 + job.rank)
+        if job.stub:
+            self.ins = self.outs = None
+            return
+        host = torch.from_numpy(np.ascontiguousarray(self.base))
+        dev = job.dev
+        self.ins, self.outs = [], []
+        for i in range(self.nbuf):
+            t = host.to(dev)
+            if batch > 1:
+                t = t.repeat(batch)
+            t = t ^ torch.tensor(i & 0xFF, dtype=torch.uint8, device=dev) if i else t  # distinct content per buffer
+            self.ins.append(t.contiguous())
+            self.outs.append((torch.empty((batch * self.yb, 64), dtype=torch.int16, device=dev),
+                              torch.empty((batch * self.cbn, 64), dtype=torch.int16, device=dev),
+                              torch.empty((batch * self.cbn, 64), dtype=torch.int16, device=dev)))
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def step(self, i):
+        if self.job.stub:
+            time.sleep(2e-5)
+            return
+        k = i % self.nbuf
+        y, cb, cr = self.outs[k]
+        self.jpeg.coefficients_device(self.ins[k], self.w, self.h, 2, self.ss, self.q, y, cb, cr, batch=self.batch, stream=self.stream)
+
+    def check(self):
+        """correctness inside the bench: buffer 0 against the oracle on a 64-row strip (Y, Cb and Cr)"""
         import oracle_lib as O
-        rows = 256  # bounded sample: 256 rows of the same image, one thread
-        t1 = time.perf_counter()
-        O.png_filter(base[: w * rows * bpp], w, rows, bpp, O.S_ADAPTIVE)
-        dt = time.perf_counter() - t1
-        line["cpu_baseline"] = {"value": round(w * rows / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-                                "sample": "first %d rows of the same 4096x4096 RGBA image, Adaptive, oracle/pixo_png_oracle.c, gcc -O2, 1 thread" % rows}
-    print(json.dumps(line, ensure_ascii=False))
-    if dist is not None:
-        dist.destroy_process_group()
-
-
-def main():
-    args = parse()
-    if args.workload == "c5":
-        return bench_png(args)
-    import numpy as np
-    import torch
-    from pixo_amd import jpeg
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if dist is not None:
-        dist.init_process_group(backend="nccl", device_id=dev)
-
-    w, h, batch, ss, label = WORKLOADS[args.workload]
-    q = args.quality
-    import synth
-    yb, cbn = jpeg.coefficient_geometry(w, h, 2, ss)
-    in_bytes = w * h * 3 * batch
-    out_bytes = (yb + 2 * cbn) * 128 * batch
-    # rotate over enough buffer sets that the working set exceeds the 256 MiB Infinity Cache
-    nbuf = max(2, -(-(640 << 20) // (in_bytes + out_bytes)))
-    nbuf = min(nbuf, 64)
-    base = synth.noise(w, h, 42 + rank)
-    if os.environ.get("PIXO_BENCH_FILL") == "zero":  # DVFS experiments only: data-dependent power
-        base = base * 0
-    host = torch.from_numpy(np.ascontiguousarray(base))
-    ins, outs = [], []
-    for i in range(nbuf):
-        t = host.to(dev)
-        if batch > 1:
-            t = t.repeat(batch)
-        # make every buffer distinct content-wise (cheap xor with the buffer index)
-        t = t ^ torch.tensor(i & 0xFF, dtype=torch.uint8, device=dev) if i else t
-        ins.append(t.contiguous())
-        outs.append((torch.empty((batch * yb, 64), dtype=torch.int16, device=dev),
-                     torch.empty((batch * cbn, 64), dtype=torch.int16, device=dev),
-                     torch.empty((batch * cbn, 64), dtype=torch.int16, device=dev)))
-    def step(i):
-        k = i % nbuf
-        y, cb, cr = outs[k]
-        jpeg.coefficients_device(ins[k], w, h, 2, ss, q, y, cb, cr, batch=batch,
-                                 stream=torch.cuda.current_stream().cuda_stream)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    settled = settle(step, args.settle_ms)
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    graphs = []
-    if args.graph > 0:  # capture the K steps (the library call only enqueues a kernel: capturable as it is)
-        side = torch.cuda.Stream(dev)
-        i = 0
-        while i < args.steps:
-            cnt = min(args.graph, args.steps - i)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                for j in range(cnt):
-                    step(args.warmup + i + j)
-            graphs.append(g)
-            i += cnt
-        for g in graphs[:2]:
-            g.replay()
-        barrier()
-    t0 = time.perf_counter()
-    ev0.record()
-    if graphs:
-        for g in graphs:
-            g.replay()
-    else:
-        for i in range(args.steps):
-            step(args.warmup + i)
-    ev1.record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream, per launch
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        dist.barrier()
-
-    # second pass: one event pair per launch (excludes inter-launch gaps), rank 0 only
-    pairs = []
-    if rank == 0:
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 64))]
-        for i, (a, b) in enumerate(evs):
-            a.record(); step(i); b.record()
-        torch.cuda.synchronize()
-        pairs = sorted(a.elapsed_time(b) for a, b in evs)
-
-    # correctness spot check inside the bench: buffer 0 against the oracle on a 64-row strip
-    if rank == 0 and not os.environ.get("PIXO_BENCH_ABLATION"):  # ablation builds compute garbage on purpose
-        import oracle_lib as O
+        np = self.np
         strip_h = 64
-        oy, ocb, ocr = O.coeffs(base[: w * strip_h * 3], w, strip_h, 2, ss, q)
-        step(0)
-        torch.cuda.synchronize()
-        gy = outs[0][0][: oy.shape[0]].cpu().numpy()
-        gcb = outs[0][1][: ocb.shape[0]].cpu().numpy()
-        if not (np.array_equal(gy, oy) and np.array_equal(gcb, ocb)):
+        oy, ocb, ocr = O.coeffs(self.base[: self.w * strip_h * 3], self.w, strip_h, 2, self.ss, self.q)
+        self.step(0)
+        self.job.sync()
+        gy = self.outs[0][0][: oy.shape[0]].cpu().numpy()
+        gcb = self.outs[0][1][: ocb.shape[0]].cpu().numpy()
+        gcr = self.outs[0][2][: ocr.shape[0]].cpu().numpy()
+        if not (np.array_equal(gy, oy) and np.array_equal(gcb, ocb) and np.array_equal(gcr, ocr)):
             raise SystemExit("bench: GPU coefficients differ from the oracle — refusing to report a number")
 
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+    def roofline(self, kernel_ms):
+        alg = self.in_bytes + self.out_bytes  # SURVEY §8d: 3 B/px read + 3 B/px written (4:2:0); 3 + 6 for 4:4:4
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        traffic, src = traffic_of(self.name)
+        return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src,
+                "kernel": "jpeg_coeffs_kernel<%s, %s>" % ("M420" if self.ss else "M444", "L_FUNNEL" if self.w * 3 % 4 else "L_ALIGNED"),
+                "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3),
+                "read_only_frac_of_peak": round(self.in_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "frac_of_measured_copy_ceiling_5770": round(achieved / COPY_CEILING_GBPS, 4)}
 
-    pixels_per_step = w * h * batch
-    value = pixels_per_step * world * args.steps / elapsed / 1e6
-    alg_bytes = in_bytes + out_bytes  # SURVEY §8d: 3 B/px read + 3 B/px written (4:2:0); 3+6 for 4:4:4
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+
+def quick_kernel(job, name, q, steps=60, blocks=5):
+    """One of the other configurations, briefly (already at steady clocks): kernel time from HIP events, roofline fraction."""
+    wl = CoeffWorkload(job, name, q)
+    wl.check()
+    _, evs = job.time_blocks(wl.step, steps, 10, blocks)
+    kernel_ms = statistics.median(evs) / steps
+    r = wl.roofline(kernel_ms)
+    out = {"workload": wl.label, "kernel_us": r["kernel_us_avg"], "Mpixels_per_s": round(wl.w * wl.h * wl.batch / kernel_ms / 1e3, 1),
+           "achieved_GBps": r["achieved"], "frac": r["frac"], "steps": steps, "blocks": blocks}
+    del wl
+    job.torch.cuda.empty_cache()
+    return out
+
+
+def quick_png(job, steps=40, blocks=5):
+    wl = PngWorkload(job)
+    wl.check()
+    _, evs = job.time_blocks(wl.step, steps, 10, blocks)
+    kernel_ms = statistics.median(evs) / steps
+    alg = wl.in_bytes + wl.out_bytes
+    out = {"workload": "configs[4]: 4096x4096 RGBA8 PNG row filters (Adaptive) + Adler-32 partials", "kernel_us": round(kernel_ms * 1e3, 3),
+           "Mpixels_per_s": round(4096 * 4096 / kernel_ms / 1e3, 1), "achieved_GBps": round(alg / (kernel_ms * 1e-3) / 1e9, 1),
+           "frac": round(alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "steps": steps, "blocks": blocks}
+    del wl
+    job.torch.cuda.empty_cache()
+    return out
+
+
+def run_coeffs(job, args):
+    wl = CoeffWorkload(job, args.workload, args.quality)
+    settled = job.settle(wl.step, 0 if job.stub else args.settle_ms)
+    walls, evs = job.time_blocks(wl.step, args.steps, args.warmup, args.blocks)
+    if job.rank == 0 and not job.stub and not os.environ.get("PIXO_BENCH_ABLATION"):
+        wl.check()
+    if job.rank != 0:
+        job.finish()
+        return
+    st = block_stats(walls, args.steps)
+    pixels_per_step = wl.w * wl.h * wl.batch
+    value = pixels_per_step * job.world / (st["ms_per_step"] * 1e-3) / 1e6
+    kernel_ms = (statistics.median(evs) / args.steps) if evs else st["ms_per_step"]
     line = {
         "metric": "Mpixels/s JPEG encode (RGB→YCbCr→DCT→quant), 4096×4096 q=80" if args.workload == "c2"
                   else "Mpixels/s JPEG encode (RGB→YCbCr→DCT→quant), %s" % args.workload,
-        "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": label, "width": w, "height": h, "batch": batch, "quality": q,
-                   "subsampling": "4:2:0" if ss else "4:4:4", "buffers_rotated": nbuf,
-                   "working_set_MiB": round(nbuf * (in_bytes + out_bytes) / 2**20, 1),
-                   "settle_launches_before_warmup": settled, "graph_nodes": args.graph,
+        "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": st["ms_per_step"], "ms_per_step_min": st["ms_per_step_min"], "ms_per_step_max": st["ms_per_step_max"],
+        "blocks": st["blocks"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "stub" if job.stub else "synthetic",
+        "config": {"workload": wl.label, "width": wl.w, "height": wl.h, "batch": wl.batch, "quality": wl.q,
+                   "subsampling": "4:2:0" if wl.ss else "4:4:4", "buffers_rotated": wl.nbuf,
+                   "working_set_MiB": round(wl.nbuf * (wl.in_bytes + wl.out_bytes) / 2**20, 1),
+                   "settle_launches_before_warmup": settled,
+                   "timing": "median of %d blocks of %d steps, each block barrier+synchronize bracketed, max over ranks" % (st["blocks"], args.steps),
                    "parallelism": "one process per GPU, images sharded across ranks, no collective"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                     "kernel": "jpeg_coeffs_kernel<%s>" % ("M420" if ss else "M444"),
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "kernel_us_avg": round(kernel_ms * 1e3, 3),
-                     "kernel_us_event_pairs_median": round(pairs[len(pairs) // 2] * 1e3, 3) if pairs else None,
-                     "kernel_us_event_pairs_min": round(pairs[0] * 1e3, 3) if pairs else None,
-                     "read_only_frac_of_peak": round(in_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                     "frac_of_measured_copy_ceiling_5770": round(achieved / COPY_CEILING_GBPS, 4)},
+        "roofline": wl.roofline(kernel_ms),
     }
-    if batch == 1 and world == 1 and not os.environ.get("PIXO_BENCH_ABLATION"):
-        # Not `value`: the whole file (coefficient kernel + device entropy stage + copy of the file to
-        # the host) from device-resident pixels, reported beside the kernel-only metric.
-        opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling(ss)).build()
+    if evs:
+        per = sorted(e / args.steps * 1e3 for e in evs)
+        line["roofline"]["kernel_us_block_min"], line["roofline"]["kernel_us_block_max"] = round(per[0], 3), round(per[-1], 3)
+    extras = (not args.no_extras) and job.world == 1 and not job.stub and not os.environ.get("PIXO_BENCH_ABLATION")
+    if extras and wl.batch == 1 and args.workload in ("c2", "c2_444"):
+        line["whole_file"] = whole_file(job, wl)
+    if extras and args.workload == "c2":
+        others = {}
+        del wl.ins, wl.outs
+        job.torch.cuda.empty_cache()
+        for name in ("c3", "c2_444", "c2_unaligned"):
+            try:
+                others[name] = quick_kernel(job, name, args.quality)
+            except BaseException as ex:  # the metric line must not depend on these
+                others[name] = {"error": repr(ex)}
         try:
-            # (a) into pinned storage the caller reuses: what the library itself takes; (b) as a fresh Python bytes
-            # object (malloc'd result + copy): what jpeg.encode_device() costs from Python
-            pinned = torch.empty(in_bytes // 2 + 4096, dtype=torch.uint8).pin_memory()
-            nbytes = jpeg.encode_device_into(pinned, ins[0], opts)
-            n_files, ts, tb = 15, [], []
-            for i in range(n_files):
-                t1 = time.perf_counter()
-                nbytes = jpeg.encode_device_into(pinned, ins[i % nbuf], opts)
-                ts.append(time.perf_counter() - t1)
-            for i in range(7):
-                t1 = time.perf_counter()
-                blob = jpeg.encode_device(ins[i % nbuf], opts)
-                tb.append(time.perf_counter() - t1)
-            dt, dtb = sorted(ts)[n_files // 2], sorted(tb)[3]
-            line["whole_file"] = {"value": round(w * h / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_image": round(dt * 1e3, 3),
-                                  "file_bytes": int(nbytes), "ms_per_image_as_python_bytes": round(dtb * 1e3, 3),
-                                  "path": "device-resident pixels -> coefficient kernel -> device Huffman/pack/stuff kernels "
-                                          "-> file in the caller's pinned host buffer (pixo_hip_jpeg_encode_device_into)"}
-        except Exception as ex:  # the metric line must not depend on this extra
-            line["whole_file"] = {"error": repr(ex)}
-    if not args.no_cpu_baseline and world == 1:
+            others["c5"] = quick_png(job)
+        except BaseException as ex:
+            others["c5"] = {"error": repr(ex)}
+        line["other_configs"] = others
+    if not args.no_cpu_baseline and job.world == 1 and not job.stub:
         try:
-            line["cpu_baseline"] = cpu_baseline(4096, 4096, ss, q, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(4096, 4096, wl.ss, wl.q, args.cpu_seconds)
         except Exception as ex:  # (the GPU numbers above stand on their own)
             line["cpu_baseline"] = {"error": repr(ex)}
         try:
-            ref = cpu_reference_wasm(4096, 4096, ss, q)
+            ref = cpu_reference_wasm(4096, 4096, wl.ss, wl.q)
         except Exception:
             ref = None
         if ref:
             line["cpu_reference"] = ref
     print(json.dumps(line, ensure_ascii=False))
-    if dist is not None:
-        dist.destroy_process_group()
+    job.finish()
+
+
+def whole_file(job, wl):
+    """Not `value`: the whole file (coefficient kernel + device entropy stage + copy of the file to the host) from
+    device-resident pixels, reported beside the kernel-only metric."""
+    torch, jpeg = job.torch, wl.jpeg
+    opts = jpeg.JpegOptions.builder(wl.w, wl.h).quality(wl.q).subsampling(jpeg.Subsampling(wl.ss)).build()
+    try:
+        pinned = torch.empty(wl.in_bytes // 2 + 4096, dtype=torch.uint8).pin_memory()
+        nbytes = jpeg.encode_device_into(pinned, wl.ins[0], opts)
+        n_files, ts, tb = 15, [], []
+        for i in range(n_files):
+            t1 = time.perf_counter()
+            nbytes = jpeg.encode_device_into(pinned, wl.ins[i % wl.nbuf], opts)
+            ts.append(time.perf_counter() - t1)
+        for i in range(7):
+            t1 = time.perf_counter()
+            jpeg.encode_device(wl.ins[i % wl.nbuf], opts)
+            tb.append(time.perf_counter() - t1)
+        dt, dtb = sorted(ts)[n_files // 2], sorted(tb)[3]
+        return {"value": round(wl.w * wl.h / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_image": round(dt * 1e3, 3),
+                "ms_per_image_min": round(min(ts) * 1e3, 3), "file_bytes": int(nbytes), "ms_per_image_as_python_bytes": round(dtb * 1e3, 3),
+                "path": "device-resident pixels -> coefficient kernel -> device Huffman/pack/stuff kernels "
+                        "-> file in the caller's pinned host buffer (pixo_hip_jpeg_encode_device_into)"}
+    except Exception as ex:  # the metric line must not depend on this extra
+        return {"error": repr(ex)}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# c5: PNG row filters
+# ------------------------------------------------------------------------------------------------------------------
+class PngWorkload:
+    def __init__(self, job):
+        import synth
+        from pixo_amd import png
+        torch = job.torch
+        self.job, self.png = job, png
+        self.w = self.h = 4096
+        self.bpp = 4
+        self.base = synth.rgba_noise_alpha1(self.w, self.h, 42 + job.rank)
+        self.in_bytes, self.out_bytes = self.w * self.h * self.bpp, png.filtered_size(self.w, self.h, self.bpp)
+        self.nbuf = 5  # 5 x 134 MB > Infinity Cache
+        host = torch.from_numpy(self.base)
+        dev = job.dev
+        self.ins = [(host.to(dev) ^ torch.tensor(i, dtype=torch.uint8, device=dev)).contiguous() for i in range(self.nbuf)]
+        self.outs = [torch.empty(self.out_bytes, dtype=torch.uint8, device=dev) for _ in range(self.nbuf)]
+        self.sums = [torch.zeros(2 * self.h, dtype=torch.int64, device=dev) for _ in range(self.nbuf)]
+        self.scratch = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def step(self, i):
+        k = i % self.nbuf
+        self.png.apply_filters_async(self.ins[k], self.w, self.h, self.bpp, self.outs[k], self.sums[k], self.scratch,
+                                     self.png.FilterStrategy.ADAPTIVE, 0, self.stream)
+
+    def check(self):
+        """buffer 0 against the reference-made vector of SURVEY §8c (rank 0's input is that very image)"""
+        import numpy as np
+        self.step(0)
+        self.job.sync()
+        adler = self.png.adler32_from_row_sums(self.sums[0].cpu().numpy().view(np.uint64), self.w, self.h, self.bpp)
+        digest = hashlib.sha256(self.outs[0].cpu().numpy().tobytes()).hexdigest()
+        if self.job.rank == 0 and (adler != 0x90CC12E3 or not digest.startswith("240e005d4da54561")):
+            raise SystemExit("bench: filtered stream differs from the reference's — refusing to report a number")
+
+
+def run_png(job, args):
+    """--workload c5: configs[4], 4096x4096 RGBA8 through the PNG row-filter stage (Adaptive strategy)
+    + Adler-32 partials.  Algorithmic bytes (SURVEY §8d): read 4 B/px + write (4 + 1/4096) B/px."""
+    wl = PngWorkload(job)
+    settled = job.settle(wl.step, args.settle_ms)
+    walls, evs = job.time_blocks(wl.step, args.steps, args.warmup, args.blocks)
+    if job.rank == 0 and not os.environ.get("PIXO_BENCH_ABLATION"):
+        wl.check()
+    if job.rank != 0:
+        job.finish()
+        return
+    st = block_stats(walls, args.steps)
+    kernel_ms = statistics.median(evs) / args.steps
+    alg = wl.in_bytes + wl.out_bytes
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    traffic, src = traffic_of("c5")
+    line = {"metric": "Mpixels/s PNG row filters + Adler-32 partials (Adaptive), 4096x4096 RGBA8",
+            "value": round(wl.w * wl.h * job.world / (st["ms_per_step"] * 1e-3) / 1e6, 1),
+            "unit": "Mpixels/s", "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": st["ms_per_step"], "ms_per_step_min": st["ms_per_step_min"], "ms_per_step_max": st["ms_per_step_max"],
+            "blocks": st["blocks"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[4]: 4096x4096 RGBA8, FilterStrategy::Adaptive, rows independent", "width": wl.w, "height": wl.h,
+                       "buffers_rotated": wl.nbuf, "settle_launches_before_warmup": settled,
+                       "parallelism": "one process per GPU, images sharded across ranks, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src,
+                         "kernel": "png_filter_kernel<4, true>", "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3)}}
+    if not args.no_cpu_baseline and job.world == 1:
+        import oracle_lib as O
+        rows = 256  # bounded sample: 256 rows of the same image, one thread
+        t1 = time.perf_counter()
+        O.png_filter(wl.base[: wl.w * rows * wl.bpp], wl.w, rows, wl.bpp, O.S_ADAPTIVE)
+        dt = time.perf_counter() - t1
+        line["cpu_baseline"] = {"value": round(wl.w * rows / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                                "sample": "first %d rows of the same 4096x4096 RGBA image, Adaptive, oracle/pixo_png_oracle.c, gcc -O2, 1 thread" % rows}
+    print(json.dumps(line, ensure_ascii=False))
+    job.finish()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# c4: one 16384x16384 image over the N GPUs
+# ------------------------------------------------------------------------------------------------------------------
+def run_c4(job, args):
+    """configs[3]: MCU-row bands of ONE image resident on the N GPUs; a step = the finished file on rank 0.
+    Strong scaling: the image is fixed, every rank holds 1/N of it."""
+    import numpy as np
+    import synth
+    from pixo_amd import jpeg, sharded
+    torch = job.torch
+    w = h = 16384
+    q = args.quality
+    opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling.S420).build()
+    b = jpeg.band(w, h, 2, 1, job.world, job.rank)
+    rows = b["row_end"] - b["row_begin"]
+    if job.dist is None:  # the exchanges are torch.distributed calls: a world of one still needs a group
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=job.dev)
+        job.dist = dist
+    mine = synth.noise_rows(w, h, 42, b["row_begin"], b["row_end"])
+    d_band = torch.from_numpy(mine).to(job.dev)
+    out = torch.empty(w * h * 3 // 4 + (1 << 20), dtype=torch.uint8).pin_memory() if job.rank == 0 else None
+    state = {}
+
+    def step(i):
+        state["len"] = sharded.encode_banded(d_band, opts, device=job.local_rank, out=out)
+
+    # the coefficient kernel of this rank's band alone (roofline object), HIP events on the launch stream
+    yb, cbn = jpeg.coefficient_geometry(w, rows, 2, 1)
+    ty = torch.empty((yb, 64), dtype=torch.int16, device=job.dev)
+    tcb = torch.empty((cbn, 64), dtype=torch.int16, device=job.dev)
+    tcr = torch.empty((cbn, 64), dtype=torch.int16, device=job.dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def kstep(i):
+        jpeg.coefficients_device(d_band, w, rows, 2, 1, q, ty, tcb, tcr, stream=stream)
+
+    job.settle(kstep, args.settle_ms)
+    _, kev = job.time_blocks(kstep, 20, 5, 5)
+    del ty, tcb, tcr
+    steps = max(1, min(args.steps, 20))
+    walls, _ = job.time_blocks(step, steps, max(1, min(args.warmup, 3)), max(3, min(args.blocks, 7)), events=False)
+    if job.rank != 0:
+        job.finish()
+        return
+    n = state["len"]
+    digest = hashlib.sha256(out[:n].numpy().tobytes()).hexdigest()
+    if (n != 178548465 or digest != C4_SHA256) and not os.environ.get("PIXO_BENCH_ABLATION"):
+        raise SystemExit("bench: the 16384x16384 file differs from the reference's — refusing to report a number")
+    st = block_stats(walls, steps)
+    kernel_ms = statistics.median(kev) / 20
+    alg = 6 * w * rows
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    line = {"metric": "Mpixels/s JPEG encode, whole file, one 16384x16384 RGB8 image q=80 4:2:0 across the GPUs (configs[3])",
+            "value": round(w * h / (st["ms_per_step"] * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "n_gpus": job.world, "steps": steps,
+            "warmup": max(1, min(args.warmup, 3)), "ms_per_step": st["ms_per_step"], "ms_per_step_min": st["ms_per_step_min"],
+            "ms_per_step_max": st["ms_per_step_max"], "blocks": st["blocks"], "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3]: single 16384x16384 RGB8 (noise seed 42) in MCU-row bands across the GPUs, per-band entropy "
+                                   "coding, 3 x i16 + u64 exchanged per band over RCCL, bodies gathered over xGMI, spliced on rank 0",
+                       "width": w, "height": h, "quality": q, "subsampling": "4:2:0", "band_rows_rank0": rows,
+                       "file_bytes": int(n), "file_sha256": digest, "parallelism": "one process per GPU, one band per rank"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "jpeg_coeffs_kernel<M420, L_ALIGNED> on rank 0's band",
+                         "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3)}}
+    print(json.dumps(line, ensure_ascii=False))
+    job.finish()
+
+
+def main():
+    args = parse()
+    job = Job(args)
+    if args.workload == "c5":
+        return run_png(job, args)
+    if args.workload == "c4":
+        return run_c4(job, args)
+    return run_coeffs(job, args)
 
 
 if __name__ == "__main__":

@@ -242,11 +242,28 @@ int pixo_hip_band_encoder_lengths(pixo_hip_band_encoder *encoder, const int16_t 
  * byte with the band before), body = its whole bytes, stuffed, tail = the bits left over. */
 int pixo_hip_band_encoder_pack(pixo_hip_band_encoder *encoder, uint64_t bit_offset, uint8_t **piece,
                                size_t *piece_len);
+/* Step 4 without the copy: the stuffed body stays in the encoder's device buffer (*d_body, *body_len; valid
+ * until the encoder's next call; both may be NULL) and only the 16 header bytes come back.  _copy_body then
+ * moves it into caller storage — typically its final place in the file (pixo_hip_jpeg_splice_layout), each
+ * band over its own GPU's PCIe link; registered / pinned storage is written directly, and `dst` may also be
+ * device memory (the send buffer of a collective). */
+int pixo_hip_band_encoder_pack_device(pixo_hip_band_encoder *encoder, uint64_t bit_offset, uint8_t header[16],
+                                      void **d_body, size_t *body_len);
+int pixo_hip_band_encoder_copy_body(pixo_hip_band_encoder *encoder, uint8_t *dst);
 /* Host: headers (src/jpeg/mod.rs:449-648) + the pieces of all bands in order, shared bytes merged and
  * stuffed, final 1-padding (BitWriterMsb::flush) + EOI = the file pixo::jpeg::encode writes. */
 int pixo_hip_jpeg_splice(const pixo_jpeg_options *options, const uint64_t *total_counts,
                          const uint8_t *const *pieces, const size_t *piece_lens, uint32_t parts,
                          uint8_t **out, size_t *out_len);
+/* The same in two steps, so that no body is copied twice: from the 16-byte headers of all pieces
+ * (`piece_headers`: parts x 16 bytes) _layout tells the file's length and where every body belongs;
+ * _finish writes everything else into `file` — JFIF headers, the bytes neighbouring bands share (merged and
+ * stuffed), the final 1-padding, EOI. */
+int pixo_hip_jpeg_splice_layout(const pixo_jpeg_options *options, const uint64_t *total_counts,
+                                const uint8_t *piece_headers, uint32_t parts, size_t *file_len,
+                                size_t *body_offsets);
+int pixo_hip_jpeg_splice_finish(const pixo_jpeg_options *options, const uint64_t *total_counts,
+                                const uint8_t *piece_headers, uint32_t parts, uint8_t *file, size_t file_len);
 /* Host twins of steps 2-4 for a band whose coefficient tuple is in host memory (`band_rows` pixel rows;
  * what pixo_hip_jpeg_entropy_encode is to the whole tuple). */
 int pixo_hip_jpeg_band_count_host(const int16_t *y, const int16_t *cb, const int16_t *cr,

@@ -31,7 +31,8 @@ SYMBOLS = [
     "pixo_hip_png_adler32_from_row_sums", "pixo_hip_band",
     "pixo_hip_band_encoder_create", "pixo_hip_band_encoder_destroy", "pixo_hip_band_encoder_rows",
     "pixo_hip_band_encoder_coeffs", "pixo_hip_band_encoder_count", "pixo_hip_band_encoder_lengths",
-    "pixo_hip_band_encoder_pack", "pixo_hip_jpeg_splice", "pixo_hip_jpeg_band_count_host",
+    "pixo_hip_band_encoder_pack", "pixo_hip_band_encoder_pack_device", "pixo_hip_band_encoder_copy_body",
+    "pixo_hip_jpeg_splice", "pixo_hip_jpeg_splice_layout", "pixo_hip_jpeg_splice_finish", "pixo_hip_jpeg_band_count_host",
     "pixo_hip_jpeg_band_bits_host", "pixo_hip_jpeg_band_piece_host", "pixo_hip_jpeg_encode_multi",
     "pixo_hip_device_count", "pixo_hip_set_device", "pixo_hip_set_producer_stream", "pixo_hip_trim", "pixo_hip_free",
     "pixo_hip_last_error", "pixo_hip_version",
@@ -107,6 +108,10 @@ def load():
     L.pixo_hip_band_encoder_count.argtypes = [C.c_void_p, i16p, u64p]
     L.pixo_hip_band_encoder_lengths.argtypes = [C.c_void_p, i16p, u64p, u64p]
     L.pixo_hip_band_encoder_pack.argtypes = [C.c_void_p, C.c_uint64, u8pp, szp]
+    L.pixo_hip_band_encoder_pack_device.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p), szp]
+    L.pixo_hip_band_encoder_copy_body.argtypes = [C.c_void_p, C.c_void_p]
+    L.pixo_hip_jpeg_splice_layout.argtypes = [optp, u64p, C.c_void_p, C.c_uint32, szp, szp]
+    L.pixo_hip_jpeg_splice_finish.argtypes = [optp, u64p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.pixo_hip_jpeg_splice.argtypes = [optp, u64p, C.POINTER(C.c_void_p), szp, C.c_uint32, u8pp, szp]
     L.pixo_hip_jpeg_band_count_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, optp, C.c_uint32, i16p, u64p]
     L.pixo_hip_jpeg_band_bits_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, optp, C.c_uint32, i16p, u64p, u64p]

@@ -1444,11 +1444,11 @@ int pixo_hip_band_encoder_lengths(pixo_hip_band_encoder *e, const int16_t prev_d
     return PIXO_OK;
 }
 
-int pixo_hip_band_encoder_pack(pixo_hip_band_encoder *e, uint64_t bit_offset, uint8_t **piece, size_t *piece_len)
+int pixo_hip_band_encoder_pack_device(pixo_hip_band_encoder *e, uint64_t bit_offset, uint8_t header[16], void **d_body,
+                                      size_t *body_len)
 {
     PIXO_REQUIRE(e);
-    PIXO_REQUIRE(piece);
-    PIXO_REQUIRE(piece_len);
+    PIXO_REQUIRE(header);
     if (e->stage < 2) return fail(PIXO_ERR_COMPRESSION, "Compression error: band encoder: lengths first");
     Context &c = *e->c;
     PIXO_ON_DEVICE_OF(c);
@@ -1456,23 +1456,60 @@ int pixo_hip_band_encoder_pack(pixo_hip_band_encoder *e, uint64_t bit_offset, ui
     int tail_bits = 0;
     int rc = scan_pack(c, e->job, c.stream, bit_offset, &head, &tail_bits, &tail);
     if (rc) return rc;
-    const size_t body = e->job.scan_bytes, total = pixo_host::kPieceHeader + body;
-    uint8_t *p = static_cast<uint8_t *>(std::malloc(total));
-    if (!p) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
+    HIP_TRY(hipStreamSynchronize(c.stream)); // the body is complete in the encoder's device buffer
     std::vector<uint8_t> hdr;
     pixo_host::make_piece(hdr, e->job.head_bits, head, tail_bits, tail, nullptr, 0);
-    std::memcpy(p, hdr.data(), pixo_host::kPieceHeader);
-    for (int i = 0; i < 8; ++i) p[8 + i] = static_cast<uint8_t>(static_cast<uint64_t>(body) >> (8 * i));
-    if (body) { // pinned bounce (a device-to-host copy into fresh pageable memory pins the pages first)
-        if ((rc = c.reserve_hfile(body))) { std::free(p); return rc; }
-        HIP_TRY(hipMemcpyAsync(c.h_file, c.e_out.p, body, hipMemcpyDeviceToHost, c.stream));
+    const uint64_t body = e->job.scan_bytes;
+    for (int i = 0; i < 8; ++i) hdr[8 + i] = static_cast<uint8_t>(body >> (8 * i));
+    std::memcpy(header, hdr.data(), pixo_host::kPieceHeader);
+    if (d_body) *d_body = c.e_out.p;
+    if (body_len) *body_len = static_cast<size_t>(body);
+    e->stage = 3;
+    return PIXO_OK;
+}
+
+int pixo_hip_band_encoder_copy_body(pixo_hip_band_encoder *e, uint8_t *dst)
+{
+    PIXO_REQUIRE(e);
+    if (e->stage < 3) return fail(PIXO_ERR_COMPRESSION, "Compression error: band encoder: pack first");
+    Context &c = *e->c;
+    PIXO_ON_DEVICE_OF(c);
+    const size_t body = static_cast<size_t>(e->job.scan_bytes);
+    if (!body) return PIXO_OK;
+    PIXO_REQUIRE(dst);
+    hipPointerAttribute_t attr;
+    const bool known = hipPointerGetAttributes(&attr, dst) == hipSuccess;
+    if (!known) (void)hipGetLastError(); // (plain malloc memory is "invalid value" to the runtime)
+    if (known && (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeDevice)) {
+        // registered / hipHostMalloc'd storage: the device-to-host copy is the only pass over the bytes;
+        // device storage (e.g. the send buffer of a collective): device to device
+        HIP_TRY(hipMemcpyAsync(dst, c.e_out.p, body, hipMemcpyDefault, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
-        big_copy(p + pixo_host::kPieceHeader, c.h_file, body);
-    } else {
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        return PIXO_OK;
     }
+    // pageable destination: through the context's pinned buffer (a direct copy makes the runtime pin the pages first)
+    int rc = c.reserve_hfile(body);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c.h_file, c.e_out.p, body, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    std::memcpy(dst, c.h_file, body);
+    return PIXO_OK;
+}
+
+int pixo_hip_band_encoder_pack(pixo_hip_band_encoder *e, uint64_t bit_offset, uint8_t **piece, size_t *piece_len)
+{
+    PIXO_REQUIRE(piece);
+    PIXO_REQUIRE(piece_len);
+    uint8_t header[pixo_host::kPieceHeader];
+    size_t body = 0;
+    int rc = pixo_hip_band_encoder_pack_device(e, bit_offset, header, nullptr, &body);
+    if (rc) return rc;
+    uint8_t *p = static_cast<uint8_t *>(std::malloc(pixo_host::kPieceHeader + body));
+    if (!p) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
+    std::memcpy(p, header, pixo_host::kPieceHeader);
+    if ((rc = pixo_hip_band_encoder_copy_body(e, p + pixo_host::kPieceHeader))) { std::free(p); return rc; }
     *piece = p;
-    *piece_len = total;
+    *piece_len = pixo_host::kPieceHeader + body;
     return PIXO_OK;
 }
 
@@ -1505,6 +1542,44 @@ int pixo_hip_jpeg_splice(const pixo_jpeg_options *options, const uint64_t *total
     std::vector<uint8_t> v;
     if ((rc = pixo_host::splice_file(*options, h, pieces, piece_lens, parts, v, msg))) return fail(rc, msg);
     return hand_over(v, out, out_len);
+}
+
+int pixo_hip_jpeg_splice_layout(const pixo_jpeg_options *options, const uint64_t *total_counts, const uint8_t *piece_headers,
+                                uint32_t parts, size_t *file_len, size_t *body_offsets)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(piece_headers);
+    PIXO_REQUIRE(file_len);
+    PIXO_REQUIRE(body_offsets);
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    pixo_host::HuffSet h;
+    if ((rc = tables_for_splice(*options, total_counts, h))) return rc;
+    pixo_host::SpliceLayout l;
+    if ((rc = pixo_host::splice_layout(*options, h, piece_headers, parts, l, msg))) return fail(rc, msg);
+    *file_len = l.file_len;
+    for (uint32_t k = 0; k < parts; ++k) body_offsets[k] = l.body_off[k];
+    return PIXO_OK;
+}
+
+int pixo_hip_jpeg_splice_finish(const pixo_jpeg_options *options, const uint64_t *total_counts, const uint8_t *piece_headers,
+                                uint32_t parts, uint8_t *file, size_t file_len)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(piece_headers);
+    PIXO_REQUIRE(file);
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    pixo_host::HuffSet h;
+    if ((rc = tables_for_splice(*options, total_counts, h))) return rc;
+    pixo_host::SpliceLayout l;
+    if ((rc = pixo_host::splice_layout(*options, h, piece_headers, parts, l, msg))) return fail(rc, msg);
+    if (file_len != l.file_len)
+        return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(l.file_len) + " bytes");
+    pixo_host::splice_finish(l, file);
+    return PIXO_OK;
 }
 
 // ---- host twins of the band encoder (a band's tuple in host memory) -----------------------------------
@@ -1615,31 +1690,25 @@ int pixo_hip_jpeg_encode_multi(const uint8_t *data, size_t data_len, const pixo_
         int16_t last_dc[3] = {0, 0, 0}, prev_dc[3] = {0, 0, 0};
         uint64_t counts[PIXO_HIP_COUNT_WORDS];
         uint64_t bits = 0;
-        uint8_t *piece = nullptr;
-        size_t piece_len = 0;
         int rc = PIXO_OK;
         std::string error;
     };
     std::vector<Band> bands(parts);
     std::vector<uint64_t> total_counts(PIXO_HIP_COUNT_WORDS, 0);
+    std::vector<uint8_t> headers(static_cast<size_t>(parts) * pixo_host::kPieceHeader, 0);
+    pixo_host::SpliceLayout layout;
+    uint8_t *file = nullptr;
     PhaseBarrier barrier(parts);
     std::atomic<bool> failed{false};
     auto body = [&](unsigned k) {
         Band &b = bands[k];
         auto step = [&](int r) { if (r && !b.rc) { b.rc = r; b.error = t_error; failed.store(true); } };
         step(pixo_hip_band_encoder_create(options, parts, k, devices[k], &b.enc));
-        if (b.enc) {
-            uint32_t r0 = 0, r1 = 0;
-            (void)pixo_hip_band_encoder_rows(b.enc, &r0, &r1);
-            step(pixo_hip_band_encoder_coeffs(b.enc, data + static_cast<size_t>(r0) * o.width * bpp, 0, b.last_dc));
-        }
+        if (b.enc) step(pixo_hip_band_encoder_coeffs(b.enc, data + static_cast<size_t>(b.enc->row_begin) * o.width * bpp, 0, b.last_dc));
         barrier.arrive(); // ---- exchange 1: the DCs at the band boundaries (3 x i16 per band)
         if (!failed.load()) {
-            for (unsigned j = 0; j < k; ++j) { // predictors = last DCs of the nearest band above that has rows
-                uint32_t r0 = 0, r1 = 0;
-                (void)pixo_hip_band_encoder_rows(bands[j].enc, &r0, &r1);
-                if (r1 > r0) std::memcpy(b.prev_dc, bands[j].last_dc, sizeof b.prev_dc);
-            }
+            for (unsigned j = 0; j < k; ++j) // predictors = last DCs of the nearest band above that has rows
+                if (bands[j].enc->rows) std::memcpy(b.prev_dc, bands[j].last_dc, sizeof b.prev_dc);
             if (o.optimize_huffman) step(pixo_hip_band_encoder_count(b.enc, b.prev_dc, b.counts));
         }
         if (o.optimize_huffman) {
@@ -1649,26 +1718,36 @@ int pixo_hip_jpeg_encode_multi(const uint8_t *data, size_t data_len, const pixo_
                     for (int i = 0; i < PIXO_HIP_COUNT_WORDS; ++i) total_counts[i] += bands[j].counts[i];
             barrier.arrive();
         }
-        if (!failed.load()) step(pixo_hip_band_encoder_lengths(b.enc, b.prev_dc, o.optimize_huffman ? total_counts.data() : nullptr, &b.bits));
+        const uint64_t *tc = o.optimize_huffman ? total_counts.data() : nullptr;
+        if (!failed.load()) step(pixo_hip_band_encoder_lengths(b.enc, b.prev_dc, tc, &b.bits));
         barrier.arrive(); // ---- exchange 2: bits per band (u64 per band) -> every band's bit offset
         if (!failed.load()) {
             uint64_t off = 0;
             for (unsigned j = 0; j < k; ++j) off += bands[j].bits;
-            step(pixo_hip_band_encoder_pack(b.enc, off, &b.piece, &b.piece_len));
+            step(pixo_hip_band_encoder_pack_device(b.enc, off, headers.data() + static_cast<size_t>(k) * pixo_host::kPieceHeader, nullptr, nullptr));
         }
+        barrier.arrive(); // ---- exchange 3: the 16-byte piece headers -> where every body goes in the file
+        if (k == 0 && !failed.load()) {
+            pixo_host::HuffSet h;
+            std::string m;
+            int r = tables_for_splice(o, tc, h);
+            if (!r && (r = pixo_host::splice_layout(o, h, headers.data(), parts, layout, m))) r = fail(r, m);
+            if (!r && !(file = static_cast<uint8_t *>(std::malloc(layout.file_len)))) r = fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
+            step(r);
+        }
+        barrier.arrive();
+        // every band's bytes go straight to their final place, over its own GPU's PCIe link, on its own thread
+        if (!failed.load()) step(pixo_hip_band_encoder_copy_body(b.enc, file + layout.body_off[k]));
         pixo_hip_band_encoder_destroy(b.enc);
         b.enc = nullptr;
     };
     run_on_threads(parts, body);
-    auto cleanup = [&] { for (Band &b : bands) std::free(b.piece); };
     for (Band &b : bands)
-        if (b.rc) { const int r = b.rc; const std::string e = b.error; cleanup(); return fail(r, e); }
-    std::vector<const uint8_t *> pieces(parts);
-    std::vector<size_t> lens(parts);
-    for (uint32_t k = 0; k < parts; ++k) { pieces[k] = bands[k].piece; lens[k] = bands[k].piece_len; }
-    rc = pixo_hip_jpeg_splice(options, o.optimize_huffman ? total_counts.data() : nullptr, pieces.data(), lens.data(), parts, out, out_len);
-    cleanup();
-    return rc;
+        if (b.rc) { const int r = b.rc; const std::string e = b.error; std::free(file); return fail(r, e); }
+    pixo_host::splice_finish(layout, file);
+    *out = file;
+    *out_len = layout.file_len;
+    return PIXO_OK;
 }
 
 int pixo_hip_band(uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling, uint32_t parts,

@@ -718,27 +718,27 @@ void band_piece(const int16_t *y, const int16_t *cb, const int16_t *cr, const pi
                body.data(), body.size());
 }
 
-int splice_file(const pixo_jpeg_options &o, const HuffSet &h, const uint8_t *const *pieces, const size_t *lens, uint32_t parts,
-                std::vector<uint8_t> &out, std::string &msg)
+int splice_layout(const pixo_jpeg_options &o, const HuffSet &h, const uint8_t *piece_headers, uint32_t parts, SpliceLayout &l,
+                  std::string &msg)
 {
-    out.clear();
-    size_t total = 1024;
-    for (uint32_t k = 0; k < parts; ++k) {
-        if (!pieces[k] || lens[k] < kPieceHeader) { msg = "Compression error: band piece " + std::to_string(k) + " is malformed"; return PIXO_ERR_COMPRESSION; }
-        total += lens[k];
-    }
-    out.reserve(total);
-    write_headers(out, o, make_quant_tables(o.quality), h);
+    l.head.clear();
+    write_headers(l.head, o, make_quant_tables(o.quality), h);
+    l.body_off.assign(parts, 0);
+    l.body_len.assign(parts, 0);
+    l.fixups.clear();
+    size_t pos = l.head.size();
     uint32_t acc = 0;
     int nacc = 0; // bits of the byte two neighbouring bands share
-    auto emit = [&](uint8_t b) { out.push_back(b); if (b == 0xFF) out.push_back(0x00); };
+    auto emit = [&](uint8_t b) {
+        l.fixups.emplace_back(pos++, b);
+        if (b == 0xFF) l.fixups.emplace_back(pos++, static_cast<uint8_t>(0x00)); // bits.rs:245-253
+    };
     for (uint32_t k = 0; k < parts; ++k) {
-        const uint8_t *p = pieces[k];
+        const uint8_t *p = piece_headers + size_t{k} * kPieceHeader;
         const int head_n = p[0], tail_n = p[2];
         uint64_t body_len = 0;
         for (int i = 0; i < 8; ++i) body_len |= static_cast<uint64_t>(p[8 + i]) << (8 * i);
-        if (head_n > 7 || tail_n > 7 || body_len != lens[k] - kPieceHeader || nacc + head_n > 8 ||
-            ((body_len || tail_n) && nacc + head_n != 8 && nacc + head_n != 0)) {
+        if (head_n > 7 || tail_n > 7 || nacc + head_n > 8 || ((body_len || tail_n) && nacc + head_n != 8 && nacc + head_n != 0)) {
             msg = "Compression error: band piece " + std::to_string(k) + " does not start at the bit offset the bands before it end at";
             return PIXO_ERR_COMPRESSION;
         }
@@ -747,11 +747,41 @@ int splice_file(const pixo_jpeg_options &o, const HuffSet &h, const uint8_t *con
             nacc += head_n;
             if (nacc == 8) { emit(static_cast<uint8_t>(acc)); acc = 0; nacc = 0; }
         }
-        out.insert(out.end(), p + kPieceHeader, p + kPieceHeader + body_len);
+        l.body_off[k] = pos;
+        l.body_len[k] = static_cast<size_t>(body_len);
+        pos += static_cast<size_t>(body_len);
         if (tail_n) { acc = p[3] & ((1u << tail_n) - 1u); nacc = tail_n; }
     }
     if (nacc) emit(static_cast<uint8_t>((acc << (8 - nacc)) | ((1u << (8 - nacc)) - 1u))); // BitWriterMsb::flush, bits.rs:261-272
-    be16(out, 0xFFD9);
+    l.fixups.emplace_back(pos++, static_cast<uint8_t>(0xFF)); // EOI
+    l.fixups.emplace_back(pos++, static_cast<uint8_t>(0xD9));
+    l.file_len = pos;
+    return PIXO_OK;
+}
+
+void splice_finish(const SpliceLayout &l, uint8_t *file)
+{
+    std::memcpy(file, l.head.data(), l.head.size());
+    for (const auto &f : l.fixups) file[f.first] = f.second;
+}
+
+int splice_file(const pixo_jpeg_options &o, const HuffSet &h, const uint8_t *const *pieces, const size_t *lens, uint32_t parts,
+                std::vector<uint8_t> &out, std::string &msg)
+{
+    std::vector<uint8_t> headers(size_t{parts} * kPieceHeader);
+    for (uint32_t k = 0; k < parts; ++k) {
+        if (!pieces[k] || lens[k] < kPieceHeader) { msg = "Compression error: band piece " + std::to_string(k) + " is malformed"; return PIXO_ERR_COMPRESSION; }
+        std::memcpy(headers.data() + size_t{k} * kPieceHeader, pieces[k], kPieceHeader);
+    }
+    SpliceLayout l;
+    int rc = splice_layout(o, h, headers.data(), parts, l, msg);
+    if (rc) return rc;
+    for (uint32_t k = 0; k < parts; ++k)
+        if (l.body_len[k] != lens[k] - kPieceHeader) { msg = "Compression error: band piece " + std::to_string(k) + " is malformed"; return PIXO_ERR_COMPRESSION; }
+    out.assign(l.file_len, 0);
+    for (uint32_t k = 0; k < parts; ++k)
+        if (l.body_len[k]) std::memcpy(out.data() + l.body_off[k], pieces[k] + kPieceHeader, l.body_len[k]);
+    splice_finish(l, out.data());
     return PIXO_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pixo_hip.h"
@@ -96,6 +97,18 @@ uint64_t band_bits(const int16_t *y, const int16_t *cb, const int16_t *cr, const
                    const int16_t prev_dc[3]);
 void band_piece(const int16_t *y, const int16_t *cb, const int16_t *cr, const pixo_jpeg_options &band, const HuffSet &h,
                 const int16_t prev_dc[3], uint64_t bit_offset, std::vector<uint8_t> &piece);
+// Where everything goes in the finished file, from the 16-byte piece headers alone: the JFIF headers, every
+// band's body (so that it can be copied straight to its final place, e.g. by its own GPU), and the bytes
+// in between — bytes two bands share (merged, stuffed), the final 1-padding, EOI — as (position, value).
+struct SpliceLayout {
+    std::vector<uint8_t> head;
+    std::vector<size_t> body_off, body_len;
+    std::vector<std::pair<size_t, uint8_t>> fixups;
+    size_t file_len = 0;
+};
+int splice_layout(const pixo_jpeg_options &o, const HuffSet &h, const uint8_t *piece_headers, uint32_t parts, SpliceLayout &l,
+                  std::string &msg);
+void splice_finish(const SpliceLayout &l, uint8_t *file); // headers + fixups (the bodies are the caller's)
 // headers + the pieces merged bit-exactly (shared bytes OR-ed and stuffed, final 1-padding) + EOI
 int splice_file(const pixo_jpeg_options &o, const HuffSet &h, const uint8_t *const *pieces, const size_t *lens, uint32_t parts,
                 std::vector<uint8_t> &out, std::string &msg);

@@ -437,6 +437,29 @@ class BandEncoder:
             _raise(rc)
         return bits.value
 
+    def pack_device(self, bit_offset: int):
+        """Step 4 without the copy: returns (16-byte piece header, length of the stuffed body); the body stays
+        in the encoder's device buffer until `copy_body`."""
+        hdr = (C.c_uint8 * 16)()
+        n = C.c_size_t()
+        rc = self._L.pixo_hip_band_encoder_pack_device(self._h, bit_offset, hdr, None, C.byref(n))
+        if rc:
+            _raise(rc)
+        return bytes(hdr), n.value
+
+    def copy_body(self, dst) -> None:
+        """The packed body -> `dst`: a torch tensor (CPU, ideally pinned, or on the encoder's GPU), a numpy
+        uint8 array, or a raw address."""
+        if hasattr(dst, "data_ptr"):
+            ptr = dst.data_ptr()
+        elif hasattr(dst, "ctypes"):
+            ptr = dst.ctypes.data
+        else:
+            ptr = int(dst)
+        rc = self._L.pixo_hip_band_encoder_copy_body(self._h, ptr)
+        if rc:
+            _raise(rc)
+
     def pack(self, bit_offset: int) -> bytes:
         out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
         rc = self._L.pixo_hip_band_encoder_pack(self._h, bit_offset, C.byref(out), C.byref(n))
@@ -507,6 +530,36 @@ def splice(options: JpegOptions, pieces, total_counts=None) -> bytes:
     if rc:
         _raise(rc)
     return _take(L, out, n)
+
+
+def splice_layout(options: JpegOptions, headers, total_counts=None):
+    """From the 16-byte headers of all pieces: (file length, [offset of every band's body in the file])."""
+    L = _lib.load()
+    n_parts = len(headers)
+    blob = np.frombuffer(b"".join(h[:16] for h in headers), np.uint8)
+    tc = _counts(total_counts)
+    flen = C.c_size_t()
+    offs = (C.c_size_t * n_parts)()
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_splice_layout(C.byref(oc), tc.ctypes.data_as(C.POINTER(C.c_uint64)) if tc is not None else None,
+                                       blob.ctypes.data, n_parts, C.byref(flen), offs)
+    if rc:
+        _raise(rc)
+    return flen.value, list(offs)
+
+
+def splice_finish(options: JpegOptions, headers, file, file_len, total_counts=None) -> None:
+    """Everything of the file that is not a band's body — JFIF headers, shared bytes, padding, EOI — into
+    `file` (torch CPU tensor / numpy uint8 array holding `file_len` bytes, the bodies already in place)."""
+    L = _lib.load()
+    blob = np.frombuffer(b"".join(h[:16] for h in headers), np.uint8)
+    tc = _counts(total_counts)
+    ptr = file.data_ptr() if hasattr(file, "data_ptr") else file.ctypes.data
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_splice_finish(C.byref(oc), tc.ctypes.data_as(C.POINTER(C.c_uint64)) if tc is not None else None,
+                                       blob.ctypes.data, len(headers), ptr, file_len)
+    if rc:
+        _raise(rc)
 
 
 def encode_multi(data, options: JpegOptions, devices) -> bytes:

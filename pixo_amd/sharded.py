@@ -89,10 +89,23 @@ def _all_gather_i64(values, group, device):
     return [o.cpu().tolist() for o in out]
 
 
-def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn=None):
+_pinned = {}  # grow-only pinned staging for the finished file on the destination rank
+
+
+def _pinned_file(n):
+    import torch
+    t = _pinned.get("file")
+    if t is None or t.numel() < n:
+        t = torch.empty(n + n // 4 + 4096, dtype=torch.uint8).pin_memory()
+        _pinned["file"] = t
+    return t
+
+
+def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn=None, out=None):
     """Collective over `group`.  Every rank passes the same `options` and ITS band's rows
     (`jpeg.band(w, h, ct, ss, world, rank)`: rows [row_begin, row_end), tightly packed) as host bytes /
-    uint8 array or as a torch uint8 tensor on its GPU.  Returns the JFIF bytes on rank `dst`, None elsewhere.
+    uint8 array or as a torch uint8 tensor on its GPU.  Returns the JFIF bytes on rank `dst`, None elsewhere;
+    with `out` (a CPU uint8 tensor on `dst`, ideally pinned) the file is written there and its length returned.
 
     `device`: HIP device index of this rank (default: torch's current device); `coeff_fn(band_pixels,
     band_options) -> (y, cb, cr)`: tests substitute a CPU function, which also routes the entropy stage
@@ -135,14 +148,46 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
         bits = enc.lengths(prev, total_counts)
         # exchange 2: bits per band -> this band's bit offset
         all_bits = [b[0] for b in _all_gather_i64([bits], group, tdev)]
-        piece = enc.pack(sum(all_bits[:rank]))
+        offset = sum(all_bits[:rank])
+        if not on_gpu:  # host twins: whole pieces, gathered as objects
+            piece = enc.pack(offset)
+            pieces = [None] * world if rank == dst else None
+            dist.gather_object(piece, pieces, dst=dst, group=group)
+            if rank != dst:
+                return None
+            blob = jpeg.splice(options, pieces, total_counts)
+            if out is None:
+                return blob
+            out[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+            return len(blob)
+        # device: the body stays in HBM; exchange 3 = the 16-byte piece headers -> the file's layout
+        hdr, n = enc.pack_device(offset)
+        words = np.frombuffer(hdr, np.int64)
+        all_hdr = [np.array(h, np.int64).tobytes() for h in _all_gather_i64([int(words[0]), int(words[1])], group, tdev)]
+        file_len, body_off = jpeg.splice_layout(options, all_hdr, total_counts)
+        lens = [int(np.frombuffer(h, np.uint64)[1]) for h in all_hdr]
+        if world == 1:
+            file = out if out is not None else _pinned_file(file_len)
+            enc.copy_body(file[body_off[0]:])  # device -> its final place in the (pinned) file
+        else:
+            # the bodies travel to dst over xGMI (one gather of equal-sized buffers), then dst's PCIe link
+            send = torch.empty(max(max(lens), 1), dtype=torch.uint8, device=tdev)
+            enc.copy_body(send)
+            recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+            dist.gather(send, recv, dst=dst, group=group)
+            if rank != dst:
+                return None
+            file = out if out is not None else _pinned_file(file_len)
+            for k in range(world):
+                if lens[k]:
+                    file[body_off[k]: body_off[k] + lens[k]].copy_(recv[k][: lens[k]], non_blocking=True)
+            torch.cuda.synchronize(tdev)
+        jpeg.splice_finish(options, all_hdr, file, file_len, total_counts)
+        if out is not None:
+            return file_len
+        return file[:file_len].numpy().tobytes()
     finally:
         enc.close()
-    pieces = [None] * world if rank == dst else None
-    dist.gather_object(piece, pieces, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return jpeg.splice(options, pieces, total_counts)
 
 
 def encode_gathered(data, options, group=None, coeff_fn=None, dst=0):

@@ -49,8 +49,26 @@ def lcg_bytes(n: int, seed: int) -> np.ndarray:
     return out
 
 
+def lcg_skip(seed: int, k: int) -> int:
+    """The generator's state after k steps (affine map composed by repeated squaring, mod 2^32)."""
+    M = 0xFFFFFFFF
+    a, c = _A, _C          # one step: x -> a x + c
+    ra, rc = 1, 0          # identity
+    while k:
+        if k & 1:
+            ra, rc = (a * ra) & M, (a * rc + c) & M
+        a, c = (a * a) & M, (a * c + c) & M
+        k >>= 1
+    return (ra * (seed & M) + rc) & M
+
+
 def noise(w: int, h: int, seed: int = 42) -> np.ndarray:
     return lcg_bytes(w * h * 3, seed)
+
+
+def noise_rows(w: int, h: int, seed: int, row_begin: int, row_end: int) -> np.ndarray:
+    """Rows [row_begin, row_end) of noise(w, h, seed) without generating the rows above them."""
+    return lcg_bytes((row_end - row_begin) * w * 3, lcg_skip(seed, row_begin * w * 3))
 
 
 def extremes(w: int, h: int, seed: int = 42) -> np.ndarray:

@@ -96,3 +96,29 @@ def test_splice_rejects_pieces_that_do_not_fit():
         jpeg.splice(o, [good, shifted])
     with pytest.raises(Exception, match="malformed"):
         jpeg.splice(o, [good[:10]])
+
+
+def test_layout_and_finish_place_every_byte_like_the_one_step_splice():
+    """pixo_hip_jpeg_splice_layout / _finish: the bodies are copied to the offsets the layout names (what every
+    GPU does with its own band), the rest is written by _finish — same file as pixo_hip_jpeg_splice."""
+    w, h, parts = 120, 16 * 11, 5
+    px = synth.extremes(w, h, 3)
+    o = jpeg.JpegOptions.builder(w, h).quality(100).subsampling(jpeg.Subsampling.S420).build()
+    bands = [jpeg.band(w, h, 2, 1, parts, k) for k in range(parts)]
+    pieces, prev, off = [], [0, 0, 0], 0
+    for b in bands:
+        rows = b["row_end"] - b["row_begin"]
+        y, cb, cr = O.coeffs(px[b["row_begin"] * w * 3: b["row_end"] * w * 3], w, rows, 2, 1, 100)
+        pieces.append(jpeg.band_piece_host(y, cb, cr, o, rows, prev, off))
+        off += jpeg.band_bits_host(y, cb, cr, o, rows, prev)
+        prev = [int(y[-1, 0]), int(cb[-1, 0]), int(cr[-1, 0])]
+    headers = [p[:16] for p in pieces]
+    file_len, body_off = jpeg.splice_layout(o, headers)
+    buf = np.full(file_len, 0xA5, np.uint8)
+    for p, at in zip(pieces, body_off):
+        buf[at: at + len(p) - 16] = np.frombuffer(p[16:], np.uint8)
+    jpeg.splice_finish(o, headers, buf, file_len)
+    want = O.encode(px, O.make_options(w, h, 2, 100, 1))
+    assert buf.tobytes() == want == jpeg.splice(o, pieces)
+    with pytest.raises(Exception, match="too small"):
+        jpeg.splice_finish(o, headers, buf, file_len - 1)

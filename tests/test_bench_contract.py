@@ -29,8 +29,35 @@ def test_committed_bench_line_follows_the_contract():
     assert c["kind"] in ("port", "reference")
 
 
+def _stub_line(gpus, extra=()):
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--gpus", str(gpus), "--steps", "4", "--warmup", "1",
+                        "--blocks", "3", "--no-cpu-baseline", *extra], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_honours_gpus_when_started_without_a_launcher():
+    """`python bench.py --gpus 2` (the form the driver uses for N = 1) must run TWO ranks and say so: the script
+    re-executes itself under torch.distributed.run.  Plumbing only (--stub: gloo, the step is a sleep)."""
+    line = _stub_line(2)
+    assert line["n_gpus"] == 2 and line["data"] == "stub" and line["steps"] == 4 and line["blocks"] == 3
+    assert line["ms_per_step_min"] <= line["ms_per_step"] <= line["ms_per_step_max"]
+    assert _stub_line(1)["n_gpus"] == 1
+
+
+def test_bench_refuses_a_launcher_world_that_differs_from_gpus():
+    import subprocess, sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
 def test_bench_parses_its_flags_without_a_gpu():
     import subprocess, sys
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], stdout=subprocess.PIPE, check=True).stdout.decode()
-    for flag in ("--gpus", "--steps", "--warmup", "--workload"):
+    for flag in ("--gpus", "--steps", "--warmup", "--workload", "--blocks", "c4", "c2_unaligned"):
         assert flag in out

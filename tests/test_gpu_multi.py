@@ -1,0 +1,199 @@
+"""One image across several devices inside one process (`pixo_hip_jpeg_encode_multi`, the band encoder,
+the splice) and the lifetime of the per-thread contexts — on the GPU, through the C ABI.  The test box has
+ONE GPU: the bands of an image all go to device 0 (a device may be listed more than once), each on its own
+host thread with its own context and stream, which exercises every exchange and the splice exactly as 8
+devices would."""
+import hashlib
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+from pixo_amd import ColorType, jpeg
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _opts(w, h, ct, ss, q, **kw):
+    b = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss))
+    for k, v in kw.items():
+        b = getattr(b, k)(v)
+    return b.build()
+
+
+@pytest.mark.parametrize("parts", [1, 2, 3, 8, 13, 30])
+@pytest.mark.parametrize("case", [(200, 203, 2, 1, 75), (1027, 333, 2, 1, 80), (97, 161, 2, 0, 90), (64, 100, 0, 0, 50)])
+def test_multi_device_file_equals_the_single_device_file(case, parts):
+    w, h, ct, ss, q = case
+    px = synth.noise_gray(w, h, 5) if ct == 0 else synth.noise(w, h, 5)
+    want = O.encode(px, O.make_options(w, h, ct, q, ss))
+    assert jpeg.encode_multi(px, _opts(w, h, ct, ss, q), [0] * parts) == want
+
+
+@pytest.mark.parametrize("parts", [2, 5, 8])
+def test_multi_device_optimised_tables_and_smooth_content(parts):
+    w, h = 640, 400
+    for px in (synth.noise(w, h, 6), synth.gradient_rgb(w, h)):
+        for ss in (0, 1):
+            want = O.encode(px, O.make_options(w, h, 2, 85, ss, optimize_huffman=True))
+            assert jpeg.encode_multi(px, _opts(w, h, 2, ss, 85, optimize_huffman=True), [0] * parts) == want
+            assert jpeg.encode_multi(px, _opts(w, h, 2, ss, 85), [0] * parts) == O.encode(px, O.make_options(w, h, 2, 85, ss))
+
+
+def test_multi_device_bands_of_a_few_bits_and_0xff_at_the_seams():
+    w, h = 8, 8 * 24  # flat gray: six bits per block, one block per band
+    px = np.full(w * h, 128, np.uint8)
+    assert jpeg.encode_multi(px, _opts(w, h, 0, 0, 80), [0] * 24) == O.encode(px, O.make_options(w, h, 0, 80, 0))
+    w, h = 48, 16 * 37  # saturated noise at q=100: 0xFF bytes everywhere, also in the bytes two bands share
+    px = synth.extremes(w, h, 11)
+    for parts in (2, 9, 37):
+        assert jpeg.encode_multi(px, _opts(w, h, 2, 1, 100), [0] * parts) == O.encode(px, O.make_options(w, h, 2, 100, 1))
+
+
+def test_multi_device_falls_back_to_one_device_for_progressive_and_restart_files():
+    w, h = 333, 211
+    px = synth.noise(w, h, 8)
+    for kw, okw in (({"restart_interval": 5}, {"restart": 5}), ({"progressive": True}, {"progressive": True}),
+                    ({"progressive": True, "trellis_quant": True, "optimize_huffman": True},
+                     {"progressive": True, "trellis": True, "optimize_huffman": True})):
+        assert jpeg.encode_multi(px, _opts(w, h, 2, 1, 80, **kw), [0, 0, 0]) == O.encode(px, O.make_options(w, h, 2, 80, 1, **okw))
+
+
+def test_band_encoder_pieces_equal_the_host_twins():
+    """Device band encoder against the host twin, step by step: last DCs, counts, bits and the piece itself
+    (head bits, stuffed body, tail bits), at every bit offset modulo 8."""
+    w, h, parts = 520, 330, 4
+    px = synth.noise(w, h, 12)
+    for optimize in (False, True):
+        o = _opts(w, h, 2, 1, 80, optimize_huffman=optimize)
+        prev = [0, 0, 0]
+        for k in range(parts):
+            enc = jpeg.BandEncoder(o, parts, k, 0)
+            rows = enc.row_end - enc.row_begin
+            sub = px[enc.row_begin * w * 3: enc.row_end * w * 3]
+            y, cb, cr = O.coeffs(sub, w, rows, 2, 1, 80)
+            last = enc.coeffs(sub)
+            assert last == [int(y[-1, 0]), int(cb[-1, 0]), int(cr[-1, 0])]
+            total = None
+            if optimize:
+                total = enc.count(prev)
+                assert np.array_equal(total, jpeg.band_count_host(y, cb, cr, o, rows, prev))
+            bits = enc.lengths(prev, total)
+            assert bits == jpeg.band_bits_host(y, cb, cr, o, rows, prev, total)
+            for off in range(8):
+                assert enc.pack(1000 + off) == jpeg.band_piece_host(y, cb, cr, o, rows, prev, 1000 + off, total), (k, off)
+            enc.close()
+            prev = last
+
+
+def test_band_encoder_refuses_option_sets_a_band_cannot_code():
+    from pixo_amd import error
+    with pytest.raises(error.Error, match="baseline scans without restart markers"):
+        jpeg.BandEncoder(_opts(64, 64, 2, 1, 80, progressive=True), 2, 0, 0)
+    with pytest.raises(error.Error, match="baseline scans without restart markers"):
+        jpeg.BandEncoder(_opts(64, 64, 2, 1, 80, restart_interval=3), 2, 0, 0)
+    with pytest.raises(error.Error, match="no HIP device"):
+        jpeg.BandEncoder(_opts(64, 64, 2, 1, 80), 2, 0, 99)
+    with pytest.raises(error.Error, match="no HIP device"):
+        jpeg.set_device(99)
+    with pytest.raises(error.Error, match="trellis_quant needs the pixels"):
+        jpeg.entropy_encode(np.zeros((64, 64), np.int16), np.zeros((64, 64), np.int16), np.zeros((64, 64), np.int16),
+                            _opts(64, 64, 2, 0, 80, progressive=True, trellis_quant=True))
+
+
+def test_config4_16384_image_in_8_bands_matches_the_reference_file():
+    """configs[3] the way 8 GPUs do it — eight bands, per-band entropy coding, boundary DCs and bit totals
+    exchanged, pieces spliced — with all bands on the one GPU of the test box: the reference's own file
+    (178,548,465 bytes, sha256 77cc6cb6...)."""
+    w = h = 16384
+    px = synth.noise(w, h, 42)
+    blob = jpeg.encode_multi(px, _opts(w, h, 2, 1, 80), [0] * 8)
+    assert len(blob) == 178548465
+    assert hashlib.sha256(blob).hexdigest() == "77cc6cb69a782693c46f2024ac57ebfdfb8411148fa3cef62698c727af36c70c"
+
+
+def test_device_pixels_are_read_after_their_producer():
+    """A device-pointer entry point called right after the kernel that writes its pixels (torch's current
+    stream) must see them: the library orders its own stream after the producer stream on the device."""
+    import torch
+    w = h = 4096
+    px = synth.noise(w, h, 42)
+    want = hashlib.sha256(jpeg.encode(px, _opts(w, h, 2, 1, 80))).hexdigest()
+    src = torch.from_numpy(px).to("cuda:0")
+    big = torch.empty(64 << 20, dtype=torch.float32, device="cuda:0")
+    jpeg.set_producer_stream(None)  # the NULL stream = torch's default stream
+    for _ in range(3):
+        d_px = torch.zeros_like(src)
+        big.normal_()          # keeps the stream busy for a while ...
+        d_px.copy_(src)        # ... before the pixels appear
+        assert hashlib.sha256(jpeg.encode_device(d_px, _opts(w, h, 2, 1, 80))).hexdigest() == want
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        jpeg.set_producer_stream(side.cuda_stream)
+        d_px = torch.zeros_like(src)
+        big.normal_()
+        d_px.copy_(src, non_blocking=True)
+        assert hashlib.sha256(jpeg.encode_device(d_px, _opts(w, h, 2, 1, 80))).hexdigest() == want
+    jpeg.set_producer_stream(None)
+    side.synchronize()
+
+
+_WORKERS = """
+    import os, sys, threading
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+    import synth
+    from pixo_amd import jpeg
+    w = h = %d
+    px = synth.noise(w, h, 42)
+    o = jpeg.JpegOptions.builder(w, h).quality(80).subsampling(jpeg.Subsampling.S420).build()
+    sizes = []
+    def work():
+        for _ in range(%d):
+            sizes.append(len(jpeg.encode(px, o)))
+"""
+
+
+def _run_script(body):
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(body)], capture_output=True, text=True, timeout=600)
+    err = "\n".join(l for l in r.stderr.splitlines() if "amdgpu.ids" not in l)
+    return r.returncode, r.stdout, err
+
+
+def test_sixteen_threads_ending_at_once_do_not_take_the_process_down():
+    """Round 1 crashed here (profiles/r02_thread_exit_crash.txt): 16 threads x a few 4096x4096 encodes, all
+    threads end together, the process exits: exit code 0, nothing on stderr."""
+    rc, out, err = _run_script((_WORKERS % (ROOT, ROOT, 4096, 3)) + """
+    ts = [threading.Thread(target=work) for _ in range(16)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    print(len(sizes), set(sizes))
+    """)
+    assert rc == 0 and err == "", (rc, err[-2000:])
+    assert out.strip() == "48 {11150133}"
+
+
+def test_workers_that_outlive_main_and_a_main_thread_that_never_calls_the_library():
+    """Daemon-less worker threads are still encoding when the main thread — which never touched the library —
+    reaches the end of the script; the interpreter waits for them, then exits: exit code 0, nothing on stderr.
+    Second form: main exits with os._exit while workers are mid-call (no destructors at all)."""
+    rc, out, err = _run_script((_WORKERS % (ROOT, ROOT, 2048, 6)) + """
+    ts = [threading.Thread(target=work) for _ in range(8)]
+    for t in ts: t.start()
+    print("main done")
+    """)
+    assert rc == 0 and err == "" and "main done" in out, (rc, err[-2000:])
+    rc, out, err = _run_script((_WORKERS % (ROOT, ROOT, 2048, 50)) + """
+    import time
+    ts = [threading.Thread(target=work, daemon=True) for _ in range(8)]
+    for t in ts: t.start()
+    time.sleep(1.0)
+    print("leaving", len(sizes) > 0, flush=True)
+    sys.exit(0)   # daemon threads are abandoned mid-call while the runtime shuts down
+    """)
+    assert rc == 0 and "leaving True" in out, (rc, err[-2000:])

@@ -243,10 +243,11 @@ def test_encode_device_resident_pixels_full_size_hashes():
     assert jpeg.encode_device(d_px, _opts(w, h, 2, 1, 80)) == jpeg.encode_device(d_px, _opts(w, h, 2, 1, 80))
 
 
-def test_banded_device_encode_over_rccl_world_of_one():
-    """encode_banded_device on the real device path (RCCL process group, device tensors, device
-    entropy stage).  Only one GPU is available to the tests, so the world has one rank; the
-    two-rank stitching logic runs on CPU over gloo (tests/test_sharding_gloo.py)."""
+def test_banded_encode_over_rccl_world_of_one():
+    """sharded.encode_banded on the real device path (RCCL process group, device tensors, device band
+    encoder) and the gathered fallback.  Only one GPU is available to the tests, so the world has one rank;
+    the multi-rank exchanges run on CPU over gloo (tests/test_sharding_gloo.py) and, inside one process,
+    in tests/test_gpu_multi.py."""
     import os
     import torch
     import torch.distributed as dist
@@ -260,8 +261,13 @@ def test_banded_device_encode_over_rccl_world_of_one():
         for (w, h, ct, ss) in [(1024, 520, 2, 1), (300, 100, 2, 0), (200, 64, 0, 0)]:
             px = synth.noise(w, h, 31) if ct == 2 else synth.noise_gray(w, h, 31)
             d_px = torch.from_numpy(px).to("cuda:0")
-            got = sharded.encode_banded_device(d_px, _opts(w, h, ct, ss, 80))
-            assert got == O.encode(px, O.make_options(w, h, ct, 80, ss))
+            want = O.encode(px, O.make_options(w, h, ct, 80, ss))
+            assert sharded.encode_banded(d_px, _opts(w, h, ct, ss, 80)) == want      # device pixels
+            assert sharded.encode_banded(px, _opts(w, h, ct, ss, 80)) == want        # host pixels
+            assert sharded.encode_banded(d_px, _opts(w, h, ct, ss, 80, optimize_huffman=True)) == \
+                O.encode(px, O.make_options(w, h, ct, 80, ss, optimize_huffman=True))
+            got = sharded.encode_gathered_device(d_px, _opts(w, h, ct, ss, 80, restart_interval=7))
+            assert got == O.encode(px, O.make_options(w, h, ct, 80, ss, restart=7))
     finally:
         dist.destroy_process_group()
 
@@ -387,8 +393,8 @@ def test_encode_into_caller_storage_and_the_reserve_and_retry_protocol():
 
 def test_threads_that_end_give_their_device_buffers_back():
     """A server with one thread per request: 24 short-lived threads in sequence, each encoding a 2048x2048
-    image (about 70 MB of per-thread device and pinned buffers).  The library frees a thread's context when the
-    thread ends, so the device's free memory does not shrink by 24 contexts."""
+    image (about 70 MB of per-thread device and pinned buffers).  A thread that ends parks its context in the
+    library's pool and the next thread adopts it, so the device's free memory does not shrink by 24 contexts."""
     import threading
     import torch
     w = h = 2048
@@ -404,6 +410,25 @@ def test_threads_that_end_give_their_device_buffers_back():
         assert res[0] == want
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 200 << 20, (free0 - free1) >> 20  # 24 leaked contexts would be > 1 GB
+    # 40 threads alive at once leave 40 parked contexts behind; the pool keeps 16, the rest is freed by the next
+    # thread that asks for one, and pixo_hip_trim frees them all
+    start = threading.Barrier(40)
+    res = []
+
+    def burst():
+        start.wait()
+        res.append(jpeg.encode(px, o) == want)
+
+    ts = [threading.Thread(target=burst) for _ in range(40)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert all(res) and len(res) == 40
+    t = threading.Thread(target=lambda: res.append(jpeg.encode(px, o) == want))
+    t.start(); t.join()
+    jpeg.trim()
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert free0 - free2 < 200 << 20, (free0 - free2) >> 20
 
 
 def test_trim_releases_the_threads_buffers_and_the_next_call_starts_over():

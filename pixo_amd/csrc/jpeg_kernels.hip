@@ -71,12 +71,19 @@ __device__ __forceinline__ TileCtx ctx_of(const KArgs &a, uint32_t img)
 // Phase A of one wavefront: COUNT items [first, first + COUNT) of the tile, HBM -> registers ->
 // planar LDS.  All loads are issued before the first conversion (no branch near a load).
 template <int MODE, int LOAD, int COUNT>
-__device__ __forceinline__ void phase_a(const TileCtx &c, const TileId &id, int first, int lane, uint8_t *lds)
+__device__ __forceinline__ void phase_a(const TileCtx &c, const TileId &id, int first, int lane, uint8_t *lds, bool last_rows)
 {
     typedef Geo<MODE> G;
     uint32_t r[COUNT * G::item_regs];
+    // (the funnel loads read one dword more than they need; only in the tiles that hold the image's last row could that
+    // dword lie behind the buffer — wave-uniform choice of the loader, all loads of the phase inside either branch)
+    if (LOAD == L_FUNNEL && !last_rows) {
 #pragma unroll
-    for (int j = 0; j < COUNT; j++) producer_load_item<MODE, LOAD>(c, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
+        for (int j = 0; j < COUNT; j++) producer_load_item<MODE, LOAD, false>(c, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < COUNT; j++) producer_load_item<MODE, LOAD, true>(c, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
+    }
 #pragma unroll
     for (int j = 0; j < COUNT; j++) {
         producer_fix_item<MODE, LOAD>(c, id.tx, first + j, lane, &r[j * G::item_regs]);
@@ -149,8 +156,9 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     const TileId id = locate(a, blockIdx.x);
     const TileCtx c = ctx_of(a, id.img);
     constexpr int base = G::items / kWaves, extra = G::items % kWaves;
-    if (extra && wave < extra) phase_a<MODE, LOAD, base + 1>(c, id, wave * (base + 1), lane, lds);
-    else phase_a<MODE, LOAD, base>(c, id, extra * (base + 1) + (wave - extra) * base, lane, lds);
+    const bool last_rows = (id.ty + 1) * (uint32_t)G::tile_h >= a.H; // this tile reads the image's last pixel row
+    if (extra && wave < extra) phase_a<MODE, LOAD, base + 1>(c, id, wave * (base + 1), lane, lds, last_rows);
+    else phase_a<MODE, LOAD, base>(c, id, extra * (base + 1) + (wave - extra) * base, lane, lds, last_rows);
     lds_barrier();
     __builtin_amdgcn_s_setprio(0);
     float v[64];

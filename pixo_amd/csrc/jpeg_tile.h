@@ -364,27 +364,47 @@ PIXO_DEV uint32_t load_dword(const TileCtx &c, const uint8_t *aligned)
 #endif
 }
 
-// L_FUNNEL: `n` (1 or 3) dwords starting at byte address `row + off`, whatever its alignment: n + 1
-// aligned dwords (the last one clamped to the buffer's last dword: it is only needed when the address
-// is not aligned, and then it holds wanted bytes) funnelled through v_alignbyte.
-template <int N> PIXO_DEV void funnel_load(const TileCtx &c, const uint8_t *row, uint32_t off, uint32_t *r)
+// L_FUNNEL: `N` (1 or 3) dwords starting at byte address `row + off`, whatever its alignment: the N + 1
+// aligned dwords around them funnelled through v_alignbyte.  The last of the N + 1 is only needed when the
+// address is not aligned (and then it holds wanted bytes), but it is always read: ONE load instruction of
+// N + 1 dwords per lane.  Behind the image's very last group it would lie outside the buffer, so the tiles
+// that hold the last pixel row (LAST_ROWS, wave-uniform) read it separately, clamped to the buffer's last dword.
+#if !defined(PIXO_EMU)
+typedef uint32_t pixo_v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t pixo_v3u __attribute__((ext_vector_type(3)));
+typedef uint32_t pixo_v4u_ld __attribute__((ext_vector_type(4)));
+#endif
+template <int N, bool LAST_ROWS> PIXO_DEV void funnel_load(const TileCtx &c, const uint8_t *row, uint32_t off, uint32_t *r)
 {
     // wave-uniform part (scalar ALU): the row's aligned base and how far the buffer's last dword is from it
     const uint32_t r3 = (uint32_t)(uintptr_t)row & 3u;
     const uint8_t *row4 = row - r3;
-    const uint64_t last64 = (((uintptr_t)c.px_end - 1) & ~(uintptr_t)3) - (uintptr_t)row4;
-    const uint32_t last = last64 > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)last64;
     // per lane: three VALU operations for the address, one per dword for the shift
     const uint32_t t = off + r3, voff = t & ~3u, sh = t & 3u;
     uint32_t w[N + 1];
+#if !defined(PIXO_EMU)
+    if (!LAST_ROWS) {
+        if (N == 3) {
+            const pixo_v4u_ld q = PIXO_GLOAD((const pixo_v4u_ld *)(row4 + voff));
+            w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+        } else {
+            const pixo_v2u q = PIXO_GLOAD((const pixo_v2u *)(row4 + voff));
+            w[0] = q.x; w[1] = q.y;
+        }
+    } else
+#endif
+    {
+        const uint64_t last64 = (((uintptr_t)c.px_end - 1) & ~(uintptr_t)3) - (uintptr_t)row4;
+        const uint32_t last = last64 > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)last64;
 #pragma unroll
-    for (int i = 0; i < N; i++) w[i] = load_dword(c, row4 + voff + 4 * i);
-    w[N] = load_dword(c, row4 + (voff + 4 * N < last ? voff + 4 * N : last));
+        for (int i = 0; i < N; i++) w[i] = load_dword(c, row4 + voff + 4 * i);
+        w[N] = load_dword(c, row4 + (voff + 4 * N < last ? voff + 4 * N : last));
+    }
 #pragma unroll
     for (int i = 0; i < N; i++) r[i] = alignbyte(w[i + 1], w[i], sh);
 }
 
-template <int MODE, int LOAD>
+template <int MODE, int LOAD, bool LAST_ROWS = true>
 PIXO_DEV void producer_load_item(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int k, int lane,
                                  uint32_t *r)
 {
@@ -398,13 +418,13 @@ PIXO_DEV void producer_load_item(const TileCtx &c, uint32_t tile_x, uint32_t til
         const uint8_t *row = c.px + (size_t)ya * ((size_t)c.W * Geo<MODE>::bpp);
         if (MODE == MGRAY) {
             if (LOAD == L_ALIGNED) r[0] = PIXO_GLOAD((const uint32_t *)(row + xoff));
-            else funnel_load<1>(c, row, xoff, r);
+            else funnel_load<1, LAST_ROWS>(c, row, xoff, r);
         } else {
             if (LOAD == L_ALIGNED) {
                 const uint32_t *q = (const uint32_t *)(row + xoff);
                 r[0] = PIXO_GLOAD(q); r[1] = PIXO_GLOAD(q + 1); r[2] = PIXO_GLOAD(q + 2);
             } else {
-                funnel_load<3>(c, row, xoff, r);
+                funnel_load<3, LAST_ROWS>(c, row, xoff, r);
             }
             if (MODE == M420) {
                 const uint32_t yb = y0 + 1 < c.H ? y0 + 1 : c.H - 1;
@@ -413,7 +433,7 @@ PIXO_DEV void producer_load_item(const TileCtx &c, uint32_t tile_x, uint32_t til
                     const uint32_t *q2 = (const uint32_t *)(row2 + xoff);
                     r[3] = PIXO_GLOAD(q2); r[4] = PIXO_GLOAD(q2 + 1); r[5] = PIXO_GLOAD(q2 + 2);
                 } else {
-                    funnel_load<3>(c, row2, xoff, r + 3);
+                    funnel_load<3, LAST_ROWS>(c, row2, xoff, r + 3);
                 }
             }
         }

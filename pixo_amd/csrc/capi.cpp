@@ -108,11 +108,12 @@ struct Context {
         template <class T> T *as() const { return static_cast<T *>(p); }
     };
     Buf e_tables, e_hist, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out, e_seg_bytes, e_seg_off;
+    Buf e_code_state, e_stuff_state; // single-pass kernels (jpeg_scan_fused.hip): tickets, look-back descriptors, totals
     Buf p_in, p_out, p_sums, p_scratch; // PNG filter stage
     Buf t_raw, t_trail;                 // progressive + trellis: unquantised DCT blocks (f32), Viterbi back-pointers
     Buf g_flags, g_rank, g_by_rank;     // progressive scans: band flags, rank among non-empty blocks and its inverse
     unsigned long long *h_sums = nullptr; size_t hsums_cap = 0; // pinned
-    uint64_t *h_totals = nullptr; // pinned, 2 words
+    uint64_t *h_totals = nullptr; // pinned, 8 words
     uint8_t *h_file = nullptr; size_t hfile_cap = 0; // pinned: the finished file lands here
     int reserve_hfile(size_t n)
     {
@@ -179,7 +180,7 @@ void Context::release()
     if (on.err != hipSuccess) return;
     if (stream) (void)hipStreamSynchronize(stream);
     Buf *bufs[] = {&e_tables, &e_hist, &e_len, &e_off, &e_tmp, &e_totals, &e_stream, &e_tile_ff, &e_tile_base, &e_out, &e_seg_bytes,
-                   &e_seg_off, &p_in, &p_out, &p_sums, &p_scratch, &t_raw, &t_trail, &g_flags, &g_rank, &g_by_rank};
+                   &e_seg_off, &e_code_state, &e_stuff_state, &p_in, &p_out, &p_sums, &p_scratch, &t_raw, &t_trail, &g_flags, &g_rank, &g_by_rank};
     for (Buf *b : bufs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr; b->cap = 0;
@@ -345,7 +346,17 @@ struct ScanJob {
     uint64_t scan_bytes = 0; // ... after stuffing, in c.e_out
     bool band = false;
     int head_bits = 0;       // band: how many of its first bits share a byte with the band before
+    bool fused = false;      // one uninterrupted scan: the two single-pass kernels of jpeg_scan_fused.hip
+    size_t stream_cap = 0;   // fused: bytes the packed stream can take at most
 };
+
+// PIXO_HIP_OLD_ENTROPY=1: the multi-pass kernels of jpeg_entropy.hip for every scan (A/B runs; they remain the path of
+// scans with restart markers, batches and progressive scans)
+bool old_entropy_forced()
+{
+    static const bool v = std::getenv("PIXO_HIP_OLD_ENTROPY") != nullptr;
+    return v;
+}
 
 // Geometry of the pass and every buffer whose size does not depend on the data.
 int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
@@ -373,8 +384,18 @@ int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, co
         a.marker_bytes = 0;
         j.nseg = batch;
     }
+    j.fused = j.nseg == 0 && !old_entropy_forced();
     HIP_TRY(c.e_tables.reserve(pixo_host::kScanTableWords * 4));
     HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
+    if (j.fused) { // a block has at most 1665 bits: the packed stream has at most n * 209 bytes (+ slack the kernels read into)
+        j.stream_cap = static_cast<size_t>(j.n) * 209 + 64;
+        HIP_TRY(c.e_stream.reserve(j.stream_cap));
+        HIP_TRY(c.e_code_state.reserve(pd::fused_code_state_words(j.n) * 8));
+        HIP_TRY(c.e_stuff_state.reserve(pd::fused_stuff_state_words(j.stream_cap) * 8));
+        if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 64, hipHostMallocDefault));
+        a.tables = c.e_tables.as<uint32_t>();
+        return PIXO_OK;
+    }
     HIP_TRY(c.e_len.reserve((j.n ? j.n : 1) * 4));
     HIP_TRY(c.e_off.reserve((j.n ? j.n : 1) * 8));
     // scratch of the three prefix sums (blocks, restart segments, 0xFF tiles), reserved before any launch:
@@ -383,7 +404,7 @@ int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, co
     j.tmp_tiles = pd::scan_tile_count(pd::stuff_tile_count(j.n * 209 + 3 * j.nseg + 8)) + 1;
     HIP_TRY(c.e_tmp.reserve((j.tmp_blocks + j.tmp_segs + j.tmp_tiles) * 8));
     HIP_TRY(c.e_totals.reserve(16));
-    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 16, hipHostMallocDefault));
+    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 64, hipHostMallocDefault));
     a.tables = c.e_tables.as<uint32_t>();
     return PIXO_OK;
 }
@@ -409,7 +430,7 @@ int scan_count(Context &c, ScanJob &j, hipStream_t stream, uint64_t counts[pixo_
 // Tables (standard; optimised from `counts`, or from this pass's own statistics when counts == null),
 // block bit lengths and their prefix sum: afterwards j.total_bits is known (one read-back).
 int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
-                 const uint64_t *counts)
+                 const uint64_t *counts, bool wait = true)
 {
     namespace pd = pixo_dev;
     if (o.optimize_huffman) { // table construction on the host, exactly like optimized_from_counts
@@ -428,6 +449,15 @@ int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_
     uint32_t packed[pixo_host::kScanTableWords];
     pixo_host::pack_scan_tables(j.h, packed);
     HIP_TRY(hipMemcpyAsync(c.e_tables.p, packed, sizeof packed, hipMemcpyHostToDevice, stream));
+    if (j.fused) { // lengths, prefix and packing in one pass; the stream starts at bit 0 whatever the band's offset will be
+        HIP_TRY(pd::launch_scan_code(j.a, c.e_code_state.as<unsigned long long>(), c.e_stream.as<uint32_t>(), stream));
+        if (!wait) return PIXO_OK; // (the caller chains the stuffing kernel and synchronises once)
+        HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_code_state.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        j.total_bits = c.h_totals[0];
+        j.nbytes = (j.total_bits + 7) / 8;
+        return PIXO_OK;
+    }
     if (j.n) HIP_TRY(pd::launch_scan_lengths(j.a, c.e_len.as<uint32_t>(), stream));
     HIP_TRY(pd::launch_exclusive_scan(c.e_len.as<uint32_t>(), j.n, c.e_off.as<uint64_t>(), c.e_tmp.as<uint64_t>(),
                                       c.e_totals.as<uint64_t>(), stream));
@@ -447,6 +477,54 @@ int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_
     return PIXO_OK;
 }
 
+// The stuffing kernel of jpeg_scan_fused.hip over the packed stream (launch_scan_code has been enqueued; with
+// `chained` its length has not been read back yet): afterwards c.e_out holds j.scan_bytes finished bytes.  The output
+// buffer is sized from experience (grow-only) — the kernel never writes beyond it and says how much it needed.
+int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offset, uint32_t *head, int *tail_bits,
+                     uint32_t *tail, bool chained = false)
+{
+    namespace pd = pixo_dev;
+    uint32_t shift = 0;
+    if (j.band) {
+        const uint64_t want = (8 - (band_bit_offset & 7)) & 7;
+        j.head_bits = static_cast<int>(j.total_bits < want ? j.total_bits : want);
+        shift = static_cast<uint32_t>(j.head_bits);
+    }
+    // entropy-coded data holds a 0xFF every ~256 bytes; start from a quarter of the worst-case stream and grow on demand
+    size_t want_cap = chained ? std::max<size_t>(j.stream_cap / 4, 4096) : static_cast<size_t>(j.nbytes + j.nbytes / 64 + 4096);
+    for (int attempt = 0;; ++attempt) {
+        HIP_TRY(c.e_out.reserve(want_cap));
+        HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), shift, j.band, j.stream_cap,
+                                       c.e_stuff_state.as<unsigned long long>(), c.e_out.as<uint8_t>(), c.e_out.cap, stream));
+        HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_code_state.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(c.h_totals + 1, c.e_stuff_state.as<uint64_t>() + 1, 16, hipMemcpyDeviceToHost, stream));
+        uint32_t edge[3] = {0, 0, 0}; // band: stream word 0 (head bits) and the two words around the tail bits
+        if (j.band) {
+            const uint64_t tail_at = static_cast<uint64_t>(j.head_bits) + 8 * ((j.total_bits - j.head_bits) / 8);
+            HIP_TRY(hipMemcpyAsync(&edge[0], c.e_stream.p, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(&edge[1], c.e_stream.as<uint32_t>() + (tail_at >> 5), 8, hipMemcpyDeviceToHost, stream));
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        j.total_bits = c.h_totals[0];
+        j.scan_bytes = c.h_totals[1];
+        j.nbytes = c.h_totals[2];
+        if (j.scan_bytes > c.e_out.cap) { // (first call with unusually many 0xFF bytes: grow and repeat the stuffing pass only)
+            if (attempt) return fail(PIXO_ERR_COMPRESSION, "Compression error: stuffed stream larger than announced");
+            want_cap = static_cast<size_t>(j.scan_bytes);
+            continue;
+        }
+        if (j.band) {
+            const int t = static_cast<int>((j.total_bits - j.head_bits) % 8);
+            const uint64_t tail_at = static_cast<uint64_t>(j.head_bits) + 8 * ((j.total_bits - j.head_bits) / 8);
+            *head = j.head_bits ? (edge[0] >> (32 - j.head_bits)) : 0u;
+            *tail_bits = t;
+            const uint64_t two = (static_cast<uint64_t>(edge[1]) << 32) | edge[2]; // MSB-first bits of the two words
+            *tail = t ? static_cast<uint32_t>((two >> (64 - (tail_at & 31) - t)) & ((1u << t) - 1u)) : 0u;
+        }
+        return PIXO_OK;
+    }
+}
+
 // Pack, 0xFF census, stuffing (+ restart markers): afterwards c.e_out holds j.scan_bytes finished bytes
 // (one read-back).  A band starting at bit `band_bit_offset` of the scan is packed so that its whole bytes
 // begin at word 1 of the stream: its first (8 - offset % 8) % 8 bits end word 0, the bits left over after the
@@ -455,6 +533,7 @@ int scan_pack(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offs
               int *tail_bits = nullptr, uint32_t *tail = nullptr)
 {
     namespace pd = pixo_dev;
+    if (j.fused) return scan_stuff_fused(c, j, stream, band_bit_offset, head, tail_bits, tail);
     uint64_t stream_bits = j.total_bits;
     uint32_t word_off = 0;
     if (j.band) {
@@ -519,10 +598,16 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
     int rc = scan_begin(c, j, dy, dcb, dcr, o, g, batch, nullptr);
     if (rc) return rc;
     sw.lap("  reserve");
-    if ((rc = scan_lengths(c, j, o, g, stream, nullptr))) return rc;
-    sw.lap("tables+lengths+scan");
-    if ((rc = scan_pack(c, j, stream))) return rc;
-    sw.lap("memset+pack+ff census");
+    if (j.fused) { // code + stuff back to back, one read-back
+        if ((rc = scan_lengths(c, j, o, g, stream, nullptr, /*wait=*/false))) return rc;
+        if ((rc = scan_stuff_fused(c, j, stream, 0, nullptr, nullptr, nullptr, /*chained=*/true))) return rc;
+        sw.lap("code+stuff (fused)");
+    } else {
+        if ((rc = scan_lengths(c, j, o, g, stream, nullptr))) return rc;
+        sw.lap("tables+lengths+scan");
+        if ((rc = scan_pack(c, j, stream))) return rc;
+        sw.lap("memset+pack+ff census");
+    }
     const uint64_t scan_bytes = j.scan_bytes;
     if (batch > 1) { // where every image's segment begins in the stuffed stream (reuses the seg_bytes buffer: 8 B/entry)
         HIP_TRY(c.e_seg_bytes.reserve(j.nseg * 8));
@@ -640,7 +725,7 @@ int device_progressive_scans(const int16_t *dy, const int16_t *dcb, const int16_
     const size_t tmp_tiles = pd::scan_tile_count(pd::stuff_tile_count(n * 212 + 64)) + 1;
     HIP_TRY(c.e_tmp.reserve((tmp_blocks + tmp_segs + tmp_tiles) * 8));
     HIP_TRY(c.e_totals.reserve(32));
-    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 16, hipHostMallocDefault));
+    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 64, hipHostMallocDefault));
     a.tables = c.e_tables.as<uint32_t>();
     a.flags = c.g_flags.as<uint32_t>();
     a.nonempty = c.e_len.as<uint32_t>(); // only the input of the rank prefix sum: the lengths reuse it
@@ -1396,7 +1481,7 @@ int pixo_hip_band_encoder_coeffs(pixo_hip_band_encoder *e, const void *band_pixe
     }
     if ((rc = coeffs_on_device(c, d_px, e->band, e->g, c.stream, &e->dy, &e->dcb, &e->dcr))) return rc;
     // the DCs the next band predicts from: first coefficient of the last block of every plane
-    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 16, hipHostMallocDefault));
+    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 64, hipHostMallocDefault));
     int16_t *h = reinterpret_cast<int16_t *>(c.h_totals);
     HIP_TRY(hipMemcpyAsync(h, e->dy + (e->g.y_blocks - 1) * 64, 2, hipMemcpyDeviceToHost, c.stream));
     if (e->g.c_blocks) {

@@ -60,6 +60,21 @@ hipError_t launch_ff_tile_count(const uint32_t *d_stream, uint64_t nbytes, uint3
 // d_out: nbytes + (number of 0xFF bytes) bytes
 hipError_t launch_stuff(const uint32_t *d_stream, uint64_t nbytes, const uint64_t *d_tile_ff_base, uint8_t *d_out, hipStream_t s);
 
+// ---- one uninterrupted baseline scan in two single-pass kernels (jpeg_scan_fused.hip) -------------------------
+// code: tuple -> packed bit stream starting at bit 0 of d_stream (a.restart must be 0, a.bit_base ignored; a.seed_dc and
+// a.pad_last as above).  d_state: fused_code_state_words(nblocks) u64 (zeroed by the launcher); afterwards d_state[1] =
+// the scan's length in bits.  d_stream: room for nblocks * 209 + 64 bytes (a block has at most 1665 bits).
+size_t fused_code_state_words(uint64_t nblocks);
+hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, uint32_t *d_stream, hipStream_t s);
+// stuff: the stream's bytes from bit `shift` (< 8) on -> d_out with 0x00 behind every 0xFF.  band = false: all bytes of a
+// whole scan (shift 0); band = true: only the whole bytes behind the band's first `shift` bits.  Reads the scan's length
+// from d_code_state[1] (no host round trip).  d_state: fused_stuff_state_words(max_stream_bytes) u64; afterwards
+// d_state[1] = bytes produced (bytes beyond out_cap are not written: the caller grows d_out and repeats this launch),
+// d_state[2] = bytes of the packed stream consumed.
+size_t fused_stuff_state_words(uint64_t max_stream_bytes);
+hipError_t launch_stuff_fused(const uint32_t *d_stream, const unsigned long long *d_code_state, uint32_t shift, bool band,
+                              uint64_t max_stream_bytes, unsigned long long *d_state, uint8_t *d_out, uint64_t out_cap, hipStream_t s);
+
 // ---- progressive scans on the device (simple_progressive_script: seven single-component scans) ------
 struct ProgArgs {
     const int16_t *y, *cb, *cr; // coefficient tuple

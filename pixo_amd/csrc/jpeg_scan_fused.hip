@@ -1,0 +1,420 @@
+// jpeg_scan_fused.hip — the device entropy stage of one uninterrupted baseline scan in TWO kernels, each a
+// single pass over its input (round 1 needed three passes over the coefficient tuple, two
+// prefix-sum launches, a memset and two host round trips — jpeg_entropy.hip, which still serves scans with
+// restart markers, batches and progressive scans):
+//
+//   code   tuple -> packed MSB-first bit stream.  A group of 192 lanes owns 192 consecutive blocks of the scan
+//          order (32 MCUs of 4:2:0, 64 of 4:4:4): the blocks come in with coalesced 16-byte loads through LDS, every
+//          lane walks its block once for its bit length (encode_block, src/jpeg/huffman.rs:423-481), the lengths are
+//          summed with wavefront scans (DPP row shifts + row broadcasts, no LDS), the group's position in the
+//          stream comes from a decoupled look-back over the groups before it (one 64-bit descriptor per group), the
+//          lane walks its block a second time and ORs its codes into an LDS bit buffer at its offset, and the group
+//          writes the buffer out with coalesced dword stores.  The word two neighbouring groups share is written by
+//          the later one, which receives the earlier one's bits through a second descriptor: no atomics on the
+//          stream, no zero-filling of it.
+//   stuff  packed stream -> final bytes with 0x00 after every 0xFF (BitWriterMsb, src/bits.rs:245-253), 4 KiB
+//          tiles: 0xFF census per lane, wavefront scans, look-back for the tile's output position, bytes expanded
+//          into LDS and written out as aligned dwords.
+//
+// Both kernels take their work from a ticket counter (a group / tile only ever waits for lower tickets, which are
+// running or done: no assumption about dispatch order or residency), and neither needs a host round trip: `stuff`
+// reads the stream's length where `code` left it.
+#include <hip/hip_runtime.h>
+
+#include "jpeg_entropy.hpp"
+#include "jpeg_scan_block.h"
+
+namespace pixo_dev {
+using namespace pixo_scan;
+
+namespace {
+constexpr int kGroup = 192;                  // lanes = blocks per group
+constexpr int kGroupWaves = kGroup / 64;
+constexpr uint32_t kBufWords = kGroup * 32;  // the 24 KiB block staging area doubles as the bit buffer
+constexpr uint64_t kFlagAggregate = 1ull << 62, kFlagPrefix = 2ull << 62, kValueMask = (1ull << 62) - 1;
+constexpr uint64_t kTailValid = 1ull << 63;
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+// ---- wavefront inclusive scan: four row shifts inside the rows of 16, two row broadcasts across them ----------
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_add(uint32_t v)
+{
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    v = dpp_add<0x111, 0xF>(v); // row_shr:1
+    v = dpp_add<0x112, 0xF>(v); // row_shr:2
+    v = dpp_add<0x114, 0xF>(v); // row_shr:4
+    v = dpp_add<0x118, 0xF>(v); // row_shr:8
+    v = dpp_add<0x142, 0xA>(v); // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long load_relaxed(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_relaxed(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Inclusive prefix of everything before ticket `g` (decoupled look-back, one lane): descriptors hold flag + value
+// in ONE 64-bit word, so a single relaxed load sees a consistent pair.
+__device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t g, uint64_t aggregate)
+{
+    if (g == 0) {
+        store_relaxed(&desc[0], kFlagPrefix | aggregate);
+        return 0;
+    }
+    store_relaxed(&desc[g], kFlagAggregate | aggregate);
+    uint64_t before = 0;
+    for (uint64_t j = g; j-- > 0;) {
+        unsigned long long d;
+        do { d = load_relaxed(&desc[j]); } while ((d >> 62) == 0);
+        before += d & kValueMask;
+        if ((d >> 62) == 2) break;
+    }
+    store_relaxed(&desc[g], kFlagPrefix | (before + aggregate));
+    return before;
+}
+
+// ---- the LDS bit buffer: PackVisitor of jpeg_scan_block.h over a window of words ----------------------------------
+// Word i of the buffer is word `first + i` of the stream.  Words a block covers completely are stored, its first and
+// last (shared with the neighbouring lanes' blocks) OR-ed with an LDS atomic; words outside [0, limit) — a group of
+// very long blocks is written out in more than one round — are skipped.
+struct WindowPack {
+    const uint32_t *tab;
+    uint32_t *buf;
+    uint32_t limit;   // words in the window
+    uint64_t acc;
+    int pending;
+    uint32_t word;    // relative to the window; wraps below zero for words before it
+    bool first;
+    __device__ __forceinline__ void begin(uint32_t *b, uint32_t lim, int64_t bit_pos)
+    { // bit_pos: the block's first bit relative to the window's first word (may be negative)
+        buf = b; limit = lim; acc = 0; first = true;
+        pending = (int)(bit_pos & 31);
+        word = (uint32_t)(bit_pos >> 5);
+    }
+    __device__ __forceinline__ void or_word(uint32_t i, uint32_t v)
+    {
+        if (i < limit && v) atomicOr(&buf[i], v);
+    }
+    __device__ __forceinline__ void put(uint32_t v, int n)
+    {
+        acc = (acc << n) | v;
+        pending += n;
+        if (pending >= 32) {
+            const uint32_t out = (uint32_t)(acc >> (pending - 32));
+            if (first) { or_word(word, out); first = false; }
+            else if (word < limit) buf[word] = out;
+            word++;
+            pending -= 32;
+            acc &= (1ull << pending) - 1ull;
+        }
+    }
+    __device__ __forceinline__ void finish()
+    {
+        if (pending > 0) or_word(word, (uint32_t)(acc << (32 - pending)));
+    }
+    __device__ __forceinline__ void dc(int cat, int diff)
+    {
+        const uint32_t t = tab[cat];
+        put(((t & 0xFFFF) << cat) | value_bits(diff, cat), (int)(t >> 16) + cat);
+    }
+    __device__ __forceinline__ void ac(int rs, int cat, int v)
+    {
+        const uint32_t t = tab[kDcSyms + rs];
+        put(((t & 0xFFFF) << cat) | value_bits(v, cat), (int)(t >> 16) + cat);
+    }
+    __device__ __forceinline__ void zrl() { const uint32_t t = tab[kDcSyms + 0xF0]; put(t & 0xFFFF, (int)(t >> 16)); }
+    __device__ __forceinline__ void eob() { const uint32_t t = tab[kDcSyms]; put(t & 0xFFFF, (int)(t >> 16)); }
+};
+
+// chunk (16 bytes) c of a group's 1536 -> which plane, which block of the group (scan position), which row
+struct ChunkRef { int comp; uint32_t plane_block; int pos, row; };
+__device__ __forceinline__ ChunkRef chunk_of(int mode, int c)
+{
+    ChunkRef r;
+    r.row = c & 7;
+    const int b = c >> 3; // 0..191
+    if (mode == 0) { r.comp = 0; r.plane_block = (uint32_t)b; r.pos = b; }
+    else if (mode == 1) { r.comp = b >> 6; r.plane_block = (uint32_t)(b & 63); r.pos = 3 * (b & 63) + r.comp; }
+    else if (b < 128) { r.comp = 0; r.plane_block = (uint32_t)b; r.pos = 6 * (b >> 2) + (b & 3); }
+    else { r.comp = 1 + ((b - 128) >> 5); r.plane_block = (uint32_t)((b - 128) & 31); r.pos = 6 * ((b - 128) & 31) + 3 + r.comp; }
+    return r;
+}
+__device__ __forceinline__ int lds_chunk(int pos, int row) { return pos * 128 + (((row ^ pos) & 7) << 4); }
+
+__global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, unsigned long long *state, uint32_t *stream)
+{
+    // state: [0] ticket, [1] total bits (out), [2 ..] per group: descriptor, then per group: tail
+    __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
+    __shared__ uint32_t tab[kTableWords];
+    __shared__ uint32_t wave_sum[kGroupWaves];
+    __shared__ unsigned long long s_ticket, s_before;
+    const int lane = threadIdx.x, wave = lane >> 6;
+    const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
+    unsigned long long *desc = state + 2, *tails = state + 2 + ngroups;
+    for (int i = lane; i < kTableWords; i += kGroup) tab[i] = a.tables[i];
+    // blocks of the luminance plane / of each chrominance plane: in all and per group
+    const uint64_t y_total = a.mode == 2 ? a.nblocks / 6 * 4 : (a.mode == 1 ? a.nblocks / 3 : a.nblocks);
+    const uint64_t c_total = a.mode == 2 ? a.nblocks / 6 : (a.mode == 1 ? a.nblocks / 3 : 0);
+    const uint32_t y_group = a.mode == 2 ? 128u : (a.mode == 1 ? 64u : 192u), c_group = a.mode == 2 ? 32u : 64u;
+    for (;;) {
+        __syncthreads(); // the previous group's buffer is written out, s_ticket is free
+        if (lane == 0) s_ticket = atomicAdd(&state[0], 1ull);
+        __syncthreads();
+        const uint64_t g = s_ticket;
+        if (g >= ngroups) return;
+        // ---- blocks in: coalesced 16-byte loads -> LDS (scan order, swizzled) -> 32 registers per lane
+        uint8_t *bytes = reinterpret_cast<uint8_t *>(buf);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const ChunkRef c = chunk_of(a.mode, i * kGroup + lane);
+            const uint64_t blk = g * (c.comp ? c_group : y_group) + c.plane_block;
+            const int16_t *base = c.comp == 0 ? a.y : (c.comp == 1 ? a.cb : a.cr);
+            v4u q = {0, 0, 0, 0};
+            if (blk < (c.comp ? c_total : y_total)) q = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(base + blk * 64) + c.row);
+            *reinterpret_cast<v4u *>(bytes + lds_chunk(c.pos, c.row)) = q;
+        }
+        __syncthreads();
+        const uint64_t s = g * kGroup + lane;
+        const bool live = s < a.nblocks;
+        uint32_t w[32];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const v4u q = *reinterpret_cast<const v4u *>(bytes + lds_chunk(lane, r));
+            w[4 * r] = q.x; w[4 * r + 1] = q.y; w[4 * r + 2] = q.z; w[4 * r + 3] = q.w;
+        }
+        // DC predictor: the previous block of the same component (jpeg/mod.rs:1417-1419); the scan's first blocks
+        // start from the seed (0, or the DCs above a band)
+        int prev_dc = 0, cls = 0;
+        if (live) {
+            const BlockRef ref = block_of(a.mode, s);
+            const int16_t *base = ref.comp == 0 ? a.y : (ref.comp == 1 ? a.cb : a.cr);
+            prev_dc = ref.index ? (int)base[(ref.index - 1) * 64] : (int)a.seed_dc[ref.comp];
+            cls = ref.comp == 0 ? 0 : 1;
+        }
+        // ---- walk 1: the block's length; group scan; look-back
+        uint32_t len = 0;
+        if (live) {
+            LengthVisitor v{tab + cls * kClassSyms, 0};
+            walk_block(w, prev_dc, v);
+            len = v.bits;
+        }
+        const uint32_t incl = wave_inclusive_scan(len);
+        if ((lane & 63) == 63) wave_sum[wave] = incl;
+        __syncthreads(); // (also: every lane has its block in registers, the staging area is free)
+        uint32_t wave_base = 0, group_bits = 0;
+#pragma unroll
+        for (int k = 0; k < kGroupWaves; k++) {
+            if (k < wave) wave_base += wave_sum[k];
+            group_bits += wave_sum[k];
+        }
+        if (lane == 0) s_before = look_back(desc, g, group_bits);
+        __syncthreads();
+        const uint64_t before = s_before;
+        const bool last_group = g + 1 == ngroups;
+        // stream bit where the group starts; the buffer's word 0 is stream word `first_word`
+        const uint64_t start = a.bit_base + before;
+        uint64_t end = start + group_bits;
+        if (last_group) {
+            if (lane == 0) state[1] = before + group_bits; // the scan's length in bits (unpadded)
+            if (a.pad_last) end = (end + 7) & ~7ull;         // BitWriterMsb::flush pads the last byte with 1-bits
+        }
+        const uint64_t first_word = start >> 5;
+        const uint32_t head_bits = (uint32_t)(start & 31);
+        const uint32_t nwords = (uint32_t)((end - (first_word << 5) + 31) >> 5);
+        const bool tail_partial = (end & 31) != 0 && !last_group; // the last word is finished by a later group
+        const bool pass_through = nwords == 1 && head_bits != 0 && tail_partial; // (a handful of bits inside one word)
+        const uint64_t my_bit = (uint64_t)head_bits + wave_base + (incl - len); // relative to the buffer
+        // ---- walk 2: pack into the LDS bit buffer, one window of kBufWords words per round (usually one)
+        for (uint32_t wbase = 0; wbase < nwords; wbase += kBufWords) {
+            const uint32_t wn = nwords - wbase < kBufWords ? nwords - wbase : kBufWords;
+            for (uint32_t i = lane; i < wn; i += kGroup) buf[i] = 0;
+            __syncthreads();
+            const int64_t rel = (int64_t)my_bit - (int64_t)wbase * 32;
+            // (opaque to the optimiser: otherwise everything the first walk derived from the 63 coefficients — values,
+            // magnitude categories, table words — stays alive for the second walk: 245 VGPRs instead of ~64)
+#pragma unroll
+            for (int i = 0; i < 32; i++) asm volatile("" : "+v"(w[i]));
+            if (live && rel < (int64_t)wn * 32 && rel + (int64_t)len > 0) {
+                WindowPack p;
+                p.tab = tab + cls * kClassSyms;
+                p.begin(buf, wn, rel);
+                walk_block(w, prev_dc, p);
+                p.finish();
+            }
+            if (last_group && a.pad_last && lane == 0) { // the 1-padding behind the scan's last bit
+                const uint64_t bits_end = start + group_bits;
+                const int n = (int)(end - bits_end);
+                if (n) {
+                    const uint64_t at = bits_end - (first_word << 5) - (uint64_t)wbase * 32; // < 2^32 when inside the window
+                    if (at < (uint64_t)wn * 32) atomicOr(&buf[at >> 5], ((1u << n) - 1u) << (32 - (int)(at & 31) - n));
+                }
+            }
+            __syncthreads();
+            // ---- out: every word of the window that this group completes, except the stream word it shares with
+            // the group before (word 0 of the first window when head_bits != 0)
+            const uint32_t lo = (wbase == 0 && head_bits != 0) ? 1u : 0u;
+            const uint32_t hi = (wbase + wn == nwords && tail_partial) ? wn - 1 : wn;
+            if (wbase + wn == nwords && tail_partial && !pass_through && lane == 0)
+                store_relaxed(&tails[g], kTailValid | buf[wn - 1]); // hand the unfinished word to the next group, early
+            for (uint32_t i = lo + lane; i < hi; i += kGroup)
+                __builtin_nontemporal_store(buf[i], &stream[first_word + wbase + i]);
+            if (wbase == 0 && head_bits != 0 && lane == 0) {
+                uint32_t inherited = 0;
+                if (g > 0) {
+                    unsigned long long t;
+                    do { t = load_relaxed(&tails[g - 1]); } while (!(t & kTailValid));
+                    inherited = (uint32_t)t;
+                }
+                const uint32_t merged = inherited | buf[0];
+                if (pass_through) store_relaxed(&tails[g], kTailValid | merged);
+                else __builtin_nontemporal_store(merged, &stream[first_word]);
+            }
+            __syncthreads();
+        }
+        if (nwords == 0 && lane == 0 && !last_group && (end & 31) != 0) { // (an empty group cannot occur: every block has bits)
+            store_relaxed(&tails[g], kTailValid);
+        }
+    }
+}
+
+// ---- stuff: 4 KiB tiles of the packed stream -----------------------------------------------------------------------
+constexpr int kStuffThreads = 256, kTileBytes = 4096; // 16 bytes per lane
+__device__ __forceinline__ uint32_t zero_byte_mask(uint32_t x)
+{ // 0x80 in every byte of x that is zero (exact)
+    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+
+__global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32_t *stream, const unsigned long long *code_state,
+                                                                   uint32_t shift, uint32_t band, unsigned long long *state,
+                                                                   uint8_t *out, uint64_t out_cap)
+{
+    // The bytes to stuff are the stream's bits from bit `shift` (< 8) on: 0 for a whole image (all bytes, the padded
+    // last one included); for a band that starts inside a byte of the scan, its first `shift` bits belong to the byte
+    // it shares with the band before, its whole bytes follow, the bits left over are the next band's business.
+    // state: [0] ticket, [1] stuffed bytes (out), [2] bytes of the packed stream that were stuffed (out), [3 ..] descriptors
+    __shared__ __attribute__((aligned(16))) uint8_t stage[2 * kTileBytes + 16];
+    __shared__ uint32_t wave_sum[kStuffThreads / 64];
+    __shared__ unsigned long long s_ticket, s_before;
+    const int lane = threadIdx.x, wave = lane >> 6;
+    const uint64_t total_bits = code_state[1];
+    const uint64_t nbytes = band ? (total_bits - (shift < total_bits ? shift : total_bits)) / 8 : (total_bits + 7) / 8;
+    const uint64_t ntiles = (nbytes + kTileBytes - 1) / kTileBytes;
+    unsigned long long *desc = state + 3;
+    if (ntiles == 0) {
+        if (blockIdx.x == 0 && lane == 0) { state[1] = 0; state[2] = 0; }
+        return;
+    }
+    for (;;) {
+        __syncthreads();
+        if (lane == 0) s_ticket = atomicAdd(&state[0], 1ull);
+        __syncthreads();
+        const uint64_t t = s_ticket;
+        if (t >= ntiles) return;
+        const uint64_t byte0 = t * kTileBytes + (uint64_t)lane * 16;
+        uint32_t w[4] = {0, 0, 0, 0};
+        uint32_t have = 0; // bytes of this lane that exist
+        if (byte0 < nbytes) {
+            have = nbytes - byte0 < 16 ? (uint32_t)(nbytes - byte0) : 16u;
+            const uint32_t *p = stream + byte0 / 4; // (the stream buffer has 32 bytes of slack behind its last word)
+            const v4u q = *reinterpret_cast<const v4u *>(p);
+            const uint32_t q4 = p[4];
+            if (shift) { // funnel: byte k of the output is bits [8 k + shift, 8 k + shift + 8) of the stream
+                w[0] = (q.x << shift) | (q.y >> (32 - shift)); w[1] = (q.y << shift) | (q.z >> (32 - shift));
+                w[2] = (q.z << shift) | (q.w >> (32 - shift)); w[3] = (q.w << shift) | (q4 >> (32 - shift));
+            } else {
+                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+            }
+        }
+        uint32_t ff = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t x = ~w[k]; // a 0xFF byte becomes 0x00
+            const uint32_t nb = have > 4u * k ? have - 4u * k : 0u; // bytes of this word that exist (MSB first)
+            if (nb < 4) x |= nb ? (0xFFFFFFFFu >> (8 * nb)) : 0xFFFFFFFFu;
+            ff += (uint32_t)__builtin_popcount(zero_byte_mask(x));
+        }
+        const uint32_t incl = wave_inclusive_scan(ff);
+        if ((lane & 63) == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t wave_base = 0, tile_ff = 0;
+#pragma unroll
+        for (int k = 0; k < kStuffThreads / 64; k++) {
+            if (k < wave) wave_base += wave_sum[k];
+            tile_ff += wave_sum[k];
+        }
+        if (lane == 0) s_before = look_back(desc, t, tile_ff);
+        __syncthreads();
+        const uint64_t ff_before = s_before;
+        const uint64_t tile_in = nbytes - t * kTileBytes < (uint64_t)kTileBytes ? nbytes - t * kTileBytes : (uint64_t)kTileBytes;
+        const uint64_t dst0 = t * kTileBytes + ff_before;      // where the tile's first output byte goes
+        const uint32_t tile_out = (uint32_t)tile_in + tile_ff; // bytes the tile produces
+        if (t + 1 == ntiles && lane == 0) { state[1] = dst0 + tile_out; state[2] = nbytes; }
+        // expand into LDS at the output's alignment: LDS dwords = global dwords
+        const uint32_t skew = (uint32_t)(dst0 & 3);
+        uint32_t at = skew + (uint32_t)lane * 16 + wave_base + (incl - ff);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if ((uint32_t)(4 * k + b) < have) {
+                    const uint8_t byte = (uint8_t)(w[k] >> (24 - 8 * b));
+                    stage[at++] = byte;
+                    if (byte == 0xFF) stage[at++] = 0x00;
+                }
+            }
+        }
+        __syncthreads();
+        // out: leading bytes up to the first aligned dword, aligned dwords, trailing bytes
+        const uint64_t base = dst0 - skew; // multiple of 4
+        const uint32_t end = skew + tile_out;
+        const uint32_t first_dw = skew ? 4u : 0u, last_dw = end & ~3u;
+        if (first_dw <= last_dw) {
+            for (uint32_t i = first_dw + 4u * lane; i < last_dw; i += 4u * kStuffThreads)
+                if (base + i + 4 <= out_cap) __builtin_nontemporal_store(*reinterpret_cast<const uint32_t *>(stage + i), reinterpret_cast<uint32_t *>(out + base + i));
+            if (lane < 4) { // bytes [skew, min(4, end)) and [last_dw, end)
+                const uint32_t i = skew + lane;
+                if (skew && i < 4 && i < end && base + i < out_cap) out[base + i] = stage[i];
+                const uint32_t j = last_dw + lane;
+                if (j < end && j >= first_dw && base + j < out_cap) out[base + j] = stage[j];
+            }
+        } else { // the whole tile lies inside one dword
+            if ((uint32_t)lane + skew < end && lane < 4 && base + skew + lane < out_cap) out[base + skew + lane] = stage[skew + lane];
+        }
+    }
+}
+} // namespace
+
+size_t fused_code_state_words(uint64_t nblocks) { return 2 + 2 * (size_t)((nblocks + kGroup - 1) / kGroup); }
+size_t fused_stuff_state_words(uint64_t max_stream_bytes) { return 3 + (size_t)((max_stream_bytes + kTileBytes - 1) / kTileBytes); }
+
+hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, uint32_t *d_stream, hipStream_t s)
+{
+    const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
+    if (ngroups == 0) return hipMemsetAsync(d_state, 0, 16, s);
+    hipError_t e = hipMemsetAsync(d_state, 0, fused_code_state_words(a.nblocks) * 8, s);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)(ngroups < 2048 ? ngroups : 2048);
+    hipLaunchKernelGGL(scan_code_kernel, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_stuff_fused(const uint32_t *d_stream, const unsigned long long *d_code_state, uint32_t shift, bool band,
+                              uint64_t max_stream_bytes, unsigned long long *d_state, uint8_t *d_out, uint64_t out_cap, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(d_state, 0, fused_stuff_state_words(max_stream_bytes) * 8, s);
+    if (e != hipSuccess) return e;
+    const uint64_t max_tiles = (max_stream_bytes + kTileBytes - 1) / kTileBytes;
+    const unsigned grid = (unsigned)(max_tiles < 1 ? 1 : (max_tiles < 1024 ? max_tiles : 1024));
+    hipLaunchKernelGGL(stuff_fused_kernel, dim3(grid), dim3(kStuffThreads), 0, s, d_stream, d_code_state, shift, band ? 1u : 0u, d_state,
+                       d_out, out_cap);
+    return hipGetLastError();
+}
+
+} // namespace pixo_dev

@@ -160,6 +160,96 @@ struct CountVisitor {
     PIXO_SMEM void eob() { bump(kDcSyms); }
 };
 
+// ---- the same walk without data-dependent branches (jpeg_scan_fused.hip) ------------------------------------------
+// walk_block above is written like the reference: per coefficient an if/else, a while loop for the 16-zero runs,
+// and inside the visitors more ifs.  On a wavefront every one of those is an exec-mask region — save, and, branch,
+// restore: ~70 scalar instructions per coefficient position, 4400 per block, and the scalar unit is shared by the
+// whole CU: that, not the vector work, bounded the entropy kernels.  The flat forms below compute every position's
+// contribution with selects; the only branches left are wave-uniform (a position at which no lane of the wavefront
+// holds a non-zero coefficient is skipped; 16-zero runs, rare, take a uniform side path).
+#if defined(PIXO_EMU)
+#define PIXO_ANY64(pred) (pred)
+PIXO_SDEV uint32_t scan_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31)); }
+#else
+#define PIXO_ANY64(pred) (__builtin_amdgcn_ballot_w64(pred) != 0)
+PIXO_SDEV uint32_t scan_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+#endif
+
+// bit length of one block (LengthVisitor's result)
+PIXO_SDEV uint32_t block_length_flat(const uint32_t *w, int prev_dc, const uint32_t *tab)
+{
+    const int diff = (int)(int16_t)(coef_of(w, 0) - prev_dc);
+    const int cat0 = magnitude_bits(diff);
+    uint32_t bits = (tab[cat0] >> 16) + (uint32_t)cat0;
+    const uint32_t zrl_len = tab[kDcSyms + 0xF0] >> 16, eob_len = tab[kDcSyms] >> 16;
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 1; k < 64; k++) {
+        const int v = coef_of(w, zigzag(k));
+        const bool nz = v != 0;
+        if (!PIXO_ANY64(nz)) { run++; continue; } // (wave-uniform on the device)
+        if (PIXO_ANY64(nz && run >= 16u)) // rare: ZRL codes in front of the symbol
+            bits += nz ? ((run & 16u) ? zrl_len : 0u) + ((run & 32u) ? 2u * zrl_len : 0u) : 0u;
+        const uint32_t cat = (uint32_t)magnitude_bits(v);
+        const uint32_t t = tab[kDcSyms + (((run & 15u) << 4) | cat)];
+        bits += nz ? (t >> 16) + cat : 0u;
+        run = nz ? 0u : run + 1u;
+    }
+    return bits + (run ? eob_len : 0u);
+}
+
+// Packing with selects.  `Sink` provides or_word(flush, word, value): OR `value` into word `word` of the
+// destination when `flush` (a no-op target otherwise) — every word of the destination starts out zero, so complete
+// words and the partial first / last word of a block are written the same way.
+template <class Sink> struct FlatPack {
+    Sink sink;
+    uint32_t acc;     // pending bits, left-aligned, zeros below
+    uint32_t pending; // < 32
+    uint32_t word;    // index of the word the pending bits belong to
+    PIXO_SMEM void put(uint32_t v, uint32_t n) // 0 <= n <= 27, v < 2^n (v = 0 when n = 0)
+    {
+        const uint32_t vl = v << ((32u - n) & 31u);            // left-aligned (n = 0: v = 0)
+        const uint32_t merged = acc | (vl >> pending);
+        const uint32_t spill = scan_alignbit(vl, 0u, pending); // the bits that did not fit: low word of {vl, 0} >> pending
+        const uint32_t total = pending + n;
+        const bool flush = total >= 32u;
+        sink.or_word(flush, word, merged);
+        word += flush ? 1u : 0u;
+        pending = total & 31u;
+        acc = flush ? spill : merged;
+    }
+    PIXO_SMEM void finish() { sink.or_word(pending != 0u, word, acc); }
+};
+
+template <class Sink> PIXO_SDEV void block_pack_flat(const uint32_t *w, int prev_dc, const uint32_t *tab, FlatPack<Sink> &p)
+{
+    const int diff = (int)(int16_t)(coef_of(w, 0) - prev_dc);
+    const int cat0 = magnitude_bits(diff);
+    const uint32_t t0 = tab[cat0];
+    p.put(((t0 & 0xFFFFu) << cat0) | value_bits(diff, cat0), (t0 >> 16) + (uint32_t)cat0);
+    const uint32_t zrl = tab[kDcSyms + 0xF0], eob = tab[kDcSyms];
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 1; k < 64; k++) {
+        const int v = coef_of(w, zigzag(k));
+        const bool nz = v != 0;
+        if (!PIXO_ANY64(nz)) { run++; continue; } // (wave-uniform on the device)
+        if (PIXO_ANY64(nz && run >= 16u)) {       // rare: up to three ZRL codes in front of the symbol
+#pragma unroll
+            for (uint32_t i = 0; i < 3; i++) {
+                const bool on = nz && (run >> 4) > i;
+                p.put(on ? (zrl & 0xFFFFu) : 0u, on ? (zrl >> 16) : 0u);
+            }
+        }
+        const uint32_t cat = (uint32_t)magnitude_bits(v);
+        const uint32_t t = tab[kDcSyms + (((run & 15u) << 4) | cat)];
+        const uint32_t code = ((t & 0xFFFFu) << cat) | value_bits(v, (int)cat);
+        p.put(nz ? code : 0u, nz ? (t >> 16) + cat : 0u);
+        run = nz ? 0u : run + 1u;
+    }
+    p.put(run ? (eob & 0xFFFFu) : 0u, run ? (eob >> 16) : 0u);
+}
+
 // ---- progressive scans (simple_progressive_script, progressive.rs:98-110) ------------------------
 // Seven single-component scans over the tuple, blocks in STORAGE order (jpeg/mod.rs:1286, :1350):
 //   0 DC Y   1 DC Cb   2 DC Cr   3 AC Y 1..10   4 AC Y 11..63   5 AC Cb 1..63   6 AC Cr 1..63

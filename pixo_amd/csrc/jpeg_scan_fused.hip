@@ -16,9 +16,15 @@
 //          tiles: 0xFF census per lane, wavefront scans, look-back for the tile's output position, bytes expanded
 //          into LDS and written out as aligned dwords.
 //
-// Both kernels take their work from a ticket counter (a group / tile only ever waits for lower tickets, which are
-// running or done: no assumption about dispatch order or residency), and neither needs a host round trip: `stuff`
-// reads the stream's length where `code` left it.
+// Neither kernel needs a host round trip: `stuff` reads the stream's length where `code` left it.
+//
+// Forward progress.  A group / tile waits only for LOWER workgroup ids (look-back, hand-off of the shared word).  The
+// hardware hands the workgroups of a 1-D grid to each XCD in increasing id order, so the smallest unfinished id is
+// either running or the next one its XCD starts: nothing it waits for can be missing.  (Taking ids from an atomic
+// ticket counter would not need that property — it was tried first: 2 x 2048 device-scope atomics on one address
+// cost 70 us per launch, more than the rest of the kernel.)  `stuff` does not know the number of tiles when it is
+// launched; its workgroups stride over the tiles, and their number is kept below what the device holds at once, so
+// that the workgroup a tile waits for is always resident.
 #include <hip/hip_runtime.h>
 
 #include "jpeg_entropy.hpp"
@@ -30,7 +36,8 @@ using namespace pixo_scan;
 namespace {
 constexpr int kGroup = 192;                  // lanes = blocks per group
 constexpr int kGroupWaves = kGroup / 64;
-constexpr uint32_t kBufWords = kGroup * 32;  // the 24 KiB block staging area doubles as the bit buffer
+constexpr uint32_t kWindowWords = 2048;               // the LDS bit buffer: 8 KiB hold a typical group (noise at q = 80: 5.4 KiB);
+constexpr uint32_t kBufWords = kWindowWords + kGroup; //   longer groups take more rounds; + one dummy word per lane for the sink
 constexpr uint64_t kFlagAggregate = 1ull << 62, kFlagPrefix = 2ull << 62, kValueMask = (1ull << 62) - 1;
 constexpr uint64_t kTailValid = 1ull << 63;
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -60,161 +67,123 @@ __device__ __forceinline__ void store_relaxed(unsigned long long *p, unsigned lo
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Inclusive prefix of everything before ticket `g` (decoupled look-back, one lane): descriptors hold flag + value
-// in ONE 64-bit word, so a single relaxed load sees a consistent pair.
+// Sum of everything before ticket `g` (decoupled look-back), by one whole wavefront: per round lane l inspects the
+// descriptors of tickets top - l - 64 i, i < 8, so that 512 predecessors are read at once (all loads in flight
+// together); a descriptor holds flag + value in ONE 64-bit word, so a single relaxed load sees a consistent pair.
+// Why so wide: every group of a launch is resident and reaches this point at about the same time, when no inclusive
+// prefix exists yet — each group then has to add up ALL aggregates before it, and a descriptor access is a round trip
+// to the fabric (the XCDs' L2s are not coherent with each other): one lane walking back took 100 us for the 4096x4096
+// image, 64 per round still 90 (32 dependent rounds for the last group).  Every lane returns the sum.
+constexpr int kLookBatch = 8;
 __device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t g, uint64_t aggregate)
 {
+    const int lane = threadIdx.x & 63;
     if (g == 0) {
-        store_relaxed(&desc[0], kFlagPrefix | aggregate);
+        if (lane == 0) store_relaxed(&desc[0], kFlagPrefix | aggregate);
         return 0;
     }
-    store_relaxed(&desc[g], kFlagAggregate | aggregate);
+    if (lane == 0) store_relaxed(&desc[g], kFlagAggregate | aggregate);
     uint64_t before = 0;
-    for (uint64_t j = g; j-- > 0;) {
-        unsigned long long d;
-        do { d = load_relaxed(&desc[j]); } while ((d >> 62) == 0);
-        before += d & kValueMask;
-        if ((d >> 62) == 2) break;
+    for (int64_t top = (int64_t)g - 1;; top -= 64 * kLookBatch) {
+        unsigned long long d[kLookBatch];
+#pragma unroll
+        for (int i = 0; i < kLookBatch; i++) {
+            const int64_t j = top - lane - 64 * i;
+            d[i] = j >= 0 ? load_relaxed(&desc[j]) : kFlagPrefix; // (below ticket 0: an inclusive prefix of nothing)
+        }
+        bool done = false;
+#pragma unroll
+        for (int i = 0; i < kLookBatch; i++) {
+            if (done) break; // (wave-uniform)
+            const int64_t j = top - lane - 64 * i;
+            while ((d[i] >> 62) == 0) { __builtin_amdgcn_s_sleep(1); d[i] = load_relaxed(&desc[j]); }
+            const uint64_t have_prefix = __builtin_amdgcn_ballot_w64((d[i] >> 62) == 2);
+            const int first = have_prefix ? __builtin_ctzll(have_prefix) : 64; // nearest predecessor that knows its inclusive prefix
+            // aggregates of the lanes in front of it (< 2^19 each: 32-bit sum), plus its prefix
+            const uint32_t part = lane < first ? (uint32_t)(d[i] & kValueMask) : 0u;
+            before += (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(part), 63);
+            if (have_prefix) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(d[i] & 0xFFFFFFFFu), first);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((d[i] & kValueMask) >> 32), first);
+                before += ((uint64_t)hi << 32) | lo;
+                done = true;
+            }
+        }
+        if (done) break;
     }
-    store_relaxed(&desc[g], kFlagPrefix | (before + aggregate));
+    if (lane == 0) store_relaxed(&desc[g], kFlagPrefix | (before + aggregate));
     return before;
 }
 
-// ---- the LDS bit buffer: PackVisitor of jpeg_scan_block.h over a window of words ----------------------------------
-// Word i of the buffer is word `first + i` of the stream.  Words a block covers completely are stored, its first and
-// last (shared with the neighbouring lanes' blocks) OR-ed with an LDS atomic; words outside [0, limit) — a group of
-// very long blocks is written out in more than one round — are skipped.
-struct WindowPack {
-    const uint32_t *tab;
+// ---- the LDS bit buffer: sink of block_pack_flat (jpeg_scan_block.h) over a window of words --------------------------
+// Word i of the window is word `first + i` of the stream; every word starts out zero and is only ever OR-ed (LDS
+// atomic without return).  Words outside [0, limit) — a group of very long blocks is written out in more than one
+// round — and the "no flush" case go to a per-lane dummy word behind the window: no branch.
+struct LdsSink {
     uint32_t *buf;
-    uint32_t limit;   // words in the window
-    uint64_t acc;
-    int pending;
-    uint32_t word;    // relative to the window; wraps below zero for words before it
-    bool first;
-    __device__ __forceinline__ void begin(uint32_t *b, uint32_t lim, int64_t bit_pos)
-    { // bit_pos: the block's first bit relative to the window's first word (may be negative)
-        buf = b; limit = lim; acc = 0; first = true;
-        pending = (int)(bit_pos & 31);
-        word = (uint32_t)(bit_pos >> 5);
-    }
-    __device__ __forceinline__ void or_word(uint32_t i, uint32_t v)
+    uint32_t limit, dummy;
+    __device__ __forceinline__ void or_word(bool flush, uint32_t word, uint32_t value)
     {
-        if (i < limit && v) atomicOr(&buf[i], v);
+        const uint32_t i = (flush && word < limit) ? word : dummy;
+        (void)__hip_atomic_fetch_or(&buf[i], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    __device__ __forceinline__ void put(uint32_t v, int n)
-    {
-        acc = (acc << n) | v;
-        pending += n;
-        if (pending >= 32) {
-            const uint32_t out = (uint32_t)(acc >> (pending - 32));
-            if (first) { or_word(word, out); first = false; }
-            else if (word < limit) buf[word] = out;
-            word++;
-            pending -= 32;
-            acc &= (1ull << pending) - 1ull;
-        }
-    }
-    __device__ __forceinline__ void finish()
-    {
-        if (pending > 0) or_word(word, (uint32_t)(acc << (32 - pending)));
-    }
-    __device__ __forceinline__ void dc(int cat, int diff)
-    {
-        const uint32_t t = tab[cat];
-        put(((t & 0xFFFF) << cat) | value_bits(diff, cat), (int)(t >> 16) + cat);
-    }
-    __device__ __forceinline__ void ac(int rs, int cat, int v)
-    {
-        const uint32_t t = tab[kDcSyms + rs];
-        put(((t & 0xFFFF) << cat) | value_bits(v, cat), (int)(t >> 16) + cat);
-    }
-    __device__ __forceinline__ void zrl() { const uint32_t t = tab[kDcSyms + 0xF0]; put(t & 0xFFFF, (int)(t >> 16)); }
-    __device__ __forceinline__ void eob() { const uint32_t t = tab[kDcSyms]; put(t & 0xFFFF, (int)(t >> 16)); }
 };
 
-// chunk (16 bytes) c of a group's 1536 -> which plane, which block of the group (scan position), which row
-struct ChunkRef { int comp; uint32_t plane_block; int pos, row; };
-__device__ __forceinline__ ChunkRef chunk_of(int mode, int c)
-{
-    ChunkRef r;
-    r.row = c & 7;
-    const int b = c >> 3; // 0..191
-    if (mode == 0) { r.comp = 0; r.plane_block = (uint32_t)b; r.pos = b; }
-    else if (mode == 1) { r.comp = b >> 6; r.plane_block = (uint32_t)(b & 63); r.pos = 3 * (b & 63) + r.comp; }
-    else if (b < 128) { r.comp = 0; r.plane_block = (uint32_t)b; r.pos = 6 * (b >> 2) + (b & 3); }
-    else { r.comp = 1 + ((b - 128) >> 5); r.plane_block = (uint32_t)((b - 128) & 31); r.pos = 6 * ((b - 128) & 31) + 3 + r.comp; }
-    return r;
-}
-__device__ __forceinline__ int lds_chunk(int pos, int row) { return pos * 128 + (((row ^ pos) & 7) << 4); }
-
+template <int MODE>
 __global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, unsigned long long *state, uint32_t *stream)
 {
-    // state: [0] ticket, [1] total bits (out), [2 ..] per group: descriptor, then per group: tail
+    // state: [0] unused, [1] total bits (out), [2 ..] per group: descriptor, then per group: tail
     __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
     __shared__ uint32_t tab[kTableWords];
     __shared__ uint32_t wave_sum[kGroupWaves];
-    __shared__ unsigned long long s_ticket, s_before;
+    __shared__ unsigned long long s_before;
     const int lane = threadIdx.x, wave = lane >> 6;
     const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
     unsigned long long *desc = state + 2, *tails = state + 2 + ngroups;
     for (int i = lane; i < kTableWords; i += kGroup) tab[i] = a.tables[i];
-    // blocks of the luminance plane / of each chrominance plane: in all and per group
-    const uint64_t y_total = a.mode == 2 ? a.nblocks / 6 * 4 : (a.mode == 1 ? a.nblocks / 3 : a.nblocks);
-    const uint64_t c_total = a.mode == 2 ? a.nblocks / 6 : (a.mode == 1 ? a.nblocks / 3 : 0);
-    const uint32_t y_group = a.mode == 2 ? 128u : (a.mode == 1 ? 64u : 192u), c_group = a.mode == 2 ? 32u : 64u;
-    for (;;) {
-        __syncthreads(); // the previous group's buffer is written out, s_ticket is free
-        if (lane == 0) s_ticket = atomicAdd(&state[0], 1ull);
-        __syncthreads();
-        const uint64_t g = s_ticket;
-        if (g >= ngroups) return;
-        // ---- blocks in: coalesced 16-byte loads -> LDS (scan order, swizzled) -> 32 registers per lane
-        uint8_t *bytes = reinterpret_cast<uint8_t *>(buf);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const ChunkRef c = chunk_of(a.mode, i * kGroup + lane);
-            const uint64_t blk = g * (c.comp ? c_group : y_group) + c.plane_block;
-            const int16_t *base = c.comp == 0 ? a.y : (c.comp == 1 ? a.cb : a.cr);
-            v4u q = {0, 0, 0, 0};
-            if (blk < (c.comp ? c_total : y_total)) q = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(base + blk * 64) + c.row);
-            *reinterpret_cast<v4u *>(bytes + lds_chunk(c.pos, c.row)) = q;
-        }
-        __syncthreads();
+    __syncthreads();
+    { // (one group per workgroup; see the note on dispatch order at the top of the file)
+        const uint64_t g = blockIdx.x;
+        // ---- blocks in: 8 x 16 bytes per lane straight into 32 registers (a lane's block is one 128-byte line; staging
+        // the group through LDS for perfectly coalesced loads cost 24 KiB per group and with it half the occupancy)
         const uint64_t s = g * kGroup + lane;
         const bool live = s < a.nblocks;
         uint32_t w[32];
+        {
+            const BlockRef ref = block_of(MODE, live ? s : 0);
+            const int16_t *base = ref.comp == 0 ? a.y : (ref.comp == 1 ? a.cb : a.cr);
+            const v4u *p = reinterpret_cast<const v4u *>(base + ref.index * 64);
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const v4u q = *reinterpret_cast<const v4u *>(bytes + lds_chunk(lane, r));
-            w[4 * r] = q.x; w[4 * r + 1] = q.y; w[4 * r + 2] = q.z; w[4 * r + 3] = q.w;
+            for (int r = 0; r < 8; r++) {
+                const v4u q = __builtin_nontemporal_load(p + r);
+                w[4 * r] = q.x; w[4 * r + 1] = q.y; w[4 * r + 2] = q.z; w[4 * r + 3] = q.w;
+            }
         }
         // DC predictor: the previous block of the same component (jpeg/mod.rs:1417-1419); the scan's first blocks
         // start from the seed (0, or the DCs above a band)
         int prev_dc = 0, cls = 0;
         if (live) {
-            const BlockRef ref = block_of(a.mode, s);
+            const BlockRef ref = block_of(MODE, s);
             const int16_t *base = ref.comp == 0 ? a.y : (ref.comp == 1 ? a.cb : a.cr);
             prev_dc = ref.index ? (int)base[(ref.index - 1) * 64] : (int)a.seed_dc[ref.comp];
             cls = ref.comp == 0 ? 0 : 1;
         }
         // ---- walk 1: the block's length; group scan; look-back
-        uint32_t len = 0;
-        if (live) {
-            LengthVisitor v{tab + cls * kClassSyms, 0};
-            walk_block(w, prev_dc, v);
-            len = v.bits;
-        }
+        uint32_t len = block_length_flat(w, prev_dc, tab + cls * kClassSyms);
+        if (!live) len = 0;
         const uint32_t incl = wave_inclusive_scan(len);
         if ((lane & 63) == 63) wave_sum[wave] = incl;
-        __syncthreads(); // (also: every lane has its block in registers, the staging area is free)
+        __syncthreads();
         uint32_t wave_base = 0, group_bits = 0;
 #pragma unroll
         for (int k = 0; k < kGroupWaves; k++) {
             if (k < wave) wave_base += wave_sum[k];
             group_bits += wave_sum[k];
         }
-        if (lane == 0) s_before = look_back(desc, g, group_bits);
+        if (wave == 0) {
+            const uint64_t sum = look_back(desc, g, group_bits);
+            if (lane == 0) s_before = sum;
+        }
         __syncthreads();
         const uint64_t before = s_before;
         const bool last_group = g + 1 == ngroups;
@@ -232,8 +201,8 @@ __global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, uns
         const bool pass_through = nwords == 1 && head_bits != 0 && tail_partial; // (a handful of bits inside one word)
         const uint64_t my_bit = (uint64_t)head_bits + wave_base + (incl - len); // relative to the buffer
         // ---- walk 2: pack into the LDS bit buffer, one window of kBufWords words per round (usually one)
-        for (uint32_t wbase = 0; wbase < nwords; wbase += kBufWords) {
-            const uint32_t wn = nwords - wbase < kBufWords ? nwords - wbase : kBufWords;
+        for (uint32_t wbase = 0; wbase < nwords; wbase += kWindowWords) {
+            const uint32_t wn = nwords - wbase < kWindowWords ? nwords - wbase : kWindowWords;
             for (uint32_t i = lane; i < wn; i += kGroup) buf[i] = 0;
             __syncthreads();
             const int64_t rel = (int64_t)my_bit - (int64_t)wbase * 32;
@@ -241,11 +210,13 @@ __global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, uns
             // magnitude categories, table words — stays alive for the second walk: 245 VGPRs instead of ~64)
 #pragma unroll
             for (int i = 0; i < 32; i++) asm volatile("" : "+v"(w[i]));
-            if (live && rel < (int64_t)wn * 32 && rel + (int64_t)len > 0) {
-                WindowPack p;
-                p.tab = tab + cls * kClassSyms;
-                p.begin(buf, wn, rel);
-                walk_block(w, prev_dc, p);
+            if (PIXO_ANY64(live && rel < (int64_t)wn * 32 && rel + (int64_t)len > 0)) { // (some block of the wavefront lies in the window)
+                FlatPack<LdsSink> p;
+                p.sink = LdsSink{buf, live ? wn : 0u, kWindowWords + (uint32_t)lane};
+                p.acc = 0;
+                p.pending = (uint32_t)(rel & 31);
+                p.word = (uint32_t)(rel >> 5); // relative to the window; wraps below zero for words before it
+                block_pack_flat(w, prev_dc, tab + cls * kClassSyms, p);
                 p.finish();
             }
             if (last_group && a.pad_last && lane == 0) { // the 1-padding behind the scan's last bit
@@ -286,6 +257,7 @@ __global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, uns
 
 // ---- stuff: 4 KiB tiles of the packed stream -----------------------------------------------------------------------
 constexpr int kStuffThreads = 256, kTileBytes = 4096; // 16 bytes per lane
+constexpr uint32_t kStageBytes = 2 * kTileBytes + 16; // worst case: every byte 0xFF, + the output's alignment skew
 __device__ __forceinline__ uint32_t zero_byte_mask(uint32_t x)
 { // 0x80 in every byte of x that is zero (exact)
     return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
@@ -298,10 +270,10 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
     // The bytes to stuff are the stream's bits from bit `shift` (< 8) on: 0 for a whole image (all bytes, the padded
     // last one included); for a band that starts inside a byte of the scan, its first `shift` bits belong to the byte
     // it shares with the band before, its whole bytes follow, the bits left over are the next band's business.
-    // state: [0] ticket, [1] stuffed bytes (out), [2] bytes of the packed stream that were stuffed (out), [3 ..] descriptors
-    __shared__ __attribute__((aligned(16))) uint8_t stage[2 * kTileBytes + 16];
+    // state: [0] unused, [1] stuffed bytes (out), [2] bytes of the packed stream that were stuffed (out), [3 ..] descriptors
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes + kStuffThreads];
     __shared__ uint32_t wave_sum[kStuffThreads / 64];
-    __shared__ unsigned long long s_ticket, s_before;
+    __shared__ unsigned long long s_before;
     const int lane = threadIdx.x, wave = lane >> 6;
     const uint64_t total_bits = code_state[1];
     const uint64_t nbytes = band ? (total_bits - (shift < total_bits ? shift : total_bits)) / 8 : (total_bits + 7) / 8;
@@ -311,12 +283,9 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
         if (blockIdx.x == 0 && lane == 0) { state[1] = 0; state[2] = 0; }
         return;
     }
-    for (;;) {
-        __syncthreads();
-        if (lane == 0) s_ticket = atomicAdd(&state[0], 1ull);
-        __syncthreads();
-        const uint64_t t = s_ticket;
-        if (t >= ntiles) return;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) { // (gridDim.x workgroups are co-resident: see the launcher)
+        __syncthreads(); // the previous tile's stage is written out
+        for (uint32_t i = 16u * lane; i < kStageBytes; i += 16u * kStuffThreads) *reinterpret_cast<v4u *>(stage + i) = v4u{0, 0, 0, 0};
         const uint64_t byte0 = t * kTileBytes + (uint64_t)lane * 16;
         uint32_t w[4] = {0, 0, 0, 0};
         uint32_t have = 0; // bytes of this lane that exist
@@ -332,14 +301,15 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
                 w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
             }
         }
-        uint32_t ff = 0;
+        // one flag per byte, stream order (bit i = byte i of the lane is 0xFF and exists)
+        uint32_t flags = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t x = ~w[k]; // a 0xFF byte becomes 0x00
-            const uint32_t nb = have > 4u * k ? have - 4u * k : 0u; // bytes of this word that exist (MSB first)
-            if (nb < 4) x |= nb ? (0xFFFFFFFFu >> (8 * nb)) : 0xFFFFFFFFu;
-            ff += (uint32_t)__builtin_popcount(zero_byte_mask(x));
+            const uint32_t m = (zero_byte_mask(~w[k]) >> 7) & 0x01010101u;  // bits 24, 16, 8, 0 = stream bytes 0, 1, 2, 3 of the word
+            flags |= ((m * 0x08040201u) >> 24 & 0xFu) << (4 * k);
         }
+        flags &= have >= 16u ? 0xFFFFu : ((1u << have) - 1u);
+        const uint32_t ff = (uint32_t)__builtin_popcount(flags);
         const uint32_t incl = wave_inclusive_scan(ff);
         if ((lane & 63) == 63) wave_sum[wave] = incl;
         __syncthreads();
@@ -349,26 +319,27 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
             if (k < wave) wave_base += wave_sum[k];
             tile_ff += wave_sum[k];
         }
-        if (lane == 0) s_before = look_back(desc, t, tile_ff);
+        if (wave == 0) {
+            const uint64_t sum = look_back(desc, t, tile_ff);
+            if (lane == 0) s_before = sum;
+        }
         __syncthreads();
         const uint64_t ff_before = s_before;
         const uint64_t tile_in = nbytes - t * kTileBytes < (uint64_t)kTileBytes ? nbytes - t * kTileBytes : (uint64_t)kTileBytes;
         const uint64_t dst0 = t * kTileBytes + ff_before;      // where the tile's first output byte goes
         const uint32_t tile_out = (uint32_t)tile_in + tile_ff; // bytes the tile produces
         if (t + 1 == ntiles && lane == 0) { state[1] = dst0 + tile_out; state[2] = nbytes; }
-        // expand into LDS at the output's alignment: LDS dwords = global dwords
+        // expand into LDS at the output's alignment (LDS dwords = global dwords).  The stage was zeroed: only the
+        // stream's bytes are written, each moved up by the number of 0xFF bytes before it — the gaps ARE the stuffed
+        // zeros.  No branch per byte: lanes without a byte at position i write into a dummy byte.
         const uint32_t skew = (uint32_t)(dst0 & 3);
-        uint32_t at = skew + (uint32_t)lane * 16 + wave_base + (incl - ff);
+        const uint32_t at0 = skew + (uint32_t)lane * 16 + wave_base + (incl - ff);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                if ((uint32_t)(4 * k + b) < have) {
-                    const uint8_t byte = (uint8_t)(w[k] >> (24 - 8 * b));
-                    stage[at++] = byte;
-                    if (byte == 0xFF) stage[at++] = 0x00;
-                }
-            }
+        for (int i = 0; i < 16; i++) {
+            const uint32_t byte = (w[i >> 2] >> (24 - 8 * (i & 3))) & 0xFFu;
+            const uint32_t moved = (uint32_t)__builtin_popcount(flags & ((1u << i) - 1u));
+            const uint32_t at = (uint32_t)i < have ? at0 + (uint32_t)i + moved : kStageBytes + (uint32_t)lane;
+            stage[at] = (uint8_t)byte;
         }
         __syncthreads();
         // out: leading bytes up to the first aligned dword, aligned dwords, trailing bytes
@@ -400,8 +371,11 @@ hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, uint
     if (ngroups == 0) return hipMemsetAsync(d_state, 0, 16, s);
     hipError_t e = hipMemsetAsync(d_state, 0, fused_code_state_words(a.nblocks) * 8, s);
     if (e != hipSuccess) return e;
-    const unsigned grid = (unsigned)(ngroups < 2048 ? ngroups : 2048);
-    hipLaunchKernelGGL(scan_code_kernel, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream);
+    if (ngroups > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)ngroups;
+    if (a.mode == 2) hipLaunchKernelGGL(scan_code_kernel<2>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream);
+    else if (a.mode == 1) hipLaunchKernelGGL(scan_code_kernel<1>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream);
+    else hipLaunchKernelGGL(scan_code_kernel<0>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream);
     return hipGetLastError();
 }
 

@@ -205,6 +205,57 @@ extern "C" void emu_scan_tables(const int16_t *y, const int16_t *cb, const int16
     pixo_host::pack_scan_tables(hs, out);
 }
 
+// The branch-free walkers of the single-pass kernels (block_length_flat / block_pack_flat, jpeg_scan_fused.hip) in
+// the same harness: lengths, prefix sum, packing in reverse block order into a zeroed stream, padding, stuffing.
+struct EmuOrSink {
+    uint32_t *stream;
+    uint64_t first_word; // the packer's word index is relative to this
+    void or_word(bool flush, uint32_t word, uint32_t value) { if (flush) stream[first_word + word] |= value; }
+};
+extern "C" long emu_scan_flat(const int16_t *y, const int16_t *cb, const int16_t *cr, int mode, uint64_t nblocks,
+                              const uint32_t *tables, uint8_t *out, long cap)
+{
+    using namespace pixo_scan;
+    std::vector<uint32_t> len(nblocks);
+    std::vector<uint64_t> off(nblocks);
+    auto load = [&](uint64_t s, uint32_t *wds, int *prev, int *cls) {
+        const BlockRef r = block_of(mode, s);
+        const int16_t *base = r.comp == 0 ? y : (r.comp == 1 ? cb : cr);
+        memcpy(wds, base + r.index * 64, 128);
+        *prev = r.index ? base[(r.index - 1) * 64] : 0;
+        *cls = r.comp ? 1 : 0;
+    };
+    uint64_t total = 0;
+    for (uint64_t s = 0; s < nblocks; s++) {
+        uint32_t wds[32]; int prev, cls;
+        load(s, wds, &prev, &cls);
+        len[s] = block_length_flat(wds, prev, tables + cls * kClassSyms);
+        off[s] = total; total += len[s];
+    }
+    std::vector<uint32_t> stream(total / 32 + 2, 0);
+    for (uint64_t i = nblocks; i-- > 0;) {
+        uint32_t wds[32]; int prev, cls;
+        load(i, wds, &prev, &cls);
+        FlatPack<EmuOrSink> p;
+        p.sink = EmuOrSink{stream.data(), off[i] >> 5};
+        p.acc = 0; p.pending = (uint32_t)(off[i] & 31); p.word = 0;
+        block_pack_flat(wds, prev, tables + cls * kClassSyms, p);
+        p.finish();
+        if (p.word * 32ull + p.pending != (off[i] & 31) + len[i]) return -2; // the two flat walks must agree on the length
+    }
+    const int n = (int)((8 - (total & 7)) & 7);
+    if (n) stream[total >> 5] |= ((1u << n) - 1u) << (32 - (int)(total & 31) - n);
+    const uint64_t nbytes = (total + 7) / 8;
+    long o = 0;
+    for (uint64_t b = 0; b < nbytes; b++) {
+        const uint8_t byte = (uint8_t)(stream[b >> 2] >> (24 - 8 * (b & 3)));
+        if (o + 2 > cap) return -1;
+        out[o++] = byte;
+        if (byte == 0xFF) out[o++] = 0x00;
+    }
+    return o;
+}
+
 extern "C" long emu_scan(const int16_t *y, const int16_t *cb, const int16_t *cr, int mode, uint64_t nblocks,
                          const uint32_t *tables, uint8_t *out, long cap)
 {

@@ -1,8 +1,9 @@
 """The DEVICE entropy-stage block code (pixo_amd/csrc/jpeg_scan_block.h: zig-zag walk, Huffman
 symbols, MSB-first packing at a bit offset, 1-padding) compiled for the host and run block by
 block — in reverse order, like lanes racing — against the oracle's entropy-coded segment.
-Covers on CPU what jpeg_entropy.hip does per lane; the workgroup scans and the stuffing copy
-are checked on the GPU (test_gpu_parity.py, whole-file byte identity)."""
+Covers on CPU what jpeg_entropy.hip and jpeg_scan_fused.hip do per lane — both forms of the walk: the
+reference-shaped one with visitors and the branch-free one; the workgroup scans, the look-back and the
+stuffing copy are checked on the GPU (test_gpu_parity.py, whole-file byte identity)."""
 import ctypes as C
 
 import numpy as np
@@ -25,17 +26,18 @@ def _scan_segment(jpeg: bytes) -> bytes:
             return jpeg[i:-2]
 
 
-def _emu_scan(y, cb, cr, w, h, ct, ss, optimize):
+def _emu_scan(y, cb, cr, w, h, ct, ss, optimize, flat=False):
     L = E.lib()
-    L.emu_scan.restype = C.c_long
-    L.emu_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_long]
+    fn = L.emu_scan_flat if flat else L.emu_scan
+    fn.restype = C.c_long
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_long]
     L.emu_scan_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
     tables = np.zeros(536, np.uint32)
     L.emu_scan_tables(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, w, h, ct, ss, int(optimize), tables.ctypes.data)
     mode = 0 if ct == 0 else (2 if ss == 1 else 1)
     n = y.shape[0] + cb.shape[0] + cr.shape[0]
     out = np.zeros(n * 260 + 64, np.uint8)
-    got = L.emu_scan(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, mode, n, tables.ctypes.data, out.ctypes.data, out.size)
+    got = fn(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, mode, n, tables.ctypes.data, out.ctypes.data, out.size)
     assert got >= 0
     return out[:got].tobytes()
 
@@ -44,6 +46,8 @@ def _check(px, w, h, ct, ss, q, optimize=False):
     y, cb, cr = O.coeffs(px, w, h, ct, ss, q)
     want = _scan_segment(O.encode_from_coeffs(y, cb, cr, O.make_options(w, h, ct, q, ss, optimize_huffman=optimize)))
     assert _emu_scan(y, cb, cr, w, h, ct, ss, optimize) == want
+    # the branch-free walkers of the single-pass kernels (block_length_flat / block_pack_flat)
+    assert _emu_scan(y, cb, cr, w, h, ct, ss, optimize, flat=True) == want
 
 
 @pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])

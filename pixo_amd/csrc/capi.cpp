@@ -492,10 +492,13 @@ int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_b
     }
     // entropy-coded data holds a 0xFF every ~256 bytes; start from a quarter of the worst-case stream and grow on demand
     size_t want_cap = chained ? std::max<size_t>(j.stream_cap / 4, 4096) : static_cast<size_t>(j.nbytes + j.nbytes / 64 + 4096);
+    // tiles: the exact number when the stream's length is known, otherwise a guess (64 bytes per block; noise at q = 80
+    // has 28) — surplus workgroups leave at once, missing ones are launched below
+    uint64_t first_tile = 0, tiles = chained ? pd::stuff_tiles(std::min<uint64_t>(j.stream_cap, j.n * 64 + 4096)) : pd::stuff_tiles(j.nbytes);
     for (int attempt = 0;; ++attempt) {
         HIP_TRY(c.e_out.reserve(want_cap));
         HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), shift, j.band, j.stream_cap,
-                                       c.e_stuff_state.as<unsigned long long>(), c.e_out.as<uint8_t>(), c.e_out.cap, stream));
+                                       first_tile, tiles, c.e_stuff_state.as<unsigned long long>(), c.e_out.as<uint8_t>(), c.e_out.cap, stream));
         HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_code_state.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(c.h_totals + 1, c.e_stuff_state.as<uint64_t>() + 1, 16, hipMemcpyDeviceToHost, stream));
         uint32_t edge[3] = {0, 0, 0}; // band: stream word 0 (head bits) and the two words around the tail bits
@@ -506,11 +509,20 @@ int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_b
         }
         HIP_TRY(hipStreamSynchronize(stream));
         j.total_bits = c.h_totals[0];
+        const uint64_t packed = j.band ? (j.total_bits - j.head_bits) / 8 : (j.total_bits + 7) / 8;
+        if (pd::stuff_tiles(packed) > first_tile + tiles) { // the guess was short: the tiles behind it, same buffers
+            if (attempt > 2) return fail(PIXO_ERR_COMPRESSION, "Compression error: packed stream longer than announced");
+            first_tile += tiles;
+            tiles = pd::stuff_tiles(packed) - first_tile;
+            continue;
+        }
         j.scan_bytes = c.h_totals[1];
         j.nbytes = c.h_totals[2];
         if (j.scan_bytes > c.e_out.cap) { // (first call with unusually many 0xFF bytes: grow and repeat the stuffing pass only)
-            if (attempt) return fail(PIXO_ERR_COMPRESSION, "Compression error: stuffed stream larger than announced");
+            if (attempt > 2) return fail(PIXO_ERR_COMPRESSION, "Compression error: stuffed stream larger than announced");
             want_cap = static_cast<size_t>(j.scan_bytes);
+            first_tile = 0;
+            tiles = pd::stuff_tiles(packed);
             continue;
         }
         if (j.band) {

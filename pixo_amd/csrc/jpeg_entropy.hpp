@@ -71,9 +71,13 @@ hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, uint
 // from d_code_state[1] (no host round trip).  d_state: fused_stuff_state_words(max_stream_bytes) u64; afterwards
 // d_state[1] = bytes produced (bytes beyond out_cap are not written: the caller grows d_out and repeats this launch),
 // d_state[2] = bytes of the packed stream consumed.
+// One workgroup per tile: tiles [first_tile, first_tile + tiles) of stuff_tiles(stream bytes); the caller launches a
+// guess, reads d_state[2] back and, if the stream has more tiles, launches the rest (first_tile > 0 keeps the state).
 size_t fused_stuff_state_words(uint64_t max_stream_bytes);
+uint64_t stuff_tiles(uint64_t stream_bytes);
 hipError_t launch_stuff_fused(const uint32_t *d_stream, const unsigned long long *d_code_state, uint32_t shift, bool band,
-                              uint64_t max_stream_bytes, unsigned long long *d_state, uint8_t *d_out, uint64_t out_cap, hipStream_t s);
+                              uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state, uint8_t *d_out,
+                              uint64_t out_cap, hipStream_t s);
 
 // ---- progressive scans on the device (simple_progressive_script: seven single-component scans) ------
 struct ProgArgs {

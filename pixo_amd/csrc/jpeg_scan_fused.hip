@@ -12,7 +12,7 @@
 //          writes the buffer out with coalesced dword stores.  The word two neighbouring groups share is written by
 //          the later one, which receives the earlier one's bits through a second descriptor: no atomics on the
 //          stream, no zero-filling of it.
-//   stuff  packed stream -> final bytes with 0x00 after every 0xFF (BitWriterMsb, src/bits.rs:245-253), 4 KiB
+//   stuff  packed stream -> final bytes with 0x00 after every 0xFF (BitWriterMsb, src/bits.rs:245-253), 16 KiB
 //          tiles: 0xFF census per lane, wavefront scans, look-back for the tile's output position, bytes expanded
 //          into LDS and written out as aligned dwords.
 //
@@ -22,9 +22,10 @@
 // hardware hands the workgroups of a 1-D grid to each XCD in increasing id order, so the smallest unfinished id is
 // either running or the next one its XCD starts: nothing it waits for can be missing.  (Taking ids from an atomic
 // ticket counter would not need that property — it was tried first: 2 x 2048 device-scope atomics on one address
-// cost 70 us per launch, more than the rest of the kernel.)  `stuff` does not know the number of tiles when it is
-// launched; its workgroups stride over the tiles, and their number is kept below what the device holds at once, so
-// that the workgroup a tile waits for is always resident.
+// cost 70 us per launch, more than the rest of the kernel.  Workgroups that stride over several tiles would need all
+// of them resident at once, which two such kernels from two host threads can deny each other.)  `stuff` does not know
+// the number of tiles when it is launched: it gets one workgroup per tile of a generous guess — surplus workgroups
+// leave at once — and, if the stream turns out longer, a second launch for the tiles behind the guess.
 #include <hip/hip_runtime.h>
 
 #include "jpeg_entropy.hpp"
@@ -75,14 +76,14 @@ __device__ __forceinline__ void store_relaxed(unsigned long long *p, unsigned lo
 // to the fabric (the XCDs' L2s are not coherent with each other): one lane walking back took 100 us for the 4096x4096
 // image, 64 per round still 90 (32 dependent rounds for the last group).  Every lane returns the sum.
 constexpr int kLookBatch = 8;
+__device__ __forceinline__ void publish_aggregate(unsigned long long *desc, uint64_t g, uint64_t aggregate)
+{ // (one lane) as early as possible: the groups behind this one wait for it
+    store_relaxed(&desc[g], (g == 0 ? kFlagPrefix : kFlagAggregate) | aggregate);
+}
 __device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t g, uint64_t aggregate)
-{
+{ // (after publish_aggregate)
     const int lane = threadIdx.x & 63;
-    if (g == 0) {
-        if (lane == 0) store_relaxed(&desc[0], kFlagPrefix | aggregate);
-        return 0;
-    }
-    if (lane == 0) store_relaxed(&desc[g], kFlagAggregate | aggregate);
+    if (g == 0) return 0;
     uint64_t before = 0;
     for (int64_t top = (int64_t)g - 1;; top -= 64 * kLookBatch) {
         unsigned long long d[kLookBatch];
@@ -111,8 +112,7 @@ __device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t
         }
         if (done) break;
     }
-    if (lane == 0) store_relaxed(&desc[g], kFlagPrefix | (before + aggregate));
-    return before;
+    return before; // (the caller publishes before + aggregate as this ticket's inclusive prefix)
 }
 
 // ---- the LDS bit buffer: sink of block_pack_flat (jpeg_scan_block.h) over a window of words --------------------------
@@ -137,15 +137,19 @@ __global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, uns
     __shared__ uint32_t tab[kTableWords];
     __shared__ uint32_t wave_sum[kGroupWaves];
     __shared__ unsigned long long s_before;
+    __shared__ uint32_t s_carry;
     const int lane = threadIdx.x, wave = lane >> 6;
+    if (lane == 0) s_carry = 0;
     const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
     unsigned long long *desc = state + 2, *tails = state + 2 + ngroups;
     for (int i = lane; i < kTableWords; i += kGroup) tab[i] = a.tables[i];
     __syncthreads();
     { // (one group per workgroup; see the note on dispatch order at the top of the file)
         const uint64_t g = blockIdx.x;
-        // ---- blocks in: 8 x 16 bytes per lane straight into 32 registers (a lane's block is one 128-byte line; staging
-        // the group through LDS for perfectly coalesced loads cost 24 KiB per group and with it half the occupancy)
+        // ---- blocks in: 8 x 16 bytes per lane straight into 32 registers.  A lane's block is one 128-byte line that its
+        // eight loads touch one after the other: cached loads (the line stays in L1 for the other seven), not
+        // non-temporal ones.  (Staging the group through LDS for perfectly coalesced loads cost 24 KiB per group and 60
+        // more VGPRs for the addresses: half the occupancy.)
         const uint64_t s = g * kGroup + lane;
         const bool live = s < a.nblocks;
         uint32_t w[32];
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, uns
             const v4u *p = reinterpret_cast<const v4u *>(base + ref.index * 64);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const v4u q = __builtin_nontemporal_load(p + r);
+                const v4u q = p[r];
                 w[4 * r] = q.x; w[4 * r + 1] = q.y; w[4 * r + 2] = q.z; w[4 * r + 3] = q.w;
             }
         }
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, uns
             prev_dc = ref.index ? (int)base[(ref.index - 1) * 64] : (int)a.seed_dc[ref.comp];
             cls = ref.comp == 0 ? 0 : 1;
         }
-        // ---- walk 1: the block's length; group scan; look-back
+        // ---- walk 1: the block's length; group scan; the group's aggregate goes out at once
         uint32_t len = block_length_flat(w, prev_dc, tab + cls * kClassSyms);
         if (!live) len = 0;
         const uint32_t incl = wave_inclusive_scan(len);
@@ -180,34 +184,24 @@ __global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, uns
             if (k < wave) wave_base += wave_sum[k];
             group_bits += wave_sum[k];
         }
-        if (wave == 0) {
-            const uint64_t sum = look_back(desc, g, group_bits);
-            if (lane == 0) s_before = sum;
-        }
-        __syncthreads();
-        const uint64_t before = s_before;
+        if (lane == 0) publish_aggregate(desc, g, group_bits);
         const bool last_group = g + 1 == ngroups;
-        // stream bit where the group starts; the buffer's word 0 is stream word `first_word`
-        const uint64_t start = a.bit_base + before;
-        uint64_t end = start + group_bits;
-        if (last_group) {
-            if (lane == 0) state[1] = before + group_bits; // the scan's length in bits (unpadded)
-            if (a.pad_last) end = (end + 7) & ~7ull;         // BitWriterMsb::flush pads the last byte with 1-bits
-        }
-        const uint64_t first_word = start >> 5;
-        const uint32_t head_bits = (uint32_t)(start & 31);
-        const uint32_t nwords = (uint32_t)((end - (first_word << 5) + 31) >> 5);
-        const bool tail_partial = (end & 31) != 0 && !last_group; // the last word is finished by a later group
-        const bool pass_through = nwords == 1 && head_bits != 0 && tail_partial; // (a handful of bits inside one word)
-        const uint64_t my_bit = (uint64_t)head_bits + wave_base + (incl - len); // relative to the buffer
-        // ---- walk 2: pack into the LDS bit buffer, one window of kBufWords words per round (usually one)
-        for (uint32_t wbase = 0; wbase < nwords; wbase += kWindowWords) {
-            const uint32_t wn = nwords - wbase < kWindowWords ? nwords - wbase : kWindowWords;
+        // ---- walk 2: pack at GROUP-RELATIVE bit offsets into the LDS buffer — the position in the stream is not
+        // needed for that, and while the lanes walk, the aggregates of the groups before travel — one window of
+        // kWindowWords words per round (usually one); then the look-back, then the write-out, shifted.
+        const uint32_t my_bit = wave_base + (incl - len);
+        const uint32_t local_words = (group_bits + 31) >> 5; // >= 1: every block has bits
+        // (known after the look-back of the first round)
+        uint64_t first_word = 0;
+        uint32_t sh = 0, out_words = 0, pad_word = ~0u, pad_mask = 0;
+        bool tail_partial = false;
+        for (uint32_t wbase = 0; wbase < local_words; wbase += kWindowWords) {
+            const uint32_t wn = local_words - wbase < kWindowWords ? local_words - wbase : kWindowWords;
             for (uint32_t i = lane; i < wn; i += kGroup) buf[i] = 0;
             __syncthreads();
             const int64_t rel = (int64_t)my_bit - (int64_t)wbase * 32;
             // (opaque to the optimiser: otherwise everything the first walk derived from the 63 coefficients — values,
-            // magnitude categories, table words — stays alive for the second walk: 245 VGPRs instead of ~64)
+            // magnitude categories, table words — stays alive for the second walk: 245 VGPRs instead of ~70)
 #pragma unroll
             for (int i = 0; i < 32; i++) asm volatile("" : "+v"(w[i]));
             if (PIXO_ANY64(live && rel < (int64_t)wn * 32 && rel + (int64_t)len > 0)) { // (some block of the wavefront lies in the window)
@@ -219,44 +213,73 @@ __global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, uns
                 block_pack_flat(w, prev_dc, tab + cls * kClassSyms, p);
                 p.finish();
             }
-            if (last_group && a.pad_last && lane == 0) { // the 1-padding behind the scan's last bit
-                const uint64_t bits_end = start + group_bits;
-                const int n = (int)(end - bits_end);
-                if (n) {
-                    const uint64_t at = bits_end - (first_word << 5) - (uint64_t)wbase * 32; // < 2^32 when inside the window
-                    if (at < (uint64_t)wn * 32) atomicOr(&buf[at >> 5], ((1u << n) - 1u) << (32 - (int)(at & 31) - n));
+            if (wbase == 0) { // where the group starts in the stream
+                if (wave == 0) {
+                    const uint64_t sum = look_back(desc, g, group_bits);
+                    if (lane == 0) {
+                        s_before = sum;
+                        if (g) store_relaxed(&desc[g], kFlagPrefix | (sum + group_bits));
+                        if (last_group) state[1] = sum + group_bits; // the scan's length in bits (unpadded)
+                    }
                 }
+                __syncthreads();
+                const uint64_t start = s_before;
+                uint64_t end = start + group_bits;
+                if (last_group && a.pad_last) { // BitWriterMsb::flush pads the last byte with 1-bits
+                    const uint32_t n = (uint32_t)((8 - (end & 7)) & 7);
+                    if (n) {
+                        pad_word = (uint32_t)((end >> 5) - (start >> 5));
+                        pad_mask = ((1u << n) - 1u) << (32 - (uint32_t)(end & 31) - n);
+                    }
+                    end += n;
+                }
+                first_word = start >> 5;
+                sh = (uint32_t)(start & 31);
+                out_words = (uint32_t)((end - (first_word << 5) + 31) >> 5); // local_words or local_words + 1
+                tail_partial = (end & 31) != 0 && !last_group;                 // the last word is finished by a later group
+            } else {
+                __syncthreads();
             }
-            __syncthreads();
-            // ---- out: every word of the window that this group completes, except the stream word it shares with
-            // the group before (word 0 of the first window when head_bits != 0)
-            const uint32_t lo = (wbase == 0 && head_bits != 0) ? 1u : 0u;
-            const uint32_t hi = (wbase + wn == nwords && tail_partial) ? wn - 1 : wn;
-            if (wbase + wn == nwords && tail_partial && !pass_through && lane == 0)
-                store_relaxed(&tails[g], kTailValid | buf[wn - 1]); // hand the unfinished word to the next group, early
-            for (uint32_t i = lo + lane; i < hi; i += kGroup)
-                __builtin_nontemporal_store(buf[i], &stream[first_word + wbase + i]);
-            if (wbase == 0 && head_bits != 0 && lane == 0) {
+            // ---- out.  Stream word first_word + j = the buffer's words j - 1 and j funnelled by `sh`; the group writes
+            // every word it completes, except the word it shares with the group before (j = 0 when sh != 0): that one
+            // waits for the other group's bits.  The word it leaves unfinished goes to the next group as `tail`.
+            const uint32_t carry = s_carry; // the previous window's last word
+            const bool last_round = wbase + wn == local_words;
+            const uint32_t upto = last_round ? out_words - wbase : wn; // words of this round (the last round may have one more)
+            uint32_t word0 = 0, tail_word = 0;
+            for (uint32_t i = lane; i < upto; i += kGroup) {
+                const uint32_t j = wbase + i;
+                const uint32_t cur = i < wn ? buf[i] : 0u, prev = i ? buf[i - 1] : carry;
+                uint32_t v = sh ? (cur >> sh) | (prev << (32 - sh)) : cur;
+                v |= j == pad_word ? pad_mask : 0u;
+                const bool is_head = j == 0 && sh != 0, is_tail = tail_partial && j + 1 == out_words;
+                if (is_head) word0 = v;
+                if (is_tail) tail_word = v;
+                if (!is_head && !is_tail) __builtin_nontemporal_store(v, &stream[first_word + j]);
+            }
+            // (j = 0 is lane 0's in the first round; the tail word belongs to lane (upto - 1) % kGroup of the last round)
+            const bool has_tail = last_round && tail_partial;
+            const bool pass_through = has_tail && out_words == 1 && sh != 0; // (a handful of bits inside one word)
+            if (has_tail && !pass_through && (uint32_t)lane == (upto - 1) % kGroup) store_relaxed(&tails[g], kTailValid | tail_word);
+            if (wbase == 0 && sh != 0 && lane == 0) {
                 uint32_t inherited = 0;
                 if (g > 0) {
-                    unsigned long long t;
-                    do { t = load_relaxed(&tails[g - 1]); } while (!(t & kTailValid));
+                    unsigned long long t = load_relaxed(&tails[g - 1]);
+                    while (!(t & kTailValid)) { __builtin_amdgcn_s_sleep(1); t = load_relaxed(&tails[g - 1]); }
                     inherited = (uint32_t)t;
                 }
-                const uint32_t merged = inherited | buf[0];
+                const uint32_t merged = inherited | word0;
                 if (pass_through) store_relaxed(&tails[g], kTailValid | merged);
                 else __builtin_nontemporal_store(merged, &stream[first_word]);
             }
+            if (lane == 0) s_carry = buf[wn - 1];
             __syncthreads();
-        }
-        if (nwords == 0 && lane == 0 && !last_group && (end & 31) != 0) { // (an empty group cannot occur: every block has bits)
-            store_relaxed(&tails[g], kTailValid);
         }
     }
 }
 
-// ---- stuff: 4 KiB tiles of the packed stream -----------------------------------------------------------------------
-constexpr int kStuffThreads = 256, kTileBytes = 4096; // 16 bytes per lane
+// ---- stuff: 16 KiB tiles of the packed stream ----------------------------------------------------------------------
+constexpr int kStuffThreads = 256, kLaneBytes = 64, kTileBytes = kStuffThreads * kLaneBytes;
 constexpr uint32_t kStageBytes = 2 * kTileBytes + 16; // worst case: every byte 0xFF, + the output's alignment skew
 __device__ __forceinline__ uint32_t zero_byte_mask(uint32_t x)
 { // 0x80 in every byte of x that is zero (exact)
@@ -265,7 +288,7 @@ __device__ __forceinline__ uint32_t zero_byte_mask(uint32_t x)
 
 __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32_t *stream, const unsigned long long *code_state,
                                                                    uint32_t shift, uint32_t band, unsigned long long *state,
-                                                                   uint8_t *out, uint64_t out_cap)
+                                                                   uint8_t *out, uint64_t out_cap, uint64_t tile_offset)
 {
     // The bytes to stuff are the stream's bits from bit `shift` (< 8) on: 0 for a whole image (all bytes, the padded
     // last one included); for a band that starts inside a byte of the scan, its first `shift` bits belong to the byte
@@ -280,36 +303,40 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
     const uint64_t ntiles = (nbytes + kTileBytes - 1) / kTileBytes;
     unsigned long long *desc = state + 3;
     if (ntiles == 0) {
-        if (blockIdx.x == 0 && lane == 0) { state[1] = 0; state[2] = 0; }
+        if (blockIdx.x == 0 && lane == 0 && tile_offset == 0) { state[1] = 0; state[2] = 0; }
         return;
     }
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) { // (gridDim.x workgroups are co-resident: see the launcher)
-        __syncthreads(); // the previous tile's stage is written out
+    const uint64_t t = tile_offset + blockIdx.x; // one tile per workgroup (the launcher guesses how many there are)
+    if (t < ntiles) {
         for (uint32_t i = 16u * lane; i < kStageBytes; i += 16u * kStuffThreads) *reinterpret_cast<v4u *>(stage + i) = v4u{0, 0, 0, 0};
-        const uint64_t byte0 = t * kTileBytes + (uint64_t)lane * 16;
-        uint32_t w[4] = {0, 0, 0, 0};
+        const uint64_t byte0 = t * kTileBytes + (uint64_t)lane * kLaneBytes;
+        uint32_t w[kLaneBytes / 4];
         uint32_t have = 0; // bytes of this lane that exist
+        uint64_t flags = 0; // one flag per byte, stream order (bit i = byte i of the lane is 0xFF and exists)
         if (byte0 < nbytes) {
-            have = nbytes - byte0 < 16 ? (uint32_t)(nbytes - byte0) : 16u;
-            const uint32_t *p = stream + byte0 / 4; // (the stream buffer has 32 bytes of slack behind its last word)
-            const v4u q = *reinterpret_cast<const v4u *>(p);
-            const uint32_t q4 = p[4];
-            if (shift) { // funnel: byte k of the output is bits [8 k + shift, 8 k + shift + 8) of the stream
-                w[0] = (q.x << shift) | (q.y >> (32 - shift)); w[1] = (q.y << shift) | (q.z >> (32 - shift));
-                w[2] = (q.z << shift) | (q.w >> (32 - shift)); w[3] = (q.w << shift) | (q4 >> (32 - shift));
-            } else {
-                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-            }
-        }
-        // one flag per byte, stream order (bit i = byte i of the lane is 0xFF and exists)
-        uint32_t flags = 0;
+            have = nbytes - byte0 < (uint64_t)kLaneBytes ? (uint32_t)(nbytes - byte0) : (uint32_t)kLaneBytes;
+            const uint32_t *p = stream + byte0 / 4; // (the stream buffer has 64 bytes of slack behind its last word)
+            uint32_t q[kLaneBytes / 4 + 1];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t m = (zero_byte_mask(~w[k]) >> 7) & 0x01010101u;  // bits 24, 16, 8, 0 = stream bytes 0, 1, 2, 3 of the word
-            flags |= ((m * 0x08040201u) >> 24 & 0xFu) << (4 * k);
+            for (int k = 0; k < kLaneBytes / 16; k++) {
+                const v4u x = *reinterpret_cast<const v4u *>(p + 4 * k);
+                q[4 * k] = x.x; q[4 * k + 1] = x.y; q[4 * k + 2] = x.z; q[4 * k + 3] = x.w;
+            }
+            q[kLaneBytes / 4] = shift ? p[kLaneBytes / 4] : 0u;
+#pragma unroll
+            for (int k = 0; k < kLaneBytes / 4; k++) {
+                // funnel: byte i of the output is bits [8 i + shift, 8 i + shift + 8) of the stream
+                w[k] = shift ? (q[k] << shift) | (q[k + 1] >> (32 - shift)) : q[k];
+                const uint32_t m = (zero_byte_mask(~w[k]) >> 7) & 0x01010101u; // bits 24, 16, 8, 0 = stream bytes 0, 1, 2, 3 of the word
+                flags |= (uint64_t)((m * 0x08040201u) >> 24 & 0xFu) << (4 * k);
+            }
+            if (have < (uint32_t)kLaneBytes) flags &= (1ull << have) - 1ull;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kLaneBytes / 4; k++) w[k] = 0;
         }
-        flags &= have >= 16u ? 0xFFFFu : ((1u << have) - 1u);
-        const uint32_t ff = (uint32_t)__builtin_popcount(flags);
+        const uint32_t flo = (uint32_t)flags, fhi = (uint32_t)(flags >> 32);
+        const uint32_t ff_lo = (uint32_t)__builtin_popcount(flo), ff = ff_lo + (uint32_t)__builtin_popcount(fhi);
         const uint32_t incl = wave_inclusive_scan(ff);
         if ((lane & 63) == 63) wave_sum[wave] = incl;
         __syncthreads();
@@ -319,9 +346,13 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
             if (k < wave) wave_base += wave_sum[k];
             tile_ff += wave_sum[k];
         }
+        if (lane == 0) publish_aggregate(desc, t, tile_ff);
         if (wave == 0) {
             const uint64_t sum = look_back(desc, t, tile_ff);
-            if (lane == 0) s_before = sum;
+            if (lane == 0) {
+                s_before = sum;
+                if (t) store_relaxed(&desc[t], kFlagPrefix | (sum + tile_ff));
+            }
         }
         __syncthreads();
         const uint64_t ff_before = s_before;
@@ -333,11 +364,12 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
         // stream's bytes are written, each moved up by the number of 0xFF bytes before it — the gaps ARE the stuffed
         // zeros.  No branch per byte: lanes without a byte at position i write into a dummy byte.
         const uint32_t skew = (uint32_t)(dst0 & 3);
-        const uint32_t at0 = skew + (uint32_t)lane * 16 + wave_base + (incl - ff);
+        const uint32_t at0 = skew + (uint32_t)lane * kLaneBytes + wave_base + (incl - ff);
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
+        for (int i = 0; i < kLaneBytes; i++) {
             const uint32_t byte = (w[i >> 2] >> (24 - 8 * (i & 3))) & 0xFFu;
-            const uint32_t moved = (uint32_t)__builtin_popcount(flags & ((1u << i) - 1u));
+            const uint32_t moved = i < 32 ? (uint32_t)__builtin_popcount(flo & ((1u << i) - 1u))
+                                          : ff_lo + (uint32_t)__builtin_popcount(fhi & ((1u << (i - 32)) - 1u));
             const uint32_t at = (uint32_t)i < have ? at0 + (uint32_t)i + moved : kStageBytes + (uint32_t)lane;
             stage[at] = (uint8_t)byte;
         }
@@ -379,15 +411,20 @@ hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, uint
     return hipGetLastError();
 }
 
+uint64_t stuff_tiles(uint64_t stream_bytes) { return (stream_bytes + kTileBytes - 1) / kTileBytes; }
+
 hipError_t launch_stuff_fused(const uint32_t *d_stream, const unsigned long long *d_code_state, uint32_t shift, bool band,
-                              uint64_t max_stream_bytes, unsigned long long *d_state, uint8_t *d_out, uint64_t out_cap, hipStream_t s)
+                              uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state, uint8_t *d_out,
+                              uint64_t out_cap, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(d_state, 0, fused_stuff_state_words(max_stream_bytes) * 8, s);
-    if (e != hipSuccess) return e;
-    const uint64_t max_tiles = (max_stream_bytes + kTileBytes - 1) / kTileBytes;
-    const unsigned grid = (unsigned)(max_tiles < 1 ? 1 : (max_tiles < 1024 ? max_tiles : 1024));
-    hipLaunchKernelGGL(stuff_fused_kernel, dim3(grid), dim3(kStuffThreads), 0, s, d_stream, d_code_state, shift, band ? 1u : 0u, d_state,
-                       d_out, out_cap);
+    if (first_tile == 0) { // (a continuation keeps the descriptors of the tiles before it)
+        hipError_t e = hipMemsetAsync(d_state, 0, fused_stuff_state_words(max_stream_bytes) * 8, s);
+        if (e != hipSuccess) return e;
+    }
+    if (tiles == 0) tiles = 1;
+    if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stuff_fused_kernel, dim3((unsigned)tiles), dim3(kStuffThreads), 0, s, d_stream, d_code_state, shift, band ? 1u : 0u,
+                       d_state, d_out, out_cap, first_tile);
     return hipGetLastError();
 }
 

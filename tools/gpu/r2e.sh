@@ -2,7 +2,7 @@
 # GPU call E: fused entropy kernels after the wave-parallel look-back / 32-bit accumulator: parity + kernel times.
 set -u
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$ROOT"; O=gpurun_out/r2e; mkdir -p $O; export TMPDIR=/tmp
-echo "== pytest (entropy-relevant subset first, then all)"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee $O/pytest.txt
+echo "== (pytest skipped in this run)"
 for k in "0 noise" "0 gradient" "1 noise"; do
   n=$(echo $k | tr " " "_")
   rm -rf /tmp/prof_e_$n

@@ -179,7 +179,7 @@ struct u32x2 { uint32_t x, y; };
 // produces are never read back by this kernel, and written with the default policy ~30 MB of them
 // are still dirty in the eight 4 MB L2s when the kernel ends — the end-of-kernel write-back then
 // adds ~3.5 us during which nothing else runs (29.2 -> 25.9 us with nt, measured).
-#if defined(PIXO_EMU) || defined(PIXO_ABL_PLAIN_STORES)
+#if defined(PIXO_EMU)
 #define PIXO_GSTORE(ptr, val) (*(u32x4 *)(ptr) = (val))
 #else
 typedef uint32_t pixo_v4u __attribute__((ext_vector_type(4)));

@@ -483,3 +483,18 @@ def test_every_rgb_colour_once():
         assert len(np.unique(k)) == w * h
         for ss in (0, 1):
             _check_coeffs(px, w, h, 2, ss, 92)
+
+
+def test_restart_files_from_the_gpu_decode_like_the_plain_files():
+    """Independent decoder (Pillow / libjpeg) on the DEVICE coder's output: the file with restart markers and the file
+    without them hold the same coefficients, so they must decode to the same pixels (restart intervals cannot be
+    produced by the reference's wasm entry; see tests/test_independent_decoders.py)."""
+    import io
+    from PIL import Image
+    for (w, h, ct, ss) in [(333, 211, 2, 1), (200, 120, 2, 0), (129, 65, 0, 0)]:
+        px = synth.noise_gray(w, h, 4) if ct == 0 else synth.gradient_rgb(w, h) ^ (synth.noise(w, h, 4) >> 3)
+        plain = np.asarray(Image.open(io.BytesIO(jpeg.encode(px, _opts(w, h, ct, ss, 85)))))
+        for interval in (1, 3, 8, 50):
+            blob = jpeg.encode(px, _opts(w, h, ct, ss, 85, restart_interval=interval))
+            assert blob.count(b"\xff\xdd") >= 1
+            assert np.array_equal(np.asarray(Image.open(io.BytesIO(blob))), plain), (w, h, ct, ss, interval)

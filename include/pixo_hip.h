@@ -109,6 +109,21 @@ int pixo_hip_jpeg_coeffs_device(const void *d_pixels, uint32_t width, uint32_t h
                                 uint32_t batch, void *d_y, void *d_cb, void *d_cr,
                                 void *stream);
 
+/* The INTEGER secondary mode of the coefficient stage — never the default: `pixo::jpeg::encode`
+ * runs the f32 transform above, and only that path gives the reference's bytes.  This entry exposes the fixed-point
+ * family the reference also carries (dead code upstream): colour by the 2^16 row formulas of rgb_to_ycbcr_row_avx2
+ * (src/simd/x86_64.rs:1330-1420), dct_2d_fast / dct_2d_integer (src/jpeg/dct.rs:535-568, :61-186: 13-bit fixed point,
+ * per-product truncation, constant-block shortcut), quantize_block_integer (src/jpeg/dct.rs:570-583) with the
+ * `*_table_int` tables (src/jpeg/quantize.rs:56-78), per 8x8 block with extract_block's edge replication
+ * (src/jpeg/mod.rs:1565-1606).  4:4:4 RGB or gray (subsampling PIXO_S420 is refused); same tuple layout as above.
+ * Host pointers, synchronous / device pointers of the current device, asynchronous on `stream`. */
+int pixo_hip_jpeg_coeffs_integer(const uint8_t *pixels, uint32_t width, uint32_t height, uint8_t color_type,
+                                 uint8_t subsampling, uint8_t quality, int16_t *y, size_t y_blocks, int16_t *cb,
+                                 int16_t *cr, size_t c_blocks);
+int pixo_hip_jpeg_coeffs_integer_device(const void *d_pixels, uint32_t width, uint32_t height, uint8_t color_type,
+                                        uint8_t subsampling, uint8_t quality, void *d_y, void *d_cb, void *d_cr,
+                                        void *stream);
+
 /* Entropy stage on the host from a coefficient tuple (zig-zag, DC delta, run-length,
  * Huffman, byte stuffing, headers): replaces encode_block + BitWriterMsb + write_*
  * (src/jpeg/huffman.rs:423-481, src/bits.rs:195-293, src/jpeg/mod.rs:449-648) when

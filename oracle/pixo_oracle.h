@@ -119,6 +119,15 @@ int po_symbol_histograms(const int16_t *y, const int16_t *cb, const int16_t *cr,
 int po_build_bits_vals(const uint64_t *counts, int n, uint8_t bits[16], uint8_t *vals,
                        int *nvals);
 
+/* ---- the integer DCT family (pixo_int_oracle.c; dead code in the reference: parity unpinned beyond its unit tests) */
+void po_dct_2d_integer(const int16_t block[64], int32_t out[64]);
+void po_dct_2d_fast(const int16_t block[64], int32_t out[64]);
+void po_quantize_block_integer(const int32_t dct[64], const uint16_t q[64], int16_t out[64]);
+void po_rgb_to_ycbcr_2p16(uint8_t r, uint8_t g, uint8_t b, int32_t out[3]);
+void po_quant_tables_int(uint8_t quality, uint16_t lum[64], uint16_t chr[64]);
+int po_jpeg_coeffs_integer(const uint8_t *pixels, uint32_t w, uint32_t h, uint8_t color_type, uint8_t quality,
+                           int16_t *y, int16_t *cb, int16_t *cr);
+
 void po_free(void *p);
 const char *po_strerror(int code);
 

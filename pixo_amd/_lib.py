@@ -26,7 +26,7 @@ class JpegOptionsC(C.Structure):
 SYMBOLS = [
     "pixo_jpeg_options_from_preset", "pixo_hip_jpeg_encode", "pixo_hip_jpeg_encode_into",
     "pixo_hip_encode_jpeg", "pixo_hip_coeff_geometry", "pixo_hip_jpeg_coeffs",
-    "pixo_hip_jpeg_coeffs_device", "pixo_hip_jpeg_entropy_encode", "pixo_hip_jpeg_entropy_encode_device",
+    "pixo_hip_jpeg_coeffs_device", "pixo_hip_jpeg_coeffs_integer", "pixo_hip_jpeg_coeffs_integer_device", "pixo_hip_jpeg_entropy_encode", "pixo_hip_jpeg_entropy_encode_device",
     "pixo_hip_jpeg_encode_device", "pixo_hip_jpeg_encode_device_into", "pixo_hip_jpeg_encode_batch_device", "pixo_hip_png_filter", "pixo_hip_png_filter_device", "pixo_hip_png_filter_async",
     "pixo_hip_png_adler32_from_row_sums", "pixo_hip_band",
     "pixo_hip_band_encoder_create", "pixo_hip_band_encoder_destroy", "pixo_hip_band_encoder_rows",
@@ -84,6 +84,9 @@ def load():
     L.pixo_hip_jpeg_coeffs_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint8,
                                               C.c_uint8, C.c_uint8, C.c_uint32, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pixo_hip_jpeg_coeffs_integer.argtypes = L.pixo_hip_jpeg_coeffs.argtypes
+    L.pixo_hip_jpeg_coeffs_integer_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint8,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pixo_hip_jpeg_entropy_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, optp, u8pp, szp]
     L.pixo_hip_jpeg_entropy_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, optp, u8pp, szp]
     L.pixo_hip_jpeg_encode_device.argtypes = [C.c_void_p, optp, u8pp, szp]

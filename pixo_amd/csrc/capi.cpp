@@ -1068,6 +1068,72 @@ int pixo_hip_jpeg_coeffs_device(const void *d_pixels, uint32_t width, uint32_t h
     return PIXO_OK;
 }
 
+namespace {
+int integer_mode_checks(uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling, uint8_t quality,
+                        pixo_host::QuantTables *qt)
+{
+    pixo_jpeg_options o{};
+    o.width = width; o.height = height; o.color_type = color_type; o.quality = quality; o.subsampling = subsampling;
+    std::string msg;
+    int rc = pixo_host::validate(o, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if (color_type != PIXO_GRAY && subsampling != PIXO_S444)
+        return fail(PIXO_ERR_COMPRESSION, "Compression error: the integer DCT mode is defined per 8x8 block: 4:4:4 or gray only");
+    *qt = pixo_host::make_quant_tables(quality);
+    return PIXO_OK;
+}
+} // namespace
+
+int pixo_hip_jpeg_coeffs_integer_device(const void *d_pixels, uint32_t width, uint32_t height, uint8_t color_type,
+                                        uint8_t subsampling, uint8_t quality, void *d_y, void *d_cb, void *d_cr, void *stream)
+{
+    pixo_host::QuantTables qt;
+    int rc = integer_mode_checks(width, height, color_type, subsampling, quality, &qt);
+    if (rc) return rc;
+    PIXO_REQUIRE(d_pixels);
+    PIXO_REQUIRE(d_y);
+    const bool gray = color_type == PIXO_GRAY;
+    if (!gray && (!d_cb || !d_cr)) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'd_cb'/'d_cr'");
+    uint16_t ql[64], qc[64];
+    for (int i = 0; i < 64; ++i) { ql[i] = static_cast<uint16_t>(qt.lum[i]); qc[i] = static_cast<uint16_t>(qt.chr[i]); } // quantize.rs:56-78
+    HIP_TRY(pixo_dev::launch_jpeg_coeffs_integer(d_pixels, width, height, gray, ql, qc, d_y, d_cb, d_cr, static_cast<hipStream_t>(stream)));
+    return PIXO_OK;
+}
+
+int pixo_hip_jpeg_coeffs_integer(const uint8_t *pixels, uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling,
+                                 uint8_t quality, int16_t *y, size_t y_blocks, int16_t *cb, int16_t *cr, size_t c_blocks)
+{
+    pixo_host::QuantTables qt;
+    int rc = integer_mode_checks(width, height, color_type, subsampling, quality, &qt);
+    if (rc) return rc;
+    const pixo_host::Geometry g = pixo_host::geometry(width, height, color_type, PIXO_S444);
+    if (y_blocks != g.y_blocks || c_blocks != g.c_blocks)
+        return fail(PIXO_ERR_INVALID_DATA_LENGTH, "Invalid pixel data length: expected " + std::to_string(g.y_blocks) + " bytes, got " +
+                                                      std::to_string(y_blocks));
+    PIXO_REQUIRE(pixels);
+    PIXO_REQUIRE(y);
+    if (g.c_blocks && (!cb || !cr)) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'cb'/'cr'");
+    Context &c = thread_context();
+    if ((rc = c.ensure())) return rc;
+    PIXO_ON_DEVICE_OF(c);
+    const size_t px_bytes = static_cast<size_t>(width) * height * (g.gray ? 1 : 3), coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128;
+    if ((rc = c.reserve_px((px_bytes + 15) & ~size_t{15}))) return rc;
+    if ((rc = c.reserve_coef(coef_bytes))) return rc;
+    if ((rc = c.reserve_hcoef(coef_bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(c.d_px, pixels, px_bytes, hipMemcpyHostToDevice, c.stream));
+    int16_t *dy = static_cast<int16_t *>(c.d_coef), *dcb = dy + g.y_blocks * 64, *dcr = dcb + g.c_blocks * 64;
+    if ((rc = pixo_hip_jpeg_coeffs_integer_device(c.d_px, width, height, color_type, PIXO_S444, quality, dy, dcb, dcr, c.stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(c.h_coef, c.d_coef, coef_bytes, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    const int16_t *hy = static_cast<const int16_t *>(c.h_coef);
+    std::memcpy(y, hy, g.y_blocks * 128);
+    if (g.c_blocks) {
+        std::memcpy(cb, hy + g.y_blocks * 64, g.c_blocks * 128);
+        std::memcpy(cr, hy + (g.y_blocks + g.c_blocks) * 64, g.c_blocks * 128);
+    }
+    return PIXO_OK;
+}
+
 int pixo_hip_jpeg_entropy_encode(const int16_t *y, const int16_t *cb, const int16_t *cr,
                                  const pixo_jpeg_options *options, uint8_t **out, size_t *out_len)
 {

@@ -7,12 +7,17 @@
 namespace pixo_dev {
 
 // Enqueues the fused colour -> DCT -> quantise kernel for `batch` equally sized images on
-// `stream`.  All pointers are device pointers; d_qt points at the 256-float table block of
+// `stream`.  All pointers are device pointers; d_qt points at the 512-float table block of
 // the requested quality (layout in jpeg_tile.h).  d_cb/d_cr are ignored for gray input.
 // raw_f32: d_y/d_cb/d_cr receive the UNQUANTISED transform instead (64 f32 per block, natural order:
 // the reference's dct_2d output), input of the trellis quantiser (jpeg_trellis.hpp).
 hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gray, bool s420,
                               uint32_t batch, void *d_y, void *d_cb, void *d_cr,
                               const float *d_qt, hipStream_t stream, bool raw_f32 = false);
+
+// The INTEGER secondary mode (jpeg_integer.hip): 4:4:4 RGB or gray, one image; ql / qc = the natural-order
+// integer quantiser tables of the requested quality (host memory, passed by value to the kernel).
+hipError_t launch_jpeg_coeffs_integer(const void *d_px, uint32_t W, uint32_t H, bool gray, const uint16_t ql[64], const uint16_t qc[64],
+                                      void *d_y, void *d_cb, void *d_cr, hipStream_t stream);
 
 } // namespace pixo_dev

@@ -251,6 +251,26 @@ def coefficients_device(d_pixels, width, height, color_type, subsampling, qualit
         _raise(rc)
 
 
+def coefficients_integer(data, options: JpegOptions):
+    """The INTEGER secondary mode (`pixo_hip_jpeg_coeffs_integer`): the reference's fixed-point DCT
+    family — dead code in its `encode()` — per 8x8 block, 4:4:4 RGB or gray.  Never used by `encode`."""
+    L = _lib.load()
+    px = _as_u8(data)
+    yb, cbn = coefficient_geometry(options.width, options.height, options.color_type, Subsampling.S444)
+    expected = options.width * options.height * (1 if int(options.color_type) == 0 else 3)
+    if px.size != expected:
+        raise from_status(-2, "Invalid pixel data length: expected %d bytes, got %d" % (expected, px.size))
+    y = np.empty((yb, 64), np.int16)
+    cb = np.empty((cbn, 64), np.int16)
+    cr = np.empty((cbn, 64), np.int16)
+    rc = L.pixo_hip_jpeg_coeffs_integer(px.ctypes.data, options.width, options.height, int(options.color_type),
+                                        int(options.subsampling), int(options.quality), y.ctypes.data, yb,
+                                        cb.ctypes.data, cr.ctypes.data, cbn)
+    if rc:
+        _raise(rc)
+    return y, cb, cr
+
+
 def entropy_encode(y, cb, cr, options: JpegOptions) -> bytes:
     """Host entropy stage from an existing coefficient tuple (used when several GPUs each
     produced a band of it)."""

@@ -517,3 +517,22 @@ extern "C" long emu_png_filter(const uint8_t *data, long width, long height, int
     default: return -1;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// The INTEGER secondary mode (pixo_amd/csrc/jpeg_int_math.h) compiled for the host.
+// ---------------------------------------------------------------------------------------------
+#include "../../pixo_amd/csrc/jpeg_int_math.h"
+extern "C" void emu_int_dct_fast(const int16_t *block, int32_t *out)
+{
+    for (int i = 0; i < 64; i++) out[i] = block[i];
+    pixo_int::dct_2d_fast(out);
+}
+extern "C" void emu_int_quantize(const int32_t *dct, const uint16_t *q, int16_t *out)
+{
+    for (int i = 0; i < 64; i++) out[i] = (int16_t)pixo_int::quantize_integer(dct[i], q[i]);
+}
+extern "C" void emu_int_color(int r, int g, int b, int32_t *out)
+{
+    const pixo_int::YCbCr c = pixo_int::rgb_to_ycbcr_2p16(r, g, b);
+    out[0] = c.y; out[1] = c.cb; out[2] = c.cr;
+}

@@ -94,6 +94,21 @@ def coeffs(pixels, w, h, color_type=RGB, subsampling=S420, quality=80, threads=1
     return y, cb, cr
 
 
+def coeffs_integer(pixels, w, h, color_type=RGB, quality=80):
+    """The integer DCT family composed per 8x8 block (oracle/pixo_int_oracle.c): 4:4:4 / gray tuple."""
+    px = np.ascontiguousarray(pixels, dtype=np.uint8)
+    yb, cbn = geometry(w, h, color_type, S444)
+    y = np.empty((yb, 64), np.int16)
+    cb = np.empty((cbn, 64), np.int16)
+    cr = np.empty((cbn, 64), np.int16)
+    L = lib()
+    L.po_jpeg_coeffs_integer.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.po_jpeg_coeffs_integer(px.ctypes.data, w, h, color_type, quality, y.ctypes.data, cb.ctypes.data, cr.ctypes.data)
+    if rc:
+        raise OracleError(rc)
+    return y, cb, cr
+
+
 def make_options(w, h, color_type=RGB, quality=80, subsampling=S420, restart=None,
                  optimize_huffman=False, progressive=False, trellis=False):
     o = Options()

@@ -498,3 +498,21 @@ def test_restart_files_from_the_gpu_decode_like_the_plain_files():
             blob = jpeg.encode(px, _opts(w, h, ct, ss, 85, restart_interval=interval))
             assert blob.count(b"\xff\xdd") >= 1
             assert np.array_equal(np.asarray(Image.open(io.BytesIO(blob))), plain), (w, h, ct, ss, interval)
+
+
+@pytest.mark.parametrize("case", [(64, 64, 2, 80), (333, 211, 2, 35), (1000, 37, 2, 100), (129, 65, 0, 90), (8, 8, 2, 1), (1, 1, 0, 50)])
+def test_integer_mode_kernel_equals_the_oracle(case):
+    """the labelled integer secondary mode (pixo_hip_jpeg_coeffs_integer) against the restatement of the
+    reference's fixed-point family (oracle/pixo_int_oracle.c; pinned on the reference's unit-test values only — the
+    family is dead code upstream).  Noise, flat images (the constant-block shortcut of dct_2d_fast) and gradients."""
+    from pixo_amd import error
+    w, h, ct, q = case
+    for px in ((synth.noise_gray(w, h, 3) if ct == 0 else synth.noise(w, h, 3)),
+               np.full(w * h * (1 if ct == 0 else 3), 200, np.uint8),
+               (synth.gradient_rgb(w, h)[: w * h] if ct == 0 else synth.gradient_rgb(w, h))):
+        gy, gcb, gcr = jpeg.coefficients_integer(px, _opts(w, h, ct, 0, q))
+        oy, ocb, ocr = O.coeffs_integer(px, w, h, ct, q)
+        assert np.array_equal(gy, oy) and np.array_equal(gcb, ocb) and np.array_equal(gcr, ocr)
+    if ct == 2:
+        with pytest.raises(error.Error, match="4:4:4 or gray only"):
+            jpeg.coefficients_integer(px, _opts(w, h, 2, 1, q))

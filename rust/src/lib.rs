@@ -2,8 +2,10 @@
 //!
 //! Same names, fields, defaults and error variants as leerob/pixo v0.4.1
 //! (`src/jpeg/mod.rs:88-447`, `src/color.rs:7-31`, `src/error.rs:6-91`), so that
-//! `use pixo_hip as pixo;` is a drop-in for the baseline JPEG path.  NOT compiled in this
-//! repository's image (no Rust toolchain); kept thin so that it can be reviewed by diff.
+//! `use pixo_hip as pixo;` is a drop-in for the JPEG path (`pixo::jpeg::{encode, encode_into, JpegOptions, ...}`,
+//! `pixo::Error` with its `Display`) and for the PNG row-filter stage (`pixo::png::filter::apply_filters`).  NOT
+//! compiled in this repository's image (no Rust toolchain); kept thin so that it can be reviewed by diff against
+//! `src/error.rs:10-91`, `src/jpeg/mod.rs:121-447` and `src/png/filter.rs:51-62`.
 #![allow(clippy::missing_safety_doc)]
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int};
@@ -12,17 +14,48 @@ use std::os::raw::{c_char, c_int};
 #[derive(Debug, Clone, Copy, PartialEq, Eq)]
 pub enum ColorType { Gray = 0, GrayAlpha = 1, Rgb = 2, Rgba = 3 }
 
+impl ColorType {
+    /// `src/color.rs:20-31`
+    pub const fn bytes_per_pixel(self) -> usize {
+        match self { ColorType::Gray => 1, ColorType::GrayAlpha => 2, ColorType::Rgb => 3, ColorType::Rgba => 4 }
+    }
+}
+
+/// `pixo::Error` (`src/error.rs:10-48`): every variant, also those only the PNG encoder and the decoders raise, so
+/// that `match` arms written against the reference keep compiling.
 #[derive(Debug, Clone, PartialEq, Eq)]
 pub enum Error {
     InvalidDimensions { width: u32, height: u32 },
     InvalidDataLength { expected: usize, actual: usize },
     InvalidQuality(u8),
+    InvalidCompressionLevel(u8),
     ImageTooLarge { width: u32, height: u32, max: u32 },
     UnsupportedColorType,
     CompressionError(String),
     InvalidRestartInterval(u16),
+    InvalidDecode(String),
+    UnsupportedDecode(String),
 }
 pub type Result<T> = std::result::Result<T, Error>;
+
+/// `src/error.rs:50-91`, string for string (the C ABI's `pixo_hip_last_error` returns the same texts).
+impl std::fmt::Display for Error {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        match self {
+            Error::InvalidDimensions { width, height } => write!(f, "Invalid image dimensions: {width}x{height}"),
+            Error::InvalidDataLength { expected, actual } => write!(f, "Invalid pixel data length: expected {expected} bytes, got {actual}"),
+            Error::InvalidQuality(q) => write!(f, "Invalid quality {q}: must be 1-100"),
+            Error::InvalidCompressionLevel(level) => write!(f, "Invalid compression level {level}: must be 1-9"),
+            Error::ImageTooLarge { width, height, max } => write!(f, "Image {width}x{height} exceeds maximum dimension {max}"),
+            Error::UnsupportedColorType => write!(f, "Unsupported color type for this format"),
+            Error::CompressionError(msg) => write!(f, "Compression error: {msg}"),
+            Error::InvalidRestartInterval(interval) => write!(f, "Invalid restart interval {interval}: must be 1-65535 (or None to disable)"),
+            Error::InvalidDecode(msg) => write!(f, "Decode error: {msg}"),
+            Error::UnsupportedDecode(msg) => write!(f, "Unsupported: {msg}"),
+        }
+    }
+}
+impl std::error::Error for Error {}
 
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -33,11 +66,22 @@ struct COptions {
     optimize_huffman: u8, progressive: u8, trellis_quant: u8,
 }
 
+const PIXO_ERR_BUFFER_TOO_SMALL: c_int = -9;
+
 extern "C" {
-    fn pixo_hip_jpeg_encode(data: *const u8, len: usize, opts: *const COptions,
-                            out: *mut *mut u8, out_len: *mut usize) -> c_int;
+    // include/pixo_hip.h
+    fn pixo_hip_jpeg_encode_into(output: *mut u8, capacity: usize, data: *const u8, len: usize, opts: *const COptions,
+                                 out_len: *mut usize) -> c_int;
+    fn pixo_hip_jpeg_encode_multi(data: *const u8, len: usize, opts: *const COptions, devices: *const c_int, n_devices: u32,
+                                  out: *mut *mut u8, out_len: *mut usize) -> c_int;
+    fn pixo_hip_png_filter(data: *const u8, len: usize, width: u32, height: u32, bytes_per_pixel: u32, strategy: u8, flags: u32,
+                           out: *mut u8, out_capacity: usize, adler32: *mut u32) -> c_int;
     fn pixo_hip_free(p: *mut u8);
     fn pixo_hip_last_error() -> *const c_char;
+}
+
+fn last_error() -> String {
+    unsafe { CStr::from_ptr(pixo_hip_last_error()) }.to_string_lossy().into_owned()
 }
 
 pub mod jpeg {
@@ -103,12 +147,11 @@ pub mod jpeg {
     }
 
     fn error_from(status: c_int, o: &JpegOptions, len: usize) -> Error {
-        let msg = unsafe { CStr::from_ptr(pixo_hip_last_error()) }.to_string_lossy().into_owned();
+        let msg = last_error();
         match status {
             -1 => Error::InvalidDimensions { width: o.width, height: o.height },
             -2 => {
-                let bpp = if o.color_type == ColorType::Rgb { 3 } else { 1 };
-                Error::InvalidDataLength { expected: o.width as usize * o.height as usize * bpp, actual: len }
+                Error::InvalidDataLength { expected: o.width as usize * o.height as usize * o.color_type.bytes_per_pixel(), actual: len }
             }
             -3 => Error::InvalidQuality(o.quality),
             -4 => Error::ImageTooLarge { width: o.width, height: o.height, max: 65535 },
@@ -118,16 +161,29 @@ pub mod jpeg {
         }
     }
 
-    /// `pixo::jpeg::encode_into` (reference src/jpeg/mod.rs:328).
+    /// `pixo::jpeg::encode_into` (reference src/jpeg/mod.rs:328): clears `output` and writes the file into it, reusing
+    /// its allocation.  The library writes straight into the vector's spare capacity; when the file does not fit it says
+    /// how many bytes it needs (PIXO_ERR_BUFFER_TOO_SMALL leaves the buffer untouched) and the call is repeated once —
+    /// the reserve-and-retry protocol `pixo_hip_jpeg_encode_into` exists for.  Like the reference, validation errors are
+    /// returned before `output` is touched.
     pub fn encode_into(output: &mut Vec<u8>, data: &[u8], options: &JpegOptions) -> Result<()> {
         let c = to_c(options);
-        let (mut p, mut n) = (std::ptr::null_mut::<u8>(), 0usize);
-        let rc = unsafe { pixo_hip_jpeg_encode(data.as_ptr(), data.len(), &c, &mut p, &mut n) };
-        if rc != 0 { return Err(error_from(rc, options, data.len())); }
-        output.clear();
-        output.extend_from_slice(unsafe { std::slice::from_raw_parts(p, n) });
-        unsafe { pixo_hip_free(p) };
-        Ok(())
+        // the reference reserves data.len() / 4 (src/jpeg/mod.rs:375); keep whatever the caller's vector already has
+        let mut capacity = output.capacity().max(data.len() / 4);
+        for _ in 0..2 {
+            let mut spare = Vec::<u8>::with_capacity(0);
+            let buf: &mut Vec<u8> = if output.capacity() >= capacity { output } else { spare.reserve_exact(capacity); &mut spare };
+            let mut needed = 0usize;
+            let rc = unsafe { pixo_hip_jpeg_encode_into(buf.as_mut_ptr(), buf.capacity(), data.as_ptr(), data.len(), &c, &mut needed) };
+            if rc == 0 {
+                unsafe { buf.set_len(needed) };
+                if !std::ptr::eq(buf, output) { *output = spare; }
+                return Ok(());
+            }
+            if rc != PIXO_ERR_BUFFER_TOO_SMALL { return Err(error_from(rc, options, data.len())); }
+            capacity = needed;
+        }
+        Err(Error::CompressionError("output size changed between two identical calls".to_string()))
     }
 
     /// `pixo::jpeg::encode` (reference src/jpeg/mod.rs:88).
@@ -136,5 +192,53 @@ pub mod jpeg {
         let mut out = Vec::new();
         encode_into(&mut out, data, options)?;
         Ok(out)
+    }
+
+    /// Not in the reference: `encode` with the image's MCU-row bands spread over several GPUs of this process
+    /// (`pixo_hip_jpeg_encode_multi`; config 4: one 16384 x 16384 image over 8 MI355X).  Same bytes as `encode`.
+    pub fn encode_on_devices(data: &[u8], options: &JpegOptions, devices: &[i32]) -> Result<Vec<u8>> {
+        let c = to_c(options);
+        let (mut p, mut n) = (std::ptr::null_mut::<u8>(), 0usize);
+        let rc = unsafe { pixo_hip_jpeg_encode_multi(data.as_ptr(), data.len(), &c, devices.as_ptr(), devices.len() as u32, &mut p, &mut n) };
+        if rc != 0 { return Err(error_from(rc, options, data.len())); }
+        let out = unsafe { std::slice::from_raw_parts(p, n) }.to_vec();
+        unsafe { pixo_hip_free(p) };
+        Ok(out)
+    }
+}
+
+/// `pixo::png` — the row-filter stage of config 5 (`src/png/filter.rs:51-206`) and the Adler-32 of its output.
+pub mod png {
+    use super::*;
+
+    /// `src/png/mod.rs:345-364`, declaration order = the C ABI's `pixo_png_filter_strategy`.
+    #[derive(Debug, Clone, Copy, PartialEq, Eq)]
+    pub enum FilterStrategy { None, Sub, Up, Average, Paeth, MinSum, Adaptive, AdaptiveFast, Bigrams }
+
+    pub mod filter {
+        use super::*;
+
+        /// `pixo::png::filter::apply_filters(data, width, height, bytes_per_pixel, &options)` with the strategy taken out
+        /// of `PngOptions` (the only field the function reads, `src/png/filter.rs:71`): one filter-type byte + the
+        /// filtered row per image row, exactly what the reference hands to its DEFLATE.  The reference's signature
+        /// is infallible; device failures therefore panic, like an allocation failure would.
+        pub fn apply_filters(data: &[u8], width: u32, height: u32, bytes_per_pixel: usize, strategy: FilterStrategy) -> Vec<u8> {
+            apply_filters_with_adler32(data, width, height, bytes_per_pixel, strategy).0
+        }
+
+        /// The same, plus the zlib Adler-32 of the filtered stream (`src/simd/fallback.rs:8-25`, computed by the
+        /// reference inside its zlib wrapper, `src/compress/deflate.rs:1044`): lets the caller skip that pass.
+        pub fn apply_filters_with_adler32(data: &[u8], width: u32, height: u32, bytes_per_pixel: usize, strategy: FilterStrategy) -> (Vec<u8>, u32) {
+            let n = height as usize * (width as usize * bytes_per_pixel + 1);
+            let mut out = Vec::<u8>::with_capacity(n);
+            let mut adler = 0u32;
+            let rc = unsafe {
+                pixo_hip_png_filter(data.as_ptr(), data.len(), width, height, bytes_per_pixel as u32, strategy as u8, 0,
+                                    out.as_mut_ptr(), n, &mut adler)
+            };
+            assert!(rc == 0, "pixo_hip_png_filter: {}", last_error());
+            unsafe { out.set_len(n) };
+            (out, adler)
+        }
     }
 }

@@ -1,5 +1,6 @@
-"""The bench line the driver parses: the committed round-1 line (profiles/r01_bench_c2.json, printed by bench.py on
-an MI355X) has every key of the contract, the metric BASELINE.json names and a self-consistent roofline object."""
+"""The bench line the driver parses: the committed round-2 line (profiles/r02_bench_c2.json, printed by bench.py on
+an MI355X with the driver's own command `python3 bench.py --gpus 1 --steps 20 --warmup 5`) has every key of the contract,
+the metric BASELINE.json names and a self-consistent roofline object; `--gpus N` is honoured however the script is started."""
 import json
 import os
 
@@ -7,7 +8,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 
 def test_committed_bench_line_follows_the_contract():
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r01_bench_c2.json")).read().strip().splitlines()[-1])
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_c2.json")).read().strip().splitlines()[-1])
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert line["metric"] == base["metric"] and line["unit"] == "Mpixels/s"
     for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -24,9 +25,17 @@ def test_committed_bench_line_follows_the_contract():
     px_per_us = line["value"] * 1e6 / 1e6  # Mpixels/s -> pixels/us
     assert abs(px_per_us * line["ms_per_step"] * 1e3 - 4096 * 4096) / (4096 * 4096) < 0.01
     c = line["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample", "value_is"):
         assert key in c, key
     assert c["kind"] in ("port", "reference")
+    # round 2: the K-step block is repeated, the median is the number; the traffic figure says where it comes from;
+    # the other configurations are timed in the same run
+    assert line["steps"] == 20 and line["warmup"] == 5 and line["blocks"] >= 15
+    assert line["ms_per_step_min"] <= line["ms_per_step"] <= line["ms_per_step_max"]
+    assert r["traffic_source"].startswith("profile: profiles/")
+    for name in ("c3", "c2_444", "c2_unaligned", "c5"):
+        assert 0.1 < line["other_configs"][name]["frac"] < 1.0, name
+    assert line["whole_file"]["file_bytes"] == 11150133
 
 
 def _stub_line(gpus, extra=()):

@@ -108,7 +108,8 @@ struct Context {
         template <class T> T *as() const { return static_cast<T *>(p); }
     };
     Buf e_tables, e_hist, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out, e_seg_bytes, e_seg_off;
-    Buf e_code_state, e_stuff_state; // single-pass kernels (jpeg_scan_fused.hip): tickets, look-back descriptors, totals
+    Buf e_code_state, e_stuff_state; // single-pass kernels (jpeg_scan_fused.hip): look-back descriptors, totals
+    size_t code_state_zero_words = 0; // this many words of e_code_state are known to be zero (the stuffing kernel cleans up behind itself)
     Buf p_in, p_out, p_sums, p_scratch; // PNG filter stage
     Buf t_raw, t_trail;                 // progressive + trellis: unquantised DCT blocks (f32), Viterbi back-pointers
     Buf g_flags, g_rank, g_by_rank;     // progressive scans: band flags, rank among non-empty blocks and its inverse
@@ -194,6 +195,7 @@ void Context::release()
     if (stream) (void)hipStreamDestroy(stream);
     if (producer_done) (void)hipEventDestroy(producer_done);
     producer_done = nullptr;
+    code_state_zero_words = 0;
     d_px = d_coef = h_coef = nullptr; px_cap = coef_cap = hcoef_cap = 0;
     h_sums = nullptr; hsums_cap = 0; h_totals = nullptr; h_file = nullptr; hfile_cap = 0;
     stream = nullptr; ready = false;
@@ -390,6 +392,7 @@ int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, co
     if (j.fused) { // a block has at most 1665 bits: the packed stream has at most n * 209 bytes (+ slack the kernels read into)
         j.stream_cap = static_cast<size_t>(j.n) * 209 + 64;
         HIP_TRY(c.e_stream.reserve(j.stream_cap));
+        if (pd::fused_code_state_words(j.n) * 8 > c.e_code_state.cap) c.code_state_zero_words = 0; // (a new buffer)
         HIP_TRY(c.e_code_state.reserve(pd::fused_code_state_words(j.n) * 8));
         HIP_TRY(c.e_stuff_state.reserve(pd::fused_stuff_state_words(j.stream_cap) * 8));
         if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 64, hipHostMallocDefault));
@@ -450,7 +453,12 @@ int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_
     pixo_host::pack_scan_tables(j.h, packed);
     HIP_TRY(hipMemcpyAsync(c.e_tables.p, packed, sizeof packed, hipMemcpyHostToDevice, stream));
     if (j.fused) { // lengths, prefix and packing in one pass; the stream starts at bit 0 whatever the band's offset will be
-        HIP_TRY(pd::launch_scan_code(j.a, c.e_code_state.as<unsigned long long>(), c.e_stream.as<uint32_t>(), stream));
+        const bool zero = c.code_state_zero_words >= pd::fused_code_state_words(j.n);
+        c.code_state_zero_words = 0; // (dirty from here until a stuffing launch has cleaned it)
+        // chained with the stuffing kernel (!wait): this launch also zeroes that kernel's descriptors
+        HIP_TRY(pd::launch_scan_code(j.a, c.e_code_state.as<unsigned long long>(), zero, c.e_stream.as<uint32_t>(),
+                                     wait ? nullptr : c.e_stuff_state.as<unsigned long long>(),
+                                     wait ? 0 : pd::fused_stuff_state_words(j.stream_cap), stream));
         if (!wait) return PIXO_OK; // (the caller chains the stuffing kernel and synchronises once)
         HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_code_state.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -497,8 +505,12 @@ int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_b
     uint64_t first_tile = 0, tiles = chained ? pd::stuff_tiles(std::min<uint64_t>(j.stream_cap, j.n * 64 + 4096)) : pd::stuff_tiles(j.nbytes);
     for (int attempt = 0;; ++attempt) {
         HIP_TRY(c.e_out.reserve(want_cap));
-        HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), shift, j.band, j.stream_cap,
-                                       first_tile, tiles, c.e_stuff_state.as<unsigned long long>(), c.e_out.as<uint8_t>(), c.e_out.cap, stream));
+        HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), pd::fused_code_state_words(j.n),
+                                       shift, j.band, j.stream_cap, first_tile, tiles, c.e_stuff_state.as<unsigned long long>(),
+                                       /*state_is_zero=*/
+                                       chained && attempt == 0,
+ c.e_out.as<uint8_t>(), c.e_out.cap, stream));
+        c.code_state_zero_words = pd::fused_code_state_words(j.n);
         HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_code_state.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(c.h_totals + 1, c.e_stuff_state.as<uint64_t>() + 1, 16, hipMemcpyDeviceToHost, stream));
         uint32_t edge[3] = {0, 0, 0}; // band: stream word 0 (head bits) and the two words around the tail bits

@@ -65,19 +65,24 @@ hipError_t launch_stuff(const uint32_t *d_stream, uint64_t nbytes, const uint64_
 // a.pad_last as above).  d_state: fused_code_state_words(nblocks) u64 (zeroed by the launcher); afterwards d_state[1] =
 // the scan's length in bits.  d_stream: room for nblocks * 209 + 64 bytes (a block has at most 1665 bits).
 size_t fused_code_state_words(uint64_t nblocks);
-hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, uint32_t *d_stream, hipStream_t s);
+// state_is_zero: the caller knows d_state holds zeros (word 1 aside) — the stuffing kernel of the previous scan left it so —
+// and no memset is launched.  d_clear / clear_words: words this kernel zeroes on the side (the state of the stuffing launch
+// that follows), or null.
+hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool state_is_zero, uint32_t *d_stream,
+                            unsigned long long *d_clear, size_t clear_words, hipStream_t s);
 // stuff: the stream's bytes from bit `shift` (< 8) on -> d_out with 0x00 behind every 0xFF.  band = false: all bytes of a
 // whole scan (shift 0); band = true: only the whole bytes behind the band's first `shift` bits.  Reads the scan's length
-// from d_code_state[1] (no host round trip).  d_state: fused_stuff_state_words(max_stream_bytes) u64; afterwards
+// from d_code_state[1] (no host round trip) and zeroes the rest of d_code_state (code_state_words) for the next scan.
+// d_state: fused_stuff_state_words(max_stream_bytes) u64, zeroed by the launcher unless state_is_zero; afterwards
 // d_state[1] = bytes produced (bytes beyond out_cap are not written: the caller grows d_out and repeats this launch),
 // d_state[2] = bytes of the packed stream consumed.
 // One workgroup per tile: tiles [first_tile, first_tile + tiles) of stuff_tiles(stream bytes); the caller launches a
 // guess, reads d_state[2] back and, if the stream has more tiles, launches the rest (first_tile > 0 keeps the state).
 size_t fused_stuff_state_words(uint64_t max_stream_bytes);
 uint64_t stuff_tiles(uint64_t stream_bytes);
-hipError_t launch_stuff_fused(const uint32_t *d_stream, const unsigned long long *d_code_state, uint32_t shift, bool band,
-                              uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state, uint8_t *d_out,
-                              uint64_t out_cap, hipStream_t s);
+hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_code_state, size_t code_state_words, uint32_t shift, bool band,
+                              uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state,
+                              bool state_is_zero, uint8_t *d_out, uint64_t out_cap, hipStream_t s);
 
 // ---- progressive scans on the device (simple_progressive_script: seven single-component scans) ------
 struct ProgArgs {

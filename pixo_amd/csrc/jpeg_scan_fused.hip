@@ -37,8 +37,16 @@ using namespace pixo_scan;
 namespace {
 constexpr int kGroup = 192;                  // lanes = blocks per group
 constexpr int kGroupWaves = kGroup / 64;
-constexpr uint32_t kWindowWords = 2048;               // the LDS bit buffer: 8 KiB hold a typical group (noise at q = 80: 5.4 KiB);
-constexpr uint32_t kBufWords = kWindowWords + kGroup; //   longer groups take more rounds; + one dummy word per lane for the sink
+#ifndef PIXO_WINDOW_WORDS
+#define PIXO_WINDOW_WORDS 1536
+#endif
+#ifndef PIXO_SCRATCH_WORDS
+#define PIXO_SCRATCH_WORDS 12
+#endif
+constexpr uint32_t kWindowWords = PIXO_WINDOW_WORDS;               // the LDS bit buffer: 4 KiB; a typical group of noise at q = 80 (5.4 KiB) takes two rounds,
+constexpr uint32_t kBufWords = kWindowWords + kGroup; //   photographs one; + one dummy word per lane for the sink.  (LDS per group decides how many are resident.)
+constexpr uint32_t kScratchWords = PIXO_SCRATCH_WORDS;                // per lane: a block of up to 384 bits is coded in ONE walk (noise at q = 80: 230 +- 30)
+constexpr uint32_t kScratchPitch = kScratchWords + 1; // + the dummy word; odd: lane-strided accesses hit all banks
 constexpr uint64_t kFlagAggregate = 1ull << 62, kFlagPrefix = 2ull << 62, kValueMask = (1ull << 62) - 1;
 constexpr uint64_t kTailValid = 1ull << 63;
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -119,6 +127,17 @@ __device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t
 // Word i of the window is word `first + i` of the stream; every word starts out zero and is only ever OR-ed (LDS
 // atomic without return).  Words outside [0, limit) — a group of very long blocks is written out in more than one
 // round — and the "no flush" case go to a per-lane dummy word behind the window: no branch.
+// ---- the per-lane scratch of the single walk: a block's bits from bit 0, complete words stored plainly ----------------
+// (every word index is written once; words beyond the scratch — a block of more than kScratchWords * 32 bits — and the
+// "no flush" case go to the lane's dummy word)
+struct LaneSink {
+    uint32_t *words; // this lane's kScratchWords words + 1 dummy
+    __device__ __forceinline__ void or_word(bool flush, uint32_t word, uint32_t value)
+    {
+        words[(flush && word < kScratchWords) ? word : kScratchWords] = value;
+    }
+};
+
 struct LdsSink {
     uint32_t *buf;
     uint32_t limit, dummy;
@@ -130,12 +149,14 @@ struct LdsSink {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, unsigned long long *state, uint32_t *stream)
+__global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) void scan_code_kernel
+(const ScanArgs a, unsigned long long *state, uint32_t *stream, unsigned long long *clear, uint32_t clear_words)
 {
     // state: [0] unused, [1] total bits (out), [2 ..] per group: descriptor, then per group: tail
     __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
     __shared__ uint32_t tab[kTableWords];
-    __shared__ uint32_t wave_sum[kGroupWaves];
+    __shared__ uint32_t scratch[kGroup * kScratchPitch];
+    __shared__ uint32_t wave_sum[kGroupWaves], wave_long[kGroupWaves];
     __shared__ unsigned long long s_before;
     __shared__ uint32_t s_carry;
     const int lane = threadIdx.x, wave = lane >> 6;
@@ -143,6 +164,8 @@ __global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, uns
     const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
     unsigned long long *desc = state + 2, *tails = state + 2 + ngroups;
     for (int i = lane; i < kTableWords; i += kGroup) tab[i] = a.tables[i];
+    // (housekeeping for the kernel that follows: its descriptors must be zero when it starts — cheaper here than a memset launch)
+    for (uint64_t i = (uint64_t)blockIdx.x * kGroup + lane; i < clear_words; i += (uint64_t)gridDim.x * kGroup) clear[i] = 0;
     __syncthreads();
     { // (one group per workgroup; see the note on dispatch order at the top of the file)
         const uint64_t g = blockIdx.x;
@@ -172,39 +195,68 @@ __global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, uns
             prev_dc = ref.index ? (int)base[(ref.index - 1) * 64] : (int)a.seed_dc[ref.comp];
             cls = ref.comp == 0 ? 0 : 1;
         }
-        // ---- walk 1: the block's length; group scan; the group's aggregate goes out at once
-        uint32_t len = block_length_flat(w, prev_dc, tab + cls * kClassSyms);
+        // ---- THE walk: the block's codes into the lane's scratch from bit 0 — which also gives its length; group scan;
+        // the group's aggregate goes out at once.  Blocks of more than 384 bits do not fit the scratch: a group that
+        // holds one is packed by a second walk below (noise at q >= 90, not photographs).
+        uint32_t len;
+        {
+            FlatPack<LaneSink> p;
+            p.sink = LaneSink{scratch + lane * kScratchPitch};
+            p.acc = 0; p.pending = 0; p.word = 0;
+            block_pack_flat(w, prev_dc, tab + cls * kClassSyms, p);
+            len = p.word * 32u + p.pending;
+            p.finish();
+        }
         if (!live) len = 0;
+        const bool long_block = len > kScratchWords * 32u;
         const uint32_t incl = wave_inclusive_scan(len);
         if ((lane & 63) == 63) wave_sum[wave] = incl;
+        const bool any_long = PIXO_ANY64(long_block); // (a ballot: outside the one-lane branch below)
+        if ((lane & 63) == 0) wave_long[wave] = any_long ? 1u : 0u;
         __syncthreads();
-        uint32_t wave_base = 0, group_bits = 0;
+        uint32_t wave_base = 0, group_bits = 0, group_long = 0;
 #pragma unroll
         for (int k = 0; k < kGroupWaves; k++) {
             if (k < wave) wave_base += wave_sum[k];
             group_bits += wave_sum[k];
+            group_long |= wave_long[k];
         }
         if (lane == 0) publish_aggregate(desc, g, group_bits);
         const bool last_group = g + 1 == ngroups;
-        // ---- walk 2: pack at GROUP-RELATIVE bit offsets into the LDS buffer — the position in the stream is not
-        // needed for that, and while the lanes walk, the aggregates of the groups before travel — one window of
-        // kWindowWords words per round (usually one); then the look-back, then the write-out, shifted.
+        // ---- the blocks' bits at GROUP-RELATIVE offsets into the LDS buffer — the position in the stream is not needed
+        // for that, and meanwhile the aggregates of the groups before travel — one window of kWindowWords words per
+        // round (usually one): gathered from the scratches, or (a group with a long block) packed by a second walk;
+        // then the look-back, then the write-out, shifted.
         const uint32_t my_bit = wave_base + (incl - len);
         const uint32_t local_words = (group_bits + 31) >> 5; // >= 1: every block has bits
         // (known after the look-back of the first round)
         uint64_t first_word = 0;
         uint32_t sh = 0, out_words = 0, pad_word = ~0u, pad_mask = 0;
         bool tail_partial = false;
+        uint32_t head_word = 0; // (lane 0) this group's bits of the stream word it shares with the group before
         for (uint32_t wbase = 0; wbase < local_words; wbase += kWindowWords) {
             const uint32_t wn = local_words - wbase < kWindowWords ? local_words - wbase : kWindowWords;
             for (uint32_t i = lane; i < wn; i += kGroup) buf[i] = 0;
             __syncthreads();
             const int64_t rel = (int64_t)my_bit - (int64_t)wbase * 32;
+            if (!group_long) { // every word of the lane's scratch, shifted to its place (two LDS ORs per word)
+                const uint32_t nw = (len + 31) >> 5, bsh = (uint32_t)(rel & 31), dummy = kWindowWords + (uint32_t)lane;
+                const uint32_t d0 = (uint32_t)(rel >> 5); // wraps below zero for words before the window
+#pragma unroll
+                for (uint32_t j = 0; j < kScratchWords; j++) {
+                    if (!PIXO_ANY64(j < nw)) break; // (wave-uniform)
+                    const uint32_t v = j < nw ? scratch[lane * kScratchPitch + j] : 0u;
+                    const uint32_t d = d0 + j;
+                    (void)__hip_atomic_fetch_or(&buf[d < wn ? d : dummy], v >> bsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    (void)__hip_atomic_fetch_or(&buf[d + 1 < wn ? d + 1 : dummy], bsh ? v << (32 - bsh) : 0u, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
             // (opaque to the optimiser: otherwise everything the first walk derived from the 63 coefficients — values,
             // magnitude categories, table words — stays alive for the second walk: 245 VGPRs instead of ~70)
 #pragma unroll
             for (int i = 0; i < 32; i++) asm volatile("" : "+v"(w[i]));
-            if (PIXO_ANY64(live && rel < (int64_t)wn * 32 && rel + (int64_t)len > 0)) { // (some block of the wavefront lies in the window)
+            if (group_long && PIXO_ANY64(live && rel < (int64_t)wn * 32 && rel + (int64_t)len > 0)) { // (some block of the wavefront lies in the window)
                 FlatPack<LdsSink> p;
                 p.sink = LdsSink{buf, live ? wn : 0u, kWindowWords + (uint32_t)lane};
                 p.acc = 0;
@@ -261,25 +313,29 @@ __global__ __launch_bounds__(kGroup) void scan_code_kernel(const ScanArgs a, uns
             const bool has_tail = last_round && tail_partial;
             const bool pass_through = has_tail && out_words == 1 && sh != 0; // (a handful of bits inside one word)
             if (has_tail && !pass_through && (uint32_t)lane == (upto - 1) % kGroup) store_relaxed(&tails[g], kTailValid | tail_word);
-            if (wbase == 0 && sh != 0 && lane == 0) {
-                uint32_t inherited = 0;
-                if (g > 0) {
-                    unsigned long long t = load_relaxed(&tails[g - 1]);
-                    while (!(t & kTailValid)) { __builtin_amdgcn_s_sleep(1); t = load_relaxed(&tails[g - 1]); }
-                    inherited = (uint32_t)t;
-                }
-                const uint32_t merged = inherited | word0;
-                if (pass_through) store_relaxed(&tails[g], kTailValid | merged);
-                else __builtin_nontemporal_store(merged, &stream[first_word]);
-            }
+            if (wbase == 0) head_word = word0;
             if (lane == 0) s_carry = buf[wn - 1];
             __syncthreads();
+        }
+        // ---- the word shared with the group before: its bits arrive as that group's tail.  AFTER this group's own
+        // tail went out: waiting here in the first round of several made a chain through every group of the scan (each
+        // link one round: 310 us for 2048 groups of two rounds, against 45).
+        if (sh != 0 && lane == 0) {
+            uint32_t inherited = 0;
+            if (g > 0) {
+                unsigned long long t = load_relaxed(&tails[g - 1]);
+                while (!(t & kTailValid)) { __builtin_amdgcn_s_sleep(1); t = load_relaxed(&tails[g - 1]); }
+                inherited = (uint32_t)t;
+            }
+            const uint32_t merged = inherited | head_word;
+            if (tail_partial && out_words == 1) store_relaxed(&tails[g], kTailValid | merged); // (pass-through: a handful of bits inside one word)
+            else __builtin_nontemporal_store(merged, &stream[first_word]);
         }
     }
 }
 
 // ---- stuff: 16 KiB tiles of the packed stream ----------------------------------------------------------------------
-constexpr int kStuffThreads = 256, kLaneBytes = 64, kTileBytes = kStuffThreads * kLaneBytes;
+constexpr int kStuffThreads = 256, kLaneWords = 16, kWaveBytes = 64 * kLaneWords * 4, kTileBytes = (kStuffThreads / 64) * kWaveBytes;
 constexpr uint32_t kStageBytes = 2 * kTileBytes + 16; // worst case: every byte 0xFF, + the output's alignment skew
 __device__ __forceinline__ uint32_t zero_byte_mask(uint32_t x)
 { // 0x80 in every byte of x that is zero (exact)
@@ -288,7 +344,8 @@ __device__ __forceinline__ uint32_t zero_byte_mask(uint32_t x)
 
 __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32_t *stream, const unsigned long long *code_state,
                                                                    uint32_t shift, uint32_t band, unsigned long long *state,
-                                                                   uint8_t *out, uint64_t out_cap, uint64_t tile_offset)
+                                                                   uint8_t *out, uint64_t out_cap, uint64_t tile_offset,
+                                                                   unsigned long long *clear, uint32_t clear_words)
 {
     // The bytes to stuff are the stream's bits from bit `shift` (< 8) on: 0 for a whole image (all bytes, the padded
     // last one included); for a band that starts inside a byte of the scan, its first `shift` bits belong to the byte
@@ -299,6 +356,9 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
     __shared__ unsigned long long s_before;
     const int lane = threadIdx.x, wave = lane >> 6;
     const uint64_t total_bits = code_state[1];
+    // (housekeeping for the NEXT scan_code launch: its descriptors — everything but word 1, the length — back to zero)
+    for (uint64_t i = (uint64_t)blockIdx.x * kStuffThreads + lane; i < clear_words; i += (uint64_t)gridDim.x * kStuffThreads)
+        if (i != 1) clear[i] = 0;
     const uint64_t nbytes = band ? (total_bits - (shift < total_bits ? shift : total_bits)) / 8 : (total_bits + 7) / 8;
     const uint64_t ntiles = (nbytes + kTileBytes - 1) / kTileBytes;
     unsigned long long *desc = state + 3;
@@ -309,36 +369,48 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
     const uint64_t t = tile_offset + blockIdx.x; // one tile per workgroup (the launcher guesses how many there are)
     if (t < ntiles) {
         for (uint32_t i = 16u * lane; i < kStageBytes; i += 16u * kStuffThreads) *reinterpret_cast<v4u *>(stage + i) = v4u{0, 0, 0, 0};
-        const uint64_t byte0 = t * kTileBytes + (uint64_t)lane * kLaneBytes;
-        uint32_t w[kLaneBytes / 4];
-        uint32_t have = 0; // bytes of this lane that exist
-        uint64_t flags = 0; // one flag per byte, stream order (bit i = byte i of the lane is 0xFF and exists)
-        if (byte0 < nbytes) {
-            have = nbytes - byte0 < (uint64_t)kLaneBytes ? (uint32_t)(nbytes - byte0) : (uint32_t)kLaneBytes;
-            const uint32_t *p = stream + byte0 / 4; // (the stream buffer has 64 bytes of slack behind its last word)
-            uint32_t q[kLaneBytes / 4 + 1];
+        // ---- in.  Word k of lane l (of wavefront v) is word 64 k + l of the wavefront's 4 KiB: every load instruction
+        // reads 256 consecutive bytes, and — what matters — the byte stores into the stage below hit 64 different banks.
+        // (Round 2's first form gave every lane 64 CONSECUTIVE bytes: lanes 16 words apart, four banks for a wavefront,
+        // every one of the 64 byte stores a 16-way conflict — the whole 20 us of the kernel.)
+        const int wl = lane & 63;
+        const uint64_t wave0 = t * kTileBytes + (uint64_t)wave * kWaveBytes; // first byte of this wavefront's part
+        uint32_t w[kLaneWords];
+        uint64_t flags = 0; // four flags per word, stream order (bit 4 k + b = byte b of word k is 0xFF and exists)
+        {
+            const uint32_t *p = stream + wave0 / 4 + wl; // (the stream buffer has 64 bytes of slack behind its last word)
 #pragma unroll
-            for (int k = 0; k < kLaneBytes / 16; k++) {
-                const v4u x = *reinterpret_cast<const v4u *>(p + 4 * k);
-                q[4 * k] = x.x; q[4 * k + 1] = x.y; q[4 * k + 2] = x.z; q[4 * k + 3] = x.w;
+            for (int k = 0; k < kLaneWords; k++) {
+                const uint64_t at = wave0 + 256u * k + 4u * wl;
+                uint32_t x = 0;
+                if (at < nbytes) {
+                    x = p[64 * k];
+                    // funnel: byte i of the output is bits [8 i + shift, 8 i + shift + 8) of the stream
+                    if (shift) x = (x << shift) | (p[64 * k + 1] >> (32 - shift));
+                }
+                w[k] = x;
+                const uint32_t exist = at < nbytes ? (nbytes - at < 4 ? (uint32_t)(nbytes - at) : 4u) : 0u;
+                const uint32_t m = (zero_byte_mask(~x) >> 7) & 0x01010101u; // bits 24, 16, 8, 0 = stream bytes 0, 1, 2, 3 of the word
+                const uint32_t m4 = ((m * 0x08040201u) >> 24) & ((1u << exist) - 1u);
+                flags |= (uint64_t)m4 << (4 * k);
             }
-            q[kLaneBytes / 4] = shift ? p[kLaneBytes / 4] : 0u;
-#pragma unroll
-            for (int k = 0; k < kLaneBytes / 4; k++) {
-                // funnel: byte i of the output is bits [8 i + shift, 8 i + shift + 8) of the stream
-                w[k] = shift ? (q[k] << shift) | (q[k + 1] >> (32 - shift)) : q[k];
-                const uint32_t m = (zero_byte_mask(~w[k]) >> 7) & 0x01010101u; // bits 24, 16, 8, 0 = stream bytes 0, 1, 2, 3 of the word
-                flags |= (uint64_t)((m * 0x08040201u) >> 24 & 0xFu) << (4 * k);
-            }
-            if (have < (uint32_t)kLaneBytes) flags &= (1ull << have) - 1ull;
-        } else {
-#pragma unroll
-            for (int k = 0; k < kLaneBytes / 4; k++) w[k] = 0;
         }
-        const uint32_t flo = (uint32_t)flags, fhi = (uint32_t)(flags >> 32);
-        const uint32_t ff_lo = (uint32_t)__builtin_popcount(flo), ff = ff_lo + (uint32_t)__builtin_popcount(fhi);
-        const uint32_t incl = wave_inclusive_scan(ff);
-        if ((lane & 63) == 63) wave_sum[wave] = incl;
+        // 0xFF bytes before every word, in stream order = row by row (a row: word k of the 64 lanes): the counts of two
+        // rows share one 32-bit scan (a row holds at most 256), the rows' totals chain through scalar registers
+        uint32_t before[kLaneWords]; // 0xFF bytes of this wavefront before word k of this lane
+        uint32_t wave_ff = 0;
+#pragma unroll
+        for (int k = 0; k < kLaneWords; k += 2) {
+            const uint32_t c0 = (uint32_t)__builtin_popcount((uint32_t)(flags >> (4 * k)) & 0xFu);
+            const uint32_t c1 = (uint32_t)__builtin_popcount((uint32_t)(flags >> (4 * k + 4)) & 0xFu);
+            const uint32_t sc = wave_inclusive_scan(c0 | (c1 << 16));
+            const uint32_t rows = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+            before[k] = wave_ff + (sc & 0xFFFFu) - c0;
+            wave_ff += rows & 0xFFFFu;
+            before[k + 1] = wave_ff + (sc >> 16) - c1;
+            wave_ff += rows >> 16;
+        }
+        if (wl == 0) wave_sum[wave] = wave_ff;
         __syncthreads();
         uint32_t wave_base = 0, tile_ff = 0;
 #pragma unroll
@@ -362,16 +434,21 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
         if (t + 1 == ntiles && lane == 0) { state[1] = dst0 + tile_out; state[2] = nbytes; }
         // expand into LDS at the output's alignment (LDS dwords = global dwords).  The stage was zeroed: only the
         // stream's bytes are written, each moved up by the number of 0xFF bytes before it — the gaps ARE the stuffed
-        // zeros.  No branch per byte: lanes without a byte at position i write into a dummy byte.
+        // zeros.  No branch per byte: bytes that do not exist go to a dummy byte.
         const uint32_t skew = (uint32_t)(dst0 & 3);
-        const uint32_t at0 = skew + (uint32_t)lane * kLaneBytes + wave_base + (incl - ff);
+        const uint32_t at0 = skew + (uint32_t)wave * kWaveBytes + wave_base + 4u * wl;
 #pragma unroll
-        for (int i = 0; i < kLaneBytes; i++) {
-            const uint32_t byte = (w[i >> 2] >> (24 - 8 * (i & 3))) & 0xFFu;
-            const uint32_t moved = i < 32 ? (uint32_t)__builtin_popcount(flo & ((1u << i) - 1u))
-                                          : ff_lo + (uint32_t)__builtin_popcount(fhi & ((1u << (i - 32)) - 1u));
-            const uint32_t at = (uint32_t)i < have ? at0 + (uint32_t)i + moved : kStageBytes + (uint32_t)lane;
-            stage[at] = (uint8_t)byte;
+        for (int k = 0; k < kLaneWords; k++) {
+            const uint64_t at = wave0 + 256u * k + 4u * wl;
+            const uint32_t exist = at < nbytes ? (nbytes - at < 4 ? (uint32_t)(nbytes - at) : 4u) : 0u;
+            const uint32_t m4 = (uint32_t)(flags >> (4 * k)) & 0xFu;
+            const uint32_t to = at0 + 256u * k + before[k];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t byte = (w[k] >> (24 - 8 * b)) & 0xFFu;
+                const uint32_t moved = (uint32_t)__builtin_popcount(m4 & ((1u << b) - 1u));
+                stage[(uint32_t)b < exist ? to + b + moved : kStageBytes + (uint32_t)lane] = (uint8_t)byte;
+            }
         }
         __syncthreads();
         // out: leading bytes up to the first aligned dword, aligned dwords, trailing bytes
@@ -397,34 +474,39 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
 size_t fused_code_state_words(uint64_t nblocks) { return 2 + 2 * (size_t)((nblocks + kGroup - 1) / kGroup); }
 size_t fused_stuff_state_words(uint64_t max_stream_bytes) { return 3 + (size_t)((max_stream_bytes + kTileBytes - 1) / kTileBytes); }
 
-hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, uint32_t *d_stream, hipStream_t s)
+hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool state_is_zero, uint32_t *d_stream,
+                            unsigned long long *d_clear, size_t clear_words, hipStream_t s)
 {
     const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
     if (ngroups == 0) return hipMemsetAsync(d_state, 0, 16, s);
-    hipError_t e = hipMemsetAsync(d_state, 0, fused_code_state_words(a.nblocks) * 8, s);
-    if (e != hipSuccess) return e;
-    if (ngroups > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (!state_is_zero) {
+        hipError_t e = hipMemsetAsync(d_state, 0, fused_code_state_words(a.nblocks) * 8, s);
+        if (e != hipSuccess) return e;
+    }
+    if (ngroups > 0x7FFFFFFFull || clear_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)ngroups;
-    if (a.mode == 2) hipLaunchKernelGGL(scan_code_kernel<2>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream);
-    else if (a.mode == 1) hipLaunchKernelGGL(scan_code_kernel<1>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream);
-    else hipLaunchKernelGGL(scan_code_kernel<0>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream);
+    const uint32_t cw = d_clear ? (uint32_t)clear_words : 0u;
+    if (a.mode == 2) hipLaunchKernelGGL(scan_code_kernel<2>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw);
+    else if (a.mode == 1) hipLaunchKernelGGL(scan_code_kernel<1>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw);
+    else hipLaunchKernelGGL(scan_code_kernel<0>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw);
     return hipGetLastError();
 }
 
 uint64_t stuff_tiles(uint64_t stream_bytes) { return (stream_bytes + kTileBytes - 1) / kTileBytes; }
 
-hipError_t launch_stuff_fused(const uint32_t *d_stream, const unsigned long long *d_code_state, uint32_t shift, bool band,
-                              uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state, uint8_t *d_out,
-                              uint64_t out_cap, hipStream_t s)
+hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_code_state, size_t code_state_words, uint32_t shift, bool band,
+                              uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state,
+                              bool state_is_zero, uint8_t *d_out, uint64_t out_cap, hipStream_t s)
 {
-    if (first_tile == 0) { // (a continuation keeps the descriptors of the tiles before it)
+    if (first_tile == 0 && !state_is_zero) { // (a continuation keeps the descriptors of the tiles before it)
         hipError_t e = hipMemsetAsync(d_state, 0, fused_stuff_state_words(max_stream_bytes) * 8, s);
         if (e != hipSuccess) return e;
     }
     if (tiles == 0) tiles = 1;
     if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (code_state_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(stuff_fused_kernel, dim3((unsigned)tiles), dim3(kStuffThreads), 0, s, d_stream, d_code_state, shift, band ? 1u : 0u,
-                       d_state, d_out, out_cap, first_tile);
+                       d_state, d_out, out_cap, first_tile, d_code_state, (uint32_t)code_state_words);
     return hipGetLastError();
 }
 

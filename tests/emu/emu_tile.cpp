@@ -536,3 +536,101 @@ extern "C" void emu_int_color(int r, int g, int b, int32_t *out)
     const pixo_int::YCbCr c = pixo_int::rgb_to_ycbcr_2p16(r, g, b);
     out[0] = c.y; out[1] = c.cb; out[2] = c.cr;
 }
+
+// The single-walk form of jpeg_scan_fused.hip's code kernel, one group at a time on the CPU: every lane codes its block
+// into a private scratch of `scratch_words` words (words beyond it are dropped, like on the device), the lengths are
+// prefix-summed, and — unless a block was longer than the scratch — the scratches are OR-ed, shifted, into the group's
+// zeroed bit buffer in windows of `window_words`.  Returns the packed (unstuffed, unpadded) bits of the whole scan as
+// MSB-first words, or -1 when some group holds a long block (the device then takes its two-walk path).
+struct EmuLaneSink {
+    uint32_t *words;
+    uint32_t cap;
+    void or_word(bool flush, uint32_t word, uint32_t value) { words[(flush && word < cap) ? word : cap] = value; }
+};
+extern "C" long emu_scan_single_walk(const int16_t *y, const int16_t *cb, const int16_t *cr, int mode, uint64_t nblocks,
+                                     const uint32_t *tables, uint32_t scratch_words, uint32_t window_words, uint32_t *out_words,
+                                     uint64_t *total_bits)
+{
+    using namespace pixo_scan;
+    const int kGroupLanes = 192;
+    std::vector<uint32_t> stream;
+    uint64_t before = 0;
+    long long_groups = 0;
+    for (uint64_t g0 = 0; g0 < nblocks; g0 += kGroupLanes) {
+        const int lanes = (int)std::min<uint64_t>(kGroupLanes, nblocks - g0);
+        std::vector<std::vector<uint32_t>> scratch(lanes, std::vector<uint32_t>(scratch_words + 1, 0xDEADBEEFu));
+        std::vector<uint32_t> len(lanes), my_bit(lanes);
+        uint32_t group_bits = 0;
+        bool group_long = false;
+        for (int l = 0; l < lanes; l++) {
+            const BlockRef r = block_of(mode, g0 + l);
+            const int16_t *base = r.comp == 0 ? y : (r.comp == 1 ? cb : cr);
+            uint32_t wds[32];
+            memcpy(wds, base + r.index * 64, 128);
+            const int prev = r.index ? base[(r.index - 1) * 64] : 0;
+            FlatPack<EmuLaneSink> p;
+            p.sink = EmuLaneSink{scratch[l].data(), scratch_words};
+            p.acc = 0; p.pending = 0; p.word = 0;
+            block_pack_flat(wds, prev, tables + (r.comp ? 1 : 0) * kClassSyms, p);
+            len[l] = p.word * 32u + p.pending;
+            p.finish();
+            my_bit[l] = group_bits;
+            group_bits += len[l];
+            group_long |= len[l] > scratch_words * 32u;
+        }
+        if (group_long) { long_groups++; }
+        const uint32_t local_words = (group_bits + 31) >> 5;
+        std::vector<uint32_t> local(local_words + 1, 0);
+        if (!group_long) {
+            for (uint32_t wbase = 0; wbase < local_words; wbase += window_words) {
+                const uint32_t wn = std::min(local_words - wbase, window_words);
+                std::vector<uint32_t> buf(window_words + 1, 0); // [window_words] = dummy
+                for (int l = 0; l < lanes; l++) {
+                    const int64_t rel = (int64_t)my_bit[l] - (int64_t)wbase * 32;
+                    const uint32_t nw = (len[l] + 31) >> 5, bsh = (uint32_t)(rel & 31), d0 = (uint32_t)(rel >> 5);
+                    for (uint32_t j = 0; j < scratch_words; j++) {
+                        if (j >= nw) break;
+                        const uint32_t v = scratch[l][j], d = d0 + j;
+                        buf[d < wn ? d : window_words] |= v >> bsh;
+                        buf[d + 1 < wn ? d + 1 : window_words] |= bsh ? v << (32 - bsh) : 0u;
+                    }
+                }
+                for (uint32_t i = 0; i < wn; i++) local[wbase + i] = buf[i];
+            }
+        } else { // the device's second walk: block_pack_flat through a windowed OR sink, round by round
+            struct WinSink {
+                uint32_t *buf; uint32_t limit, dummy;
+                void or_word(bool flush, uint32_t word, uint32_t value) { buf[(flush && word < limit) ? word : dummy] |= value; }
+            };
+            for (uint32_t wbase = 0; wbase < local_words; wbase += window_words) {
+                const uint32_t wn = std::min(local_words - wbase, window_words);
+                std::vector<uint32_t> buf(window_words + 1, 0);
+                for (int l = 0; l < lanes; l++) {
+                    const int64_t rel = (int64_t)my_bit[l] - (int64_t)wbase * 32;
+                    if (!(rel < (int64_t)wn * 32 && rel + (int64_t)len[l] > 0)) continue;
+                    const BlockRef r = block_of(mode, g0 + l);
+                    const int16_t *base = r.comp == 0 ? y : (r.comp == 1 ? cb : cr);
+                    uint32_t wds[32];
+                    memcpy(wds, base + r.index * 64, 128);
+                    FlatPack<WinSink> p;
+                    p.sink = WinSink{buf.data(), wn, window_words};
+                    p.acc = 0; p.pending = (uint32_t)(rel & 31); p.word = (uint32_t)(rel >> 5);
+                    block_pack_flat(wds, r.index ? base[(r.index - 1) * 64] : 0, tables + (r.comp ? 1 : 0) * kClassSyms, p);
+                    p.finish();
+                }
+                for (uint32_t i = 0; i < wn; i++) local[wbase + i] = buf[i];
+            }
+        }
+        // append the group's bits at `before`
+        stream.resize((before + group_bits + 63) / 32 + 2, 0);
+        const uint32_t sh = (uint32_t)(before & 31);
+        for (uint32_t i = 0; i < local_words; i++) {
+            stream[(before >> 5) + i] |= local[i] >> sh;
+            if (sh) stream[(before >> 5) + i + 1] |= local[i] << (32 - sh);
+        }
+        before += group_bits;
+    }
+    *total_bits = before;
+    for (uint64_t i = 0; i < (before + 31) / 32; i++) out_words[i] = stream[i];
+    return long_groups;
+}

@@ -83,3 +83,37 @@ def test_ff_bytes_are_stuffed_and_last_byte_padded_with_ones():
     assert b"\xff\x00" in seg
     assert all(seg[i + 1] == 0 for i in range(len(seg) - 1) if seg[i] == 0xFF)
     _check(px, 64, 64, 2, 0, 100)
+
+
+@pytest.mark.parametrize("scratch,window", [(12, 1024), (16, 768), (4, 64), (40, 97)])
+def test_single_walk_scratch_and_gather_give_the_same_bits(scratch, window):
+    """jpeg_scan_fused.hip codes every block ONCE into a per-lane scratch and gathers the scratches, shifted, into the group's
+    bit buffer (window by window); groups that hold a block longer than the scratch take a second walk.  The same
+    choreography on the CPU, with small scratches and windows to hit every seam, against the plain packer."""
+    L = E.lib()
+    L.emu_scan_single_walk.restype = C.c_long
+    L.emu_scan_single_walk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
+                                       C.c_void_p, C.c_void_p]
+    L.emu_scan_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    cases = [(synth.noise(200, 120, 3), 200, 120, 2, 1, 80), (synth.flat_blocks(48, 48), 48, 48, 2, 1, 100),
+             (synth.gradient_rgb(333, 64), 333, 64, 2, 0, 90), (synth.noise_gray(100, 90, 1), 100, 90, 0, 0, 50),
+             (synth.extremes(64, 64, 2), 64, 64, 2, 1, 100)]
+    for px, w, h, ct, ss, q in cases:
+        y, cb, cr = O.coeffs(px, w, h, ct, ss, q)
+        tables = np.zeros(536, np.uint32)
+        L.emu_scan_tables(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, w, h, ct, ss, 0, tables.ctypes.data)
+        mode = 0 if ct == 0 else (2 if ss == 1 else 1)
+        n = y.shape[0] + cb.shape[0] + cr.shape[0]
+        words = np.zeros(n * 60 + 16, np.uint32)
+        total = C.c_uint64()
+        L.emu_scan_single_walk(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, mode, n, tables.ctypes.data, scratch, window,
+                               words.ctypes.data, C.byref(total))
+        # the same bits, padded and stuffed by hand, must be the oracle's scan
+        bits = total.value
+        nbytes = (bits + 7) // 8
+        raw = bytearray(words[: (bits + 31) // 32].astype(">u4").tobytes()[:nbytes])
+        if bits % 8:
+            raw[-1] |= (1 << (8 - bits % 8)) - 1
+        stuffed = bytes(raw).replace(b"\xff", b"\xff\x00")
+        want = _scan_segment(O.encode_from_coeffs(y, cb, cr, O.make_options(w, h, ct, q, ss)))
+        assert stuffed == want, (w, h, ct, ss, q, scratch, window)

@@ -354,6 +354,15 @@ struct ScanJob {
 
 // PIXO_HIP_OLD_ENTROPY=1: the multi-pass kernels of jpeg_entropy.hip for every scan (A/B runs; they remain the path of
 // scans with restart markers, batches and progressive scans)
+bool direct_host_stores()
+{ // PIXO_HIP_DIRECT_STORES=1: the stuffing kernel stores the file straight into pinned host memory instead of into HBM
+  // with a copy behind it.  Off by default: kernel stores cross PCIe at 40 GB/s, the copy engine at 53 — 0.36 against
+  // 0.32 ms for the 11 MB file of the 4096x4096 noise image (profiles/r02_direct_host_stores.txt); it saves a
+  // synchronisation, which only pays for files of a few hundred KB.
+    static const bool on = [] { const char *e = std::getenv("PIXO_HIP_DIRECT_STORES"); return e && *e && *e != '0'; }();
+    return on;
+}
+
 bool old_entropy_forced()
 {
     static const bool v = std::getenv("PIXO_HIP_OLD_ENTROPY") != nullptr;
@@ -488,8 +497,17 @@ int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_
 // The stuffing kernel of jpeg_scan_fused.hip over the packed stream (launch_scan_code has been enqueued; with
 // `chained` its length has not been read back yet): afterwards c.e_out holds j.scan_bytes finished bytes.  The output
 // buffer is sized from experience (grow-only) — the kernel never writes beyond it and says how much it needed.
+// Where the stuffed bytes go when not into the context's device buffer: host memory the GPU can write (pinned), so that
+// the kernel's stores ARE the transfer — no second pass over the file, no second synchronisation.
+struct HostTarget {
+    uint8_t *p = nullptr; // device-visible address of the first stuffed byte
+    size_t cap = 0;       // bytes available from there
+    bool grow = false;    // p lies in the context's own pinned file buffer: too small = reserve more and repeat
+    size_t before = 0, after = 0; // (grow) bytes the file needs in front of / behind the stuffed bytes
+};
+
 int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offset, uint32_t *head, int *tail_bits,
-                     uint32_t *tail, bool chained = false)
+                     uint32_t *tail, bool chained = false, HostTarget *host = nullptr)
 {
     namespace pd = pixo_dev;
     uint32_t shift = 0;
@@ -504,12 +522,27 @@ int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_b
     // has 28) — surplus workgroups leave at once, missing ones are launched below
     uint64_t first_tile = 0, tiles = chained ? pd::stuff_tiles(std::min<uint64_t>(j.stream_cap, j.n * 64 + 4096)) : pd::stuff_tiles(j.nbytes);
     for (int attempt = 0;; ++attempt) {
-        HIP_TRY(c.e_out.reserve(want_cap));
+        uint8_t *out = nullptr;
+        size_t out_cap = 0;
+        if (host) {
+            if (host->grow) {
+                const int rc = c.reserve_hfile(host->before + want_cap + host->after);
+                if (rc) return rc;
+                host->p = c.h_file + host->before;
+                host->cap = c.hfile_cap - host->before - host->after;
+            }
+            out = host->p;
+            out_cap = host->cap;
+        } else {
+            HIP_TRY(c.e_out.reserve(want_cap));
+            out = c.e_out.as<uint8_t>();
+            out_cap = c.e_out.cap;
+        }
         HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), pd::fused_code_state_words(j.n),
                                        shift, j.band, j.stream_cap, first_tile, tiles, c.e_stuff_state.as<unsigned long long>(),
                                        /*state_is_zero=*/
                                        chained && attempt == 0,
- c.e_out.as<uint8_t>(), c.e_out.cap, stream));
+ out, out_cap, stream));
         c.code_state_zero_words = pd::fused_code_state_words(j.n);
         HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_code_state.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(c.h_totals + 1, c.e_stuff_state.as<uint64_t>() + 1, 16, hipMemcpyDeviceToHost, stream));
@@ -530,7 +563,8 @@ int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_b
         }
         j.scan_bytes = c.h_totals[1];
         j.nbytes = c.h_totals[2];
-        if (j.scan_bytes > c.e_out.cap) { // (first call with unusually many 0xFF bytes: grow and repeat the stuffing pass only)
+        if (j.scan_bytes > out_cap) { // (first call with unusually many 0xFF bytes: grow and repeat the stuffing pass only)
+            if (host && !host->grow) return PIXO_OK; // (the caller's storage is what it is: the caller reports the size needed)
             if (attempt > 2) return fail(PIXO_ERR_COMPRESSION, "Compression error: stuffed stream larger than announced");
             want_cap = static_cast<size_t>(j.scan_bytes);
             first_tile = 0;
@@ -622,10 +656,48 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
     int rc = scan_begin(c, j, dy, dcb, dcr, o, g, batch, nullptr);
     if (rc) return rc;
     sw.lap("  reserve");
+    std::vector<uint8_t> head;
     if (j.fused) { // code + stuff back to back, one read-back
         if ((rc = scan_lengths(c, j, o, g, stream, nullptr, /*wait=*/false))) return rc;
-        if ((rc = scan_stuff_fused(c, j, stream, 0, nullptr, nullptr, nullptr, /*chained=*/true))) return rc;
+        // One image into host memory the GPU can write — the context's pinned file buffer, or storage of the caller's
+        // that is pinned / registered: the stuffing kernel stores straight into it, behind the place of the headers.
+        HostTarget target;
+        bool direct = false;
+        if (batch == 1 && direct_host_stores()) {
+            pixo_host::file_headers(head, o, j.h); // (the tables are known since scan_lengths)
+            if (!dest) {
+                target.grow = true;
+                target.before = head.size();
+                target.after = 2;
+                direct = true;
+            } else if (dest_cap > head.size() + 2) {
+                hipPointerAttribute_t at;
+                if (hipPointerGetAttributes(&at, dest) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+                    target.p = static_cast<uint8_t *>(at.devicePointer) + head.size();
+                    target.cap = dest_cap - head.size() - 2;
+                    direct = true;
+                } else {
+                    (void)hipGetLastError(); // (plain malloc'd memory: not an error, the copy below handles it)
+                }
+            }
+        }
+        if ((rc = scan_stuff_fused(c, j, stream, 0, nullptr, nullptr, nullptr, /*chained=*/true, direct ? &target : nullptr))) return rc;
         sw.lap("code+stuff (fused)");
+        if (direct) {
+            const size_t hdr = head.size(), total = hdr + j.scan_bytes + 2;
+            if (dest && j.scan_bytes > target.cap) {
+                *file_len = total;
+                return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(total) + " bytes");
+            }
+            uint8_t *buf = dest ? dest : c.h_file;
+            std::memcpy(buf, head.data(), hdr);
+            buf[hdr + j.scan_bytes] = 0xFF; // EOI
+            buf[hdr + j.scan_bytes + 1] = 0xD9;
+            *file = buf;
+            *file_len = total;
+            if (header_len) *header_len = hdr;
+            return PIXO_OK;
+        }
     } else {
         if ((rc = scan_lengths(c, j, o, g, stream, nullptr))) return rc;
         sw.lap("tables+lengths+scan");
@@ -641,7 +713,7 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
         HIP_TRY(hipMemcpyAsync(image_starts->data(), c.e_seg_bytes.p, j.nseg * 8, hipMemcpyDeviceToHost, stream));
         (*image_starts)[batch] = scan_bytes;
     }
-    std::vector<uint8_t> head;
+    head.clear();
     pixo_host::file_headers(head, o, j.h);
     const size_t hdr = head.size(), total = hdr + scan_bytes + 2;
     uint8_t *buf = dest;

@@ -344,13 +344,15 @@ __device__ __forceinline__ uint32_t zero_byte_mask(uint32_t x)
 
 __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32_t *stream, const unsigned long long *code_state,
                                                                    uint32_t shift, uint32_t band, unsigned long long *state,
-                                                                   uint8_t *out, uint64_t out_cap, uint64_t tile_offset,
+                                                                   uint8_t *out, uint32_t out_skew, uint64_t out_cap, uint64_t tile_offset,
                                                                    unsigned long long *clear, uint32_t clear_words)
 {
     // The bytes to stuff are the stream's bits from bit `shift` (< 8) on: 0 for a whole image (all bytes, the padded
     // last one included); for a band that starts inside a byte of the scan, its first `shift` bits belong to the byte
     // it shares with the band before, its whole bytes follow, the bits left over are the next band's business.
     // state: [0] unused, [1] stuffed bytes (out), [2] bytes of the packed stream that were stuffed (out), [3 ..] descriptors
+    // out: 16-byte aligned; the first stuffed byte goes to out[out_skew] (< 16; the bytes before it are somebody else's — the
+    // file headers when `out` is the caller's host buffer — and are not touched); out_cap counts from out[0].
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes + kStuffThreads];
     __shared__ uint32_t wave_sum[kStuffThreads / 64];
     __shared__ unsigned long long s_before;
@@ -429,13 +431,13 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
         __syncthreads();
         const uint64_t ff_before = s_before;
         const uint64_t tile_in = nbytes - t * kTileBytes < (uint64_t)kTileBytes ? nbytes - t * kTileBytes : (uint64_t)kTileBytes;
-        const uint64_t dst0 = t * kTileBytes + ff_before;      // where the tile's first output byte goes
+        const uint64_t dst0 = out_skew + t * kTileBytes + ff_before; // where the tile's first output byte goes
         const uint32_t tile_out = (uint32_t)tile_in + tile_ff; // bytes the tile produces
-        if (t + 1 == ntiles && lane == 0) { state[1] = dst0 + tile_out; state[2] = nbytes; }
+        if (t + 1 == ntiles && lane == 0) { state[1] = dst0 + tile_out - out_skew; state[2] = nbytes; }
         // expand into LDS at the output's alignment (LDS dwords = global dwords).  The stage was zeroed: only the
         // stream's bytes are written, each moved up by the number of 0xFF bytes before it — the gaps ARE the stuffed
         // zeros.  No branch per byte: bytes that do not exist go to a dummy byte.
-        const uint32_t skew = (uint32_t)(dst0 & 3);
+        const uint32_t skew = (uint32_t)(dst0 & 15);
         const uint32_t at0 = skew + (uint32_t)wave * kWaveBytes + wave_base + 4u * wl;
 #pragma unroll
         for (int k = 0; k < kLaneWords; k++) {
@@ -451,21 +453,21 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
             }
         }
         __syncthreads();
-        // out: leading bytes up to the first aligned dword, aligned dwords, trailing bytes
-        const uint64_t base = dst0 - skew; // multiple of 4
+        // out: leading bytes up to the first aligned 16 bytes, aligned 16-byte pieces, trailing bytes
+        const uint64_t base = dst0 - skew; // multiple of 16
         const uint32_t end = skew + tile_out;
-        const uint32_t first_dw = skew ? 4u : 0u, last_dw = end & ~3u;
-        if (first_dw <= last_dw) {
-            for (uint32_t i = first_dw + 4u * lane; i < last_dw; i += 4u * kStuffThreads)
-                if (base + i + 4 <= out_cap) __builtin_nontemporal_store(*reinterpret_cast<const uint32_t *>(stage + i), reinterpret_cast<uint32_t *>(out + base + i));
-            if (lane < 4) { // bytes [skew, min(4, end)) and [last_dw, end)
+        const uint32_t first_q = skew ? 16u : 0u, last_q = end & ~15u;
+        if (first_q <= last_q) {
+            for (uint32_t i = first_q + 16u * lane; i < last_q; i += 16u * kStuffThreads)
+                if (base + i + 16 <= out_cap) __builtin_nontemporal_store(*reinterpret_cast<const v4u *>(stage + i), reinterpret_cast<v4u *>(out + base + i));
+            if (lane < 16) { // bytes [skew, min(16, end)) and [last_q, end)
                 const uint32_t i = skew + lane;
-                if (skew && i < 4 && i < end && base + i < out_cap) out[base + i] = stage[i];
-                const uint32_t j = last_dw + lane;
-                if (j < end && j >= first_dw && base + j < out_cap) out[base + j] = stage[j];
+                if (skew && i < 16 && i < end && base + i < out_cap) out[base + i] = stage[i];
+                const uint32_t j = last_q + lane;
+                if (j < end && j >= first_q && base + j < out_cap) out[base + j] = stage[j];
             }
-        } else { // the whole tile lies inside one dword
-            if ((uint32_t)lane + skew < end && lane < 4 && base + skew + lane < out_cap) out[base + skew + lane] = stage[skew + lane];
+        } else { // the whole tile lies inside one 16-byte piece
+            if ((uint32_t)lane + skew < end && lane < 16 && base + skew + lane < out_cap) out[base + skew + lane] = stage[skew + lane];
         }
     }
 }
@@ -498,6 +500,10 @@ hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_co
                               uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state,
                               bool state_is_zero, uint8_t *d_out, uint64_t out_cap, hipStream_t s)
 {
+    // (d_out may start anywhere: the kernel gets the 16-byte boundary below it and the distance)
+    const uint32_t out_skew = (uint32_t)(reinterpret_cast<uintptr_t>(d_out) & 15);
+    d_out -= out_skew;
+    out_cap += out_skew;
     if (first_tile == 0 && !state_is_zero) { // (a continuation keeps the descriptors of the tiles before it)
         hipError_t e = hipMemsetAsync(d_state, 0, fused_stuff_state_words(max_stream_bytes) * 8, s);
         if (e != hipSuccess) return e;
@@ -506,7 +512,7 @@ hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_co
     if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (code_state_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(stuff_fused_kernel, dim3((unsigned)tiles), dim3(kStuffThreads), 0, s, d_stream, d_code_state, shift, band ? 1u : 0u,
-                       d_state, d_out, out_cap, first_tile, d_code_state, (uint32_t)code_state_words);
+                       d_state, d_out, out_skew, out_cap, first_tile, d_code_state, (uint32_t)code_state_words);
     return hipGetLastError();
 }
 

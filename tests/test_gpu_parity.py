@@ -471,6 +471,67 @@ def test_encode_device_into_pinned_and_pageable_storage():
         assert ei.value.needed == len(want) and (small == 0x77).all()
 
 
+def _pinned_storage_cases():
+    """Pinned storage: every alignment of the destination and of the scan's first byte, the bytes around the file
+    untouched, a buffer of exactly the file's size, one that is a byte short (size reported)."""
+    import torch
+    from pixo_amd import error
+    B = jpeg.JpegOptions.builder
+    for (w, h, q, ss, opt) in ((640, 360, 80, 1, False), (33, 50, 95, 0, False), (1000, 700, 100, 1, False), (512, 512, 30, 1, True),
+                               (8, 8, 50, 0, False), (2048, 1024, 90, 1, False)):
+        px = synth.noise(w, h, w + q)
+        if q == 100:
+            px[: len(px) // 2] = 255  # runs of 0xFF bytes in the stream as well
+        d_px = torch.from_numpy(px).to("cuda:0")
+        torch.cuda.synchronize()
+        o = B(w, h).quality(q).subsampling(jpeg.Subsampling(ss)).optimize_huffman(opt).build()
+        want = jpeg.encode(px, o)
+        for lead in range(5):
+            store = torch.full((lead + len(want) + 37,), 0xA5, dtype=torch.uint8).pin_memory()
+            n = jpeg.encode_device_into(store[lead:], d_px, o)
+            got = store.numpy()
+            assert n == len(want) and got[lead:lead + n].tobytes() == want, (w, h, q, lead)
+            assert (got[:lead] == 0xA5).all() and (got[lead + n:] == 0xA5).all(), (w, h, q, lead)
+        exact = torch.zeros(len(want), dtype=torch.uint8).pin_memory()
+        assert jpeg.encode_device_into(exact, d_px, o) == len(want) and exact.numpy().tobytes() == want
+        short = torch.zeros(len(want) - 1, dtype=torch.uint8).pin_memory()
+        with pytest.raises(error.BufferTooSmall) as ei:
+            jpeg.encode_device_into(short, d_px, o)
+        assert ei.value.needed == len(want)
+        assert jpeg.encode_device(d_px, o) == want  # (the context's own pinned buffer, then Python bytes)
+
+
+def test_encode_device_into_pinned_storage_every_alignment():
+    _pinned_storage_cases()
+
+
+def test_direct_store_switch_gives_the_same_files():
+    """PIXO_HIP_DIRECT_STORES=1 (the stuffing kernel writes the caller's pinned memory itself) in a fresh process:
+    the alignment cases above, and the same bytes as the default path."""
+    import subprocess, sys, hashlib
+    code = ("import sys, hashlib, torch; sys.path.insert(0, 'tests'); import synth; from pixo_amd import jpeg\n"
+            "px = synth.noise(1024, 768, 5); d = torch.from_numpy(px).to('cuda:0'); torch.cuda.synchronize()\n"
+            "o = jpeg.JpegOptions.builder(1024, 768).quality(80).subsampling(jpeg.Subsampling.S420).build()\n"
+            "pin = torch.zeros(4 << 20, dtype=torch.uint8).pin_memory(); n = jpeg.encode_device_into(pin, d, o)\n"
+            "print(hashlib.sha256(pin[:n].numpy().tobytes()).hexdigest(), hashlib.sha256(jpeg.encode_device(d, o)).hexdigest())")
+    import os
+    outs = []
+    for direct in ("0", "1"):
+        env = dict(os.environ, PIXO_HIP_DIRECT_STORES=direct)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if len(ln.split()) == 2 and len(ln.split()[0]) == 64][-1].split())
+    px = synth.noise(1024, 768, 5)
+    o = jpeg.JpegOptions.builder(1024, 768).quality(80).subsampling(jpeg.Subsampling.S420).build()
+    want = hashlib.sha256(jpeg.encode(px, o)).hexdigest()
+    assert outs[0] == [want, want] and outs[1] == [want, want]
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, 'tests'); import test_gpu_parity as t; t._pinned_storage_cases(); print('cases ok')"],
+                       capture_output=True, text=True, env=dict(os.environ, PIXO_HIP_DIRECT_STORES="1"), timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "cases ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_every_rgb_colour_once():
     """A 4096x4096 image that contains each of the 16,777,216 RGB triples exactly once (two different
     arrangements, so that every colour meets different neighbours in the 4:2:0 box sums): coefficient

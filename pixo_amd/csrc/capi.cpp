@@ -3,7 +3,7 @@
 // Owns the thread-local device context (HIP stream, grow-only device and pinned host
 // buffers) and the per-device quantiser-table cache.  No CPU fallback exists: without a
 // usable GPU every compute entry point fails with PIXO_ERR_COMPRESSION and says so.
-#include <hip/hip_runtime_api.h>
+#include <hip/hip_runtime.h>
 
 #include <chrono>
 #include <cstdio>
@@ -22,6 +22,7 @@
 #include "jpeg_entropy.hpp"
 #include "jpeg_host.hpp"
 #include "jpeg_kernels.hpp"
+#include "jpeg_scan_block.h" // (the table form of the flat walk: built on the host, see upload_scan_tables)
 #include "jpeg_trellis.hpp"
 #include "png_filter.hpp"
 
@@ -109,6 +110,7 @@ struct Context {
     };
     Buf e_tables, e_hist, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out, e_seg_bytes, e_seg_off;
     Buf e_code_state, e_stuff_state; // single-pass kernels (jpeg_scan_fused.hip): look-back descriptors, totals
+    uint32_t tables_held[pixo_scan::kScanTableUpload]; bool tables_valid = false; hipStream_t tables_stream = nullptr; // what e_tables holds (no upload when unchanged)
     size_t code_state_zero_words = 0; // this many words of e_code_state are known to be zero (the stuffing kernel cleans up behind itself)
     Buf p_in, p_out, p_sums, p_scratch; // PNG filter stage
     Buf t_raw, t_trail;                 // progressive + trellis: unquantised DCT blocks (f32), Viterbi back-pointers
@@ -196,6 +198,7 @@ void Context::release()
     if (producer_done) (void)hipEventDestroy(producer_done);
     producer_done = nullptr;
     code_state_zero_words = 0;
+    tables_valid = false;
     d_px = d_coef = h_coef = nullptr; px_cap = coef_cap = hcoef_cap = 0;
     h_sums = nullptr; hsums_cap = 0; h_totals = nullptr; h_file = nullptr; hfile_cap = 0;
     stream = nullptr; ready = false;
@@ -354,6 +357,21 @@ struct ScanJob {
 
 // PIXO_HIP_OLD_ENTROPY=1: the multi-pass kernels of jpeg_entropy.hip for every scan (A/B runs; they remain the path of
 // scans with restart markers, batches and progressive scans)
+// The packed Huffman tables of a scan into e_tables — unless they are what the buffer holds already (the standard
+// tables, image after image: one small copy less on the stream per file).
+int upload_scan_tables(Context &c, const uint32_t (&packed)[pixo_host::kScanTableWords], hipStream_t stream)
+{
+    if (c.tables_valid && c.tables_stream == stream && std::memcmp(c.tables_held, packed, sizeof packed) == 0) return PIXO_OK;
+    c.tables_valid = false;
+    std::memcpy(c.tables_held, packed, sizeof packed);
+    for (int i = 0; i < pixo_scan::kWalkWords; ++i) // the same tables in the form of the flat walk (jpeg_scan_block.h)
+        c.tables_held[pixo_scan::kTableWords + i] = pixo_scan::walk_table_word(packed, i);
+    HIP_TRY(hipMemcpyAsync(c.e_tables.p, c.tables_held, sizeof c.tables_held, hipMemcpyHostToDevice, stream));
+    c.tables_valid = true;
+    c.tables_stream = stream;
+    return PIXO_OK;
+}
+
 bool direct_host_stores()
 { // PIXO_HIP_DIRECT_STORES=1: the stuffing kernel stores the file straight into pinned host memory instead of into HBM
   // with a copy behind it.  Off by default: kernel stores cross PCIe at 40 GB/s, the copy engine at 53 — 0.36 against
@@ -396,7 +414,7 @@ int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, co
         j.nseg = batch;
     }
     j.fused = j.nseg == 0 && !old_entropy_forced();
-    HIP_TRY(c.e_tables.reserve(pixo_host::kScanTableWords * 4));
+    HIP_TRY(c.e_tables.reserve(pixo_scan::kScanTableUpload * 4));
     HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
     if (j.fused) { // a block has at most 1665 bits: the packed stream has at most n * 209 bytes (+ slack the kernels read into)
         j.stream_cap = static_cast<size_t>(j.n) * 209 + 64;
@@ -460,17 +478,17 @@ int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_
     }
     uint32_t packed[pixo_host::kScanTableWords];
     pixo_host::pack_scan_tables(j.h, packed);
-    HIP_TRY(hipMemcpyAsync(c.e_tables.p, packed, sizeof packed, hipMemcpyHostToDevice, stream));
+    int rc_tables;
+    if ((rc_tables = upload_scan_tables(c, packed, stream))) return rc_tables;
     if (j.fused) { // lengths, prefix and packing in one pass; the stream starts at bit 0 whatever the band's offset will be
         const bool zero = c.code_state_zero_words >= pd::fused_code_state_words(j.n);
         c.code_state_zero_words = 0; // (dirty from here until a stuffing launch has cleaned it)
         // chained with the stuffing kernel (!wait): this launch also zeroes that kernel's descriptors
         HIP_TRY(pd::launch_scan_code(j.a, c.e_code_state.as<unsigned long long>(), zero, c.e_stream.as<uint32_t>(),
                                      wait ? nullptr : c.e_stuff_state.as<unsigned long long>(),
-                                     wait ? 0 : pd::fused_stuff_state_words(j.stream_cap), stream));
+                                     wait ? 0 : pd::fused_stuff_state_words(j.stream_cap), reinterpret_cast<unsigned long long *>(c.h_totals), stream));
         if (!wait) return PIXO_OK; // (the caller chains the stuffing kernel and synchronises once)
-        HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_code_state.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipStreamSynchronize(stream)); // (the kernel wrote the length into the pinned mailbox itself)
         j.total_bits = c.h_totals[0];
         j.nbytes = (j.total_bits + 7) / 8;
         return PIXO_OK;
@@ -542,10 +560,10 @@ int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_b
                                        shift, j.band, j.stream_cap, first_tile, tiles, c.e_stuff_state.as<unsigned long long>(),
                                        /*state_is_zero=*/
                                        chained && attempt == 0,
- out, out_cap, stream));
+ out, out_cap, reinterpret_cast<unsigned long long *>(c.h_totals), stream));
         c.code_state_zero_words = pd::fused_code_state_words(j.n);
-        HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_code_state.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(c.h_totals + 1, c.e_stuff_state.as<uint64_t>() + 1, 16, hipMemcpyDeviceToHost, stream));
+        // (no read-back copies: both kernels store their totals into the pinned mailbox h_totals — [0] bits of the scan,
+        // [1] stuffed bytes, [2] packed bytes — which the host reads after the synchronisation below)
         uint32_t edge[3] = {0, 0, 0}; // band: stream word 0 (head bits) and the two words around the tail bits
         if (j.band) {
             const uint64_t tail_at = static_cast<uint64_t>(j.head_bits) + 8 * ((j.total_bits - j.head_bits) / 8);
@@ -808,7 +826,7 @@ int device_progressive_scans(const int16_t *dy, const int16_t *dcb, const int16_
     a.first[0] = 0;
     for (int i = 0; i < 7; ++i) a.first[i + 1] = a.first[i] + size[i];
     const uint64_t n = a.first[7];
-    HIP_TRY(c.e_tables.reserve(pixo_host::kScanTableWords * 4));
+    HIP_TRY(c.e_tables.reserve(pixo_scan::kScanTableUpload * 4));
     HIP_TRY(c.g_flags.reserve(n * 4));
     HIP_TRY(c.g_rank.reserve(n * 8));
     HIP_TRY(c.g_by_rank.reserve(n * 4));
@@ -832,7 +850,7 @@ int device_progressive_scans(const int16_t *dy, const int16_t *dcb, const int16_
     pixo_host::pack_scan_tables(h, packed);
     for (uint32_t &w : packed) // progressive.rs:363-381: a symbol the table lacks is coded as (0, 4 bits)
         if ((w >> 16) == 0) w = 4u << 16;
-    HIP_TRY(hipMemcpyAsync(c.e_tables.p, packed, sizeof packed, hipMemcpyHostToDevice, stream));
+    { const int rc = upload_scan_tables(c, packed, stream); if (rc) return rc; }
     uint64_t *totals = c.e_totals.as<uint64_t>();
     HIP_TRY(pd::launch_prog_flags(a, stream));
     HIP_TRY(pd::launch_exclusive_scan(a.nonempty, n, c.g_rank.as<uint64_t>(), c.e_tmp.as<uint64_t>(), totals + 2, stream));
@@ -996,7 +1014,9 @@ int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options
     PIXO_ON_DEVICE_OF(c);
     const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
     if ((rc = c.reserve_px((px_bytes + 15) & ~size_t{15}))) return rc;
+    Stopwatch sw;
     HIP_TRY(hipMemcpyAsync(c.d_px, data, px_bytes, hipMemcpyHostToDevice, c.stream));
+    sw.lap("pixels to device (enqueued)");
     if (o.progressive) {
         if ((rc = progressive_to_vector(c.d_px, o, g, c, spill))) return rc;
         *file = spill.data();
@@ -1046,7 +1066,10 @@ int pixo_hip_jpeg_encode(const uint8_t *data, size_t data_len, const pixo_jpeg_o
     size_t n = 0;
     int rc = encode_to_view(data, data_len, *options, spill, &file, &n);
     if (rc) return rc;
-    return deliver(file, n, out, out_len);
+    Stopwatch sw;
+    rc = deliver(file, n, out, out_len);
+    sw.lap("file into fresh host memory");
+    return rc;
 }
 
 int pixo_hip_jpeg_encode_into(uint8_t *output, size_t capacity, const uint8_t *data, size_t data_len,

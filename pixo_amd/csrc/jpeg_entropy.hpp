@@ -10,7 +10,7 @@ namespace pixo_dev {
 
 struct ScanArgs {
     const int16_t *y, *cb, *cr; // coefficient tuple, natural order, 64 i16 per block
-    const uint32_t *tables;     // pixo_scan::kTableWords words: (length << 16) | code
+    const uint32_t *tables;     // pixo_scan::kTableWords words: (length << 16) | code; behind them pixo_scan::kWalkWords words in the flat walk's form
     int mode;                   // 0 gray, 1 4:4:4, 2 4:2:0 (block order of encode_scan)
     uint64_t nblocks;           // blocks in scan order
     uint32_t restart;           // MCUs per segment, 0 = one uninterrupted stream.  A segment starts on a byte
@@ -67,9 +67,9 @@ hipError_t launch_stuff(const uint32_t *d_stream, uint64_t nbytes, const uint64_
 size_t fused_code_state_words(uint64_t nblocks);
 // state_is_zero: the caller knows d_state holds zeros (word 1 aside) — the stuffing kernel of the previous scan left it so —
 // and no memset is launched.  d_clear / clear_words: words this kernel zeroes on the side (the state of the stuffing launch
-// that follows), or null.
+// that follows), or null.  host_totals: pinned host memory (or null): [0] also receives the scan's length — no read-back copy.
 hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool state_is_zero, uint32_t *d_stream,
-                            unsigned long long *d_clear, size_t clear_words, hipStream_t s);
+                            unsigned long long *d_clear, size_t clear_words, unsigned long long *host_totals, hipStream_t s);
 // stuff: the stream's bytes from bit `shift` (< 8) on -> d_out with 0x00 behind every 0xFF.  band = false: all bytes of a
 // whole scan (shift 0); band = true: only the whole bytes behind the band's first `shift` bits.  Reads the scan's length
 // from d_code_state[1] (no host round trip) and zeroes the rest of d_code_state (code_state_words) for the next scan.
@@ -78,11 +78,12 @@ hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool
 // d_state[2] = bytes of the packed stream consumed.
 // One workgroup per tile: tiles [first_tile, first_tile + tiles) of stuff_tiles(stream bytes); the caller launches a
 // guess, reads d_state[2] back and, if the stream has more tiles, launches the rest (first_tile > 0 keeps the state).
+// host_totals (pinned host memory, or null): [1] and [2] receive d_state[1] and d_state[2] as well.
 size_t fused_stuff_state_words(uint64_t max_stream_bytes);
 uint64_t stuff_tiles(uint64_t stream_bytes);
 hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_code_state, size_t code_state_words, uint32_t shift, bool band,
                               uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state,
-                              bool state_is_zero, uint8_t *d_out, uint64_t out_cap, hipStream_t s);
+                              bool state_is_zero, uint8_t *d_out, uint64_t out_cap, unsigned long long *host_totals, hipStream_t s);
 
 // ---- progressive scans on the device (simple_progressive_script: seven single-component scans) ------
 struct ProgArgs {

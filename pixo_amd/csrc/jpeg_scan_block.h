@@ -13,9 +13,11 @@
 #if defined(PIXO_EMU)
 #define PIXO_SDEV static inline // free functions
 #define PIXO_SMEM inline        // member functions
+#define PIXO_SHOST static inline // ... that the host side of the library calls as well
 #else
 #define PIXO_SDEV __device__ __forceinline__
 #define PIXO_SMEM __device__ __forceinline__
+#define PIXO_SHOST __host__ __device__ inline
 #endif
 
 namespace pixo_scan {
@@ -164,51 +166,71 @@ struct CountVisitor {
 // walk_block above is written like the reference: per coefficient an if/else, a while loop for the 16-zero runs,
 // and inside the visitors more ifs.  On a wavefront every one of those is an exec-mask region — save, and, branch,
 // restore: ~70 scalar instructions per coefficient position, 4400 per block, and the scalar unit is shared by the
-// whole CU: that, not the vector work, bounded the entropy kernels.  The flat forms below compute every position's
+// whole CU: that, not the vector work, bounded the entropy kernels.  The flat form below computes every position's
 // contribution with selects; the only branches left are wave-uniform (a position at which no lane of the wavefront
 // holds a non-zero coefficient is skipped; 16-zero runs, rare, take a uniform side path).
 #if defined(PIXO_EMU)
-#define PIXO_ANY64(pred) (pred)
+#define PIXO_BALLOT64(pred) ((uint64_t)((pred) ? 1 : 0))
 PIXO_SDEV uint32_t scan_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31)); }
-#else
-#define PIXO_ANY64(pred) (__builtin_amdgcn_ballot_w64(pred) != 0)
-PIXO_SDEV uint32_t scan_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
-#endif
-
-// bit length of one block (LengthVisitor's result)
-PIXO_SDEV uint32_t block_length_flat(const uint32_t *w, int prev_dc, const uint32_t *tab)
+PIXO_SDEV uint32_t scan_sign_bits(int x) // v_ffbh_i32: leading bits equal to the sign bit; -1 for 0 and -1
 {
-    const int diff = (int)(int16_t)(coef_of(w, 0) - prev_dc);
-    const int cat0 = magnitude_bits(diff);
-    uint32_t bits = (tab[cat0] >> 16) + (uint32_t)cat0;
-    const uint32_t zrl_len = tab[kDcSyms + 0xF0] >> 16, eob_len = tab[kDcSyms] >> 16;
-    uint32_t run = 0;
-#pragma unroll
-    for (int k = 1; k < 64; k++) {
-        const int v = coef_of(w, zigzag(k));
-        const bool nz = v != 0;
-        if (!PIXO_ANY64(nz)) { run++; continue; } // (wave-uniform on the device)
-        if (PIXO_ANY64(nz && run >= 16u)) // rare: ZRL codes in front of the symbol
-            bits += nz ? ((run & 16u) ? zrl_len : 0u) + ((run & 32u) ? 2u * zrl_len : 0u) : 0u;
-        const uint32_t cat = (uint32_t)magnitude_bits(v);
-        const uint32_t t = tab[kDcSyms + (((run & 15u) << 4) | cat)];
-        bits += nz ? (t >> 16) + cat : 0u;
-        run = nz ? 0u : run + 1u;
-    }
-    return bits + (run ? eob_len : 0u);
+    if (x == 0 || x == -1) return 0xFFFFFFFFu;
+    return (uint32_t)__builtin_clz((unsigned)(x < 0 ? ~x : x));
+}
+#else
+#define PIXO_BALLOT64(pred) __builtin_amdgcn_ballot_w64(pred)
+PIXO_SDEV uint32_t scan_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+PIXO_SDEV uint32_t scan_sign_bits(int x)
+{
+    uint32_t r;
+    asm("v_ffbh_i32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+#endif
+#define PIXO_ANY64(pred) (PIXO_BALLOT64(pred) != 0)
+
+// The tables as the flat walk wants them: per class
+//   [0, 16)     DC, slot = (32 - category) & 15 — category 0 -> 0, 1 -> 15, ... 11 -> 5
+//   [16, 272)   AC, slot = run << 4 | ((32 - category) & 15), run < 16
+//   272, 273    end of block, run of 16 zeros
+// and one word per symbol that does the work of several instructions per coefficient:
+//   bits 31..16  the code, LEFT-aligned in 16 bits        byte 0  the code's length
+//   byte 1       the code's length + 32 (the walk subtracts m = 32 - category: what is left is length + category)
+// AC slots of category 0 — where the walk looks for a coefficient that is zero — say "nothing": no code, no bits.
+// The index (32 - category) & 15 is what falls out of v_ffbh_i32 without a subtraction.
+constexpr int kWalkDc = 16, kWalkAc = 256, kWalkEob = kWalkDc + kWalkAc, kWalkZrl = kWalkEob + 1, kWalkClassWords = kWalkZrl + 1;
+constexpr int kWalkWords = 2 * kWalkClassWords, kScanTableUpload = kTableWords + kWalkWords;
+constexpr uint32_t kWalkNothing = 32u << 8;
+PIXO_SHOST uint32_t walk_word(uint32_t packed) // (length << 16) | code  ->  the form above
+{
+    const uint32_t len = packed >> 16, code = packed & 0xFFFFu;
+    return len ? ((code << (16u - len)) << 16) | ((len + 32u) << 8) | len : kWalkNothing;
+}
+// word i of the flat walk's tables from the packed tables (kTableWords words); the host builds them once per scan and
+// uploads them behind the packed ones: kScanTableUpload words in all
+PIXO_SHOST uint32_t walk_table_word(const uint32_t *packed, int i)
+{
+    const int cls = i / kWalkClassWords, slot = i % kWalkClassWords;
+    const uint32_t *t = packed + cls * kClassSyms;
+    if (slot == kWalkEob) return walk_word(t[kDcSyms]);
+    if (slot == kWalkZrl) return walk_word(t[kDcSyms + 0xF0]);
+    const int c4 = slot & 15, cat = c4 ? 32 - (c4 | 16) : 0;
+    if (slot < kWalkDc) return cat < kDcSyms ? walk_word(t[cat]) : kWalkNothing;
+    const int run = (slot - kWalkDc) >> 4;
+    return cat ? walk_word(t[kDcSyms + ((run << 4) | cat)]) : kWalkNothing;
 }
 
-// Packing with selects.  `Sink` provides or_word(flush, word, value): OR `value` into word `word` of the
-// destination when `flush` (a no-op target otherwise) — every word of the destination starts out zero, so complete
-// words and the partial first / last word of a block are written the same way.
+// Packing with selects.  `Sink` provides or_word(flush, word, value): OR `value` into word `word` of the destination
+// when `flush` — every word of the destination starts out zero, so complete words and the partial first / last word of
+// a block are written the same way — or, a sink that owns its words alone, store it whether `flush` or not (the word
+// is stored again, more complete, until the packer moves on: the last store wins).
 template <class Sink> struct FlatPack {
     Sink sink;
     uint32_t acc;     // pending bits, left-aligned, zeros below
     uint32_t pending; // < 32
     uint32_t word;    // index of the word the pending bits belong to
-    PIXO_SMEM void put(uint32_t v, uint32_t n) // 0 <= n <= 27, v < 2^n (v = 0 when n = 0)
+    PIXO_SMEM void put_left(uint32_t vl, uint32_t n) // 0 <= n <= 27 bits at the top of vl, zeros below (vl = 0 when n = 0)
     {
-        const uint32_t vl = v << ((32u - n) & 31u);            // left-aligned (n = 0: v = 0)
         const uint32_t merged = acc | (vl >> pending);
         const uint32_t spill = scan_alignbit(vl, 0u, pending); // the bits that did not fit: low word of {vl, 0} >> pending
         const uint32_t total = pending + n;
@@ -221,33 +243,46 @@ template <class Sink> struct FlatPack {
     PIXO_SMEM void finish() { sink.or_word(pending != 0u, word, acc); }
 };
 
-template <class Sink> PIXO_SDEV void block_pack_flat(const uint32_t *w, int prev_dc, const uint32_t *tab, FlatPack<Sink> &p)
+// One symbol: table word `t` (above), the coefficient as u = v - (v < 0) — its low `category` bits are the value bits,
+// every bit above them equals the sign — and m = 32 - category.
+template <class Sink> PIXO_SDEV void put_symbol(FlatPack<Sink> &p, uint32_t t, uint32_t u, uint32_t m)
 {
-    const int diff = (int)(int16_t)(coef_of(w, 0) - prev_dc);
-    const int cat0 = magnitude_bits(diff);
-    const uint32_t t0 = tab[cat0];
-    p.put(((t0 & 0xFFFFu) << cat0) | value_bits(diff, cat0), (t0 >> 16) + (uint32_t)cat0);
-    const uint32_t zrl = tab[kDcSyms + 0xF0], eob = tab[kDcSyms];
-    uint32_t run = 0;
+    const uint32_t value_left = u << (m & 31u);                       // the value bits at the top (category 0: u = 0)
+    p.put_left((t & 0xFFFF0000u) | (value_left >> (t & 0xFFu)), ((t >> 8) & 0xFFu) - m);
+}
+
+// `wtab`: this class's kWalkClassWords words.
+template <class Sink> PIXO_SDEV void block_pack_flat(const uint32_t *w, int prev_dc, const uint32_t *wtab, FlatPack<Sink> &p)
+{
+    {
+        const int diff = (int)(int16_t)(coef_of(w, 0) - prev_dc); // i16 arithmetic like the reference
+        const int u = diff + (diff >> 31);
+        const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u;
+        put_symbol(p, wtab[m & 15u], (uint32_t)u, m);
+    }
+    const uint32_t zrl = wtab[kWalkZrl], eob = wtab[kWalkEob];
+    uint32_t run16 = 0; // 16 x the zeros since the last non-zero coefficient
 #pragma unroll
     for (int k = 1; k < 64; k++) {
         const int v = coef_of(w, zigzag(k));
+        const uint64_t nz_lanes = PIXO_BALLOT64(v != 0);
+        if (!nz_lanes) { run16 += 16u; continue; } // (wave-uniform on the device)
         const bool nz = v != 0;
-        if (!PIXO_ANY64(nz)) { run++; continue; } // (wave-uniform on the device)
-        if (PIXO_ANY64(nz && run >= 16u)) {       // rare: up to three ZRL codes in front of the symbol
+        if (k > 16 && __builtin_expect((PIXO_BALLOT64(run16 >= 256u) & nz_lanes) != 0, 0)) { // rare: up to three ZRL codes in front of the symbol
 #pragma unroll
             for (uint32_t i = 0; i < 3; i++) {
-                const bool on = nz && (run >> 4) > i;
-                p.put(on ? (zrl & 0xFFFFu) : 0u, on ? (zrl >> 16) : 0u);
+                const bool on = nz && (run16 >> 8) > i;
+                p.put_left(on ? (zrl & 0xFFFF0000u) : 0u, on ? (zrl & 0xFFu) : 0u);
             }
+            run16 = nz ? (run16 & 255u) : run16;
         }
-        const uint32_t cat = (uint32_t)magnitude_bits(v);
-        const uint32_t t = tab[kDcSyms + (((run & 15u) << 4) | cat)];
-        const uint32_t code = ((t & 0xFFFFu) << cat) | value_bits(v, (int)cat);
-        p.put(nz ? code : 0u, nz ? (t >> 16) + cat : 0u);
-        run = nz ? 0u : run + 1u;
+        const int u = v + (v >> 31);
+        const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u; // v = 0: m = 32, slot 0 of its run = "nothing"
+        const uint32_t slot = (k > 16 ? (run16 & 255u) : run16) | (m & 15u); // (a lane without a coefficient here may be anywhere in a long run)
+        put_symbol(p, wtab[kWalkDc + slot], (uint32_t)u, m);
+        run16 = nz ? 0u : run16 + 16u;
     }
-    p.put(run ? (eob & 0xFFFFu) : 0u, run ? (eob >> 16) : 0u);
+    p.put_left(run16 ? (eob & 0xFFFF0000u) : 0u, run16 ? (eob & 0xFFu) : 0u);
 }
 
 // ---- progressive scans (simple_progressive_script, progressive.rs:98-110) ------------------------

@@ -127,14 +127,15 @@ __device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t
 // Word i of the window is word `first + i` of the stream; every word starts out zero and is only ever OR-ed (LDS
 // atomic without return).  Words outside [0, limit) — a group of very long blocks is written out in more than one
 // round — and the "no flush" case go to a per-lane dummy word behind the window: no branch.
-// ---- the per-lane scratch of the single walk: a block's bits from bit 0, complete words stored plainly ----------------
-// (every word index is written once; words beyond the scratch — a block of more than kScratchWords * 32 bits — and the
-// "no flush" case go to the lane's dummy word)
+// ---- the per-lane scratch of the single walk: a block's bits from bit 0, words stored plainly ------------------------
+// (the word being filled is stored after every symbol — the last store, the complete word, wins: cheaper than a
+// select on "complete"; words beyond the scratch — a block of more than kScratchWords * 32 bits — go to the lane's
+// dummy word)
 struct LaneSink {
     uint32_t *words; // this lane's kScratchWords words + 1 dummy
-    __device__ __forceinline__ void or_word(bool flush, uint32_t word, uint32_t value)
+    __device__ __forceinline__ void or_word(bool, uint32_t word, uint32_t value)
     {
-        words[(flush && word < kScratchWords) ? word : kScratchWords] = value;
+        words[word < kScratchWords ? word : kScratchWords] = value;
     }
 };
 
@@ -150,11 +151,12 @@ struct LdsSink {
 
 template <int MODE>
 __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) void scan_code_kernel
-(const ScanArgs a, unsigned long long *state, uint32_t *stream, unsigned long long *clear, uint32_t clear_words)
+(const ScanArgs a, unsigned long long *state, uint32_t *stream, unsigned long long *clear, uint32_t clear_words,
+ unsigned long long *host_totals)
 {
     // state: [0] unused, [1] total bits (out), [2 ..] per group: descriptor, then per group: tail
     __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
-    __shared__ uint32_t tab[kTableWords];
+    __shared__ uint32_t tab[kWalkWords]; // the Huffman tables in the flat walk's form (jpeg_scan_block.h)
     __shared__ uint32_t scratch[kGroup * kScratchPitch];
     __shared__ uint32_t wave_sum[kGroupWaves], wave_long[kGroupWaves];
     __shared__ unsigned long long s_before;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     if (lane == 0) s_carry = 0;
     const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
     unsigned long long *desc = state + 2, *tails = state + 2 + ngroups;
-    for (int i = lane; i < kTableWords; i += kGroup) tab[i] = a.tables[i];
+    for (int i = lane; i < kWalkWords; i += kGroup) tab[i] = a.tables[kTableWords + i]; // (the walk's form lies behind the packed one)
     // (housekeeping for the kernel that follows: its descriptors must be zero when it starts — cheaper here than a memset launch)
     for (uint64_t i = (uint64_t)blockIdx.x * kGroup + lane; i < clear_words; i += (uint64_t)gridDim.x * kGroup) clear[i] = 0;
     __syncthreads();
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             FlatPack<LaneSink> p;
             p.sink = LaneSink{scratch + lane * kScratchPitch};
             p.acc = 0; p.pending = 0; p.word = 0;
-            block_pack_flat(w, prev_dc, tab + cls * kClassSyms, p);
+            block_pack_flat(w, prev_dc, tab + cls * kWalkClassWords, p);
             len = p.word * 32u + p.pending;
             p.finish();
         }
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                 p.acc = 0;
                 p.pending = (uint32_t)(rel & 31);
                 p.word = (uint32_t)(rel >> 5); // relative to the window; wraps below zero for words before it
-                block_pack_flat(w, prev_dc, tab + cls * kClassSyms, p);
+                block_pack_flat(w, prev_dc, tab + cls * kWalkClassWords, p);
                 p.finish();
             }
             if (wbase == 0) { // where the group starts in the stream
@@ -271,7 +273,10 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                     if (lane == 0) {
                         s_before = sum;
                         if (g) store_relaxed(&desc[g], kFlagPrefix | (sum + group_bits));
-                        if (last_group) state[1] = sum + group_bits; // the scan's length in bits (unpadded)
+                        if (last_group) { // the scan's length in bits (unpadded)
+                            state[1] = sum + group_bits;
+                            if (host_totals) host_totals[0] = sum + group_bits;
+                        }
                     }
                 }
                 __syncthreads();
@@ -345,7 +350,8 @@ __device__ __forceinline__ uint32_t zero_byte_mask(uint32_t x)
 __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32_t *stream, const unsigned long long *code_state,
                                                                    uint32_t shift, uint32_t band, unsigned long long *state,
                                                                    uint8_t *out, uint32_t out_skew, uint64_t out_cap, uint64_t tile_offset,
-                                                                   unsigned long long *clear, uint32_t clear_words)
+                                                                   unsigned long long *clear, uint32_t clear_words,
+                                                                   unsigned long long *host_totals)
 {
     // The bytes to stuff are the stream's bits from bit `shift` (< 8) on: 0 for a whole image (all bytes, the padded
     // last one included); for a band that starts inside a byte of the scan, its first `shift` bits belong to the byte
@@ -365,7 +371,10 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
     const uint64_t ntiles = (nbytes + kTileBytes - 1) / kTileBytes;
     unsigned long long *desc = state + 3;
     if (ntiles == 0) {
-        if (blockIdx.x == 0 && lane == 0 && tile_offset == 0) { state[1] = 0; state[2] = 0; }
+        if (blockIdx.x == 0 && lane == 0 && tile_offset == 0) {
+            state[1] = 0; state[2] = 0;
+            if (host_totals) { host_totals[1] = 0; host_totals[2] = 0; }
+        }
         return;
     }
     const uint64_t t = tile_offset + blockIdx.x; // one tile per workgroup (the launcher guesses how many there are)
@@ -433,7 +442,10 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
         const uint64_t tile_in = nbytes - t * kTileBytes < (uint64_t)kTileBytes ? nbytes - t * kTileBytes : (uint64_t)kTileBytes;
         const uint64_t dst0 = out_skew + t * kTileBytes + ff_before; // where the tile's first output byte goes
         const uint32_t tile_out = (uint32_t)tile_in + tile_ff; // bytes the tile produces
-        if (t + 1 == ntiles && lane == 0) { state[1] = dst0 + tile_out - out_skew; state[2] = nbytes; }
+        if (t + 1 == ntiles && lane == 0) {
+            state[1] = dst0 + tile_out - out_skew; state[2] = nbytes;
+            if (host_totals) { host_totals[1] = dst0 + tile_out - out_skew; host_totals[2] = nbytes; }
+        }
         // expand into LDS at the output's alignment (LDS dwords = global dwords).  The stage was zeroed: only the
         // stream's bytes are written, each moved up by the number of 0xFF bytes before it — the gaps ARE the stuffed
         // zeros.  No branch per byte: bytes that do not exist go to a dummy byte.
@@ -477,10 +489,13 @@ size_t fused_code_state_words(uint64_t nblocks) { return 2 + 2 * (size_t)((nbloc
 size_t fused_stuff_state_words(uint64_t max_stream_bytes) { return 3 + (size_t)((max_stream_bytes + kTileBytes - 1) / kTileBytes); }
 
 hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool state_is_zero, uint32_t *d_stream,
-                            unsigned long long *d_clear, size_t clear_words, hipStream_t s)
+                            unsigned long long *d_clear, size_t clear_words, unsigned long long *host_totals, hipStream_t s)
 {
     const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
-    if (ngroups == 0) return hipMemsetAsync(d_state, 0, 16, s);
+    if (ngroups == 0) {
+        if (host_totals) host_totals[0] = 0; // (nothing in flight writes it: a context's launches are serial)
+        return hipMemsetAsync(d_state, 0, 16, s);
+    }
     if (!state_is_zero) {
         hipError_t e = hipMemsetAsync(d_state, 0, fused_code_state_words(a.nblocks) * 8, s);
         if (e != hipSuccess) return e;
@@ -488,9 +503,9 @@ hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool
     if (ngroups > 0x7FFFFFFFull || clear_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)ngroups;
     const uint32_t cw = d_clear ? (uint32_t)clear_words : 0u;
-    if (a.mode == 2) hipLaunchKernelGGL(scan_code_kernel<2>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw);
-    else if (a.mode == 1) hipLaunchKernelGGL(scan_code_kernel<1>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw);
-    else hipLaunchKernelGGL(scan_code_kernel<0>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw);
+    if (a.mode == 2) hipLaunchKernelGGL(scan_code_kernel<2>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals);
+    else if (a.mode == 1) hipLaunchKernelGGL(scan_code_kernel<1>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals);
+    else hipLaunchKernelGGL(scan_code_kernel<0>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals);
     return hipGetLastError();
 }
 
@@ -498,7 +513,7 @@ uint64_t stuff_tiles(uint64_t stream_bytes) { return (stream_bytes + kTileBytes 
 
 hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_code_state, size_t code_state_words, uint32_t shift, bool band,
                               uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state,
-                              bool state_is_zero, uint8_t *d_out, uint64_t out_cap, hipStream_t s)
+                              bool state_is_zero, uint8_t *d_out, uint64_t out_cap, unsigned long long *host_totals, hipStream_t s)
 {
     // (d_out may start anywhere: the kernel gets the 16-byte boundary below it and the distance)
     const uint32_t out_skew = (uint32_t)(reinterpret_cast<uintptr_t>(d_out) & 15);
@@ -512,7 +527,7 @@ hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_co
     if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (code_state_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(stuff_fused_kernel, dim3((unsigned)tiles), dim3(kStuffThreads), 0, s, d_stream, d_code_state, shift, band ? 1u : 0u,
-                       d_state, d_out, out_skew, out_cap, first_tile, d_code_state, (uint32_t)code_state_words);
+                       d_state, d_out, out_skew, out_cap, first_tile, d_code_state, (uint32_t)code_state_words, host_totals);
     return hipGetLastError();
 }
 

@@ -205,7 +205,7 @@ extern "C" void emu_scan_tables(const int16_t *y, const int16_t *cb, const int16
     pixo_host::pack_scan_tables(hs, out);
 }
 
-// The branch-free walkers of the single-pass kernels (block_length_flat / block_pack_flat, jpeg_scan_fused.hip) in
+// The branch-free walkers of the single-pass kernels (block_pack_flat, jpeg_scan_fused.hip) in
 // the same harness: lengths, prefix sum, packing in reverse block order into a zeroed stream, padding, stuffing.
 struct EmuOrSink {
     uint32_t *stream;
@@ -218,6 +218,9 @@ extern "C" long emu_scan_flat(const int16_t *y, const int16_t *cb, const int16_t
     using namespace pixo_scan;
     std::vector<uint32_t> len(nblocks);
     std::vector<uint64_t> off(nblocks);
+    uint32_t wtab[kWalkWords]; // the flat walk's own table form, built as the kernel builds it in LDS
+    for (int i = 0; i < kWalkWords; i++) wtab[i] = walk_table_word(tables, i);
+    struct NullSink { void or_word(bool, uint32_t, uint32_t) {} };
     auto load = [&](uint64_t s, uint32_t *wds, int *prev, int *cls) {
         const BlockRef r = block_of(mode, s);
         const int16_t *base = r.comp == 0 ? y : (r.comp == 1 ? cb : cr);
@@ -229,7 +232,10 @@ extern "C" long emu_scan_flat(const int16_t *y, const int16_t *cb, const int16_t
     for (uint64_t s = 0; s < nblocks; s++) {
         uint32_t wds[32]; int prev, cls;
         load(s, wds, &prev, &cls);
-        len[s] = block_length_flat(wds, prev, tables + cls * kClassSyms);
+        FlatPack<NullSink> q;
+        q.acc = 0; q.pending = 0; q.word = 0;
+        block_pack_flat(wds, prev, wtab + cls * kWalkClassWords, q);
+        len[s] = q.word * 32u + q.pending;
         off[s] = total; total += len[s];
     }
     std::vector<uint32_t> stream(total / 32 + 2, 0);
@@ -239,9 +245,9 @@ extern "C" long emu_scan_flat(const int16_t *y, const int16_t *cb, const int16_t
         FlatPack<EmuOrSink> p;
         p.sink = EmuOrSink{stream.data(), off[i] >> 5};
         p.acc = 0; p.pending = (uint32_t)(off[i] & 31); p.word = 0;
-        block_pack_flat(wds, prev, tables + cls * kClassSyms, p);
+        block_pack_flat(wds, prev, wtab + cls * kWalkClassWords, p);
         p.finish();
-        if (p.word * 32ull + p.pending != (off[i] & 31) + len[i]) return -2; // the two flat walks must agree on the length
+        if (p.word * 32ull + p.pending != (off[i] & 31) + len[i]) return -2; // the walk into nothing and the walk into the stream must agree on the length
     }
     const int n = (int)((8 - (total & 7)) & 7);
     if (n) stream[total >> 5] |= ((1u << n) - 1u) << (32 - (int)(total & 31) - n);
@@ -545,7 +551,7 @@ extern "C" void emu_int_color(int r, int g, int b, int32_t *out)
 struct EmuLaneSink {
     uint32_t *words;
     uint32_t cap;
-    void or_word(bool flush, uint32_t word, uint32_t value) { words[(flush && word < cap) ? word : cap] = value; }
+    void or_word(bool, uint32_t word, uint32_t value) { words[word < cap ? word : cap] = value; } // (the last store wins)
 };
 extern "C" long emu_scan_single_walk(const int16_t *y, const int16_t *cb, const int16_t *cr, int mode, uint64_t nblocks,
                                      const uint32_t *tables, uint32_t scratch_words, uint32_t window_words, uint32_t *out_words,
@@ -553,6 +559,8 @@ extern "C" long emu_scan_single_walk(const int16_t *y, const int16_t *cb, const 
 {
     using namespace pixo_scan;
     const int kGroupLanes = 192;
+    uint32_t wtab[kWalkWords];
+    for (int i = 0; i < kWalkWords; i++) wtab[i] = walk_table_word(tables, i);
     std::vector<uint32_t> stream;
     uint64_t before = 0;
     long long_groups = 0;
@@ -571,7 +579,7 @@ extern "C" long emu_scan_single_walk(const int16_t *y, const int16_t *cb, const 
             FlatPack<EmuLaneSink> p;
             p.sink = EmuLaneSink{scratch[l].data(), scratch_words};
             p.acc = 0; p.pending = 0; p.word = 0;
-            block_pack_flat(wds, prev, tables + (r.comp ? 1 : 0) * kClassSyms, p);
+            block_pack_flat(wds, prev, wtab + (r.comp ? 1 : 0) * kWalkClassWords, p);
             len[l] = p.word * 32u + p.pending;
             p.finish();
             my_bit[l] = group_bits;
@@ -615,7 +623,7 @@ extern "C" long emu_scan_single_walk(const int16_t *y, const int16_t *cb, const 
                     FlatPack<WinSink> p;
                     p.sink = WinSink{buf.data(), wn, window_words};
                     p.acc = 0; p.pending = (uint32_t)(rel & 31); p.word = (uint32_t)(rel >> 5);
-                    block_pack_flat(wds, r.index ? base[(r.index - 1) * 64] : 0, tables + (r.comp ? 1 : 0) * kClassSyms, p);
+                    block_pack_flat(wds, r.index ? base[(r.index - 1) * 64] : 0, wtab + (r.comp ? 1 : 0) * kWalkClassWords, p);
                     p.finish();
                 }
                 for (uint32_t i = 0; i < wn; i++) local[wbase + i] = buf[i];

@@ -46,7 +46,7 @@ def _check(px, w, h, ct, ss, q, optimize=False):
     y, cb, cr = O.coeffs(px, w, h, ct, ss, q)
     want = _scan_segment(O.encode_from_coeffs(y, cb, cr, O.make_options(w, h, ct, q, ss, optimize_huffman=optimize)))
     assert _emu_scan(y, cb, cr, w, h, ct, ss, optimize) == want
-    # the branch-free walkers of the single-pass kernels (block_length_flat / block_pack_flat)
+    # the branch-free walkers of the single-pass kernels (block_pack_flat)
     assert _emu_scan(y, cb, cr, w, h, ct, ss, optimize, flat=True) == want
 
 

@@ -108,7 +108,7 @@ struct Context {
         }
         template <class T> T *as() const { return static_cast<T *>(p); }
     };
-    Buf e_tables, e_hist, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out, e_seg_bytes, e_seg_off;
+    Buf e_tables, e_hist, e_count, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out, e_seg_bytes, e_seg_off;
     Buf e_code_state, e_stuff_state; // single-pass kernels (jpeg_scan_fused.hip): look-back descriptors, totals
     uint32_t tables_held[pixo_scan::kScanTableUpload]; bool tables_valid = false; hipStream_t tables_stream = nullptr; // what e_tables holds (no upload when unchanged)
     size_t code_state_zero_words = 0; // this many words of e_code_state are known to be zero (the stuffing kernel cleans up behind itself)
@@ -182,7 +182,7 @@ void Context::release()
     DeviceScope on(device);
     if (on.err != hipSuccess) return;
     if (stream) (void)hipStreamSynchronize(stream);
-    Buf *bufs[] = {&e_tables, &e_hist, &e_len, &e_off, &e_tmp, &e_totals, &e_stream, &e_tile_ff, &e_tile_base, &e_out, &e_seg_bytes,
+    Buf *bufs[] = {&e_tables, &e_hist, &e_count, &e_len, &e_off, &e_tmp, &e_totals, &e_stream, &e_tile_ff, &e_tile_base, &e_out, &e_seg_bytes,
                    &e_seg_off, &e_code_state, &e_stuff_state, &p_in, &p_out, &p_sums, &p_scratch, &t_raw, &t_trail, &g_flags, &g_rank, &g_by_rank};
     for (Buf *b : bufs) {
         if (b->p) (void)hipFree(b->p);
@@ -450,8 +450,8 @@ void split_counts(const uint64_t counts[pixo_host::kScanTableWords], uint64_t dc
 // count_block statistics of the pass (src/jpeg/mod.rs:826-860) gathered on the device: [class][12 DC + 256 AC].
 int scan_count(Context &c, ScanJob &j, hipStream_t stream, uint64_t counts[pixo_host::kScanTableWords])
 {
-    HIP_TRY(hipMemsetAsync(c.e_hist.p, 0, pixo_host::kScanTableWords * 8, stream));
-    if (j.n) HIP_TRY(pixo_dev::launch_scan_count(j.a, c.e_hist.as<unsigned long long>(), stream));
+    HIP_TRY(c.e_count.reserve(pixo_dev::scan_count_scratch_bytes()));
+    HIP_TRY(pixo_dev::launch_scan_count(j.a, c.e_count.as<uint32_t>(), c.e_hist.as<unsigned long long>(), stream));
     HIP_TRY(hipMemcpyAsync(counts, c.e_hist.p, pixo_host::kScanTableWords * 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return PIXO_OK;
@@ -923,8 +923,8 @@ int huffman_for_tuple(const int16_t *dy, const int16_t *dcb, const int16_t *dcr,
     a.restart = scan_has_restart_markers(o, g) ? o.restart_interval : 0;
     a.seed_dc[0] = a.seed_dc[1] = a.seed_dc[2] = 0; a.bit_base = 0; a.pad_last = 1;
     HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
-    HIP_TRY(hipMemsetAsync(c.e_hist.p, 0, pixo_host::kScanTableWords * 8, c.stream));
-    HIP_TRY(pd::launch_scan_count(a, c.e_hist.as<unsigned long long>(), c.stream));
+    HIP_TRY(c.e_count.reserve(pd::scan_count_scratch_bytes()));
+    HIP_TRY(pd::launch_scan_count(a, c.e_count.as<uint32_t>(), c.e_hist.as<unsigned long long>(), c.stream));
     uint64_t counts[pixo_host::kScanTableWords];
     HIP_TRY(hipMemcpyAsync(counts, c.e_hist.p, sizeof counts, hipMemcpyDeviceToHost, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));

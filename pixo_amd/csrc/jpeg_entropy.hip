@@ -27,22 +27,17 @@ using namespace pixo_scan;
 namespace {
 constexpr int kScanThreads = 256;
 
-enum { WHAT_LENGTH = 0, WHAT_PACK = 1, WHAT_COUNT = 2 };
+enum { WHAT_LENGTH = 0, WHAT_PACK = 1 }; // (symbol statistics: scan_count_kernel in jpeg_scan_fused.hip)
 
 // first block (scan order) of restart segment k
 __device__ __forceinline__ uint64_t segment_first(const ScanArgs &a, uint64_t k) { return k * a.restart * a.blocks_per_mcu; }
 
 template <int WHAT>
 __global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(const ScanArgs a, uint32_t *len, const uint64_t *off,
-                                                                  uint32_t *stream, unsigned long long *hist,
-                                                                  uint64_t total_bits, const uint64_t *seg_byte_off)
+                                                                  uint32_t *stream, uint64_t total_bits, const uint64_t *seg_byte_off)
 {
     __shared__ uint32_t tab[kTableWords];
-    __shared__ uint32_t lhist[WHAT == WHAT_COUNT ? kTableWords : 1];
-    for (int i = threadIdx.x; i < kTableWords; i += kScanThreads) {
-        if (WHAT != WHAT_COUNT) tab[i] = a.tables[i];
-        else lhist[i] = 0;
-    }
+    for (int i = threadIdx.x; i < kTableWords; i += kScanThreads) tab[i] = a.tables[i];
     __syncthreads();
     const uint64_t s = (uint64_t)blockIdx.x * kScanThreads + threadIdx.x;
     if (s < a.nblocks) {
@@ -71,7 +66,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(const ScanArg
             LengthVisitor v{tab + cls * kClassSyms, 0};
             walk_block(w, prev_dc, v);
             len[s] = v.bits;
-        } else if (WHAT == WHAT_PACK) {
+        } else {
             PackVisitor v;
             v.tab = tab + cls * kClassSyms;
             uint64_t pos = off[s] + a.bit_base, end_bits = total_bits + a.bit_base; // end of the stream / of this block's segment
@@ -91,15 +86,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(const ScanArg
                 const int n = (int)((8 - (end_bits & 7)) & 7);
                 if (n) v.or_word(end_bits >> 5, ((1u << n) - 1u) << (32 - (int)(end_bits & 31) - n));
             }
-        } else {
-            CountVisitor v{lhist + cls * kClassSyms};
-            walk_block(w, prev_dc, v);
         }
-    }
-    if (WHAT == WHAT_COUNT) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < kTableWords; i += kScanThreads)
-            if (lhist[i]) atomicAdd(&hist[i], (unsigned long long)lhist[i]);
     }
 }
 
@@ -372,17 +359,10 @@ inline unsigned grid_for(uint64_t n, uint64_t per_group) { return (unsigned)((n 
 size_t scan_tile_count(uint64_t n) { return (size_t)((n + kTileElems - 1) / kTileElems); }
 size_t stuff_tile_count(uint64_t nbytes) { return (size_t)((nbytes + kStuffTileBytes - 1) / kStuffTileBytes); }
 
-hipError_t launch_scan_count(const ScanArgs &a, unsigned long long *d_hist, hipStream_t s)
-{
-    hipLaunchKernelGGL((scan_blocks_kernel<WHAT_COUNT>), dim3(grid_for(a.nblocks, kScanThreads)), dim3(kScanThreads), 0, s, a,
-                       nullptr, nullptr, nullptr, d_hist, 0, nullptr);
-    return hipGetLastError();
-}
-
 hipError_t launch_scan_lengths(const ScanArgs &a, uint32_t *d_len, hipStream_t s)
 {
     hipLaunchKernelGGL((scan_blocks_kernel<WHAT_LENGTH>), dim3(grid_for(a.nblocks, kScanThreads)), dim3(kScanThreads), 0, s, a,
-                       d_len, nullptr, nullptr, nullptr, 0, nullptr);
+                       d_len, nullptr, nullptr, 0, nullptr);
     return hipGetLastError();
 }
 
@@ -390,7 +370,7 @@ hipError_t launch_scan_pack(const ScanArgs &a, const uint64_t *d_off, uint64_t t
                             uint32_t *d_stream, hipStream_t s)
 {
     hipLaunchKernelGGL((scan_blocks_kernel<WHAT_PACK>), dim3(grid_for(a.nblocks, kScanThreads)), dim3(kScanThreads), 0, s, a,
-                       nullptr, d_off, d_stream, nullptr, total_bits, seg ? seg->seg_byte_off : nullptr);
+                       nullptr, d_off, d_stream, total_bits, seg ? seg->seg_byte_off : nullptr);
     return hipGetLastError();
 }
 

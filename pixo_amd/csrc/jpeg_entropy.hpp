@@ -35,8 +35,10 @@ struct SegmentPlan {
 size_t scan_tile_count(uint64_t n);        // u64 scratch words launch_exclusive_scan needs for n elements
 size_t stuff_tile_count(uint64_t nbytes);  // 4 KiB tiles of the packed stream
 
-// d_hist: pixo_scan::kTableWords zero-initialised 64-bit counters ([class][12 DC + 256 AC])
-hipError_t launch_scan_count(const ScanArgs &a, unsigned long long *d_hist, hipStream_t s);
+// symbol statistics of a scan (restart intervals honoured; jpeg_scan_fused.hip).  d_hist: pixo_scan::kTableWords 64-bit
+// counters ([class][12 DC + 256 AC]), overwritten; d_scratch: scan_count_scratch_bytes() bytes.
+size_t scan_count_scratch_bytes();
+hipError_t launch_scan_count(const ScanArgs &a, uint32_t *d_scratch, unsigned long long *d_hist, hipStream_t s);
 hipError_t launch_scan_lengths(const ScanArgs &a, uint32_t *d_len, hipStream_t s);
 // d_out[i] = sum of d_in[0..i) (may be null: totals only); *d_total = sum of all
 hipError_t launch_exclusive_scan(const uint32_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *d_tile_tmp, uint64_t *d_total,

@@ -285,6 +285,42 @@ template <class Sink> PIXO_SDEV void block_pack_flat(const uint32_t *w, int prev
     p.put_left(run16 ? (eob & 0xFFFF0000u) : 0u, run16 ? (eob & 0xFFu) : 0u);
 }
 
+// Symbol statistics with the same walk (count_block, jpeg/mod.rs:826-860): `Bump` provides bump(slot, on, amount) —
+// add `amount` to the counter of the walk-table slot `slot` of the block's class when `on`.
+template <class Bump> PIXO_SDEV void block_count_flat(const uint32_t *w, int prev_dc, Bump &h)
+{
+    {
+        const int diff = (int)(int16_t)(coef_of(w, 0) - prev_dc);
+        const uint32_t s = scan_sign_bits(diff + (diff >> 31)), m = s < 32u ? s : 32u;
+        h.bump(m & 15u, true, 1u);
+    }
+    uint32_t run16 = 0;
+#pragma unroll
+    for (int k = 1; k < 64; k++) {
+        const int v = coef_of(w, zigzag(k));
+        const uint64_t nz_lanes = PIXO_BALLOT64(v != 0);
+        if (!nz_lanes) { run16 += 16u; continue; }
+        const bool nz = v != 0;
+        if (k > 16 && __builtin_expect((PIXO_BALLOT64(run16 >= 256u) & nz_lanes) != 0, 0)) {
+            h.bump((uint32_t)kWalkZrl, nz && run16 >= 256u, run16 >> 8);
+            run16 = nz ? (run16 & 255u) : run16;
+        }
+        const uint32_t s = scan_sign_bits(v + (v >> 31)), m = s < 32u ? s : 32u;
+        h.bump((uint32_t)kWalkDc + ((k > 16 ? (run16 & 255u) : run16) | (m & 15u)), nz, 1u);
+        run16 = nz ? 0u : run16 + 16u;
+    }
+    h.bump((uint32_t)kWalkEob, run16 != 0u, 1u);
+}
+// where the counter of walk-table slot `slot` (of one class) belongs among the class's kClassSyms symbols; -1: no symbol
+PIXO_SHOST int walk_slot_symbol(int slot)
+{
+    if (slot == kWalkEob) return kDcSyms;
+    if (slot == kWalkZrl) return kDcSyms + 0xF0;
+    const int c4 = slot & 15, cat = c4 ? 32 - (c4 | 16) : 0;
+    if (slot < kWalkDc) return cat < kDcSyms ? cat : -1;
+    return cat ? kDcSyms + ((((slot - kWalkDc) >> 4) << 4) | cat) : -1;
+}
+
 // ---- progressive scans (simple_progressive_script, progressive.rs:98-110) ------------------------
 // Seven single-component scans over the tuple, blocks in STORAGE order (jpeg/mod.rs:1286, :1350):
 //   0 DC Y   1 DC Cb   2 DC Cr   3 AC Y 1..10   4 AC Y 11..63   5 AC Cb 1..63   6 AC Cr 1..63

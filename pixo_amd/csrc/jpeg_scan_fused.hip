@@ -339,6 +339,86 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     }
 }
 
+// ---- count: symbol statistics for optimised tables (count_block, jpeg/mod.rs:826-860) with the flat walk ---------------
+// One lane per block like the code kernel; the counters live in LDS per workgroup (LDS atomics without return, a
+// private dummy counter per lane for "no symbol here").  Every workgroup then stores its counters as one row of a
+// slab in HBM and a second, tiny kernel adds the rows up: 2048 workgroups adding their 536 counters to the same 536
+// words with global atomics took longer than the walk itself (58 us for an image with hardly any symbols).
+// Restart intervals reset the predictors exactly as in the scan (jpeg/mod.rs:1441-1444).
+constexpr unsigned kCountWorkgroups = 2048; // rows of the slab (a larger scan: several groups per workgroup)
+constexpr int kCountRowsPerSum = 64; // rows one workgroup of the summing kernel adds up (16 per thread)
+struct LdsBump {
+    uint32_t *hist; // the class's kWalkClassWords counters
+    uint32_t dummy; // index of this lane's dummy counter, relative to hist
+    bool live;
+    __device__ __forceinline__ void bump(uint32_t slot, bool on, uint32_t amount)
+    {
+        (void)__hip_atomic_fetch_add(&hist[on && live ? slot : dummy], amount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kGroup) void scan_count_kernel(const ScanArgs a, uint32_t *slab, unsigned long long *hist)
+{
+    __shared__ uint32_t lhist[kWalkWords + kGroup];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < kWalkWords + kGroup; i += kGroup) lhist[i] = 0;
+    if (blockIdx.x == 0) // (the sums start from zero: cheaper here than a memset launch)
+        for (int i = lane; i < kTableWords; i += kGroup) hist[i] = 0;
+    __syncthreads();
+    const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
+    for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint64_t s = g * kGroup + lane;
+        const bool live = s < a.nblocks;
+        const BlockRef ref = block_of(MODE, live ? s : 0);
+        const int16_t *base = ref.comp == 0 ? a.y : (ref.comp == 1 ? a.cb : a.cr);
+        uint32_t w[32];
+        {
+            const v4u *p = reinterpret_cast<const v4u *>(base + ref.index * 64);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const v4u q = p[r];
+                w[4 * r] = q.x; w[4 * r + 1] = q.y; w[4 * r + 2] = q.z; w[4 * r + 3] = q.w;
+            }
+        }
+        int prev_dc = ref.index ? (int)base[(ref.index - 1) * 64] : (int)a.seed_dc[ref.comp];
+        if (a.restart) {
+            const uint64_t mcu = s / a.blocks_per_mcu;
+            const uint32_t k = (uint32_t)(s - mcu * a.blocks_per_mcu);
+            const bool first_of_comp = MODE == 2 ? (k == 0 || k >= 4) : true;
+            if (mcu % a.restart == 0 && first_of_comp) prev_dc = 0;
+        }
+        const uint32_t cls = ref.comp == 0 ? 0u : 1u;
+        LdsBump h{lhist + cls * kWalkClassWords, (uint32_t)(kWalkWords + lane) - cls * kWalkClassWords, live};
+        block_count_flat(w, prev_dc, h);
+    }
+    __syncthreads();
+    for (int i = lane; i < kWalkWords; i += kGroup) slab[(size_t)blockIdx.x * kWalkWords + i] = lhist[i];
+}
+
+// blockIdx.x: 64 columns of the slab, blockIdx.y: kCountRowsPerSum rows; thread = column x one of four row phases
+__global__ __launch_bounds__(256) void scan_count_sum_kernel(const uint32_t *slab, uint32_t rows, unsigned long long *hist)
+{
+    __shared__ uint32_t part[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), phase = threadIdx.x >> 6;
+    const uint32_t r0 = blockIdx.y * kCountRowsPerSum;
+    uint32_t n = 0;
+    if (col < kWalkWords) {
+#pragma unroll
+        for (int k = 0; k < kCountRowsPerSum / 4; k++) {
+            const uint32_t r = r0 + 4 * k + phase;
+            n += r < rows ? slab[(size_t)r * kWalkWords + col] : 0u;
+        }
+    }
+    part[phase][threadIdx.x & 63] = n;
+    __syncthreads();
+    if (phase == 0 && col < kWalkWords) {
+        const unsigned long long sum = (unsigned long long)part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        const int sym = walk_slot_symbol(col % kWalkClassWords);
+        if (sum && sym >= 0) atomicAdd(&hist[(col / kWalkClassWords) * kClassSyms + sym], sum);
+    }
+}
+
 // ---- stuff: 16 KiB tiles of the packed stream ----------------------------------------------------------------------
 constexpr int kStuffThreads = 256, kLaneWords = 16, kWaveBytes = 64 * kLaneWords * 4, kTileBytes = (kStuffThreads / 64) * kWaveBytes;
 constexpr uint32_t kStageBytes = 2 * kTileBytes + 16; // worst case: every byte 0xFF, + the output's alignment skew
@@ -506,6 +586,21 @@ hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool
     if (a.mode == 2) hipLaunchKernelGGL(scan_code_kernel<2>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals);
     else if (a.mode == 1) hipLaunchKernelGGL(scan_code_kernel<1>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals);
     else hipLaunchKernelGGL(scan_code_kernel<0>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals);
+    return hipGetLastError();
+}
+
+size_t scan_count_scratch_bytes() { return (size_t)kCountWorkgroups * kWalkWords * 4; }
+
+hipError_t launch_scan_count(const ScanArgs &a, uint32_t *d_scratch, unsigned long long *d_hist, hipStream_t s)
+{
+    const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
+    if (ngroups == 0) return hipMemsetAsync(d_hist, 0, kTableWords * 8, s);
+    const unsigned grid = ngroups < kCountWorkgroups ? (unsigned)ngroups : kCountWorkgroups;
+    if (a.mode == 2) hipLaunchKernelGGL(scan_count_kernel<2>, dim3(grid), dim3(kGroup), 0, s, a, d_scratch, d_hist);
+    else if (a.mode == 1) hipLaunchKernelGGL(scan_count_kernel<1>, dim3(grid), dim3(kGroup), 0, s, a, d_scratch, d_hist);
+    else hipLaunchKernelGGL(scan_count_kernel<0>, dim3(grid), dim3(kGroup), 0, s, a, d_scratch, d_hist);
+    hipLaunchKernelGGL(scan_count_sum_kernel, dim3((kWalkWords + 63) / 64, (grid + kCountRowsPerSum - 1) / kCountRowsPerSum), dim3(256), 0, s, d_scratch, grid,
+                       d_hist);
     return hipGetLastError();
 }
 

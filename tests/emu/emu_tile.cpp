@@ -205,6 +205,40 @@ extern "C" void emu_scan_tables(const int16_t *y, const int16_t *cb, const int16
     pixo_host::pack_scan_tables(hs, out);
 }
 
+// Symbol statistics: the reference-shaped walk with CountVisitor against the flat walk of scan_count_kernel
+// (block_count_flat into walk-table slots, mapped back with walk_slot_symbol).  Returns the number of counters that
+// differ (0 = same histograms); out (536 words, may be null) receives the flat walk's histogram.
+extern "C" long emu_count_compare(const int16_t *y, const int16_t *cb, const int16_t *cr, int mode, uint64_t nblocks, uint32_t *out)
+{
+    using namespace pixo_scan;
+    std::vector<uint32_t> want(kTableWords, 0), slots(kWalkWords + 1, 0), got(kTableWords, 0);
+    struct EmuBump {
+        uint32_t *hist;
+        void bump(uint32_t slot, bool on, uint32_t amount) { if (on) hist[slot] += amount; }
+    };
+    for (uint64_t s = 0; s < nblocks; s++) {
+        const BlockRef r = block_of(mode, s);
+        const int16_t *base = r.comp == 0 ? y : (r.comp == 1 ? cb : cr);
+        uint32_t wds[32];
+        memcpy(wds, base + r.index * 64, 128);
+        const int prev = r.index ? base[(r.index - 1) * 64] : 0, cls = r.comp ? 1 : 0;
+        CountVisitor v{want.data() + cls * kClassSyms};
+        walk_block(wds, prev, v);
+        EmuBump h{slots.data() + cls * kWalkClassWords};
+        block_count_flat(wds, prev, h);
+    }
+    long lost = 0;
+    for (int i = 0; i < kWalkWords; i++) {
+        const int sym = walk_slot_symbol(i % kWalkClassWords);
+        if (sym >= 0) got[(i / kWalkClassWords) * kClassSyms + sym] += slots[i];
+        else lost += slots[i]; // a count in a slot that stands for no symbol
+    }
+    long bad = lost;
+    for (int i = 0; i < kTableWords; i++) bad += want[i] != got[i];
+    if (out) memcpy(out, got.data(), kTableWords * 4);
+    return bad;
+}
+
 // The branch-free walkers of the single-pass kernels (block_pack_flat, jpeg_scan_fused.hip) in
 // the same harness: lengths, prefix sum, packing in reverse block order into a zeroed stream, padding, stuffing.
 struct EmuOrSink {

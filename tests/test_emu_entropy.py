@@ -75,6 +75,33 @@ def test_optimised_tables_from_device_histogram_visitor():
     _check(synth.noise_gray(50, 50, 3), 50, 50, 0, 0, 85, optimize=True)
 
 
+def test_flat_count_walk_gives_the_visitor_histogram():
+    """scan_count_kernel's walk (block_count_flat: walk-table slots, ZRL counted run/16 at a time) against the
+    reference-shaped walk with CountVisitor: same 536 counters, nothing counted in a slot that stands for no symbol."""
+    L = E.lib()
+    L.emu_count_compare.restype = C.c_long
+    L.emu_count_compare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
+    cases = [(synth.noise(200, 120, 3), 200, 120, 2, 1, 80), (synth.flat_blocks(48, 48), 48, 48, 2, 1, 100),
+             (synth.gradient_rgb(333, 64), 333, 64, 2, 0, 90), (synth.noise_gray(100, 90, 1), 100, 90, 0, 0, 50),
+             (synth.extremes(64, 64, 2), 64, 64, 2, 1, 100), (synth.noise(64, 64, 8), 64, 64, 2, 0, 1),
+             (synth.checkerboard(64, 64, 3), 64, 64, 2, 0, 100), (synth.constant(33, 17, 128), 33, 17, 2, 1, 50)]
+    for px, w, h, ct, ss, q in cases:
+        y, cb, cr = O.coeffs(px, w, h, ct, ss, q)
+        mode = 0 if ct == 0 else (2 if ss == 1 else 1)
+        n = y.shape[0] + cb.shape[0] + cr.shape[0]
+        hist = np.zeros(536, np.uint32)
+        assert L.emu_count_compare(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, mode, n, hist.ctypes.data) == 0, (w, h, ct, ss, q)
+        assert hist.sum() > n  # at least DC + one more symbol per block on average
+    # a hand-made block: one coefficient after 62 zeros (three ZRLs), and a DC difference of the largest category
+    y = np.zeros((2, 64), np.int16); y[0, 63] = -5; y[1, 0] = 2047; y[1, 17] = 1
+    z = np.zeros((0, 64), np.int16)
+    hist = np.zeros(536, np.uint32)
+    assert L.emu_count_compare(y.ctypes.data, z.ctypes.data, z.ctypes.data, 0, 2, hist.ctypes.data) == 0
+    # (natural index 17 is position 8 of the zig-zag scan: a run of 7)
+    assert hist[12 + 0xF0] == 3 and hist[12 + 0xE3] == 1 and hist[12 + 0x71] == 1 and hist[12] == 1 and hist[11] == 1 and hist[0] == 1
+    assert hist.sum() == 8
+
+
 def test_ff_bytes_are_stuffed_and_last_byte_padded_with_ones():
     # noise at q=100 produces plenty of 0xFF bytes in the packed stream
     px = synth.noise(64, 64, 4)

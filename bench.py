@@ -452,7 +452,7 @@ def whole_file(job, wl):
     torch, jpeg = job.torch, wl.jpeg
     opts = jpeg.JpegOptions.builder(wl.w, wl.h).quality(wl.q).subsampling(jpeg.Subsampling(wl.ss)).build()
     try:
-        pinned = torch.empty(wl.in_bytes // 2 + 4096, dtype=torch.uint8).pin_memory()
+        pinned = torch.empty(wl.in_bytes // 2 + (1 << 16), dtype=torch.uint8).pin_memory()  # (64 B per block + 10 KB or more: the library may write it piece by piece)
         nbytes = jpeg.encode_device_into(pinned, wl.ins[0], opts)
         n_files, ts, tb = 15, [], []
         for i in range(n_files):

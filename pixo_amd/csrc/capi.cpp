@@ -110,13 +110,17 @@ struct Context {
     };
     Buf e_tables, e_hist, e_count, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out, e_seg_bytes, e_seg_off;
     Buf e_code_state, e_stuff_state; // single-pass kernels (jpeg_scan_fused.hip): look-back descriptors, totals
+    Buf e_chain;                     // a scan coded in pieces: bits / bytes of the scan before every piece (device_entropy_pieces)
+    hipStream_t copy_stream = nullptr; // ... whose bytes travel to the host on this stream while the next piece is coded
+    std::vector<hipEvent_t> piece_done;
     uint32_t tables_held[pixo_scan::kScanTableUpload]; bool tables_valid = false; hipStream_t tables_stream = nullptr; // what e_tables holds (no upload when unchanged)
     size_t code_state_zero_words = 0; // this many words of e_code_state are known to be zero (the stuffing kernel cleans up behind itself)
     Buf p_in, p_out, p_sums, p_scratch; // PNG filter stage
     Buf t_raw, t_trail;                 // progressive + trellis: unquantised DCT blocks (f32), Viterbi back-pointers
     Buf g_flags, g_rank, g_by_rank;     // progressive scans: band flags, rank among non-empty blocks and its inverse
     unsigned long long *h_sums = nullptr; size_t hsums_cap = 0; // pinned
-    uint64_t *h_totals = nullptr; // pinned, 8 words
+    uint64_t *h_totals = nullptr; // pinned, kTotalsWords words: the kernels' mailbox (4 words per piece of a scan)
+    static constexpr size_t kTotalsWords = 4 * 32;
     uint8_t *h_file = nullptr; size_t hfile_cap = 0; // pinned: the finished file lands here
     int reserve_hfile(size_t n)
     {
@@ -183,7 +187,7 @@ void Context::release()
     if (on.err != hipSuccess) return;
     if (stream) (void)hipStreamSynchronize(stream);
     Buf *bufs[] = {&e_tables, &e_hist, &e_count, &e_len, &e_off, &e_tmp, &e_totals, &e_stream, &e_tile_ff, &e_tile_base, &e_out, &e_seg_bytes,
-                   &e_seg_off, &e_code_state, &e_stuff_state, &p_in, &p_out, &p_sums, &p_scratch, &t_raw, &t_trail, &g_flags, &g_rank, &g_by_rank};
+                   &e_seg_off, &e_code_state, &e_stuff_state, &e_chain, &p_in, &p_out, &p_sums, &p_scratch, &t_raw, &t_trail, &g_flags, &g_rank, &g_by_rank};
     for (Buf *b : bufs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr; b->cap = 0;
@@ -195,6 +199,10 @@ void Context::release()
     if (h_totals) (void)hipHostFree(h_totals);
     if (h_file) (void)hipHostFree(h_file);
     if (stream) (void)hipStreamDestroy(stream);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    copy_stream = nullptr;
+    for (hipEvent_t e : piece_done) (void)hipEventDestroy(e);
+    piece_done.clear();
     if (producer_done) (void)hipEventDestroy(producer_done);
     producer_done = nullptr;
     code_state_zero_words = 0;
@@ -350,6 +358,7 @@ struct ScanJob {
     uint64_t nbytes = 0;     // bytes of the packed stream that get stuffed (a band: its whole bytes only)
     uint64_t scan_bytes = 0; // ... after stuffing, in c.e_out
     bool band = false;
+    bool tables_ready = false; // j.h is built and on the device (scan_tables)
     int head_bits = 0;       // band: how many of its first bits share a byte with the band before
     bool fused = false;      // one uninterrupted scan: the two single-pass kernels of jpeg_scan_fused.hip
     size_t stream_cap = 0;   // fused: bytes the packed stream can take at most
@@ -422,7 +431,7 @@ int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, co
         if (pd::fused_code_state_words(j.n) * 8 > c.e_code_state.cap) c.code_state_zero_words = 0; // (a new buffer)
         HIP_TRY(c.e_code_state.reserve(pd::fused_code_state_words(j.n) * 8));
         HIP_TRY(c.e_stuff_state.reserve(pd::fused_stuff_state_words(j.stream_cap) * 8));
-        if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 64, hipHostMallocDefault));
+        if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), Context::kTotalsWords * 8, hipHostMallocDefault));
         a.tables = c.e_tables.as<uint32_t>();
         return PIXO_OK;
     }
@@ -434,7 +443,7 @@ int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, co
     j.tmp_tiles = pd::scan_tile_count(pd::stuff_tile_count(j.n * 209 + 3 * j.nseg + 8)) + 1;
     HIP_TRY(c.e_tmp.reserve((j.tmp_blocks + j.tmp_segs + j.tmp_tiles) * 8));
     HIP_TRY(c.e_totals.reserve(16));
-    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 64, hipHostMallocDefault));
+    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), Context::kTotalsWords * 8, hipHostMallocDefault));
     a.tables = c.e_tables.as<uint32_t>();
     return PIXO_OK;
 }
@@ -459,10 +468,10 @@ int scan_count(Context &c, ScanJob &j, hipStream_t stream, uint64_t counts[pixo_
 
 // Tables (standard; optimised from `counts`, or from this pass's own statistics when counts == null),
 // block bit lengths and their prefix sum: afterwards j.total_bits is known (one read-back).
-int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
-                 const uint64_t *counts, bool wait = true)
+int scan_tables(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
+                const uint64_t *counts)
 {
-    namespace pd = pixo_dev;
+    if (j.tables_ready) return PIXO_OK;
     if (o.optimize_huffman) { // table construction on the host, exactly like optimized_from_counts
         uint64_t own[pixo_host::kScanTableWords];
         if (!counts) {
@@ -478,8 +487,19 @@ int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_
     }
     uint32_t packed[pixo_host::kScanTableWords];
     pixo_host::pack_scan_tables(j.h, packed);
-    int rc_tables;
-    if ((rc_tables = upload_scan_tables(c, packed, stream))) return rc_tables;
+    const int rc = upload_scan_tables(c, packed, stream);
+    j.tables_ready = rc == PIXO_OK;
+    return rc;
+}
+
+int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
+                 const uint64_t *counts, bool wait = true)
+{
+    namespace pd = pixo_dev;
+    {
+        const int rc = scan_tables(c, j, o, g, stream, counts);
+        if (rc) return rc;
+    }
     if (j.fused) { // lengths, prefix and packing in one pass; the stream starts at bit 0 whatever the band's offset will be
         const bool zero = c.code_state_zero_words >= pd::fused_code_state_words(j.n);
         c.code_state_zero_words = 0; // (dirty from here until a stuffing launch has cleaned it)
@@ -654,6 +674,101 @@ int scan_pack(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offs
     return PIXO_OK;
 }
 
+// One uninterrupted scan of a large image, coded in PIECES so that the file's way to the host (0.21 of the 0.31 ms of a
+// 4096x4096 noise image, 3.3 of 4.4 ms for 16384x16384) overlaps the coding: piece k = a run of consecutive groups,
+// coded and stuffed by its own launch pair; the pieces hand each other the bit position and the byte position on the
+// device (pixo_dev::ScanPiece), the host only waits for piece k's event to learn how many bytes it may copy — on a second
+// stream — while piece k + 1 is being coded.  The bytes are the same as from one launch pair; a piece whose stream
+// outgrows the guess its stuffing grid was sized for, or an output buffer that proves too small, sends the caller back
+// to the one-piece path (return value 1; nothing of the result is kept).
+bool pieces_enabled()
+{ // PIXO_HIP_ONE_PIECE=1: always the one-piece path (A/B)
+    static const bool on = [] { const char *e = std::getenv("PIXO_HIP_ONE_PIECE"); return !(e && *e && *e != '0'); }();
+    return on;
+}
+constexpr uint32_t kMaxPieces = 16;
+uint64_t piece_min_groups()
+{ // a piece is at least this many groups of 192 blocks, and a scan of fewer than two such pieces is coded in one.
+  // 2048 groups = the scan of a 4096x4096 4:2:0 image: the kernels of a smaller piece are mostly start-up — a sixth of
+  // that scan takes 28 us where the whole takes 52 — and a 4096x4096 image in 2 or 6 pieces is no faster than in one
+  // (0.30-0.33 against 0.31 ms); a 16384x16384 scan in 16 such pieces hides its 1 ms of coding behind 3.4 ms of PCIe.
+  // (PIXO_HIP_PIECE_GROUPS=n: tests cut small images into many pieces to meet every alignment of the seams)
+    static const uint64_t n = [] {
+        const char *e = std::getenv("PIXO_HIP_PIECE_GROUPS");
+        const long v = e ? std::atol(e) : 0;
+        return static_cast<uint64_t>(v > 0 ? v : 2048);
+    }();
+    return n;
+}
+
+int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *dst, size_t dst_cap, uint64_t *scan_bytes)
+{ // dst: where the stuffed scan goes on the host (dst_cap bytes available); tables are uploaded, j.a is set up
+    namespace pd = pixo_dev;
+    const uint64_t kGroupBlocks = 192, groups = (j.n + kGroupBlocks - 1) / kGroupBlocks;
+    const uint64_t groups_per_piece = (groups + kMaxPieces - 1) / kMaxPieces > piece_min_groups() ? (groups + kMaxPieces - 1) / kMaxPieces
+                                                                                                 : piece_min_groups();
+    const uint32_t pieces = static_cast<uint32_t>((groups + groups_per_piece - 1) / groups_per_piece); // (none is empty)
+    if (!c.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+    while (c.piece_done.size() < pieces) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c.piece_done.push_back(e);
+    }
+    HIP_TRY(c.e_chain.reserve(2 * (kMaxPieces + 1) * 8));
+    unsigned long long *bits_chain = c.e_chain.as<unsigned long long>(), *out_chain = bits_chain + kMaxPieces + 1;
+    const size_t out_cap = std::max<size_t>(j.stream_cap / 4, 4096);
+    HIP_TRY(c.e_out.reserve(out_cap));
+    // every piece has its own part of the stream buffer (a block has at most 209 bytes; 64 bytes of slack per piece)
+    struct Piece { uint64_t first_block, blocks, tiles; uint32_t *stream; };
+    Piece pc[kMaxPieces];
+    for (uint32_t k = 0; k < pieces; ++k) {
+        pc[k].first_block = std::min<uint64_t>(j.n, k * groups_per_piece * kGroupBlocks);
+        pc[k].blocks = std::min<uint64_t>(j.n, (k + 1) * groups_per_piece * kGroupBlocks) - pc[k].first_block;
+        pc[k].tiles = pd::stuff_tiles(pc[k].blocks * 64 + 4096);
+    }
+    HIP_TRY(c.e_stream.reserve(j.stream_cap + 80 * kMaxPieces));
+    for (uint32_t k = 0; k < pieces; ++k) pc[k].stream = c.e_stream.as<uint32_t>() + (pc[k].first_block * 209 + 64 * k + 15) / 16 * 4;
+    const size_t state_words = pd::fused_code_state_words(j.n);
+    Stopwatch sw;
+    for (uint32_t k = 0; k < pieces; ++k) {
+        pd::ScanArgs a = j.a;
+        a.nblocks = pc[k].blocks;
+        a.pad_last = k + 1 == pieces ? 1u : 0u;
+        const pd::ScanPiece piece{pc[k].first_block, k, bits_chain, k ? pc[k - 1].stream : nullptr};
+        unsigned long long *mail = reinterpret_cast<unsigned long long *>(c.h_totals) + 4 * k;
+        const bool zero = c.code_state_zero_words >= state_words;
+        c.code_state_zero_words = 0;
+        HIP_TRY(pd::launch_scan_code(a, c.e_code_state.as<unsigned long long>(), zero, pc[k].stream, c.e_stuff_state.as<unsigned long long>(),
+                                     pd::fused_stuff_state_words(j.stream_cap), mail, stream, &piece));
+        HIP_TRY(pd::launch_stuff_fused(pc[k].stream, c.e_code_state.as<unsigned long long>(), state_words, 0, /*band=*/k + 1 != pieces,
+                                       j.stream_cap, 0, pc[k].tiles, c.e_stuff_state.as<unsigned long long>(), /*state_is_zero=*/true,
+                                       c.e_out.as<uint8_t>(), c.e_out.cap, mail, stream, out_chain, k));
+        c.code_state_zero_words = state_words;
+        HIP_TRY(hipEventRecord(c.piece_done[k], stream));
+    }
+    uint64_t done = 0; // bytes of the scan that are on their way to the host
+    bool redo = false;
+    sw.lap("  pieces enqueued");
+    for (uint32_t k = 0; k < pieces; ++k) {
+        HIP_TRY(hipEventSynchronize(c.piece_done[k]));
+        sw.lap("  piece coded");
+        if (redo) continue; // (still wait for everything that was enqueued)
+        const uint64_t *mail = c.h_totals + 4 * k;
+        const uint64_t stream_bits = mail[0], packed = k + 1 != pieces ? stream_bits / 8 : (stream_bits + 7) / 8;
+        if (pd::stuff_tiles(packed) > pc[k].tiles) { redo = true; continue; } // (the stuffing grid was a guess: this piece is not complete)
+        const uint64_t bytes = mail[1];
+        if (done + bytes > c.e_out.cap || done + bytes > dst_cap) { redo = true; continue; }
+        if (bytes) HIP_TRY(hipMemcpyAsync(dst + done, c.e_out.as<uint8_t>() + done, bytes, hipMemcpyDeviceToHost, c.copy_stream));
+        done += bytes;
+        sw.lap("  copy enqueued");
+    }
+    HIP_TRY(hipStreamSynchronize(c.copy_stream));
+    sw.lap("  copies done");
+    if (redo) return 1;
+    *scan_bytes = done;
+    return PIXO_OK;
+}
+
 // Device coefficient tuple -> whole file in the context's PINNED host buffer (headers written by
 // the host, entropy-coded segment by the kernels of jpeg_entropy.hip and copied straight behind
 // them).  Pinned on purpose: a device-to-host copy into fresh pageable memory makes the runtime
@@ -675,6 +790,36 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
     if (rc) return rc;
     sw.lap("  reserve");
     std::vector<uint8_t> head;
+    // a large scan: in pieces, the file leaving for the host while the rest is still being coded — into the context's
+    // pinned buffer, or into the caller's storage if that can hold any file the stuffing grids are sized for (a smaller
+    // one might not fit the file, and then nothing may have been written to it: one piece, size first)
+    const size_t likely_most = 1024 + static_cast<size_t>(j.n) * 64 + 8192;
+    if (j.fused && batch == 1 && pieces_enabled() && !direct_host_stores() && (j.n + 191) / 192 >= 2 * piece_min_groups() &&
+        (!dest || dest_cap >= likely_most)) {
+        if ((rc = scan_tables(c, j, o, g, stream, nullptr))) return rc;
+        pixo_host::file_headers(head, o, j.h);
+        const size_t hdr = head.size();
+        uint8_t *buf = dest;
+        if (!buf) {
+            if ((rc = c.reserve_hfile(likely_most))) return rc;
+            buf = c.h_file;
+        }
+        const size_t room = (dest ? dest_cap : c.hfile_cap) - hdr - 2;
+        uint64_t scan_bytes = 0;
+        rc = device_entropy_pieces(c, j, stream, buf + hdr, room, &scan_bytes);
+        sw.lap("code+stuff+copy (pieces)");
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            std::memcpy(buf, head.data(), hdr);
+            buf[hdr + scan_bytes] = 0xFF; // EOI
+            buf[hdr + scan_bytes + 1] = 0xD9;
+            *file = buf;
+            *file_len = hdr + scan_bytes + 2;
+            if (header_len) *header_len = hdr;
+            return PIXO_OK;
+        }
+        c.code_state_zero_words = 0; // (rc == 1: start over in one piece, below)
+    }
     if (j.fused) { // code + stuff back to back, one read-back
         if ((rc = scan_lengths(c, j, o, g, stream, nullptr, /*wait=*/false))) return rc;
         // One image into host memory the GPU can write — the context's pinned file buffer, or storage of the caller's
@@ -839,7 +984,7 @@ int device_progressive_scans(const int16_t *dy, const int16_t *dcb, const int16_
     const size_t tmp_tiles = pd::scan_tile_count(pd::stuff_tile_count(n * 212 + 64)) + 1;
     HIP_TRY(c.e_tmp.reserve((tmp_blocks + tmp_segs + tmp_tiles) * 8));
     HIP_TRY(c.e_totals.reserve(32));
-    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 64, hipHostMallocDefault));
+    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), Context::kTotalsWords * 8, hipHostMallocDefault));
     a.tables = c.e_tables.as<uint32_t>();
     a.flags = c.g_flags.as<uint32_t>();
     a.nonempty = c.e_len.as<uint32_t>(); // only the input of the rank prefix sum: the lengths reuse it
@@ -1666,7 +1811,7 @@ int pixo_hip_band_encoder_coeffs(pixo_hip_band_encoder *e, const void *band_pixe
     }
     if ((rc = coeffs_on_device(c, d_px, e->band, e->g, c.stream, &e->dy, &e->dcb, &e->dcr))) return rc;
     // the DCs the next band predicts from: first coefficient of the last block of every plane
-    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), 64, hipHostMallocDefault));
+    if (!c.h_totals) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_totals), Context::kTotalsWords * 8, hipHostMallocDefault));
     int16_t *h = reinterpret_cast<int16_t *>(c.h_totals);
     HIP_TRY(hipMemcpyAsync(h, e->dy + (e->g.y_blocks - 1) * 64, 2, hipMemcpyDeviceToHost, c.stream));
     if (e->g.c_blocks) {

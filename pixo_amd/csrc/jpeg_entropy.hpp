@@ -67,11 +67,24 @@ hipError_t launch_stuff(const uint32_t *d_stream, uint64_t nbytes, const uint64_
 // a.pad_last as above).  d_state: fused_code_state_words(nblocks) u64 (zeroed by the launcher); afterwards d_state[1] =
 // the scan's length in bits.  d_stream: room for nblocks * 209 + 64 bytes (a block has at most 1665 bits).
 size_t fused_code_state_words(uint64_t nblocks);
+// A scan coded in PIECES — runs of consecutive blocks, one launch pair (code, stuff) each, so that the first pieces' bytes
+// can travel to the host while the later ones are coded.  Piece k codes blocks [first_block, first_block + a.nblocks)
+// of the tuple `a` describes; chain[k] = bits of the scan before piece k (the code kernel of piece k reads chain[k] and
+// chain[k - 1], k > 0, and writes chain[k + 1]); its stream starts with the chain[k] % 8 last bits of the piece before
+// (taken from prev_stream), i.e. it is byte-aligned with the scan: stuffed with shift 0, `band` = true for every piece but
+// the last (whole bytes only; the leftover bits lead the next piece), a.pad_last = 1 only for the last.
+struct ScanPiece {
+    uint64_t first_block;
+    uint32_t index;            // k
+    unsigned long long *chain; // device, pieces + 1 words (null: not a chain)
+    const uint32_t *prev_stream;
+};
 // state_is_zero: the caller knows d_state holds zeros (word 1 aside) — the stuffing kernel of the previous scan left it so —
 // and no memset is launched.  d_clear / clear_words: words this kernel zeroes on the side (the state of the stuffing launch
 // that follows), or null.  host_totals: pinned host memory (or null): [0] also receives the scan's length — no read-back copy.
 hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool state_is_zero, uint32_t *d_stream,
-                            unsigned long long *d_clear, size_t clear_words, unsigned long long *host_totals, hipStream_t s);
+                            unsigned long long *d_clear, size_t clear_words, unsigned long long *host_totals, hipStream_t s,
+                            const ScanPiece *piece = nullptr);
 // stuff: the stream's bytes from bit `shift` (< 8) on -> d_out with 0x00 behind every 0xFF.  band = false: all bytes of a
 // whole scan (shift 0); band = true: only the whole bytes behind the band's first `shift` bits.  Reads the scan's length
 // from d_code_state[1] (no host round trip) and zeroes the rest of d_code_state (code_state_words) for the next scan.
@@ -85,7 +98,10 @@ size_t fused_stuff_state_words(uint64_t max_stream_bytes);
 uint64_t stuff_tiles(uint64_t stream_bytes);
 hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_code_state, size_t code_state_words, uint32_t shift, bool band,
                               uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state,
-                              bool state_is_zero, uint8_t *d_out, uint64_t out_cap, unsigned long long *host_totals, hipStream_t s);
+                              bool state_is_zero, uint8_t *d_out, uint64_t out_cap, unsigned long long *host_totals, hipStream_t s,
+                              unsigned long long *d_out_chain = nullptr, uint32_t piece = 0);
+// (d_out_chain, piece: the piece's bytes go to d_out + d_out_chain[piece] (piece 0: d_out); d_out_chain[piece + 1] receives
+// where they end; d_state[1] / host_totals[1] count this piece's bytes only)
 
 // ---- progressive scans on the device (simple_progressive_script: seven single-component scans) ------
 struct ProgArgs {

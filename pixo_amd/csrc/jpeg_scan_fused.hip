@@ -152,7 +152,7 @@ struct LdsSink {
 template <int MODE>
 __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) void scan_code_kernel
 (const ScanArgs a, unsigned long long *state, uint32_t *stream, unsigned long long *clear, uint32_t clear_words,
- unsigned long long *host_totals)
+ unsigned long long *host_totals, const ScanPiece piece)
 {
     // state: [0] unused, [1] total bits (out), [2 ..] per group: descriptor, then per group: tail
     __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
@@ -165,6 +165,11 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     if (lane == 0) s_carry = 0;
     const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
     unsigned long long *desc = state + 2, *tails = state + 2 + ngroups;
+    // A scan coded piece by piece (ScanPiece, jpeg_entropy.hpp): the piece's stream is byte-aligned with the SCAN — its
+    // first `lead` bits are the end of the piece before — so that the stuffing kernel can work on it without a shift.
+    const uint64_t bits_before_piece = piece.index ? piece.chain[piece.index] : 0ull;
+    const uint32_t lead = (uint32_t)(bits_before_piece & 7);
+    if (piece.chain && piece.index == 0 && blockIdx.x == 0 && lane == 0) piece.chain[0] = 0; // (read by piece 1)
     for (int i = lane; i < kWalkWords; i += kGroup) tab[i] = a.tables[kTableWords + i]; // (the walk's form lies behind the packed one)
     // (housekeeping for the kernel that follows: its descriptors must be zero when it starts — cheaper here than a memset launch)
     for (uint64_t i = (uint64_t)blockIdx.x * kGroup + lane; i < clear_words; i += (uint64_t)gridDim.x * kGroup) clear[i] = 0;
@@ -175,8 +180,8 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         // eight loads touch one after the other: cached loads (the line stays in L1 for the other seven), not
         // non-temporal ones.  (Staging the group through LDS for perfectly coalesced loads cost 24 KiB per group and 60
         // more VGPRs for the addresses: half the occupancy.)
-        const uint64_t s = g * kGroup + lane;
-        const bool live = s < a.nblocks;
+        const uint64_t s = piece.first_block + g * kGroup + lane;
+        const bool live = g * kGroup + lane < a.nblocks;
         uint32_t w[32];
         {
             const BlockRef ref = block_of(MODE, live ? s : 0);
@@ -273,14 +278,15 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                     if (lane == 0) {
                         s_before = sum;
                         if (g) store_relaxed(&desc[g], kFlagPrefix | (sum + group_bits));
-                        if (last_group) { // the scan's length in bits (unpadded)
-                            state[1] = sum + group_bits;
-                            if (host_totals) host_totals[0] = sum + group_bits;
+                        if (last_group) { // the stream's length in bits (unpadded; a later piece: with its leading bits)
+                            state[1] = lead + sum + group_bits;
+                            if (host_totals) host_totals[0] = lead + sum + group_bits;
+                            if (piece.chain) piece.chain[piece.index + 1] = bits_before_piece + sum + group_bits;
                         }
                     }
                 }
                 __syncthreads();
-                const uint64_t start = s_before;
+                const uint64_t start = lead + s_before;
                 uint64_t end = start + group_bits;
                 if (last_group && a.pad_last) { // BitWriterMsb::flush pads the last byte with 1-bits
                     const uint32_t n = (uint32_t)((8 - (end & 7)) & 7);
@@ -331,6 +337,12 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                 unsigned long long t = load_relaxed(&tails[g - 1]);
                 while (!(t & kTailValid)) { __builtin_amdgcn_s_sleep(1); t = load_relaxed(&tails[g - 1]); }
                 inherited = (uint32_t)t;
+            } else if (piece.index) { // the `lead` bits of the byte shared with the piece before: the last, partial byte of its stream
+                const uint64_t before_prev = piece.chain[piece.index - 1];
+                const uint64_t prev_bits = (before_prev & 7) + (bits_before_piece - before_prev);
+                const uint64_t at = prev_bits >> 3; // (byte index in the previous stream)
+                const uint32_t byte = (piece.prev_stream[at >> 2] >> (24 - 8 * (uint32_t)(at & 3))) & 0xFFu;
+                inherited = (byte & (0xFF00u >> lead) & 0xFFu) << 24;
             }
             const uint32_t merged = inherited | head_word;
             if (tail_partial && out_words == 1) store_relaxed(&tails[g], kTailValid | merged); // (pass-through: a handful of bits inside one word)
@@ -431,7 +443,8 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
                                                                    uint32_t shift, uint32_t band, unsigned long long *state,
                                                                    uint8_t *out, uint32_t out_skew, uint64_t out_cap, uint64_t tile_offset,
                                                                    unsigned long long *clear, uint32_t clear_words,
-                                                                   unsigned long long *host_totals)
+                                                                   unsigned long long *host_totals, unsigned long long *out_chain,
+                                                                   uint32_t piece)
 {
     // The bytes to stuff are the stream's bits from bit `shift` (< 8) on: 0 for a whole image (all bytes, the padded
     // last one included); for a band that starts inside a byte of the scan, its first `shift` bits belong to the byte
@@ -447,6 +460,8 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
     // (housekeeping for the NEXT scan_code launch: its descriptors — everything but word 1, the length — back to zero)
     for (uint64_t i = (uint64_t)blockIdx.x * kStuffThreads + lane; i < clear_words; i += (uint64_t)gridDim.x * kStuffThreads)
         if (i != 1) clear[i] = 0;
+    // (a scan stuffed piece by piece: this piece's bytes go behind those of the pieces before, out_chain[piece])
+    const uint64_t out_before = out_chain && piece ? out_chain[piece] : 0ull;
     const uint64_t nbytes = band ? (total_bits - (shift < total_bits ? shift : total_bits)) / 8 : (total_bits + 7) / 8;
     const uint64_t ntiles = (nbytes + kTileBytes - 1) / kTileBytes;
     unsigned long long *desc = state + 3;
@@ -454,6 +469,7 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
         if (blockIdx.x == 0 && lane == 0 && tile_offset == 0) {
             state[1] = 0; state[2] = 0;
             if (host_totals) { host_totals[1] = 0; host_totals[2] = 0; }
+            if (out_chain) out_chain[piece + 1] = out_before;
         }
         return;
     }
@@ -520,11 +536,12 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
         __syncthreads();
         const uint64_t ff_before = s_before;
         const uint64_t tile_in = nbytes - t * kTileBytes < (uint64_t)kTileBytes ? nbytes - t * kTileBytes : (uint64_t)kTileBytes;
-        const uint64_t dst0 = out_skew + t * kTileBytes + ff_before; // where the tile's first output byte goes
+        const uint64_t dst0 = out_skew + out_before + t * kTileBytes + ff_before; // where the tile's first output byte goes
         const uint32_t tile_out = (uint32_t)tile_in + tile_ff; // bytes the tile produces
-        if (t + 1 == ntiles && lane == 0) {
-            state[1] = dst0 + tile_out - out_skew; state[2] = nbytes;
-            if (host_totals) { host_totals[1] = dst0 + tile_out - out_skew; host_totals[2] = nbytes; }
+        if (t + 1 == ntiles && lane == 0) { // (totals of this launch's piece; out_chain: of the scan so far)
+            state[1] = dst0 + tile_out - out_skew - out_before; state[2] = nbytes;
+            if (host_totals) { host_totals[1] = dst0 + tile_out - out_skew - out_before; host_totals[2] = nbytes; }
+            if (out_chain) out_chain[piece + 1] = dst0 + tile_out - out_skew;
         }
         // expand into LDS at the output's alignment (LDS dwords = global dwords).  The stage was zeroed: only the
         // stream's bytes are written, each moved up by the number of 0xFF bytes before it — the gaps ARE the stuffed
@@ -569,8 +586,10 @@ size_t fused_code_state_words(uint64_t nblocks) { return 2 + 2 * (size_t)((nbloc
 size_t fused_stuff_state_words(uint64_t max_stream_bytes) { return 3 + (size_t)((max_stream_bytes + kTileBytes - 1) / kTileBytes); }
 
 hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool state_is_zero, uint32_t *d_stream,
-                            unsigned long long *d_clear, size_t clear_words, unsigned long long *host_totals, hipStream_t s)
+                            unsigned long long *d_clear, size_t clear_words, unsigned long long *host_totals, hipStream_t s,
+                            const ScanPiece *piece_or_null)
 {
+    const ScanPiece piece = piece_or_null ? *piece_or_null : ScanPiece{0, 0, nullptr, nullptr};
     const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
     if (ngroups == 0) {
         if (host_totals) host_totals[0] = 0; // (nothing in flight writes it: a context's launches are serial)
@@ -583,9 +602,9 @@ hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool
     if (ngroups > 0x7FFFFFFFull || clear_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)ngroups;
     const uint32_t cw = d_clear ? (uint32_t)clear_words : 0u;
-    if (a.mode == 2) hipLaunchKernelGGL(scan_code_kernel<2>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals);
-    else if (a.mode == 1) hipLaunchKernelGGL(scan_code_kernel<1>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals);
-    else hipLaunchKernelGGL(scan_code_kernel<0>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals);
+    if (a.mode == 2) hipLaunchKernelGGL(scan_code_kernel<2>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals, piece);
+    else if (a.mode == 1) hipLaunchKernelGGL(scan_code_kernel<1>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals, piece);
+    else hipLaunchKernelGGL(scan_code_kernel<0>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals, piece);
     return hipGetLastError();
 }
 
@@ -608,7 +627,8 @@ uint64_t stuff_tiles(uint64_t stream_bytes) { return (stream_bytes + kTileBytes 
 
 hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_code_state, size_t code_state_words, uint32_t shift, bool band,
                               uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state,
-                              bool state_is_zero, uint8_t *d_out, uint64_t out_cap, unsigned long long *host_totals, hipStream_t s)
+                              bool state_is_zero, uint8_t *d_out, uint64_t out_cap, unsigned long long *host_totals, hipStream_t s,
+                              unsigned long long *d_out_chain, uint32_t piece)
 {
     // (d_out may start anywhere: the kernel gets the 16-byte boundary below it and the distance)
     const uint32_t out_skew = (uint32_t)(reinterpret_cast<uintptr_t>(d_out) & 15);
@@ -622,7 +642,7 @@ hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_co
     if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (code_state_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(stuff_fused_kernel, dim3((unsigned)tiles), dim3(kStuffThreads), 0, s, d_stream, d_code_state, shift, band ? 1u : 0u,
-                       d_state, d_out, out_skew, out_cap, first_tile, d_code_state, (uint32_t)code_state_words, host_totals);
+                       d_state, d_out, out_skew, out_cap, first_tile, d_code_state, (uint32_t)code_state_words, host_totals, d_out_chain, piece);
     return hipGetLastError();
 }
 

@@ -532,6 +532,31 @@ def test_direct_store_switch_gives_the_same_files():
     assert r.returncode == 0 and "cases ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_scans_coded_in_pieces_give_the_same_files():
+    """Large scans are coded in pieces (runs of groups, one launch pair each) whose bytes leave for the host while the next
+    piece is coded; the pieces hand each other bit and byte positions on the device.  With PIXO_HIP_PIECE_GROUPS=1 and 3
+    every reference-made golden above two or six groups goes through that path in up to 16 pieces — every alignment of
+    the seams — and PIXO_HIP_ONE_PIECE=1 switches it off; a 4096x4096 4:4:4 image takes the path by its own size."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env in ({"PIXO_HIP_PIECE_GROUPS": "1"}, {"PIXO_HIP_PIECE_GROUPS": "3"}, {"PIXO_HIP_ONE_PIECE": "1"}):
+        r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                            "-k", "goldens or device_entropy_stage or encode_device_into_pinned_and_pageable or band"],
+                           capture_output=True, text=True, env=dict(os.environ, **env), timeout=900, cwd=root)
+        assert r.returncode == 0, (env, r.stdout[-3000:])
+    # by its own size: 4096 groups of 192 blocks = two pieces (and the 16384x16384 file of test_config4... = sixteen)
+    import torch
+    w, h = 4096, 4096
+    px = synth.noise(w, h, 77)
+    o = jpeg.JpegOptions.builder(w, h).quality(75).subsampling(jpeg.Subsampling.S444).build()
+    want = O.encode(px, O.make_options(w, h, 2, 75, 0))
+    assert jpeg.encode(px, o) == want
+    d_px = torch.from_numpy(px).to("cuda:0")
+    pinned = torch.full((w * h * 3,), 0x33, dtype=torch.uint8).pin_memory()
+    n = jpeg.encode_device_into(pinned, d_px, o)
+    assert n == len(want) and pinned[:n].numpy().tobytes() == want and bool((pinned[n:] == 0x33).all())
+
+
 def test_every_rgb_colour_once():
     """A 4096x4096 image that contains each of the 16,777,216 RGB triples exactly once (two different
     arrangements, so that every colour meets different neighbours in the 4:2:0 box sums): coefficient

@@ -544,6 +544,17 @@ def test_scans_coded_in_pieces_give_the_same_files():
                             "-k", "goldens or device_entropy_stage or encode_device_into_pinned_and_pageable or band"],
                            capture_output=True, text=True, env=dict(os.environ, **env), timeout=900, cwd=root)
         assert r.returncode == 0, (env, r.stdout[-3000:])
+    # a piece whose stream outgrows the guess its stuffing grid was sized for (64 bytes per block; noise at q = 100 has
+    # 150) sends the call back to the one-piece path: same bytes
+    code = ("import sys; sys.path.insert(0, 'tests'); import synth, oracle_lib as O; from pixo_amd import jpeg\n"
+            "px = synth.noise(256, 256, 3)\n"
+            "for ss in (0, 1):\n"
+            "    o = jpeg.JpegOptions.builder(256, 256).quality(100).subsampling(jpeg.Subsampling(ss)).build()\n"
+            "    assert jpeg.encode(px, o) == O.encode(px, O.make_options(256, 256, 2, 100, ss))\n"
+            "print('redo ok')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PIXO_HIP_PIECE_GROUPS="1"),
+                       timeout=300, cwd=root)
+    assert r.returncode == 0 and "redo ok" in r.stdout, r.stderr[-2000:]
     # by its own size: 4096 groups of 192 blocks = two pieces (and the 16384x16384 file of test_config4... = sixteen)
     import torch
     w, h = 4096, 4096

@@ -532,6 +532,18 @@ def test_direct_store_switch_gives_the_same_files():
     assert r.returncode == 0 and "cases ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_stuffing_grid_guesses_that_fall_short_are_completed():
+    """The stuffing kernel's grid is sized for 64 bytes per block before the scan's length is known: noise at q = 100
+    (150 bytes per block) needs more than twice as many tiles — the missing ones are launched afterwards, same bytes;
+    smooth images in between use a fraction of the grid."""
+    w, h = 1024, 768
+    smooth, noisy = synth.gradient_rgb(w, h), synth.noise(w, h, 19)
+    for px, q in ((smooth, 60), (noisy, 100), (smooth, 60), (noisy, 35), (noisy, 100), (smooth, 95)):
+        for ss in (1, 0):
+            o = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling(ss)).build()
+            assert jpeg.encode(px, o) == O.encode(px, O.make_options(w, h, 2, q, ss)), (q, ss)
+
+
 def test_scans_coded_in_pieces_give_the_same_files():
     """Large scans are coded in pieces (runs of groups, one launch pair each) whose bytes leave for the host while the next
     piece is coded; the pieces hand each other bit and byte positions on the device.  With PIXO_HIP_PIECE_GROUPS=1 and 3

@@ -136,9 +136,14 @@ __device__ __forceinline__ void store_raw_block(const KArgs &a, const TileCtx &c
         if ((uint32_t)lane < nvalid && brow < c.units_y) dst = a.ry + (size_t)id.img * a.y_stride + ((size_t)brow * c.units_x + u0 + lane) * 64;
     }
     if (!dst) return;
+    // The trellis kernel's layout: the three planes are one run of blocks (launch_jpeg_coeffs checks it), block B's
+    // coefficient i lies at [B / 64][i][B % 64] — the 64 blocks one wavefront of that kernel searches side by side, so
+    // that each of its steps is one coalesced load instead of a staging area in LDS.  Here: consecutive lanes hold
+    // consecutive blocks, every one of the 64 stores below is a run of dwords.
+    const size_t B = (size_t)(dst - a.ry) >> 6;
+    float *col = a.ry + ((B >> 6) << 12) + (B & 63);
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-        reinterpret_cast<float4 *>(dst)[i] = make_float4(v[4 * i] * scale, v[4 * i + 1] * scale, v[4 * i + 2] * scale, v[4 * i + 3] * scale);
+    for (int i = 0; i < 64; i++) col[i * 64] = v[i] * scale;
 }
 
 template <int MODE, int LOAD, bool RAW = false>
@@ -206,8 +211,9 @@ hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gra
 {
     KArgs a;
     a.ry = a.rcb = a.rcr = nullptr;
-    if (raw_f32) { // the same three planes, as 64 f32 per block
+    if (raw_f32) { // the same three planes back to back, 64 f32 per block, in the trellis kernel's layout (store_raw_block)
         a.ry = static_cast<float *>(d_y); a.rcb = static_cast<float *>(d_cb); a.rcr = static_cast<float *>(d_cr);
+        if (batch != 1) return hipErrorInvalidValue;
     }
     a.px = static_cast<const uint8_t *>(d_px);
     a.y = static_cast<int16_t *>(d_y);

@@ -9,8 +9,9 @@ namespace pixo_dev {
 // Enqueues the fused colour -> DCT -> quantise kernel for `batch` equally sized images on
 // `stream`.  All pointers are device pointers; d_qt points at the 512-float table block of
 // the requested quality (layout in jpeg_tile.h).  d_cb/d_cr are ignored for gray input.
-// raw_f32: d_y/d_cb/d_cr receive the UNQUANTISED transform instead (64 f32 per block, natural order:
-// the reference's dct_2d output), input of the trellis quantiser (jpeg_trellis.hpp).
+// raw_f32 (batch 1): the UNQUANTISED transform instead (the reference's dct_2d output, f32), input of the trellis quantiser
+// (jpeg_trellis.hpp) and in its layout: d_y, d_cb = d_y + 64 y_blocks, d_cr = d_cb + 64 c_blocks are ONE run of blocks,
+// coefficient i (natural order) of block B at d_y[(B / 64 * 64 + i) * 64 + B % 64]; room for the run rounded up to 64 blocks.
 hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gray, bool s420,
                               uint32_t batch, void *d_y, void *d_cb, void *d_cr,
                               const float *d_qt, hipStream_t stream, bool raw_f32 = false);

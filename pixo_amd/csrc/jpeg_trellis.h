@@ -195,8 +195,10 @@ template <class Env> PIXO_TDEV void quantize_block_fast(Env &env)
 #pragma unroll
     for (int i = 0; i < 8; i++) { cc[i] = kNoState; run[i] = 0; }
     cc[0] = 0; // cost 0.0
+    float coef_next = env.coef(1), step_next = env.step(1); // (fetched a step ahead: on the device a load from HBM)
     for (int zz = 1; zz < 64; zz++) {
-        const float coef = env.coef(zz), qq = env.step(zz);
+        const float coef = coef_next, qq = step_next;
+        if (zz < 63) { coef_next = env.coef(zz + 1); step_next = env.step(zz + 1); }
         const Kinds k = candidate_kinds(coef / qq);
         uint64_t e[12];
         // non-zero candidates -> slots 1..4
@@ -272,10 +274,13 @@ template <class Env> PIXO_TDEV void quantize_block_fast(Env &env)
         if (run[i] > 0) c += 4.0f;
         if (i == 0 || c < best) { best = c; idx = i; }
     }
+    coef_next = env.coef(63); step_next = env.step(63);
+    uint64_t trail_next = env.trail_get(62);
     for (int zz = 63; zz >= 1; zz--) {
-        const uint32_t f = (uint32_t)(env.trail_get(zz - 1) >> (6 * idx)) & 63u;
+        const uint32_t f = (uint32_t)(trail_next >> (6 * idx)) & 63u;
         const int kind = (int)(f >> 3);
-        const Kinds k = candidate_kinds(env.coef(zz) / env.step(zz));
+        const Kinds k = candidate_kinds(coef_next / step_next);
+        if (zz > 1) { coef_next = env.coef(zz - 1); step_next = env.step(zz - 1); trail_next = env.trail_get(zz - 2); }
         int v = 0;
 #pragma unroll
         for (int j = 1; j < 5; j++) v = kind == j ? k.v[j] : v;

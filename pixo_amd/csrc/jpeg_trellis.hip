@@ -3,12 +3,14 @@
 // 968-976 -> src/jpeg/trellis.rs).
 //
 // One lane = one block, one wave = one workgroup = 64 consecutive blocks.  The Viterbi state of a lane
-// (8 costs, 8 runs, 12 successor keys) stays in registers (pixo_trellis::quantize_block_fast); the wave's
-// 64 x 64 coefficients are staged through LDS (coalesced 16-byte loads, lane stride 65 words: no bank
-// conflicts on the per-lane zig-zag reads), the code-length estimates are a 256-entry LDS table, the
-// back-pointers (8 bytes per lane and coefficient) go to a global scratch laid out [wave][position][lane]
-// so that both directions are full-line accesses.  Results return through the coefficient slots in LDS
-// and leave as whole 128-byte blocks.  ALU work: ~700 VALU instructions per coefficient position.
+// (8 costs, 8 runs, 12 successor keys) stays in registers (pixo_trellis::quantize_block_fast).  The coefficient
+// kernel's raw mode writes the transform already in this kernel's order — [wave][coefficient][lane] — so every step of
+// the search is one coalesced load, fetched a step ahead; the code-length estimates are a 256-entry LDS table; the
+// back-pointers (8 bytes per lane and coefficient) go to a global scratch laid out [wave][position][lane] so that both
+// directions are full-line accesses; the results are collected as i16 in LDS (8 KiB) and leave as whole 128-byte blocks.
+// Round 1 staged the wave's 64 x 64 f32 coefficients in LDS: 18 KiB per wavefront = 8 wavefronts per CU, two per SIMD,
+// for a kernel whose every step is a chain of dependent LDS look-ups; 10 KiB and four per SIMD now.
+// ALU work: ~700 VALU instructions per coefficient position.
 #include <hip/hip_runtime.h>
 
 #include "jpeg_trellis.h"
@@ -18,7 +20,7 @@
 
 namespace pixo_dev {
 namespace {
-constexpr int kLaneStride = 65; // words between two lanes' blocks in LDS
+constexpr int kOutPitch = 66; // i16 slots between two lanes' result rows in LDS (33 words: no bank conflicts)
 
 __constant__ int c_zigzag_nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
                                      12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
@@ -26,24 +28,24 @@ __constant__ int c_zigzag_nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32,
                                      58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 struct LaneEnv {
-    float *mine;          // this lane's 64 coefficient slots in LDS (natural order)
+    const float *col;     // this lane's column of the wave's coefficients: natural index i at col[64 i]
     const float *steps;   // this lane's 64 quantiser steps in LDS (natural order)
     const float *table;   // 256 code-length estimates in LDS
     uint64_t *trail;      // this lane's column of the wave's back-pointer scratch
-    __device__ __forceinline__ float coef(int zz) const { return mine[c_zigzag_nat[zz]]; }
+    int16_t *mine;        // this lane's 64 result slots in LDS (natural order)
+    __device__ __forceinline__ float coef(int zz) const { return col[c_zigzag_nat[zz] * 64]; }
     __device__ __forceinline__ float step(int zz) const { return steps[c_zigzag_nat[zz]]; }
     __device__ __forceinline__ float bits(int rs) const { return table[rs]; }
     __device__ __forceinline__ void trail_put(int pos, uint64_t w) { __builtin_nontemporal_store(w, trail + pos * 64); }
     __device__ __forceinline__ uint64_t trail_get(int pos) const { return __builtin_nontemporal_load(trail + pos * 64); }
-    // the result replaces the coefficient it was derived from (each slot is read before it is written)
-    __device__ __forceinline__ void out(int zz, int16_t v) { reinterpret_cast<int *>(mine)[c_zigzag_nat[zz]] = v; }
+    __device__ __forceinline__ void out(int zz, int16_t v) { mine[c_zigzag_nat[zz]] = v; }
 };
 
-// Blocks [0, nluma) use q_luma, the rest q_chroma: the three planes of a tuple are contiguous, one launch.
+// Blocks [0, nluma) use q_luma, the rest q_chroma: the three planes of a tuple are one run of blocks, one launch.
 __global__ __launch_bounds__(64) void trellis_kernel(const float *raw, const float *q_luma, const float *q_chroma, int16_t *out,
                                                      uint64_t nblocks, uint64_t nluma, uint64_t *trail)
 {
-    __shared__ float s_coef[64 * kLaneStride];
+    __shared__ __attribute__((aligned(4))) int16_t s_out[64 * kOutPitch];
     __shared__ float s_step[128];
     __shared__ float s_bits[256];
     const int lane = threadIdx.x;
@@ -53,26 +55,18 @@ __global__ __launch_bounds__(64) void trellis_kernel(const float *raw, const flo
     s_step[64 + lane] = q_chroma[lane];
 #pragma unroll
     for (int i = 0; i < 4; i++) s_bits[i * 64 + lane] = pixo_trellis::rate_bits(i * 64 + lane);
-    const float4 *src = reinterpret_cast<const float4 *>(raw + first * 64);
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-        const int i = it * 64 + lane, blk = i >> 4, part = i & 15;
-        // a short last wave recomputes its last block in the idle lanes
-        const float4 v = src[(uint64_t)(blk < (int)have ? blk : (int)have - 1) * 16 + part];
-        float *d = s_coef + blk * kLaneStride + part * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
     __syncthreads();
-    LaneEnv env{s_coef + lane * kLaneStride, s_step + (first + lane < nluma ? 0 : 64), s_bits, trail + (uint64_t)blockIdx.x * 63 * 64 + lane};
+    // (a short last wave searches its last block again in the idle lanes)
+    const int mine = lane < (int)have ? lane : (int)have - 1;
+    LaneEnv env{raw + (uint64_t)blockIdx.x * 4096 + mine, s_step + (first + mine < nluma ? 0 : 64), s_bits,
+                trail + (uint64_t)blockIdx.x * 63 * 64 + lane, s_out + lane * kOutPitch};
     pixo_trellis::quantize_block_fast(env);
     __syncthreads();
     uint32_t *dst = reinterpret_cast<uint32_t *>(out + first * 64);
-    const int *res = reinterpret_cast<const int *>(s_coef);
 #pragma unroll
     for (int it = 0; it < 32; it++) {
         const int i = it * 64 + lane, blk = i >> 5, pair = i & 31;
-        const int *p = res + blk * kLaneStride + pair * 2;
-        if (blk < (int)have) __builtin_nontemporal_store((uint32_t)(uint16_t)p[0] | ((uint32_t)(uint16_t)p[1] << 16), dst + i);
+        if (blk < (int)have) __builtin_nontemporal_store(*reinterpret_cast<const uint32_t *>(s_out + blk * kOutPitch + pair * 2), dst + i);
     }
 }
 } // namespace

@@ -780,9 +780,15 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
 int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                              const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len,
                              uint32_t batch = 1, std::vector<uint64_t> *image_starts = nullptr, size_t *header_len = nullptr,
-                             uint8_t *dest = nullptr, size_t dest_cap = 0)
+                             uint8_t *dest = nullptr, size_t dest_cap = 0, bool *own_malloc = nullptr)
 { // dest != null: the file goes straight into the caller's storage (no pinned intermediate); when it does not
-  // fit, *file_len says how much is needed and nothing is copied (PIXO_ERR_BUFFER_TOO_SMALL)
+  // fit, *file_len says how much is needed and nothing is copied (PIXO_ERR_BUFFER_TOO_SMALL).
+  // own_malloc != null (and no dest): the caller wants the file in malloc'd memory it will own — once the size is known
+  // the block is allocated and the device-to-host copy goes straight into it (*own_malloc = true, *file = the block);
+  // the copy into pageable memory runs at the link's rate, and what it saves is the second pass over the file from
+  // the pinned buffer (tools/ubench/upload.cpp: 0.21 ms + a warm 11 MB memcpy, or 1.30 against 1.38 ms for new pages).
+  // *own_malloc stays false when the file was assembled in the pinned buffer after all (a scan coded in pieces).
+    if (own_malloc) *own_malloc = false;
     namespace pd = pixo_dev;
     Stopwatch sw;
     ScanJob j;
@@ -880,18 +886,28 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
     pixo_host::file_headers(head, o, j.h);
     const size_t hdr = head.size(), total = hdr + scan_bytes + 2;
     uint8_t *buf = dest;
+    bool mine = false;
     if (dest) {
         if (total > dest_cap) {
             *file_len = total;
             return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(total) + " bytes");
         }
+    } else if (own_malloc && batch == 1) {
+        buf = static_cast<uint8_t *>(std::malloc(total));
+        if (!buf) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
+        mine = true;
     } else {
         if ((rc = c.reserve_hfile(total))) return rc;
         buf = c.h_file;
     }
     std::memcpy(buf, head.data(), hdr);
-    HIP_TRY(hipMemcpyAsync(buf + hdr, c.e_out.p, scan_bytes, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    hipError_t ce = hipMemcpyAsync(buf + hdr, c.e_out.p, scan_bytes, hipMemcpyDeviceToHost, stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(stream);
+    if (ce != hipSuccess) {
+        if (mine) std::free(buf);
+        return hip_fail(ce, "device-to-host copy of the file");
+    }
+    if (mine) *own_malloc = true;
     buf[hdr + scan_bytes] = 0xFF; // EOI (of the only image; batches append it per file)
     buf[hdr + scan_bytes + 1] = 0xD9;
     *file = buf;
@@ -949,8 +965,14 @@ int device_entropy_to_malloc(Context &c, const int16_t *dy, const int16_t *dcb, 
 {
     const uint8_t *file = nullptr;
     size_t n = 0;
-    int rc = device_entropy_to_pinned(c, dy, dcb, dcr, o, g, stream, &file, &n);
+    bool own = false;
+    int rc = device_entropy_to_pinned(c, dy, dcb, dcr, o, g, stream, &file, &n, 1, nullptr, nullptr, nullptr, 0, &own);
     if (rc) return rc;
+    if (own) { // (already in a block of its own)
+        *out_buf = const_cast<uint8_t *>(file);
+        *out_len = n;
+        return PIXO_OK;
+    }
     return deliver(file, n, out_buf, out_len);
 }
 
@@ -1154,9 +1176,12 @@ int hand_over(const std::vector<uint8_t> &v, uint8_t **out, size_t *out_len)
 
 // Encodes host pixels; on return `*file` points at the finished file, either in the context's
 // pinned buffer or in `spill` (host coder: scans with restart markers).
+// dest / dest_cap / own_malloc: as for device_entropy_to_pinned (honoured by the baseline device path; the others
+// return a view and the caller copies).
 int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options &o, std::vector<uint8_t> &spill,
-                   const uint8_t **file, size_t *file_len)
+                   const uint8_t **file, size_t *file_len, uint8_t *dest = nullptr, size_t dest_cap = 0, bool *own_malloc = nullptr)
 {
+    if (own_malloc) *own_malloc = false;
     std::string msg;
     int rc = pixo_host::validate(o, true, data_len, msg);
     if (rc) return fail(rc, msg);
@@ -1181,7 +1206,7 @@ int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options
     if (o.progressive) return progressive_to_view(c.d_px, o, g, c, spill, file, file_len);
     int16_t *dy, *dcb, *dcr;
     if ((rc = coeffs_on_device(c, c.d_px, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
-    return device_entropy_to_pinned(c, dy, dcb, dcr, o, g, c.stream, file, file_len);
+    return device_entropy_to_pinned(c, dy, dcb, dcr, o, g, c.stream, file, file_len, 1, nullptr, nullptr, dest, dest_cap, own_malloc);
 }
 
 } // namespace
@@ -1220,8 +1245,14 @@ int pixo_hip_jpeg_encode(const uint8_t *data, size_t data_len, const pixo_jpeg_o
     std::vector<uint8_t> spill;
     const uint8_t *file = nullptr;
     size_t n = 0;
-    int rc = encode_to_view(data, data_len, *options, spill, &file, &n);
+    bool own = false;
+    int rc = encode_to_view(data, data_len, *options, spill, &file, &n, nullptr, 0, &own);
     if (rc) return rc;
+    if (own) { // (the device-to-host copy went straight into the block the caller gets)
+        *out = const_cast<uint8_t *>(file);
+        *out_len = n;
+        return PIXO_OK;
+    }
     Stopwatch sw;
     rc = deliver(file, n, out, out_len);
     sw.lap("file into fresh host memory");
@@ -1237,9 +1268,11 @@ int pixo_hip_jpeg_encode_into(uint8_t *output, size_t capacity, const uint8_t *d
     std::vector<uint8_t> spill;
     const uint8_t *file = nullptr;
     size_t n = 0;
-    int rc = encode_to_view(data, data_len, *options, spill, &file, &n);
+    static uint8_t nowhere; // (a null output with capacity 0 is a size query)
+    int rc = encode_to_view(data, data_len, *options, spill, &file, &n, output ? output : &nowhere, output ? capacity : 0);
+    if (rc == PIXO_OK || rc == PIXO_ERR_BUFFER_TOO_SMALL) *out_len = n; // (the size needed when the file does not fit)
     if (rc) return rc;
-    *out_len = n;
+    if (file == output) return PIXO_OK; // (copied from the device straight into the caller's storage)
     if (n > capacity)
         return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(n) + " bytes");
     std::memcpy(output, file, n);

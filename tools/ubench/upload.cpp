@@ -1,6 +1,7 @@
 // Microbenchmark: ways of getting 48 MiB of pageable host pixels into HBM.
 //   hipcc -O2 -o /tmp/upload tools/ubench/upload.cpp -lpthread && /tmp/upload
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -61,6 +62,24 @@ int main()
     }
     // registering the caller's pages instead
     for (int i = 0; i < 5; i++) { double a = now(); CK(hipHostRegister(page, n, hipHostRegisterDefault)); double b = now(); CK(hipMemcpyAsync(dev, page, n, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s)); double c2 = now(); CK(hipHostUnregister(page)); double d = now(); if (i == 4) std::printf("register %.3f ms, copy %.3f ms, unregister %.3f ms\n", (b - a) * 1e3, (c2 - b) * 1e3, (d - c2) * 1e3); }
+    // ---- the other direction: an 11 MB file from HBM into host memory the caller will own
+    const size_t m = size_t{11} << 20;
+    for (int i = 0; i < 9; i++) { double a = now(); CK(hipMemcpyAsync(pin, dev, m, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); t.push_back(now() - a); }
+    std::printf("D2H 11 MiB into pinned                         %.3f ms\n", med(t)); t.clear();
+    for (int i = 0; i < 9; i++) { double a = now(); CK(hipMemcpyAsync(page, dev, m, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); t.push_back(now() - a); }
+    std::printf("D2H 11 MiB into the same pageable buffer       %.3f ms\n", med(t)); t.clear();
+    for (int i = 0; i < 9; i++) { double a = now(); uint8_t *f = static_cast<uint8_t *>(std::malloc(m)); CK(hipMemcpyAsync(f, dev, m, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); t.push_back(now() - a); std::free(f); }
+    std::printf("D2H 11 MiB into malloc, freed every time       %.3f ms (max %.3f)\n", med(t), *std::max_element(t.begin(), t.end()) * 1e3); t.clear();
+    { std::vector<uint8_t *> keep;
+      for (int i = 0; i < 9; i++) { double a = now(); uint8_t *f = static_cast<uint8_t *>(std::malloc(m)); CK(hipMemcpyAsync(f, dev, m, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); t.push_back(now() - a); keep.push_back(f); }
+      std::printf("D2H 11 MiB into malloc, all kept (new pages)   %.3f ms (max %.3f)\n", med(t), *std::max_element(t.begin(), t.end()) * 1e3); t.clear();
+      for (int i = 0; i < 9; i++) { double a = now(); uint8_t *f = static_cast<uint8_t *>(std::malloc(m)); CK(hipMemcpyAsync(pin, dev, m, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); std::memcpy(f, pin, m); t.push_back(now() - a); keep.push_back(f); }
+      std::printf("D2H into pinned + memcpy into kept malloc      %.3f ms (max %.3f)\n", med(t), *std::max_element(t.begin(), t.end()) * 1e3); t.clear();
+      for (int i = 0; i < 9; i++) { double a = now(); uint8_t *f = static_cast<uint8_t *>(std::malloc(m)); CK(hipMemcpyAsync(pin, dev, m, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s));
+          std::vector<std::thread> w; for (int k = 0; k < 8; k++) w.emplace_back([&, k] { size_t lo = m * k / 8, hi = m * (k + 1) / 8; std::memcpy(f + lo, pin + lo, hi - lo); }); for (auto &x : w) x.join();
+          t.push_back(now() - a); keep.push_back(f); }
+      std::printf("D2H into pinned + 8-thread memcpy, kept malloc %.3f ms (max %.3f)\n", med(t), *std::max_element(t.begin(), t.end()) * 1e3); t.clear();
+      for (auto f : keep) std::free(f); }
     std::printf("hardware threads: %u\n", std::thread::hardware_concurrency());
     return 0;
 }

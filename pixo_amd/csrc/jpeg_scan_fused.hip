@@ -4,17 +4,21 @@
 // restart markers, batches and progressive scans):
 //
 //   code   tuple -> packed MSB-first bit stream.  A group of 192 lanes owns 192 consecutive blocks of the scan
-//          order (32 MCUs of 4:2:0, 64 of 4:4:4): the blocks come in with coalesced 16-byte loads through LDS, every
-//          lane walks its block once for its bit length (encode_block, src/jpeg/huffman.rs:423-481), the lengths are
-//          summed with wavefront scans (DPP row shifts + row broadcasts, no LDS), the group's position in the
-//          stream comes from a decoupled look-back over the groups before it (one 64-bit descriptor per group), the
-//          lane walks its block a second time and ORs its codes into an LDS bit buffer at its offset, and the group
-//          writes the buffer out with coalesced dword stores.  The word two neighbouring groups share is written by
-//          the later one, which receives the earlier one's bits through a second descriptor: no atomics on the
-//          stream, no zero-filling of it.
+//          order (32 MCUs of 4:2:0, 64 of 4:4:4): every lane loads its block into 32 registers and walks it ONCE
+//          (encode_block, src/jpeg/huffman.rs:423-481; the branch-free block_pack_flat of jpeg_scan_block.h), coding it
+//          from bit 0 into a few words of LDS of its own — where the packer stands at the end is the block's length;
+//          the lengths are summed with wavefront scans (DPP row shifts + row broadcasts, no LDS), every lane moves
+//          its words, shifted, into the group's LDS bit buffer at its group-relative offset, the group's position in
+//          the stream comes from a decoupled look-back over the groups before it (one 64-bit descriptor per group),
+//          and the group writes the buffer out with coalesced dword stores.  The word two neighbouring groups share is
+//          written by the later one, which receives the earlier one's bits through a second descriptor: no atomics
+//          on the stream, no zero-filling of it.  A scan can be coded in pieces (ScanPiece) that hand each other the
+//          bit position on the device.
 //   stuff  packed stream -> final bytes with 0x00 after every 0xFF (BitWriterMsb, src/bits.rs:245-253), 16 KiB
-//          tiles: 0xFF census per lane, wavefront scans, look-back for the tile's output position, bytes expanded
-//          into LDS and written out as aligned dwords.
+//          tiles: 0xFF census per word, wavefront scans, look-back for the tile's output position, bytes expanded
+//          into LDS and written out as aligned 16-byte stores.
+//   count  (optimised tables) the same walk, counting symbols instead of coding them; per-workgroup rows summed by
+//          a second small kernel.
 //
 // Neither kernel needs a host round trip: `stuff` reads the stream's length where `code` left it.
 //
@@ -43,9 +47,9 @@ constexpr int kGroupWaves = kGroup / 64;
 #ifndef PIXO_SCRATCH_WORDS
 #define PIXO_SCRATCH_WORDS 12
 #endif
-constexpr uint32_t kWindowWords = PIXO_WINDOW_WORDS;               // the LDS bit buffer: 4 KiB; a typical group of noise at q = 80 (5.4 KiB) takes two rounds,
-constexpr uint32_t kBufWords = kWindowWords + kGroup; //   photographs one; + one dummy word per lane for the sink.  (LDS per group decides how many are resident.)
-constexpr uint32_t kScratchWords = PIXO_SCRATCH_WORDS;                // per lane: a block of up to 384 bits is coded in ONE walk (noise at q = 80: 230 +- 30)
+constexpr uint32_t kWindowWords = PIXO_WINDOW_WORDS;  // the LDS bit buffer: 6 KiB, one round for a group of noise at q = 80 (5.4 KiB); a longer group takes several
+constexpr uint32_t kBufWords = kWindowWords + kGroup; // + one dummy word per lane for the sinks.  (19 KiB of LDS per group in all: eight groups per CU.)
+constexpr uint32_t kScratchWords = PIXO_SCRATCH_WORDS; // per lane: a block of up to 384 bits is coded in ONE walk (noise at q = 80: 230 +- 30)
 constexpr uint32_t kScratchPitch = kScratchWords + 1; // + the dummy word; odd: lane-strided accesses hit all banks
 constexpr uint64_t kFlagAggregate = 1ull << 62, kFlagPrefix = 2ull << 62, kValueMask = (1ull << 62) - 1;
 constexpr uint64_t kTailValid = 1ull << 63;

@@ -296,6 +296,64 @@ extern "C" long emu_scan_flat(const int16_t *y, const int16_t *cb, const int16_t
     return o;
 }
 
+// A scan coded in PIECES (pixo_dev::ScanPiece, capi.cpp device_entropy_pieces) on the CPU: piece k codes blocks
+// [k * per_piece, ...) with the flat walk into a stream of its own that starts with the `lead` = (bits before the piece) % 8
+// last bits of the piece before — taken from that piece's stream, like the device does — so that it is byte-aligned with
+// the scan; every piece but the last is stuffed in whole bytes only, the last one is padded with 1-bits; the stuffed
+// pieces are concatenated.  The result must be the oracle's scan.
+extern "C" long emu_scan_pieces(const int16_t *y, const int16_t *cb, const int16_t *cr, int mode, uint64_t nblocks,
+                                const uint32_t *tables, uint64_t per_piece, uint8_t *out, long cap)
+{
+    using namespace pixo_scan;
+    uint32_t wtab[kWalkWords];
+    for (int i = 0; i < kWalkWords; i++) wtab[i] = walk_table_word(tables, i);
+    std::vector<uint32_t> prev_stream;
+    uint64_t before_prev = 0, before = 0; // chain[k - 1], chain[k]
+    long o = 0;
+    const uint64_t pieces = (nblocks + per_piece - 1) / per_piece;
+    for (uint64_t k = 0; k < pieces; k++) {
+        const uint64_t first = k * per_piece, n = std::min<uint64_t>(per_piece, nblocks - first);
+        const uint32_t lead = (uint32_t)(before & 7);
+        std::vector<uint32_t> stream(n * 53 + 4, 0);
+        if (k && lead) { // the last, partial byte of the previous piece's stream
+            const uint64_t prev_bits = (before_prev & 7) + (before - before_prev), at = prev_bits >> 3;
+            const uint32_t byte = (prev_stream[at >> 2] >> (24 - 8 * (uint32_t)(at & 3))) & 0xFFu;
+            stream[0] = (byte & (0xFF00u >> lead) & 0xFFu) << 24;
+        }
+        uint64_t pos = lead;
+        for (uint64_t s = first; s < first + n; s++) {
+            const BlockRef r = block_of(mode, s);
+            const int16_t *base = r.comp == 0 ? y : (r.comp == 1 ? cb : cr);
+            uint32_t wds[32];
+            memcpy(wds, base + r.index * 64, 128);
+            FlatPack<EmuOrSink> p;
+            p.sink = EmuOrSink{stream.data(), pos >> 5};
+            p.acc = 0; p.pending = (uint32_t)(pos & 31); p.word = 0;
+            block_pack_flat(wds, r.index ? base[(r.index - 1) * 64] : 0, wtab + (r.comp ? 1 : 0) * kWalkClassWords, p);
+            p.finish();
+            pos = ((pos >> 5) + p.word) * 32 + p.pending;
+        }
+        const bool last = k + 1 == pieces;
+        uint64_t total = pos; // the stream's length with its leading bits
+        if (last) {
+            const int pad = (int)((8 - (total & 7)) & 7);
+            if (pad) stream[total >> 5] |= ((1u << pad) - 1u) << (32 - (int)(total & 31) - pad);
+            total += pad;
+        }
+        const uint64_t nbytes = total / 8; // (whole bytes: every piece but the last leaves its last bits to the next)
+        for (uint64_t b = 0; b < nbytes; b++) {
+            const uint8_t byte = (uint8_t)(stream[b >> 2] >> (24 - 8 * (b & 3)));
+            if (o + 2 > cap) return -1;
+            out[o++] = byte;
+            if (byte == 0xFF) out[o++] = 0x00;
+        }
+        before_prev = before;
+        before += pos - lead;
+        prev_stream.swap(stream);
+    }
+    return o;
+}
+
 extern "C" long emu_scan(const int16_t *y, const int16_t *cb, const int16_t *cr, int mode, uint64_t nblocks,
                          const uint32_t *tables, uint8_t *out, long cap)
 {

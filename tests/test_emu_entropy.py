@@ -102,6 +102,30 @@ def test_flat_count_walk_gives_the_visitor_histogram():
     assert hist.sum() == 8
 
 
+@pytest.mark.parametrize("per_piece", [1, 5, 192, 1000])
+def test_a_scan_coded_in_pieces_is_the_same_scan(per_piece):
+    """Large scans are coded in pieces that hand each other the bit position (capi.cpp device_entropy_pieces, pixo_dev::ScanPiece):
+    a piece's stream starts with the (bits before) % 8 last bits of the piece before, every piece but the last is stuffed in
+    whole bytes only.  The same hand-off on the CPU with the device's flat walk, pieces of 1 block to 1000, against the oracle's scan."""
+    L = E.lib()
+    L.emu_scan_pieces.restype = C.c_long
+    L.emu_scan_pieces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_long]
+    L.emu_scan_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    cases = [(synth.noise(200, 120, 3), 200, 120, 2, 1, 80), (synth.flat_blocks(48, 48), 48, 48, 2, 1, 100),
+             (synth.gradient_rgb(333, 64), 333, 64, 2, 0, 90), (synth.noise_gray(100, 90, 1), 100, 90, 0, 0, 50),
+             (synth.extremes(64, 64, 2), 64, 64, 2, 1, 100), (synth.constant(33, 17, 128), 33, 17, 2, 1, 50)]
+    for px, w, h, ct, ss, q in cases:
+        y, cb, cr = O.coeffs(px, w, h, ct, ss, q)
+        tables = np.zeros(536, np.uint32)
+        L.emu_scan_tables(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, w, h, ct, ss, 0, tables.ctypes.data)
+        mode = 0 if ct == 0 else (2 if ss == 1 else 1)
+        n = y.shape[0] + cb.shape[0] + cr.shape[0]
+        out = np.zeros(n * 260 + 64, np.uint8)
+        got = L.emu_scan_pieces(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, mode, n, tables.ctypes.data, per_piece, out.ctypes.data, out.size)
+        want = _scan_segment(O.encode_from_coeffs(y, cb, cr, O.make_options(w, h, ct, q, ss)))
+        assert got >= 0 and out[:got].tobytes() == want, (w, h, ct, ss, q, per_piece)
+
+
 def test_ff_bytes_are_stuffed_and_last_byte_padded_with_ones():
     # noise at q=100 produces plenty of 0xFF bytes in the packed stream
     px = synth.noise(64, 64, 4)

@@ -174,38 +174,37 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     const uint64_t bits_before_piece = piece.index ? piece.chain[piece.index] : 0ull;
     const uint32_t lead = (uint32_t)(bits_before_piece & 7);
     if (piece.chain && piece.index == 0 && blockIdx.x == 0 && lane == 0) piece.chain[0] = 0; // (read by piece 1)
+    const uint64_t g = blockIdx.x; // (one group per workgroup; see the note on dispatch order at the top of the file)
+    // ---- blocks in, before anything else (the barrier below then waits once for these, the tables and the housekeeping):
+    // 8 x 16 bytes per lane straight into 32 registers.  A lane's block is one 128-byte line that its eight loads touch
+    // one after the other: cached loads (the line stays in L1 for the other seven), not non-temporal ones.  (Staging
+    // the group through LDS for perfectly coalesced loads cost 24 KiB per group and 60 more VGPRs for the addresses:
+    // half the occupancy.)
+    const uint64_t s = piece.first_block + g * kGroup + lane;
+    const bool live = g * kGroup + lane < a.nblocks;
+    uint32_t w[32];
+    // DC predictor: the previous block of the same component (jpeg/mod.rs:1417-1419); the scan's first blocks start
+    // from the seed (0, or the DCs above a band)
+    int prev_dc = 0, cls = 0;
+    {
+        const BlockRef ref = block_of(MODE, live ? s : 0);
+        const int16_t *base = ref.comp == 0 ? a.y : (ref.comp == 1 ? a.cb : a.cr);
+        const v4u *p = reinterpret_cast<const v4u *>(base + ref.index * 64);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const v4u q = p[r];
+            w[4 * r] = q.x; w[4 * r + 1] = q.y; w[4 * r + 2] = q.z; w[4 * r + 3] = q.w;
+        }
+        if (live) {
+            prev_dc = ref.index ? (int)base[(ref.index - 1) * 64] : (int)a.seed_dc[ref.comp];
+            cls = ref.comp == 0 ? 0 : 1;
+        }
+    }
     for (int i = lane; i < kWalkWords; i += kGroup) tab[i] = a.tables[kTableWords + i]; // (the walk's form lies behind the packed one)
     // (housekeeping for the kernel that follows: its descriptors must be zero when it starts — cheaper here than a memset launch)
     for (uint64_t i = (uint64_t)blockIdx.x * kGroup + lane; i < clear_words; i += (uint64_t)gridDim.x * kGroup) clear[i] = 0;
     __syncthreads();
-    { // (one group per workgroup; see the note on dispatch order at the top of the file)
-        const uint64_t g = blockIdx.x;
-        // ---- blocks in: 8 x 16 bytes per lane straight into 32 registers.  A lane's block is one 128-byte line that its
-        // eight loads touch one after the other: cached loads (the line stays in L1 for the other seven), not
-        // non-temporal ones.  (Staging the group through LDS for perfectly coalesced loads cost 24 KiB per group and 60
-        // more VGPRs for the addresses: half the occupancy.)
-        const uint64_t s = piece.first_block + g * kGroup + lane;
-        const bool live = g * kGroup + lane < a.nblocks;
-        uint32_t w[32];
-        {
-            const BlockRef ref = block_of(MODE, live ? s : 0);
-            const int16_t *base = ref.comp == 0 ? a.y : (ref.comp == 1 ? a.cb : a.cr);
-            const v4u *p = reinterpret_cast<const v4u *>(base + ref.index * 64);
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const v4u q = p[r];
-                w[4 * r] = q.x; w[4 * r + 1] = q.y; w[4 * r + 2] = q.z; w[4 * r + 3] = q.w;
-            }
-        }
-        // DC predictor: the previous block of the same component (jpeg/mod.rs:1417-1419); the scan's first blocks
-        // start from the seed (0, or the DCs above a band)
-        int prev_dc = 0, cls = 0;
-        if (live) {
-            const BlockRef ref = block_of(MODE, s);
-            const int16_t *base = ref.comp == 0 ? a.y : (ref.comp == 1 ? a.cb : a.cr);
-            prev_dc = ref.index ? (int)base[(ref.index - 1) * 64] : (int)a.seed_dc[ref.comp];
-            cls = ref.comp == 0 ? 0 : 1;
-        }
+    {
         // ---- THE walk: the block's codes into the lane's scratch from bit 0 — which also gives its length; group scan;
         // the group's aggregate goes out at once.  Blocks of more than 384 bits do not fit the scratch: a group that
         // holds one is packed by a second walk below (noise at q >= 90, not photographs).

@@ -114,6 +114,7 @@ struct Context {
     hipStream_t copy_stream = nullptr; // ... whose bytes travel to the host on this stream while the next piece is coded
     std::vector<hipEvent_t> piece_done;
     uint32_t tables_held[pixo_scan::kScanTableUpload]; bool tables_valid = false; hipStream_t tables_stream = nullptr; // what e_tables holds (no upload when unchanged)
+    uint32_t packed_per_block = 0; // bytes per block of the last whole scan this context coded (0: none yet), see device_entropy_to_pinned
     size_t code_state_zero_words = 0; // this many words of e_code_state are known to be zero (the stuffing kernel cleans up behind itself)
     Buf p_in, p_out, p_sums, p_scratch; // PNG filter stage
     Buf t_raw, t_trail;                 // progressive + trellis: unquantised DCT blocks (f32), Viterbi back-pointers
@@ -701,13 +702,66 @@ uint64_t piece_min_groups()
     return n;
 }
 
+// Medium scans (piece_medium_groups() <= groups < 2 piece_min_groups()): relative sizes of the pieces, first to last
+// (PIXO_HIP_PIECE_SCHEDULE="1,3"; "1" = one piece).  4096x4096 noise, 11 MB file, into pinned memory: one piece 0.313 ms,
+// "1,3" 0.301, "1,2,5" 0.302, "1,2,3,4" 0.315 (tools/gpu/r2w.sh): the first piece's bytes leave 70 us after the start
+// instead of 100, the rest is the file's 0.21 ms on PCIe.
+const std::vector<uint32_t> &piece_schedule()
+{
+    static const std::vector<uint32_t> w = [] {
+        std::vector<uint32_t> v;
+        const char *e = std::getenv("PIXO_HIP_PIECE_SCHEDULE");
+        std::string t = e && *e ? e : "1,3";
+        for (size_t i = 0; i < t.size();) {
+            const size_t k = t.find(',', i);
+            const long x = std::atol(t.substr(i, k == std::string::npos ? std::string::npos : k - i).c_str());
+            if (x > 0) v.push_back(static_cast<uint32_t>(x));
+            if (k == std::string::npos) break;
+            i = k + 1;
+        }
+        if (v.empty()) v.push_back(1);
+        return v;
+    }();
+    return w;
+}
+bool piece_medium_forced()
+{ // (tests: PIXO_HIP_PIECE_MEDIUM set = medium scans in pieces whatever the last file's size)
+    static const bool on = std::getenv("PIXO_HIP_PIECE_MEDIUM") != nullptr;
+    return on;
+}
+uint64_t piece_medium_groups()
+{ // scans of fewer groups than this are coded in one piece (PIXO_HIP_PIECE_MEDIUM=n)
+    static const uint64_t n = [] {
+        const char *e = std::getenv("PIXO_HIP_PIECE_MEDIUM");
+        const long v = e ? std::atol(e) : 0;
+        return static_cast<uint64_t>(v > 0 ? v : 1024);
+    }();
+    return n;
+}
+
 int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *dst, size_t dst_cap, uint64_t *scan_bytes)
 { // dst: where the stuffed scan goes on the host (dst_cap bytes available); tables are uploaded, j.a is set up
     namespace pd = pixo_dev;
     const uint64_t kGroupBlocks = 192, groups = (j.n + kGroupBlocks - 1) / kGroupBlocks;
-    const uint64_t groups_per_piece = (groups + kMaxPieces - 1) / kMaxPieces > piece_min_groups() ? (groups + kMaxPieces - 1) / kMaxPieces
-                                                                                                 : piece_min_groups();
-    const uint32_t pieces = static_cast<uint32_t>((groups + groups_per_piece - 1) / groups_per_piece); // (none is empty)
+    // where the pieces begin (in groups).  A large scan: equal pieces of at least piece_min_groups().  A medium one (a
+    // 4096x4096 image): a few pieces that GROW — the first small, so that its bytes leave early, each next one coded
+    // while the one before travels (weights from piece_schedule()).
+    uint64_t begin[kMaxPieces + 1];
+    uint32_t pieces = 0;
+    if (groups >= 2 * piece_min_groups()) {
+        const uint64_t per = std::max<uint64_t>((groups + kMaxPieces - 1) / kMaxPieces, piece_min_groups());
+        for (uint64_t g0 = 0; g0 < groups; g0 += per) begin[pieces++] = g0; // (none is empty)
+    } else {
+        const std::vector<uint32_t> &w = piece_schedule();
+        uint64_t sum = 0, acc = 0;
+        for (uint32_t x : w) sum += x;
+        for (size_t i = 0; i < w.size() && pieces < kMaxPieces; ++i) {
+            const uint64_t g0 = groups * acc / sum;
+            if (pieces == 0 || g0 > begin[pieces - 1]) begin[pieces++] = g0;
+            acc += w[i];
+        }
+    }
+    begin[pieces] = groups;
     if (!c.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
     while (c.piece_done.size() < pieces) {
         hipEvent_t e;
@@ -722,8 +776,8 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
     struct Piece { uint64_t first_block, blocks, tiles; uint32_t *stream; };
     Piece pc[kMaxPieces];
     for (uint32_t k = 0; k < pieces; ++k) {
-        pc[k].first_block = std::min<uint64_t>(j.n, k * groups_per_piece * kGroupBlocks);
-        pc[k].blocks = std::min<uint64_t>(j.n, (k + 1) * groups_per_piece * kGroupBlocks) - pc[k].first_block;
+        pc[k].first_block = std::min<uint64_t>(j.n, begin[k] * kGroupBlocks);
+        pc[k].blocks = std::min<uint64_t>(j.n, begin[k + 1] * kGroupBlocks) - pc[k].first_block;
         pc[k].tiles = pd::stuff_tiles(pc[k].blocks * 64 + 4096);
     }
     HIP_TRY(c.e_stream.reserve(j.stream_cap + 80 * kMaxPieces));
@@ -800,27 +854,40 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
     // pinned buffer, or into the caller's storage if that can hold any file the stuffing grids are sized for (a smaller
     // one might not fit the file, and then nothing may have been written to it: one piece, size first)
     const size_t likely_most = 1024 + static_cast<size_t>(j.n) * 64 + 8192;
-    if (j.fused && batch == 1 && pieces_enabled() && !direct_host_stores() && (j.n + 191) / 192 >= 2 * piece_min_groups() &&
-        (!dest || dest_cap >= likely_most)) {
+    // A medium scan in pieces only pays when the file is large (a 0.3 MB file of a smooth 4096x4096 image: 0.12 ms in one
+    // piece, more in two): the context remembers the bytes per block of its last scan and cuts the next one only when that
+    // was 12 or more (a stream of similar images; the first one is coded in one piece).
+    const uint64_t scan_groups = (j.n + 191) / 192;
+    const bool large = scan_groups >= 2 * piece_min_groups();
+    const bool medium = !large && scan_groups >= piece_medium_groups() && (c.packed_per_block >= 12 || piece_medium_forced());
+    // (Not for a caller that wants a malloc'd block of its own: the block would have to be allocated before the size is
+    // known — 64 bytes per block, cut to size afterwards — and a block of a new size is new pages every call, which the
+    // device-to-host copy has to fault in and pin: 20 ms instead of 0.7 for the 4096x4096 noise image.  One piece, the
+    // exact size, recycled by malloc.)
+    if (j.fused && batch == 1 && pieces_enabled() && !direct_host_stores() && (large || medium) && (!dest || dest_cap >= likely_most) &&
+        !(own_malloc && !dest)) {
         if ((rc = scan_tables(c, j, o, g, stream, nullptr))) return rc;
         pixo_host::file_headers(head, o, j.h);
         const size_t hdr = head.size();
         uint8_t *buf = dest;
+        size_t cap = dest_cap;
         if (!buf) {
             if ((rc = c.reserve_hfile(likely_most))) return rc;
             buf = c.h_file;
+            cap = c.hfile_cap;
         }
-        const size_t room = (dest ? dest_cap : c.hfile_cap) - hdr - 2;
         uint64_t scan_bytes = 0;
-        rc = device_entropy_pieces(c, j, stream, buf + hdr, room, &scan_bytes);
+        rc = device_entropy_pieces(c, j, stream, buf + hdr, cap - hdr - 2, &scan_bytes);
         sw.lap("code+stuff+copy (pieces)");
         if (rc < 0) return rc;
         if (rc == 0) {
+            c.packed_per_block = static_cast<uint32_t>(scan_bytes / (j.n ? j.n : 1));
+            const size_t total = hdr + scan_bytes + 2;
             std::memcpy(buf, head.data(), hdr);
             buf[hdr + scan_bytes] = 0xFF; // EOI
             buf[hdr + scan_bytes + 1] = 0xD9;
             *file = buf;
-            *file_len = hdr + scan_bytes + 2;
+            *file_len = total;
             if (header_len) *header_len = hdr;
             return PIXO_OK;
         }
@@ -874,6 +941,7 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
         sw.lap("memset+pack+ff census");
     }
     const uint64_t scan_bytes = j.scan_bytes;
+    if (batch == 1 && j.n) c.packed_per_block = static_cast<uint32_t>(scan_bytes / j.n);
     if (batch > 1) { // where every image's segment begins in the stuffed stream (reuses the seg_bytes buffer: 8 B/entry)
         HIP_TRY(c.e_seg_bytes.reserve(j.nseg * 8));
         HIP_TRY(pd::launch_segment_out_offsets(j.plan, j.nbytes, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),

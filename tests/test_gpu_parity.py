@@ -551,7 +551,8 @@ def test_scans_coded_in_pieces_give_the_same_files():
     the seams — and PIXO_HIP_ONE_PIECE=1 switches it off; a 4096x4096 4:4:4 image takes the path by its own size."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for env in ({"PIXO_HIP_PIECE_GROUPS": "1"}, {"PIXO_HIP_PIECE_GROUPS": "3"}, {"PIXO_HIP_ONE_PIECE": "1"}):
+    for env in ({"PIXO_HIP_PIECE_GROUPS": "1"}, {"PIXO_HIP_PIECE_GROUPS": "3"}, {"PIXO_HIP_ONE_PIECE": "1"},
+                {"PIXO_HIP_PIECE_MEDIUM": "2"}, {"PIXO_HIP_PIECE_MEDIUM": "3", "PIXO_HIP_PIECE_SCHEDULE": "1,2,5"}):
         r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
                             "-k", "goldens or device_entropy_stage or encode_device_into_pinned_and_pageable or band"],
                            capture_output=True, text=True, env=dict(os.environ, **env), timeout=900, cwd=root)
@@ -567,8 +568,23 @@ def test_scans_coded_in_pieces_give_the_same_files():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PIXO_HIP_PIECE_GROUPS="1"),
                        timeout=300, cwd=root)
     assert r.returncode == 0 and "redo ok" in r.stdout, r.stderr[-2000:]
-    # by its own size: 4096 groups of 192 blocks = two pieces (and the 16384x16384 file of test_config4... = sixteen)
+    # a medium scan (a 4096x4096 4:2:0 image: 2048 groups) is cut into growing pieces once the context has seen that its
+    # files are large: the first call in one piece, the following ones in two — same bytes; a smooth image in between
+    # switches back
     import torch
+    w = h = 4096
+    px = synth.noise(w, h, 42)
+    o = jpeg.JpegOptions.builder(w, h).quality(80).subsampling(jpeg.Subsampling.S420).build()
+    want = O.encode(px, O.make_options(w, h, 2, 80, 1))
+    d_px = torch.from_numpy(px).to("cuda:0")
+    d_smooth = torch.from_numpy(synth.gradient_rgb(w, h)).to("cuda:0")
+    smooth_want = O.encode(synth.gradient_rgb(w, h), O.make_options(w, h, 2, 80, 1))
+    pinned = torch.full((w * h * 3,), 0x44, dtype=torch.uint8).pin_memory()
+    for d, ref in ((d_px, want), (d_px, want), (d_px, want), (d_smooth, smooth_want), (d_px, want), (d_px, want)):
+        n = jpeg.encode_device_into(pinned, d, o)
+        assert n == len(ref) and pinned[:n].numpy().tobytes() == ref
+        assert jpeg.encode_device(d, o) == ref  # (into a block of its own)
+    # by its own size: 4096 groups of 192 blocks = two pieces (and the 16384x16384 file of test_config4... = sixteen)
     w, h = 4096, 4096
     px = synth.noise(w, h, 77)
     o = jpeg.JpegOptions.builder(w, h).quality(75).subsampling(jpeg.Subsampling.S444).build()

@@ -310,21 +310,42 @@ int coeffs_to_pinned(Context &c, const uint8_t *pixels, const pixo_jpeg_options 
 }
 
 // Device pixels -> device coefficient tuple inside the context's buffer.
-int coeffs_on_device(Context &c, const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
-                     int16_t **dy, int16_t **dcb, int16_t **dcr)
+// The tuple's place in the context (no launch)
+int coeffs_reserve(Context &c, const pixo_host::Geometry &g, int16_t **dy, int16_t **dcb, int16_t **dcr)
 {
-    const float *qt_all = nullptr;
-    int rc = device_tables(c.device, &qt_all);
-    if (rc) return rc;
     const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128;
-    if ((rc = c.reserve_coef(coef_bytes))) return rc;
+    const int rc = c.reserve_coef(coef_bytes);
+    if (rc) return rc;
     *dy = static_cast<int16_t *>(c.d_coef);
     *dcb = *dy + g.y_blocks * 64;
     *dcr = *dcb + g.c_blocks * 64;
-    HIP_TRY(pixo_dev::launch_jpeg_coeffs(d_pixels, o.width, o.height, g.gray, g.s420, 1, *dy,
-                                         g.gray ? nullptr : *dcb, g.gray ? nullptr : *dcr,
+    return PIXO_OK;
+}
+// The coefficient kernel over MCU rows [row0, row0 + rows) of the image — a sub-image of the same width whose blocks
+// land at their places in the whole image's tuple (MCU rows are independent: SURVEY §8e; the last rows replicate the
+// image's bottom edge as the whole-image launch does).  rows = 0: to the end.
+int coeffs_rows(Context &c, const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
+                int16_t *dy, int16_t *dcb, int16_t *dcr, uint32_t row0, uint32_t rows)
+{
+    const float *qt_all = nullptr;
+    const int rc = device_tables(c.device, &qt_all);
+    if (rc) return rc;
+    const uint32_t unit = (!g.gray && g.s420) ? 16u : 8u, units_x = (o.width + unit - 1) / unit, units_y = (o.height + unit - 1) / unit;
+    if (rows == 0 || row0 + rows > units_y) rows = units_y - row0;
+    const uint32_t y0 = row0 * unit, y1 = row0 + rows >= units_y ? o.height : (row0 + rows) * unit;
+    const size_t bpp = g.gray ? 1 : 3, m0 = static_cast<size_t>(row0) * units_x;
+    const uint8_t *px = static_cast<const uint8_t *>(d_pixels) + static_cast<size_t>(y0) * o.width * bpp;
+    HIP_TRY(pixo_dev::launch_jpeg_coeffs(px, o.width, y1 - y0, g.gray, g.s420, 1, dy + m0 * (unit == 16 ? 4 : 1) * 64,
+                                         g.gray ? nullptr : dcb + m0 * 64, g.gray ? nullptr : dcr + m0 * 64,
                                          qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, stream));
     return PIXO_OK;
+}
+int coeffs_on_device(Context &c, const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
+                     int16_t **dy, int16_t **dcb, int16_t **dcr)
+{
+    const int rc = coeffs_reserve(c, g, dy, dcb, dcr);
+    if (rc) return rc;
+    return coeffs_rows(c, d_pixels, o, g, stream, *dy, *dcb, *dcr, 0, 0);
 }
 
 // Does the scan emit RSTn markers (jpeg/mod.rs:1431-1445: only while more MCUs follow)?
@@ -739,7 +760,18 @@ uint64_t piece_medium_groups()
     return n;
 }
 
-int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *dst, size_t dst_cap, uint64_t *scan_bytes)
+// Pixels whose coefficients have not been computed yet (the tuple's place is reserved, j.a points at it): the entropy
+// stage launches the coefficient kernel itself — for a scan coded in pieces, band by band in front of each piece, so
+// that the first piece's bytes can leave before the rest of the image has even been transformed.
+struct PixelSource {
+    const void *d_px;
+    const pixo_jpeg_options *o;
+    const pixo_host::Geometry *g;
+    int16_t *dy, *dcb, *dcr;
+};
+
+int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *dst, size_t dst_cap, uint64_t *scan_bytes,
+                          const PixelSource *src = nullptr)
 { // dst: where the stuffed scan goes on the host (dst_cap bytes available); tables are uploaded, j.a is set up
     namespace pd = pixo_dev;
     const uint64_t kGroupBlocks = 192, groups = (j.n + kGroupBlocks - 1) / kGroupBlocks;
@@ -762,6 +794,26 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
         }
     }
     begin[pieces] = groups;
+    // coefficient bands in front of the pieces: only where a piece can begin with an MCU row (the groups of 192 blocks and
+    // the MCU rows must share boundaries: 4:2:0 widths that are multiples of 512, 4:4:4 of 512, gray of 1536)
+    uint64_t groups_per_row = 0;
+    if (src) {
+        const uint32_t unit = (!src->g->gray && src->g->s420) ? 16u : 8u, units_x = (src->o->width + unit - 1) / unit;
+        const uint64_t row_blocks = static_cast<uint64_t>(units_x) * j.a.blocks_per_mcu;
+        if (row_blocks % kGroupBlocks == 0) {
+            groups_per_row = row_blocks / kGroupBlocks;
+            uint32_t kept = 1; // (piece 0 begins at row 0)
+            for (uint32_t k = 1; k < pieces; ++k) {
+                const uint64_t g0 = begin[k] / groups_per_row * groups_per_row;
+                if (g0 > begin[kept - 1]) begin[kept++] = g0;
+            }
+            pieces = kept;
+            begin[pieces] = groups;
+        } else { // (no common boundaries: the whole image first)
+            const int rc = coeffs_rows(c, src->d_px, *src->o, *src->g, stream, src->dy, src->dcb, src->dcr, 0, 0);
+            if (rc) return rc;
+        }
+    }
     if (!c.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
     while (c.piece_done.size() < pieces) {
         hipEvent_t e;
@@ -792,6 +844,12 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
         unsigned long long *mail = reinterpret_cast<unsigned long long *>(c.h_totals) + 4 * k;
         const bool zero = c.code_state_zero_words >= state_words;
         c.code_state_zero_words = 0;
+        if (groups_per_row) { // this piece's MCU rows through the coefficient kernel
+            const uint32_t row0 = static_cast<uint32_t>(begin[k] / groups_per_row);
+            const uint32_t rows = k + 1 == pieces ? 0u : static_cast<uint32_t>(begin[k + 1] / groups_per_row) - row0;
+            const int rc = coeffs_rows(c, src->d_px, *src->o, *src->g, stream, src->dy, src->dcb, src->dcr, row0, rows);
+            if (rc) return rc;
+        }
         HIP_TRY(pd::launch_scan_code(a, c.e_code_state.as<unsigned long long>(), zero, pc[k].stream, c.e_stuff_state.as<unsigned long long>(),
                                      pd::fused_stuff_state_words(j.stream_cap), mail, stream, &piece));
         HIP_TRY(pd::launch_stuff_fused(pc[k].stream, c.e_code_state.as<unsigned long long>(), state_words, 0, /*band=*/k + 1 != pieces,
@@ -834,8 +892,9 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
 int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                              const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len,
                              uint32_t batch = 1, std::vector<uint64_t> *image_starts = nullptr, size_t *header_len = nullptr,
-                             uint8_t *dest = nullptr, size_t dest_cap = 0, bool *own_malloc = nullptr)
-{ // dest != null: the file goes straight into the caller's storage (no pinned intermediate); when it does not
+                             uint8_t *dest = nullptr, size_t dest_cap = 0, bool *own_malloc = nullptr, const PixelSource *src = nullptr)
+{ // src != null: the tuple (dy, dcb, dcr = src's) has not been computed yet, see PixelSource.
+  // dest != null: the file goes straight into the caller's storage (no pinned intermediate); when it does not
   // fit, *file_len says how much is needed and nothing is copied (PIXO_ERR_BUFFER_TOO_SMALL).
   // own_malloc != null (and no dest): the caller wants the file in malloc'd memory it will own — once the size is known
   // the block is allocated and the device-to-host copy goes straight into it (*own_malloc = true, *file = the block);
@@ -866,6 +925,10 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
     // exact size, recycled by malloc.)
     if (j.fused && batch == 1 && pieces_enabled() && !direct_host_stores() && (large || medium) && (!dest || dest_cap >= likely_most) &&
         !(own_malloc && !dest)) {
+        if (src && o.optimize_huffman) { // (the statistics need the whole tuple)
+            if ((rc = coeffs_rows(c, src->d_px, o, g, stream, src->dy, src->dcb, src->dcr, 0, 0))) return rc;
+            src = nullptr;
+        }
         if ((rc = scan_tables(c, j, o, g, stream, nullptr))) return rc;
         pixo_host::file_headers(head, o, j.h);
         const size_t hdr = head.size();
@@ -877,7 +940,8 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
             cap = c.hfile_cap;
         }
         uint64_t scan_bytes = 0;
-        rc = device_entropy_pieces(c, j, stream, buf + hdr, cap - hdr - 2, &scan_bytes);
+        rc = device_entropy_pieces(c, j, stream, buf + hdr, cap - hdr - 2, &scan_bytes, src);
+        src = nullptr; // (the tuple is complete now, whatever happened)
         sw.lap("code+stuff+copy (pieces)");
         if (rc < 0) return rc;
         if (rc == 0) {
@@ -893,6 +957,7 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
         }
         c.code_state_zero_words = 0; // (rc == 1: start over in one piece, below)
     }
+    if (src && (rc = coeffs_rows(c, src->d_px, o, g, stream, src->dy, src->dcb, src->dcr, 0, 0))) return rc; // one piece: the whole image first
     if (j.fused) { // code + stuff back to back, one read-back
         if ((rc = scan_lengths(c, j, o, g, stream, nullptr, /*wait=*/false))) return rc;
         // One image into host memory the GPU can write — the context's pinned file buffer, or storage of the caller's
@@ -1650,13 +1715,15 @@ int pixo_hip_jpeg_encode_device_into(const void *d_pixels, const pixo_jpeg_optio
         std::free(p);
         return PIXO_OK;
     }
+    PIXO_REQUIRE(d_pixels);
     int16_t *dy, *dcb, *dcr;
-    if ((rc = coeffs_on_device(*c, d_pixels, *options, g, c->stream, &dy, &dcb, &dcr))) return rc;
+    if ((rc = coeffs_reserve(*c, g, &dy, &dcb, &dcr))) return rc;
+    const PixelSource src{d_pixels, options, &g, dy, dcb, dcr}; // (the entropy stage launches the coefficient kernel: whole, or band by band)
     const uint8_t *file = nullptr;
     // (a null output with capacity 0 is a size query)
     static uint8_t nowhere;
     return device_entropy_to_pinned(*c, dy, dcb, dcr, *options, g, c->stream, &file, out_len, 1, nullptr, nullptr,
-                                    output ? output : &nowhere, output ? capacity : 0);
+                                    output ? output : &nowhere, output ? capacity : 0, nullptr, &src);
 }
 
 namespace {

@@ -725,8 +725,9 @@ uint64_t piece_min_groups()
 
 // Medium scans (piece_medium_groups() <= groups < 2 piece_min_groups()): relative sizes of the pieces, first to last
 // (PIXO_HIP_PIECE_SCHEDULE="1,3"; "1" = one piece).  4096x4096 noise, 11 MB file, into pinned memory: one piece 0.313 ms,
-// "1,3" 0.301, "1,2,5" 0.302, "1,2,3,4" 0.315 (tools/gpu/r2w.sh): the first piece's bytes leave 70 us after the start
-// instead of 100, the rest is the file's 0.21 ms on PCIe.
+// "1,3" 0.301, "1,2,5" 0.302, "1,2,3,4" 0.315; with the coefficient kernel band by band as well: "1,3" 0.291, "1,2,5" 0.299,
+// "1,5" 0.310 (tools/gpu/r2w.sh): the first piece's bytes leave 60 us after the start instead of 100, the rest is the
+// file's 0.21 ms on PCIe.
 const std::vector<uint32_t> &piece_schedule()
 {
     static const std::vector<uint32_t> w = [] {

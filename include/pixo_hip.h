@@ -311,9 +311,18 @@ int pixo_hip_set_device(int device);        /* device for the calling thread's c
  * caller has enqueued so far on `stream` (a hipStream_t of the calling thread's current device; default:
  * the NULL stream, which is also PyTorch's default stream).  Per thread. */
 int pixo_hip_set_producer_stream(void *stream);
-/* Releases the calling thread's device and pinned buffers (they only grow while the thread lives and are
- * released by themselves when it ends): for a long-lived thread after an unusually large image. */
+void *pixo_hip_get_producer_stream(void);   /* what the calling thread set (to save and restore it around a call) */
+/* Releases the calling thread's device and pinned buffers AND every context parked by threads that have ended.
+ * Buffers only grow while a thread lives; when it ends its context is parked for the next thread (no hipMalloc per
+ * request in a thread-per-request server).  Parked contexts are bounded — at most 16 of them and 1 GiB of device +
+ * pinned memory together, the oldest give their large buffers back first — but a LIVE thread keeps what its largest
+ * image needed (a 16384x16384 image: ~2 GB of HBM, ~0.4 GB pinned) until it calls this. */
 int pixo_hip_trim(void);
+/* Tests and A/B tools only: replaces the debug switches read from the environment variable PIXO_HIP_DEBUG
+ * ("name[=value],...": trace, host_entropy, multipass_entropy, direct_stores, one_piece, piece_groups=n, piece_medium=n,
+ * piece_schedule=a:b:c, copy_threads=n, spin_budget=n, no_bands_upload — pixo_amd/csrc/capi_internal.hpp).  None of
+ * them changes the bytes of a file.  NULL = read the environment again.  Not synchronised with calls in flight. */
+int pixo_hip_debug_configure(const char *switches_or_null);
 void pixo_hip_free(void *p);
 const char *pixo_hip_last_error(void);      /* thread-local, never NULL               */
 const char *pixo_hip_version(void);

@@ -1,0 +1,427 @@
+// jpeg_api.cpp — the extern "C" JPEG entry points declared in include/pixo_hip.h.  No CPU fallback exists: without a
+// usable GPU every compute entry point fails with PIXO_ERR_COMPRESSION and says so.
+#include <algorithm>
+
+#include "capi_internal.hpp"
+
+using namespace pixo_capi;
+
+namespace {
+// Encodes host pixels; on return `*file` points at the finished file, either in the context's
+// pinned buffer or in `spill` (host coder: scans with restart markers).
+// dest / dest_cap / own_malloc: as for device_entropy_to_pinned (honoured by the baseline device path; the others
+// return a view and the caller copies).
+int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options &o, std::vector<uint8_t> &spill,
+                   const uint8_t **file, size_t *file_len, uint8_t *dest = nullptr, size_t dest_cap = 0, bool *own_malloc = nullptr)
+{
+    if (own_malloc) *own_malloc = false;
+    std::string msg;
+    int rc = pixo_host::validate(o, true, data_len, msg);
+    if (rc) return fail(rc, msg);
+    if (!data) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'data'");
+    const pixo_host::Geometry g = pixo_host::geometry(o.width, o.height, o.color_type, o.subsampling);
+    Context &c = thread_context();
+    if (!o.progressive && debug().host_entropy) { // (experiments: the host twin of the entropy stage)
+        const int16_t *y, *cb, *cr;
+        if ((rc = coeffs_to_pinned(c, data, o, g, &y, &cb, &cr))) return rc;
+        pixo_host::encode_file(y, cb, cr, o, spill);
+        *file = spill.data();
+        *file_len = spill.size();
+        return PIXO_OK;
+    }
+    if ((rc = c.ensure())) return rc;
+    PIXO_ON_DEVICE_OF(c);
+    const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
+    if ((rc = c.reserve_px((px_bytes + 15) & ~size_t{15}))) return rc;
+    Stopwatch sw;
+    HIP_TRY(hipMemcpyAsync(c.d_px, data, px_bytes, hipMemcpyHostToDevice, c.stream));
+    sw.lap("pixels to device (enqueued)");
+    if (o.progressive) return progressive_to_view(c.d_px, o, g, c, spill, file, file_len);
+    int16_t *dy, *dcb, *dcr;
+    if ((rc = coeffs_on_device(c, c.d_px, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
+    return device_entropy_to_pinned(c, dy, dcb, dcr, o, g, c.stream, file, file_len, 1, nullptr, nullptr, dest, dest_cap, own_malloc);
+}
+
+int fail_tuple_trellis()
+{ // trellis quantisation happens between the transform and the tuple (src/jpeg/mod.rs:932-976): a tuple entry cannot apply it
+    return fail(PIXO_ERR_COMPRESSION, "Compression error: trellis_quant needs the pixels: quantise the tuple with the trellis "
+                                      "quantiser first and clear the flag, or use an entry point that takes pixels");
+}
+} // namespace
+
+extern "C" {
+
+void pixo_jpeg_options_from_preset(pixo_jpeg_options *o, uint32_t width, uint32_t height,
+                                   uint8_t quality, uint8_t preset)
+{ // jpeg/mod.rs:162-216
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->width = width; o->height = height; o->color_type = PIXO_RGB; o->quality = quality;
+    o->subsampling = PIXO_S444;
+    if (preset == 0) return;
+    o->optimize_huffman = 1;
+    if (preset == 2) { o->subsampling = PIXO_S420; o->progressive = 1; o->trellis_quant = 1; }
+}
+
+int pixo_hip_jpeg_encode(const uint8_t *data, size_t data_len, const pixo_jpeg_options *options,
+                         uint8_t **out, size_t *out_len)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(out);
+    PIXO_REQUIRE(out_len);
+    std::vector<uint8_t> spill;
+    const uint8_t *file = nullptr;
+    size_t n = 0;
+    bool own = false;
+    int rc = encode_to_view(data, data_len, *options, spill, &file, &n, nullptr, 0, &own);
+    if (rc) return rc;
+    if (own) { // (the device-to-host copy went straight into the block the caller gets)
+        *out = const_cast<uint8_t *>(file);
+        *out_len = n;
+        return PIXO_OK;
+    }
+    Stopwatch sw;
+    rc = deliver(file, n, out, out_len);
+    sw.lap("file into fresh host memory");
+    return rc;
+}
+
+int pixo_hip_jpeg_encode_into(uint8_t *output, size_t capacity, const uint8_t *data, size_t data_len,
+                              const pixo_jpeg_options *options, size_t *out_len)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(out_len);
+    if (capacity && !output) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'output'");
+    std::vector<uint8_t> spill;
+    const uint8_t *file = nullptr;
+    size_t n = 0;
+    static uint8_t nowhere; // (a null output with capacity 0 is a size query)
+    int rc = encode_to_view(data, data_len, *options, spill, &file, &n, output ? output : &nowhere, output ? capacity : 0);
+    if (rc == PIXO_OK || rc == PIXO_ERR_BUFFER_TOO_SMALL) *out_len = n; // (the size needed when the file does not fit)
+    if (rc) return rc;
+    if (file == output) return PIXO_OK; // (copied from the device straight into the caller's storage)
+    if (n > capacity)
+        return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(n) + " bytes");
+    std::memcpy(output, file, n);
+    return PIXO_OK;
+}
+
+int pixo_hip_encode_jpeg(const uint8_t *data, size_t data_len, uint32_t width, uint32_t height,
+                         uint8_t color_type, uint8_t quality, uint8_t preset, int subsampling_420,
+                         uint8_t **out, size_t *out_len)
+{ // wasm.rs:113-142
+    PIXO_REQUIRE(out);
+    PIXO_REQUIRE(out_len);
+    if (color_type != PIXO_GRAY && color_type != PIXO_RGB)
+        return fail(PIXO_ERR_INVALID_COLOR_ARG, "Invalid color type for JPEG: " + std::to_string(color_type) +
+                                                    ". Expected 0 (Gray) or 2 (Rgb)");
+    pixo_jpeg_options o;
+    pixo_jpeg_options_from_preset(&o, width, height, quality, preset); // .quality(q).preset(p)
+    o.color_type = color_type;                                         // preset keeps the colour type
+    o.subsampling = subsampling_420 ? PIXO_S420 : PIXO_S444;           // .subsampling(...) overrides
+    return pixo_hip_jpeg_encode(data, data_len, &o, out, out_len);
+}
+
+int pixo_hip_coeff_geometry(uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling,
+                            size_t *y_blocks, size_t *c_blocks)
+{
+    PIXO_REQUIRE(y_blocks);
+    PIXO_REQUIRE(c_blocks);
+    if (width == 0 || height == 0)
+        return fail(PIXO_ERR_INVALID_DIMENSIONS,
+                    "Invalid image dimensions: " + std::to_string(width) + "x" + std::to_string(height));
+    if (color_type != PIXO_GRAY && color_type != PIXO_RGB)
+        return fail(PIXO_ERR_UNSUPPORTED_COLOR_TYPE, "Unsupported color type for this format");
+    const pixo_host::Geometry g = pixo_host::geometry(width, height, color_type, subsampling);
+    *y_blocks = g.y_blocks;
+    *c_blocks = g.c_blocks;
+    return PIXO_OK;
+}
+
+int pixo_hip_jpeg_coeffs(const uint8_t *pixels, uint32_t width, uint32_t height, uint8_t color_type,
+                         uint8_t subsampling, uint8_t quality, int16_t *y, size_t y_blocks, int16_t *cb,
+                         int16_t *cr, size_t c_blocks)
+{
+    pixo_jpeg_options o{};
+    o.width = width; o.height = height; o.color_type = color_type; o.quality = quality;
+    o.subsampling = subsampling;
+    std::string msg;
+    int rc = pixo_host::validate(o, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    const pixo_host::Geometry g = pixo_host::geometry(width, height, color_type, subsampling);
+    if (y_blocks != g.y_blocks || c_blocks != g.c_blocks)
+        return fail(PIXO_ERR_INVALID_DATA_LENGTH,
+                    "Invalid pixel data length: expected " + std::to_string(g.y_blocks) + " bytes, got " +
+                        std::to_string(y_blocks));
+    PIXO_REQUIRE(pixels);
+    PIXO_REQUIRE(y);
+    if (g.c_blocks && (!cb || !cr)) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'cb'/'cr'");
+    const int16_t *hy, *hcb, *hcr;
+    if ((rc = coeffs_to_pinned(thread_context(), pixels, o, g, &hy, &hcb, &hcr))) return rc;
+    std::memcpy(y, hy, g.y_blocks * 128);
+    if (g.c_blocks) {
+        std::memcpy(cb, hcb, g.c_blocks * 128);
+        std::memcpy(cr, hcr, g.c_blocks * 128);
+    }
+    return PIXO_OK;
+}
+
+int pixo_hip_jpeg_coeffs_device(const void *d_pixels, uint32_t width, uint32_t height, uint8_t color_type,
+                                uint8_t subsampling, uint8_t quality, uint32_t batch, void *d_y, void *d_cb,
+                                void *d_cr, void *stream)
+{
+    pixo_jpeg_options o{};
+    o.width = width; o.height = height; o.color_type = color_type; o.quality = quality;
+    o.subsampling = subsampling;
+    std::string msg;
+    int rc = pixo_host::validate(o, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if (batch == 0 || batch > 65535) return fail(PIXO_ERR_COMPRESSION, "Compression error: batch must be 1..65535");
+    PIXO_REQUIRE(d_pixels);
+    PIXO_REQUIRE(d_y);
+    if (color_type != PIXO_GRAY && (!d_cb || !d_cr)) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'd_cb'/'d_cr'");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const float *qt_all = nullptr;
+    if ((rc = device_tables(dev, &qt_all))) return rc;
+    const bool gray = color_type == PIXO_GRAY;
+    HIP_TRY(pixo_dev::launch_jpeg_coeffs(d_pixels, width, height, gray, !gray && subsampling == PIXO_S420,
+                                         batch, d_y, gray ? nullptr : d_cb, gray ? nullptr : d_cr,
+                                         qt_all + (quality - 1) * pixo_host::kDeviceQtFloats, static_cast<hipStream_t>(stream)));
+    return PIXO_OK;
+}
+
+namespace {
+int integer_mode_checks(uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling, uint8_t quality,
+                        pixo_host::QuantTables *qt)
+{
+    pixo_jpeg_options o{};
+    o.width = width; o.height = height; o.color_type = color_type; o.quality = quality; o.subsampling = subsampling;
+    std::string msg;
+    int rc = pixo_host::validate(o, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if (color_type != PIXO_GRAY && subsampling != PIXO_S444)
+        return fail(PIXO_ERR_COMPRESSION, "Compression error: the integer DCT mode is defined per 8x8 block: 4:4:4 or gray only");
+    *qt = pixo_host::make_quant_tables(quality);
+    return PIXO_OK;
+}
+} // namespace
+
+int pixo_hip_jpeg_coeffs_integer_device(const void *d_pixels, uint32_t width, uint32_t height, uint8_t color_type,
+                                        uint8_t subsampling, uint8_t quality, void *d_y, void *d_cb, void *d_cr, void *stream)
+{
+    pixo_host::QuantTables qt;
+    int rc = integer_mode_checks(width, height, color_type, subsampling, quality, &qt);
+    if (rc) return rc;
+    PIXO_REQUIRE(d_pixels);
+    PIXO_REQUIRE(d_y);
+    const bool gray = color_type == PIXO_GRAY;
+    if (!gray && (!d_cb || !d_cr)) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'd_cb'/'d_cr'");
+    uint16_t ql[64], qc[64];
+    for (int i = 0; i < 64; ++i) { ql[i] = static_cast<uint16_t>(qt.lum[i]); qc[i] = static_cast<uint16_t>(qt.chr[i]); } // quantize.rs:56-78
+    HIP_TRY(pixo_dev::launch_jpeg_coeffs_integer(d_pixels, width, height, gray, ql, qc, d_y, d_cb, d_cr, static_cast<hipStream_t>(stream)));
+    return PIXO_OK;
+}
+
+int pixo_hip_jpeg_coeffs_integer(const uint8_t *pixels, uint32_t width, uint32_t height, uint8_t color_type, uint8_t subsampling,
+                                 uint8_t quality, int16_t *y, size_t y_blocks, int16_t *cb, int16_t *cr, size_t c_blocks)
+{
+    pixo_host::QuantTables qt;
+    int rc = integer_mode_checks(width, height, color_type, subsampling, quality, &qt);
+    if (rc) return rc;
+    const pixo_host::Geometry g = pixo_host::geometry(width, height, color_type, PIXO_S444);
+    if (y_blocks != g.y_blocks || c_blocks != g.c_blocks)
+        return fail(PIXO_ERR_INVALID_DATA_LENGTH, "Invalid pixel data length: expected " + std::to_string(g.y_blocks) + " bytes, got " +
+                                                      std::to_string(y_blocks));
+    PIXO_REQUIRE(pixels);
+    PIXO_REQUIRE(y);
+    if (g.c_blocks && (!cb || !cr)) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'cb'/'cr'");
+    Context &c = thread_context();
+    if ((rc = c.ensure())) return rc;
+    PIXO_ON_DEVICE_OF(c);
+    const size_t px_bytes = static_cast<size_t>(width) * height * (g.gray ? 1 : 3), coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128;
+    if ((rc = c.reserve_px((px_bytes + 15) & ~size_t{15}))) return rc;
+    if ((rc = c.reserve_coef(coef_bytes))) return rc;
+    if ((rc = c.reserve_hcoef(coef_bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(c.d_px, pixels, px_bytes, hipMemcpyHostToDevice, c.stream));
+    int16_t *dy = static_cast<int16_t *>(c.d_coef), *dcb = dy + g.y_blocks * 64, *dcr = dcb + g.c_blocks * 64;
+    if ((rc = pixo_hip_jpeg_coeffs_integer_device(c.d_px, width, height, color_type, PIXO_S444, quality, dy, dcb, dcr, c.stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(c.h_coef, c.d_coef, coef_bytes, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    const int16_t *hy = static_cast<const int16_t *>(c.h_coef);
+    std::memcpy(y, hy, g.y_blocks * 128);
+    if (g.c_blocks) {
+        std::memcpy(cb, hy + g.y_blocks * 64, g.c_blocks * 128);
+        std::memcpy(cr, hy + (g.y_blocks + g.c_blocks) * 64, g.c_blocks * 128);
+    }
+    return PIXO_OK;
+}
+
+int pixo_hip_jpeg_entropy_encode(const int16_t *y, const int16_t *cb, const int16_t *cr,
+                                 const pixo_jpeg_options *options, uint8_t **out, size_t *out_len)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(out);
+    PIXO_REQUIRE(out_len);
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if (options->progressive && options->trellis_quant) return fail_tuple_trellis();
+    PIXO_REQUIRE(y);
+    std::vector<uint8_t> v;
+    pixo_host::encode_file(y, cb, cr, *options, v);
+    return hand_over(v, out, out_len);
+}
+
+int pixo_hip_jpeg_entropy_encode_device(const void *d_y, const void *d_cb, const void *d_cr,
+                                        const pixo_jpeg_options *options, uint8_t **out, size_t *out_len)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(out);
+    PIXO_REQUIRE(out_len);
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if (options->progressive && options->trellis_quant) return fail_tuple_trellis();
+    PIXO_REQUIRE(d_y);
+    Context *c = nullptr;
+    if ((rc = context_on_current_device(&c))) return rc;
+    const pixo_host::Geometry g = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
+    return device_tuple_to_malloc(static_cast<const int16_t *>(d_y), static_cast<const int16_t *>(d_cb),
+                                  static_cast<const int16_t *>(d_cr), *options, g, *c, out, out_len);
+}
+
+int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *options, uint8_t **out, size_t *out_len)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(d_pixels);
+    PIXO_REQUIRE(out);
+    PIXO_REQUIRE(out_len);
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    Context *c = nullptr;
+    if ((rc = context_on_current_device(&c))) return rc;
+    const pixo_host::Geometry g = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
+    if (options->progressive) {
+        std::vector<uint8_t> spill;
+        const uint8_t *file = nullptr;
+        size_t n = 0;
+        if ((rc = progressive_to_view(d_pixels, *options, g, *c, spill, &file, &n))) return rc;
+        return deliver(file, n, out, out_len);
+    }
+    int16_t *dy, *dcb, *dcr;
+    if ((rc = coeffs_on_device(*c, d_pixels, *options, g, c->stream, &dy, &dcb, &dcr))) return rc;
+    return device_tuple_to_malloc(dy, dcb, dcr, *options, g, *c, out, out_len);
+}
+
+int pixo_hip_jpeg_encode_device_into(const void *d_pixels, const pixo_jpeg_options *options, uint8_t *output, size_t capacity,
+                                     size_t *out_len)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(out_len);
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    Context *c = nullptr;
+    if ((rc = context_on_current_device(&c))) return rc;
+    const pixo_host::Geometry g = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
+    if (options->progressive) { // assembled in the context's pinned buffer: one copy from there if it fits
+        PIXO_REQUIRE(d_pixels);
+        std::vector<uint8_t> spill;
+        const uint8_t *file = nullptr;
+        size_t n = 0;
+        if ((rc = progressive_to_view(d_pixels, *options, g, *c, spill, &file, &n))) return rc;
+        *out_len = n;
+        if (n > capacity) return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(n) + " bytes");
+        std::memcpy(output, file, n);
+        return PIXO_OK;
+    }
+    if (debug().host_entropy) { // assembled on the host: copy if it fits
+        uint8_t *p = nullptr;
+        size_t n = 0;
+        if ((rc = pixo_hip_jpeg_encode_device(d_pixels, options, &p, &n))) return rc;
+        *out_len = n;
+        if (n > capacity) {
+            std::free(p);
+            return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(n) + " bytes");
+        }
+        std::memcpy(output, p, n);
+        std::free(p);
+        return PIXO_OK;
+    }
+    PIXO_REQUIRE(d_pixels);
+    int16_t *dy, *dcb, *dcr;
+    if ((rc = coeffs_reserve(*c, g, &dy, &dcb, &dcr))) return rc;
+    const PixelSource src{d_pixels, options, &g, dy, dcb, dcr}; // (the entropy stage launches the coefficient kernel: whole, or band by band)
+    const uint8_t *file = nullptr;
+    // (a null output with capacity 0 is a size query)
+    static uint8_t nowhere;
+    return device_entropy_to_pinned(*c, dy, dcb, dcr, *options, g, c->stream, &file, out_len, 1, nullptr, nullptr,
+                                    output ? output : &nowhere, output ? capacity : 0, nullptr, &src);
+}
+
+int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_options *options, uint32_t batch,
+                                      uint8_t **files, size_t *lens)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(files);
+    PIXO_REQUIRE(lens);
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if (batch == 0 || batch > 65535) return fail(PIXO_ERR_COMPRESSION, "Compression error: batch must be 1..65535");
+    Context *c = nullptr;
+    if ((rc = context_on_current_device(&c))) return rc;
+    const pixo_jpeg_options &o = *options;
+    const pixo_host::Geometry g = pixo_host::geometry(o.width, o.height, o.color_type, o.subsampling);
+    const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
+    for (uint32_t i = 0; i < batch; ++i) { files[i] = nullptr; lens[i] = 0; }
+    auto release = [&](int code) { for (uint32_t i = 0; i < batch; ++i) { std::free(files[i]); files[i] = nullptr; } return code; };
+    // Per-image tables or restart segments inside the images: one image at a time.
+    if (o.progressive) {
+        for (uint32_t i = 0; i < batch; ++i)
+            if ((rc = pixo_hip_jpeg_encode_device(static_cast<const uint8_t *>(d_pixels) + i * px_bytes, options, &files[i], &lens[i]))) return release(rc);
+        return PIXO_OK;
+    }
+    if (batch == 1 || o.optimize_huffman || scan_has_restart_markers(o, g) || px_bytes % 4 != 0) {
+        for (uint32_t i = 0; i < batch; ++i) {
+            int16_t *dy, *dcb, *dcr;
+            if ((rc = coeffs_on_device(*c, static_cast<const uint8_t *>(d_pixels) + i * px_bytes, o, g, c->stream, &dy, &dcb, &dcr))) return release(rc);
+            if ((rc = device_tuple_to_malloc(dy, dcb, dcr, o, g, *c, &files[i], &lens[i]))) return release(rc);
+        }
+        return PIXO_OK;
+    }
+    // one coefficient launch and one entropy pass for the whole batch
+    const float *qt_all = nullptr;
+    if ((rc = device_tables(c->device, &qt_all))) return rc;
+    const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128 * batch;
+    if ((rc = c->reserve_coef(coef_bytes))) return rc;
+    int16_t *dy = static_cast<int16_t *>(c->d_coef), *dcb = dy + g.y_blocks * 64 * batch, *dcr = dcb + g.c_blocks * 64 * batch;
+    HIP_TRY(pixo_dev::launch_jpeg_coeffs(d_pixels, o.width, o.height, g.gray, g.s420, batch, dy, g.gray ? nullptr : dcb,
+                                         g.gray ? nullptr : dcr, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c->stream));
+    const uint8_t *blob = nullptr;
+    size_t blob_len = 0, hdr = 0;
+    std::vector<uint64_t> starts;
+    if ((rc = device_entropy_to_pinned(*c, dy, dcb, dcr, o, g, c->stream, &blob, &blob_len, batch, &starts, &hdr))) return rc;
+    for (uint32_t i = 0; i < batch; ++i) {
+        lens[i] = hdr + static_cast<size_t>(starts[i + 1] - starts[i]) + 2;
+        files[i] = static_cast<uint8_t *>(std::malloc(lens[i]));
+        if (!files[i]) return release(fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory"));
+    }
+    // headers + own segment + EOI into every file; the files are fresh memory: several threads (see big_copy)
+    const size_t total = blob_len + static_cast<size_t>(batch) * hdr;
+    const unsigned t = static_cast<unsigned>(std::min<size_t>(std::min<size_t>(debug().copy_threads, batch), total >> 21));
+    run_on_threads(t ? t : 1, [&](unsigned k) {
+        for (uint32_t i = k; i < batch; i += (t ? t : 1)) {
+            const size_t seg = lens[i] - hdr - 2;
+            uint8_t *p = files[i];
+            std::memcpy(p, blob, hdr);
+            std::memcpy(p + hdr, blob + hdr + starts[i], seg);
+            p[hdr + seg] = 0xFF; p[hdr + seg + 1] = 0xD9;
+        }
+    });
+    return PIXO_OK;
+}
+
+} // extern "C"

@@ -37,6 +37,23 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+#if defined(PIXO_PROBE)
+// Timeline builds only (tools/ab_build.sh probe "-DPIXO_PROBE"; never the shipped library): every wavefront stores eight
+// time stamps — the 100 MHz constant clock (s_memrealtime: the same counter on every XCD) — into a buffer the host hands
+// over with pixo_hip_debug_probe_buffer().  tools/probe_timeline.py turns them into the dispatch's timeline.
+__device__ unsigned long long *g_probe = nullptr;
+__device__ __forceinline__ void probe_stamp(int slot)
+{
+    unsigned long long *p = g_probe;
+    if (!p) return;
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) p[((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8 + slot] = t;
+}
+#define PIXO_STAMP(slot) probe_stamp(slot)
+#else
+#define PIXO_STAMP(slot) ((void)0)
+#endif
+
 // A tile is (image, tile column, tile row): three SGPRs.  The full TileCtx is rebuilt from the
 // kernel arguments where it is needed instead of being carried (three live copies of it cost
 // ~30 SGPRs and pushed the kernel to the 102-SGPR limit).
@@ -88,7 +105,9 @@ __device__ __forceinline__ void phase_a(const TileCtx &c, const TileId &id, int 
     for (int j = 0; j < COUNT; j++) {
         producer_fix_item<MODE, LOAD>(c, id.tx, first + j, lane, &r[j * G::item_regs]);
         producer_color_item<MODE>(first + j, lane, &r[j * G::item_regs], lds);
+        if (j == 0) PIXO_STAMP(1); // the first item's pixels have arrived and are converted
     }
+    PIXO_STAMP(2); // ... the last item's
 }
 
 // One tile per workgroup of THREE wavefronts.  Phase A: the wavefronts share the tile's items
@@ -150,7 +169,19 @@ template <int MODE, int LOAD, bool RAW = false>
 __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(const KArgs a)
 {
     typedef Geo<MODE> G;
+#if defined(PIXO_QUANT_LDS)
+    __shared__ __attribute__((aligned(16))) uint8_t lds[G::planar + (RAW ? 0 : kQuantLdsFloats * 4)];
+    float *ldsq = reinterpret_cast<float *>(lds + G::planar); // the quantiser's reciprocals (jpeg_tile.h: consumer_quant_lds)
+    if (!RAW) {
+        const int i = threadIdx.x;
+        if (i < 128) {
+            ldsq[i] = a.qt[quant_lds_source<MODE>(i)];
+            if (MODE != MGRAY) ldsq[i + 128] = a.qt[quant_lds_source<MODE>(i + 128)];
+        }
+    }
+#else
     __shared__ __attribute__((aligned(16))) uint8_t lds[G::planar];
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // Phase A runs at raised wave priority: the hardware otherwise issues oldest-first, the colour
     // conversion of the younger workgroups waits behind the older ones' phase B, and few wavefronts
@@ -158,6 +189,7 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     // image (all workgroups resident at once), +10 % for 4:4:4 and for the 64-image batch (measured at
     // steady clocks, profiles/r01_ablation_steady_clocks.txt).
     __builtin_amdgcn_s_setprio(1);
+    PIXO_STAMP(0); // the wavefront runs
     const TileId id = locate(a, blockIdx.x);
     const TileCtx c = ctx_of(a, id.img);
     constexpr int base = G::items / kWaves, extra = G::items % kWaves;
@@ -166,16 +198,23 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     else phase_a<MODE, LOAD, base>(c, id, extra * (base + 1) + (wave - extra) * base, lane, lds, last_rows);
     lds_barrier();
     __builtin_amdgcn_s_setprio(0);
+    PIXO_STAMP(3); // barrier passed: phase B begins
     float v[64];
     consumer_rows<MODE>(wave, lane, lds, v);
     consumer_cols(v);
+    PIXO_STAMP(4); // transform done
     if (RAW) { // hand the transformed blocks to the trellis quantiser instead of quantising here
         store_raw_block<MODE>(a, c, id, wave, lane, v);
         return;
     }
     uint8_t *stage = lds + stage_offset<MODE>(wave); // inside this wavefront's own planar area
     uint32_t qw[32];
+#if defined(PIXO_QUANT_LDS)
+    consumer_quant_lds<MODE>(wave, lane, a.qt, ldsq, v, qw);
+#else
     consumer_quant<MODE>(wave, lane, a.qt, v, qw);
+#endif
+    PIXO_STAMP(5); // quantised: the first store is next
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         consumer_stage_blocks(lane, h, qw, stage);
@@ -183,6 +222,11 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
         consumer_store_blocks<MODE>(c, id.tx, id.ty, wave, lane, h, stage);
         consumer_stage_sync();
     }
+#if defined(PIXO_PROBE)
+    PIXO_STAMP(6); // last store issued
+    __builtin_amdgcn_s_waitcnt(0); // (vmcnt(0): the stores have been acknowledged)
+    PIXO_STAMP(7);
+#endif
 }
 
 template <int MODE, int LOAD> static hipError_t launch_mode(KArgs &a, hipStream_t s)
@@ -243,3 +287,11 @@ hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gra
 }
 
 } // namespace pixo_dev
+
+#if defined(PIXO_PROBE)
+extern "C" int pixo_hip_debug_probe_buffer(void *d_buffer)
+{ // d_buffer: workgroups x 3 x 8 u64, or null to switch the stamps off
+    unsigned long long *p = static_cast<unsigned long long *>(d_buffer);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(pixo_dev::g_probe), &p, sizeof p);
+}
+#endif

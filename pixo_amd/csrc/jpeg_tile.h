@@ -162,6 +162,16 @@ PIXO_DEV uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
 #endif
 }
 
+// v_alignbyte_b32: ({hi, lo} >> 8 * (sh & 3)) & 0xffffffff
+PIXO_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+#if defined(PIXO_EMU)
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));
+#else
+    return __builtin_amdgcn_alignbyte(hi, lo, sh & 3);
+#endif
+}
+
 typedef PIXO_CONST_AS const float *qtab_t;
 PIXO_DEV qtab_t as_qtab(const float *p) { return (qtab_t)(uintptr_t)p; }
 
@@ -284,6 +294,64 @@ PIXO_DEV Row4 color_row4(uint32_t d0, uint32_t d1, uint32_t d2)
     return o;
 }
 
+// ---- the same conversion with v_dot4_u32_u8 (one instruction = one pixel's three multiply-adds) --------------------
+// For 4:2:0, where the chroma values are only ever needed as bytes to add up.  A pixel's three bytes lie in ONE dword
+// (pixels 0 and 3 of a group do already: d0 = R0 G0 B0 R1, d2 = B2 R3 G3 B3; pixels 1 and 2 after one v_alignbyte
+// each); the coefficient dword says which byte is which, so pixel 3 needs no shift.  Negative coefficients: the
+// instruction multiplies unsigned bytes, so the bytes they apply to are complemented (one xor per pixel and component):
+//   Cb:  X = 128 B + 32896 - 43 R - 85 G = 128 B + 43 (255 - R) + 85 (255 - G) + 256        (43 * 255 + 85 * 255 = 32640)
+//   Cr:  X = 128 R + 107 (255 - G) + 21 (255 - B) + 256                                     (107 * 255 + 21 * 255 = 32640)
+// and the value is byte 1 of X (bits 8..15) — except for X = 65536 (pure blue / pure red), where the reference clamps
+// 256 to 255 (color.rs:69-76): the accumulator starts at 0xFFFF0000 + 256 and the instruction SATURATES at 2^32 - 1, so
+// that X = 65536 yields 0xFFFFFFFF, byte 1 = 255, and every other X yields 0xFFFF0000 + X.  Y = 77 R + 150 G + 29 B + 128
+// never exceeds 65408.  12 dot products + 8 xors + 2 shifts per 4 pixels against 18 packed multiply-adds + 6 byte
+// shuffles; the price is that every result is a dword of its own (three more instructions to gather the four Y bytes).
+PIXO_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c, bool clamp)
+{
+#if defined(PIXO_EMU)
+    uint64_t t = c;
+    for (int i = 0; i < 4; i++) t += (uint64_t)((a >> (8 * i)) & 0xFF) * ((b >> (8 * i)) & 0xFF);
+    return (uint32_t)(clamp && t > 0xFFFFFFFFull ? 0xFFFFFFFFull : t);
+#else
+    return clamp ? __builtin_amdgcn_udot4(a, b, c, true) : __builtin_amdgcn_udot4(a, b, c, false);
+#endif
+}
+struct Row4D {
+    uint32_t y4;           // Y0..Y3 as bytes
+    uint32_t cb[4], cr[4]; // per pixel: byte 1 = the value (byte 0: discarded fraction, bytes 2-3: ones)
+};
+PIXO_DEV Row4D color_row4_dot(uint32_t d0, uint32_t d1, uint32_t d2)
+{
+    const uint32_t p[4] = {d0, alignbyte(d1, d0, 3), alignbyte(d2, d1, 2), d2}; // pixel i at bytes 0..2 (i = 3: bytes 1..3)
+    const uint32_t kC = 0xFFFF0100u;
+    uint32_t y[4];
+    Row4D o;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int sh = i == 3 ? 8 : 0;
+        y[i] = udot4(p[i], 0x001D964Du << sh, 128u, false);                         // 77, 150, 29
+        o.cb[i] = udot4(p[i] ^ (0x0000FFFFu << sh), 0x0080552Bu << sh, kC, true);   // 43 ~R, 85 ~G, 128 B
+        o.cr[i] = udot4(p[i] ^ (0x00FFFF00u << sh), 0x00156B80u << sh, kC, true);   // 128 R, 107 ~G, 21 ~B
+    }
+    o.y4 = perm(y[1], y[0], 0x0C0C0501u) | perm(y[3], y[2], 0x05010C0Cu); // byte 1 of each, pixel order
+    return o;
+}
+// (byte 1 of a + byte 1 of b, byte 1 of c + byte 1 of d) as two u16 lanes (see add_high_bytes)
+PIXO_DEV uint32_t add_bytes1(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+#if defined(PIXO_EMU)
+    return (((a >> 8) & 0xFF) + ((b >> 8) & 0xFF)) | ((((c >> 8) & 0xFF) + ((d >> 8) & 0xFF)) << 16);
+#else
+    uint32_t r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_sdwa %0, %3, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"
+        "s_nop 0"
+        : "=&v"(r) : "v"(a), "v"(b), "v"(c), "v"(d));
+    return r;
+#endif
+}
+
 // Edge path: 4 pixels with the reference's clamp-replicate addressing
 // (x = min(x, W-1), y = min(y, H-1); jpeg/mod.rs:1578-1579,1626-1627), byte loads.
 struct u32x3 { uint32_t a, b, c; };
@@ -336,16 +404,6 @@ PIXO_DEV uint32_t gather_row4_gray(const uint8_t *px, uint32_t W, uint32_t H, ui
 #else
 #define PIXO_GLOAD(ptr) __builtin_nontemporal_load(ptr)
 #endif
-
-// v_alignbyte_b32: ({hi, lo} >> 8 * (sh & 3)) & 0xffffffff
-PIXO_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
-{
-#if defined(PIXO_EMU)
-    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));
-#else
-    return __builtin_amdgcn_alignbyte(hi, lo, sh & 3);
-#endif
-}
 
 // One aligned dword of the pixel buffer.  The device reads it as it is: a dword that holds at least
 // one pixel byte lies in the same page as that byte.  The emulation assembles it from the bytes that
@@ -491,10 +549,23 @@ template <int MODE> PIXO_DEV void producer_color_item(int k, int lane, const uin
 {
     const int h = k & 1, g = h * 64 + lane, row = k >> 1;
     if (MODE == M420) {
+        uint8_t *yp = planar + h * 4352 + (2 * row) * kPitchHalf + 4 * lane;
+#if defined(PIXO_COLOR_DOT4) || defined(PIXO_EMU_COLOR_DOT4)
+        {
+            const Row4D a = color_row4_dot(r[0], r[1], r[2]);
+            PIXO_SCHED_FENCE(); // one row at a time: few temporaries
+            const Row4D b = color_row4_dot(r[3], r[4], r[5]);
+            *(uint32_t *)yp = a.y4;
+            *(uint32_t *)(yp + kPitchHalf) = b.y4;
+            // 2x2 box sums (jpeg/mod.rs:1641-1646), u16 exact (<= 1020); the two rows' halves never carry into each other
+            *(uint32_t *)(planar + 8704 + row * 512 + 4 * g) = add_bytes1(a.cb[0], a.cb[1], a.cb[2], a.cb[3]) + add_bytes1(b.cb[0], b.cb[1], b.cb[2], b.cb[3]);
+            *(uint32_t *)(planar + 12800 + row * 512 + 4 * g) = add_bytes1(a.cr[0], a.cr[1], a.cr[2], a.cr[3]) + add_bytes1(b.cr[0], b.cr[1], b.cr[2], b.cr[3]);
+            return;
+        }
+#endif
         Row4 a = color_row4(r[0], r[1], r[2]);
         PIXO_SCHED_FENCE(); // one row at a time: few temporaries
         Row4 b = color_row4(r[3], r[4], r[5]);
-        uint8_t *yp = planar + h * 4352 + (2 * row) * kPitchHalf + 4 * lane;
         *(uint32_t *)yp = a.y4;
         *(uint32_t *)(yp + kPitchHalf) = b.y4;
         // 2x2 box sums (jpeg/mod.rs:1641-1646) of the high bytes, u16 exact (<= 1020):
@@ -807,6 +878,68 @@ template <int MODE> PIXO_DEV void consumer_quant(int wave, int lane, const float
     const BlockDesc d = block_desc<MODE>(wave, lane, nullptr);
     const qtab_t tab = as_qtab(qt);
     block_quant(v, tab + uniform_i32(d.rcp_off), tab + uniform_i32(d.q_off), d.scale, out);
+}
+
+// The same with the bracketing reciprocals in VECTOR registers, read from a copy of the table in LDS (every lane the
+// same address: a broadcast read).  A VALU instruction with a scalar-register operand issues at half rate on gfx950
+// (tools/ubench/form_rate.hip: v_fma_f32 v, s, v 4.2 cycles; v_fmaak_f32 v, v, v, K 2.1): with the reciprocals in
+// VGPRs the two roundings of a coefficient cost 4.2 cycles instead of 8.4.  Only four coefficients' worth (eight
+// registers) are alive at a time, fetched right before their use — the other five wavefronts of the SIMD cover the
+// LDS latency — because the block's 64 floats are still alive when the quantiser starts.
+// LDS layout (floats): kind k at [128 k, 128 k + 128) = rlo[64], rhi[64]; kind 0 = luminance, kind 1 = chrominance
+// (4:2:0: the table for the 2x2 sums).
+constexpr int kQuantLdsFloats = 256;
+template <int MODE> PIXO_DEV int quant_lds_source(int i) // which float of the quality's table block goes to LDS float i
+{
+    return (i < 128 ? 0 : (MODE == M420 ? 384 : 256) - 128) + i;
+}
+struct alignas(16) f32x4 { float x, y, z, w; };
+// four coefficients: quant_row4 with the reciprocals read from LDS at `lq` (rlo) and `lq + 64` (rhi).  The rare path
+// reads them again instead of keeping them: the registers are needed for the block's floats.
+PIXO_DEV void quant_row4_lds(const float *x, const float *lq, qtab_t q, float scale, uint32_t out[2])
+{
+    float s[4];
+    uint32_t differ = 0;
+    {
+        const f32x4 l4 = *(const f32x4 *)lq, h4 = *(const f32x4 *)(lq + 64);
+        differ |= quant_bracket(x[0], l4.x, h4.x, &s[0]);
+        differ |= quant_bracket(x[1], l4.y, h4.y, &s[1]);
+        differ |= quant_bracket(x[2], l4.z, h4.z, &s[2]);
+        differ |= quant_bracket(x[3], l4.w, h4.w, &s[3]);
+    }
+    if (PIXO_ANY_LANE(differ != 0)) { // rare: some quotient next to a rounding boundary
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float xc = x[c], t;
+            PIXO_PIN(xc);
+            if (PIXO_ANY_LANE(quant_bracket(xc, lq[c], lq[64 + c], &t) != 0)) {
+                const float n = __builtin_roundf((x[c] * scale) / q[c]); // the reference operation itself
+                s[c] = n + kRoundMagic;                                   // exact: |n| < 2^15
+            }
+            PIXO_SCHED_FENCE();
+        }
+    }
+    out[0] = perm(fbits(s[1]), fbits(s[0]), 0x05040100u);
+    out[1] = perm(fbits(s[3]), fbits(s[2]), 0x05040100u);
+}
+PIXO_DEV void block_quant_lds(const float *v, const float *lq, qtab_t q, float scale, uint32_t *out)
+{
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const int at = u * 8 + hh * 4;
+            quant_row4_lds(&v[at], lq + at, q + at, scale, &out[u * 4 + hh * 2]);
+            PIXO_PIN(out[u * 4 + hh * 2]); PIXO_PIN(out[u * 4 + hh * 2 + 1]);
+            PIXO_SCHED_FENCE();
+        }
+    }
+}
+template <int MODE> PIXO_DEV void consumer_quant_lds(int wave, int lane, const float *qt, const float *ldsq, const float *v, uint32_t *out)
+{
+    const BlockDesc d = block_desc<MODE>(wave, lane, nullptr);
+    const qtab_t tab = as_qtab(qt);
+    block_quant_lds(v, ldsq + uniform_i32(d.rcp_off ? 128 : 0), tab + uniform_i32(d.q_off), d.scale, out);
 }
 
 // Consumer step 4' (round h = 0, 1): the lanes of half h stage their blocks.

@@ -1,0 +1,402 @@
+// pieces.cpp — whole baseline files from a device tuple (or from pixels not transformed yet): a scan coded in PIECES so
+// that the file's way to the host overlaps the coding, the one-piece path, delivery into pinned / caller / malloc'd memory.
+#include <algorithm>
+
+#include "capi_internal.hpp"
+
+namespace pixo_capi {
+
+// One uninterrupted scan of a large image, coded in PIECES so that the file's way to the host (0.21 of the 0.31 ms of a
+// 4096x4096 noise image, 3.3 of 4.4 ms for 16384x16384) overlaps the coding: piece k = a run of consecutive groups,
+// coded and stuffed by its own launch pair; the pieces hand each other the bit position and the byte position on the
+// device (pixo_dev::ScanPiece), the host only waits for piece k's event to learn how many bytes it may copy — on a second
+// stream — while piece k + 1 is being coded.  The bytes are the same as from one launch pair; a piece whose stream
+// outgrows the guess its stuffing grid was sized for, or an output buffer that proves too small, sends the caller back
+// to the one-piece path (return value 1; nothing of the result is kept).
+constexpr uint32_t kMaxPieces = 16;
+// Piece sizes (debug switches piece_groups / piece_medium / piece_schedule, capi_internal.hpp):
+//  * a piece is at least debug().piece_groups (2048) groups of 192 blocks, and a scan of fewer than two such pieces is not cut
+//    into equal pieces.  2048 groups = the scan of a 4096x4096 4:2:0 image: the kernels of a smaller piece are mostly
+//    start-up — a sixth of that scan takes 28 us where the whole takes 52 — and a 4096x4096 image in 2 or 6 equal pieces is
+//    no faster than in one (0.30-0.33 against 0.31 ms); a 16384x16384 scan in 16 such pieces hides its 1 ms of coding
+//    behind 3.4 ms of PCIe;
+//  * medium scans (debug().piece_medium (1024) <= groups < 2 piece_groups): a few pieces that GROW, relative sizes
+//    debug().piece_schedule ("1:3").  4096x4096 noise, 11 MB file, into pinned memory: one piece 0.313 ms, "1:3" 0.301,
+//    "1:2:5" 0.302, "1:2:3:4" 0.315; with the coefficient kernel band by band as well: "1:3" 0.291, "1:2:5" 0.299, "1:5" 0.310
+//    (tools/gpu/r2w.sh): the first piece's bytes leave 60 us after the start instead of 100, the rest is the file's
+//    0.21 ms on PCIe.
+inline bool pieces_enabled() { return !debug().one_piece; }
+inline uint64_t piece_min_groups() { return debug().piece_groups; }
+inline const std::vector<uint32_t> &piece_schedule() { return debug().piece_schedule; }
+inline bool piece_medium_forced() { return debug().piece_medium_forced; }
+inline uint64_t piece_medium_groups() { return debug().piece_medium; }
+inline bool direct_host_stores() { return debug().direct_stores; }
+
+// Pixels whose coefficients have not been computed yet (the tuple's place is reserved, j.a points at it): the entropy
+// stage launches the coefficient kernel itself — for a scan coded in pieces, band by band in front of each piece, so
+// that the first piece's bytes can leave before the rest of the image has even been transformed.
+
+int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *dst, size_t dst_cap, uint64_t *scan_bytes,
+                          const PixelSource *src)
+{ // dst: where the stuffed scan goes on the host (dst_cap bytes available); tables are uploaded, j.a is set up
+    namespace pd = pixo_dev;
+    const uint64_t kGroupBlocks = 192, groups = (j.n + kGroupBlocks - 1) / kGroupBlocks;
+    // where the pieces begin (in groups).  A large scan: equal pieces of at least piece_min_groups().  A medium one (a
+    // 4096x4096 image): a few pieces that GROW — the first small, so that its bytes leave early, each next one coded
+    // while the one before travels (weights from piece_schedule()).
+    uint64_t begin[kMaxPieces + 1];
+    uint32_t pieces = 0;
+    if (groups >= 2 * piece_min_groups()) {
+        const uint64_t per = std::max<uint64_t>((groups + kMaxPieces - 1) / kMaxPieces, piece_min_groups());
+        for (uint64_t g0 = 0; g0 < groups; g0 += per) begin[pieces++] = g0; // (none is empty)
+    } else {
+        const std::vector<uint32_t> &w = piece_schedule();
+        uint64_t sum = 0, acc = 0;
+        for (uint32_t x : w) sum += x;
+        for (size_t i = 0; i < w.size() && pieces < kMaxPieces; ++i) {
+            const uint64_t g0 = groups * acc / sum;
+            if (pieces == 0 || g0 > begin[pieces - 1]) begin[pieces++] = g0;
+            acc += w[i];
+        }
+    }
+    begin[pieces] = groups;
+    // coefficient bands in front of the pieces: only where a piece can begin with an MCU row (the groups of 192 blocks and
+    // the MCU rows must share boundaries: 4:2:0 widths that are multiples of 512, 4:4:4 of 512, gray of 1536)
+    uint64_t groups_per_row = 0;
+    if (src) {
+        const uint32_t unit = (!src->g->gray && src->g->s420) ? 16u : 8u, units_x = (src->o->width + unit - 1) / unit;
+        const uint64_t row_blocks = static_cast<uint64_t>(units_x) * j.a.blocks_per_mcu;
+        if (row_blocks % kGroupBlocks == 0) {
+            groups_per_row = row_blocks / kGroupBlocks;
+            uint32_t kept = 1; // (piece 0 begins at row 0)
+            for (uint32_t k = 1; k < pieces; ++k) {
+                const uint64_t g0 = begin[k] / groups_per_row * groups_per_row;
+                if (g0 > begin[kept - 1]) begin[kept++] = g0;
+            }
+            pieces = kept;
+            begin[pieces] = groups;
+        } else { // (no common boundaries: the whole image first)
+            const int rc = coeffs_rows(c, src->d_px, *src->o, *src->g, stream, src->dy, src->dcb, src->dcr, 0, 0);
+            if (rc) return rc;
+        }
+    }
+    if (!c.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+    while (c.piece_done.size() < pieces) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c.piece_done.push_back(e);
+    }
+    HIP_TRY(c.e_chain.reserve(2 * (kMaxPieces + 1) * 8));
+    unsigned long long *bits_chain = c.e_chain.as<unsigned long long>(), *out_chain = bits_chain + kMaxPieces + 1;
+    const size_t out_cap = std::max<size_t>(j.stream_cap / 4, 4096);
+    HIP_TRY(c.e_out.reserve(out_cap));
+    // every piece has its own part of the stream buffer (a block has at most 209 bytes; 64 bytes of slack per piece)
+    struct Piece { uint64_t first_block, blocks, tiles; uint32_t *stream; };
+    Piece pc[kMaxPieces];
+    for (uint32_t k = 0; k < pieces; ++k) {
+        pc[k].first_block = std::min<uint64_t>(j.n, begin[k] * kGroupBlocks);
+        pc[k].blocks = std::min<uint64_t>(j.n, begin[k + 1] * kGroupBlocks) - pc[k].first_block;
+        pc[k].tiles = pd::stuff_tiles(pc[k].blocks * 64 + 4096);
+    }
+    HIP_TRY(c.e_stream.reserve(j.stream_cap + 80 * kMaxPieces));
+    for (uint32_t k = 0; k < pieces; ++k) pc[k].stream = c.e_stream.as<uint32_t>() + (pc[k].first_block * 209 + 64 * k + 15) / 16 * 4;
+    const size_t state_words = pd::fused_code_state_words(j.n);
+    Stopwatch sw;
+    for (uint32_t k = 0; k < pieces; ++k) {
+        pd::ScanArgs a = j.a;
+        a.nblocks = pc[k].blocks;
+        a.pad_last = k + 1 == pieces ? 1u : 0u;
+        const pd::ScanPiece piece{pc[k].first_block, k, bits_chain, k ? pc[k - 1].stream : nullptr};
+        unsigned long long *mail = reinterpret_cast<unsigned long long *>(c.h_totals) + 4 * k;
+        const bool zero = c.code_state_zero_words >= state_words;
+        c.code_state_zero_words = 0;
+        if (groups_per_row) { // this piece's MCU rows through the coefficient kernel
+            const uint32_t row0 = static_cast<uint32_t>(begin[k] / groups_per_row);
+            const uint32_t rows = k + 1 == pieces ? 0u : static_cast<uint32_t>(begin[k + 1] / groups_per_row) - row0;
+            const int rc = coeffs_rows(c, src->d_px, *src->o, *src->g, stream, src->dy, src->dcb, src->dcr, row0, rows);
+            if (rc) return rc;
+        }
+        HIP_TRY(pd::launch_scan_code(a, c.e_code_state.as<unsigned long long>(), zero, pc[k].stream, c.e_stuff_state.as<unsigned long long>(),
+                                     pd::fused_stuff_state_words(j.stream_cap), mail, stream, &piece));
+        HIP_TRY(pd::launch_stuff_fused(pc[k].stream, c.e_code_state.as<unsigned long long>(), state_words, 0, /*band=*/k + 1 != pieces,
+                                       j.stream_cap, 0, pc[k].tiles, c.e_stuff_state.as<unsigned long long>(), /*state_is_zero=*/true,
+                                       c.e_out.as<uint8_t>(), c.e_out.cap, mail, stream, out_chain, k));
+        c.code_state_zero_words = state_words;
+        HIP_TRY(hipEventRecord(c.piece_done[k], stream));
+    }
+    uint64_t done = 0; // bytes of the scan that are on their way to the host
+    bool redo = false;
+    sw.lap("  pieces enqueued");
+    for (uint32_t k = 0; k < pieces; ++k) {
+        HIP_TRY(hipEventSynchronize(c.piece_done[k]));
+        sw.lap("  piece coded");
+        if (redo) continue; // (still wait for everything that was enqueued)
+        const uint64_t *mail = c.h_totals + 4 * k;
+        const uint64_t stream_bits = mail[0], packed = k + 1 != pieces ? stream_bits / 8 : (stream_bits + 7) / 8;
+        if (pd::stuff_tiles(packed) > pc[k].tiles) { redo = true; continue; } // (the stuffing grid was a guess: this piece is not complete)
+        const uint64_t bytes = mail[1];
+        if (done + bytes > c.e_out.cap || done + bytes > dst_cap) { redo = true; continue; }
+        if (bytes) HIP_TRY(hipMemcpyAsync(dst + done, c.e_out.as<uint8_t>() + done, bytes, hipMemcpyDeviceToHost, c.copy_stream));
+        done += bytes;
+        sw.lap("  copy enqueued");
+    }
+    HIP_TRY(hipStreamSynchronize(c.copy_stream));
+    sw.lap("  copies done");
+    if (redo) return 1;
+    *scan_bytes = done;
+    return PIXO_OK;
+}
+
+// Device coefficient tuple -> whole file in the context's PINNED host buffer (headers written by
+// the host, entropy-coded segment by the kernels of jpeg_entropy.hip and copied straight behind
+// them).  Pinned on purpose: a device-to-host copy into fresh pageable memory makes the runtime
+// pin those pages first, which costs 10-25 ms for an 11 MB file every time the address changes.
+// batch > 1 (standard tables, no restart markers): the tuples of `batch` equal images back to back;
+// every image is a byte-aligned segment of ONE packed stream.  Then *file = headers (once) followed by
+// all the entropy-coded segments, and image_starts[i] (batch + 1 entries) are their offsets behind the
+// headers; no EOI is written.
+int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+                             const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len,
+                             uint32_t batch, std::vector<uint64_t> *image_starts, size_t *header_len,
+                             uint8_t *dest, size_t dest_cap, bool *own_malloc, const PixelSource *src)
+{ // src != null: the tuple (dy, dcb, dcr = src's) has not been computed yet, see PixelSource.
+  // dest != null: the file goes straight into the caller's storage (no pinned intermediate); when it does not
+  // fit, *file_len says how much is needed and nothing is copied (PIXO_ERR_BUFFER_TOO_SMALL).
+  // own_malloc != null (and no dest): the caller wants the file in malloc'd memory it will own — once the size is known
+  // the block is allocated and the device-to-host copy goes straight into it (*own_malloc = true, *file = the block);
+  // the copy into pageable memory runs at the link's rate, and what it saves is the second pass over the file from
+  // the pinned buffer (tools/ubench/upload.cpp: 0.21 ms + a warm 11 MB memcpy, or 1.30 against 1.38 ms for new pages).
+  // *own_malloc stays false when the file was assembled in the pinned buffer after all (a scan coded in pieces).
+    if (own_malloc) *own_malloc = false;
+    namespace pd = pixo_dev;
+    Stopwatch sw;
+    ScanJob j;
+    int rc = scan_begin(c, j, dy, dcb, dcr, o, g, batch, nullptr);
+    if (rc) return rc;
+    sw.lap("  reserve");
+    std::vector<uint8_t> head;
+    // a large scan: in pieces, the file leaving for the host while the rest is still being coded — into the context's
+    // pinned buffer, or into the caller's storage if that can hold any file the stuffing grids are sized for (a smaller
+    // one might not fit the file, and then nothing may have been written to it: one piece, size first)
+    const size_t likely_most = 1024 + static_cast<size_t>(j.n) * 64 + 8192;
+    // A medium scan in pieces only pays when the file is large (a 0.3 MB file of a smooth 4096x4096 image: 0.12 ms in one
+    // piece, more in two): the context remembers the bytes per block of its last scan and cuts the next one only when that
+    // was 12 or more (a stream of similar images; the first one is coded in one piece).
+    const uint64_t scan_groups = (j.n + 191) / 192;
+    const bool large = scan_groups >= 2 * piece_min_groups();
+    const bool medium = !large && scan_groups >= piece_medium_groups() && (c.packed_per_block >= 12 || piece_medium_forced());
+    // (Not for a caller that wants a malloc'd block of its own: the block would have to be allocated before the size is
+    // known — 64 bytes per block, cut to size afterwards — and a block of a new size is new pages every call, which the
+    // device-to-host copy has to fault in and pin: 20 ms instead of 0.7 for the 4096x4096 noise image.  One piece, the
+    // exact size, recycled by malloc.)
+    if (j.fused && batch == 1 && pieces_enabled() && !direct_host_stores() && (large || medium) && (!dest || dest_cap >= likely_most) &&
+        !(own_malloc && !dest)) {
+        if (src && o.optimize_huffman) { // (the statistics need the whole tuple)
+            if ((rc = coeffs_rows(c, src->d_px, o, g, stream, src->dy, src->dcb, src->dcr, 0, 0))) return rc;
+            src = nullptr;
+        }
+        if ((rc = scan_tables(c, j, o, g, stream, nullptr))) return rc;
+        pixo_host::file_headers(head, o, j.h);
+        const size_t hdr = head.size();
+        uint8_t *buf = dest;
+        size_t cap = dest_cap;
+        if (!buf) {
+            if ((rc = c.reserve_hfile(likely_most))) return rc;
+            buf = c.h_file;
+            cap = c.hfile_cap;
+        }
+        uint64_t scan_bytes = 0;
+        rc = device_entropy_pieces(c, j, stream, buf + hdr, cap - hdr - 2, &scan_bytes, src);
+        src = nullptr; // (the tuple is complete now, whatever happened)
+        sw.lap("code+stuff+copy (pieces)");
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            c.packed_per_block = static_cast<uint32_t>(scan_bytes / (j.n ? j.n : 1));
+            const size_t total = hdr + scan_bytes + 2;
+            std::memcpy(buf, head.data(), hdr);
+            buf[hdr + scan_bytes] = 0xFF; // EOI
+            buf[hdr + scan_bytes + 1] = 0xD9;
+            *file = buf;
+            *file_len = total;
+            if (header_len) *header_len = hdr;
+            return PIXO_OK;
+        }
+        c.code_state_zero_words = 0; // (rc == 1: start over in one piece, below)
+    }
+    if (src && (rc = coeffs_rows(c, src->d_px, o, g, stream, src->dy, src->dcb, src->dcr, 0, 0))) return rc; // one piece: the whole image first
+    if (j.fused) { // code + stuff back to back, one read-back
+        if ((rc = scan_lengths(c, j, o, g, stream, nullptr, /*wait=*/false))) return rc;
+        // One image into host memory the GPU can write — the context's pinned file buffer, or storage of the caller's
+        // that is pinned / registered: the stuffing kernel stores straight into it, behind the place of the headers.
+        HostTarget target;
+        bool direct = false;
+        if (batch == 1 && direct_host_stores()) {
+            pixo_host::file_headers(head, o, j.h); // (the tables are known since scan_lengths)
+            if (!dest) {
+                target.grow = true;
+                target.before = head.size();
+                target.after = 2;
+                direct = true;
+            } else if (dest_cap > head.size() + 2) {
+                hipPointerAttribute_t at;
+                if (hipPointerGetAttributes(&at, dest) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+                    target.p = static_cast<uint8_t *>(at.devicePointer) + head.size();
+                    target.cap = dest_cap - head.size() - 2;
+                    direct = true;
+                } else {
+                    (void)hipGetLastError(); // (plain malloc'd memory: not an error, the copy below handles it)
+                }
+            }
+        }
+        if ((rc = scan_stuff_fused(c, j, stream, 0, nullptr, nullptr, nullptr, /*chained=*/true, direct ? &target : nullptr))) return rc;
+        sw.lap("code+stuff (fused)");
+        if (direct) {
+            const size_t hdr = head.size(), total = hdr + j.scan_bytes + 2;
+            if (dest && j.scan_bytes > target.cap) {
+                *file_len = total;
+                return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(total) + " bytes");
+            }
+            uint8_t *buf = dest ? dest : c.h_file;
+            std::memcpy(buf, head.data(), hdr);
+            buf[hdr + j.scan_bytes] = 0xFF; // EOI
+            buf[hdr + j.scan_bytes + 1] = 0xD9;
+            *file = buf;
+            *file_len = total;
+            if (header_len) *header_len = hdr;
+            return PIXO_OK;
+        }
+    } else {
+        if ((rc = scan_lengths(c, j, o, g, stream, nullptr))) return rc;
+        sw.lap("tables+lengths+scan");
+        if ((rc = scan_pack(c, j, stream))) return rc;
+        sw.lap("memset+pack+ff census");
+    }
+    const uint64_t scan_bytes = j.scan_bytes;
+    if (batch == 1 && j.n) c.packed_per_block = static_cast<uint32_t>(scan_bytes / j.n);
+    if (batch > 1) { // where every image's segment begins in the stuffed stream (reuses the seg_bytes buffer: 8 B/entry)
+        HIP_TRY(c.e_seg_bytes.reserve(j.nseg * 8));
+        HIP_TRY(pd::launch_segment_out_offsets(j.plan, j.nbytes, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
+                                               c.e_seg_bytes.as<uint64_t>(), stream));
+        image_starts->assign(batch + 1, 0);
+        HIP_TRY(hipMemcpyAsync(image_starts->data(), c.e_seg_bytes.p, j.nseg * 8, hipMemcpyDeviceToHost, stream));
+        (*image_starts)[batch] = scan_bytes;
+    }
+    head.clear();
+    pixo_host::file_headers(head, o, j.h);
+    const size_t hdr = head.size(), total = hdr + scan_bytes + 2;
+    uint8_t *buf = dest;
+    bool mine = false;
+    if (dest) {
+        if (total > dest_cap) {
+            *file_len = total;
+            return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(total) + " bytes");
+        }
+    } else if (own_malloc && batch == 1) {
+        buf = static_cast<uint8_t *>(std::malloc(total));
+        if (!buf) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
+        mine = true;
+    } else {
+        if ((rc = c.reserve_hfile(total))) return rc;
+        buf = c.h_file;
+    }
+    std::memcpy(buf, head.data(), hdr);
+    hipError_t ce = hipMemcpyAsync(buf + hdr, c.e_out.p, scan_bytes, hipMemcpyDeviceToHost, stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(stream);
+    if (ce != hipSuccess) {
+        if (mine) std::free(buf);
+        return hip_fail(ce, "device-to-host copy of the file");
+    }
+    if (mine) *own_malloc = true;
+    buf[hdr + scan_bytes] = 0xFF; // EOI (of the only image; batches append it per file)
+    buf[hdr + scan_bytes + 1] = 0xD9;
+    *file = buf;
+    *file_len = total;
+    if (header_len) *header_len = hdr;
+    sw.lap("stuff+copy to host");
+    return PIXO_OK;
+}
+
+// Copies into FRESH host memory are page-fault bound (one core maps and fills a few GB/s of new pages):
+// above a few MB the bytes are spread over a handful of threads (PIXO_HIP_COPY_THREADS, default 8; 1 = none).
+inline unsigned copy_threads() { return debug().copy_threads; }
+void big_copy(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    constexpr size_t kSlice = size_t{1} << 20;
+    const size_t slices = (n + kSlice - 1) / kSlice;
+    const unsigned t = static_cast<unsigned>(std::min<size_t>(copy_threads(), slices / 2));
+    if (t <= 1) { std::memcpy(dst, src, n); return; }
+    run_on_threads(t, [&](unsigned i) {
+        const size_t a = slices * i / t * kSlice, b = std::min(n, slices * (i + 1) / t * kSlice);
+        if (b > a) std::memcpy(dst + a, src + a, b - a);
+    });
+}
+
+// ... and into memory the caller owns: a fresh malloc block, or storage it supplied
+int deliver(const uint8_t *file, size_t n, uint8_t **out, size_t *out_len)
+{
+    uint8_t *p = static_cast<uint8_t *>(std::malloc(n ? n : 1));
+    if (!p) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
+    big_copy(p, file, n);
+    *out = p;
+    *out_len = n;
+    return PIXO_OK;
+}
+
+int device_entropy_to_malloc(Context &c, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+                             const pixo_host::Geometry &g, hipStream_t stream, uint8_t **out_buf, size_t *out_len)
+{
+    const uint8_t *file = nullptr;
+    size_t n = 0;
+    bool own = false;
+    int rc = device_entropy_to_pinned(c, dy, dcb, dcr, o, g, stream, &file, &n, 1, nullptr, nullptr, nullptr, 0, &own);
+    if (rc) return rc;
+    if (own) { // (already in a block of its own)
+        *out_buf = const_cast<uint8_t *>(file);
+        *out_len = n;
+        return PIXO_OK;
+    }
+    return deliver(file, n, out_buf, out_len);
+}
+
+int hand_over(const std::vector<uint8_t> &v, uint8_t **out, size_t *out_len)
+{
+    uint8_t *p = static_cast<uint8_t *>(std::malloc(v.size() ? v.size() : 1));
+    if (!p) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
+    big_copy(p, v.data(), v.size());
+    *out = p;
+    *out_len = v.size();
+    return PIXO_OK;
+}
+
+int device_tuple_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+                           const pixo_host::Geometry &g, Context &c, uint8_t **out, size_t *out_len)
+{
+    if (!debug().host_entropy) {
+        if (!o.progressive) return device_entropy_to_malloc(c, dy, dcb, dcr, o, g, c.stream, out, out_len);
+        pixo_host::HuffSet h;
+        int rc = huffman_for_tuple(dy, dcb, dcr, o, g, c, h);
+        if (rc) return rc;
+        std::vector<uint8_t> head;
+        pixo_host::file_headers(head, o, h);
+        const uint8_t *file = nullptr;
+        size_t n = 0;
+        if ((rc = device_progressive_scans(dy, dcb, dcr, g, h, c, head, &file, &n))) return rc;
+        return deliver(file, n, out, out_len);
+    }
+    // for experiments, the host twin of the scan coders: host code on a copy of the tuple
+    const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128;
+    int rc = c.reserve_hcoef(coef_bytes);
+    if (rc) return rc;
+    int16_t *hy = static_cast<int16_t *>(c.h_coef), *hcb = hy + g.y_blocks * 64, *hcr = hcb + g.c_blocks * 64;
+    HIP_TRY(hipMemcpyAsync(hy, dy, g.y_blocks * 128, hipMemcpyDeviceToHost, c.stream));
+    if (g.c_blocks) {
+        HIP_TRY(hipMemcpyAsync(hcb, dcb, g.c_blocks * 128, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipMemcpyAsync(hcr, dcr, g.c_blocks * 128, hipMemcpyDeviceToHost, c.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    std::vector<uint8_t> v;
+    pixo_host::encode_file(hy, hcb, hcr, o, v);
+    return hand_over(v, out, out_len);
+}
+
+} // namespace pixo_capi

@@ -1,0 +1,196 @@
+// progressive.cpp — preset 2 ("max"): Huffman statistics of a tuple, the trellis-quantised tuple, the seven progressive
+// scans of simple_progressive_script coded on the device.
+#include "capi_internal.hpp"
+#include "jpeg_trellis.hpp"
+
+namespace pixo_capi {
+
+// The seven scans of simple_progressive_script (progressive.rs:98-110) coded by the kernels of
+// jpeg_entropy.hip over the device tuple; `out` already holds the file headers.  All scans are ONE
+// packed stream of byte-aligned segments (the virtual block order is scan by scan, storage order inside
+// a scan), so lengths / prefix sum / pack / 0xFF stuffing run once; the host only splices the seven SOS
+// headers between the stuffed segments.
+// The file is assembled in the context's pinned buffer: `head` (the file headers), then per scan its SOS header and its
+// stuffed segment — every segment copied from the device straight to its final place — then EOI.  (Round 1 copied the
+// stuffed stream to the host in one piece and spliced it into a std::vector, which the caller copied once more: two
+// extra passes over the file through freshly mapped pages, about half of the 2.3 ms of a 4096x4096 preset-2 file.)
+int device_progressive_scans(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_host::Geometry &g,
+                             const pixo_host::HuffSet &h, Context &c, const std::vector<uint8_t> &head, const uint8_t **file,
+                             size_t *file_len)
+{
+    namespace pd = pixo_dev;
+    Stopwatch sw;
+    hipStream_t stream = c.stream;
+    pd::ProgArgs a;
+    a.y = dy; a.cb = g.gray ? dy : dcb; a.cr = g.gray ? dy : dcr;
+    const uint64_t size[7] = {g.y_blocks, g.c_blocks, g.c_blocks, g.y_blocks, g.y_blocks, g.c_blocks, g.c_blocks};
+    a.first[0] = 0;
+    for (int i = 0; i < 7; ++i) a.first[i + 1] = a.first[i] + size[i];
+    const uint64_t n = a.first[7];
+    HIP_TRY(c.e_tables.reserve(pixo_scan::kScanTableUpload * 4));
+    HIP_TRY(c.g_flags.reserve(n * 4));
+    HIP_TRY(c.g_rank.reserve(n * 8));
+    HIP_TRY(c.g_by_rank.reserve(n * 4));
+    HIP_TRY(c.e_len.reserve(n * 4));
+    HIP_TRY(c.e_off.reserve(n * 8));
+    HIP_TRY(c.e_seg_bytes.reserve(8 * 8));
+    HIP_TRY(c.e_seg_off.reserve(8 * 8));
+    // a block of an AC scan: at most 63 * 26 bits + an end-of-band run of at most 16 + 14 bits
+    const size_t tmp_blocks = pd::scan_tile_count(n) + 1, tmp_segs = pd::scan_tile_count(7) + 1;
+    const size_t tmp_tiles = pd::scan_tile_count(pd::stuff_tile_count(n * 212 + 64)) + 1;
+    HIP_TRY(c.e_tmp.reserve((tmp_blocks + tmp_segs + tmp_tiles) * 8));
+    HIP_TRY(c.e_totals.reserve(32));
+    { const int rc_t = c.ensure_totals(); if (rc_t) return rc_t; }
+    a.tables = c.e_tables.as<uint32_t>();
+    a.flags = c.g_flags.as<uint32_t>();
+    a.nonempty = c.e_len.as<uint32_t>(); // only the input of the rank prefix sum: the lengths reuse it
+    a.rank = c.g_rank.as<uint64_t>();
+    a.by_rank = c.g_by_rank.as<uint32_t>();
+
+    uint32_t packed[pixo_host::kScanTableWords];
+    pixo_host::pack_scan_tables(h, packed);
+    for (uint32_t &w : packed) // progressive.rs:363-381: a symbol the table lacks is coded as (0, 4 bits)
+        if ((w >> 16) == 0) w = 4u << 16;
+    { const int rc = upload_scan_tables(c, packed, stream); if (rc) return rc; }
+    uint64_t *totals = c.e_totals.as<uint64_t>();
+    HIP_TRY(pd::launch_prog_flags(a, stream));
+    HIP_TRY(pd::launch_exclusive_scan(a.nonempty, n, c.g_rank.as<uint64_t>(), c.e_tmp.as<uint64_t>(), totals + 2, stream));
+    HIP_TRY(pd::launch_prog_by_rank(a, stream));
+    HIP_TRY(pd::launch_prog_lengths(a, c.e_len.as<uint32_t>(), stream));
+    HIP_TRY(pd::launch_exclusive_scan(c.e_len.as<uint32_t>(), n, c.e_off.as<uint64_t>(), c.e_tmp.as<uint64_t>(), totals, stream));
+    HIP_TRY(pd::launch_prog_segment_sizes(a, c.e_off.as<uint64_t>(), totals, c.e_seg_bytes.as<uint32_t>(), stream));
+    HIP_TRY(pd::launch_exclusive_scan(c.e_seg_bytes.as<uint32_t>(), 7, c.e_seg_off.as<uint64_t>(), c.e_tmp.as<uint64_t>() + tmp_blocks,
+                                      totals + 1, stream));
+    HIP_TRY(hipMemcpyAsync(c.h_totals, totals, 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    sw.lap("prog flags+rank+lengths");
+    const uint64_t total_bits = c.h_totals[0], nbytes = c.h_totals[1];
+    const size_t stream_bytes = (nbytes / 4 + 2) * 4;
+    HIP_TRY(c.e_stream.reserve(stream_bytes));
+    HIP_TRY(hipMemsetAsync(c.e_stream.p, 0, stream_bytes, stream));
+    HIP_TRY(pd::launch_prog_pack(a, c.e_off.as<uint64_t>(), total_bits, c.e_seg_off.as<uint64_t>(), c.e_stream.as<uint32_t>(), stream));
+    const size_t tiles = pd::stuff_tile_count(nbytes);
+    HIP_TRY(c.e_tile_ff.reserve(tiles * 4));
+    HIP_TRY(c.e_tile_base.reserve(tiles * 8));
+    HIP_TRY(pd::launch_ff_tile_count(c.e_stream.as<uint32_t>(), nbytes, c.e_tile_ff.as<uint32_t>(), stream));
+    HIP_TRY(pd::launch_exclusive_scan(c.e_tile_ff.as<uint32_t>(), tiles, c.e_tile_base.as<uint64_t>(),
+                                      c.e_tmp.as<uint64_t>() + tmp_blocks + tmp_segs, totals + 1, stream));
+    HIP_TRY(hipMemcpyAsync(c.h_totals + 1, totals + 1, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    sw.lap("prog pack+ff census");
+    const uint64_t scan_bytes = nbytes + c.h_totals[1];
+    HIP_TRY(c.e_out.reserve(scan_bytes + 16));
+    HIP_TRY(pd::launch_stuff(c.e_stream.as<uint32_t>(), nbytes, c.e_tile_base.as<uint64_t>(), c.e_out.as<uint8_t>(), stream));
+    const pd::SegmentPlan plan{7, c.e_seg_off.as<uint64_t>()};
+    HIP_TRY(pd::launch_segment_out_offsets(plan, nbytes, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
+                                           c.g_rank.as<uint64_t>(), stream)); // the rank array is free again
+    uint64_t start[8];
+    HIP_TRY(hipMemcpyAsync(start, c.g_rank.p, 7 * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    start[7] = scan_bytes;
+    for (int i = 6; i >= 0; --i)
+        if (start[i] == ~0ull) start[i] = start[i + 1]; // empty scans at the end of the stream
+    const size_t total = head.size() + 7 * 10 + scan_bytes + 2;
+    int rc = c.reserve_hfile(total);
+    if (rc) return rc;
+    uint8_t *p = c.h_file;
+    std::memcpy(p, head.data(), head.size());
+    size_t pos = head.size();
+    static const uint8_t script[7][3] = {{0, 0, 0}, {1, 0, 0}, {2, 0, 0}, {0, 1, 10}, {0, 11, 63}, {1, 1, 63}, {2, 1, 63}};
+    for (int i = 0; i < 7; ++i) { // write_sos_progressive, jpeg/mod.rs:650-682
+        const uint8_t sos[10] = {0xFF, 0xDA, 0, 8, 1, static_cast<uint8_t>(script[i][0] + 1),
+                                 static_cast<uint8_t>(script[i][0] == 0 ? 0x00 : 0x11), script[i][1], script[i][2], 0};
+        std::memcpy(p + pos, sos, 10);
+        pos += 10;
+        const size_t n = static_cast<size_t>(start[i + 1] - start[i]);
+        if (n) HIP_TRY(hipMemcpyAsync(p + pos, c.e_out.as<uint8_t>() + start[i], n, hipMemcpyDeviceToHost, stream));
+        pos += n;
+    }
+    p[pos] = 0xFF; p[pos + 1] = 0xD9;
+    HIP_TRY(hipStreamSynchronize(stream));
+    *file = p;
+    *file_len = pos + 2;
+    sw.lap("prog stuff+copy+splice");
+    return PIXO_OK;
+}
+
+// Huffman tables of a file over the device tuple: the standard ones, or (optimize_huffman) those built
+// from the statistics of a baseline walk (build_optimized_huffman_tables, jpeg/mod.rs:684-824) — counted
+// on the device, constructed on the host.
+int huffman_for_tuple(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+                      const pixo_host::Geometry &g, Context &c, pixo_host::HuffSet &h)
+{
+    namespace pd = pixo_dev;
+    h = pixo_host::HuffSet::standard();
+    if (!o.optimize_huffman) return PIXO_OK;
+    pd::ScanArgs a;
+    a.y = dy; a.cb = dcb; a.cr = dcr; a.tables = nullptr;
+    a.mode = g.gray ? 0 : (g.s420 ? 2 : 1);
+    a.nblocks = g.y_blocks + 2 * g.c_blocks;
+    a.blocks_per_mcu = g.gray ? 1 : (g.s420 ? 6 : 3);
+    a.marker_bytes = 2;
+    a.restart = scan_has_restart_markers(o, g) ? o.restart_interval : 0;
+    a.seed_dc[0] = a.seed_dc[1] = a.seed_dc[2] = 0; a.bit_base = 0; a.pad_last = 1;
+    HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
+    HIP_TRY(c.e_count.reserve(pd::scan_count_scratch_bytes()));
+    HIP_TRY(pd::launch_scan_count(a, c.e_count.as<uint32_t>(), c.e_hist.as<unsigned long long>(), c.stream));
+    uint64_t counts[pixo_host::kScanTableWords];
+    HIP_TRY(hipMemcpyAsync(counts, c.e_hist.p, sizeof counts, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    uint64_t dc[2][12], ac[2][256];
+    split_counts(counts, dc, ac);
+    h = pixo_host::HuffSet::optimized(dc, ac, !g.gray);
+    return PIXO_OK;
+}
+
+// Progressive files (jpeg/mod.rs:397-419, :872-927).  Device pixels -> file in `out`:
+//   tables   optimised ones come from the statistics of a BASELINE walk over the PLAIN quantiser's
+//            coefficients (build_optimized_huffman_tables, :684-824, never uses trellis): the ordinary
+//            coefficient kernel + the device histogram pass;
+//   tuple    `trellis_quant`: the coefficient kernel in raw mode (unquantised transform) followed by the
+//            trellis kernel; otherwise the ordinary kernel (`trellis_quant` acts nowhere else: a baseline
+//            encode with the flag set is an ordinary baseline encode, encode_scan never reads it);
+//   scans    device_progressive_scans above (PIXO_HIP_HOST_ENTROPY=1: the host twin in jpeg_host.cpp on a
+//            pinned copy of the tuple).
+// Progressive file from device pixels; *file points into the context's pinned buffer (or into `spill`: the host twin).
+int progressive_to_view(const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, Context &c,
+                        std::vector<uint8_t> &spill, const uint8_t **file, size_t *file_len)
+{
+    namespace pd = pixo_dev;
+    int rc;
+    int16_t *dy = nullptr, *dcb = nullptr, *dcr = nullptr;
+    const float *qt_all = nullptr;
+    if ((rc = device_tables(c.device, &qt_all))) return rc;
+    const float *qt = qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats;
+    pixo_host::HuffSet h;
+    const bool need_plain = o.optimize_huffman || !o.trellis_quant;
+    if (need_plain && (rc = coeffs_on_device(c, d_pixels, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
+    if ((rc = huffman_for_tuple(dy, dcb, dcr, o, g, c, h))) return rc;
+    const size_t blocks = g.y_blocks + 2 * g.c_blocks, coef_bytes = blocks * 128;
+    if (o.trellis_quant) {
+        HIP_TRY(c.t_raw.reserve((blocks + 63) / 64 * 64 * 256)); // (whole wavefronts of the trellis kernel: jpeg_kernels.hpp)
+        if ((rc = c.reserve_coef(coef_bytes))) return rc;
+        float *ry = c.t_raw.as<float>(), *rcb = ry + g.y_blocks * 64, *rcr = rcb + g.c_blocks * 64;
+        dy = static_cast<int16_t *>(c.d_coef); dcb = dy + g.y_blocks * 64; dcr = dcb + g.c_blocks * 64;
+        HIP_TRY(pd::launch_jpeg_coeffs(d_pixels, o.width, o.height, g.gray, g.s420, 1, ry, g.gray ? nullptr : rcb,
+                                       g.gray ? nullptr : rcr, qt, c.stream, /*raw_f32=*/true));
+        // one launch over the whole tuple (the planes are contiguous): luminance steps, then chrominance steps
+        HIP_TRY(c.t_trail.reserve(pd::trellis_scratch_bytes(blocks)));
+        HIP_TRY(pd::launch_trellis(ry, qt + 128, qt + 192, dy, blocks, g.y_blocks, c.t_trail.p, c.stream));
+    }
+    if (!debug().host_entropy) {
+        std::vector<uint8_t> head;
+        pixo_host::file_headers(head, o, h);
+        return device_progressive_scans(dy, dcb, dcr, g, h, c, head, file, file_len);
+    }
+    if ((rc = c.reserve_hcoef(coef_bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(c.h_coef, dy, coef_bytes, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    const int16_t *hy = static_cast<const int16_t *>(c.h_coef), *hcb = hy + g.y_blocks * 64, *hcr = hcb + g.c_blocks * 64;
+    pixo_host::encode_progressive_file(hy, hcb, hcr, o, h, spill);
+    *file = spill.data();
+    *file_len = spill.size();
+    return PIXO_OK;
+}
+
+} // namespace pixo_capi

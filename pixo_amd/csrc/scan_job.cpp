@@ -1,0 +1,376 @@
+// scan_job.cpp — coefficient launches on a context, and ONE pass of the device entropy stage over a coefficient tuple in
+// HBM in the steps a caller may need to interleave with exchanges (whole image, batch of images, band of a larger image).
+#include <algorithm>
+
+#include "capi_internal.hpp"
+
+namespace pixo_capi {
+
+// Runs the device pipeline for host pixels; on success `*coef` points at pinned host
+// memory holding [y | cb | cr] contiguously.
+int coeffs_to_pinned(Context &c, const uint8_t *pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g,
+                     const int16_t **y, const int16_t **cb, const int16_t **cr)
+{
+    int rc = c.ensure();
+    if (rc) return rc;
+    PIXO_ON_DEVICE_OF(c);
+    const float *qt_all = nullptr;
+    rc = device_tables(c.device, &qt_all);
+    if (rc) return rc;
+    const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
+    const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128;
+    if ((rc = c.reserve_px((px_bytes + 15) & ~size_t{15}))) return rc;
+    if ((rc = c.reserve_coef(coef_bytes))) return rc;
+    if ((rc = c.reserve_hcoef(coef_bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(c.d_px, pixels, px_bytes, hipMemcpyHostToDevice, c.stream));
+    int16_t *dy = static_cast<int16_t *>(c.d_coef);
+    int16_t *dcb = dy + g.y_blocks * 64;
+    int16_t *dcr = dcb + g.c_blocks * 64;
+    HIP_TRY(pixo_dev::launch_jpeg_coeffs(c.d_px, o.width, o.height, g.gray, g.s420, 1, dy,
+                                         g.gray ? nullptr : dcb, g.gray ? nullptr : dcr,
+                                         qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c.stream));
+    HIP_TRY(hipMemcpyAsync(c.h_coef, c.d_coef, coef_bytes, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    *y = static_cast<const int16_t *>(c.h_coef);
+    *cb = *y + g.y_blocks * 64;
+    *cr = *cb + g.c_blocks * 64;
+    return PIXO_OK;
+}
+
+// Device pixels -> device coefficient tuple inside the context's buffer.
+// The tuple's place in the context (no launch)
+int coeffs_reserve(Context &c, const pixo_host::Geometry &g, int16_t **dy, int16_t **dcb, int16_t **dcr)
+{
+    const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128;
+    const int rc = c.reserve_coef(coef_bytes);
+    if (rc) return rc;
+    *dy = static_cast<int16_t *>(c.d_coef);
+    *dcb = *dy + g.y_blocks * 64;
+    *dcr = *dcb + g.c_blocks * 64;
+    return PIXO_OK;
+}
+// The coefficient kernel over MCU rows [row0, row0 + rows) of the image — a sub-image of the same width whose blocks
+// land at their places in the whole image's tuple (MCU rows are independent: SURVEY §8e; the last rows replicate the
+// image's bottom edge as the whole-image launch does).  rows = 0: to the end.
+int coeffs_rows(Context &c, const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
+                int16_t *dy, int16_t *dcb, int16_t *dcr, uint32_t row0, uint32_t rows)
+{
+    const float *qt_all = nullptr;
+    const int rc = device_tables(c.device, &qt_all);
+    if (rc) return rc;
+    const uint32_t unit = (!g.gray && g.s420) ? 16u : 8u, units_x = (o.width + unit - 1) / unit, units_y = (o.height + unit - 1) / unit;
+    if (rows == 0 || row0 + rows > units_y) rows = units_y - row0;
+    const uint32_t y0 = row0 * unit, y1 = row0 + rows >= units_y ? o.height : (row0 + rows) * unit;
+    const size_t bpp = g.gray ? 1 : 3, m0 = static_cast<size_t>(row0) * units_x;
+    const uint8_t *px = static_cast<const uint8_t *>(d_pixels) + static_cast<size_t>(y0) * o.width * bpp;
+    HIP_TRY(pixo_dev::launch_jpeg_coeffs(px, o.width, y1 - y0, g.gray, g.s420, 1, dy + m0 * (unit == 16 ? 4 : 1) * 64,
+                                         g.gray ? nullptr : dcb + m0 * 64, g.gray ? nullptr : dcr + m0 * 64,
+                                         qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, stream));
+    return PIXO_OK;
+}
+int coeffs_on_device(Context &c, const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
+                     int16_t **dy, int16_t **dcb, int16_t **dcr)
+{
+    const int rc = coeffs_reserve(c, g, dy, dcb, dcr);
+    if (rc) return rc;
+    return coeffs_rows(c, d_pixels, o, g, stream, *dy, *dcb, *dcr, 0, 0);
+}
+
+// Does the scan emit RSTn markers (jpeg/mod.rs:1431-1445: only while more MCUs follow)?
+bool scan_has_restart_markers(const pixo_jpeg_options &o, const pixo_host::Geometry &g)
+{
+    return o.has_restart_interval && o.restart_interval != 0 && o.restart_interval < g.units;
+}
+
+// ---- the device entropy stage, in the steps a caller may need to interleave with exchanges ------------
+// One pass of jpeg_entropy.hip over a coefficient tuple in HBM: a whole image, a batch of images (one
+// byte-aligned segment each), or a BAND of a larger image (predictors seeded from the band
+// above, packed at the band's bit offset modulo 8, no final padding).
+
+// The packed Huffman tables of a scan into e_tables — unless they are what the buffer holds already (the standard
+// tables, image after image: one small copy less on the stream per file).
+int upload_scan_tables(Context &c, const uint32_t (&packed)[pixo_host::kScanTableWords], hipStream_t stream)
+{
+    if (c.tables_valid && c.tables_stream == stream && std::memcmp(c.tables_held, packed, sizeof packed) == 0) return PIXO_OK;
+    c.tables_valid = false;
+    std::memcpy(c.tables_held, packed, sizeof packed);
+    for (int i = 0; i < pixo_scan::kWalkWords; ++i) // the same tables in the form of the flat walk (jpeg_scan_block.h)
+        c.tables_held[pixo_scan::kTableWords + i] = pixo_scan::walk_table_word(packed, i);
+    HIP_TRY(hipMemcpyAsync(c.e_tables.p, c.tables_held, sizeof c.tables_held, hipMemcpyHostToDevice, stream));
+    c.tables_valid = true;
+    c.tables_stream = stream;
+    return PIXO_OK;
+}
+
+// Geometry of the pass and every buffer whose size does not depend on the data.
+int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+               const pixo_host::Geometry &g, uint32_t batch, const int16_t *band_seed_dc)
+{
+    namespace pd = pixo_dev;
+    j.n = (g.y_blocks + 2 * g.c_blocks) * batch;
+    pd::ScanArgs &a = j.a;
+    a.y = dy; a.cb = dcb; a.cr = dcr;
+    a.mode = g.gray ? 0 : (g.s420 ? 2 : 1);
+    a.nblocks = j.n;
+    a.blocks_per_mcu = g.gray ? 1 : (g.s420 ? 6 : 3);
+    a.marker_bytes = 2;
+    a.restart = (!band_seed_dc && scan_has_restart_markers(o, g)) ? o.restart_interval : 0;
+    a.seed_dc[0] = a.seed_dc[1] = a.seed_dc[2] = 0;
+    a.bit_base = 0; a.pad_last = 1;
+    j.band = band_seed_dc != nullptr;
+    if (j.band) {
+        for (int i = 0; i < 3; ++i) a.seed_dc[i] = band_seed_dc[i];
+        a.pad_last = 0;
+    }
+    j.nseg = a.restart ? (g.units + a.restart - 1) / a.restart : 0;
+    if (batch > 1) { // one segment per image, no marker between them
+        a.restart = static_cast<uint32_t>(g.units);
+        a.marker_bytes = 0;
+        j.nseg = batch;
+    }
+    j.fused = j.nseg == 0 && !debug().multipass_entropy;
+    HIP_TRY(c.e_tables.reserve(pixo_scan::kScanTableUpload * 4));
+    HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
+    if (j.fused) { // a block has at most 1665 bits: the packed stream has at most n * 209 bytes (+ slack the kernels read into)
+        j.stream_cap = static_cast<size_t>(j.n) * 209 + 64;
+        HIP_TRY(c.e_stream.reserve(j.stream_cap));
+        if (pd::fused_code_state_words(j.n) * 8 > c.e_code_state.cap) c.code_state_zero_words = 0; // (a new buffer)
+        HIP_TRY(c.e_code_state.reserve(pd::fused_code_state_words(j.n) * 8));
+        HIP_TRY(c.e_stuff_state.reserve(pd::fused_stuff_state_words(j.stream_cap) * 8));
+        { const int rc_t = c.ensure_totals(); if (rc_t) return rc_t; }
+        a.tables = c.e_tables.as<uint32_t>();
+        return PIXO_OK;
+    }
+    HIP_TRY(c.e_len.reserve((j.n ? j.n : 1) * 4));
+    HIP_TRY(c.e_off.reserve((j.n ? j.n : 1) * 8));
+    // scratch of the three prefix sums (blocks, restart segments, 0xFF tiles), reserved before any launch:
+    // a block has at most 1665 bits, so the packed stream has at most n * 209 + 3 * nseg bytes
+    j.tmp_blocks = pd::scan_tile_count(j.n) + 1; j.tmp_segs = pd::scan_tile_count(j.nseg ? j.nseg : 1) + 1;
+    j.tmp_tiles = pd::scan_tile_count(pd::stuff_tile_count(j.n * 209 + 3 * j.nseg + 8)) + 1;
+    HIP_TRY(c.e_tmp.reserve((j.tmp_blocks + j.tmp_segs + j.tmp_tiles) * 8));
+    HIP_TRY(c.e_totals.reserve(16));
+    { const int rc_t = c.ensure_totals(); if (rc_t) return rc_t; }
+    a.tables = c.e_tables.as<uint32_t>();
+    return PIXO_OK;
+}
+
+void split_counts(const uint64_t counts[pixo_host::kScanTableWords], uint64_t dc[2][12], uint64_t ac[2][256])
+{
+    for (int cls = 0; cls < 2; ++cls) {
+        std::memcpy(dc[cls], counts + cls * 268, sizeof dc[cls]);
+        std::memcpy(ac[cls], counts + cls * 268 + 12, sizeof ac[cls]);
+    }
+}
+
+// count_block statistics of the pass (src/jpeg/mod.rs:826-860) gathered on the device: [class][12 DC + 256 AC].
+int scan_count(Context &c, ScanJob &j, hipStream_t stream, uint64_t counts[pixo_host::kScanTableWords])
+{
+    HIP_TRY(c.e_count.reserve(pixo_dev::scan_count_scratch_bytes()));
+    HIP_TRY(pixo_dev::launch_scan_count(j.a, c.e_count.as<uint32_t>(), c.e_hist.as<unsigned long long>(), stream));
+    HIP_TRY(hipMemcpyAsync(counts, c.e_hist.p, pixo_host::kScanTableWords * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return PIXO_OK;
+}
+
+// Tables (standard; optimised from `counts`, or from this pass's own statistics when counts == null),
+// block bit lengths and their prefix sum: afterwards j.total_bits is known (one read-back).
+int scan_tables(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
+                const uint64_t *counts)
+{
+    if (j.tables_ready) return PIXO_OK;
+    if (o.optimize_huffman) { // table construction on the host, exactly like optimized_from_counts
+        uint64_t own[pixo_host::kScanTableWords];
+        if (!counts) {
+            int rc = scan_count(c, j, stream, own);
+            if (rc) return rc;
+            counts = own;
+        }
+        uint64_t dc[2][12], ac[2][256];
+        split_counts(counts, dc, ac);
+        j.h = pixo_host::HuffSet::optimized(dc, ac, !g.gray);
+    } else {
+        j.h = pixo_host::HuffSet::standard();
+    }
+    uint32_t packed[pixo_host::kScanTableWords];
+    pixo_host::pack_scan_tables(j.h, packed);
+    const int rc = upload_scan_tables(c, packed, stream);
+    j.tables_ready = rc == PIXO_OK;
+    return rc;
+}
+
+int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
+                 const uint64_t *counts, bool wait)
+{
+    namespace pd = pixo_dev;
+    {
+        const int rc = scan_tables(c, j, o, g, stream, counts);
+        if (rc) return rc;
+    }
+    if (j.fused) { // lengths, prefix and packing in one pass; the stream starts at bit 0 whatever the band's offset will be
+        const bool zero = c.code_state_zero_words >= pd::fused_code_state_words(j.n);
+        c.code_state_zero_words = 0; // (dirty from here until a stuffing launch has cleaned it)
+        // chained with the stuffing kernel (!wait): this launch also zeroes that kernel's descriptors
+        HIP_TRY(pd::launch_scan_code(j.a, c.e_code_state.as<unsigned long long>(), zero, c.e_stream.as<uint32_t>(),
+                                     wait ? nullptr : c.e_stuff_state.as<unsigned long long>(),
+                                     wait ? 0 : pd::fused_stuff_state_words(j.stream_cap), reinterpret_cast<unsigned long long *>(c.h_totals), stream));
+        if (!wait) return PIXO_OK; // (the caller chains the stuffing kernel and synchronises once)
+        HIP_TRY(hipStreamSynchronize(stream)); // (the kernel wrote the length into the pinned mailbox itself)
+        j.total_bits = c.h_totals[0];
+        j.nbytes = (j.total_bits + 7) / 8;
+        return PIXO_OK;
+    }
+    if (j.n) HIP_TRY(pd::launch_scan_lengths(j.a, c.e_len.as<uint32_t>(), stream));
+    HIP_TRY(pd::launch_exclusive_scan(c.e_len.as<uint32_t>(), j.n, c.e_off.as<uint64_t>(), c.e_tmp.as<uint64_t>(),
+                                      c.e_totals.as<uint64_t>(), stream));
+    if (j.nseg) { // restart markers: byte-aligned segments, each followed by two marker bytes
+        HIP_TRY(c.e_seg_bytes.reserve(j.nseg * 8));
+        HIP_TRY(c.e_seg_off.reserve(j.nseg * 8));
+        HIP_TRY(pd::launch_segment_sizes(j.a, c.e_off.as<uint64_t>(), c.e_totals.as<uint64_t>(), j.nseg, c.e_seg_bytes.as<uint32_t>(), stream));
+        HIP_TRY(pd::launch_exclusive_scan(c.e_seg_bytes.as<uint32_t>(), j.nseg, c.e_seg_off.as<uint64_t>(),
+                                          c.e_tmp.as<uint64_t>() + j.tmp_blocks, c.e_totals.as<uint64_t>() + 1, stream));
+        j.plan.nsegments = j.nseg;
+        j.plan.seg_byte_off = c.e_seg_off.as<uint64_t>();
+    }
+    HIP_TRY(hipMemcpyAsync(c.h_totals, c.e_totals.p, 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream)); // `packed` may go out of scope after this, too
+    j.total_bits = c.h_totals[0];
+    j.nbytes = j.nseg ? c.h_totals[1] : (j.total_bits + 7) / 8; // bytes of the packed (unstuffed) stream
+    return PIXO_OK;
+}
+
+// The stuffing kernel of jpeg_scan_fused.hip over the packed stream (launch_scan_code has been enqueued; with
+// `chained` its length has not been read back yet): afterwards c.e_out holds j.scan_bytes finished bytes.  The output
+// buffer is sized from experience (grow-only) — the kernel never writes beyond it and says how much it needed.
+// Where the stuffed bytes go when not into the context's device buffer: host memory the GPU can write (pinned), so that
+// the kernel's stores ARE the transfer — no second pass over the file, no second synchronisation.
+
+int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offset, uint32_t *head, int *tail_bits,
+                     uint32_t *tail, bool chained, HostTarget *host)
+{
+    namespace pd = pixo_dev;
+    uint32_t shift = 0;
+    if (j.band) {
+        const uint64_t want = (8 - (band_bit_offset & 7)) & 7;
+        j.head_bits = static_cast<int>(j.total_bits < want ? j.total_bits : want);
+        shift = static_cast<uint32_t>(j.head_bits);
+    }
+    // entropy-coded data holds a 0xFF every ~256 bytes; start from a quarter of the worst-case stream and grow on demand
+    size_t want_cap = chained ? std::max<size_t>(j.stream_cap / 4, 4096) : static_cast<size_t>(j.nbytes + j.nbytes / 64 + 4096);
+    // tiles: the exact number when the stream's length is known, otherwise a guess (64 bytes per block; noise at q = 80
+    // has 28) — surplus workgroups leave at once, missing ones are launched below
+    uint64_t first_tile = 0, tiles = chained ? pd::stuff_tiles(std::min<uint64_t>(j.stream_cap, j.n * 64 + 4096)) : pd::stuff_tiles(j.nbytes);
+    for (int attempt = 0;; ++attempt) {
+        uint8_t *out = nullptr;
+        size_t out_cap = 0;
+        if (host) {
+            if (host->grow) {
+                const int rc = c.reserve_hfile(host->before + want_cap + host->after);
+                if (rc) return rc;
+                host->p = c.h_file + host->before;
+                host->cap = c.hfile_cap - host->before - host->after;
+            }
+            out = host->p;
+            out_cap = host->cap;
+        } else {
+            HIP_TRY(c.e_out.reserve(want_cap));
+            out = c.e_out.as<uint8_t>();
+            out_cap = c.e_out.cap;
+        }
+        HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), pd::fused_code_state_words(j.n),
+                                       shift, j.band, j.stream_cap, first_tile, tiles, c.e_stuff_state.as<unsigned long long>(),
+                                       /*state_is_zero=*/
+                                       chained && attempt == 0,
+ out, out_cap, reinterpret_cast<unsigned long long *>(c.h_totals), stream));
+        c.code_state_zero_words = pd::fused_code_state_words(j.n);
+        // (no read-back copies: both kernels store their totals into the pinned mailbox h_totals — [0] bits of the scan,
+        // [1] stuffed bytes, [2] packed bytes — which the host reads after the synchronisation below)
+        uint32_t edge[3] = {0, 0, 0}; // band: stream word 0 (head bits) and the two words around the tail bits
+        if (j.band) {
+            const uint64_t tail_at = static_cast<uint64_t>(j.head_bits) + 8 * ((j.total_bits - j.head_bits) / 8);
+            HIP_TRY(hipMemcpyAsync(&edge[0], c.e_stream.p, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(&edge[1], c.e_stream.as<uint32_t>() + (tail_at >> 5), 8, hipMemcpyDeviceToHost, stream));
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        j.total_bits = c.h_totals[0];
+        const uint64_t packed = j.band ? (j.total_bits - j.head_bits) / 8 : (j.total_bits + 7) / 8;
+        if (pd::stuff_tiles(packed) > first_tile + tiles) { // the guess was short: the tiles behind it, same buffers
+            if (attempt > 2) return fail(PIXO_ERR_COMPRESSION, "Compression error: packed stream longer than announced");
+            first_tile += tiles;
+            tiles = pd::stuff_tiles(packed) - first_tile;
+            continue;
+        }
+        j.scan_bytes = c.h_totals[1];
+        j.nbytes = c.h_totals[2];
+        if (j.scan_bytes > out_cap) { // (first call with unusually many 0xFF bytes: grow and repeat the stuffing pass only)
+            if (host && !host->grow) return PIXO_OK; // (the caller's storage is what it is: the caller reports the size needed)
+            if (attempt > 2) return fail(PIXO_ERR_COMPRESSION, "Compression error: stuffed stream larger than announced");
+            want_cap = static_cast<size_t>(j.scan_bytes);
+            first_tile = 0;
+            tiles = pd::stuff_tiles(packed);
+            continue;
+        }
+        if (j.band) {
+            const int t = static_cast<int>((j.total_bits - j.head_bits) % 8);
+            const uint64_t tail_at = static_cast<uint64_t>(j.head_bits) + 8 * ((j.total_bits - j.head_bits) / 8);
+            *head = j.head_bits ? (edge[0] >> (32 - j.head_bits)) : 0u;
+            *tail_bits = t;
+            const uint64_t two = (static_cast<uint64_t>(edge[1]) << 32) | edge[2]; // MSB-first bits of the two words
+            *tail = t ? static_cast<uint32_t>((two >> (64 - (tail_at & 31) - t)) & ((1u << t) - 1u)) : 0u;
+        }
+        return PIXO_OK;
+    }
+}
+
+// Pack, 0xFF census, stuffing (+ restart markers): afterwards c.e_out holds j.scan_bytes finished bytes
+// (one read-back).  A band starting at bit `band_bit_offset` of the scan is packed so that its whole bytes
+// begin at word 1 of the stream: its first (8 - offset % 8) % 8 bits end word 0, the bits left over after the
+// last whole byte follow it; both are returned unstuffed in head / tail (value, right-aligned).
+int scan_pack(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offset, uint32_t *head, int *tail_bits, uint32_t *tail)
+{
+    namespace pd = pixo_dev;
+    if (j.fused) return scan_stuff_fused(c, j, stream, band_bit_offset, head, tail_bits, tail);
+    uint64_t stream_bits = j.total_bits;
+    uint32_t word_off = 0;
+    if (j.band) {
+        const uint64_t want = (8 - (band_bit_offset & 7)) & 7;
+        j.head_bits = static_cast<int>(j.total_bits < want ? j.total_bits : want);
+        j.a.bit_base = 32 - static_cast<uint32_t>(j.head_bits);
+        j.nbytes = (j.total_bits - j.head_bits) / 8;
+        stream_bits = j.a.bit_base + j.total_bits;
+        word_off = 1;
+    }
+    const size_t stream_bytes = j.band ? ((stream_bits + 31) / 32 + 2) * 4 : (j.nbytes / 4 + 2) * 4;
+    HIP_TRY(c.e_stream.reserve(stream_bytes));
+    HIP_TRY(hipMemsetAsync(c.e_stream.p, 0, stream_bytes, stream));
+    if (j.n) HIP_TRY(pd::launch_scan_pack(j.a, c.e_off.as<uint64_t>(), j.total_bits, j.nseg ? &j.plan : nullptr, c.e_stream.as<uint32_t>(), stream));
+    const uint32_t *body = c.e_stream.as<uint32_t>() + word_off;
+    const size_t tiles = pd::stuff_tile_count(j.nbytes);
+    HIP_TRY(c.e_tile_ff.reserve((tiles ? tiles : 1) * 4));
+    HIP_TRY(c.e_tile_base.reserve((tiles ? tiles : 1) * 8));
+    if (tiles) HIP_TRY(pd::launch_ff_tile_count(body, j.nbytes, c.e_tile_ff.as<uint32_t>(), stream));
+    HIP_TRY(pd::launch_exclusive_scan(c.e_tile_ff.as<uint32_t>(), tiles, c.e_tile_base.as<uint64_t>(),
+                                      c.e_tmp.as<uint64_t>() + j.tmp_blocks + j.tmp_segs, c.e_totals.as<uint64_t>() + 1, stream));
+    HIP_TRY(hipMemcpyAsync(c.h_totals + 1, c.e_totals.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, stream));
+    uint32_t edge[2] = {0, 0}; // band: word 0 (head bits) and the word holding the tail bits
+    if (j.band) {
+        HIP_TRY(hipMemcpyAsync(&edge[0], c.e_stream.p, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&edge[1], c.e_stream.as<uint32_t>() + 1 + j.nbytes / 4, 4, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    j.scan_bytes = j.nbytes + c.h_totals[1];
+    HIP_TRY(c.e_out.reserve(j.scan_bytes ? j.scan_bytes : 1));
+    if (tiles) HIP_TRY(pd::launch_stuff(body, j.nbytes, c.e_tile_base.as<uint64_t>(), c.e_out.as<uint8_t>(), stream));
+    if (j.nseg) HIP_TRY(pd::launch_restart_markers(j.a, c.e_off.as<uint64_t>(), j.plan, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
+                                                   c.e_out.as<uint8_t>(), stream));
+    if (j.band) {
+        const int t = static_cast<int>((j.total_bits - j.head_bits) % 8);
+        *head = j.head_bits ? (edge[0] & ((1u << j.head_bits) - 1u)) : 0u;
+        *tail_bits = t;
+        // the tail bits are the top bits of stream byte nbytes (MSB-first bytes inside big-endian words)
+        const uint32_t byte = (edge[1] >> (24 - 8 * static_cast<uint32_t>(j.nbytes % 4))) & 0xFFu;
+        *tail = t ? (byte >> (8 - t)) : 0u;
+    }
+    return PIXO_OK;
+}
+
+} // namespace pixo_capi

@@ -598,8 +598,35 @@ def encode_multi(data, options: JpegOptions, devices) -> bytes:
 
 def set_producer_stream(stream) -> None:
     """Device-pointer entry points are ordered after the work enqueued so far on `stream` (a hipStream_t
-    handle as int, 0 / None = the NULL stream, PyTorch's default)."""
+    handle as int, 0 / None = the NULL stream, PyTorch's default).  Per thread and sticky: see `producer_stream`."""
     _lib.load().pixo_hip_set_producer_stream(C.c_void_p(stream) if stream else None)
+
+
+def get_producer_stream() -> int:
+    return _lib.load().pixo_hip_get_producer_stream() or 0
+
+
+class producer_stream:
+    """`with producer_stream(handle): ...` — names the producer stream for the calls inside and puts the thread's
+    previous setting back afterwards (the setting is per thread and sticky; a stream of another device left behind
+    would make later device-pointer calls wait on the host for it)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        self.prev = get_producer_stream()
+        set_producer_stream(self.stream)
+        return self
+
+    def __exit__(self, *exc):
+        set_producer_stream(self.prev)
+        return False
+
+
+def debug_configure(switches=None) -> None:
+    """Tests and A/B tools: replace the library's debug switches (`PIXO_HIP_DEBUG` syntax); None = re-read the environment."""
+    _lib.load().pixo_hip_debug_configure(switches.encode() if switches is not None else None)
 
 
 def device_count() -> int:

@@ -118,12 +118,15 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
                          "encode_gathered_device")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     on_gpu = coeff_fn is None
+    prev_producer = None
     if on_gpu:
         if device is None:
             device = torch.cuda.current_device()
         enc = jpeg.BandEncoder(options, world, rank, device)
         tdev = torch.device("cuda", device)
         if hasattr(band_pixels, "is_cuda") and band_pixels.is_cuda:
+            # (per thread and sticky: the previous setting is put back when the call returns, see `finally`)
+            prev_producer = jpeg.get_producer_stream()
             jpeg.set_producer_stream(torch.cuda.current_stream(tdev).cuda_stream)
     else:
         enc = _HostBand(options, world, rank, coeff_fn)
@@ -188,6 +191,8 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
         return file[:file_len].numpy().tobytes()
     finally:
         enc.close()
+        if prev_producer is not None:
+            jpeg.set_producer_stream(prev_producer)
 
 
 def encode_gathered(data, options, group=None, coeff_fn=None, dst=0):
@@ -268,5 +273,5 @@ def encode_gathered_device(d_band_pixels, options, group=None, dst=0, coeff_fn=N
         return entropy_fn(fy, fcb, fcr, options)
     if fcb.shape[0] == 0:  # gray: the planes are unused but must be valid pointers
         fcb = fcr = fy
-    jpeg.set_producer_stream(torch.cuda.current_stream(dev).cuda_stream)  # the gathers above precede the entropy stage
-    return jpeg.entropy_encode_device(fy, fcb, fcr, options)
+    with jpeg.producer_stream(torch.cuda.current_stream(dev).cuda_stream):  # the gathers above precede the entropy stage
+        return jpeg.entropy_encode_device(fy, fcb, fcr, options)

@@ -296,7 +296,7 @@ extern "C" long emu_scan_flat(const int16_t *y, const int16_t *cb, const int16_t
     return o;
 }
 
-// A scan coded in PIECES (pixo_dev::ScanPiece, capi.cpp device_entropy_pieces) on the CPU: piece k codes blocks
+// A scan coded in PIECES (pixo_dev::ScanPiece, pieces.cpp device_entropy_pieces) on the CPU: piece k codes blocks
 // [k * per_piece, ...) with the flat walk into a stream of its own that starts with the `lead` = (bits before the piece) % 8
 // last bits of the piece before — taken from that piece's stream, like the device does — so that it is byte-aligned with
 // the scan; every piece but the last is stuffed in whole bytes only, the last one is padded with 1-bits; the stuffed
@@ -516,7 +516,7 @@ extern "C" void emu_progressive_tables(uint32_t *out /* 536 words */)
 // and group by group on the host — neighbour alignment for every pixel size, SWAR filters, packed Paeth,
 // scores, the reference's decision sequences, checksum terms and their combination.  `strategy` is the
 // one the launcher would run (the <= 4096-pixel rule and the sequential AdaptiveFast are host logic in
-// capi.cpp).  Returns the Adler-32 of the stream.
+// png_api.cpp).  Returns the Adler-32 of the stream.
 // ---------------------------------------------------------------------------------------------
 #include "../../pixo_amd/csrc/png_filter_math.h"
 namespace {
@@ -595,7 +595,7 @@ template <int BPP> uint32_t emu_png_rows(const uint8_t *data, long n, long heigh
                     if (4 * (k0 + j) + b < n) o[1 + 4 * (k0 + j) + b] = (uint8_t)(v >> (8 * b));
             }
         }
-        // combine_adler (capi.cpp): s2 += row_len * s1_before + B, s1 += A
+        // combine_adler (png_api.cpp): s2 += row_len * s1_before + B, s1 += A
         a2 = (a2 + (L % M) * a1 + s2 % M) % M;
         a1 = (a1 + s1 % M) % M;
     }

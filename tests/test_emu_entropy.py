@@ -104,7 +104,7 @@ def test_flat_count_walk_gives_the_visitor_histogram():
 
 @pytest.mark.parametrize("per_piece", [1, 5, 192, 1000])
 def test_a_scan_coded_in_pieces_is_the_same_scan(per_piece):
-    """Large scans are coded in pieces that hand each other the bit position (capi.cpp device_entropy_pieces, pixo_dev::ScanPiece):
+    """Large scans are coded in pieces that hand each other the bit position (pieces.cpp device_entropy_pieces, pixo_dev::ScanPiece):
     a piece's stream starts with the (bits before) % 8 last bits of the piece before, every piece but the last is stuffed in
     whole bytes only.  The same hand-off on the CPU with the device's flat walk, pieces of 1 block to 1000, against the oracle's scan."""
     L = E.lib()

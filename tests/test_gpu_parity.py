@@ -506,7 +506,7 @@ def test_encode_device_into_pinned_storage_every_alignment():
 
 
 def test_direct_store_switch_gives_the_same_files():
-    """PIXO_HIP_DIRECT_STORES=1 (the stuffing kernel writes the caller's pinned memory itself) in a fresh process:
+    """PIXO_HIP_DEBUG=direct_stores (the stuffing kernel writes the caller's pinned memory itself) in a fresh process:
     the alignment cases above, and the same bytes as the default path."""
     import subprocess, sys, hashlib
     code = ("import sys, hashlib, torch; sys.path.insert(0, 'tests'); import synth; from pixo_amd import jpeg\n"
@@ -516,8 +516,8 @@ def test_direct_store_switch_gives_the_same_files():
             "print(hashlib.sha256(pin[:n].numpy().tobytes()).hexdigest(), hashlib.sha256(jpeg.encode_device(d, o)).hexdigest())")
     import os
     outs = []
-    for direct in ("0", "1"):
-        env = dict(os.environ, PIXO_HIP_DIRECT_STORES=direct)
+    for direct in ("", "direct_stores"):
+        env = dict(os.environ, PIXO_HIP_DEBUG=direct)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, r.stderr[-2000:]
@@ -527,7 +527,7 @@ def test_direct_store_switch_gives_the_same_files():
     want = hashlib.sha256(jpeg.encode(px, o)).hexdigest()
     assert outs[0] == [want, want] and outs[1] == [want, want]
     r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, 'tests'); import test_gpu_parity as t; t._pinned_storage_cases(); print('cases ok')"],
-                       capture_output=True, text=True, env=dict(os.environ, PIXO_HIP_DIRECT_STORES="1"), timeout=600,
+                       capture_output=True, text=True, env=dict(os.environ, PIXO_HIP_DEBUG="direct_stores"), timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "cases ok" in r.stdout, r.stderr[-2000:]
 
@@ -546,13 +546,13 @@ def test_stuffing_grid_guesses_that_fall_short_are_completed():
 
 def test_scans_coded_in_pieces_give_the_same_files():
     """Large scans are coded in pieces (runs of groups, one launch pair each) whose bytes leave for the host while the next
-    piece is coded; the pieces hand each other bit and byte positions on the device.  With PIXO_HIP_PIECE_GROUPS=1 and 3
+    piece is coded; the pieces hand each other bit and byte positions on the device.  With PIXO_HIP_DEBUG=piece_groups=1 and 3
     every reference-made golden above two or six groups goes through that path in up to 16 pieces — every alignment of
-    the seams — and PIXO_HIP_ONE_PIECE=1 switches it off; a 4096x4096 4:4:4 image takes the path by its own size."""
+    the seams — and PIXO_HIP_DEBUG=one_piece switches it off; a 4096x4096 4:4:4 image takes the path by its own size."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for env in ({"PIXO_HIP_PIECE_GROUPS": "1"}, {"PIXO_HIP_PIECE_GROUPS": "3"}, {"PIXO_HIP_ONE_PIECE": "1"},
-                {"PIXO_HIP_PIECE_MEDIUM": "2"}, {"PIXO_HIP_PIECE_MEDIUM": "3", "PIXO_HIP_PIECE_SCHEDULE": "1,2,5"}):
+    for env in ({"PIXO_HIP_DEBUG": "piece_groups=1"}, {"PIXO_HIP_DEBUG": "piece_groups=3"}, {"PIXO_HIP_DEBUG": "one_piece"},
+                {"PIXO_HIP_DEBUG": "piece_medium=2"}, {"PIXO_HIP_DEBUG": "piece_medium=3,piece_schedule=1:2:5"}):
         r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
                             "-k", "goldens or device_entropy_stage or encode_device_into_pinned_and_pageable or band"],
                            capture_output=True, text=True, env=dict(os.environ, **env), timeout=900, cwd=root)
@@ -565,7 +565,7 @@ def test_scans_coded_in_pieces_give_the_same_files():
             "    o = jpeg.JpegOptions.builder(256, 256).quality(100).subsampling(jpeg.Subsampling(ss)).build()\n"
             "    assert jpeg.encode(px, o) == O.encode(px, O.make_options(256, 256, 2, 100, ss))\n"
             "print('redo ok')")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PIXO_HIP_PIECE_GROUPS="1"),
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PIXO_HIP_DEBUG="piece_groups=1"),
                        timeout=300, cwd=root)
     assert r.returncode == 0 and "redo ok" in r.stdout, r.stderr[-2000:]
     # a medium scan (a 4096x4096 4:2:0 image: 2048 groups) is cut into growing pieces once the context has seen that its

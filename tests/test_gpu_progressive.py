@@ -83,9 +83,9 @@ def test_end_of_band_runs_longer_than_32767_blocks():
 
 
 @pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])
-def test_progressive_scans_over_a_device_tuple_and_the_host_twin(mode, monkeypatch):
+def test_progressive_scans_over_a_device_tuple_and_the_host_twin(mode):
     """`entropy_encode_device` with progressive options codes the seven scans on the device from a tuple
-    that never leaves HBM; the host twin (PIXO_HIP_HOST_ENTROPY) must give the same bytes."""
+    that never leaves HBM; the host twin (debug switch host_entropy) must give the same bytes."""
     import torch
     ct, ss = mode
     w, h = 413, 290
@@ -101,22 +101,27 @@ def test_progressive_scans_over_a_device_tuple_and_the_host_twin(mode, monkeypat
             if not optimize else O.encode(px, O.make_options(w, h, ct, 88, ss, progressive=True, optimize_huffman=True))
         got = jpeg.entropy_encode_device(dy, dcb, dcr, o)
         assert got == want
-        monkeypatch.setenv("PIXO_HIP_HOST_ENTROPY", "1")
-        assert jpeg.entropy_encode_device(dy, dcb, dcr, o) == want
-        assert jpeg.encode(px, o) == want
-        monkeypatch.delenv("PIXO_HIP_HOST_ENTROPY")
+        jpeg.debug_configure("host_entropy")
+        try:
+            assert jpeg.entropy_encode_device(dy, dcb, dcr, o) == want
+            assert jpeg.encode(px, o) == want
+        finally:
+            jpeg.debug_configure(None)
         assert jpeg.encode(px, o) == want
 
 
-def test_progressive_large_noise_matches_host_twin(monkeypatch):
+def test_progressive_large_noise_matches_host_twin():
     """4096x4096 noise (the stream has millions of 0xFF bytes and every scan is many tiles long): device
     scan coder == host twin byte for byte (the twin is pinned to the oracle on the CPU suite)."""
     w = h = 4096
     px = synth.noise(w, h, 77)
     o = jpeg.JpegOptions.from_preset(w, h, 85, 2)
     dev = jpeg.encode(px, o)
-    monkeypatch.setenv("PIXO_HIP_HOST_ENTROPY", "1")
-    host = jpeg.encode(px, o)
+    jpeg.debug_configure("host_entropy")
+    try:
+        host = jpeg.encode(px, o)
+    finally:
+        jpeg.debug_configure(None)
     assert hashlib.sha256(dev).hexdigest() == hashlib.sha256(host).hexdigest() and len(dev) == len(host)
 
 

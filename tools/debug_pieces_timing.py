@@ -1,4 +1,4 @@
-"""Per-piece wall times of the pipelined delivery (PIXO_HIP_TRACE=1): python tools/debug_pieces_timing.py"""
+"""Per-piece wall times of the pipelined delivery (PIXO_HIP_DEBUG=trace): python tools/debug_pieces_timing.py"""
 import os, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import torch, synth

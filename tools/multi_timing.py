@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """pixo_hip_jpeg_encode_multi on ONE GPU with 1, 2, 4, 8 bands (each band its own thread, context and stream) against
-pixo_hip_jpeg_encode: 4096x4096 and 16384x16384 noise from host pixels.  With PIXO_HIP_TRACE=1 the per-phase times."""
+pixo_hip_jpeg_encode: 4096x4096 and 16384x16384 noise from host pixels.  With PIXO_HIP_DEBUG=trace the per-phase times."""
 import os, sys, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -20,11 +20,11 @@ for (w, h, preset_kw) in [(1024, 1024, 0), (2048, 2048, 0), (4096, 4096, 0), (40
     if preset_kw >= 1: b = b.optimize_huffman(True)
     if preset_kw >= 2: b = b.trellis_quant(True)
     o = b.build()
-    os.environ.pop("PIXO_HIP_HOST_ENTROPY", None)
+    jpeg.debug_configure("")
     dev = jpeg.encode(px, o)
-    os.environ["PIXO_HIP_HOST_ENTROPY"] = "1"
+    jpeg.debug_configure("host_entropy")
     host = jpeg.encode(px, o)
-    os.environ.pop("PIXO_HIP_HOST_ENTROPY", None)
+    jpeg.debug_configure(None)
     if dev == host:
         print(w, h, preset_kw, "equal", len(dev)); continue
     a, c = np.frombuffer(dev, np.uint8), np.frombuffer(host, np.uint8)

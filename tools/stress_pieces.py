@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity stress of the piece-wise delivery (not part of the test-suite): encode_device_into into pinned storage
-with PIXO_HIP_PIECE_MEDIUM=2 (every scan of two or more groups in growing pieces, the coefficient kernel band by band where
+with PIXO_HIP_DEBUG=piece_medium=2 (every scan of two or more groups in growing pieces, the coefficient kernel band by band where
 MCU rows and groups share boundaries), random widths (multiples of 512 and others), heights, qualities, subsampling,
-optimised tables; GPU against the oracle.  Usage: PIXO_HIP_PIECE_MEDIUM=2 stress_pieces.py SECONDS [SEED]"""
+optimised tables; GPU against the oracle.  Usage: PIXO_HIP_DEBUG=piece_medium=2 stress_pieces.py SECONDS [SEED]"""
 import os, sys, time
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..")); sys.path.insert(0, os.path.join(HERE, "..", "tests"))

@@ -16,16 +16,42 @@
 namespace pixo_dev {
 using namespace pixo_tile;
 
-struct KArgs {
-    const uint8_t *px;
-    int16_t *y, *cb, *cr;
-    const float *qt;
-    uint32_t W, H, units_x, units_y, tiles_x, tiles_y, batch, fast;
-    size_t px_stride; // bytes between consecutive images of a batch
+#if defined(PIXO_NO_DOT4) // (A/B builds: the packed multiply-add colour conversion everywhere)
+constexpr bool kDot4 = false;
+#else
+constexpr bool kDot4 = true;
+#endif
+
+// Kernel arguments.  The kernel takes the first 14 dwords as separate parameters, in this order, and is compiled with
+// -mllvm -amdgpu-kernarg-preload-count=14 (Makefile): the command processor hands them to every wavefront in SCALAR
+// REGISTERS at launch.  Read from the kernarg segment with s_load instead, they are the first thing every wavefront waits
+// for — and the wavefronts that start a microsecond late queue behind the 50 MB of pixel loads the early ones have already
+// issued: 0.25 us for the first wavefront, 1.5 us for the median, 6 us for the last (profiles/r03_timeline_c2_before.txt).
+// Everything else (KRest) is not needed before the pixel loads are out and comes by s_load as before.
+struct KRest {
     size_t px_bytes;  // all pixel bytes of the launch (L_FUNNEL never reads a dword beyond them)
-    size_t y_stride;  // i16 elements between images
+    size_t y_stride;  // i16 elements between consecutive images of a batch
     size_t c_stride;
     float *ry, *rcb, *rcr;   // RAW kernels only: unquantised DCT blocks (64 f32 each) instead of y/cb/cr
+    uint32_t units_x, units_y, fast;
+#if defined(PIXO_PROBE)
+    uint32_t probe_launch;   // timeline builds: which part of the probe buffer this launch stamps
+#endif
+};
+struct KArgs {
+    const uint8_t *px;
+    uint32_t W, H;
+    size_t px_stride; // bytes between consecutive images of a batch
+    int16_t *y, *cb, *cr;
+    const float *qt;
+    // ---- (14 dwords up to here) ----
+    size_t px_bytes, y_stride, c_stride;
+    float *ry, *rcb, *rcr;
+    uint32_t units_x, units_y, fast;
+    uint32_t tiles_x, tiles_y, batch; // host only
+#if defined(PIXO_PROBE)
+    uint32_t probe_launch;
+#endif
 };
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, which would
@@ -38,18 +64,22 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 #if defined(PIXO_PROBE)
-// Timeline builds only (tools/ab_build.sh probe "-DPIXO_PROBE"; never the shipped library): every wavefront stores eight
-// time stamps — the 100 MHz constant clock (s_memrealtime: the same counter on every XCD) — into a buffer the host hands
-// over with pixo_hip_debug_probe_buffer().  tools/probe_timeline.py turns them into the dispatch's timeline.
+// Timeline builds only (tools/ab_build.sh probe "-DPIXO_PROBE"; never the shipped library): every wavefront stores
+// kProbeSlots time stamps — the 100 MHz constant clock (s_memrealtime: the same counter on every XCD) — into a buffer the
+// host hands over with pixo_hip_debug_probe_buffer(); consecutive launches use consecutive parts of it (kProbeLaunches,
+// round robin), so that the overlap of back-to-back dispatches can be seen.  tools/probe_timeline.py prints the timeline.
+constexpr int kProbeSlots = 12, kProbeLaunches = 8;
 __device__ unsigned long long *g_probe = nullptr;
-__device__ __forceinline__ void probe_stamp(int slot)
+__device__ unsigned g_probe_stride = 0; // u64 words per launch
+static unsigned g_probe_launch = 0;     // host: which part the next launch writes
+__device__ __forceinline__ void probe_stamp(uint32_t launch, int slot)
 {
     unsigned long long *p = g_probe;
     if (!p) return;
     const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-    if ((threadIdx.x & 63) == 0) p[((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8 + slot] = t;
+    if ((threadIdx.x & 63) == 0) p[(size_t)launch * g_probe_stride + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * kWaves + (threadIdx.x >> 6)) * kProbeSlots + slot] = t;
 }
-#define PIXO_STAMP(slot) probe_stamp(slot)
+#define PIXO_STAMP(slot) probe_stamp(a.probe_launch, slot)
 #else
 #define PIXO_STAMP(slot) ((void)0)
 #endif
@@ -61,53 +91,51 @@ struct TileId {
     uint32_t img, tx, ty;
 };
 
-__device__ __forceinline__ TileId locate(const KArgs &a, uint32_t t)
-{
-    const uint32_t per_img = a.tiles_x * a.tiles_y;
-    TileId id;
-    id.img = t / per_img;
-    const uint32_t r = t - id.img * per_img;
-    id.ty = r / a.tiles_x;
-    id.tx = r - id.ty * a.tiles_x;
-    return id;
-}
-
-__device__ __forceinline__ TileCtx ctx_of(const KArgs &a, uint32_t img)
+// what phase A needs (pixels in); the coefficient arrays are filled in after the barrier (ctx_out): their address
+// arithmetic has no business in front of the pixel loads
+__device__ __forceinline__ TileCtx ctx_in(const KArgs &a, uint32_t img)
 {
     TileCtx c;
     c.px = a.px + (size_t)img * a.px_stride;
-    c.y = a.y + (size_t)img * a.y_stride;
-    c.cb = a.cb ? a.cb + (size_t)img * a.c_stride : nullptr;
-    c.cr = a.cr ? a.cr + (size_t)img * a.c_stride : nullptr;
+    c.y = c.cb = c.cr = nullptr;
     c.qt = a.qt;
     c.W = a.W; c.H = a.H; c.units_x = a.units_x; c.units_y = a.units_y; c.fast = a.fast;
     c.px_end = a.px + a.px_bytes;
     return c;
 }
+__device__ __forceinline__ void ctx_out(TileCtx &c, const KArgs &a, uint32_t img)
+{
+    c.y = a.y + (size_t)img * a.y_stride;
+    c.cb = a.cb ? a.cb + (size_t)img * a.c_stride : nullptr;
+    c.cr = a.cr ? a.cr + (size_t)img * a.c_stride : nullptr;
+}
 
 // Phase A of one wavefront: COUNT items [first, first + COUNT) of the tile, HBM -> registers ->
 // planar LDS.  All loads are issued before the first conversion (no branch near a load).
 template <int MODE, int LOAD, int COUNT>
-__device__ __forceinline__ void phase_a(const TileCtx &c, const TileId &id, int first, int lane, uint8_t *lds, bool last_rows)
+__device__ __forceinline__ void phase_a(const KArgs &a, const TileCtx &c, const TileId &id, int first, int lane, uint8_t *lds, bool last_rows)
 {
     typedef Geo<MODE> G;
     uint32_t r[COUNT * G::item_regs];
+    LaneAddr la{};
+    if (LOAD != L_BYTES) la = lane_addr<MODE>(c, id.tx, id.ty, lane); // (the byte gathers address every pixel by themselves)
     // (the funnel loads read one dword more than they need; only in the tiles that hold the image's last row could that
     // dword lie behind the buffer — wave-uniform choice of the loader, all loads of the phase inside either branch)
     if (LOAD == L_FUNNEL && !last_rows) {
 #pragma unroll
-        for (int j = 0; j < COUNT; j++) producer_load_item<MODE, LOAD, false>(c, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
+        for (int j = 0; j < COUNT; j++) producer_load_item<MODE, LOAD, false>(c, la, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
     } else {
 #pragma unroll
-        for (int j = 0; j < COUNT; j++) producer_load_item<MODE, LOAD, true>(c, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
+        for (int j = 0; j < COUNT; j++) producer_load_item<MODE, LOAD, true>(c, la, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
     }
+    PIXO_STAMP(2); // every load of the phase has been issued
 #pragma unroll
     for (int j = 0; j < COUNT; j++) {
         producer_fix_item<MODE, LOAD>(c, id.tx, first + j, lane, &r[j * G::item_regs]);
-        producer_color_item<MODE>(first + j, lane, &r[j * G::item_regs], lds);
-        if (j == 0) PIXO_STAMP(1); // the first item's pixels have arrived and are converted
+        producer_color_item<MODE, kDot4 && LOAD != L_BYTES>(first + j, lane, &r[j * G::item_regs], lds);
+        if (j == 0) PIXO_STAMP(3); // the first item's pixels have arrived and are converted
     }
-    PIXO_STAMP(2); // ... the last item's
+    PIXO_STAMP(4); // ... the last item's
 }
 
 // One tile per workgroup of THREE wavefronts.  Phase A: the wavefronts share the tile's items
@@ -166,21 +194,17 @@ __device__ __forceinline__ void store_raw_block(const KArgs &a, const TileCtx &c
 }
 
 template <int MODE, int LOAD, bool RAW = false>
-__global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(const KArgs a)
+__global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(const uint8_t *a_px, uint32_t a_W, uint32_t a_H, size_t a_px_stride, int16_t *a_y,
+                                                                              int16_t *a_cb, int16_t *a_cr, const float *a_qt, const KRest rest)
 {
     typedef Geo<MODE> G;
-#if defined(PIXO_QUANT_LDS)
-    __shared__ __attribute__((aligned(16))) uint8_t lds[G::planar + (RAW ? 0 : kQuantLdsFloats * 4)];
-    float *ldsq = reinterpret_cast<float *>(lds + G::planar); // the quantiser's reciprocals (jpeg_tile.h: consumer_quant_lds)
-    if (!RAW) {
-        const int i = threadIdx.x;
-        if (i < 128) {
-            ldsq[i] = a.qt[quant_lds_source<MODE>(i)];
-            if (MODE != MGRAY) ldsq[i + 128] = a.qt[quant_lds_source<MODE>(i + 128)];
-        }
-    }
-#else
     __shared__ __attribute__((aligned(16))) uint8_t lds[G::planar];
+    KArgs a;
+    a.px = a_px; a.W = a_W; a.H = a_H; a.px_stride = a_px_stride; a.y = a_y; a.cb = a_cb; a.cr = a_cr; a.qt = a_qt;
+    a.px_bytes = rest.px_bytes; a.y_stride = rest.y_stride; a.c_stride = rest.c_stride; a.ry = rest.ry; a.rcb = rest.rcb; a.rcr = rest.rcr;
+    a.units_x = rest.units_x; a.units_y = rest.units_y; a.fast = rest.fast;
+#if defined(PIXO_PROBE)
+    a.probe_launch = rest.probe_launch;
 #endif
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // Phase A runs at raised wave priority: the hardware otherwise issues oldest-first, the colour
@@ -190,31 +214,37 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     // steady clocks, profiles/r01_ablation_steady_clocks.txt).
     __builtin_amdgcn_s_setprio(1);
     PIXO_STAMP(0); // the wavefront runs
-    const TileId id = locate(a, blockIdx.x);
-    const TileCtx c = ctx_of(a, id.img);
+    const TileId id{blockIdx.z, blockIdx.x, blockIdx.y}; // (a 3-D grid: no division on the way to the first load)
+    TileCtx c = ctx_in(a, id.img);
+#if defined(PIXO_PROBE)
+    { uint32_t seen = id.ty + c.W; asm volatile("" : "+s"(seen)); } // (the kernel arguments have arrived)
+    PIXO_STAMP(1);
+#endif
     constexpr int base = G::items / kWaves, extra = G::items % kWaves;
     const bool last_rows = (id.ty + 1) * (uint32_t)G::tile_h >= a.H; // this tile reads the image's last pixel row
-    if (extra && wave < extra) phase_a<MODE, LOAD, base + 1>(c, id, wave * (base + 1), lane, lds, last_rows);
-    else phase_a<MODE, LOAD, base>(c, id, extra * (base + 1) + (wave - extra) * base, lane, lds, last_rows);
+    const int first = (extra && wave < extra) ? wave * (base + 1) : extra * (base + 1) + (wave - extra) * base;
+    if (extra && wave < extra) phase_a<MODE, LOAD, base + 1>(a, c, id, first, lane, lds, last_rows);
+    else phase_a<MODE, LOAD, base>(a, c, id, first, lane, lds, last_rows);
     lds_barrier();
     __builtin_amdgcn_s_setprio(0);
-    PIXO_STAMP(3); // barrier passed: phase B begins
+    {
+        uint32_t img = id.img;
+        asm volatile("" : "+s"(img)); // (keeps the output pointers' arithmetic behind the barrier)
+        ctx_out(c, a, img);
+    }
+    PIXO_STAMP(5); // barrier passed: phase B begins
     float v[64];
     consumer_rows<MODE>(wave, lane, lds, v);
     consumer_cols(v);
-    PIXO_STAMP(4); // transform done
+    PIXO_STAMP(6); // transform done
     if (RAW) { // hand the transformed blocks to the trellis quantiser instead of quantising here
         store_raw_block<MODE>(a, c, id, wave, lane, v);
         return;
     }
     uint8_t *stage = lds + stage_offset<MODE>(wave); // inside this wavefront's own planar area
     uint32_t qw[32];
-#if defined(PIXO_QUANT_LDS)
-    consumer_quant_lds<MODE>(wave, lane, a.qt, ldsq, v, qw);
-#else
     consumer_quant<MODE>(wave, lane, a.qt, v, qw);
-#endif
-    PIXO_STAMP(5); // quantised: the first store is next
+    PIXO_STAMP(7); // quantised: the first store is next
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         consumer_stage_blocks(lane, h, qw, stage);
@@ -223,9 +253,9 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
         consumer_stage_sync();
     }
 #if defined(PIXO_PROBE)
-    PIXO_STAMP(6); // last store issued
+    PIXO_STAMP(8); // last store issued
     __builtin_amdgcn_s_waitcnt(0); // (vmcnt(0): the stores have been acknowledged)
-    PIXO_STAMP(7);
+    PIXO_STAMP(9);
 #endif
 }
 
@@ -234,11 +264,19 @@ template <int MODE, int LOAD> static hipError_t launch_mode(KArgs &a, hipStream_
     const bool raw = a.ry != nullptr;
     a.tiles_x = (a.units_x + Geo<MODE>::units_x - 1) / Geo<MODE>::units_x;
     a.tiles_y = (a.units_y * (MODE == M420 ? 16u : 8u) + Geo<MODE>::tile_h - 1) / Geo<MODE>::tile_h;
-    const uint64_t total64 = (uint64_t)a.tiles_x * a.tiles_y * a.batch;
-    if (total64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const uint32_t total = (uint32_t)total64;
-    if (raw) hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, true>), dim3(total), dim3(kThreads), 0, s, a);
-    else hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, false>), dim3(total), dim3(kThreads), 0, s, a);
+    if (a.tiles_y > 65535u || a.batch > 65535u) return hipErrorInvalidValue; // (grid y and z; heights and batches are at most 65535)
+    const dim3 grid(a.tiles_x, a.tiles_y, a.batch); // workgroups are numbered x fastest: consecutive tiles of a row on consecutive XCDs
+#if defined(PIXO_PROBE)
+    a.probe_launch = g_probe_launch++ % kProbeLaunches;
+#endif
+    KRest rest;
+    rest.px_bytes = a.px_bytes; rest.y_stride = a.y_stride; rest.c_stride = a.c_stride; rest.ry = a.ry; rest.rcb = a.rcb; rest.rcr = a.rcr;
+    rest.units_x = a.units_x; rest.units_y = a.units_y; rest.fast = a.fast;
+#if defined(PIXO_PROBE)
+    rest.probe_launch = a.probe_launch;
+#endif
+    if (raw) hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, true>), grid, dim3(kThreads), 0, s, a.px, a.W, a.H, a.px_stride, a.y, a.cb, a.cr, a.qt, rest);
+    else hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, false>), grid, dim3(kThreads), 0, s, a.px, a.W, a.H, a.px_stride, a.y, a.cb, a.cr, a.qt, rest);
     return hipGetLastError();
 }
 
@@ -289,9 +327,12 @@ hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gra
 } // namespace pixo_dev
 
 #if defined(PIXO_PROBE)
-extern "C" int pixo_hip_debug_probe_buffer(void *d_buffer)
-{ // d_buffer: workgroups x 3 x 8 u64, or null to switch the stamps off
+extern "C" int pixo_hip_debug_probe_buffer(void *d_buffer, unsigned words_per_launch)
+{ // d_buffer: kProbeLaunches x words_per_launch u64 (a launch needs workgroups x 3 x kProbeSlots), or null to switch the stamps off
     unsigned long long *p = static_cast<unsigned long long *>(d_buffer);
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(pixo_dev::g_probe), &p, sizeof p);
+    pixo_dev::g_probe_launch = 0;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(pixo_dev::g_probe_stride), &words_per_launch, sizeof words_per_launch);
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(pixo_dev::g_probe), &p, sizeof p);
+    return (int)e;
 }
 #endif

@@ -88,28 +88,56 @@ __device__ __forceinline__ void store_relaxed(unsigned long long *p, unsigned lo
 // to the fabric (the XCDs' L2s are not coherent with each other): one lane walking back took 100 us for the 4096x4096
 // image, 64 per round still 90 (32 dependent rounds for the last group).  Every lane returns the sum.
 constexpr int kLookBatch = 8;
-__device__ __forceinline__ void publish_aggregate(unsigned long long *desc, uint64_t g, uint64_t aggregate)
-{ // (one lane) as early as possible: the groups behind this one wait for it
-    store_relaxed(&desc[g], (g == 0 ? kFlagPrefix : kFlagAggregate) | aggregate);
+// Waiting is BOUNDED: forward progress of these kernels rests on the hardware starting the workgroups of a
+// grid in increasing id order (file header) — observed, not promised by HIP.  Every poll loop gives up after `budget`
+// polls (launch argument; 2^20 polls of >= 64 cycles each = tens of milliseconds, three orders of magnitude beyond any
+// real wait) and raises the launch's abort flag, which every other waiting workgroup checks as well: the kernel then
+// ends with garbage in its outputs instead of hanging the GPU, and the host — which reads the flag from the pinned
+// mailbox behind the stream's synchronisation — codes the scan again with the multi-pass kernels of jpeg_entropy.hip.
+struct Waiter {
+    unsigned long long *abort_flag; // device word, zero at launch; host_abort: the same in the pinned mailbox (or null)
+    unsigned long long *host_abort;
+    uint32_t budget;
+    uint32_t polls = 0;
+    bool failed = false;
+    __device__ __forceinline__ bool keep_waiting() // one poll has found nothing: sleep, count, look at the flag
+    {
+        __builtin_amdgcn_s_sleep(1);
+        if (++polls > budget || ((polls & 63u) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            failed = true;
+            __hip_atomic_store(abort_flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (host_abort) *host_abort = 1ull;
+            return false;
+        }
+        return true;
+    }
+};
+__device__ __forceinline__ void publish_aggregate(unsigned long long *desc, uint64_t g, uint64_t floor, uint64_t aggregate)
+{ // (one lane) as early as possible: the groups behind this one wait for it.  `floor`: first ticket of g's chain (0; the
+  // first group of g's segment): it has nothing before it, its aggregate IS its inclusive prefix
+    store_relaxed(&desc[g], (g == floor ? kFlagPrefix : kFlagAggregate) | aggregate);
 }
-__device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t g, uint64_t aggregate)
+__device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t g, uint64_t floor, uint64_t aggregate, Waiter &w)
 { // (after publish_aggregate)
     const int lane = threadIdx.x & 63;
-    if (g == 0) return 0;
+    if (g == floor) return 0;
     uint64_t before = 0;
     for (int64_t top = (int64_t)g - 1;; top -= 64 * kLookBatch) {
         unsigned long long d[kLookBatch];
 #pragma unroll
         for (int i = 0; i < kLookBatch; i++) {
             const int64_t j = top - lane - 64 * i;
-            d[i] = j >= 0 ? load_relaxed(&desc[j]) : kFlagPrefix; // (below ticket 0: an inclusive prefix of nothing)
+            d[i] = j >= (int64_t)floor ? load_relaxed(&desc[j]) : kFlagPrefix; // (below the chain's first ticket: an inclusive prefix of nothing)
         }
         bool done = false;
 #pragma unroll
         for (int i = 0; i < kLookBatch; i++) {
             if (done) break; // (wave-uniform)
             const int64_t j = top - lane - 64 * i;
-            while ((d[i] >> 62) == 0) { __builtin_amdgcn_s_sleep(1); d[i] = load_relaxed(&desc[j]); }
+            while (PIXO_ANY64((d[i] >> 62) == 0)) { // (wave-uniform loop: the budget is counted per wavefront)
+                if (!w.keep_waiting()) return 0;
+                if ((d[i] >> 62) == 0) d[i] = load_relaxed(&desc[j]);
+            }
             const uint64_t have_prefix = __builtin_amdgcn_ballot_w64((d[i] >> 62) == 2);
             const int first = have_prefix ? __builtin_ctzll(have_prefix) : 64; // nearest predecessor that knows its inclusive prefix
             // aggregates of the lanes in front of it (< 2^19 each: 32-bit sum), plus its prefix
@@ -153,38 +181,56 @@ struct LdsSink {
     }
 };
 
-template <int MODE>
+// SEG (segmented scans: the images of a batch, restart intervals — SegArgs in jpeg_entropy.hpp): the scan consists of
+// byte-aligned segments of seg.blocks blocks, each coded from DC predictors 0 into a packed stream of ITS OWN (region
+// seg.stream_words * segment of `stream`) and padded with 1-bits like the end of a scan; the groups of 192 blocks are
+// aligned with the segments (the last group of a segment is partly empty), a segment's first group is the floor of its
+// groups' look-back — nothing crosses a segment — and its last group leaves the segment's length in seg.bits.  How the
+// segments follow each other in the file is the stuffing kernel's business.
+template <int MODE, bool SEG>
 __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) void scan_code_kernel
 (const ScanArgs a, unsigned long long *state, uint32_t *stream, unsigned long long *clear, uint32_t clear_words,
- unsigned long long *host_totals, const ScanPiece piece)
+ unsigned long long *host_totals, const ScanPiece piece, const SegArgs seg, uint32_t spin_budget)
 {
-    // state: [0] unused, [1] total bits (out), [2 ..] per group: descriptor, then per group: tail
+    // state: [0] abort flag, [1] total bits (out), [2 ..] per group: descriptor, then per group: tail
     __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
     __shared__ uint32_t tab[kWalkWords]; // the Huffman tables in the flat walk's form (jpeg_scan_block.h)
     __shared__ uint32_t scratch[kGroup * kScratchPitch];
     __shared__ uint32_t wave_sum[kGroupWaves], wave_long[kGroupWaves];
     __shared__ unsigned long long s_before;
-    __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_carry, s_abort;
     const int lane = threadIdx.x, wave = lane >> 6;
-    if (lane == 0) s_carry = 0;
-    const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
-    unsigned long long *desc = state + 2, *tails = state + 2 + ngroups;
+    if (lane == 0) { s_carry = 0; s_abort = 0; }
+    const uint64_t g = blockIdx.x; // (one group per workgroup; see the note on dispatch order at the top of the file)
+    // the group's place: segment, first ticket of the segment (the look-back's floor), blocks
+    uint64_t floor_g = 0, first_in_chain = g * kGroup, nblocks_chain = a.nblocks, sidx = 0;
+    if (SEG) {
+        sidx = g / seg.groups;
+        floor_g = sidx * seg.groups;
+        const uint64_t seg_first_block = sidx * seg.blocks;
+        nblocks_chain = a.nblocks - seg_first_block < seg.blocks ? a.nblocks - seg_first_block : seg.blocks;
+        first_in_chain = (g - floor_g) * kGroup;
+        if (first_in_chain >= nblocks_chain) return; // (the last segment is shorter: its surplus groups)
+        stream += sidx * seg.stream_words;
+    }
+    const uint64_t ngroups_total = SEG ? seg.nsegs * seg.groups : (a.nblocks + kGroup - 1) / kGroup;
+    unsigned long long *desc = state + 2, *tails = state + 2 + ngroups_total;
+    Waiter waiter{state, host_totals ? host_totals + 3 : nullptr, spin_budget};
     // A scan coded piece by piece (ScanPiece, jpeg_entropy.hpp): the piece's stream is byte-aligned with the SCAN — its
     // first `lead` bits are the end of the piece before — so that the stuffing kernel can work on it without a shift.
     const uint64_t bits_before_piece = piece.index ? piece.chain[piece.index] : 0ull;
     const uint32_t lead = (uint32_t)(bits_before_piece & 7);
     if (piece.chain && piece.index == 0 && blockIdx.x == 0 && lane == 0) piece.chain[0] = 0; // (read by piece 1)
-    const uint64_t g = blockIdx.x; // (one group per workgroup; see the note on dispatch order at the top of the file)
     // ---- blocks in, before anything else (the barrier below then waits once for these, the tables and the housekeeping):
     // 8 x 16 bytes per lane straight into 32 registers.  A lane's block is one 128-byte line that its eight loads touch
     // one after the other: cached loads (the line stays in L1 for the other seven), not non-temporal ones.  (Staging
     // the group through LDS for perfectly coalesced loads cost 24 KiB per group and 60 more VGPRs for the addresses:
     // half the occupancy.)
-    const uint64_t s = piece.first_block + g * kGroup + lane;
-    const bool live = g * kGroup + lane < a.nblocks;
+    const bool live = first_in_chain + lane < nblocks_chain;
+    const uint64_t s = piece.first_block + (SEG ? sidx * seg.blocks : 0) + first_in_chain + lane;
     uint32_t w[32];
     // DC predictor: the previous block of the same component (jpeg/mod.rs:1417-1419); the scan's first blocks start
-    // from the seed (0, or the DCs above a band)
+    // from the seed (0, or the DCs above a band); a segment's first blocks from 0 (jpeg/mod.rs:1441-1444)
     int prev_dc = 0, cls = 0;
     {
         const BlockRef ref = block_of(MODE, live ? s : 0);
@@ -198,6 +244,11 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         if (live) {
             prev_dc = ref.index ? (int)base[(ref.index - 1) * 64] : (int)a.seed_dc[ref.comp];
             cls = ref.comp == 0 ? 0 : 1;
+            if (SEG) { // the first block of every component in the segment's first MCU
+                const uint64_t in_seg = first_in_chain + lane;
+                const bool first_of_comp = MODE == 2 ? (in_seg == 0 || in_seg == 4 || in_seg == 5) : in_seg < (uint64_t)a.blocks_per_mcu;
+                if (first_of_comp) prev_dc = 0;
+            }
         }
     }
     for (int i = lane; i < kWalkWords; i += kGroup) tab[i] = a.tables[kTableWords + i]; // (the walk's form lies behind the packed one)
@@ -231,8 +282,8 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             group_bits += wave_sum[k];
             group_long |= wave_long[k];
         }
-        if (lane == 0) publish_aggregate(desc, g, group_bits);
-        const bool last_group = g + 1 == ngroups;
+        if (lane == 0) publish_aggregate(desc, g, floor_g, group_bits);
+        const bool last_group = first_in_chain + kGroup >= nblocks_chain;
         // ---- the blocks' bits at GROUP-RELATIVE offsets into the LDS buffer — the position in the stream is not needed
         // for that, and meanwhile the aggregates of the groups before travel — one window of kWindowWords words per
         // round (usually one): gathered from the scratches, or (a group with a long block) packed by a second walk;
@@ -277,18 +328,24 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             }
             if (wbase == 0) { // where the group starts in the stream
                 if (wave == 0) {
-                    const uint64_t sum = look_back(desc, g, group_bits);
+                    const uint64_t sum = look_back(desc, g, floor_g, group_bits, waiter);
                     if (lane == 0) {
+                        if (waiter.failed) s_abort = 1;
                         s_before = sum;
-                        if (g) store_relaxed(&desc[g], kFlagPrefix | (sum + group_bits));
+                        if (g != floor_g) store_relaxed(&desc[g], kFlagPrefix | (sum + group_bits));
                         if (last_group) { // the stream's length in bits (unpadded; a later piece: with its leading bits)
-                            state[1] = lead + sum + group_bits;
-                            if (host_totals) host_totals[0] = lead + sum + group_bits;
-                            if (piece.chain) piece.chain[piece.index + 1] = bits_before_piece + sum + group_bits;
+                            if (SEG) {
+                                seg.bits[sidx] = sum + group_bits;
+                            } else {
+                                state[1] = lead + sum + group_bits;
+                                if (host_totals) host_totals[0] = lead + sum + group_bits;
+                                if (piece.chain) piece.chain[piece.index + 1] = bits_before_piece + sum + group_bits;
+                            }
                         }
                     }
                 }
                 __syncthreads();
+                if (s_abort) return; // (the look-back gave up: the host codes this scan again, see Waiter)
                 const uint64_t start = lead + s_before;
                 uint64_t end = start + group_bits;
                 if (last_group && a.pad_last) { // BitWriterMsb::flush pads the last byte with 1-bits
@@ -336,9 +393,12 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         // link one round: 310 us for 2048 groups of two rounds, against 45).
         if (sh != 0 && lane == 0) {
             uint32_t inherited = 0;
-            if (g > 0) {
+            if (g > floor_g) {
                 unsigned long long t = load_relaxed(&tails[g - 1]);
-                while (!(t & kTailValid)) { __builtin_amdgcn_s_sleep(1); t = load_relaxed(&tails[g - 1]); }
+                while (!(t & kTailValid)) {
+                    if (!waiter.keep_waiting()) return;
+                    t = load_relaxed(&tails[g - 1]);
+                }
                 inherited = (uint32_t)t;
             } else if (piece.index) { // the `lead` bits of the byte shared with the piece before: the last, partial byte of its stream
                 const uint64_t before_prev = piece.chain[piece.index - 1];

@@ -462,40 +462,74 @@ template <int N, bool LAST_ROWS> PIXO_DEV void funnel_load(const TileCtx &c, con
     for (int i = 0; i < N; i++) r[i] = alignbyte(w[i + 1], w[i], sh);
 }
 
+// What a lane needs to address its pixels, computed ONCE per wavefront (vector paths): the tile's first row as a
+// wave-uniform 64-bit pointer and the lane's byte offset inside a row for each half of the tile — clamped to the row's last
+// 4-pixel group, which is the reference's replicate rule.  Every load is then  tile_row0 + (row inside the tile) * stride
+// [scalar, 32-bit arithmetic] + xoff[half] [vector]: five or six scalar instructions per row.  The scalar unit is shared
+// by the CU's 24 wavefronts, which all start within a microsecond and all do their address arithmetic before their first
+// load: with a 64-bit multiplication per row and divisions for the tile's coordinates (~300 scalar instructions per
+// wavefront) the median wavefront issued its loads 4.5 us after the dispatch began, the memory system idle meanwhile
+// (profiles/r03_timeline_c2_before.txt).
+struct LaneAddr {
+    const uint8_t *tile_row0; // uniform: first byte of the tile's first pixel row (x = 0)
+    uint32_t stride;          // uniform: bytes per pixel row
+    uint32_t row_first;       // uniform: the tile's first pixel row
+    uint32_t xoff0, xoff1;    // per lane: byte offset of the lane's 4-pixel group in the left / right half of the tile
+};
+template <int MODE> PIXO_DEV LaneAddr lane_addr(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int lane)
+{
+    typedef Geo<MODE> G;
+    LaneAddr a;
+    a.stride = c.W * (uint32_t)G::bpp;
+    a.row_first = tile_y * (uint32_t)G::tile_h;
+    a.tile_row0 = c.px + (size_t)a.row_first * a.stride;
+    const uint32_t x0 = tile_x * kTileW + 4u * (uint32_t)lane, x1 = x0 + 256u, last = c.W >= 4 ? c.W - 4 : 0u;
+    a.xoff0 = (x0 < last ? x0 : last) * (uint32_t)G::bpp;
+    a.xoff1 = (x1 < last ? x1 : last) * (uint32_t)G::bpp;
+    PIXO_PIN(a.xoff0); PIXO_PIN(a.xoff1); // (two registers for the whole phase; left alone the compiler re-derives them per item from three)
+    return a;
+}
+
+// three dwords at a dword-aligned address: ONE 12-byte load (three separate loads left the merging to the compiler, which
+// at times made a 4-byte and an 8-byte load with a 64-bit vector address of their own)
+PIXO_DEV void load_dwordx3(const uint8_t *p, uint32_t *r)
+{
+#if defined(PIXO_EMU)
+    memcpy(r, p, 12);
+#else
+    typedef uint32_t v3a4 __attribute__((ext_vector_type(3), aligned(4)));
+    const v3a4 q = PIXO_GLOAD((const v3a4 *)p);
+    r[0] = q.x; r[1] = q.y; r[2] = q.z;
+#endif
+}
+
 template <int MODE, int LOAD, bool LAST_ROWS = true>
-PIXO_DEV void producer_load_item(const TileCtx &c, uint32_t tile_x, uint32_t tile_y, int k, int lane,
+PIXO_DEV void producer_load_item(const TileCtx &c, const LaneAddr &la, uint32_t tile_x, uint32_t tile_y, int k, int lane,
                                  uint32_t *r)
 {
-    const uint32_t x0 = tile_x * kTileW + 4 * ((k & 1) * 64 + lane);
-    const uint32_t y0 = tile_y * Geo<MODE>::tile_h + (MODE == M420 ? 2 : 1) * (k >> 1);
     if (LOAD != L_BYTES) {
-        // uniform 64-bit row base (scalar ALU) + per-lane 32-bit byte offset: the loads use the
-        // saddr + voffset form and cost no 64-bit vector arithmetic
-        const uint32_t xoff = (x0 < c.W - 4 ? x0 : c.W - 4) * Geo<MODE>::bpp;
+        // rows inside the tile, clamped to the image's last row (the reference's replicate rule for rows,
+        // jpeg/mod.rs:1579,1627); everything wave-uniform and 32-bit: a tile has at most 24 rows of at most 196,605 bytes
+        const uint32_t y0 = la.row_first + (MODE == M420 ? 2u : 1u) * (uint32_t)(k >> 1);
         const uint32_t ya = y0 < c.H ? y0 : c.H - 1;
-        const uint8_t *row = c.px + (size_t)ya * ((size_t)c.W * Geo<MODE>::bpp);
+        const uint8_t *row = la.tile_row0 + (ya - la.row_first) * la.stride;
+        const uint32_t xoff = (k & 1) ? la.xoff1 : la.xoff0; // (a select, not an indexed array: that would live in scratch)
         if (MODE == MGRAY) {
             if (LOAD == L_ALIGNED) r[0] = PIXO_GLOAD((const uint32_t *)(row + xoff));
             else funnel_load<1, LAST_ROWS>(c, row, xoff, r);
         } else {
-            if (LOAD == L_ALIGNED) {
-                const uint32_t *q = (const uint32_t *)(row + xoff);
-                r[0] = PIXO_GLOAD(q); r[1] = PIXO_GLOAD(q + 1); r[2] = PIXO_GLOAD(q + 2);
-            } else {
-                funnel_load<3, LAST_ROWS>(c, row, xoff, r);
-            }
+            if (LOAD == L_ALIGNED) load_dwordx3(row + xoff, r);
+            else funnel_load<3, LAST_ROWS>(c, row, xoff, r);
             if (MODE == M420) {
                 const uint32_t yb = y0 + 1 < c.H ? y0 + 1 : c.H - 1;
-                const uint8_t *row2 = c.px + (size_t)yb * ((size_t)c.W * 3);
-                if (LOAD == L_ALIGNED) {
-                    const uint32_t *q2 = (const uint32_t *)(row2 + xoff);
-                    r[3] = PIXO_GLOAD(q2); r[4] = PIXO_GLOAD(q2 + 1); r[5] = PIXO_GLOAD(q2 + 2);
-                } else {
-                    funnel_load<3, LAST_ROWS>(c, row2, xoff, r + 3);
-                }
+                const uint8_t *row2 = la.tile_row0 + (yb - la.row_first) * la.stride;
+                if (LOAD == L_ALIGNED) load_dwordx3(row2 + xoff, r + 3);
+                else funnel_load<3, LAST_ROWS>(c, row2, xoff, r + 3);
             }
         }
     } else {
+        const uint32_t x0 = tile_x * kTileW + 4 * ((k & 1) * 64 + lane);
+        const uint32_t y0 = tile_y * Geo<MODE>::tile_h + (MODE == M420 ? 2 : 1) * (k >> 1);
         if (MODE == MGRAY) {
             r[0] = gather_row4_gray(c.px, c.W, c.H, x0, y0);
         } else {
@@ -545,13 +579,14 @@ PIXO_DEV void producer_fix_item(const TileCtx &c, uint32_t tile_x, int k, int la
     }
 }
 
-template <int MODE> PIXO_DEV void producer_color_item(int k, int lane, const uint32_t *r, uint8_t *planar)
+// DOT4: the 4:2:0 conversion with v_dot4_u32_u8 (color_row4_dot) — the kernels that read pixels with vector loads; the
+// byte-gather kernel (images narrower than four pixels) keeps the packed multiply-adds.
+template <int MODE, bool DOT4 = false> PIXO_DEV void producer_color_item(int k, int lane, const uint32_t *r, uint8_t *planar)
 {
     const int h = k & 1, g = h * 64 + lane, row = k >> 1;
     if (MODE == M420) {
         uint8_t *yp = planar + h * 4352 + (2 * row) * kPitchHalf + 4 * lane;
-#if defined(PIXO_COLOR_DOT4) || defined(PIXO_EMU_COLOR_DOT4)
-        {
+        if (DOT4) {
             const Row4D a = color_row4_dot(r[0], r[1], r[2]);
             PIXO_SCHED_FENCE(); // one row at a time: few temporaries
             const Row4D b = color_row4_dot(r[3], r[4], r[5]);
@@ -562,7 +597,6 @@ template <int MODE> PIXO_DEV void producer_color_item(int k, int lane, const uin
             *(uint32_t *)(planar + 12800 + row * 512 + 4 * g) = add_bytes1(a.cr[0], a.cr[1], a.cr[2], a.cr[3]) + add_bytes1(b.cr[0], b.cr[1], b.cr[2], b.cr[3]);
             return;
         }
-#endif
         Row4 a = color_row4(r[0], r[1], r[2]);
         PIXO_SCHED_FENCE(); // one row at a time: few temporaries
         Row4 b = color_row4(r[3], r[4], r[5]);
@@ -878,68 +912,6 @@ template <int MODE> PIXO_DEV void consumer_quant(int wave, int lane, const float
     const BlockDesc d = block_desc<MODE>(wave, lane, nullptr);
     const qtab_t tab = as_qtab(qt);
     block_quant(v, tab + uniform_i32(d.rcp_off), tab + uniform_i32(d.q_off), d.scale, out);
-}
-
-// The same with the bracketing reciprocals in VECTOR registers, read from a copy of the table in LDS (every lane the
-// same address: a broadcast read).  A VALU instruction with a scalar-register operand issues at half rate on gfx950
-// (tools/ubench/form_rate.hip: v_fma_f32 v, s, v 4.2 cycles; v_fmaak_f32 v, v, v, K 2.1): with the reciprocals in
-// VGPRs the two roundings of a coefficient cost 4.2 cycles instead of 8.4.  Only four coefficients' worth (eight
-// registers) are alive at a time, fetched right before their use — the other five wavefronts of the SIMD cover the
-// LDS latency — because the block's 64 floats are still alive when the quantiser starts.
-// LDS layout (floats): kind k at [128 k, 128 k + 128) = rlo[64], rhi[64]; kind 0 = luminance, kind 1 = chrominance
-// (4:2:0: the table for the 2x2 sums).
-constexpr int kQuantLdsFloats = 256;
-template <int MODE> PIXO_DEV int quant_lds_source(int i) // which float of the quality's table block goes to LDS float i
-{
-    return (i < 128 ? 0 : (MODE == M420 ? 384 : 256) - 128) + i;
-}
-struct alignas(16) f32x4 { float x, y, z, w; };
-// four coefficients: quant_row4 with the reciprocals read from LDS at `lq` (rlo) and `lq + 64` (rhi).  The rare path
-// reads them again instead of keeping them: the registers are needed for the block's floats.
-PIXO_DEV void quant_row4_lds(const float *x, const float *lq, qtab_t q, float scale, uint32_t out[2])
-{
-    float s[4];
-    uint32_t differ = 0;
-    {
-        const f32x4 l4 = *(const f32x4 *)lq, h4 = *(const f32x4 *)(lq + 64);
-        differ |= quant_bracket(x[0], l4.x, h4.x, &s[0]);
-        differ |= quant_bracket(x[1], l4.y, h4.y, &s[1]);
-        differ |= quant_bracket(x[2], l4.z, h4.z, &s[2]);
-        differ |= quant_bracket(x[3], l4.w, h4.w, &s[3]);
-    }
-    if (PIXO_ANY_LANE(differ != 0)) { // rare: some quotient next to a rounding boundary
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            float xc = x[c], t;
-            PIXO_PIN(xc);
-            if (PIXO_ANY_LANE(quant_bracket(xc, lq[c], lq[64 + c], &t) != 0)) {
-                const float n = __builtin_roundf((x[c] * scale) / q[c]); // the reference operation itself
-                s[c] = n + kRoundMagic;                                   // exact: |n| < 2^15
-            }
-            PIXO_SCHED_FENCE();
-        }
-    }
-    out[0] = perm(fbits(s[1]), fbits(s[0]), 0x05040100u);
-    out[1] = perm(fbits(s[3]), fbits(s[2]), 0x05040100u);
-}
-PIXO_DEV void block_quant_lds(const float *v, const float *lq, qtab_t q, float scale, uint32_t *out)
-{
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-#pragma unroll
-        for (int hh = 0; hh < 2; hh++) {
-            const int at = u * 8 + hh * 4;
-            quant_row4_lds(&v[at], lq + at, q + at, scale, &out[u * 4 + hh * 2]);
-            PIXO_PIN(out[u * 4 + hh * 2]); PIXO_PIN(out[u * 4 + hh * 2 + 1]);
-            PIXO_SCHED_FENCE();
-        }
-    }
-}
-template <int MODE> PIXO_DEV void consumer_quant_lds(int wave, int lane, const float *qt, const float *ldsq, const float *v, uint32_t *out)
-{
-    const BlockDesc d = block_desc<MODE>(wave, lane, nullptr);
-    const qtab_t tab = as_qtab(qt);
-    block_quant_lds(v, ldsq + uniform_i32(d.rcp_off ? 128 : 0), tab + uniform_i32(d.q_off), d.scale, out);
 }
 
 // Consumer step 4' (round h = 0, 1): the lanes of half h stage their blocks.

@@ -107,6 +107,9 @@ int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, co
                const pixo_host::Geometry &g, uint32_t batch, const int16_t *band_seed_dc)
 {
     namespace pd = pixo_dev;
+    // every pass starts from scratch: a job object that is kept across calls (the band encoder's) must not carry the last
+    // image's tables, lengths or flags into the next one (scan_tables would otherwise return early with the old tables)
+    j = ScanJob{};
     j.n = (g.y_blocks + 2 * g.c_blocks) * batch;
     pd::ScanArgs &a = j.a;
     a.y = dy; a.cb = dcb; a.cr = dcr;

@@ -27,10 +27,12 @@ static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long
             memset(planar, 0xA5, G::planar); // nothing may rely on a previous tile's samples
             // producer wavefront: every lane loads and converts its items of this tile
             for (int lane = 0; lane < 64; lane++) {
-                for (int k = 0; k < G::items; k++) producer_load_item<MODE, LOAD>(c, tx, ty, k, lane, &regs[k * G::item_regs]);
+                LaneAddr la{};
+                if (LOAD != L_BYTES) la = lane_addr<MODE>(c, tx, ty, lane);
+                for (int k = 0; k < G::items; k++) producer_load_item<MODE, LOAD>(c, la, tx, ty, k, lane, &regs[k * G::item_regs]);
                 for (int k = 0; k < G::items; k++) {
                     producer_fix_item<MODE, LOAD>(c, tx, k, lane, &regs[k * G::item_regs]);
-                    producer_color_item<MODE>(k, lane, &regs[k * G::item_regs], planar);
+                    producer_color_item<MODE, LOAD != L_BYTES>(k, lane, &regs[k * G::item_regs], planar); // (the shipped kernels: dot4 conversion with the vector loads)
                 }
             }
             // (barrier) consumer wavefronts, in a caller-chosen order: they share nothing

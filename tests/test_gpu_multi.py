@@ -92,6 +92,31 @@ def test_band_encoder_pieces_equal_the_host_twins():
             prev = last
 
 
+def test_one_band_encoder_reused_for_two_images_builds_each_image_its_own_tables():
+    """A band encoder kept across images (persistent workers do that) must start every pass from scratch: with optimised
+    tables the second image's scan has to be coded with the tables of ITS statistics, and `lengths` called twice with
+    different statistics must follow the second (the job used to keep `tables_ready` and the first tables)."""
+    w, h = 520, 330
+    o = _opts(w, h, 2, 1, 80, optimize_huffman=True)
+    enc = jpeg.BandEncoder(o, 1, 0, 0)
+    try:
+        for seed, make in ((12, synth.noise), (3, lambda w_, h_, s_: synth.gradient_rgb(w_, h_)), (5, synth.noise)):
+            px = make(w, h, seed)
+            y, cb, cr = O.coeffs(px, w, h, 2, 1, 80)
+            enc.coeffs(px)
+            total = enc.count([0, 0, 0])
+            assert np.array_equal(total, jpeg.band_count_host(y, cb, cr, o, h, [0, 0, 0]))
+            other = total.copy()
+            other[:12] = other[:12][::-1]  # some other statistics first: the second call must win
+            other[other == 0] = 1
+            enc.lengths([0, 0, 0], other)
+            bits = enc.lengths([0, 0, 0], total)
+            assert bits == jpeg.band_bits_host(y, cb, cr, o, h, [0, 0, 0], total)
+            assert enc.pack(0) == jpeg.band_piece_host(y, cb, cr, o, h, [0, 0, 0], 0, total)
+    finally:
+        enc.close()
+
+
 def test_band_encoder_refuses_option_sets_a_band_cannot_code():
     from pixo_amd import error
     with pytest.raises(error.Error, match="baseline scans without restart markers"):

@@ -11,8 +11,11 @@ for f in jpeg_integer.hip jpeg_entropy.hip jpeg_scan_fused.hip jpeg_trellis.hip 
   if [ ! -f $o ] || [ $f -nt $o ] || [ -n "$(find . ../../include -name '*.h*' -newer $o | head -1)" ]; then /opt/rocm/bin/hipcc $FLAGS -c $f -o $o & fi
 done
 wait
+# (the shipped build's flag for jpeg_kernels.hip, see the Makefile; a variant may override it with its own -mllvm option)
+PRELOAD="-mllvm -amdgpu-kernarg-preload-count=14"
 while [ $# -ge 2 ]; do
-  /opt/rocm/bin/hipcc $FLAGS $2 -c jpeg_kernels.hip -o $OBJ/jpeg_kernels_$1.o
+  case "$2" in *NO_PRELOAD*) P="";; *) P="$PRELOAD";; esac
+  /opt/rocm/bin/hipcc $FLAGS $P $2 -c jpeg_kernels.hip -o $OBJ/jpeg_kernels_$1.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../ab_$1.so $OBJ/jpeg_kernels_$1.o $OBJ/jpeg_integer.o $OBJ/jpeg_entropy.o $OBJ/jpeg_scan_fused.o $OBJ/jpeg_trellis.o $OBJ/png_filter.o $OBJ/context.o $OBJ/scan_job.o $OBJ/pieces.o $OBJ/progressive.o $OBJ/jpeg_api.o $OBJ/png_api.o $OBJ/bands.o $OBJ/jpeg_host.o
   echo "built ab_$1.so ($2)"
   shift 2

@@ -441,6 +441,10 @@ def run_coeffs(job, args):
         except Exception:
             pass
         try:
+            others["c3_whole_file"] = batch_whole_files(job, args.quality)
+        except BaseException as ex:
+            others["c3_whole_file"] = {"error": repr(ex)}
+        try:
             others["c5"] = quick_png(job)
         except BaseException as ex:
             others["c5"] = {"error": repr(ex)}
@@ -457,6 +461,43 @@ def run_coeffs(job, args):
         if ref:
             line["cpu_reference"] = ref
     job.finish(line)
+
+
+def batch_whole_files(job, q, n_batches=7):
+    """configs[2] as WHOLE FILES: 64 x 1920x1080 device-resident images -> 64 JPEG files back to back in the caller's pinned
+    arena (pixo_hip_jpeg_encode_batch_device_into): one coefficient launch, the images as segments of the two single-pass
+    entropy kernels, every file copied from the device straight to its final place."""
+    import numpy as np
+    import synth
+    from pixo_amd import jpeg
+    torch = job.torch
+    w, h, n = 1920, 1080, 64
+    base = torch.from_numpy(np.ascontiguousarray(synth.noise(w, h, 42))).to(job.dev)
+    d = torch.cat([base ^ torch.tensor(i, dtype=torch.uint8, device=job.dev) for i in range(n)]).contiguous()
+    opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling.S420).build()
+    arena = torch.empty(n * w * h, dtype=torch.uint8).pin_memory()
+    offs, lens = jpeg.encode_batch_device_into(arena, d, opts, n)
+    import oracle_lib as O
+    first = arena[offs[0]: offs[0] + lens[0]].numpy().tobytes()
+    if first != O.encode(synth.noise(w, h, 42), O.make_options(w, h, 2, q, 1)):
+        raise SystemExit("bench: batch file 0 differs from the oracle's — refusing to report a number")
+    ts = []
+    for _ in range(n_batches):
+        t1 = time.perf_counter()
+        offs, lens = jpeg.encode_batch_device_into(arena, d, opts, n)
+        ts.append(time.perf_counter() - t1)
+    dt = sorted(ts)[len(ts) // 2]
+    tb = []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        jpeg.encode_batch_device(d, opts, n)
+        tb.append(time.perf_counter() - t1)
+    del d, arena
+    torch.cuda.empty_cache()
+    return {"workload": "configs[2] whole files: 64 x 1920x1080 RGB8 noise, q=%d, 4:2:0 -> 64 files in one pinned arena" % q,
+            "ms_per_batch": round(dt * 1e3, 3), "ms_per_batch_min": round(min(ts) * 1e3, 3), "Mpixels_per_s": round(w * h * n / dt / 1e6, 1),
+            "file_bytes_total": int(sum(lens)), "ms_per_batch_as_64_malloced_files": round(sorted(tb)[1] * 1e3, 3),
+            "path": "pixo_hip_jpeg_encode_batch_device_into"}
 
 
 def whole_file(job, wl):
@@ -477,7 +518,14 @@ def whole_file(job, wl):
             jpeg.encode_device(wl.ins[i % wl.nbuf], opts)
             tb.append(time.perf_counter() - t1)
         dt, dtb = sorted(ts)[n_files // 2], sorted(tb)[3]
+        host_px = torch.from_numpy(wl.base.copy())  # pageable host pixels, as pixo::jpeg::encode's caller has them
+        th = []
+        for i in range(7):
+            t1 = time.perf_counter()
+            jpeg.encode_into_buffer(pinned.numpy(), host_px.numpy(), opts)
+            th.append(time.perf_counter() - t1)
         return {"value": round(wl.w * wl.h / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_image": round(dt * 1e3, 3),
+                "whole_file_from_host_ms": round(sorted(th)[3] * 1e3, 3), "whole_file_from_host_min_ms": round(min(th) * 1e3, 3),
                 "ms_per_image_min": round(min(ts) * 1e3, 3), "file_bytes": int(nbytes), "ms_per_image_as_python_bytes": round(dtb * 1e3, 3),
                 "path": "device-resident pixels -> coefficient kernel -> device Huffman/pack/stuff kernels "
                         "-> file in the caller's pinned host buffer (pixo_hip_jpeg_encode_device_into)"}

@@ -164,11 +164,20 @@ int pixo_hip_jpeg_encode_device_into(const void *d_pixels, const pixo_jpeg_optio
                                      uint8_t *output, size_t capacity, size_t *out_len);
 
 /* pixo::jpeg::encode for `batch` equally sized images back to back in HBM (config 3: 64 x 1080p):
- * one coefficient launch and ONE pass of the device entropy stage for all of them (every image is a
- * byte-aligned segment of one packed stream), files[i] / lens[i] receive `batch` malloc'd files
- * (pixo_hip_free).  With optimize_huffman or restart markers the images are encoded one by one. */
+ * one coefficient launch and ONE pass of the device entropy stage for all of them — every image a byte-aligned
+ * segment of the two single-pass entropy kernels — files[i] / lens[i] receive `batch` malloc'd files
+ * (pixo_hip_free).  With optimize_huffman, progressive scans or restart markers the images are encoded one by one. */
 int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_options *options, uint32_t batch,
                                       uint8_t **files, size_t *lens);
+
+/* The same into ONE block of caller storage: file i occupies arena[offsets[i], offsets[i] + lens[i]), the files follow
+ * each other without gaps (offsets[0] = 0); every file is copied from the device straight to its final place — with
+ * pinned (hipHostMalloc / registered) storage the device-to-host copy is the only pass over the bytes.  offsets and lens
+ * have `batch` entries.  When the files do not fit, offsets / lens are still filled in (capacity needed =
+ * offsets[batch - 1] + lens[batch - 1]), nothing is copied and PIXO_ERR_BUFFER_TOO_SMALL is returned.  A null arena with
+ * capacity 0 is a size query.  Replaces a loop over pixo::jpeg::encode_into (src/jpeg/mod.rs:328). */
+int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg_options *options, uint32_t batch,
+                                           uint8_t *arena, size_t capacity, size_t *offsets, size_t *lens);
 
 /* ---- PNG row filters + Adler-32 ------------------------------ */
 
@@ -323,6 +332,9 @@ int pixo_hip_trim(void);
  * piece_schedule=a:b:c, copy_threads=n, spin_budget=n, no_bands_upload — pixo_amd/csrc/capi_internal.hpp).  None of
  * them changes the bytes of a file.  NULL = read the environment again.  Not synchronised with calls in flight. */
 int pixo_hip_debug_configure(const char *switches_or_null);
+/* How often a single-pass entropy kernel gave up waiting (its waits on other workgroups are bounded) and the scan was
+ * coded again by the multi-pass kernels, in this process.  0 in normal operation. */
+uint64_t pixo_hip_debug_lookback_fallbacks(void);
 void pixo_hip_free(void *p);
 const char *pixo_hip_last_error(void);      /* thread-local, never NULL               */
 const char *pixo_hip_version(void);

@@ -18,6 +18,8 @@ struct pixo_hip_band_encoder {
     ScanJob job;
     int stage = 0;                       // 0 created, 1 coefficients done, 2 lengths done
     int16_t last_dc[3] = {0, 0, 0};
+    int16_t prev_dc[3] = {0, 0, 0};      // what `lengths` was called with (a pack that has to start over needs them again)
+    std::vector<uint64_t> counts;        // ... and the statistics of all bands (optimised tables), empty = none
 };
 
 namespace {
@@ -146,9 +148,18 @@ int pixo_hip_band_encoder_lengths(pixo_hip_band_encoder *e, const int16_t prev_d
         return fail(PIXO_ERR_COMPRESSION, "Compression error: band encoder: optimised tables need the statistics of all bands");
     Context &c = *e->c;
     PIXO_ON_DEVICE_OF(c);
+    for (int i = 0; i < 3; ++i) e->prev_dc[i] = prev_dc[i];
+    e->counts.clear();
+    if (total_counts) e->counts.assign(total_counts, total_counts + PIXO_HIP_COUNT_WORDS);
     int rc = scan_begin(c, e->job, e->dy, e->dcb, e->dcr, e->band, e->g, 1, prev_dc);
     if (rc) return rc;
-    if ((rc = scan_lengths(c, e->job, e->image, e->g, c.stream, total_counts))) return rc;
+    rc = scan_lengths(c, e->job, e->image, e->g, c.stream, total_counts);
+    if (rc == kRetryMultipass) { // a single-pass kernel gave up waiting: the band again with the multi-pass kernels
+        RetryMultipass scope;
+        if ((rc = scan_begin(c, e->job, e->dy, e->dcb, e->dcr, e->band, e->g, 1, prev_dc))) return rc;
+        rc = scan_lengths(c, e->job, e->image, e->g, c.stream, total_counts);
+    }
+    if (rc) return rc == kRetryMultipass ? fail(PIXO_ERR_COMPRESSION, "Compression error: the entropy kernels could not make progress") : rc;
     *bits = e->job.total_bits;
     e->stage = 2;
     return PIXO_OK;
@@ -165,7 +176,14 @@ int pixo_hip_band_encoder_pack_device(pixo_hip_band_encoder *e, uint64_t bit_off
     uint32_t head = 0, tail = 0;
     int tail_bits = 0;
     int rc = scan_pack(c, e->job, c.stream, bit_offset, &head, &tail_bits, &tail);
-    if (rc) return rc;
+    if (rc == kRetryMultipass) { // (the stuffing kernel gave up waiting: lengths and packing again, multi-pass)
+        RetryMultipass scope;
+        const uint64_t *tc = e->counts.empty() ? nullptr : e->counts.data();
+        if ((rc = scan_begin(c, e->job, e->dy, e->dcb, e->dcr, e->band, e->g, 1, e->prev_dc))) return rc;
+        if ((rc = scan_lengths(c, e->job, e->image, e->g, c.stream, tc))) return rc;
+        rc = scan_pack(c, e->job, c.stream, bit_offset, &head, &tail_bits, &tail);
+    }
+    if (rc) return rc == kRetryMultipass ? fail(PIXO_ERR_COMPRESSION, "Compression error: the entropy kernels could not make progress") : rc;
     HIP_TRY(hipStreamSynchronize(c.stream)); // the body is complete in the encoder's device buffer
     std::vector<uint8_t> hdr;
     pixo_host::make_piece(hdr, e->job.head_bits, head, tail_bits, tail, nullptr, 0);

@@ -221,8 +221,20 @@ struct ScanJob {
     int head_bits = 0;       // band: how many of its first bits share a byte with the band before
     bool fused = false;      // one uninterrupted scan: the two single-pass kernels of jpeg_scan_fused.hip
     bool segmented = false;  // byte-aligned segments (images of a batch, restart intervals) in the single-pass kernels
+    pixo_dev::SegArgs seg;   // ... their geometry and per-segment arrays (c.e_segs, c.h_segs)
     size_t stream_cap = 0;   // fused: bytes the packed stream can take at most
 };
+// A step of a job returns this when a single-pass kernel gave up waiting (bounded look-back, jpeg_scan_fused.hip): nothing of
+// the job's results is valid; run the job again inside a RetryMultipass scope, which makes scan_begin choose the multi-pass
+// kernels.  (Internal: never returned through the C ABI.)
+constexpr int kRetryMultipass = 1000;
+extern thread_local bool t_force_multipass;
+struct RetryMultipass {
+    RetryMultipass() { t_force_multipass = true; }
+    ~RetryMultipass() { t_force_multipass = false; }
+};
+int scan_retry_multipass(Context &c);
+uint64_t lookback_fallbacks(); // how often that has happened in this process (tests)
 // Where the stuffed bytes go when not into the context's device buffer: host memory the GPU can write (pinned), so that
 // the kernel's stores ARE the transfer — no second pass over the file, no second synchronisation.
 struct HostTarget {
@@ -259,7 +271,10 @@ struct PixelSource {
 int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                              const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len,
                              uint32_t batch = 1, std::vector<uint64_t> *image_starts = nullptr, size_t *header_len = nullptr,
-                             uint8_t *dest = nullptr, size_t dest_cap = 0, bool *own_malloc = nullptr, const PixelSource *src = nullptr);
+                             uint8_t *dest = nullptr, size_t dest_cap = 0, bool *own_malloc = nullptr, const PixelSource *src = nullptr,
+                             std::vector<uint8_t> *head_out = nullptr);
+// (head_out != null: no copy to the host — *head_out receives the file headers, *file_len the bytes of the stuffed scan(s)
+// left in c.e_out, image_starts where each image's bytes begin; the caller delivers them)
 int device_entropy_to_malloc(Context &c, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                              const pixo_host::Geometry &g, hipStream_t stream, uint8_t **out_buf, size_t *out_len);
 int device_tuple_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,

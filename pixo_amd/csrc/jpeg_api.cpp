@@ -33,13 +33,17 @@ int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options
     PIXO_ON_DEVICE_OF(c);
     const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
     if ((rc = c.reserve_px((px_bytes + 15) & ~size_t{15}))) return rc;
-    Stopwatch sw;
-    HIP_TRY(hipMemcpyAsync(c.d_px, data, px_bytes, hipMemcpyHostToDevice, c.stream));
-    sw.lap("pixels to device (enqueued)");
-    if (o.progressive) return progressive_to_view(c.d_px, o, g, c, spill, file, file_len);
+    if (o.progressive) {
+        HIP_TRY(hipMemcpyAsync(c.d_px, data, px_bytes, hipMemcpyHostToDevice, c.stream));
+        return progressive_to_view(c.d_px, o, g, c, spill, file, file_len);
+    }
+    // baseline: the entropy stage launches the uploads and the coefficient kernel itself — band by band for images of
+    // 2048x2048 pixels and more, so that bands are transformed and coded while the next ones cross PCIe and the file's
+    // first pieces travel back meanwhile (pieces.cpp)
     int16_t *dy, *dcb, *dcr;
-    if ((rc = coeffs_on_device(c, c.d_px, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
-    return device_entropy_to_pinned(c, dy, dcb, dcr, o, g, c.stream, file, file_len, 1, nullptr, nullptr, dest, dest_cap, own_malloc);
+    if ((rc = coeffs_reserve(c, g, &dy, &dcb, &dcr))) return rc;
+    PixelSource src{c.d_px, &o, &g, dy, dcb, dcr, data};
+    return device_entropy_to_pinned(c, dy, dcb, dcr, o, g, c.stream, file, file_len, 1, nullptr, nullptr, dest, dest_cap, own_malloc, &src);
 }
 
 int fail_tuple_trellis()
@@ -361,6 +365,34 @@ int pixo_hip_jpeg_encode_device_into(const void *d_pixels, const pixo_jpeg_optio
                                     output ? output : &nowhere, output ? capacity : 0, nullptr, &src);
 }
 
+} // extern "C"
+
+namespace {
+// The entropy-coded bytes of a batch in c.e_out: one coefficient launch + one pass of the entropy stage (the images are
+// segments of the single-pass kernels).  Only for option sets that allow it (see the callers).
+int batch_on_device(Context &c, const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, uint32_t batch,
+                    std::vector<uint8_t> &head, std::vector<uint64_t> &starts)
+{
+    const float *qt_all = nullptr;
+    int rc = device_tables(c.device, &qt_all);
+    if (rc) return rc;
+    const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128 * batch;
+    if ((rc = c.reserve_coef(coef_bytes))) return rc;
+    int16_t *dy = static_cast<int16_t *>(c.d_coef), *dcb = dy + g.y_blocks * 64 * batch, *dcr = dcb + g.c_blocks * 64 * batch;
+    HIP_TRY(pixo_dev::launch_jpeg_coeffs(d_pixels, o.width, o.height, g.gray, g.s420, batch, dy, g.gray ? nullptr : dcb,
+                                         g.gray ? nullptr : dcr, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c.stream));
+    const uint8_t *unused = nullptr;
+    size_t scan_bytes = 0;
+    return device_entropy_to_pinned(c, dy, dcb, dcr, o, g, c.stream, &unused, &scan_bytes, batch, &starts, nullptr, nullptr, 0, nullptr, nullptr, &head);
+}
+bool batch_in_one_pass(const pixo_jpeg_options &o, const pixo_host::Geometry &g, uint32_t batch, size_t px_bytes)
+{
+    return batch > 1 && !o.progressive && !o.optimize_huffman && !scan_has_restart_markers(o, g) && px_bytes % 4 == 0;
+}
+} // namespace
+
+extern "C" {
+
 int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_options *options, uint32_t batch,
                                       uint8_t **files, size_t *lens)
 {
@@ -371,6 +403,7 @@ int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_opti
     int rc = pixo_host::validate(*options, false, 0, msg);
     if (rc) return fail(rc, msg);
     if (batch == 0 || batch > 65535) return fail(PIXO_ERR_COMPRESSION, "Compression error: batch must be 1..65535");
+    PIXO_REQUIRE(d_pixels);
     Context *c = nullptr;
     if ((rc = context_on_current_device(&c))) return rc;
     const pixo_jpeg_options &o = *options;
@@ -378,50 +411,99 @@ int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_opti
     const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
     for (uint32_t i = 0; i < batch; ++i) { files[i] = nullptr; lens[i] = 0; }
     auto release = [&](int code) { for (uint32_t i = 0; i < batch; ++i) { std::free(files[i]); files[i] = nullptr; } return code; };
-    // Per-image tables or restart segments inside the images: one image at a time.
-    if (o.progressive) {
+    if (!batch_in_one_pass(o, g, batch, px_bytes)) { // per-image tables or segments inside the images: one image at a time
         for (uint32_t i = 0; i < batch; ++i)
             if ((rc = pixo_hip_jpeg_encode_device(static_cast<const uint8_t *>(d_pixels) + i * px_bytes, options, &files[i], &lens[i]))) return release(rc);
         return PIXO_OK;
     }
-    if (batch == 1 || o.optimize_huffman || scan_has_restart_markers(o, g) || px_bytes % 4 != 0) {
-        for (uint32_t i = 0; i < batch; ++i) {
-            int16_t *dy, *dcb, *dcr;
-            if ((rc = coeffs_on_device(*c, static_cast<const uint8_t *>(d_pixels) + i * px_bytes, o, g, c->stream, &dy, &dcb, &dcr))) return release(rc);
-            if ((rc = device_tuple_to_malloc(dy, dcb, dcr, o, g, *c, &files[i], &lens[i]))) return release(rc);
-        }
-        return PIXO_OK;
-    }
-    // one coefficient launch and one entropy pass for the whole batch
-    const float *qt_all = nullptr;
-    if ((rc = device_tables(c->device, &qt_all))) return rc;
-    const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128 * batch;
-    if ((rc = c->reserve_coef(coef_bytes))) return rc;
-    int16_t *dy = static_cast<int16_t *>(c->d_coef), *dcb = dy + g.y_blocks * 64 * batch, *dcr = dcb + g.c_blocks * 64 * batch;
-    HIP_TRY(pixo_dev::launch_jpeg_coeffs(d_pixels, o.width, o.height, g.gray, g.s420, batch, dy, g.gray ? nullptr : dcb,
-                                         g.gray ? nullptr : dcr, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c->stream));
-    const uint8_t *blob = nullptr;
-    size_t blob_len = 0, hdr = 0;
+    std::vector<uint8_t> head;
     std::vector<uint64_t> starts;
-    if ((rc = device_entropy_to_pinned(*c, dy, dcb, dcr, o, g, c->stream, &blob, &blob_len, batch, &starts, &hdr))) return rc;
+    if ((rc = batch_on_device(*c, d_pixels, o, g, batch, head, starts))) return rc;
+    const size_t hdr = head.size(), scan_bytes = static_cast<size_t>(starts[batch]);
+    // the stuffed bytes cross PCIe once, into the context's pinned buffer (a device-to-host copy into fresh pageable blocks
+    // would make the runtime pin new pages every call); from there into the files the caller will own — fresh memory,
+    // page-fault bound: several threads (see big_copy)
+    if ((rc = c->reserve_hfile(scan_bytes ? scan_bytes : 1))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h_file, c->e_out.p, scan_bytes, hipMemcpyDeviceToHost, c->stream));
     for (uint32_t i = 0; i < batch; ++i) {
         lens[i] = hdr + static_cast<size_t>(starts[i + 1] - starts[i]) + 2;
         files[i] = static_cast<uint8_t *>(std::malloc(lens[i]));
-        if (!files[i]) return release(fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory"));
+        if (!files[i]) { (void)hipStreamSynchronize(c->stream); return release(fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory")); }
     }
-    // headers + own segment + EOI into every file; the files are fresh memory: several threads (see big_copy)
-    const size_t total = blob_len + static_cast<size_t>(batch) * hdr;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t total = scan_bytes + static_cast<size_t>(batch) * (hdr + 2);
     const unsigned t = static_cast<unsigned>(std::min<size_t>(std::min<size_t>(debug().copy_threads, batch), total >> 21));
     run_on_threads(t ? t : 1, [&](unsigned k) {
         for (uint32_t i = k; i < batch; i += (t ? t : 1)) {
             const size_t seg = lens[i] - hdr - 2;
             uint8_t *p = files[i];
-            std::memcpy(p, blob, hdr);
-            std::memcpy(p + hdr, blob + hdr + starts[i], seg);
+            std::memcpy(p, head.data(), hdr);
+            std::memcpy(p + hdr, c->h_file + starts[i], seg);
             p[hdr + seg] = 0xFF; p[hdr + seg + 1] = 0xD9;
         }
     });
     return PIXO_OK;
 }
+
+int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg_options *options, uint32_t batch,
+                                           uint8_t *arena, size_t capacity, size_t *offsets, size_t *lens)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(offsets);
+    PIXO_REQUIRE(lens);
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if (batch == 0 || batch > 65535) return fail(PIXO_ERR_COMPRESSION, "Compression error: batch must be 1..65535");
+    PIXO_REQUIRE(d_pixels);
+    if (capacity && !arena) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'arena'");
+    Context *c = nullptr;
+    if ((rc = context_on_current_device(&c))) return rc;
+    const pixo_jpeg_options &o = *options;
+    const pixo_host::Geometry g = pixo_host::geometry(o.width, o.height, o.color_type, o.subsampling);
+    const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
+    for (uint32_t i = 0; i < batch; ++i) { offsets[i] = 0; lens[i] = 0; }
+    if (!batch_in_one_pass(o, g, batch, px_bytes)) { // one image at a time, each straight into its place behind the one before
+        size_t at = 0;
+        bool fits = true;
+        for (uint32_t i = 0; i < batch; ++i) {
+            size_t n = 0;
+            static uint8_t nowhere;
+            uint8_t *dst = fits && arena && at < capacity ? arena + at : &nowhere;
+            rc = pixo_hip_jpeg_encode_device_into(static_cast<const uint8_t *>(d_pixels) + i * px_bytes, options, dst, dst == &nowhere ? 0 : capacity - at, &n);
+            if (rc == PIXO_ERR_BUFFER_TOO_SMALL) fits = false;
+            else if (rc) return rc;
+            offsets[i] = at; lens[i] = n;
+            at += n;
+        }
+        if (!fits) return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(at) + " bytes");
+        return PIXO_OK;
+    }
+    std::vector<uint8_t> head;
+    std::vector<uint64_t> starts;
+    if ((rc = batch_on_device(*c, d_pixels, o, g, batch, head, starts))) return rc;
+    const size_t hdr = head.size();
+    size_t at = 0;
+    for (uint32_t i = 0; i < batch; ++i) {
+        offsets[i] = at;
+        lens[i] = hdr + static_cast<size_t>(starts[i + 1] - starts[i]) + 2;
+        at += lens[i];
+    }
+    if (at > capacity) return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(at) + " bytes");
+    // every file's entropy-coded bytes from the device straight to their final place; headers and EOI by the host meanwhile
+    for (uint32_t i = 0; i < batch; ++i) {
+        const size_t seg = lens[i] - hdr - 2;
+        if (seg) HIP_TRY(hipMemcpyAsync(arena + offsets[i] + hdr, c->e_out.as<uint8_t>() + starts[i], seg, hipMemcpyDeviceToHost, c->stream));
+    }
+    for (uint32_t i = 0; i < batch; ++i) {
+        uint8_t *p = arena + offsets[i];
+        std::memcpy(p, head.data(), hdr);
+        p[lens[i] - 2] = 0xFF; p[lens[i] - 1] = 0xD9;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PIXO_OK;
+}
+
+uint64_t pixo_hip_debug_lookback_fallbacks(void) { return lookback_fallbacks(); }
 
 } // extern "C"

@@ -79,12 +79,38 @@ struct ScanPiece {
     unsigned long long *chain; // device, pieces + 1 words (null: not a chain)
     const uint32_t *prev_stream;
 };
+// SEGMENTED scans in the single-pass kernels: the scan is cut into byte-aligned segments of `blocks` blocks (the last
+// one may be shorter) — the images of a batch (marker_bytes 0) or restart intervals (marker_bytes 2: FF D0+(k & 7)
+// behind every segment but the last, jpeg/mod.rs:1423-1445).  Every segment starts from DC predictors 0, is packed into a
+// stream of its own (region `stream_words` * k of d_stream: blocks * 209 bytes + slack, a multiple of 16) and 1-padded.
+// code<SEG> -> bits[k]; launch_seg_layout -> layout / bytes; stuff<SEG> -> the segments back to back in d_out (markers
+// in between), out_end[k] = where segment k's entropy-coded bytes end (device array; host_out_end: the same in pinned
+// host memory, or null).
+struct SegArgs {
+    uint64_t nsegs = 0;
+    uint32_t blocks = 0, groups = 0;     // per segment: blocks, groups of 192 (seg_groups(blocks))
+    uint64_t stream_words = 0;
+    unsigned long long *bits = nullptr;        // [nsegs] out of code
+    const unsigned long long *layout = nullptr; // [nsegs + 2] out of launch_seg_layout: [0] tiles, [1 + k] first tile of segment k
+    const unsigned long long *bytes = nullptr;  // [nsegs] packed bytes per segment
+    unsigned long long *out_end = nullptr;      // [nsegs]
+    unsigned long long *host_out_end = nullptr;
+    uint32_t marker_bytes = 0;
+};
+uint32_t seg_groups(uint64_t seg_blocks);
+size_t fused_code_state_words_seg(uint64_t nsegs, uint64_t seg_blocks);
+hipError_t launch_seg_layout(const SegArgs &seg, unsigned long long *d_layout, unsigned long long *d_bytes, unsigned long long *host_totals,
+                             hipStream_t s); // host_totals[2] (or null) receives the total number of 16 KiB tiles
+
+// The single-pass kernels wait for lower-numbered workgroups (look-back, shared words).  Every wait is bounded by
+// `spin_budget` polls: a kernel that exhausts it raises an abort flag — d_state[0] and host_totals[3] — and ends without
+// hanging the GPU; its outputs are garbage then and the caller must code the scan another way.
 // state_is_zero: the caller knows d_state holds zeros (word 1 aside) — the stuffing kernel of the previous scan left it so —
 // and no memset is launched.  d_clear / clear_words: words this kernel zeroes on the side (the state of the stuffing launch
 // that follows), or null.  host_totals: pinned host memory (or null): [0] also receives the scan's length — no read-back copy.
 hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool state_is_zero, uint32_t *d_stream,
                             unsigned long long *d_clear, size_t clear_words, unsigned long long *host_totals, hipStream_t s,
-                            const ScanPiece *piece = nullptr);
+                            const ScanPiece *piece = nullptr, const SegArgs *seg = nullptr, uint32_t spin_budget = 1u << 20);
 // stuff: the stream's bytes from bit `shift` (< 8) on -> d_out with 0x00 behind every 0xFF.  band = false: all bytes of a
 // whole scan (shift 0); band = true: only the whole bytes behind the band's first `shift` bits.  Reads the scan's length
 // from d_code_state[1] (no host round trip) and zeroes the rest of d_code_state (code_state_words) for the next scan.
@@ -99,7 +125,8 @@ uint64_t stuff_tiles(uint64_t stream_bytes);
 hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_code_state, size_t code_state_words, uint32_t shift, bool band,
                               uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state,
                               bool state_is_zero, uint8_t *d_out, uint64_t out_cap, unsigned long long *host_totals, hipStream_t s,
-                              unsigned long long *d_out_chain = nullptr, uint32_t piece = 0);
+                              unsigned long long *d_out_chain = nullptr, uint32_t piece = 0, const SegArgs *seg = nullptr,
+                              uint32_t spin_budget = 1u << 20);
 // (d_out_chain, piece: the piece's bytes go to d_out + d_out_chain[piece] (piece 0: d_out); d_out_chain[piece + 1] receives
 // where they end; d_state[1] / host_totals[1] count this piece's bytes only)
 

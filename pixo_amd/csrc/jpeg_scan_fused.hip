@@ -94,31 +94,22 @@ constexpr int kLookBatch = 8;
 // real wait) and raises the launch's abort flag, which every other waiting workgroup checks as well: the kernel then
 // ends with garbage in its outputs instead of hanging the GPU, and the host — which reads the flag from the pinned
 // mailbox behind the stream's synchronisation — codes the scan again with the multi-pass kernels of jpeg_entropy.hip.
-struct Waiter {
-    unsigned long long *abort_flag; // device word, zero at launch; host_abort: the same in the pinned mailbox (or null)
-    unsigned long long *host_abort;
-    uint32_t budget;
-    uint32_t polls = 0;
-    bool failed = false;
-    __device__ __forceinline__ bool keep_waiting() // one poll has found nothing: sleep, count, look at the flag
-    {
-        __builtin_amdgcn_s_sleep(1);
-        if (++polls > budget || ((polls & 63u) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-            failed = true;
-            __hip_atomic_store(abort_flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (host_abort) *host_abort = 1ull;
-            return false;
-        }
-        return true;
-    }
-};
+// (one lane) raises the launch's abort flag, on the device and in the pinned mailbox
+__device__ __forceinline__ void raise_abort(unsigned long long *abort_flag, unsigned long long *host_abort)
+{
+    __hip_atomic_store(abort_flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (host_abort) *host_abort = 1ull;
+}
+constexpr uint64_t kLookBackFailed = ~0ull;
 __device__ __forceinline__ void publish_aggregate(unsigned long long *desc, uint64_t g, uint64_t floor, uint64_t aggregate)
 { // (one lane) as early as possible: the groups behind this one wait for it.  `floor`: first ticket of g's chain (0; the
   // first group of g's segment): it has nothing before it, its aggregate IS its inclusive prefix
     store_relaxed(&desc[g], (g == floor ? kFlagPrefix : kFlagAggregate) | aggregate);
 }
-__device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t g, uint64_t floor, uint64_t aggregate, Waiter &w)
-{ // (after publish_aggregate)
+__device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t g, uint64_t floor, uint64_t aggregate, unsigned long long *abort_flag,
+                                              unsigned long long *host_abort, uint32_t budget)
+{ // (after publish_aggregate); kLookBackFailed: gave up waiting
+    uint32_t polls = 0;
     const int lane = threadIdx.x & 63;
     if (g == floor) return 0;
     uint64_t before = 0;
@@ -134,9 +125,15 @@ __device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t
         for (int i = 0; i < kLookBatch; i++) {
             if (done) break; // (wave-uniform)
             const int64_t j = top - lane - 64 * i;
-            while (PIXO_ANY64((d[i] >> 62) == 0)) { // (wave-uniform loop: the budget is counted per wavefront)
-                if (!w.keep_waiting()) return 0;
-                if ((d[i] >> 62) == 0) d[i] = load_relaxed(&desc[j]);
+            bool gave_up = false;
+            while ((d[i] >> 62) == 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++polls > budget) { gave_up = true; break; }
+                d[i] = load_relaxed(&desc[j]);
+            }
+            if (PIXO_ANY64(gave_up)) { // (wave-uniform)
+                if (gave_up) raise_abort(abort_flag, host_abort);
+                return kLookBackFailed;
             }
             const uint64_t have_prefix = __builtin_amdgcn_ballot_w64((d[i] >> 62) == 2);
             const int first = have_prefix ? __builtin_ctzll(have_prefix) : 64; // nearest predecessor that knows its inclusive prefix
@@ -210,12 +207,12 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const uint64_t seg_first_block = sidx * seg.blocks;
         nblocks_chain = a.nblocks - seg_first_block < seg.blocks ? a.nblocks - seg_first_block : seg.blocks;
         first_in_chain = (g - floor_g) * kGroup;
-        if (first_in_chain >= nblocks_chain) return; // (the last segment is shorter: its surplus groups)
         stream += sidx * seg.stream_words;
     }
+    const bool surplus = SEG && first_in_chain >= nblocks_chain; // (the last segment is shorter: its surplus groups only do the housekeeping)
     const uint64_t ngroups_total = SEG ? seg.nsegs * seg.groups : (a.nblocks + kGroup - 1) / kGroup;
     unsigned long long *desc = state + 2, *tails = state + 2 + ngroups_total;
-    Waiter waiter{state, host_totals ? host_totals + 3 : nullptr, spin_budget};
+    unsigned long long *const host_abort = host_totals ? host_totals + 3 : nullptr;
     // A scan coded piece by piece (ScanPiece, jpeg_entropy.hpp): the piece's stream is byte-aligned with the SCAN — its
     // first `lead` bits are the end of the piece before — so that the stuffing kernel can work on it without a shift.
     const uint64_t bits_before_piece = piece.index ? piece.chain[piece.index] : 0ull;
@@ -226,7 +223,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     // one after the other: cached loads (the line stays in L1 for the other seven), not non-temporal ones.  (Staging
     // the group through LDS for perfectly coalesced loads cost 24 KiB per group and 60 more VGPRs for the addresses:
     // half the occupancy.)
-    const bool live = first_in_chain + lane < nblocks_chain;
+    const bool live = !surplus && first_in_chain + lane < nblocks_chain;
     const uint64_t s = piece.first_block + (SEG ? sidx * seg.blocks : 0) + first_in_chain + lane;
     uint32_t w[32];
     // DC predictor: the previous block of the same component (jpeg/mod.rs:1417-1419); the scan's first blocks start
@@ -254,6 +251,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     for (int i = lane; i < kWalkWords; i += kGroup) tab[i] = a.tables[kTableWords + i]; // (the walk's form lies behind the packed one)
     // (housekeeping for the kernel that follows: its descriptors must be zero when it starts — cheaper here than a memset launch)
     for (uint64_t i = (uint64_t)blockIdx.x * kGroup + lane; i < clear_words; i += (uint64_t)gridDim.x * kGroup) clear[i] = 0;
+    if (surplus) return;
     __syncthreads();
     {
         // ---- THE walk: the block's codes into the lane's scratch from bit 0 — which also gives its length; group scan;
@@ -328,9 +326,9 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             }
             if (wbase == 0) { // where the group starts in the stream
                 if (wave == 0) {
-                    const uint64_t sum = look_back(desc, g, floor_g, group_bits, waiter);
+                    const uint64_t sum = look_back(desc, g, floor_g, group_bits, state, host_abort, spin_budget);
                     if (lane == 0) {
-                        if (waiter.failed) s_abort = 1;
+                        if (sum == kLookBackFailed) s_abort = 1;
                         s_before = sum;
                         if (g != floor_g) store_relaxed(&desc[g], kFlagPrefix | (sum + group_bits));
                         if (last_group) { // the stream's length in bits (unpadded; a later piece: with its leading bits)
@@ -395,8 +393,10 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             uint32_t inherited = 0;
             if (g > floor_g) {
                 unsigned long long t = load_relaxed(&tails[g - 1]);
+                uint32_t polls = 0;
                 while (!(t & kTailValid)) {
-                    if (!waiter.keep_waiting()) return;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > spin_budget) { raise_abort(state, host_abort); return; }
                     t = load_relaxed(&tails[g - 1]);
                 }
                 inherited = (uint32_t)t;
@@ -496,37 +496,94 @@ __global__ __launch_bounds__(256) void scan_count_sum_kernel(const uint32_t *sla
 
 // ---- stuff: 16 KiB tiles of the packed stream ----------------------------------------------------------------------
 constexpr int kStuffThreads = 256, kLaneWords = 16, kWaveBytes = 64 * kLaneWords * 4, kTileBytes = (kStuffThreads / 64) * kWaveBytes;
-constexpr uint32_t kStageBytes = 2 * kTileBytes + 16; // worst case: every byte 0xFF, + the output's alignment skew
+constexpr uint32_t kStageBytes = 2 * kTileBytes + 32; // worst case: every byte 0xFF, + the output's alignment skew, + a marker (16-byte granules)
 __device__ __forceinline__ uint32_t zero_byte_mask(uint32_t x)
 { // 0x80 in every byte of x that is zero (exact)
     return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
 }
 
-__global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32_t *stream, const unsigned long long *code_state,
+// ---- segmented scans: where every segment's tiles begin -----------------------------------------------------------------
+// One workgroup, after scan_code<SEG>: from the segments' bit lengths the bytes of each (1-padded: whole bytes) and the
+// exclusive prefix sum of their 16 KiB tile counts, so that a stuffing workgroup finds its segment by binary search.
+// layout: [0] total tiles, [1 ..] first tile of segment i (nsegs + 1 entries); bytes: packed bytes of segment i.
+__global__ __launch_bounds__(1024) void seg_layout_kernel(const unsigned long long *seg_bits, uint64_t nsegs, unsigned long long *layout,
+                                                        unsigned long long *bytes, unsigned long long *host_totals)
+{
+    __shared__ uint64_t carry;
+    __shared__ uint64_t wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < nsegs; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t nb = i < nsegs ? (seg_bits[i] + 7) / 8 : 0;
+        if (i < nsegs) bytes[i] = nb;
+        const uint32_t t = (uint32_t)((nb + kTileBytes - 1) / kTileBytes);
+        const uint32_t incl = wave_inclusive_scan(t);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint64_t before = carry;
+        for (int k = 0; k < wave; k++) before += wsum[k];
+        if (i < nsegs) layout[1 + i] = before + incl - t;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        layout[1 + nsegs] = carry;
+        layout[0] = carry;
+        if (host_totals) host_totals[2] = carry; // (the host launches the tiles its guess missed)
+    }
+}
+
+// SEG: the tiles of all segments in one grid.  A tile's aggregate is what it PRODUCES (its bytes + the zeros stuffed
+// into them + the two marker bytes behind a segment's last tile), so the look-back over all tiles before it gives its
+// place in the output whatever the segments' lengths; the last tile of segment k also stores where the segment ends
+// (seg.out_end[k], device and pinned mailbox: a batch's files are cut there) and — restart intervals — writes RSTn.
+template <bool SEG>
+__global__ __launch_bounds__(kStuffThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void stuff_fused_kernel(const uint32_t *stream, const unsigned long long *code_state,
                                                                    uint32_t shift, uint32_t band, unsigned long long *state,
                                                                    uint8_t *out, uint32_t out_skew, uint64_t out_cap, uint64_t tile_offset,
                                                                    unsigned long long *clear, uint32_t clear_words,
                                                                    unsigned long long *host_totals, unsigned long long *out_chain,
-                                                                   uint32_t piece)
+                                                                   uint32_t piece, const SegArgs seg, uint32_t spin_budget)
 {
     // The bytes to stuff are the stream's bits from bit `shift` (< 8) on: 0 for a whole image (all bytes, the padded
     // last one included); for a band that starts inside a byte of the scan, its first `shift` bits belong to the byte
     // it shares with the band before, its whole bytes follow, the bits left over are the next band's business.
-    // state: [0] unused, [1] stuffed bytes (out), [2] bytes of the packed stream that were stuffed (out), [3 ..] descriptors
+    // state: [0] abort flag, [1] stuffed bytes (out), [2] bytes of the packed stream that were stuffed (out), [3 ..] descriptors
     // out: 16-byte aligned; the first stuffed byte goes to out[out_skew] (< 16; the bytes before it are somebody else's — the
     // file headers when `out` is the caller's host buffer — and are not touched); out_cap counts from out[0].
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes + kStuffThreads];
     __shared__ uint32_t wave_sum[kStuffThreads / 64];
     __shared__ unsigned long long s_before;
+    __shared__ uint32_t s_abort;
     const int lane = threadIdx.x, wave = lane >> 6;
-    const uint64_t total_bits = code_state[1];
+    if (lane == 0) s_abort = 0;
     // (housekeeping for the NEXT scan_code launch: its descriptors — everything but word 1, the length — back to zero)
     for (uint64_t i = (uint64_t)blockIdx.x * kStuffThreads + lane; i < clear_words; i += (uint64_t)gridDim.x * kStuffThreads)
         if (i != 1) clear[i] = 0;
     // (a scan stuffed piece by piece: this piece's bytes go behind those of the pieces before, out_chain[piece])
     const uint64_t out_before = out_chain && piece ? out_chain[piece] : 0ull;
-    const uint64_t nbytes = band ? (total_bits - (shift < total_bits ? shift : total_bits)) / 8 : (total_bits + 7) / 8;
-    const uint64_t ntiles = (nbytes + kTileBytes - 1) / kTileBytes;
+    const uint64_t t = tile_offset + blockIdx.x; // one tile per workgroup (the launcher guesses how many there are)
+    uint64_t nbytes, ntiles, local_t = t, sidx = 0;
+    if (SEG) {
+        ntiles = seg.layout[0];
+        if (t >= ntiles) return;
+        uint64_t lo = 0, hi = seg.nsegs; // the segment whose tiles include t: first[lo] <= t < first[lo + 1]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (seg.layout[1 + mid] <= t) lo = mid; else hi = mid;
+        }
+        sidx = lo;
+        local_t = t - seg.layout[1 + sidx];
+        nbytes = seg.bytes[sidx];
+        stream += sidx * seg.stream_words;
+    } else {
+        const uint64_t total_bits = code_state[1];
+        nbytes = band ? (total_bits - (shift < total_bits ? shift : total_bits)) / 8 : (total_bits + 7) / 8;
+        ntiles = (nbytes + kTileBytes - 1) / kTileBytes;
+    }
     unsigned long long *desc = state + 3;
     if (ntiles == 0) {
         if (blockIdx.x == 0 && lane == 0 && tile_offset == 0) {
@@ -536,7 +593,6 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
         }
         return;
     }
-    const uint64_t t = tile_offset + blockIdx.x; // one tile per workgroup (the launcher guesses how many there are)
     if (t < ntiles) {
         for (uint32_t i = 16u * lane; i < kStageBytes; i += 16u * kStuffThreads) *reinterpret_cast<v4u *>(stage + i) = v4u{0, 0, 0, 0};
         // ---- in.  Word k of lane l (of wavefront v) is word 64 k + l of the wavefront's 4 KiB: every load instruction
@@ -544,7 +600,7 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
         // (Round 2's first form gave every lane 64 CONSECUTIVE bytes: lanes 16 words apart, four banks for a wavefront,
         // every one of the 64 byte stores a 16-way conflict — the whole 20 us of the kernel.)
         const int wl = lane & 63;
-        const uint64_t wave0 = t * kTileBytes + (uint64_t)wave * kWaveBytes; // first byte of this wavefront's part
+        const uint64_t wave0 = local_t * kTileBytes + (uint64_t)wave * kWaveBytes; // first byte of this wavefront's part
         uint32_t w[kLaneWords];
         uint64_t flags = 0; // four flags per word, stream order (bit 4 k + b = byte b of word k is 0xFF and exists)
         {
@@ -588,22 +644,34 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
             if (k < wave) wave_base += wave_sum[k];
             tile_ff += wave_sum[k];
         }
-        if (lane == 0) publish_aggregate(desc, t, tile_ff);
+        const uint64_t tile_in = nbytes - local_t * kTileBytes < (uint64_t)kTileBytes ? nbytes - local_t * kTileBytes : (uint64_t)kTileBytes;
+        // SEG: is this the segment's last tile, and does a marker follow the segment?
+        const bool seg_last = SEG && (local_t + 1) * kTileBytes >= nbytes;
+        const uint32_t marker = seg_last && seg.marker_bytes && sidx + 1 < seg.nsegs ? 2u : 0u;
+        // the tile's aggregate: 0xFF bytes (one scan: its input bytes are known from t) — SEG: everything it produces
+        const uint32_t aggregate = SEG ? (uint32_t)tile_in + tile_ff + marker : tile_ff;
+        if (lane == 0) publish_aggregate(desc, t, 0, aggregate);
         if (wave == 0) {
-            const uint64_t sum = look_back(desc, t, tile_ff);
+            const uint64_t sum = look_back(desc, t, 0, aggregate, state, host_totals ? host_totals + 3 : nullptr, spin_budget);
             if (lane == 0) {
+                if (sum == kLookBackFailed) s_abort = 1;
                 s_before = sum;
-                if (t) store_relaxed(&desc[t], kFlagPrefix | (sum + tile_ff));
+                if (t) store_relaxed(&desc[t], kFlagPrefix | (sum + aggregate));
             }
         }
         __syncthreads();
-        const uint64_t ff_before = s_before;
-        const uint64_t tile_in = nbytes - t * kTileBytes < (uint64_t)kTileBytes ? nbytes - t * kTileBytes : (uint64_t)kTileBytes;
-        const uint64_t dst0 = out_skew + out_before + t * kTileBytes + ff_before; // where the tile's first output byte goes
-        const uint32_t tile_out = (uint32_t)tile_in + tile_ff; // bytes the tile produces
+        if (s_abort) return; // (the look-back gave up: the host codes this scan again, see Waiter)
+        const uint64_t produced_before = SEG ? s_before : t * kTileBytes + s_before;
+        const uint64_t dst0 = out_skew + out_before + produced_before; // where the tile's first output byte goes
+        const uint32_t tile_out = (uint32_t)tile_in + tile_ff + marker; // bytes the tile produces
+        if (SEG && seg_last && lane == 0) { // where the segment's entropy-coded bytes end (its marker not counted)
+            const uint64_t end = dst0 + tile_out - marker - out_skew;
+            seg.out_end[sidx] = end;
+            if (seg.host_out_end) seg.host_out_end[sidx] = end;
+        }
         if (t + 1 == ntiles && lane == 0) { // (totals of this launch's piece; out_chain: of the scan so far)
             state[1] = dst0 + tile_out - out_skew - out_before; state[2] = nbytes;
-            if (host_totals) { host_totals[1] = dst0 + tile_out - out_skew - out_before; host_totals[2] = nbytes; }
+            if (host_totals) { host_totals[1] = dst0 + tile_out - out_skew - out_before; if (!SEG) host_totals[2] = nbytes; }
             if (out_chain) out_chain[piece + 1] = dst0 + tile_out - out_skew;
         }
         // expand into LDS at the output's alignment (LDS dwords = global dwords).  The stage was zeroed: only the
@@ -625,6 +693,11 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
             }
         }
         __syncthreads();
+        if (marker && lane == 0) { // RSTn behind the segment (jpeg/mod.rs:1431-1440): FF D0 + (index & 7), never stuffed
+            stage[skew + tile_out - 2] = 0xFF;
+            stage[skew + tile_out - 1] = (uint8_t)(0xD0 + (sidx & 7));
+        }
+        if (marker) __syncthreads();
         // out: leading bytes up to the first aligned 16 bytes, aligned 16-byte pieces, trailing bytes
         const uint64_t base = dst0 - skew; // multiple of 16
         const uint32_t end = skew + tile_out;
@@ -646,28 +719,43 @@ __global__ __launch_bounds__(kStuffThreads) void stuff_fused_kernel(const uint32
 } // namespace
 
 size_t fused_code_state_words(uint64_t nblocks) { return 2 + 2 * (size_t)((nblocks + kGroup - 1) / kGroup); }
+size_t fused_code_state_words_seg(uint64_t nsegs, uint64_t seg_blocks) { return 2 + 2 * (size_t)(nsegs * ((seg_blocks + kGroup - 1) / kGroup)); }
 size_t fused_stuff_state_words(uint64_t max_stream_bytes) { return 3 + (size_t)((max_stream_bytes + kTileBytes - 1) / kTileBytes); }
+uint32_t seg_groups(uint64_t seg_blocks) { return (uint32_t)((seg_blocks + kGroup - 1) / kGroup); }
 
 hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool state_is_zero, uint32_t *d_stream,
                             unsigned long long *d_clear, size_t clear_words, unsigned long long *host_totals, hipStream_t s,
-                            const ScanPiece *piece_or_null)
+                            const ScanPiece *piece_or_null, const SegArgs *seg_or_null, uint32_t spin_budget)
 {
     const ScanPiece piece = piece_or_null ? *piece_or_null : ScanPiece{0, 0, nullptr, nullptr};
-    const uint64_t ngroups = (a.nblocks + kGroup - 1) / kGroup;
+    const SegArgs seg = seg_or_null ? *seg_or_null : SegArgs{};
+    const uint64_t ngroups = seg_or_null ? seg.nsegs * seg.groups : (a.nblocks + kGroup - 1) / kGroup;
+    const size_t state_words = seg_or_null ? fused_code_state_words_seg(seg.nsegs, seg.blocks) : fused_code_state_words(a.nblocks);
+    if (host_totals) host_totals[3] = 0; // (the kernels' abort flag: nothing in flight writes it, a context's launches are serial)
     if (ngroups == 0) {
-        if (host_totals) host_totals[0] = 0; // (nothing in flight writes it: a context's launches are serial)
+        if (host_totals) host_totals[0] = 0;
         return hipMemsetAsync(d_state, 0, 16, s);
     }
     if (!state_is_zero) {
-        hipError_t e = hipMemsetAsync(d_state, 0, fused_code_state_words(a.nblocks) * 8, s);
+        hipError_t e = hipMemsetAsync(d_state, 0, state_words * 8, s);
         if (e != hipSuccess) return e;
     }
     if (ngroups > 0x7FFFFFFFull || clear_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)ngroups;
     const uint32_t cw = d_clear ? (uint32_t)clear_words : 0u;
-    if (a.mode == 2) hipLaunchKernelGGL(scan_code_kernel<2>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals, piece);
-    else if (a.mode == 1) hipLaunchKernelGGL(scan_code_kernel<1>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals, piece);
-    else hipLaunchKernelGGL(scan_code_kernel<0>, dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals, piece);
+#define PIXO_LAUNCH_CODE(MODE, SEG) hipLaunchKernelGGL((scan_code_kernel<MODE, SEG>), dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals, piece, seg, spin_budget)
+    if (seg_or_null) {
+        if (a.mode == 2) PIXO_LAUNCH_CODE(2, true); else if (a.mode == 1) PIXO_LAUNCH_CODE(1, true); else PIXO_LAUNCH_CODE(0, true);
+    } else {
+        if (a.mode == 2) PIXO_LAUNCH_CODE(2, false); else if (a.mode == 1) PIXO_LAUNCH_CODE(1, false); else PIXO_LAUNCH_CODE(0, false);
+    }
+#undef PIXO_LAUNCH_CODE
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_layout(const SegArgs &seg, unsigned long long *d_layout, unsigned long long *d_bytes, unsigned long long *host_totals, hipStream_t s)
+{
+    hipLaunchKernelGGL(seg_layout_kernel, dim3(1), dim3(1024), 0, s, seg.bits, seg.nsegs, d_layout, d_bytes, host_totals);
     return hipGetLastError();
 }
 
@@ -691,7 +779,7 @@ uint64_t stuff_tiles(uint64_t stream_bytes) { return (stream_bytes + kTileBytes 
 hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_code_state, size_t code_state_words, uint32_t shift, bool band,
                               uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state,
                               bool state_is_zero, uint8_t *d_out, uint64_t out_cap, unsigned long long *host_totals, hipStream_t s,
-                              unsigned long long *d_out_chain, uint32_t piece)
+                              unsigned long long *d_out_chain, uint32_t piece, const SegArgs *seg_or_null, uint32_t spin_budget)
 {
     // (d_out may start anywhere: the kernel gets the 16-byte boundary below it and the distance)
     const uint32_t out_skew = (uint32_t)(reinterpret_cast<uintptr_t>(d_out) & 15);
@@ -704,8 +792,13 @@ hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_co
     if (tiles == 0) tiles = 1;
     if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (code_state_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(stuff_fused_kernel, dim3((unsigned)tiles), dim3(kStuffThreads), 0, s, d_stream, d_code_state, shift, band ? 1u : 0u,
-                       d_state, d_out, out_skew, out_cap, first_tile, d_code_state, (uint32_t)code_state_words, host_totals, d_out_chain, piece);
+    const SegArgs seg = seg_or_null ? *seg_or_null : SegArgs{};
+    if (seg_or_null)
+        hipLaunchKernelGGL(stuff_fused_kernel<true>, dim3((unsigned)tiles), dim3(kStuffThreads), 0, s, d_stream, d_code_state, shift, band ? 1u : 0u,
+                           d_state, d_out, out_skew, out_cap, first_tile, d_code_state, (uint32_t)code_state_words, host_totals, d_out_chain, piece, seg, spin_budget);
+    else
+        hipLaunchKernelGGL(stuff_fused_kernel<false>, dim3((unsigned)tiles), dim3(kStuffThreads), 0, s, d_stream, d_code_state, shift, band ? 1u : 0u,
+                           d_state, d_out, out_skew, out_cap, first_tile, d_code_state, (uint32_t)code_state_words, host_totals, d_out_chain, piece, seg, spin_budget);
     return hipGetLastError();
 }
 

@@ -46,7 +46,16 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
     // while the one before travels (weights from piece_schedule()).
     uint64_t begin[kMaxPieces + 1];
     uint32_t pieces = 0;
-    if (groups >= 2 * piece_min_groups()) {
+    const bool from_host = src && src->host_px;
+    if (from_host) { // pixels still in host memory: pieces sized for the UPLOAD pipeline — about 6 MB of pixels each, so that
+        // a band's kernels (tens of microseconds) disappear behind the next band's way over PCIe (>= 100 us)
+        const uint64_t px_bytes = static_cast<uint64_t>(src->o->width) * src->o->height * (src->g->gray ? 1 : 3);
+        const uint32_t want = static_cast<uint32_t>(std::min<uint64_t>(kMaxPieces, std::max<uint64_t>(2, px_bytes / (6u << 20))));
+        for (uint32_t k = 0; k < want; ++k) {
+            const uint64_t g0 = groups * k / want;
+            if (pieces == 0 || g0 > begin[pieces - 1]) begin[pieces++] = g0;
+        }
+    } else if (groups >= 2 * piece_min_groups()) {
         const uint64_t per = std::max<uint64_t>((groups + kMaxPieces - 1) / kMaxPieces, piece_min_groups());
         for (uint64_t g0 = 0; g0 < groups; g0 += per) begin[pieces++] = g0; // (none is empty)
     } else {
@@ -76,8 +85,21 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
             pieces = kept;
             begin[pieces] = groups;
         } else { // (no common boundaries: the whole image first)
+            if (from_host) {
+                const size_t px_bytes = static_cast<size_t>(src->o->width) * src->o->height * (src->g->gray ? 1 : 3);
+                HIP_TRY(hipMemcpyAsync(const_cast<void *>(src->d_px), src->host_px, px_bytes, hipMemcpyHostToDevice, stream));
+            }
             const int rc = coeffs_rows(c, src->d_px, *src->o, *src->g, stream, src->dy, src->dcb, src->dcr, 0, 0);
             if (rc) return rc;
+        }
+    }
+    const bool upload_bands = from_host && groups_per_row != 0;
+    if (upload_bands) {
+        if (!c.upload_stream) HIP_TRY(hipStreamCreateWithFlags(&c.upload_stream, hipStreamNonBlocking));
+        while (c.band_up.size() < pieces) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c.band_up.push_back(e);
         }
     }
     if (!c.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
@@ -102,6 +124,23 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
     for (uint32_t k = 0; k < pieces; ++k) pc[k].stream = c.e_stream.as<uint32_t>() + (pc[k].first_block * 209 + 64 * k + 15) / 16 * 4;
     const size_t state_words = pd::fused_code_state_words(j.n);
     Stopwatch sw;
+    uint64_t done = 0; // bytes of the scan that are on their way to the host
+    bool redo = false, gave_up = false;
+    uint32_t next_out = 0; // first piece whose bytes have not been sent yet
+    // piece k has been coded (its event has fired): its bytes onto the copy stream, unless something went wrong
+    auto send_piece = [&](uint32_t k) -> int {
+        if (redo) return PIXO_OK; // (everything that was enqueued is still waited for)
+        const uint64_t *mail = c.h_totals + 4 * k;
+        if (mail[3]) { redo = gave_up = true; return PIXO_OK; } // (a kernel of this piece gave up waiting: the later pieces follow suit)
+        const uint64_t stream_bits = mail[0], packed = k + 1 != pieces ? stream_bits / 8 : (stream_bits + 7) / 8;
+        if (pd::stuff_tiles(packed) > pc[k].tiles) { redo = true; return PIXO_OK; } // (the stuffing grid was a guess: this piece is not complete)
+        const uint64_t bytes = mail[1];
+        if (done + bytes > c.e_out.cap || done + bytes > dst_cap) { redo = true; return PIXO_OK; }
+        if (bytes) HIP_TRY(hipMemcpyAsync(dst + done, c.e_out.as<uint8_t>() + done, bytes, hipMemcpyDeviceToHost, c.copy_stream));
+        done += bytes;
+        sw.lap("  copy enqueued");
+        return PIXO_OK;
+    };
     for (uint32_t k = 0; k < pieces; ++k) {
         pd::ScanArgs a = j.a;
         a.nblocks = pc[k].blocks;
@@ -113,35 +152,43 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
         if (groups_per_row) { // this piece's MCU rows through the coefficient kernel
             const uint32_t row0 = static_cast<uint32_t>(begin[k] / groups_per_row);
             const uint32_t rows = k + 1 == pieces ? 0u : static_cast<uint32_t>(begin[k + 1] / groups_per_row) - row0;
+            if (upload_bands) { // ... which come over PCIe on the upload stream while the band before is transformed and coded
+                const uint32_t unit = (!src->g->gray && src->g->s420) ? 16u : 8u;
+                const size_t row_bytes = static_cast<size_t>(src->o->width) * (src->g->gray ? 1 : 3);
+                const size_t y0 = static_cast<size_t>(row0) * unit, y1 = rows ? std::min<size_t>(src->o->height, static_cast<size_t>(row0 + rows) * unit) : src->o->height;
+                HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(const_cast<void *>(src->d_px)) + y0 * row_bytes, src->host_px + y0 * row_bytes,
+                                       (y1 - y0) * row_bytes, hipMemcpyHostToDevice, c.upload_stream));
+                HIP_TRY(hipEventRecord(c.band_up[k], c.upload_stream));
+                HIP_TRY(hipStreamWaitEvent(stream, c.band_up[k], 0));
+            }
             const int rc = coeffs_rows(c, src->d_px, *src->o, *src->g, stream, src->dy, src->dcb, src->dcr, row0, rows);
             if (rc) return rc;
         }
         HIP_TRY(pd::launch_scan_code(a, c.e_code_state.as<unsigned long long>(), zero, pc[k].stream, c.e_stuff_state.as<unsigned long long>(),
-                                     pd::fused_stuff_state_words(j.stream_cap), mail, stream, &piece));
+                                     pd::fused_stuff_state_words(j.stream_cap), mail, stream, &piece, nullptr, debug().spin_budget));
         HIP_TRY(pd::launch_stuff_fused(pc[k].stream, c.e_code_state.as<unsigned long long>(), state_words, 0, /*band=*/k + 1 != pieces,
                                        j.stream_cap, 0, pc[k].tiles, c.e_stuff_state.as<unsigned long long>(), /*state_is_zero=*/true,
-                                       c.e_out.as<uint8_t>(), c.e_out.cap, mail, stream, out_chain, k));
+                                       c.e_out.as<uint8_t>(), c.e_out.cap, mail, stream, out_chain, k, nullptr, debug().spin_budget));
         c.code_state_zero_words = state_words;
         HIP_TRY(hipEventRecord(c.piece_done[k], stream));
+        // pixels from the host: enqueuing a band's upload kept this thread busy for as long as the band took to cross PCIe —
+        // pieces that have been coded meanwhile start their way back now (the other direction of the link)
+        if (upload_bands)
+            while (next_out < k && !redo && hipEventQuery(c.piece_done[next_out]) == hipSuccess) {
+                const int rc = send_piece(next_out++);
+                if (rc) return rc;
+            }
     }
-    uint64_t done = 0; // bytes of the scan that are on their way to the host
-    bool redo = false;
     sw.lap("  pieces enqueued");
-    for (uint32_t k = 0; k < pieces; ++k) {
-        HIP_TRY(hipEventSynchronize(c.piece_done[k]));
+    for (; next_out < pieces; ++next_out) {
+        HIP_TRY(hipEventSynchronize(c.piece_done[next_out]));
         sw.lap("  piece coded");
-        if (redo) continue; // (still wait for everything that was enqueued)
-        const uint64_t *mail = c.h_totals + 4 * k;
-        const uint64_t stream_bits = mail[0], packed = k + 1 != pieces ? stream_bits / 8 : (stream_bits + 7) / 8;
-        if (pd::stuff_tiles(packed) > pc[k].tiles) { redo = true; continue; } // (the stuffing grid was a guess: this piece is not complete)
-        const uint64_t bytes = mail[1];
-        if (done + bytes > c.e_out.cap || done + bytes > dst_cap) { redo = true; continue; }
-        if (bytes) HIP_TRY(hipMemcpyAsync(dst + done, c.e_out.as<uint8_t>() + done, bytes, hipMemcpyDeviceToHost, c.copy_stream));
-        done += bytes;
-        sw.lap("  copy enqueued");
+        const int rc = send_piece(next_out);
+        if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(c.copy_stream));
     sw.lap("  copies done");
+    if (gave_up) return scan_retry_multipass(c);
     if (redo) return 1;
     *scan_bytes = done;
     return PIXO_OK;
@@ -155,10 +202,11 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
 // every image is a byte-aligned segment of ONE packed stream.  Then *file = headers (once) followed by
 // all the entropy-coded segments, and image_starts[i] (batch + 1 entries) are their offsets behind the
 // headers; no EOI is written.
-int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
-                             const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len,
-                             uint32_t batch, std::vector<uint64_t> *image_starts, size_t *header_len,
-                             uint8_t *dest, size_t dest_cap, bool *own_malloc, const PixelSource *src)
+static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+                                         const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len,
+                                         uint32_t batch, std::vector<uint64_t> *image_starts, size_t *header_len,
+                                         uint8_t *dest, size_t dest_cap, bool *own_malloc, const PixelSource *src, bool *tuple_done,
+                                         std::vector<uint8_t> *head_out)
 { // src != null: the tuple (dy, dcb, dcr = src's) has not been computed yet, see PixelSource.
   // dest != null: the file goes straight into the caller's storage (no pinned intermediate); when it does not
   // fit, *file_len says how much is needed and nothing is copied (PIXO_ERR_BUFFER_TOO_SMALL).
@@ -168,6 +216,7 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
   // the pinned buffer (tools/ubench/upload.cpp: 0.21 ms + a warm 11 MB memcpy, or 1.30 against 1.38 ms for new pages).
   // *own_malloc stays false when the file was assembled in the pinned buffer after all (a scan coded in pieces).
     if (own_malloc) *own_malloc = false;
+    if (!src) *tuple_done = true;
     namespace pd = pixo_dev;
     Stopwatch sw;
     ScanJob j;
@@ -185,15 +234,35 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
     const uint64_t scan_groups = (j.n + 191) / 192;
     const bool large = scan_groups >= 2 * piece_min_groups();
     const bool medium = !large && scan_groups >= piece_medium_groups() && (c.packed_per_block >= 12 || piece_medium_forced());
+    // Pixels still in host memory (pixo_hip_jpeg_encode / _encode_into): their way over PCIe is most of the call (0.9 of
+    // 1.6 ms for a 4096x4096 image), so from 512 groups on (a 2048x2048 image) the image is uploaded in bands, each band
+    // transformed and coded while the next one travels, and coded pieces start their way back meanwhile
+    // (device_entropy_pieces).  Whatever path is taken, the pixels are uploaded exactly once.
+    bool host_px_pending = src && src->host_px;
+    const bool host_bands = host_px_pending && scan_groups >= 512 && !debug().no_bands_upload;
+    auto upload_all = [&]() -> int {
+        if (!host_px_pending) return PIXO_OK;
+        const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
+        HIP_TRY(hipMemcpyAsync(const_cast<void *>(src->d_px), src->host_px, px_bytes, hipMemcpyHostToDevice, stream));
+        host_px_pending = false;
+        return PIXO_OK;
+    };
     // (Not for a caller that wants a malloc'd block of its own: the block would have to be allocated before the size is
     // known — 64 bytes per block, cut to size afterwards — and a block of a new size is new pages every call, which the
     // device-to-host copy has to fault in and pin: 20 ms instead of 0.7 for the 4096x4096 noise image.  One piece, the
     // exact size, recycled by malloc.)
-    if (j.fused && batch == 1 && pieces_enabled() && !direct_host_stores() && (large || medium) && (!dest || dest_cap >= likely_most) &&
-        !(own_malloc && !dest)) {
+    if (j.fused && !j.segmented && batch == 1 && pieces_enabled() && !direct_host_stores() && (large || medium || host_bands) &&
+        (!dest || dest_cap >= likely_most) && (host_bands || !(own_malloc && !dest))) {
+        PixelSource device_src; // (the same source once the pixels are on the device)
         if (src && o.optimize_huffman) { // (the statistics need the whole tuple)
+            if ((rc = upload_all())) return rc;
             if ((rc = coeffs_rows(c, src->d_px, o, g, stream, src->dy, src->dcb, src->dcr, 0, 0))) return rc;
             src = nullptr;
+        } else if (src && src->host_px && !host_bands) { // (device pieces of a scan whose pixels come in one copy)
+            if ((rc = upload_all())) return rc;
+            device_src = *src;
+            device_src.host_px = nullptr;
+            src = &device_src;
         }
         if ((rc = scan_tables(c, j, o, g, stream, nullptr))) return rc;
         pixo_host::file_headers(head, o, j.h);
@@ -208,8 +277,10 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
         uint64_t scan_bytes = 0;
         rc = device_entropy_pieces(c, j, stream, buf + hdr, cap - hdr - 2, &scan_bytes, src);
         src = nullptr; // (the tuple is complete now, whatever happened)
+        host_px_pending = false;
+        *tuple_done = true;
         sw.lap("code+stuff+copy (pieces)");
-        if (rc < 0) return rc;
+        if (rc < 0 || rc == kRetryMultipass) return rc;
         if (rc == 0) {
             c.packed_per_block = static_cast<uint32_t>(scan_bytes / (j.n ? j.n : 1));
             const size_t total = hdr + scan_bytes + 2;
@@ -223,14 +294,16 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
         }
         c.code_state_zero_words = 0; // (rc == 1: start over in one piece, below)
     }
+    if ((rc = upload_all())) return rc;
     if (src && (rc = coeffs_rows(c, src->d_px, o, g, stream, src->dy, src->dcb, src->dcr, 0, 0))) return rc; // one piece: the whole image first
+    *tuple_done = true;
     if (j.fused) { // code + stuff back to back, one read-back
         if ((rc = scan_lengths(c, j, o, g, stream, nullptr, /*wait=*/false))) return rc;
         // One image into host memory the GPU can write — the context's pinned file buffer, or storage of the caller's
         // that is pinned / registered: the stuffing kernel stores straight into it, behind the place of the headers.
         HostTarget target;
         bool direct = false;
-        if (batch == 1 && direct_host_stores()) {
+        if (batch == 1 && !j.segmented && direct_host_stores()) {
             pixo_host::file_headers(head, o, j.h); // (the tables are known since scan_lengths)
             if (!dest) {
                 target.grow = true;
@@ -273,7 +346,10 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
     }
     const uint64_t scan_bytes = j.scan_bytes;
     if (batch == 1 && j.n) c.packed_per_block = static_cast<uint32_t>(scan_bytes / j.n);
-    if (batch > 1) { // where every image's segment begins in the stuffed stream (reuses the seg_bytes buffer: 8 B/entry)
+    if (batch > 1 && j.segmented) { // the stuffing kernel left every image's end in the pinned mailbox
+        image_starts->assign(batch + 1, 0);
+        for (uint32_t i = 0; i < batch; ++i) (*image_starts)[i + 1] = c.h_segs[i];
+    } else if (batch > 1) { // where every image's segment begins in the stuffed stream (reuses the seg_bytes buffer: 8 B/entry)
         HIP_TRY(c.e_seg_bytes.reserve(j.nseg * 8));
         HIP_TRY(pd::launch_segment_out_offsets(j.plan, j.nbytes, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
                                                c.e_seg_bytes.as<uint64_t>(), stream));
@@ -284,6 +360,14 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
     head.clear();
     pixo_host::file_headers(head, o, j.h);
     const size_t hdr = head.size(), total = hdr + scan_bytes + 2;
+    if (head_out) { // the caller delivers the bytes itself from c.e_out (a batch: every file to its final place)
+        if (batch > 1 && !j.segmented) HIP_TRY(hipStreamSynchronize(stream)); // (image_starts is being copied)
+        *head_out = head;
+        *file = nullptr;
+        *file_len = static_cast<size_t>(scan_bytes);
+        if (header_len) *header_len = hdr;
+        return PIXO_OK;
+    }
     uint8_t *buf = dest;
     bool mine = false;
     if (dest) {
@@ -314,6 +398,22 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
     if (header_len) *header_len = hdr;
     sw.lap("stuff+copy to host");
     return PIXO_OK;
+}
+
+int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
+                             const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len,
+                             uint32_t batch, std::vector<uint64_t> *image_starts, size_t *header_len,
+                             uint8_t *dest, size_t dest_cap, bool *own_malloc, const PixelSource *src, std::vector<uint8_t> *head_out)
+{
+    bool tuple_done = false;
+    int rc = device_entropy_to_pinned_once(c, dy, dcb, dcr, o, g, stream, file, file_len, batch, image_starts, header_len, dest, dest_cap,
+                                           own_malloc, src, &tuple_done, head_out);
+    if (rc != kRetryMultipass) return rc;
+    // a single-pass kernel gave up waiting (its waits are bounded): the same scan with the multi-pass kernels
+    RetryMultipass scope;
+    rc = device_entropy_to_pinned_once(c, dy, dcb, dcr, o, g, stream, file, file_len, batch, image_starts, header_len, dest, dest_cap,
+                                       own_malloc, tuple_done ? nullptr : src, &tuple_done, head_out);
+    return rc == kRetryMultipass ? fail(PIXO_ERR_COMPRESSION, "Compression error: the entropy kernels could not make progress") : rc;
 }
 
 // Copies into FRESH host memory are page-fault bound (one core maps and fills a few GB/s of new pages):

@@ -1,6 +1,7 @@
 // scan_job.cpp — coefficient launches on a context, and ONE pass of the device entropy stage over a coefficient tuple in
 // HBM in the steps a caller may need to interleave with exchanges (whole image, batch of images, band of a larger image).
 #include <algorithm>
+#include <atomic>
 
 #include "capi_internal.hpp"
 
@@ -102,6 +103,21 @@ int upload_scan_tables(Context &c, const uint32_t (&packed)[pixo_host::kScanTabl
     return PIXO_OK;
 }
 
+// The single-pass kernels bound their waits (jpeg_scan_fused.hip): a launch that gave up says so in the pinned mailbox
+// (h_totals[3]); its outputs are garbage.  The caller of the step that notices gets kRetryMultipass back and codes the scan
+// again with t_force_multipass set (RetryMultipass below): the multi-pass kernels wait for nothing but kernel boundaries.
+thread_local bool t_force_multipass = false;
+std::atomic<uint64_t> g_lookback_fallbacks{0};
+int scan_retry_multipass(Context &c)
+{
+    c.code_state_zero_words = 0; // (the descriptors and the flag are dirty: the next single-pass launch starts with a memset)
+    g_lookback_fallbacks.fetch_add(1, std::memory_order_relaxed);
+    return kRetryMultipass;
+}
+uint64_t lookback_fallbacks() { return g_lookback_fallbacks.load(std::memory_order_relaxed); }
+
+constexpr uint64_t kMinSegBlocks = 96; // a segment's groups are aligned with it: at least half a group of 192 blocks
+
 // Geometry of the pass and every buffer whose size does not depend on the data.
 int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                const pixo_host::Geometry &g, uint32_t batch, const int16_t *band_seed_dc)
@@ -131,9 +147,44 @@ int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, co
         a.marker_bytes = 0;
         j.nseg = batch;
     }
-    j.fused = j.nseg == 0 && !debug().multipass_entropy;
+    // Which kernels: the two single-pass kernels of jpeg_scan_fused.hip for an uninterrupted scan and — since round 3 — for
+    // segments of at least kMinSegBlocks blocks (the images of a batch; restart intervals of 16 MCUs of 4:2:0 or more:
+    // a segment's groups of 192 blocks are aligned with it, so short segments would leave most lanes idle); the multi-pass
+    // kernels of jpeg_entropy.hip for short restart intervals, on request (debug switch), and after a single-pass
+    // launch gave up waiting (t_force_multipass, see scan_retry_multipass).
+    const uint64_t seg_blocks = static_cast<uint64_t>(a.restart) * a.blocks_per_mcu;
+    const bool single_pass = !debug().multipass_entropy && !t_force_multipass;
+    j.segmented = single_pass && j.nseg > 0 && seg_blocks >= kMinSegBlocks && seg_blocks <= 0xFFFFFFFFull;
+    j.fused = single_pass && (j.nseg == 0 || j.segmented);
     HIP_TRY(c.e_tables.reserve(pixo_scan::kScanTableUpload * 4));
     HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
+    if (j.segmented) {
+        pd::SegArgs &sg = j.seg;
+        sg.nsegs = j.nseg;
+        sg.blocks = static_cast<uint32_t>(seg_blocks);
+        sg.groups = pd::seg_groups(seg_blocks);
+        sg.stream_words = (seg_blocks * 209 + 64 + 15) / 16 * 4;
+        sg.marker_bytes = a.marker_bytes;
+        j.stream_cap = static_cast<size_t>(sg.stream_words) * 4 * j.nseg;
+        HIP_TRY(c.e_stream.reserve(j.stream_cap + 64));
+        const size_t state_words = pd::fused_code_state_words_seg(j.nseg, seg_blocks);
+        if (state_words * 8 > c.e_code_state.cap) c.code_state_zero_words = 0; // (a new buffer)
+        HIP_TRY(c.e_code_state.reserve(state_words * 8));
+        // every segment's last tile is partial: one tile more per segment than the bytes alone would need
+        HIP_TRY(c.e_stuff_state.reserve((pd::fused_stuff_state_words(j.stream_cap) + j.nseg) * 8));
+        HIP_TRY(c.e_segs.reserve((4 * j.nseg + 2) * 8));
+        unsigned long long *base = c.e_segs.as<unsigned long long>();
+        sg.bits = base;
+        sg.layout = base + j.nseg;
+        sg.bytes = base + 2 * j.nseg + 2;
+        sg.out_end = base + 3 * j.nseg + 2;
+        { const int rc_s = c.reserve_hsegs(j.nseg); if (rc_s) return rc_s; }
+        sg.host_out_end = reinterpret_cast<unsigned long long *>(c.h_segs);
+        { const int rc_t = c.ensure_totals(); if (rc_t) return rc_t; }
+        a.tables = c.e_tables.as<uint32_t>();
+        a.pad_last = 1;
+        return PIXO_OK;
+    }
     if (j.fused) { // a block has at most 1665 bits: the packed stream has at most n * 209 bytes (+ slack the kernels read into)
         j.stream_cap = static_cast<size_t>(j.n) * 209 + 64;
         HIP_TRY(c.e_stream.reserve(j.stream_cap));
@@ -209,15 +260,32 @@ int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_
         const int rc = scan_tables(c, j, o, g, stream, counts);
         if (rc) return rc;
     }
+    if (j.segmented) { // every segment packed into its own stream from bit 0; always chained with the stuffing kernel
+        const size_t state_words = pd::fused_code_state_words_seg(j.seg.nsegs, j.seg.blocks);
+        const bool zero = c.code_state_zero_words >= state_words;
+        c.code_state_zero_words = 0;
+        HIP_TRY(pd::launch_scan_code(j.a, c.e_code_state.as<unsigned long long>(), zero, c.e_stream.as<uint32_t>(),
+                                     c.e_stuff_state.as<unsigned long long>(), pd::fused_stuff_state_words(j.stream_cap) + j.nseg,
+                                     reinterpret_cast<unsigned long long *>(c.h_totals), stream, nullptr, &j.seg, debug().spin_budget));
+        HIP_TRY(pd::launch_seg_layout(j.seg, const_cast<unsigned long long *>(j.seg.layout), const_cast<unsigned long long *>(j.seg.bytes),
+                                      reinterpret_cast<unsigned long long *>(c.h_totals), stream));
+        if (wait) { // (a caller that wants the lengths now: none of the product's paths; kept for symmetry)
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (c.h_totals[3]) return scan_retry_multipass(c);
+        }
+        return PIXO_OK;
+    }
     if (j.fused) { // lengths, prefix and packing in one pass; the stream starts at bit 0 whatever the band's offset will be
         const bool zero = c.code_state_zero_words >= pd::fused_code_state_words(j.n);
         c.code_state_zero_words = 0; // (dirty from here until a stuffing launch has cleaned it)
         // chained with the stuffing kernel (!wait): this launch also zeroes that kernel's descriptors
         HIP_TRY(pd::launch_scan_code(j.a, c.e_code_state.as<unsigned long long>(), zero, c.e_stream.as<uint32_t>(),
                                      wait ? nullptr : c.e_stuff_state.as<unsigned long long>(),
-                                     wait ? 0 : pd::fused_stuff_state_words(j.stream_cap), reinterpret_cast<unsigned long long *>(c.h_totals), stream));
+                                     wait ? 0 : pd::fused_stuff_state_words(j.stream_cap), reinterpret_cast<unsigned long long *>(c.h_totals), stream,
+                                     nullptr, nullptr, debug().spin_budget));
         if (!wait) return PIXO_OK; // (the caller chains the stuffing kernel and synchronises once)
         HIP_TRY(hipStreamSynchronize(stream)); // (the kernel wrote the length into the pinned mailbox itself)
+        if (c.h_totals[3]) return scan_retry_multipass(c);
         j.total_bits = c.h_totals[0];
         j.nbytes = (j.total_bits + 7) / 8;
         return PIXO_OK;
@@ -247,6 +315,47 @@ int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_
 // Where the stuffed bytes go when not into the context's device buffer: host memory the GPU can write (pinned), so that
 // the kernel's stores ARE the transfer — no second pass over the file, no second synchronisation.
 
+// Segmented scans: all segments' tiles in one launch (scan_lengths has enqueued code + layout).  Afterwards c.e_out holds
+// j.scan_bytes bytes — the segments back to back, RSTn markers between them if the job has any — and c.h_segs[k] where
+// segment k's bytes end.
+int scan_stuff_segmented(Context &c, ScanJob &j, hipStream_t stream)
+{
+    namespace pd = pixo_dev;
+    const size_t code_words = pd::fused_code_state_words_seg(j.seg.nsegs, j.seg.blocks);
+    // tiles: a guess of 64 bytes per block (noise at q = 80 has 28) + one partial tile per segment; surplus workgroups
+    // leave at once, missing ones are launched below once the layout kernel has said how many there are
+    const uint64_t per_seg = pd::stuff_tiles(static_cast<uint64_t>(j.seg.blocks) * 64 + 4096);
+    uint64_t first_tile = 0, tiles = per_seg * j.nseg;
+    size_t want_cap = std::max<size_t>(j.stream_cap / 4, 4096);
+    for (int attempt = 0;; ++attempt) {
+        HIP_TRY(c.e_out.reserve(want_cap));
+        HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), code_words, 0, false,
+                                       j.stream_cap + j.nseg * 16384, first_tile, tiles, c.e_stuff_state.as<unsigned long long>(),
+                                       /*state_is_zero=*/attempt == 0, c.e_out.as<uint8_t>(), c.e_out.cap,
+                                       reinterpret_cast<unsigned long long *>(c.h_totals), stream, nullptr, 0, &j.seg, debug().spin_budget));
+        c.code_state_zero_words = code_words;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c.h_totals[3]) return scan_retry_multipass(c);
+        const uint64_t all_tiles = c.h_totals[2];
+        if (all_tiles > first_tile + tiles) { // the guess was short: the tiles behind it, same buffers
+            if (attempt > 2) return fail(PIXO_ERR_COMPRESSION, "Compression error: packed stream longer than announced");
+            first_tile += tiles;
+            tiles = all_tiles - first_tile;
+            continue;
+        }
+        j.scan_bytes = c.h_totals[1];
+        if (j.scan_bytes > c.e_out.cap) { // (unusually many 0xFF bytes: grow and repeat the stuffing pass only)
+            if (attempt > 2) return fail(PIXO_ERR_COMPRESSION, "Compression error: stuffed stream larger than announced");
+            want_cap = static_cast<size_t>(j.scan_bytes);
+            first_tile = 0;
+            tiles = all_tiles;
+            continue;
+        }
+        j.nbytes = 0;
+        return PIXO_OK;
+    }
+}
+
 int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offset, uint32_t *head, int *tail_bits,
                      uint32_t *tail, bool chained, HostTarget *host)
 {
@@ -257,6 +366,7 @@ int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_b
         j.head_bits = static_cast<int>(j.total_bits < want ? j.total_bits : want);
         shift = static_cast<uint32_t>(j.head_bits);
     }
+    if (j.segmented) return scan_stuff_segmented(c, j, stream);
     // entropy-coded data holds a 0xFF every ~256 bytes; start from a quarter of the worst-case stream and grow on demand
     size_t want_cap = chained ? std::max<size_t>(j.stream_cap / 4, 4096) : static_cast<size_t>(j.nbytes + j.nbytes / 64 + 4096);
     // tiles: the exact number when the stream's length is known, otherwise a guess (64 bytes per block; noise at q = 80
@@ -281,9 +391,8 @@ int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_b
         }
         HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), pd::fused_code_state_words(j.n),
                                        shift, j.band, j.stream_cap, first_tile, tiles, c.e_stuff_state.as<unsigned long long>(),
-                                       /*state_is_zero=*/
-                                       chained && attempt == 0,
- out, out_cap, reinterpret_cast<unsigned long long *>(c.h_totals), stream));
+                                       /*state_is_zero=*/chained && attempt == 0, out, out_cap,
+                                       reinterpret_cast<unsigned long long *>(c.h_totals), stream, nullptr, 0, nullptr, debug().spin_budget));
         c.code_state_zero_words = pd::fused_code_state_words(j.n);
         // (no read-back copies: both kernels store their totals into the pinned mailbox h_totals — [0] bits of the scan,
         // [1] stuffed bytes, [2] packed bytes — which the host reads after the synchronisation below)
@@ -294,6 +403,7 @@ int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_b
             HIP_TRY(hipMemcpyAsync(&edge[1], c.e_stream.as<uint32_t>() + (tail_at >> 5), 8, hipMemcpyDeviceToHost, stream));
         }
         HIP_TRY(hipStreamSynchronize(stream));
+        if (c.h_totals[3]) return scan_retry_multipass(c);
         j.total_bits = c.h_totals[0];
         const uint64_t packed = j.band ? (j.total_bits - j.head_bits) / 8 : (j.total_bits + 7) / 8;
         if (pd::stuff_tiles(packed) > first_tile + tiles) { // the guess was short: the tiles behind it, same buffers

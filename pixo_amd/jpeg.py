@@ -365,6 +365,33 @@ def encode_batch_device(d_pixels, options: JpegOptions, batch: int):
     return out
 
 
+def encode_batch_device_into(arena, d_pixels, options: JpegOptions, batch: int):
+    """`pixo_hip_jpeg_encode_batch_device_into`: the `batch` files back to back in `arena` (a torch uint8 CPU tensor —
+    ideally pinned —, a numpy uint8 array, or None for a size query), every file copied from the device straight to its
+    final place.  Returns (offsets, lens); raises BufferTooSmall (`.needed`) when the files do not fit."""
+    L = _lib.load()
+    offsets = (C.c_size_t * batch)()
+    lens = (C.c_size_t * batch)()
+    if arena is None:
+        ptr, cap = None, 0
+    elif hasattr(arena, "data_ptr"):
+        ptr, cap = arena.data_ptr(), arena.numel()
+    else:
+        ptr, cap = arena.ctypes.data, arena.size
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_encode_batch_device_into(_dev_ptr(d_pixels), C.byref(oc), batch, ptr, cap, offsets, lens)
+    if rc == -9 and arena is None:  # PIXO_ERR_BUFFER_TOO_SMALL: the answer to a size query
+        return list(offsets), list(lens)
+    if rc:
+        _raise(rc)
+    return list(offsets), list(lens)
+
+
+def lookback_fallbacks() -> int:
+    """How often a single-pass entropy kernel gave up waiting and the multi-pass kernels coded the scan instead (tests)."""
+    return int(_lib.load().pixo_hip_debug_lookback_fallbacks())
+
+
 def band(width, height, color_type, subsampling, parts, index):
     """MCU-row band `index` of `parts`: dict(row_begin,row_end,y_offset,y_blocks,
     c_offset,c_blocks).  Bands are independent sub-images of the same width."""

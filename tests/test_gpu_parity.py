@@ -311,6 +311,99 @@ def test_batch_whole_files_one_entropy_pass(shape):
         assert files[i] == O.encode(imgs[i], O.make_options(w, h, ct, 80, ss, optimize_huffman=True, restart=5)), i
 
 
+@pytest.mark.parametrize("shape", [(1920, 1080, 2, 1, 5), (333, 77, 2, 0, 9), (64, 64, 0, 0, 5), (16, 16, 2, 1, 40)])
+def test_batch_into_one_arena_every_file_at_its_final_place(shape):
+    """`pixo_hip_jpeg_encode_batch_device_into`: the files back to back in caller storage (pinned and pageable), offsets and
+    lengths reported, each file equal to its own oracle file; the size query; a capacity that is one byte short."""
+    import torch
+    from pixo_amd import error
+    w, h, ct, ss, n = shape
+    imgs = [(synth.noise(w, h, 300 + i) if ct == 2 else synth.noise_gray(w, h, 300 + i)) for i in range(n)]
+    imgs[n // 2] = synth.gradient_rgb(w, h) if ct == 2 else synth.constant(w, h, 31, 1)
+    want = [O.encode(im, O.make_options(w, h, ct, 80, ss)) for im in imgs]
+    d_px = torch.from_numpy(np.concatenate(imgs)).to("cuda:0")
+    torch.cuda.synchronize()
+    o = _opts(w, h, ct, ss, 80)
+    offs, lens = jpeg.encode_batch_device_into(None, d_px, o, n)  # size query
+    assert lens == [len(f) for f in want] and offs == [sum(lens[:i]) for i in range(n)]
+    total = sum(lens)
+    for arena in (torch.full((total + 64,), 0x5A, dtype=torch.uint8).pin_memory(), torch.full((total,), 0x5A, dtype=torch.uint8),
+                  np.full(total + 7, 0x5A, np.uint8)):
+        offs, lens = jpeg.encode_batch_device_into(arena, d_px, o, n)
+        raw = arena.numpy() if hasattr(arena, "numpy") else arena
+        for i in range(n):
+            assert raw[offs[i]: offs[i] + lens[i]].tobytes() == want[i], i
+        assert bool((raw[total:] == 0x5A).all())
+    small = torch.zeros(total - 1, dtype=torch.uint8).pin_memory()
+    with pytest.raises(error.Error, match="need %d bytes" % total):
+        jpeg.encode_batch_device_into(small, d_px, o, n)
+    # per-image option sets go one by one, into the same layout
+    o2 = _opts(w, h, ct, ss, 80, optimize_huffman=True)
+    want2 = [O.encode(im, O.make_options(w, h, ct, 80, ss, optimize_huffman=True)) for im in imgs]
+    arena = torch.zeros(sum(len(f) for f in want2) + 16, dtype=torch.uint8).pin_memory()
+    offs, lens = jpeg.encode_batch_device_into(arena, d_px, o2, n)
+    for i in range(n):
+        assert arena.numpy()[offs[i]: offs[i] + lens[i]].tobytes() == want2[i], i
+
+
+def test_restart_intervals_in_the_single_pass_kernels_and_around_their_threshold():
+    """Restart intervals of 96 blocks or more (16 MCUs of 4:2:0, 32 of 4:4:4, 96 gray blocks) are segments of the
+    single-pass kernels — groups aligned with the segments, RSTn written by the stuffing kernel —, shorter ones take the
+    multi-pass kernels: intervals on both sides of the threshold, intervals that divide the image and that do not, a
+    last segment of one MCU, an MCU row, images of many tiles per segment; all against the oracle."""
+    cases = [(640, 480, 2, 1, (15, 16, 17, 40, 1199, 1200)), (640, 480, 2, 0, (31, 32, 33, 80, 4799)), (512, 384, 0, 0, (95, 96, 97, 3071)),
+             (2048, 2048, 2, 1, (128, 1000, 16383)), (4096, 512, 2, 0, (512, 4097))]
+    for w, h, ct, ss, intervals in cases:
+        px = synth.noise(w, h, w + h) if ct == 2 else synth.noise_gray(w, h, w + h)
+        smooth = synth.gradient_rgb(w, h) if ct == 2 else synth.gradient_rgb(w, h).reshape(-1, 3)[:, 1].copy()
+        for r in intervals:
+            for img, q in ((px, 80), (smooth, 92)):
+                got = jpeg.encode(img, _opts(w, h, ct, ss, q, restart_interval=r))
+                assert got == O.encode(img, O.make_options(w, h, ct, q, ss, restart=r)), (w, h, ct, ss, r, q)
+    # optimised tables with restart markers (the statistics honour the resets) in the single-pass kernels
+    w, h = 800, 608
+    px = synth.noise(w, h, 4)
+    for r in (16, 50, 1900):
+        assert jpeg.encode(px, _opts(w, h, 2, 1, 75, restart_interval=r, optimize_huffman=True)) == \
+            O.encode(px, O.make_options(w, h, 2, 75, 1, restart=r, optimize_huffman=True)), r
+
+
+def test_single_pass_kernels_that_give_up_waiting_fall_back_to_the_multi_pass_kernels():
+    """The look-back kernels bound their waits.  With a budget of zero polls every wait for another
+    workgroup fails at once: the kernels raise their abort flag instead of spinning, the host sees it in the pinned mailbox
+    and codes the scan again with the multi-pass kernels — same bytes, no hang; the fallback counter shows that it happened.
+    In a fresh process (the switch is read at start-up) over plain files, pieces, batches, restart segments and bands."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, 'tests'); import synth, oracle_lib as O; from pixo_amd import jpeg\n"
+            "def opts(w, h, ss, **kw):\n"
+            "    b = jpeg.JpegOptions.builder(w, h).quality(80).subsampling(jpeg.Subsampling(ss))\n"
+            "    for k, v in kw.items(): b = getattr(b, k)(v)\n"
+            "    return b.build()\n"
+            "n0 = jpeg.lookback_fallbacks()\n"
+            "for (w, h, ss) in ((1024, 768, 1), (777, 333, 0), (4096, 4096, 1)):\n"
+            "    px = synth.noise(w, h, 5)\n"
+            "    assert jpeg.encode(px, opts(w, h, ss)) == O.encode(px, O.make_options(w, h, 2, 80, ss)), (w, h, ss)\n"
+            "    d = torch.from_numpy(px).to('cuda:0'); pin = torch.zeros(w * h * 3, dtype=torch.uint8).pin_memory()\n"
+            "    n = jpeg.encode_device_into(pin, d, opts(w, h, ss))\n"
+            "    assert pin[:n].numpy().tobytes() == O.encode(px, O.make_options(w, h, 2, 80, ss))\n"
+            "n1 = jpeg.lookback_fallbacks(); assert n1 > n0, (n0, n1)\n"
+            "px = synth.noise(640, 480, 6)\n"
+            "assert jpeg.encode(px, opts(640, 480, 1, restart_interval=40)) == O.encode(px, O.make_options(640, 480, 2, 80, 1, restart=40))\n"
+            "imgs = [synth.noise(320, 240, 50 + i) for i in range(6)]\n"
+            "files = jpeg.encode_batch_device(torch.from_numpy(np.concatenate(imgs)).to('cuda:0'), opts(320, 240, 1), 6)\n"
+            "assert all(files[i] == O.encode(imgs[i], O.make_options(320, 240, 2, 80, 1)) for i in range(6))\n"
+            "px = synth.noise(520, 330, 12)\n"
+            "assert jpeg.encode_multi(px, opts(520, 330, 1, optimize_huffman=True), [0, 0, 0]) == O.encode(px, O.make_options(520, 330, 2, 80, 1, optimize_huffman=True))\n"
+            "n2 = jpeg.lookback_fallbacks(); assert n2 > n1 + 2, (n1, n2)\n"
+            "print('fallbacks', n2)")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PIXO_HIP_DEBUG="spin_budget=0"),
+                       timeout=600, cwd=root)
+    assert r.returncode == 0 and "fallbacks" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    # and in THIS process (default budget) nothing ever falls back
+    assert jpeg.lookback_fallbacks() == 0
+
+
 def test_config4_16384_image_on_one_gpu_matches_the_reference_file():
     """configs[3] at full size on a single MI355X (0.8 GB of pixels, 6.3 M blocks, a 178 MB file):
     64-bit offsets everywhere, and the reference's own result for this input (made by

@@ -64,6 +64,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip whole_file and other_configs (A/B runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--workload c4 only: ONE process drives the N GPUs through pixo_hip_jpeg_encode_multi (a host thread per band, every "
+                         "band over its own GPU's PCIe link) instead of one rank per GPU over RCCL; pixels start in HOST memory")
     ap.add_argument("--stub", action="store_true",
                     help="plumbing test without a GPU: gloo process group, the step is a short sleep (data: 'stub')")
     return ap.parse_args(argv)
@@ -84,6 +87,10 @@ def ensure_world(args):
     """Returns (rank, local_rank, world).  `python bench.py --gpus N` with N > 1 and no launcher environment
     re-executes itself as N ranks under torch.distributed.run; a launcher whose world size differs from --gpus is an error."""
     env_world = os.environ.get("WORLD_SIZE")
+    if getattr(args, "single_process", False):
+        if env_world not in (None, "1"):
+            raise SystemExit("bench: --single-process is ONE process for all GPUs: do not start it under a multi-rank launcher")
+        return 0, 0, 1
     if env_world is None and args.gpus > 1:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -680,9 +687,49 @@ def run_c4(job, args):
     job.finish(line)
 
 
+def run_c4_single_process(job, args):
+    """configs[3] in ONE process: pixo_hip_jpeg_encode_multi spreads the 16384x16384 image's MCU-row bands over the N GPUs — a
+    persistent host thread per band, the band's rows over that GPU's own PCIe link, per-band entropy coding, three tiny
+    exchanges through shared memory, every body copied to its final place in the file.  The pixels start in HOST memory (this
+    entry's contract), so a step includes their way over PCIe: strong scaling over N links."""
+    import synth
+    from pixo_amd import jpeg
+    torch = job.torch
+    w = h = 16384
+    n = args.gpus
+    have = torch.cuda.device_count()
+    devices = [i % max(have, 1) for i in range(n)]
+    opts = jpeg.JpegOptions.builder(w, h).quality(args.quality).subsampling(jpeg.Subsampling.S420).build()
+    px = synth.noise(w, h, 42)
+    state = {}
+
+    def step(i):
+        state["file"] = jpeg.encode_multi(px, opts, devices)
+
+    steps = max(1, min(args.steps, 5))
+    walls, _ = job.time_blocks(step, steps, 1, max(3, min(args.blocks, 5)), events=False)
+    blob = state["file"]
+    digest = hashlib.sha256(blob).hexdigest()
+    if (len(blob) != 178548465 or digest != C4_SHA256) and not os.environ.get("PIXO_BENCH_ABLATION"):
+        raise SystemExit("bench: the 16384x16384 file differs from the reference's — refusing to report a number")
+    st = block_stats(walls, steps)
+    line = {"metric": "Mpixels/s JPEG encode, whole file from host pixels, one 16384x16384 RGB8 image q=80 4:2:0 across the GPUs of one process (configs[3])",
+            "value": round(w * h / (st["ms_per_step"] * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "n_gpus": n, "steps": steps, "warmup": 1,
+            "ms_per_step": st["ms_per_step"], "ms_per_step_min": st["ms_per_step_min"], "ms_per_step_max": st["ms_per_step_max"],
+            "blocks": st["blocks"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3], single process: pixo_hip_jpeg_encode_multi over %d band(s) on device(s) %s; 805 MB of pixels in "
+                                   "over PCIe, 178.5 MB file out (as Python bytes: one more copy)" % (n, sorted(set(devices))),
+                       "width": w, "height": h, "quality": args.quality, "subsampling": "4:2:0", "file_bytes": len(blob), "file_sha256": digest,
+                       "devices_visible": have, "parallelism": "one process, one persistent host thread per band"},
+            "roofline": None}
+    job.finish(line)
+
+
 def main():
     args = parse()
     job = Job(args)
+    if args.workload == "c4" and args.single_process:
+        return run_c4_single_process(job, args)
     if args.workload == "c5":
         return run_png(job, args)
     if args.workload == "c4":

@@ -1,6 +1,7 @@
 // bands.cpp — one image across several GPUs: per-band entropy coding + bit-exact splice.
 #include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <memory>
 
 #include "capi_internal.hpp"
@@ -109,12 +110,8 @@ int pixo_hip_band_encoder_coeffs(pixo_hip_band_encoder *e, const void *band_pixe
     if ((rc = coeffs_on_device(c, d_px, e->band, e->g, c.stream, &e->dy, &e->dcb, &e->dcr))) return rc;
     // the DCs the next band predicts from: first coefficient of the last block of every plane
     { const int rc_t = c.ensure_totals(); if (rc_t) return rc_t; }
-    int16_t *h = reinterpret_cast<int16_t *>(c.h_totals);
-    HIP_TRY(hipMemcpyAsync(h, e->dy + (e->g.y_blocks - 1) * 64, 2, hipMemcpyDeviceToHost, c.stream));
-    if (e->g.c_blocks) {
-        HIP_TRY(hipMemcpyAsync(h + 1, e->dcb + (e->g.c_blocks - 1) * 64, 2, hipMemcpyDeviceToHost, c.stream));
-        HIP_TRY(hipMemcpyAsync(h + 2, e->dcr + (e->g.c_blocks - 1) * 64, 2, hipMemcpyDeviceToHost, c.stream));
-    }
+    int16_t *h = reinterpret_cast<int16_t *>(c.h_totals + Context::kTotalsWords - 1); // (the mailbox's last word: no kernel of the entropy stage writes it)
+    HIP_TRY(pixo_dev::launch_last_dcs(e->dy, e->g.y_blocks, e->dcb, e->dcr, e->g.c_blocks, h, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));
     e->last_dc[0] = h[0];
     e->last_dc[1] = e->g.c_blocks ? h[1] : 0;
@@ -386,6 +383,73 @@ class PhaseBarrier { // every band thread arrives at every phase boundary, also 
     std::condition_variable cv_;
     unsigned n_, count_ = 0, gen_ = 0;
 };
+
+// Band workers: threads that live as long as the process, one per band slot, each with the library context of its own
+// (bound to the device of the band it last served; re-bound when a call lists another device for that slot).  A call of
+// pixo_hip_jpeg_encode_multi hands every worker the same closure and waits for all of them: no thread is created and no
+// context taken from the pool per call (round 2 spawned n threads and created n encoders every time).  One multi-device
+// encode runs at a time per process (the workers are shared); callers on other threads wait their turn.
+class BandWorkers {
+  public:
+    // runs body(k) for k in [0, n) on workers 0 .. n - 1 and returns when all have finished; false = the threads could not
+    // be created (nothing has run)
+    bool run(unsigned n, const std::function<void(unsigned)> &body)
+    {
+        std::lock_guard<std::mutex> turn(turn_);
+        try {
+            while (workers_.size() < n) {
+                std::unique_ptr<Worker> w(new Worker);
+                Worker *raw = w.get();
+                w->thread = std::thread([this, raw] { loop(*raw); });
+                workers_.push_back(std::move(w));
+            }
+        } catch (...) { // (std::system_error: no more threads; std::bad_alloc) — the workers that exist stay idle
+            return false;
+        }
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            body_ = &body;
+            pending_ = n;
+            for (unsigned k = 0; k < n; ++k) workers_[k]->job = static_cast<int>(k);
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> lock(m_);
+        done_.wait(lock, [&] { return pending_ == 0; });
+        body_ = nullptr;
+        return true;
+    }
+  private:
+    struct Worker { std::thread thread; int job = -1; };
+    void loop(Worker &w)
+    {
+        for (;;) {
+            const std::function<void(unsigned)> *body = nullptr;
+            int job = -1;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                cv_.wait(lock, [&] { return w.job >= 0; });
+                job = w.job;
+                w.job = -1;
+                body = body_;
+            }
+            (*body)(static_cast<unsigned>(job));
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::mutex turn_, m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::unique_ptr<Worker>> workers_; // (never destroyed: the threads are detached from process exit like the context pool)
+    const std::function<void(unsigned)> *body_ = nullptr;
+    unsigned pending_ = 0;
+};
+BandWorkers &band_workers_instance()
+{
+    static BandWorkers *w = new BandWorkers; // leaked on purpose: worker threads must not be joined from a static destructor
+    return *w;
+}
 } // namespace
 
 int pixo_hip_jpeg_encode_multi(const uint8_t *data, size_t data_len, const pixo_jpeg_options *options, const int *devices,
@@ -460,7 +524,7 @@ int pixo_hip_jpeg_encode_multi(const uint8_t *data, size_t data_len, const pixo_
             std::string m;
             int r = tables_for_splice(o, tc, h);
             if (!r && (r = pixo_host::splice_layout(o, h, headers.data(), parts, layout, m))) r = fail(r, m);
-            if (!r && !(file = static_cast<uint8_t *>(std::malloc(layout.file_len)))) r = fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
+            if (!r && !(file = alloc_file(layout.file_len))) r = fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
             step(r);
         }
         barrier.arrive();
@@ -469,7 +533,7 @@ int pixo_hip_jpeg_encode_multi(const uint8_t *data, size_t data_len, const pixo_
         pixo_hip_band_encoder_destroy(b.enc);
         b.enc = nullptr;
     };
-    run_on_threads(parts, body);
+    if (!band_workers_instance().run(parts, body)) return fail(PIXO_ERR_COMPRESSION, "Compression error: could not start the band worker threads");
     for (Band &b : bands)
         if (b.rc) { const int r = b.rc; const std::string e = b.error; std::free(file); return fail(r, e); }
     pixo_host::splice_finish(layout, file);

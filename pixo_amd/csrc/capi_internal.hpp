@@ -115,6 +115,7 @@ struct Context {
     Buf e_segs;                      // segmented scans (batches, restart intervals): per-segment results of the single-pass kernels
     hipStream_t copy_stream = nullptr; // ... whose bytes travel to the host on this stream while the next piece is coded
     hipStream_t upload_stream = nullptr; // host pixels arrive band by band on this stream while earlier bands are transformed
+    struct CopyHelper *helper = nullptr; // ... and a second host thread sends the coded pieces back meanwhile (pieces.cpp; never destroyed)
     std::vector<hipEvent_t> piece_done, band_up;
     uint32_t tables_held[pixo_scan::kScanTableUpload]; bool tables_valid = false; hipStream_t tables_stream = nullptr; // what e_tables holds (no upload when unchanged)
     uint32_t packed_per_block = 0; // bytes per block of the last whole scan this context coded (0: none yet), see device_entropy_to_pinned
@@ -190,6 +191,9 @@ template <class F> void run_on_threads(unsigned t, F &&body) // body(index) for 
     for (auto &w : workers) w.join();
 }
 void big_copy(uint8_t *dst, const uint8_t *src, size_t n);
+uint8_t *alloc_file(size_t n); // a block for a finished file that the caller will own: large ones come from the blocks pixo_hip_free kept
+void free_file(void *p);       // pixo_hip_free: large blocks are kept (at most two) for the next large file
+void drop_kept_blocks();       // pixo_hip_trim
 int deliver(const uint8_t *file, size_t n, uint8_t **out, size_t *out_len);   // a fresh malloc block the caller owns
 int hand_over(const std::vector<uint8_t> &v, uint8_t **out, size_t *out_len);
 
@@ -222,6 +226,8 @@ struct ScanJob {
     bool fused = false;      // one uninterrupted scan: the two single-pass kernels of jpeg_scan_fused.hip
     bool segmented = false;  // byte-aligned segments (images of a batch, restart intervals) in the single-pass kernels
     pixo_dev::SegArgs seg;   // ... their geometry and per-segment arrays (c.e_segs, c.h_segs)
+    uint32_t seg_gap = 0;    // set BEFORE scan_begin: bytes a batch wants left free between its images' scans in c.e_out
+                             // (headers + EOI: the whole batch then leaves the device in one copy); honoured only by segmented jobs
     size_t stream_cap = 0;   // fused: bytes the packed stream can take at most
 };
 // A step of a job returns this when a single-pass kernel gave up waiting (bounded look-back, jpeg_scan_fused.hip): nothing of
@@ -272,9 +278,11 @@ int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, 
                              const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len,
                              uint32_t batch = 1, std::vector<uint64_t> *image_starts = nullptr, size_t *header_len = nullptr,
                              uint8_t *dest = nullptr, size_t dest_cap = 0, bool *own_malloc = nullptr, const PixelSource *src = nullptr,
-                             std::vector<uint8_t> *head_out = nullptr);
+                             std::vector<uint8_t> *head_out = nullptr, uint32_t seg_gap = 0, bool *gaps_left = nullptr);
 // (head_out != null: no copy to the host — *head_out receives the file headers, *file_len the bytes of the stuffed scan(s)
-// left in c.e_out, image_starts where each image's bytes begin; the caller delivers them)
+// left in c.e_out, image_starts where each image's bytes begin; the caller delivers them.  seg_gap: bytes to leave free in
+// c.e_out between consecutive images' scans, *gaps_left says whether that was done — only segmented single-pass jobs can —:
+// image_starts then counts the gaps, image i's bytes are [starts[i], starts[i + 1] - gap).)
 int device_entropy_to_malloc(Context &c, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                              const pixo_host::Geometry &g, hipStream_t stream, uint8_t **out_buf, size_t *out_len);
 int device_tuple_to_malloc(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,

@@ -377,10 +377,11 @@ int pixo_hip_trim(void)
 {
     if (t_slot.c) t_slot.c->release();
     pool().drain();
+    drop_kept_blocks();
     return PIXO_OK;
 }
 
-void pixo_hip_free(void *p) { std::free(p); }
+void pixo_hip_free(void *p) { free_file(p); }
 
 const char *pixo_hip_last_error(void) { return t_error.c_str(); }
 

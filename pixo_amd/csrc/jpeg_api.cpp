@@ -371,8 +371,11 @@ namespace {
 // The entropy-coded bytes of a batch in c.e_out: one coefficient launch + one pass of the entropy stage (the images are
 // segments of the single-pass kernels).  Only for option sets that allow it (see the callers).
 int batch_on_device(Context &c, const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, uint32_t batch,
-                    std::vector<uint8_t> &head, std::vector<uint64_t> &starts)
-{
+                    std::vector<uint8_t> &head, std::vector<uint64_t> &starts, bool *gaps)
+{ // *gaps: the scans lie in c.e_out with room for EOI + the next file's headers between them (the files' final spacing)
+    std::vector<uint8_t> probe_head;
+    pixo_host::file_headers(probe_head, o, pixo_host::HuffSet::standard()); // (a one-pass batch has the standard tables)
+    const uint32_t gap = static_cast<uint32_t>(probe_head.size() + 2);
     const float *qt_all = nullptr;
     int rc = device_tables(c.device, &qt_all);
     if (rc) return rc;
@@ -383,7 +386,8 @@ int batch_on_device(Context &c, const void *d_pixels, const pixo_jpeg_options &o
                                          g.gray ? nullptr : dcr, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c.stream));
     const uint8_t *unused = nullptr;
     size_t scan_bytes = 0;
-    return device_entropy_to_pinned(c, dy, dcb, dcr, o, g, c.stream, &unused, &scan_bytes, batch, &starts, nullptr, nullptr, 0, nullptr, nullptr, &head);
+    return device_entropy_to_pinned(c, dy, dcb, dcr, o, g, c.stream, &unused, &scan_bytes, batch, &starts, nullptr, nullptr, 0, nullptr, nullptr, &head,
+                                    gap, gaps);
 }
 bool batch_in_one_pass(const pixo_jpeg_options &o, const pixo_host::Geometry &g, uint32_t batch, size_t px_bytes)
 {
@@ -418,15 +422,16 @@ int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_opti
     }
     std::vector<uint8_t> head;
     std::vector<uint64_t> starts;
-    if ((rc = batch_on_device(*c, d_pixels, o, g, batch, head, starts))) return rc;
-    const size_t hdr = head.size(), scan_bytes = static_cast<size_t>(starts[batch]);
+    bool gaps = false;
+    if ((rc = batch_on_device(*c, d_pixels, o, g, batch, head, starts, &gaps))) return rc;
+    const size_t hdr = head.size(), scan_bytes = static_cast<size_t>(starts[batch]), gap = gaps ? hdr + 2 : 0;
     // the stuffed bytes cross PCIe once, into the context's pinned buffer (a device-to-host copy into fresh pageable blocks
     // would make the runtime pin new pages every call); from there into the files the caller will own — fresh memory,
     // page-fault bound: several threads (see big_copy)
     if ((rc = c->reserve_hfile(scan_bytes ? scan_bytes : 1))) return rc;
     HIP_TRY(hipMemcpyAsync(c->h_file, c->e_out.p, scan_bytes, hipMemcpyDeviceToHost, c->stream));
     for (uint32_t i = 0; i < batch; ++i) {
-        lens[i] = hdr + static_cast<size_t>(starts[i + 1] - starts[i]) + 2;
+        lens[i] = hdr + static_cast<size_t>(starts[i + 1] - starts[i]) - (i + 1 < batch ? gap : 0) + 2;
         files[i] = static_cast<uint8_t *>(std::malloc(lens[i]));
         if (!files[i]) { (void)hipStreamSynchronize(c->stream); return release(fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory")); }
     }
@@ -481,26 +486,34 @@ int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg
     }
     std::vector<uint8_t> head;
     std::vector<uint64_t> starts;
-    if ((rc = batch_on_device(*c, d_pixels, o, g, batch, head, starts))) return rc;
-    const size_t hdr = head.size();
+    bool gaps = false;
+    if ((rc = batch_on_device(*c, d_pixels, o, g, batch, head, starts, &gaps))) return rc;
+    const size_t hdr = head.size(), gap = gaps ? hdr + 2 : 0;
     size_t at = 0;
     for (uint32_t i = 0; i < batch; ++i) {
         offsets[i] = at;
-        lens[i] = hdr + static_cast<size_t>(starts[i + 1] - starts[i]) + 2;
+        lens[i] = hdr + static_cast<size_t>(starts[i + 1] - starts[i]) - (i + 1 < batch ? gap : 0) + 2;
         at += lens[i];
     }
     if (at > capacity) return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(at) + " bytes");
-    // every file's entropy-coded bytes from the device straight to their final place; headers and EOI by the host meanwhile
-    for (uint32_t i = 0; i < batch; ++i) {
-        const size_t seg = lens[i] - hdr - 2;
-        if (seg) HIP_TRY(hipMemcpyAsync(arena + offsets[i] + hdr, c->e_out.as<uint8_t>() + starts[i], seg, hipMemcpyDeviceToHost, c->stream));
+    if (gaps) {
+        // the scans lie in the device buffer at their files' final spacing (the stuffing kernel left room for EOI + headers
+        // between them): ONE copy for the whole batch, the host fills the gaps in afterwards
+        const size_t run = static_cast<size_t>(starts[batch]);
+        if (run) HIP_TRY(hipMemcpyAsync(arena + hdr, c->e_out.p, run, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } else { // (multi-pass kernels: every file's entropy-coded bytes by a copy of its own)
+        for (uint32_t i = 0; i < batch; ++i) {
+            const size_t seg = lens[i] - hdr - 2;
+            if (seg) HIP_TRY(hipMemcpyAsync(arena + offsets[i] + hdr, c->e_out.as<uint8_t>() + starts[i], seg, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
     }
     for (uint32_t i = 0; i < batch; ++i) {
         uint8_t *p = arena + offsets[i];
         std::memcpy(p, head.data(), hdr);
         p[lens[i] - 2] = 0xFF; p[lens[i] - 1] = 0xD9;
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
     return PIXO_OK;
 }
 

@@ -80,8 +80,8 @@ struct ScanPiece {
     const uint32_t *prev_stream;
 };
 // SEGMENTED scans in the single-pass kernels: the scan is cut into byte-aligned segments of `blocks` blocks (the last
-// one may be shorter) — the images of a batch (marker_bytes 0) or restart intervals (marker_bytes 2: FF D0+(k & 7)
-// behind every segment but the last, jpeg/mod.rs:1423-1445).  Every segment starts from DC predictors 0, is packed into a
+// one may be shorter) — the images of a batch (marker_bytes = room for the next file's headers and this file's EOI) or
+// restart intervals (marker_bytes 2, rst_markers: FF D0+(k & 7) behind every segment but the last, jpeg/mod.rs:1423-1445).  Every segment starts from DC predictors 0, is packed into a
 // stream of its own (region `stream_words` * k of d_stream: blocks * 209 bytes + slack, a multiple of 16) and 1-padded.
 // code<SEG> -> bits[k]; launch_seg_layout -> layout / bytes; stuff<SEG> -> the segments back to back in d_out (markers
 // in between), out_end[k] = where segment k's entropy-coded bytes end (device array; host_out_end: the same in pinned
@@ -95,9 +95,11 @@ struct SegArgs {
     const unsigned long long *bytes = nullptr;  // [nsegs] packed bytes per segment
     unsigned long long *out_end = nullptr;      // [nsegs]
     unsigned long long *host_out_end = nullptr;
-    uint32_t marker_bytes = 0;
+    uint32_t marker_bytes = 0;  // bytes left free in d_out behind every segment but the last (at most seg_max_gap())
+    uint32_t rst_markers = 0;   // 1: marker_bytes == 2 and the stuffing kernel writes FF D0+(k & 7) there
 };
 uint32_t seg_groups(uint64_t seg_blocks);
+uint32_t seg_max_gap();
 size_t fused_code_state_words_seg(uint64_t nsegs, uint64_t seg_blocks);
 hipError_t launch_seg_layout(const SegArgs &seg, unsigned long long *d_layout, unsigned long long *d_bytes, unsigned long long *host_totals,
                              hipStream_t s); // host_totals[2] (or null) receives the total number of 16 KiB tiles

@@ -287,6 +287,21 @@ template <int MODE> static hipError_t launch_load(int load, KArgs &a, hipStream_
     return launch_mode<MODE, L_BYTES>(a, s);
 }
 
+// The quantised DC of the last block of every plane — what the next band of a multi-GPU image predicts from — stored
+// straight into pinned host memory by one thread: one launch instead of three 2-byte copies.
+__global__ void last_dcs_kernel(const int16_t *y, size_t y_blocks, const int16_t *cb, const int16_t *cr, size_t c_blocks, int16_t *out)
+{
+    out[0] = y[(y_blocks - 1) * 64];
+    out[1] = c_blocks ? cb[(c_blocks - 1) * 64] : (int16_t)0;
+    out[2] = c_blocks ? cr[(c_blocks - 1) * 64] : (int16_t)0;
+}
+hipError_t launch_last_dcs(const void *d_y, size_t y_blocks, const void *d_cb, const void *d_cr, size_t c_blocks, int16_t *host_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(last_dcs_kernel, dim3(1), dim3(1), 0, stream, static_cast<const int16_t *>(d_y), y_blocks, static_cast<const int16_t *>(d_cb),
+                       static_cast<const int16_t *>(d_cr), c_blocks, host_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gray, bool s420,
                               uint32_t batch, void *d_y, void *d_cb, void *d_cr,
                               const float *d_qt, hipStream_t stream, bool raw_f32)

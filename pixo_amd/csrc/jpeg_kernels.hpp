@@ -16,6 +16,10 @@ hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gra
                               uint32_t batch, void *d_y, void *d_cb, void *d_cr,
                               const float *d_qt, hipStream_t stream, bool raw_f32 = false);
 
+// host_out[0..2] (pinned host memory) = the quantised DC of the last block of the Y / Cb / Cr plane (0 for planes without
+// blocks): what the next band of an image spread over several GPUs predicts from.  One launch, no copy.
+hipError_t launch_last_dcs(const void *d_y, size_t y_blocks, const void *d_cb, const void *d_cr, size_t c_blocks, int16_t *host_out, hipStream_t stream);
+
 // The INTEGER secondary mode (jpeg_integer.hip): 4:4:4 RGB or gray, one image; ql / qc = the natural-order
 // integer quantiser tables of the requested quality (host memory, passed by value to the kernel).
 hipError_t launch_jpeg_coeffs_integer(const void *d_px, uint32_t W, uint32_t H, bool gray, const uint16_t ql[64], const uint16_t qc[64],

@@ -496,7 +496,8 @@ __global__ __launch_bounds__(256) void scan_count_sum_kernel(const uint32_t *sla
 
 // ---- stuff: 16 KiB tiles of the packed stream ----------------------------------------------------------------------
 constexpr int kStuffThreads = 256, kLaneWords = 16, kWaveBytes = 64 * kLaneWords * 4, kTileBytes = (kStuffThreads / 64) * kWaveBytes;
-constexpr uint32_t kStageBytes = 2 * kTileBytes + 32; // worst case: every byte 0xFF, + the output's alignment skew, + a marker (16-byte granules)
+constexpr uint32_t kMaxSegGap = 1024;                        // bytes a segmented scan may leave free behind a segment (SegArgs::marker_bytes)
+constexpr uint32_t kStageBytes = 2 * kTileBytes + 32 + kMaxSegGap; // worst case: every byte 0xFF, + the output's alignment skew, + the gap behind a segment
 __device__ __forceinline__ uint32_t zero_byte_mask(uint32_t x)
 { // 0x80 in every byte of x that is zero (exact)
     return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
@@ -647,7 +648,9 @@ __global__ __launch_bounds__(kStuffThreads) __attribute__((amdgpu_waves_per_eu(4
         const uint64_t tile_in = nbytes - local_t * kTileBytes < (uint64_t)kTileBytes ? nbytes - local_t * kTileBytes : (uint64_t)kTileBytes;
         // SEG: is this the segment's last tile, and does a marker follow the segment?
         const bool seg_last = SEG && (local_t + 1) * kTileBytes >= nbytes;
-        const uint32_t marker = seg_last && seg.marker_bytes && sidx + 1 < seg.nsegs ? 2u : 0u;
+        // (restart intervals: the two bytes of RSTn; a batch: room for the next file's headers — the caller's, written by the
+        // host — so that the whole batch is ONE run of bytes with every file at its final distance from the others)
+        const uint32_t marker = seg_last && sidx + 1 < seg.nsegs ? seg.marker_bytes : 0u;
         // the tile's aggregate: 0xFF bytes (one scan: its input bytes are known from t) — SEG: everything it produces
         const uint32_t aggregate = SEG ? (uint32_t)tile_in + tile_ff + marker : tile_ff;
         if (lane == 0) publish_aggregate(desc, t, 0, aggregate);
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(kStuffThreads) __attribute__((amdgpu_waves_per_eu(4
             }
         }
         __syncthreads();
-        if (marker && lane == 0) { // RSTn behind the segment (jpeg/mod.rs:1431-1440): FF D0 + (index & 7), never stuffed
+        if (marker == 2 && seg.rst_markers && lane == 0) { // RSTn behind the segment (jpeg/mod.rs:1431-1440): FF D0 + (index & 7), never stuffed
             stage[skew + tile_out - 2] = 0xFF;
             stage[skew + tile_out - 1] = (uint8_t)(0xD0 + (sidx & 7));
         }
@@ -722,6 +725,7 @@ size_t fused_code_state_words(uint64_t nblocks) { return 2 + 2 * (size_t)((nbloc
 size_t fused_code_state_words_seg(uint64_t nsegs, uint64_t seg_blocks) { return 2 + 2 * (size_t)(nsegs * ((seg_blocks + kGroup - 1) / kGroup)); }
 size_t fused_stuff_state_words(uint64_t max_stream_bytes) { return 3 + (size_t)((max_stream_bytes + kTileBytes - 1) / kTileBytes); }
 uint32_t seg_groups(uint64_t seg_blocks) { return (uint32_t)((seg_blocks + kGroup - 1) / kGroup); }
+uint32_t seg_max_gap() { return kMaxSegGap; }
 
 hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool state_is_zero, uint32_t *d_stream,
                             unsigned long long *d_clear, size_t clear_words, unsigned long long *host_totals, hipStream_t s,

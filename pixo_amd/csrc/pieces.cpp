@@ -1,6 +1,12 @@
 // pieces.cpp — whole baseline files from a device tuple (or from pixels not transformed yet): a scan coded in PIECES so
 // that the file's way to the host overlaps the coding, the one-piece path, delivery into pinned / caller / malloc'd memory.
+#include <malloc.h>
+#include <sys/mman.h>
+
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 
 #include "capi_internal.hpp"
 
@@ -36,6 +42,55 @@ inline bool direct_host_stores() { return debug().direct_stores; }
 // stage launches the coefficient kernel itself — for a scan coded in pieces, band by band in front of each piece, so
 // that the first piece's bytes can leave before the rest of the image has even been transformed.
 
+} // namespace pixo_capi
+
+// A context's second host thread.  A copy from or to PAGEABLE host memory keeps the calling thread inside the runtime until
+// the bytes have moved (it stages them through pinned buffers): one thread can therefore not keep both directions of the
+// PCIe link busy — 48 MiB in + 11 MiB out take 1.11 ms from one thread and 0.93 ms from two (tools/ubench/duplex.cpp,
+// profiles/r03_duplex_copies.txt).  The helper runs one job at a time for its context; it lives as long as the process.
+struct pixo_capi::CopyHelper {
+    std::mutex m;
+    std::condition_variable cv, idle;
+    std::function<void()> job;
+    bool has_job = false, busy = false;
+    std::thread th;
+    CopyHelper() : th([this] { loop(); }) { th.detach(); }
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv.wait(lock, [&] { return has_job; });
+                f.swap(job);
+                has_job = false;
+            }
+            f();
+            {
+                std::lock_guard<std::mutex> lock(m);
+                busy = false;
+            }
+            idle.notify_all();
+        }
+    }
+    void start(std::function<void()> f)
+    {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            job = std::move(f);
+            has_job = busy = true;
+        }
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        idle.wait(lock, [&] { return !busy; });
+    }
+};
+
+namespace pixo_capi {
+
 int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *dst, size_t dst_cap, uint64_t *scan_bytes,
                           const PixelSource *src)
 { // dst: where the stuffed scan goes on the host (dst_cap bytes available); tables are uploaded, j.a is set up
@@ -47,10 +102,10 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
     uint64_t begin[kMaxPieces + 1];
     uint32_t pieces = 0;
     const bool from_host = src && src->host_px;
-    if (from_host) { // pixels still in host memory: pieces sized for the UPLOAD pipeline — about 6 MB of pixels each, so that
+    if (from_host) { // pixels still in host memory: pieces sized for the UPLOAD pipeline — about 12 MB of pixels each, so that
         // a band's kernels (tens of microseconds) disappear behind the next band's way over PCIe (>= 100 us)
         const uint64_t px_bytes = static_cast<uint64_t>(src->o->width) * src->o->height * (src->g->gray ? 1 : 3);
-        const uint32_t want = static_cast<uint32_t>(std::min<uint64_t>(kMaxPieces, std::max<uint64_t>(2, px_bytes / (6u << 20))));
+        const uint32_t want = static_cast<uint32_t>(std::min<uint64_t>(kMaxPieces, std::max<uint64_t>(2, px_bytes / (12u << 20))));
         for (uint32_t k = 0; k < want; ++k) {
             const uint64_t g0 = groups * k / want;
             if (pieces == 0 || g0 > begin[pieces - 1]) begin[pieces++] = g0;
@@ -141,7 +196,8 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
         sw.lap("  copy enqueued");
         return PIXO_OK;
     };
-    for (uint32_t k = 0; k < pieces; ++k) {
+    // piece k: its MCU rows through the coefficient kernel (where the pieces follow the rows), then the two entropy kernels
+    auto launch_piece = [&](uint32_t k) -> int {
         pd::ScanArgs a = j.a;
         a.nblocks = pc[k].blocks;
         a.pad_last = k + 1 == pieces ? 1u : 0u;
@@ -149,18 +205,10 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
         unsigned long long *mail = reinterpret_cast<unsigned long long *>(c.h_totals) + 4 * k;
         const bool zero = c.code_state_zero_words >= state_words;
         c.code_state_zero_words = 0;
-        if (groups_per_row) { // this piece's MCU rows through the coefficient kernel
+        if (groups_per_row) {
             const uint32_t row0 = static_cast<uint32_t>(begin[k] / groups_per_row);
             const uint32_t rows = k + 1 == pieces ? 0u : static_cast<uint32_t>(begin[k + 1] / groups_per_row) - row0;
-            if (upload_bands) { // ... which come over PCIe on the upload stream while the band before is transformed and coded
-                const uint32_t unit = (!src->g->gray && src->g->s420) ? 16u : 8u;
-                const size_t row_bytes = static_cast<size_t>(src->o->width) * (src->g->gray ? 1 : 3);
-                const size_t y0 = static_cast<size_t>(row0) * unit, y1 = rows ? std::min<size_t>(src->o->height, static_cast<size_t>(row0 + rows) * unit) : src->o->height;
-                HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(const_cast<void *>(src->d_px)) + y0 * row_bytes, src->host_px + y0 * row_bytes,
-                                       (y1 - y0) * row_bytes, hipMemcpyHostToDevice, c.upload_stream));
-                HIP_TRY(hipEventRecord(c.band_up[k], c.upload_stream));
-                HIP_TRY(hipStreamWaitEvent(stream, c.band_up[k], 0));
-            }
+            if (upload_bands) HIP_TRY(hipStreamWaitEvent(stream, c.band_up[k], 0)); // (its pixels arrive on the upload stream)
             const int rc = coeffs_rows(c, src->d_px, *src->o, *src->g, stream, src->dy, src->dcb, src->dcr, row0, rows);
             if (rc) return rc;
         }
@@ -171,22 +219,74 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
                                        c.e_out.as<uint8_t>(), c.e_out.cap, mail, stream, out_chain, k, nullptr, debug().spin_budget));
         c.code_state_zero_words = state_words;
         HIP_TRY(hipEventRecord(c.piece_done[k], stream));
-        // pixels from the host: enqueuing a band's upload kept this thread busy for as long as the band took to cross PCIe —
-        // pieces that have been coded meanwhile start their way back now (the other direction of the link)
-        if (upload_bands)
-            while (next_out < k && !redo && hipEventQuery(c.piece_done[next_out]) == hipSuccess) {
-                const int rc = send_piece(next_out++);
+        return PIXO_OK;
+    };
+    if (upload_bands) {
+        // Pixels from the host.  A copy from pageable memory keeps the calling thread inside the runtime until the bytes have
+        // moved, and whatever else that thread has to do in between — launches, events — is time the link stands still.  So
+        // THIS thread does nothing but enqueue the bands' uploads back to back; the context's helper thread follows it band
+        // by band (`uploaded`): launches the band's kernels behind its upload event and sends the piece before it — coded
+        // while this band travelled — back over the other direction of the link.
+        struct Progress { // bands uploaded so far, handed from the uploading thread to the helper
+            std::mutex m;
+            std::condition_variable cv;
+            uint32_t n = 0;
+            void set(uint32_t v) { { std::lock_guard<std::mutex> lock(m); if (v > n) n = v; } cv.notify_all(); }
+            void wait_beyond(uint32_t k) { std::unique_lock<std::mutex> lock(m); cv.wait(lock, [&] { return n > k; }); }
+        } uploaded;
+        int helper_rc = PIXO_OK;
+        if (!c.helper) c.helper = new CopyHelper;
+        const int device = c.device;
+        c.helper->start([&, device] {
+            (void)hipSetDevice(device);
+            auto body = [&]() -> int {
+                for (uint32_t k = 0; k < pieces; ++k) {
+                    uploaded.wait_beyond(k);
+                    int rc = launch_piece(k);
+                    if (rc) return rc;
+                    if (k) {
+                        HIP_TRY(hipEventSynchronize(c.piece_done[k - 1]));
+                        if ((rc = send_piece(k - 1))) return rc;
+                    }
+                }
+                HIP_TRY(hipEventSynchronize(c.piece_done[pieces - 1]));
+                const int rc = send_piece(pieces - 1);
                 if (rc) return rc;
-            }
+                HIP_TRY(hipStreamSynchronize(c.copy_stream));
+                return PIXO_OK;
+            };
+            helper_rc = body();
+        });
+        // (whatever happens below, the helper must have finished before this frame's variables go away)
+        struct HelperGuard { Context &c; Progress &up; uint32_t n; ~HelperGuard() { up.set(n); c.helper->wait(); } } guard{c, uploaded, pieces};
+        const uint32_t unit = (!src->g->gray && src->g->s420) ? 16u : 8u;
+        const size_t row_bytes = static_cast<size_t>(src->o->width) * (src->g->gray ? 1 : 3);
+        for (uint32_t k = 0; k < pieces; ++k) {
+            const size_t r0 = static_cast<size_t>(begin[k] / groups_per_row), r1 = k + 1 == pieces ? ~size_t{0} : static_cast<size_t>(begin[k + 1] / groups_per_row);
+            const size_t y0 = std::min<size_t>(src->o->height, r0 * unit), y1 = k + 1 == pieces ? src->o->height : std::min<size_t>(src->o->height, r1 * unit);
+            if (y1 > y0)
+                HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(const_cast<void *>(src->d_px)) + y0 * row_bytes, src->host_px + y0 * row_bytes,
+                                       (y1 - y0) * row_bytes, hipMemcpyHostToDevice, c.upload_stream));
+            HIP_TRY(hipEventRecord(c.band_up[k], c.upload_stream));
+            uploaded.set(k + 1);
+        }
+        sw.lap("  bands uploaded");
+        c.helper->wait();
+        if (helper_rc) return helper_rc;
+    } else {
+        for (uint32_t k = 0; k < pieces; ++k) {
+            const int rc = launch_piece(k);
+            if (rc) return rc;
+        }
+        sw.lap("  pieces enqueued");
+        for (; next_out < pieces; ++next_out) {
+            HIP_TRY(hipEventSynchronize(c.piece_done[next_out]));
+            sw.lap("  piece coded");
+            const int rc = send_piece(next_out);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipStreamSynchronize(c.copy_stream));
     }
-    sw.lap("  pieces enqueued");
-    for (; next_out < pieces; ++next_out) {
-        HIP_TRY(hipEventSynchronize(c.piece_done[next_out]));
-        sw.lap("  piece coded");
-        const int rc = send_piece(next_out);
-        if (rc) return rc;
-    }
-    HIP_TRY(hipStreamSynchronize(c.copy_stream));
     sw.lap("  copies done");
     if (gave_up) return scan_retry_multipass(c);
     if (redo) return 1;
@@ -206,7 +306,7 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
                                          const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len,
                                          uint32_t batch, std::vector<uint64_t> *image_starts, size_t *header_len,
                                          uint8_t *dest, size_t dest_cap, bool *own_malloc, const PixelSource *src, bool *tuple_done,
-                                         std::vector<uint8_t> *head_out)
+                                         std::vector<uint8_t> *head_out, uint32_t seg_gap, bool *gaps_left)
 { // src != null: the tuple (dy, dcb, dcr = src's) has not been computed yet, see PixelSource.
   // dest != null: the file goes straight into the caller's storage (no pinned intermediate); when it does not
   // fit, *file_len says how much is needed and nothing is copied (PIXO_ERR_BUFFER_TOO_SMALL).
@@ -220,8 +320,10 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
     namespace pd = pixo_dev;
     Stopwatch sw;
     ScanJob j;
+    j.seg_gap = batch > 1 ? seg_gap : 0;
     int rc = scan_begin(c, j, dy, dcb, dcr, o, g, batch, nullptr);
     if (rc) return rc;
+    if (gaps_left) *gaps_left = j.segmented && j.seg.marker_bytes == seg_gap && seg_gap != 0;
     sw.lap("  reserve");
     std::vector<uint8_t> head;
     // a large scan: in pieces, the file leaving for the host while the rest is still being coded — into the context's
@@ -234,12 +336,14 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
     const uint64_t scan_groups = (j.n + 191) / 192;
     const bool large = scan_groups >= 2 * piece_min_groups();
     const bool medium = !large && scan_groups >= piece_medium_groups() && (c.packed_per_block >= 12 || piece_medium_forced());
-    // Pixels still in host memory (pixo_hip_jpeg_encode / _encode_into): their way over PCIe is most of the call (0.9 of
-    // 1.6 ms for a 4096x4096 image), so from 512 groups on (a 2048x2048 image) the image is uploaded in bands, each band
-    // transformed and coded while the next one travels, and coded pieces start their way back meanwhile
-    // (device_entropy_pieces).  Whatever path is taken, the pixels are uploaded exactly once.
+    // Pixels still in host memory (pixo_hip_jpeg_encode / _encode_into): their way over PCIe is most of the call.  From 96 MB
+    // of pixels on (8192x4096) the image is uploaded in bands, each band transformed and coded while the next one travels,
+    // coded pieces on their way back meanwhile (device_entropy_pieces): 16384x16384 17.7 -> 15.1 ms, which is the upload
+    // alone at 53 GB/s.  Below that the two extra threads' hand-offs cost what the overlap gains (4096x4096: 1.18 ms either
+    // way, of which 0.95 are the upload; profiles/r03_host_pipeline.txt).  Whatever path is taken, the pixels are uploaded once.
     bool host_px_pending = src && src->host_px;
-    const bool host_bands = host_px_pending && scan_groups >= 512 && !debug().no_bands_upload;
+    const bool host_bands = host_px_pending && static_cast<uint64_t>(o.width) * o.height * (g.gray ? 1 : 3) >= (uint64_t{96} << 20) &&
+                            !debug().no_bands_upload;
     auto upload_all = [&]() -> int {
         if (!host_px_pending) return PIXO_OK;
         const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
@@ -347,8 +451,8 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
     const uint64_t scan_bytes = j.scan_bytes;
     if (batch == 1 && j.n) c.packed_per_block = static_cast<uint32_t>(scan_bytes / j.n);
     if (batch > 1 && j.segmented) { // the stuffing kernel left every image's end in the pinned mailbox
-        image_starts->assign(batch + 1, 0);
-        for (uint32_t i = 0; i < batch; ++i) (*image_starts)[i + 1] = c.h_segs[i];
+        image_starts->assign(batch + 1, 0); // (h_segs[i]: where image i's bytes end; the next image begins behind the gap)
+        for (uint32_t i = 0; i < batch; ++i) (*image_starts)[i + 1] = c.h_segs[i] + (i + 1 < batch ? j.seg.marker_bytes : 0);
     } else if (batch > 1) { // where every image's segment begins in the stuffed stream (reuses the seg_bytes buffer: 8 B/entry)
         HIP_TRY(c.e_seg_bytes.reserve(j.nseg * 8));
         HIP_TRY(pd::launch_segment_out_offsets(j.plan, j.nbytes, c.e_stream.as<uint32_t>(), c.e_tile_base.as<uint64_t>(),
@@ -376,7 +480,7 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
             return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(total) + " bytes");
         }
     } else if (own_malloc && batch == 1) {
-        buf = static_cast<uint8_t *>(std::malloc(total));
+        buf = alloc_file(total);
         if (!buf) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
         mine = true;
     } else {
@@ -403,22 +507,90 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
 int device_entropy_to_pinned(Context &c, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                              const pixo_host::Geometry &g, hipStream_t stream, const uint8_t **file, size_t *file_len,
                              uint32_t batch, std::vector<uint64_t> *image_starts, size_t *header_len,
-                             uint8_t *dest, size_t dest_cap, bool *own_malloc, const PixelSource *src, std::vector<uint8_t> *head_out)
+                             uint8_t *dest, size_t dest_cap, bool *own_malloc, const PixelSource *src, std::vector<uint8_t> *head_out,
+                             uint32_t seg_gap, bool *gaps_left)
 {
     bool tuple_done = false;
     int rc = device_entropy_to_pinned_once(c, dy, dcb, dcr, o, g, stream, file, file_len, batch, image_starts, header_len, dest, dest_cap,
-                                           own_malloc, src, &tuple_done, head_out);
+                                           own_malloc, src, &tuple_done, head_out, seg_gap, gaps_left);
     if (rc != kRetryMultipass) return rc;
     // a single-pass kernel gave up waiting (its waits are bounded): the same scan with the multi-pass kernels
     RetryMultipass scope;
     rc = device_entropy_to_pinned_once(c, dy, dcb, dcr, o, g, stream, file, file_len, batch, image_starts, header_len, dest, dest_cap,
-                                       own_malloc, tuple_done ? nullptr : src, &tuple_done, head_out);
+                                       own_malloc, tuple_done ? nullptr : src, &tuple_done, head_out, seg_gap, gaps_left);
     return rc == kRetryMultipass ? fail(PIXO_ERR_COMPRESSION, "Compression error: the entropy kernels could not make progress") : rc;
 }
 
 // Copies into FRESH host memory are page-fault bound (one core maps and fills a few GB/s of new pages):
 // above a few MB the bytes are spread over a handful of threads (PIXO_HIP_COPY_THREADS, default 8; 1 = none).
 inline unsigned copy_threads() { return debug().copy_threads; }
+// A block the caller will own and give back with pixo_hip_free.  Small files: malloc — glibc serves blocks up to its
+// (dynamic, <= 32 MB) mmap threshold from recycled heap pages.  Larger ones would be fresh mappings every time, and a
+// fresh mapping costs a page fault per 4 KiB when it is first written: for the 178 MB file of a 16384x16384 image that is
+// several times the file's whole way over PCIe, and more threads do not help much (the faults serialise on the address
+// space; tools/ubench/fresh_pages.cpp).  So pixo_hip_free keeps up to two large blocks instead of unmapping them and the
+// next large file reuses one: its pages are resident.  pixo_hip_trim releases them.
+constexpr size_t kLargeBlock = size_t{24} << 20;
+struct BlockCache {
+    std::mutex m;
+    struct Entry { void *p; size_t cap; };
+    std::vector<Entry> kept;
+    static constexpr size_t kMaxKept = 2, kMaxBytes = size_t{1} << 30;
+};
+BlockCache &block_cache()
+{
+    static BlockCache *b = new BlockCache;
+    return *b;
+}
+uint8_t *alloc_file(size_t n)
+{
+    if (n < kLargeBlock) return static_cast<uint8_t *>(std::malloc(n ? n : 1));
+    {
+        BlockCache &bc = block_cache();
+        std::lock_guard<std::mutex> lock(bc.m);
+        size_t best = bc.kept.size();
+        for (size_t i = 0; i < bc.kept.size(); ++i) // smallest block that holds the file and is not absurdly larger
+            if (bc.kept[i].cap >= n && bc.kept[i].cap <= 2 * n + kLargeBlock && (best == bc.kept.size() || bc.kept[i].cap < bc.kept[best].cap)) best = i;
+        if (best < bc.kept.size()) {
+            void *p = bc.kept[best].p;
+            bc.kept.erase(bc.kept.begin() + static_cast<long>(best));
+            return static_cast<uint8_t *>(p);
+        }
+    }
+    // a fresh block: 2 MiB aligned with a transparent-huge-page hint — filled by big_copy's threads it costs 2.7 ms for 178 MB
+    // on the GPU box where plain malloc'd pages cost 15 (one thread: 28); a recycled block 1.7 (tools/ubench/fresh_pages.cpp,
+    // profiles/r03_fresh_pages.txt).  Head-room: the next file of about this size fits the recycled block.
+    constexpr size_t kHuge = size_t{2} << 20;
+    const size_t rounded = (n + n / 8 + kHuge - 1) / kHuge * kHuge;
+    void *p = nullptr;
+    if (posix_memalign(&p, kHuge, rounded) != 0) return nullptr;
+    (void)madvise(p, rounded, MADV_HUGEPAGE);
+    return static_cast<uint8_t *>(p);
+}
+void free_file(void *p)
+{
+    if (!p) return;
+    const size_t cap = malloc_usable_size(p);
+    if (cap >= kLargeBlock) {
+        BlockCache &bc = block_cache();
+        std::lock_guard<std::mutex> lock(bc.m);
+        size_t bytes = cap;
+        for (const BlockCache::Entry &e : bc.kept) bytes += e.cap;
+        if (bc.kept.size() < BlockCache::kMaxKept && bytes <= BlockCache::kMaxBytes) {
+            bc.kept.push_back({p, cap});
+            return;
+        }
+    }
+    std::free(p);
+}
+void drop_kept_blocks()
+{
+    BlockCache &bc = block_cache();
+    std::lock_guard<std::mutex> lock(bc.m);
+    for (const BlockCache::Entry &e : bc.kept) std::free(e.p);
+    bc.kept.clear();
+}
+
 void big_copy(uint8_t *dst, const uint8_t *src, size_t n)
 {
     constexpr size_t kSlice = size_t{1} << 20;
@@ -434,7 +606,7 @@ void big_copy(uint8_t *dst, const uint8_t *src, size_t n)
 // ... and into memory the caller owns: a fresh malloc block, or storage it supplied
 int deliver(const uint8_t *file, size_t n, uint8_t **out, size_t *out_len)
 {
-    uint8_t *p = static_cast<uint8_t *>(std::malloc(n ? n : 1));
+    uint8_t *p = alloc_file(n);
     if (!p) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
     big_copy(p, file, n);
     *out = p;
@@ -460,7 +632,7 @@ int device_entropy_to_malloc(Context &c, const int16_t *dy, const int16_t *dcb, 
 
 int hand_over(const std::vector<uint8_t> &v, uint8_t **out, size_t *out_len)
 {
-    uint8_t *p = static_cast<uint8_t *>(std::malloc(v.size() ? v.size() : 1));
+    uint8_t *p = alloc_file(v.size());
     if (!p) return fail(PIXO_ERR_COMPRESSION, "Compression error: out of host memory");
     big_copy(p, v.data(), v.size());
     *out = p;

@@ -54,20 +54,32 @@ PIXO_PDEV uint32_t gt_mask(s16x2 x, s16x2 y)
 { // per 16-bit lane: 0xFFFF where x > y  (two packed ops: subtract, arithmetic shift)
     return as_u((y - x) >> 15);
 }
-// Paeth predictor (fallback.rs:144-159) on two bytes held in the low bytes of 16-bit lanes:
-// p = a + b - c, pa = |p - a| = |b - c|, pb = |p - b| = |a - c|, pc = |p - c| = |(b - c) + (a - c)|;
-// a unless pa > pb or pa > pc, then b unless pb > pc, then c.
+// Paeth predictor (fallback.rs:144-159) on two bytes held in the low bytes of 16-bit lanes.
+// The reference: p = a + b - c, pa = |p - a|, pb = |p - b|, pc = |p - c|; a if pa <= pb and pa <= pc, else b if pb <= pc,
+// else c.  Restated without absolute values (round 3; the 2^24 triples are enumerated in tests/test_emu_png.py and on the
+// GPU): with lo = min(a, b), hi = max(a, b) the answer only depends on where c lies —
+//     c >= hi: p <= lo, the nearest of the three is lo;     c <= lo: hi;
+//     lo < c < hi: p = lo + hi - c lies between them at distances (hi - c) from lo, (c - lo) from hi and |(hi - c) - (c - lo)|
+//     from c:  lo if 2 (hi - c) <= c - lo,  hi if 2 (c - lo) <= hi - c,  else c   (ties go to a, b before c: "<=")
+// and the outer cases satisfy the same two inequalities, so for ALL c, with x = 3 c - (a + b):
+//     predictor = lo if x - hi >= 0,  else hi if lo - x >= 0,  else c.
+// 11 packed operations per two bytes (min, max, add, multiply, subtract; two differences; two sign smears; two bit selects)
+// where the distances needed 17 (three subtractions, three negations, three maxima, a minimum, two compares of two
+// operations each, two selects) — the kernel is VALU bound and Paeth was 60 % of it.
+typedef unsigned short pu16x2 __attribute__((ext_vector_type(2)));
+PIXO_PDEV pu16x2 as_us(uint32_t v) { return __builtin_bit_cast(pu16x2, v); }
 PIXO_PDEV uint32_t paeth2(uint32_t a, uint32_t b, uint32_t c)
-{ // 14 packed operations + 2 bit selects
-    const s16x2 da = as_s(b) - as_s(c), db = as_s(a) - as_s(c), dd = da + db;
-    const s16x2 pa = __builtin_elementwise_max(da, -da), pb = __builtin_elementwise_max(db, -db);
-    const s16x2 pc = __builtin_elementwise_max(dd, -dd);
-    uint32_t not_a = gt_mask(pa, __builtin_elementwise_min(pb, pc)), use_c = gt_mask(pb, pc);
-    // (opaque: otherwise the masks are turned back into 16-bit compares + SDWA selects + a permute, 5 half-rate
-    // instructions where subtract, shift, bit-select are 3)
-    PIXO_POPAQUE(not_a); PIXO_POPAQUE(use_c);
-    const uint32_t bc_sel = (c & use_c) | (b & ~use_c);
-    return (bc_sel & not_a) | (a & ~not_a);
+{
+    const pu16x2 ua = as_us(a), ub = as_us(b), uc = as_us(c);
+    const pu16x2 lo = __builtin_elementwise_min(ua, ub), hi = __builtin_elementwise_max(ua, ub);
+    const pu16x2 three = {3, 3};
+    const s16x2 x = __builtin_bit_cast(s16x2, (pu16x2)(uc * three - (ua + ub))); // in [-510, 765]
+    uint32_t not_lo = as_u((x - __builtin_bit_cast(s16x2, hi)) >> 15); // ones where x - hi < 0
+    uint32_t not_hi = as_u((__builtin_bit_cast(s16x2, lo) - x) >> 15); // ones where lo - x < 0
+    // (opaque: otherwise the masks are turned back into 16-bit compares + SDWA selects + a permute)
+    PIXO_POPAQUE(not_lo); PIXO_POPAQUE(not_hi);
+    const uint32_t hc = (c & not_hi) | (__builtin_bit_cast(uint32_t, hi) & ~not_hi);
+    return (hc & not_lo) | (__builtin_bit_cast(uint32_t, lo) & ~not_lo);
 }
 PIXO_PDEV uint32_t paeth4(uint32_t a, uint32_t b, uint32_t c)
 {

@@ -125,7 +125,9 @@ int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, co
     namespace pd = pixo_dev;
     // every pass starts from scratch: a job object that is kept across calls (the band encoder's) must not carry the last
     // image's tables, lengths or flags into the next one (scan_tables would otherwise return early with the old tables)
+    const uint32_t seg_gap = j.seg_gap; // (the one input a caller sets before the pass begins)
     j = ScanJob{};
+    j.seg_gap = seg_gap <= pd::seg_max_gap() ? seg_gap : 0;
     j.n = (g.y_blocks + 2 * g.c_blocks) * batch;
     pd::ScanArgs &a = j.a;
     a.y = dy; a.cb = dcb; a.cr = dcr;
@@ -164,7 +166,8 @@ int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, co
         sg.blocks = static_cast<uint32_t>(seg_blocks);
         sg.groups = pd::seg_groups(seg_blocks);
         sg.stream_words = (seg_blocks * 209 + 64 + 15) / 16 * 4;
-        sg.marker_bytes = a.marker_bytes;
+        sg.marker_bytes = a.marker_bytes ? 2u : j.seg_gap; // RSTn, or the gap a batch wants between its files' scans
+        sg.rst_markers = a.marker_bytes ? 1u : 0u;
         j.stream_cap = static_cast<size_t>(sg.stream_words) * 4 * j.nseg;
         HIP_TRY(c.e_stream.reserve(j.stream_cap + 64));
         const size_t state_words = pd::fused_code_state_words_seg(j.nseg, seg_blocks);

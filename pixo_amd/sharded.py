@@ -101,11 +101,47 @@ def _pinned_file(n):
     return t
 
 
-def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn=None, out=None):
+class SharedFile:
+    """A file buffer in POSIX shared memory that every rank of ONE node maps (`SharedFile(name, size, create=rank == 0)`,
+    the others after a barrier with `create=False`).  With it `encode_banded` lets every rank copy its band's body from its
+    GPU over its OWN PCIe link straight to the body's final place in the file — no gather to one rank, whose xGMI links
+    and single PCIe link would otherwise carry everybody's bytes.  `register()` pins this process's mapping
+    (hipHostRegister) so that the copy is one DMA; without it the copy is staged through the library's pinned buffer."""
+
+    def __init__(self, name, size, create):
+        from multiprocessing import shared_memory
+        self.shm = shared_memory.SharedMemory(name=name, create=create, size=size if create else 0)
+        self.size = size
+        self.registered = False
+
+    def array(self):
+        return np.ndarray((self.size,), dtype=np.uint8, buffer=self.shm.buf)
+
+    def register(self):
+        import torch
+        if not self.registered:
+            rc = torch.cuda.cudart().cudaHostRegister(self.array().ctypes.data, self.size, 0)
+            self.registered = int(rc) == 0
+        return self.registered
+
+    def close(self, unlink=False):
+        import torch
+        if self.registered:
+            torch.cuda.cudart().cudaHostUnregister(self.array().ctypes.data)
+            self.registered = False
+        self.shm.close()
+        if unlink:
+            self.shm.unlink()
+
+
+def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn=None, out=None, shared=None):
     """Collective over `group`.  Every rank passes the same `options` and ITS band's rows
     (`jpeg.band(w, h, ct, ss, world, rank)`: rows [row_begin, row_end), tightly packed) as host bytes /
     uint8 array or as a torch uint8 tensor on its GPU.  Returns the JFIF bytes on rank `dst`, None elsewhere;
     with `out` (a CPU uint8 tensor on `dst`, ideally pinned) the file is written there and its length returned.
+
+    `shared`: a `SharedFile` every rank has mapped (one node): every rank writes its body into it over its own PCIe
+    link; the file's length is returned on `dst` (the bytes are in `shared.array()`), None elsewhere.
 
     `device`: HIP device index of this rank (default: torch's current device); `coeff_fn(band_pixels,
     band_options) -> (y, cb, cr)`: tests substitute a CPU function, which also routes the entropy stage
@@ -152,6 +188,19 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
         # exchange 2: bits per band -> this band's bit offset
         all_bits = [b[0] for b in _all_gather_i64([bits], group, tdev)]
         offset = sum(all_bits[:rank])
+        if not on_gpu and shared is not None:  # host twins through the shared file: header exchange, body at its final place
+            piece = enc.pack(offset)
+            words = np.frombuffer(piece[:16], np.int64)
+            all_hdr = [np.array(h, np.int64).tobytes() for h in _all_gather_i64([int(words[0]), int(words[1])], group, tdev)]
+            file_len, body_off = jpeg.splice_layout(options, all_hdr, total_counts)
+            arr = shared.array()
+            body = np.frombuffer(piece, np.uint8)[16:]
+            arr[body_off[rank]: body_off[rank] + body.size] = body
+            dist.barrier(group=group)
+            if rank != dst:
+                return None
+            jpeg.splice_finish(options, all_hdr, arr, file_len, total_counts)
+            return file_len
         if not on_gpu:  # host twins: whole pieces, gathered as objects
             piece = enc.pack(offset)
             pieces = [None] * world if rank == dst else None
@@ -169,6 +218,16 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
         all_hdr = [np.array(h, np.int64).tobytes() for h in _all_gather_i64([int(words[0]), int(words[1])], group, tdev)]
         file_len, body_off = jpeg.splice_layout(options, all_hdr, total_counts)
         lens = [int(np.frombuffer(h, np.uint64)[1]) for h in all_hdr]
+        if shared is not None:
+            # every rank: device -> the body's final place in the node's shared file, over this GPU's own PCIe link
+            arr = shared.array()
+            if lens[rank]:
+                enc.copy_body(arr.ctypes.data + body_off[rank])
+            dist.barrier(group=group)
+            if rank != dst:
+                return None
+            jpeg.splice_finish(options, all_hdr, arr, file_len, total_counts)
+            return file_len
         if world == 1:
             file = out if out is not None else _pinned_file(file_len)
             enc.copy_body(file[body_off[0]:])  # device -> its final place in the (pinned) file

@@ -171,16 +171,23 @@ pub mod jpeg {
         // the reference reserves data.len() / 4 (src/jpeg/mod.rs:375); keep whatever the caller's vector already has
         let mut capacity = output.capacity().max(data.len() / 4);
         for _ in 0..2 {
-            let mut spare = Vec::<u8>::with_capacity(0);
-            let buf: &mut Vec<u8> = if output.capacity() >= capacity { output } else { spare.reserve_exact(capacity); &mut spare };
+            // grow the caller's vector in place, then hand the library the raw pointer / capacity pair — no second `&mut` to
+            // the vector is alive across the FFI call.  Its length is not changed before success: a validation error
+            // (which the library returns before it writes anything) leaves `output` as it was, like the reference.
+            if output.capacity() < capacity {
+                output.reserve_exact(capacity - output.len());
+            }
+            let (ptr, cap) = (output.as_mut_ptr(), output.capacity());
             let mut needed = 0usize;
-            let rc = unsafe { pixo_hip_jpeg_encode_into(buf.as_mut_ptr(), buf.capacity(), data.as_ptr(), data.len(), &c, &mut needed) };
+            let rc = unsafe { pixo_hip_jpeg_encode_into(ptr, cap, data.as_ptr(), data.len(), &c, &mut needed) };
             if rc == 0 {
-                unsafe { buf.set_len(needed) };
-                if !std::ptr::eq(buf, output) { *output = spare; }
+                // SAFETY: the library has initialised `needed` <= `cap` bytes behind `ptr`
+                unsafe { output.set_len(needed) };
                 return Ok(());
             }
-            if rc != PIXO_ERR_BUFFER_TOO_SMALL { return Err(error_from(rc, options, data.len())); }
+            if rc != PIXO_ERR_BUFFER_TOO_SMALL {
+                return Err(error_from(rc, options, data.len()));
+            }
             capacity = needed;
         }
         Err(Error::CompressionError("output size changed between two identical calls".to_string()))

@@ -97,6 +97,43 @@ def test_three_rank_uneven_bands(flags):
     assert _run(_worker_banded_flags, 3, (flags,)) is True
 
 
+def _worker_banded_shared(rank, world, port, w, h, ct, ss, q, flags, ret):
+    """encode_banded with a SharedFile: every rank writes its body to its final place in one shared-memory file
+    (on a GPU node: over its own PCIe link); rank 0 finishes the splice in place."""
+    dist = _setup(rank, world, port)
+    import numpy as np
+    import oracle_lib as O
+    import synth
+    from pixo_amd import jpeg, sharded
+    px = synth.noise(w, h, 77)
+
+    def cpu_coeffs(sub, o):
+        return O.coeffs(sub, o.width, o.height, int(o.color_type), int(o.subsampling), o.quality)
+
+    o = _options(w, h, ct, ss, q, flags)
+    name = "pixo_test_%d" % port
+    size = w * h * 3 + 4096
+    shared = sharded.SharedFile(name, size, create=True) if rank == 0 else None
+    dist.barrier()
+    if rank != 0:
+        shared = sharded.SharedFile(name, size, create=False)
+    b = jpeg.band(w, h, ct, ss, world, rank)
+    mine = px[b["row_begin"] * w * 3: b["row_end"] * w * 3]
+    n = sharded.encode_banded(mine, o, coeff_fn=cpu_coeffs, shared=shared)
+    if rank == 0:
+        ret.put(shared.array()[:n].tobytes() == O.encode(px, O.make_options(w, h, ct, q, ss, **flags)))
+    else:
+        assert n is None
+    dist.barrier()
+    shared.close(unlink=rank == 0)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("flags", [{}, {"optimize_huffman": True}])
+def test_three_ranks_write_their_bodies_into_one_shared_file(flags):
+    assert _run(_worker_banded_shared, 3, (200, 203, 2, 1, 75, flags)) is True
+
+
 def test_banded_form_refuses_what_a_band_cannot_code():
     sys.path.insert(0, os.path.dirname(HERE))
     from pixo_amd import jpeg, sharded

@@ -26,9 +26,16 @@ def batch_case(kind):
     for mode in ("", "multipass_entropy"):
         jpeg.debug_configure(mode)
         a = med(lambda: jpeg.encode_batch_device_into(arena, d, o, n))
-        b = med(lambda: jpeg.encode_batch_device(d, o, n), 5)
+        import ctypes as C
+        from pixo_amd import _lib
+        L = _lib.load(); files = (C.POINTER(C.c_uint8) * n)(); lens_c = (C.c_size_t * n)(); oc = o._c()
+        def c_call():
+            rc = L.pixo_hip_jpeg_encode_batch_device(d.data_ptr(), C.byref(oc), n, files, lens_c)
+            assert rc == 0
+            for i in range(n): L.pixo_hip_free(files[i])
+        b = med(c_call, 5)
         offs, lens = jpeg.encode_batch_device_into(arena, d, o, n)
-        print("batch 64 x 1080p %-8s %-18s into pinned arena %7.3f ms (min %7.3f)   64 malloc'd files %7.3f ms (min %7.3f)   %d bytes"
+        print("batch 64 x 1080p %-8s %-18s into pinned arena %7.3f ms (min %7.3f)   64 malloc'd files (C call) %7.3f ms (min %7.3f)   %d bytes"
               % (kind, mode or "single-pass", a[0], a[1], b[0], b[1], sum(lens)), flush=True)
     jpeg.debug_configure(None)
 

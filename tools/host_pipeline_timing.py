@@ -20,8 +20,8 @@ def med(fn, reps):
 for size, kind, reps in ((2048, "noise", 9), (4096, "noise", 9), (4096, "smooth", 9), (16384, "noise", 3)):
     px = synth.noise(size, size, 42) if kind == "noise" else synth.gradient_rgb(size, size)
     o = jpeg.JpegOptions.builder(size, size).quality(80).subsampling(jpeg.Subsampling.S420).build()
-    pin = torch.empty(size * size, dtype=torch.uint8).pin_memory()
-    pageable = np.empty(size * size, np.uint8)
+    pin = torch.empty(size * size * 2, dtype=torch.uint8).pin_memory()
+    pageable = np.empty(size * size * 2, np.uint8)
     digests = set()
     for mode in ("", "no_bands_upload"):
         jpeg.debug_configure(mode)

@@ -34,7 +34,7 @@ SYMBOLS = [
     "pixo_hip_band_encoder_pack", "pixo_hip_band_encoder_pack_device", "pixo_hip_band_encoder_copy_body",
     "pixo_hip_jpeg_splice", "pixo_hip_jpeg_splice_layout", "pixo_hip_jpeg_splice_finish", "pixo_hip_jpeg_band_count_host",
     "pixo_hip_jpeg_band_bits_host", "pixo_hip_jpeg_band_piece_host", "pixo_hip_jpeg_encode_multi",
-    "pixo_hip_device_count", "pixo_hip_set_device", "pixo_hip_set_producer_stream", "pixo_hip_get_producer_stream", "pixo_hip_debug_configure", "pixo_hip_trim", "pixo_hip_free",
+    "pixo_hip_device_count", "pixo_hip_set_device", "pixo_hip_set_producer_stream", "pixo_hip_get_producer_stream", "pixo_hip_debug_configure", "pixo_hip_trim", "pixo_hip_free", "pixo_hip_copy_file",
     "pixo_hip_last_error", "pixo_hip_version",
 ]
 
@@ -130,6 +130,8 @@ def load():
     L.pixo_hip_set_device.argtypes = [C.c_int]
     L.pixo_hip_free.argtypes = [C.c_void_p]
     L.pixo_hip_free.restype = None
+    L.pixo_hip_copy_file.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.pixo_hip_copy_file.restype = None
     L.pixo_hip_last_error.restype = C.c_char_p
     L.pixo_hip_version.restype = C.c_char_p
     for name in ("pixo_hip_jpeg_encode", "pixo_hip_jpeg_encode_into", "pixo_hip_encode_jpeg",
@@ -138,3 +140,19 @@ def load():
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
+
+
+_bytes_new = C.pythonapi.PyBytes_FromStringAndSize
+_bytes_new.restype = C.py_object
+_bytes_new.argtypes = [C.c_void_p, C.c_ssize_t]
+
+
+def file_bytes(L, ptr, n: int) -> bytes:
+    """The n bytes at ptr as a Python bytes object.  Large files are copied by the library's copy threads into a bytes
+    object created uninitialised (ours alone until it is returned), with a huge-page hint before its first touch:
+    ctypes.string_at on a 178 MB file is a one-thread memcpy into 43,000 fresh pages, 28 ms of a 45 ms call."""
+    if n < (2 << 20):
+        return C.string_at(ptr, n)
+    b = _bytes_new(None, n)
+    L.pixo_hip_copy_file(C.cast(C.c_char_p(b), C.c_void_p), ptr, n)
+    return b

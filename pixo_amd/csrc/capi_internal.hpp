@@ -191,6 +191,7 @@ template <class F> void run_on_threads(unsigned t, F &&body) // body(index) for 
     for (auto &w : workers) w.join();
 }
 void big_copy(uint8_t *dst, const uint8_t *src, size_t n);
+void advise_huge(void *p, size_t n);
 uint8_t *alloc_file(size_t n); // a block for a finished file that the caller will own: large ones come from the blocks pixo_hip_free kept
 void free_file(void *p);       // pixo_hip_free: large blocks are kept (at most two) for the next large file
 void drop_kept_blocks();       // pixo_hip_trim

@@ -382,6 +382,10 @@ int pixo_hip_trim(void)
 }
 
 void pixo_hip_free(void *p) { free_file(p); }
+void pixo_hip_copy_file(void *dst, const void *src, size_t n)
+{
+    if (dst && src && n) big_copy(static_cast<uint8_t *>(dst), static_cast<const uint8_t *>(src), n);
+}
 
 const char *pixo_hip_last_error(void) { return t_error.c_str(); }
 

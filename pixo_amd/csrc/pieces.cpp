@@ -373,6 +373,7 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
         const size_t hdr = head.size();
         uint8_t *buf = dest;
         size_t cap = dest_cap;
+        if (buf) advise_huge(buf, std::min(cap, likely_most));
         if (!buf) {
             if ((rc = c.reserve_hfile(likely_most))) return rc;
             buf = c.h_file;
@@ -591,8 +592,19 @@ void drop_kept_blocks()
     bc.kept.clear();
 }
 
+// Transparent huge pages for the whole 2 MiB units inside [p, p + n): a hint before the first touch of a large block the
+// CALLER allocated (a fresh 178 MB block is 43,000 page faults otherwise: 15 ms over 8 threads against 2.7 with huge pages,
+// profiles/r03_fresh_pages.txt; resident pages are not affected).
+void advise_huge(void *p, size_t n)
+{
+    constexpr uintptr_t kHuge = uintptr_t{2} << 20;
+    const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + kHuge - 1) & ~(kHuge - 1), b = (reinterpret_cast<uintptr_t>(p) + n) & ~(kHuge - 1);
+    if (n >= kLargeBlock && b > a) (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
+}
+
 void big_copy(uint8_t *dst, const uint8_t *src, size_t n)
 {
+    advise_huge(dst, n);
     constexpr size_t kSlice = size_t{1} << 20;
     const size_t slices = (n + kSlice - 1) / kSlice;
     const unsigned t = static_cast<unsigned>(std::min<size_t>(copy_threads(), slices / 2));

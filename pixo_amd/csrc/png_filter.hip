@@ -101,11 +101,22 @@ __device__ __forceinline__ unsigned long long wg_sum(unsigned long long v, unsig
     return lds[0] + lds[1] + lds[2] + lds[3];
 }
 
+// v + (v of the lane the DPP control names; 0 where that lane does not exist or the row is masked out)
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ uint32_t dpp_add(uint32_t v)
+{
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
-{ // every lane gets the wavefront's total (the caller guarantees it fits 32 bits)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+{ // the wavefront's total, uniform (the caller guarantees it fits 32 bits): four DPP additions inside every row of 16
+  // lanes, two across the rows, lane 63 read back — 7 instructions where six rounds of __shfl_xor were 6 ds_bpermute + 6
+  // additions + their address arithmetic, for each of the 8 totals of a row
+    v = dpp_add<0xB1>(v);       // quad_perm:[1,0,3,2]
+    v = dpp_add<0x4E>(v);       // quad_perm:[2,3,0,1]
+    v = dpp_add<0x141>(v);      // row_half_mirror
+    v = dpp_add<0x140>(v);      // row_mirror: every lane of a row holds the row's total
+    v = dpp_add<0x142, 0xA>(v); // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v); // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 struct Args {
@@ -135,14 +146,14 @@ __device__ __forceinline__ void emit_group(const Group &g, int k0, int n, T L, b
 {
     uint32_t v[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        v[j] = filtered(F, g, j) & g.valid[j];
-        // bytes at output positions p = 1 + 4k + b, weight L - p
-        uint32_t sum, ramp;
-        adler_terms(v[j], sum, ramp); // byte sum; 3*b0 + 2*b1 + 1*b2 + 0*b3
-        s1 += sum;
-        s2 += (L - (T)(4 * (k0 + j) + 4)) * sum + ramp;
-    }
+    for (int j = 0; j < 4; j++) v[j] = filtered(F, g, j) & g.valid[j];
+    // the group's 16 bytes sit at output positions p = 1 + 4 k0 + i, weight L - p = (L - (4 k0 + 16)) + (15 - i); bytes
+    // past the end of the row are zero.  (Unsigned arithmetic: the first factor of a row's last, partial group may
+    // "be negative" — the sum is right modulo 2^32 / 2^64 and the true value fits.)
+    uint32_t sum, ramp;
+    adler_terms16(v, sum, ramp);
+    s1 += sum;
+    s2 += (L - (T)(4 * k0 + 16)) * sum + ramp;
     if (staged) {
         *reinterpret_cast<uint4 *>(stage + 16 + 4 * k0) = make_uint4(v[0], v[1], v[2], v[3]); // (zero beyond the row)
     } else {
@@ -158,19 +169,18 @@ __device__ __forceinline__ void emit_group(const Group &g, int k0, int n, T L, b
 // The staged row (filter byte at LDS offset 15, row byte i at 16 + i) -> global memory as 16-byte chunks
 // aligned in GLOBAL memory: each chunk is five aligned LDS dwords shifted by a row-uniform byte count; the
 // few bytes before the first / after the last aligned chunk are stored singly.
-template <int NT> __device__ __forceinline__ void flush_stage(const uint8_t *stage, uint8_t *orow, int n)
+template <int NT> __device__ __forceinline__ void flush_stage_body(const uint8_t *stage, uint8_t *orow, int n, int tid)
 {
-    __syncthreads();
     // stream byte p of this row (0 = filter byte) sits at LDS offset 15 + p
     const int total = n + 1;
     const int head = (int)((16 - (reinterpret_cast<uintptr_t>(orow) & 15)) & 15); // bytes before the first aligned chunk
     const int h = head < total ? head : total;
     const int chunks = (total - h) / 16, tail = total - h - 16 * chunks;
-    if ((int)threadIdx.x < h) orow[threadIdx.x] = stage[15 + threadIdx.x];
-    if ((int)threadIdx.x < tail) orow[h + 16 * chunks + threadIdx.x] = stage[15 + h + 16 * chunks + threadIdx.x];
+    if (tid < h) orow[tid] = stage[15 + tid];
+    if (tid < tail) orow[h + 16 * chunks + tid] = stage[15 + h + 16 * chunks + tid];
     const int t = 15 + h, r = t & 3; // LDS offset of the first chunk; r is uniform
     const uint32_t *w = reinterpret_cast<const uint32_t *>(stage) + (t >> 2);
-    for (int c = threadIdx.x; c < chunks; c += NT) {
+    for (int c = tid; c < chunks; c += NT) {
         uint32_t d[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) d[i] = w[4 * c + i];
@@ -179,6 +189,11 @@ template <int NT> __device__ __forceinline__ void flush_stage(const uint8_t *sta
         o.z = __builtin_amdgcn_alignbyte(d[3], d[2], r); o.w = __builtin_amdgcn_alignbyte(d[4], d[3], r);
         *reinterpret_cast<uint4 *>(orow + h + 16 * c) = o;
     }
+}
+template <int NT> __device__ __forceinline__ void flush_stage(const uint8_t *stage, uint8_t *orow, int n, int tid)
+{
+    __syncthreads();
+    flush_stage_body<NT>(stage, orow, n, tid);
 }
 
 // Pass 2 for filter F.  The output row starts at byte y * (n + 1) of the stream — a different
@@ -202,7 +217,7 @@ __device__ __forceinline__ void write_row(const Args &a, uint32_t y, const uint8
         load_group<BPP, FAST, NEED>(row, prev, k0, n, g);
         emit_group<F, unsigned long long>(g, k0, n, L, staged, stage, orow, s1, s2);
     }
-    if (staged) flush_stage<kThreads>(stage, orow, n);
+    if (staged) flush_stage<kThreads>(stage, orow, n, (int)threadIdx.x);
 }
 
 // The register-resident form (rows of at most kRegIters x 4 KiB with 256 threads, x 8 KiB with 512; always
@@ -210,18 +225,18 @@ __device__ __forceinline__ void write_row(const Args &a, uint32_t y, const uint8
 // the whole row and the row above ONCE, all loads in flight together; scoring and the winning filter
 // both work from those registers.
 constexpr int kRegIters = 4;
-template <int BPP, int F, int NT>
-__device__ __forceinline__ void write_row_regs(const Args &a, uint32_t y, const Raw *raw, int n, unsigned long long *acc64)
+template <int BPP, int F, int NT, int ITERS>
+__device__ __forceinline__ void stage_row_regs(const Args &a, uint32_t y, const Raw *raw, int n, unsigned long long *acc64, int tid)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
     const int ndw = (n + 3) / 4, per_iter = NT * 4; // (256 or 512 threads)
     uint8_t *orow = a.out + (size_t)y * (a.row_bytes + 1);
     const uint32_t L = (uint32_t)n + 1;
     uint32_t s1 = 0, s2 = 0; // this thread's 64 bytes: s2 < 16 x 16385 x 1020 < 2^32
-    if (threadIdx.x == 0) { stage[15] = (uint8_t)F; s1 = (unsigned)F; s2 = L * (unsigned)F; }
+    if (tid == 0) { stage[15] = (uint8_t)F; s1 = (unsigned)F; s2 = L * (unsigned)F; }
 #pragma unroll
-    for (int it = 0; it < kRegIters; it++) {
-        const int k0 = (int)threadIdx.x * 4 + it * per_iter;
+    for (int it = 0; it < ITERS; it++) {
+        const int k0 = tid * 4 + it * per_iter;
         if (k0 < ndw) {
             Group g;
             if (4 * (k0 + 4) <= n) group_of<BPP, false>(raw[it], k0, n, g);
@@ -232,11 +247,17 @@ __device__ __forceinline__ void write_row_regs(const Args &a, uint32_t y, const 
     // row totals: 32-bit butterflies inside the wavefront (s2 in two 16-bit halves so that the wave totals
     // fit), one LDS atomic per wavefront; flush_stage's barrier orders them for the reader
     const uint32_t w1 = wave_sum_u32(s1), lo = wave_sum_u32(s2 & 0xFFFFu), hi = wave_sum_u32(s2 >> 16);
-    if ((threadIdx.x & 63) == 0) {
+    if ((tid & 63) == 0) {
         atomicAdd(&acc64[0], (unsigned long long)w1);
         atomicAdd(&acc64[1], ((unsigned long long)hi << 16) + lo);
     }
-    flush_stage<NT>(stage, orow, n);
+}
+template <int BPP, int F, int NT, int ITERS>
+__device__ __forceinline__ void write_row_regs(const Args &a, uint32_t y, const Raw *raw, int n, unsigned long long *acc64, int tid)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+    stage_row_regs<BPP, F, NT, ITERS>(a, y, raw, n, acc64, tid);
+    flush_stage<NT>(stage, a.out + (size_t)y * (a.row_bytes + 1), n, tid);
 }
 
 // Bigrams (filter.rs:406-472, score_bigrams :635-649): the score of a candidate is the number of DISTINCT
@@ -285,8 +306,12 @@ __device__ __forceinline__ unsigned long long bigram_score(const uint8_t *row, c
 // K_BIGRAMS (~110).
 // K_REGS512: the same with 512 threads, rows of up to 32 KiB.
 enum { K_GENERAL = 0, K_REGS = 1, K_BIGRAMS = 2, K_REGS512 = 3 };
-template <int BPP, bool FAST, int KIND>
-__global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) void png_filter_kernel(const Args a)
+#ifndef PIXO_PNG_WAVES // (experiments: tools/ab_build.sh)
+#define PIXO_PNG_WAVES 1
+#endif
+template <int BPP, bool FAST, int KIND, int ITERS = kRegIters>
+__global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) __attribute__((amdgpu_waves_per_eu(KIND == K_REGS ? PIXO_PNG_WAVES : 1)))
+void png_filter_kernel(const Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
     __shared__ unsigned long long red[20];
@@ -323,9 +348,9 @@ __global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) void p
         // the whole row (and the row above) in registers: one round of loads, all in flight together
         if (threadIdx.x < 8) acc32[threadIdx.x] = 0;
         if (threadIdx.x < 2) acc64[threadIdx.x] = 0;
-        Raw raw[kRegIters];
+        Raw raw[ITERS];
 #pragma unroll
-        for (int it = 0; it < kRegIters; it++) {
+        for (int it = 0; it < ITERS; it++) {
             const int k0 = (int)threadIdx.x * 4 + it * per_iter;
             if (it * per_iter < ndw) load_raw<BPP, FAST>(row, prev, k0, n, raw[it]); // (uniform; k0 >= ndw loads zeros)
             else {
@@ -337,7 +362,7 @@ __global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) void p
         uint32_t sc[5] = {0, 0, 0, 0, 0};
         const bool fast = strategy == PNG_S_ADAPTIVE_FAST;
 #pragma unroll
-        for (int it = 0; it < kRegIters; it++) {
+        for (int it = 0; it < ITERS; it++) {
             const int k0 = (int)threadIdx.x * 4 + it * per_iter;
             if (k0 >= ndw) continue;
             if (4 * (k0 + 4) <= n) score_group<BPP, false>(raw[it], k0, n, fast, sc);
@@ -351,17 +376,17 @@ __global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) void p
             if ((threadIdx.x & 63) == 0) atomicAdd(&acc32[i], t);
         }
         __syncthreads();
-        unsigned long long tot[5];
+        uint32_t tot[5]; // (uniform, < 2^32: the decision runs on the scalar unit)
 #pragma unroll
-        for (int i = 0; i < 5; i++) tot[i] = acc32[i];
-        f = decide(strategy, tot, (unsigned long long)n);
+        for (int i = 0; i < 5; i++) tot[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)acc32[i]);
+        f = decide<uint32_t>(strategy, tot, (uint32_t)n);
         if (a.winner0 && y == 0 && threadIdx.x == 0) *a.winner0 = f;
         switch (f) {
-        case F_NONE: write_row_regs<BPP, F_NONE, NT>(a, y, raw, n, acc64); break;
-        case F_SUB: write_row_regs<BPP, F_SUB, NT>(a, y, raw, n, acc64); break;
-        case F_UP: write_row_regs<BPP, F_UP, NT>(a, y, raw, n, acc64); break;
-        case F_AVG: write_row_regs<BPP, F_AVG, NT>(a, y, raw, n, acc64); break;
-        default: write_row_regs<BPP, F_PAETH, NT>(a, y, raw, n, acc64); break;
+        case F_NONE: write_row_regs<BPP, F_NONE, NT, ITERS>(a, y, raw, n, acc64, (int)threadIdx.x); break;
+        case F_SUB: write_row_regs<BPP, F_SUB, NT, ITERS>(a, y, raw, n, acc64, (int)threadIdx.x); break;
+        case F_UP: write_row_regs<BPP, F_UP, NT, ITERS>(a, y, raw, n, acc64, (int)threadIdx.x); break;
+        case F_AVG: write_row_regs<BPP, F_AVG, NT, ITERS>(a, y, raw, n, acc64, (int)threadIdx.x); break;
+        default: write_row_regs<BPP, F_PAETH, NT, ITERS>(a, y, raw, n, acc64, (int)threadIdx.x); break;
         }
         if (threadIdx.x == 0) { a.row_sums[2 * (size_t)y] = acc64[0]; a.row_sums[2 * (size_t)y + 1] = acc64[1]; }
         return;
@@ -378,7 +403,7 @@ __global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) void p
         unsigned long long tot[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) tot[i] = wg_sum(sc[i], red);
-        f = decide(strategy, tot, (unsigned long long)n);
+        f = decide<unsigned long long>(strategy, tot, (unsigned long long)n);
     }
     if (a.winner0 && y == 0 && threadIdx.x == 0) *a.winner0 = f;
 
@@ -408,6 +433,12 @@ template <int BPP> hipError_t launch_bpp(const Args &a, uint32_t rows, bool fast
         else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_BIGRAMS>), dim3(rows), dim3(kThreads), lds, s, a);
     } else if (a.strategy > PNG_S_PAETH && !a.forced && ndw <= (uint64_t)kRegIters * 2 * kThreads * 4 && a.stage_bytes != 0) {
         // rows of up to 16 KiB: 256 threads hold them; up to 32 KiB: 512 threads
+#ifdef PIXO_PNG_T512I2 // (experiment: rows of up to 16 KiB on 512 threads x 2 groups)
+        if (ndw <= 2ull * 2 * kThreads * 4) {
+            if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, K_REGS512, 2>), dim3(rows), dim3(2 * kThreads), a.stage_bytes, s, a);
+            else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_REGS512, 2>), dim3(rows), dim3(2 * kThreads), a.stage_bytes, s, a);
+        } else
+#endif
         if (ndw <= (uint64_t)kRegIters * kThreads * 4) {
             if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, K_REGS>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
             else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_REGS>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);

@@ -29,6 +29,18 @@ static inline uint32_t pixo_udot4(uint32_t a, uint32_t b)
 #define pixo_alignbyte(hi, lo, sh) __builtin_amdgcn_alignbyte((hi), (lo), (sh))
 #define pixo_udot4(a, b) __builtin_amdgcn_udot4((a), (b), 0u, false)
 #endif
+#if defined(PIXO_EMU)
+#define pixo_udot4_acc(a, b, acc) (pixo_udot4((a), (b)) + (acc))
+static inline uint32_t pixo_mad_u24(uint32_t a, uint32_t b, uint32_t c) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu) + c; }
+#else
+#define pixo_udot4_acc(a, b, acc) __builtin_amdgcn_udot4((a), (b), (acc), false)
+__device__ __forceinline__ uint32_t pixo_mad_u24(uint32_t a, uint32_t b, uint32_t c)
+{ // (spelled out: the compiler splits the product and the sum and re-associates the sum with its neighbours)
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#endif
 
 namespace pixo_png {
 
@@ -62,24 +74,25 @@ PIXO_PDEV uint32_t gt_mask(s16x2 x, s16x2 y)
 //     lo < c < hi: p = lo + hi - c lies between them at distances (hi - c) from lo, (c - lo) from hi and |(hi - c) - (c - lo)|
 //     from c:  lo if 2 (hi - c) <= c - lo,  hi if 2 (c - lo) <= hi - c,  else c   (ties go to a, b before c: "<=")
 // and the outer cases satisfy the same two inequalities, so for ALL c, with x = 3 c - (a + b):
-//     predictor = lo if x - hi >= 0,  else hi if lo - x >= 0,  else c.
-// 11 packed operations per two bytes (min, max, add, multiply, subtract; two differences; two sign smears; two bit selects)
-// where the distances needed 17 (three subtractions, three negations, three maxima, a minimum, two compares of two
-// operations each, two selects) — the kernel is VALU bound and Paeth was 60 % of it.
+//     predictor = lo if x >= hi,  else hi if x <= lo,  else c.
+// The distances needed 17 packed 16-bit operations per two bytes (half rate on this chip: 34 issue slots).  Here: ONE
+// packed minimum and two packed arithmetic shifts (6 slots); everything else is plain 32-bit arithmetic on the two lanes
+// at once (full rate, 10 slots), which is exact because no lane ever borrows from its neighbour — a + b <= 510 and
+// 3 c <= 765 fit a lane, and x is carried with a bias of 0x8000 per lane, so that the lane's bit 15 IS the sign of the
+// difference under test.  The kernel is VALU bound and Paeth was 60 % of it.
 typedef unsigned short pu16x2 __attribute__((ext_vector_type(2)));
 PIXO_PDEV pu16x2 as_us(uint32_t v) { return __builtin_bit_cast(pu16x2, v); }
 PIXO_PDEV uint32_t paeth2(uint32_t a, uint32_t b, uint32_t c)
 {
-    const pu16x2 ua = as_us(a), ub = as_us(b), uc = as_us(c);
-    const pu16x2 lo = __builtin_elementwise_min(ua, ub), hi = __builtin_elementwise_max(ua, ub);
-    const pu16x2 three = {3, 3};
-    const s16x2 x = __builtin_bit_cast(s16x2, (pu16x2)(uc * three - (ua + ub))); // in [-510, 765]
-    uint32_t not_lo = as_u((x - __builtin_bit_cast(s16x2, hi)) >> 15); // ones where x - hi < 0
-    uint32_t not_hi = as_u((__builtin_bit_cast(s16x2, lo) - x) >> 15); // ones where lo - x < 0
+    const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(as_us(a), as_us(b)));
+    const uint32_t s = a + b, hi = s - lo;
+    const uint32_t xk = pixo_mad_u24(c, 3u, 0x80008000u - s); // lanes: 0x8000 + x, x in [-510, 765]  (0x8000 - s > 0: no borrow)
+    uint32_t is_lo = as_u(as_s(xk - hi) >> 15);                // ones where x - hi >= 0 (lanes 0x8000 +- 1020: no borrow)
+    uint32_t not_hi = as_u(as_s(xk - lo - 0x00010001u) >> 15); // ones where x - lo - 1 >= 0, i.e. NOT x <= lo
     // (opaque: otherwise the masks are turned back into 16-bit compares + SDWA selects + a permute)
-    PIXO_POPAQUE(not_lo); PIXO_POPAQUE(not_hi);
-    const uint32_t hc = (c & not_hi) | (__builtin_bit_cast(uint32_t, hi) & ~not_hi);
-    return (hc & not_lo) | (__builtin_bit_cast(uint32_t, lo) & ~not_lo);
+    PIXO_POPAQUE(is_lo); PIXO_POPAQUE(not_hi);
+    const uint32_t hc = (c & not_hi) | (hi & ~not_hi);
+    return (lo & is_lo) | (hc & ~is_lo);
 }
 PIXO_PDEV uint32_t paeth4(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -152,13 +165,13 @@ PIXO_PDEV void score_group(const Raw &r, int k0, int n, bool fast, uint32_t sc[5
 }
 
 // the reference's decision sequences, replayed on the five row scores
-PIXO_PDEV int decide(int strategy, const unsigned long long s[5], unsigned long long n)
+template <class T> PIXO_PDEV int decide(int strategy, const T s[5], T n)
 {
     if (strategy <= S_PAETH) return strategy; // None, Sub, Up, Average, Paeth
     if (strategy == S_ADAPTIVE_FAST) { // filter.rs:474-527
-        const unsigned long long early = n / 8 + 1;
+        const T early = n / 8 + 1;
         int best = F_SUB;
-        unsigned long long bs = s[F_SUB];
+        T bs = s[F_SUB];
         if (bs <= early) return best;
         if (s[F_UP] < bs) { bs = s[F_UP]; best = F_UP; }
         if (bs <= early) return best;
@@ -167,9 +180,9 @@ PIXO_PDEV int decide(int strategy, const unsigned long long s[5], unsigned long 
     }
     // Adaptive / MinSum, filter.rs:302-404: None, Sub, Up, Average, Paeth in this order, a later
     // filter wins only with a strictly smaller score, stop as soon as the best is <= early (or 0)
-    const unsigned long long early = n / 4 + 1;
+    const T early = n / 4 + 1;
     int best = F_NONE;
-    unsigned long long bs = s[F_NONE];
+    T bs = s[F_NONE];
     if (bs <= early || bs == 0) return best;
 #pragma unroll
     for (int f = F_SUB; f <= F_AVG; f++) {
@@ -186,6 +199,14 @@ PIXO_PDEV void adler_terms(uint32_t v, uint32_t &sum, uint32_t &ramp)
 {
     sum = pixo_sad_u8(v, 0u, 0u);
     ramp = pixo_udot4(v, 0x00010203u);
+}
+
+// The same for a whole group of four filtered dwords (16 stream bytes): their sum and 15 b0 + 14 b1 + ... + 0 b15 — the
+// caller adds (weight of the group's LAST byte) * sum + ramp: one multiplication per group instead of four.
+PIXO_PDEV void adler_terms16(const uint32_t v[4], uint32_t &sum, uint32_t &ramp)
+{
+    sum = pixo_sad_u8(v[3], 0u, pixo_sad_u8(v[2], 0u, pixo_sad_u8(v[1], 0u, pixo_sad_u8(v[0], 0u, 0u))));
+    ramp = pixo_udot4_acc(v[0], 0x0C0D0E0Fu, pixo_udot4_acc(v[1], 0x08090A0Bu, pixo_udot4_acc(v[2], 0x04050607u, pixo_udot4(v[3], 0x00010203u))));
 }
 
 // Bigrams (score_bigrams, filter.rs:635-649): the pairs (byte p, byte p + 1) that START in filtered dword v and end

@@ -152,7 +152,7 @@ def encode(data, options: JpegOptions) -> bytes:
     if rc:
         _raise(rc)
     try:
-        return C.string_at(out, n.value)
+        return _lib.file_bytes(L, out, n.value)
     finally:
         L.pixo_hip_free(out)
 
@@ -197,7 +197,7 @@ def encode_jpeg(data, width, height, color_type, quality, preset, subsampling_42
     if rc:
         _raise(rc)
     try:
-        return C.string_at(out, n.value)
+        return _lib.file_bytes(L, out, n.value)
     finally:
         L.pixo_hip_free(out)
 
@@ -285,7 +285,7 @@ def entropy_encode(y, cb, cr, options: JpegOptions) -> bytes:
     if rc:
         _raise(rc)
     try:
-        return C.string_at(out, n.value)
+        return _lib.file_bytes(L, out, n.value)
     finally:
         L.pixo_hip_free(out)
 
@@ -308,7 +308,7 @@ def entropy_encode_device(d_y, d_cb, d_cr, options: JpegOptions) -> bytes:
     if rc:
         _raise(rc)
     try:
-        return C.string_at(out, n.value)
+        return _lib.file_bytes(L, out, n.value)
     finally:
         L.pixo_hip_free(out)
 
@@ -322,7 +322,7 @@ def encode_device(d_pixels, options: JpegOptions) -> bytes:
     if rc:
         _raise(rc)
     try:
-        return C.string_at(out, n.value)
+        return _lib.file_bytes(L, out, n.value)
     finally:
         L.pixo_hip_free(out)
 
@@ -360,7 +360,7 @@ def encode_batch_device(d_pixels, options: JpegOptions, batch: int):
         _raise(rc)
     out = []
     for i in range(batch):
-        out.append(C.string_at(files[i], lens[i]))
+        out.append(_lib.file_bytes(L, files[i], lens[i]))
         L.pixo_hip_free(files[i])
     return out
 
@@ -411,7 +411,7 @@ COUNT_WORDS = 536  # PIXO_HIP_COUNT_WORDS: [class][12 DC categories + 256 AC run
 
 def _take(L, out, n):
     try:
-        return C.string_at(out, n.value)
+        return _lib.file_bytes(L, out, n.value)
     finally:
         L.pixo_hip_free(out)
 

@@ -587,15 +587,15 @@ template <int BPP> uint32_t emu_png_rows(const uint8_t *data, long n, long heigh
             for (int i = 0; i < 6; i++) { r.x[i] = host_dword(row, k0 - 2 + i, n); r.u[i] = host_dword(prev, k0 - 2 + i, n); }
             Group g;
             group_of<BPP, true>(r, (int)k0, (int)n, g);
+            uint32_t v[4], sum, ramp;
             for (int j = 0; j < 4; j++) {
-                const uint32_t v = filtered(f, g, j) & g.valid[j];
-                uint32_t sum, ramp;
-                adler_terms(v, sum, ramp);
-                s1 += sum;
-                s2 += (L - (uint64_t)(4 * (k0 + j) + 4)) * sum + ramp;
+                v[j] = filtered(f, g, j) & g.valid[j];
                 for (int b = 0; b < 4; b++)
-                    if (4 * (k0 + j) + b < n) o[1 + 4 * (k0 + j) + b] = (uint8_t)(v >> (8 * b));
+                    if (4 * (k0 + j) + b < n) o[1 + 4 * (k0 + j) + b] = (uint8_t)(v[j] >> (8 * b));
             }
+            adler_terms16(v, sum, ramp); // (the kernel's emit_group: one multiplication per group, modular for the last one)
+            s1 += sum;
+            s2 += (L - (uint64_t)(4 * k0 + 16)) * sum + ramp;
         }
         // combine_adler (png_api.cpp): s2 += row_len * s1_before + B, s1 += A
         a2 = (a2 + (L % M) * a1 + s2 % M) % M;

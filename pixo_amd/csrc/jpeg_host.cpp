@@ -76,14 +76,14 @@ void fill_device_qt(uint8_t quality, float out[kDeviceQtFloats])
 {
     const QuantTables t = make_quant_tables(quality);
     for (int i = 0; i < 64; ++i) {
-        out[i] = bracket_lo(t.lum[i]);
-        out[64 + i] = bracket_hi(t.lum[i]);
+        out[2 * i] = bracket_lo(t.lum[i]); // (rlo, rhi) side by side: one operand pair of the kernel's packed multiply-add
+        out[2 * i + 1] = bracket_hi(t.lum[i]);
         out[128 + i] = t.lum[i];
         out[192 + i] = t.chr[i];
-        out[256 + i] = bracket_lo(t.chr[i]);
-        out[320 + i] = bracket_hi(t.chr[i]);
-        out[384 + i] = out[256 + i] * 0.25f; // exact: 4:2:0 chroma is transformed at 4x scale
-        out[448 + i] = out[320 + i] * 0.25f;
+        out[256 + 2 * i] = bracket_lo(t.chr[i]);
+        out[256 + 2 * i + 1] = bracket_hi(t.chr[i]);
+        out[384 + 2 * i] = out[256 + 2 * i] * 0.25f; // exact: 4:2:0 chroma is transformed at 4x scale
+        out[384 + 2 * i + 1] = out[256 + 2 * i + 1] * 0.25f;
     }
 }
 

@@ -199,6 +199,10 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
 {
     typedef Geo<MODE> G;
     __shared__ __attribute__((aligned(16))) uint8_t lds[G::planar];
+#if defined(PIXO_LDS_PAD) // (experiment: fewer workgroups per CU, so that a 4096x4096 launch runs in generations)
+    __shared__ uint8_t lds_pad[PIXO_LDS_PAD];
+    if (a_W == 0xFFFFFFFFu) lds_pad[threadIdx.x] = 1;
+#endif
     KArgs a;
     a.px = a_px; a.W = a_W; a.H = a_H; a.px_stride = a_px_stride; a.y = a_y; a.cb = a_cb; a.cr = a_cr; a.qt = a_qt;
     a.px_bytes = rest.px_bytes; a.y_stride = rest.y_stride; a.c_stride = rest.c_stride; a.ry = rest.ry; a.rcb = rest.rcb; a.rcr = rest.rcr;
@@ -214,6 +218,17 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     // steady clocks, profiles/r01_ablation_steady_clocks.txt).
     __builtin_amdgcn_s_setprio(1);
     PIXO_STAMP(0); // the wavefront runs
+#if !defined(PIXO_NO_STAGGER)
+    // The chip holds 2048 of these workgroups at once (8 per CU): a 4096x4096 launch is ONE generation whose loads all
+    // come first and whose stores all come last.  The second half of that generation (dispatch order 1024..2047) starts
+    // one s_sleep (8128 clocks, ~3.4 us) late, so that its loads meet the first half's arithmetic and stores: 19.1 ->
+    // 18.35 us on one box of the pool, nothing gained or lost (17.4) on a faster one, two sleeps or other halves worse
+    // (profiles/r03_stagger_and_occupancy_ab.txt).  Later generations are not touched.
+    if (MODE == M420) {
+        const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if ((lin >> 10) == 1u && gridDim.x * gridDim.y * gridDim.z >= 2048u) __builtin_amdgcn_s_sleep(127); // (a full first generation only)
+    }
+#endif
     const TileId id{blockIdx.z, blockIdx.x, blockIdx.y}; // (a 3-D grid: no division on the way to the first load)
     TileCtx c = ctx_in(a, id.img);
 #if defined(PIXO_PROBE)

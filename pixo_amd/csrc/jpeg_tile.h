@@ -87,10 +87,10 @@ constexpr int kPitchHalf = 272; // planar row pitch, 256-px half planes (4:2:0 l
 
 // Quantiser table block for one quality, resident in HBM, read with scalar loads (rlo / rhi: the
 // bracketing reciprocals of quant_row8, correctly directed roundings made by the host):
-//   [0,64)    rlo luminance     [64,128)   rhi luminance
+//   [0,128)   (rlo, rhi) luminance, coefficient i at 2 i, 2 i + 1 — the pair is ONE operand of the packed multiply-add
 //   [128,192) q   luminance     [192,256)  q   chrominance   (f32, exact integers 1..255)
-//   [256,320) rlo chrominance   [320,384)  rhi chrominance
-//   [384,448) rlo chrominance/4 [448,512)  rhi chrominance/4 — for 4:2:0 chroma, whose DCT runs on
+//   [256,384) (rlo, rhi) chrominance
+//   [384,512) (rlo, rhi) chrominance/4 — for 4:2:0 chroma, whose DCT runs on
 //             the 2x2 SUMS (4x the sample; a power-of-two scale commutes with every f32 rounding)
 constexpr int kQtFloats = 512;
 
@@ -733,52 +733,83 @@ PIXO_DEV uint32_t quant_bracket(float x, float rlo, float rhi, float *s)
     return fbits(lo) ^ fbits(hi);
 }
 
-#if defined(PIXO_QUANT_PK) && !defined(PIXO_EMU)
+// The same with the pair (rlo, rhi) as it lies in the table (round 3): on the device ONE packed multiply-add
+// (v_pk_fma_f32: x broadcast to both halves, the pair straight from two scalar registers, the rounding constant from a
+// register pair) where two v_fma_f32 with a scalar operand each took an issue slot pair of their own, and the
+// difference folded into the row's flag by one three-input bit operation instead of a compare per element —
+// 3 issue slots per coefficient instead of 6, of a kernel whose time IS its vector instruction issue.
+struct QPair { float lo, hi; };
+#if defined(PIXO_EMU)
+PIXO_DEV uint32_t quant_bracket_pair(float x, QPair r, float *s) { return quant_bracket(x, r.lo, r.hi, s); }
+#else
 typedef float pixo_f2 __attribute__((ext_vector_type(2)));
+PIXO_DEV uint32_t quant_bracket_pair(float x, QPair r, float *s)
+{
+    const pixo_f2 p = __builtin_elementwise_fma((pixo_f2){x, x}, (pixo_f2){r.lo, r.hi}, (pixo_f2){kRoundMagic, kRoundMagic});
+    *s = p.x;
+    return fbits(p.x) ^ fbits(p.y);
+}
 #endif
+
+// {hi[15:0], lo[15:0]}
+PIXO_DEV uint32_t pack_lo16(uint32_t hi, uint32_t lo)
+{
+    return perm(hi, lo, 0x05040100u);
+}
 // four coefficients -> two registers of packed i16 pairs
-PIXO_DEV void quant_row4(const float *x, const float *rlo, const float *rhi, qtab_t q, float scale, uint32_t out[2])
+PIXO_DEV void quant_row4(const float *x, const QPair *r, qtab_t q, float scale, uint32_t out[2])
 {
     float s[4];
-#if defined(PIXO_QUANT_PK) && !defined(PIXO_EMU)
-    // two elements per v_pk_fma_f32, one 64-bit compare per pair
-    bool any = false;
+    uint32_t differ = 0;
+#if defined(PIXO_EMU)
+#pragma unroll
+    for (int c = 0; c < 4; c++) differ |= quant_bracket_pair(x[c], r[c], &s[c]);
+#else
+    // Two neighbouring coefficients share one aligned register pair and each multiply-add broadcasts its own half
+    // (op_sel).  The pair is pinned as a pair: left to itself the compiler makes every x the LOW half of a pair of its
+    // own — 64 live floats then want 128 registers and the kernel spills 136.
+    pixo_f2 xx[2];
 #pragma unroll
     for (int c = 0; c < 4; c += 2) {
-        const pixo_f2 xx = {x[c], x[c + 1]}, m = {kRoundMagic, kRoundMagic};
-        const pixo_f2 lo = __builtin_elementwise_fma(xx, (pixo_f2){rlo[c], rlo[c + 1]}, m);
-        const pixo_f2 hi = __builtin_elementwise_fma(xx, (pixo_f2){rhi[c], rhi[c + 1]}, m);
-        s[c] = lo.x; s[c + 1] = lo.y;
-        any |= __builtin_bit_cast(uint64_t, lo) != __builtin_bit_cast(uint64_t, hi);
+        xx[c / 2] = (pixo_f2){x[c], x[c + 1]};
+        asm volatile("" : "+v"(xx[c / 2]));
+        const pixo_f2 m = {kRoundMagic, kRoundMagic};
+        const pixo_f2 p0 = __builtin_elementwise_fma(__builtin_shufflevector(xx[c / 2], xx[c / 2], 0, 0), (pixo_f2){r[c].lo, r[c].hi}, m);
+        const pixo_f2 p1 = __builtin_elementwise_fma(__builtin_shufflevector(xx[c / 2], xx[c / 2], 1, 1), (pixo_f2){r[c + 1].lo, r[c + 1].hi}, m);
+        s[c] = p0.x; s[c + 1] = p1.x;
+        differ |= (fbits(p0.x) ^ fbits(p0.y)) | (fbits(p1.x) ^ fbits(p1.y));
     }
-    const bool flagged = PIXO_ANY_LANE(any);
-#else
-    uint32_t differ = 0;
-#pragma unroll
-    for (int c = 0; c < 4; c++) differ |= quant_bracket(x[c], rlo[c], rhi[c], &s[c]);
-    const bool flagged = PIXO_ANY_LANE(differ != 0);
+    PIXO_PIN(differ); // (as bit operations — one per coefficient; otherwise it becomes a compare per coefficient again)
 #endif
+    // low 16 bits of each s = the i16 result (never saturates: |x/q| <= 2^11)
+    out[0] = pack_lo16(fbits(s[1]), fbits(s[0]));
+    out[1] = pack_lo16(fbits(s[3]), fbits(s[2]));
+    const bool flagged = PIXO_ANY_LANE(differ != 0);
     if (flagged) { // rare: some quotient next to a rounding boundary
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            float xc = x[c], t;
+#if defined(PIXO_EMU)
+            const float x0 = x[c];
+#else
+            const float x0 = (c & 1) ? xx[c / 2].y : xx[c / 2].x;
+#endif
+            float xc = x0, t;
             PIXO_PIN(xc); // recompute the test here: reusing the fast path's values keeps them all alive
-            if (PIXO_ANY_LANE(quant_bracket(xc, rlo[c], rhi[c], &t) != 0)) {
-                const float n = __builtin_roundf((x[c] * scale) / q[c]); // the reference operation itself
-                s[c] = n + kRoundMagic;                                   // exact: |n| < 2^15
+            if (PIXO_ANY_LANE(quant_bracket_pair(xc, r[c], &t) != 0)) {
+                const float n = __builtin_roundf((x0 * scale) / q[c]); // the reference operation itself
+                s[c] = n + kRoundMagic;                                  // exact: |n| < 2^15
             }
             PIXO_SCHED_FENCE(); // one element at a time: few temporaries
         }
+        out[0] = pack_lo16(fbits(s[1]), fbits(s[0]));
+        out[1] = pack_lo16(fbits(s[3]), fbits(s[2]));
     }
-    // low 16 bits of each s = the i16 result (never saturates: |x/q| <= 2^11)
-    out[0] = perm(fbits(s[1]), fbits(s[0]), 0x05040100u);
-    out[1] = perm(fbits(s[3]), fbits(s[2]), 0x05040100u);
 }
-PIXO_DEV void quant_row8(const float *x, const float *rlo, const float *rhi, qtab_t q, float scale, uint32_t out[4])
+PIXO_DEV void quant_row8(const float *x, const QPair *r, qtab_t q, float scale, uint32_t out[4])
 {
-    quant_row4(x, rlo, rhi, q, scale, out);
+    quant_row4(x, r, q, scale, out);
     PIXO_PIN(out[0]); PIXO_PIN(out[1]);
-    quant_row4(x + 4, rlo + 4, rhi + 4, q + 4, scale, out + 2);
+    quant_row4(x + 4, r + 4, q + 4, scale, out + 2);
 }
 
 // Block kinds (wave-uniform): quantiser table, DC shift of the row pass, scale.
@@ -833,7 +864,7 @@ PIXO_DEV void block_cols(float *v)
 struct BlockDesc {
     const uint8_t *src;
     int pitch;
-    int rcp_off, q_off; // offsets into the quantiser table block (rlo at rcp_off, rhi 64 floats behind)
+    int rcp_off, q_off; // offsets into the quantiser table block ((rlo, rhi) pairs from rcp_off)
     float dc_shift, scale;
     bool u16;
 };
@@ -888,23 +919,23 @@ PIXO_DEV int stage_addr_block(int bl, int r) { return bl * 128 + (((r ^ bl) & 7)
 // their latency hides under the previous row's arithmetic.
 PIXO_DEV void block_quant(const float *v, qtab_t rcp, qtab_t q, float scale, uint32_t *out)
 {
-    float lo[8], hi[8], lo_n[8], hi_n[8];
+    QPair r[8], r_n[8]; // (rlo, rhi) of coefficient i at rcp[2 i], rcp[2 i + 1]: one aligned scalar register pair each
 #pragma unroll
-    for (int c = 0; c < 8; c++) { lo[c] = rcp[c]; hi[c] = rcp[64 + c]; }
+    for (int c = 0; c < 8; c++) { r[c].lo = rcp[2 * c]; r[c].hi = rcp[2 * c + 1]; }
     PIXO_SCHED_FENCE();
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         if (u < 7) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) { lo_n[c] = rcp[(u + 1) * 8 + c]; hi_n[c] = rcp[64 + (u + 1) * 8 + c]; }
+            for (int c = 0; c < 8; c++) { r_n[c].lo = rcp[2 * ((u + 1) * 8 + c)]; r_n[c].hi = rcp[2 * ((u + 1) * 8 + c) + 1]; }
             PIXO_SCHED_FENCE();
         }
-        quant_row8(&v[u * 8], lo, hi, q + u * 8, scale, &out[u * 4]);
+        quant_row8(&v[u * 8], r, q + u * 8, scale, &out[u * 4]);
         // the row's four result registers exist from here on (and its eight floats are dead)
         PIXO_PIN(out[u * 4]); PIXO_PIN(out[u * 4 + 1]); PIXO_PIN(out[u * 4 + 2]); PIXO_PIN(out[u * 4 + 3]);
         PIXO_SCHED_FENCE();
 #pragma unroll
-        for (int c = 0; c < 8; c++) { lo[c] = lo_n[c]; hi[c] = hi_n[c]; }
+        for (int c = 0; c < 8; c++) r[c] = r_n[c];
     }
 }
 template <int MODE> PIXO_DEV void consumer_quant(int wave, int lane, const float *qt, const float *v, uint32_t *out)

@@ -156,8 +156,8 @@ PIXO_TDEV void quantize_block(const float *dct, const float *q, int16_t *out, ui
 //     the values), the eight smallest survive;
 //   * a back-pointer is 6 bits (candidate kind, parent): 48 bits per coefficient; values are recomputed
 //     from the kind while walking back.
-// Env: coef(zz), step(zz) (zig-zag position -> f32), bits(rs) (the code-length estimate table of
-// ac_rate), trail_put(pos, u64), trail_get(pos), out(zz, i16).
+// Env: coef(zz), step(zz) (zig-zag position -> f32), rate_at(4 rs) (ac_rate as a table of rate_value(rs), by byte offset),
+// trail_put(pos, u64), trail_get(pos), out(zz, i16).
 PIXO_TDEV float rate_bits(int rs)
 { // trellis.rs:246-279 without the value bits; rs = (run << 4) | size, 0..255
     switch (rs) {
@@ -167,9 +167,13 @@ PIXO_TDEV float rate_bits(int rs)
     default: return 3.0f + (float)(rs >> 4) * 0.5f + (float)(rs & 0x0F) * 0.3f;
     }
 }
+PIXO_TDEV float rate_value(int rs) { return rate_bits(rs) + (float)(rs & 0x0F); } // ac_rate: estimate + value bits (size)
 PIXO_TDEV uint32_t f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 PIXO_TDEV float u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
-constexpr uint32_t kNoState = 0xFFFFFFFFu; // as a float: NaN — never smaller than anything, never chosen
+// "No state": as a float a NaN — never smaller than anything, never chosen — and, as the HIGH word of a 64-bit sort key read
+// as a double, a finite positive number above every cost (costs are non-negative f32: their bit patterns are at most
+// 0x7F800000), so that the sorting network can run on v_min_f64 / v_max_f64 (below).
+constexpr uint32_t kNoState = 0x7FEFFFFFu;
 
 struct Kinds { int v[5]; bool ok[5]; }; // [0] is the zero candidate
 PIXO_TDEV Kinds candidate_kinds(float fq)
@@ -185,15 +189,31 @@ PIXO_TDEV Kinds candidate_kinds(float fq)
     return k;
 }
 
+// One compare-exchange of the sorting network.  The keys (cost bits, slot, ...) are distinct, non-negative as 64-bit
+// integers and — with kNoState as above — finite or denormal positive doubles, which order exactly like the integers:
+// on the device a compare-exchange is v_min_f64 + v_max_f64 (two instructions of the double-precision pipe) where the
+// 64-bit integer compare and its four selects were about twice that; 39 of them per coefficient position were nearly
+// half of the kernel.  (Denormals: the kernel runs with f64 denormals preserved — the HSA default — and min / max return
+// an operand unchanged.)
+#if defined(__HIP_DEVICE_COMPILE__)
+PIXO_TDEV uint64_t min_key(uint64_t a, uint64_t b) { uint64_t r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#define PIXO_CE_LO(a, b) { e[a] = min_key(e[a], e[b]); } // (the larger one is not looked at again: checked for wires 8..11 below)
+#define PIXO_CE(a, b) { uint64_t lo_, hi_; asm("v_min_f64 %0, %1, %2" : "=v"(lo_) : "v"(e[a]), "v"(e[b])); \
+                        asm("v_max_f64 %0, %1, %2" : "=v"(hi_) : "v"(e[a]), "v"(e[b])); e[a] = lo_; e[b] = hi_; }
+#else
+PIXO_TDEV uint64_t min_key(uint64_t a, uint64_t b) { return a < b ? a : b; }
+#define PIXO_CE_LO(a, b) { e[a] = min_key(e[a], e[b]); }
 #define PIXO_CE(a, b) { const uint64_t lo_ = e[a] < e[b] ? e[a] : e[b], hi_ = e[a] < e[b] ? e[b] : e[a]; e[a] = lo_; e[b] = hi_; }
+#endif
 
 template <class Env> PIXO_TDEV void quantize_block_fast(Env &env)
 {
     env.out(0, to_i16(__builtin_roundf(env.coef(0) / env.step(0)))); // DC: plain rounding (trellis.rs:75)
     uint32_t cc[8]; // cost bits of the surviving states, cheapest first; kNoState beyond their number
-    int run[8];
+    uint32_t run6[8]; // the states' zero runs, as run << 6: the byte offset of the run's row in the rate table, and where
+                      // the run sits in a sort key's payload
 #pragma unroll
-    for (int i = 0; i < 8; i++) { cc[i] = kNoState; run[i] = 0; }
+    for (int i = 0; i < 8; i++) { cc[i] = kNoState; run6[i] = 0; }
     cc[0] = 0; // cost 0.0
     float coef_next = env.coef(1), step_next = env.step(1); // (fetched a step ahead: on the device a load from HBM)
     for (int zz = 1; zz < 64; zz++) {
@@ -205,65 +225,64 @@ template <class Env> PIXO_TDEV void quantize_block_fast(Env &env)
 #pragma unroll
         for (int j = 1; j < 5; j++) {
             const float rec = (float)k.v[j] * qq, d = coef - rec, dist = d * d;
-            const int cat = size_category(k.v[j]);
-            const float catf = (float)cat;
-            float best = 0.0f;
-            int parent = 0;
+            const uint32_t cat4 = (uint32_t)size_category(k.v[j]) << 2;
+            // the first strict minimum over the parents = the smallest (cost bits, parent) pair: costs are non-negative (their
+            // bit patterns order like their values) and a dead parent's NaN cost is a pattern above every number — one
+            // v_min_f64 per parent on the device instead of a compare and two selects
+            uint64_t bestk = 0;
 #pragma unroll
             for (int pi = 0; pi < 8; pi++) {
-                const float rate = env.bits((run[pi] << 4) | cat) + catf;
+                const float rate = env.rate_at(run6[pi] | cat4); // ac_rate(run, size) — byte offset 4 (run << 4 | size)
                 const float cost = u2f(cc[pi]) + rate + 1.0f * dist;
-                if (pi == 0 || cost < best) { best = cost; parent = pi; }
+                const uint64_t key = ((uint64_t)f2u(cost) << 32) | (uint32_t)pi;
+                bestk = pi == 0 ? key : min_key(bestk, key);
             }
-            const uint32_t lo = ((uint32_t)j << 28) | ((uint32_t)j << 8) | (uint32_t)parent; // slot, kind, run 0, parent
-            e[j] = ((uint64_t)(k.ok[j] ? f2u(best) : kNoState) << 32) | lo;
+            // payload (low word): slot << 28 | run << 6 | kind << 3 | parent — run 0, kind = slot = j
+            const uint32_t lo = (uint32_t)bestk | ((uint32_t)j << 28) | ((uint32_t)j << 3);
+            e[j] = ((uint64_t)(k.ok[j] ? (uint32_t)(bestk >> 32) : kNoState) << 32) | lo;
         }
-        // zero candidate -> slot 0 (parent 0) and slots 5..11 (parents 1..7)
+        // zero candidate -> slot 0 (parent 0) and slots 5..11 (parents 1..7).  Successors are keyed by their run; two
+        // parents give the same run only when both have run 0 (then the successor is (0, 1)): those fold into ONE entry at
+        // the first of them, with the first strict minimum of their costs.  The states are sorted by cost and every member
+        // of that group adds the same two terms (+ 0.0, + dist0; f32 addition is monotone), so the first strict minimum IS
+        // the first member: the entry is simply that parent's own, the later members vanish.
         const float dist0 = coef * coef; // (coef - 0 * step)^2
-        float zc[8];
-        bool alive[8], have = false;
-        float gbest = 0.0f;
-        int gparent = 0, first0 = 8;
-#pragma unroll
-        for (int pi = 0; pi < 8; pi++) {
-            alive[pi] = cc[pi] != kNoState;
-            const bool over = run[pi] + 1 >= 16; // a ZRL symbol will be needed (trellis.rs:117-120)
-            zc[pi] = u2f(cc[pi]) + (over ? 10.0f : 0.0f) + 1.0f * dist0;
-            const bool in_group = alive[pi] && run[pi] == 0; // successors keyed (0, 1): fold, first strict minimum
-            if (in_group && (!have || zc[pi] < gbest)) { gbest = zc[pi]; gparent = pi; }
-            if (in_group && !have) first0 = pi;
-            have = have || in_group;
-        }
+        bool seen0 = false;
 #pragma unroll
         for (int pi = 0; pi < 8; pi++) {
             const int slot = pi == 0 ? 0 : 4 + pi;
-            const bool grouped = run[pi] == 0;
-            const bool ok = alive[pi] && (!grouped || pi == first0);
-            const int nrun = run[pi] + 1 >= 16 ? 0 : run[pi] + 1;
-            const float cost = grouped ? gbest : zc[pi];
-            const int parent = grouped ? gparent : pi;
-            const uint32_t lo = ((uint32_t)slot << 28) | ((uint32_t)nrun << 4) | (uint32_t)parent; // kind 0
+            const bool alive = cc[pi] != kNoState, run0 = run6[pi] == 0;
+            const bool over = run6[pi] == (15u << 6); // a ZRL symbol will be needed (trellis.rs:117-120): run + 1 >= 16
+            const float cost = u2f(cc[pi]) + (over ? 10.0f : 0.0f) + 1.0f * dist0;
+            const bool ok = alive && !(run0 && seen0);
+            seen0 = seen0 || (alive && run0);
+            const uint32_t nrun6 = (run6[pi] + 64u) & (15u << 6); // run + 1, 16 -> 0
+            const uint32_t lo = ((uint32_t)slot << 28) | nrun6 | (uint32_t)pi; // kind 0
             e[slot] = ((uint64_t)(ok ? f2u(cost) : kNoState) << 32) | lo;
         }
         // stable sort by cost == sort by (cost bits, slot); 39 compare-exchanges (optimal for 12 inputs)
         PIXO_CE(0, 8) PIXO_CE(1, 7) PIXO_CE(2, 6) PIXO_CE(3, 11) PIXO_CE(4, 10) PIXO_CE(5, 9)
         PIXO_CE(0, 1) PIXO_CE(2, 5) PIXO_CE(3, 4) PIXO_CE(6, 9) PIXO_CE(7, 8) PIXO_CE(10, 11)
         PIXO_CE(0, 2) PIXO_CE(1, 6) PIXO_CE(5, 10) PIXO_CE(9, 11)
-        PIXO_CE(0, 3) PIXO_CE(1, 2) PIXO_CE(4, 6) PIXO_CE(5, 7) PIXO_CE(8, 11) PIXO_CE(9, 10)
+        PIXO_CE(0, 3) PIXO_CE(1, 2) PIXO_CE(4, 6) PIXO_CE(5, 7) PIXO_CE_LO(8, 11) PIXO_CE(9, 10)
         PIXO_CE(1, 4) PIXO_CE(3, 5) PIXO_CE(6, 8) PIXO_CE(7, 10)
-        PIXO_CE(1, 3) PIXO_CE(2, 5) PIXO_CE(6, 9) PIXO_CE(8, 10)
-        PIXO_CE(2, 3) PIXO_CE(4, 5) PIXO_CE(6, 7) PIXO_CE(8, 9)
+        PIXO_CE(1, 3) PIXO_CE(2, 5) PIXO_CE(6, 9) PIXO_CE_LO(8, 10)
+        PIXO_CE(2, 3) PIXO_CE(4, 5) PIXO_CE(6, 7) PIXO_CE_LO(8, 9)
         PIXO_CE(4, 6) PIXO_CE(5, 7)
-        PIXO_CE(3, 4) PIXO_CE(5, 6) PIXO_CE(7, 8)
-        uint64_t back = 0;
+        PIXO_CE(3, 4) PIXO_CE(5, 6) PIXO_CE_LO(7, 8)
+        // (only the eight smallest are looked at: four exchanges keep just their minimum — with the maximum replaced by
+        // "largest" all 4096 zero-one inputs still give the right first eight, tools/trellis_network_check.py)
+        uint32_t back_lo = 0, back_hi = 0; // 8 x 6 bits (kind, parent): survivor i at bit 6 i
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const uint32_t lo = (uint32_t)e[i];
+            const uint32_t lo = (uint32_t)e[i], f = lo & 63u;
             cc[i] = (uint32_t)(e[i] >> 32);
-            run[i] = (int)((lo >> 4) & 15u);
-            back |= (uint64_t)((((lo >> 8) & 7u) << 3) | (lo & 7u)) << (6 * i);
+            run6[i] = lo & (15u << 6);
+            if (6 * i + 6 <= 32) back_lo |= f << (6 * i);
+            else if (6 * i < 32) { back_lo |= f << (6 * i); back_hi |= f >> (32 - 6 * i); }
+            else back_hi |= f << (6 * i - 32);
         }
-        env.trail_put(zz - 1, back);
+        env.trail_put(zz - 1, ((uint64_t)back_hi << 32) | back_lo);
     }
     // trailing zeros: an EOB will be coded (trellis.rs:172-178); min_by: the first of equal minima
     int idx = 0;
@@ -271,7 +290,7 @@ template <class Env> PIXO_TDEV void quantize_block_fast(Env &env)
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         float c = u2f(cc[i]);
-        if (run[i] > 0) c += 4.0f;
+        if (run6[i] > 0) c += 4.0f;
         if (i == 0 || c < best) { best = c; idx = i; }
     }
     coef_next = env.coef(63); step_next = env.step(63);
@@ -289,5 +308,6 @@ template <class Env> PIXO_TDEV void quantize_block_fast(Env &env)
     }
 }
 #undef PIXO_CE
+#undef PIXO_CE_LO
 
 } // namespace pixo_trellis

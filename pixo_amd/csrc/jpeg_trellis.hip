@@ -30,12 +30,12 @@ __constant__ int c_zigzag_nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32,
 struct LaneEnv {
     const float *col;     // this lane's column of the wave's coefficients: natural index i at col[64 i]
     const float *steps;   // this lane's 64 quantiser steps in LDS (natural order)
-    const float *table;   // 256 code-length estimates in LDS
+    const float *table;   // ac_rate for the 256 (run, size) symbols in LDS
     uint64_t *trail;      // this lane's column of the wave's back-pointer scratch
     int16_t *mine;        // this lane's 64 result slots in LDS (natural order)
     __device__ __forceinline__ float coef(int zz) const { return col[c_zigzag_nat[zz] * 64]; }
     __device__ __forceinline__ float step(int zz) const { return steps[c_zigzag_nat[zz]]; }
-    __device__ __forceinline__ float bits(int rs) const { return table[rs]; }
+    __device__ __forceinline__ float rate_at(uint32_t byte_off) const { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(table) + byte_off); }
     __device__ __forceinline__ void trail_put(int pos, uint64_t w) { __builtin_nontemporal_store(w, trail + pos * 64); }
     __device__ __forceinline__ uint64_t trail_get(int pos) const { return __builtin_nontemporal_load(trail + pos * 64); }
     __device__ __forceinline__ void out(int zz, int16_t v) { mine[c_zigzag_nat[zz]] = v; }
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void trellis_kernel(const float *raw, const flo
     s_step[lane] = q_luma[lane];
     s_step[64 + lane] = q_chroma[lane];
 #pragma unroll
-    for (int i = 0; i < 4; i++) s_bits[i * 64 + lane] = pixo_trellis::rate_bits(i * 64 + lane);
+    for (int i = 0; i < 4; i++) s_bits[i * 64 + lane] = pixo_trellis::rate_value(i * 64 + lane);
     __syncthreads();
     // (a short last wave searches its last block again in the idle lanes)
     const int mine = lane < (int)have ? lane : (int)have - 1;

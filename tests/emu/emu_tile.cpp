@@ -111,12 +111,13 @@ extern "C" long emu_quant_mismatches(const float *x, long n, int qlo, int qhi)
         const float fq = (float)q;
         float lo, hi;
         bracket_of(q, &lo, &hi);
-        float rl[8], rh[8], qq[8], xx[8];
-        for (int i = 0; i < 8; i++) { rl[i] = lo; rh[i] = hi; qq[i] = fq; }
+        QPair rr[8];
+        float qq[8], xx[8];
+        for (int i = 0; i < 8; i++) { rr[i].lo = lo; rr[i].hi = hi; qq[i] = fq; }
         for (long i = 0; i + 8 <= n; i += 8) {
             uint32_t out[4];
             for (int k = 0; k < 8; k++) xx[k] = x[i + k];
-            quant_row8(xx, rl, rh, as_qtab(qq), 1.0f, out);
+            quant_row8(xx, rr, as_qtab(qq), 1.0f, out);
             for (int k = 0; k < 8; k++) {
                 int16_t got = (int16_t)(out[k >> 1] >> (16 * (k & 1)));
                 float want = roundf(xx[k] / fq);
@@ -426,7 +427,7 @@ struct HostTrellisEnv {
     float table[256];
     float coef(int zz) const { return dct[pixo_trellis::kZigzagNat[zz]]; }
     float step(int zz) const { return q[pixo_trellis::kZigzagNat[zz]]; }
-    float bits(int rs) const { return table[rs]; }
+    float rate_at(uint32_t byte_off) const { return table[byte_off / 4]; }
     void trail_put(int pos, uint64_t w) { trail[pos] = w; }
     uint64_t trail_get(int pos) const { return trail[pos]; }
     void out(int zz, int16_t v) { res[pixo_trellis::kZigzagNat[zz]] = v; }
@@ -435,7 +436,7 @@ struct HostTrellisEnv {
 extern "C" void emu_trellis_fast(const float *dct, const float *q, long nblocks, int16_t *out)
 {
     HostTrellisEnv env;
-    for (int rs = 0; rs < 256; rs++) env.table[rs] = pixo_trellis::rate_bits(rs);
+    for (int rs = 0; rs < 256; rs++) env.table[rs] = pixo_trellis::rate_value(rs);
     for (long b = 0; b < nblocks; b++) {
         env.dct = dct + b * 64; env.q = q; env.res = out + b * 64;
         pixo_trellis::quantize_block_fast(env);

@@ -29,7 +29,7 @@ constexpr bool kDot4 = true;
 // issued: 0.25 us for the first wavefront, 1.5 us for the median, 6 us for the last (profiles/r03_timeline_c2_before.txt).
 // Everything else (KRest) is not needed before the pixel loads are out and comes by s_load as before.
 struct KRest {
-    size_t px_bytes;  // all pixel bytes of the launch (L_FUNNEL never reads a dword beyond them)
+    size_t px_bytes;  // all pixel bytes of the launch (the emulation checks every load against them)
     size_t y_stride;  // i16 elements between consecutive images of a batch
     size_t c_stride;
     float *ry, *rcb, *rcr;   // RAW kernels only: unquantised DCT blocks (64 f32 each) instead of y/cb/cr
@@ -113,21 +113,14 @@ __device__ __forceinline__ void ctx_out(TileCtx &c, const KArgs &a, uint32_t img
 // Phase A of one wavefront: COUNT items [first, first + COUNT) of the tile, HBM -> registers ->
 // planar LDS.  All loads are issued before the first conversion (no branch near a load).
 template <int MODE, int LOAD, int COUNT>
-__device__ __forceinline__ void phase_a(const KArgs &a, const TileCtx &c, const TileId &id, int first, int lane, uint8_t *lds, bool last_rows)
+__device__ __forceinline__ void phase_a(const KArgs &a, const TileCtx &c, const TileId &id, int first, int lane, uint8_t *lds)
 {
     typedef Geo<MODE> G;
     uint32_t r[COUNT * G::item_regs];
     LaneAddr la{};
     if (LOAD != L_BYTES) la = lane_addr<MODE>(c, id.tx, id.ty, lane); // (the byte gathers address every pixel by themselves)
-    // (the funnel loads read one dword more than they need; only in the tiles that hold the image's last row could that
-    // dword lie behind the buffer — wave-uniform choice of the loader, all loads of the phase inside either branch)
-    if (LOAD == L_FUNNEL && !last_rows) {
 #pragma unroll
-        for (int j = 0; j < COUNT; j++) producer_load_item<MODE, LOAD, false>(c, la, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < COUNT; j++) producer_load_item<MODE, LOAD, true>(c, la, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
-    }
+    for (int j = 0; j < COUNT; j++) producer_load_item<MODE, LOAD>(c, la, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
     PIXO_STAMP(2); // every load of the phase has been issued
 #pragma unroll
     for (int j = 0; j < COUNT; j++) {
@@ -236,10 +229,9 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     PIXO_STAMP(1);
 #endif
     constexpr int base = G::items / kWaves, extra = G::items % kWaves;
-    const bool last_rows = (id.ty + 1) * (uint32_t)G::tile_h >= a.H; // this tile reads the image's last pixel row
     const int first = (extra && wave < extra) ? wave * (base + 1) : extra * (base + 1) + (wave - extra) * base;
-    if (extra && wave < extra) phase_a<MODE, LOAD, base + 1>(a, c, id, first, lane, lds, last_rows);
-    else phase_a<MODE, LOAD, base>(a, c, id, first, lane, lds, last_rows);
+    if (extra && wave < extra) phase_a<MODE, LOAD, base + 1>(a, c, id, first, lane, lds);
+    else phase_a<MODE, LOAD, base>(a, c, id, first, lane, lds);
     lds_barrier();
     __builtin_amdgcn_s_setprio(0);
     {

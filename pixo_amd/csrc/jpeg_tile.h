@@ -131,7 +131,8 @@ struct TileCtx {
 
 // How phase A reads the pixels (a launch-time choice, template parameter of the kernel):
 //   L_ALIGNED  every row dword aligned (base % 4 == 0, W * bpp % 4 == 0): one 12-byte load per lane and row
-//   L_FUNNEL   any alignment, W >= 4: the aligned dwords around the lane's 12 bytes + v_alignbyte
+//   L_FUNNEL   any alignment, W >= 4: the same 12-byte load at the lane's own byte address (unaligned_load; the name is
+//              round 2's, which funnelled aligned dwords through v_alignbyte)
 //   L_BYTES    byte gathers (images narrower than one 4-pixel group)
 enum Load { L_BYTES = 0, L_ALIGNED = 1, L_FUNNEL = 2 };
 
@@ -405,61 +406,26 @@ PIXO_DEV uint32_t gather_row4_gray(const uint8_t *px, uint32_t W, uint32_t H, ui
 #define PIXO_GLOAD(ptr) __builtin_nontemporal_load(ptr)
 #endif
 
-// One aligned dword of the pixel buffer.  The device reads it as it is: a dword that holds at least
-// one pixel byte lies in the same page as that byte.  The emulation assembles it from the bytes that
-// exist (others read as 0xEE and must never reach a result).
-PIXO_DEV uint32_t load_dword(const TileCtx &c, const uint8_t *aligned)
+// L_UNALIGNED: `N` (1 or 3) dwords starting at byte address `row + off`, whatever its alignment, with ONE load at that
+// address: global memory is in unaligned access mode under ROCm (the compiler itself emits global_load_dwordx3 for a vector
+// of alignment 1), and exactly the lane's own bytes are read — nothing before the row, nothing behind the buffer.
+// Round 2 read the N + 1 ALIGNED dwords around them and funnelled those through v_alignbyte (three half-rate operations
+// per row + address arithmetic, a special case for the tiles that hold the buffer's last dword): 20.8-21.2 us for a
+// 4094-pixel-wide image against 19.3-19.6 now (aligned 4096: 18.3; profiles/r03_unaligned_direct_loads.txt).
+template <int N> PIXO_DEV void unaligned_load(const uint8_t *row, uint32_t off, uint32_t *r)
 {
 #if defined(PIXO_EMU)
-    uint32_t v = 0;
-    for (int i = 0; i < 4; i++) {
-        const uint8_t *p = aligned + i;
-        v |= (uint32_t)((p >= c.px_first && p < c.px_end) ? *p : 0xEE) << (8 * i);
-    }
-    return v;
+    memcpy(r, row + off, 4 * N);
 #else
-    return PIXO_GLOAD((const uint32_t *)aligned);
-#endif
-}
-
-// L_FUNNEL: `N` (1 or 3) dwords starting at byte address `row + off`, whatever its alignment: the N + 1
-// aligned dwords around them funnelled through v_alignbyte.  The last of the N + 1 is only needed when the
-// address is not aligned (and then it holds wanted bytes), but it is always read: ONE load instruction of
-// N + 1 dwords per lane.  Behind the image's very last group it would lie outside the buffer, so the tiles
-// that hold the last pixel row (LAST_ROWS, wave-uniform) read it separately, clamped to the buffer's last dword.
-#if !defined(PIXO_EMU)
-typedef uint32_t pixo_v2u __attribute__((ext_vector_type(2)));
-typedef uint32_t pixo_v3u __attribute__((ext_vector_type(3)));
-typedef uint32_t pixo_v4u_ld __attribute__((ext_vector_type(4)));
-#endif
-template <int N, bool LAST_ROWS> PIXO_DEV void funnel_load(const TileCtx &c, const uint8_t *row, uint32_t off, uint32_t *r)
-{
-    // wave-uniform part (scalar ALU): the row's aligned base and how far the buffer's last dword is from it
-    const uint32_t r3 = (uint32_t)(uintptr_t)row & 3u;
-    const uint8_t *row4 = row - r3;
-    // per lane: three VALU operations for the address, one per dword for the shift
-    const uint32_t t = off + r3, voff = t & ~3u, sh = t & 3u;
-    uint32_t w[N + 1];
-#if !defined(PIXO_EMU)
-    if (!LAST_ROWS) {
-        if (N == 3) {
-            const pixo_v4u_ld q = PIXO_GLOAD((const pixo_v4u_ld *)(row4 + voff));
-            w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-        } else {
-            const pixo_v2u q = PIXO_GLOAD((const pixo_v2u *)(row4 + voff));
-            w[0] = q.x; w[1] = q.y;
-        }
-    } else
-#endif
-    {
-        const uint64_t last64 = (((uintptr_t)c.px_end - 1) & ~(uintptr_t)3) - (uintptr_t)row4;
-        const uint32_t last = last64 > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)last64;
-#pragma unroll
-        for (int i = 0; i < N; i++) w[i] = load_dword(c, row4 + voff + 4 * i);
-        w[N] = load_dword(c, row4 + (voff + 4 * N < last ? voff + 4 * N : last));
+    if (N == 3) {
+        typedef uint32_t v3a1 __attribute__((ext_vector_type(3), aligned(1)));
+        const v3a1 q = PIXO_GLOAD((const v3a1 *)(row + off));
+        r[0] = q.x; r[1] = q.y; r[2] = q.z;
+    } else {
+        typedef uint32_t v1a1 __attribute__((aligned(1)));
+        r[0] = PIXO_GLOAD((const v1a1 *)(row + off));
     }
-#pragma unroll
-    for (int i = 0; i < N; i++) r[i] = alignbyte(w[i + 1], w[i], sh);
+#endif
 }
 
 // What a lane needs to address its pixels, computed ONCE per wavefront (vector paths): the tile's first row as a
@@ -503,7 +469,7 @@ PIXO_DEV void load_dwordx3(const uint8_t *p, uint32_t *r)
 #endif
 }
 
-template <int MODE, int LOAD, bool LAST_ROWS = true>
+template <int MODE, int LOAD>
 PIXO_DEV void producer_load_item(const TileCtx &c, const LaneAddr &la, uint32_t tile_x, uint32_t tile_y, int k, int lane,
                                  uint32_t *r)
 {
@@ -516,15 +482,15 @@ PIXO_DEV void producer_load_item(const TileCtx &c, const LaneAddr &la, uint32_t 
         const uint32_t xoff = (k & 1) ? la.xoff1 : la.xoff0; // (a select, not an indexed array: that would live in scratch)
         if (MODE == MGRAY) {
             if (LOAD == L_ALIGNED) r[0] = PIXO_GLOAD((const uint32_t *)(row + xoff));
-            else funnel_load<1, LAST_ROWS>(c, row, xoff, r);
+            else unaligned_load<1>(row, xoff, r);
         } else {
             if (LOAD == L_ALIGNED) load_dwordx3(row + xoff, r);
-            else funnel_load<3, LAST_ROWS>(c, row, xoff, r);
+            else unaligned_load<3>(row, xoff, r);
             if (MODE == M420) {
                 const uint32_t yb = y0 + 1 < c.H ? y0 + 1 : c.H - 1;
                 const uint8_t *row2 = la.tile_row0 + (yb - la.row_first) * la.stride;
                 if (LOAD == L_ALIGNED) load_dwordx3(row2 + xoff, r + 3);
-                else funnel_load<3, LAST_ROWS>(c, row2, xoff, r + 3);
+                else unaligned_load<3>(row2, xoff, r + 3);
             }
         }
     } else {

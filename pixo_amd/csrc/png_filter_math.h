@@ -14,6 +14,12 @@ static inline uint32_t pixo_sad_u8(uint32_t a, uint32_t b, uint32_t acc)
     for (int i = 0; i < 4; i++) { const int x = (a >> (8 * i)) & 255, y = (b >> (8 * i)) & 255; acc += (uint32_t)(x > y ? x - y : y - x); }
     return acc;
 }
+static inline uint32_t pixo_lerp_u8(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) r |= ((((a >> (8 * i)) & 255) + ((b >> (8 * i)) & 255) + ((c >> (8 * i)) & 1)) >> 1) << (8 * i);
+    return r;
+}
 static inline uint32_t pixo_alignbyte(uint32_t hi, uint32_t lo, int sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * sh)); }
 static inline uint32_t pixo_udot4(uint32_t a, uint32_t b)
 {
@@ -28,6 +34,7 @@ static inline uint32_t pixo_udot4(uint32_t a, uint32_t b)
 #define pixo_sad_u8(a, b, acc) __builtin_amdgcn_sad_u8((a), (b), (acc))
 #define pixo_alignbyte(hi, lo, sh) __builtin_amdgcn_alignbyte((hi), (lo), (sh))
 #define pixo_udot4(a, b) __builtin_amdgcn_udot4((a), (b), 0u, false)
+#define pixo_lerp_u8(a, b, c) __builtin_amdgcn_lerp((a), (b), (c))
 #endif
 #if defined(PIXO_EMU)
 #define pixo_udot4_acc(a, b, acc) (pixo_udot4((a), (b)) + (acc))
@@ -56,8 +63,8 @@ PIXO_PDEV uint32_t sub4(uint32_t a, uint32_t b)
     return ((a | kH) - (b & ~kH)) ^ ((a ^ ~b) & kH);
 }
 PIXO_PDEV uint32_t avg4(uint32_t a, uint32_t b)
-{ // per-byte floor((a + b) / 2)  (fallback.rs:127: u16 sum, / 2)
-    return (a & b) + (((a ^ b) & 0xFEFEFEFEu) >> 1);
+{ // per-byte floor((a + b) / 2)  (fallback.rs:127: u16 sum, / 2): v_lerp_u8 is ((a + b + carry-in bit) >> 1) per byte
+    return pixo_lerp_u8(a, b, 0u);
 }
 PIXO_PDEV s16x2 as_s(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 PIXO_PDEV uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }

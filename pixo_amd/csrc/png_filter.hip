@@ -424,10 +424,107 @@ void png_filter_kernel(const Args a)
     if (threadIdx.x == 0) { a.row_sums[2 * (size_t)y] = t1; a.row_sums[2 * (size_t)y + 1] = t2; }
 }
 
+// Bigrams with the row in registers (round 3; rows of at most kRegIters x 4 KiB, staged): the row and the row above are
+// loaded ONCE for the five candidates and the write-out (the two-pass form above reads them six times and, for the pair
+// that straddles two 16-byte groups, loads and filters the neighbouring group's first dword a second time).  Here that
+// dword comes from the neighbouring thread through a 4 KiB exchange array in LDS — thread t, group `it` is entry
+// 256 it + t, its successor simply the next entry — and two bitmaps alternate between the candidates, so that a candidate
+// costs two barriers: | filter, publish first dwords | A | read successor's, 16 atomic ORs per group | B | population
+// count of the bitmap, clear it for the candidate after next |.
+template <int BPP, bool FAST, int F>
+__device__ __forceinline__ void bigram_candidate(const Raw *raw, int n, int ndw, int tid, uint32_t *bitmap, uint32_t *xch, unsigned int *count)
+{
+    constexpr int per_iter = kThreads * 4;
+    uint32_t v[kRegIters][4];
+#pragma unroll
+    for (int it = 0; it < kRegIters; it++) {
+        const int k0 = tid * 4 + it * per_iter;
+        if (k0 >= ndw) continue;
+        Group g;
+        group_of<BPP, false>(raw[it], k0, n, g);
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[it][j] = filtered(F, g, j);
+        xch[it * kThreads + tid] = v[it][0];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kRegIters; it++) {
+        const int k0 = tid * 4 + it * per_iter;
+        if (k0 >= ndw) continue;
+        const uint32_t next = k0 + 4 < ndw ? xch[it * kThreads + tid + 1] : 0u; // the following group's first filtered dword
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t key[4];
+            const int cnt = bigram_keys(v[it][j], j < 3 ? v[it][j + 1] : next, n - 1 - 4 * (k0 + j), key);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (i < cnt) atomicOr(&bitmap[key[i] >> 5], 1u << (key[i] & 31u));
+        }
+    }
+    __syncthreads();
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += (uint32_t)__builtin_popcount(bitmap[tid * 8 + i]); bitmap[tid * 8 + i] = 0; }
+    c = wave_sum_u32(c);
+    if ((tid & 63) == 0) atomicAdd(count, c);
+}
+
+template <int BPP, bool FAST>
+__global__ __launch_bounds__(kThreads) void png_bigrams_regs_kernel(const Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+    __shared__ unsigned long long acc64[2];
+    __shared__ unsigned int cnt[5];
+    const uint32_t nb = gridDim.x, full = nb & ~255u; // rows in chunks of 32 per XCD (png_filter_kernel)
+    uint32_t y = blockIdx.x;
+    if (y < full) { const uint32_t xcd = y & 7u, i = y >> 3; y = (((i >> 5) * 8u + xcd) << 5) + (i & 31u); }
+    const int n = (int)a.row_bytes, ndw = (n + 3) / 4, tid = (int)threadIdx.x;
+    const uint8_t *row = a.data + (size_t)y * a.row_bytes;
+    const uint8_t *prev = y ? row - a.row_bytes : nullptr;
+    uint32_t *bm0 = reinterpret_cast<uint32_t *>(stage + a.bitmap_off), *bm1 = bm0 + 2048, *xch = bm1 + 2048;
+    if (tid < 5) cnt[tid] = 0;
+    if (tid < 2) acc64[tid] = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) bm0[i * kThreads + tid] = 0; // both bitmaps
+    Raw raw[kRegIters];
+#pragma unroll
+    for (int it = 0; it < kRegIters; it++) {
+        const int k0 = tid * 4 + it * kThreads * 4;
+        if (it * kThreads * 4 < ndw) load_raw<BPP, FAST>(row, prev, k0, n, raw[it]);
+        else {
+#pragma unroll
+            for (int i = 0; i < 6; i++) { raw[it].x[i] = 0; raw[it].u[i] = 0; }
+        }
+    }
+    __syncthreads();
+    bigram_candidate<BPP, FAST, F_NONE>(raw, n, ndw, tid, bm0, xch, &cnt[F_NONE]);
+    bigram_candidate<BPP, FAST, F_SUB>(raw, n, ndw, tid, bm1, xch, &cnt[F_SUB]);
+    bigram_candidate<BPP, FAST, F_UP>(raw, n, ndw, tid, bm0, xch, &cnt[F_UP]);
+    bigram_candidate<BPP, FAST, F_AVG>(raw, n, ndw, tid, bm1, xch, &cnt[F_AVG]);
+    bigram_candidate<BPP, FAST, F_PAETH>(raw, n, ndw, tid, bm0, xch, &cnt[F_PAETH]);
+    __syncthreads();
+    unsigned long long tot[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) tot[i] = cnt[i];
+    const int f = decide_bigrams(tot);
+    switch (f) {
+    case F_NONE: write_row_regs<BPP, F_NONE, kThreads, kRegIters>(a, y, raw, n, acc64, tid); break;
+    case F_SUB: write_row_regs<BPP, F_SUB, kThreads, kRegIters>(a, y, raw, n, acc64, tid); break;
+    case F_UP: write_row_regs<BPP, F_UP, kThreads, kRegIters>(a, y, raw, n, acc64, tid); break;
+    case F_AVG: write_row_regs<BPP, F_AVG, kThreads, kRegIters>(a, y, raw, n, acc64, tid); break;
+    default: write_row_regs<BPP, F_PAETH, kThreads, kRegIters>(a, y, raw, n, acc64, tid); break;
+    }
+    if (tid == 0) { a.row_sums[2 * (size_t)y] = acc64[0]; a.row_sums[2 * (size_t)y + 1] = acc64[1]; }
+}
+
 template <int BPP> hipError_t launch_bpp(const Args &a, uint32_t rows, bool fast, hipStream_t s)
 {
     const uint64_t ndw = (a.row_bytes + 3) / 4;
-    if (a.strategy == PNG_S_BIGRAMS) {
+    if (a.strategy == PNG_S_BIGRAMS && a.stage_bytes != 0 && ndw <= (uint64_t)kRegIters * kThreads * 4) {
+        const uint32_t lds = a.stage_bytes + 2 * 8192u + 4u * (kRegIters * kThreads + 1); // stage | two bitmaps | exchange array
+        if (fast) hipLaunchKernelGGL((png_bigrams_regs_kernel<BPP, true>), dim3(rows), dim3(kThreads), lds, s, a);
+        else hipLaunchKernelGGL((png_bigrams_regs_kernel<BPP, false>), dim3(rows), dim3(kThreads), lds, s, a);
+    } else if (a.strategy == PNG_S_BIGRAMS) {
         const uint32_t lds = a.stage_bytes + 8192u;
         if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, K_BIGRAMS>), dim3(rows), dim3(kThreads), lds, s, a);
         else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_BIGRAMS>), dim3(rows), dim3(kThreads), lds, s, a);

@@ -231,3 +231,19 @@ def test_null_arguments_are_errors_not_crashes():
     assert L.pixo_hip_jpeg_encode_device(None, None, C.byref(out), C.byref(n)) == -6
     L.pixo_hip_coeff_geometry.argtypes = [C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, C.c_void_p, C.c_void_p]
     assert L.pixo_hip_coeff_geometry(8, 8, 2, 1, None, None) == -6
+
+
+def test_copy_file_copies_exactly_and_large_results_come_back_as_bytes():
+    """pixo_hip_copy_file (host code: the library's copy threads + a huge-page hint) and the Python mirror's use of it
+    for large results: same bytes as a plain copy, for sizes around the thresholds and for unaligned ends."""
+    L = _lib.load()
+    rng = np.random.RandomState(7)
+    for n in (1, 4097, (2 << 20) - 1, (2 << 20) + 5, (24 << 20) + 3, (40 << 20) + 1):
+        src = rng.randint(0, 256, n + 9, dtype=np.uint8)
+        dst = np.zeros(n + 9, dtype=np.uint8)
+        L.pixo_hip_copy_file(dst.ctypes.data + 3, src.ctypes.data + 5, n)
+        assert dst[:3].sum() == 0 and dst[3 + n:].sum() == 0
+        assert np.array_equal(dst[3:3 + n], src[5:5 + n])
+        b = _lib.file_bytes(L, src.ctypes.data + 5, n)
+        assert isinstance(b, bytes) and len(b) == n and b == src[5:5 + n].tobytes()
+    L.pixo_hip_copy_file(None, None, 0)  # nothing to do, no crash

@@ -720,6 +720,8 @@ PIXO_DEV uint32_t quant_bracket_pair(float x, QPair r, float *s)
 // {hi[15:0], lo[15:0]}
 PIXO_DEV uint32_t pack_lo16(uint32_t hi, uint32_t lo)
 {
+    // (v_pack_b32_f16 would be one instruction, but it is a FLOAT operation: it does not pass every bit pattern through —
+    // the q = 100 gradient golden fails with it — and it is no faster; profiles/r03_pack_f16_ab.txt)
     return perm(hi, lo, 0x05040100u);
 }
 // four coefficients -> two registers of packed i16 pairs

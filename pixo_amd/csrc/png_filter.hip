@@ -306,12 +306,8 @@ __device__ __forceinline__ unsigned long long bigram_score(const uint8_t *row, c
 // K_BIGRAMS (~110).
 // K_REGS512: the same with 512 threads, rows of up to 32 KiB.
 enum { K_GENERAL = 0, K_REGS = 1, K_BIGRAMS = 2, K_REGS512 = 3 };
-#ifndef PIXO_PNG_WAVES // (experiments: tools/ab_build.sh)
-#define PIXO_PNG_WAVES 1
-#endif
 template <int BPP, bool FAST, int KIND, int ITERS = kRegIters>
-__global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) __attribute__((amdgpu_waves_per_eu(KIND == K_REGS ? PIXO_PNG_WAVES : 1)))
-void png_filter_kernel(const Args a)
+__global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) void png_filter_kernel(const Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
     __shared__ unsigned long long red[20];
@@ -414,11 +410,7 @@ void png_filter_kernel(const Args a)
     case F_SUB: write_row<BPP, FAST, F_SUB, 1>(a, y, row, prev, n, s1, s2); break;
     case F_UP: write_row<BPP, FAST, F_UP, 2>(a, y, row, prev, n, s1, s2); break;
     case F_AVG: write_row<BPP, FAST, F_AVG, 3>(a, y, row, prev, n, s1, s2); break;
-#ifdef PIXO_PNG_EXP_AVG7 // (timing experiment: Paeth's loads, Average's arithmetic)
-    default: write_row<BPP, FAST, F_AVG, 7>(a, y, row, prev, n, s1, s2); break;
-#else
     default: write_row<BPP, FAST, F_PAETH, 7>(a, y, row, prev, n, s1, s2); break;
-#endif
     }
     const unsigned long long t1 = wg_sum(s1, red), t2 = wg_sum(s2, red);
     if (threadIdx.x == 0) { a.row_sums[2 * (size_t)y] = t1; a.row_sums[2 * (size_t)y + 1] = t2; }
@@ -530,12 +522,6 @@ template <int BPP> hipError_t launch_bpp(const Args &a, uint32_t rows, bool fast
         else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_BIGRAMS>), dim3(rows), dim3(kThreads), lds, s, a);
     } else if (a.strategy > PNG_S_PAETH && !a.forced && ndw <= (uint64_t)kRegIters * 2 * kThreads * 4 && a.stage_bytes != 0) {
         // rows of up to 16 KiB: 256 threads hold them; up to 32 KiB: 512 threads
-#ifdef PIXO_PNG_T512I2 // (experiment: rows of up to 16 KiB on 512 threads x 2 groups)
-        if (ndw <= 2ull * 2 * kThreads * 4) {
-            if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, K_REGS512, 2>), dim3(rows), dim3(2 * kThreads), a.stage_bytes, s, a);
-            else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_REGS512, 2>), dim3(rows), dim3(2 * kThreads), a.stage_bytes, s, a);
-        } else
-#endif
         if (ndw <= (uint64_t)kRegIters * kThreads * 4) {
             if (fast) hipLaunchKernelGGL((png_filter_kernel<BPP, true, K_REGS>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);
             else hipLaunchKernelGGL((png_filter_kernel<BPP, false, K_REGS>), dim3(rows), dim3(kThreads), a.stage_bytes, s, a);

@@ -216,8 +216,9 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     // come first and whose stores all come last.  The second half of that generation (dispatch order 1024..2047) starts
     // one s_sleep (8128 clocks, ~3.4 us) late, so that its loads meet the first half's arithmetic and stores: 19.1 ->
     // 18.35 us on one box of the pool, nothing gained or lost (17.4) on a faster one, two sleeps or other halves worse
-    // (profiles/r03_stagger_and_occupancy_ab.txt).  Later generations are not touched.
-    if (MODE == M420) {
+    // (profiles/r03_stagger_and_occupancy_ab.txt); the 4:4:4 kernel, two generations per 4096x4096 image: 33.8 -> 30.9 us
+    // (profiles/r03_stagger_444.txt).  Later generations are not touched (every odd thousand late: the batch loses 6 %).
+    {
         const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         if ((lin >> 10) == 1u && gridDim.x * gridDim.y * gridDim.z >= 2048u) __builtin_amdgcn_s_sleep(127); // (a full first generation only)
     }

@@ -320,6 +320,10 @@ __global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) void p
     // 8 MiB apart hit the same HBM channels at the same time and stream 30 % slower.
     const uint32_t nb = gridDim.x, full = nb & ~255u;
     uint32_t y = blockIdx.x;
+    // The chip holds 2048 of these workgroups (8 per CU): the first generation of a tall image loads all at once, scores all
+    // at once, stores all at once.  Its second half starts one s_sleep (~3.4 us) late: 42.9 -> 40.8 us for the 4096-row image
+    // (two sleeps 41.6, four 43.0, graded quarters 41.6-44.5; profiles/r03_png_stagger_ab.txt).
+    if (KIND == K_REGS && nb >= 2048u && (y >> 10) == 1u) __builtin_amdgcn_s_sleep(127);
     if (y < full) { const uint32_t xcd = y & 7u, i = y >> 3; y = (((i >> 5) * 8u + xcd) << 5) + (i & 31u); }
     y += a.first_row;
     const int n = (int)a.row_bytes; // < 2^31 (checked by the launcher)
@@ -357,12 +361,22 @@ __global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) void p
         __syncthreads(); // (the zeroed totals; the loads are needed from here on anyway)
         uint32_t sc[5] = {0, 0, 0, 0, 0};
         const bool fast = strategy == PNG_S_ADAPTIVE_FAST;
+        if (fast) { // (uniform)
 #pragma unroll
-        for (int it = 0; it < ITERS; it++) {
-            const int k0 = (int)threadIdx.x * 4 + it * per_iter;
-            if (k0 >= ndw) continue;
-            if (4 * (k0 + 4) <= n) score_group<BPP, false>(raw[it], k0, n, fast, sc);
-            else score_group<BPP, true>(raw[it], k0, n, fast, sc);
+            for (int it = 0; it < ITERS; it++) {
+                const int k0 = (int)threadIdx.x * 4 + it * per_iter;
+                if (k0 >= ndw) continue;
+                if (4 * (k0 + 4) <= n) score_group<BPP, false, true>(raw[it], k0, n, sc);
+                else score_group<BPP, true, true>(raw[it], k0, n, sc);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                const int k0 = (int)threadIdx.x * 4 + it * per_iter;
+                if (k0 >= ndw) continue;
+                if (4 * (k0 + 4) <= n) score_group<BPP, false, false>(raw[it], k0, n, sc);
+                else score_group<BPP, true, false>(raw[it], k0, n, sc);
+            }
         }
         // row totals (< 2^32: at most 16 KiB x 128): 32-bit butterflies, one LDS atomic per wavefront and score
 #pragma unroll
@@ -393,8 +407,13 @@ __global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) void p
         for (int k0 = (int)threadIdx.x * 4; k0 < ndw; k0 += per_iter) {
             Raw r;
             load_raw<BPP, FAST>(row, prev, k0, n, r);
-            if (4 * (k0 + 4) <= n) score_group<BPP, false>(r, k0, n, fast, sc);
-            else score_group<BPP, true>(r, k0, n, fast, sc);
+            if (fast) {
+                if (4 * (k0 + 4) <= n) score_group<BPP, false, true>(r, k0, n, sc);
+                else score_group<BPP, true, true>(r, k0, n, sc);
+            } else {
+                if (4 * (k0 + 4) <= n) score_group<BPP, false, false>(r, k0, n, sc);
+                else score_group<BPP, true, false>(r, k0, n, sc);
+            }
         }
         unsigned long long tot[5];
 #pragma unroll

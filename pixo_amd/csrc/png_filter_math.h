@@ -20,6 +20,16 @@ static inline uint32_t pixo_lerp_u8(uint32_t a, uint32_t b, uint32_t c)
     for (int i = 0; i < 4; i++) r |= ((((a >> (8 * i)) & 255) + ((b >> (8 * i)) & 255) + ((c >> (8 * i)) & 1)) >> 1) << (8 * i);
     return r;
 }
+static inline uint32_t pixo_perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{ // v_perm_b32: selector byte 0..3 = that byte of s1, 4..7 = of s0, 12 = 0x00
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t k = (sel >> (8 * i)) & 255u;
+        const uint32_t b = k < 4 ? (s1 >> (8 * k)) & 255u : (k < 8 ? (s0 >> (8 * (k - 4))) & 255u : 0u);
+        r |= b << (8 * i);
+    }
+    return r;
+}
 static inline uint32_t pixo_alignbyte(uint32_t hi, uint32_t lo, int sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * sh)); }
 static inline uint32_t pixo_udot4(uint32_t a, uint32_t b)
 {
@@ -35,6 +45,7 @@ static inline uint32_t pixo_udot4(uint32_t a, uint32_t b)
 #define pixo_alignbyte(hi, lo, sh) __builtin_amdgcn_alignbyte((hi), (lo), (sh))
 #define pixo_udot4(a, b) __builtin_amdgcn_udot4((a), (b), 0u, false)
 #define pixo_lerp_u8(a, b, c) __builtin_amdgcn_lerp((a), (b), (c))
+#define pixo_perm(s0, s1, sel) __builtin_amdgcn_perm((s0), (s1), (sel))
 #endif
 #if defined(PIXO_EMU)
 #define pixo_udot4_acc(a, b, acc) (pixo_udot4((a), (b)) + (acc))
@@ -105,7 +116,8 @@ PIXO_PDEV uint32_t paeth4(uint32_t a, uint32_t b, uint32_t c)
 {
     const uint32_t M = 0x00FF00FFu;
     const uint32_t e = paeth2(a & M, b & M, c & M);
-    const uint32_t o = paeth2((a >> 8) & M, (b >> 8) & M, (c >> 8) & M);
+    // (the odd bytes by one byte permute each: a shift by a constant is in the expensive class, profiles/r03_ubench_form_rate.txt)
+    const uint32_t o = paeth2(pixo_perm(0u, a, 0x0C030C01u), pixo_perm(0u, b, 0x0C030C01u), pixo_perm(0u, c, 0x0C030C01u));
     return e | (o << 8);
 }
 PIXO_PDEV uint32_t score4(uint32_t f, uint32_t acc)
@@ -153,8 +165,10 @@ PIXO_PDEV uint32_t filtered(int f, const Group &g, int j)
     }
 }
 
-template <int BPP, bool MASK>
-PIXO_PDEV void score_group(const Raw &r, int k0, int n, bool fast, uint32_t sc[5])
+// (FASTMODE: AdaptiveFast never looks at None / Average — a template parameter, not a run-time flag: as a flag the compiler
+// computed both candidates and threw them away, AdaptiveFast was no faster than Adaptive)
+template <int BPP, bool MASK, bool FASTMODE>
+PIXO_PDEV void score_group(const Raw &r, int k0, int n, uint32_t sc[5])
 {
     Group g;
     group_of<BPP, MASK>(r, k0, n, g);
@@ -164,7 +178,7 @@ PIXO_PDEV void score_group(const Raw &r, int k0, int n, bool fast, uint32_t sc[5
         sc[F_SUB] = score4(filtered(F_SUB, g, j) & m, sc[F_SUB]);
         sc[F_UP] = score4(filtered(F_UP, g, j) & m, sc[F_UP]);
         sc[F_PAETH] = score4(filtered(F_PAETH, g, j) & m, sc[F_PAETH]);
-        if (!fast) {
+        if (!FASTMODE) {
             sc[F_NONE] = score4(g.cur[j] & m, sc[F_NONE]);
             sc[F_AVG] = score4(filtered(F_AVG, g, j) & m, sc[F_AVG]);
         }

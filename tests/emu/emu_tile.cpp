@@ -572,8 +572,8 @@ template <int BPP> uint32_t emu_png_rows(const uint8_t *data, long n, long heigh
             for (long k0 = 0; k0 < ndw; k0 += 4) {
                 Raw r;
                 for (int i = 0; i < 6; i++) { r.x[i] = host_dword(row, k0 - 2 + i, n); r.u[i] = host_dword(prev, k0 - 2 + i, n); }
-                if (4 * (k0 + 4) <= n) score_group<BPP, false>(r, (int)k0, (int)n, strategy == S_ADAPTIVE_FAST, sc);
-                else score_group<BPP, true>(r, (int)k0, (int)n, strategy == S_ADAPTIVE_FAST, sc);
+                if (4 * (k0 + 4) <= n) { if (strategy == S_ADAPTIVE_FAST) score_group<BPP, false, true>(r, (int)k0, (int)n, sc); else score_group<BPP, false, false>(r, (int)k0, (int)n, sc); }
+                else { if (strategy == S_ADAPTIVE_FAST) score_group<BPP, true, true>(r, (int)k0, (int)n, sc); else score_group<BPP, true, false>(r, (int)k0, (int)n, sc); }
             }
             unsigned long long tot[5];
             for (int i = 0; i < 5; i++) tot[i] = sc[i];

@@ -218,6 +218,8 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     // 18.35 us on one box of the pool, nothing gained or lost (17.4) on a faster one, two sleeps or other halves worse
     // (profiles/r03_stagger_and_occupancy_ab.txt); the 4:4:4 kernel, two generations per 4096x4096 image: 33.8 -> 30.9 us
     // (profiles/r03_stagger_444.txt).  Later generations are not touched (every odd thousand late: the batch loses 6 %).
+    // On the fastest kind of box the late start COSTS 1 % (17.36 -> 17.55 us; 4:4:4 29.3 -> 29.8): accepted for the 4-8 % it
+    // gains on the others.
     {
         const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         if ((lin >> 10) == 1u && gridDim.x * gridDim.y * gridDim.z >= 2048u) __builtin_amdgcn_s_sleep(127); // (a full first generation only)

@@ -174,8 +174,10 @@ int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_opti
  * each other without gaps (offsets[0] = 0); every file is copied from the device straight to its final place — with
  * pinned (hipHostMalloc / registered) storage the device-to-host copy is the only pass over the bytes.  offsets and lens
  * have `batch` entries.  When the files do not fit, offsets / lens are still filled in (capacity needed =
- * offsets[batch - 1] + lens[batch - 1]), nothing is copied and PIXO_ERR_BUFFER_TOO_SMALL is returned.  A null arena with
- * capacity 0 is a size query.  Replaces a loop over pixo::jpeg::encode_into (src/jpeg/mod.rs:328). */
+ * offsets[batch - 1] + lens[batch - 1]) and PIXO_ERR_BUFFER_TOO_SMALL is returned; a null arena with capacity 0 is a size
+ * query (nothing is copied).  Batches of 64 MB of pixels and more are coded in sub-batches whose files cross PCIe while the
+ * next sub-batch's kernels run (two of the library's contexts alternate): an arena that turns out too small may then
+ * hold the files of the first sub-batches.  Replaces a loop over pixo::jpeg::encode_into (src/jpeg/mod.rs:328). */
 int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg_options *options, uint32_t batch,
                                            uint8_t *arena, size_t capacity, size_t *offsets, size_t *lens);
 

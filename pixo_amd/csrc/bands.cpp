@@ -446,7 +446,7 @@ class BandWorkers {
     const std::function<void(unsigned)> *body_ = nullptr;
     unsigned pending_ = 0;
 };
-BandWorkers &band_workers_instance()
+extern "C++" BandWorkers &band_workers_instance() // (C++ linkage: this file's body sits inside extern "C")
 {
     static BandWorkers *w = new BandWorkers; // leaked on purpose: worker threads must not be joined from a static destructor
     return *w;

@@ -734,3 +734,33 @@ def test_integer_mode_kernel_equals_the_oracle(case):
     if ct == 2:
         with pytest.raises(error.Error, match="4:4:4 or gray only"):
             jpeg.coefficients_integer(px, _opts(w, h, 2, 1, q))
+
+
+@pytest.mark.gpu
+def test_large_batches_go_in_sub_batches_over_two_contexts_and_give_the_same_files():
+    """A batch of 64 MB of pixels and more is cut into sub-batches that alternate between two contexts, so that one
+    sub-batch's files cross PCIe while the next one's kernels run: same files at the same places as one image at a
+    time, for batch sizes that do and do not divide evenly, with a smooth image among the noise and a short arena."""
+    import torch
+    from pixo_amd import error
+    w, h = 1280, 720
+    o = _opts(w, h, 2, 1, 80)
+    base = [synth.noise(w, h, 900 + i) for i in range(4)] + [synth.gradient_rgb(w, h)]
+    want_of = [O.encode(im, O.make_options(w, h, 2, 80, 1)) for im in base]
+    for n in (25, 33, 64):  # 3, 4 and 8 sub-batches
+        order = [(7 * i + 3) % len(base) for i in range(n)]
+        d_px = torch.from_numpy(np.concatenate([base[k] for k in order])).to("cuda:0")
+        torch.cuda.synchronize()
+        want = [want_of[k] for k in order]
+        total = sum(len(f) for f in want)
+        arena = torch.full((total + 32,), 0x5A, dtype=torch.uint8).pin_memory()
+        offs, lens = jpeg.encode_batch_device_into(arena, d_px, o, n)
+        assert lens == [len(f) for f in want] and offs == [sum(lens[:i]) for i in range(n)]
+        raw = arena.numpy()
+        for i in range(n):
+            assert raw[offs[i]: offs[i] + lens[i]].tobytes() == want[i], (n, i)
+        assert bool((raw[total:] == 0x5A).all())
+        with pytest.raises(error.Error, match="need %d bytes" % total):
+            jpeg.encode_batch_device_into(torch.zeros(total - 1, dtype=torch.uint8).pin_memory(), d_px, o, n)
+        files = jpeg.encode_batch_device(d_px, o, n)  # (the malloc'ing form: one pass, unchanged)
+        assert files == want

@@ -295,8 +295,10 @@ int huffman_for_tuple(const int16_t *dy, const int16_t *dcb, const int16_t *dcr,
                       const pixo_host::Geometry &g, Context &c, pixo_host::HuffSet &h);
 int device_progressive_scans(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_host::Geometry &g,
                              const pixo_host::HuffSet &h, Context &c, const std::vector<uint8_t> &head, const uint8_t **file,
-                             size_t *file_len);
+                             size_t *file_len, uint8_t *pinned_dest = nullptr, size_t dest_cap = 0);
+// (pinned_dest: caller storage the GPU can write — the file is assembled there when it fits, *file == pinned_dest then)
 int progressive_to_view(const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, Context &c,
-                        std::vector<uint8_t> &spill, const uint8_t **file, size_t *file_len);
+                        std::vector<uint8_t> &spill, const uint8_t **file, size_t *file_len, uint8_t *pinned_dest = nullptr,
+                        size_t dest_cap = 0);
 
 } // namespace pixo_capi

@@ -335,10 +335,16 @@ int pixo_hip_jpeg_encode_device_into(const void *d_pixels, const pixo_jpeg_optio
         std::vector<uint8_t> spill;
         const uint8_t *file = nullptr;
         size_t n = 0;
-        if ((rc = progressive_to_view(d_pixels, *options, g, *c, spill, &file, &n))) return rc;
+        uint8_t *direct = nullptr; // pinned / registered storage: the scans are copied from the device straight into it
+        if (output && capacity) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, output) == hipSuccess && at.type == hipMemoryTypeHost) direct = output;
+            else (void)hipGetLastError(); // (plain malloc'd memory is "invalid value" to the runtime: not an error)
+        }
+        if ((rc = progressive_to_view(d_pixels, *options, g, *c, spill, &file, &n, direct, capacity))) return rc;
         *out_len = n;
         if (n > capacity) return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(n) + " bytes");
-        std::memcpy(output, file, n);
+        if (file != output) big_copy(output, file, n);
         return PIXO_OK;
     }
     if (debug().host_entropy) { // assembled on the host: copy if it fits

@@ -16,7 +16,7 @@ namespace pixo_capi {
 // extra passes over the file through freshly mapped pages, about half of the 2.3 ms of a 4096x4096 preset-2 file.)
 int device_progressive_scans(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_host::Geometry &g,
                              const pixo_host::HuffSet &h, Context &c, const std::vector<uint8_t> &head, const uint8_t **file,
-                             size_t *file_len)
+                             size_t *file_len, uint8_t *pinned_dest, size_t dest_cap)
 {
     namespace pd = pixo_dev;
     Stopwatch sw;
@@ -91,9 +91,12 @@ int device_progressive_scans(const int16_t *dy, const int16_t *dcb, const int16_
     for (int i = 6; i >= 0; --i)
         if (start[i] == ~0ull) start[i] = start[i + 1]; // empty scans at the end of the stream
     const size_t total = head.size() + 7 * 10 + scan_bytes + 2;
-    int rc = c.reserve_hfile(total);
-    if (rc) return rc;
-    uint8_t *p = c.h_file;
+    uint8_t *p = pinned_dest; // the caller's pinned storage when the file fits: the seven copies below are its only pass over the bytes
+    if (!p || total > dest_cap) {
+        int rc = c.reserve_hfile(total);
+        if (rc) return rc;
+        p = c.h_file;
+    }
     std::memcpy(p, head.data(), head.size());
     size_t pos = head.size();
     static const uint8_t script[7][3] = {{0, 0, 0}, {1, 0, 0}, {2, 0, 0}, {0, 1, 10}, {0, 11, 63}, {1, 1, 63}, {2, 1, 63}};
@@ -154,7 +157,7 @@ int huffman_for_tuple(const int16_t *dy, const int16_t *dcb, const int16_t *dcr,
 //            pinned copy of the tuple).
 // Progressive file from device pixels; *file points into the context's pinned buffer (or into `spill`: the host twin).
 int progressive_to_view(const void *d_pixels, const pixo_jpeg_options &o, const pixo_host::Geometry &g, Context &c,
-                        std::vector<uint8_t> &spill, const uint8_t **file, size_t *file_len)
+                        std::vector<uint8_t> &spill, const uint8_t **file, size_t *file_len, uint8_t *pinned_dest, size_t dest_cap)
 {
     namespace pd = pixo_dev;
     int rc;
@@ -181,7 +184,7 @@ int progressive_to_view(const void *d_pixels, const pixo_jpeg_options &o, const 
     if (!debug().host_entropy) {
         std::vector<uint8_t> head;
         pixo_host::file_headers(head, o, h);
-        return device_progressive_scans(dy, dcb, dcr, g, h, c, head, file, file_len);
+        return device_progressive_scans(dy, dcb, dcr, g, h, c, head, file, file_len, pinned_dest, dest_cap);
     }
     if ((rc = c.reserve_hcoef(coef_bytes))) return rc;
     HIP_TRY(hipMemcpyAsync(c.h_coef, dy, coef_bytes, hipMemcpyDeviceToHost, c.stream));

@@ -148,3 +148,27 @@ def test_random_sweep_of_small_progressive_images():
         got = jpeg.encode(px, _opts(w, h, ct, ss, q, progressive=True, trellis_quant=trellis, optimize_huffman=optimize))
         want = O.encode(px, O.make_options(w, h, ct, q, ss, progressive=True, trellis=trellis, optimize_huffman=optimize))
         assert got == want, (i, w, h, ct, ss, q, kind, trellis, optimize)
+
+
+def test_progressive_files_straight_into_pinned_caller_storage():
+    """`encode_device_into` with progressive options: pinned storage gets the seven scans copied from the device straight
+    into it (no pass through the context's buffer), pageable storage one copy from there — same bytes either way, a
+    capacity that is one byte short reports the size, and storage with head-room is not touched beyond the file."""
+    import torch
+    from pixo_amd import error
+    for (w, h, ct, ss, kw) in [(1920, 1080, 2, 1, dict(progressive=True)), (333, 77, 2, 0, dict(progressive=True, trellis_quant=True)),
+                               (512, 512, 0, 0, dict(progressive=True, optimize_huffman=True, trellis_quant=True))]:
+        px = synth.noise(w, h, 77) if ct == 2 else synth.noise_gray(w, h, 77)
+        o = _opts(w, h, ct, ss, 85, **kw)
+        d = torch.from_numpy(px).to("cuda:0")
+        want = jpeg.encode_device(d, o)
+        okw = {("trellis" if k == "trellis_quant" else k): v for k, v in kw.items()}
+        assert want == O.encode(px, O.make_options(w, h, ct, 85, ss, **okw))
+        for arena in (torch.full((len(want) + 40,), 0x5A, dtype=torch.uint8).pin_memory(), torch.full((len(want),), 0x5A, dtype=torch.uint8).pin_memory(),
+                      np.full(len(want) + 3, 0x5A, np.uint8)):
+            n = jpeg.encode_device_into(arena, d, o)
+            raw = arena.numpy() if hasattr(arena, "numpy") else arena
+            assert n == len(want) and raw[:n].tobytes() == want
+            assert bool((raw[n:] == 0x5A).all())
+        with pytest.raises(error.Error, match="need %d bytes" % len(want)):
+            jpeg.encode_device_into(torch.zeros(len(want) - 1, dtype=torch.uint8).pin_memory(), d, o)

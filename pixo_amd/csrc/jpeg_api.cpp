@@ -35,7 +35,13 @@ int encode_to_view(const uint8_t *data, size_t data_len, const pixo_jpeg_options
     if ((rc = c.reserve_px((px_bytes + 15) & ~size_t{15}))) return rc;
     if (o.progressive) {
         HIP_TRY(hipMemcpyAsync(c.d_px, data, px_bytes, hipMemcpyHostToDevice, c.stream));
-        return progressive_to_view(c.d_px, o, g, c, spill, file, file_len);
+        uint8_t *direct = nullptr; // pinned / registered caller storage: the scans are copied from the device straight into it
+        if (dest && dest_cap > 1) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, dest) == hipSuccess && at.type == hipMemoryTypeHost) direct = dest;
+            else (void)hipGetLastError(); // (plain malloc'd memory is "invalid value" to the runtime: not an error)
+        }
+        return progressive_to_view(c.d_px, o, g, c, spill, file, file_len, direct, dest_cap);
     }
     // baseline: the entropy stage launches the uploads and the coefficient kernel itself — band by band for images of
     // 2048x2048 pixels and more, so that bands are transformed and coded while the next ones cross PCIe and the file's

@@ -172,3 +172,10 @@ def test_progressive_files_straight_into_pinned_caller_storage():
             assert bool((raw[n:] == 0x5A).all())
         with pytest.raises(error.Error, match="need %d bytes" % len(want)):
             jpeg.encode_device_into(torch.zeros(len(want) - 1, dtype=torch.uint8).pin_memory(), d, o)
+        # the same from HOST pixels (pixo_hip_jpeg_encode_into): pinned and pageable storage, one byte short
+        for arena in (torch.full((len(want) + 9,), 0x5A, dtype=torch.uint8).pin_memory().numpy(), np.full(len(want), 0x5A, np.uint8)):
+            n = jpeg.encode_into_buffer(arena, px, o)
+            assert n == len(want) and arena[:n].tobytes() == want and bool((arena[n:] == 0x5A).all())
+        with pytest.raises(error.BufferTooSmall) as e:
+            jpeg.encode_into_buffer(torch.zeros(len(want) - 1, dtype=torch.uint8).pin_memory().numpy(), px, o)
+        assert e.value.needed == len(want)

@@ -2,6 +2,9 @@
 #include "capi_internal.hpp"
 #include "png_filter.hpp"
 
+#include <algorithm>
+#include <vector>
+
 using namespace pixo_capi;
 
 namespace {
@@ -81,7 +84,35 @@ int pixo_hip_png_filter(const uint8_t *data, size_t data_len, uint32_t width, ui
     HIP_TRY(c.p_out.reserve(out_bytes));
     HIP_TRY(hipMemcpyAsync(c.p_in.p, data, in_bytes, hipMemcpyHostToDevice, c.stream));
     if ((rc = png_filter_on_device(c, c.p_in.p, width, height, bytes_per_pixel, run, seq, c.p_out.p, adler32))) return rc;
-    HIP_TRY(hipMemcpy(out, c.p_out.p, out_bytes, hipMemcpyDeviceToHost));
+    // The stream's way to the caller (round 3).  A device-to-host copy straight into pageable storage makes the runtime
+    // fault in and pin the pages as it goes: 30-39 ms for the 67 MB of a 4096x4096 RGBA image, where the bytes need 1.3 ms
+    // on the link.  So, like the JPEG files: into the context's pinned buffer in pieces of 8 MiB, each piece copied on by
+    // the library's copy threads while the next one crosses PCIe, with a huge-page hint for storage not yet touched.
+    if (out_bytes < (size_t{4} << 20)) {
+        HIP_TRY(hipMemcpy(out, c.p_out.p, out_bytes, hipMemcpyDeviceToHost));
+        return PIXO_OK;
+    }
+    if ((rc = c.reserve_hfile(out_bytes))) return rc;
+    advise_huge(out, out_bytes);
+    constexpr size_t kPiece = size_t{8} << 20;
+    const size_t pieces = (out_bytes + kPiece - 1) / kPiece;
+    std::vector<hipEvent_t> arrived(pieces, nullptr);
+    hipError_t e = hipSuccess;
+    for (size_t i = 0; i < pieces && e == hipSuccess; ++i) {
+        const size_t off = i * kPiece, n = std::min(kPiece, out_bytes - off);
+        e = hipEventCreateWithFlags(&arrived[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMemcpyAsync(c.h_file + off, static_cast<const uint8_t *>(c.p_out.p) + off, n, hipMemcpyDeviceToHost, c.stream);
+        if (e == hipSuccess) e = hipEventRecord(arrived[i], c.stream);
+    }
+    for (size_t i = 0; i < pieces && e == hipSuccess; ++i) {
+        const size_t off = i * kPiece, n = std::min(kPiece, out_bytes - off);
+        e = hipEventSynchronize(arrived[i]);
+        if (e == hipSuccess) big_copy(out + off, c.h_file + off, n);
+    }
+    if (e != hipSuccess) (void)hipStreamSynchronize(c.stream); // (nothing of ours in flight when the events go)
+    for (hipEvent_t ev : arrived)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e != hipSuccess) return hip_fail(e, "device-to-host copy of the filtered stream");
     return PIXO_OK;
 }
 

@@ -516,6 +516,13 @@ int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg
     size_t at = 0;
     uint32_t first = 0;
     rc = PIXO_OK;
+    bool arena_pinned = false;
+    if (arena) {
+        hipPointerAttribute_t pa;
+        if (hipPointerGetAttributes(&pa, arena) == hipSuccess && pa.type == hipMemoryTypeHost) arena_pinned = true;
+        else (void)hipGetLastError(); // (plain malloc'd memory is "invalid value" to the runtime: not an error)
+        if (!arena_pinned) advise_huge(arena, capacity);
+    }
     for (uint32_t part = 0; part < parts && !rc; ++part) {
         uint32_t nb = (batch - first + (parts - part) - 1) / (parts - part);
         Context &cx = (second && (part & 1)) ? *second : *c;
@@ -531,7 +538,16 @@ int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg
         }
         if (at <= capacity) {
             hipError_t e = hipSuccess;
-            if (gaps) { // the scans lie in the device buffer at their files' final spacing: ONE copy, the host fills the gaps in afterwards
+            if (gaps && !arena_pinned) { // pageable arena: through the context's pinned buffer + the copy threads (a copy straight
+                                         // into pageable pages makes the runtime fault them in and pin them as it goes)
+                const size_t run = static_cast<size_t>(starts[nb]);
+                if (run) {
+                    if ((rc = cx.reserve_hfile(run))) break;
+                    e = hipMemcpyAsync(cx.h_file, cx.e_out.p, run, hipMemcpyDeviceToHost, cx.stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(cx.stream);
+                    if (e == hipSuccess) big_copy(arena + at0 + hdr, cx.h_file, run);
+                }
+            } else if (gaps) { // the scans lie in the device buffer at their files' final spacing: ONE copy, the host fills the gaps in afterwards
                 const size_t run = static_cast<size_t>(starts[nb]);
                 if (run) e = hipMemcpyAsync(arena + at0 + hdr, cx.e_out.p, run, hipMemcpyDeviceToHost, cx.stream);
             } else { // (multi-pass kernels: every file's entropy-coded bytes by a copy of its own)

@@ -58,6 +58,66 @@ int png_filter_on_device(Context &c, const void *d_in, uint32_t width, uint32_t 
     *adler = combine_adler(c.h_sums, height, static_cast<uint64_t>(width) * bpp + 1);
     return PIXO_OK;
 }
+
+// A large image from host pixels to caller storage, band by band (round 3).  Rows are independent once the row above is on
+// the device, so: the calling thread uploads bands of ~8 MiB back to back on the upload stream (a pageable source blocks it
+// for the copy's duration anyway); each band's kernel and the download of its filtered rows into the context's PINNED
+// buffer follow on the context's stream as soon as the band has arrived; and while the next band uploads, the band before
+// last is copied on into the caller's storage by the library's copy threads (huge-page hint first: the result array of
+// a call is usually fresh).  A device-to-host copy straight into that pageable storage made the runtime fault in and pin
+// its pages as it went: 30-39 ms for the 67 MB of a 4096x4096 RGBA image whose bytes need 1.3 ms each way on the link.
+// The stateful AdaptiveFast (row 0 decides for all) runs as one launch after the whole upload.
+int png_filter_in_bands(Context &c, const uint8_t *data, uint32_t width, uint32_t height, uint32_t bpp, int run, bool seq,
+                        uint8_t *out, uint32_t *adler)
+{
+    const size_t row_in = static_cast<size_t>(width) * bpp, row_out = row_in + 1;
+    const size_t out_bytes = row_out * height;
+    int rc = c.reserve_hfile(out_bytes);
+    if (rc) return rc;
+    HIP_TRY(c.p_sums.reserve(static_cast<size_t>(height) * 16));
+    HIP_TRY(c.p_scratch.reserve(16));
+    if (static_cast<size_t>(height) * 16 > c.hsums_cap) {
+        if (c.h_sums) (void)hipHostFree(c.h_sums);
+        c.h_sums = nullptr; c.hsums_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_sums), static_cast<size_t>(height) * 16, hipHostMallocDefault));
+        c.hsums_cap = static_cast<size_t>(height) * 16;
+    }
+    if (!c.upload_stream) HIP_TRY(hipStreamCreateWithFlags(&c.upload_stream, hipStreamNonBlocking));
+    advise_huge(out, out_bytes);
+    const uint32_t band_rows = seq ? height : static_cast<uint32_t>(std::max<size_t>(1, (size_t{8} << 20) / row_in));
+    const uint32_t bands = (height + band_rows - 1) / band_rows;
+    std::vector<hipEvent_t> up(bands, nullptr), down(bands, nullptr);
+    hipError_t e = hipSuccess;
+    auto copy_on = [&](uint32_t b) { // band b's filtered rows: pinned buffer -> the caller's storage
+        e = hipEventSynchronize(down[b]);
+        const size_t off = static_cast<size_t>(b) * band_rows * row_out;
+        const size_t n = std::min(static_cast<size_t>(band_rows) * row_out, out_bytes - off);
+        if (e == hipSuccess) big_copy(out + off, c.h_file + off, n);
+    };
+    for (uint32_t b = 0; b < bands && e == hipSuccess; ++b) {
+        const uint32_t r0 = b * band_rows, rows = std::min(band_rows, height - r0);
+        e = hipEventCreateWithFlags(&up[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&down[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMemcpyAsync(static_cast<uint8_t *>(c.p_in.p) + r0 * row_in, data + r0 * row_in, rows * row_in, hipMemcpyHostToDevice, c.upload_stream);
+        if (e == hipSuccess) e = hipEventRecord(up[b], c.upload_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c.stream, up[b], 0);
+        if (e == hipSuccess) e = pixo_dev::launch_png_filter_rows(c.p_in.p, width, height, bpp, run, seq, c.p_out.p, c.p_sums.as<unsigned long long>(),
+                                                                  c.p_scratch.as<int>(), r0, rows, c.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c.h_file + r0 * row_out, static_cast<const uint8_t *>(c.p_out.p) + r0 * row_out, rows * row_out, hipMemcpyDeviceToHost, c.stream);
+        if (e == hipSuccess) e = hipEventRecord(down[b], c.stream);
+        if (e == hipSuccess && b >= 2) copy_on(b - 2);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(c.h_sums, c.p_sums.p, static_cast<size_t>(height) * 16, hipMemcpyDeviceToHost, c.stream);
+    for (uint32_t b = bands >= 2 ? bands - 2 : 0; b < bands && e == hipSuccess; ++b) copy_on(b);
+    const hipError_t e2 = hipStreamSynchronize(c.stream); // (also after an error: nothing of ours in flight when the events go)
+    (void)hipStreamSynchronize(c.upload_stream);
+    if (e == hipSuccess) e = e2;
+    for (hipEvent_t ev : up) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : down) if (ev) (void)hipEventDestroy(ev);
+    if (e != hipSuccess) return hip_fail(e, "PNG filter stage in bands");
+    *adler = combine_adler(c.h_sums, height, row_out);
+    return PIXO_OK;
+}
 } // namespace
 
 extern "C" {
@@ -82,38 +142,13 @@ int pixo_hip_png_filter(const uint8_t *data, size_t data_len, uint32_t width, ui
     PIXO_ON_DEVICE_OF(c);
     HIP_TRY(c.p_in.reserve((in_bytes + 15) & ~size_t{15}));
     HIP_TRY(c.p_out.reserve(out_bytes));
-    HIP_TRY(hipMemcpyAsync(c.p_in.p, data, in_bytes, hipMemcpyHostToDevice, c.stream));
-    if ((rc = png_filter_on_device(c, c.p_in.p, width, height, bytes_per_pixel, run, seq, c.p_out.p, adler32))) return rc;
-    // The stream's way to the caller (round 3).  A device-to-host copy straight into pageable storage makes the runtime
-    // fault in and pin the pages as it goes: 30-39 ms for the 67 MB of a 4096x4096 RGBA image, where the bytes need 1.3 ms
-    // on the link.  So, like the JPEG files: into the context's pinned buffer in pieces of 8 MiB, each piece copied on by
-    // the library's copy threads while the next one crosses PCIe, with a huge-page hint for storage not yet touched.
-    if (out_bytes < (size_t{4} << 20)) {
+    if (out_bytes < (size_t{4} << 20)) { // small: one copy each way
+        HIP_TRY(hipMemcpyAsync(c.p_in.p, data, in_bytes, hipMemcpyHostToDevice, c.stream));
+        if ((rc = png_filter_on_device(c, c.p_in.p, width, height, bytes_per_pixel, run, seq, c.p_out.p, adler32))) return rc;
         HIP_TRY(hipMemcpy(out, c.p_out.p, out_bytes, hipMemcpyDeviceToHost));
         return PIXO_OK;
     }
-    if ((rc = c.reserve_hfile(out_bytes))) return rc;
-    advise_huge(out, out_bytes);
-    constexpr size_t kPiece = size_t{8} << 20;
-    const size_t pieces = (out_bytes + kPiece - 1) / kPiece;
-    std::vector<hipEvent_t> arrived(pieces, nullptr);
-    hipError_t e = hipSuccess;
-    for (size_t i = 0; i < pieces && e == hipSuccess; ++i) {
-        const size_t off = i * kPiece, n = std::min(kPiece, out_bytes - off);
-        e = hipEventCreateWithFlags(&arrived[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipMemcpyAsync(c.h_file + off, static_cast<const uint8_t *>(c.p_out.p) + off, n, hipMemcpyDeviceToHost, c.stream);
-        if (e == hipSuccess) e = hipEventRecord(arrived[i], c.stream);
-    }
-    for (size_t i = 0; i < pieces && e == hipSuccess; ++i) {
-        const size_t off = i * kPiece, n = std::min(kPiece, out_bytes - off);
-        e = hipEventSynchronize(arrived[i]);
-        if (e == hipSuccess) big_copy(out + off, c.h_file + off, n);
-    }
-    if (e != hipSuccess) (void)hipStreamSynchronize(c.stream); // (nothing of ours in flight when the events go)
-    for (hipEvent_t ev : arrived)
-        if (ev) (void)hipEventDestroy(ev);
-    if (e != hipSuccess) return hip_fail(e, "device-to-host copy of the filtered stream");
-    return PIXO_OK;
+    return png_filter_in_bands(c, data, width, height, bytes_per_pixel, run, seq, out, adler32);
 }
 
 int pixo_hip_png_filter_async(const void *d_data, uint32_t width, uint32_t height, uint32_t bytes_per_pixel,

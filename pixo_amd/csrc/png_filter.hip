@@ -489,6 +489,7 @@ __global__ __launch_bounds__(kThreads) void png_bigrams_regs_kernel(const Args a
     const uint32_t nb = gridDim.x, full = nb & ~255u; // rows in chunks of 32 per XCD (png_filter_kernel)
     uint32_t y = blockIdx.x;
     if (y < full) { const uint32_t xcd = y & 7u, i = y >> 3; y = (((i >> 5) * 8u + xcd) << 5) + (i & 31u); }
+    y += a.first_row;
     const int n = (int)a.row_bytes, ndw = (n + 3) / 4, tid = (int)threadIdx.x;
     const uint8_t *row = a.data + (size_t)y * a.row_bytes;
     const uint8_t *prev = y ? row - a.row_bytes : nullptr;
@@ -569,6 +570,17 @@ hipError_t launch_png_filter(const void *d_data, uint32_t width, uint32_t height
                              bool sequential_fast, void *d_out, unsigned long long *d_row_sums, int *d_scratch,
                              hipStream_t stream)
 {
+    return launch_png_filter_rows(d_data, width, height, bpp, strategy, sequential_fast, d_out, d_row_sums, d_scratch, 0, height, stream);
+}
+
+// Rows [first_row, first_row + rows) of the image (the row above the first one must be in d_data already): the host-pixel
+// entry uploads, filters and downloads a large image band by band.  The stateful AdaptiveFast needs the whole image.
+hipError_t launch_png_filter_rows(const void *d_data, uint32_t width, uint32_t height, uint32_t bpp, int strategy,
+                                  bool sequential_fast, void *d_out, unsigned long long *d_row_sums, int *d_scratch,
+                                  uint32_t first_row, uint32_t rows, hipStream_t stream)
+{
+    if (rows == 0) return hipSuccess;
+    if (first_row + rows > height) return hipErrorInvalidValue;
     Args a;
     a.data = static_cast<const uint8_t *>(d_data);
     a.out = static_cast<uint8_t *>(d_out);
@@ -587,13 +599,15 @@ hipError_t launch_png_filter(const void *d_data, uint32_t width, uint32_t height
     if (strategy == PNG_S_ADAPTIVE_FAST && sequential_fast && height > 1) {
         // sequential AdaptiveFast (filter.rs:147-167): the first row's winner (always Sub, Up or
         // Paeth) is forced on every later row; two launches, no host round trip
+        if (first_row != 0 || rows != height) return hipErrorInvalidValue;
         a.winner0 = d_scratch;
         hipError_t e = launch_rows(a, 1, bpp, fast, stream);
         if (e != hipSuccess) return e;
         a.winner0 = nullptr; a.forced = d_scratch; a.first_row = 1;
         return launch_rows(a, height - 1, bpp, fast, stream);
     }
-    return launch_rows(a, height, bpp, fast, stream);
+    a.first_row = first_row;
+    return launch_rows(a, rows, bpp, fast, stream);
 }
 
 } // namespace pixo_dev

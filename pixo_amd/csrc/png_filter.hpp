@@ -17,5 +17,10 @@ enum { PNG_S_NONE = 0, PNG_S_SUB, PNG_S_UP, PNG_S_AVERAGE, PNG_S_PAETH, PNG_S_MI
 hipError_t launch_png_filter(const void *d_data, uint32_t width, uint32_t height, uint32_t bpp, int strategy,
                              bool sequential_fast, void *d_out, unsigned long long *d_row_sums, int *d_scratch,
                              hipStream_t stream);
+// rows [first_row, first_row + rows) only (the row above the first must already be in d_data; not for the stateful
+// AdaptiveFast, which needs row 0's decision first)
+hipError_t launch_png_filter_rows(const void *d_data, uint32_t width, uint32_t height, uint32_t bpp, int strategy,
+                                  bool sequential_fast, void *d_out, unsigned long long *d_row_sums, int *d_scratch,
+                                  uint32_t first_row, uint32_t rows, hipStream_t stream);
 
 } // namespace pixo_dev

@@ -168,10 +168,11 @@ int pixo_hip_jpeg_coeffs(const uint8_t *pixels, uint32_t width, uint32_t height,
     if (g.c_blocks && (!cb || !cr)) return fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'cb'/'cr'");
     const int16_t *hy, *hcb, *hcr;
     if ((rc = coeffs_to_pinned(thread_context(), pixels, o, g, &hy, &hcb, &hcr))) return rc;
-    std::memcpy(y, hy, g.y_blocks * 128);
+    // (the library's copy threads and a huge-page hint for large planes: 50 MB into a caller's fresh arrays)
+    big_copy(reinterpret_cast<uint8_t *>(y), reinterpret_cast<const uint8_t *>(hy), g.y_blocks * 128);
     if (g.c_blocks) {
-        std::memcpy(cb, hcb, g.c_blocks * 128);
-        std::memcpy(cr, hcr, g.c_blocks * 128);
+        big_copy(reinterpret_cast<uint8_t *>(cb), reinterpret_cast<const uint8_t *>(hcb), g.c_blocks * 128);
+        big_copy(reinterpret_cast<uint8_t *>(cr), reinterpret_cast<const uint8_t *>(hcr), g.c_blocks * 128);
     }
     return PIXO_OK;
 }

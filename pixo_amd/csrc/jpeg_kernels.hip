@@ -22,7 +22,7 @@ constexpr bool kDot4 = false;
 constexpr bool kDot4 = true;
 #endif
 
-// Kernel arguments.  The kernel takes the first 14 dwords as separate parameters, in this order, and is compiled with
+// Kernel arguments.  The kernel takes the first 15 dwords as separate parameters, in this order, and is compiled with
 // -mllvm -amdgpu-kernarg-preload-count=14 (Makefile): the command processor hands them to every wavefront in SCALAR
 // REGISTERS at launch.  Read from the kernarg segment with s_load instead, they are the first thing every wavefront waits
 // for — and the wavefronts that start a microsecond late queue behind the 50 MB of pixel loads the early ones have already
@@ -187,8 +187,8 @@ __device__ __forceinline__ void store_raw_block(const KArgs &a, const TileCtx &c
 }
 
 template <int MODE, int LOAD, bool RAW = false>
-__global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(const uint8_t *a_px, uint32_t a_W, uint32_t a_H, size_t a_px_stride, int16_t *a_y,
-                                                                              int16_t *a_cb, int16_t *a_cr, const float *a_qt, const KRest rest)
+__global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(const uint8_t *a_px, uint32_t a_W, uint32_t a_H, size_t a_px_stride, uint32_t a_grid,
+                                                                              uint32_t a_unused, int16_t *a_y, int16_t *a_cb, int16_t *a_cr, const float *a_qt, const KRest rest)
 {
     typedef Geo<MODE> G;
     __shared__ __attribute__((aligned(16))) uint8_t lds[G::planar];
@@ -220,9 +220,12 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     // (profiles/r03_stagger_444.txt).  Later generations are not touched (every odd thousand late: the batch loses 6 %).
     // On the fastest kind of box the late start COSTS 1 % (17.36 -> 17.55 us; 4:4:4 29.3 -> 29.8): accepted for the 4-8 % it
     // gains on the others.
-    {
-        const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if ((lin >> 10) == 1u && gridDim.x * gridDim.y * gridDim.z >= 2048u) __builtin_amdgcn_s_sleep(127); // (a full first generation only)
+    // (the grid's shape comes as a preloaded argument — tiles_x | tiles_y << 8 | "2048 workgroups or more" << 31: gridDim
+    // would be a scalar load from the hidden arguments and a wait for it in front of every wavefront's first instruction)
+    if (a_grid >> 31) {
+        const uint32_t gx = a_grid & 0xFFu, gy = (a_grid >> 8) & 0xFFFFu;
+        const uint32_t lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        if ((lin >> 10) == 1u) __builtin_amdgcn_s_sleep(127); // (a full first generation only)
     }
 #endif
     const TileId id{blockIdx.z, blockIdx.x, blockIdx.y}; // (a 3-D grid: no division on the way to the first load)
@@ -285,8 +288,10 @@ template <int MODE, int LOAD> static hipError_t launch_mode(KArgs &a, hipStream_
 #if defined(PIXO_PROBE)
     rest.probe_launch = a.probe_launch;
 #endif
-    if (raw) hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, true>), grid, dim3(kThreads), 0, s, a.px, a.W, a.H, a.px_stride, a.y, a.cb, a.cr, a.qt, rest);
-    else hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, false>), grid, dim3(kThreads), 0, s, a.px, a.W, a.H, a.px_stride, a.y, a.cb, a.cr, a.qt, rest);
+    // tiles_x <= 128 (65535 / 512), tiles_y <= 8192 (65535 / 8)
+    const uint32_t a_grid = grid.x | (grid.y << 8) | ((uint64_t)grid.x * grid.y * grid.z >= 2048u ? 0x80000000u : 0u);
+    if (raw) hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, true>), grid, dim3(kThreads), 0, s, a.px, a.W, a.H, a.px_stride, a_grid, 0u, a.y, a.cb, a.cr, a.qt, rest);
+    else hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, false>), grid, dim3(kThreads), 0, s, a.px, a.W, a.H, a.px_stride, a_grid, 0u, a.y, a.cb, a.cr, a.qt, rest);
     return hipGetLastError();
 }
 

@@ -218,14 +218,15 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     // 18.35 us on one box of the pool, nothing gained or lost (17.4) on a faster one, two sleeps or other halves worse
     // (profiles/r03_stagger_and_occupancy_ab.txt); the 4:4:4 kernel, two generations per 4096x4096 image: 33.8 -> 30.9 us
     // (profiles/r03_stagger_444.txt).  Later generations are not touched (every odd thousand late: the batch loses 6 %).
-    // On the fastest kind of box the late start COSTS 1 % (17.36 -> 17.55 us; 4:4:4 29.3 -> 29.8): accepted for the 4-8 % it
-    // gains on the others.
+    // With the grid's shape pre-loaded (below) the gain is 19.9-20.6 -> 18.3 us on a medium box and 21.8 -> 19.1 us on a slow
+    // one (profiles/r03_stagger_length_ab.txt); on the fastest kind of box it was within +-1 %.
     // (the grid's shape comes as a preloaded argument — tiles_x | tiles_y << 8 | "2048 workgroups or more" << 31: gridDim
     // would be a scalar load from the hidden arguments and a wait for it in front of every wavefront's first instruction)
     if (a_grid >> 31) {
         const uint32_t gx = a_grid & 0xFFu, gy = (a_grid >> 8) & 0xFFFFu;
         const uint32_t lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        if ((lin >> 10) == 1u) __builtin_amdgcn_s_sleep(127); // (a full first generation only)
+        if ((lin >> 10) == 1u) __builtin_amdgcn_s_sleep(127); // (a full first generation only; 112..160 units are a plateau, 96 or 200 lose most of it;
+                                                                 //  quarters or thirds with graded delays are no better)
     }
 #endif
     const TileId id{blockIdx.z, blockIdx.x, blockIdx.y}; // (a 3-D grid: no division on the way to the first load)

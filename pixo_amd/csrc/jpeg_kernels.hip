@@ -290,6 +290,7 @@ template <int MODE, int LOAD> static hipError_t launch_mode(KArgs &a, hipStream_
     rest.probe_launch = a.probe_launch;
 #endif
     // tiles_x <= 128 (65535 / 512), tiles_y <= 8192 (65535 / 8)
+    // (launches of 1280-1792 workgroups neither gain nor lose with it: tools/shape_timing.py, profiles/r03_stagger_length_ab.txt)
     const uint32_t a_grid = grid.x | (grid.y << 8) | ((uint64_t)grid.x * grid.y * grid.z >= 2048u ? 0x80000000u : 0u);
     if (raw) hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, true>), grid, dim3(kThreads), 0, s, a.px, a.W, a.H, a.px_stride, a_grid, 0u, a.y, a.cb, a.cr, a.qt, rest);
     else hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, false>), grid, dim3(kThreads), 0, s, a.px, a.W, a.H, a.px_stride, a_grid, 0u, a.y, a.cb, a.cr, a.qt, rest);

@@ -59,6 +59,11 @@ int hip_fail(hipError_t e, const char *what); // pixo::Error::CompressionError(S
 struct DebugSwitches {
     bool trace = false, host_entropy = false, multipass_entropy = false, direct_stores = false, one_piece = false;
     bool piece_medium_forced = false, no_bands_upload = false;
+    // host pixels are uploaded in bands from this many MiB of pixels on (bands_upload_min_mb=n), in bands of about
+    // bands_upload_mb=n MiB.  A 4096x4096 RGB image (48 MiB) in six bands of 8 MiB: noise 1.18 -> 1.14 ms into caller storage,
+    // but a smooth image 0.99 -> 1.10 ms and the malloc'ing entry 1.43 -> 1.55: not below 96 MiB (profiles/r03_host_bands_probe.txt)
+    uint32_t bands_upload_min_mb = 96;
+    uint32_t bands_upload_mb = 12;
     uint64_t piece_groups = 2048, piece_medium = 1024;
     std::vector<uint32_t> piece_schedule{1, 3};
     unsigned copy_threads = 8;

@@ -105,7 +105,7 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
     if (from_host) { // pixels still in host memory: pieces sized for the UPLOAD pipeline — about 12 MB of pixels each, so that
         // a band's kernels (tens of microseconds) disappear behind the next band's way over PCIe (>= 100 us)
         const uint64_t px_bytes = static_cast<uint64_t>(src->o->width) * src->o->height * (src->g->gray ? 1 : 3);
-        const uint32_t want = static_cast<uint32_t>(std::min<uint64_t>(kMaxPieces, std::max<uint64_t>(2, px_bytes / (12u << 20))));
+        const uint32_t want = static_cast<uint32_t>(std::min<uint64_t>(kMaxPieces, std::max<uint64_t>(2, px_bytes / (uint64_t{debug().bands_upload_mb} << 20))));
         for (uint32_t k = 0; k < want; ++k) {
             const uint64_t g0 = groups * k / want;
             if (pieces == 0 || g0 > begin[pieces - 1]) begin[pieces++] = g0;
@@ -342,7 +342,7 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
     // alone at 53 GB/s.  Below that the two extra threads' hand-offs cost what the overlap gains (4096x4096: 1.18 ms either
     // way, of which 0.95 are the upload; profiles/r03_host_pipeline.txt).  Whatever path is taken, the pixels are uploaded once.
     bool host_px_pending = src && src->host_px;
-    const bool host_bands = host_px_pending && static_cast<uint64_t>(o.width) * o.height * (g.gray ? 1 : 3) >= (uint64_t{96} << 20) &&
+    const bool host_bands = host_px_pending && static_cast<uint64_t>(o.width) * o.height * (g.gray ? 1 : 3) >= (uint64_t{debug().bands_upload_min_mb} << 20) &&
                             !debug().no_bands_upload;
     auto upload_all = [&]() -> int {
         if (!host_px_pending) return PIXO_OK;

@@ -404,7 +404,13 @@ def run_coeffs(job, args):
     walls, evs = job.time_blocks(wl.step, args.steps, args.warmup, args.blocks)
     if job.rank == 0 and not job.stub and not os.environ.get("PIXO_BENCH_ABLATION"):
         wl.check()
+    multi = (not args.no_extras) and args.workload == "c2" and not os.environ.get("PIXO_BENCH_ABLATION")
     if job.rank != 0:
+        if multi:
+            del wl
+            if not job.stub:
+                job.torch.cuda.empty_cache()
+            multi_gpu_extras(job, args)
         job.finish()
         return
     st = block_stats(walls, args.steps)
@@ -456,6 +462,16 @@ def run_coeffs(job, args):
         except BaseException as ex:
             others["c5"] = {"error": repr(ex)}
         line["other_configs"] = others
+    if multi:
+        # configs[3] and configs[2] over the ranks of this run (N = 1: a world of one, the same calls), and what RCCL saw
+        for key in ("ins", "outs"):
+            if hasattr(wl, key):
+                delattr(wl, key)
+        if not job.stub:
+            job.torch.cuda.empty_cache()
+        m = multi_gpu_extras(job, args)
+        line["rccl"] = m.pop("rccl", None)
+        line.setdefault("other_configs", {}).update(m)
     if not args.no_cpu_baseline and job.world == 1 and not job.stub:
         try:
             line["cpu_baseline"] = cpu_baseline(4096, 4096, wl.ss, wl.q, args.cpu_seconds)
@@ -620,71 +636,257 @@ def run_png(job, args):
 # ------------------------------------------------------------------------------------------------------------------
 # c4: one 16384x16384 image over the N GPUs
 # ------------------------------------------------------------------------------------------------------------------
-def run_c4(job, args):
-    """configs[3]: MCU-row bands of ONE image resident on the N GPUs; a step = the finished file on rank 0.
-    Strong scaling: the image is fixed, every rank holds 1/N of it."""
-    import numpy as np
-    import synth
-    from pixo_amd import jpeg, sharded
-    torch = job.torch
-    w = h = 16384
-    q = args.quality
-    opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling.S420).build()
-    b = jpeg.band(w, h, 2, 1, job.world, job.rank)
-    rows = b["row_end"] - b["row_begin"]
-    if job.dist is None:  # the exchanges are torch.distributed calls: a world of one still needs a group
+def ensure_group(job):
+    """The exchanges of pixo_amd/sharded.py are torch.distributed calls: a world of one still needs a group."""
+    if job.dist is None:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
-        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=job.dev)
+        if job.stub:
+            dist.init_process_group(backend="gloo", rank=0, world_size=1)
+        else:
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=job.dev)
         job.dist = dist
+
+
+def agree(job, ok):
+    """True when EVERY rank says ok (one MIN all_reduce): a rank that failed to prepare an extra workload must not leave the
+    others inside that workload's collectives."""
+    if job.dist is None:
+        return bool(ok)
+    t = job.torch.tensor([1 if ok else 0], dtype=job.torch.int64, device=job.dev)
+    job.dist.all_reduce(t, op=job.dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def rccl_evidence(job):
+    """What the process group really was in this run: ranks seen, backend, library version, the device behind every rank,
+    and one all_reduce whose result only comes out right when all ranks took part."""
+    torch, dist = job.torch, job.dist
+    out = {"world": dist.get_world_size(), "backend": dist.get_backend()}
+    t = torch.tensor([job.rank + 1], dtype=torch.int64, device=job.dev)
+    dist.all_reduce(t)
+    out["all_reduce_of_rank_plus_1"] = int(t.item())
+    out["all_reduce_expected"] = job.world * (job.world + 1) // 2
+    if job.stub:
+        mine = {"rank": job.rank, "device": "cpu (stub)", "pid": os.getpid()}
+    else:
+        pr = torch.cuda.get_device_properties(job.dev)
+        mine = {"rank": job.rank, "device": job.local_rank, "name": pr.name, "pci_bus_id": getattr(pr, "pci_bus_id", None),
+                "uuid": str(getattr(pr, "uuid", "")), "pid": os.getpid()}
+        try:
+            out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            pass
+    seen = [None] * job.world
+    dist.all_gather_object(seen, mine)
+    out["devices"] = seen
+    return out
+
+
+def measure_c4(job, q, steps, warmup, blocks, settle_ms):
+    """configs[3]: MCU-row bands of ONE 16384x16384 image resident on the N GPUs; a step = the finished file on rank 0.
+    Strong scaling: the image is fixed, every rank holds 1/N of it.  Every rank calls; rank 0 gets the result dict.
+    --stub: a 256x192 image through the host twins over gloo (plumbing), the oracle's file as the reference."""
+    import synth
+    from pixo_amd import jpeg, sharded
+    torch = job.torch
+    ensure_group(job)
+    w, h = (256, 192) if job.stub else (16384, 16384)
+    opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling.S420).build()
+    b = jpeg.band(w, h, 2, 1, job.world, job.rank)
+    rows = b["row_end"] - b["row_begin"]
     mine = synth.noise_rows(w, h, 42, b["row_begin"], b["row_end"])
-    d_band = torch.from_numpy(mine).to(job.dev)
-    out = torch.empty(w * h * 3 // 4 + (1 << 20), dtype=torch.uint8).pin_memory() if job.rank == 0 else None
     state = {}
+    if job.stub:
+        import oracle_lib as O
 
-    def step(i):
-        state["len"] = sharded.encode_banded(d_band, opts, device=job.local_rank, out=out)
+        def step(i):
+            state["file"] = sharded.encode_banded(mine, opts, coeff_fn=lambda sub, o: O.coeffs(sub, o.width, o.height, 2, 1, o.quality))
+        kev = None
+    else:
+        d_band = torch.from_numpy(mine).to(job.dev)
+        out = torch.empty(w * h * 3 // 4 + (1 << 20), dtype=torch.uint8).pin_memory() if job.rank == 0 else None
 
-    # the coefficient kernel of this rank's band alone (roofline object), HIP events on the launch stream
-    yb, cbn = jpeg.coefficient_geometry(w, rows, 2, 1)
-    ty = torch.empty((yb, 64), dtype=torch.int16, device=job.dev)
-    tcb = torch.empty((cbn, 64), dtype=torch.int16, device=job.dev)
-    tcr = torch.empty((cbn, 64), dtype=torch.int16, device=job.dev)
-    stream = torch.cuda.current_stream().cuda_stream
+        def step(i):
+            state["len"] = sharded.encode_banded(d_band, opts, device=job.local_rank, out=out)
 
-    def kstep(i):
-        jpeg.coefficients_device(d_band, w, rows, 2, 1, q, ty, tcb, tcr, stream=stream)
+        # the coefficient kernel of this rank's band alone (roofline object), HIP events on the launch stream
+        yb, cbn = jpeg.coefficient_geometry(w, rows, 2, 1)
+        ty = torch.empty((yb, 64), dtype=torch.int16, device=job.dev)
+        tcb = torch.empty((cbn, 64), dtype=torch.int16, device=job.dev)
+        tcr = torch.empty((cbn, 64), dtype=torch.int16, device=job.dev)
+        stream = torch.cuda.current_stream().cuda_stream
 
-    job.settle(kstep, args.settle_ms)
-    _, kev = job.time_blocks(kstep, 20, 5, 5)
-    del ty, tcb, tcr
+        def kstep(i):
+            jpeg.coefficients_device(d_band, w, rows, 2, 1, q, ty, tcb, tcr, stream=stream)
+
+        job.settle(kstep, settle_ms)
+        _, kev = job.time_blocks(kstep, 20, 5, 5)
+        del ty, tcb, tcr
+    walls, _ = job.time_blocks(step, steps, warmup, blocks, events=False)
+    if job.rank != 0:
+        return None
+    if job.stub:
+        blob = state["file"]
+        n, digest = len(blob), hashlib.sha256(blob).hexdigest()
+        want = hashlib.sha256(O.encode(synth.noise(w, h, 42), O.make_options(w, h, 2, q, 1))).hexdigest()
+        if digest != want:
+            raise RuntimeError("the banded file differs from the oracle's")
+    else:
+        n = state["len"]
+        digest = hashlib.sha256(out[:n].numpy().tobytes()).hexdigest()
+        if (n != 178548465 or digest != C4_SHA256) and not os.environ.get("PIXO_BENCH_ABLATION"):
+            raise RuntimeError("the 16384x16384 file differs from the reference's (sha256 %s)" % digest)
+    st = block_stats(walls, steps)
+    res = {"value": round(w * h / (st["ms_per_step"] * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "n_gpus": job.world, "steps": steps,
+           "warmup": warmup, **st, "scaling": "strong",
+           "config": {"workload": "configs[3]: single %dx%d RGB8 (noise seed 42) in MCU-row bands across the GPUs, per-band entropy "
+                                  "coding, 3 x i16 + u64 exchanged per band over RCCL, bodies gathered over xGMI, spliced on rank 0" % (w, h),
+                      "width": w, "height": h, "quality": q, "subsampling": "4:2:0", "band_rows_rank0": rows,
+                      "file_bytes": int(n), "file_sha256": digest, "sha256_is_the_reference_s": (not job.stub) and digest == C4_SHA256,
+                      "parallelism": "one process per GPU, one band per rank"},
+           "roofline": None}
+    if kev:
+        kernel_ms = statistics.median(kev) / 20
+        alg = 6 * w * rows
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        res["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "jpeg_coeffs_kernel<M420, L_ALIGNED> on rank 0's band",
+                           "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3)}
+    return res
+
+
+def run_c4(job, args):
     steps = max(1, min(args.steps, 20))
-    walls, _ = job.time_blocks(step, steps, max(1, min(args.warmup, 3)), max(3, min(args.blocks, 7)), events=False)
+    warmup = max(1, min(args.warmup, 3))
+    try:
+        res = measure_c4(job, args.quality, steps, warmup, max(3, min(args.blocks, 7)), args.settle_ms)
+    except RuntimeError as ex:
+        raise SystemExit("bench: %s — refusing to report a number" % ex)
     if job.rank != 0:
         job.finish()
         return
-    n = state["len"]
-    digest = hashlib.sha256(out[:n].numpy().tobytes()).hexdigest()
-    if (n != 178548465 or digest != C4_SHA256) and not os.environ.get("PIXO_BENCH_ABLATION"):
-        raise SystemExit("bench: the 16384x16384 file differs from the reference's — refusing to report a number")
-    st = block_stats(walls, steps)
-    kernel_ms = statistics.median(kev) / 20
-    alg = 6 * w * rows
-    achieved = alg / (kernel_ms * 1e-3) / 1e9
     line = {"metric": "Mpixels/s JPEG encode, whole file, one 16384x16384 RGB8 image q=80 4:2:0 across the GPUs (configs[3])",
-            "value": round(w * h / (st["ms_per_step"] * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "n_gpus": job.world, "steps": steps,
-            "warmup": max(1, min(args.warmup, 3)), "ms_per_step": st["ms_per_step"], "ms_per_step_min": st["ms_per_step_min"],
-            "ms_per_step_max": st["ms_per_step_max"], "blocks": st["blocks"], "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[3]: single 16384x16384 RGB8 (noise seed 42) in MCU-row bands across the GPUs, per-band entropy "
-                                   "coding, 3 x i16 + u64 exchanged per band over RCCL, bodies gathered over xGMI, spliced on rank 0",
-                       "width": w, "height": h, "quality": q, "subsampling": "4:2:0", "band_rows_rank0": rows,
-                       "file_bytes": int(n), "file_sha256": digest, "parallelism": "one process per GPU, one band per rank"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "jpeg_coeffs_kernel<M420, L_ALIGNED> on rank 0's band",
-                         "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3)}}
+            "value": res["value"], "unit": "Mpixels/s", "n_gpus": job.world, "steps": steps, "warmup": warmup,
+            "ms_per_step": res["ms_per_step"], "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_max": res["ms_per_step_max"],
+            "blocks": res["blocks"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "stub" if job.stub else "synthetic", "config": res["config"], "roofline": res["roofline"]}
     job.finish(line)
+
+
+C3_IMAGE0_SHA256 = "d1811ba1761f6b2a76d7f2c3d43418784f38909e0b20af631d5ead73e7d9436a"  # SURVEY §8c: noise(1920,1080,42), made by the reference
+
+
+def measure_c3_sharded(job, q, steps, warmup, blocks):
+    """configs[2] on a node (SURVEY §8e "C3 batch"): 64 x 1920x1080 images RESIDENT ON RANK 0's GPU; a step =
+    sharded.encode_batch: whole images to the ranks point to point over xGMI, every rank encodes its share, the files come
+    back to rank 0 the same way and cross PCIe once into a pinned arena.  Strong scaling (the batch is fixed).
+    --stub: 16 images of 32x24 through the oracle over gloo (plumbing)."""
+    import numpy as np
+    import synth
+    from pixo_amd import jpeg, sharded
+    import oracle_lib as O
+    torch = job.torch
+    ensure_group(job)
+    w, h, n = (32, 24, 16) if job.stub else (1920, 1080, 64)
+    opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling.S420).build()
+    oo = O.make_options(w, h, 2, q, 1)
+    d = out = None
+    if job.rank == 0:
+        host = torch.from_numpy(np.concatenate([synth.noise(w, h, 42 + i) for i in range(n)]))
+        d = host if job.stub else host.to(job.dev)
+        out = None if job.stub else torch.empty(n * w * h, dtype=torch.uint8).pin_memory()
+    px = w * h * 3
+    fn = (lambda chunk, o, count: [O.encode(chunk[i * px: (i + 1) * px], oo) for i in range(count)]) if job.stub else None
+    state = {}
+
+    def step(i):
+        state["got"] = sharded.encode_batch(d, opts, n, encode_fn=fn, out=out, device=None if job.stub else job.local_rank)
+
+    walls, _ = job.time_blocks(step, steps, warmup, blocks, events=False)
+    if job.rank != 0:
+        return None
+    arena, offs, lens = state["got"]
+    parts = sharded.batch_partition(n, job.world)
+    sample = sorted({a for a, b in parts if b > a} | {n - 1})  # the first file of every rank's share + the last file
+    for i in sample:
+        f = arena[offs[i]: offs[i] + lens[i]].numpy().tobytes()
+        if f != O.encode(synth.noise(w, h, 42 + i), oo):
+            raise RuntimeError("file %d of the sharded batch differs from the oracle's" % i)
+    sha0 = hashlib.sha256(arena[offs[0]: offs[0] + lens[0]].numpy().tobytes()).hexdigest()
+    if not job.stub and q == 80 and sha0 != C3_IMAGE0_SHA256:
+        raise RuntimeError("file 0 of the sharded batch differs from the reference's")
+    st = block_stats(walls, steps)
+    return {"value": round(w * h * n / (st["ms_per_step"] * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "n_gpus": job.world, "steps": steps, "warmup": warmup,
+            **st, "scaling": "strong",
+            "config": {"workload": "configs[2] on a node: %d x %dx%d RGB8 noise (seeds 42..%d) resident on rank 0, q=%d 4:2:0 -> %d files in rank 0's pinned arena"
+                                   % (n, w, h, 42 + n - 1, q, n),
+                       "images_per_rank": [b - a for a, b in parts], "pixels_scattered_bytes": (n - (parts[0][1] - parts[0][0])) * px,
+                       "file_bytes_total": int(sum(lens)), "files_checked_against_oracle": sample, "file0_sha256": sha0,
+                       "path": "sharded.encode_batch: isend/irecv of whole images (one peer per xGMI link) -> pixo_hip_jpeg_encode_batch_device_into "
+                               "(device arena) per rank -> all_gather of lengths -> isend/irecv of file runs to their final offsets -> one D2H copy"}}
+
+
+def measure_c4_single_process(job, q, n_dev, steps=3, blocks=3):
+    """configs[3] in ONE process (rank 0 only, the other ranks idle): pixo_hip_jpeg_encode_multi drives `n_dev` GPUs from host
+    threads — host pixels in over every GPU's own PCIe link, the file's bodies back the same way."""
+    import synth
+    from pixo_amd import jpeg
+    w = h = 16384
+    opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling.S420).build()
+    px = synth.noise(w, h, 42)
+    devices = list(range(n_dev))
+    blob = jpeg.encode_multi(px, opts, devices)  # (also the warm-up: band workers, contexts, pinned buffers)
+    digest = hashlib.sha256(blob).hexdigest()
+    if len(blob) != 178548465 or digest != C4_SHA256:
+        raise RuntimeError("the single-process 16384x16384 file differs from the reference's (sha256 %s)" % digest)
+    ts = []
+    for _ in range(blocks):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            jpeg.encode_multi(px, opts, devices)
+        ts.append((time.perf_counter() - t0) / steps)
+    ts.sort()
+    return {"value": round(w * h / ts[len(ts) // 2] / 1e6, 1), "unit": "Mpixels/s", "n_gpus": n_dev, "steps": steps, "blocks": blocks,
+            "ms_per_step": round(ts[len(ts) // 2] * 1e3, 3), "ms_per_step_min": round(ts[0] * 1e3, 3), "ms_per_step_max": round(ts[-1] * 1e3, 3),
+            "scaling": "strong",
+            "config": {"workload": "configs[3], single process: pixo_hip_jpeg_encode_multi over devices %s; 805 MB of HOST pixels in over PCIe, "
+                                   "178.5 MB file out as Python bytes" % devices, "file_bytes": len(blob), "file_sha256": digest,
+                       "sha256_is_the_reference_s": True}}
+
+
+def multi_gpu_extras(job, args):
+    """Every rank calls (collectives inside).  configs[3] and configs[2] over the ranks of THIS run + what the process group
+    was.  Each leg under try/except and behind an `agree` round; the metric line does not depend on them."""
+    out = {}
+    try:
+        ensure_group(job)
+        out["rccl"] = rccl_evidence(job)
+    except BaseException as ex:
+        out["rccl"] = {"error": repr(ex)}
+    small = job.stub
+    legs = (("c4", lambda: measure_c4(job, args.quality, 2 if small else 5, 1, 3, 0 if small else QUICK_SETTLE_MS)),
+            ("c3_sharded", lambda: measure_c3_sharded(job, args.quality, 2 if small else 5, 1, 3)))
+    if job.world > 1 and not job.stub:  # (rank 0 alone; the others wait in the next `agree`)
+        legs += (("c4_single_process", lambda: measure_c4_single_process(job, args.quality, job.world) if job.rank == 0 else None),)
+    for name, fn in legs:
+        t0 = time.perf_counter()
+        if not agree(job, True):
+            out[name] = {"error": "a rank could not start this leg"}
+            continue
+        try:
+            res = fn()
+            ok = True
+        except BaseException as ex:  # (a rank-local failure after the collectives: the others have finished the leg)
+            res, ok = {"error": repr(ex)}, False
+        if job.rank == 0:
+            if isinstance(res, dict):
+                res["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+            out[name] = res
+        if not job.stub:
+            job.torch.cuda.empty_cache()
+    return out
 
 
 def run_c4_single_process(job, args):

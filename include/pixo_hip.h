@@ -177,7 +177,10 @@ int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_opti
  * offsets[batch - 1] + lens[batch - 1]) and PIXO_ERR_BUFFER_TOO_SMALL is returned; a null arena with capacity 0 is a size
  * query (nothing is copied).  Batches of 64 MB of pixels and more are coded in sub-batches whose files cross PCIe while the
  * next sub-batch's kernels run (two of the library's contexts alternate): an arena that turns out too small may then
- * hold the files of the first sub-batches.  Replaces a loop over pixo::jpeg::encode_into (src/jpeg/mod.rs:328). */
+ * hold the files of the first sub-batches.  `arena` may also be DEVICE memory (hipMalloc, on the current device): the
+ * files then stay in HBM, complete with headers and EOI, for a caller that moves them on itself — pixo_amd/sharded.py
+ * gathers the files of a batch that was scattered over several GPUs with RCCL ("C3 batch").
+ * Replaces a loop over pixo::jpeg::encode_into (src/jpeg/mod.rs:328). */
 int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg_options *options, uint32_t batch,
                                            uint8_t *arena, size_t capacity, size_t *offsets, size_t *lens);
 

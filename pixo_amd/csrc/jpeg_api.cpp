@@ -481,6 +481,30 @@ int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg
     const pixo_host::Geometry g = pixo_host::geometry(o.width, o.height, o.color_type, o.subsampling);
     const size_t px_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
     for (uint32_t i = 0; i < batch; ++i) { offsets[i] = 0; lens[i] = 0; }
+    bool arena_pinned = false, arena_device = false;
+    if (arena) {
+        hipPointerAttribute_t pa;
+        if (hipPointerGetAttributes(&pa, arena) == hipSuccess) {
+            arena_pinned = pa.type == hipMemoryTypeHost;
+            arena_device = pa.type == hipMemoryTypeDevice;
+        } else (void)hipGetLastError(); // (plain malloc'd memory is "invalid value" to the runtime: not an error)
+    }
+    if (!batch_in_one_pass(o, g, batch, px_bytes) && arena_device) { // per-image tables / segments inside the images, files to stay in HBM:
+        size_t at = 0;                                                // each image through a host file, then host-to-device behind the one before
+        hipError_t e = hipSuccess;
+        for (uint32_t i = 0; i < batch && e == hipSuccess; ++i) {
+            uint8_t *f = nullptr;
+            size_t n = 0;
+            if ((rc = pixo_hip_jpeg_encode_device(static_cast<const uint8_t *>(d_pixels) + i * px_bytes, options, &f, &n))) return rc;
+            offsets[i] = at; lens[i] = n;
+            if (at + n <= capacity) e = hipMemcpy(arena + at, f, n, hipMemcpyHostToDevice);
+            at += n;
+            pixo_hip_free(f);
+        }
+        if (e != hipSuccess) return hip_fail(e, "host-to-device copy of a batch file");
+        if (at > capacity) return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(at) + " bytes");
+        return PIXO_OK;
+    }
     if (!batch_in_one_pass(o, g, batch, px_bytes)) { // one image at a time, each straight into its place behind the one before
         size_t at = 0;
         bool fits = true;
@@ -517,13 +541,7 @@ int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg
     size_t at = 0;
     uint32_t first = 0;
     rc = PIXO_OK;
-    bool arena_pinned = false;
-    if (arena) {
-        hipPointerAttribute_t pa;
-        if (hipPointerGetAttributes(&pa, arena) == hipSuccess && pa.type == hipMemoryTypeHost) arena_pinned = true;
-        else (void)hipGetLastError(); // (plain malloc'd memory is "invalid value" to the runtime: not an error)
-        if (!arena_pinned) advise_huge(arena, capacity);
-    }
+    if (arena && !arena_pinned && !arena_device) advise_huge(arena, capacity);
     for (uint32_t part = 0; part < parts && !rc; ++part) {
         uint32_t nb = (batch - first + (parts - part) - 1) / (parts - part);
         Context &cx = (second && (part & 1)) ? *second : *c;
@@ -539,7 +557,10 @@ int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg
         }
         if (at <= capacity) {
             hipError_t e = hipSuccess;
-            if (gaps && !arena_pinned) { // pageable arena: through the context's pinned buffer + the copy threads (a copy straight
+            if (gaps && arena_device) { // the files stay in HBM (a caller that gathers them over RCCL, pixo_amd/sharded.py): one device-to-device copy
+                const size_t run = static_cast<size_t>(starts[nb]);
+                if (run) e = hipMemcpyAsync(arena + at0 + hdr, cx.e_out.p, run, hipMemcpyDeviceToDevice, cx.stream);
+            } else if (gaps && !arena_pinned) { // pageable arena: through the context's pinned buffer + the copy threads (a copy straight
                                          // into pageable pages makes the runtime fault them in and pin them as it goes)
                 const size_t run = static_cast<size_t>(starts[nb]);
                 if (run) {
@@ -554,7 +575,8 @@ int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg
             } else { // (multi-pass kernels: every file's entropy-coded bytes by a copy of its own)
                 for (uint32_t i = 0; i < nb && e == hipSuccess; ++i) {
                     const size_t seg = lens[first + i] - hdr - 2;
-                    if (seg) e = hipMemcpyAsync(arena + offsets[first + i] + hdr, cx.e_out.as<uint8_t>() + starts[i], seg, hipMemcpyDeviceToHost, cx.stream);
+                    if (seg) e = hipMemcpyAsync(arena + offsets[first + i] + hdr, cx.e_out.as<uint8_t>() + starts[i], seg,
+                                                arena_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, cx.stream);
                 }
             }
             if (e != hipSuccess) rc = hip_fail(e, "device-to-host copy of the batch");
@@ -576,6 +598,18 @@ int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg
     if (rc) return rc;
     if (at > capacity) return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(at) + " bytes");
     const size_t hdr = head.size();
+    if (arena_device) { // headers and EOI markers by small host-to-device copies: EOI of file i and the headers of file i + 1 are neighbours
+        std::vector<uint8_t> seam(hdr + 2);
+        seam[0] = 0xFF; seam[1] = 0xD9;
+        std::memcpy(seam.data() + 2, head.data(), hdr);
+        hipError_t e = hipMemcpyAsync(arena, seam.data() + 2, hdr, hipMemcpyHostToDevice, c->stream);
+        for (uint32_t i = 1; i < batch && e == hipSuccess; ++i)
+            e = hipMemcpyAsync(arena + offsets[i] - 2, seam.data(), hdr + 2, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(arena + at - 2, seam.data(), 2, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_fail(e, "headers of the batch files");
+        return PIXO_OK;
+    }
     for (uint32_t i = 0; i < batch; ++i) {
         uint8_t *p = arena + offsets[i];
         std::memcpy(p, head.data(), hdr);

@@ -20,6 +20,11 @@ segments that ignore band boundaries): for those the finished coefficient bands 
 (`encode_gathered*`), which runs the ordinary entropy stage over the stitched tuple.
 
 The process group (RCCL for device tensors, gloo for host arrays) only carries these exchanges.
+
+A BATCH of images that is resident on ONE GPU (BASELINE config 3 on a node, SURVEY §8e "C3 batch") is the other
+multi-GPU form, `encode_batch`: whole images travel from the source rank to the ranks point to point (one peer per
+xGMI link, all posted at once), every rank encodes its images (src/jpeg/mod.rs:88 per image), and the finished FILES
+travel to `dst` the same way — pixels out, files back, never a coefficient.
 """
 import numpy as np
 
@@ -134,6 +139,28 @@ class SharedFile:
             self.shm.unlink()
 
 
+def shared_file_bound(options) -> int:
+    """A `SharedFile` size NO baseline file of these options can exceed: 2 KiB of headers + 416 bytes per 8x8 block (a DC
+    symbol of <= 16 + 11 bits and 63 AC symbols of <= 16 + 10 bits are 1,665 bits = 209 bytes, and byte stuffing at most
+    doubles them).  Real files are far smaller (noise at quality 80: 11 bytes per block) and untouched pages of a shared
+    segment cost nothing, but a segment that is `register()`ed is pinned whole: choose a smaller one from what the content
+    is known to need — `encode_banded` raises BufferTooSmall (`.needed`) on EVERY rank, before any byte moves, when the
+    file turns out larger than the segment."""
+    w, h = options.width, options.height
+    blocks = ((w + 7) // 8) * ((h + 7) // 8) * (1 if int(options.color_type) == 0 else 3)
+    return 2048 + 416 * blocks
+
+
+def _check_shared(shared, file_len):
+    """All ranks computed the same `file_len` from the gathered piece headers: all raise, nobody is left in a barrier."""
+    if file_len > shared.size:
+        from . import error
+        e = error.BufferTooSmall("output buffer too small: the file needs %d bytes, the shared segment has %d"
+                                 % (file_len, shared.size))
+        e.needed = file_len
+        raise e
+
+
 def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn=None, out=None, shared=None):
     """Collective over `group`.  Every rank passes the same `options` and ITS band's rows
     (`jpeg.band(w, h, ct, ss, world, rank)`: rows [row_begin, row_end), tightly packed) as host bytes /
@@ -141,7 +168,9 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
     with `out` (a CPU uint8 tensor on `dst`, ideally pinned) the file is written there and its length returned.
 
     `shared`: a `SharedFile` every rank has mapped (one node): every rank writes its body into it over its own PCIe
-    link; the file's length is returned on `dst` (the bytes are in `shared.array()`), None elsewhere.
+    link; the file's length is returned on `dst` (the bytes are in `shared.array()`), None elsewhere.  The segment's size
+    has to be chosen before the file's length is known: `shared_file_bound(options)` is always enough (and usually far too much); a segment that
+    turns out too small makes EVERY rank raise `BufferTooSmall` (`.needed` = the file's length) before any byte is written.
 
     `device`: HIP device index of this rank (default: torch's current device); `coeff_fn(band_pixels,
     band_options) -> (y, cb, cr)`: tests substitute a CPU function, which also routes the entropy stage
@@ -193,6 +222,7 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
             words = np.frombuffer(piece[:16], np.int64)
             all_hdr = [np.array(h, np.int64).tobytes() for h in _all_gather_i64([int(words[0]), int(words[1])], group, tdev)]
             file_len, body_off = jpeg.splice_layout(options, all_hdr, total_counts)
+            _check_shared(shared, file_len)
             arr = shared.array()
             body = np.frombuffer(piece, np.uint8)[16:]
             arr[body_off[rank]: body_off[rank] + body.size] = body
@@ -220,6 +250,7 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
         lens = [int(np.frombuffer(h, np.uint64)[1]) for h in all_hdr]
         if shared is not None:
             # every rank: device -> the body's final place in the node's shared file, over this GPU's own PCIe link
+            _check_shared(shared, file_len)
             arr = shared.array()
             if lens[rank]:
                 enc.copy_body(arr.ctypes.data + body_off[rank])
@@ -334,3 +365,145 @@ def encode_gathered_device(d_band_pixels, options, group=None, dst=0, coeff_fn=N
         fcb = fcr = fy
     with jpeg.producer_stream(torch.cuda.current_stream(dev).cuda_stream):  # the gathers above precede the entropy stage
         return jpeg.entropy_encode_device(fy, fcb, fcr, options)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a batch of images resident on one GPU, encoded by all of them (SURVEY §8e "C3 batch")
+# ----------------------------------------------------------------------------------------------------------------------
+def batch_partition(n, world):
+    """Images [lo, hi) of rank r: contiguous runs whose sizes differ by at most one, the longer ones first (64 images over
+    8 ranks: 8 each; 5 images over 8 ranks: ranks 0-4 one each, ranks 5-7 none)."""
+    base, extra = divmod(n, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def _global(group, r):
+    import torch.distributed as dist
+    return dist.get_global_rank(group, r) if group is not None else r
+
+
+def _p2p(ops):
+    """Posts all sends / receives of one step at once (RCCL runs them as one group: the source's seven xGMI links carry
+    seven different peers' images at the same time) and waits for them."""
+    import torch.distributed as dist
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+def encode_batch(batch_pixels, options, n, group=None, src=0, dst=0, device=None, encode_fn=None, out=None):
+    """Collective over `group`: `n` equally sized images (described by `options`) lie back to back on rank `src` — a torch
+    uint8 tensor on its GPU (other ranks pass None) — and come back as `n` JFIF files on rank `dst`, each byte-identical to
+    `pixo::jpeg::encode` of that image (src/jpeg/mod.rs:88).
+
+      1. scatter   whole images, `batch_partition(n, world)`, point to point from `src` (send/recv of 6.2 MB images for
+                   1080p, one peer per link; `src` keeps its own share where it is)
+      2. encode    every rank: `pixo_hip_jpeg_encode_batch_device_into` into an arena in ITS HBM (one coefficient launch,
+                   one pass of the device entropy stage, files complete with headers)
+      3. sizes     one all_gather of the per-image file lengths (8 bytes per image)
+      4. gather    every rank sends its run of files to `dst`, which receives each run at its final offset of ONE device
+                   arena and copies that arena to the host once
+
+    Returns `(arena, offsets, lens)` on `dst` — `arena` a CPU uint8 tensor (`out` if given: ideally pinned; BufferTooSmall
+    with `.needed` when it is too small), file i = `arena[offsets[i]: offsets[i] + lens[i]]` — and None elsewhere.
+
+    `encode_fn(images, options, count) -> list of bytes` replaces step 2 for tests without a GPU (gloo, CPU tensors: the
+    scatter, the size exchange and the gather are the same calls)."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    on_gpu = encode_fn is None
+    bpp = 1 if int(options.color_type) == 0 else 3
+    px = options.width * options.height * bpp
+    parts = batch_partition(n, world)
+    lo, hi = parts[rank]
+    cnt = hi - lo
+    if on_gpu:
+        if device is None:
+            device = torch.cuda.current_device()
+        tdev = torch.device("cuda", device)
+    else:
+        tdev = torch.device("cpu")
+    gsrc, gdst = _global(group, src), _global(group, dst)
+
+    # 1. scatter
+    if rank == src:
+        if batch_pixels is None or batch_pixels.numel() != n * px:
+            raise ValueError("encode_batch: rank src passes the %d images back to back (%d bytes)" % (n, n * px))
+        whole = batch_pixels.reshape(-1)
+        mine = whole[lo * px: hi * px]
+        _p2p([dist.P2POp(dist.isend, whole[a * px: b * px], _global(group, r), group)
+              for r, (a, b) in enumerate(parts) if r != src and b > a])
+    else:
+        mine = torch.empty(cnt * px, dtype=torch.uint8, device=tdev)
+        if cnt:
+            _p2p([dist.P2POp(dist.irecv, mine, gsrc, group)])
+
+    # 2. encode this rank's images; the files stay where the next step sends them from
+    lens = []
+    if not on_gpu:
+        files = encode_fn(mine.numpy(), options, cnt) if cnt else []
+        lens = [len(f) for f in files]
+        run = torch.frombuffer(bytearray(b"".join(files)), dtype=torch.uint8) if cnt and sum(lens) else torch.empty(0, dtype=torch.uint8)
+    elif cnt:
+        cap = cnt * (px // 2 + 4096)
+        prev = jpeg.get_producer_stream()
+        jpeg.set_producer_stream(torch.cuda.current_stream(tdev).cuda_stream)  # the received pixels were written on torch's stream
+        try:
+            while True:
+                run = torch.empty(cap, dtype=torch.uint8, device=tdev)
+                try:
+                    _, lens = jpeg.encode_batch_device_into(run, mine, options, cnt)
+                    break
+                except jpeg.error.BufferTooSmall as e:  # (offsets / lens were filled in: the second attempt fits)
+                    cap = int(e.needed)
+        finally:
+            jpeg.set_producer_stream(prev)
+    else:
+        run = torch.empty(0, dtype=torch.uint8, device=tdev)
+
+    # 3. sizes: every rank's per-image lengths, padded to the longest share
+    most = max(b - a for a, b in parts)
+    all_lens = _all_gather_i64(lens + [0] * (most - cnt), group, tdev)
+    lens_all = [x for r, (a, b) in enumerate(parts) for x in all_lens[r][: b - a]]
+    offsets, at = [], 0
+    for x in lens_all:
+        offsets.append(at)
+        at += x
+    run_len = [sum(all_lens[r][: b - a]) for r, (a, b) in enumerate(parts)]
+    run_off = [offsets[a] if b > a else at for (a, b) in parts]
+
+    # 4. gather the files on dst, every run straight to its final offset
+    if rank != dst:
+        if run_len[rank]:
+            _p2p([dist.P2POp(dist.isend, run[: run_len[rank]], gdst, group)])
+        return None
+    if out is not None and out.numel() < at:
+        from . import error
+        e = error.BufferTooSmall("output buffer too small: need %d bytes" % at)
+        e.needed = at
+        # (the peers' sends are already posted: receive them into scratch so that nobody is left waiting, then raise)
+        scratch = torch.empty(max(at, 1), dtype=torch.uint8, device=tdev)
+        _p2p([dist.P2POp(dist.irecv, scratch[run_off[r]: run_off[r] + run_len[r]], _global(group, r), group)
+              for r in range(world) if r != dst and run_len[r]])
+        raise e
+    whole = torch.empty(max(at, 1), dtype=torch.uint8, device=tdev)
+    if run_len[rank]:
+        whole[run_off[rank]: run_off[rank] + run_len[rank]].copy_(run[: run_len[rank]])
+    _p2p([dist.P2POp(dist.irecv, whole[run_off[r]: run_off[r] + run_len[r]], _global(group, r), group)
+          for r in range(world) if r != dst and run_len[r]])
+    if not on_gpu:
+        arena = whole if out is None else out
+        if out is not None:
+            out[:at].copy_(whole[:at])
+        return arena, offsets, lens_all
+    arena = out if out is not None else _pinned_file(at)
+    arena[:at].copy_(whole[:at], non_blocking=True)
+    torch.cuda.synchronize(tdev)
+    return arena, offsets, lens_all

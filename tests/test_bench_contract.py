@@ -54,7 +54,17 @@ def test_bench_honours_gpus_when_started_without_a_launcher():
     line = _stub_line(2)
     assert line["n_gpus"] == 2 and line["data"] == "stub" and line["steps"] == 4 and line["blocks"] == 3
     assert line["ms_per_step_min"] <= line["ms_per_step"] <= line["ms_per_step_max"]
-    assert _stub_line(1)["n_gpus"] == 1
+    # round 4: a run with N > 1 also measures configs[3] and configs[2] over ITS ranks and says what the process group was
+    assert line["rccl"]["world"] == 2 and line["rccl"]["all_reduce_of_rank_plus_1"] == line["rccl"]["all_reduce_expected"] == 3
+    assert [d["rank"] for d in line["rccl"]["devices"]] == [0, 1] and line["rccl"]["backend"] == "gloo"
+    c4, c3 = line["other_configs"]["c4"], line["other_configs"]["c3_sharded"]
+    for leg in (c4, c3):
+        assert "error" not in leg, leg
+        assert leg["n_gpus"] == 2 and leg["scaling"] == "strong" and leg["value"] > 0 and leg["ms_per_step_min"] <= leg["ms_per_step"]
+    assert len(c4["config"]["file_sha256"]) == 64 and c3["config"]["images_per_rank"] == [8, 8]
+    one = _stub_line(1)
+    assert one["n_gpus"] == 1 and one["rccl"]["world"] == 1 and "error" not in one["other_configs"]["c4"]
+    assert one["other_configs"]["c3_sharded"]["config"]["images_per_rank"] == [16]
 
 
 def test_bench_refuses_a_launcher_world_that_differs_from_gpus():

@@ -222,3 +222,51 @@ def test_workers_that_outlive_main_and_a_main_thread_that_never_calls_the_librar
     sys.exit(0)   # daemon threads are abandoned mid-call while the runtime shuts down
     """)
     assert rc == 0 and "leaving True" in out, (rc, err[-2000:])
+
+
+def test_world_of_one_rccl_batch_and_bench_legs_of_a_multi_gpu_run():
+    """What a node with N GPUs runs, on the one GPU the test box has: a world-of-one RCCL group through
+    `sharded.encode_batch` (scatter = nothing to send, device arena, size exchange, gather = nothing to receive, one D2H) for
+    several option sets, and `bench.py --gpus 1`, whose line must carry the `rccl` block and the configs[3] / configs[2]
+    legs a multi-GPU run measures — configs[3]'s file with the reference's sha256."""
+    code = textwrap.dedent("""
+        import os, sys, json, hashlib
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np, torch, torch.distributed as dist
+        import oracle_lib as O, synth
+        from pixo_amd import ColorType, jpeg, sharded, error
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29571"
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        for (w, h, ct, ss, n, kw) in [(640, 360, 2, 1, 9, {}), (97, 61, 2, 0, 5, {"optimize_huffman": True}), (64, 48, 0, 0, 3, {}),
+                                      (120, 80, 2, 1, 4, {"progressive": True})]:
+            imgs = [(synth.noise(w, h, 42 + i) if ct else synth.noise_gray(w, h, 42 + i)) for i in range(n)]
+            b = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(77).subsampling(jpeg.Subsampling(ss))
+            for k, v in kw.items():
+                b = getattr(b, k)(v)
+            d = torch.from_numpy(np.concatenate(imgs)).cuda()
+            arena, offs, lens = sharded.encode_batch(d, b.build(), n)
+            for i in range(n):
+                assert arena[offs[i]: offs[i] + lens[i]].numpy().tobytes() == O.encode(imgs[i], O.make_options(w, h, ct, 77, ss, **kw)), (w, h, i)
+            small = torch.empty(10, dtype=torch.uint8).pin_memory()
+            try:
+                sharded.encode_batch(d, b.build(), n, out=small)
+                raise SystemExit("a 10-byte arena was accepted")
+            except error.BufferTooSmall as e:
+                assert e.needed == sum(lens)
+        dist.destroy_process_group()
+        print("BATCH_OK")
+    """ % (ROOT, ROOT))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "BATCH_OK" in r.stdout, r.stderr[-3000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--blocks", "3",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["rccl"]["world"] == 1 and line["rccl"]["backend"] == "nccl" and line["rccl"]["devices"][0]["rank"] == 0
+    c4, c3 = line["other_configs"]["c4"], line["other_configs"]["c3_sharded"]
+    assert "error" not in c4 and "error" not in c3, (c4, c3)
+    assert c4["config"]["file_sha256"] == "77cc6cb69a782693c46f2024ac57ebfdfb8411148fa3cef62698c727af36c70c" and c4["config"]["file_bytes"] == 178548465
+    assert c3["config"]["images_per_rank"] == [64] and c3["config"]["file0_sha256"].startswith("d1811ba1761f6b2a")
+    assert c4["value"] > 1000 and c3["value"] > 1000

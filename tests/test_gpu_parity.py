@@ -117,7 +117,7 @@ def test_device_api_batch_of_1080p_matches_per_image_oracle():
                              stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     y, cb, cr = d_y.cpu().numpy(), d_cb.cpu().numpy(), d_cr.cpu().numpy()
-    for i in (0, 3, 7):
+    for i in range(n):  # every image of the batch (round 3 compared three of the eight)
         oy, ocb, ocr = O.coeffs(imgs[i], w, h, 2, 1, 80, threads=8)
         assert np.array_equal(y[i * yb:(i + 1) * yb], oy)
         assert np.array_equal(cb[i * cbn:(i + 1) * cbn], ocb) and np.array_equal(cr[i * cbn:(i + 1) * cbn], ocr)
@@ -764,3 +764,59 @@ def test_large_batches_go_in_sub_batches_over_two_contexts_and_give_the_same_fil
             jpeg.encode_batch_device_into(torch.zeros(total - 1, dtype=torch.uint8).pin_memory(), d_px, o, n)
         files = jpeg.encode_batch_device(d_px, o, n)  # (the malloc'ing form: one pass, unchanged)
         assert files == want
+
+
+@pytest.mark.gpu
+def test_config_3_exactly_all_64_files_of_64_x_1080p_against_the_oracle():
+    """BASELINE configs[2] at its exact shape: 64 x 1920x1080 RGB8 noise, seeds 42..105, q=80 4:2:0, device resident, into one
+    pinned arena in one call — ALL 64 files equal the oracle's, file 0 equals the reference-made golden of SURVEY §8c, and the
+    same batch with the files left in HBM (device arena, what sharded.encode_batch gathers over RCCL) gives the same bytes."""
+    import hashlib
+    import torch
+    w, h, n = 1920, 1080, 64
+    o = _opts(w, h, 2, 1, 80)
+    oo = O.make_options(w, h, 2, 80, 1)
+    imgs = [synth.noise(w, h, 42 + i) for i in range(n)]
+    d_px = torch.from_numpy(np.concatenate(imgs)).to("cuda:0")
+    torch.cuda.synchronize()
+    arena = torch.empty(n * w * h, dtype=torch.uint8).pin_memory()
+    offs, lens = jpeg.encode_batch_device_into(arena, d_px, o, n)
+    raw = arena.numpy()
+    assert hashlib.sha256(raw[: lens[0]].tobytes()).hexdigest() == "d1811ba1761f6b2a76d7f2c3d43418784f38909e0b20af631d5ead73e7d9436a"
+    assert lens[0] == 1388296 and offs == [sum(lens[:i]) for i in range(n)]
+    for i in range(n):
+        assert raw[offs[i]: offs[i] + lens[i]].tobytes() == O.encode(imgs[i], oo), i
+    total = offs[-1] + lens[-1]
+    d_arena = torch.full((total + 16,), 0x5A, dtype=torch.uint8, device="cuda:0")
+    offs2, lens2 = jpeg.encode_batch_device_into(d_arena, d_px, o, n)
+    assert (offs2, lens2) == (offs, lens)
+    back = d_arena.cpu().numpy()
+    assert np.array_equal(back[:total], raw[:total]) and bool((back[total:] == 0x5A).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(333, 77, 2, 0, 9, {}), (64, 64, 0, 0, 5, {}), (100, 36, 2, 1, 3, {"optimize_huffman": True}),
+                                   (200, 120, 2, 1, 4, {"restart_interval": 3}), (16, 16, 2, 1, 40, {"progressive": True})])
+def test_batch_into_a_device_arena_files_complete_in_hbm(shape):
+    """`arena` in device memory: headers, scans and EOI of every file at their final places in HBM, for the one-pass batch and
+    for option sets that are coded image by image; one byte short is refused with the size needed."""
+    import torch
+    from pixo_amd import error
+    w, h, ct, ss, n, kw = shape
+    imgs = [(synth.noise(w, h, 700 + i) if ct == 2 else synth.noise_gray(w, h, 700 + i)) for i in range(n)]
+    okw = {("restart" if k == "restart_interval" else k): v for k, v in kw.items()}
+    want = [O.encode(im, O.make_options(w, h, ct, 80, ss, **okw)) for im in imgs]
+    total = sum(len(f) for f in want)
+    d_px = torch.from_numpy(np.concatenate(imgs)).to("cuda:0")
+    d_arena = torch.full((total + 5,), 0x5A, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    o = _opts(w, h, ct, ss, 80, **kw)
+    offs, lens = jpeg.encode_batch_device_into(d_arena, d_px, o, n)
+    raw = d_arena.cpu().numpy()
+    assert lens == [len(f) for f in want]
+    for i in range(n):
+        assert raw[offs[i]: offs[i] + lens[i]].tobytes() == want[i], i
+    assert bool((raw[total:] == 0x5A).all())
+    with pytest.raises(error.BufferTooSmall) as ei:
+        jpeg.encode_batch_device_into(torch.empty(total - 1, dtype=torch.uint8, device="cuda:0"), d_px, o, n)
+    assert "need %d bytes" % total in str(ei.value)

@@ -203,3 +203,152 @@ def _worker_gathered_device(rank, world, port, w, h, ct, ss, q, ret):
 @pytest.mark.parametrize("case", [(333, 211, 2, 1, 80), (100, 72, 2, 0, 60), (64, 40, 0, 0, 90)])
 def test_two_rank_device_form_gathers_equal_sized_bands(case):
     assert _run(_worker_gathered_device, 2, case) is True
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 4: 8 ranks (the node's shape), the C4 partition rule scaled down, the shared segment's bound, the batch form
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [
+    (256, 128 * 16 // 8, 2, 1, 80),   # 16 MCU rows over 8 ranks = 2 each: configs[3]'s rule (1024 MCU rows -> 128 per rank) scaled down
+    (100, 16 * 13, 2, 1, 70),         # 13 MCU rows over 8 ranks: 2,2,2,2,2,1,1,1 (uneven)
+    (64, 16 * 5 - 3, 2, 1, 85),       # 5 MCU rows over 8 ranks: ranks 5, 6, 7 hold nothing and forward their predecessor's DCs
+    (72, 8 * 11, 2, 0, 60),           # 4:4:4: 11 block rows
+    (40, 8 * 3, 0, 0, 90),            # gray, 3 block rows over 8 ranks
+])
+def test_eight_rank_bands_uneven_and_empty(case):
+    assert _run(_worker_banded, 8, case, timeout=300) is True
+
+
+def test_eight_rank_bands_with_summed_symbol_counts():
+    assert _run(_worker_banded_flags, 8, ({"optimize_huffman": True},), timeout=300) is True
+
+
+def test_eight_rank_partition_rule_of_config_4():
+    """jpeg.band over 8 parts: contiguous MCU-row bands that cover the image once, sizes differ by at most one MCU row;
+    16384 rows of 4:2:0 -> 128 MCU rows = 2048 pixel rows per rank."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from pixo_amd import jpeg
+    bands = [jpeg.band(16384, 16384, 2, 1, 8, r) for r in range(8)]
+    assert [(b["row_begin"], b["row_end"]) for b in bands] == [(2048 * r, 2048 * (r + 1)) for r in range(8)]
+    for (w, h, ct, ss) in [(100, 16 * 13, 2, 1), (64, 77, 2, 1), (40, 24, 0, 0), (33, 1000, 2, 0)]:
+        bands = [jpeg.band(w, h, ct, ss, 8, r) for r in range(8)]
+        unit = 16 if (ct and ss) else 8
+        assert bands[0]["row_begin"] == 0 and bands[-1]["row_end"] == h
+        assert all(a["row_end"] == b["row_begin"] for a, b in zip(bands, bands[1:]))
+        sizes = [-(-(b["row_end"] - b["row_begin"]) // unit) for b in bands]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def _worker_shared_too_small(rank, world, port, ret):
+    """a SharedFile smaller than the file must make EVERY rank raise BufferTooSmall (with the size needed)
+    before any byte moves — nobody writes past the mapping, nobody is left in the barrier."""
+    dist = _setup(rank, world, port)
+    import oracle_lib as O
+    import synth
+    from pixo_amd import error, jpeg, sharded
+    w, h, ct, ss, q = 200, 203, 2, 1, 75
+    px = synth.noise(w, h, 77)
+
+    def cpu_coeffs(sub, o):
+        return O.coeffs(sub, o.width, o.height, int(o.color_type), int(o.subsampling), o.quality)
+
+    o = _options(w, h, ct, ss, q, {})
+    want = O.encode(px, O.make_options(w, h, ct, q, ss))
+    name = "pixo_small_%d" % port
+    size = len(want) - 100
+    shared = sharded.SharedFile(name, size, create=True) if rank == 0 else None
+    dist.barrier()
+    if rank != 0:
+        shared = sharded.SharedFile(name, size, create=False)
+    shared.array()[:] = 0xAB
+    b = jpeg.band(w, h, ct, ss, world, rank)
+    mine = px[b["row_begin"] * w * 3: b["row_end"] * w * 3]
+    try:
+        sharded.encode_banded(mine, o, coeff_fn=cpu_coeffs, shared=shared)
+        ok = False
+    except error.BufferTooSmall as e:
+        ok = e.needed == len(want)
+    dist.barrier()  # (every rank got here: nobody hangs)
+    ok = ok and bool((shared.array() == 0xAB).all())
+    assert sharded.shared_file_bound(o) >= len(want)
+    if rank == 0:
+        ret.put(ok)
+    else:
+        assert ok
+    dist.barrier()
+    shared.close(unlink=rank == 0)
+    dist.destroy_process_group()
+
+
+def test_shared_file_too_small_raises_on_every_rank_and_writes_nothing():
+    assert _run(_worker_shared_too_small, 3, ()) is True
+
+
+def _worker_batch(rank, world, port, n, w, h, ct, ss, q, src, dst, flags, small_out, ret):
+    """sharded.encode_batch over gloo with CPU tensors: the scatter of whole images from `src`, the size exchange and the
+    gather of the files on `dst` are the calls a GPU node makes; the oracle stands in for every rank's encoder."""
+    dist = _setup(rank, world, port)
+    import numpy as np
+    import torch
+    import oracle_lib as O
+    import synth
+    from pixo_amd import error, sharded
+    bpp = 1 if ct == 0 else 3
+    px = w * h * bpp
+    images = [synth.noise_gray(w, h, 42 + i) if ct == 0 else synth.noise(w, h, 42 + i) for i in range(n)]
+    oo = O.make_options(w, h, ct, q, ss, **flags)
+
+    def cpu_encode(chunk, o, count):
+        assert chunk.size == count * px
+        return [O.encode(chunk[i * px: (i + 1) * px], oo) for i in range(count)]
+
+    o = _options(w, h, ct, ss, q, flags)
+    batch = torch.from_numpy(np.concatenate(images)) if rank == src else None  # only src holds pixels
+    lo, hi = sharded.batch_partition(n, world)[rank]
+    if small_out:
+        out = torch.empty(64, dtype=torch.uint8) if rank == dst else None
+        try:
+            sharded.encode_batch(batch, o, n, src=src, dst=dst, encode_fn=cpu_encode, out=out)
+            ok = rank != dst
+        except error.BufferTooSmall as e:
+            ok = rank == dst and e.needed == sum(len(O.encode(im, oo)) for im in images)
+    else:
+        got = sharded.encode_batch(batch, o, n, src=src, dst=dst, encode_fn=cpu_encode)
+        if rank == dst:
+            arena, offs, lens = got
+            ok = len(offs) == n and offs[0] == 0 and all(offs[i + 1] == offs[i] + lens[i] for i in range(n - 1))
+            for i in range(n):
+                ok = ok and arena[offs[i]: offs[i] + lens[i]].numpy().tobytes() == O.encode(images[i], oo)
+        else:
+            ok = got is None
+    dist.barrier()
+    if rank == dst:
+        ret.put(bool(ok))
+    else:
+        assert ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,case", [
+    (2, 5, (48, 40, 2, 1, 80, 0, 0, {})),                            # 3 + 2 images
+    (3, 7, (40, 24, 2, 0, 60, 0, 0, {"optimize_huffman": True})),    # 3 + 2 + 2, per-image tables
+    (3, 4, (33, 17, 0, 0, 90, 1, 2, {})),                            # gray; src = 1, dst = 2: the files end up on a rank that held no pixels
+    (8, 64, (32, 24, 2, 1, 80, 0, 0, {})),                           # configs[2]'s shape on a node: 64 images, 8 per rank
+    (8, 5, (32, 16, 2, 1, 75, 3, 0, {})),                            # fewer images than ranks: ranks 5-7 neither receive nor send
+    (8, 13, (24, 24, 2, 0, 50, 7, 7, {"progressive": True})),        # uneven 2,2,2,2,2,1,1,1
+])
+def test_batch_scattered_from_one_rank_and_files_gathered(world, n, case):
+    assert _run(_worker_batch, world, (n,) + case + (False,), timeout=300) is True
+
+
+def test_batch_output_too_small_raises_on_dst_and_strands_nobody():
+    assert _run(_worker_batch, 3, (5, 48, 40, 2, 1, 80, 0, 1, {}, True)) is True
+
+
+def test_batch_partition_rule():
+    sys.path.insert(0, os.path.dirname(HERE))
+    from pixo_amd import sharded
+    assert sharded.batch_partition(64, 8) == [(8 * r, 8 * r + 8) for r in range(8)]
+    assert sharded.batch_partition(5, 8) == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]
+    assert sharded.batch_partition(13, 8) == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 10), (10, 11), (11, 12), (12, 13)]
+    assert sharded.batch_partition(0, 3) == [(0, 0)] * 3

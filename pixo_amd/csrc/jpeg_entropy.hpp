@@ -97,6 +97,10 @@ struct SegArgs {
     unsigned long long *host_out_end = nullptr;
     uint32_t marker_bytes = 0;  // bytes left free in d_out behind every segment but the last (at most seg_max_gap())
     uint32_t rst_markers = 0;   // 1: marker_bytes == 2 and the stuffing kernel writes FF D0+(k & 7) there
+    // Segments of DIFFERENT sizes (the scans of a progressive file, prog_code_kernel): var != 0, nsegs <= 8, segment k's
+    // packed stream begins at word var_word[k] of d_stream (blocks / groups / stream_words are not used then)
+    uint32_t var = 0;
+    uint64_t var_word[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 uint32_t seg_groups(uint64_t seg_blocks);
 uint32_t seg_max_gap();
@@ -132,7 +136,29 @@ hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_co
 // (d_out_chain, piece: the piece's bytes go to d_out + d_out_chain[piece] (piece 0: d_out); d_out_chain[piece + 1] receives
 // where they end; d_state[1] / host_totals[1] count this piece's bytes only)
 
-// ---- progressive scans on the device (simple_progressive_script: seven single-component scans) ------
+// ---- progressive scans in ONE pass (round 4): the seven scans of simple_progressive_script (progressive.rs:98-110) as
+// byte-aligned segments of one launch of prog_code_kernel (jpeg_scan_fused.hip) — every lane codes one (scan, block) pair
+// with the flat walk, the end-of-band run counter travels through wavefront ballots and a look-back of its own, the bits
+// are placed like scan_code's.  Scans without blocks (the chroma scans of a gray image) are left out: nscans <= 7.
+// code -> seg.bits[k]; launch_seg_layout; stuff<SEG> with seg.var = 1 (the segments' streams at seg.var_word[k]).
+struct ProgCode {
+    const int16_t *y, *cb, *cr;
+    const uint32_t *tables;   // packed ((length << 16) | code, absent symbols (4 << 16)), then the flat walk's form
+    uint32_t nscans;
+    uint32_t scan_id[7];      // index into the script: 0..2 DC of Y, Cb, Cr; 3 Y 1..10; 4 Y 11..63; 5 Cb 1..63; 6 Cr 1..63
+    uint64_t size[7];         // blocks
+    uint64_t first_group[8];  // first group (of 192 blocks) of scan k; [nscans] = groups in all
+};
+size_t prog_code_state_words(uint64_t groups); // u64 words of d_state
+uint64_t prog_groups(uint64_t blocks);         // groups of one scan
+// d_state: zeroed (by the launcher unless state_is_zero); d_stream: scan k at word seg.var_word[k], room for
+// prog_stream_bytes(scan_id, blocks) bytes; d_clear / clear_words, host_totals ([3]: abort flag), spin_budget: as launch_scan_code
+size_t prog_stream_bytes(uint32_t scan_id, uint64_t blocks);
+hipError_t launch_prog_code(const ProgCode &a, const SegArgs &seg, unsigned long long *d_state, bool state_is_zero, uint32_t *d_stream,
+                            unsigned long long *d_clear, size_t clear_words, unsigned long long *host_totals, hipStream_t s,
+                            uint32_t spin_budget = 1u << 20);
+
+// ---- progressive scans on the device, multi-pass (round 1; the fallback of the single-pass form) ------
 struct ProgArgs {
     const int16_t *y, *cb, *cr; // coefficient tuple
     const uint32_t *tables;     // packed like ScanArgs::tables; absent symbols hold (4 << 16): code 0, 4 bits

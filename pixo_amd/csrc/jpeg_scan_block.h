@@ -419,6 +419,125 @@ PIXO_SDEV void prog_emit(int scan, const uint32_t *w, int prev_dc, uint32_t flag
     if (last_of_scan && counter) emit_band_run(counter, vis); // jpeg/mod.rs:1361-1364
 }
 
+// ---- the same scans in ONE pass (prog_code_kernel, jpeg_scan_fused.hip; round 4) -----------------------------------
+// The multi-pass form above needs to know every block's run counter before any bit is placed (flags, ranks, the r-th
+// non-empty block ...).  The single-pass form codes a block's OWN symbols first, with the flat walk, from bit 0 of the
+// lane's scratch, and places what the run counter adds — an end-of-band run in front of a non-empty block, the flush at
+// 32767 inside a run of empty blocks, the flush behind the scan's last block — around them afterwards:
+//
+//   counter on entry to block b  =  C_b mod 32767,   C_b = sum of t_j over j in [p, b),  p = the last non-empty block
+//   before b (the scan's first block if there is none, whose sum then starts at it), t_j = 1 for an empty block and for a
+//   non-empty one whose last non-zero coefficient lies before the band's end (progressive.rs:156-162, :206-209).
+//
+// Inside a wavefront C_b comes from two ballots (bits p .. b-1 of the t mask); a lane with no non-empty block before it
+// in its wavefront adds what flows in from the wavefronts / groups before (BandCount::carried).
+//
+// The flat walk over zig-zag [ss, se] of a FIRST AC scan (progressive.rs:141-210 with al = 0): block_pack_flat without
+// the DC symbol and without an end-of-block code; ss / se are wave-uniform run-time values (one instance serves the
+// three bands of the script), positions outside the band are skipped by a uniform branch.  *any: the band holds a
+// non-zero coefficient; *ends_zero: its last coefficient is zero (the block leaves the run counter at 1 — or, empty,
+// adds one to it).
+template <class Sink>
+PIXO_SDEV void band_pack_flat(const uint32_t *w, int ss, int se, const uint32_t *wtab, FlatPack<Sink> &p, bool *any, bool *ends_zero)
+{
+    const uint32_t zrl = wtab[kWalkZrl];
+    uint32_t run16 = 0;
+    bool seen = false;
+#pragma unroll
+    for (int k = 1; k < 64; k++) {
+        if (k < ss || k > se) continue; // (wave-uniform)
+        const int v = coef_of(w, zigzag(k));
+        const uint64_t nz_lanes = PIXO_BALLOT64(v != 0);
+        if (!nz_lanes) { run16 += 16u; continue; } // (wave-uniform on the device)
+        const bool nz = v != 0;
+        seen = seen || nz;
+        if (k > 16 && __builtin_expect((PIXO_BALLOT64(run16 >= 256u) & nz_lanes) != 0, 0)) { // up to three ZRL codes in front of the symbol
+#pragma unroll
+            for (uint32_t i = 0; i < 3; i++) {
+                const bool on = nz && (run16 >> 8) > i;
+                p.put_left(on ? (zrl & 0xFFFF0000u) : 0u, on ? (zrl & 0xFFu) : 0u);
+            }
+            run16 = nz ? (run16 & 255u) : run16;
+        }
+        const int u = v + (v >> 31);
+        const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u;
+        const uint32_t slot = (k > 16 ? (run16 & 255u) : run16) | (m & 15u);
+        put_symbol(p, wtab[kWalkDc + slot], (uint32_t)u, m);
+        run16 = nz ? 0u : run16 + 16u;
+    }
+    *any = seen;
+    *ends_zero = run16 != 0u;
+}
+// the DC symbol of a first DC scan (encode_dc_first, progressive.rs:112-133 with al = 0)
+template <class Sink> PIXO_SDEV void dc_pack_flat(const uint32_t *w, int prev_dc, const uint32_t *wtab, FlatPack<Sink> &p)
+{
+    const int diff = (int)(int16_t)(coef_of(w, 0) - prev_dc);
+    const int u = diff + (diff >> 31);
+    const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u;
+    put_symbol(p, wtab[m & 15u], (uint32_t)u, m);
+}
+
+// C_b inside one wavefront.  zmask / tmask: ballots of "non-empty" and "t" (lanes beyond the scan's end: neither).
+struct BandCount { uint32_t local; bool carried; }; // C_b = local (+ the count flowing into the wavefront when `carried`)
+PIXO_SDEV BandCount band_count_in_wave(uint64_t zmask, uint64_t tmask, int lane)
+{
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const uint64_t pz = zmask & below;
+    BandCount c;
+    if (pz) {
+        const int p = 63 - __builtin_clzll(pz);
+        c.local = (uint32_t)__builtin_popcountll(tmask & below & ~((1ull << p) - 1ull)); // t of lanes p .. lane - 1
+        c.carried = false;
+    } else {
+        c.local = (uint32_t)__builtin_popcountll(tmask & below);
+        c.carried = true;
+    }
+    return c;
+}
+// what a wavefront hands on: does it hold a non-empty block, and the count behind its last one (all of its t when it holds none)
+PIXO_SDEV void band_wave_summary(uint64_t zmask, uint64_t tmask, bool *any, uint32_t *tail)
+{
+    *any = zmask != 0;
+    if (zmask) {
+        const int p = 63 - __builtin_clzll(zmask);
+        *tail = (uint32_t)__builtin_popcountll(tmask & ~((1ull << p) - 1ull));
+    } else {
+        *tail = (uint32_t)__builtin_popcountll(tmask);
+    }
+}
+// One end-of-band-run symbol (flush_eob_run, progressive.rs:313-345) as bits at the top of a word: `eob_syms` are the
+// packed table words ((length << 16) | code) of the class's symbols 0x00, 0x10 ... 0xE0.  run in 1..32767.
+struct BandBits { uint32_t left; uint32_t len; }; // len <= 30
+PIXO_SDEV BandBits band_run_bits(uint32_t run, const uint32_t *eob_syms)
+{
+    const uint32_t nbits = 31u - (uint32_t)__builtin_clz(run);
+    const uint32_t t = eob_syms[nbits], clen = t >> 16;
+    const uint32_t v = ((t & 0xFFFFu) << nbits) | (run - (1u << nbits));
+    BandBits b;
+    b.len = clen + nbits;
+    b.left = v << (32u - b.len);
+    return b;
+}
+// What the run counter makes a lane emit in front of (`pre`) and behind (`post`) its own symbols.  C: C_b above.
+struct BandEdge { BandBits pre, post; };
+PIXO_SDEV BandEdge band_edge(uint32_t C, bool live, bool nonempty, bool ends_zero, bool last_of_scan, const uint32_t *eob_syms)
+{ // (C < 2^32: a scan has at most 65535 x 65535 / 64 blocks)
+    BandEdge e;
+    e.pre.left = e.pre.len = e.post.left = e.post.len = 0;
+    if (!live) return e;
+    const uint32_t before = C % kMaxBandRun;
+    uint32_t counter;
+    if (nonempty) {
+        if (before) e.pre = band_run_bits(before, eob_syms); // flush the pending run first (progressive.rs:171-174)
+        counter = ends_zero ? 1u : 0u;                          // (:206-209)
+    } else {
+        counter = before + 1;
+        if (counter == kMaxBandRun) { e.pre = band_run_bits(counter, eob_syms); counter = 0; } // (:160-163)
+    }
+    if (last_of_scan && counter) e.post = band_run_bits(counter, eob_syms); // jpeg/mod.rs:1361-1364
+    return e;
+}
+
 // Scan-order position -> (component, block index inside that component's array).
 // mode 0 gray: Y;  1 4:4:4: Y Cb Cr per block;  2 4:2:0: Y0 Y1 Y2 Y3 Cb Cr per MCU
 // (encode_scan, jpeg/mod.rs:1491-1544).  comp: 0 Y, 1 Cb, 2 Cr.

@@ -414,6 +414,257 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     }
 }
 
+// ---- progressive scans in one pass (round 4) ----------------------------------------------------------------------------
+// The scans of simple_progressive_script (progressive.rs:98-110; jpeg/mod.rs:872-927, :1248-1380) as segments of ONE launch:
+// group g belongs to scan k when first_group[k] <= g < first_group[k + 1]; lane l of it codes block (g - first_group[k]) * 192
+// + l of the scan's component (storage order).  What differs from scan_code_kernel<SEG>:
+//   * segments of different sizes, each with its own walk: DC scans code one symbol per block (encode_dc_first), AC scans the
+//     band [ss, se] without an end-of-block code (band_pack_flat);
+//   * the END-OF-BAND RUN counter (progressive.rs:156-162, :171-174, :206-209, :313-345) crosses blocks: what it makes a lane
+//     emit around its own symbols (band_edge, jpeg_scan_block.h) depends on C_b, the count of run contributions since the last
+//     non-empty block — inside the wavefront two ballots, across wavefronts three LDS words, across groups a look-back of
+//     its own (descriptor A: a group that holds a non-empty block publishes the count behind it as a PREFIX at once; a
+//     group of empty blocks publishes its count as an aggregate and, once it knows what flows in, the sum as a prefix).  The
+//     A descriptors go out right after the walk, before any length is known, so that look-back rarely waits;
+//   * a group may have no bits at all (192 empty blocks): it still takes part in look-back B and hands the shared word on.
+// state: [0] abort flag, [1] -, then per group: descriptor A, descriptor B, tail.
+constexpr uint32_t kEobSyms = 16; // per class: the packed words of symbols 0x00 .. 0xE0 (end-of-band runs), one spare
+__global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) void prog_code_kernel
+(const ProgCode a, const SegArgs seg, unsigned long long *state, uint32_t *stream, unsigned long long *clear, uint32_t clear_words,
+ unsigned long long *host_totals, uint32_t spin_budget)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
+    __shared__ uint32_t tab[kWalkWords];
+    __shared__ uint32_t eobs[2 * kEobSyms];
+    __shared__ uint32_t scratch[kGroup * kScratchPitch];
+    __shared__ uint32_t wave_sum[kGroupWaves], wave_long[kGroupWaves], wave_any[kGroupWaves], wave_tail[kGroupWaves];
+    __shared__ unsigned long long s_before, s_in;
+    __shared__ uint32_t s_carry, s_abort;
+    const int lane = threadIdx.x, wave = lane >> 6;
+    if (lane == 0) { s_carry = 0; s_abort = 0; s_in = 0; }
+    const uint64_t g = blockIdx.x;
+    uint32_t k = 0; // the scan this group belongs to (wave-uniform)
+#pragma unroll
+    for (uint32_t i = 1; i < 7; i++) k += (i < a.nscans && g >= a.first_group[i]) ? 1u : 0u;
+    const uint32_t scan = a.scan_id[k];
+    const uint64_t floor_g = a.first_group[k], nblocks_chain = a.size[k], first_in_chain = (g - floor_g) * kGroup;
+    const uint64_t ngroups_total = a.first_group[a.nscans];
+    unsigned long long *desc_a = state + 2, *desc = state + 2 + ngroups_total, *tails = state + 2 + 2 * ngroups_total;
+    unsigned long long *const host_abort = host_totals ? host_totals + 3 : nullptr;
+    stream += seg.var_word[k];
+    const bool dc_scan = scan < 3;
+    const int comp = prog_comp((int)scan), cls = comp ? 1 : 0;
+    const int ss = scan == 4 ? 11 : 1, se = scan == 3 ? 10 : 63;
+    const bool live = first_in_chain + lane < nblocks_chain;
+    const bool last_of_scan = first_in_chain + lane + 1 == nblocks_chain;
+    uint32_t w[32];
+    int prev_dc = 0;
+    {
+        const int16_t *base = comp == 0 ? a.y : (comp == 1 ? a.cb : a.cr);
+        const uint64_t b = live ? first_in_chain + lane : 0;
+        if (dc_scan) { // only the block's first coefficient (and the one before it: the predictor, jpeg/mod.rs:1268-1300)
+#pragma unroll
+            for (int i = 0; i < 32; i++) w[i] = 0;
+            w[0] = (uint32_t)(uint16_t)base[b * 64];
+            prev_dc = b ? (int)base[(b - 1) * 64] : 0;
+        } else {
+            const v4u *p = reinterpret_cast<const v4u *>(base + b * 64);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const v4u q = p[r];
+                w[4 * r] = q.x; w[4 * r + 1] = q.y; w[4 * r + 2] = q.z; w[4 * r + 3] = q.w;
+            }
+        }
+    }
+    for (int i = lane; i < kWalkWords; i += kGroup) tab[i] = a.tables[kTableWords + i];
+    if (lane < 30) eobs[(lane / 15) * kEobSyms + lane % 15] = a.tables[(lane / 15) * kClassSyms + kDcSyms + ((lane % 15) << 4)];
+    for (uint64_t i = (uint64_t)blockIdx.x * kGroup + lane; i < clear_words; i += (uint64_t)gridDim.x * kGroup) clear[i] = 0;
+    __syncthreads();
+    // ---- the walk: the lane's own symbols into its scratch from bit 0
+    uint32_t own;
+    bool nonempty = false, ends_zero = false;
+    {
+        FlatPack<LaneSink> p;
+        p.sink = LaneSink{scratch + lane * kScratchPitch};
+        p.acc = 0; p.pending = 0; p.word = 0;
+        if (dc_scan) dc_pack_flat(w, prev_dc, tab + cls * kWalkClassWords, p);
+        else band_pack_flat(w, ss, se, tab + cls * kWalkClassWords, p, &nonempty, &ends_zero);
+        own = p.word * 32u + p.pending;
+        p.finish();
+    }
+    if (!live) { own = 0; nonempty = false; ends_zero = false; }
+    // ---- the run counter: what it puts in front of and behind the lane's symbols
+    BandEdge edge;
+    edge.pre.left = edge.pre.len = edge.post.left = edge.post.len = 0;
+    if (!dc_scan) { // (wave-uniform)
+        const uint64_t zmask = PIXO_BALLOT64(nonempty), tmask = PIXO_BALLOT64(ends_zero);
+        const BandCount bc = band_count_in_wave(zmask, tmask, lane & 63);
+        if ((lane & 63) == 0) {
+            bool any; uint32_t tail;
+            band_wave_summary(zmask, tmask, &any, &tail);
+            wave_any[wave] = any ? 1u : 0u;
+            wave_tail[wave] = tail;
+        }
+        __syncthreads();
+        uint32_t into_wave = 0, group_tail = 0; // counts from the wavefronts before this one / of the whole group, not counting what flows into the group
+        bool wave_open = true, group_open = true; // "no non-empty block so far": what flows into the group is still to be added
+#pragma unroll
+        for (int i = 0; i < kGroupWaves; i++) {
+            if (i < wave) { if (wave_any[i]) { into_wave = wave_tail[i]; wave_open = false; } else into_wave += wave_tail[i]; }
+            if (wave_any[i]) { group_tail = wave_tail[i]; group_open = false; } else group_tail += wave_tail[i];
+        }
+        if (lane == 0) {
+            if (!group_open) store_relaxed(&desc_a[g], kFlagPrefix | group_tail); // nothing before this group matters behind it
+            else publish_aggregate(desc_a, g, floor_g, group_tail);
+        }
+        if (wave == 0) {
+            const uint64_t sum = look_back(desc_a, g, floor_g, group_tail, state, host_abort, spin_budget);
+            if (lane == 0) {
+                if (sum == kLookBackFailed) s_abort = 1;
+                s_in = sum;
+                if (group_open && g != floor_g && sum != kLookBackFailed) store_relaxed(&desc_a[g], kFlagPrefix | (sum + group_tail));
+            }
+        }
+        __syncthreads();
+        if (s_abort) return;
+        const uint32_t C = bc.local + (bc.carried ? into_wave + (wave_open ? (uint32_t)s_in : 0u) : 0u);
+        edge = band_edge(C, live, nonempty, ends_zero, last_of_scan, eobs + cls * kEobSyms);
+    }
+    {
+        const uint32_t len = edge.pre.len + own + edge.post.len;
+        const bool long_block = own > kScratchWords * 32u;
+        const uint32_t incl = wave_inclusive_scan(len);
+        if ((lane & 63) == 63) wave_sum[wave] = incl;
+        const bool any_long = PIXO_ANY64(long_block);
+        if ((lane & 63) == 0) wave_long[wave] = any_long ? 1u : 0u;
+        __syncthreads();
+        uint32_t wave_base = 0, group_bits = 0, group_long = 0;
+#pragma unroll
+        for (int i = 0; i < kGroupWaves; i++) {
+            if (i < wave) wave_base += wave_sum[i];
+            group_bits += wave_sum[i];
+            group_long |= wave_long[i];
+        }
+        if (lane == 0) publish_aggregate(desc, g, floor_g, group_bits);
+        const bool last_group = first_in_chain + kGroup >= nblocks_chain;
+        const uint32_t my_bit = wave_base + (incl - len);
+        const uint32_t bit_words = (group_bits + 31) >> 5;
+        const uint32_t local_words = bit_words ? bit_words : 1u; // (a group without bits still runs one round: look-back, shared word)
+        uint64_t first_word = 0;
+        uint32_t sh = 0, out_words = 0, pad_word = ~0u, pad_mask = 0;
+        bool tail_partial = false;
+        uint32_t head_word = 0;
+        for (uint32_t wbase = 0; wbase < local_words; wbase += kWindowWords) {
+            const uint32_t wn = local_words - wbase < kWindowWords ? local_words - wbase : kWindowWords;
+            for (uint32_t i = lane; i < wn; i += kGroup) buf[i] = 0;
+            __syncthreads();
+            const uint32_t dummy = kWindowWords + (uint32_t)lane;
+            // `n` bits at the top of `left`, at bit `at` of the window (negative / beyond it: the parts outside go to the dummy word)
+            auto or_bits = [&](uint32_t left, uint32_t n, int64_t at) {
+                if (!PIXO_ANY64(n != 0)) return; // (wave-uniform)
+                const uint32_t bsh = (uint32_t)(at & 31), d = (uint32_t)(at >> 5);
+                (void)__hip_atomic_fetch_or(&buf[(n && d < wn) ? d : dummy], left >> bsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_or(&buf[(n && d + 1 < wn) ? d + 1 : dummy], bsh ? left << (32 - bsh) : 0u, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            const int64_t rel = (int64_t)my_bit - (int64_t)wbase * 32;  // the lane's first bit
+            const int64_t rel_own = rel + (int64_t)edge.pre.len;          // its own symbols' first bit
+            or_bits(edge.pre.left, edge.pre.len, rel);
+            or_bits(edge.post.left, edge.post.len, rel_own + (int64_t)own);
+            if (!group_long) {
+                const uint32_t nw = (own + 31) >> 5, bsh = (uint32_t)(rel_own & 31);
+                const uint32_t d0 = (uint32_t)(rel_own >> 5);
+#pragma unroll
+                for (uint32_t j = 0; j < kScratchWords; j++) {
+                    if (!PIXO_ANY64(j < nw)) break; // (wave-uniform)
+                    const uint32_t v = j < nw ? scratch[lane * kScratchPitch + j] : 0u;
+                    const uint32_t d = d0 + j;
+                    (void)__hip_atomic_fetch_or(&buf[d < wn ? d : dummy], v >> bsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    (void)__hip_atomic_fetch_or(&buf[d + 1 < wn ? d + 1 : dummy], bsh ? v << (32 - bsh) : 0u, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 32; i++) asm volatile("" : "+v"(w[i]));
+            if (group_long && PIXO_ANY64(live && rel_own < (int64_t)wn * 32 && rel_own + (int64_t)own > 0)) { // (only AC scans have long blocks)
+                FlatPack<LdsSink> p;
+                p.sink = LdsSink{buf, live ? wn : 0u, dummy};
+                p.acc = 0;
+                p.pending = (uint32_t)(rel_own & 31);
+                p.word = (uint32_t)(rel_own >> 5);
+                bool z2, t2;
+                band_pack_flat(w, ss, se, tab + cls * kWalkClassWords, p, &z2, &t2);
+                p.finish();
+            }
+            if (wbase == 0) {
+                if (wave == 0) {
+                    const uint64_t sum = look_back(desc, g, floor_g, group_bits, state, host_abort, spin_budget);
+                    if (lane == 0) {
+                        if (sum == kLookBackFailed) s_abort = 1;
+                        s_before = sum;
+                        if (g != floor_g) store_relaxed(&desc[g], kFlagPrefix | (sum + group_bits));
+                        if (last_group) seg.bits[k] = sum + group_bits;
+                    }
+                }
+                __syncthreads();
+                if (s_abort) return;
+                const uint64_t start = s_before;
+                uint64_t end = start + group_bits;
+                if (last_group) { // every scan ends on a byte boundary, padded with 1-bits (BitWriterMsb::finish)
+                    const uint32_t n = (uint32_t)((8 - (end & 7)) & 7);
+                    if (n) {
+                        pad_word = (uint32_t)((end >> 5) - (start >> 5));
+                        pad_mask = ((1u << n) - 1u) << (32 - (uint32_t)(end & 31) - n);
+                    }
+                    end += n;
+                }
+                first_word = start >> 5;
+                sh = (uint32_t)(start & 31);
+                out_words = (uint32_t)((end - (first_word << 5) + 31) >> 5);
+                tail_partial = (end & 31) != 0 && !last_group;
+            } else {
+                __syncthreads();
+            }
+            const uint32_t carry = s_carry;
+            const bool last_round = wbase + wn == local_words;
+            const uint32_t upto = last_round ? out_words - wbase : wn;
+            uint32_t word0 = 0, tail_word = 0;
+            for (uint32_t i = lane; i < upto; i += kGroup) {
+                const uint32_t j = wbase + i;
+                const uint32_t cur = i < wn ? buf[i] : 0u, prev = i ? buf[i - 1] : carry;
+                uint32_t v = sh ? (cur >> sh) | (prev << (32 - sh)) : cur;
+                v |= j == pad_word ? pad_mask : 0u;
+                const bool is_head = j == 0 && sh != 0, is_tail = tail_partial && j + 1 == out_words;
+                if (is_head) word0 = v;
+                if (is_tail) tail_word = v;
+                if (!is_head && !is_tail) __builtin_nontemporal_store(v, &stream[first_word + j]);
+            }
+            const bool has_tail = last_round && tail_partial;
+            const bool pass_through = has_tail && out_words == 1 && sh != 0;
+            if (has_tail && !pass_through && (uint32_t)lane == (upto - 1) % kGroup) store_relaxed(&tails[g], kTailValid | tail_word);
+            if (wbase == 0) head_word = word0;
+            if (lane == 0) s_carry = buf[wn - 1];
+            __syncthreads();
+        }
+        if (sh != 0 && lane == 0) {
+            uint32_t inherited = 0;
+            if (g > floor_g) {
+                unsigned long long t = load_relaxed(&tails[g - 1]);
+                uint32_t polls = 0;
+                while (!(t & kTailValid)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > spin_budget) { raise_abort(state, host_abort); return; }
+                    t = load_relaxed(&tails[g - 1]);
+                }
+                inherited = (uint32_t)t;
+            }
+            const uint32_t merged = inherited | head_word;
+            if (tail_partial && out_words == 1) store_relaxed(&tails[g], kTailValid | merged);
+            else __builtin_nontemporal_store(merged, &stream[first_word]);
+        }
+    }
+}
+
 // ---- count: symbol statistics for optimised tables (count_block, jpeg/mod.rs:826-860) with the flat walk ---------------
 // One lane per block like the code kernel; the counters live in LDS per workgroup (LDS atomics without return, a
 // private dummy counter per lane for "no symbol here").  Every workgroup then stores its counters as one row of a
@@ -579,7 +830,7 @@ __global__ __launch_bounds__(kStuffThreads) __attribute__((amdgpu_waves_per_eu(4
         sidx = lo;
         local_t = t - seg.layout[1 + sidx];
         nbytes = seg.bytes[sidx];
-        stream += sidx * seg.stream_words;
+        stream += seg.var ? seg.var_word[sidx] : sidx * seg.stream_words;
     } else {
         const uint64_t total_bits = code_state[1];
         nbytes = band ? (total_bits - (shift < total_bits ? shift : total_bits)) / 8 : (total_bits + 7) / 8;
@@ -754,6 +1005,29 @@ hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool
         if (a.mode == 2) PIXO_LAUNCH_CODE(2, false); else if (a.mode == 1) PIXO_LAUNCH_CODE(1, false); else PIXO_LAUNCH_CODE(0, false);
     }
 #undef PIXO_LAUNCH_CODE
+    return hipGetLastError();
+}
+
+size_t prog_code_state_words(uint64_t groups) { return 2 + 3 * (size_t)groups; }
+uint64_t prog_groups(uint64_t blocks) { return (blocks + kGroup - 1) / kGroup; }
+size_t prog_stream_bytes(uint32_t scan_id, uint64_t blocks)
+{ // per block: a DC symbol of at most 16 + 11 bits; a band of n coefficients: n symbols of at most 16 + 10 bits (ZRL codes
+  // only where coefficients are missing) + run symbols of at most 30 bits in front and behind; + 64 bytes the kernels read into
+    const uint64_t bits = scan_id < 3 ? 27 : ((scan_id == 3 ? 10 : (scan_id == 4 ? 53 : 63)) * 26 + 60);
+    return (size_t)((blocks * bits + 7) / 8 + 64 + 15) / 16 * 16;
+}
+hipError_t launch_prog_code(const ProgCode &a, const SegArgs &seg, unsigned long long *d_state, bool state_is_zero, uint32_t *d_stream,
+                            unsigned long long *d_clear, size_t clear_words, unsigned long long *host_totals, hipStream_t s, uint32_t spin_budget)
+{
+    const uint64_t groups = a.first_group[a.nscans];
+    if (host_totals) host_totals[3] = 0;
+    if (groups == 0 || groups > 0x7FFFFFFFull || clear_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (!state_is_zero) {
+        hipError_t e = hipMemsetAsync(d_state, 0, prog_code_state_words(groups) * 8, s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(prog_code_kernel, dim3((unsigned)groups), dim3(kGroup), 0, s, a, seg, d_state, d_stream, d_clear,
+                       d_clear ? (uint32_t)clear_words : 0u, host_totals, spin_budget);
     return hipGetLastError();
 }
 

@@ -14,9 +14,9 @@ namespace pixo_capi {
 // stuffed segment — every segment copied from the device straight to its final place — then EOI.  (Round 1 copied the
 // stuffed stream to the host in one piece and spliced it into a std::vector, which the caller copied once more: two
 // extra passes over the file through freshly mapped pages, about half of the 2.3 ms of a 4096x4096 preset-2 file.)
-int device_progressive_scans(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_host::Geometry &g,
-                             const pixo_host::HuffSet &h, Context &c, const std::vector<uint8_t> &head, const uint8_t **file,
-                             size_t *file_len, uint8_t *pinned_dest, size_t dest_cap)
+static int device_progressive_scans_multipass(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_host::Geometry &g,
+                                              const pixo_host::HuffSet &h, Context &c, const std::vector<uint8_t> &head, const uint8_t **file,
+                                              size_t *file_len, uint8_t *pinned_dest, size_t dest_cap)
 {
     namespace pd = pixo_dev;
     Stopwatch sw;
@@ -115,6 +115,158 @@ int device_progressive_scans(const int16_t *dy, const int16_t *dcb, const int16_
     *file_len = pos + 2;
     sw.lap("prog stuff+copy+splice");
     return PIXO_OK;
+}
+
+// write_sos_progressive (jpeg/mod.rs:650-682) of scan i of simple_progressive_script (progressive.rs:98-110)
+static void sos_of_scan(int i, uint8_t sos[10])
+{
+    static const uint8_t script[7][3] = {{0, 0, 0}, {1, 0, 0}, {2, 0, 0}, {0, 1, 10}, {0, 11, 63}, {1, 1, 63}, {2, 1, 63}};
+    const uint8_t v[10] = {0xFF, 0xDA, 0, 8, 1, static_cast<uint8_t>(script[i][0] + 1), static_cast<uint8_t>(script[i][0] == 0 ? 0x00 : 0x11),
+                           script[i][1], script[i][2], 0};
+    std::memcpy(sos, v, 10);
+}
+
+// The same scans in ONE pass over the tuple (round 4): prog_code_kernel (every scan a byte-aligned segment with a packed stream
+// of its own), the segment layout, and stuff_fused<SEG>, which leaves the seven stuffed scans in c.e_out at their FINAL
+// spacing — ten free bytes between two of them, where the next scan's SOS header goes — so that the file's entropy-coded
+// part crosses PCIe as one copy (a gray image, whose chroma scans are empty and yet have headers: one copy per run of scans
+// that lie at their final spacing) and the host only fills in the headers.  Three launches and one synchronisation, where
+// the multi-pass form above has about twenty launches, three synchronisations and one copy per scan.
+// kRetryMultipass: a look-back gave up waiting (the caller runs the multi-pass form).
+static int device_progressive_scans_fused(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_host::Geometry &g,
+                                          const pixo_host::HuffSet &h, Context &c, const std::vector<uint8_t> &head, const uint8_t **file,
+                                          size_t *file_len, uint8_t *pinned_dest, size_t dest_cap)
+{
+    namespace pd = pixo_dev;
+    Stopwatch sw;
+    hipStream_t stream = c.stream;
+    const uint64_t size[7] = {g.y_blocks, g.c_blocks, g.c_blocks, g.y_blocks, g.y_blocks, g.c_blocks, g.c_blocks};
+    pd::ProgCode a{};
+    pd::SegArgs sg;
+    a.y = dy; a.cb = g.gray ? dy : dcb; a.cr = g.gray ? dy : dcr;
+    size_t stream_bytes = 0;
+    uint64_t blocks_all = 0;
+    a.first_group[0] = 0;
+    for (uint32_t i = 0; i < 7; ++i) {
+        if (!size[i]) continue; // (the chroma scans of a gray image: headers only)
+        const uint32_t k = a.nscans++;
+        a.scan_id[k] = i;
+        a.size[k] = size[i];
+        a.first_group[k + 1] = a.first_group[k] + pd::prog_groups(size[i]);
+        sg.var_word[k] = stream_bytes / 4;
+        stream_bytes += pd::prog_stream_bytes(i, size[i]);
+        blocks_all += size[i];
+    }
+    const uint64_t groups = a.first_group[a.nscans];
+    sg.nsegs = a.nscans;
+    sg.var = 1;
+    sg.marker_bytes = 10; // room for the next scan's SOS header
+    HIP_TRY(c.e_tables.reserve(pixo_scan::kScanTableUpload * 4));
+    HIP_TRY(c.e_stream.reserve(stream_bytes + 64));
+    const size_t state_words = pd::prog_code_state_words(groups);
+    if (state_words * 8 > c.e_code_state.cap) c.code_state_zero_words = 0; // (a new buffer)
+    HIP_TRY(c.e_code_state.reserve(state_words * 8));
+    const size_t stuff_words = pd::fused_stuff_state_words(stream_bytes) + 8;
+    HIP_TRY(c.e_stuff_state.reserve(stuff_words * 8));
+    HIP_TRY(c.e_segs.reserve((4 * 8 + 2) * 8));
+    unsigned long long *base = c.e_segs.as<unsigned long long>();
+    sg.bits = base; sg.layout = base + 8; sg.bytes = base + 2 * 8 + 2; sg.out_end = base + 3 * 8 + 2;
+    { const int rc_s = c.reserve_hsegs(8); if (rc_s) return rc_s; }
+    sg.host_out_end = reinterpret_cast<unsigned long long *>(c.h_segs);
+    { const int rc_t = c.ensure_totals(); if (rc_t) return rc_t; }
+    uint32_t packed[pixo_host::kScanTableWords];
+    pixo_host::pack_scan_tables(h, packed);
+    for (uint32_t &w : packed) // progressive.rs:363-381: a symbol the table lacks is coded as (0, 4 bits)
+        if ((w >> 16) == 0) w = 4u << 16;
+    { const int rc = upload_scan_tables(c, packed, stream); if (rc) return rc; }
+    a.tables = c.e_tables.as<uint32_t>();
+    const bool zero = c.code_state_zero_words >= state_words;
+    c.code_state_zero_words = 0;
+    unsigned long long *mailbox = reinterpret_cast<unsigned long long *>(c.h_totals);
+    HIP_TRY(pd::launch_prog_code(a, sg, c.e_code_state.as<unsigned long long>(), zero, c.e_stream.as<uint32_t>(),
+                                 c.e_stuff_state.as<unsigned long long>(), stuff_words, mailbox, stream, debug().spin_budget));
+    HIP_TRY(pd::launch_seg_layout(sg, const_cast<unsigned long long *>(sg.layout), const_cast<unsigned long long *>(sg.bytes), mailbox, stream));
+    // tiles: a guess of 40 bytes per (scan, block) pair + one partial tile per scan; the layout kernel says how many there are
+    uint64_t first_tile = 0, tiles = pd::stuff_tiles(blocks_all * 40 + 4096) + a.nscans;
+    size_t want_cap = std::max<size_t>(stream_bytes / 4, 4096);
+    uint64_t scan_bytes = 0;
+    for (int attempt = 0;; ++attempt) {
+        HIP_TRY(c.e_out.reserve(want_cap));
+        HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), state_words, 0, false,
+                                       stream_bytes + 8 * 16384, first_tile, tiles, c.e_stuff_state.as<unsigned long long>(),
+                                       /*state_is_zero=*/attempt == 0, c.e_out.as<uint8_t>(), c.e_out.cap, mailbox, stream, nullptr, 0, &sg,
+                                       debug().spin_budget));
+        c.code_state_zero_words = state_words;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c.h_totals[3]) return scan_retry_multipass(c);
+        const uint64_t all_tiles = c.h_totals[2];
+        if (all_tiles > first_tile + tiles) { // the guess was short: the tiles behind it, same buffers
+            if (attempt > 2) return fail(PIXO_ERR_COMPRESSION, "Compression error: packed stream longer than announced");
+            first_tile += tiles;
+            tiles = all_tiles - first_tile;
+            continue;
+        }
+        scan_bytes = c.h_totals[1];
+        if (scan_bytes > c.e_out.cap) { // (unusually large: grow and repeat the stuffing pass only)
+            if (attempt > 2) return fail(PIXO_ERR_COMPRESSION, "Compression error: stuffed stream larger than announced");
+            want_cap = static_cast<size_t>(scan_bytes);
+            first_tile = 0;
+            tiles = all_tiles;
+            continue;
+        }
+        break;
+    }
+    sw.lap("prog code+layout+stuff");
+    // c.e_out: [scan k0 | 10 | scan k1 | 10 | ...]; c.h_segs[k]: where scan k's bytes end.  The file: head, then per scan of the
+    // script its SOS header and (if it has blocks) its bytes, then EOI.
+    uint64_t dev_begin[7], dev_end[7];
+    for (uint32_t k = 0; k < a.nscans; ++k) {
+        dev_end[k] = c.h_segs[k];
+        dev_begin[k] = k ? c.h_segs[k - 1] + sg.marker_bytes : 0;
+    }
+    const size_t payload = static_cast<size_t>(scan_bytes - static_cast<uint64_t>(sg.marker_bytes) * (a.nscans - 1));
+    const size_t total = head.size() + 7 * 10 + payload + 2;
+    uint8_t *p = pinned_dest;
+    if (!p || total > dest_cap) {
+        const int rc = c.reserve_hfile(total);
+        if (rc) return rc;
+        p = c.h_file;
+    }
+    std::memcpy(p, head.data(), head.size());
+    size_t pos = head.size();
+    size_t file_at[7]; // where scan k's bytes go
+    size_t sos_at[7];
+    { uint32_t k = 0;
+      for (int i = 0; i < 7; ++i) {
+          sos_at[i] = pos; pos += 10;
+          if (size[i]) { file_at[k] = pos; pos += static_cast<size_t>(dev_end[k] - dev_begin[k]); ++k; }
+      } }
+    // one copy per run of scans whose spacing in c.e_out is their spacing in the file
+    for (uint32_t k = 0; k < a.nscans;) {
+        uint32_t e = k;
+        while (e + 1 < a.nscans && file_at[e + 1] - file_at[k] == dev_begin[e + 1] - dev_begin[k]) ++e;
+        const size_t n = static_cast<size_t>(dev_end[e] - dev_begin[k]);
+        if (n) HIP_TRY(hipMemcpyAsync(p + file_at[k], c.e_out.as<uint8_t>() + dev_begin[k], n, hipMemcpyDeviceToHost, stream));
+        k = e + 1;
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int i = 0; i < 7; ++i) sos_of_scan(i, p + sos_at[i]); // (after the copies: a run's copy passes over the gaps)
+    p[pos] = 0xFF; p[pos + 1] = 0xD9;
+    *file = p;
+    *file_len = pos + 2;
+    sw.lap("prog copy+headers");
+    return PIXO_OK;
+}
+
+int device_progressive_scans(const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_host::Geometry &g,
+                             const pixo_host::HuffSet &h, Context &c, const std::vector<uint8_t> &head, const uint8_t **file,
+                             size_t *file_len, uint8_t *pinned_dest, size_t dest_cap)
+{
+    if (!debug().multipass_entropy) {
+        const int rc = device_progressive_scans_fused(dy, dcb, dcr, g, h, c, head, file, file_len, pinned_dest, dest_cap);
+        if (rc != kRetryMultipass) return rc;
+    }
+    return device_progressive_scans_multipass(dy, dcb, dcr, g, h, c, head, file, file_len, pinned_dest, dest_cap);
 }
 
 // Huffman tables of a file over the device tuple: the standard ones, or (optimize_huffman) those built

@@ -443,6 +443,12 @@ extern "C" void emu_trellis_fast(const float *dct, const float *q, long nblocks,
     }
 }
 
+// (a lane's scratch: the sink of the flat walks in the single-pass kernels)
+struct EmuLaneSink {
+    uint32_t *words;
+    uint32_t cap;
+    void or_word(bool, uint32_t word, uint32_t value) { words[word < cap ? word : cap] = value; } // (the last store wins)
+};
 // ---------------------------------------------------------------------------------------------
 // Device progressive scan coder (jpeg_scan_block.h: band_flags, band_run_before, prog_emit) lane by
 // lane: flags, rank / by_rank, lengths, prefix sum, pack (blocks in reverse order), pad, stuffing.
@@ -503,6 +509,98 @@ extern "C" long emu_progressive(const int16_t *y, const int16_t *cb, const int16
             if (byte == 0xFF) out[o++] = 0x00;
         }
         seg_len[i] = o - start;
+    }
+    return o;
+}
+
+// The SINGLE-PASS form of the progressive coder (prog_code_kernel, jpeg_scan_fused.hip) group by group on the CPU: every lane
+// codes its block's own symbols with the flat band walk into a scratch from bit 0 (band_pack_flat / dc_pack_flat), the run
+// counter's contributions come from the ballots of each 64-lane wavefront (band_count_in_wave, band_wave_summary), the
+// count carried from wavefront to wavefront and from group to group, and band_edge says what goes in front of and behind
+// the lane's symbols.  Same output format as emu_progressive.
+extern "C" long emu_progressive_flat(const int16_t *y, const int16_t *cb, const int16_t *cr, uint64_t yb, uint64_t cbn,
+                                     const uint32_t *tables, uint8_t *out, long cap, long *seg_len)
+{
+    using namespace pixo_scan;
+    const uint64_t sizes[7] = {yb, cbn, cbn, yb, yb, cbn, cbn};
+    uint32_t wtab[kWalkWords];
+    for (int i = 0; i < kWalkWords; i++) wtab[i] = walk_table_word(tables, i);
+    const int kLanes = 192, kScratch = 64;
+    long o = 0;
+    for (int scan = 0; scan < 7; scan++) {
+        const int comp = prog_comp(scan), cls = comp ? 1 : 0;
+        const int16_t *base = comp == 0 ? y : (comp == 1 ? cb : cr);
+        const int ss = scan < 3 ? 0 : (scan == 4 ? 11 : 1), se = scan < 3 ? 0 : (scan == 3 ? 10 : 63);
+        uint32_t eob_syms[15];
+        for (int n = 0; n < 15; n++) eob_syms[n] = tables[cls * kClassSyms + kDcSyms + (n << 4)];
+        std::vector<uint32_t> stream(1, 0);
+        uint64_t bits = 0;
+        auto put = [&](uint32_t left, uint32_t len) { // `len` bits at the top of `left`
+            for (uint32_t i = 0; i < len; i++) {
+                if ((bits >> 5) >= stream.size()) stream.push_back(0);
+                if ((left >> (31 - i)) & 1u) stream[bits >> 5] |= 1u << (31 - (bits & 31));
+                bits++;
+            }
+        };
+        uint64_t carry_group = 0; // the count flowing into the group
+        for (uint64_t g0 = 0; g0 < sizes[scan]; g0 += kLanes) {
+            uint32_t scratch[kLanes][kScratch + 1];
+            uint32_t len[kLanes];
+            bool z[kLanes], t[kLanes], live[kLanes];
+            for (int l = 0; l < kLanes; l++) {
+                const uint64_t b = g0 + l;
+                live[l] = b < sizes[scan];
+                z[l] = t[l] = false; len[l] = 0;
+                if (!live[l]) continue;
+                uint32_t wds[32];
+                memcpy(wds, base + b * 64, 128);
+                FlatPack<EmuLaneSink> p;
+                p.sink = EmuLaneSink{scratch[l], (uint32_t)kScratch};
+                p.acc = 0; p.pending = 0; p.word = 0;
+                if (scan < 3) dc_pack_flat(wds, b ? base[(b - 1) * 64] : 0, wtab + cls * kWalkClassWords, p);
+                else band_pack_flat(wds, ss, se, wtab + cls * kWalkClassWords, p, &z[l], &t[l]);
+                len[l] = p.word * 32u + p.pending;
+                p.finish();
+            }
+            uint64_t wave_in = carry_group;
+            bool group_any = false;
+            for (int wv = 0; wv < kLanes / 64; wv++) {
+                uint64_t zmask = 0, tmask = 0;
+                for (int l = 0; l < 64; l++) {
+                    if (z[wv * 64 + l]) zmask |= 1ull << l;
+                    if (t[wv * 64 + l] && live[wv * 64 + l]) tmask |= 1ull << l;
+                }
+                for (int l = 0; l < 64; l++) {
+                    const int L = wv * 64 + l;
+                    if (!live[L]) continue;
+                    BandEdge e{};
+                    if (scan >= 3) {
+                        const BandCount c = band_count_in_wave(zmask, tmask, l);
+                        e = band_edge((uint32_t)(c.local + (c.carried ? wave_in : 0)), true, z[L], t[L], g0 + L + 1 == sizes[scan], eob_syms);
+                    }
+                    put(e.pre.left, e.pre.len);
+                    for (uint32_t i = 0; i < len[L]; i += 32) put(scratch[L][i >> 5], std::min(32u, len[L] - i));
+                    put(e.post.left, e.post.len);
+                }
+                bool any; uint32_t tail;
+                band_wave_summary(zmask, tmask, &any, &tail);
+                wave_in = any ? tail : wave_in + tail;
+                group_any |= any;
+            }
+            carry_group = wave_in;
+            (void)group_any;
+        }
+        const int n = (int)((8 - (bits & 7)) & 7);
+        put(0xFFFFFFFFu, (uint32_t)n);
+        const uint64_t nbytes = bits / 8;
+        const long start = o;
+        for (uint64_t b = 0; b < nbytes; b++) {
+            const uint8_t byte = (uint8_t)(stream[b >> 2] >> (24 - 8 * (b & 3)));
+            if (o + 2 > cap) return -1;
+            out[o++] = byte;
+            if (byte == 0xFF) out[o++] = 0x00;
+        }
+        seg_len[scan] = o - start;
     }
     return o;
 }
@@ -643,11 +741,6 @@ extern "C" void emu_int_color(int r, int g, int b, int32_t *out)
 // prefix-summed, and — unless a block was longer than the scratch — the scratches are OR-ed, shifted, into the group's
 // zeroed bit buffer in windows of `window_words`.  Returns the packed (unstuffed, unpadded) bits of the whole scan as
 // MSB-first words, or -1 when some group holds a long block (the device then takes its two-walk path).
-struct EmuLaneSink {
-    uint32_t *words;
-    uint32_t cap;
-    void or_word(bool, uint32_t word, uint32_t value) { words[word < cap ? word : cap] = value; } // (the last store wins)
-};
 extern "C" long emu_scan_single_walk(const int16_t *y, const int16_t *cb, const int16_t *cr, int mode, uint64_t nblocks,
                                      const uint32_t *tables, uint32_t scratch_words, uint32_t window_words, uint32_t *out_words,
                                      uint64_t *total_bits)

@@ -1,6 +1,8 @@
-"""The DEVICE progressive scan coder (jpeg_scan_block.h: band_flags / band_run_before / prog_emit)
-compiled for the host and run lane by lane — blocks packed in reverse order — against the seven
-entropy-coded segments of the oracle's progressive file (standard tables)."""
+"""The DEVICE progressive scan coder compiled for the host and run lane by lane against the seven entropy-coded segments
+of the oracle's progressive file (standard tables) — in both of its forms: the multi-pass one (jpeg_scan_block.h:
+band_flags / band_run_before / prog_emit; blocks packed in reverse order) and the single-pass one of round 4
+(band_pack_flat / dc_pack_flat for a lane's own symbols, band_count_in_wave / band_wave_summary / band_edge for what the
+end-of-band run counter adds around them, wavefront by wavefront and group by group)."""
 import ctypes as C
 
 import numpy as np
@@ -30,17 +32,18 @@ def _segments(jpeg: bytes):
     return segs
 
 
-def _emu(y, cb, cr):
+def _emu(y, cb, cr, entry="emu_progressive"):
     L = E.lib()
-    L.emu_progressive.restype = C.c_long
-    L.emu_progressive.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+    fn = getattr(L, entry)
+    fn.restype = C.c_long
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.emu_progressive_tables.argtypes = [C.c_void_p]
     tables = np.zeros(536, np.uint32)
     L.emu_progressive_tables(tables.ctypes.data)
     n = y.shape[0] + 2 * cb.shape[0]
     out = np.zeros(n * 600 + 64, np.uint8)
     seg_len = (C.c_long * 7)()
-    total = L.emu_progressive(y.ctypes.data, cb.ctypes.data if cb.size else None, cr.ctypes.data if cr.size else None,
+    total = fn(y.ctypes.data, cb.ctypes.data if cb.size else None, cr.ctypes.data if cr.size else None,
                               y.shape[0], cb.shape[0], tables.ctypes.data, out.ctypes.data, out.size, seg_len)
     assert total >= 0
     segs, o = [], 0
@@ -55,6 +58,7 @@ def _check(px, w, h, ct, ss, q):
     want = _segments(O.encode_from_coeffs(y, cb, cr, O.make_options(w, h, ct, q, ss, progressive=True)))
     assert len(want) == 7
     assert _emu(y, cb, cr) == want
+    assert _emu(y, cb, cr, "emu_progressive_flat") == want  # the single-pass form (round 4)
 
 
 @pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])

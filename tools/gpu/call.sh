@@ -1,0 +1,82 @@
+#!/bin/bash
+# The ONE runner for gpurun calls (round 4 replaced 54 one-off r*.sh scripts; what they measured is kept under profiles/).
+#   gpurun --timeout T -- 'bash tools/gpu/call.sh <tag> <recipe> [args] [-- <recipe> [args]]...'
+# Everything a recipe prints goes to gpurun_out/<tag>/<recipe>_<k>.txt as well.  Recipes:
+#   info                      GPU, host cores, cgroup quota
+#   smoke                     __graft_entry__.smoke()
+#   tests [pytest args]       python -m pytest -m gpu -x -q <args or tests/>
+#   bench [bench.py args]     one bench line (summary + the raw line in bench_line.json)
+#   ab <workload> <reps> <variant>...   bench.py --no-extras per variant: "base" = the in-tree library, anything else =
+#                             pixo_amd/ab_<variant>.so (built by tools/ab_build.sh); prints ms_per_step / kernel_us / frac
+#   kstats <name> <cmd...>    rocprofv3 --kernel-trace --stats of <cmd>, the kernel_stats csv copied to <tag>/<name>_kernel_stats.csv
+#   pmc <name> <filter> <cmd...>   separate rocprofv3 --pmc passes (tools/pmc_summary.py on kernels matching <filter>)
+#   py <script> [args]        python <script> (tools/*.py probes)
+set -u
+ROOT="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$ROOT"; export TMPDIR=/tmp
+TAG="$1"; shift
+O="gpurun_out/$TAG"; mkdir -p "$O"
+
+recipe_info() { rocminfo | grep -E "Marketing Name|gfx" | head -4; nproc; grep -m1 "model name" /proc/cpuinfo; cat /sys/fs/cgroup/cpu.max 2>/dev/null; rocm-smi --showclocks 2>/dev/null | grep -E "sclk|mclk" | head -4; }
+recipe_smoke() { timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5; }
+recipe_tests() { if [ $# -eq 0 ]; then set -- tests; fi; timeout 2400 python -m pytest -m gpu -x -q "$@" 2>&1 | tail -25; }
+recipe_bench() {
+  timeout 1500 python bench.py "$@" 2>"$O/bench_stderr.txt" | grep '^{' | tail -1 > "$O/bench_line.json"
+  python3 - "$O/bench_line.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read())
+r = d.get("roofline") or {}
+print("value", d["value"], d["unit"], "ms_per_step", d["ms_per_step"], d.get("ms_per_step_min"), d.get("ms_per_step_max"), "kernel_us", r.get("kernel_us_avg"), "frac", r.get("frac"))
+print("frac by wall", round(r.get("algorithmic_bytes_per_launch", 0) / (d["ms_per_step"] * 1e-3) / 8e12, 4) if r else None)
+for k, v in (d.get("other_configs") or {}).items():
+    print(" ", k, {a: b for a, b in v.items() if a in ("kernel_us", "frac", "ms_per_step", "ms_per_batch", "value", "error", "leg_wall_s", "bound", "frac_issue")})
+for k in ("whole_file", "rccl", "cpu_baseline"):
+    if k in d: print(" ", k, json.dumps(d[k])[:400])
+PY
+  tail -5 "$O/bench_stderr.txt"
+}
+recipe_ab() {
+  wl="$1"; reps="$2"; shift 2
+  for rep in $(seq 1 "$reps"); do
+    for v in "$@"; do
+      lib=""; [ "$v" != base ] && lib="$ROOT/pixo_amd/ab_$v.so"
+      PIXO_HIP_LIB=$lib timeout 300 python3 bench.py --workload "$wl" --no-cpu-baseline --no-extras 2>/dev/null | grep '^{' | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$wl $v rep$rep ms_per_step', d['ms_per_step'], 'min', d.get('ms_per_step_min'), 'kernel_us', d['roofline']['kernel_us_avg'], 'frac', d['roofline']['frac'])"
+    done
+  done
+}
+# (rocprofv3 runs its command from /tmp: arguments that name files of the repo become absolute paths)
+absargs() { ABS=(); for a in "$@"; do if [ -e "$ROOT/$a" ] && [ "${a#/}" = "$a" ]; then ABS+=("$ROOT/$a"); else ABS+=("$a"); fi; done; }
+recipe_kstats() {
+  name="$1"; shift
+  absargs "$@"; set -- "${ABS[@]}"
+  rm -rf "/tmp/prof_$name"
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "/tmp/prof_$name" -o kt -- "$@" > "$ROOT/$O/${name}_under_trace.log" 2>&1)
+  find "/tmp/prof_$name" -name "*kernel_stats*" -exec cp {} "$O/${name}_kernel_stats.csv" \;
+  find "/tmp/prof_$name" -name "*kernel_trace*" -exec cp {} "$O/${name}_kernel_trace.csv" \;
+  head -12 "$O/${name}_kernel_stats.csv"
+}
+recipe_pmc() {
+  name="$1"; filt="$2"; shift 2
+  absargs "$@"; set -- "${ABS[@]}"
+  i=0
+  for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+             "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM" \
+             "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
+    i=$((i+1)); rm -rf "/tmp/pmc_${name}_$i"
+    (cd /tmp && timeout 400 rocprofv3 --pmc $PMC --output-format csv -d "/tmp/pmc_${name}_$i" -o pmc -- "$@" > "$ROOT/$O/${name}_pmc$i.log" 2>&1)
+    f=$(find "/tmp/pmc_${name}_$i" -name "*counter_collection*" | head -1)
+    [ -n "$f" ] && python "$ROOT/tools/pmc_summary.py" "$f" "$filt" 2>&1 | tee "$O/${name}_pmc${i}_summary.txt"
+  done
+}
+recipe_py() { timeout 900 python "$@" 2>&1 | tail -60; }
+
+while [ $# -gt 0 ]; do
+  r="$1"; shift
+  args=()
+  while [ $# -gt 0 ] && [ "$1" != "--" ]; do args+=("$1"); shift; done
+  [ $# -gt 0 ] && shift
+  echo "==== $r ${args[*]:-}"
+  n=$(ls "$O" | grep -c "^${r}_") || true
+  "recipe_$r" ${args[@]+"${args[@]}"} 2>&1 | tee "$O/${r}_${n}.txt"
+done

@@ -426,7 +426,8 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 //     its own (descriptor A: a group that holds a non-empty block publishes the count behind it as a PREFIX at once; a
 //     group of empty blocks publishes its count as an aggregate and, once it knows what flows in, the sum as a prefix).  The
 //     A descriptors go out right after the walk, before any length is known, so that look-back rarely waits;
-//   * a group may have no bits at all (192 empty blocks): it still takes part in look-back B and hands the shared word on.
+//   * a group may have no bits at all (192 empty blocks): it leaves an aggregate of zero bits in look-back B and a
+//     "transparent" mark in its tail slot (the stream word two groups share is found by a look-back over the tails) and is done.
 // state: [0] abort flag, [1] -, then per group: descriptor A, descriptor B, tail.
 constexpr uint32_t kEobSyms = 16; // per class: the packed words of symbols 0x00 .. 0xE0 (end-of-band runs), one spare
 __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) void prog_code_kernel
@@ -547,6 +548,15 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         }
         if (lane == 0) publish_aggregate(desc, g, floor_g, group_bits);
         const bool last_group = first_in_chain + kGroup >= nblocks_chain;
+        // The stream word two groups share travels as the earlier group's `tail`.  A group WITHOUT bits (192 empty blocks) is
+        // transparent for it: it says so at once, and the group that needs the word finds the last group with bits by a
+        // look-back over the tails (512 per round) — passing the word on from group to group made one chain of waits out
+        // of every run of empty groups (a smooth 4096x4096 image: 1,366 groups in a row, 276 us for the launch).
+        const bool transparent = group_bits == 0 && !last_group;
+        if (transparent) { // nothing to place: its B descriptor stays an aggregate of zero bits, which later groups walk past
+            if (lane == 0) store_relaxed(&tails[g], kFlagAggregate);
+            return;
+        }
         const uint32_t my_bit = wave_base + (incl - len);
         const uint32_t bit_words = (group_bits + 31) >> 5;
         const uint32_t local_words = bit_words ? bit_words : 1u; // (a group without bits still runs one round: look-back, shared word)
@@ -622,6 +632,9 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                 sh = (uint32_t)(start & 31);
                 out_words = (uint32_t)((end - (first_word << 5) + 31) >> 5);
                 tail_partial = (end & 31) != 0 && !last_group;
+                // (every group leaves SOMETHING in its tail slot — the look-back over the tails waits for all the slots it reads:
+                // a group whose bits end on a word boundary hands nothing on)
+                if (!tail_partial && lane == 0) store_relaxed(&tails[g], kFlagPrefix);
             } else {
                 __syncthreads();
             }
@@ -641,26 +654,24 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             }
             const bool has_tail = last_round && tail_partial;
             const bool pass_through = has_tail && out_words == 1 && sh != 0;
-            if (has_tail && !pass_through && (uint32_t)lane == (upto - 1) % kGroup) store_relaxed(&tails[g], kTailValid | tail_word);
+            if (has_tail && !pass_through && (uint32_t)lane == (upto - 1) % kGroup) store_relaxed(&tails[g], kFlagPrefix | tail_word);
             if (wbase == 0) head_word = word0;
             if (lane == 0) s_carry = buf[wn - 1];
             __syncthreads();
         }
-        if (sh != 0 && lane == 0) {
-            uint32_t inherited = 0;
-            if (g > floor_g) {
-                unsigned long long t = load_relaxed(&tails[g - 1]);
-                uint32_t polls = 0;
-                while (!(t & kTailValid)) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++polls > spin_budget) { raise_abort(state, host_abort); return; }
-                    t = load_relaxed(&tails[g - 1]);
-                }
-                inherited = (uint32_t)t;
+        // ---- the word shared with the bits before.  A group whose bits all lie INSIDE that word (a few symbols among empty
+        // blocks) has nothing to write: it leaves its bits as an AGGREGATE in its tail slot — bits of different groups are
+        // different bits, so the look-back's sum over such slots is their OR — and the group that completes the word finds
+        // them, and the tail of the last group that left a word unfinished (a PREFIX), in one look-back: no group waits for
+        // another group's look-back (handing the word on from group to group chained every run of small groups).
+        if (sh != 0) {
+            if (tail_partial && out_words == 1) {
+                if (lane == 0) store_relaxed(&tails[g], kFlagAggregate | head_word);
+            } else if (wave == 0) {
+                const uint64_t inherited = look_back(tails, g, floor_g, 0, state, host_abort, spin_budget);
+                if (inherited == kLookBackFailed) return;
+                if (lane == 0) __builtin_nontemporal_store((uint32_t)inherited | head_word, &stream[first_word]);
             }
-            const uint32_t merged = inherited | head_word;
-            if (tail_partial && out_words == 1) store_relaxed(&tails[g], kTailValid | merged);
-            else __builtin_nontemporal_store(merged, &stream[first_word]);
         }
     }
 }

@@ -151,11 +151,12 @@ PIXO_TDEV void quantize_block(const float *dct, const float *q, int16_t *out, ui
 //     run 0 (all non-zero-valued parents and a (0, 0) parent): those fold into one entry that sits where
 //     the first of them would have been inserted;
 //   * insertion order therefore is: zero-successor of parent 0, the candidates, the zero-successors of
-//     parents 1..7 — twelve slots; the reference's stable sort by cost is a sorting network over 64-bit
+//     parents 1..7 — twelve slots, of which at most eleven are ever filled (the round and the ceil candidate exclude each
+//     other, candidate_kinds3); the reference's stable sort by cost is an 11-input sorting network over 64-bit
 //     keys (cost bits, slot) (costs are sums of non-negative terms, so their bit patterns order like
 //     the values), the eight smallest survive;
-//   * a back-pointer is 6 bits (candidate kind, parent): 48 bits per coefficient; values are recomputed
-//     from the kind while walking back.
+//   * a back-pointer is 6 bits (candidate kind, parent), one byte per survivor: 64 bits per coefficient; values are
+//     recomputed from the kind while walking back.
 // Env: coef(zz), step(zz) (zig-zag position -> f32), rate_at(4 rs) (ac_rate as a table of rate_value(rs), by byte offset),
 // trail_put(pos, u64), trail_get(pos), out(zz, i16).
 PIXO_TDEV float rate_bits(int rs)
@@ -175,6 +176,15 @@ PIXO_TDEV float u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f
 // 0x7F800000), so that the sorting network can run on v_min_f64 / v_max_f64 (below).
 constexpr uint32_t kNoState = 0x7FEFFFFFu;
 
+// (c ? a : b stays v_cndmask_b32.  The instruction microbenchmarks price it at ~23.5 cycles per wavefront and SIMD
+// (profiles/r01_ubench_valu_rates.txt, r03_ubench_form_rate.txt), which would make the ~50 selects per coefficient
+// position half of this kernel; replacing 21 of them by a v_mov under a narrowed EXEC mask — v_cmp into a scalar pair,
+// three scalar instructions around the move — made the kernel SLOWER, 294 -> 321 us for 4096x4096 (round 4,
+// profiles/r04_trellis.txt): inside real code the select does not cost what the isolated loop says, and every write to
+// EXEC stalls the vector pipe.)
+PIXO_TDEV uint32_t sel_u32(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
+PIXO_TDEV int sel_i32(bool c, int a, int b) { return c ? a : b; }
+
 struct Kinds { int v[5]; bool ok[5]; }; // [0] is the zero candidate
 PIXO_TDEV Kinds candidate_kinds(float fq)
 {
@@ -187,6 +197,33 @@ PIXO_TDEV Kinds candidate_kinds(float fq)
     k.v[3] = ce; k.ok[3] = ce != 0 && ce != fl && ce != r;
     k.v[4] = ext; k.ok[4] = __builtin_fabsf(fq) > 1.5f && ext != 0 && ext != fl && ext != r && ext != ce;
     return k;
+}
+// The candidates that can coexist (round 4).  round(fq) is floor(fq) or ceil(fq), so of the kinds 2 (round) and 3 (ceil) at
+// most ONE is valid: kind 2 when round != floor (then ceil == round is a duplicate), kind 3 when round == floor and
+// ceil != floor.  The search therefore evaluates three non-zero candidates — floor, "the other end", one-further — and the
+// middle one remembers which kind it is: its place in the insertion order (sort key) and in the back-pointer is that kind's.
+struct Kinds3 { int v[3]; bool ok[3]; uint32_t kind[3]; }; // kinds 1, 2 or 3, 4
+PIXO_TDEV Kinds3 candidate_kinds3(float fq)
+{
+    const int r = to_i16(__builtin_roundf(fq)), fl = to_i16(__builtin_floorf(fq)), ce = to_i16(__builtin_ceilf(fq));
+    const int ext = (int16_t)sel_i32(fq >= 0.0f, ce + 1, fl - 1);
+    Kinds3 k;
+    k.v[0] = fl; k.ok[0] = fl != 0; k.kind[0] = 1;
+    const bool is_round = r != fl;
+    const int mid = sel_i32(is_round, r, ce);
+    k.v[1] = mid; k.ok[1] = mid != 0 && mid != fl; k.kind[1] = 3u - (is_round ? 1u : 0u);
+    k.v[2] = ext; k.ok[2] = __builtin_fabsf(fq) > 1.5f && ext != 0 && ext != fl && ext != mid; k.kind[2] = 4;
+    return k;
+}
+// byte 0 of a, b, c, d as one word (a lowest): on the device three v_perm_b32
+PIXO_TDEV uint32_t low_bytes(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t ab = __builtin_amdgcn_perm(b, a, 0x0C0C0400u), cd = __builtin_amdgcn_perm(d, c, 0x04000C0Cu);
+    return ab | cd;
+#else
+    return (a & 0xFFu) | ((b & 0xFFu) << 8) | ((c & 0xFFu) << 16) | (d << 24);
+#endif
 }
 
 // One compare-exchange of the sorting network.  The keys (cost bits, slot, ...) are distinct, non-negative as 64-bit
@@ -219,11 +256,11 @@ template <class Env> PIXO_TDEV void quantize_block_fast(Env &env)
     for (int zz = 1; zz < 64; zz++) {
         const float coef = coef_next, qq = step_next;
         if (zz < 63) { coef_next = env.coef(zz + 1); step_next = env.step(zz + 1); }
-        const Kinds k = candidate_kinds(coef / qq);
-        uint64_t e[12];
-        // non-zero candidates -> slots 1..4
+        const Kinds3 k = candidate_kinds3(coef / qq);
+        uint64_t e[11];
+        // non-zero candidates -> wires 1..3
 #pragma unroll
-        for (int j = 1; j < 5; j++) {
+        for (int j = 0; j < 3; j++) {
             const float rec = (float)k.v[j] * qq, d = coef - rec, dist = d * d;
             const uint32_t cat4 = (uint32_t)size_category(k.v[j]) << 2;
             // the first strict minimum over the parents = the smallest (cost bits, parent) pair: costs are non-negative (their
@@ -237,11 +274,11 @@ template <class Env> PIXO_TDEV void quantize_block_fast(Env &env)
                 const uint64_t key = ((uint64_t)f2u(cost) << 32) | (uint32_t)pi;
                 bestk = pi == 0 ? key : min_key(bestk, key);
             }
-            // payload (low word): slot << 28 | run << 6 | kind << 3 | parent — run 0, kind = slot = j
-            const uint32_t lo = (uint32_t)bestk | ((uint32_t)j << 28) | ((uint32_t)j << 3);
-            e[j] = ((uint64_t)(k.ok[j] ? (uint32_t)(bestk >> 32) : kNoState) << 32) | lo;
+            // payload (low word): slot << 28 | run << 6 | kind << 3 | parent — run 0, slot = kind (the reference's generation order)
+            const uint32_t lo = (uint32_t)bestk | (k.kind[j] << 28) | (k.kind[j] << 3);
+            e[1 + j] = ((uint64_t)sel_u32(k.ok[j], (uint32_t)(bestk >> 32), kNoState) << 32) | lo;
         }
-        // zero candidate -> slot 0 (parent 0) and slots 5..11 (parents 1..7).  Successors are keyed by their run; two
+        // zero candidate -> wire 0 (parent 0) and wires 4..10 (parents 1..7).  Successors are keyed by their run; two
         // parents give the same run only when both have run 0 (then the successor is (0, 1)): those fold into ONE entry at
         // the first of them, with the first strict minimum of their costs.  The states are sorted by cost and every member
         // of that group adds the same two terms (+ 0.0, + dist0; f32 addition is monotone), so the first strict minimum IS
@@ -250,39 +287,35 @@ template <class Env> PIXO_TDEV void quantize_block_fast(Env &env)
         bool seen0 = false;
 #pragma unroll
         for (int pi = 0; pi < 8; pi++) {
-            const int slot = pi == 0 ? 0 : 4 + pi;
+            const int slot = pi == 0 ? 0 : 4 + pi, wire = pi == 0 ? 0 : 3 + pi;
             const bool alive = cc[pi] != kNoState, run0 = run6[pi] == 0;
             const bool over = run6[pi] == (15u << 6); // a ZRL symbol will be needed (trellis.rs:117-120): run + 1 >= 16
-            const float cost = u2f(cc[pi]) + (over ? 10.0f : 0.0f) + 1.0f * dist0;
+            const float cost = u2f(cc[pi]) + u2f(sel_u32(over, 0x41200000u /* 10.0f */, 0u)) + 1.0f * dist0;
             const bool ok = alive && !(run0 && seen0);
             seen0 = seen0 || (alive && run0);
             const uint32_t nrun6 = (run6[pi] + 64u) & (15u << 6); // run + 1, 16 -> 0
             const uint32_t lo = ((uint32_t)slot << 28) | nrun6 | (uint32_t)pi; // kind 0
-            e[slot] = ((uint64_t)(ok ? f2u(cost) : kNoState) << 32) | lo;
+            e[wire] = ((uint64_t)sel_u32(ok, f2u(cost), kNoState) << 32) | lo;
         }
-        // stable sort by cost == sort by (cost bits, slot); 39 compare-exchanges (optimal for 12 inputs)
-        PIXO_CE(0, 8) PIXO_CE(1, 7) PIXO_CE(2, 6) PIXO_CE(3, 11) PIXO_CE(4, 10) PIXO_CE(5, 9)
-        PIXO_CE(0, 1) PIXO_CE(2, 5) PIXO_CE(3, 4) PIXO_CE(6, 9) PIXO_CE(7, 8) PIXO_CE(10, 11)
-        PIXO_CE(0, 2) PIXO_CE(1, 6) PIXO_CE(5, 10) PIXO_CE(9, 11)
-        PIXO_CE(0, 3) PIXO_CE(1, 2) PIXO_CE(4, 6) PIXO_CE(5, 7) PIXO_CE_LO(8, 11) PIXO_CE(9, 10)
-        PIXO_CE(1, 4) PIXO_CE(3, 5) PIXO_CE(6, 8) PIXO_CE(7, 10)
-        PIXO_CE(1, 3) PIXO_CE(2, 5) PIXO_CE(6, 9) PIXO_CE_LO(8, 10)
-        PIXO_CE(2, 3) PIXO_CE(4, 5) PIXO_CE(6, 7) PIXO_CE_LO(8, 9)
-        PIXO_CE(4, 6) PIXO_CE(5, 7)
-        PIXO_CE(3, 4) PIXO_CE(5, 6) PIXO_CE_LO(7, 8)
-        // (only the eight smallest are looked at: four exchanges keep just their minimum — with the maximum replaced by
-        // "largest" all 4096 zero-one inputs still give the right first eight, tools/trellis_network_check.py)
-        uint32_t back_lo = 0, back_hi = 0; // 8 x 6 bits (kind, parent): survivor i at bit 6 i
+        // stable sort by cost == sort by (cost bits, slot); the 35 compare-exchanges of the optimal 11-input network, three of
+        // which keep only their minimum: the eight smallest are all that is looked at (tools/trellis_network_check.py)
+        PIXO_CE(0, 9) PIXO_CE(1, 6) PIXO_CE(2, 4) PIXO_CE(3, 7) PIXO_CE(5, 8)
+        PIXO_CE(0, 1) PIXO_CE(3, 5) PIXO_CE(4, 10) PIXO_CE(6, 9) PIXO_CE(7, 8)
+        PIXO_CE(1, 3) PIXO_CE(2, 5) PIXO_CE(4, 7) PIXO_CE(8, 10)
+        PIXO_CE(0, 4) PIXO_CE(1, 2) PIXO_CE(3, 7) PIXO_CE(5, 9) PIXO_CE(6, 8)
+        PIXO_CE(0, 1) PIXO_CE(2, 6) PIXO_CE(4, 5) PIXO_CE(7, 8) PIXO_CE_LO(9, 10)
+        PIXO_CE(2, 4) PIXO_CE(3, 6) PIXO_CE(5, 7) PIXO_CE_LO(8, 9)
+        PIXO_CE(1, 2) PIXO_CE(3, 4) PIXO_CE(5, 6) PIXO_CE_LO(7, 8)
+        PIXO_CE(2, 3) PIXO_CE(4, 5) PIXO_CE(6, 7)
+        // back-pointers: one byte per survivor — bits 0..5 (kind, parent), bits 6..7 the low bits of the run (ignored when read)
+        uint32_t lo8[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const uint32_t lo = (uint32_t)e[i], f = lo & 63u;
+            lo8[i] = (uint32_t)e[i];
             cc[i] = (uint32_t)(e[i] >> 32);
-            run6[i] = lo & (15u << 6);
-            if (6 * i + 6 <= 32) back_lo |= f << (6 * i);
-            else if (6 * i < 32) { back_lo |= f << (6 * i); back_hi |= f >> (32 - 6 * i); }
-            else back_hi |= f << (6 * i - 32);
+            run6[i] = lo8[i] & (15u << 6);
         }
-        env.trail_put(zz - 1, ((uint64_t)back_hi << 32) | back_lo);
+        env.trail_put(zz - 1, ((uint64_t)low_bytes(lo8[4], lo8[5], lo8[6], lo8[7]) << 32) | low_bytes(lo8[0], lo8[1], lo8[2], lo8[3]));
     }
     // trailing zeros: an EOB will be coded (trellis.rs:172-178); min_by: the first of equal minima
     int idx = 0;
@@ -296,7 +329,7 @@ template <class Env> PIXO_TDEV void quantize_block_fast(Env &env)
     coef_next = env.coef(63); step_next = env.step(63);
     uint64_t trail_next = env.trail_get(62);
     for (int zz = 63; zz >= 1; zz--) {
-        const uint32_t f = (uint32_t)(trail_next >> (6 * idx)) & 63u;
+        const uint32_t f = (uint32_t)(trail_next >> (8 * idx)) & 63u;
         const int kind = (int)(f >> 3);
         const Kinds k = candidate_kinds(coef_next / step_next);
         if (zz > 1) { coef_next = env.coef(zz - 1); step_next = env.step(zz - 1); trail_next = env.trail_get(zz - 2); }

@@ -283,6 +283,32 @@ def cpu_reference_wasm(w, h, ss, quality):
         return {"error": str(e)}
 
 
+GPU_CLOCK_HZ = 2.4e9  # MI355X peak engine clock (rocminfo clockRate; MI355X_MICROARCH.md): the issue roofline's denominator
+SIMDS = 1024          # 256 CUs x 4
+
+
+def issue_of(name, kernel_us):
+    """The VALU-ISSUE roofline of a kernel: vector instructions per launch from the committed PMC profile
+    profiles/issue_<name>.json (rocprofv3 --pmc SQ_INSTS_VALU ..., tools/issue_profile.py) x 4 cycles — the measured average
+    issue cost of this code's instruction mix (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 quad-cycles) — over what 1,024 SIMDs
+    could issue at the peak clock during the kernel time measured IN THIS RUN.  Near 1: only fewer or cheaper vector
+    instructions make the kernel faster, whatever its HBM fraction says."""
+    path = os.path.join(ROOT, "profiles", "issue_%s.json" % name)
+    try:
+        d = json.load(open(path))
+        frac = d["insts_valu_per_launch"] * 4.0 / (SIMDS * GPU_CLOCK_HZ * kernel_us * 1e-6)
+        return {"frac_issue": round(frac, 4), "valu_insts_per_launch": d["insts_valu_per_launch"],
+                "issue_source": "profile: " + os.path.relpath(path, ROOT) + " (x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time of this run))"}
+    except Exception:
+        return {}
+
+
+def bound_of(frac_hbm, issue):
+    """Which roofline binds: the larger of the two fractions."""
+    fi = issue.get("frac_issue")
+    return "valu-issue" if fi is not None and fi > frac_hbm else "hbm"
+
+
 def traffic_of(workload):
     """HBM bytes per launch from the committed PMC profile of this workload (separate rocprofv3 --pmc passes,
     corrected as MI355X_MICROARCH.md prescribes) — read from profiles/, NOT measured in this run."""
@@ -355,8 +381,12 @@ class CoeffWorkload:
         alg = self.in_bytes + self.out_bytes  # 3 B/px read + 3 B/px written (4:2:0); 3 + 6 for 4:4:4
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         traffic, src = traffic_of(self.name)
+        issue = issue_of(self.name, kernel_ms * 1e3)
+        # (`bound` stays "hbm" for the coefficient kernels — the metric BASELINE.json names is the HBM fraction —; `binding`
+        # says which of the two rooflines is the nearer one)
         return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src, **issue,
+                "binding": bound_of(achieved / HBM_PEAK_GBPS, issue),
                 "kernel": "jpeg_coeffs_kernel<%s, %s>" % ("M420" if self.ss else "M444", "L_FUNNEL" if self.w * 3 % 4 else "L_ALIGNED"),
                 "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3),
                 "read_only_frac_of_peak": round(self.in_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -377,7 +407,10 @@ def quick_kernel(job, name, q, steps=200, blocks=7):
     kernel_ms = statistics.median(evs) / steps
     r = wl.roofline(kernel_ms)
     out = {"workload": wl.label, "kernel_us": r["kernel_us_avg"], "Mpixels_per_s": round(wl.w * wl.h * wl.batch / kernel_ms / 1e3, 1),
-           "achieved_GBps": r["achieved"], "frac": r["frac"], "steps": steps, "blocks": blocks, "settle_ms": QUICK_SETTLE_MS}
+           "achieved_GBps": r["achieved"], "frac": r["frac"], "bound": r["binding"], "steps": steps, "blocks": blocks, "settle_ms": QUICK_SETTLE_MS}
+    for key in ("frac_issue", "valu_insts_per_launch", "issue_source"):
+        if key in r:
+            out[key] = r[key]
     del wl
     job.torch.cuda.empty_cache()
     return out
@@ -390,9 +423,11 @@ def quick_png(job, steps=100, blocks=7):
     _, evs = job.time_blocks(wl.step, steps, 20, blocks)
     kernel_ms = statistics.median(evs) / steps
     alg = wl.in_bytes + wl.out_bytes
+    issue = issue_of("c5", kernel_ms * 1e3)
+    frac = alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
     out = {"workload": "configs[4]: 4096x4096 RGBA8 PNG row filters (Adaptive) + Adler-32 partials", "kernel_us": round(kernel_ms * 1e3, 3),
            "Mpixels_per_s": round(4096 * 4096 / kernel_ms / 1e3, 1), "achieved_GBps": round(alg / (kernel_ms * 1e-3) / 1e9, 1),
-           "frac": round(alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "steps": steps, "blocks": blocks}
+           "frac": round(frac, 4), "bound": bound_of(frac, issue), **issue, "steps": steps, "blocks": blocks}
     del wl
     job.torch.cuda.empty_cache()
     return out
@@ -621,6 +656,7 @@ def run_png(job, args):
                        "parallelism": "one process per GPU, images sharded across ranks, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src,
+                         **issue_of("c5", kernel_ms * 1e3), "binding": bound_of(achieved / HBM_PEAK_GBPS, issue_of("c5", kernel_ms * 1e3)),
                          "kernel": "png_filter_kernel<4, true>", "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3)}}
     if not args.no_cpu_baseline and job.world == 1:
         import oracle_lib as O

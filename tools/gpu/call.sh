@@ -10,6 +10,7 @@
 #                             pixo_amd/ab_<variant>.so (built by tools/ab_build.sh); prints ms_per_step / kernel_us / frac
 #   kstats <name> <cmd...>    rocprofv3 --kernel-trace --stats of <cmd>, the kernel_stats csv copied to <tag>/<name>_kernel_stats.csv
 #   pmc <name> <filter> <cmd...>   separate rocprofv3 --pmc passes (tools/pmc_summary.py on kernels matching <filter>)
+#   issue <name> <filter> <cmd...> one PMC pass -> issue_<name>.json: VALU-busy fraction of the kernel (tools/issue_profile.py)
 #   py <script> [args]        python <script> (tools/*.py probes)
 set -u
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$ROOT"; export TMPDIR=/tmp
@@ -68,6 +69,15 @@ recipe_pmc() {
     f=$(find "/tmp/pmc_${name}_$i" -name "*counter_collection*" | head -1)
     [ -n "$f" ] && python "$ROOT/tools/pmc_summary.py" "$f" "$filt" 2>&1 | tee "$O/${name}_pmc${i}_summary.txt"
   done
+}
+# issue <name> <kernel substring> <cmd...>: one PMC pass -> gpurun_out/<tag>/issue_<name>.json (tools/issue_profile.py)
+recipe_issue() {
+  name="$1"; filt="$2"; shift 2
+  absargs "$@"; set -- "${ABS[@]}"
+  rm -rf "/tmp/issue_$name"
+  (cd /tmp && timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "/tmp/issue_$name" -o pmc -- "$@" > "$ROOT/$O/issue_${name}.log" 2>&1)
+  f=$(find "/tmp/issue_$name" -name "*counter_collection*" | head -1)
+  if [ -n "$f" ]; then python "$ROOT/tools/issue_profile.py" "$f" "$filt" "$O/issue_$name.json" "$name"; else tail -5 "$O/issue_${name}.log"; fi
 }
 recipe_py() { timeout 900 python "$@" 2>&1 | tail -60; }
 

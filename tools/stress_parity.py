@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity stress (not part of the test-suite: minutes of oracle time): JPEG whole files with
 random shapes / qualities / flags and PNG filter streams with random shapes / strategies / pixel sizes,
-GPU against the oracle.  Usage: stress_parity.py SECONDS [SEED]"""
+GPU against the oracle.  Usage: stress_parity.py SECONDS [SEED] [progressive]   (progressive: every JPEG case is a progressive
+file, sizes and contents chosen so that the scans span many groups of the single-pass coder — long runs of empty blocks, a few
+symbols here and there; no PNG cases).  Also fails when a single-pass entropy launch fell back to the multi-pass kernels."""
 import os, sys, time
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..")); sys.path.insert(0, os.path.join(HERE, "..", "tests"))
@@ -11,24 +13,29 @@ from pixo_amd import jpeg, png, ColorType
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+prog_only = len(sys.argv) > 3 and sys.argv[3] == "progressive"
 t0 = time.time(); nj = npn = 0; bad = []
 
 def content(n, kind, seed):
     if kind == 0: return synth.lcg_bytes(n, seed)
     if kind == 1: return (np.cumsum(synth.lcg_bytes(n, seed).astype(np.int64) % 5) % 256).astype(np.uint8)
     if kind == 2: return np.full(n, seed % 256, np.uint8)
+    if kind == 4:  # flat with sparse specks: most blocks empty in every band, a symbol now and then
+        b = np.full(n, seed % 256, np.uint8); k = synth.lcg_bytes(n, seed); b[k < 2] = 255 - (seed % 256); return b
+    if kind == 5:  # a slow ramp: only DC changes, end-of-band runs of thousands of blocks
+        return ((np.arange(n, dtype=np.int64) // 3 // max(1, (seed % 97) + 8)) % 256).astype(np.uint8)
     b = synth.lcg_bytes(n, seed); b[b < 128] = 0; b[b >= 128] = 255; return b
 
 while time.time() - t0 < budget:
     # ---- JPEG
-    big = rng.rand() < 0.15
+    big = rng.rand() < (0.6 if prog_only else 0.15)
     w = int(rng.randint(1, 2600 if big else 400)); h = int(rng.randint(1, 1400 if big else 300))
     ct = 2 if rng.rand() < 0.75 else 0
     ss = int(rng.rand() < 0.6)
     q = int(rng.randint(1, 101))
-    flags = dict(optimize_huffman=bool(rng.rand() < 0.4), progressive=bool(rng.rand() < 0.3), trellis=bool(rng.rand() < 0.3))
+    flags = dict(optimize_huffman=bool(rng.rand() < 0.4), progressive=bool(prog_only or rng.rand() < 0.3), trellis=bool(rng.rand() < 0.3))
     restart = int(rng.randint(1, 40)) if rng.rand() < 0.25 else None
-    px = content(w * h * (3 if ct == 2 else 1), int(rng.randint(0, 4)), int(rng.randint(1, 1 << 30)))
+    px = content(w * h * (3 if ct == 2 else 1), int(rng.randint(0, 6)), int(rng.randint(1, 1 << 30)))
     b = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss)) \
         .optimize_huffman(flags["optimize_huffman"]).progressive(flags["progressive"]).trellis_quant(flags["trellis"])
     if restart: b = b.restart_interval(restart)
@@ -39,6 +46,8 @@ while time.time() - t0 < budget:
     nj += 1
     if got != want:
         bad.append(("jpeg", w, h, ct, ss, q, flags, restart)); print("MISMATCH", bad[-1], flush=True)
+    if prog_only:
+        continue
     # ---- PNG
     bpp = int(rng.choice([1, 2, 3, 4, 6, 8])); w = int(rng.randint(1, 6000 if rng.rand() < 0.2 else 700)); h = int(rng.randint(1, 120))
     st = int(rng.randint(0, 9))
@@ -48,5 +57,7 @@ while time.time() - t0 < budget:
     npn += 1
     if not (np.array_equal(got, want) and gad == wad):
         bad.append(("png", w, h, bpp, st)); print("MISMATCH", bad[-1], flush=True)
-print("jpeg cases %d, png cases %d, mismatches %d, %.0f s" % (nj, npn, len(bad), time.time() - t0))
-sys.exit(1 if bad else 0)
+fb = jpeg.lookback_fallbacks()
+print("jpeg cases %d, png cases %d, mismatches %d, single-pass launches that fell back to the multi-pass kernels %d, %.0f s"
+      % (nj, npn, len(bad), fb, time.time() - t0))
+sys.exit(1 if bad or fb else 0)

@@ -120,7 +120,7 @@ struct Context {
     Buf e_segs;                      // segmented scans (batches, restart intervals): per-segment results of the single-pass kernels
     hipStream_t copy_stream = nullptr; // ... whose bytes travel to the host on this stream while the next piece is coded
     hipStream_t upload_stream = nullptr; // host pixels arrive band by band on this stream while earlier bands are transformed
-    struct CopyHelper *helper = nullptr; // ... and a second host thread sends the coded pieces back meanwhile (pieces.cpp; never destroyed)
+    struct CopyHelper *helper = nullptr; // ... and a second host thread sends the coded pieces back meanwhile (pieces.cpp; stopped and joined by release())
     std::vector<hipEvent_t> piece_done, band_up;
     uint32_t tables_held[pixo_scan::kScanTableUpload]; bool tables_valid = false; hipStream_t tables_stream = nullptr; // what e_tables holds (no upload when unchanged)
     uint32_t packed_per_block = 0; // bytes per block of the last whole scan this context coded (0: none yet), see device_entropy_to_pinned
@@ -185,6 +185,8 @@ struct Stopwatch { // debug switch `trace`: per-phase wall times of the device e
         t = n;
     }
 };
+
+void destroy_copy_helper(struct CopyHelper *h); // pieces.cpp (the type is complete only there)
 
 // ---- host memory helpers (pieces.cpp) -------------------------------------------------------------------------------
 template <class F> void run_on_threads(unsigned t, F &&body) // body(index) for index in [0, t)

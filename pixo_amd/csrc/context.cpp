@@ -203,6 +203,7 @@ void Context::shrink_to(size_t max_buffer_bytes)
 
 void Context::release()
 {
+    if (helper) { destroy_copy_helper(helper); helper = nullptr; } // (stops and joins the context's second host thread)
     if (!ready) return;
     DeviceScope on(device);
     if (on.err != hipSuccess) return;

@@ -29,7 +29,7 @@ constexpr bool kDot4 = true;
 // issued: 0.25 us for the first wavefront, 1.5 us for the median, 6 us for the last (profiles/r03_timeline_c2_before.txt).
 // Everything else (KRest) is not needed before the pixel loads are out and comes by s_load as before.
 struct KRest {
-    size_t px_bytes;  // all pixel bytes of the launch (the emulation checks every load against them)
+    size_t px_bytes;  // all pixel bytes of the launch (the host emulation checks every vector load against them: jpeg_tile.h emu_check_load)
     size_t y_stride;  // i16 elements between consecutive images of a batch
     size_t c_stride;
     float *ry, *rcb, *rcr;   // RAW kernels only: unquantised DCT blocks (64 f32 each) instead of y/cb/cr

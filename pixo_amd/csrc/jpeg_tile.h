@@ -125,7 +125,7 @@ struct TileCtx {
     uint32_t fast;        // vector loads (L_ALIGNED or L_FUNNEL); 0 = byte gathers
     const uint8_t *px_end; // one past the last pixel byte of the launch (all images of a batch)
 #if defined(PIXO_EMU)
-    const uint8_t *px_first; // first pixel byte of the launch (bounds of the emulated dword loads)
+    const uint8_t *px_first; // first pixel byte of the launch (the emulation checks every vector load against [px_first, px_end): emu_check_load)
 #endif
 };
 
@@ -412,9 +412,20 @@ PIXO_DEV uint32_t gather_row4_gray(const uint8_t *px, uint32_t W, uint32_t H, ui
 // Round 2 read the N + 1 ALIGNED dwords around them and funnelled those through v_alignbyte (three half-rate operations
 // per row + address arithmetic, a special case for the tiles that hold the buffer's last dword): 20.8-21.2 us for a
 // 4094-pixel-wide image against 19.3-19.6 now (aligned 4096: 18.3; profiles/r03_unaligned_direct_loads.txt).
+#if defined(PIXO_EMU)
+// (host emulation only) every vector load of the pixel path must lie inside the launch's pixel bytes: the tests then catch a
+// load that the device would get away with.  Set by the harness around a launch (tests/emu/emu_tile.cpp).
+static const uint8_t *g_emu_px_first = nullptr, *g_emu_px_end = nullptr;
+static long g_emu_oob_loads = 0;
+static inline void emu_check_load(const uint8_t *p, size_t n)
+{
+    if (g_emu_px_first && (p < g_emu_px_first || p + n > g_emu_px_end)) g_emu_oob_loads++;
+}
+#endif
 template <int N> PIXO_DEV void unaligned_load(const uint8_t *row, uint32_t off, uint32_t *r)
 {
 #if defined(PIXO_EMU)
+    emu_check_load(row + off, 4 * N);
     memcpy(r, row + off, 4 * N);
 #else
     if (N == 3) {
@@ -461,6 +472,7 @@ template <int MODE> PIXO_DEV LaneAddr lane_addr(const TileCtx &c, uint32_t tile_
 PIXO_DEV void load_dwordx3(const uint8_t *p, uint32_t *r)
 {
 #if defined(PIXO_EMU)
+    emu_check_load(p, 12);
     memcpy(r, p, 12);
 #else
     typedef uint32_t v3a4 __attribute__((ext_vector_type(3), aligned(4)));
@@ -481,6 +493,9 @@ PIXO_DEV void producer_load_item(const TileCtx &c, const LaneAddr &la, uint32_t 
         const uint8_t *row = la.tile_row0 + (ya - la.row_first) * la.stride;
         const uint32_t xoff = (k & 1) ? la.xoff1 : la.xoff0; // (a select, not an indexed array: that would live in scratch)
         if (MODE == MGRAY) {
+#if defined(PIXO_EMU)
+            if (LOAD == L_ALIGNED) emu_check_load(row + xoff, 4);
+#endif
             if (LOAD == L_ALIGNED) r[0] = PIXO_GLOAD((const uint32_t *)(row + xoff));
             else unaligned_load<1>(row, xoff, r);
         } else {

@@ -52,16 +52,28 @@ struct pixo_capi::CopyHelper {
     std::mutex m;
     std::condition_variable cv, idle;
     std::function<void()> job;
-    bool has_job = false, busy = false;
+    bool has_job = false, busy = false, stop = false;
     std::thread th;
-    CopyHelper() : th([this] { loop(); }) { th.detach(); }
+    CopyHelper() : th([this] { loop(); }) {}
+    // (a context that is deleted — excess contexts of the pool, pixo_hip_trim — takes its helper thread with it;
+    // it used to stay behind, blocked on its condition variable, one per deleted context)
+    ~CopyHelper()
+    {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            stop = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
     void loop()
     {
         for (;;) {
             std::function<void()> f;
             {
                 std::unique_lock<std::mutex> lock(m);
-                cv.wait(lock, [&] { return has_job; });
+                cv.wait(lock, [&] { return has_job || stop; });
+                if (!has_job) return; // (stop)
                 f.swap(job);
                 has_job = false;
             }
@@ -90,6 +102,8 @@ struct pixo_capi::CopyHelper {
 };
 
 namespace pixo_capi {
+
+void destroy_copy_helper(CopyHelper *h) { delete h; }
 
 int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *dst, size_t dst_cap, uint64_t *scan_bytes,
                           const PixelSource *src)
@@ -183,6 +197,7 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
     bool redo = false, gave_up = false;
     uint32_t next_out = 0; // first piece whose bytes have not been sent yet
     // piece k has been coded (its event has fired): its bytes onto the copy stream, unless something went wrong
+    Stopwatch sw_send; // (send_piece may run on the helper thread: a stopwatch of its own)
     auto send_piece = [&](uint32_t k) -> int {
         if (redo) return PIXO_OK; // (everything that was enqueued is still waited for)
         const uint64_t *mail = c.h_totals + 4 * k;
@@ -193,7 +208,7 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
         if (done + bytes > c.e_out.cap || done + bytes > dst_cap) { redo = true; return PIXO_OK; }
         if (bytes) HIP_TRY(hipMemcpyAsync(dst + done, c.e_out.as<uint8_t>() + done, bytes, hipMemcpyDeviceToHost, c.copy_stream));
         done += bytes;
-        sw.lap("  copy enqueued");
+        sw_send.lap("  copy enqueued");
         return PIXO_OK;
     };
     // piece k: its MCU rows through the coefficient kernel (where the pieces follow the rows), then the two entropy kernels
@@ -235,6 +250,7 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
             void wait_beyond(uint32_t k) { std::unique_lock<std::mutex> lock(m); cv.wait(lock, [&] { return n > k; }); }
         } uploaded;
         int helper_rc = PIXO_OK;
+        std::string helper_error; // (the helper's failures set ITS thread's message: carried over to the caller's below)
         if (!c.helper) c.helper = new CopyHelper;
         const int device = c.device;
         c.helper->start([&, device] {
@@ -256,6 +272,7 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
                 return PIXO_OK;
             };
             helper_rc = body();
+            if (helper_rc) helper_error = t_error;
         });
         // (whatever happens below, the helper must have finished before this frame's variables go away)
         struct HelperGuard { Context &c; Progress &up; uint32_t n; ~HelperGuard() { up.set(n); c.helper->wait(); } } guard{c, uploaded, pieces};
@@ -272,7 +289,7 @@ int device_entropy_pieces(Context &c, ScanJob &j, hipStream_t stream, uint8_t *d
         }
         sw.lap("  bands uploaded");
         c.helper->wait();
-        if (helper_rc) return helper_rc;
+        if (helper_rc) return helper_rc > 0 ? helper_rc : fail(helper_rc, helper_error); // (pixo_hip_last_error() is per thread)
     } else {
         for (uint32_t k = 0; k < pieces; ++k) {
             const int rc = launch_piece(k);

@@ -73,7 +73,14 @@ int png_filter_in_bands(Context &c, const uint8_t *data, uint32_t width, uint32_
     const size_t row_in = static_cast<size_t>(width) * bpp, row_out = row_in + 1;
     const size_t out_bytes = row_out * height;
     int rc = c.reserve_hfile(out_bytes);
-    if (rc) return rc;
+    if (rc) { // (the pinned staging is an optimisation — a 16384x16384 RGBA image wants 1.3 GB of it.  Without it:
+              // the whole image in one go, its rows straight into the caller's storage, as before round 3)
+        (void)hipGetLastError();
+        HIP_TRY(hipMemcpyAsync(c.p_in.p, data, row_in * height, hipMemcpyHostToDevice, c.stream));
+        if ((rc = png_filter_on_device(c, c.p_in.p, width, height, bpp, run, seq, c.p_out.p, adler))) return rc;
+        HIP_TRY(hipMemcpy(out, c.p_out.p, out_bytes, hipMemcpyDeviceToHost));
+        return PIXO_OK;
+    }
     HIP_TRY(c.p_sums.reserve(static_cast<size_t>(height) * 16));
     HIP_TRY(c.p_scratch.reserve(16));
     if (static_cast<size_t>(height) * 16 > c.hsums_cap) {

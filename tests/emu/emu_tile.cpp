@@ -73,6 +73,7 @@ extern "C" int emu_jpeg_coeffs(const uint8_t *px, uint32_t W, uint32_t H, int co
     int load = (!allow_fast || W < 4) ? L_BYTES : (aligned && allow_fast != 2 ? L_ALIGNED : L_FUNNEL);
     c.fast = load != L_BYTES;
     if (stats) stats[0] = stats[1] = stats[2] = 0;
+    g_emu_px_first = c.px_first; g_emu_px_end = c.px_end; g_emu_oob_loads = 0; // (every vector load is checked against the image's bytes)
     const uint32_t tx_gray = (c.units_x + 63) / 64, ty_gray = (c.units_y + 2) / 3;
 #define PIXO_RUN(MODE, TX, TY)                                                     \
     do {                                                                           \
@@ -84,7 +85,8 @@ extern "C" int emu_jpeg_coeffs(const uint8_t *px, uint32_t W, uint32_t H, int co
     else if (s420) PIXO_RUN(M420, (c.units_x + 31) / 32, c.units_y);
     else PIXO_RUN(M444, (c.units_x + 63) / 64, c.units_y);
 #undef PIXO_RUN
-    return 0;
+    g_emu_px_first = g_emu_px_end = nullptr;
+    return g_emu_oob_loads ? -(int)(g_emu_oob_loads > 1000000 ? 1000000 : g_emu_oob_loads) : 0; // < 0: loads outside the image's bytes
 }
 
 // The bracketing reciprocals of one divisor exactly as the device tables hold them (fill_device_qt

@@ -46,6 +46,7 @@ def coeffs(pixels, w, h, color_type=2, subsampling=1, quality=80, allow_fast=Tru
     cb = np.full((max(cbn, 1), 64), -32768, np.int16)
     cr = np.full((max(cbn, 1), 64), -32768, np.int16)
     stats = (C.c_long * 3)()
-    lib().emu_jpeg_coeffs(px.ctypes.data, w, h, color_type, subsampling, quality, y.ctypes.data,
-                          cb.ctypes.data, cr.ctypes.data, int(allow_fast), stats, wave_order)
+    rc = lib().emu_jpeg_coeffs(px.ctypes.data, w, h, color_type, subsampling, quality, y.ctypes.data,
+                               cb.ctypes.data, cr.ctypes.data, int(allow_fast), stats, wave_order)
+    assert rc == 0, "the emulated kernel issued %d vector load(s) outside the image's bytes" % -rc  # (jpeg_tile.h emu_check_load)
     return y, cb[:cbn], cr[:cbn], (stats[0], stats[1], stats[2])

@@ -445,7 +445,9 @@ def run_coeffs(job, args):
             del wl
             if not job.stub:
                 job.torch.cuda.empty_cache()
-            multi_gpu_extras(job, args)
+            _, abandoned = guarded_multi_gpu_extras(job, args)
+            if abandoned:
+                leave_without_teardown(None)
         job.finish()
         return
     st = block_stats(walls, args.steps)
@@ -504,9 +506,11 @@ def run_coeffs(job, args):
                 delattr(wl, key)
         if not job.stub:
             job.torch.cuda.empty_cache()
-        m = multi_gpu_extras(job, args)
+        m, abandoned = guarded_multi_gpu_extras(job, args)
         line["rccl"] = m.pop("rccl", None)
         line.setdefault("other_configs", {}).update(m)
+        if abandoned:
+            leave_without_teardown(line)
     if not args.no_cpu_baseline and job.world == 1 and not job.stub:
         try:
             line["cpu_baseline"] = cpu_baseline(4096, 4096, wl.ss, wl.q, args.cpu_seconds)
@@ -890,6 +894,47 @@ def measure_c4_single_process(job, q, n_dev, steps=3, blocks=3):
             "config": {"workload": "configs[3], single process: pixo_hip_jpeg_encode_multi over devices %s; 805 MB of HOST pixels in over PCIe, "
                                    "178.5 MB file out as Python bytes" % devices, "file_bytes": len(blob), "file_sha256": digest,
                        "sha256_is_the_reference_s": True}}
+
+
+MULTI_LEGS_DEADLINE_S = 240.0  # all multi-GPU legs together (they take ~3 s on one GPU); the metric line must not wait longer
+
+
+def guarded_multi_gpu_extras(job, args):
+    """multi_gpu_extras + the final barrier on a worker thread with a DEADLINE.  These legs run collectives that no
+    single-GPU box of this project's sessions could ever exercise with N > 1 ranks; if one of them hangs on a real node, the
+    run must still print its metric line.  Returns (results or None, timed_out).  After a timeout the process group is in an
+    unknown state: the caller prints its line and leaves with os._exit (no barrier, no destroy)."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            if not job.stub:
+                job.torch.cuda.set_device(job.local_rank)  # (the current device is per thread)
+            box["out"] = multi_gpu_extras(job, args)
+            if job.dist is not None:
+                job.dist.barrier()
+            box["done"] = True
+        except BaseException as ex:
+            box["error"] = repr(ex)
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(MULTI_LEGS_DEADLINE_S)
+    if th.is_alive() or not box.get("done"):
+        out = box.get("out") or {}
+        out["multi_gpu_legs"] = {"error": box.get("error") or "no result within %.0f s: abandoned" % MULTI_LEGS_DEADLINE_S}
+        return out, True
+    return box["out"], False
+
+
+def leave_without_teardown(line):
+    """After a multi-GPU leg was abandoned: print the line (rank 0) and end the process at once — collectives may be stuck."""
+    if line is not None:
+        sys.stdout.flush()
+        print(json.dumps(line, ensure_ascii=False), flush=True)
+    sys.stderr.flush()
+    os._exit(0)
 
 
 def multi_gpu_extras(job, args):

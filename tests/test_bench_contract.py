@@ -80,3 +80,24 @@ def test_bench_parses_its_flags_without_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], stdout=subprocess.PIPE, check=True).stdout.decode()
     for flag in ("--gpus", "--steps", "--warmup", "--workload", "--blocks", "c4", "c2_unaligned"):
         assert flag in out
+
+
+def test_a_stuck_multi_gpu_leg_cannot_take_the_metric_line_with_it():
+    """The legs bench.py runs after the metric's blocks (configs[3], configs[2] over the ranks) use collectives that no
+    single-GPU session could exercise with N > 1: they run behind a deadline, and a leg that hangs costs its own result only —
+    the ONE JSON line with the metric is still printed and the process ends with status 0."""
+    import subprocess, sys
+    code = r'''
+import sys, time
+sys.argv = ["bench.py", "--stub", "--gpus", "1", "--steps", "2", "--warmup", "1", "--blocks", "3", "--no-cpu-baseline"]
+import bench
+bench.MULTI_LEGS_DEADLINE_S = 2.0
+bench.measure_c4 = lambda *a, **k: time.sleep(120)
+bench.main()
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=100)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] > 0 and line["n_gpus"] == 1 and "abandoned" in line["other_configs"]["multi_gpu_legs"]["error"]

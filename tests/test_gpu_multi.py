@@ -254,6 +254,20 @@ def test_world_of_one_rccl_batch_and_bench_legs_of_a_multi_gpu_run():
                 raise SystemExit("a 10-byte arena was accepted")
             except error.BufferTooSmall as e:
                 assert e.needed == sum(lens)
+        # the same batch with the files written into a node-shared arena (every rank over its own PCIe link)
+        total = sum(lens)
+        for size in (total + 64, total - 1):
+            shared = sharded.SharedFile("pixo_gpu_batch_%d" % size, size, create=True)
+            try:
+                got = sharded.encode_batch(d, b.build(), n, shared=shared)
+                assert size >= total
+                _, offs2, lens2 = got
+                arr = shared.array()
+                for i in range(n):
+                    assert arr[offs2[i]: offs2[i] + lens2[i]].tobytes() == O.encode(imgs[i], O.make_options(w, h, ct, 77, ss, **kw)), i
+            except error.BufferTooSmall as e:
+                assert size < total and e.needed == total
+            shared.close(unlink=True)
         dist.destroy_process_group()
         print("BATCH_OK")
     """ % (ROOT, ROOT))

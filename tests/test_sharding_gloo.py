@@ -352,3 +352,53 @@ def test_batch_partition_rule():
     assert sharded.batch_partition(5, 8) == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]
     assert sharded.batch_partition(13, 8) == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 10), (10, 11), (11, 12), (12, 13)]
     assert sharded.batch_partition(0, 3) == [(0, 0)] * 3
+
+
+def _worker_batch_shared(rank, world, port, n, w, h, ret):
+    """encode_batch with a SharedFile: every rank writes its run of files to its final place in one shared arena."""
+    dist = _setup(rank, world, port)
+    import numpy as np
+    import torch
+    import oracle_lib as O
+    import synth
+    from pixo_amd import error, sharded
+    px = w * h * 3
+    images = [synth.noise(w, h, 42 + i) for i in range(n)]
+    oo = O.make_options(w, h, 2, 80, 1)
+    want = [O.encode(im, oo) for im in images]
+
+    def cpu_encode(chunk, o, count):
+        return [O.encode(chunk[i * px: (i + 1) * px], oo) for i in range(count)]
+
+    o = _options(w, h, 2, 1, 80, {})
+    batch = torch.from_numpy(np.concatenate(images)) if rank == 0 else None
+    ok = True
+    for size in (sum(len(f) for f in want) + 100, sum(len(f) for f in want) - 1):  # large enough; one byte short
+        name = "pixo_batch_%d_%d" % (port, size)
+        shared = sharded.SharedFile(name, size, create=True) if rank == 0 else None
+        dist.barrier()
+        if rank != 0:
+            shared = sharded.SharedFile(name, size, create=False)
+        try:
+            got = sharded.encode_batch(batch, o, n, encode_fn=cpu_encode, shared=shared)
+            fits = True
+        except error.BufferTooSmall as e:
+            fits = False
+            ok = ok and e.needed == sum(len(f) for f in want)
+        ok = ok and fits == (size >= sum(len(f) for f in want))
+        if fits and rank == 0:
+            _, offs, lens = got
+            arr = shared.array()
+            ok = ok and all(arr[offs[i]: offs[i] + lens[i]].tobytes() == want[i] for i in range(n))
+        dist.barrier()
+        shared.close(unlink=rank == 0)
+    if rank == 0:
+        ret.put(bool(ok))
+    else:
+        assert ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batch_files_written_by_every_rank_into_one_shared_arena():
+    assert _run(_worker_batch_shared, 3, (7, 40, 24), timeout=300) is True

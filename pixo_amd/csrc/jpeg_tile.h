@@ -831,6 +831,49 @@ PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v
     }
 }
 
+#if !defined(PIXO_EMU) && !defined(PIXO_SCALAR_COLS) // (PIXO_SCALAR_COLS: A/B builds, tools/ab_build.sh)
+// The column pass on PAIRS of neighbouring columns (round 4): v[8 r + 2 k], v[8 r + 2 k + 1] as one aligned register
+// pair, the same operation sequence as aan8 on both halves at once (v_pk_add_f32 / v_pk_mul_f32: IEEE per lane, no
+// contraction) — 42 packed instructions per column pair where two scalar transforms take 84 at 0.6 of the packed
+// instruction's issue cost each (profiles/r03_ubench_form_rate.txt: 2.67 against 4.37 cycles): 8.70 M -> 8.19 M vector
+// instructions per 4096x4096 launch.  Measured (profiles/r04_ab_packed_cols.txt): 4:4:4 30.5 -> 30.0 us, the 64-image batch
+// 139.1 -> 137.9 us — the issue-bound launches —, one 4:2:0 image unchanged (18.1-18.3 either way).  The row pass stays scalar
+// and simply leaves its outputs in the pairs' halves; the quantiser already wants neighbouring coefficients as pairs.
+typedef float pixo_cf2 __attribute__((ext_vector_type(2)));
+PIXO_DEV void aan8_cols2(pixo_cf2 &d0, pixo_cf2 &d1, pixo_cf2 &d2, pixo_cf2 &d3, pixo_cf2 &d4, pixo_cf2 &d5, pixo_cf2 &d6, pixo_cf2 &d7)
+{
+    const pixo_cf2 t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
+    const pixo_cf2 t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+    const pixo_cf2 e0 = t0 + t3, e3 = t0 - t3, e1 = t1 + t2, e2 = t1 - t2;
+    const pixo_cf2 r0 = e0 + e1, r4 = e0 - e1;
+    const pixo_cf2 z1 = (e2 + e3) * PIXO_A1;
+    const pixo_cf2 r2 = e3 + z1, r6 = e3 - z1;
+    const pixo_cf2 o0 = t4 + t5, o1 = t5 + t6, o2 = t6 + t7;
+    const pixo_cf2 z5 = (o0 - o2) * PIXO_A5;
+    const pixo_cf2 z2 = o0 * PIXO_A2 + z5;
+    const pixo_cf2 z4 = o2 * PIXO_A4 + z5;
+    const pixo_cf2 z3 = o1 * PIXO_A1;
+    const pixo_cf2 z11 = t7 + z3, z13 = t7 - z3;
+    const pixo_cf2 r5 = z13 + z2, r3 = z13 - z2, r1 = z11 + z4, r7 = z11 - z4;
+    d0 = r0 * 0.3535534f; d1 = r1 * 0.2548978f; d2 = r2 * 0.2705981f; d3 = r3 * 0.3006724f;
+    d4 = r4 * 0.3535534f; d5 = r5 * 0.4499881f; d6 = r6 * 0.6532815f; d7 = r7 * 1.2814578f;
+}
+PIXO_DEV void block_cols(float *v)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        pixo_cf2 d[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { d[r] = (pixo_cf2){v[8 * r + 2 * k], v[8 * r + 2 * k + 1]}; asm volatile("" : "+v"(d[r])); }
+        aan8_cols2(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+#pragma unroll
+        for (int r = 0; r < 8; r++) { asm volatile("" : "+v"(d[r])); v[8 * r + 2 * k] = d[r].x; v[8 * r + 2 * k + 1] = d[r].y; }
+        PIXO_SCHED_FENCE();
+    }
+#pragma unroll
+    for (int i = 0; i < 64; i++) PIXO_PIN(v[i]);
+}
+#else
 PIXO_DEV void block_cols(float *v)
 {
 #pragma unroll
@@ -841,6 +884,7 @@ PIXO_DEV void block_cols(float *v)
 #pragma unroll
     for (int i = 0; i < 64; i++) PIXO_PIN(v[i]);
 }
+#endif
 
 // What the block of lane `lane` of consumer wave `wave` is, and where its planar rows start
 // (everything wave-uniform except src).

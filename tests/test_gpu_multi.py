@@ -257,7 +257,7 @@ def test_world_of_one_rccl_batch_and_bench_legs_of_a_multi_gpu_run():
         # the same batch with the files written into a node-shared arena (every rank over its own PCIe link)
         total = sum(lens)
         for size in (total + 64, total - 1):
-            shared = sharded.SharedFile("pixo_gpu_batch_%d" % size, size, create=True)
+            shared = sharded.SharedFile("pixo_gpu_batch_" + str(size), size, create=True)
             try:
                 got = sharded.encode_batch(d, b.build(), n, shared=shared)
                 assert size >= total

@@ -81,3 +81,16 @@ def test_end_of_band_run_reaches_32767():
     # 3 x 32767 + 5 empty blocks in a row: the counter is flushed at 32767 three times
     w, h = 8 * 1024, 8 * 97  # 99,328 gray blocks of a constant image
     _check(synth.constant(w, h, 10, 1), w, h, 0, 0, 50)
+
+
+def test_synthetic_tuples_run_counter_at_every_alignment_of_groups_wavefronts_and_32767():
+    """The end-of-band run counter of the single-pass coder travels through wavefront ballots, three LDS words per group and a
+    look-back across groups.  Directed tuples (tests/band_cases.py) put its events at every alignment; both forms of the
+    device coder, run on the CPU, against the oracle's segments."""
+    import band_cases
+    empty = np.zeros((0, 64), np.int16)
+    for nblocks, where in band_cases.cases():
+        y, w, h = band_cases.tuple_of(nblocks, where)
+        want = _segments(O.encode_from_coeffs(y, empty, empty, O.make_options(w, h, 0, 50, 0, progressive=True)))
+        assert _emu(y, empty, empty, "emu_progressive_flat") == want, (nblocks, where[:6])
+        assert _emu(y, empty, empty) == want, (nblocks, where[:6])

@@ -179,3 +179,18 @@ def test_progressive_files_straight_into_pinned_caller_storage():
         with pytest.raises(error.BufferTooSmall) as e:
             jpeg.encode_into_buffer(torch.zeros(len(want) - 1, dtype=torch.uint8).pin_memory().numpy(), px, o)
         assert e.value.needed == len(want)
+
+
+def test_directed_tuples_for_the_run_counter_on_the_device():
+    """tests/band_cases.py through `prog_code_kernel` (device tuple -> progressive file): the end-of-band run counter's events at
+    every alignment of wavefronts, groups and the 32767 limit — whole files equal to the oracle's."""
+    import torch
+    import band_cases
+    empty = np.zeros((0, 64), np.int16)
+    for nblocks, where in band_cases.cases():
+        y, w, h = band_cases.tuple_of(nblocks, where)
+        want = O.encode_from_coeffs(y, empty, empty, O.make_options(w, h, 0, 50, 0, progressive=True))
+        dy = torch.from_numpy(y).to("cuda:0")
+        torch.cuda.synchronize()
+        got = jpeg.entropy_encode_device(dy, dy, dy, _opts(w, h, 0, 0, 50, progressive=True))
+        assert got == want, (nblocks, where[:6])

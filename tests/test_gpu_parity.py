@@ -372,7 +372,8 @@ def test_single_pass_kernels_that_give_up_waiting_fall_back_to_the_multi_pass_ke
     """The look-back kernels bound their waits.  With a budget of zero polls every wait for another
     workgroup fails at once: the kernels raise their abort flag instead of spinning, the host sees it in the pinned mailbox
     and codes the scan again with the multi-pass kernels — same bytes, no hang; the fallback counter shows that it happened.
-    In a fresh process (the switch is read at start-up) over plain files, pieces, batches, restart segments and bands."""
+    In a fresh process (the switch is read at start-up) over plain files, pieces, batches, restart segments, bands and
+    progressive files."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys, numpy as np, torch; sys.path.insert(0, 'tests'); import synth, oracle_lib as O; from pixo_amd import jpeg\n"
@@ -396,7 +397,13 @@ def test_single_pass_kernels_that_give_up_waiting_fall_back_to_the_multi_pass_ke
             "px = synth.noise(520, 330, 12)\n"
             "assert jpeg.encode_multi(px, opts(520, 330, 1, optimize_huffman=True), [0, 0, 0]) == O.encode(px, O.make_options(520, 330, 2, 80, 1, optimize_huffman=True))\n"
             "n2 = jpeg.lookback_fallbacks(); assert n2 > n1 + 2, (n1, n2)\n"
-            "print('fallbacks', n2)")
+            # round 4: the single-pass progressive coder (prog_code_kernel, three look-backs) falls back the same way
+            "for (w, h, ss, kw) in ((1024, 768, 1, {}), (777, 333, 0, dict(optimize_huffman=True)), (640, 480, 1, dict(trellis_quant=True))):\n"
+            "    px = synth.noise(w, h, 7)\n"
+            "    okw = {('trellis' if k == 'trellis_quant' else k): v for k, v in kw.items()}\n"
+            "    assert jpeg.encode(px, opts(w, h, ss, progressive=True, **kw)) == O.encode(px, O.make_options(w, h, 2, 80, ss, progressive=True, **okw)), (w, h, kw)\n"
+            "n3 = jpeg.lookback_fallbacks(); assert n3 >= n2 + 3, (n2, n3)\n"
+            "print('fallbacks', n3)")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PIXO_HIP_DEBUG="spin_budget=0"),
                        timeout=600, cwd=root)
     assert r.returncode == 0 and "fallbacks" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

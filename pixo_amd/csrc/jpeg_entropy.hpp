@@ -150,7 +150,7 @@ struct ProgCode {
     uint64_t first_group[8];  // first group (of 192 blocks) of scan k; [nscans] = groups in all
 };
 size_t prog_code_state_words(uint64_t groups); // u64 words of d_state
-uint64_t prog_groups(uint64_t blocks);         // groups of one scan
+uint64_t prog_groups(uint32_t scan_id, uint64_t blocks); // groups of one scan (192 blocks; a DC scan: 768)
 // d_state: zeroed (by the launcher unless state_is_zero); d_stream: scan k at word seg.var_word[k], room for
 // prog_stream_bytes(scan_id, blocks) bytes; d_clear / clear_words, host_totals ([3]: abort flag), spin_budget: as launch_scan_code
 size_t prog_stream_bytes(uint32_t scan_id, uint64_t blocks);

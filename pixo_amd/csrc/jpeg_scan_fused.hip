@@ -417,7 +417,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 // ---- progressive scans in one pass (round 4) ----------------------------------------------------------------------------
 // The scans of simple_progressive_script (progressive.rs:98-110; jpeg/mod.rs:872-927, :1248-1380) as segments of ONE launch:
 // group g belongs to scan k when first_group[k] <= g < first_group[k + 1]; lane l of it codes block (g - first_group[k]) * 192
-// + l of the scan's component (storage order).  What differs from scan_code_kernel<SEG>:
+// + l of the scan's component (storage order) — in a DC scan four consecutive blocks, 768 per group.  What differs from scan_code_kernel<SEG>:
 //   * segments of different sizes, each with its own walk: DC scans code one symbol per block (encode_dc_first), AC scans the
 //     band [ss, se] without an end-of-block code (band_pack_flat);
 //   * the END-OF-BAND RUN counter (progressive.rs:156-162, :171-174, :206-209, :313-345) crosses blocks: what it makes a lane
@@ -429,6 +429,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 //   * a group may have no bits at all (192 empty blocks): it leaves an aggregate of zero bits in look-back B and a
 //     "transparent" mark in its tail slot (the stream word two groups share is found by a look-back over the tails) and is done.
 // state: [0] abort flag, [1] -, then per group: descriptor A, descriptor B, tail.
+constexpr uint32_t kDcPerLane = 4; // blocks a lane of a DC scan codes (4 x at most 27 bits: inside the lane's scratch)
 constexpr uint32_t kEobSyms = 16; // per class: the packed words of symbols 0x00 .. 0xE0 (end-of-band runs), one spare
 __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) void prog_code_kernel
 (const ProgCode a, const SegArgs seg, unsigned long long *state, uint32_t *stream, unsigned long long *clear, uint32_t clear_words,
@@ -448,26 +449,34 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 #pragma unroll
     for (uint32_t i = 1; i < 7; i++) k += (i < a.nscans && g >= a.first_group[i]) ? 1u : 0u;
     const uint32_t scan = a.scan_id[k];
-    const uint64_t floor_g = a.first_group[k], nblocks_chain = a.size[k], first_in_chain = (g - floor_g) * kGroup;
+    const bool dc_scan = scan < 3;
+    // (a lane of a DC scan codes kDcPerLane consecutive blocks — one short symbol each: with one block per lane the three DC
+    // scans were 37 % of the launch's groups for 2 % of its work)
+    const uint32_t group_blocks = dc_scan ? kGroup * kDcPerLane : kGroup;
+    const uint64_t floor_g = a.first_group[k], nblocks_chain = a.size[k], first_in_chain = (g - floor_g) * group_blocks;
     const uint64_t ngroups_total = a.first_group[a.nscans];
     unsigned long long *desc_a = state + 2, *desc = state + 2 + ngroups_total, *tails = state + 2 + 2 * ngroups_total;
     unsigned long long *const host_abort = host_totals ? host_totals + 3 : nullptr;
     stream += seg.var_word[k];
-    const bool dc_scan = scan < 3;
     const int comp = prog_comp((int)scan), cls = comp ? 1 : 0;
     const int ss = scan == 4 ? 11 : 1, se = scan == 3 ? 10 : 63;
-    const bool live = first_in_chain + lane < nblocks_chain;
-    const bool last_of_scan = first_in_chain + lane + 1 == nblocks_chain;
+    const uint64_t my_first = first_in_chain + (uint64_t)lane * (dc_scan ? kDcPerLane : 1u);
+    const bool live = my_first < nblocks_chain;
+    const bool last_of_scan = !dc_scan && my_first + 1 == nblocks_chain;
     uint32_t w[32];
-    int prev_dc = 0;
+    int dcs[kDcPerLane + 1]; // DC scans: the predictor and the lane's blocks' first coefficients
+    uint32_t dc_count = 0;
     {
         const int16_t *base = comp == 0 ? a.y : (comp == 1 ? a.cb : a.cr);
-        const uint64_t b = live ? first_in_chain + lane : 0;
-        if (dc_scan) { // only the block's first coefficient (and the one before it: the predictor, jpeg/mod.rs:1268-1300)
+        const uint64_t b = live ? my_first : 0;
+        if (dc_scan) { // only the blocks' first coefficients (and the one before them: the predictor, jpeg/mod.rs:1268-1300)
 #pragma unroll
             for (int i = 0; i < 32; i++) w[i] = 0;
-            w[0] = (uint32_t)(uint16_t)base[b * 64];
-            prev_dc = b ? (int)base[(b - 1) * 64] : 0;
+            const uint64_t left = live ? nblocks_chain - my_first : 0;
+            dc_count = left < kDcPerLane ? (uint32_t)left : kDcPerLane;
+            dcs[0] = b ? (int)base[(b - 1) * 64] : 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kDcPerLane; j++) dcs[j + 1] = j < dc_count ? (int)base[(b + j) * 64] : 0;
         } else {
             const v4u *p = reinterpret_cast<const v4u *>(base + b * 64);
 #pragma unroll
@@ -488,8 +497,16 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         FlatPack<LaneSink> p;
         p.sink = LaneSink{scratch + lane * kScratchPitch};
         p.acc = 0; p.pending = 0; p.word = 0;
-        if (dc_scan) dc_pack_flat(w, prev_dc, tab + cls * kWalkClassWords, p);
-        else band_pack_flat(w, ss, se, tab + cls * kWalkClassWords, p, &nonempty, &ends_zero);
+        if (dc_scan) {
+#pragma unroll
+            for (uint32_t j = 0; j < kDcPerLane; j++) { // encode_dc_first (progressive.rs:112-133, al = 0), block after block
+                const bool on = j < dc_count;
+                const int diff = (int)(int16_t)(dcs[j + 1] - dcs[j]);
+                const int u = on ? diff + (diff >> 31) : 0;
+                const uint32_t sb = scan_sign_bits(u), m = sb < 32u ? sb : 32u;
+                put_symbol(p, on ? tab[cls * kWalkClassWords + (m & 15u)] : kWalkNothing, (uint32_t)u, m);
+            }
+        } else band_pack_flat(w, ss, se, tab + cls * kWalkClassWords, p, &nonempty, &ends_zero);
         own = p.word * 32u + p.pending;
         p.finish();
     }
@@ -547,7 +564,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             group_long |= wave_long[i];
         }
         if (lane == 0) publish_aggregate(desc, g, floor_g, group_bits);
-        const bool last_group = first_in_chain + kGroup >= nblocks_chain;
+        const bool last_group = first_in_chain + group_blocks >= nblocks_chain;
         // The stream word two groups share travels as the earlier group's `tail`.  A group WITHOUT bits (192 empty blocks) is
         // transparent for it: it says so at once, and the group that needs the word finds the last group with bits by a
         // look-back over the tails (512 per round) — passing the word on from group to group made one chain of waits out
@@ -1020,7 +1037,11 @@ hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool
 }
 
 size_t prog_code_state_words(uint64_t groups) { return 2 + 3 * (size_t)groups; }
-uint64_t prog_groups(uint64_t blocks) { return (blocks + kGroup - 1) / kGroup; }
+uint64_t prog_groups(uint32_t scan_id, uint64_t blocks)
+{
+    const uint64_t per = scan_id < 3 ? (uint64_t)kGroup * kDcPerLane : kGroup;
+    return (blocks + per - 1) / per;
+}
 size_t prog_stream_bytes(uint32_t scan_id, uint64_t blocks)
 { // per block: a DC symbol of at most 16 + 11 bits; a band of n coefficients: n symbols of at most 16 + 10 bits (ZRL codes
   // only where coefficients are missing) + run symbols of at most 30 bits in front and behind; + 64 bytes the kernels read into

@@ -152,7 +152,7 @@ static int device_progressive_scans_fused(const int16_t *dy, const int16_t *dcb,
         const uint32_t k = a.nscans++;
         a.scan_id[k] = i;
         a.size[k] = size[i];
-        a.first_group[k + 1] = a.first_group[k] + pd::prog_groups(size[i]);
+        a.first_group[k + 1] = a.first_group[k] + pd::prog_groups(i, size[i]);
         sg.var_word[k] = stream_bytes / 4;
         stream_bytes += pd::prog_stream_bytes(i, size[i]);
         blocks_all += size[i];

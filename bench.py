@@ -818,7 +818,7 @@ def run_c4(job, args):
 C3_IMAGE0_SHA256 = "d1811ba1761f6b2a76d7f2c3d43418784f38909e0b20af631d5ead73e7d9436a"  # noise(1920,1080,42), made by the reference
 
 
-def measure_c3_sharded(job, q, steps, warmup, blocks):
+def measure_c3_sharded(job, q, steps, warmup, blocks, shared_arena=False):
     """configs[2] on a node (SURVEY §8e "C3 batch"): 64 x 1920x1080 images RESIDENT ON RANK 0's GPU; a step =
     sharded.encode_batch: whole images to the ranks point to point over xGMI, every rank encodes its share, the files come
     back to rank 0 the same way and cross PCIe once into a pinned arena.  Strong scaling (the batch is fixed).
@@ -840,11 +840,30 @@ def measure_c3_sharded(job, q, steps, warmup, blocks):
     px = w * h * 3
     fn = (lambda chunk, o, count: [O.encode(chunk[i * px: (i + 1) * px], oo) for i in range(count)]) if job.stub else None
     state = {}
+    shared = None
+    if shared_arena:  # one arena in POSIX shared memory that every rank of the node maps: every rank writes ITS files over its own PCIe link
+        name = "pixo_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), n)
+        size = n * px // 2 + (1 << 20)
+        if job.rank == 0:
+            shared = sharded.SharedFile(name, size, create=True)
+        job.barrier()
+        if job.rank != 0:
+            shared = sharded.SharedFile(name, size, create=False)
+        if not job.stub:
+            shared.register()
 
     def step(i):
-        state["got"] = sharded.encode_batch(d, opts, n, encode_fn=fn, out=out, device=None if job.stub else job.local_rank)
+        state["got"] = sharded.encode_batch(d, opts, n, encode_fn=fn, out=out, device=None if job.stub else job.local_rank, shared=shared)
 
-    walls, _ = job.time_blocks(step, steps, warmup, blocks, events=False)
+    try:
+        walls, _ = job.time_blocks(step, steps, warmup, blocks, events=False)
+        if job.rank == 0 and shared is not None:
+            _, offs_s, lens_s = state["got"]
+            state["got"] = (job.torch.from_numpy(shared.array().copy()), offs_s, lens_s)
+    finally:
+        if shared is not None:
+            job.barrier()
+            shared.close(unlink=job.rank == 0)
     if job.rank != 0:
         return None
     arena, offs, lens = state["got"]
@@ -864,8 +883,11 @@ def measure_c3_sharded(job, q, steps, warmup, blocks):
                                    % (n, w, h, 42 + n - 1, q, n),
                        "images_per_rank": [b - a for a, b in parts], "pixels_scattered_bytes": (n - (parts[0][1] - parts[0][0])) * px,
                        "file_bytes_total": int(sum(lens)), "files_checked_against_oracle": sample, "file0_sha256": sha0,
-                       "path": "sharded.encode_batch: isend/irecv of whole images (one peer per xGMI link) -> pixo_hip_jpeg_encode_batch_device_into "
-                               "(device arena) per rank -> all_gather of lengths -> isend/irecv of file runs to their final offsets -> one D2H copy"}}
+                       "path": ("sharded.encode_batch(shared=SharedFile): isend/irecv of whole images (one peer per xGMI link) -> "
+                                "pixo_hip_jpeg_encode_batch_device_into (device arena) per rank -> all_gather of lengths -> every rank copies its files "
+                                "over its OWN PCIe link to their final offsets in one node-shared, registered arena") if shared_arena else
+                               ("sharded.encode_batch: isend/irecv of whole images (one peer per xGMI link) -> pixo_hip_jpeg_encode_batch_device_into "
+                                "(device arena) per rank -> all_gather of lengths -> isend/irecv of file runs to their final offsets -> one D2H copy")}}
 
 
 def measure_c4_single_process(job, q, n_dev, steps=3, blocks=3):
@@ -948,7 +970,8 @@ def multi_gpu_extras(job, args):
         out["rccl"] = {"error": repr(ex)}
     small = job.stub
     legs = (("c4", lambda: measure_c4(job, args.quality, 2 if small else 5, 1, 3, 0 if small else QUICK_SETTLE_MS)),
-            ("c3_sharded", lambda: measure_c3_sharded(job, args.quality, 2 if small else 5, 1, 3)))
+            ("c3_sharded", lambda: measure_c3_sharded(job, args.quality, 2 if small else 5, 1, 3)),
+            ("c3_sharded_shared_arena", lambda: measure_c3_sharded(job, args.quality, 2 if small else 5, 1, 3, shared_arena=True)))
     if job.world > 1 and not job.stub:  # (rank 0 alone; the others wait in the next `agree`)
         legs += (("c4_single_process", lambda: measure_c4_single_process(job, args.quality, job.world) if job.rank == 0 else None),)
     for name, fn in legs:

@@ -96,6 +96,7 @@ struct Context {
     bool ready = false;
     hipStream_t stream = nullptr;
     hipEvent_t producer_done = nullptr; // orders the context's stream after the caller's (device-pointer entries)
+    hipEvent_t stats_done = nullptr;    // preset 2: the symbol counts of the statistics pass have reached the host (progressive.cpp)
     void *d_px = nullptr;   size_t px_cap = 0;
     void *d_coef = nullptr; size_t coef_cap = 0;
     void *h_coef = nullptr; size_t hcoef_cap = 0; // pinned

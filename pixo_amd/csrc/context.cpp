@@ -229,6 +229,8 @@ void Context::release()
     band_up.clear();
     if (producer_done) (void)hipEventDestroy(producer_done);
     producer_done = nullptr;
+    if (stats_done) (void)hipEventDestroy(stats_done);
+    stats_done = nullptr;
     code_state_zero_words = 0;
     tables_valid = false;
     d_px = d_coef = h_coef = nullptr; px_cap = coef_cap = hcoef_cap = 0;

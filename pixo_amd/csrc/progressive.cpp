@@ -320,7 +320,28 @@ int progressive_to_view(const void *d_pixels, const pixo_jpeg_options &o, const 
     pixo_host::HuffSet h;
     const bool need_plain = o.optimize_huffman || !o.trellis_quant;
     if (need_plain && (rc = coeffs_on_device(c, d_pixels, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
-    if ((rc = huffman_for_tuple(dy, dcb, dcr, o, g, c, h))) return rc;
+    // Preset 2 (optimised tables AND trellis): the statistics (plain tuple -> baseline walk -> counts) are enqueued, the counts
+    // start their way to a pinned buffer, and the raw transform + trellis search follow on the same stream AT ONCE: the host
+    // waits for the counts' event only and builds the tables while the search (0.29 ms for 4096x4096) runs.  Rounds 1-3
+    // synchronised, built the tables and only then launched the search: 30 us of idle GPU per file.
+    const bool late_tables = o.optimize_huffman && o.trellis_quant && !debug().host_entropy;
+    if (late_tables) {
+        pd::ScanArgs a;
+        a.y = dy; a.cb = dcb; a.cr = dcr; a.tables = nullptr;
+        a.mode = g.gray ? 0 : (g.s420 ? 2 : 1);
+        a.nblocks = g.y_blocks + 2 * g.c_blocks;
+        a.blocks_per_mcu = g.gray ? 1 : (g.s420 ? 6 : 3);
+        a.marker_bytes = 2;
+        a.restart = scan_has_restart_markers(o, g) ? o.restart_interval : 0;
+        a.seed_dc[0] = a.seed_dc[1] = a.seed_dc[2] = 0; a.bit_base = 0; a.pad_last = 1;
+        HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
+        HIP_TRY(c.e_count.reserve(pd::scan_count_scratch_bytes()));
+        HIP_TRY(pd::launch_scan_count(a, c.e_count.as<uint32_t>(), c.e_hist.as<unsigned long long>(), c.stream));
+        if ((rc = c.reserve_hsegs(pixo_host::kScanTableWords))) return rc;
+        HIP_TRY(hipMemcpyAsync(c.h_segs, c.e_hist.p, pixo_host::kScanTableWords * 8, hipMemcpyDeviceToHost, c.stream));
+        if (!c.stats_done) HIP_TRY(hipEventCreateWithFlags(&c.stats_done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c.stats_done, c.stream));
+    } else if ((rc = huffman_for_tuple(dy, dcb, dcr, o, g, c, h))) return rc;
     const size_t blocks = g.y_blocks + 2 * g.c_blocks, coef_bytes = blocks * 128;
     if (o.trellis_quant) {
         HIP_TRY(c.t_raw.reserve((blocks + 63) / 64 * 64 * 256)); // (whole wavefronts of the trellis kernel: jpeg_kernels.hpp)
@@ -332,6 +353,12 @@ int progressive_to_view(const void *d_pixels, const pixo_jpeg_options &o, const 
         // one launch over the whole tuple (the planes are contiguous): luminance steps, then chrominance steps
         HIP_TRY(c.t_trail.reserve(pd::trellis_scratch_bytes(blocks)));
         HIP_TRY(pd::launch_trellis(ry, qt + 128, qt + 192, dy, blocks, g.y_blocks, c.t_trail.p, c.stream));
+    }
+    if (late_tables) { // the counts have arrived (the search is still running): tables, exactly like optimized_from_counts
+        HIP_TRY(hipEventSynchronize(c.stats_done));
+        uint64_t dc[2][12], ac[2][256];
+        split_counts(c.h_segs, dc, ac);
+        h = pixo_host::HuffSet::optimized(dc, ac, !g.gray);
     }
     if (!debug().host_entropy) {
         std::vector<uint8_t> head;

@@ -128,6 +128,7 @@ hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool
 // host_totals (pinned host memory, or null): [1] and [2] receive d_state[1] and d_state[2] as well.
 size_t fused_stuff_state_words(uint64_t max_stream_bytes);
 uint64_t stuff_tiles(uint64_t stream_bytes);
+uint64_t stuff_tile_bytes(); // bytes of the packed stream one stuffing workgroup takes
 hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_code_state, size_t code_state_words, uint32_t shift, bool band,
                               uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state,
                               bool state_is_zero, uint8_t *d_out, uint64_t out_cap, unsigned long long *host_totals, hipStream_t s,

@@ -774,7 +774,10 @@ __global__ __launch_bounds__(256) void scan_count_sum_kernel(const uint32_t *sla
 }
 
 // ---- stuff: 16 KiB tiles of the packed stream ----------------------------------------------------------------------
-constexpr int kStuffThreads = 256, kLaneWords = 16, kWaveBytes = 64 * kLaneWords * 4, kTileBytes = (kStuffThreads / 64) * kWaveBytes;
+#ifndef PIXO_STUFF_LANE_WORDS
+#define PIXO_STUFF_LANE_WORDS 16 // (A/B builds: tools/ab_build.sh; 16 words per lane = 16 KiB tiles)
+#endif
+constexpr int kStuffThreads = 256, kLaneWords = PIXO_STUFF_LANE_WORDS, kWaveBytes = 64 * kLaneWords * 4, kTileBytes = (kStuffThreads / 64) * kWaveBytes;
 constexpr uint32_t kMaxSegGap = 1024;                        // bytes a segmented scan may leave free behind a segment (SegArgs::marker_bytes)
 constexpr uint32_t kStageBytes = 2 * kTileBytes + 32 + kMaxSegGap; // worst case: every byte 0xFF, + the output's alignment skew, + the gap behind a segment
 __device__ __forceinline__ uint32_t zero_byte_mask(uint32_t x)
@@ -1085,6 +1088,7 @@ hipError_t launch_scan_count(const ScanArgs &a, uint32_t *d_scratch, unsigned lo
 }
 
 uint64_t stuff_tiles(uint64_t stream_bytes) { return (stream_bytes + kTileBytes - 1) / kTileBytes; }
+uint64_t stuff_tile_bytes() { return kTileBytes; }
 
 hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_code_state, size_t code_state_words, uint32_t shift, bool band,
                               uint64_t max_stream_bytes, uint64_t first_tile, uint64_t tiles, unsigned long long *d_state,

@@ -193,7 +193,7 @@ static int device_progressive_scans_fused(const int16_t *dy, const int16_t *dcb,
     for (int attempt = 0;; ++attempt) {
         HIP_TRY(c.e_out.reserve(want_cap));
         HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), state_words, 0, false,
-                                       stream_bytes + 8 * 16384, first_tile, tiles, c.e_stuff_state.as<unsigned long long>(),
+                                       stream_bytes + 8 * pd::stuff_tile_bytes(), first_tile, tiles, c.e_stuff_state.as<unsigned long long>(),
                                        /*state_is_zero=*/attempt == 0, c.e_out.as<uint8_t>(), c.e_out.cap, mailbox, stream, nullptr, 0, &sg,
                                        debug().spin_budget));
         c.code_state_zero_words = state_words;

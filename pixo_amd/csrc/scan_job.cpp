@@ -333,7 +333,7 @@ int scan_stuff_segmented(Context &c, ScanJob &j, hipStream_t stream)
     for (int attempt = 0;; ++attempt) {
         HIP_TRY(c.e_out.reserve(want_cap));
         HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), code_words, 0, false,
-                                       j.stream_cap + j.nseg * 16384, first_tile, tiles, c.e_stuff_state.as<unsigned long long>(),
+                                       j.stream_cap + j.nseg * pd::stuff_tile_bytes(), first_tile, tiles, c.e_stuff_state.as<unsigned long long>(),
                                        /*state_is_zero=*/attempt == 0, c.e_out.as<uint8_t>(), c.e_out.cap,
                                        reinterpret_cast<unsigned long long *>(c.h_totals), stream, nullptr, 0, &j.seg, debug().spin_budget));
         c.code_state_zero_words = code_words;

@@ -81,13 +81,18 @@ __device__ __forceinline__ void store_relaxed(unsigned long long *p, unsigned lo
 }
 
 // Sum of everything before ticket `g` (decoupled look-back), by one whole wavefront: per round lane l inspects the
-// descriptors of tickets top - l - 64 i, i < 8, so that 512 predecessors are read at once (all loads in flight
-// together); a descriptor holds flag + value in ONE 64-bit word, so a single relaxed load sees a consistent pair.
-// Why so wide: every group of a launch is resident and reaches this point at about the same time, when no inclusive
-// prefix exists yet — each group then has to add up ALL aggregates before it, and a descriptor access is a round trip
-// to the fabric (the XCDs' L2s are not coherent with each other): one lane walking back took 100 us for the 4096x4096
-// image, 64 per round still 90 (32 dependent rounds for the last group).  Every lane returns the sum.
-constexpr int kLookBatch = 8;
+// descriptors of tickets top - l - 64 i, i < kLookBatch (all loads in flight together); a descriptor holds flag + value
+// in ONE 64-bit word, so a single relaxed load sees a consistent pair.  Every lane returns the sum.
+// Round width: every group of a launch is resident and reaches this point at about the same time, and a descriptor
+// access is a round trip to the fabric (the XCDs' L2s are not coherent with each other).  One LANE walking back took
+// 100 us for the 4096x4096 image (round 3).  Rounds of 512 were the round-3 choice; with the round-4 kernels (tails
+// published by every group, aggregate tails) the A/B of 64 / 128 / 256 / 512 / 1024 / 2048 per round has 64 equal on
+// baseline files and 7-11 us faster on progressive ones, and the wide rounds clearly slower (1024: +30..+70 us) — the
+// descriptor reads of 2048+ simultaneous look-backs are the traffic that matters.
+#ifndef PIXO_LOOK_BATCH
+#define PIXO_LOOK_BATCH 1 // 64 predecessors per round; 2..32 measured slower (profiles/r04_ab_look_batch.txt)
+#endif
+constexpr int kLookBatch = PIXO_LOOK_BATCH;
 // Waiting is BOUNDED: forward progress of these kernels rests on the hardware starting the workgroups of a
 // grid in increasing id order (file header) — observed, not promised by HIP.  Every poll loop gives up after `budget`
 // polls (launch argument; 2^20 polls of >= 64 cycles each = tens of milliseconds, three orders of magnitude beyond any

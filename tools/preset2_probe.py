@@ -11,7 +11,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "progressive"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 kind = sys.argv[3] if len(sys.argv) > 3 else "noise"
 w = h = 4096
-px = synth.noise(w, h, 42) if kind == "noise" else synth.gradient_rgb(w, h)
+px = synth.noise(w, h, 42) if kind == "noise" else (synth.gradient_rgb(w, h) if kind == "gradient" else synth.constant(w, h, 77))
 d = torch.from_numpy(px).to("cuda:0"); torch.cuda.synchronize()
 b = jpeg.JpegOptions.builder(w, h).quality(80).subsampling(jpeg.Subsampling.S420)
 kw = {"baseline": {}, "progressive": dict(progressive=True), "trellis": dict(progressive=True, trellis_quant=True),

@@ -114,3 +114,30 @@ def case_of(case_id, max_side=320):
     px = content(kind, w, h, ch, raw)
     assert px.size == w * h * ch and px.dtype == np.uint8
     return dict(id=case_id, kind=kind, w=w, h=h, color_type=color_type, quality=quality, preset=preset, s420=s420), px
+
+
+PNG_BPP = {0: 1, 1: 2, 2: 3, 3: 4}
+
+
+def png_case_of(case_id, max_side=200):
+    """(dict, pixel bytes) of PNG row-filter case `case_id`: colour types 0..3 (gray, gray+alpha, RGB, RGBA), wasm presets 0..2
+    (AdaptiveFast / Adaptive / Bigrams).  Alpha samples are made odd (never 0: the reference's optimize_alpha rewrites pixels under
+    alpha 0 at presets 1 and 2).  Presets 1 and 2 also reduce colour type / palettise when the content allows: the campaign
+    skips such cases (the PNG's IHDR says so), the recorded ones are those the reference left in their pixel format."""
+    raw = _Raw(0xC2B2AE3D27D4EB4F ^ (case_id * 0x100000001B3))
+    kind = KINDS[raw.below(len(KINDS))]
+    ct = raw.below(4)
+    preset = (0, 0, 1, 1, 2)[raw.below(5)]
+    side = 48 if preset == 2 else max_side            # preset 2 runs the reference's optimal DEFLATE: small images only
+    shape = raw.below(8)
+    if shape == 0:
+        w, h = 1 + raw.below(12), 1 + raw.below(12)
+    elif shape == 1:
+        w, h = 1 + raw.below(side * 4), 1 + raw.below(8)
+    else:
+        w, h = 1 + raw.below(side), 1 + raw.below(side)
+    ch = PNG_BPP[ct]
+    px = content(kind, w, h, ch, raw)
+    if ct in (1, 3):
+        px[ch - 1::ch] |= 1
+    return dict(id=case_id, kind=kind, w=w, h=h, color_type=ct, preset=preset), px

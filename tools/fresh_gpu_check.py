@@ -16,6 +16,21 @@ for i in range(first, first + count):
     b = bytes(O.encode_flat(px, o["w"], o["h"], o["color_type"], o["quality"], o["preset"], o["s420"]))
     if a != b:
         bad += 1; print("MISMATCH", o, len(a), len(b), flush=True)
+pbad = 0
+from pixo_amd import png
+import numpy as np
+for i in range(first, first + count):
+    o, px = F.png_case_of(i)
+    bpp = F.PNG_BPP[o["color_type"]]
+    strategy, flags, ostrat, stateful = {0: (png.FilterStrategy.ADAPTIVE_FAST, png.NO_RAYON, O.S_ADAPTIVE_FAST, True),
+                                         1: (png.FilterStrategy.ADAPTIVE, 0, O.S_ADAPTIVE, False),
+                                         2: (png.FilterStrategy.BIGRAMS, 0, O.S_BIGRAMS, False)}[o["preset"]]
+    got, gad = png.apply_filters(px, o["w"], o["h"], bpp, strategy, flags)
+    want, wad = O.png_filter(px, o["w"], o["h"], bpp, ostrat, stateful)
+    if not np.array_equal(got, want) or gad != wad:
+        pbad += 1; print("PNG MISMATCH", o, flush=True)
+print("fresh png cases %d..%d: %d compared, %d mismatches" % (first, first + count - 1, count, pbad))
+bad += pbad
 print("fresh cases %d..%d: %d compared, %d mismatches, single-pass fallbacks %d, %.0f s" %
       (first, first + count - 1, count, bad, jpeg.lookback_fallbacks(), time.time() - t0))
 sys.exit(1 if bad else 0)

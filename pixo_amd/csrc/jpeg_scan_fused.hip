@@ -189,6 +189,12 @@ struct LdsSink {
 // aligned with the segments (the last group of a segment is partly empty), a segment's first group is the floor of its
 // groups' look-back — nothing crosses a segment — and its last group leaves the segment's length in seg.bits.  How the
 // segments follow each other in the file is the stuffing kernel's business.
+#ifdef PIXO_TIMELINE // (experiment builds only, tools/scan_timeline.py: where a group's time goes; 100 MHz constant clock)
+__device__ unsigned long long g_timeline[8192 * 8];
+#define PIXO_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_timeline[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PIXO_STAMP(k) do { } while (0)
+#endif
 template <int MODE, bool SEG>
 __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) void scan_code_kernel
 (const ScanArgs a, unsigned long long *state, uint32_t *stream, unsigned long long *clear, uint32_t clear_words,
@@ -202,6 +208,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     __shared__ unsigned long long s_before;
     __shared__ uint32_t s_carry, s_abort;
     const int lane = threadIdx.x, wave = lane >> 6;
+    PIXO_STAMP(0);
     if (lane == 0) { s_carry = 0; s_abort = 0; }
     const uint64_t g = blockIdx.x; // (one group per workgroup; see the note on dispatch order at the top of the file)
     // the group's place: segment, first ticket of the segment (the look-back's floor), blocks
@@ -240,7 +247,11 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const v4u *p = reinterpret_cast<const v4u *>(base + ref.index * 64);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
+#ifdef PIXO_EXPERIMENT_ROWS // (upper-bound experiment, flat images only: rows >= N are taken as zero without being read)
+            const v4u q = r < PIXO_EXPERIMENT_ROWS ? p[r] : v4u{0, 0, 0, 0};
+#else
             const v4u q = p[r];
+#endif
             w[4 * r] = q.x; w[4 * r + 1] = q.y; w[4 * r + 2] = q.z; w[4 * r + 3] = q.w;
         }
         if (live) {
@@ -258,6 +269,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     for (uint64_t i = (uint64_t)blockIdx.x * kGroup + lane; i < clear_words; i += (uint64_t)gridDim.x * kGroup) clear[i] = 0;
     if (surplus) return;
     __syncthreads();
+    PIXO_STAMP(1);
     {
         // ---- THE walk: the block's codes into the lane's scratch from bit 0 — which also gives its length; group scan;
         // the group's aggregate goes out at once.  Blocks of more than 384 bits do not fit the scratch: a group that
@@ -278,6 +290,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const bool any_long = PIXO_ANY64(long_block); // (a ballot: outside the one-lane branch below)
         if ((lane & 63) == 0) wave_long[wave] = any_long ? 1u : 0u;
         __syncthreads();
+        PIXO_STAMP(2);
         uint32_t wave_base = 0, group_bits = 0, group_long = 0;
 #pragma unroll
         for (int k = 0; k < kGroupWaves; k++) {
@@ -330,6 +343,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                 p.finish();
             }
             if (wbase == 0) { // where the group starts in the stream
+                PIXO_STAMP(3);
                 if (wave == 0) {
                     const uint64_t sum = look_back(desc, g, floor_g, group_bits, state, host_abort, spin_budget);
                     if (lane == 0) {
@@ -348,6 +362,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                     }
                 }
                 __syncthreads();
+                PIXO_STAMP(4);
                 if (s_abort) return; // (the look-back gave up: the host codes this scan again, see Waiter)
                 const uint64_t start = lead + s_before;
                 uint64_t end = start + group_bits;
@@ -391,6 +406,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             if (lane == 0) s_carry = buf[wn - 1];
             __syncthreads();
         }
+        PIXO_STAMP(5);
         // ---- the word shared with the group before: its bits arrive as that group's tail.  AFTER this group's own
         // tail went out: waiting here in the first round of several made a chain through every group of the scan (each
         // link one round: 310 us for 2048 groups of two rounds, against 45).
@@ -416,8 +432,15 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             if (tail_partial && out_words == 1) store_relaxed(&tails[g], kTailValid | merged); // (pass-through: a handful of bits inside one word)
             else __builtin_nontemporal_store(merged, &stream[first_word]);
         }
+        PIXO_STAMP(6);
     }
 }
+#ifdef PIXO_TIMELINE
+extern "C" __attribute__((visibility("default"))) int pixo_hip_debug_scan_timeline(unsigned long long *out, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // ---- progressive scans in one pass (round 4) ----------------------------------------------------------------------------
 // The scans of simple_progressive_script (progressive.rs:98-110; jpeg/mod.rs:872-927, :1248-1380) as segments of ONE launch:

@@ -827,3 +827,24 @@ def test_batch_into_a_device_arena_files_complete_in_hbm(shape):
     with pytest.raises(error.BufferTooSmall) as ei:
         jpeg.encode_batch_device_into(torch.empty(total - 1, dtype=torch.uint8, device="cuda:0"), d_px, o, n)
     assert "need %d bytes" % total in str(ei.value)
+
+
+@pytest.mark.parametrize("w,h", [(65535, 1), (1, 65535), (65535, 9), (9, 65535), (65535, 17), (17, 65535)])
+@pytest.mark.parametrize("preset", [0, 1, 2])
+def test_maximum_dimension_strips_whole_files(w, h, preset):
+    """The format's largest side (jpeg/mod.rs:338-345, MAX_DIMENSION) as a strip in either direction: 8,192 MCU columns / rows of
+    which the last is partial, for the three wasm presets, RGB 4:2:0 / 4:4:4 and gray."""
+    for ct, s420, seed in ((2, True, 5), (2, False, 6), (0, False, 7)):
+        px = synth.noise_gray(w, h, seed) if ct == 0 else synth.noise(w, h, seed)
+        want = bytes(O.encode_flat(px, w, h, ct, 77, preset, s420))
+        got = bytes(jpeg.encode_jpeg(px, w, h, ct, 77, preset, s420))
+        assert got == want, (w, h, preset, ct, s420)
+
+
+def test_maximum_width_many_rows_and_maximum_height_many_columns():
+    for (w, h) in ((65535, 200), (200, 65535)):
+        px = synth.gradient_rgb(w, h)
+        px = (px.astype(np.int32) + (synth.noise(w, h, 3).astype(np.int32) & 7)).clip(0, 255).astype(np.uint8)
+        for s420 in (True, False):
+            want = bytes(O.encode_flat(px, w, h, 2, 85, 0, s420))
+            assert bytes(jpeg.encode_jpeg(px, w, h, 2, 85, 0, s420)) == want, (w, h, s420)

@@ -18,7 +18,7 @@ kw = {"baseline": {}, "progressive": dict(progressive=True), "trellis": dict(pro
       "preset2": dict(progressive=True, trellis_quant=True, optimize_huffman=True)}[what]
 for k, v in kw.items(): b = getattr(b, k)(v)
 o = b.build()
-pinned = torch.empty(w * h * 3 // 2, dtype=torch.uint8).pin_memory()
+pinned = torch.empty(w * h * 2, dtype=torch.uint8).pin_memory()  # (>= 64 B per block + headers: the library then may deliver in pieces)
 for _ in range(3): jpeg.encode_device_into(pinned, d, o)
 ts = []
 for _ in range(n):

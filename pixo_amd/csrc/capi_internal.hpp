@@ -118,6 +118,7 @@ struct Context {
     Buf e_tables, e_hist, e_count, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out, e_seg_bytes, e_seg_off;
     Buf e_code_state, e_stuff_state; // single-pass kernels (jpeg_scan_fused.hip): look-back descriptors, totals
     Buf e_chain;                     // a scan coded in pieces: bits / bytes of the scan before every piece (device_entropy_pieces)
+    Buf e_seams;                     // batch files that stay in HBM: their offsets + the header bytes for batch_seams_kernel
     Buf e_segs;                      // segmented scans (batches, restart intervals): per-segment results of the single-pass kernels
     hipStream_t copy_stream = nullptr; // ... whose bytes travel to the host on this stream while the next piece is coded
     hipStream_t upload_stream = nullptr; // host pixels arrive band by band on this stream while earlier bands are transformed

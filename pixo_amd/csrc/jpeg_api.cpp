@@ -598,14 +598,14 @@ int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg
     if (rc) return rc;
     if (at > capacity) return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(at) + " bytes");
     const size_t hdr = head.size();
-    if (arena_device) { // headers and EOI markers by small host-to-device copies: EOI of file i and the headers of file i + 1 are neighbours
-        std::vector<uint8_t> seam(hdr + 2);
-        seam[0] = 0xFF; seam[1] = 0xD9;
-        std::memcpy(seam.data() + 2, head.data(), hdr);
-        hipError_t e = hipMemcpyAsync(arena, seam.data() + 2, hdr, hipMemcpyHostToDevice, c->stream);
-        for (uint32_t i = 1; i < batch && e == hipSuccess; ++i)
-            e = hipMemcpyAsync(arena + offsets[i] - 2, seam.data(), hdr + 2, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(arena + at - 2, seam.data(), 2, hipMemcpyHostToDevice, c->stream);
+    if (arena_device) { // headers and EOI markers: one small upload (offsets + the header bytes) and one launch, a workgroup per seam
+        std::vector<uint64_t> meta(batch + 1 + (hdr + 7) / 8);
+        for (uint32_t i = 0; i < batch; ++i) meta[i] = offsets[i];
+        meta[batch] = at;
+        std::memcpy(meta.data() + batch + 1, head.data(), hdr);
+        hipError_t e = c->e_seams.reserve(meta.size() * 8);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->e_seams.p, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = pixo_dev::launch_batch_seams(arena, c->e_seams.as<unsigned long long>(), batch, static_cast<uint32_t>(hdr), c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return hip_fail(e, "headers of the batch files");
         return PIXO_OK;

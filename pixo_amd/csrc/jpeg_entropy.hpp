@@ -105,6 +105,8 @@ struct SegArgs {
 uint32_t seg_groups(uint64_t seg_blocks);
 uint32_t seg_max_gap();
 size_t fused_code_state_words_seg(uint64_t nsegs, uint64_t seg_blocks);
+// headers + EOI markers of batch files that stay on the device; d_meta: [offsets[0..batch-1], end] (u64), then `hdr` header bytes
+hipError_t launch_batch_seams(uint8_t *d_arena, const unsigned long long *d_meta, uint32_t batch, uint32_t hdr, hipStream_t s);
 hipError_t launch_seg_layout(const SegArgs &seg, unsigned long long *d_layout, unsigned long long *d_bytes, unsigned long long *host_totals,
                              hipStream_t s); // host_totals[2] (or null) receives the total number of 16 KiB tiles
 

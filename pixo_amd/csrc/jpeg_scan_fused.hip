@@ -1094,6 +1094,25 @@ hipError_t launch_prog_code(const ProgCode &a, const SegArgs &seg, unsigned long
     return hipGetLastError();
 }
 
+// Files of a batch that stay in HBM (a caller that gathers them over RCCL): the scans already lie at their final spacing, what
+// is missing are the bytes between them — EOI of file i - 1 and the headers of file i, which are the same for every file.
+// `meta` = [offsets[0 .. batch - 1], end] as 64-bit words, then the header bytes.  One workgroup per seam.
+__global__ __launch_bounds__(256) void batch_seams_kernel(uint8_t *arena, const unsigned long long *meta, uint32_t batch, uint32_t hdr)
+{
+    const uint32_t i = blockIdx.x; // seam i: in front of file i; seam `batch`: the last file's EOI
+    const uint8_t *head = reinterpret_cast<const uint8_t *>(meta + batch + 1);
+    const unsigned long long at = meta[i];
+    if (i < batch)
+        for (uint32_t k = threadIdx.x; k < hdr; k += 256) arena[at + k] = head[k];
+    if (i > 0 && threadIdx.x < 2) arena[at - 2 + threadIdx.x] = threadIdx.x ? 0xD9 : 0xFF;
+}
+
+hipError_t launch_batch_seams(uint8_t *d_arena, const unsigned long long *d_meta, uint32_t batch, uint32_t hdr, hipStream_t s)
+{
+    hipLaunchKernelGGL(batch_seams_kernel, dim3(batch + 1), dim3(256), 0, s, d_arena, d_meta, batch, hdr);
+    return hipGetLastError();
+}
+
 hipError_t launch_seg_layout(const SegArgs &seg, unsigned long long *d_layout, unsigned long long *d_bytes, unsigned long long *host_totals, hipStream_t s)
 {
     hipLaunchKernelGGL(seg_layout_kernel, dim3(1), dim3(1024), 0, s, seg.bits, seg.nsegs, d_layout, d_bytes, host_totals);

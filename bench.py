@@ -724,9 +724,11 @@ def rccl_evidence(job):
     return out
 
 
-def measure_c4(job, q, steps, warmup, blocks, settle_ms):
+def measure_c4(job, q, steps, warmup, blocks, settle_ms, shared_arena=False):
     """configs[3]: MCU-row bands of ONE 16384x16384 image resident on the N GPUs; a step = the finished file on rank 0.
     Strong scaling: the image is fixed, every rank holds 1/N of it.  Every rank calls; rank 0 gets the result dict.
+    shared_arena: the file is assembled in ONE node-shared, registered segment — every rank copies its band's body over its OWN
+    PCIe link (1/N of the 178 MB each) instead of all bodies travelling to rank 0 over xGMI and then over rank 0's single link.
     --stub: a 256x192 image through the host twins over gloo (plumbing), the oracle's file as the reference."""
     import synth
     from pixo_amd import jpeg, sharded
@@ -738,18 +740,31 @@ def measure_c4(job, q, steps, warmup, blocks, settle_ms):
     rows = b["row_end"] - b["row_begin"]
     mine = synth.noise_rows(w, h, 42, b["row_begin"], b["row_end"])
     state = {}
+    shared = None
+    if shared_arena:
+        name = "pixo_bench_c4_%s" % os.environ.get("MASTER_PORT", "0")
+        size = w * h * 3 // 4 + (1 << 20)
+        if job.rank == 0:
+            shared = sharded.SharedFile(name, size, create=True)
+        job.barrier()
+        if job.rank != 0:
+            shared = sharded.SharedFile(name, size, create=False)
+        if not job.stub:
+            shared.register()
+        state["shared"] = shared
     if job.stub:
         import oracle_lib as O
 
         def step(i):
-            state["file"] = sharded.encode_banded(mine, opts, coeff_fn=lambda sub, o: O.coeffs(sub, o.width, o.height, 2, 1, o.quality))
+            got = sharded.encode_banded(mine, opts, coeff_fn=lambda sub, o: O.coeffs(sub, o.width, o.height, 2, 1, o.quality), shared=shared)
+            state["file"] = got if shared is None or got is None else shared.array()[:got].tobytes()
         kev = None
     else:
         d_band = torch.from_numpy(mine).to(job.dev)
-        out = torch.empty(w * h * 3 // 4 + (1 << 20), dtype=torch.uint8).pin_memory() if job.rank == 0 else None
+        out = torch.empty(w * h * 3 // 4 + (1 << 20), dtype=torch.uint8).pin_memory() if job.rank == 0 and not shared_arena else None
 
         def step(i):
-            state["len"] = sharded.encode_banded(d_band, opts, device=job.local_rank, out=out)
+            state["len"] = sharded.encode_banded(d_band, opts, device=job.local_rank, out=out, shared=shared)
 
         # the coefficient kernel of this rank's band alone (roofline object), HIP events on the launch stream
         yb, cbn = jpeg.coefficient_geometry(w, rows, 2, 1)
@@ -764,7 +779,14 @@ def measure_c4(job, q, steps, warmup, blocks, settle_ms):
         job.settle(kstep, settle_ms)
         _, kev = job.time_blocks(kstep, 20, 5, 5)
         del ty, tcb, tcr
-    walls, _ = job.time_blocks(step, steps, warmup, blocks, events=False)
+    try:
+        walls, _ = job.time_blocks(step, steps, warmup, blocks, events=False)
+        if job.rank == 0 and shared is not None and not job.stub:
+            out = torch.from_numpy(shared.array()[: state["len"]].copy())
+    finally:
+        if shared is not None:
+            job.barrier()
+            shared.close(unlink=job.rank == 0)
     if job.rank != 0:
         return None
     if job.stub:
@@ -782,7 +804,9 @@ def measure_c4(job, q, steps, warmup, blocks, settle_ms):
     res = {"value": round(w * h / (st["ms_per_step"] * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "n_gpus": job.world, "steps": steps,
            "warmup": warmup, **st, "scaling": "strong",
            "config": {"workload": "configs[3]: single %dx%d RGB8 (noise seed 42) in MCU-row bands across the GPUs, per-band entropy "
-                                  "coding, 3 x i16 + u64 exchanged per band over RCCL, bodies gathered over xGMI, spliced on rank 0" % (w, h),
+                                  "coding, 3 x i16 + u64 exchanged per band over RCCL, %s, spliced on rank 0"
+                                  % (w, h, "every band's body copied over its own GPU's PCIe link into one node-shared registered arena" if shared_arena
+                                     else "bodies gathered over xGMI"),
                       "width": w, "height": h, "quality": q, "subsampling": "4:2:0", "band_rows_rank0": rows,
                       "file_bytes": int(n), "file_sha256": digest, "sha256_is_the_reference_s": (not job.stub) and digest == C4_SHA256,
                       "parallelism": "one process per GPU, one band per rank"},
@@ -970,6 +994,7 @@ def multi_gpu_extras(job, args):
         out["rccl"] = {"error": repr(ex)}
     small = job.stub
     legs = (("c4", lambda: measure_c4(job, args.quality, 2 if small else 5, 1, 3, 0 if small else QUICK_SETTLE_MS)),
+            ("c4_shared_arena", lambda: measure_c4(job, args.quality, 2 if small else 5, 1, 3, 0, shared_arena=True)),
             ("c3_sharded", lambda: measure_c3_sharded(job, args.quality, 2 if small else 5, 1, 3)),
             ("c3_sharded_shared_arena", lambda: measure_c3_sharded(job, args.quality, 2 if small else 5, 1, 3, shared_arena=True)))
     if job.world > 1 and not job.stub:  # (rank 0 alone; the others wait in the next `agree`)

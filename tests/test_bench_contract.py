@@ -62,6 +62,8 @@ def test_bench_honours_gpus_when_started_without_a_launcher():
         assert "error" not in leg, leg
         assert leg["n_gpus"] == 2 and leg["scaling"] == "strong" and leg["value"] > 0 and leg["ms_per_step_min"] <= leg["ms_per_step"]
     assert len(c4["config"]["file_sha256"]) == 64 and c3["config"]["images_per_rank"] == [8, 8]
+    c4s = line["other_configs"]["c4_shared_arena"]  # the same file, every band's body written into one node-shared segment
+    assert "error" not in c4s and c4s["config"]["file_sha256"] == c4["config"]["file_sha256"] and "shared" in c4s["config"]["workload"]
     one = _stub_line(1)
     assert one["n_gpus"] == 1 and one["rccl"]["world"] == 1 and "error" not in one["other_configs"]["c4"]
     assert one["other_configs"]["c3_sharded"]["config"]["images_per_rank"] == [16]

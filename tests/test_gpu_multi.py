@@ -284,6 +284,8 @@ def test_world_of_one_rccl_batch_and_bench_legs_of_a_multi_gpu_run():
     assert c4["config"]["file_sha256"] == "77cc6cb69a782693c46f2024ac57ebfdfb8411148fa3cef62698c727af36c70c" and c4["config"]["file_bytes"] == 178548465
     assert c3["config"]["images_per_rank"] == [64] and c3["config"]["file0_sha256"].startswith("d1811ba1761f6b2a")
     assert c4["value"] > 1000 and c3["value"] > 1000
+    c4s = line["other_configs"]["c4_shared_arena"]
+    assert "error" not in c4s and c4s["config"]["file_sha256"] == c4["config"]["file_sha256"], c4s
     c3s = line["other_configs"]["c3_sharded_shared_arena"]
     assert "error" not in c3s, c3s
     assert c3s["config"]["file0_sha256"] == c3["config"]["file0_sha256"] and c3s["config"]["file_bytes_total"] == c3["config"]["file_bytes_total"]

@@ -115,7 +115,13 @@ class SharedFile:
 
     def __init__(self, name, size, create):
         from multiprocessing import shared_memory
-        self.shm = shared_memory.SharedMemory(name=name, create=create, size=size if create else 0)
+        try:
+            self.shm = shared_memory.SharedMemory(name=name, create=create, size=size if create else 0)
+        except FileExistsError:  # a segment of that name left behind by a run that died: the creating rank owns the name
+            stale = shared_memory.SharedMemory(name=name, create=False)
+            stale.close()
+            stale.unlink()
+            self.shm = shared_memory.SharedMemory(name=name, create=True, size=size)
         self.size = size
         self.registered = False
 

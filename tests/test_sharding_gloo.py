@@ -402,3 +402,16 @@ def _worker_batch_shared(rank, world, port, n, w, h, ret):
 
 def test_batch_files_written_by_every_rank_into_one_shared_arena():
     assert _run(_worker_batch_shared, 3, (7, 40, 24), timeout=300) is True
+
+
+def test_shared_file_replaces_a_stale_segment_of_the_same_name():
+    from pixo_amd import sharded
+    name = "pixo_test_stale_%d" % os.getpid()
+    a = sharded.SharedFile(name, 4096, create=True)
+    a.array()[:4] = 7
+    a.shm.close()  # (the run "died": mapping gone, name left behind)
+    b = sharded.SharedFile(name, 8192, create=True)
+    try:
+        assert b.array().size == 8192 and int(b.array()[:4].sum()) == 0
+    finally:
+        b.close(unlink=True)

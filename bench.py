@@ -97,6 +97,7 @@ def ensure_world(args):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         sys.stdout.flush()
         os.execv(sys.executable, cmd)
+    claim_stdout()  # (not before the re-execution above: the ranks it starts inherit this process's descriptors)
     world = int(env_world or "1")
     if world != args.gpus:
         raise SystemExit("bench: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a number "
@@ -194,8 +195,7 @@ class Job:
                 ctypes.CDLL(None).fflush(None)
             except Exception:
                 pass
-            sys.stdout.flush()
-            print(json.dumps(line, ensure_ascii=False), flush=True)
+            emit(line)
 
 
 def block_stats(walls, steps):
@@ -977,8 +977,7 @@ def guarded_multi_gpu_extras(job, args):
 def leave_without_teardown(line):
     """After a multi-GPU leg was abandoned: print the line (rank 0) and end the process at once — collectives may be stuck."""
     if line is not None:
-        sys.stdout.flush()
-        print(json.dumps(line, ensure_ascii=False), flush=True)
+        emit(line)
     sys.stderr.flush()
     os._exit(0)
 
@@ -1054,6 +1053,26 @@ def run_c4_single_process(job, args):
                        "devices_visible": have, "parallelism": "one process, one persistent host thread per band"},
             "roofline": None}
     job.finish(line)
+
+
+_LINE_OUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner when its first
+    communicator is made): from here on file descriptor 1 IS stderr, and only `emit` holds the real stdout."""
+    global _LINE_OUT
+    if _LINE_OUT is None:
+        sys.stdout.flush()
+        _LINE_OUT = os.fdopen(os.dup(1), "w", encoding="utf-8")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    out = _LINE_OUT if _LINE_OUT is not None else sys.stdout
+    out.write(json.dumps(line, ensure_ascii=False) + "\n")
+    out.flush()
 
 
 def main():

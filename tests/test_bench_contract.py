@@ -43,8 +43,8 @@ def _stub_line(gpus, extra=()):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--gpus", str(gpus), "--steps", "4", "--warmup", "1",
                         "--blocks", "3", "--no-cpu-baseline", *extra], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout  # rank 0 prints ONE line
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout  # stdout carries ONE line: the JSON (libraries' banners go to stderr)
     return json.loads(lines[0])
 
 

@@ -277,6 +277,7 @@ def test_world_of_one_rccl_batch_and_bench_legs_of_a_multi_gpu_run():
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     import json
+    assert [l[:1] for l in r.stdout.splitlines() if l.strip()] == ["{"], r.stdout[:2000]  # ONE line on stdout, RCCL's banner included in stderr
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["rccl"]["world"] == 1 and line["rccl"]["backend"] == "nccl" and line["rccl"]["devices"][0]["rank"] == 0
     c4, c3 = line["other_configs"]["c4"], line["other_configs"]["c3_sharded"]

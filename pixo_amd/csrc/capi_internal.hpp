@@ -56,9 +56,12 @@ int hip_fail(hipError_t e, const char *what); // pixo::Error::CompressionError(S
 //   copy_threads=n     threads that copy finished files above 2 MB into fresh host memory (default 8)
 //   spin_budget=n      look-back kernels give up waiting after n polls (default 2^20; tests force the fallback with 0)
 //   no_bands_upload    host pixels are uploaded in one copy instead of MCU-row bands pipelined with the kernels
+//   plain_host         no host-memory policy (for embedders that own theirs): pixo_hip_free returns every block to malloc at once
+//                      (no blocks kept for the next large file), fresh blocks are plain malloc, no madvise(MADV_HUGEPAGE) on the
+//                      caller's or the library's memory.  Costs what profiles/r03_fresh_pages.txt shows for files of 24 MiB and more.
 struct DebugSwitches {
     bool trace = false, host_entropy = false, multipass_entropy = false, direct_stores = false, one_piece = false;
-    bool piece_medium_forced = false, no_bands_upload = false;
+    bool piece_medium_forced = false, no_bands_upload = false, plain_host = false;
     // host pixels are uploaded in bands from this many MiB of pixels on (bands_upload_min_mb=n), in bands of about
     // bands_upload_mb=n MiB.  A 4096x4096 RGB image (48 MiB) in six bands of 8 MiB: noise 1.18 -> 1.14 ms into caller storage,
     // but a smooth image 0.99 -> 1.10 ms and the malloc'ing entry 1.43 -> 1.55: not below 96 MiB (profiles/r03_host_bands_probe.txt)

@@ -562,7 +562,7 @@ BlockCache &block_cache()
 }
 uint8_t *alloc_file(size_t n)
 {
-    if (n < kLargeBlock) return static_cast<uint8_t *>(std::malloc(n ? n : 1));
+    if (n < kLargeBlock || debug().plain_host) return static_cast<uint8_t *>(std::malloc(n ? n : 1));
     {
         BlockCache &bc = block_cache();
         std::lock_guard<std::mutex> lock(bc.m);
@@ -588,7 +588,7 @@ uint8_t *alloc_file(size_t n)
 void free_file(void *p)
 {
     if (!p) return;
-    const size_t cap = malloc_usable_size(p);
+    const size_t cap = debug().plain_host ? 0 : malloc_usable_size(p);
     if (cap >= kLargeBlock) {
         BlockCache &bc = block_cache();
         std::lock_guard<std::mutex> lock(bc.m);
@@ -616,7 +616,7 @@ void advise_huge(void *p, size_t n)
 {
     constexpr uintptr_t kHuge = uintptr_t{2} << 20;
     const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + kHuge - 1) & ~(kHuge - 1), b = (reinterpret_cast<uintptr_t>(p) + n) & ~(kHuge - 1);
-    if (n >= kLargeBlock && b > a) (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
+    if (n >= kLargeBlock && b > a && !debug().plain_host) (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
 }
 
 void big_copy(uint8_t *dst, const uint8_t *src, size_t n)

@@ -848,3 +848,25 @@ def test_maximum_width_many_rows_and_maximum_height_many_columns():
         for s420 in (True, False):
             want = bytes(O.encode_flat(px, w, h, 2, 85, 0, s420))
             assert bytes(jpeg.encode_jpeg(px, w, h, 2, 85, 0, s420)) == want, (w, h, s420)
+
+
+def test_plain_host_switch_keeps_no_blocks_and_the_bytes():
+    """PIXO_HIP_DEBUG=plain_host: pixo_hip_free gives large blocks straight back (nothing cached), no madvise; the file is the same."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import hashlib, synth
+from pixo_amd import jpeg
+px = synth.noise(8192, 4096, 9)
+o = jpeg.JpegOptions.builder(8192, 4096).quality(90).subsampling(jpeg.Subsampling(0)).build()
+a = jpeg.encode(px, o); b = jpeg.encode(px, o)
+assert a == b and len(a) > (24 << 20)
+print("SHA", hashlib.sha256(a).hexdigest())
+''' % (root, root)
+    outs = []
+    for dbg in ("", "plain_host"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PIXO_HIP_DEBUG=dbg))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("SHA")][0])
+    assert outs[0] == outs[1]

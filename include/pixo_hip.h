@@ -156,7 +156,8 @@ int pixo_hip_jpeg_encode_device(const void *d_pixels, const pixo_jpeg_options *o
 /* The same into caller storage (`encode_into` for resident pixels): headers and the entropy-coded bytes
  * are written straight into `output` — with pinned (hipHostMalloc / registered) storage the device-to-host
  * copy is the only pass over the file.  *out_len receives the file size, also on
- * PIXO_ERR_BUFFER_TOO_SMALL (nothing is copied then).  A large scan (more than 786,432 blocks: 8192 x 4096 at
+ * PIXO_ERR_BUFFER_TOO_SMALL (what `output` holds then is unspecified: a pinned `output` is written by the GPU directly,
+ * up to its capacity).  A large scan (more than 786,432 blocks: 8192 x 4096 at
  * 4:2:0) is coded in pieces whose bytes travel while the next piece is coded — into `output` directly when
  * capacity >= 64 bytes per 8x8 block + 10 KB (a smaller `output` gets the file in one copy at the end; an `output` that
  * large may have been written to when a file larger still is refused with PIXO_ERR_BUFFER_TOO_SMALL). */

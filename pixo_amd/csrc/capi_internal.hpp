@@ -48,7 +48,8 @@ int hip_fail(hipError_t e, const char *what); // pixo::Error::CompressionError(S
 //   trace              per-phase wall times of the device entropy stage on stderr
 //   host_entropy       the host twin of the scan coders instead of the device kernels (jpeg_host.cpp)
 //   multipass_entropy  the multi-pass entropy kernels (jpeg_entropy.hip) for every scan instead of the single-pass ones
-//   direct_stores      the stuffing kernel stores straight into pinned host memory instead of HBM + copy
+//   direct_stores      the stuffing kernel stores straight into pinned host memory instead of HBM + copy, for files of every size
+//   no_direct_small    ... and never, not even for small files (their default since round 4)
 //   one_piece          never code a scan in pieces
 //   piece_groups=n     equal pieces of n groups of 192 blocks instead of 2048
 //   piece_medium=n     growing pieces from n groups on instead of 1024, whatever the last file's size
@@ -61,7 +62,7 @@ int hip_fail(hipError_t e, const char *what); // pixo::Error::CompressionError(S
 //                      caller's or the library's memory.  Costs what profiles/r03_fresh_pages.txt shows for files of 24 MiB and more.
 struct DebugSwitches {
     bool trace = false, host_entropy = false, multipass_entropy = false, direct_stores = false, one_piece = false;
-    bool piece_medium_forced = false, no_bands_upload = false, plain_host = false;
+    bool piece_medium_forced = false, no_bands_upload = false, plain_host = false, no_direct_small = false;
     // host pixels are uploaded in bands from this many MiB of pixels on (bands_upload_min_mb=n), in bands of about
     // bands_upload_mb=n MiB.  A 4096x4096 RGB image (48 MiB) in six bands of 8 MiB: noise 1.18 -> 1.14 ms into caller storage,
     // but a smooth image 0.99 -> 1.10 ms and the malloc'ing entry 1.43 -> 1.55: not below 96 MiB (profiles/r03_host_bands_probe.txt)

@@ -423,9 +423,17 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
         if ((rc = scan_lengths(c, j, o, g, stream, nullptr, /*wait=*/false))) return rc;
         // One image into host memory the GPU can write — the context's pinned file buffer, or storage of the caller's
         // that is pinned / registered: the stuffing kernel stores straight into it, behind the place of the headers.
+        // Small files take that way by default: the stuffing kernel's stores ARE the transfer, and the call has one wait instead
+        // of wait + copy + wait — 64x64 62 -> 42 us, 512x512 noise 65 -> 54 us (device pixels -> pinned), any smooth 1080p image
+        // 59 -> 48 us; a 1.4 MB file (1080p noise) is where the copy engine wins again (profiles/r04_small_latency.txt).  "Small" =
+        // at most 32,768 blocks (1024x1365 px at 4:2:0), or a file predicted below 768 KB from the bytes per block of this
+        // context's last scan.  Large files: the debug switch `direct_stores` (slower, profiles/r02_direct_host_stores.txt).
+        constexpr uint64_t kDirectBlocks = 32768, kDirectBytes = 768u << 10;
+        const bool small_file = !debug().no_direct_small &&
+                                (j.n <= kDirectBlocks || (c.packed_per_block && j.n * static_cast<uint64_t>(c.packed_per_block + 1) <= kDirectBytes));
         HostTarget target;
         bool direct = false;
-        if (batch == 1 && !j.segmented && direct_host_stores()) {
+        if (batch == 1 && !j.segmented && (direct_host_stores() || small_file)) {
             pixo_host::file_headers(head, o, j.h); // (the tables are known since scan_lengths)
             if (!dest) {
                 target.grow = true;
@@ -451,6 +459,7 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
                 *file_len = total;
                 return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(total) + " bytes");
             }
+            if (j.n) c.packed_per_block = static_cast<uint32_t>(j.scan_bytes / j.n);
             uint8_t *buf = dest ? dest : c.h_file;
             std::memcpy(buf, head.data(), hdr);
             buf[hdr + j.scan_bytes] = 0xFF; // EOI

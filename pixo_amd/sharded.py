@@ -83,6 +83,25 @@ class _HostBand:
         return jpeg.band_piece_host(self.y, self.cb, self.cr, self.options, self.rows, self._prev, bit_offset, self._counts)
 
 
+def _wire(group, tdev):
+    """Where the tensors of a collective live.  RCCL takes device tensors as they are; gloo moves host memory only, so on a gloo
+    group device tensors are staged through the host (nodes without RCCL between them — and the tests that run two or three
+    ranks on ONE GPU, which RCCL refuses)."""
+    import torch
+    import torch.distributed as dist
+    return torch.device("cpu") if dist.get_backend(group) == "gloo" else tdev
+
+
+def _gather_bulk(t, dst, group, wire):
+    """`dist.gather` of equally sized byte tensors; on `dst` the list of every rank's tensor (host tensors when staged)."""
+    import torch
+    import torch.distributed as dist
+    send = t if t.device == wire or wire.type != "cpu" else t.cpu()
+    recv = [torch.empty_like(send) for _ in range(dist.get_world_size(group))] if dist.get_rank(group) == dst else None
+    dist.gather(send, recv, dst=_global(group, dst), group=group)
+    return recv
+
+
 def _all_gather_i64(values, group, device):
     """all_gather of a few integers per rank (the exchanges of the path are this small)."""
     import torch
@@ -202,11 +221,12 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
     else:
         enc = _HostBand(options, world, rank, coeff_fn)
         tdev = torch.device("cpu")
+    wire = _wire(group, tdev)
     try:
         rows = enc.row_end - enc.row_begin
         last = enc.coeffs(band_pixels)
         # exchange 1: boundary DCs (+ whether the band has rows)
-        got = _all_gather_i64([rows > 0] + last, group, tdev)
+        got = _all_gather_i64([rows > 0] + last, group, wire)
         prev = [0, 0, 0]
         for r in range(rank):
             if got[r][0]:
@@ -214,19 +234,19 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
         total_counts = None
         if options.optimize_huffman:  # exchange 1b: symbol statistics, summed
             counts = enc.count(prev)
-            t = torch.from_numpy(counts.view(np.int64).copy()).to(tdev)
+            t = torch.from_numpy(counts.view(np.int64).copy()).to(wire)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             total_counts = t.cpu().numpy().view(np.uint64)
         if not on_gpu:
             enc._prev, enc._counts = prev, total_counts
         bits = enc.lengths(prev, total_counts)
         # exchange 2: bits per band -> this band's bit offset
-        all_bits = [b[0] for b in _all_gather_i64([bits], group, tdev)]
+        all_bits = [b[0] for b in _all_gather_i64([bits], group, wire)]
         offset = sum(all_bits[:rank])
         if not on_gpu and shared is not None:  # host twins through the shared file: header exchange, body at its final place
             piece = enc.pack(offset)
             words = np.frombuffer(piece[:16], np.int64)
-            all_hdr = [np.array(h, np.int64).tobytes() for h in _all_gather_i64([int(words[0]), int(words[1])], group, tdev)]
+            all_hdr = [np.array(h, np.int64).tobytes() for h in _all_gather_i64([int(words[0]), int(words[1])], group, wire)]
             file_len, body_off = jpeg.splice_layout(options, all_hdr, total_counts)
             _check_shared(shared, file_len)
             arr = shared.array()
@@ -251,7 +271,7 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
         # device: the body stays in HBM; exchange 3 = the 16-byte piece headers -> the file's layout
         hdr, n = enc.pack_device(offset)
         words = np.frombuffer(hdr, np.int64)
-        all_hdr = [np.array(h, np.int64).tobytes() for h in _all_gather_i64([int(words[0]), int(words[1])], group, tdev)]
+        all_hdr = [np.array(h, np.int64).tobytes() for h in _all_gather_i64([int(words[0]), int(words[1])], group, wire)]
         file_len, body_off = jpeg.splice_layout(options, all_hdr, total_counts)
         lens = [int(np.frombuffer(h, np.uint64)[1]) for h in all_hdr]
         if shared is not None:
@@ -272,8 +292,7 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
             # the bodies travel to dst over xGMI (one gather of equal-sized buffers), then dst's PCIe link
             send = torch.empty(max(max(lens), 1), dtype=torch.uint8, device=tdev)
             enc.copy_body(send)
-            recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-            dist.gather(send, recv, dst=dst, group=group)
+            recv = _gather_bulk(send, dst, group, wire)
             if rank != dst:
                 return None
             file = out if out is not None else _pinned_file(file_len)
@@ -357,9 +376,8 @@ def encode_gathered_device(d_band_pixels, options, group=None, dst=0, coeff_fn=N
     outs = []
     for t in (y, cb, cr):
         tb = t.view(torch.uint8)  # neither RCCL nor gloo has a 16-bit integer type: move bytes
-        parts = [torch.empty_like(tb) for _ in range(world)] if rank == dst else None
-        dist.gather(tb, parts, dst=dst, group=group)
-        outs.append([p.view(torch.int16) for p in parts] if parts is not None else None)
+        parts = _gather_bulk(tb, dst, group, _wire(group, dev))
+        outs.append([p.to(dev).view(torch.int16) for p in parts] if parts is not None else None)
     if rank != dst:
         return None
     fy = torch.cat([outs[0][r][: bands[r]["y_blocks"]] for r in range(world)])
@@ -393,13 +411,29 @@ def _global(group, r):
     return dist.get_global_rank(group, r) if group is not None else r
 
 
-def _p2p(ops):
+def _p2p(ops, group=None):
     """Posts all sends / receives of one step at once (RCCL runs them as one group: the source's seven xGMI links carry
-    seven different peers' images at the same time) and waits for them."""
+    seven different peers' images at the same time) and waits for them.  ops: ("send" | "recv", tensor, global peer rank).
+    On a gloo group device tensors travel through host copies (`_wire`)."""
+    import torch
     import torch.distributed as dist
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+    if not ops:
+        return
+    staged_wire = dist.get_backend(group) == "gloo"
+    posted, landed = [], []
+    for kind, t, peer in ops:
+        w = t
+        if staged_wire and t.is_cuda:
+            if kind == "send":
+                w = t.cpu()
+            else:
+                w = torch.empty(t.shape, dtype=t.dtype)
+                landed.append((t, w))
+        posted.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, w, peer, group))
+    for req in dist.batch_isend_irecv(posted):
+        req.wait()
+    for t, w in landed:
+        t.copy_(w)
 
 
 def encode_batch(batch_pixels, options, n, group=None, src=0, dst=0, device=None, encode_fn=None, out=None, shared=None):
@@ -449,12 +483,11 @@ def encode_batch(batch_pixels, options, n, group=None, src=0, dst=0, device=None
             raise ValueError("encode_batch: rank src passes the %d images back to back (%d bytes)" % (n, n * px))
         whole = batch_pixels.reshape(-1)
         mine = whole[lo * px: hi * px]
-        _p2p([dist.P2POp(dist.isend, whole[a * px: b * px], _global(group, r), group)
-              for r, (a, b) in enumerate(parts) if r != src and b > a])
+        _p2p([("send", whole[a * px: b * px], _global(group, r)) for r, (a, b) in enumerate(parts) if r != src and b > a], group)
     else:
         mine = torch.empty(cnt * px, dtype=torch.uint8, device=tdev)
         if cnt:
-            _p2p([dist.P2POp(dist.irecv, mine, gsrc, group)])
+            _p2p([("recv", mine, gsrc)], group)
 
     # 2. encode this rank's images; the files stay where the next step sends them from
     lens = []
@@ -481,7 +514,7 @@ def encode_batch(batch_pixels, options, n, group=None, src=0, dst=0, device=None
 
     # 3. sizes: every rank's per-image lengths, padded to the longest share
     most = max(b - a for a, b in parts)
-    all_lens = _all_gather_i64(lens + [0] * (most - cnt), group, tdev)
+    all_lens = _all_gather_i64(lens + [0] * (most - cnt), group, _wire(group, tdev))
     lens_all = [x for r, (a, b) in enumerate(parts) for x in all_lens[r][: b - a]]
     offsets, at = [], 0
     for x in lens_all:
@@ -503,7 +536,7 @@ def encode_batch(batch_pixels, options, n, group=None, src=0, dst=0, device=None
     # 4. gather the files on dst, every run straight to its final offset
     if rank != dst:
         if run_len[rank]:
-            _p2p([dist.P2POp(dist.isend, run[: run_len[rank]], gdst, group)])
+            _p2p([("send", run[: run_len[rank]], gdst)], group)
         return None
     if out is not None and out.numel() < at:
         from . import error
@@ -511,14 +544,12 @@ def encode_batch(batch_pixels, options, n, group=None, src=0, dst=0, device=None
         e.needed = at
         # (the peers' sends are already posted: receive them into scratch so that nobody is left waiting, then raise)
         scratch = torch.empty(max(at, 1), dtype=torch.uint8, device=tdev)
-        _p2p([dist.P2POp(dist.irecv, scratch[run_off[r]: run_off[r] + run_len[r]], _global(group, r), group)
-              for r in range(world) if r != dst and run_len[r]])
+        _p2p([("recv", scratch[run_off[r]: run_off[r] + run_len[r]], _global(group, r)) for r in range(world) if r != dst and run_len[r]], group)
         raise e
     whole = torch.empty(max(at, 1), dtype=torch.uint8, device=tdev)
     if run_len[rank]:
         whole[run_off[rank]: run_off[rank] + run_len[rank]].copy_(run[: run_len[rank]])
-    _p2p([dist.P2POp(dist.irecv, whole[run_off[r]: run_off[r] + run_len[r]], _global(group, r), group)
-          for r in range(world) if r != dst and run_len[r]])
+    _p2p([("recv", whole[run_off[r]: run_off[r] + run_len[r]], _global(group, r)) for r in range(world) if r != dst and run_len[r]], group)
     if not on_gpu:
         arena = whole if out is None else out
         if out is not None:

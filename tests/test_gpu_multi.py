@@ -290,3 +290,100 @@ def test_world_of_one_rccl_batch_and_bench_legs_of_a_multi_gpu_run():
     c3s = line["other_configs"]["c3_sharded_shared_arena"]
     assert "error" not in c3s, c3s
     assert c3s["config"]["file0_sha256"] == c3["config"]["file0_sha256"] and c3s["config"]["file_bytes_total"] == c3["config"]["file_bytes_total"]
+
+
+_RANKS_ON_ONE_GPU = """
+import os, sys, hashlib
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+import numpy as np, torch, torch.distributed as dist
+import oracle_lib as O, synth
+from pixo_amd import ColorType, jpeg, sharded, error
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = torch.device("cuda", 0)
+ok = True
+# --- one image in MCU-row bands, every rank's band RESIDENT ON THE GPU, per-band entropy coding on the GPU ---
+for (w, h, ct, ss, q, kw) in [(1000, 700, 2, 1, 80, {}), (333, 517, 2, 0, 91, {}), (640, 200, 0, 0, 60, {}), (512, 512, 2, 1, 75, {"optimize_huffman": True}),
+                              (130, 20, 2, 1, 80, {}), (2048, 2048, 2, 1, 85, {})]:
+    px = synth.noise_gray(w, h, 11) if ct == 0 else (synth.noise(w, h, 11) if w != 2048 else synth.gradient_rgb(w, h))
+    b = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss))
+    for k, v in kw.items():
+        b = getattr(b, k)(v)
+    opts = b.build()
+    band = jpeg.band(w, h, ct, ss, world, rank)
+    bpp = 1 if ct == 0 else 3
+    mine = torch.from_numpy(px[band["row_begin"] * w * bpp: band["row_end"] * w * bpp].copy()).to(dev)
+    want = O.encode(px, O.make_options(w, h, ct, q, ss, **kw))
+    for dst in (0, world - 1):
+        got = sharded.encode_banded(mine, opts, dst=dst, device=0)
+        if rank == dst:
+            ok = ok and got == want
+        else:
+            ok = ok and got is None
+    # the same with every rank writing its body into one node-shared, registered segment
+    name = "pixo_gpu_ranks_%%s_%%d_%%d" %% (port, w, h)
+    size = len(want) + 100
+    shared = sharded.SharedFile(name, size, create=True) if rank == 0 else None
+    dist.barrier()
+    if rank != 0:
+        shared = sharded.SharedFile(name, size, create=False)
+    shared.register()
+    n = sharded.encode_banded(mine, opts, dst=0, device=0, shared=shared)
+    if rank == 0:
+        ok = ok and n == len(want) and shared.array()[:n].tobytes() == want
+    dist.barrier()
+    shared.close(unlink=rank == 0)
+# --- progressive files cannot be coded in bands: coefficient bands gathered on dst, entropy stage there ---
+w, h = 320, 240
+px = synth.noise(w, h, 5)
+opts = jpeg.JpegOptions.builder(w, h).quality(70).subsampling(jpeg.Subsampling(1)).progressive(True).build()
+band = jpeg.band(w, h, 2, 1, world, rank)
+mine = torch.from_numpy(px[band["row_begin"] * w * 3: band["row_end"] * w * 3].copy()).to(dev)
+got = sharded.encode_gathered_device(mine, opts, dst=0)
+if rank == 0:
+    ok = ok and got == O.encode(px, O.make_options(w, h, 2, 70, 1, progressive=True))
+# --- a batch resident on rank `src`, encoded by every rank on the GPU, files gathered on `dst` ---
+for (w, h, n, src, dst) in [(640, 360, 7, 0, 0), (96, 64, 2, world - 1, 0), (200, 120, 11, 0, world - 1)]:
+    imgs = [synth.noise(w, h, 100 + i) for i in range(n)]
+    opts = jpeg.JpegOptions.builder(w, h).quality(82).subsampling(jpeg.Subsampling(1)).build()
+    d = torch.from_numpy(np.concatenate(imgs)).to(dev) if rank == src else None
+    got = sharded.encode_batch(d, opts, n, src=src, dst=dst, device=0)
+    if rank == dst:
+        arena, offs, lens = got
+        for i in range(n):
+            ok = ok and arena[offs[i]: offs[i] + lens[i]].numpy().tobytes() == O.encode(imgs[i], O.make_options(w, h, 2, 82, 1))
+    else:
+        ok = ok and got is None
+flag = torch.tensor([1 if ok else 0])
+dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+print("RANK", rank, "OK" if ok else "MISMATCH", "ALL", int(flag[0]), "fallbacks", jpeg.lookback_fallbacks(), flush=True)
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_ranks_above_zero_on_a_gpu_bands_batches_and_gathered_tuples(world):
+    """N processes, ALL on the one GPU the box has (RCCL refuses that; the exchanges travel over gloo, device tensors staged
+    through the host by `sharded._wire`): the first time ranks above 0 run the DEVICE band encoder (non-zero bit offsets, seeded
+    predictors, bodies copied into a registered shared segment from a second process), `encode_gathered_device` and
+    `encode_batch` on received device tensors.  Every file against the oracle."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+    code = _RANKS_ON_ONE_GPU % {"root": ROOT}
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world), port], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out, err))
+    for r, (rc, out, err) in enumerate(outs):
+        assert rc == 0, (r, err[-3000:])
+        assert "RANK %d OK ALL 1 fallbacks 0" % r in out, (r, out, err[-2000:])

@@ -120,15 +120,25 @@ class Job:
             self.dist = dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # TEST MODE (PIXO_BENCH_SHARE_GPU=1, tests/test_gpu_multi.py): the N ranks of a run all use GPU 0 and talk over gloo — RCCL
+        # refuses two ranks on one device.  What a box with ONE GPU can check of an N-rank run: every leg's control flow and the
+        # files' bytes at ranks above 0.  The line says so (`data`, `rccl.backend`); its numbers are not N-GPU numbers.
+        self.share_gpu = bool(os.environ.get("PIXO_BENCH_SHARE_GPU")) and not self.stub and self.world > 1
         if self.stub:
-            self.dev = torch.device("cpu")
+            self.dev = self.wire = torch.device("cpu")
+            self.gpu_index = None
             if self.dist is not None:
                 self.dist.init_process_group(backend="gloo")
         else:
-            torch.cuda.set_device(self.local_rank)
-            self.dev = torch.device("cuda", self.local_rank)
+            self.gpu_index = 0 if self.share_gpu else self.local_rank
+            torch.cuda.set_device(self.gpu_index)
+            self.dev = torch.device("cuda", self.gpu_index)
+            self.wire = torch.device("cpu") if self.share_gpu else self.dev  # where the tensors of the timing collectives live
             if self.dist is not None:
-                self.dist.init_process_group(backend="nccl", device_id=self.dev)
+                if self.share_gpu:
+                    self.dist.init_process_group(backend="gloo")
+                else:
+                    self.dist.init_process_group(backend="nccl", device_id=self.dev)
 
     def sync(self):
         if not self.stub:
@@ -142,7 +152,7 @@ class Job:
     def max_over_ranks(self, seconds):
         if self.dist is None:
             return seconds
-        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.dev)
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.wire)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -460,7 +470,8 @@ def run_coeffs(job, args):
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": st["ms_per_step"], "ms_per_step_min": st["ms_per_step_min"], "ms_per_step_max": st["ms_per_step_max"],
         "blocks": st["blocks"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "stub" if job.stub else "synthetic",
+        "dtype": "f32", "data": "stub" if job.stub else ("synthetic — TEST MODE: the %d ranks share ONE GPU over gloo (PIXO_BENCH_SHARE_GPU), not an N-GPU measurement" % job.world
+                                                           if job.share_gpu else "synthetic"),
         "config": {"workload": wl.label, "width": wl.w, "height": wl.h, "batch": wl.batch, "quality": wl.q,
                    "subsampling": "4:2:0" if wl.ss else "4:4:4", "buffers_rotated": wl.nbuf,
                    "working_set_MiB": round(wl.nbuf * (wl.in_bytes + wl.out_bytes) / 2**20, 1),
@@ -694,7 +705,7 @@ def agree(job, ok):
     others inside that workload's collectives."""
     if job.dist is None:
         return bool(ok)
-    t = job.torch.tensor([1 if ok else 0], dtype=job.torch.int64, device=job.dev)
+    t = job.torch.tensor([1 if ok else 0], dtype=job.torch.int64, device=job.wire)
     job.dist.all_reduce(t, op=job.dist.ReduceOp.MIN)
     return bool(t.item())
 
@@ -704,7 +715,7 @@ def rccl_evidence(job):
     and one all_reduce whose result only comes out right when all ranks took part."""
     torch, dist = job.torch, job.dist
     out = {"world": dist.get_world_size(), "backend": dist.get_backend()}
-    t = torch.tensor([job.rank + 1], dtype=torch.int64, device=job.dev)
+    t = torch.tensor([job.rank + 1], dtype=torch.int64, device=job.wire)
     dist.all_reduce(t)
     out["all_reduce_of_rank_plus_1"] = int(t.item())
     out["all_reduce_expected"] = job.world * (job.world + 1) // 2
@@ -712,7 +723,7 @@ def rccl_evidence(job):
         mine = {"rank": job.rank, "device": "cpu (stub)", "pid": os.getpid()}
     else:
         pr = torch.cuda.get_device_properties(job.dev)
-        mine = {"rank": job.rank, "device": job.local_rank, "name": pr.name, "pci_bus_id": getattr(pr, "pci_bus_id", None),
+        mine = {"rank": job.rank, "device": job.gpu_index, "name": pr.name, "pci_bus_id": getattr(pr, "pci_bus_id", None),
                 "uuid": str(getattr(pr, "uuid", "")), "pid": os.getpid()}
         try:
             out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
@@ -764,7 +775,7 @@ def measure_c4(job, q, steps, warmup, blocks, settle_ms, shared_arena=False):
         out = torch.empty(w * h * 3 // 4 + (1 << 20), dtype=torch.uint8).pin_memory() if job.rank == 0 and not shared_arena else None
 
         def step(i):
-            state["len"] = sharded.encode_banded(d_band, opts, device=job.local_rank, out=out, shared=shared)
+            state["len"] = sharded.encode_banded(d_band, opts, device=job.gpu_index, out=out, shared=shared)
 
         # the coefficient kernel of this rank's band alone (roofline object), HIP events on the launch stream
         yb, cbn = jpeg.coefficient_geometry(w, rows, 2, 1)
@@ -877,7 +888,7 @@ def measure_c3_sharded(job, q, steps, warmup, blocks, shared_arena=False):
             shared.register()
 
     def step(i):
-        state["got"] = sharded.encode_batch(d, opts, n, encode_fn=fn, out=out, device=None if job.stub else job.local_rank, shared=shared)
+        state["got"] = sharded.encode_batch(d, opts, n, encode_fn=fn, out=out, device=None if job.stub else job.gpu_index, shared=shared)
 
     try:
         walls, _ = job.time_blocks(step, steps, warmup, blocks, events=False)
@@ -922,7 +933,7 @@ def measure_c4_single_process(job, q, n_dev, steps=3, blocks=3):
     w = h = 16384
     opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling.S420).build()
     px = synth.noise(w, h, 42)
-    devices = list(range(n_dev))
+    devices = [0] * n_dev if job.share_gpu else list(range(n_dev))  # (test mode: the bands share GPU 0)
     blob = jpeg.encode_multi(px, opts, devices)  # (also the warm-up: band workers, contexts, pinned buffers)
     digest = hashlib.sha256(blob).hexdigest()
     if len(blob) != 178548465 or digest != C4_SHA256:
@@ -956,7 +967,7 @@ def guarded_multi_gpu_extras(job, args):
     def work():
         try:
             if not job.stub:
-                job.torch.cuda.set_device(job.local_rank)  # (the current device is per thread)
+                job.torch.cuda.set_device(job.gpu_index)  # (the current device is per thread)
             box["out"] = multi_gpu_extras(job, args)
             if job.dist is not None:
                 job.dist.barrier()

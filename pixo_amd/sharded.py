@@ -141,6 +141,12 @@ class SharedFile:
             stale.close()
             stale.unlink()
             self.shm = shared_memory.SharedMemory(name=name, create=True, size=size)
+        if not create:  # (Python < 3.13 registers attached segments with the resource tracker too, which then unlinks — or complains
+            try:        # about — a segment this process does not own when the process ends)
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(self.shm._name, "shared_memory")
+            except Exception:
+                pass
         self.size = size
         self.registered = False
 

@@ -387,3 +387,28 @@ def test_ranks_above_zero_on_a_gpu_bands_batches_and_gathered_tuples(world):
     for r, (rc, out, err) in enumerate(outs):
         assert rc == 0, (r, err[-3000:])
         assert "RANK %d OK ALL 1 fallbacks 0" % r in out, (r, out, err[-2000:])
+
+
+def test_bench_run_of_two_ranks_sharing_the_gpu_measures_every_multi_gpu_leg():
+    """`bench.py --gpus 2` as the driver starts it on a node, except that both ranks use GPU 0 and talk over gloo
+    (PIXO_BENCH_SHARE_GPU=1: test mode, flagged in the line): every leg a multi-GPU run adds must finish without an error and with the
+    reference's / the oracle's bytes — configs[3] in two bands (sha256 of the reference's file), the same through the shared arena,
+    configs[2] scattered from rank 0 and gathered, the single-process form — and stdout must carry exactly the one line."""
+    import json
+    env = dict(os.environ, PIXO_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--blocks", "3",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and "TEST MODE" in line["data"] and line["rccl"]["world"] == 2 and line["rccl"]["backend"] == "gloo"
+    assert line["rccl"]["all_reduce_of_rank_plus_1"] == 3 and [d["rank"] for d in line["rccl"]["devices"]] == [0, 1]
+    oc = line["other_configs"]
+    for name in ("c4", "c4_shared_arena", "c3_sharded", "c3_sharded_shared_arena", "c4_single_process"):
+        assert name in oc and "error" not in oc[name], (name, oc.get(name))
+    sha = "77cc6cb69a782693c46f2024ac57ebfdfb8411148fa3cef62698c727af36c70c"
+    assert oc["c4"]["config"]["file_sha256"] == sha and oc["c4_shared_arena"]["config"]["file_sha256"] == sha
+    assert oc["c4_single_process"]["config"]["file_sha256"] == sha and oc["c4"]["n_gpus"] == 2
+    assert oc["c3_sharded"]["config"]["images_per_rank"] == [32, 32] and oc["c3_sharded"]["config"]["file0_sha256"].startswith("d1811ba1761f6b2a")
+    assert oc["c3_sharded_shared_arena"]["config"]["file_bytes_total"] == oc["c3_sharded"]["config"]["file_bytes_total"]

@@ -405,6 +405,7 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
         if (rc < 0 || rc == kRetryMultipass) return rc;
         if (rc == 0) {
             c.packed_per_block = static_cast<uint32_t>(scan_bytes / (j.n ? j.n : 1));
+            c.last_scan_bytes = scan_bytes; c.last_scan_blocks = j.n;
             const size_t total = hdr + scan_bytes + 2;
             std::memcpy(buf, head.data(), hdr);
             buf[hdr + scan_bytes] = 0xFF; // EOI
@@ -430,7 +431,8 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
         // context's last scan.  Large files: the debug switch `direct_stores` (slower, profiles/r02_direct_host_stores.txt).
         constexpr uint64_t kDirectBlocks = 32768, kDirectBytes = 768u << 10;
         const bool small_file = !debug().no_direct_small &&
-                                (j.n <= kDirectBlocks || (c.packed_per_block && j.n * static_cast<uint64_t>(c.packed_per_block + 1) <= kDirectBytes));
+                                (j.n <= kDirectBlocks ||
+                                 (c.last_scan_blocks && static_cast<double>(j.n) * static_cast<double>(c.last_scan_bytes) / static_cast<double>(c.last_scan_blocks) <= kDirectBytes));
         HostTarget target;
         bool direct = false;
         if (batch == 1 && !j.segmented && (direct_host_stores() || small_file)) {
@@ -459,7 +461,7 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
                 *file_len = total;
                 return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(total) + " bytes");
             }
-            if (j.n) c.packed_per_block = static_cast<uint32_t>(j.scan_bytes / j.n);
+            if (j.n) { c.packed_per_block = static_cast<uint32_t>(j.scan_bytes / j.n); c.last_scan_bytes = j.scan_bytes; c.last_scan_blocks = j.n; }
             uint8_t *buf = dest ? dest : c.h_file;
             std::memcpy(buf, head.data(), hdr);
             buf[hdr + j.scan_bytes] = 0xFF; // EOI
@@ -476,7 +478,7 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
         sw.lap("memset+pack+ff census");
     }
     const uint64_t scan_bytes = j.scan_bytes;
-    if (batch == 1 && j.n) c.packed_per_block = static_cast<uint32_t>(scan_bytes / j.n);
+    if (batch == 1 && j.n) { c.packed_per_block = static_cast<uint32_t>(scan_bytes / j.n); c.last_scan_bytes = scan_bytes; c.last_scan_blocks = j.n; }
     if (batch > 1 && j.segmented) { // the stuffing kernel left every image's end in the pinned mailbox
         image_starts->assign(batch + 1, 0); // (h_segs[i]: where image i's bytes end; the next image begins behind the gap)
         for (uint32_t i = 0; i < batch; ++i) (*image_starts)[i + 1] = c.h_segs[i] + (i + 1 < batch ? j.seg.marker_bytes : 0);

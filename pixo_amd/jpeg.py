@@ -382,6 +382,12 @@ def encode_batch_device_into(arena, d_pixels, options: JpegOptions, batch: int):
     rc = L.pixo_hip_jpeg_encode_batch_device_into(_dev_ptr(d_pixels), C.byref(oc), batch, ptr, cap, offsets, lens)
     if rc == -9 and arena is None:  # PIXO_ERR_BUFFER_TOO_SMALL: the answer to a size query
         return list(offsets), list(lens)
+    if rc == -9:  # (offsets / lens were filled in: the size a second attempt needs)
+        try:
+            _raise(rc)
+        except error.BufferTooSmall as e:
+            e.needed = int(offsets[batch - 1] + lens[batch - 1]) if batch else 0
+            raise
     if rc:
         _raise(rc)
     return list(offsets), list(lens)

@@ -483,6 +483,26 @@ def encode_batch(batch_pixels, options, n, group=None, src=0, dst=0, device=None
         tdev = torch.device("cpu")
     gsrc, gdst = _global(group, src), _global(group, dst)
 
+    if world == 1 and on_gpu and shared is None:
+        # nothing to scatter or gather: the files go straight from this GPU into the destination's host arena (the library overlaps
+        # their way over PCIe with the kernels of the next sub-batch) — no device arena, no second pass over the bytes
+        if batch_pixels is None or batch_pixels.numel() != n * px:
+            raise ValueError("encode_batch: rank src passes the %d images back to back (%d bytes)" % (n, n * px))
+        prev = jpeg.get_producer_stream()
+        jpeg.set_producer_stream(torch.cuda.current_stream(tdev).cuda_stream)
+        try:
+            arena = out if out is not None else _pinned_file(n * (px // 2 + 4096))
+            while True:
+                try:
+                    offsets, lens = jpeg.encode_batch_device_into(arena, batch_pixels.reshape(-1), options, n)
+                    return arena, [int(x) for x in offsets], [int(x) for x in lens]
+                except jpeg.error.BufferTooSmall as e:
+                    if out is not None:
+                        raise
+                    arena = _pinned_file(int(e.needed))
+        finally:
+            jpeg.set_producer_stream(prev)
+
     # 1. scatter
     if rank == src:
         if batch_pixels is None or batch_pixels.numel() != n * px:

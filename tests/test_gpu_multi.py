@@ -345,15 +345,16 @@ got = sharded.encode_gathered_device(mine, opts, dst=0)
 if rank == 0:
     ok = ok and got == O.encode(px, O.make_options(w, h, 2, 70, 1, progressive=True))
 # --- a batch resident on rank `src`, encoded by every rank on the GPU, files gathered on `dst` ---
-for (w, h, n, src, dst) in [(640, 360, 7, 0, 0), (96, 64, 2, world - 1, 0), (200, 120, 11, 0, world - 1)]:
+for (w, h, n, src, dst, q) in [(640, 360, 7, 0, 0, 82), (96, 64, 2, world - 1, 0, 82), (200, 120, 11, 0, world - 1, 82),
+                               (256, 256, 9, 0, 0, 100)]:  # (q = 100 noise: files larger than the first arena a rank reserves — reserve and retry)
     imgs = [synth.noise(w, h, 100 + i) for i in range(n)]
-    opts = jpeg.JpegOptions.builder(w, h).quality(82).subsampling(jpeg.Subsampling(1)).build()
+    opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling(1)).build()
     d = torch.from_numpy(np.concatenate(imgs)).to(dev) if rank == src else None
     got = sharded.encode_batch(d, opts, n, src=src, dst=dst, device=0)
     if rank == dst:
         arena, offs, lens = got
         for i in range(n):
-            ok = ok and arena[offs[i]: offs[i] + lens[i]].numpy().tobytes() == O.encode(imgs[i], O.make_options(w, h, 2, 82, 1))
+            ok = ok and arena[offs[i]: offs[i] + lens[i]].numpy().tobytes() == O.encode(imgs[i], O.make_options(w, h, 2, q, 1))
     else:
         ok = ok and got is None
 flag = torch.tensor([1 if ok else 0])

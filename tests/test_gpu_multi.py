@@ -306,7 +306,8 @@ dev = torch.device("cuda", 0)
 ok = True
 # --- one image in MCU-row bands, every rank's band RESIDENT ON THE GPU, per-band entropy coding on the GPU ---
 for (w, h, ct, ss, q, kw) in [(1000, 700, 2, 1, 80, {}), (333, 517, 2, 0, 91, {}), (640, 200, 0, 0, 60, {}), (512, 512, 2, 1, 75, {"optimize_huffman": True}),
-                              (130, 20, 2, 1, 80, {}), (2048, 2048, 2, 1, 85, {})]:
+                              (130, 20, 2, 1, 80, {}), (2048, 2048, 2, 1, 85, {}), (777, 1301, 2, 1, 100, {}),
+                              (64, 4096, 2, 0, 50, {"optimize_huffman": True}), (4096, 48, 0, 0, 97, {"optimize_huffman": True})]:
     px = synth.noise_gray(w, h, 11) if ct == 0 else (synth.noise(w, h, 11) if w != 2048 else synth.gradient_rgb(w, h))
     b = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss))
     for k, v in kw.items():

@@ -870,3 +870,29 @@ print("SHA", hashlib.sha256(a).hexdigest())
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("SHA")][0])
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (512, 384), (1024, 1024)])
+def test_small_file_into_pinned_storage_that_is_too_small_exact_and_roomy(shape):
+    """Small files are stored by the stuffing kernel straight into the caller's pinned buffer (round 4): a buffer that is too small by
+    one byte, by half, or has room for 16 bytes only must give BufferTooSmall with the file's length and leave everything BEHIND its
+    capacity alone; the exact size and a roomy buffer must give the file."""
+    import torch
+    from pixo_amd import error
+    w, h = shape
+    px = synth.noise(w, h, 31)
+    o = _opts(w, h, 2, 1, 88)
+    want = bytes(O.encode(px, O.make_options(w, h, 2, 88, 1)))
+    d = torch.from_numpy(px).to("cuda:0")
+    torch.cuda.synchronize()
+    for cap in (16, len(want) // 2, len(want) - 1, len(want), len(want) + 4096):
+        buf = torch.full((cap + 64,), 0xA5, dtype=torch.uint8).pin_memory()
+        view = buf[:cap]
+        if cap < len(want):
+            with pytest.raises(error.BufferTooSmall) as ei:
+                jpeg.encode_device_into(view, d, o)
+            assert ei.value.needed == len(want)
+        else:
+            n = jpeg.encode_device_into(view, d, o)
+            assert n == len(want) and view[:n].numpy().tobytes() == want
+        assert bool((buf[cap:] == 0xA5).all()), "bytes behind the buffer's capacity were written (capacity %d)" % cap

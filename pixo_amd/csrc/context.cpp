@@ -396,6 +396,6 @@ void pixo_hip_copy_file(void *dst, const void *src, size_t n)
 
 const char *pixo_hip_last_error(void) { return t_error.c_str(); }
 
-const char *pixo_hip_version(void) { return "pixo_hip 0.3.0 (gfx950; reference pixo 0.4.1)"; }
+const char *pixo_hip_version(void) { return "pixo_hip 0.4.0 (gfx950; reference pixo 0.4.1)"; }
 
 } // extern "C"

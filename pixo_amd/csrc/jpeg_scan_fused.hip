@@ -157,6 +157,56 @@ __device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t
     return before; // (the caller publishes before + aggregate as this ticket's inclusive prefix)
 }
 
+// The same sum by REDUCE-THEN-SCAN in two levels (round 4): nothing but aggregates is ever read, so no group waits for
+// another group's look-back.  Groups are taken in blocks of 64 (counted from the chain's floor); the LAST group of a block
+// adds up its block — its own aggregate and the 63 before it, one round — and publishes the block's sum in `sup`; a group
+// then needs the aggregates in front of it inside its own block (<= 63, one load per lane) and the sums of all blocks
+// before (one load per lane and 4096 groups), all issued together.  Critical path: aggregates -> block sums -> done, two
+// fabric round trips, where the chained form above takes g / 128 rounds when all groups of a launch arrive at once (a
+// smooth image: 4.5 us median, 8 us for the last groups of 2048; profiles/r04_scan_code_timeline.txt).
+// desc[g] must hold kFlagAggregate | aggregate (publish_aggregate also writes kFlagPrefix for the floor: any flag counts).
+// `sup`: the chain's block sums (zero before the launch).  Every lane returns the sum; kLookBackFailed: gave up waiting.
+__device__ __forceinline__ uint64_t look_back_blocks(unsigned long long *desc, unsigned long long *sup, uint64_t g, uint64_t floor, uint64_t aggregate,
+                                                     unsigned long long *abort_flag, unsigned long long *host_abort, uint32_t budget)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t rel = g - floor, k = rel >> 6;
+    const uint32_t in_block = (uint32_t)(rel & 63);
+    const uint64_t block_first = floor + (k << 6);
+    uint32_t polls = 0;
+    bool gave_up = false;
+    // (A) the aggregates in front of g inside its block, (B) the first 64 block sums — in flight together
+    unsigned long long a = (uint32_t)lane < in_block ? load_relaxed(&desc[block_first + lane]) : kFlagAggregate;
+    unsigned long long b = (uint64_t)lane < k ? load_relaxed(&sup[lane]) : kFlagAggregate;
+    while ((a >> 62) == 0 && !gave_up) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++polls > budget) gave_up = true; else a = load_relaxed(&desc[block_first + lane]);
+    }
+    if (PIXO_ANY64(gave_up)) {
+        if (gave_up) raise_abort(abort_flag, host_abort);
+        return kLookBackFailed;
+    }
+    const uint32_t in_front = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)(a & kValueMask)), 63); // (< 64 x 2^19)
+    if (in_block == 63 && lane == 0) store_relaxed(&sup[k], kFlagAggregate | ((uint64_t)in_front + aggregate)); // this block's sum, before waiting for the others'
+    uint64_t before = in_front;
+    for (uint64_t base = 0;;) { // block sums, 64 per round (one round up to 4096 groups)
+        while ((b >> 62) == 0 && !gave_up) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++polls > budget) gave_up = true; else b = load_relaxed(&sup[base + lane]);
+        }
+        if (PIXO_ANY64(gave_up)) {
+            if (gave_up) raise_abort(abort_flag, host_abort);
+            return kLookBackFailed;
+        }
+        // (a block sum is below 64 x 2^19 = 2^25: 64 of them fit 32 bits)
+        before += (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)(b & kValueMask)), 63);
+        base += 64;
+        if (base >= k) break;
+        b = base + lane < k ? load_relaxed(&sup[base + lane]) : kFlagAggregate;
+    }
+    return before;
+}
+
 // ---- the LDS bit buffer: sink of block_pack_flat (jpeg_scan_block.h) over a window of words --------------------------
 // Word i of the window is word `first + i` of the stream; every word starts out zero and is only ever OR-ed (LDS
 // atomic without return).  Words outside [0, limit) — a group of very long blocks is written out in more than one
@@ -224,6 +274,8 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     const bool surplus = SEG && first_in_chain >= nblocks_chain; // (the last segment is shorter: its surplus groups only do the housekeeping)
     const uint64_t ngroups_total = SEG ? seg.nsegs * seg.groups : (a.nblocks + kGroup - 1) / kGroup;
     unsigned long long *desc = state + 2, *tails = state + 2 + ngroups_total;
+    // block sums of the two-level look-back: per chain (the scan; a segment) one word per 64 groups, behind the tails
+    unsigned long long *sup = state + 2 + 2 * ngroups_total + (SEG ? sidx * ((seg.groups + 63) >> 6) : 0);
     unsigned long long *const host_abort = host_totals ? host_totals + 3 : nullptr;
     // A scan coded piece by piece (ScanPiece, jpeg_entropy.hpp): the piece's stream is byte-aligned with the SCAN — its
     // first `lead` bits are the end of the piece before — so that the stuffing kernel can work on it without a shift.
@@ -345,11 +397,17 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             if (wbase == 0) { // where the group starts in the stream
                 PIXO_STAMP(3);
                 if (wave == 0) {
+#ifdef PIXO_LOOK_CHAINED // (A/B: the chained decoupled look-back of rounds 2-4)
                     const uint64_t sum = look_back(desc, g, floor_g, group_bits, state, host_abort, spin_budget);
+#else
+                    const uint64_t sum = look_back_blocks(desc, sup, g, floor_g, group_bits, state, host_abort, spin_budget);
+#endif
                     if (lane == 0) {
                         if (sum == kLookBackFailed) s_abort = 1;
                         s_before = sum;
+#ifdef PIXO_LOOK_CHAINED
                         if (g != floor_g) store_relaxed(&desc[g], kFlagPrefix | (sum + group_bits));
+#endif
                         if (last_group) { // the stream's length in bits (unpadded; a later piece: with its leading bits)
                             if (SEG) {
                                 seg.bits[sidx] = sum + group_bits;
@@ -1031,8 +1089,16 @@ __global__ __launch_bounds__(kStuffThreads) __attribute__((amdgpu_waves_per_eu(4
 }
 } // namespace
 
-size_t fused_code_state_words(uint64_t nblocks) { return 2 + 2 * (size_t)((nblocks + kGroup - 1) / kGroup); }
-size_t fused_code_state_words_seg(uint64_t nsegs, uint64_t seg_blocks) { return 2 + 2 * (size_t)(nsegs * ((seg_blocks + kGroup - 1) / kGroup)); }
+size_t fused_code_state_words(uint64_t nblocks)
+{ // abort flag, total bits, per group: descriptor + tail, per 64 groups: block sum (+ 1)
+    const size_t groups = (size_t)((nblocks + kGroup - 1) / kGroup);
+    return 2 + 2 * groups + (groups + 63) / 64 + 1;
+}
+size_t fused_code_state_words_seg(uint64_t nsegs, uint64_t seg_blocks)
+{
+    const size_t per = (size_t)((seg_blocks + kGroup - 1) / kGroup);
+    return 2 + 2 * (size_t)nsegs * per + (size_t)nsegs * ((per + 63) / 64) + 1;
+}
 size_t fused_stuff_state_words(uint64_t max_stream_bytes) { return 3 + (size_t)((max_stream_bytes + kTileBytes - 1) / kTileBytes); }
 uint32_t seg_groups(uint64_t seg_blocks) { return (uint32_t)((seg_blocks + kGroup - 1) / kGroup); }
 uint32_t seg_max_gap() { return kMaxSegGap; }

@@ -299,11 +299,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const v4u *p = reinterpret_cast<const v4u *>(base + ref.index * 64);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-#ifdef PIXO_EXPERIMENT_ROWS // (upper-bound experiment, flat images only: rows >= N are taken as zero without being read)
-            const v4u q = r < PIXO_EXPERIMENT_ROWS ? p[r] : v4u{0, 0, 0, 0};
-#else
             const v4u q = p[r];
-#endif
             w[4 * r] = q.x; w[4 * r + 1] = q.y; w[4 * r + 2] = q.z; w[4 * r + 3] = q.w;
         }
         if (live) {

@@ -3,7 +3,7 @@
 randomised cases of tests/fresh_cases.py through the REFERENCE (wasm `encode_jpeg`, src/wasm.rs:113-142) and through the
 oracle's restatement (`po_encode_jpeg_flat`), whole files compared byte for byte.
 
-    python tools/oracle_vs_wasm.py FIRST COUNT [--record N]
+    python tools/oracle_vs_wasm.py FIRST COUNT [--record N] [--max-side S]
 
 --record N writes length + sha256 of the first N cases to tests/golden/jpeg_fresh_cases.json (the CPU and GPU tests then hold the
 oracle and the HIP library to the reference's answers without node)."""
@@ -14,11 +14,14 @@ import fresh_cases as F  # noqa: E402
 import oracle_lib as O  # noqa: E402
 
 
+MAX_SIDE = int(sys.argv[sys.argv.index("--max-side") + 1]) if "--max-side" in sys.argv else 320  # (larger images: another case set)
+
+
 def run_chunk(ids, tmp):
     man = {"cases": []}
     opts, pxs = [], []
     for k, i in enumerate(ids):
-        o, px = F.case_of(i)
+        o, px = F.case_of(i, MAX_SIDE)
         inp = os.path.join(tmp, "in%d.bin" % k)
         px.tofile(inp)
         man["cases"].append(dict(kind="jpeg", input=inp, w=o["w"], h=o["h"], color_type=o["color_type"], quality=o["quality"],
@@ -54,7 +57,7 @@ def main():
                 print("MISMATCH", o, len(ref), len(mine), flush=True)
             if o["id"] < first + record:
                 recs.append(dict(o, len=len(ref), sha256=hashlib.sha256(ref).hexdigest()))
-    print("cases %d..%d: %d compared, %d mismatches, %.0f s" % (first, first + count - 1, count, len(bad), time.time() - t0))
+    print("cases %d..%d (max side %d): %d compared, %d mismatches, %.0f s" % (first, first + count - 1, MAX_SIDE, count, len(bad), time.time() - t0))
     print("by (kind, preset):", " ".join("%s/p%d:%d" % (k[0], k[1], v) for k, v in sorted(by.items())))
     if record:
         assert not bad

@@ -82,8 +82,10 @@ void fill_device_qt(uint8_t quality, float out[kDeviceQtFloats])
         out[192 + i] = t.chr[i];
         out[256 + 2 * i] = bracket_lo(t.chr[i]);
         out[256 + 2 * i + 1] = bracket_hi(t.chr[i]);
-        out[384 + 2 * i] = out[256 + 2 * i] * 0.25f; // exact: 4:2:0 chroma is transformed at 4x scale
-        out[384 + 2 * i + 1] = out[256 + 2 * i + 1] * 0.25f;
+        // 4:2:0 chroma is transformed at 4x scale and NEGATED (the kernel's planes hold 255 - Cb, jpeg_tile.h
+        // color_row4_dot): exact factor -1/4; the two products still bracket the reference quotient
+        out[384 + 2 * i] = out[256 + 2 * i] * -0.25f;
+        out[384 + 2 * i + 1] = out[256 + 2 * i + 1] * -0.25f;
     }
 }
 

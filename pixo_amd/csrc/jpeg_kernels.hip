@@ -163,7 +163,7 @@ __device__ __forceinline__ void store_raw_block(const KArgs &a, const TileCtx &c
         } else {
             const int m = lane & 31;
             if ((uint32_t)m < nvalid) dst = (lane < 32 ? a.rcb : a.rcr) + (size_t)id.img * a.c_stride + (mcu0 + m) * 64;
-            scale = 0.25f;
+            scale = kChromaSumScale;
         }
     } else if (MODE == M444) {
         const size_t blk = (size_t)id.ty * c.units_x + u0 + lane;

@@ -48,6 +48,7 @@
 #define PIXO_SCHED_FENCE() ((void)0)
 #define PIXO_WAVE_SYNC() ((void)0)
 #define PIXO_PIN(x) ((void)0)
+#define PIXO_PIN2(x) ((void)0)
 #define PIXO_CONST_AS
 #else
 #define PIXO_DEV __device__ __forceinline__
@@ -64,6 +65,8 @@
 // Materialises a value here: stops LLVM from sinking the column pass into the quantiser's
 // basic blocks (which kept every column's butterflies alive across them).
 #define PIXO_PIN(x) asm volatile("" : "+v"(x))
+// The same for two floats that must live in ONE aligned register pair (the operand form of v_pk_add_f32 / v_pk_mul_f32).
+#define PIXO_PIN2(x) asm volatile("" : "+v"(x))
 // The quantiser tables are read through the constant address space so that the compiler may
 // use scalar (SMEM) loads.  Inside the persistent loop a plain global pointer is "clobbered"
 // by the kernel's own stores as far as alias analysis knows, and becomes VECTOR loads — whose
@@ -295,44 +298,67 @@ PIXO_DEV Row4 color_row4(uint32_t d0, uint32_t d1, uint32_t d2)
     return o;
 }
 
-// ---- the same conversion with v_dot4_u32_u8 (one instruction = one pixel's three multiply-adds) --------------------
+// ---- the same conversion with dot-product instructions (one instruction = one pixel's three multiply-adds) ----------
 // For 4:2:0, where the chroma values are only ever needed as bytes to add up.  A pixel's three bytes lie in ONE dword
 // (pixels 0 and 3 of a group do already: d0 = R0 G0 B0 R1, d2 = B2 R3 G3 B3; pixels 1 and 2 after one v_alignbyte
-// each); the coefficient dword says which byte is which, so pixel 3 needs no shift.  Negative coefficients: the
-// instruction multiplies unsigned bytes, so the bytes they apply to are complemented (one xor per pixel and component):
-//   Cb:  X = 128 B + 32896 - 43 R - 85 G = 128 B + 43 (255 - R) + 85 (255 - G) + 256        (43 * 255 + 85 * 255 = 32640)
-//   Cr:  X = 128 R + 107 (255 - G) + 21 (255 - B) + 256                                     (107 * 255 + 21 * 255 = 32640)
-// and the value is byte 1 of X (bits 8..15) — except for X = 65536 (pure blue / pure red), where the reference clamps
-// 256 to 255 (color.rs:69-76): the accumulator starts at 0xFFFF0000 + 256 and the instruction SATURATES at 2^32 - 1, so
-// that X = 65536 yields 0xFFFFFFFF, byte 1 = 255, and every other X yields 0xFFFF0000 + X.  Y = 77 R + 150 G + 29 B + 128
-// never exceeds 65408.  12 dot products + 8 xors + 2 shifts per 4 pixels against 18 packed multiply-adds + 6 byte
-// shuffles; the price is that every result is a dword of its own (three more instructions to gather the four Y bytes).
-PIXO_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c, bool clamp)
+// each); the coefficient dword says which byte is which, so pixel 3 needs no shift.
+//   Y = 77 R + 150 G + 29 B + 128 <= 65408: v_dot4_u32_u8 on the pixel as it is, the value is byte 1.
+// Chroma has negative coefficients.  Round 5: ONE xor per pixel turns its bytes into SIGNED ones (s = x - 128) and
+// v_dot4_i32_i8 takes them with signed coefficients — the offsets cancel, (-43 - 85 + 128) * 128 = 0:
+//   Cb:  X = 128 B - 43 R - 85 G + 32896 = 128 sB - 43 sR - 85 sG + 32896     in [256, 65536]
+//   Cr:  X = 128 R - 107 G - 21 B + 32896 = 128 sR - 107 sG - 21 sB + 32896
+// +128 is not an i8 — but -128 is: the lane computes the COMPLEMENT  255 - Cb = 255 - min(X >> 8, 255) = max(V, 0) >> 8
+// with V = 65535 - X = 43 sR + 85 sG - 128 sB + 32639 in [-1, 65279] (the identity 255 - floor(X / 256) =
+// floor((65535 - X) / 256) holds for 0 <= X <= 65535).  V = -1 is X = 65536 — pure blue / pure red, the one colour the
+// reference clamps (256 -> 255, color.rs:69-76): the accumulator starts at 32639 - 2^31 and the instruction SATURATES at
+// -2^31, so that the result is 0x80000000 + max(V, 0) and byte 1 is the complemented value.  The 2x2 sums are then
+// S' = 1020 - S, every value of the chroma transform the exact negative of the reference's (all inputs are integers,
+// f32 rounding is symmetric), and the quantiser multiplies by NEGATED reciprocals (jpeg_host.cpp fill_device_qt): the same
+// coefficients.  (Rounds 3-4 complemented the bytes with negative coefficients: two xors per pixel.)
+// 12 dot products + 4 xors + 2 shifts per 4 pixels against 18 packed multiply-adds + 6 byte shuffles; the price is that
+// every result is a dword of its own (three more instructions to gather the four Y bytes).
+PIXO_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c)
 {
 #if defined(PIXO_EMU)
-    uint64_t t = c;
-    for (int i = 0; i < 4; i++) t += (uint64_t)((a >> (8 * i)) & 0xFF) * ((b >> (8 * i)) & 0xFF);
-    return (uint32_t)(clamp && t > 0xFFFFFFFFull ? 0xFFFFFFFFull : t);
+    uint32_t t = c;
+    for (int i = 0; i < 4; i++) t += ((a >> (8 * i)) & 0xFF) * ((b >> (8 * i)) & 0xFF);
+    return t;
 #else
-    return clamp ? __builtin_amdgcn_udot4(a, b, c, true) : __builtin_amdgcn_udot4(a, b, c, false);
+    return __builtin_amdgcn_udot4(a, b, c, false);
 #endif
 }
+// signed bytes, signed 32-bit accumulator, the result saturated to [-2^31, 2^31 - 1] (v_dot4_i32_i8 ... clamp)
+PIXO_DEV uint32_t sdot4_sat(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(PIXO_EMU)
+    int64_t t = (int32_t)c;
+    for (int i = 0; i < 4; i++) t += (int64_t)(int8_t)(a >> (8 * i)) * (int8_t)(b >> (8 * i));
+    t = t < -2147483648ll ? -2147483648ll : (t > 2147483647ll ? 2147483647ll : t);
+    return (uint32_t)(int32_t)t;
+#else
+    return (uint32_t)__builtin_amdgcn_sdot4((int)a, (int)b, (int)c, true);
+#endif
+}
+// What the chroma planes of the dot-product path hold, and what phase B therefore uses for a 4:2:0 chroma block:
+constexpr float kChromaSumShift = 8.0f * 508.0f; // row DC shift: 512 - S = -(S' - 508), S' = 1020 - S
+constexpr float kChromaSumScale = -0.25f;        // back to the reference's magnitude AND sign
 struct Row4D {
     uint32_t y4;           // Y0..Y3 as bytes
-    uint32_t cb[4], cr[4]; // per pixel: byte 1 = the value (byte 0: discarded fraction, bytes 2-3: ones)
+    uint32_t cb[4], cr[4]; // per pixel: byte 1 = 255 - the value (byte 0: discarded fraction, bytes 2-3: 0x00 0x80)
 };
 PIXO_DEV Row4D color_row4_dot(uint32_t d0, uint32_t d1, uint32_t d2)
 {
     const uint32_t p[4] = {d0, alignbyte(d1, d0, 3), alignbyte(d2, d1, 2), d2}; // pixel i at bytes 0..2 (i = 3: bytes 1..3)
-    const uint32_t kC = 0xFFFF0100u;
+    const uint32_t kC = 0x80000000u + 32639u;
     uint32_t y[4];
     Row4D o;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int sh = i == 3 ? 8 : 0;
-        y[i] = udot4(p[i], 0x001D964Du << sh, 128u, false);                         // 77, 150, 29
-        o.cb[i] = udot4(p[i] ^ (0x0000FFFFu << sh), 0x0080552Bu << sh, kC, true);   // 43 ~R, 85 ~G, 128 B
-        o.cr[i] = udot4(p[i] ^ (0x00FFFF00u << sh), 0x00156B80u << sh, kC, true);   // 128 R, 107 ~G, 21 ~B
+        y[i] = udot4(p[i], 0x001D964Du << sh, 128u);             // 77, 150, 29
+        const uint32_t s = p[i] ^ (0x00808080u << sh);           // signed bytes
+        o.cb[i] = sdot4_sat(s, 0x0080552Bu << sh, kC);           // 43 sR, 85 sG, -128 sB
+        o.cr[i] = sdot4_sat(s, 0x00156B80u << sh, kC);           // -128 sR, 107 sG, 21 sB
     }
     o.y4 = perm(y[1], y[0], 0x0C0C0501u) | perm(y[3], y[2], 0x05010C0Cu); // byte 1 of each, pixel order
     return o;
@@ -585,8 +611,9 @@ template <int MODE, bool DOT4 = false> PIXO_DEV void producer_color_item(int k, 
         *(uint32_t *)(yp + kPitchHalf) = b.y4;
         // 2x2 box sums (jpeg/mod.rs:1641-1646) of the high bytes, u16 exact (<= 1020):
         // even + odd lanes = horizontal neighbours, then the two rows
-        u16x2 cbs = add_high_bytes(a.cbE, a.cbO) + add_high_bytes(b.cbE, b.cbO);
-        u16x2 crs = add_high_bytes(a.crE, a.crO) + add_high_bytes(b.crE, b.crO);
+        // (stored complemented, S' = 1020 - S, like the dot-product path: phase B knows one convention)
+        u16x2 cbs = splat(1020) - (add_high_bytes(a.cbE, a.cbO) + add_high_bytes(b.cbE, b.cbO));
+        u16x2 crs = splat(1020) - (add_high_bytes(a.crE, a.crO) + add_high_bytes(b.crE, b.crO));
         *(uint32_t *)(planar + 8704 + row * 512 + 4 * g) = bits(cbs);
         *(uint32_t *)(planar + 12800 + row * 512 + 4 * g) = bits(crs);
     } else if (MODE == M444) {
@@ -609,25 +636,32 @@ template <int MODE, bool DOT4 = false> PIXO_DEV void producer_color_item(int k, 
 // first butterflies are sums and differences of exact small integers, the shift cancels in
 // every difference and reaches only the DC term of the row, where one subtraction removes it
 // (same arithmetic as the reference's `x as f32 - 128.0`, all values exact integers in f32).
-PIXO_DEV void row_from_bytes(uint32_t lo, uint32_t hi, float *v)
+// Two rows at a time (round 5): sample c of rows r and r + 1 becomes the two halves of ONE aligned register pair, the
+// operand form of the packed f32 instructions the row pass now runs on (aan8_pair).
+typedef float pixo_cf2 __attribute__((ext_vector_type(2)));
+PIXO_DEV void rows2_from_bytes(u32x2 a, u32x2 b, pixo_cf2 *d)
 {
-    v[0] = (float)(lo & 0xFF);         v[1] = (float)((lo >> 8) & 0xFF);
-    v[2] = (float)((lo >> 16) & 0xFF); v[3] = (float)(lo >> 24);
-    v[4] = (float)(hi & 0xFF);         v[5] = (float)((hi >> 8) & 0xFF);
-    v[6] = (float)((hi >> 16) & 0xFF); v[7] = (float)(hi >> 24);
+    d[0] = (pixo_cf2){(float)(a.x & 0xFF), (float)(b.x & 0xFF)};
+    d[1] = (pixo_cf2){(float)((a.x >> 8) & 0xFF), (float)((b.x >> 8) & 0xFF)};
+    d[2] = (pixo_cf2){(float)((a.x >> 16) & 0xFF), (float)((b.x >> 16) & 0xFF)};
+    d[3] = (pixo_cf2){(float)(a.x >> 24), (float)(b.x >> 24)};
+    d[4] = (pixo_cf2){(float)(a.y & 0xFF), (float)(b.y & 0xFF)};
+    d[5] = (pixo_cf2){(float)((a.y >> 8) & 0xFF), (float)((b.y >> 8) & 0xFF)};
+    d[6] = (pixo_cf2){(float)((a.y >> 16) & 0xFF), (float)((b.y >> 16) & 0xFF)};
+    d[7] = (pixo_cf2){(float)(a.y >> 24), (float)(b.y >> 24)};
     // (keeps LLVM from folding the first butterflies into integer SDWA adds + conversions:
     // twice as many half-rate instructions)
 #pragma unroll
-    for (int i = 0; i < 8; i++) PIXO_PIN(v[i]);
+    for (int i = 0; i < 8; i++) PIXO_PIN2(d[i]);
 }
-PIXO_DEV void row_from_u16(u32x4 w, float *v)
+PIXO_DEV void rows2_from_u16(u32x4 a, u32x4 b, pixo_cf2 *d)
 {
-    v[0] = (float)(w.x & 0xFFFF); v[1] = (float)(w.x >> 16);
-    v[2] = (float)(w.y & 0xFFFF); v[3] = (float)(w.y >> 16);
-    v[4] = (float)(w.z & 0xFFFF); v[5] = (float)(w.z >> 16);
-    v[6] = (float)(w.w & 0xFFFF); v[7] = (float)(w.w >> 16);
+    d[0] = (pixo_cf2){(float)(a.x & 0xFFFF), (float)(b.x & 0xFFFF)}; d[1] = (pixo_cf2){(float)(a.x >> 16), (float)(b.x >> 16)};
+    d[2] = (pixo_cf2){(float)(a.y & 0xFFFF), (float)(b.y & 0xFFFF)}; d[3] = (pixo_cf2){(float)(a.y >> 16), (float)(b.y >> 16)};
+    d[4] = (pixo_cf2){(float)(a.z & 0xFFFF), (float)(b.z & 0xFFFF)}; d[5] = (pixo_cf2){(float)(a.z >> 16), (float)(b.z >> 16)};
+    d[6] = (pixo_cf2){(float)(a.w & 0xFFFF), (float)(b.w & 0xFFFF)}; d[7] = (pixo_cf2){(float)(a.w >> 16), (float)(b.w >> 16)};
 #pragma unroll
-    for (int i = 0; i < 8; i++) PIXO_PIN(v[i]);
+    for (int i = 0; i < 8; i++) PIXO_PIN2(d[i]);
 }
 
 // f32 AAN DCT, dct.rs:651-700, operation for operation.
@@ -636,48 +670,43 @@ PIXO_DEV void row_from_u16(u32x4 w, float *v)
 #define PIXO_A4 1.3065629f
 #define PIXO_A5 0.38268343f
 
-// everything of dct.rs:651-700 after the first butterfly stage
-PIXO_DEV void aan8_core(float t0, float t1, float t2, float t3, float t4, float t5, float t6, float t7,
-                        float dc_shift, float &d0, float &d1, float &d2, float &d3, float &d4,
-                        float &d5, float &d6, float &d7)
+// One 1-D transform of dct.rs:651-700 on TWO independent vectors at once — the halves of eight register pairs: rows r and
+// r + 1 in the row pass, columns 2 k and 2 k + 1 in the column pass.  Every operation is the reference's, in the reference's
+// order, applied to both halves by one packed instruction (v_pk_add_f32 / v_pk_mul_f32: IEEE per half, no contraction), so
+// each half sees exactly the roundings of the scalar sequence.  The closing scale multiplications are left to the caller:
+// the column pass does them packed, the row pass as plain multiplications that write straight into the halves of the
+// COLUMN pass's pairs (neighbouring columns of one row) — the transposition between the two pairings costs nothing.
+//
+// SHIFT (row pass): the samples come unshifted (true inputs b_i - L).  The butterflies' sums carry +2L, +4L, +8L and the
+// differences nothing, so only r0 needs the shift (8L = dc_shift).  Every value up to the first multiplication is an exact
+// integer below 2^14, so the reference's own sequence of f32 additions yields the same numbers.
+template <bool SHIFT>
+PIXO_DEV void aan8_pair(pixo_cf2 dc_shift, const pixo_cf2 *d, pixo_cf2 *r)
 {
-    float e0 = t0 + t3, e3 = t0 - t3, e1 = t1 + t2, e2 = t1 - t2;
-    float r0 = (e0 + e1) - dc_shift, r4 = e0 - e1; // dc_shift == 0 in the column pass
-    float z1 = (e2 + e3) * PIXO_A1;
-    float r2 = e3 + z1, r6 = e3 - z1;
-
-    float o0 = t4 + t5, o1 = t5 + t6, o2 = t6 + t7;
-    float z5 = (o0 - o2) * PIXO_A5;
-    float z2 = o0 * PIXO_A2 + z5;
-    float z4 = o2 * PIXO_A4 + z5;
-    float z3 = o1 * PIXO_A1; // A3 == A1
-    float z11 = t7 + z3, z13 = t7 - z3;
-    float r5 = z13 + z2, r3 = z13 - z2, r1 = z11 + z4, r7 = z11 - z4;
-
-    d0 = r0 * 0.3535534f; d1 = r1 * 0.2548978f; d2 = r2 * 0.2705981f; d3 = r3 * 0.3006724f;
-    d4 = r4 * 0.3535534f; d5 = r5 * 0.4499881f; d6 = r6 * 0.6532815f; d7 = r7 * 1.2814578f;
+    const pixo_cf2 t0 = d[0] + d[7], t7 = d[0] - d[7], t1 = d[1] + d[6], t6 = d[1] - d[6];
+    const pixo_cf2 t2 = d[2] + d[5], t5 = d[2] - d[5], t3 = d[3] + d[4], t4 = d[3] - d[4];
+    const pixo_cf2 e0 = t0 + t3, e3 = t0 - t3, e1 = t1 + t2, e2 = t1 - t2;
+    r[0] = SHIFT ? (e0 + e1) - dc_shift : e0 + e1;
+    r[4] = e0 - e1;
+    const pixo_cf2 z1 = (e2 + e3) * PIXO_A1;
+    r[2] = e3 + z1; r[6] = e3 - z1;
+    const pixo_cf2 o0 = t4 + t5, o1 = t5 + t6, o2 = t6 + t7;
+    const pixo_cf2 z5 = (o0 - o2) * PIXO_A5;
+    const pixo_cf2 z2 = o0 * PIXO_A2 + z5;
+    const pixo_cf2 z4 = o2 * PIXO_A4 + z5;
+    const pixo_cf2 z3 = o1 * PIXO_A1; // A3 == A1
+    const pixo_cf2 z11 = t7 + z3, z13 = t7 - z3;
+    r[5] = z13 + z2; r[3] = z13 - z2; r[1] = z11 + z4; r[7] = z11 - z4;
 }
-
-// column pass: plain inputs, no shift (x - 0.0f is exact and folds away)
-PIXO_DEV void aan8(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5, float &d6,
-                   float &d7)
-{
-    float t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
-    float t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
-    aan8_core(t0, t1, t2, t3, t4, t5, t6, t7, 0.0f, d0, d1, d2, d3, d4, d5, d6, d7);
-}
-
-// Row transform on unshifted samples b_i (true inputs b_i - L): the butterflies' sums carry
-// +2L, +4L, +8L and the differences nothing, so only r0 needs the shift (8L = dc_shift).  Every
-// value up to the first multiplication is an exact integer below 2^14, so the reference's own
-// sequence of f32 additions yields the same numbers.
-PIXO_DEV void aan8_shift(float dc_shift, float &d0, float &d1, float &d2, float &d3, float &d4,
-                         float &d5, float &d6, float &d7)
-{
-    float t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
-    float t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
-    aan8_core(t0, t1, t2, t3, t4, t5, t6, t7, dc_shift, d0, d1, d2, d3, d4, d5, d6, d7);
-}
+// the scale factors that close each pass (dct.rs:689-699)
+#define PIXO_S0 0.3535534f
+#define PIXO_S1 0.2548978f
+#define PIXO_S2 0.2705981f
+#define PIXO_S3 0.3006724f
+#define PIXO_S4 0.3535534f
+#define PIXO_S5 0.4499881f
+#define PIXO_S6 0.6532815f
+#define PIXO_S7 1.2814578f
 
 // Quantise one row of 8 coefficients.
 // Reference: (x / q).round() as i16 with IEEE f32 divide and round-half-away.
@@ -797,8 +826,8 @@ PIXO_DEV void quant_row8(const float *x, const QPair *r, qtab_t q, float scale, 
 
 // Block kinds (wave-uniform): quantiser table, DC shift of the row pass, scale.
 //   luminance, chroma 4:4:4   samples b, level shift 128     row DC shift 8*128 = 1024
-//   chroma 4:2:0 (U16)        2x2 sums S = 4*mean, transform at 4x scale:
-//                             mean - 128 = (S - 512)/4       row DC shift 8*512 = 4096
+//   chroma 4:2:0 (U16)        complemented 2x2 sums S' = 1020 - S, S = 4*mean; transform at -4x scale:
+//                             mean - 128 = (S - 512)/4 = -(S' - 508)/4      row DC shift 8*508 = 4064, scale -1/4
 // `src` points at this lane's first planar row; rows are `pitch` bytes apart and are read from
 // LDS as the row pass needs them (2-4 registers), not staged in 16-32 registers.
 template <bool U16>
@@ -814,77 +843,49 @@ PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v
         else raw8[r] = *(const u32x2 *)(src + r * pitch);
     }
     PIXO_SCHED_FENCE();
+    // Round 5: the row pass on PAIRS of rows — 35 packed instructions + 16 plain multiplications per row pair where two
+    // scalar transforms took 86 (7.67 M -> 6.8 M vector instructions per 4096x4096 launch).
+    const pixo_cf2 shift2 = {dc_shift, dc_shift};
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        if (U16) row_from_u16(raw16[r], &v[r * 8]);
-        else row_from_bytes(raw8[r].x, raw8[r].y, &v[r * 8]);
-        aan8_shift(dc_shift, v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4],
-                   v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7]);
-        if (r & 1) {
-            // finish both rows (scale multiplications included) before the next pair starts:
-            // left free, the compiler batches all 64 scale multiplications after row 7 into
-            // fresh registers
+    for (int r = 0; r < 8; r += 2) {
+        pixo_cf2 d[8], o[8];
+        if (U16) rows2_from_u16(raw16[r], raw16[r + 1], d);
+        else rows2_from_bytes(raw8[r], raw8[r + 1], d);
+        aan8_pair<true>(shift2, d, o);
+        float *lo = &v[r * 8], *hi = &v[r * 8 + 8];
+        lo[0] = o[0].x * PIXO_S0; hi[0] = o[0].y * PIXO_S0; lo[1] = o[1].x * PIXO_S1; hi[1] = o[1].y * PIXO_S1;
+        lo[2] = o[2].x * PIXO_S2; hi[2] = o[2].y * PIXO_S2; lo[3] = o[3].x * PIXO_S3; hi[3] = o[3].y * PIXO_S3;
+        lo[4] = o[4].x * PIXO_S4; hi[4] = o[4].y * PIXO_S4; lo[5] = o[5].x * PIXO_S5; hi[5] = o[5].y * PIXO_S5;
+        lo[6] = o[6].x * PIXO_S6; hi[6] = o[6].y * PIXO_S6; lo[7] = o[7].x * PIXO_S7; hi[7] = o[7].y * PIXO_S7;
+        // finish both rows (scale multiplications included) before the next pair starts: left free, the compiler
+        // batches all 64 scale multiplications after row 7 into fresh registers
 #pragma unroll
-            for (int i = 0; i < 16; i++) PIXO_PIN(v[(r - 1) * 8 + i]);
-            PIXO_SCHED_FENCE();
-        }
+        for (int i = 0; i < 16; i++) PIXO_PIN(v[r * 8 + i]);
+        PIXO_SCHED_FENCE();
     }
 }
 
-#if !defined(PIXO_EMU) && !defined(PIXO_SCALAR_COLS) // (PIXO_SCALAR_COLS: A/B builds, tools/ab_build.sh)
 // The column pass on PAIRS of neighbouring columns (round 4): v[8 r + 2 k], v[8 r + 2 k + 1] as one aligned register
-// pair, the same operation sequence as aan8 on both halves at once (v_pk_add_f32 / v_pk_mul_f32: IEEE per lane, no
-// contraction) — 42 packed instructions per column pair where two scalar transforms take 84 at 0.6 of the packed
-// instruction's issue cost each (profiles/r03_ubench_form_rate.txt: 2.67 against 4.37 cycles): 8.70 M -> 8.19 M vector
-// instructions per 4096x4096 launch.  Measured (profiles/r04_ab_packed_cols.txt): 4:4:4 30.5 -> 30.0 us, the 64-image batch
-// 139.1 -> 137.9 us — the issue-bound launches —, one 4:2:0 image unchanged (18.1-18.3 either way).  The row pass stays scalar
-// and simply leaves its outputs in the pairs' halves; the quantiser already wants neighbouring coefficients as pairs.
-typedef float pixo_cf2 __attribute__((ext_vector_type(2)));
-PIXO_DEV void aan8_cols2(pixo_cf2 &d0, pixo_cf2 &d1, pixo_cf2 &d2, pixo_cf2 &d3, pixo_cf2 &d4, pixo_cf2 &d5, pixo_cf2 &d6, pixo_cf2 &d7)
-{
-    const pixo_cf2 t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
-    const pixo_cf2 t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
-    const pixo_cf2 e0 = t0 + t3, e3 = t0 - t3, e1 = t1 + t2, e2 = t1 - t2;
-    const pixo_cf2 r0 = e0 + e1, r4 = e0 - e1;
-    const pixo_cf2 z1 = (e2 + e3) * PIXO_A1;
-    const pixo_cf2 r2 = e3 + z1, r6 = e3 - z1;
-    const pixo_cf2 o0 = t4 + t5, o1 = t5 + t6, o2 = t6 + t7;
-    const pixo_cf2 z5 = (o0 - o2) * PIXO_A5;
-    const pixo_cf2 z2 = o0 * PIXO_A2 + z5;
-    const pixo_cf2 z4 = o2 * PIXO_A4 + z5;
-    const pixo_cf2 z3 = o1 * PIXO_A1;
-    const pixo_cf2 z11 = t7 + z3, z13 = t7 - z3;
-    const pixo_cf2 r5 = z13 + z2, r3 = z13 - z2, r1 = z11 + z4, r7 = z11 - z4;
-    d0 = r0 * 0.3535534f; d1 = r1 * 0.2548978f; d2 = r2 * 0.2705981f; d3 = r3 * 0.3006724f;
-    d4 = r4 * 0.3535534f; d5 = r5 * 0.4499881f; d6 = r6 * 0.6532815f; d7 = r7 * 1.2814578f;
-}
+// pair — 43 packed instructions per column pair where two scalar transforms take 86 at 0.6 of the packed instruction's
+// issue cost each (profiles/r03_ubench_form_rate.txt: 2.67 against 4.37 cycles).  Measured (profiles/r04_ab_packed_cols.txt):
+// 4:4:4 30.5 -> 30.0 us, the 64-image batch 139.1 -> 137.9 us — the issue-bound launches —, one 4:2:0 image unchanged.
 PIXO_DEV void block_cols(float *v)
 {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        pixo_cf2 d[8];
+        pixo_cf2 d[8], o[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) { d[r] = (pixo_cf2){v[8 * r + 2 * k], v[8 * r + 2 * k + 1]}; asm volatile("" : "+v"(d[r])); }
-        aan8_cols2(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+        for (int r = 0; r < 8; r++) { d[r] = (pixo_cf2){v[8 * r + 2 * k], v[8 * r + 2 * k + 1]}; PIXO_PIN2(d[r]); }
+        aan8_pair<false>((pixo_cf2){0.0f, 0.0f}, d, o);
+        o[0] = o[0] * PIXO_S0; o[1] = o[1] * PIXO_S1; o[2] = o[2] * PIXO_S2; o[3] = o[3] * PIXO_S3;
+        o[4] = o[4] * PIXO_S4; o[5] = o[5] * PIXO_S5; o[6] = o[6] * PIXO_S6; o[7] = o[7] * PIXO_S7;
 #pragma unroll
-        for (int r = 0; r < 8; r++) { asm volatile("" : "+v"(d[r])); v[8 * r + 2 * k] = d[r].x; v[8 * r + 2 * k + 1] = d[r].y; }
+        for (int r = 0; r < 8; r++) { PIXO_PIN2(o[r]); v[8 * r + 2 * k] = o[r].x; v[8 * r + 2 * k + 1] = o[r].y; }
         PIXO_SCHED_FENCE();
     }
 #pragma unroll
     for (int i = 0; i < 64; i++) PIXO_PIN(v[i]);
 }
-#else
-PIXO_DEV void block_cols(float *v)
-{
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        aan8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
-        if (c & 1) PIXO_SCHED_FENCE();
-    }
-#pragma unroll
-    for (int i = 0; i < 64; i++) PIXO_PIN(v[i]);
-}
-#endif
 
 // What the block of lane `lane` of consumer wave `wave` is, and where its planar rows start
 // (everything wave-uniform except src).
@@ -908,7 +909,7 @@ template <int MODE> PIXO_DEV BlockDesc block_desc(int wave, int lane, const uint
             d.pitch = kPitchHalf;
         } else {
             d.src = planar + 8704 + (lane >> 5) * 4096 + (lane & 31) * 16;
-            d.pitch = 512; d.u16 = true; d.rcp_off = 384; d.q_off = 192; d.dc_shift = 4096.0f; d.scale = 0.25f;
+            d.pitch = 512; d.u16 = true; d.rcp_off = 384; d.q_off = 192; d.dc_shift = kChromaSumShift; d.scale = kChromaSumScale;
         }
     } else if (MODE == M444) {
         if (wave >= 1) { d.rcp_off = 256; d.q_off = 192; }
@@ -920,7 +921,7 @@ template <int MODE> PIXO_DEV BlockDesc block_desc(int wave, int lane, const uint
 template <int MODE> PIXO_DEV void consumer_rows(int wave, int lane, const uint8_t *planar, float *v)
 {
     const BlockDesc d = block_desc<MODE>(wave, lane, planar);
-    if (MODE == M420 && d.u16) block_rows<true>(d.src, 512, 4096.0f, v);
+    if (MODE == M420 && d.u16) block_rows<true>(d.src, 512, kChromaSumShift, v);
     else block_rows<false>(d.src, d.pitch, d.dc_shift, v);
 }
 

@@ -35,9 +35,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# what a plain tiled copy with this kernel's 1:1 read/write mix reaches on the part (tools/ubench/tile_copy.hip,
-# profiles/r01_ubench_tile_copy.txt: 12- or 16-byte loads, whole-line non-temporal stores); read-only streams: ~6400
-COPY_CEILING_GBPS = 5770.0
 C4_SHA256 = "77cc6cb69a782693c46f2024ac57ebfdfb8411148fa3cef62698c727af36c70c"  # SURVEY §8c, made by the reference
 
 WORKLOADS = {
@@ -219,9 +216,9 @@ def block_stats(walls, steps):
 # ------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(w, h, ss, quality, budget_s):
     """The oracle (C restatement, gcc -O2 -ffp-contract=off, OpenMP over MCU rows) timed on this host's cores on the same
-    4096x4096 image, coefficient stage only (the work the GPU kernel does).  `value` = the SUSTAINED rate of the bounded
-    sample at the thread count a short probe found fastest on this box (cgroup quotas make "all logical CPUs" slower than
-    fewer threads); the probe's single runs and the best / median / worst repetition are listed for information only."""
+    4096x4096 image, coefficient stage only (the work the GPU kernel does).  `value` = the median of separated single runs
+    at the thread count a short probe found fastest on this box (cgroup quotas make "all logical CPUs" slower than fewer
+    threads); `value_1_thread` beside it; a back-to-back burst only as a note."""
     import oracle_lib as O
     import synth
     px = synth.noise(w, h, 42)
@@ -242,25 +239,32 @@ def cpu_baseline(w, h, ss, quality, budget_s):
         tried[th] = round(w * h / min(dts) / 1e6, 1)
         if best_dt is None or min(dts) < best_dt:
             best_dt, cores = min(dts), th
-    reps = max(5, min(60, int(budget_s / max(best_dt, 1e-3))))
-    dts = []
-    t_all = time.perf_counter()
-    for _ in range(reps):
+    # `value` = the MEDIAN of single runs at that thread count, each behind a pause: the boxes run under a cgroup CPU quota,
+    # a back-to-back burst spends the quota's accumulated budget in its first repetitions and is throttled for the rest —
+    # its sustained rate measured the quota, not the cores, and moved from round to round (702 -> 272 Mpixels/s for the
+    # same code).  Separated runs each start with a refilled budget: comparable from run to run.  The burst stays as a note.
+    pause = 0.5
+    n_single = max(5, min(15, int(budget_s / (pause + best_dt))))
+    singles = []
+    for _ in range(n_single):
+        time.sleep(pause)
         t0 = time.perf_counter()
         O.coeffs(px, w, h, 2, ss, quality, threads=cores)
-        dts.append(time.perf_counter() - t0)
+        singles.append(time.perf_counter() - t0)
+    singles.sort()
+    reps = 8
+    t_all = time.perf_counter()
+    for _ in range(reps):
+        O.coeffs(px, w, h, 2, ss, quality, threads=cores)
     t_all = time.perf_counter() - t_all
-    dts.sort()
-    # the boxes run under a cgroup CPU quota: single repetitions swing between "all cores" and "throttled"; the figure that
-    # describes the host is the SUSTAINED rate = all pixels of the sample / its wall time
-    out = {"value": round(reps * w * h / t_all / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-           "value_is": "sustained rate: %d repetitions back to back at %d threads in %.1f s (cgroup CPU quota included)" % (reps, cores, t_all),
-           "median_repetition_Mpx_s": round(w * h / statistics.median(dts) / 1e6, 2),
-           "best_repetition_Mpx_s": round(w * h / dts[0] / 1e6, 2), "worst_repetition_Mpx_s": round(w * h / dts[-1] / 1e6, 2),
+    out = {"value": round(w * h / statistics.median(singles) / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+           "value_is": "median of %d single runs at %d threads, %.1f s apart" % (n_single, cores, pause),
+           "best_single_run_Mpx_s": round(w * h / singles[0] / 1e6, 2), "worst_single_run_Mpx_s": round(w * h / singles[-1] / 1e6, 2),
+           "note_burst_of_%d_back_to_back_Mpx_s" % reps: round(reps * w * h / t_all / 1e6, 2),
            "logical_cpus": avail, "probe_single_runs_Mpx_s_by_threads": tried,
            "sample": "%d x (%dx%d RGB8 noise seed 42, q=%d, %s) coefficient stage (colour+DCT+quant) "
                      "by oracle/pixo_oracle.c, gcc -O2 -ffp-contract=off, OpenMP %d threads over MCU rows"
-                     % (reps, w, h, quality, "4:2:0" if ss else "4:4:4", cores)}
+                     % (n_single, w, h, quality, "4:2:0" if ss else "4:4:4", cores)}
     t0 = time.perf_counter()  # the reference's baseline encode_scan is single-threaded
     O.coeffs(px, w, h, 2, ss, quality, threads=1)
     out["value_1_thread"] = round(w * h / (time.perf_counter() - t0) / 1e6, 2)
@@ -387,20 +391,41 @@ class CoeffWorkload:
         if not (np.array_equal(gy, oy) and np.array_equal(gcb, ocb) and np.array_equal(gcr, ocr)):
             raise SystemExit("bench: GPU coefficients differ from the oracle — refusing to report a number")
 
-    def roofline(self, kernel_ms):
+    def roofline(self, kernel_ms, copy_ms=None):
         alg = self.in_bytes + self.out_bytes  # 3 B/px read + 3 B/px written (4:2:0); 3 + 6 for 4:4:4
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         traffic, src = traffic_of(self.name)
         issue = issue_of(self.name, kernel_ms * 1e3)
-        # (`bound` stays "hbm" for the coefficient kernels — the metric BASELINE.json names is the HBM fraction —; `binding`
-        # says which of the two rooflines is the nearer one)
-        return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src, **issue,
-                "binding": bound_of(achieved / HBM_PEAK_GBPS, issue),
-                "kernel": "jpeg_coeffs_kernel<%s, %s>" % ("M420" if self.ss else "M444", "L_FUNNEL" if self.w * 3 % 4 else "L_ALIGNED"),
-                "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3),
-                "read_only_frac_of_peak": round(self.in_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "frac_of_measured_copy_ceiling_5770": round(achieved / COPY_CEILING_GBPS, 4)}
+        # `bound` is COMPUTED: the larger of the two fractions of this run (HBM bytes against 8 TB/s, vector instructions
+        # against what 1,024 SIMDs issue) names the roofline that binds
+        r = {"bound": bound_of(achieved / HBM_PEAK_GBPS, issue), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src, **issue,
+             "kernel": "jpeg_coeffs_kernel<%s, %s>" % ("M420" if self.ss else "M444", "L_FUNNEL" if self.w * 3 % 4 else "L_ALIGNED"),
+             "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3),
+             "read_only_frac_of_peak": round(self.in_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        if copy_ms:
+            # the plain copy of the same bytes in the same launch shape, timed in THIS run by the same block protocol
+            # (pixo_hip_debug_stream_copy): what the memory system of this box, at this moment, gives 50 MB in + 50 MB out
+            r["copy_us_same_run"] = round(copy_ms * 1e3, 3)
+            r["copy_GBps_same_run"] = round(alg / (copy_ms * 1e-3) / 1e9, 1)
+            r["copy_frac_of_peak_same_run"] = round(alg / (copy_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+            r["kernel_over_copy_same_run"] = round(kernel_ms / copy_ms, 4)
+            r["frac_of_copy_same_run"] = round(copy_ms / kernel_ms, 4)
+        return r
+
+    def copy_step_factory(self):
+        """A plain copy of this workload's bytes (4:2:0: as many out as in) over the same rotating input buffers."""
+        if self.in_bytes != self.out_bytes or self.in_bytes % 24576:
+            return None
+        torch = self.job.torch
+        outs = [torch.empty(self.in_bytes, dtype=torch.uint8, device=self.job.dev) for _ in range(self.nbuf)]
+        jpeg, ins, n, nb, stream = self.jpeg, self.ins, self.in_bytes, self.nbuf, self.stream
+
+        def step(i):
+            k = i % nb
+            jpeg.debug_stream_copy(ins[k], outs[k], n, stream=stream)
+        step.outs = outs
+        return step
 
 
 QUICK_SETTLE_MS = 60.0  # the extras run behind host-bound phases (allocations, uploads, the oracle check): the clocks have dropped
@@ -417,7 +442,7 @@ def quick_kernel(job, name, q, steps=200, blocks=7):
     kernel_ms = statistics.median(evs) / steps
     r = wl.roofline(kernel_ms)
     out = {"workload": wl.label, "kernel_us": r["kernel_us_avg"], "Mpixels_per_s": round(wl.w * wl.h * wl.batch / kernel_ms / 1e3, 1),
-           "achieved_GBps": r["achieved"], "frac": r["frac"], "bound": r["binding"], "steps": steps, "blocks": blocks, "settle_ms": QUICK_SETTLE_MS}
+           "achieved_GBps": r["achieved"], "frac": r["frac"], "bound": r["bound"], "steps": steps, "blocks": blocks, "settle_ms": QUICK_SETTLE_MS}
     for key in ("frac_issue", "valu_insts_per_launch", "issue_source"):
         if key in r:
             out[key] = r[key]
@@ -447,6 +472,21 @@ def run_coeffs(job, args):
     wl = CoeffWorkload(job, args.workload, args.quality)
     settled = job.settle(wl.step, 0 if job.stub else args.settle_ms)
     walls, evs = job.time_blocks(wl.step, args.steps, args.warmup, args.blocks)
+    copy_ms = None
+    if job.rank == 0 and not job.stub and job.world == 1 and wl.batch == 1:
+        # right behind the metric's blocks, same clocks, same protocol: the plain copy of the kernel's bytes; then the
+        # kernel once more, so that the pair (kernel, copy) is also available in the order copy -> kernel
+        try:
+            cstep = wl.copy_step_factory()
+            if cstep is not None:
+                _, cevs = job.time_blocks(cstep, args.steps, min(args.warmup, 20), args.blocks)
+                copy_ms = statistics.median(cevs) / args.steps
+                _, kevs2 = job.time_blocks(wl.step, args.steps, min(args.warmup, 20), max(3, args.blocks // 3))
+                kernel_after_copy_ms = statistics.median(kevs2) / args.steps
+                del cstep
+        except BaseException as ex:  # the metric must not depend on the comparison
+            copy_ms = None
+            sys.stderr.write("bench: same-run copy failed: %r\n" % (ex,))
     if job.rank == 0 and not job.stub and not os.environ.get("PIXO_BENCH_ABLATION"):
         wl.check()
     multi = (not args.no_extras) and args.workload == "c2" and not os.environ.get("PIXO_BENCH_ABLATION")
@@ -478,8 +518,10 @@ def run_coeffs(job, args):
                    "settle_launches_before_warmup": settled,
                    "timing": "median of %d blocks of %d steps, each block barrier+synchronize bracketed, max over ranks" % (st["blocks"], args.steps),
                    "parallelism": "one process per GPU, images sharded across ranks, no collective"},
-        "roofline": wl.roofline(kernel_ms),
+        "roofline": wl.roofline(kernel_ms, copy_ms),
     }
+    if copy_ms:
+        line["roofline"]["kernel_us_after_copy"] = round(kernel_after_copy_ms * 1e3, 3)
     if evs:
         per = sorted(e / args.steps * 1e3 for e in evs)
         line["roofline"]["kernel_us_block_min"], line["roofline"]["kernel_us_block_max"] = round(per[0], 3), round(per[-1], 3)
@@ -688,9 +730,9 @@ def run_png(job, args):
             "config": {"workload": "configs[4]: 4096x4096 RGBA8, FilterStrategy::Adaptive, rows independent", "width": wl.w, "height": wl.h,
                        "buffers_rotated": wl.nbuf, "settle_launches_before_warmup": settled,
                        "parallelism": "one process per GPU, images sharded across ranks, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": bound_of(achieved / HBM_PEAK_GBPS, issue_of("c5", kernel_ms * 1e3)), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src,
-                         **issue_of("c5", kernel_ms * 1e3), "binding": bound_of(achieved / HBM_PEAK_GBPS, issue_of("c5", kernel_ms * 1e3)),
+                         **issue_of("c5", kernel_ms * 1e3),
                          "kernel": "png_filter_kernel<4, true>", "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3)}}
     if not args.no_cpu_baseline and job.world == 1:
         import oracle_lib as O

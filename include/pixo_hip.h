@@ -341,6 +341,12 @@ int pixo_hip_debug_configure(const char *switches_or_null);
 /* How often a single-pass entropy kernel gave up waiting (its waits on other workgroups are bounded) and the scan was
  * coded again by the multi-pass kernels, in this process.  0 in normal operation. */
 uint64_t pixo_hip_debug_lookback_fallbacks(void);
+/* MEASUREMENT only (bench.py, tools/ab_binaries.py): a plain copy of `bytes` bytes of device memory in the coefficient
+ * kernel's launch shape — one generation of 192-thread workgroups, 24 KiB each, 8 non-temporal 16-byte loads then 8
+ * non-temporal stores per thread, no arithmetic (pixo_amd/csrc/stream_copy.hip) — so that a run can report what the
+ * memory system of THIS box gives the kernel's 50 MB + 50 MB beside the kernel's own time.  Replaces nothing of the
+ * reference.  `bytes` must be a multiple of 24576, the pointers 16-byte aligned; asynchronous on `stream`. */
+int pixo_hip_debug_stream_copy(const void *d_in, void *d_out, size_t bytes, void *stream);
 /* Releases a buffer the library returned.  Blocks of 24 MiB and more are kept (at most two, 1 GiB) for the next large
  * file instead of going back to the system — their pages are resident, a fresh block of that size costs more than the
  * encode (profiles/r03_fresh_pages.txt); pixo_hip_trim() returns them. */

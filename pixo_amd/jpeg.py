@@ -393,6 +393,15 @@ def encode_batch_device_into(arena, d_pixels, options: JpegOptions, batch: int):
     return list(offsets), list(lens)
 
 
+def debug_stream_copy(d_in, d_out, nbytes, stream=0):
+    """MEASUREMENT only (`pixo_hip_debug_stream_copy`): a plain device copy in the coefficient kernel's launch shape."""
+    def ptr(x):
+        return x.data_ptr() if hasattr(x, "data_ptr") else int(x)
+    rc = _lib.load().pixo_hip_debug_stream_copy(ptr(d_in), ptr(d_out), int(nbytes), C.c_void_p(stream) if stream else None)
+    if rc:
+        _raise(rc)
+
+
 def lookback_fallbacks() -> int:
     """How often a single-pass entropy kernel gave up waiting and the multi-pass kernels coded the scan instead (tests)."""
     return int(_lib.load().pixo_hip_debug_lookback_fallbacks())

@@ -77,7 +77,8 @@ recipe_issue() {
   rm -rf "/tmp/issue_$name"
   (cd /tmp && timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "/tmp/issue_$name" -o pmc -- "$@" > "$ROOT/$O/issue_${name}.log" 2>&1)
   f=$(find "/tmp/issue_$name" -name "*counter_collection*" | head -1)
-  if [ -n "$f" ]; then python "$ROOT/tools/issue_profile.py" "$f" "$filt" "$O/issue_$name.json" "$name"; else tail -5 "$O/issue_${name}.log"; fi
+  # (the raw counter rows of the kernels matching the filter travel with the summary: profiles/issue_<name>_raw.csv)
+  if [ -n "$f" ]; then python "$ROOT/tools/issue_profile.py" "$f" "$filt" "$O/issue_$name.json" "$name"; (head -1 "$f"; grep -F "$filt" "$f") > "$O/issue_${name}_raw.csv"; else tail -5 "$O/issue_${name}.log"; fi
 }
 recipe_py() { timeout 900 python "$@" 2>&1 | tail -60; }
 

@@ -25,6 +25,7 @@
 #include "jpeg_entropy.hpp"
 #include "jpeg_host.hpp"
 #include "jpeg_kernels.hpp"
+#include "jpeg_pixels_code.hpp"
 #include "jpeg_scan_block.h" // (the table form of the flat walk: built on the host, see upload_scan_tables)
 
 namespace pixo_capi {
@@ -51,6 +52,7 @@ int hip_fail(hipError_t e, const char *what); // pixo::Error::CompressionError(S
 //   direct_stores      the stuffing kernel stores straight into pinned host memory instead of HBM + copy, for files of every size
 //   no_direct_small    ... and never, not even for small files (their default since round 4)
 //   one_piece          never code a scan in pieces
+//   two_kernel_scan    never use the fused pixel -> bit stream kernel (jpeg_pixels_code.hip): coefficient kernel + scan_code as in rounds 2-4
 //   piece_groups=n     equal pieces of n groups of 192 blocks instead of 2048
 //   piece_medium=n     growing pieces from n groups on instead of 1024, whatever the last file's size
 //   piece_schedule=a:b:c   their relative sizes (default 1:3)
@@ -62,7 +64,7 @@ int hip_fail(hipError_t e, const char *what); // pixo::Error::CompressionError(S
 //                      caller's or the library's memory.  Costs what profiles/r03_fresh_pages.txt shows for files of 24 MiB and more.
 struct DebugSwitches {
     bool trace = false, host_entropy = false, multipass_entropy = false, direct_stores = false, one_piece = false;
-    bool piece_medium_forced = false, no_bands_upload = false, plain_host = false, no_direct_small = false;
+    bool piece_medium_forced = false, no_bands_upload = false, plain_host = false, no_direct_small = false, two_kernel_scan = false;
     // host pixels are uploaded in bands from this many MiB of pixels on (bands_upload_min_mb=n), in bands of about
     // bands_upload_mb=n MiB.  A 4096x4096 RGB image (48 MiB) in six bands of 8 MiB: noise 1.18 -> 1.14 ms into caller storage,
     // but a smooth image 0.99 -> 1.10 ms and the malloc'ing entry 1.43 -> 1.55: not below 96 MiB (profiles/r03_host_bands_probe.txt)
@@ -245,6 +247,7 @@ struct ScanJob {
     uint32_t seg_gap = 0;    // set BEFORE scan_begin: bytes a batch wants left free between its images' scans in c.e_out
                              // (headers + EOI: the whole batch then leaves the device in one copy); honoured only by segmented jobs
     size_t stream_cap = 0;   // fused: bytes the packed stream can take at most
+    size_t code_state_words = 0; // fused: u64 words of c.e_code_state the code kernel of this job uses (the stuffing kernel zeroes them again)
 };
 // A step of a job returns this when a single-pass kernel gave up waiting (bounded look-back, jpeg_scan_fused.hip): nothing of
 // the job's results is valid; run the job again inside a RetryMultipass scope, which makes scan_begin choose the multi-pass
@@ -273,6 +276,11 @@ int scan_count(Context &c, ScanJob &j, hipStream_t stream, uint64_t counts[pixo_
 int scan_tables(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream, const uint64_t *counts);
 int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
                  const uint64_t *counts, bool wait = true);
+// The fused pixel -> bit stream kernel (jpeg_pixels_code.hip) in place of coefficient kernel + scan_code for this job?  (one
+// RGB image, one uninterrupted scan, tables known without the tuple's statistics)
+bool pixels_code_usable(const ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, uint32_t batch);
+// ... tables + that kernel, chained with the stuffing kernel like scan_lengths(wait = false); no tuple is written
+int scan_code_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream, const void *d_pixels);
 int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offset, uint32_t *head, int *tail_bits,
                      uint32_t *tail, bool chained = false, HostTarget *host = nullptr);
 int scan_pack(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offset = 0, uint32_t *head = nullptr,

@@ -66,6 +66,7 @@ DebugSwitches parse_switches(const char *e)
         else if (name == "no_bands_upload") v.no_bands_upload = true;
         else if (name == "plain_host") v.plain_host = true;
         else if (name == "no_direct_small") v.no_direct_small = true;
+        else if (name == "two_kernel_scan") v.two_kernel_scan = true;
         else if (name == "bands_upload_min_mb" && num > 0) v.bands_upload_min_mb = static_cast<uint32_t>(num);
         else if (name == "bands_upload_mb" && num > 0) v.bands_upload_mb = static_cast<uint32_t>(num);
         else if (name == "piece_groups" && num > 0) v.piece_groups = static_cast<uint64_t>(num);

@@ -251,15 +251,9 @@ template <class Sink> PIXO_SDEV void put_symbol(FlatPack<Sink> &p, uint32_t t, u
     p.put_left((t & 0xFFFF0000u) | (value_left >> (t & 0xFFu)), ((t >> 8) & 0xFFu) - m);
 }
 
-// `wtab`: this class's kWalkClassWords words.
-template <class Sink> PIXO_SDEV void block_pack_flat(const uint32_t *w, int prev_dc, const uint32_t *wtab, FlatPack<Sink> &p)
+// The AC part of a block (positions 1..63 and the end-of-block code).  `wtab`: this class's kWalkClassWords words.
+template <class Sink> PIXO_SDEV void block_pack_flat_ac(const uint32_t *w, const uint32_t *wtab, FlatPack<Sink> &p)
 {
-    {
-        const int diff = (int)(int16_t)(coef_of(w, 0) - prev_dc); // i16 arithmetic like the reference
-        const int u = diff + (diff >> 31);
-        const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u;
-        put_symbol(p, wtab[m & 15u], (uint32_t)u, m);
-    }
     const uint32_t zrl = wtab[kWalkZrl], eob = wtab[kWalkEob];
     uint32_t run16 = 0; // 16 x the zeros since the last non-zero coefficient
 #pragma unroll
@@ -283,6 +277,33 @@ template <class Sink> PIXO_SDEV void block_pack_flat(const uint32_t *w, int prev
         run16 = nz ? 0u : run16 + 16u;
     }
     p.put_left(run16 ? (eob & 0xFFFF0000u) : 0u, run16 ? (eob & 0xFFu) : 0u);
+}
+// The DC symbol of a block as bits at the top of a word (encode_block's first step, huffman.rs:430-437): `left` holds the
+// Huffman code followed by the value bits, `len` <= 27 of them.  For a walk whose DC predictor arrives late (the fused
+// pixel -> bit stream kernel): the AC part is coded first, from bit 0, and this is placed in front of it afterwards.
+struct DcBits { uint32_t left, len; };
+PIXO_SDEV DcBits dc_symbol_bits(int dc, int prev_dc, const uint32_t *wtab)
+{
+    const int diff = (int)(int16_t)(dc - prev_dc); // i16 arithmetic like the reference
+    const int u = diff + (diff >> 31);
+    const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u;
+    const uint32_t t = wtab[m & 15u];
+    const uint32_t value_left = (uint32_t)u << (m & 31u);
+    DcBits b;
+    b.left = (t & 0xFFFF0000u) | (value_left >> (t & 0xFFu));
+    b.len = ((t >> 8) & 0xFFu) - m;
+    return b;
+}
+// A whole block: the DC symbol, then the AC part.
+template <class Sink> PIXO_SDEV void block_pack_flat(const uint32_t *w, int prev_dc, const uint32_t *wtab, FlatPack<Sink> &p)
+{
+    {
+        const int diff = (int)(int16_t)(coef_of(w, 0) - prev_dc); // i16 arithmetic like the reference
+        const int u = diff + (diff >> 31);
+        const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u;
+        put_symbol(p, wtab[m & 15u], (uint32_t)u, m);
+    }
+    block_pack_flat_ac(w, wtab, p);
 }
 
 // Symbol statistics with the same walk (count_block, jpeg/mod.rs:826-860): `Bump` provides bump(slot, on, amount) —

@@ -372,7 +372,12 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
     // known — 64 bytes per block, cut to size afterwards — and a block of a new size is new pages every call, which the
     // device-to-host copy has to fault in and pin: 20 ms instead of 0.7 for the 4096x4096 noise image.  One piece, the
     // exact size, recycled by malloc.)
-    if (j.fused && !j.segmented && batch == 1 && pieces_enabled() && !direct_host_stores() && (large || medium || host_bands) &&
+    // Round 5: pixels that have not been transformed yet go through the fused pixel -> bit stream kernel (jpeg_pixels_code.hip)
+    // where that kernel serves the job — one piece: the whole scan is coded ~50 us after the call began, which is where the
+    // first of a medium scan's pieces used to be.  Large scans and host pixels in bands keep the pieces (their PCIe time is
+    // what the pieces hide); their bands run coefficient kernel + scan_code as before.
+    const bool from_pixels = src && pixels_code_usable(j, o, g, batch);
+    if (j.fused && !j.segmented && batch == 1 && pieces_enabled() && !direct_host_stores() && (large || (medium && !from_pixels) || host_bands) &&
         (!dest || dest_cap >= likely_most) && (host_bands || !(own_malloc && !dest))) {
         PixelSource device_src; // (the same source once the pixels are on the device)
         if (src && o.optimize_huffman) { // (the statistics need the whole tuple)
@@ -418,10 +423,15 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
         c.code_state_zero_words = 0; // (rc == 1: start over in one piece, below)
     }
     if ((rc = upload_all())) return rc;
-    if (src && (rc = coeffs_rows(c, src->d_px, o, g, stream, src->dy, src->dcb, src->dcr, 0, 0))) return rc; // one piece: the whole image first
-    *tuple_done = true;
+    const bool fuse_now = from_pixels && src; // (src is null once a pieces attempt above has computed the tuple)
+    if (fuse_now) { // pixels -> packed stream in one kernel; the tuple is never written (a retry with the multi-pass kernels computes it)
+        if ((rc = scan_code_from_pixels(c, j, o, g, stream, src->d_px))) return rc;
+    } else {
+        if (src && (rc = coeffs_rows(c, src->d_px, o, g, stream, src->dy, src->dcb, src->dcr, 0, 0))) return rc; // one piece: the whole image first
+        *tuple_done = true;
+    }
     if (j.fused) { // code + stuff back to back, one read-back
-        if ((rc = scan_lengths(c, j, o, g, stream, nullptr, /*wait=*/false))) return rc;
+        if (!fuse_now && (rc = scan_lengths(c, j, o, g, stream, nullptr, /*wait=*/false))) return rc;
         // One image into host memory the GPU can write — the context's pinned file buffer, or storage of the caller's
         // that is pinned / registered: the stuffing kernel stores straight into it, behind the place of the headers.
         // Small files take that way by default: the stuffing kernel's stores ARE the transfer, and the call has one wait instead

@@ -173,6 +173,7 @@ int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, co
         const size_t state_words = pd::fused_code_state_words_seg(j.nseg, seg_blocks);
         if (state_words * 8 > c.e_code_state.cap) c.code_state_zero_words = 0; // (a new buffer)
         HIP_TRY(c.e_code_state.reserve(state_words * 8));
+        j.code_state_words = state_words;
         // every segment's last tile is partial: one tile more per segment than the bytes alone would need
         HIP_TRY(c.e_stuff_state.reserve((pd::fused_stuff_state_words(j.stream_cap) + j.nseg) * 8));
         HIP_TRY(c.e_segs.reserve((4 * j.nseg + 2) * 8));
@@ -193,6 +194,7 @@ int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, co
         HIP_TRY(c.e_stream.reserve(j.stream_cap));
         if (pd::fused_code_state_words(j.n) * 8 > c.e_code_state.cap) c.code_state_zero_words = 0; // (a new buffer)
         HIP_TRY(c.e_code_state.reserve(pd::fused_code_state_words(j.n) * 8));
+        j.code_state_words = pd::fused_code_state_words(j.n);
         HIP_TRY(c.e_stuff_state.reserve(pd::fused_stuff_state_words(j.stream_cap) * 8));
         { const int rc_t = c.ensure_totals(); if (rc_t) return rc_t; }
         a.tables = c.e_tables.as<uint32_t>();
@@ -312,6 +314,32 @@ int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_
     return PIXO_OK;
 }
 
+bool pixels_code_usable(const ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, uint32_t batch)
+{
+    return j.fused && !j.segmented && !j.band && batch == 1 && !g.gray && !o.optimize_huffman && !o.progressive && !debug().two_kernel_scan &&
+           pixo_dev::pixels_code_supported(o.width, o.height, g.gray);
+}
+
+int scan_code_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream, const void *d_pixels)
+{
+    namespace pd = pixo_dev;
+    int rc = scan_tables(c, j, o, g, stream, nullptr);
+    if (rc) return rc;
+    const float *qt_all = nullptr;
+    if ((rc = device_tables(c.device, &qt_all))) return rc;
+    const size_t words = pd::pixels_code_state_words(pd::pixels_code_groups(o.width, o.height, g.s420));
+    if (words * 8 > c.e_code_state.cap) c.code_state_zero_words = 0; // (a new buffer)
+    HIP_TRY(c.e_code_state.reserve(words * 8));
+    j.code_state_words = words;
+    const bool zero = c.code_state_zero_words >= words;
+    c.code_state_zero_words = 0; // (dirty from here until a stuffing launch has cleaned it)
+    HIP_TRY(pd::launch_pixels_code(d_pixels, o.width, o.height, g.s420, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c.e_tables.as<uint32_t>(),
+                                   c.e_code_state.as<unsigned long long>(), zero, c.e_stream.as<uint32_t>(), c.e_stuff_state.as<unsigned long long>(),
+                                   pd::fused_stuff_state_words(j.stream_cap), reinterpret_cast<unsigned long long *>(c.h_totals), nullptr, true, stream,
+                                   debug().spin_budget));
+    return PIXO_OK;
+}
+
 // The stuffing kernel of jpeg_scan_fused.hip over the packed stream (launch_scan_code has been enqueued; with
 // `chained` its length has not been read back yet): afterwards c.e_out holds j.scan_bytes finished bytes.  The output
 // buffer is sized from experience (grow-only) — the kernel never writes beyond it and says how much it needed.
@@ -392,11 +420,11 @@ int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_b
             out = c.e_out.as<uint8_t>();
             out_cap = c.e_out.cap;
         }
-        HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), pd::fused_code_state_words(j.n),
+        HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), j.code_state_words,
                                        shift, j.band, j.stream_cap, first_tile, tiles, c.e_stuff_state.as<unsigned long long>(),
                                        /*state_is_zero=*/chained && attempt == 0, out, out_cap,
                                        reinterpret_cast<unsigned long long *>(c.h_totals), stream, nullptr, 0, nullptr, debug().spin_budget));
-        c.code_state_zero_words = pd::fused_code_state_words(j.n);
+        c.code_state_zero_words = j.code_state_words;
         // (no read-back copies: both kernels store their totals into the pinned mailbox h_totals — [0] bits of the scan,
         // [1] stuffed bytes, [2] packed bytes — which the host reads after the synchronisation below)
         uint32_t edge[3] = {0, 0, 0}; // band: stream word 0 (head bits) and the two words around the tail bits

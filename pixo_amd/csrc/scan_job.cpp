@@ -518,3 +518,46 @@ int scan_pack(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offs
 }
 
 } // namespace pixo_capi
+
+// MEASUREMENT only (bench.py, tools/): the DEVICE work of one baseline file — pixels -> packed stream -> stuffed scan in the
+// context's device buffer — enqueued on the caller's stream and not waited for: K calls back to back between two events give
+// the device time per file without the call's host side (waits, the file's way over PCIe).  The kernels are the product's:
+// the fused pixel -> bit stream kernel where it serves the job (or, *form = 0, coefficient kernel + scan_code), then the
+// stuffing kernel on a grid sized like the product's first guess.  Nothing is delivered.
+extern "C" int pixo_hip_debug_scan_device_async(const void *d_pixels, const pixo_jpeg_options *options, void *stream_, int *form)
+{
+    using namespace pixo_capi;
+    namespace pd = pixo_dev;
+    PIXO_REQUIRE(d_pixels);
+    PIXO_REQUIRE(options);
+    std::string msg;
+    int rc = pixo_host::validate(*options, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    if (options->progressive || options->optimize_huffman) return fail(PIXO_ERR_COMPRESSION, "Compression error: pixo_hip_debug_scan_device_async measures baseline scans with standard tables");
+    Context *c = nullptr;
+    if ((rc = context_on_current_device(&c))) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const pixo_host::Geometry g = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
+    int16_t *dy, *dcb, *dcr;
+    if ((rc = coeffs_reserve(*c, g, &dy, &dcb, &dcr))) return rc;
+    ScanJob j;
+    if ((rc = scan_begin(*c, j, dy, dcb, dcr, *options, g, 1, nullptr))) return rc;
+    if (!j.fused || j.segmented) return fail(PIXO_ERR_COMPRESSION, "Compression error: not a single-pass scan");
+    const bool fused = pixels_code_usable(j, *options, g, 1);
+    if (form) *form = fused ? 1 : 0;
+    if (fused) {
+        if ((rc = scan_code_from_pixels(*c, j, *options, g, stream, d_pixels))) return rc;
+    } else {
+        if ((rc = coeffs_rows(*c, d_pixels, *options, g, stream, dy, dcb, dcr, 0, 0))) return rc;
+        if ((rc = scan_lengths(*c, j, *options, g, stream, nullptr, /*wait=*/false))) return rc;
+    }
+    const size_t want_cap = std::max<size_t>(j.stream_cap / 4, 4096);
+    HIP_TRY(c->e_out.reserve(want_cap));
+    const uint64_t tiles = pd::stuff_tiles(std::min<uint64_t>(j.stream_cap, j.n * 64 + 4096));
+    HIP_TRY(pd::launch_stuff_fused(c->e_stream.as<uint32_t>(), c->e_code_state.as<unsigned long long>(), j.code_state_words, 0, false, j.stream_cap, 0,
+                                   tiles, c->e_stuff_state.as<unsigned long long>(), /*state_is_zero=*/true, c->e_out.as<uint8_t>(), c->e_out.cap,
+                                   reinterpret_cast<unsigned long long *>(c->h_totals), stream, nullptr, 0, nullptr, debug().spin_budget));
+    c->code_state_zero_words = j.code_state_words;
+    return PIXO_OK;
+}
+

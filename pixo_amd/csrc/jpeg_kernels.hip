@@ -16,11 +16,6 @@
 namespace pixo_dev {
 using namespace pixo_tile;
 
-#if defined(PIXO_NO_DOT4) // (A/B builds: the packed multiply-add colour conversion everywhere)
-constexpr bool kDot4 = false;
-#else
-constexpr bool kDot4 = true;
-#endif
 
 // Kernel arguments.  The kernel takes the first 15 dwords as separate parameters, in this order, and is compiled with
 // -mllvm -amdgpu-kernarg-preload-count=14 (Makefile): the command processor hands them to every wavefront in SCALAR
@@ -34,9 +29,6 @@ struct KRest {
     size_t c_stride;
     float *ry, *rcb, *rcr;   // RAW kernels only: unquantised DCT blocks (64 f32 each) instead of y/cb/cr
     uint32_t units_x, units_y, fast;
-#if defined(PIXO_PROBE)
-    uint32_t probe_launch;   // timeline builds: which part of the probe buffer this launch stamps
-#endif
 };
 struct KArgs {
     const uint8_t *px;
@@ -49,9 +41,6 @@ struct KArgs {
     float *ry, *rcb, *rcr;
     uint32_t units_x, units_y, fast;
     uint32_t tiles_x, tiles_y, batch; // host only
-#if defined(PIXO_PROBE)
-    uint32_t probe_launch;
-#endif
 };
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, which would
@@ -63,26 +52,6 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-#if defined(PIXO_PROBE)
-// Timeline builds only (tools/ab_build.sh probe "-DPIXO_PROBE"; never the shipped library): every wavefront stores
-// kProbeSlots time stamps — the 100 MHz constant clock (s_memrealtime: the same counter on every XCD) — into a buffer the
-// host hands over with pixo_hip_debug_probe_buffer(); consecutive launches use consecutive parts of it (kProbeLaunches,
-// round robin), so that the overlap of back-to-back dispatches can be seen.  tools/probe_timeline.py prints the timeline.
-constexpr int kProbeSlots = 12, kProbeLaunches = 8;
-__device__ unsigned long long *g_probe = nullptr;
-__device__ unsigned g_probe_stride = 0; // u64 words per launch
-static unsigned g_probe_launch = 0;     // host: which part the next launch writes
-__device__ __forceinline__ void probe_stamp(uint32_t launch, int slot)
-{
-    unsigned long long *p = g_probe;
-    if (!p) return;
-    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-    if ((threadIdx.x & 63) == 0) p[(size_t)launch * g_probe_stride + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * kWaves + (threadIdx.x >> 6)) * kProbeSlots + slot] = t;
-}
-#define PIXO_STAMP(slot) probe_stamp(a.probe_launch, slot)
-#else
-#define PIXO_STAMP(slot) ((void)0)
-#endif
 
 // A tile is (image, tile column, tile row): three SGPRs.  The full TileCtx is rebuilt from the
 // kernel arguments where it is needed instead of being carried (three live copies of it cost
@@ -121,14 +90,11 @@ __device__ __forceinline__ void phase_a(const KArgs &a, const TileCtx &c, const 
     if (LOAD != L_BYTES) la = lane_addr<MODE>(c, id.tx, id.ty, lane); // (the byte gathers address every pixel by themselves)
 #pragma unroll
     for (int j = 0; j < COUNT; j++) producer_load_item<MODE, LOAD>(c, la, id.tx, id.ty, first + j, lane, &r[j * G::item_regs]);
-    PIXO_STAMP(2); // every load of the phase has been issued
 #pragma unroll
     for (int j = 0; j < COUNT; j++) {
         producer_fix_item<MODE, LOAD>(c, id.tx, first + j, lane, &r[j * G::item_regs]);
-        producer_color_item<MODE, kDot4 && LOAD != L_BYTES>(first + j, lane, &r[j * G::item_regs], lds);
-        if (j == 0) PIXO_STAMP(3); // the first item's pixels have arrived and are converted
+        producer_color_item<MODE, LOAD != L_BYTES>(first + j, lane, &r[j * G::item_regs], lds);
     }
-    PIXO_STAMP(4); // ... the last item's
 }
 
 // One tile per workgroup of THREE wavefronts.  Phase A: the wavefronts share the tile's items
@@ -192,17 +158,10 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
 {
     typedef Geo<MODE> G;
     __shared__ __attribute__((aligned(16))) uint8_t lds[G::planar];
-#if defined(PIXO_LDS_PAD) // (experiment: fewer workgroups per CU, so that a 4096x4096 launch runs in generations)
-    __shared__ uint8_t lds_pad[PIXO_LDS_PAD];
-    if (a_W == 0xFFFFFFFFu) lds_pad[threadIdx.x] = 1;
-#endif
     KArgs a;
     a.px = a_px; a.W = a_W; a.H = a_H; a.px_stride = a_px_stride; a.y = a_y; a.cb = a_cb; a.cr = a_cr; a.qt = a_qt;
     a.px_bytes = rest.px_bytes; a.y_stride = rest.y_stride; a.c_stride = rest.c_stride; a.ry = rest.ry; a.rcb = rest.rcb; a.rcr = rest.rcr;
     a.units_x = rest.units_x; a.units_y = rest.units_y; a.fast = rest.fast;
-#if defined(PIXO_PROBE)
-    a.probe_launch = rest.probe_launch;
-#endif
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // Phase A runs at raised wave priority: the hardware otherwise issues oldest-first, the colour
     // conversion of the younger workgroups waits behind the older ones' phase B, and few wavefronts
@@ -210,8 +169,6 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     // image (all workgroups resident at once), +10 % for 4:4:4 and for the 64-image batch (measured at
     // steady clocks, profiles/r01_ablation_steady_clocks.txt).
     __builtin_amdgcn_s_setprio(1);
-    PIXO_STAMP(0); // the wavefront runs
-#if !defined(PIXO_NO_STAGGER)
     // The chip holds 2048 of these workgroups at once (8 per CU): a 4096x4096 launch is ONE generation whose loads all
     // come first and whose stores all come last.  The second half of that generation (dispatch order 1024..2047) starts
     // one s_sleep (8128 clocks, ~3.4 us) late, so that its loads meet the first half's arithmetic and stores: 19.1 ->
@@ -228,13 +185,8 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
         if ((lin >> 10) == 1u) __builtin_amdgcn_s_sleep(127); // (a full first generation only; 112..160 units are a plateau, 96 or 200 lose most of it;
                                                                  //  quarters or thirds with graded delays are no better)
     }
-#endif
     const TileId id{blockIdx.z, blockIdx.x, blockIdx.y}; // (a 3-D grid: no division on the way to the first load)
     TileCtx c = ctx_in(a, id.img);
-#if defined(PIXO_PROBE)
-    { uint32_t seen = id.ty + c.W; asm volatile("" : "+s"(seen)); } // (the kernel arguments have arrived)
-    PIXO_STAMP(1);
-#endif
     constexpr int base = G::items / kWaves, extra = G::items % kWaves;
     const int first = (extra && wave < extra) ? wave * (base + 1) : extra * (base + 1) + (wave - extra) * base;
     if (extra && wave < extra) phase_a<MODE, LOAD, base + 1>(a, c, id, first, lane, lds);
@@ -246,11 +198,9 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
         asm volatile("" : "+s"(img)); // (keeps the output pointers' arithmetic behind the barrier)
         ctx_out(c, a, img);
     }
-    PIXO_STAMP(5); // barrier passed: phase B begins
     float v[64];
     consumer_rows<MODE>(wave, lane, lds, v);
     consumer_cols(v);
-    PIXO_STAMP(6); // transform done
     if (RAW) { // hand the transformed blocks to the trellis quantiser instead of quantising here
         store_raw_block<MODE>(a, c, id, wave, lane, v);
         return;
@@ -258,7 +208,6 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     uint8_t *stage = lds + stage_offset<MODE>(wave); // inside this wavefront's own planar area
     uint32_t qw[32];
     consumer_quant<MODE>(wave, lane, a.qt, v, qw);
-    PIXO_STAMP(7); // quantised: the first store is next
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         consumer_stage_blocks(lane, h, qw, stage);
@@ -266,11 +215,6 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
         consumer_store_blocks<MODE>(c, id.tx, id.ty, wave, lane, h, stage);
         consumer_stage_sync();
     }
-#if defined(PIXO_PROBE)
-    PIXO_STAMP(8); // last store issued
-    __builtin_amdgcn_s_waitcnt(0); // (vmcnt(0): the stores have been acknowledged)
-    PIXO_STAMP(9);
-#endif
 }
 
 template <int MODE, int LOAD> static hipError_t launch_mode(KArgs &a, hipStream_t s)
@@ -280,15 +224,9 @@ template <int MODE, int LOAD> static hipError_t launch_mode(KArgs &a, hipStream_
     a.tiles_y = (a.units_y * (MODE == M420 ? 16u : 8u) + Geo<MODE>::tile_h - 1) / Geo<MODE>::tile_h;
     if (a.tiles_y > 65535u || a.batch > 65535u) return hipErrorInvalidValue; // (grid y and z; heights and batches are at most 65535)
     const dim3 grid(a.tiles_x, a.tiles_y, a.batch); // workgroups are numbered x fastest: consecutive tiles of a row on consecutive XCDs
-#if defined(PIXO_PROBE)
-    a.probe_launch = g_probe_launch++ % kProbeLaunches;
-#endif
     KRest rest;
     rest.px_bytes = a.px_bytes; rest.y_stride = a.y_stride; rest.c_stride = a.c_stride; rest.ry = a.ry; rest.rcb = a.rcb; rest.rcr = a.rcr;
     rest.units_x = a.units_x; rest.units_y = a.units_y; rest.fast = a.fast;
-#if defined(PIXO_PROBE)
-    rest.probe_launch = a.probe_launch;
-#endif
     // tiles_x <= 128 (65535 / 512), tiles_y <= 8192 (65535 / 8)
     // (launches of 1280-1792 workgroups neither gain nor lose with it: tools/shape_timing.py, profiles/r03_stagger_length_ab.txt)
     const uint32_t a_grid = grid.x | (grid.y << 8) | ((uint64_t)grid.x * grid.y * grid.z >= 2048u ? 0x80000000u : 0u);
@@ -358,13 +296,3 @@ hipError_t launch_jpeg_coeffs(const void *d_px, uint32_t W, uint32_t H, bool gra
 
 } // namespace pixo_dev
 
-#if defined(PIXO_PROBE)
-extern "C" int pixo_hip_debug_probe_buffer(void *d_buffer, unsigned words_per_launch)
-{ // d_buffer: kProbeLaunches x words_per_launch u64 (a launch needs workgroups x 3 x kProbeSlots), or null to switch the stamps off
-    unsigned long long *p = static_cast<unsigned long long *>(d_buffer);
-    pixo_dev::g_probe_launch = 0;
-    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(pixo_dev::g_probe_stride), &words_per_launch, sizeof words_per_launch);
-    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(pixo_dev::g_probe), &p, sizeof p);
-    return (int)e;
-}
-#endif

@@ -251,7 +251,28 @@ template <class Sink> PIXO_SDEV void put_symbol(FlatPack<Sink> &p, uint32_t t, u
     p.put_left((t & 0xFFFF0000u) | (value_left >> (t & 0xFFu)), ((t >> 8) & 0xFFu) - m);
 }
 
+// One position of the AC walk, any run length.
+template <class Sink> PIXO_SDEV void walk_position(int k, int v, uint32_t &run16, uint32_t zrl, const uint32_t *wtab, FlatPack<Sink> &p, uint64_t nz_lanes)
+{
+    const bool nz = v != 0;
+    if (k > 16 && __builtin_expect((PIXO_BALLOT64(run16 >= 256u) & nz_lanes) != 0, 0)) { // rare: up to three ZRL codes in front of the symbol
+#pragma unroll
+        for (uint32_t i = 0; i < 3; i++) {
+            const bool on = nz && (run16 >> 8) > i;
+            p.put_left(on ? (zrl & 0xFFFF0000u) : 0u, on ? (zrl & 0xFFu) : 0u);
+        }
+        run16 = nz ? (run16 & 255u) : run16;
+    }
+    const int u = v + (v >> 31);
+    const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u; // v = 0: m = 32, slot 0 of its run = "nothing"
+    const uint32_t slot = (k > 16 ? (run16 & 255u) : run16) | (m & 15u); // (a lane without a coefficient here may be anywhere in a long run)
+    put_symbol(p, wtab[kWalkDc + slot], (uint32_t)u, m);
+    run16 = nz ? 0u : run16 + 16u;
+}
 // The AC part of a block (positions 1..63 and the end-of-block code).  `wtab`: this class's kWalkClassWords words.
+// (Round 5 also measured the positions in CHUNKS of 2 / 4 / 8 with the chunk's table words fetched from LDS together: the fused
+// kernel's device time per 4096x4096 file was the same within 1 us for noise, photo and gradient content — the table look-up's
+// latency is not what the walk waits for — profiles/r05_walk_chunks.txt; the simpler form stays.)
 template <class Sink> PIXO_SDEV void block_pack_flat_ac(const uint32_t *w, const uint32_t *wtab, FlatPack<Sink> &p)
 {
     const uint32_t zrl = wtab[kWalkZrl], eob = wtab[kWalkEob];
@@ -261,20 +282,7 @@ template <class Sink> PIXO_SDEV void block_pack_flat_ac(const uint32_t *w, const
         const int v = coef_of(w, zigzag(k));
         const uint64_t nz_lanes = PIXO_BALLOT64(v != 0);
         if (!nz_lanes) { run16 += 16u; continue; } // (wave-uniform on the device)
-        const bool nz = v != 0;
-        if (k > 16 && __builtin_expect((PIXO_BALLOT64(run16 >= 256u) & nz_lanes) != 0, 0)) { // rare: up to three ZRL codes in front of the symbol
-#pragma unroll
-            for (uint32_t i = 0; i < 3; i++) {
-                const bool on = nz && (run16 >> 8) > i;
-                p.put_left(on ? (zrl & 0xFFFF0000u) : 0u, on ? (zrl & 0xFFu) : 0u);
-            }
-            run16 = nz ? (run16 & 255u) : run16;
-        }
-        const int u = v + (v >> 31);
-        const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u; // v = 0: m = 32, slot 0 of its run = "nothing"
-        const uint32_t slot = (k > 16 ? (run16 & 255u) : run16) | (m & 15u); // (a lane without a coefficient here may be anywhere in a long run)
-        put_symbol(p, wtab[kWalkDc + slot], (uint32_t)u, m);
-        run16 = nz ? 0u : run16 + 16u;
+        walk_position(k, v, run16, zrl, wtab, p, nz_lanes);
     }
     p.put_left(run16 ? (eob & 0xFFFF0000u) : 0u, run16 ? (eob & 0xFFu) : 0u);
 }

@@ -426,7 +426,7 @@ PIXO_DEV uint32_t gather_row4_gray(const uint8_t *px, uint32_t W, uint32_t H, ui
 //
 // Pixels are read once: the loads are non-temporal (they do not displace the other workgroups'
 // lines in L2 / Infinity Cache on their way through).
-#if defined(PIXO_EMU) || defined(PIXO_PLAIN_LOADS) // (PIXO_PLAIN_LOADS: A/B builds, tools/ab_build.sh)
+#if defined(PIXO_EMU)
 #define PIXO_GLOAD(ptr) (*(ptr))
 #else
 #define PIXO_GLOAD(ptr) __builtin_nontemporal_load(ptr)

@@ -318,6 +318,19 @@ int pixo_hip_jpeg_band_piece_host(const int16_t *y, const int16_t *cb, const int
 int pixo_hip_jpeg_encode_multi(const uint8_t *data, size_t data_len, const pixo_jpeg_options *options,
                                const int *devices, uint32_t n_devices, uint8_t **out, size_t *out_len);
 
+/* A BATCH over `n_devices` GPUs of this process (configs[2] on a node, SURVEY §8e "C3 batch"): `batch` equally sized images
+ * back to back at `pixels` — memory of ANY of the process's GPUs (the images of the other GPUs' shares travel by peer copies,
+ * hipMemcpyPeer: one peer per xGMI link) or host memory (every GPU fetches its share over its own PCIe link).  devices[k]
+ * encodes images [batch k / n, batch (k + 1) / n) with pixo_hip_jpeg_encode_batch_device_into's one-pass kernels into its own
+ * HBM, the persistent worker threads of pixo_hip_jpeg_encode_multi exchange the file lengths in shared memory, and every GPU
+ * copies its run of finished files to their final place in `arena` (host memory, pinned for full speed) over its OWN PCIe
+ * link.  offsets / lens / capacity / PIXO_ERR_BUFFER_TOO_SMALL as pixo_hip_jpeg_encode_batch_device_into (a null arena with
+ * capacity 0 is a size query); a device may appear more than once.  Byte-identical to that entry on one GPU.
+ * Replaces a loop over pixo::jpeg::encode (src/jpeg/mod.rs:88) spread over the GPUs of a node. */
+int pixo_hip_jpeg_encode_batch_multi(const void *pixels, const pixo_jpeg_options *options, uint32_t batch,
+                                     const int *devices, uint32_t n_devices, uint8_t *arena, size_t capacity,
+                                     size_t *offsets, size_t *lens);
+
 /* ---- runtime ----------------------------------------------------------------------- */
 
 int pixo_hip_device_count(void);            /* 0 when no GPU / no driver              */

@@ -33,7 +33,7 @@ SYMBOLS = [
     "pixo_hip_band_encoder_coeffs", "pixo_hip_band_encoder_count", "pixo_hip_band_encoder_lengths",
     "pixo_hip_band_encoder_pack", "pixo_hip_band_encoder_pack_device", "pixo_hip_band_encoder_copy_body",
     "pixo_hip_jpeg_splice", "pixo_hip_jpeg_splice_layout", "pixo_hip_jpeg_splice_finish", "pixo_hip_jpeg_band_count_host",
-    "pixo_hip_jpeg_band_bits_host", "pixo_hip_jpeg_band_piece_host", "pixo_hip_jpeg_encode_multi",
+    "pixo_hip_jpeg_band_bits_host", "pixo_hip_jpeg_band_piece_host", "pixo_hip_jpeg_encode_multi", "pixo_hip_jpeg_encode_batch_multi",
     "pixo_hip_device_count", "pixo_hip_set_device", "pixo_hip_set_producer_stream", "pixo_hip_get_producer_stream", "pixo_hip_debug_configure", "pixo_hip_trim", "pixo_hip_free", "pixo_hip_copy_file",
     "pixo_hip_last_error", "pixo_hip_version",
 ]
@@ -125,6 +125,7 @@ def load():
     L.pixo_hip_jpeg_band_piece_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, optp, C.c_uint32, i16p, u64p, C.c_uint64,
                                                 u8pp, szp]
     L.pixo_hip_jpeg_encode_multi.argtypes = [C.c_void_p, C.c_size_t, optp, C.POINTER(C.c_int), C.c_uint32, u8pp, szp]
+    L.pixo_hip_jpeg_encode_batch_multi.argtypes = [C.c_void_p, optp, C.c_uint32, C.POINTER(C.c_int), C.c_uint32, C.c_void_p, C.c_size_t, szp, szp]
     L.pixo_hip_set_producer_stream.argtypes = [C.c_void_p]
     L.pixo_hip_get_producer_stream.restype = C.c_void_p
     L.pixo_hip_debug_configure.argtypes = [C.c_char_p]

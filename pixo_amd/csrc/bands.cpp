@@ -567,4 +567,138 @@ int pixo_hip_band(uint32_t width, uint32_t height, uint8_t color_type, uint8_t s
     return PIXO_OK;
 }
 
+
+// ---- a batch of images over the GPUs of one process (SURVEY §8e "C3 batch"; round 5) --------------------------------------
+namespace {
+// Device storage of a band worker between calls (grow-only; the worker threads live as long as the process): the images it
+// received from another GPU, and its files before they travel.
+struct BatchWorkerBuffers {
+    int device = -1;
+    void *px = nullptr, *arena = nullptr;
+    size_t px_cap = 0, arena_cap = 0;
+    void drop()
+    {
+        if (device >= 0) {
+            DeviceScope on(device);
+            if (px) (void)hipFree(px);
+            if (arena) (void)hipFree(arena);
+        }
+        px = arena = nullptr; px_cap = arena_cap = 0;
+    }
+    hipError_t reserve(void **p, size_t *cap, size_t want)
+    {
+        if (*cap >= want) return hipSuccess;
+        if (*p) (void)hipFree(*p);
+        *p = nullptr; *cap = 0;
+        const hipError_t e = hipMalloc(p, want);
+        if (e == hipSuccess) *cap = want;
+        return e;
+    }
+};
+thread_local BatchWorkerBuffers t_batch_buffers;
+} // namespace
+
+int pixo_hip_jpeg_encode_batch_multi(const void *pixels, const pixo_jpeg_options *options, uint32_t batch, const int *devices, uint32_t n_devices,
+                                     uint8_t *arena, size_t capacity, size_t *offsets, size_t *lens)
+{
+    PIXO_REQUIRE(options);
+    PIXO_REQUIRE(devices);
+    PIXO_REQUIRE(offsets);
+    PIXO_REQUIRE(lens);
+    const pixo_jpeg_options &o = *options;
+    std::string msg;
+    int rc = pixo_host::validate(o, false, 0, msg);
+    if (rc) return fail(rc, msg);
+    PIXO_REQUIRE(pixels);
+    if (batch == 0) return fail(PIXO_ERR_COMPRESSION, "Compression error: empty batch");
+    if (n_devices == 0 || n_devices > 1024) return fail(PIXO_ERR_COMPRESSION, "Compression error: need 1..1024 devices");
+    if (arena == nullptr && capacity != 0) return fail(PIXO_ERR_COMPRESSION, "Compression error: null arena with a capacity");
+    const pixo_host::Geometry g = pixo_host::geometry(o.width, o.height, o.color_type, o.subsampling);
+    const size_t image_bytes = static_cast<size_t>(o.width) * o.height * (g.gray ? 1 : 3);
+    // where the pixels are: in some GPU's memory (images then reach the other GPUs by peer copies, one peer per xGMI link)
+    // or in host memory (every GPU fetches its own images over its own PCIe link)
+    int src_device = -1;
+    {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, pixels) == hipSuccess && at.type == hipMemoryTypeDevice) src_device = at.device;
+        else (void)hipGetLastError(); // (plain host memory is "invalid value" to the runtime: not an error)
+    }
+    const uint32_t parts = n_devices;
+    struct Share {
+        uint32_t first = 0, count = 0;
+        std::vector<size_t> offs, lens;
+        size_t bytes = 0; // this share's files, back to back
+        int rc = PIXO_OK;
+        std::string error;
+    };
+    std::vector<Share> shares(parts);
+    for (uint32_t k = 0; k < parts; ++k) { // contiguous runs of images, as even as the batch allows
+        shares[k].first = static_cast<uint32_t>(static_cast<uint64_t>(batch) * k / parts);
+        shares[k].count = static_cast<uint32_t>(static_cast<uint64_t>(batch) * (k + 1) / parts) - shares[k].first;
+    }
+    PhaseBarrier barrier(parts);
+    std::atomic<bool> failed{false};
+    std::atomic<bool> too_small{false};
+    size_t total = 0;
+    auto body = [&](unsigned k) {
+        Share &sh = shares[k];
+        auto step = [&](int r) { if (r && !sh.rc) { sh.rc = r; sh.error = t_error; failed.store(true); } };
+        auto hip_step = [&](hipError_t e, const char *what) { if (e != hipSuccess) step(hip_fail(e, what)); };
+        BatchWorkerBuffers &buf = t_batch_buffers;
+        const int dev = devices[k];
+        if (sh.count) {
+            step(pixo_hip_set_device(dev)); // (binds this worker's library context and the HIP device of this thread)
+            if (!sh.rc) hip_step(hipSetDevice(dev), "hipSetDevice");
+            if (buf.device != dev) { buf.drop(); buf.device = dev; }
+            // ---- the share's images into this GPU's memory
+            const uint8_t *src = static_cast<const uint8_t *>(pixels) + static_cast<size_t>(sh.first) * image_bytes;
+            const void *local = src;
+            const size_t px_bytes = static_cast<size_t>(sh.count) * image_bytes;
+            if (!sh.rc && src_device != dev) {
+                hip_step(buf.reserve(&buf.px, &buf.px_cap, px_bytes), "hipMalloc (images of a batch share)");
+                if (!sh.rc) {
+                    if (src_device >= 0) hip_step(hipMemcpyPeer(buf.px, dev, src, src_device, px_bytes), "hipMemcpyPeer (images of a batch share)");
+                    else hip_step(hipMemcpy(buf.px, src, px_bytes, hipMemcpyHostToDevice), "upload of a batch share");
+                    local = buf.px;
+                }
+            }
+            // ---- its files, complete with headers and EOI, back to back in this GPU's memory (grow and repeat when the guess
+            // was short: pixo_hip_jpeg_encode_batch_device_into fills in the lengths either way)
+            sh.offs.assign(sh.count, 0); sh.lens.assign(sh.count, 0);
+            size_t want = std::max<size_t>(px_bytes / 3, size_t{1} << 16);
+            for (int attempt = 0; !sh.rc && attempt < 3; ++attempt) {
+                hip_step(buf.reserve(&buf.arena, &buf.arena_cap, want), "hipMalloc (files of a batch share)");
+                if (sh.rc) break;
+                const int r = pixo_hip_jpeg_encode_batch_device_into(local, options, sh.count, static_cast<uint8_t *>(buf.arena), buf.arena_cap,
+                                                                     sh.offs.data(), sh.lens.data());
+                if (r == PIXO_ERR_BUFFER_TOO_SMALL && attempt < 2) { want = sh.offs[sh.count - 1] + sh.lens[sh.count - 1] + 4096; continue; }
+                step(r);
+                break;
+            }
+            if (!sh.rc) sh.bytes = sh.offs[sh.count - 1] + sh.lens[sh.count - 1];
+        }
+        barrier.arrive(); // ---- exchange: every share's file lengths -> where every file goes in the caller's arena
+        if (k == 0 && !failed.load()) {
+            size_t at = 0;
+            for (uint32_t j = 0; j < parts; ++j)
+                for (uint32_t i = 0; i < shares[j].count; ++i) {
+                    offsets[shares[j].first + i] = at;
+                    lens[shares[j].first + i] = shares[j].lens[i];
+                    at += shares[j].lens[i];
+                }
+            total = at;
+            if (total > capacity) too_small.store(true);
+        }
+        barrier.arrive();
+        // ---- every share's run of files to its final place, over its own GPU's PCIe link, on its own thread
+        if (!failed.load() && !too_small.load() && sh.count && sh.bytes)
+            hip_step(hipMemcpy(arena + offsets[sh.first], buf.arena, sh.bytes, hipMemcpyDeviceToHost), "device-to-host copy of a batch share's files");
+    };
+    if (!band_workers_instance().run(parts, body)) return fail(PIXO_ERR_COMPRESSION, "Compression error: could not start the worker threads");
+    for (Share &sh : shares)
+        if (sh.rc) { const int r = sh.rc; const std::string e = sh.error; return fail(r, e); }
+    if (too_small.load()) return fail(PIXO_ERR_BUFFER_TOO_SMALL, "output buffer too small: need " + std::to_string(total) + " bytes");
+    return PIXO_OK;
+}
+
 } // extern "C"

@@ -393,6 +393,42 @@ def encode_batch_device_into(arena, d_pixels, options: JpegOptions, batch: int):
     return list(offsets), list(lens)
 
 
+def encode_batch_multi(arena, pixels, options: JpegOptions, batch: int, devices):
+    """`pixo_hip_jpeg_encode_batch_multi`: `batch` equally sized images — a device tensor / pointer on any GPU of this process,
+    or a numpy array in host memory — encoded by `devices` (one contiguous run of images each; a device may be listed more than
+    once), every GPU copying its files to their final place in `arena` (torch uint8 CPU tensor, ideally pinned, numpy uint8
+    array, or None for a size query) over its own PCIe link.  Returns (offsets, lens); raises BufferTooSmall (`.needed`)."""
+    L = _lib.load()
+    offsets = (C.c_size_t * batch)()
+    lens = (C.c_size_t * batch)()
+    if arena is None:
+        ptr, cap = None, 0
+    elif hasattr(arena, "data_ptr"):
+        ptr, cap = arena.data_ptr(), arena.numel()
+    else:
+        ptr, cap = arena.ctypes.data, arena.size
+    if hasattr(pixels, "data_ptr"):
+        src = pixels.data_ptr()
+    elif isinstance(pixels, np.ndarray):
+        src = _as_u8(pixels).ctypes.data
+    else:
+        src = int(pixels)
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    oc = options._c()
+    rc = L.pixo_hip_jpeg_encode_batch_multi(src, C.byref(oc), batch, devs, len(devices), ptr, cap, offsets, lens)
+    if rc == -9 and arena is None:  # PIXO_ERR_BUFFER_TOO_SMALL: the answer to a size query
+        return list(offsets), list(lens)
+    if rc == -9:
+        try:
+            _raise(rc)
+        except error.BufferTooSmall as e:
+            e.needed = int(offsets[batch - 1] + lens[batch - 1]) if batch else 0
+            raise
+    if rc:
+        _raise(rc)
+    return list(offsets), list(lens)
+
+
 def debug_stream_copy(d_in, d_out, nbytes, stream=0):
     """MEASUREMENT only (`pixo_hip_debug_stream_copy`): a plain device copy in the coefficient kernel's launch shape."""
     def ptr(x):

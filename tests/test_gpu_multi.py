@@ -414,3 +414,62 @@ def test_bench_run_of_two_ranks_sharing_the_gpu_measures_every_multi_gpu_leg():
     assert oc["c4_single_process"]["config"]["file_sha256"] == sha and oc["c4"]["n_gpus"] == 2
     assert oc["c3_sharded"]["config"]["images_per_rank"] == [32, 32] and oc["c3_sharded"]["config"]["file0_sha256"].startswith("d1811ba1761f6b2a")
     assert oc["c3_sharded_shared_arena"]["config"]["file_bytes_total"] == oc["c3_sharded"]["config"]["file_bytes_total"]
+
+
+# ---- a BATCH over the GPUs of one process (pixo_hip_jpeg_encode_batch_multi; round 5) ----------------------
+@pytest.mark.parametrize("parts", [1, 2, 3, 5, 8])
+def test_batch_multi_same_device_repeated_equals_the_one_gpu_batch(parts):
+    """the same device listed 1-8 times: byte-equal to pixo_hip_jpeg_encode_batch_device_into over the whole batch, device
+    pixels and host pixels, pinned and pageable arena"""
+    import torch
+    w, h, n = 320, 200, 11
+    o = _opts(w, h, 2, 1, 80)
+    imgs = np.concatenate([synth.noise(w, h, 100 + i) for i in range(n)])
+    d = torch.from_numpy(imgs).cuda()
+    ref_arena = torch.empty(n * w * h * 2, dtype=torch.uint8).pin_memory()
+    ro, rl = jpeg.encode_batch_device_into(ref_arena, d, o, n)
+    want = bytes(ref_arena[: ro[-1] + rl[-1]].numpy().tobytes())
+    for i in range(n):
+        assert want[ro[i]: ro[i] + rl[i]] == O.encode(imgs[i * w * h * 3:(i + 1) * w * h * 3], O.make_options(w, h, 2, 80, 1))
+    for src in (d, imgs):  # device memory; host memory
+        arena = torch.empty(n * w * h * 2, dtype=torch.uint8).pin_memory()
+        offs, lens = jpeg.encode_batch_multi(arena, src, o, n, [0] * parts)
+        assert (offs, lens) == (ro, rl)
+        assert bytes(arena[: offs[-1] + lens[-1]].numpy().tobytes()) == want
+    pageable = np.empty(ro[-1] + rl[-1], np.uint8)
+    offs, lens = jpeg.encode_batch_multi(pageable, d, o, n, [0] * parts)
+    assert pageable.tobytes() == want
+
+
+def test_batch_multi_fewer_images_than_devices_size_query_and_small_arena():
+    import torch
+    from pixo_amd import error
+    w, h, n = 200, 120, 3
+    o = _opts(w, h, 2, 0, 90)
+    imgs = np.concatenate([synth.noise(w, h, 7 + i) for i in range(n)])
+    d = torch.from_numpy(imgs).cuda()
+    offs, lens = jpeg.encode_batch_multi(None, d, o, n, [0] * 8)  # size query
+    need = offs[-1] + lens[-1]
+    arena = np.empty(need, np.uint8)
+    o2, l2 = jpeg.encode_batch_multi(arena, d, o, n, [0] * 8)
+    assert (o2, l2) == (offs, lens)
+    for i in range(n):
+        assert arena[offs[i]: offs[i] + lens[i]].tobytes() == O.encode(imgs[i * w * h * 3:(i + 1) * w * h * 3], O.make_options(w, h, 2, 90, 0))
+    small = np.zeros(need - 1, np.uint8)
+    with pytest.raises(error.BufferTooSmall) as e:
+        jpeg.encode_batch_multi(small, d, o, n, [0, 0])
+    assert e.value.needed == need and not small.any()  # nothing was copied
+
+
+def test_batch_multi_options_that_are_coded_image_by_image():
+    import torch
+    w, h, n = 256, 144, 4
+    imgs = np.concatenate([synth.noise(w, h, 50 + i) for i in range(n)])
+    d = torch.from_numpy(imgs).cuda()
+    for kw, okw in (({"optimize_huffman": True}, {"optimize_huffman": True}), ({"progressive": True}, {"progressive": True})):
+        o = _opts(w, h, 2, 1, 75, **kw)
+        offs, lens = jpeg.encode_batch_multi(None, d, o, n, [0, 0, 0])
+        arena = np.empty(offs[-1] + lens[-1], np.uint8)
+        jpeg.encode_batch_multi(arena, d, o, n, [0, 0, 0])
+        for i in range(n):
+            assert arena[offs[i]: offs[i] + lens[i]].tobytes() == O.encode(imgs[i * w * h * 3:(i + 1) * w * h * 3], O.make_options(w, h, 2, 75, 1, **okw))

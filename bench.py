@@ -838,6 +838,16 @@ def rccl_evidence(job):
     return out
 
 
+def gather_phases(job, ph):
+    """every rank's per-phase milliseconds of one instrumented call, on rank 0 (a list indexed by rank)"""
+    ph = {k: round(v, 3) for k, v in ph.items()}
+    if job.dist is None:
+        return [ph]
+    got = [None] * job.world if job.rank == 0 else None
+    job.dist.gather_object(ph, got, dst=0)
+    return got
+
+
 def measure_c4(job, q, steps, warmup, blocks, settle_ms, shared_arena=False):
     """configs[3]: MCU-row bands of ONE 16384x16384 image resident on the N GPUs; a step = the finished file on rank 0.
     Strong scaling: the image is fixed, every rank holds 1/N of it.  Every rank calls; rank 0 gets the result dict.
@@ -895,6 +905,13 @@ def measure_c4(job, q, steps, warmup, blocks, settle_ms, shared_arena=False):
         del ty, tcb, tcr
     try:
         walls, _ = job.time_blocks(step, steps, warmup, blocks, events=False)
+        # one more, instrumented call: where a step's time goes on every rank (diagnosis of the first node run)
+        ph = {}
+        if job.stub:
+            sharded.encode_banded(mine, opts, coeff_fn=lambda sub, o: O.coeffs(sub, o.width, o.height, 2, 1, o.quality), shared=shared, phases=ph)
+        else:
+            sharded.encode_banded(d_band, opts, device=job.gpu_index, out=out, shared=shared, phases=ph)
+        state["phases"] = gather_phases(job, ph)
         if job.rank == 0 and shared is not None and not job.stub:
             out = torch.from_numpy(shared.array()[: state["len"]].copy())
     finally:
@@ -924,6 +941,7 @@ def measure_c4(job, q, steps, warmup, blocks, settle_ms, shared_arena=False):
                       "width": w, "height": h, "quality": q, "subsampling": "4:2:0", "band_rows_rank0": rows,
                       "file_bytes": int(n), "file_sha256": digest, "sha256_is_the_reference_s": (not job.stub) and digest == C4_SHA256,
                       "parallelism": "one process per GPU, one band per rank"},
+           "phases_ms_by_rank": state.get("phases"),
            "roofline": None}
     if kev:
         kernel_ms = statistics.median(kev) / 20
@@ -956,7 +974,7 @@ def run_c4(job, args):
 C3_IMAGE0_SHA256 = "d1811ba1761f6b2a76d7f2c3d43418784f38909e0b20af631d5ead73e7d9436a"  # noise(1920,1080,42), made by the reference
 
 
-def measure_c3_sharded(job, q, steps, warmup, blocks, shared_arena=False):
+def measure_c3_sharded(job, q, steps, warmup, blocks, shared_arena=False, waves=1):
     """configs[2] on a node (SURVEY §8e "C3 batch"): 64 x 1920x1080 images RESIDENT ON RANK 0's GPU; a step =
     sharded.encode_batch: whole images to the ranks point to point over xGMI, every rank encodes its share, the files come
     back to rank 0 the same way and cross PCIe once into a pinned arena.  Strong scaling (the batch is fixed).
@@ -991,10 +1009,13 @@ def measure_c3_sharded(job, q, steps, warmup, blocks, shared_arena=False):
             shared.register()
 
     def step(i):
-        state["got"] = sharded.encode_batch(d, opts, n, encode_fn=fn, out=out, device=None if job.stub else job.gpu_index, shared=shared)
+        state["got"] = sharded.encode_batch(d, opts, n, encode_fn=fn, out=out, device=None if job.stub else job.gpu_index, shared=shared, waves=waves)
 
     try:
         walls, _ = job.time_blocks(step, steps, warmup, blocks, events=False)
+        ph = {}  # one more, instrumented call (the device is synchronised at the step boundaries: not part of the timed blocks)
+        sharded.encode_batch(d, opts, n, encode_fn=fn, out=out, device=None if job.stub else job.gpu_index, shared=shared, waves=waves, phases=ph)
+        state["phases"] = gather_phases(job, ph)
         if job.rank == 0 and shared is not None:
             _, offs_s, lens_s = state["got"]
             state["got"] = (job.torch.from_numpy(shared.array().copy()), offs_s, lens_s)
@@ -1019,6 +1040,7 @@ def measure_c3_sharded(job, q, steps, warmup, blocks, shared_arena=False):
             **st, "scaling": "strong",
             "config": {"workload": "configs[2] on a node: %d x %dx%d RGB8 noise (seeds 42..%d) resident on rank 0, q=%d 4:2:0 -> %d files in rank 0's pinned arena"
                                    % (n, w, h, 42 + n - 1, q, n),
+                       "waves": waves, "phases_ms_by_rank": state.get("phases"),
                        "images_per_rank": [b - a for a, b in parts], "pixels_scattered_bytes": (n - (parts[0][1] - parts[0][0])) * px,
                        "file_bytes_total": int(sum(lens)), "files_checked_against_oracle": sample, "file0_sha256": sha0,
                        "path": ("sharded.encode_batch(shared=SharedFile): isend/irecv of whole images (one peer per xGMI link) -> "
@@ -1054,6 +1076,40 @@ def measure_c4_single_process(job, q, n_dev, steps=3, blocks=3):
             "config": {"workload": "configs[3], single process: pixo_hip_jpeg_encode_multi over devices %s; 805 MB of HOST pixels in over PCIe, "
                                    "178.5 MB file out as Python bytes" % devices, "file_bytes": len(blob), "file_sha256": digest,
                        "sha256_is_the_reference_s": True}}
+
+
+def measure_c3_single_process(job, q, n_dev, steps=5, blocks=3):
+    """configs[2] in ONE process (rank 0 only): pixo_hip_jpeg_encode_batch_multi — the 64 x 1080p images resident on GPU 0, the other
+    GPUs' shares by peer copies (one peer per xGMI link), every GPU encodes its share and copies its files over its OWN PCIe link
+    to their final place in one pinned arena.  The torch-free form of c3_sharded_shared_arena."""
+    import numpy as np
+    import synth
+    from pixo_amd import jpeg
+    import oracle_lib as O
+    torch = job.torch
+    w, h, n = 1920, 1080, 64
+    opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling.S420).build()
+    d = torch.from_numpy(np.concatenate([synth.noise(w, h, 42 + i) for i in range(n)])).to(job.dev)
+    arena = torch.empty(n * w * h, dtype=torch.uint8).pin_memory()
+    devices = [0] * n_dev if job.share_gpu else list(range(n_dev))
+    job.sync()
+    offs, lens = jpeg.encode_batch_multi(arena, d, opts, n, devices)  # (also the warm-up: workers, contexts, device buffers)
+    for i in sorted({n * k // n_dev for k in range(n_dev)} | {n - 1}):
+        if arena[offs[i]: offs[i] + lens[i]].numpy().tobytes() != O.encode(synth.noise(w, h, 42 + i), O.make_options(w, h, 2, q, 1)):
+            raise RuntimeError("file %d of the single-process batch differs from the oracle's" % i)
+    ts = []
+    for _ in range(blocks):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            jpeg.encode_batch_multi(arena, d, opts, n, devices)
+        ts.append((time.perf_counter() - t0) / steps)
+    ts.sort()
+    del d, arena
+    return {"value": round(w * h * n / ts[len(ts) // 2] / 1e6, 1), "unit": "Mpixels/s", "n_gpus": n_dev, "steps": steps, "blocks": blocks,
+            "ms_per_step": round(ts[len(ts) // 2] * 1e3, 3), "ms_per_step_min": round(ts[0] * 1e3, 3), "ms_per_step_max": round(ts[-1] * 1e3, 3),
+            "scaling": "strong",
+            "config": {"workload": "configs[2], single process: pixo_hip_jpeg_encode_batch_multi over devices %s; 64 x 1920x1080 RGB8 noise resident on "
+                                   "device %d, files into one pinned arena" % (devices, devices[0]), "file_bytes_total": int(sum(lens))}}
 
 
 MULTI_LEGS_DEADLINE_S = 240.0  # all multi-GPU legs together (they take ~3 s on one GPU); the metric line must not wait longer
@@ -1110,7 +1166,11 @@ def multi_gpu_extras(job, args):
             ("c4_shared_arena", lambda: measure_c4(job, args.quality, 2 if small else 5, 1, 3, 0, shared_arena=True)),
             ("c3_sharded", lambda: measure_c3_sharded(job, args.quality, 2 if small else 5, 1, 3)),
             ("c3_sharded_shared_arena", lambda: measure_c3_sharded(job, args.quality, 2 if small else 5, 1, 3, shared_arena=True)))
-    if job.world > 1 and not job.stub:  # (rank 0 alone; the others wait in the next `agree`)
+    if job.world > 1:  # the batch in two waves: the second half of every share travels while the first half is encoded
+        legs += (("c3_sharded_two_waves", lambda: measure_c3_sharded(job, args.quality, 2 if small else 5, 1, 3, waves=2)),)
+    if not job.stub:  # (rank 0 alone; the others wait in the next `agree`)
+        legs += (("c3_single_process", lambda: measure_c3_single_process(job, args.quality, job.world) if job.rank == 0 else None),)
+    if job.world > 1 and not job.stub:
         legs += (("c4_single_process", lambda: measure_c4_single_process(job, args.quality, job.world) if job.rank == 0 else None),)
     for name, fn in legs:
         t0 = time.perf_counter()

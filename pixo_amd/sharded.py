@@ -192,7 +192,7 @@ def _check_shared(shared, file_len):
         raise e
 
 
-def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn=None, out=None, shared=None):
+def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn=None, out=None, shared=None, phases=None):
     """Collective over `group`.  Every rank passes the same `options` and ITS band's rows
     (`jpeg.band(w, h, ct, ss, world, rank)`: rows [row_begin, row_end), tightly packed) as host bytes /
     uint8 array or as a torch uint8 tensor on its GPU.  Returns the JFIF bytes on rank `dst`, None elsewhere;
@@ -202,6 +202,10 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
     link; the file's length is returned on `dst` (the bytes are in `shared.array()`), None elsewhere.  The segment's size
     has to be chosen before the file's length is known: `shared_file_bound(options)` is always enough (and usually far too much); a segment that
     turns out too small makes EVERY rank raise `BufferTooSmall` (`.needed` = the file's length) before any byte is written.
+
+    `phases`: a dict that receives this rank's wall milliseconds per step (coeffs_ms, exchange_dc_ms, lengths_ms, exchange_bits_ms,
+    pack_ms, exchange_hdr_ms, bodies_ms, splice_ms, total_ms): every step of the band encoder waits for its kernels itself, so the
+    laps need no extra synchronisation.
 
     `device`: HIP device index of this rank (default: torch's current device); `coeff_fn(band_pixels,
     band_options) -> (y, cb, cr)`: tests substitute a CPU function, which also routes the entropy stage
@@ -228,11 +232,23 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
         enc = _HostBand(options, world, rank, coeff_fn)
         tdev = torch.device("cpu")
     wire = _wire(group, tdev)
+    import time
+    t_start = t_lap = time.perf_counter()
+
+    def lap(name):
+        nonlocal t_lap
+        if phases is not None:
+            t1 = time.perf_counter()
+            phases[name] = phases.get(name, 0.0) + (t1 - t_lap) * 1e3
+            phases["total_ms"] = (t1 - t_start) * 1e3
+            t_lap = t1
     try:
         rows = enc.row_end - enc.row_begin
         last = enc.coeffs(band_pixels)
+        lap("coeffs_ms")
         # exchange 1: boundary DCs (+ whether the band has rows)
         got = _all_gather_i64([rows > 0] + last, group, wire)
+        lap("exchange_dc_ms")
         prev = [0, 0, 0]
         for r in range(rank):
             if got[r][0]:
@@ -246,9 +262,11 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
         if not on_gpu:
             enc._prev, enc._counts = prev, total_counts
         bits = enc.lengths(prev, total_counts)
+        lap("lengths_ms")
         # exchange 2: bits per band -> this band's bit offset
         all_bits = [b[0] for b in _all_gather_i64([bits], group, wire)]
         offset = sum(all_bits[:rank])
+        lap("exchange_bits_ms")
         if not on_gpu and shared is not None:  # host twins through the shared file: header exchange, body at its final place
             piece = enc.pack(offset)
             words = np.frombuffer(piece[:16], np.int64)
@@ -276,10 +294,12 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
             return len(blob)
         # device: the body stays in HBM; exchange 3 = the 16-byte piece headers -> the file's layout
         hdr, n = enc.pack_device(offset)
+        lap("pack_ms")
         words = np.frombuffer(hdr, np.int64)
         all_hdr = [np.array(h, np.int64).tobytes() for h in _all_gather_i64([int(words[0]), int(words[1])], group, wire)]
         file_len, body_off = jpeg.splice_layout(options, all_hdr, total_counts)
         lens = [int(np.frombuffer(h, np.uint64)[1]) for h in all_hdr]
+        lap("exchange_hdr_ms")
         if shared is not None:
             # every rank: device -> the body's final place in the node's shared file, over this GPU's own PCIe link
             _check_shared(shared, file_len)
@@ -287,9 +307,11 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
             if lens[rank]:
                 enc.copy_body(arr.ctypes.data + body_off[rank])
             dist.barrier(group=group)
+            lap("bodies_ms")
             if rank != dst:
                 return None
             jpeg.splice_finish(options, all_hdr, arr, file_len, total_counts)
+            lap("splice_ms")
             return file_len
         if world == 1:
             file = out if out is not None else _pinned_file(file_len)
@@ -300,13 +322,16 @@ def encode_banded(band_pixels, options, group=None, dst=0, device=None, coeff_fn
             enc.copy_body(send)
             recv = _gather_bulk(send, dst, group, wire)
             if rank != dst:
+                lap("bodies_ms")
                 return None
             file = out if out is not None else _pinned_file(file_len)
             for k in range(world):
                 if lens[k]:
                     file[body_off[k]: body_off[k] + lens[k]].copy_(recv[k][: lens[k]], non_blocking=True)
             torch.cuda.synchronize(tdev)
+        lap("bodies_ms")
         jpeg.splice_finish(options, all_hdr, file, file_len, total_counts)
+        lap("splice_ms")
         if out is not None:
             return file_len
         return file[:file_len].numpy().tobytes()
@@ -417,14 +442,14 @@ def _global(group, r):
     return dist.get_global_rank(group, r) if group is not None else r
 
 
-def _p2p(ops, group=None):
+def _p2p_post(ops, group=None):
     """Posts all sends / receives of one step at once (RCCL runs them as one group: the source's seven xGMI links carry
-    seven different peers' images at the same time) and waits for them.  ops: ("send" | "recv", tensor, global peer rank).
-    On a gloo group device tensors travel through host copies (`_wire`)."""
+    seven different peers' images at the same time) WITHOUT waiting.  ops: ("send" | "recv", tensor, global peer rank).
+    On a gloo group device tensors travel through host copies (`_wire`).  Returns a handle for `_p2p_wait`."""
     import torch
     import torch.distributed as dist
     if not ops:
-        return
+        return None
     staged_wire = dist.get_backend(group) == "gloo"
     posted, landed = [], []
     for kind, t, peer in ops:
@@ -436,13 +461,25 @@ def _p2p(ops, group=None):
                 w = torch.empty(t.shape, dtype=t.dtype)
                 landed.append((t, w))
         posted.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, w, peer, group))
-    for req in dist.batch_isend_irecv(posted):
+    return dist.batch_isend_irecv(posted), landed, posted
+
+
+def _p2p_wait(handle):
+    if handle is None:
+        return
+    reqs, landed, _ = handle
+    for req in reqs:
         req.wait()
     for t, w in landed:
         t.copy_(w)
 
 
-def encode_batch(batch_pixels, options, n, group=None, src=0, dst=0, device=None, encode_fn=None, out=None, shared=None):
+def _p2p(ops, group=None):
+    """post + wait"""
+    _p2p_wait(_p2p_post(ops, group))
+
+
+def encode_batch(batch_pixels, options, n, group=None, src=0, dst=0, device=None, encode_fn=None, out=None, shared=None, waves=1, phases=None):
     """Collective over `group`: `n` equally sized images (described by `options`) lie back to back on rank `src` — a torch
     uint8 tensor on its GPU (other ranks pass None) — and come back as `n` JFIF files on rank `dst`, each byte-identical to
     `pixo::jpeg::encode` of that image (src/jpeg/mod.rs:88).
@@ -462,6 +499,17 @@ def encode_batch(batch_pixels, options, n, group=None, src=0, dst=0, device=None
     GPU over its OWN PCIe link to the run's final offset in the shared arena (one barrier; nothing travels over xGMI and
     rank `dst`'s single link does not carry everybody's bytes: 89 MB for 64 x 1080p noise).  Returns `(None, offsets, lens)`
     on `dst` (the bytes are in `shared.array()`); a segment that is too small makes EVERY rank raise BufferTooSmall.
+
+    `waves` (1 or 2): every share travels and is encoded in that many parts — the second part's images are on the wire while the
+    first part's are encoded (the scatter of 348 MB of pixels is the long step of 64 x 1080p on a node: 7 links x ~50 GB/s);
+    in either case `src` encodes its own share while its sends are in flight.  The files are the same bytes.
+
+    `phases`: a dict that receives this rank's wall milliseconds per step (scatter_wait_ms, encode_ms, sizes_ms, gather_ms or
+    copy_ms, total_ms) — the device is synchronised at the step boundaries then, so a call with `phases` is for diagnosis,
+    not for timing the whole.
+
+    A rank whose encode step fails (or, with `shared`, a segment that is too small) makes EVERY rank raise before any file
+    moves: the size exchange carries a status word.
 
     `encode_fn(images, options, count) -> list of bytes` replaces step 2 for tests without a GPU (gloo, CPU tensors: the
     scatter, the size exchange and the gather are the same calls)."""
@@ -483,64 +531,134 @@ def encode_batch(batch_pixels, options, n, group=None, src=0, dst=0, device=None
         tdev = torch.device("cpu")
     gsrc, gdst = _global(group, src), _global(group, dst)
 
-    if world == 1 and on_gpu and shared is None:
-        # nothing to scatter or gather: the files go straight from this GPU into the destination's host arena (the library overlaps
-        # their way over PCIe with the kernels of the next sub-batch) — no device arena, no second pass over the bytes
+    import time
+    t_start = time.perf_counter()
+
+    def lap(name, t0):
+        if phases is None:
+            return time.perf_counter()
+        if on_gpu:
+            torch.cuda.synchronize(tdev)
+        t1 = time.perf_counter()
+        phases[name] = phases.get(name, 0.0) + (t1 - t0) * 1e3
+        return t1
+
+    if world == 1 and on_gpu:
+        # nothing to scatter or gather: the files go straight from this GPU into the destination's host arena — the caller's,
+        # or the node-shared segment (registered: the device-to-host copies land in it directly) — while the library overlaps
+        # their way over PCIe with the kernels of the next sub-batch: no device arena, no second pass over the bytes
         if batch_pixels is None or batch_pixels.numel() != n * px:
             raise ValueError("encode_batch: rank src passes the %d images back to back (%d bytes)" % (n, n * px))
         prev = jpeg.get_producer_stream()
         jpeg.set_producer_stream(torch.cuda.current_stream(tdev).cuda_stream)
         try:
-            arena = out if out is not None else _pinned_file(n * (px // 2 + 4096))
+            if shared is not None:
+                arena = torch.from_numpy(shared.array())
+            else:
+                arena = out if out is not None else _pinned_file(n * (px // 2 + 4096))
             while True:
                 try:
                     offsets, lens = jpeg.encode_batch_device_into(arena, batch_pixels.reshape(-1), options, n)
-                    return arena, [int(x) for x in offsets], [int(x) for x in lens]
+                    lap("encode_ms", t_start)
+                    if phases is not None:
+                        phases["total_ms"] = (time.perf_counter() - t_start) * 1e3
+                    return (None if shared is not None else arena), [int(x) for x in offsets], [int(x) for x in lens]
                 except jpeg.error.BufferTooSmall as e:
-                    if out is not None:
+                    if out is not None or shared is not None:
                         raise
                     arena = _pinned_file(int(e.needed))
         finally:
             jpeg.set_producer_stream(prev)
 
-    # 1. scatter
+    # 1. scatter — posted, not waited for: `src` goes on to its own share while its sends are in flight; with two waves a
+    # receiver encodes the first part of its share while the second part travels
+    nw = 2 if (waves == 2 and n >= 2 * world) else 1
+
+    def cut(a, b):  # the parts of a share, in image indices
+        if nw == 1 or b - a < 2:
+            return [(a, b)]
+        m = (a + b + 1) // 2
+        return [(a, m), (m, b)]
+    my_parts = cut(lo, hi)
+    pending = []
     if rank == src:
         if batch_pixels is None or batch_pixels.numel() != n * px:
             raise ValueError("encode_batch: rank src passes the %d images back to back (%d bytes)" % (n, n * px))
         whole = batch_pixels.reshape(-1)
         mine = whole[lo * px: hi * px]
-        _p2p([("send", whole[a * px: b * px], _global(group, r)) for r, (a, b) in enumerate(parts) if r != src and b > a], group)
+        for w in range(nw):
+            ops = []
+            for r, (a, b) in enumerate(parts):
+                pr = cut(a, b)
+                if r != src and w < len(pr) and pr[w][1] > pr[w][0]:
+                    ops.append(("send", whole[pr[w][0] * px: pr[w][1] * px], _global(group, r)))
+            pending.append(_p2p_post(ops, group))
+        arrivals = [None] * len(my_parts)  # (its own images are where they are)
     else:
         mine = torch.empty(cnt * px, dtype=torch.uint8, device=tdev)
-        if cnt:
-            _p2p([("recv", mine, gsrc)], group)
+        arrivals = [_p2p_post([("recv", mine[(a - lo) * px: (b - lo) * px], gsrc)], group) if b > a else None for (a, b) in my_parts]
+    t_lap = lap("scatter_post_ms", t_start)
 
-    # 2. encode this rank's images; the files stay where the next step sends them from
-    lens = []
-    if not on_gpu:
-        files = encode_fn(mine.numpy(), options, cnt) if cnt else []
-        lens = [len(f) for f in files]
-        run = torch.frombuffer(bytearray(b"".join(files)), dtype=torch.uint8) if cnt and sum(lens) else torch.empty(0, dtype=torch.uint8)
-    elif cnt:
-        cap = cnt * (px // 2 + 4096)
-        prev = jpeg.get_producer_stream()
-        jpeg.set_producer_stream(torch.cuda.current_stream(tdev).cuda_stream)  # the received pixels were written on torch's stream
-        try:
-            while True:
+    # 2. encode this rank's images part by part; the files stay, back to back, where the next step sends them from.  A
+    # failure here must not leave the other ranks waiting in step 3: it travels as a status word.
+    lens, failure = [], None
+    run = torch.empty(0, dtype=torch.uint8, device=tdev)
+    try:
+        if not on_gpu:
+            files = []
+            for k, (a, b) in enumerate(my_parts):
+                _p2p_wait(arrivals[k])
+                t_lap = lap("scatter_wait_ms", t_lap)
+                if b > a:
+                    files += encode_fn(mine[(a - lo) * px: (b - lo) * px].numpy(), options, b - a)
+                t_lap = lap("encode_ms", t_lap)
+            lens = [len(f) for f in files]
+            if cnt and sum(lens):
+                run = torch.frombuffer(bytearray(b"".join(files)), dtype=torch.uint8)
+        elif cnt:
+            cap = cnt * (px // 2 + 4096)
+            prev = jpeg.get_producer_stream()
+            jpeg.set_producer_stream(torch.cuda.current_stream(tdev).cuda_stream)  # the received pixels were written on torch's stream
+            try:
                 run = torch.empty(cap, dtype=torch.uint8, device=tdev)
-                try:
-                    _, lens = jpeg.encode_batch_device_into(run, mine, options, cnt)
-                    break
-                except jpeg.error.BufferTooSmall as e:  # (offsets / lens were filled in: the second attempt fits)
-                    cap = int(e.needed)
-        finally:
-            jpeg.set_producer_stream(prev)
-    else:
-        run = torch.empty(0, dtype=torch.uint8, device=tdev)
+                at_run = 0
+                for k, (a, b) in enumerate(my_parts):
+                    _p2p_wait(arrivals[k])
+                    t_lap = lap("scatter_wait_ms", t_lap)
+                    if b <= a:
+                        continue
+                    while True:
+                        try:
+                            _, part_lens = jpeg.encode_batch_device_into(run[at_run:], mine[(a - lo) * px: (b - lo) * px], options, b - a)
+                            break
+                        except jpeg.error.BufferTooSmall as e:  # (the lengths were filled in: the second attempt fits)
+                            grown = torch.empty(at_run + int(e.needed) + (hi - b) * (px // 2 + 4096), dtype=torch.uint8, device=tdev)
+                            grown[:at_run].copy_(run[:at_run])
+                            run = grown
+                    lens += [int(x) for x in part_lens]
+                    at_run += sum(int(x) for x in part_lens)
+                    t_lap = lap("encode_ms", t_lap)
+            finally:
+                jpeg.set_producer_stream(prev)
+    except Exception as ex:  # noqa: BLE001 — reported to every rank below
+        failure = ex
+        lens = [0] * cnt
+    for h in pending:  # (src: its sends have long left; they must have before the tensors they read are released)
+        _p2p_wait(h)
+    t_lap = lap("scatter_wait_ms", t_lap)
 
     # 3. sizes: every rank's per-image lengths, padded to the longest share
     most = max(b - a for a, b in parts)
-    all_lens = _all_gather_i64(lens + [0] * (most - cnt), group, _wire(group, tdev))
+    my_cap = int(out.numel()) if (out is not None and rank == dst and shared is None) else -1  # (dst's fixed output, if any)
+    gathered = _all_gather_i64([0 if failure is None else -1, my_cap] + lens + [0] * (most - cnt), group, _wire(group, tdev))
+    bad = [r for r in range(world) if gathered[r][0] != 0]
+    if bad:  # every rank knows: nobody posts a send or a receive, everybody raises
+        if failure is not None:
+            raise failure
+        raise RuntimeError("encode_batch: the encode step failed on rank(s) %s of the group" % bad)
+    all_lens = [g[2:] for g in gathered]
+    dst_cap = gathered[dst][1]
+    t_lap = lap("sizes_ms", t_lap)
     lens_all = [x for r, (a, b) in enumerate(parts) for x in all_lens[r][: b - a]]
     offsets, at = [], 0
     for x in lens_all:
@@ -558,20 +676,24 @@ def encode_batch(batch_pixels, options, n, group=None, src=0, dst=0, device=None
             if on_gpu:
                 torch.cuda.synchronize(tdev)
         dist.barrier(group=group)
+        lap("copy_ms", t_lap)
+        if phases is not None:
+            phases["total_ms"] = (time.perf_counter() - t_start) * 1e3
         return (None, offsets, lens_all) if rank == dst else None
-    # 4. gather the files on dst, every run straight to its final offset
-    if rank != dst:
-        if run_len[rank]:
-            _p2p([("send", run[: run_len[rank]], gdst)], group)
-        return None
-    if out is not None and out.numel() < at:
+    # 4. gather the files on dst, every run straight to its final offset.  dst's output too small: every rank knows (its
+    # capacity travelled with the sizes) and raises the same error before a byte moves.
+    if 0 <= dst_cap < at:
         from . import error
         e = error.BufferTooSmall("output buffer too small: need %d bytes" % at)
         e.needed = at
-        # (the peers' sends are already posted: receive them into scratch so that nobody is left waiting, then raise)
-        scratch = torch.empty(max(at, 1), dtype=torch.uint8, device=tdev)
-        _p2p([("recv", scratch[run_off[r]: run_off[r] + run_len[r]], _global(group, r)) for r in range(world) if r != dst and run_len[r]], group)
         raise e
+    if rank != dst:
+        if run_len[rank]:
+            _p2p([("send", run[: run_len[rank]], gdst)], group)
+        lap("gather_ms", t_lap)
+        if phases is not None:
+            phases["total_ms"] = (time.perf_counter() - t_start) * 1e3
+        return None
     whole = torch.empty(max(at, 1), dtype=torch.uint8, device=tdev)
     if run_len[rank]:
         whole[run_off[rank]: run_off[rank] + run_len[rank]].copy_(run[: run_len[rank]])
@@ -580,8 +702,15 @@ def encode_batch(batch_pixels, options, n, group=None, src=0, dst=0, device=None
         arena = whole if out is None else out
         if out is not None:
             out[:at].copy_(whole[:at])
+        lap("gather_ms", t_lap)
+        if phases is not None:
+            phases["total_ms"] = (time.perf_counter() - t_start) * 1e3
         return arena, offsets, lens_all
+    t_lap = lap("gather_ms", t_lap)
     arena = out if out is not None else _pinned_file(at)
     arena[:at].copy_(whole[:at], non_blocking=True)
     torch.cuda.synchronize(tdev)
+    lap("copy_ms", t_lap)
+    if phases is not None:
+        phases["total_ms"] = (time.perf_counter() - t_start) * 1e3
     return arena, offsets, lens_all

@@ -62,6 +62,11 @@ def test_bench_honours_gpus_when_started_without_a_launcher():
         assert "error" not in leg, leg
         assert leg["n_gpus"] == 2 and leg["scaling"] == "strong" and leg["value"] > 0 and leg["ms_per_step_min"] <= leg["ms_per_step"]
     assert len(c4["config"]["file_sha256"]) == 64 and c3["config"]["images_per_rank"] == [8, 8]
+    # round 5: per-rank phase breakdown of one instrumented step; the batch also in two waves
+    assert len(c4["phases_ms_by_rank"]) == 2 and all("total_ms" in p for p in c4["phases_ms_by_rank"])
+    assert len(c3["config"]["phases_ms_by_rank"]) == 2 and "sizes_ms" in c3["config"]["phases_ms_by_rank"][0]
+    c3w = line["other_configs"]["c3_sharded_two_waves"]
+    assert "error" not in c3w and c3w["config"]["waves"] == 2 and c3w["config"]["file_bytes_total"] == c3["config"]["file_bytes_total"]
     c4s = line["other_configs"]["c4_shared_arena"]  # the same file, every band's body written into one node-shared segment
     assert "error" not in c4s and c4s["config"]["file_sha256"] == c4["config"]["file_sha256"] and "shared" in c4s["config"]["workload"]
     one = _stub_line(1)

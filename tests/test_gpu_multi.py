@@ -407,8 +407,13 @@ def test_bench_run_of_two_ranks_sharing_the_gpu_measures_every_multi_gpu_leg():
     assert line["n_gpus"] == 2 and "TEST MODE" in line["data"] and line["rccl"]["world"] == 2 and line["rccl"]["backend"] == "gloo"
     assert line["rccl"]["all_reduce_of_rank_plus_1"] == 3 and [d["rank"] for d in line["rccl"]["devices"]] == [0, 1]
     oc = line["other_configs"]
-    for name in ("c4", "c4_shared_arena", "c3_sharded", "c3_sharded_shared_arena", "c4_single_process"):
+    for name in ("c4", "c4_shared_arena", "c3_sharded", "c3_sharded_shared_arena", "c3_sharded_two_waves", "c3_single_process", "c4_single_process"):
         assert name in oc and "error" not in oc[name], (name, oc.get(name))
+    # round 5: every leg says where a step's time goes, rank by rank; the batch also runs in two waves and through the C ABI alone
+    assert len(oc["c4"]["phases_ms_by_rank"]) == 2 and "coeffs_ms" in oc["c4"]["phases_ms_by_rank"][1]
+    assert len(oc["c3_sharded"]["config"]["phases_ms_by_rank"]) == 2 and "encode_ms" in oc["c3_sharded"]["config"]["phases_ms_by_rank"][1]
+    assert oc["c3_sharded_two_waves"]["config"]["waves"] == 2
+    assert oc["c3_sharded_two_waves"]["config"]["file_bytes_total"] == oc["c3_sharded"]["config"]["file_bytes_total"] == oc["c3_single_process"]["config"]["file_bytes_total"]
     sha = "77cc6cb69a782693c46f2024ac57ebfdfb8411148fa3cef62698c727af36c70c"
     assert oc["c4"]["config"]["file_sha256"] == sha and oc["c4_shared_arena"]["config"]["file_sha256"] == sha
     assert oc["c4_single_process"]["config"]["file_sha256"] == sha and oc["c4"]["n_gpus"] == 2

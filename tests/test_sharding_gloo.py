@@ -296,6 +296,8 @@ def _worker_batch(rank, world, port, n, w, h, ct, ss, q, src, dst, flags, small_
     bpp = 1 if ct == 0 else 3
     px = w * h * bpp
     images = [synth.noise_gray(w, h, 42 + i) if ct == 0 else synth.noise(w, h, 42 + i) for i in range(n)]
+    flags = dict(flags)
+    waves, fail_rank = flags.pop("_waves", 1), flags.pop("_fail_rank", None)  # (test controls, not encoder options)
     oo = O.make_options(w, h, ct, q, ss, **flags)
 
     def cpu_encode(chunk, o, count):
@@ -307,13 +309,34 @@ def _worker_batch(rank, world, port, n, w, h, ct, ss, q, src, dst, flags, small_
     lo, hi = sharded.batch_partition(n, world)[rank]
     if small_out:
         out = torch.empty(64, dtype=torch.uint8) if rank == dst else None
-        try:
+        try:  # (round 5: dst's capacity travels with the sizes — EVERY rank raises, before any file moves)
             sharded.encode_batch(batch, o, n, src=src, dst=dst, encode_fn=cpu_encode, out=out)
-            ok = rank != dst
+            ok = False
         except error.BufferTooSmall as e:
-            ok = rank == dst and e.needed == sum(len(O.encode(im, oo)) for im in images)
+            ok = e.needed == sum(len(O.encode(im, oo)) for im in images)
     else:
-        got = sharded.encode_batch(batch, o, n, src=src, dst=dst, encode_fn=cpu_encode)
+        phases = {}
+        if fail_rank is not None:  # one rank's encode step throws: every rank must raise, nobody may hang in the exchange
+            def failing(chunk, o_, count):
+                if rank == fail_rank:
+                    raise ValueError("boom on rank %d" % rank)
+                return cpu_encode(chunk, o_, count)
+            try:
+                sharded.encode_batch(batch, o, n, src=src, dst=dst, encode_fn=failing, waves=waves)
+                ok = False
+            except ValueError:
+                ok = rank == fail_rank
+            except RuntimeError as e:
+                ok = rank != fail_rank and str(fail_rank) in str(e)
+            dist.barrier()
+            if rank == dst:
+                ret.put(bool(ok))
+            else:
+                assert ok
+            dist.destroy_process_group()
+            return
+        got = sharded.encode_batch(batch, o, n, src=src, dst=dst, encode_fn=cpu_encode, waves=waves, phases=phases)
+        assert "total_ms" in phases and "sizes_ms" in phases and ("encode_ms" in phases or hi == lo)
         if rank == dst:
             arena, offs, lens = got
             ok = len(offs) == n and offs[0] == 0 and all(offs[i + 1] == offs[i] + lens[i] for i in range(n - 1))
@@ -341,8 +364,23 @@ def test_batch_scattered_from_one_rank_and_files_gathered(world, n, case):
     assert _run(_worker_batch, world, (n,) + case + (False,), timeout=300) is True
 
 
-def test_batch_output_too_small_raises_on_dst_and_strands_nobody():
+def test_batch_output_too_small_raises_on_every_rank_before_any_file_moves():
     assert _run(_worker_batch, 3, (5, 48, 40, 2, 1, 80, 0, 1, {}, True)) is True
+
+
+@pytest.mark.parametrize("world,n,case", [
+    (2, 5, (48, 40, 2, 1, 80, 0, 0, {"_waves": 2})),
+    (3, 13, (40, 24, 2, 0, 60, 1, 2, {"_waves": 2})),       # shares of 5, 4, 4 in parts of 3 + 2, 2 + 2, 2 + 2; src != dst
+    (8, 64, (32, 24, 2, 1, 80, 0, 0, {"_waves": 2})),       # configs[2]'s shape on a node, two waves of 4 images per rank
+    (8, 9, (32, 16, 2, 1, 75, 3, 0, {"_waves": 2})),        # fewer than 2 images per rank: one wave after all
+])
+def test_batch_in_two_waves_gives_the_same_files(world, n, case):
+    assert _run(_worker_batch, world, (n,) + case + (False,), timeout=300) is True
+
+
+@pytest.mark.parametrize("world,fail_rank", [(3, 1), (3, 0), (8, 5)])
+def test_batch_a_failing_rank_makes_every_rank_raise(world, fail_rank):
+    assert _run(_worker_batch, world, (2 * world + 1, 32, 24, 2, 1, 80, 0, 0, {"_fail_rank": fail_rank}, False), timeout=300) is True
 
 
 def test_batch_partition_rule():

@@ -11,6 +11,7 @@
 #   kstats <name> <cmd...>    rocprofv3 --kernel-trace --stats of <cmd>, the kernel_stats csv copied to <tag>/<name>_kernel_stats.csv
 #   pmc <name> <filter> <cmd...>   separate rocprofv3 --pmc passes (tools/pmc_summary.py on kernels matching <filter>)
 #   issue <name> <filter> <cmd...> one PMC pass -> issue_<name>.json: VALU-busy fraction of the kernel (tools/issue_profile.py)
+#   traffic <name> <filter> <algorithmic bytes> <cmd...>   FETCH_SIZE / WRITE_SIZE passes -> traffic_<name>.json + raw rows
 #   py <script> [args]        python <script> (tools/*.py probes)
 set -u
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$ROOT"; export TMPDIR=/tmp
@@ -79,6 +80,34 @@ recipe_issue() {
   f=$(find "/tmp/issue_$name" -name "*counter_collection*" | head -1)
   # (the raw counter rows of the kernels matching the filter travel with the summary: profiles/issue_<name>_raw.csv)
   if [ -n "$f" ]; then python "$ROOT/tools/issue_profile.py" "$f" "$filt" "$O/issue_$name.json" "$name"; (head -1 "$f"; grep -F "$filt" "$f") > "$O/issue_${name}_raw.csv"; else tail -5 "$O/issue_${name}.log"; fi
+}
+# traffic <name> <kernel substring> <algorithmic bytes> <cmd...>: HBM bytes per launch of one kernel — separate --pmc passes for
+# FETCH_SIZE and WRITE_SIZE (MI355X_MICROARCH.md: TCC counters do not fit one pass), FETCH_SIZE x 2 on gfx950 —
+# -> gpurun_out/<tag>/traffic_<name>.json + the raw counter rows traffic_<name>_raw.csv
+recipe_traffic() {
+  name="$1"; filt="$2"; alg="$3"; shift 3
+  absargs "$@"; set -- "${ABS[@]}"
+  : > "$O/traffic_${name}_raw.csv"
+  for PMC in FETCH_SIZE WRITE_SIZE; do
+    rm -rf "/tmp/traffic_${name}_$PMC"
+    (cd /tmp && timeout 400 rocprofv3 --pmc $PMC --output-format csv -d "/tmp/traffic_${name}_$PMC" -o pmc -- "$@" > "$ROOT/$O/traffic_${name}_$PMC.log" 2>&1)
+    f=$(find "/tmp/traffic_${name}_$PMC" -name "*counter_collection*" | head -1)
+    [ -n "$f" ] && { [ -s "$O/traffic_${name}_raw.csv" ] || head -1 "$f" > "$O/traffic_${name}_raw.csv"; grep -F "$filt" "$f" >> "$O/traffic_${name}_raw.csv"; }
+  done
+  python3 - "$O/traffic_${name}_raw.csv" "$O/traffic_$name.json" "$alg" "$name" <<'PY'
+import collections, csv, json, sys
+acc = collections.defaultdict(list)
+kern = None
+for row in csv.DictReader(open(sys.argv[1])):
+    acc[row["Counter_Name"]].append(float(row["Counter_Value"])); kern = row["Kernel_Name"].split("(")[0]
+rd = sum(acc["FETCH_SIZE"]) / max(1, len(acc["FETCH_SIZE"])) * 1024 * 2   # KiB, x 2: the gfx950 correction for wide streaming reads
+wr = sum(acc["WRITE_SIZE"]) / max(1, len(acc["WRITE_SIZE"])) * 1024
+alg = int(sys.argv[3])
+d = {"kernel": kern, "label": sys.argv[4], "hbm_bytes_per_launch": round(rd + wr), "read_bytes": round(rd), "write_bytes": round(wr),
+     "launches": [len(acc["FETCH_SIZE"]), len(acc["WRITE_SIZE"])], "algorithmic_bytes": alg, "over_algorithmic": round((rd + wr) / alg, 4) if alg else None,
+     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (KiB; FETCH_SIZE x 2 on gfx950, MI355X_MICROARCH.md HBM section); raw rows: traffic_%s_raw.csv" % sys.argv[4]}
+json.dump(d, open(sys.argv[2], "w"), indent=1); print(json.dumps(d))
+PY
 }
 recipe_py() { timeout 900 python "$@" 2>&1 | tail -60; }
 

@@ -181,6 +181,8 @@ int pixo_hip_jpeg_encode_batch_device(const void *d_pixels, const pixo_jpeg_opti
  * hold the files of the first sub-batches.  `arena` may also be DEVICE memory (hipMalloc, on the current device): the
  * files then stay in HBM, complete with headers and EOI, for a caller that moves them on itself — pixo_amd/sharded.py
  * gathers the files of a batch that was scattered over several GPUs with RCCL ("C3 batch").
+ * (A batch that is NOT coded in one pass — optimize_huffman, progressive scans, restart markers — reaches a device arena image by
+ * image through host files: every image crosses PCIe twice there; a too small arena is noticed only after all images were coded.)
  * Replaces a loop over pixo::jpeg::encode_into (src/jpeg/mod.rs:328). */
 int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg_options *options, uint32_t batch,
                                            uint8_t *arena, size_t capacity, size_t *offsets, size_t *lens);

@@ -132,7 +132,7 @@ __device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t
 // adds up its block — its own aggregate and the 63 before it, one round — and publishes the block's sum in `sup`; a group
 // then needs the aggregates in front of it inside its own block (<= 63, one load per lane) and the sums of all blocks
 // before (one load per lane and 4096 groups), all issued together.  Critical path: aggregates -> block sums -> done, two
-// fabric round trips, where the chained form above takes g / 128 rounds when all groups of a launch arrive at once (a
+// fabric round trips, where the chained form above takes up to g / 64 rounds (64 predecessors per round) when all groups of a launch arrive at once (a
 // smooth image: 4.5 us median, 8 us for the last groups of 2048; profiles/r04_scan_code_timeline.txt).
 // desc[g] must hold kFlagAggregate | aggregate (publish_aggregate also writes kFlagPrefix for the floor: any flag counts).
 // `sup`: the chain's block sums (zero before the launch).  Every lane returns the sum; kLookBackFailed: gave up waiting.

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const bool last_group = first_in_chain + group_blocks >= nblocks_chain;
         // The stream word two groups share travels as the earlier group's `tail`.  A group WITHOUT bits (192 empty blocks) is
         // transparent for it: it says so at once, and the group that needs the word finds the last group with bits by a
-        // look-back over the tails (512 per round) — passing the word on from group to group made one chain of waits out
+        // look-back over the tails (64 per round, kLookBatch = 1) — passing the word on from group to group made one chain of waits out
         // of every run of empty groups (a smooth 4096x4096 image: 1,366 groups in a row, 276 us for the launch).
         const bool transparent = group_bits == 0 && !last_group;
         if (transparent) { // nothing to place: its B descriptor stays an aggregate of zero bits, which later groups walk past

@@ -168,8 +168,9 @@ def encode_into(output: bytearray, data, options: JpegOptions) -> None:
 def encode_into_buffer(buffer: np.ndarray, data, options: JpegOptions) -> int:
     """The fixed-capacity form of `encode_into` (`pixo_hip_jpeg_encode_into`): writes the file into the
     caller's uint8 array and returns its length.  Raises `error.BufferTooSmall` (its `.needed` says how
-    many bytes the file has) without touching `buffer` when it does not fit — the reserve-and-retry
-    protocol a Rust `Vec` would use."""
+    many bytes the file has) when it does not fit — the reserve-and-retry protocol a Rust `Vec` would use.  What `buffer`
+    holds after that error is unspecified: pageable memory is left alone, but a PINNED buffer is written by the GPU directly,
+    up to its capacity and never beyond (include/pixo_hip.h)."""
     L = _lib.load()
     px = _as_u8(data)
     if buffer.dtype != np.uint8 or not buffer.flags["C_CONTIGUOUS"]:
@@ -330,7 +331,8 @@ def encode_device(d_pixels, options: JpegOptions) -> bytes:
 def encode_device_into(buffer, d_pixels, options: JpegOptions) -> int:
     """Device pixels -> file written straight into `buffer` (a contiguous uint8 numpy array or a torch CPU
     tensor, ideally pinned: then the device-to-host copy is the only pass over the file).  Returns the
-    file's length; raises `error.BufferTooSmall` (with `.needed`) without copying when it does not fit."""
+    file's length; raises `error.BufferTooSmall` (with `.needed`) when it does not fit — a pinned `buffer` may then have been
+    written up to its capacity (small files are stored into pinned memory by the stuffing kernel itself), never beyond it."""
     L = _lib.load()
     if hasattr(buffer, "data_ptr"):
         ptr, cap = buffer.data_ptr(), buffer.numel() * buffer.element_size()

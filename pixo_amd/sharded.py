@@ -26,6 +26,8 @@ multi-GPU form, `encode_batch`: whole images travel from the source rank to the 
 xGMI link, all posted at once), every rank encodes its images (src/jpeg/mod.rs:88 per image), and the finished FILES
 travel to `dst` the same way — pixels out, files back, never a coefficient.
 """
+import os
+
 import numpy as np
 
 from . import jpeg
@@ -134,13 +136,22 @@ class SharedFile:
 
     def __init__(self, name, size, create):
         from multiprocessing import shared_memory
+        self._owner = None
         try:
             self.shm = shared_memory.SharedMemory(name=name, create=create, size=size if create else 0)
-        except FileExistsError:  # a segment of that name left behind by a run that died: the creating rank owns the name
+        except FileExistsError:
+            # A segment of that name exists.  Left behind by a run that died: replace it.  In use by a LIVE process (another job
+            # on the node that chose the same name): refuse — unlinking it would take the other job's file away under it
+            # (ADVICE r4).  Who made a segment is written into a small companion segment "<name>.owner" (its pid).
+            owner = self._read_owner(name)
+            if owner is not None and owner != os.getpid() and self._alive(owner):
+                raise FileExistsError("SharedFile %r is in use by live process %d: names must be unique per job" % (name, owner))
             stale = shared_memory.SharedMemory(name=name, create=False)
             stale.close()
             stale.unlink()
             self.shm = shared_memory.SharedMemory(name=name, create=True, size=size)
+        if create:
+            self._write_owner(name)
         if not create:  # (Python < 3.13 registers attached segments with the resource tracker too, which then unlinks — or complains
             try:        # about — a segment this process does not own when the process ends)
                 from multiprocessing import resource_tracker
@@ -149,6 +160,41 @@ class SharedFile:
                 pass
         self.size = size
         self.registered = False
+
+    @staticmethod
+    def _alive(pid):
+        try:
+            os.kill(pid, 0)
+            return True
+        except ProcessLookupError:
+            return False
+        except PermissionError:
+            return True
+
+    @staticmethod
+    def _read_owner(name):
+        from multiprocessing import shared_memory
+        try:
+            o = shared_memory.SharedMemory(name=name + ".owner", create=False)
+        except FileNotFoundError:
+            return None  # (made by an older version, or its maker died before writing: treated as stale)
+        try:
+            from multiprocessing import resource_tracker
+            resource_tracker.unregister(o._name, "shared_memory")
+        except Exception:
+            pass
+        pid = int.from_bytes(bytes(o.buf[:8]), "little")
+        o.close()
+        return pid or None
+
+    def _write_owner(self, name):
+        from multiprocessing import shared_memory
+        try:
+            o = shared_memory.SharedMemory(name=name + ".owner", create=True, size=8)
+        except FileExistsError:
+            o = shared_memory.SharedMemory(name=name + ".owner", create=False)
+        o.buf[:8] = os.getpid().to_bytes(8, "little")
+        self._owner = o
 
     def array(self):
         return np.ndarray((self.size,), dtype=np.uint8, buffer=self.shm.buf)
@@ -168,6 +214,14 @@ class SharedFile:
         self.shm.close()
         if unlink:
             self.shm.unlink()
+        if self._owner is not None:
+            self._owner.close()
+            if unlink:
+                try:
+                    self._owner.unlink()
+                except FileNotFoundError:
+                    pass
+            self._owner = None
 
 
 def shared_file_bound(options) -> int:

@@ -76,3 +76,25 @@ def test_fused_kernel_tall_narrow_and_many_rows():
     for (w, h) in [(16, 4096), (40, 3000), (520, 1500)]:
         _both(synth.noise(w, h, 5), w, h, 1, 85)
         _both(synth.noise(w, h, 6), w, h, 0, 60)
+
+
+def test_pinned_destination_one_byte_short_is_never_written_beyond_its_capacity():
+    """small files are stored into a pinned destination by the stuffing kernel itself.  A destination that is one
+    byte short (or holds only the headers + 2 bytes) must get BufferTooSmall with the size needed, and the guard bytes behind
+    its capacity must stay untouched."""
+    import torch
+    from pixo_amd import error
+    w, h = 256, 160
+    px = synth.noise(w, h, 9)
+    o = _opts(w, h, 1, 80)
+    want = O.encode(px, O.make_options(w, h, 2, 80, 1))
+    d = torch.from_numpy(np.ascontiguousarray(px)).cuda()
+    for cap in (len(want) - 1, 700, 625):
+        pinned = torch.full((len(want) + 64,), 0xA5, dtype=torch.uint8).pin_memory()
+        with pytest.raises(error.BufferTooSmall) as e:
+            jpeg.encode_device_into(pinned[:cap], d, o)
+        assert e.value.needed == len(want)
+        assert bool((pinned[cap:] == 0xA5).all()), "bytes behind the capacity were written"
+    pinned = torch.full((len(want) + 64,), 0xA5, dtype=torch.uint8).pin_memory()
+    n = jpeg.encode_device_into(pinned[: len(want)], d, o)
+    assert n == len(want) and pinned[:n].numpy().tobytes() == want and bool((pinned[n:] == 0xA5).all())

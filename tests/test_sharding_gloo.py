@@ -453,3 +453,28 @@ def test_shared_file_replaces_a_stale_segment_of_the_same_name():
         assert b.array().size == 8192 and int(b.array()[:4].sum()) == 0
     finally:
         b.close(unlink=True)
+
+
+def test_shared_file_refuses_a_name_that_a_live_process_holds():
+    """create=True must not unlink a segment that another LIVE job uses; a dead maker's segment is replaced."""
+    import subprocess
+    from pixo_amd import sharded
+    name = "pixo_test_live_%d" % os.getpid()
+    code = ("import sys, time; sys.path.insert(0, %r); from pixo_amd import sharded; s = sharded.SharedFile(%r, 4096, create=True); "
+            "s.array()[:4] = 9; print('up', flush=True); time.sleep(30)" % (os.path.dirname(HERE), name))
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True)
+    try:
+        assert p.stdout.readline().strip() == "up"
+        with pytest.raises(FileExistsError):
+            sharded.SharedFile(name, 4096, create=True)
+        peer = sharded.SharedFile(name, 4096, create=False)  # attaching is what the other ranks of that job do: fine
+        assert int(peer.array()[:4].sum()) == 36
+        peer.close()
+    finally:
+        p.kill()
+        p.wait()
+    b = sharded.SharedFile(name, 8192, create=True)  # its maker is dead now: stale, replaced
+    try:
+        assert b.array().size == 8192 and int(b.array()[:4].sum()) == 0
+    finally:
+        b.close(unlink=True)

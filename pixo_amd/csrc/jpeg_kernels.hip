@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     }
     float v[64];
     consumer_rows<MODE>(wave, lane, lds, v);
-    consumer_cols(v);
+    consumer_cols<MODE>(v);
     if (RAW) { // hand the transformed blocks to the trellis quantiser instead of quantising here
         store_raw_block<MODE>(a, c, id, wave, lane, v);
         return;

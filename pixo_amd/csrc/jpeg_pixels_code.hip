@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     {
         float v[64];
         consumer_rows<MODE>(wave, lane, lds, v);
-        consumer_cols(v);
+        consumer_cols<MODE>(v);
         consumer_quant<MODE>(wave, lane, a_qt, v, qw);
     }
     // ---- from here on: the group's part of the entropy-coded scan ----------------------------------------------------------

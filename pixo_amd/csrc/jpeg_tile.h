@@ -680,22 +680,22 @@ PIXO_DEV void rows2_from_u16(u32x4 a, u32x4 b, pixo_cf2 *d)
 // SHIFT (row pass): the samples come unshifted (true inputs b_i - L).  The butterflies' sums carry +2L, +4L, +8L and the
 // differences nothing, so only r0 needs the shift (8L = dc_shift).  Every value up to the first multiplication is an exact
 // integer below 2^14, so the reference's own sequence of f32 additions yields the same numbers.
-template <bool SHIFT>
-PIXO_DEV void aan8_pair(pixo_cf2 dc_shift, const pixo_cf2 *d, pixo_cf2 *r)
+template <bool SHIFT, class T = pixo_cf2>
+PIXO_DEV void aan8_pair(T dc_shift, const T *d, T *r)
 {
-    const pixo_cf2 t0 = d[0] + d[7], t7 = d[0] - d[7], t1 = d[1] + d[6], t6 = d[1] - d[6];
-    const pixo_cf2 t2 = d[2] + d[5], t5 = d[2] - d[5], t3 = d[3] + d[4], t4 = d[3] - d[4];
-    const pixo_cf2 e0 = t0 + t3, e3 = t0 - t3, e1 = t1 + t2, e2 = t1 - t2;
+    const T t0 = d[0] + d[7], t7 = d[0] - d[7], t1 = d[1] + d[6], t6 = d[1] - d[6];
+    const T t2 = d[2] + d[5], t5 = d[2] - d[5], t3 = d[3] + d[4], t4 = d[3] - d[4];
+    const T e0 = t0 + t3, e3 = t0 - t3, e1 = t1 + t2, e2 = t1 - t2;
     r[0] = SHIFT ? (e0 + e1) - dc_shift : e0 + e1;
     r[4] = e0 - e1;
-    const pixo_cf2 z1 = (e2 + e3) * PIXO_A1;
+    const T z1 = (e2 + e3) * PIXO_A1;
     r[2] = e3 + z1; r[6] = e3 - z1;
-    const pixo_cf2 o0 = t4 + t5, o1 = t5 + t6, o2 = t6 + t7;
-    const pixo_cf2 z5 = (o0 - o2) * PIXO_A5;
-    const pixo_cf2 z2 = o0 * PIXO_A2 + z5;
-    const pixo_cf2 z4 = o2 * PIXO_A4 + z5;
-    const pixo_cf2 z3 = o1 * PIXO_A1; // A3 == A1
-    const pixo_cf2 z11 = t7 + z3, z13 = t7 - z3;
+    const T o0 = t4 + t5, o1 = t5 + t6, o2 = t6 + t7;
+    const T z5 = (o0 - o2) * PIXO_A5;
+    const T z2 = o0 * PIXO_A2 + z5;
+    const T z4 = o2 * PIXO_A4 + z5;
+    const T z3 = o1 * PIXO_A1; // A3 == A1
+    const T z11 = t7 + z3, z13 = t7 - z3;
     r[5] = z13 + z2; r[3] = z13 - z2; r[1] = z11 + z4; r[7] = z11 - z4;
 }
 // the scale factors that close each pass (dct.rs:689-699)
@@ -830,7 +830,19 @@ PIXO_DEV void quant_row8(const float *x, const QPair *r, qtab_t q, float scale, 
 //                             mean - 128 = (S - 512)/4 = -(S' - 508)/4      row DC shift 8*508 = 4064, scale -1/4
 // `src` points at this lane's first planar row; rows are `pitch` bytes apart and are read from
 // LDS as the row pass needs them (2-4 registers), not staged in 16-32 registers.
-template <bool U16>
+// The two passes exist in two forms with the SAME arithmetic (aan8_pair on float or on pairs):
+//   scalar   one row / one column at a time, plain v_add / v_sub / v_mul_f32
+//   packed   two rows / two neighbouring columns at a time, v_pk_add_f32 / v_pk_mul_f32 (round 4: columns, round 5: rows)
+// Which one a kernel uses is decided by MEASUREMENT, per mode (profiles/r05_ab_scalar_vs_packed.txt, same-process A/B of library
+// variants, 21 rounds of 200 launches): one 4096x4096 4:2:0 image — the metric, a single generation of workgroups whose last
+// tiles run with one or two wavefronts per SIMD — is 0.3-0.6 us FASTER with the scalar passes although they issue 13 % more
+// vector instructions (scalar 17.98 / 18.58 us on two boxes where packed rows + columns took 18.61 / 18.93, the plain copy
+// 17.71 / 17.95): few wavefronts cannot hide the packed instructions' latency, and the instruction count is not what bounds
+// that launch.  4:4:4 (two generations, issue-bound) is 2 % faster packed (30.4 against 31.0 us); the 64-image batch is the
+// same either way (138.9 / 139.2 us).  So: 4:2:0 scalar, 4:4:4 and gray packed.
+// Scheduling fences: the scalar column pass runs without any (the compiler interleaves the eight columns; c8 in the profile),
+// the scalar row pass is pinned row by row (r1), the 4:2:0 quantiser runs unfenced (q0): together another 0.3 us.
+template <bool U16, bool PACKED>
 PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v)
 {
     // all eight planar rows are fetched first (16 or 32 registers that are free this early:
@@ -843,8 +855,34 @@ PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v
         else raw8[r] = *(const u32x2 *)(src + r * pitch);
     }
     PIXO_SCHED_FENCE();
-    // Round 5: the row pass on PAIRS of rows — 35 packed instructions + 16 plain multiplications per row pair where two
-    // scalar transforms took 86 (7.67 M -> 6.8 M vector instructions per 4096x4096 launch).
+    if (!PACKED) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            float d[8], o[8];
+            if (U16) {
+                const u32x4 w = raw16[r];
+                d[0] = (float)(w.x & 0xFFFF); d[1] = (float)(w.x >> 16); d[2] = (float)(w.y & 0xFFFF); d[3] = (float)(w.y >> 16);
+                d[4] = (float)(w.z & 0xFFFF); d[5] = (float)(w.z >> 16); d[6] = (float)(w.w & 0xFFFF); d[7] = (float)(w.w >> 16);
+            } else {
+                const uint32_t lo = raw8[r].x, hi = raw8[r].y;
+                d[0] = (float)(lo & 0xFF); d[1] = (float)((lo >> 8) & 0xFF); d[2] = (float)((lo >> 16) & 0xFF); d[3] = (float)(lo >> 24);
+                d[4] = (float)(hi & 0xFF); d[5] = (float)((hi >> 8) & 0xFF); d[6] = (float)((hi >> 16) & 0xFF); d[7] = (float)(hi >> 24);
+            }
+            // (keeps LLVM from folding the first butterflies into integer SDWA adds + conversions: twice as many half-rate instructions)
+#pragma unroll
+            for (int i = 0; i < 8; i++) PIXO_PIN(d[i]);
+            aan8_pair<true, float>(dc_shift, d, o);
+            float *lo = &v[r * 8];
+            lo[0] = o[0] * PIXO_S0; lo[1] = o[1] * PIXO_S1; lo[2] = o[2] * PIXO_S2; lo[3] = o[3] * PIXO_S3;
+            lo[4] = o[4] * PIXO_S4; lo[5] = o[5] * PIXO_S5; lo[6] = o[6] * PIXO_S6; lo[7] = o[7] * PIXO_S7;
+            // finish the row (scale multiplications included) before the next one starts: left free, the compiler batches
+            // all 64 scale multiplications after row 7 into fresh registers
+#pragma unroll
+            for (int i = 0; i < 8; i++) PIXO_PIN(v[r * 8 + i]);
+            PIXO_SCHED_FENCE();
+        }
+        return;
+    }
     const pixo_cf2 shift2 = {dc_shift, dc_shift};
 #pragma unroll
     for (int r = 0; r < 8; r += 2) {
@@ -857,35 +895,43 @@ PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v
         lo[2] = o[2].x * PIXO_S2; hi[2] = o[2].y * PIXO_S2; lo[3] = o[3].x * PIXO_S3; hi[3] = o[3].y * PIXO_S3;
         lo[4] = o[4].x * PIXO_S4; hi[4] = o[4].y * PIXO_S4; lo[5] = o[5].x * PIXO_S5; hi[5] = o[5].y * PIXO_S5;
         lo[6] = o[6].x * PIXO_S6; hi[6] = o[6].y * PIXO_S6; lo[7] = o[7].x * PIXO_S7; hi[7] = o[7].y * PIXO_S7;
-        // finish both rows (scale multiplications included) before the next pair starts: left free, the compiler
-        // batches all 64 scale multiplications after row 7 into fresh registers
 #pragma unroll
         for (int i = 0; i < 16; i++) PIXO_PIN(v[r * 8 + i]);
         PIXO_SCHED_FENCE();
     }
 }
 
-// The column pass on PAIRS of neighbouring columns (round 4): v[8 r + 2 k], v[8 r + 2 k + 1] as one aligned register
-// pair — 43 packed instructions per column pair where two scalar transforms take 86 at 0.6 of the packed instruction's
-// issue cost each (profiles/r03_ubench_form_rate.txt: 2.67 against 4.37 cycles).  Measured (profiles/r04_ab_packed_cols.txt):
-// 4:4:4 30.5 -> 30.0 us, the 64-image batch 139.1 -> 137.9 us — the issue-bound launches —, one 4:2:0 image unchanged.
-PIXO_DEV void block_cols(float *v)
+template <bool PACKED> PIXO_DEV void block_cols(float *v)
 {
+    if (!PACKED) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        pixo_cf2 d[8], o[8];
+        for (int c = 0; c < 8; c++) {
+            float d[8], o[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) { d[r] = (pixo_cf2){v[8 * r + 2 * k], v[8 * r + 2 * k + 1]}; PIXO_PIN2(d[r]); }
-        aan8_pair<false>((pixo_cf2){0.0f, 0.0f}, d, o);
-        o[0] = o[0] * PIXO_S0; o[1] = o[1] * PIXO_S1; o[2] = o[2] * PIXO_S2; o[3] = o[3] * PIXO_S3;
-        o[4] = o[4] * PIXO_S4; o[5] = o[5] * PIXO_S5; o[6] = o[6] * PIXO_S6; o[7] = o[7] * PIXO_S7;
+            for (int r = 0; r < 8; r++) d[r] = v[8 * r + c];
+            aan8_pair<false, float>(0.0f, d, o);
+            v[c] = o[0] * PIXO_S0; v[8 + c] = o[1] * PIXO_S1; v[16 + c] = o[2] * PIXO_S2; v[24 + c] = o[3] * PIXO_S3;
+            v[32 + c] = o[4] * PIXO_S4; v[40 + c] = o[5] * PIXO_S5; v[48 + c] = o[6] * PIXO_S6; v[56 + c] = o[7] * PIXO_S7;
+        }
+    } else {
+        // pairs of neighbouring columns: v[8 r + 2 k], v[8 r + 2 k + 1] as one aligned register pair
 #pragma unroll
-        for (int r = 0; r < 8; r++) { PIXO_PIN2(o[r]); v[8 * r + 2 * k] = o[r].x; v[8 * r + 2 * k + 1] = o[r].y; }
-        PIXO_SCHED_FENCE();
+        for (int k = 0; k < 4; k++) {
+            pixo_cf2 d[8], o[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) { d[r] = (pixo_cf2){v[8 * r + 2 * k], v[8 * r + 2 * k + 1]}; PIXO_PIN2(d[r]); }
+            aan8_pair<false>((pixo_cf2){0.0f, 0.0f}, d, o);
+            o[0] = o[0] * PIXO_S0; o[1] = o[1] * PIXO_S1; o[2] = o[2] * PIXO_S2; o[3] = o[3] * PIXO_S3;
+            o[4] = o[4] * PIXO_S4; o[5] = o[5] * PIXO_S5; o[6] = o[6] * PIXO_S6; o[7] = o[7] * PIXO_S7;
+#pragma unroll
+            for (int r = 0; r < 8; r++) { PIXO_PIN2(o[r]); v[8 * r + 2 * k] = o[r].x; v[8 * r + 2 * k + 1] = o[r].y; }
+            PIXO_SCHED_FENCE();
+        }
     }
 #pragma unroll
     for (int i = 0; i < 64; i++) PIXO_PIN(v[i]);
 }
+template <int MODE> constexpr bool packed_passes() { return MODE != M420; }
 
 // What the block of lane `lane` of consumer wave `wave` is, and where its planar rows start
 // (everything wave-uniform except src).
@@ -921,12 +967,12 @@ template <int MODE> PIXO_DEV BlockDesc block_desc(int wave, int lane, const uint
 template <int MODE> PIXO_DEV void consumer_rows(int wave, int lane, const uint8_t *planar, float *v)
 {
     const BlockDesc d = block_desc<MODE>(wave, lane, planar);
-    if (MODE == M420 && d.u16) block_rows<true>(d.src, 512, kChromaSumShift, v);
-    else block_rows<false>(d.src, d.pitch, d.dc_shift, v);
+    if (MODE == M420 && d.u16) block_rows<true, packed_passes<MODE>()>(d.src, 512, kChromaSumShift, v);
+    else block_rows<false, packed_passes<MODE>()>(d.src, d.pitch, d.dc_shift, v);
 }
 
 // Consumer step 2: column pass (registers only).
-PIXO_DEV void consumer_cols(float *v) { block_cols(v); }
+template <int MODE> PIXO_DEV void consumer_cols(float *v) { block_cols<packed_passes<MODE>()>(v); }
 
 // ---------------------------------------------------------------------------------
 // Whole-block write-out.  Two 64-byte halves of a 128-byte block stored a microsecond apart cost
@@ -945,6 +991,7 @@ PIXO_DEV int stage_addr_block(int bl, int r) { return bl * 128 + (((r ^ bl) & 7)
 // Consumer step 3': quantise the lane's block, row r -> out[4 r .. 4 r + 3] (packed i16 pairs).
 // The reciprocals are wave-uniform scalar (SMEM) loads, fetched one row ahead of their use so that
 // their latency hides under the previous row's arithmetic.
+template <bool FENCED>
 PIXO_DEV void block_quant(const float *v, qtab_t rcp, qtab_t q, float scale, uint32_t *out)
 {
     QPair r[8], r_n[8]; // (rlo, rhi) of coefficient i at rcp[2 i], rcp[2 i + 1]: one aligned scalar register pair each
@@ -961,7 +1008,7 @@ PIXO_DEV void block_quant(const float *v, qtab_t rcp, qtab_t q, float scale, uin
         quant_row8(&v[u * 8], r, q + u * 8, scale, &out[u * 4]);
         // the row's four result registers exist from here on (and its eight floats are dead)
         PIXO_PIN(out[u * 4]); PIXO_PIN(out[u * 4 + 1]); PIXO_PIN(out[u * 4 + 2]); PIXO_PIN(out[u * 4 + 3]);
-        PIXO_SCHED_FENCE();
+        if (FENCED) PIXO_SCHED_FENCE(); // (4:2:0 runs the rows unfenced: profiles/r05_ab_scalar_vs_packed.txt)
 #pragma unroll
         for (int c = 0; c < 8; c++) r[c] = r_n[c];
     }
@@ -970,7 +1017,7 @@ template <int MODE> PIXO_DEV void consumer_quant(int wave, int lane, const float
 {
     const BlockDesc d = block_desc<MODE>(wave, lane, nullptr);
     const qtab_t tab = as_qtab(qt);
-    block_quant(v, tab + uniform_i32(d.rcp_off), tab + uniform_i32(d.q_off), d.scale, out);
+    block_quant<MODE != M420>(v, tab + uniform_i32(d.rcp_off), tab + uniform_i32(d.q_off), d.scale, out);
 }
 
 // Consumer step 4' (round h = 0, 1): the lanes of half h stage their blocks.

@@ -41,7 +41,7 @@ static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long
                 // a wavefront runs these steps in lockstep: every lane finishes a step before any
                 // lane starts the next (the stage is written by block and read back by chunk)
                 for (int l = 0; l < 64; l++) consumer_rows<MODE>(w, l, planar, &v[(w * 64 + l) * 64]);
-                for (int l = 0; l < 64; l++) consumer_cols(&v[(w * 64 + l) * 64]);
+                for (int l = 0; l < 64; l++) consumer_cols<MODE>(&v[(w * 64 + l) * 64]);
                 // the shipped write-out: whole block into registers, two rounds of 32 blocks through the stage
                 static thread_local uint32_t qw[64 * 32];
                 for (int l = 0; l < 64; l++) consumer_quant<MODE>(w, l, c.qt, &v[(w * 64 + l) * 64], &qw[l * 32]);

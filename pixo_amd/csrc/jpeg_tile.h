@@ -769,18 +769,28 @@ PIXO_DEV uint32_t pack_lo16(uint32_t hi, uint32_t lo)
     return perm(hi, lo, 0x05040100u);
 }
 // four coefficients -> two registers of packed i16 pairs
+// PACKED: the two roundings of a coefficient by ONE v_pk_fma_f32 (round 3) — or, not PACKED, by two v_fma_f32 with a scalar
+// operand each.  The packed form issues half as many instructions and is what the issue-bound launches want (4:4:4); on the
+// one-generation 4:2:0 launch the plain form is 0.5 us FASTER (19.06 -> 18.53 us, profiles/r05_ab_scalar_vs_packed.txt), like
+// the scalar DCT passes: few wavefronts per SIMD at the launch's end, and packed f32 instructions do not pipeline behind each other.
+template <bool PACKED>
 PIXO_DEV void quant_row4(const float *x, const QPair *r, qtab_t q, float scale, uint32_t out[2])
 {
     float s[4];
     uint32_t differ = 0;
-#if defined(PIXO_EMU)
+#if !defined(PIXO_EMU)
+    if (!PACKED) {
+#endif
 #pragma unroll
-    for (int c = 0; c < 4; c++) differ |= quant_bracket_pair(x[c], r[c], &s[c]);
-#else
+        for (int c = 0; c < 4; c++) differ |= quant_bracket(x[c], r[c].lo, r[c].hi, &s[c]);
+#if !defined(PIXO_EMU)
+        PIXO_PIN(differ);
+    }
+    pixo_f2 xx[2];
+    if (PACKED) {
     // Two neighbouring coefficients share one aligned register pair and each multiply-add broadcasts its own half
     // (op_sel).  The pair is pinned as a pair: left to itself the compiler makes every x the LOW half of a pair of its
     // own — 64 live floats then want 128 registers and the kernel spills 136.
-    pixo_f2 xx[2];
 #pragma unroll
     for (int c = 0; c < 4; c += 2) {
         xx[c / 2] = (pixo_f2){x[c], x[c + 1]};
@@ -792,6 +802,7 @@ PIXO_DEV void quant_row4(const float *x, const QPair *r, qtab_t q, float scale, 
         differ |= (fbits(p0.x) ^ fbits(p0.y)) | (fbits(p1.x) ^ fbits(p1.y));
     }
     PIXO_PIN(differ); // (as bit operations — one per coefficient; otherwise it becomes a compare per coefficient again)
+    }
 #endif
     // low 16 bits of each s = the i16 result (never saturates: |x/q| <= 2^11)
     out[0] = pack_lo16(fbits(s[1]), fbits(s[0]));
@@ -803,11 +814,11 @@ PIXO_DEV void quant_row4(const float *x, const QPair *r, qtab_t q, float scale, 
 #if defined(PIXO_EMU)
             const float x0 = x[c];
 #else
-            const float x0 = (c & 1) ? xx[c / 2].y : xx[c / 2].x;
+            const float x0 = PACKED ? ((c & 1) ? xx[c / 2].y : xx[c / 2].x) : x[c];
 #endif
             float xc = x0, t;
             PIXO_PIN(xc); // recompute the test here: reusing the fast path's values keeps them all alive
-            if (PIXO_ANY_LANE(quant_bracket_pair(xc, r[c], &t) != 0)) {
+            if (PIXO_ANY_LANE((PACKED ? quant_bracket_pair(xc, r[c], &t) : quant_bracket(xc, r[c].lo, r[c].hi, &t)) != 0)) {
                 const float n = __builtin_roundf((x0 * scale) / q[c]); // the reference operation itself
                 s[c] = n + kRoundMagic;                                  // exact: |n| < 2^15
             }
@@ -817,11 +828,12 @@ PIXO_DEV void quant_row4(const float *x, const QPair *r, qtab_t q, float scale, 
         out[1] = pack_lo16(fbits(s[3]), fbits(s[2]));
     }
 }
+template <bool PACKED>
 PIXO_DEV void quant_row8(const float *x, const QPair *r, qtab_t q, float scale, uint32_t out[4])
 {
-    quant_row4(x, r, q, scale, out);
+    quant_row4<PACKED>(x, r, q, scale, out);
     PIXO_PIN(out[0]); PIXO_PIN(out[1]);
-    quant_row4(x + 4, r + 4, q + 4, scale, out + 2);
+    quant_row4<PACKED>(x + 4, r + 4, q + 4, scale, out + 2);
 }
 
 // Block kinds (wave-uniform): quantiser table, DC shift of the row pass, scale.
@@ -1005,7 +1017,7 @@ PIXO_DEV void block_quant(const float *v, qtab_t rcp, qtab_t q, float scale, uin
             for (int c = 0; c < 8; c++) { r_n[c].lo = rcp[2 * ((u + 1) * 8 + c)]; r_n[c].hi = rcp[2 * ((u + 1) * 8 + c) + 1]; }
             PIXO_SCHED_FENCE();
         }
-        quant_row8(&v[u * 8], r, q + u * 8, scale, &out[u * 4]);
+        quant_row8<FENCED>(&v[u * 8], r, q + u * 8, scale, &out[u * 4]); // (FENCED = the issue-bound modes: they also take the packed form)
         // the row's four result registers exist from here on (and its eight floats are dead)
         PIXO_PIN(out[u * 4]); PIXO_PIN(out[u * 4 + 1]); PIXO_PIN(out[u * 4 + 2]); PIXO_PIN(out[u * 4 + 3]);
         if (FENCED) PIXO_SCHED_FENCE(); // (4:2:0 runs the rows unfenced: profiles/r05_ab_scalar_vs_packed.txt)

@@ -119,7 +119,7 @@ extern "C" long emu_quant_mismatches(const float *x, long n, int qlo, int qhi)
         for (long i = 0; i + 8 <= n; i += 8) {
             uint32_t out[4];
             for (int k = 0; k < 8; k++) xx[k] = x[i + k];
-            quant_row8(xx, rr, as_qtab(qq), 1.0f, out);
+            quant_row8<false>(xx, rr, as_qtab(qq), 1.0f, out);
             for (int k = 0; k < 8; k++) {
                 int16_t got = (int16_t)(out[k >> 1] >> (16 * (k & 1)));
                 float want = roundf(xx[k] / fq);

@@ -152,7 +152,7 @@ __device__ __forceinline__ void store_raw_block(const KArgs &a, const TileCtx &c
     for (int i = 0; i < 64; i++) col[i * 64] = v[i] * scale;
 }
 
-template <int MODE, int LOAD, bool RAW = false>
+template <int MODE, int LOAD, bool RAW, bool PACKED>
 __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(const uint8_t *a_px, uint32_t a_W, uint32_t a_H, size_t a_px_stride, uint32_t a_grid,
                                                                               uint32_t a_unused, int16_t *a_y, int16_t *a_cb, int16_t *a_cr, const float *a_qt, const KRest rest)
 {
@@ -199,15 +199,15 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
         ctx_out(c, a, img);
     }
     float v[64];
-    consumer_rows<MODE>(wave, lane, lds, v);
-    consumer_cols<MODE>(v);
+    consumer_rows<MODE, PACKED>(wave, lane, lds, v);
+    consumer_cols<PACKED>(v);
     if (RAW) { // hand the transformed blocks to the trellis quantiser instead of quantising here
         store_raw_block<MODE>(a, c, id, wave, lane, v);
         return;
     }
     uint8_t *stage = lds + stage_offset<MODE>(wave); // inside this wavefront's own planar area
     uint32_t qw[32];
-    consumer_quant<MODE>(wave, lane, a.qt, v, qw);
+    consumer_quant<MODE, PACKED>(wave, lane, a.qt, v, qw);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         consumer_stage_blocks(lane, h, qw, stage);
@@ -230,8 +230,13 @@ template <int MODE, int LOAD> static hipError_t launch_mode(KArgs &a, hipStream_
     // tiles_x <= 128 (65535 / 512), tiles_y <= 8192 (65535 / 8)
     // (launches of 1280-1792 workgroups neither gain nor lose with it: tools/shape_timing.py, profiles/r03_stagger_length_ab.txt)
     const uint32_t a_grid = grid.x | (grid.y << 8) | ((uint64_t)grid.x * grid.y * grid.z >= 2048u ? 0x80000000u : 0u);
-    if (raw) hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, true>), grid, dim3(kThreads), 0, s, a.px, a.W, a.H, a.px_stride, a_grid, 0u, a.y, a.cb, a.cr, a.qt, rest);
-    else hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, false>), grid, dim3(kThreads), 0, s, a.px, a.W, a.H, a.px_stride, a_grid, 0u, a.y, a.cb, a.cr, a.qt, rest);
+    // one generation of workgroups (at most 2048: all resident at once): the scalar forms of the DCT passes and the quantiser;
+    // more: the packed forms (jpeg_tile.h, block_rows)
+    const bool packed = packed_launch((uint64_t)grid.x * grid.y * grid.z);
+#define PIXO_LAUNCH_C(RAW, PACKED) hipLaunchKernelGGL((jpeg_coeffs_kernel<MODE, LOAD, RAW, PACKED>), grid, dim3(kThreads), 0, s, a.px, a.W, a.H, a.px_stride, a_grid, 0u, a.y, a.cb, a.cr, a.qt, rest)
+    if (raw) { if (packed) PIXO_LAUNCH_C(true, true); else PIXO_LAUNCH_C(true, false); }
+    else { if (packed) PIXO_LAUNCH_C(false, true); else PIXO_LAUNCH_C(false, false); }
+#undef PIXO_LAUNCH_C
     return hipGetLastError();
 }
 

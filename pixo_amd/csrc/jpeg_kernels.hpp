@@ -6,6 +6,11 @@
 
 namespace pixo_dev {
 
+// Which form of the DCT passes and the quantiser a launch of `workgroups` tiles takes (jpeg_tile.h, block_rows): one generation
+// (all workgroups resident at once: 8 per CU x 256 CUs) is latency-bound at its end and runs the scalar forms; several
+// generations are issue-bound and run the packed ones.
+inline bool packed_launch(uint64_t workgroups) { return workgroups > 2048; }
+
 // Enqueues the fused colour -> DCT -> quantise kernel for `batch` equally sized images on
 // `stream`.  All pointers are device pointers; d_qt points at the 512-float table block of
 // the requested quality (layout in jpeg_tile.h).  d_cb/d_cr are ignored for gray input.

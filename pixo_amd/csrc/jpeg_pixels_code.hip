@@ -31,6 +31,7 @@
 // jpeg_scan_fused.hip); every wait is bounded and raises the abort flag.
 #include <hip/hip_runtime.h>
 
+#include "jpeg_kernels.hpp"
 #include "jpeg_pixels_code.hpp"
 #include "jpeg_scan_dev.h"
 #include "jpeg_tile.h"
@@ -97,7 +98,7 @@ __device__ __forceinline__ void phase_a_tab(const TileCtx &c, uint32_t tx, uint3
     }
 }
 
-template <int MODE, int LOAD>
+template <int MODE, int LOAD, bool PACKED>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void pixels_code_kernel
 (const uint8_t *a_px, uint32_t a_W, uint32_t a_H, const float *a_qt, uint32_t a_units_x, uint32_t a_units_y, const uint32_t *a_tables,
  unsigned long long *a_state, uint32_t *a_stream, const PRest rest)
@@ -129,9 +130,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     uint32_t qw[32];
     {
         float v[64];
-        consumer_rows<MODE>(wave, lane, lds, v);
-        consumer_cols<MODE>(v);
-        consumer_quant<MODE>(wave, lane, a_qt, v, qw);
+        consumer_rows<MODE, PACKED>(wave, lane, lds, v);
+        consumer_cols<PACKED>(v);
+        consumer_quant<MODE, PACKED>(wave, lane, a_qt, v, qw);
     }
     // ---- from here on: the group's part of the entropy-coded scan ----------------------------------------------------------
     const uint64_t ngroups = rest.groups, g = (uint64_t)ty * rest.tiles_x + tx;
@@ -376,7 +377,9 @@ hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s42
     const bool aligned = reinterpret_cast<uintptr_t>(d_px) % 4 == 0 && row_bytes % 4 == 0;
     const dim3 grid(tiles_x, tiles_y);
     const uint8_t *px = static_cast<const uint8_t *>(d_px);
-#define PIXO_LAUNCH_PC(MODE, LOAD) hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, units_x, units_y, d_tables, d_state, d_stream, rest)
+    const bool packed = packed_launch(groups); // (scalar or packed DCT passes and quantiser: jpeg_kernels.hpp)
+#define PIXO_LAUNCH_PC(MODE, LOAD) do { if (packed) hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, true>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, units_x, units_y, d_tables, d_state, d_stream, rest); \
+                                        else hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, false>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, units_x, units_y, d_tables, d_state, d_stream, rest); } while (0)
     if (s420) { if (aligned) PIXO_LAUNCH_PC(M420, L_ALIGNED); else PIXO_LAUNCH_PC(M420, L_FUNNEL); }
     else { if (aligned) PIXO_LAUNCH_PC(M444, L_ALIGNED); else PIXO_LAUNCH_PC(M444, L_FUNNEL); }
 #undef PIXO_LAUNCH_PC

@@ -845,15 +845,15 @@ PIXO_DEV void quant_row8(const float *x, const QPair *r, qtab_t q, float scale, 
 // The two passes exist in two forms with the SAME arithmetic (aan8_pair on float or on pairs):
 //   scalar   one row / one column at a time, plain v_add / v_sub / v_mul_f32
 //   packed   two rows / two neighbouring columns at a time, v_pk_add_f32 / v_pk_mul_f32 (round 4: columns, round 5: rows)
-// Which one a kernel uses is decided by MEASUREMENT, per mode (profiles/r05_ab_scalar_vs_packed.txt, same-process A/B of library
-// variants, 21 rounds of 200 launches): one 4096x4096 4:2:0 image — the metric, a single generation of workgroups whose last
-// tiles run with one or two wavefronts per SIMD — is 0.3-0.6 us FASTER with the scalar passes although they issue 13 % more
-// vector instructions (scalar 17.98 / 18.58 us on two boxes where packed rows + columns took 18.61 / 18.93, the plain copy
-// 17.71 / 17.95): few wavefronts cannot hide the packed instructions' latency, and the instruction count is not what bounds
-// that launch.  4:4:4 (two generations, issue-bound) is 2 % faster packed (30.4 against 31.0 us); the 64-image batch is the
-// same either way (138.9 / 139.2 us).  So: 4:2:0 scalar, 4:4:4 and gray packed.
-// Scheduling fences: the scalar column pass runs without any (the compiler interleaves the eight columns; c8 in the profile),
-// the scalar row pass is pinned row by row (r1), the 4:2:0 quantiser runs unfenced (q0): together another 0.3 us.
+// Which one a LAUNCH uses is decided by measurement (profiles/r05_ab_scalar_vs_packed.txt, same-process A/B of library variants,
+// 21 rounds of 200 launches): a launch of ONE generation of workgroups — at most 2048, the metric's 4096x4096 4:2:0 image —
+// ends with one or two wavefronts per SIMD, which cannot hide the packed instructions' latency: it is 0.5 us FASTER with the
+// scalar passes and the plain quantiser although they issue 20 % more vector instructions (17.86 us = 1.0006 x the plain copy
+// of the same bytes, where the round-4 kernel took 18.36 and packed rows + columns 18.6-18.9).  Launches of several generations
+// are issue-bound and want the packed forms: 4096x4096 4:4:4 30.0 against 31.0 us, the 64 x 1080p batch 138.9 against 143.8.
+// So the kernels exist in both forms and the launcher picks by the number of workgroups (jpeg_kernels.hip, packed_launch()).
+// Scheduling fences of the scalar form: none in the column pass (the compiler interleaves the eight columns; c8 in the profile),
+// the row pass pinned row by row (r1), the quantiser's rows unfenced (q0): together another 0.3 us.
 template <bool U16, bool PACKED>
 PIXO_DEV void block_rows(const uint8_t *src, int pitch, float dc_shift, float *v)
 {
@@ -943,7 +943,6 @@ template <bool PACKED> PIXO_DEV void block_cols(float *v)
 #pragma unroll
     for (int i = 0; i < 64; i++) PIXO_PIN(v[i]);
 }
-template <int MODE> constexpr bool packed_passes() { return MODE != M420; }
 
 // What the block of lane `lane` of consumer wave `wave` is, and where its planar rows start
 // (everything wave-uniform except src).
@@ -976,15 +975,15 @@ template <int MODE> PIXO_DEV BlockDesc block_desc(int wave, int lane, const uint
 }
 
 // Consumer step 1: planar rows -> registers, row pass.
-template <int MODE> PIXO_DEV void consumer_rows(int wave, int lane, const uint8_t *planar, float *v)
+template <int MODE, bool PACKED> PIXO_DEV void consumer_rows(int wave, int lane, const uint8_t *planar, float *v)
 {
     const BlockDesc d = block_desc<MODE>(wave, lane, planar);
-    if (MODE == M420 && d.u16) block_rows<true, packed_passes<MODE>()>(d.src, 512, kChromaSumShift, v);
-    else block_rows<false, packed_passes<MODE>()>(d.src, d.pitch, d.dc_shift, v);
+    if (MODE == M420 && d.u16) block_rows<true, PACKED>(d.src, 512, kChromaSumShift, v);
+    else block_rows<false, PACKED>(d.src, d.pitch, d.dc_shift, v);
 }
 
 // Consumer step 2: column pass (registers only).
-template <int MODE> PIXO_DEV void consumer_cols(float *v) { block_cols<packed_passes<MODE>()>(v); }
+template <bool PACKED> PIXO_DEV void consumer_cols(float *v) { block_cols<PACKED>(v); }
 
 // ---------------------------------------------------------------------------------
 // Whole-block write-out.  Two 64-byte halves of a 128-byte block stored a microsecond apart cost
@@ -1003,7 +1002,7 @@ PIXO_DEV int stage_addr_block(int bl, int r) { return bl * 128 + (((r ^ bl) & 7)
 // Consumer step 3': quantise the lane's block, row r -> out[4 r .. 4 r + 3] (packed i16 pairs).
 // The reciprocals are wave-uniform scalar (SMEM) loads, fetched one row ahead of their use so that
 // their latency hides under the previous row's arithmetic.
-template <bool FENCED>
+template <bool PACKED>
 PIXO_DEV void block_quant(const float *v, qtab_t rcp, qtab_t q, float scale, uint32_t *out)
 {
     QPair r[8], r_n[8]; // (rlo, rhi) of coefficient i at rcp[2 i], rcp[2 i + 1]: one aligned scalar register pair each
@@ -1017,19 +1016,19 @@ PIXO_DEV void block_quant(const float *v, qtab_t rcp, qtab_t q, float scale, uin
             for (int c = 0; c < 8; c++) { r_n[c].lo = rcp[2 * ((u + 1) * 8 + c)]; r_n[c].hi = rcp[2 * ((u + 1) * 8 + c) + 1]; }
             PIXO_SCHED_FENCE();
         }
-        quant_row8<FENCED>(&v[u * 8], r, q + u * 8, scale, &out[u * 4]); // (FENCED = the issue-bound modes: they also take the packed form)
+        quant_row8<PACKED>(&v[u * 8], r, q + u * 8, scale, &out[u * 4]);
         // the row's four result registers exist from here on (and its eight floats are dead)
         PIXO_PIN(out[u * 4]); PIXO_PIN(out[u * 4 + 1]); PIXO_PIN(out[u * 4 + 2]); PIXO_PIN(out[u * 4 + 3]);
-        if (FENCED) PIXO_SCHED_FENCE(); // (4:2:0 runs the rows unfenced: profiles/r05_ab_scalar_vs_packed.txt)
+        if (PACKED) PIXO_SCHED_FENCE(); // (the scalar form runs the rows unfenced: profiles/r05_ab_scalar_vs_packed.txt)
 #pragma unroll
         for (int c = 0; c < 8; c++) r[c] = r_n[c];
     }
 }
-template <int MODE> PIXO_DEV void consumer_quant(int wave, int lane, const float *qt, const float *v, uint32_t *out)
+template <int MODE, bool PACKED> PIXO_DEV void consumer_quant(int wave, int lane, const float *qt, const float *v, uint32_t *out)
 {
     const BlockDesc d = block_desc<MODE>(wave, lane, nullptr);
     const qtab_t tab = as_qtab(qt);
-    block_quant<MODE != M420>(v, tab + uniform_i32(d.rcp_off), tab + uniform_i32(d.q_off), d.scale, out);
+    block_quant<PACKED>(v, tab + uniform_i32(d.rcp_off), tab + uniform_i32(d.q_off), d.scale, out);
 }
 
 // Consumer step 4' (round h = 0, 1): the lanes of half h stage their blocks.

@@ -12,7 +12,7 @@
 
 using namespace pixo_tile;
 
-template <int MODE, int LOAD>
+template <int MODE, int LOAD, bool PACKED>
 static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long *stats, int wave_order)
 {
     typedef Geo<MODE> G;
@@ -40,11 +40,11 @@ static void run_image(const TileCtx &c, uint32_t tiles_x, uint32_t tiles_y, long
                 const int w = wave_order == 0 ? k : (wave_order == 1 ? 2 - k : (k + 1) % 3);
                 // a wavefront runs these steps in lockstep: every lane finishes a step before any
                 // lane starts the next (the stage is written by block and read back by chunk)
-                for (int l = 0; l < 64; l++) consumer_rows<MODE>(w, l, planar, &v[(w * 64 + l) * 64]);
-                for (int l = 0; l < 64; l++) consumer_cols<MODE>(&v[(w * 64 + l) * 64]);
+                for (int l = 0; l < 64; l++) consumer_rows<MODE, PACKED>(w, l, planar, &v[(w * 64 + l) * 64]);
+                for (int l = 0; l < 64; l++) consumer_cols<PACKED>(&v[(w * 64 + l) * 64]);
                 // the shipped write-out: whole block into registers, two rounds of 32 blocks through the stage
                 static thread_local uint32_t qw[64 * 32];
-                for (int l = 0; l < 64; l++) consumer_quant<MODE>(w, l, c.qt, &v[(w * 64 + l) * 64], &qw[l * 32]);
+                for (int l = 0; l < 64; l++) consumer_quant<MODE, PACKED>(w, l, c.qt, &v[(w * 64 + l) * 64], &qw[l * 32]);
                 for (int h = 0; h < 2; h++) {
                     for (int l = 0; l < 64; l++) consumer_stage_blocks(l, h, &qw[l * 32], lds + stage_offset<MODE>(w));
                     for (int l = 0; l < 64; l++) consumer_store_blocks<MODE>(c, tx, ty, w, l, h, lds + stage_offset<MODE>(w));
@@ -77,9 +77,17 @@ extern "C" int emu_jpeg_coeffs(const uint8_t *px, uint32_t W, uint32_t H, int co
     const uint32_t tx_gray = (c.units_x + 63) / 64, ty_gray = (c.units_y + 2) / 3;
 #define PIXO_RUN(MODE, TX, TY)                                                     \
     do {                                                                           \
-        if (load == L_ALIGNED) run_image<MODE, L_ALIGNED>(c, TX, TY, stats, wave_order); \
-        else if (load == L_FUNNEL) run_image<MODE, L_FUNNEL>(c, TX, TY, stats, wave_order); \
-        else run_image<MODE, L_BYTES>(c, TX, TY, stats, wave_order);                 \
+        /* both forms of the DCT passes and the quantiser exist on the device (jpeg_tile.h block_rows): wave orders 0 and 2 run the \
+           packed one, wave order 1 the scalar one — the tests use all three on every image */ \
+        if (wave_order != 1) { \
+            if (load == L_ALIGNED) run_image<MODE, L_ALIGNED, true>(c, TX, TY, stats, wave_order); \
+            else if (load == L_FUNNEL) run_image<MODE, L_FUNNEL, true>(c, TX, TY, stats, wave_order); \
+            else run_image<MODE, L_BYTES, true>(c, TX, TY, stats, wave_order); \
+        } else { \
+            if (load == L_ALIGNED) run_image<MODE, L_ALIGNED, false>(c, TX, TY, stats, wave_order); \
+            else if (load == L_FUNNEL) run_image<MODE, L_FUNNEL, false>(c, TX, TY, stats, wave_order); \
+            else run_image<MODE, L_BYTES, false>(c, TX, TY, stats, wave_order); \
+        } \
     } while (0)
     if (gray) PIXO_RUN(MGRAY, tx_gray, ty_gray);
     else if (s420) PIXO_RUN(M420, (c.units_x + 31) / 32, c.units_y);

@@ -49,4 +49,9 @@ def coeffs(pixels, w, h, color_type=2, subsampling=1, quality=80, allow_fast=Tru
     rc = lib().emu_jpeg_coeffs(px.ctypes.data, w, h, color_type, subsampling, quality, y.ctypes.data,
                                cb.ctypes.data, cr.ctypes.data, int(allow_fast), stats, wave_order)
     assert rc == 0, "the emulated kernel issued %d vector load(s) outside the image's bytes" % -rc  # (jpeg_tile.h emu_check_load)
+    if wave_order == 0:
+        # the device has the DCT passes and the quantiser in two forms (packed: launches of several generations; scalar: one
+        # generation — jpeg_tile.h block_rows): wave order 0 ran the packed one, order 1 runs the scalar one: same tuple
+        y2, cb2, cr2, _ = coeffs(pixels, w, h, color_type, subsampling, quality, allow_fast, misalign, wave_order=1)
+        assert np.array_equal(y, y2) and np.array_equal(cb[:cbn], cb2) and np.array_equal(cr[:cbn], cr2), "scalar and packed forms differ"
     return y, cb[:cbn], cr[:cbn], (stats[0], stats[1], stats[2])

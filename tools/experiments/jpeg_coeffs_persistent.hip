@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 3))
         // ---- phase B, the product's
         float v[64];
         consumer_rows<M420>(wave, lane, planar, v);
-        consumer_cols<MODE>(v);
+        consumer_cols<true>(v);
         uint8_t *stage = planar + stage_offset<M420>(wave);
         uint32_t qw[32];
         consumer_quant<M420>(wave, lane, a.qt, v, qw);

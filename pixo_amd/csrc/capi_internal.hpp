@@ -123,6 +123,9 @@ struct Context {
     };
     Buf e_tables, e_hist, e_count, e_len, e_off, e_tmp, e_totals, e_stream, e_tile_ff, e_tile_base, e_out, e_seg_bytes, e_seg_off;
     Buf e_code_state, e_stuff_state; // single-pass kernels (jpeg_scan_fused.hip): look-back descriptors, totals
+    Buf e_pc_state;                  // the fused pixel -> scan kernel (jpeg_pixels_code.hip): TWO state blocks that alternate — a launch zeroes the
+    size_t pc_half_words = 0;        //   block of the launch before it (words per block; 0: nothing is known to be zero)
+    int pc_flip = 0;                 //   which block the next launch uses
     Buf e_chain;                     // a scan coded in pieces: bits / bytes of the scan before every piece (device_entropy_pieces)
     Buf e_seams;                     // batch files that stay in HBM: their offsets + the header bytes for batch_seams_kernel
     Buf e_segs;                      // segmented scans (batches, restart intervals): per-segment results of the single-pass kernels
@@ -260,14 +263,6 @@ struct RetryMultipass {
 };
 int scan_retry_multipass(Context &c);
 uint64_t lookback_fallbacks(); // how often that has happened in this process (tests)
-// Where the stuffed bytes go when not into the context's device buffer: host memory the GPU can write (pinned), so that
-// the kernel's stores ARE the transfer — no second pass over the file, no second synchronisation.
-struct HostTarget {
-    uint8_t *p = nullptr; // device-visible address of the first stuffed byte
-    size_t cap = 0;       // bytes available from there
-    bool grow = false;    // p lies in the context's own pinned file buffer: too small = reserve more and repeat
-    size_t before = 0, after = 0; // (grow) bytes the file needs in front of / behind the stuffed bytes
-};
 int upload_scan_tables(Context &c, const uint32_t (&packed)[pixo_host::kScanTableWords], hipStream_t stream);
 int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, const int16_t *dcr, const pixo_jpeg_options &o,
                const pixo_host::Geometry &g, uint32_t batch, const int16_t *band_seed_dc);
@@ -276,11 +271,22 @@ int scan_count(Context &c, ScanJob &j, hipStream_t stream, uint64_t counts[pixo_
 int scan_tables(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream, const uint64_t *counts);
 int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
                  const uint64_t *counts, bool wait = true);
+// Where the stuffed bytes go when not into the context's device buffer: host memory the GPU can write (pinned), so that
+// the kernel's stores ARE the transfer — no second pass over the file, no second synchronisation.
+struct HostTarget {
+    uint8_t *p = nullptr; // device-visible address of the first stuffed byte
+    size_t cap = 0;       // bytes available from there
+    bool grow = false;    // p lies in the context's own pinned file buffer: too small = reserve more and repeat
+    size_t before = 0, after = 0; // (grow) bytes the file needs in front of / behind the stuffed bytes
+};
 // The fused pixel -> bit stream kernel (jpeg_pixels_code.hip) in place of coefficient kernel + scan_code for this job?  (one
 // RGB image, one uninterrupted scan, tables known without the tuple's statistics)
 bool pixels_code_usable(const ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, uint32_t batch);
-// ... tables + that kernel, chained with the stuffing kernel like scan_lengths(wait = false); no tuple is written
-int scan_code_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream, const void *d_pixels);
+// ... tables + that kernel: afterwards the finished (stuffed, padded) scan lies in c.e_out — or at `host`, memory of the host
+// that the GPU can write — and j.scan_bytes / j.total_bits / j.nbytes say how long it is.  No tuple, no packed stream is written.
+// wait = false: only enqueued (measurements); the totals are then in c.h_totals[0..2] once the stream has been synchronised.
+int scan_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream, const void *d_pixels,
+                     HostTarget *host, bool wait = true);
 int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offset, uint32_t *head, int *tail_bits,
                      uint32_t *tail, bool chained = false, HostTarget *host = nullptr);
 int scan_pack(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offset = 0, uint32_t *head = nullptr,

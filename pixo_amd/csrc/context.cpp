@@ -174,7 +174,7 @@ namespace {
 template <class F> void each_buf(Context &c, F &&f)
 {
     Context::Buf *bufs[] = {&c.e_tables, &c.e_hist, &c.e_count, &c.e_len, &c.e_off, &c.e_tmp, &c.e_totals, &c.e_stream, &c.e_tile_ff, &c.e_tile_base,
-                            &c.e_out, &c.e_seg_bytes, &c.e_seg_off, &c.e_code_state, &c.e_stuff_state, &c.e_chain, &c.e_segs, &c.e_seams, &c.p_in, &c.p_out,
+                            &c.e_out, &c.e_seg_bytes, &c.e_seg_off, &c.e_code_state, &c.e_stuff_state, &c.e_pc_state, &c.e_chain, &c.e_segs, &c.e_seams, &c.p_in, &c.p_out,
                             &c.p_sums, &c.p_scratch, &c.t_raw, &c.t_trail, &c.g_flags, &c.g_rank, &c.g_by_rank};
     for (Context::Buf *b : bufs) f(*b);
 }
@@ -198,6 +198,7 @@ void Context::shrink_to(size_t max_buffer_bytes)
     });
     if (e_tables.p == nullptr) tables_valid = false;
     if (e_code_state.p == nullptr) code_state_zero_words = 0;
+    if (e_pc_state.p == nullptr) pc_half_words = 0;
     if (px_cap > max_buffer_bytes) { (void)hipFree(d_px); d_px = nullptr; px_cap = 0; }
     if (coef_cap > max_buffer_bytes) { (void)hipFree(d_coef); d_coef = nullptr; coef_cap = 0; }
     if (hcoef_cap > max_buffer_bytes) { (void)hipHostFree(h_coef); h_coef = nullptr; hcoef_cap = 0; }

@@ -31,6 +31,8 @@
 // jpeg_scan_fused.hip); every wait is bounded and raises the abort flag.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "jpeg_kernels.hpp"
 #include "jpeg_pixels_code.hpp"
 #include "jpeg_scan_dev.h"
@@ -59,7 +61,15 @@ struct PRest {
     uint32_t groups;
     int16_t seed_dc[3];
     uint16_t pad_last;
+    uint32_t out_skew;  // < 16: the bytes before it are somebody else's (the file headers when `out` is the caller's host buffer)
+    uint64_t out_cap;   // bytes available from out[0]: nothing is stored beyond (the totals say what was needed)
+    uint32_t *block_spill; // groups x 192 x 32 words: where a group of several rounds keeps its quantised blocks between the rounds' walks
 };
+
+// A value every lane of the wavefront holds alike — read from LDS, say — as the compiler can SEE it: a scalar register.  Branches
+// on it become real branches (a register that is dead on one side is free there) instead of two exec-masked regions in a row.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
 
 __device__ __forceinline__ void lds_only_barrier()
 {
@@ -101,7 +111,7 @@ __device__ __forceinline__ void phase_a_tab(const TileCtx &c, uint32_t tx, uint3
 template <int MODE, int LOAD, bool PACKED>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void pixels_code_kernel
 (const uint8_t *a_px, uint32_t a_W, uint32_t a_H, const float *a_qt, uint32_t a_units_x, uint32_t a_units_y, const uint32_t *a_tables,
- unsigned long long *a_state, uint32_t *a_stream, const PRest rest)
+ unsigned long long *a_state, uint8_t *a_out, const PRest rest)
 {
     typedef Geo<MODE> G;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kFusedLds];
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     __shared__ int16_t s_dc[kGroup];
     __shared__ uint32_t wave_sum[kGroupWaves], wave_long[kGroupWaves];
     __shared__ unsigned long long s_before;
-    __shared__ uint32_t s_carry, s_abort;
+    __shared__ uint32_t s_carry, s_abort, s_head, s_front2;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     __builtin_amdgcn_s_setprio(1); // phase A in front of the older workgroups' phase B (jpeg_kernels.hip)
     const uint32_t tx = blockIdx.x, ty = blockIdx.y;
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     c.px = a_px; c.y = c.cb = c.cr = nullptr; c.qt = a_qt;
     c.W = a_W; c.H = a_H; c.units_x = a_units_x; c.units_y = a_units_y; c.fast = 1;
     c.px_end = a_px + rest.px_bytes;
-    if (tid == 0) { s_carry = 0; s_abort = 0; }
+    if (tid == 0) { s_carry = 0; s_abort = 0; s_head = 0; s_front2 = 0; }
     {
         constexpr int base = G::items / kWaves, extra = G::items % kWaves;
         const int first = (extra && wave < extra) ? wave * (base + 1) : extra * (base + 1) + (wave - extra) * base;
@@ -135,6 +145,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         consumer_quant<MODE, PACKED>(wave, lane, a_qt, v, qw);
     }
     // ---- from here on: the group's part of the entropy-coded scan ----------------------------------------------------------
+    // (the thread's coordinates again, opaque to the optimiser: whatever the second half derives from them is computed here and
+    // does not occupy registers through phase B, which runs at the 80-register limit)
+    int tid_again = threadIdx.x;
+    asm volatile("" : "+v"(tid_again));
+#define tid tid_again
+    const int lane_again = tid & 63, wave_again = __builtin_amdgcn_readfirstlane(tid >> 6);
+#define lane lane_again
+#define wave wave_again
     const uint64_t ngroups = rest.groups, g = (uint64_t)ty * rest.tiles_x + tx;
     unsigned long long *desc = a_state + 2, *tails = desc + ngroups, *dcw = tails + ngroups, *sup = dcw + 3 * ngroups;
     unsigned long long *const host_abort = rest.host_totals ? rest.host_totals + 3 : nullptr;
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     const bool long_block = live && len_ac > kScratchWords * 32u;
     s_pos[sidx] = len;
     __syncthreads();
-    if (s_abort) return; // (a predictor never arrived: the host codes this image with the two-kernel form)
+    if (uni(s_abort)) return; // (a predictor never arrived: the host codes this image with the two-kernel form)
     // ---- exclusive prefix of the lengths in SCAN order: thread t takes position t
     const uint32_t mine = s_pos[tid];
     const uint32_t incl = wave_inclusive_scan(mine);
@@ -208,27 +226,62 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         group_bits += wave_sum[k];
         group_long |= wave_long[k];
     }
+    group_bits = uni(group_bits); group_long = uni(group_long);
     s_pos[tid] = wave_base + (incl - mine);
     if (tid == 0) publish_aggregate(desc, g, 0, group_bits);
     __syncthreads();
     const uint32_t my_bit = s_pos[sidx];
     const bool last_group = g + 1 == ngroups;
-    // ---- the blocks' bits at GROUP-RELATIVE offsets into the LDS window (one round of kWindowWords words, usually), the
-    // look-back, the write-out: scan_code_kernel's (jpeg_scan_fused.hip), with the DC symbol placed in front of the AC words
+    // ---- place, stuff, write.  The group's bits go into the LDS window at GROUP-RELATIVE offsets (scan_code_kernel's gather, with
+    // the DC symbol in front of the AC words); a look-back over the groups' bit counts gives the group's first bit S in the
+    // scan; from there on everything is BYTES of the finished scan (round 5: stuff_fused_kernel's work happens here, the packed
+    // stream never exists in HBM):
+    //   * the group OWNS the scan's bytes [S / 8, E / 8) (E = S + its bits; the last group: up to the 1-padded end).  A first
+    //     byte that began in the group before (S % 8 != 0) arrives as that group's `tail` — its last E' % 8 bits, which it
+    //     publishes as soon as it knows S', before it waits for anything else — and is completed here;
+    //   * "aligned word" j of the group = its owned bytes 4 j .. 4 j + 3 = the window's words j - 1 and j funnelled by S % 8;
+    //     thread (wave v, row k, lane l) takes aligned word 512 v + 64 k + l of the round — 0xFF census per word, wavefront
+    //     scans row by row, the group's count published and a second look-back (both two-level, look_back_blocks' form) for
+    //     the number of stuffed zeros before the group;
+    //   * the bytes are expanded into an LDS stage at the output's 16-byte alignment — each moved up by the 0xFF bytes before
+    //     it: the gaps ARE the stuffed zeros (BitWriterMsb, src/bits.rs:245-253) — and stored as aligned 16-byte pieces.
+    // The stage is the walk's scratch area (dead after the gather): a group of several rounds, whose later gathers would need the
+    // scratch again, packs every round by a second walk straight into the window (the long-block path).
+    constexpr uint32_t kWin = kWindowWords - 1; // group words per round: the round's aligned words (one more) are at most 3 x 512
+    constexpr uint32_t kStageCap = kGroup * kScratchPitch * 4;
+    constexpr int kRows = 8;                    // aligned words per lane and round
+    static_assert(kWindowWords == 3 * 64 * kRows, "three wavefronts x 8 rows of 64 aligned words");
     const uint32_t local_words = (group_bits + 31) >> 5; // >= 1: every block has bits
-    uint64_t first_word = 0;
-    uint32_t sh = 0, out_words = 0, pad_word = ~0u, pad_mask = 0;
-    bool tail_partial = false;
-    uint32_t head_word = 0; // (thread 0) this group's bits of the stream word it shares with the group before
-    for (uint32_t wbase = 0; wbase < local_words; wbase += kWindowWords) {
-        const uint32_t wn = local_words - wbase < kWindowWords ? local_words - wbase : kWindowWords;
-        for (uint32_t i = tid; i < wn; i += kGroup) buf[i] = 0;
+    const bool walk_into_window = group_long != 0 || local_words > kWin;
+    unsigned long long *desc2 = sup + ((ngroups + 63) >> 6) + 1, *sup2 = desc2 + ngroups;
+    uint8_t *stage = lds;
+    uint8_t *const out = a_out; // 16-byte aligned; the scan's first byte goes to out[rest.out_skew]
+    uint64_t S = 0, ff_before_groups = 0;
+    uint32_t nb_total = 0, sh8 = 0, tail_count = 0, pad_word = ~0u, pad_mask = 0, ff_group = 0, in_front2 = 0;
+    bool aborted = false;
+    // MULTI: a group of several rounds / with a very long block (rare: noise at q >= 90): the quantised block stays alive for the
+    // second walks.  The common case is its own instantiation, in which the block's registers are dead after the first walk.
+    // (such a group parks its blocks in HBM — a slot per lane in the space reserved for the tuple this kernel never writes — and
+    // loads them again for every round's walk: the 32 registers are not alive through the byte stage of the common path)
+    uint32_t *const my_spill = rest.block_spill + ((size_t)g * kGroup + (size_t)tid) * 32u;
+    uint32_t park = uni(walk_into_window ? 1u : 0u);
+    asm volatile("" : "+s"(park)); // (not recognisable as the condition of the branch below: otherwise this store is moved into that branch
+                                   //  and the 32 registers stay occupied through the other side's code as well)
+    if (park) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) *reinterpret_cast<v4u *>(my_spill + 4 * i) = v4u{qw[4 * i], qw[4 * i + 1], qw[4 * i + 2], qw[4 * i + 3]};
+    }
+    auto rounds = [&](auto multi_tag) __attribute__((always_inline)) {
+    constexpr bool MULTI = decltype(multi_tag)::value;
+    for (uint32_t wbase = 0; wbase < (MULTI ? local_words : 1u); wbase += kWin) {
+        const uint32_t wn = MULTI ? (local_words - wbase < kWin ? local_words - wbase : kWin) : local_words;
+        for (uint32_t i = tid; i <= wn; i += kGroup) buf[i] = 0; // (word wn: read by the funnel of the round's last aligned word)
         __syncthreads();
         const int64_t rel = (int64_t)my_bit - (int64_t)wbase * 32;
         const uint32_t dummy = kWindowWords + (uint32_t)tid;
-        if (!group_long) {
+        if (!MULTI) {
             { // the DC symbol (<= 27 bits at the top of db.left)
-                const uint32_t bsh = (uint32_t)(rel & 31), d = (uint32_t)(rel >> 5); // (wraps below zero for words before the window)
+                const uint32_t bsh = (uint32_t)(rel & 31), d = (uint32_t)(rel >> 5);
                 const uint32_t hi = live ? db.left >> bsh : 0u, lo = (live && bsh) ? db.left << (32 - bsh) : 0u;
                 (void)__hip_atomic_fetch_or(&buf[d < wn ? d : dummy], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 (void)__hip_atomic_fetch_or(&buf[d + 1 < wn ? d + 1 : dummy], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -247,96 +300,240 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                                             __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        // (opaque to the optimiser: otherwise everything the first walk derived from the coefficients stays alive for the second)
+        if (MULTI && PIXO_ANY64(live && rel < (int64_t)wn * 32 && rel + (int64_t)len > 0)) { // (some block of the wavefront lies in the window)
+            uint32_t w[32]; // the lane's block again (its own stores: visible to it)
+            const uint32_t *back = my_spill;
+            asm volatile("" : "+v"(back) : : "memory"); // (a pointer the optimiser cannot see through: no forwarding of the stored registers, which would keep them alive)
 #pragma unroll
-        for (int i = 0; i < 32; i++) asm volatile("" : "+v"(qw[i]));
-        if (group_long && PIXO_ANY64(live && rel < (int64_t)wn * 32 && rel + (int64_t)len > 0)) { // a block of more than 384 AC bits
-            FlatPack<LdsSink> p;                                                                   // in the group: a second walk, straight into the window
+            for (int i = 0; i < 8; i++) {
+                const v4u q = *reinterpret_cast<const v4u *>(back + 4 * i);
+                w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+            }
+            FlatPack<LdsSink> p;
             p.sink = LdsSink{buf, live ? wn : 0u, dummy};
             p.acc = 0;
             p.pending = (uint32_t)(rel & 31);
             p.word = (uint32_t)(rel >> 5);
-            block_pack_flat(qw, prev_dc, wtab, p);
+            block_pack_flat(w, prev_dc, wtab, p);
             p.finish();
         }
-        if (wbase == 0) { // where the group starts in the stream
+        const bool last_round = !MULTI || wbase + wn == local_words;
+        if (wbase == 0) { // where the group starts in the scan
             if (wave == 0) {
                 const uint64_t sum = look_back_blocks(desc, sup, g, 0, group_bits, a_state, host_abort, rest.spin_budget);
                 if (lane == 0) {
                     if (sum == kLookBackFailed) s_abort = 1;
                     s_before = sum;
-                    if (last_group) { // the stream's length in bits (unpadded)
-                        a_state[1] = sum + group_bits;
-                        if (rest.host_totals) rest.host_totals[0] = sum + group_bits;
+                }
+            }
+            __syncthreads();
+            if (uni(s_abort)) { aborted = true; return; }
+            S = uni64(s_before);
+            sh8 = (uint32_t)(S & 7);
+            const uint64_t end_bits = (uint64_t)sh8 + group_bits; // in aligned bits: bit 0 = the first bit of the group's first owned byte
+            tail_count = last_group ? 0u : (uint32_t)(end_bits & 7);
+            nb_total = (uint32_t)(last_group ? (end_bits + 7) >> 3 : end_bits >> 3);
+            if (last_group && (end_bits & 7)) { // BitWriterMsb::flush pads the last byte with 1-bits
+                const uint32_t n = 8u - (uint32_t)(end_bits & 7);
+                pad_word = (uint32_t)(end_bits >> 5);
+                pad_mask = ((1u << n) - 1u) << (32u - (uint32_t)(end_bits & 31) - n);
+            }
+        } else {
+            __syncthreads();
+        }
+        // ---- the round's aligned words: thread (wave, row k, lane) takes word 512 wave + 64 k + lane
+        const uint32_t head = uni(wbase ? s_carry : s_head); // the bits in front of the round's first word (low sh8 bits; 0 until the tail of the group before has arrived: see below)
+        uint32_t x[kRows];
+        auto aligned_word = [&](uint32_t jl, uint32_t first_prev) -> uint32_t {
+            const uint32_t cur = jl <= wn ? buf[jl] : 0u, prev = jl ? (jl - 1 <= wn ? buf[jl - 1] : 0u) : first_prev;
+            uint32_t v = sh8 ? (prev << (32u - sh8)) | (cur >> sh8) : cur;
+            v |= wbase + jl == pad_word ? pad_mask : 0u;
+            return v;
+        };
+        // the tail for the group behind: the group's last (S + bits) % 8 bits — never bits of the group before (>= 12 bits per group)
+        if (last_round && !last_group) {
+            const uint32_t at = nb_total * 8u;               // aligned bit where the unfinished byte begins
+            const uint32_t jl = (at >> 5) - wbase;           // its aligned word, in this round
+            if ((uint32_t)tid == (jl % kGroup)) {            // (any one thread)
+                const uint32_t v = aligned_word(jl, wbase ? s_carry : 0u); // (its bits lie behind the head bits: those are not needed)
+                const uint32_t bits_left = tail_count ? (v >> (32u - (at & 31u) - tail_count)) & ((1u << tail_count) - 1u) : 0u;
+                store_relaxed(&tails[g], kTailValid | ((uint64_t)tail_count << 8) | bits_left);
+            }
+        }
+        // the group's first byte began in the group before: wait for its bits (published above by that group, before ITS wait)
+        if (wbase == 0 && sh8 != 0 && g > 0) {
+            if (tid == 0) {
+                unsigned long long t = load_relaxed(&tails[g - 1]);
+                uint32_t polls = 0;
+                while (!(t & kTailValid)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > rest.spin_budget) { raise_abort(a_state, host_abort); s_abort = 1; break; }
+                    t = load_relaxed(&tails[g - 1]);
+                }
+                s_head = (uint32_t)t & 0x7Fu;
+            }
+            __syncthreads();
+            if (uni(s_abort)) { aborted = true; return; }
+        }
+        const uint32_t head_now = wbase ? head : uni(s_head);
+        // owned bytes of THIS round: up to the group's last one, or (not the last round) up to the round's last complete aligned word
+        const uint32_t round_first = 4u * wbase;
+        const uint32_t limit = last_round ? nb_total : (nb_total < 4u * (wbase + wn) ? nb_total : 4u * (wbase + wn));
+        const uint32_t bytes_this = limit > round_first ? limit - round_first : 0u;
+        uint64_t flags = 0; // four flags per word: byte b of word k is 0xFF and belongs to this round
+        const uint32_t jl0 = 512u * (uint32_t)wave + (uint32_t)lane;
+#pragma unroll
+        for (int k = 0; k < kRows; k++) {
+            const uint32_t jl = jl0 + 64u * k;
+            x[k] = aligned_word(jl, head_now);
+            const uint32_t first_byte = 4u * (wbase + jl);
+            const uint32_t exist = first_byte < limit ? (limit - first_byte < 4u ? limit - first_byte : 4u) : 0u;
+            const uint32_t m = (zero_byte_mask(~x[k]) >> 7) & 0x01010101u; // bits 24, 16, 8, 0 = bytes 0, 1, 2, 3 of the word (stream order)
+            const uint32_t m4 = ((m * 0x08040201u) >> 24) & ((1u << exist) - 1u);
+            flags |= (uint64_t)m4 << (4 * k);
+        }
+        // 0xFF bytes before every word of the wavefront, in stream order = row by row; two rows share one 32-bit scan
+        uint32_t before[kRows];
+        uint32_t wave_ff = 0;
+#pragma unroll
+        for (int k = 0; k < kRows; k += 2) {
+            const uint32_t c0 = (uint32_t)__builtin_popcount((uint32_t)(flags >> (4 * k)) & 0xFu);
+            const uint32_t c1 = (uint32_t)__builtin_popcount((uint32_t)(flags >> (4 * k + 4)) & 0xFu);
+            const uint32_t sc = wave_inclusive_scan(c0 | (c1 << 16));
+            const uint32_t rows = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+            before[k] = wave_ff + (sc & 0xFFFFu) - c0;
+            wave_ff += rows & 0xFFFFu;
+            before[k + 1] = wave_ff + (sc >> 16) - c1;
+            wave_ff += rows >> 16;
+        }
+        if (lane == 0) wave_sum[wave] = wave_ff;
+        __syncthreads();
+        uint32_t wave_base_ff = 0, round_ff = 0;
+        uint32_t ff_of_wave[kGroupWaves];
+#pragma unroll
+        for (int k = 0; k < kGroupWaves; k++) {
+            ff_of_wave[k] = uni(wave_sum[k]);
+            if (k < wave) wave_base_ff += ff_of_wave[k];
+            round_ff += ff_of_wave[k];
+        }
+        // ---- the number of stuffed zeros before the group: its own count goes out when it is complete (the last round), the
+        // look-back for the groups before it runs in the first round
+        if (last_round && tid == 0) store_relaxed(&desc2[g], kFlagAggregate | (uint64_t)(ff_group + round_ff));
+        if (wbase == 0) {
+            if (wave == 0) { // (look_back_blocks' two levels; the block's sum is published below, when this group's own count is complete)
+                const uint64_t rel_g = g, kblk = rel_g >> 6;
+                const uint32_t in_block = (uint32_t)(rel_g & 63);
+                const uint64_t block_first = kblk << 6;
+                uint32_t polls = 0;
+                bool gave_up = false;
+                unsigned long long da = (uint32_t)lane < in_block ? load_relaxed(&desc2[block_first + lane]) : kFlagAggregate;
+                unsigned long long db2 = (uint64_t)lane < kblk ? load_relaxed(&sup2[lane]) : kFlagAggregate;
+                while ((da >> 62) == 0 && !gave_up) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > rest.spin_budget) gave_up = true; else da = load_relaxed(&desc2[block_first + lane]);
+                }
+                uint64_t before2 = 0;
+                uint32_t front = 0;
+                if (!PIXO_ANY64(gave_up)) {
+                    front = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)(da & kValueMask)), 63);
+                    before2 = front;
+                    for (uint64_t base = 0;;) {
+                        while ((db2 >> 62) == 0 && !gave_up) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++polls > rest.spin_budget) gave_up = true; else db2 = load_relaxed(&sup2[base + lane]);
+                        }
+                        if (PIXO_ANY64(gave_up)) break;
+                        before2 += (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)(db2 & kValueMask)), 63);
+                        base += 64;
+                        if (base >= kblk) break;
+                        db2 = base + lane < kblk ? load_relaxed(&sup2[base + lane]) : kFlagAggregate;
+                    }
+                }
+                if (PIXO_ANY64(gave_up)) {
+                    if (gave_up) raise_abort(a_state, host_abort);
+                    if (lane == 0) s_abort = 1;
+                } else if (lane == 0) {
+                    s_before = before2;
+                    s_front2 = front;
+                }
+            }
+            __syncthreads();
+            if (uni(s_abort)) { aborted = true; return; }
+            ff_before_groups = uni64(s_before);
+            in_front2 = uni(s_front2);
+        }
+        // ---- expand + store.  Output offset of the round's first byte (owned byte 4 wbase of the group):
+        const uint64_t dst_round = (uint64_t)rest.out_skew + (S >> 3) + ff_before_groups + round_first + ff_group;
+        const bool all_at_once = ((uint32_t)dst_round & 15u) + bytes_this + round_ff <= kStageCap;
+        for (int turn = 0; turn < (all_at_once ? 1 : kGroupWaves); turn++) { // (wave by wave when a round's bytes + zeros do not fit the stage)
+            const uint32_t before_turn = all_at_once ? 0u : (turn == 0 ? 0u : (turn == 1 ? ff_of_wave[0] : ff_of_wave[0] + ff_of_wave[1]));
+            const uint64_t dst0 = dst_round + (all_at_once ? 0u : 2048u * (uint32_t)turn + before_turn);
+            const uint32_t skew = (uint32_t)(dst0 & 15);
+            const uint32_t turn_bytes = all_at_once ? bytes_this : (bytes_this > 2048u * (uint32_t)turn ? (bytes_this - 2048u * (uint32_t)turn < 2048u ? bytes_this - 2048u * (uint32_t)turn : 2048u) : 0u);
+            const uint32_t turn_ff = all_at_once ? round_ff : (turn == 0 ? ff_of_wave[0] : (turn == 1 ? ff_of_wave[1] : ff_of_wave[2]));
+            const uint32_t tile_out = turn_bytes + turn_ff;
+            for (uint32_t i = 16u * tid; i < ((skew + tile_out + 15u) & ~15u); i += 16u * kGroup) *reinterpret_cast<v4u *>(stage + i) = v4u{0, 0, 0, 0};
+            __syncthreads();
+            if (all_at_once || wave == turn) {
+                const uint32_t at0 = skew + (all_at_once ? 2048u * (uint32_t)wave + wave_base_ff : 0u) + 4u * (uint32_t)lane;
+#pragma unroll
+                for (int k = 0; k < kRows; k++) {
+                    const uint32_t first_byte = 4u * (wbase + jl0 + 64u * k);
+                    const uint32_t exist = first_byte < limit ? (limit - first_byte < 4u ? limit - first_byte : 4u) : 0u;
+                    const uint32_t m4 = (uint32_t)(flags >> (4 * k)) & 0xFu;
+                    const uint32_t to = at0 + 256u * k + before[k];
+#pragma unroll
+                    for (int bb = 0; bb < 4; bb++) {
+                        const uint32_t byte = (x[k] >> (24 - 8 * bb)) & 0xFFu;
+                        const uint32_t moved = (uint32_t)__builtin_popcount(m4 & ((1u << bb) - 1u));
+                        if ((uint32_t)bb < exist) stage[to + bb + moved] = (uint8_t)byte;
                     }
                 }
             }
             __syncthreads();
-            if (s_abort) return;
-            const uint64_t start = s_before;
-            uint64_t end = start + group_bits;
-            if (last_group && rest.pad_last) { // BitWriterMsb::flush pads the last byte with 1-bits
-                const uint32_t n = (uint32_t)((8 - (end & 7)) & 7);
-                if (n) {
-                    pad_word = (uint32_t)((end >> 5) - (start >> 5));
-                    pad_mask = ((1u << n) - 1u) << (32 - (uint32_t)(end & 31) - n);
+            // out: leading bytes up to the first aligned 16 bytes, aligned 16-byte pieces, trailing bytes — never beyond out_cap
+            const uint64_t base = dst0 - skew; // multiple of 16
+            const uint32_t end = skew + tile_out;
+            const uint32_t first_q = skew ? 16u : 0u, last_q = end & ~15u;
+            if (first_q <= last_q) {
+                for (uint32_t i = first_q + 16u * tid; i < last_q; i += 16u * kGroup)
+                    if (base + i + 16 <= rest.out_cap) __builtin_nontemporal_store(*reinterpret_cast<const v4u *>(stage + i), reinterpret_cast<v4u *>(out + base + i));
+                if (tid < 16) { // bytes [skew, min(16, end)) and [last_q, end)
+                    const uint32_t i = skew + tid;
+                    if (skew && i < 16 && i < end && base + i < rest.out_cap) out[base + i] = stage[i];
+                    const uint32_t j = last_q + tid;
+                    if (j < end && j >= first_q && base + j < rest.out_cap) out[base + j] = stage[j];
                 }
-                end += n;
+            } else { // the whole turn lies inside one 16-byte piece
+                if ((uint32_t)tid + skew < end && tid < 16 && base + skew + tid < rest.out_cap) out[base + skew + tid] = stage[skew + tid];
             }
-            first_word = start >> 5;
-            sh = (uint32_t)(start & 31);
-            out_words = (uint32_t)((end - (first_word << 5) + 31) >> 5); // local_words or local_words + 1
-            tail_partial = (end & 31) != 0 && !last_group;                 // the last word is finished by a later group
-        } else {
             __syncthreads();
         }
-        // ---- out.  Stream word first_word + j = the window's words j - 1 and j funnelled by `sh`; the group writes every
-        // word it completes, except the word it shares with the group before (j = 0 when sh != 0): that one waits for the
-        // other group's bits.  The word it leaves unfinished goes to the next group as `tail`.
-        const uint32_t carry = s_carry; // the previous window's last word
-        const bool last_round = wbase + wn == local_words;
-        const uint32_t upto = last_round ? out_words - wbase : wn;
-        uint32_t word0 = 0, tail_word = 0;
-        for (uint32_t i = tid; i < upto; i += kGroup) {
-            const uint32_t j = wbase + i;
-            const uint32_t cur = i < wn ? buf[i] : 0u, prev = i ? buf[i - 1] : carry;
-            uint32_t v = sh ? (cur >> sh) | (prev << (32 - sh)) : cur;
-            v |= j == pad_word ? pad_mask : 0u;
-            const bool is_head = j == 0 && sh != 0, is_tail = tail_partial && j + 1 == out_words;
-            if (is_head) word0 = v;
-            if (is_tail) tail_word = v;
-            if (!is_head && !is_tail) __builtin_nontemporal_store(v, &a_stream[first_word + j]);
+        ff_group += round_ff;
+        if (MULTI) {
+            if (tid == 0) s_carry = buf[wn - 1];
+            __syncthreads();
         }
-        const bool has_tail = last_round && tail_partial;
-        const bool pass_through = has_tail && out_words == 1 && sh != 0; // (a handful of bits inside one word)
-        if (has_tail && !pass_through && (uint32_t)tid == (upto - 1) % kGroup) store_relaxed(&tails[g], kTailValid | tail_word);
-        if (wbase == 0) head_word = word0;
-        if (tid == 0) s_carry = buf[wn - 1];
-        __syncthreads();
     }
-    // ---- the word shared with the group before: its bits arrive as that group's tail (after this group's own tail went out)
-    if (sh != 0 && tid == 0) {
-        uint32_t inherited = 0;
-        if (g > 0) {
-            unsigned long long t = load_relaxed(&tails[g - 1]);
-            uint32_t polls = 0;
-            while (!(t & kTailValid)) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++polls > rest.spin_budget) { raise_abort(a_state, host_abort); return; }
-                t = load_relaxed(&tails[g - 1]);
-            }
-            inherited = (uint32_t)t;
-        }
-        const uint32_t merged = inherited | head_word;
-        if (tail_partial && out_words == 1) store_relaxed(&tails[g], kTailValid | merged); // (pass-through)
-        else __builtin_nontemporal_store(merged, &a_stream[first_word]);
+    };
+    if (walk_into_window) rounds(std::true_type{}); else rounds(std::false_type{});
+    if (aborted) return;
+    // the block of 64 groups is complete with its last group: its sum of stuffed zeros for the groups behind
+    if ((g & 63) == 63 && tid == 0) store_relaxed(&sup2[g >> 6], kFlagAggregate | ((uint64_t)in_front2 + ff_group));
+    if (last_group && tid == 0) { // totals: the scan's length in bits (unpadded), its bytes before and after stuffing
+        const uint64_t bits = S + group_bits, packed = (S >> 3) + nb_total, stuffed = packed + ff_before_groups + ff_group;
+        a_state[1] = bits;
+        if (rest.host_totals) { rest.host_totals[0] = bits; rest.host_totals[1] = stuffed; rest.host_totals[2] = packed; }
     }
+#undef tid
+#undef lane
+#undef wave
 }
 } // namespace
 
 size_t pixels_code_state_words(uint64_t groups)
-{ // abort flag, total bits, per group: descriptor + tail + three DC words, per 64 groups: block sum (+ 1)
-    return 2 + 5 * (size_t)groups + (size_t)(groups + 63) / 64 + 1;
+{ // abort flag, total bits; per group: bit-count descriptor, tail, three DC words, 0xFF-count descriptor; per 64 groups: two block sums (+ 1 each)
+    return 2 + 6 * (size_t)groups + 2 * ((size_t)(groups + 63) / 64 + 1);
 }
 
 uint64_t pixels_code_groups(uint32_t W, uint32_t H, bool s420)
@@ -352,8 +549,9 @@ bool pixels_code_supported(uint32_t W, uint32_t H, bool gray)
 }
 
 hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s420, const float *d_qt, const uint32_t *d_tables,
-                              unsigned long long *d_state, bool state_is_zero, uint32_t *d_stream, unsigned long long *d_clear, size_t clear_words,
-                              unsigned long long *host_totals, const int16_t seed_dc[3], bool pad_last, hipStream_t s, uint32_t spin_budget)
+                              unsigned long long *d_state, bool state_is_zero, unsigned long long *d_clear, size_t clear_words, uint8_t *d_out,
+                              uint64_t out_cap, unsigned long long *host_totals, const int16_t seed_dc[3], bool pad_last, void *d_block_spill, hipStream_t s,
+                              uint32_t spin_budget)
 {
     if (!pixels_code_supported(W, H, false) || clear_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const uint32_t unit = s420 ? 16u : 8u, per_tile = s420 ? 32u : 64u;
@@ -374,12 +572,17 @@ hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s42
     rest.tiles_x = tiles_x; rest.groups = (uint32_t)groups;
     for (int i = 0; i < 3; i++) rest.seed_dc[i] = seed_dc ? seed_dc[i] : (int16_t)0;
     rest.pad_last = pad_last ? 1 : 0;
+    // (d_out may start anywhere: the kernel gets the 16-byte boundary below it and the distance)
+    rest.out_skew = (uint32_t)(reinterpret_cast<uintptr_t>(d_out) & 15);
+    uint8_t *out = d_out - rest.out_skew;
+    rest.out_cap = out_cap + rest.out_skew;
+    rest.block_spill = static_cast<uint32_t *>(d_block_spill);
     const bool aligned = reinterpret_cast<uintptr_t>(d_px) % 4 == 0 && row_bytes % 4 == 0;
     const dim3 grid(tiles_x, tiles_y);
     const uint8_t *px = static_cast<const uint8_t *>(d_px);
     const bool packed = packed_launch(groups); // (scalar or packed DCT passes and quantiser: jpeg_kernels.hpp)
-#define PIXO_LAUNCH_PC(MODE, LOAD) do { if (packed) hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, true>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, units_x, units_y, d_tables, d_state, d_stream, rest); \
-                                        else hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, false>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, units_x, units_y, d_tables, d_state, d_stream, rest); } while (0)
+#define PIXO_LAUNCH_PC(MODE, LOAD) do { if (packed) hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, true>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, units_x, units_y, d_tables, d_state, out, rest); \
+                                        else hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, false>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, units_x, units_y, d_tables, d_state, out, rest); } while (0)
     if (s420) { if (aligned) PIXO_LAUNCH_PC(M420, L_ALIGNED); else PIXO_LAUNCH_PC(M420, L_FUNNEL); }
     else { if (aligned) PIXO_LAUNCH_PC(M444, L_ALIGNED); else PIXO_LAUNCH_PC(M444, L_FUNNEL); }
 #undef PIXO_LAUNCH_PC

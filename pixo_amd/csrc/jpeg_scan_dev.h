@@ -202,5 +202,10 @@ struct LdsSink {
         (void)__hip_atomic_fetch_or(&buf[i], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
+__device__ __forceinline__ uint32_t zero_byte_mask(uint32_t x)
+{ // 0x80 in every byte of x that is zero (exact)
+    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+
 } // namespace
 } // namespace pixo_dev

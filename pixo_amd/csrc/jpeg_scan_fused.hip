@@ -670,10 +670,6 @@ __global__ __launch_bounds__(256) void scan_count_sum_kernel(const uint32_t *sla
 constexpr int kStuffThreads = 256, kLaneWords = PIXO_STUFF_LANE_WORDS, kWaveBytes = 64 * kLaneWords * 4, kTileBytes = (kStuffThreads / 64) * kWaveBytes;
 constexpr uint32_t kMaxSegGap = 1024;                        // bytes a segmented scan may leave free behind a segment (SegArgs::marker_bytes)
 constexpr uint32_t kStageBytes = 2 * kTileBytes + 32 + kMaxSegGap; // worst case: every byte 0xFF, + the output's alignment skew, + the gap behind a segment
-__device__ __forceinline__ uint32_t zero_byte_mask(uint32_t x)
-{ // 0x80 in every byte of x that is zero (exact)
-    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
-}
 
 // ---- segmented scans: where every segment's tiles begin -----------------------------------------------------------------
 // One workgroup, after scan_code<SEG>: from the segments' bit lengths the bytes of each (1-padded: whole bytes) and the

@@ -424,14 +424,13 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
     }
     if ((rc = upload_all())) return rc;
     const bool fuse_now = from_pixels && src; // (src is null once a pieces attempt above has computed the tuple)
-    if (fuse_now) { // pixels -> packed stream in one kernel; the tuple is never written (a retry with the multi-pass kernels computes it)
-        if ((rc = scan_code_from_pixels(c, j, o, g, stream, src->d_px))) return rc;
+    if (fuse_now) { // pixels -> finished scan in ONE kernel (below); the tuple is never written (a retry with the multi-pass kernels computes it)
     } else {
         if (src && (rc = coeffs_rows(c, src->d_px, o, g, stream, src->dy, src->dcb, src->dcr, 0, 0))) return rc; // one piece: the whole image first
         *tuple_done = true;
     }
     if (j.fused) { // code + stuff back to back, one read-back
-        if (!fuse_now && (rc = scan_lengths(c, j, o, g, stream, nullptr, /*wait=*/false))) return rc;
+        if ((rc = fuse_now ? scan_tables(c, j, o, g, stream, nullptr) : scan_lengths(c, j, o, g, stream, nullptr, /*wait=*/false))) return rc;
         // One image into host memory the GPU can write — the context's pinned file buffer, or storage of the caller's
         // that is pinned / registered: the stuffing kernel stores straight into it, behind the place of the headers.
         // Small files take that way by default: the stuffing kernel's stores ARE the transfer, and the call has one wait instead
@@ -463,7 +462,9 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
                 }
             }
         }
-        if ((rc = scan_stuff_fused(c, j, stream, 0, nullptr, nullptr, nullptr, /*chained=*/true, direct ? &target : nullptr))) return rc;
+        if (fuse_now) rc = scan_from_pixels(c, j, o, g, stream, src->d_px, direct ? &target : nullptr);
+        else rc = scan_stuff_fused(c, j, stream, 0, nullptr, nullptr, nullptr, /*chained=*/true, direct ? &target : nullptr);
+        if (rc) return rc;
         sw.lap("code+stuff (fused)");
         if (direct) {
             const size_t hdr = head.size(), total = hdr + j.scan_bytes + 2;

@@ -320,24 +320,63 @@ bool pixels_code_usable(const ScanJob &j, const pixo_jpeg_options &o, const pixo
            pixo_dev::pixels_code_supported(o.width, o.height, g.gray);
 }
 
-int scan_code_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream, const void *d_pixels)
+int scan_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream, const void *d_pixels,
+                     HostTarget *host, bool wait)
 {
     namespace pd = pixo_dev;
     int rc = scan_tables(c, j, o, g, stream, nullptr);
     if (rc) return rc;
     const float *qt_all = nullptr;
     if ((rc = device_tables(c.device, &qt_all))) return rc;
-    const size_t words = pd::pixels_code_state_words(pd::pixels_code_groups(o.width, o.height, g.s420));
-    if (words * 8 > c.e_code_state.cap) c.code_state_zero_words = 0; // (a new buffer)
-    HIP_TRY(c.e_code_state.reserve(words * 8));
-    j.code_state_words = words;
-    const bool zero = c.code_state_zero_words >= words;
-    c.code_state_zero_words = 0; // (dirty from here until a stuffing launch has cleaned it)
-    HIP_TRY(pd::launch_pixels_code(d_pixels, o.width, o.height, g.s420, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c.e_tables.as<uint32_t>(),
-                                   c.e_code_state.as<unsigned long long>(), zero, c.e_stream.as<uint32_t>(), c.e_stuff_state.as<unsigned long long>(),
-                                   pd::fused_stuff_state_words(j.stream_cap), reinterpret_cast<unsigned long long *>(c.h_totals), nullptr, true, stream,
-                                   debug().spin_budget));
-    return PIXO_OK;
+    const uint64_t groups = pd::pixels_code_groups(o.width, o.height, g.s420);
+    const size_t words = pd::pixels_code_state_words(groups);
+    // two state blocks: this launch's must be zero, and the launch zeroes the other one (the launch before it used that) on the side
+    if (c.e_pc_state.cap < 2 * words * 8 || c.pc_half_words != words) {
+        HIP_TRY(c.e_pc_state.reserve(2 * words * 8));
+        HIP_TRY(hipMemsetAsync(c.e_pc_state.p, 0, 2 * words * 8, stream));
+        c.pc_half_words = words;
+        c.pc_flip = 0;
+    }
+    // groups of several 6 KiB rounds park their blocks in the space of the tuple this path never writes (jpeg_pixels_code.hip)
+    if ((rc = c.reserve_coef(static_cast<size_t>(groups) * 192 * 128))) return rc;
+    size_t want_cap = std::max<size_t>(j.stream_cap / 4, 4096);
+    for (int attempt = 0;; ++attempt) {
+        uint8_t *out = nullptr;
+        size_t out_cap = 0;
+        if (host) {
+            if (host->grow) {
+                const int rc_h = c.reserve_hfile(host->before + want_cap + host->after);
+                if (rc_h) return rc_h;
+                host->p = c.h_file + host->before;
+                host->cap = c.hfile_cap - host->before - host->after;
+            }
+            out = host->p;
+            out_cap = host->cap;
+        } else {
+            HIP_TRY(c.e_out.reserve(want_cap));
+            out = c.e_out.as<uint8_t>();
+            out_cap = c.e_out.cap;
+        }
+        unsigned long long *mine = c.e_pc_state.as<unsigned long long>() + static_cast<size_t>(c.pc_flip) * words;
+        unsigned long long *other = c.e_pc_state.as<unsigned long long>() + static_cast<size_t>(c.pc_flip ^ 1) * words;
+        c.pc_flip ^= 1;
+        HIP_TRY(pd::launch_pixels_code(d_pixels, o.width, o.height, g.s420, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c.e_tables.as<uint32_t>(),
+                                       mine, /*state_is_zero=*/true, other, words, out, out_cap, reinterpret_cast<unsigned long long *>(c.h_totals), nullptr, true,
+                                       c.d_coef, stream, debug().spin_budget));
+        if (!wait) return PIXO_OK;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c.h_totals[3]) { c.pc_half_words = 0; return scan_retry_multipass(c); } // (both blocks are memset before the next use)
+        j.total_bits = c.h_totals[0];
+        j.scan_bytes = c.h_totals[1];
+        j.nbytes = c.h_totals[2];
+        if (j.scan_bytes > out_cap) { // (nothing was stored beyond the capacity: more room, the same kernel again)
+            if (host && !host->grow) return PIXO_OK; // (the caller's storage is what it is: the caller reports the size needed)
+            if (attempt > 1) return fail(PIXO_ERR_COMPRESSION, "Compression error: scan larger than announced");
+            want_cap = static_cast<size_t>(j.scan_bytes);
+            continue;
+        }
+        return PIXO_OK;
+    }
 }
 
 // The stuffing kernel of jpeg_scan_fused.hip over the packed stream (launch_scan_code has been enqueued; with
@@ -545,9 +584,8 @@ extern "C" int pixo_hip_debug_scan_device_async(const void *d_pixels, const pixo
     if (!j.fused || j.segmented) return fail(PIXO_ERR_COMPRESSION, "Compression error: not a single-pass scan");
     const bool fused = pixels_code_usable(j, *options, g, 1);
     if (form) *form = fused ? 1 : 0;
-    if (fused) {
-        if ((rc = scan_code_from_pixels(*c, j, *options, g, stream, d_pixels))) return rc;
-    } else {
+    if (fused) return scan_from_pixels(*c, j, *options, g, stream, d_pixels, nullptr, /*wait=*/false); // (ONE kernel: the stuffed scan in c.e_out)
+    {
         if ((rc = coeffs_rows(*c, d_pixels, *options, g, stream, dy, dcb, dcr, 0, 0))) return rc;
         if ((rc = scan_lengths(*c, j, *options, g, stream, nullptr, /*wait=*/false))) return rc;
     }

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     uint8_t *stage = lds;
     uint8_t *const out = a_out; // 16-byte aligned; the scan's first byte goes to out[rest.out_skew]
     uint64_t S = 0, ff_before_groups = 0;
-    uint32_t nb_total = 0, sh8 = 0, tail_count = 0, pad_word = ~0u, pad_mask = 0, ff_group = 0, in_front2 = 0;
+    uint32_t nb_total = 0, sh8 = 0, pad_word = ~0u, pad_mask = 0, ff_group = 0, in_front2 = 0;
     bool aborted = false;
     // MULTI: a group of several rounds / with a very long block (rare: noise at q >= 90): the quantised block stays alive for the
     // second walks.  The common case is its own instantiation, in which the block's registers are dead after the first walk.
@@ -318,6 +318,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             p.finish();
         }
         const bool last_round = !MULTI || wbase + wn == local_words;
+        __syncthreads(); // the round's window is complete
+        // The group's LAST SEVEN BITS for the group behind (its first byte may begin in this group): they do not depend on where
+        // this group starts, so they go out at once — the group behind then finds them waiting instead of waiting for them.
+        // (>= 12 bits per group: they are this group's own.)
+        if (last_round && !last_group && tid == 64) {
+            const uint32_t e = group_bits - wbase * 32u; // the end of the group's bits in this window
+            const uint32_t wi = (e - 1u) >> 5, lo = wi ? buf[wi - 1] : (wbase ? s_carry : 0u), hi = buf[wi];
+            const uint32_t used = e - wi * 32u; // bits of word wi in use (1..32): the last 7 bits = bits [used - 7, used) of {lo, hi}
+            const uint64_t both = ((uint64_t)lo << 32) | hi;
+            store_relaxed(&tails[g], kTailValid | (uint32_t)((both >> (32u - used)) & 0x7Fu));
+        }
         if (wbase == 0) { // where the group starts in the scan
             if (wave == 0) {
                 const uint64_t sum = look_back_blocks(desc, sup, g, 0, group_bits, a_state, host_abort, rest.spin_budget);
@@ -325,44 +336,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                     if (sum == kLookBackFailed) s_abort = 1;
                     s_before = sum;
                 }
-            }
-            __syncthreads();
-            if (uni(s_abort)) { aborted = true; return; }
-            S = uni64(s_before);
-            sh8 = (uint32_t)(S & 7);
-            const uint64_t end_bits = (uint64_t)sh8 + group_bits; // in aligned bits: bit 0 = the first bit of the group's first owned byte
-            tail_count = last_group ? 0u : (uint32_t)(end_bits & 7);
-            nb_total = (uint32_t)(last_group ? (end_bits + 7) >> 3 : end_bits >> 3);
-            if (last_group && (end_bits & 7)) { // BitWriterMsb::flush pads the last byte with 1-bits
-                const uint32_t n = 8u - (uint32_t)(end_bits & 7);
-                pad_word = (uint32_t)(end_bits >> 5);
-                pad_mask = ((1u << n) - 1u) << (32u - (uint32_t)(end_bits & 31) - n);
-            }
-        } else {
-            __syncthreads();
-        }
-        // ---- the round's aligned words: thread (wave, row k, lane) takes word 512 wave + 64 k + lane
-        const uint32_t head = uni(wbase ? s_carry : s_head); // the bits in front of the round's first word (low sh8 bits; 0 until the tail of the group before has arrived: see below)
-        uint32_t x[kRows];
-        auto aligned_word = [&](uint32_t jl, uint32_t first_prev) -> uint32_t {
-            const uint32_t cur = jl <= wn ? buf[jl] : 0u, prev = jl ? (jl - 1 <= wn ? buf[jl - 1] : 0u) : first_prev;
-            uint32_t v = sh8 ? (prev << (32u - sh8)) | (cur >> sh8) : cur;
-            v |= wbase + jl == pad_word ? pad_mask : 0u;
-            return v;
-        };
-        // the tail for the group behind: the group's last (S + bits) % 8 bits — never bits of the group before (>= 12 bits per group)
-        if (last_round && !last_group) {
-            const uint32_t at = nb_total * 8u;               // aligned bit where the unfinished byte begins
-            const uint32_t jl = (at >> 5) - wbase;           // its aligned word, in this round
-            if ((uint32_t)tid == (jl % kGroup)) {            // (any one thread)
-                const uint32_t v = aligned_word(jl, wbase ? s_carry : 0u); // (its bits lie behind the head bits: those are not needed)
-                const uint32_t bits_left = tail_count ? (v >> (32u - (at & 31u) - tail_count)) & ((1u << tail_count) - 1u) : 0u;
-                store_relaxed(&tails[g], kTailValid | ((uint64_t)tail_count << 8) | bits_left);
-            }
-        }
-        // the group's first byte began in the group before: wait for its bits (published above by that group, before ITS wait)
-        if (wbase == 0 && sh8 != 0 && g > 0) {
-            if (tid == 0) {
+            } else if (tid == 128 && g > 0) { // meanwhile: the seven bits in front of this group (used if it starts inside a byte)
                 unsigned long long t = load_relaxed(&tails[g - 1]);
                 uint32_t polls = 0;
                 while (!(t & kTailValid)) {
@@ -374,8 +348,28 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             }
             __syncthreads();
             if (uni(s_abort)) { aborted = true; return; }
+            S = uni64(s_before);
+            sh8 = (uint32_t)(S & 7);
+            const uint64_t end_bits = (uint64_t)sh8 + group_bits; // in aligned bits: bit 0 = the first bit of the group's first owned byte
+            nb_total = (uint32_t)(last_group ? (end_bits + 7) >> 3 : end_bits >> 3);
+            if (last_group && (end_bits & 7)) { // BitWriterMsb::flush pads the last byte with 1-bits
+                const uint32_t n = 8u - (uint32_t)(end_bits & 7);
+                pad_word = (uint32_t)(end_bits >> 5);
+                pad_mask = ((1u << n) - 1u) << (32u - (uint32_t)(end_bits & 31) - n);
+            }
+        } else {
+            __syncthreads();
         }
-        const uint32_t head_now = wbase ? head : uni(s_head);
+        // ---- the round's aligned words: thread (wave, row k, lane) takes word 512 wave + 64 k + lane
+        const uint32_t head = uni(wbase ? s_carry : 0u); // a later round: the previous round's last word is in front of its first aligned word
+        uint32_t x[kRows];
+        auto aligned_word = [&](uint32_t jl, uint32_t first_prev) -> uint32_t {
+            const uint32_t cur = jl <= wn ? buf[jl] : 0u, prev = jl ? (jl - 1 <= wn ? buf[jl - 1] : 0u) : first_prev;
+            uint32_t v = sh8 ? (prev << (32u - sh8)) | (cur >> sh8) : cur;
+            v |= wbase + jl == pad_word ? pad_mask : 0u;
+            return v;
+        };
+        const uint32_t head_now = wbase ? head : (uni(s_head) & ((1u << sh8) - 1u)); // the last sh8 of the seven bits in front
         // owned bytes of THIS round: up to the group's last one, or (not the last round) up to the round's last complete aligned word
         const uint32_t round_first = 4u * wbase;
         const uint32_t limit = last_round ? nb_total : (nb_total < 4u * (wbase + wn) ? nb_total : 4u * (wbase + wn));
@@ -384,6 +378,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         const uint32_t jl0 = 512u * (uint32_t)wave + (uint32_t)lane;
 #pragma unroll
         for (int k = 0; k < kRows; k++) {
+            x[k] = 0;
+            if (4u * (wbase + 512u * (uint32_t)wave + 64u * k) >= limit) continue; // (wave-uniform: the row lies behind the round's bytes — most rows of a smooth image's groups)
             const uint32_t jl = jl0 + 64u * k;
             x[k] = aligned_word(jl, head_now);
             const uint32_t first_byte = 4u * (wbase + jl);
@@ -397,6 +393,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         uint32_t wave_ff = 0;
 #pragma unroll
         for (int k = 0; k < kRows; k += 2) {
+            if (4u * (wbase + 512u * (uint32_t)wave + 64u * k) >= limit) { before[k] = before[k + 1] = wave_ff; continue; } // (no bytes, no 0xFF bytes)
             const uint32_t c0 = (uint32_t)__builtin_popcount((uint32_t)(flags >> (4 * k)) & 0xFu);
             const uint32_t c1 = (uint32_t)__builtin_popcount((uint32_t)(flags >> (4 * k + 4)) & 0xFu);
             const uint32_t sc = wave_inclusive_scan(c0 | (c1 << 16));
@@ -437,6 +434,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                 if (!PIXO_ANY64(gave_up)) {
                     front = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)(da & kValueMask)), 63);
                     before2 = front;
+                    // the block's own sum goes out BEFORE waiting for the other blocks' sums (a group of one round knows its count here):
+                    // published behind that wait, the blocks' last groups would form one chain of waits through the whole scan
+                    if (in_block == 63 && last_round && lane == 0) store_relaxed(&sup2[kblk], kFlagAggregate | ((uint64_t)front + ff_group + round_ff));
                     for (uint64_t base = 0;;) {
                         while ((db2 >> 62) == 0 && !gave_up) {
                             __builtin_amdgcn_s_sleep(1);
@@ -478,6 +478,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                 const uint32_t at0 = skew + (all_at_once ? 2048u * (uint32_t)wave + wave_base_ff : 0u) + 4u * (uint32_t)lane;
 #pragma unroll
                 for (int k = 0; k < kRows; k++) {
+                    if (4u * (wbase + 512u * (uint32_t)wave + 64u * k) >= limit) continue; // (wave-uniform)
                     const uint32_t first_byte = 4u * (wbase + jl0 + 64u * k);
                     const uint32_t exist = first_byte < limit ? (limit - first_byte < 4u ? limit - first_byte : 4u) : 0u;
                     const uint32_t m4 = (uint32_t)(flags >> (4 * k)) & 0xFu;
@@ -519,7 +520,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     if (walk_into_window) rounds(std::true_type{}); else rounds(std::false_type{});
     if (aborted) return;
     // the block of 64 groups is complete with its last group: its sum of stuffed zeros for the groups behind
-    if ((g & 63) == 63 && tid == 0) store_relaxed(&sup2[g >> 6], kFlagAggregate | ((uint64_t)in_front2 + ff_group));
+    // (a group of several rounds knows its count only now)
+    if ((g & 63) == 63 && walk_into_window && tid == 0) store_relaxed(&sup2[g >> 6], kFlagAggregate | ((uint64_t)in_front2 + ff_group));
     if (last_group && tid == 0) { // totals: the scan's length in bits (unpadded), its bytes before and after stuffing
         const uint64_t bits = S + group_bits, packed = (S >> 3) + nb_total, stuffed = packed + ff_before_groups + ff_group;
         a_state[1] = bits;

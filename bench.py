@@ -631,7 +631,7 @@ def batch_whole_files(job, q, n_batches=7):
 
 
 def whole_file(job, wl):
-    """Not `value`: the whole file (fused pixel -> bit stream kernel + stuffing kernel + copy of the file to the host) from
+    """Not `value`: the whole file (the fused pixel -> scan kernel + copy of the file to the host) from
     device-resident pixels, reported beside the kernel-only metric."""
     torch, jpeg = job.torch, wl.jpeg
     opts = jpeg.JpegOptions.builder(wl.w, wl.h).quality(wl.q).subsampling(jpeg.Subsampling(wl.ss)).build()
@@ -683,8 +683,8 @@ def whole_file(job, wl):
             smooth["ms_per_image_photo"] = round(sorted(tp)[7] * 1e3, 3)
             smooth["file_bytes_photo"] = int(nb_p)
             smooth["bits_per_pixel_photo"] = round(nb_p * 8 / (wl.w * wl.h), 3)
-            # the DEVICE time per file (pixo_hip_debug_scan_device_async: the product's kernels for one baseline file — the fused
-            # pixel -> bit stream kernel + the stuffing kernel — enqueued back to back, HIP events on the launch stream, no waits,
+            # the DEVICE time per file (pixo_hip_debug_scan_device_async: the product's kernel for one baseline file — pixels -> the
+            # finished, stuffed scan in ONE kernel — enqueued back to back, HIP events on the launch stream, no waits,
             # no PCIe): K files between two events, median of the blocks.  frac = (pixels read + file written) / time / 8 TB/s.
             dev = {}
             for name, d_img, nb in (("noise", wl.ins[0], nbytes), ("photo", d_p, nb_p), ("gradient", d_g, nb_g)):
@@ -693,7 +693,7 @@ def whole_file(job, wl):
                 _, evs = job.time_blocks(lambda i, d_img=d_img: jpeg.debug_scan_device_async(d_img, opts, stream=wl.stream), 50, 10, 5)
                 us = statistics.median(evs) / 50 * 1e3
                 dev[name] = {"device_us_per_file": round(us, 2), "frac_hbm_pixels_plus_file": round((wl.in_bytes + nb) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
-                             "kernels": "pixels_code + stuff_fused" if form else "jpeg_coeffs + scan_code + stuff_fused"}
+                             "kernels": "pixels_code_kernel (one kernel: pixels -> stuffed scan)" if form else "jpeg_coeffs + scan_code + stuff_fused"}
             smooth["device_time"] = dev
             for _ in range(2):
                 jpeg.encode_device_into(pinned, wl.ins[0], opts)
@@ -703,8 +703,8 @@ def whole_file(job, wl):
         return {"value": round(wl.w * wl.h / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_image": round(dt * 1e3, 3), **smooth,
                 "whole_file_from_host_ms": round(sorted(th)[3] * 1e3, 3), "whole_file_from_host_min_ms": round(min(th) * 1e3, 3),
                 "ms_per_image_min": round(min(ts) * 1e3, 3), "file_bytes": int(nbytes), "ms_per_image_as_python_bytes": round(dtb * 1e3, 3),
-                "path": "device-resident pixels -> fused pixel -> bit stream kernel (no coefficient tuple in HBM) -> stuffing kernel "
-                        "-> file in the caller's pinned host buffer (pixo_hip_jpeg_encode_device_into)"}
+                "path": "device-resident pixels -> ONE kernel: colour, DCT, quantiser, Huffman walk, bit placement, 0xFF stuffing (no coefficient tuple, no "
+                        "packed stream in HBM) -> file in the caller's pinned host buffer (pixo_hip_jpeg_encode_device_into)"}
     except Exception as ex:  # the metric line must not depend on this extra
         return {"error": repr(ex)}
 

@@ -362,12 +362,12 @@ uint64_t pixo_hip_debug_lookback_fallbacks(void);
  * memory system of THIS box gives the kernel's 50 MB + 50 MB beside the kernel's own time.  Replaces nothing of the
  * reference.  `bytes` must be a multiple of 24576, the pointers 16-byte aligned; asynchronous on `stream`. */
 int pixo_hip_debug_stream_copy(const void *d_in, void *d_out, size_t bytes, void *stream);
-/* MEASUREMENT only: the DEVICE work of one baseline file with standard tables — pixels -> packed bit stream -> stuffed scan
- * in the context's device buffer — enqueued on `stream` and NOT waited for; nothing is delivered.  The kernels are the ones
- * pixo_hip_jpeg_encode_device[_into] runs: the fused pixel -> bit stream kernel (jpeg_pixels_code.hip; *form = 1) or
- * coefficient kernel + scan_code (*form = 0: gray images, debug switch two_kernel_scan), then the stuffing kernel.  K calls
- * between two events on `stream` = the device time per file without the call's waits and the file's way over PCIe.  The
- * caller synchronises the stream before it calls anything else of this library on the same thread. */
+/* MEASUREMENT only: the DEVICE work of one baseline file with standard tables — pixels -> the finished (stuffed, padded) scan in
+ * the context's device buffer — enqueued on `stream` and NOT waited for; nothing is delivered.  The kernels are the ones
+ * pixo_hip_jpeg_encode_device[_into] runs: the fused pixel -> scan kernel (jpeg_pixels_code.hip: ONE kernel; *form = 1) or
+ * coefficient kernel + scan_code + stuffing kernel (*form = 0: gray images, debug switch two_kernel_scan).  K calls between
+ * two events on `stream` = the device time per file without the call's waits and the file's way over PCIe.  The caller
+ * synchronises the stream before it calls anything else of this library on the same thread. */
 int pixo_hip_debug_scan_device_async(const void *d_pixels, const pixo_jpeg_options *options, void *stream, int *form);
 /* Releases a buffer the library returned.  Blocks of 24 MiB and more are kept (at most two, 1 GiB) for the next large
  * file instead of going back to the system — their pages are resident, a fresh block of that size costs more than the

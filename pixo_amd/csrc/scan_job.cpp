@@ -558,11 +558,11 @@ int scan_pack(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offs
 
 } // namespace pixo_capi
 
-// MEASUREMENT only (bench.py, tools/): the DEVICE work of one baseline file — pixels -> packed stream -> stuffed scan in the
-// context's device buffer — enqueued on the caller's stream and not waited for: K calls back to back between two events give
-// the device time per file without the call's host side (waits, the file's way over PCIe).  The kernels are the product's:
-// the fused pixel -> bit stream kernel where it serves the job (or, *form = 0, coefficient kernel + scan_code), then the
-// stuffing kernel on a grid sized like the product's first guess.  Nothing is delivered.
+// MEASUREMENT only (bench.py, tools/): the DEVICE work of one baseline file — pixels -> the finished scan in the context's
+// device buffer — enqueued on the caller's stream and not waited for: K calls back to back between two events give the device
+// time per file without the call's host side (waits, the file's way over PCIe).  The kernels are the product's: the fused
+// pixel -> scan kernel where it serves the job (*form = 1), else coefficient kernel + scan_code + the stuffing kernel on a grid
+// sized like the product's first guess.  Nothing is delivered.
 extern "C" int pixo_hip_debug_scan_device_async(const void *d_pixels, const pixo_jpeg_options *options, void *stream_, int *form)
 {
     using namespace pixo_capi;

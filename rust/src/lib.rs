@@ -74,6 +74,10 @@ extern "C" {
                                  out_len: *mut usize) -> c_int;
     fn pixo_hip_jpeg_encode_multi(data: *const u8, len: usize, opts: *const COptions, devices: *const c_int, n_devices: u32,
                                   out: *mut *mut u8, out_len: *mut usize) -> c_int;
+    fn pixo_hip_jpeg_encode_batch_multi(pixels: *const u8, opts: *const COptions, batch: u32, devices: *const c_int, n_devices: u32,
+                                        arena: *mut u8, capacity: usize, offsets: *mut usize, lens: *mut usize) -> c_int;
+    fn pixo_hip_encode_jpeg(data: *const u8, len: usize, width: u32, height: u32, color_type: u8, quality: u8, preset: u8,
+                            subsampling_420: c_int, out: *mut *mut u8, out_len: *mut usize) -> c_int;
     fn pixo_hip_png_filter(data: *const u8, len: usize, width: u32, height: u32, bytes_per_pixel: u32, strategy: u8, flags: u32,
                            out: *mut u8, out_capacity: usize, adler32: *mut u32) -> c_int;
     fn pixo_hip_free(p: *mut u8);
@@ -219,6 +223,49 @@ pub mod jpeg {
         }
         Ok(out)
     }
+
+    /// Not in the reference (its counterpart is a loop over `encode`, src/jpeg/mod.rs:88): `images.len() / image_bytes` equally
+    /// sized images, back to back in host memory, encoded by several GPUs of this process (`pixo_hip_jpeg_encode_batch_multi`;
+    /// configs[2] on a node: every GPU fetches its share over its own PCIe link, encodes it in one pass and copies its files to
+    /// their final place).  Returns the files back to back and where each begins: file i = `arena[offsets[i]..offsets[i + 1]]`.
+    pub fn encode_batch_on_devices(images: &[u8], options: &JpegOptions, batch: u32, devices: &[i32]) -> Result<(Vec<u8>, Vec<usize>)> {
+        let c = to_c(options);
+        let n = batch as usize;
+        let (mut offsets, mut lens) = (vec![0usize; n], vec![0usize; n]);
+        let mut arena = Vec::<u8>::with_capacity(images.len() / 4 + 4096);
+        for _ in 0..2 {
+            let rc = unsafe {
+                pixo_hip_jpeg_encode_batch_multi(images.as_ptr(), &c, batch, devices.as_ptr(), devices.len() as u32, arena.as_mut_ptr(),
+                                                 arena.capacity(), offsets.as_mut_ptr(), lens.as_mut_ptr())
+            };
+            let total = if n > 0 { offsets[n - 1] + lens[n - 1] } else { 0 };
+            if rc == 0 {
+                // SAFETY: the library has initialised `total` <= capacity bytes of the arena
+                unsafe { arena.set_len(total) };
+                offsets.push(total);
+                return Ok((arena, offsets));
+            }
+            if rc != PIXO_ERR_BUFFER_TOO_SMALL { return Err(error_from(rc, options, images.len())); }
+            arena.reserve_exact(total); // (offsets / lens were filled in: the second attempt fits)
+        }
+        Err(Error::CompressionError("output size changed between two identical calls".to_string()))
+    }
+}
+
+/// The reference's flat wasm export (`src/wasm.rs:113-142`: `encode_jpeg(data, width, height, color_type, quality, preset,
+/// subsampling_420)`), same seven arguments, through `pixo_hip_encode_jpeg`; errors as the reference's strings.
+pub fn encode_jpeg(data: &[u8], width: u32, height: u32, color_type: u8, quality: u8, preset: u8, subsampling_420: bool)
+    -> std::result::Result<Vec<u8>, String> {
+    let (mut p, mut n) = (std::ptr::null_mut::<u8>(), 0usize);
+    let rc = unsafe { pixo_hip_encode_jpeg(data.as_ptr(), data.len(), width, height, color_type, quality, preset, subsampling_420 as c_int, &mut p, &mut n) };
+    if rc != 0 { return Err(last_error()); }
+    let mut out = Vec::<u8>::with_capacity(n);
+    unsafe {
+        pixo_hip_copy_file(out.as_mut_ptr(), p, n);
+        out.set_len(n);
+        pixo_hip_free(p);
+    }
+    Ok(out)
 }
 
 /// `pixo::png` — the row-filter stage of config 5 (`src/png/filter.rs:51-206`) and the Adler-32 of its output.

@@ -14,6 +14,7 @@ from pixo_amd import jpeg, png, ColorType
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 prog_only = len(sys.argv) > 3 and sys.argv[3] == "progressive"
+fused_only = len(sys.argv) > 3 and sys.argv[3] == "fused"  # only what the fused pixel -> scan kernel serves: RGB, baseline, standard tables
 t0 = time.time(); nj = npn = 0; bad = []
 
 def content(n, kind, seed):
@@ -35,6 +36,12 @@ while time.time() - t0 < budget:
     q = int(rng.randint(1, 101))
     flags = dict(optimize_huffman=bool(rng.rand() < 0.4), progressive=bool(prog_only or rng.rand() < 0.3), trellis=bool(rng.rand() < 0.3))
     restart = int(rng.randint(1, 40)) if rng.rand() < 0.25 else None
+    if fused_only:
+        ct, restart = 2, None
+        flags = dict(optimize_huffman=False, progressive=False, trellis=False)
+        big = rng.rand() < 0.5
+        w = int(rng.randint(4, 4200 if big else 600)); h = int(rng.randint(1, 1200 if big else 300))
+        if rng.rand() < 0.3: q = int(rng.randint(90, 101))  # long blocks, groups of several rounds, many 0xFF bytes
     px = content(w * h * (3 if ct == 2 else 1), int(rng.randint(0, 6)), int(rng.randint(1, 1 << 30)))
     b = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss)) \
         .optimize_huffman(flags["optimize_huffman"]).progressive(flags["progressive"]).trellis_quant(flags["trellis"])
@@ -46,7 +53,7 @@ while time.time() - t0 < budget:
     nj += 1
     if got != want:
         bad.append(("jpeg", w, h, ct, ss, q, flags, restart)); print("MISMATCH", bad[-1], flush=True)
-    if prog_only:
+    if prog_only or fused_only:
         continue
     # ---- PNG
     bpp = int(rng.choice([1, 2, 3, 4, 6, 8])); w = int(rng.randint(1, 6000 if rng.rand() < 0.2 else 700)); h = int(rng.randint(1, 120))

@@ -310,9 +310,11 @@ def issue_of(name, kernel_us):
     path = os.path.join(ROOT, "profiles", "issue_%s.json" % name)
     try:
         d = json.load(open(path))
-        frac = d["insts_valu_per_launch"] * 4.0 / (SIMDS * GPU_CLOCK_HZ * kernel_us * 1e-6)
-        return {"frac_issue": round(frac, 4), "valu_insts_per_launch": d["insts_valu_per_launch"],
-                "issue_source": "profile: " + os.path.relpath(path, ROOT) + " (x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time of this run))"}
+        # cycles in which a SIMD's vector ALU was issuing, summed over the SIMDs (SQ_ACTIVE_INST_VALU x 4; older profiles: instructions x 4)
+        active = d.get("active_valu_cycles_per_launch") or d["insts_valu_per_launch"] * 4.0
+        frac = active / (SIMDS * GPU_CLOCK_HZ * kernel_us * 1e-6)
+        return {"frac_issue": round(frac, 4), "valu_insts_per_launch": d["insts_valu_per_launch"], "valu_active_cycles_per_launch": active,
+                "issue_source": "profile: " + os.path.relpath(path, ROOT) + " (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x 2.4 GHz x kernel time of this run))"}
     except Exception:
         return {}
 

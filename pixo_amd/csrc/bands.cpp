@@ -662,9 +662,17 @@ int pixo_hip_jpeg_encode_batch_multi(const void *pixels, const pixo_jpeg_options
                     local = buf.px;
                 }
             }
+            sh.offs.assign(sh.count, 0); sh.lens.assign(sh.count, 0);
+            if (parts == 1 && !sh.rc) { // one GPU: nothing to place among other shares — the files go straight into the caller's arena, their
+                // way over PCIe overlapping the kernels of the next sub-batch (no device arena, no second pass over the bytes)
+                const int r = pixo_hip_jpeg_encode_batch_device_into(local, options, sh.count, arena, capacity, sh.offs.data(), sh.lens.data());
+                for (uint32_t i = 0; i < sh.count; ++i) { offsets[i] = sh.offs[i]; lens[i] = sh.lens[i]; }
+                if (r == PIXO_ERR_BUFFER_TOO_SMALL) { total = sh.offs[sh.count - 1] + sh.lens[sh.count - 1]; too_small.store(true); }
+                else step(r);
+                return;
+            }
             // ---- its files, complete with headers and EOI, back to back in this GPU's memory (grow and repeat when the guess
             // was short: pixo_hip_jpeg_encode_batch_device_into fills in the lengths either way)
-            sh.offs.assign(sh.count, 0); sh.lens.assign(sh.count, 0);
             size_t want = std::max<size_t>(px_bytes / 3, size_t{1} << 16);
             for (int attempt = 0; !sh.rc && attempt < 3; ++attempt) {
                 hip_step(buf.reserve(&buf.arena, &buf.arena_cap, want), "hipMalloc (files of a batch share)");

@@ -74,6 +74,7 @@ struct DebugSwitches {
     std::vector<uint32_t> piece_schedule{1, 3};
     unsigned copy_threads = 8;
     uint32_t spin_budget = 1u << 20;
+    uint32_t batch_parts = 0; // (measurements) sub-batches of pixo_hip_jpeg_encode_batch_device_into, 0 = the library's choice
 };
 const DebugSwitches &debug();
 

@@ -72,6 +72,7 @@ DebugSwitches parse_switches(const char *e)
         else if (name == "piece_groups" && num > 0) v.piece_groups = static_cast<uint64_t>(num);
         else if (name == "piece_medium") { v.piece_medium_forced = true; if (num > 0) v.piece_medium = static_cast<uint64_t>(num); }
         else if (name == "copy_threads") v.copy_threads = static_cast<unsigned>(num < 1 ? 1 : (num > 64 ? 64 : num));
+        else if (name == "batch_parts" && num > 0) v.batch_parts = static_cast<uint32_t>(num);
         else if (name == "spin_budget" && !val.empty()) v.spin_budget = static_cast<uint32_t>(num < 0 ? 0 : num);
         else if (name == "piece_schedule") {
             std::vector<uint32_t> w;

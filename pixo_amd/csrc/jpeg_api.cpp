@@ -529,9 +529,17 @@ int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg
     // the same batch, and eight passes cost 0.66 ms where one takes 0.43.  The context remembers the last batch's bytes per
     // block; an unknown or changed content is found out after the first sub-batch, the rest then goes in one pass.
     const size_t blocks_per_image = g.y_blocks + 2 * g.c_blocks;
-    constexpr uint32_t kWorthIt = 8; // bytes per block
-    uint32_t parts = px_bytes * batch >= (size_t{64} << 20) && (c->batch_per_block == 0 || c->batch_per_block > kWorthIt)
-                         ? std::min<uint32_t>(std::max<uint32_t>(batch / 8, 1), 8) : 1;
+    // Round 5: in between (photograph-like content, 3-8 bytes per block: 64 x 1080p = 22 MB) four sub-batches — 0.76 -> 0.61 ms,
+    // where eight take 0.73 (profiles/r05_batch_parts.txt).
+    constexpr uint32_t kWorthIt = 8, kMedium = 3; // bytes per block
+    auto parts_for = [&](uint32_t one_plus_per_block) -> uint32_t {
+        if (px_bytes * batch < (size_t{64} << 20)) return 1;
+        if (one_plus_per_block == 0 || one_plus_per_block > kWorthIt) return std::min<uint32_t>(std::max<uint32_t>(batch / 8, 1), 8);
+        if (one_plus_per_block > kMedium) return std::min<uint32_t>(std::max<uint32_t>(batch / 16, 1), 4);
+        return 1;
+    };
+    uint32_t parts = parts_for(c->batch_per_block);
+    if (debug().batch_parts) parts = std::min<uint32_t>(debug().batch_parts, batch);
     Context *second = nullptr;
     if (parts > 1) {
         second = pool().take(c->device);
@@ -584,7 +592,10 @@ int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg
         first += nb;
         const size_t per_block = (at - at0) / (static_cast<size_t>(nb) * blocks_per_image);
         c->batch_per_block = static_cast<uint32_t>(1 + per_block);
-        if (part == 0 && parts > 1 && per_block < kWorthIt) parts = 2; // (small files after all: everything else in one more pass)
+        if (part == 0 && parts > 1 && !debug().batch_parts) { // (what the content really is: the rest in as many passes as that is worth)
+            const uint32_t want = parts_for(c->batch_per_block);
+            if (want < parts) parts = std::max<uint32_t>(want, 2);
+        } // (small files after all: everything else in one more pass)
     }
     { // (both streams: also after an error, the second context goes back to the pool idle)
         hipError_t e = hipStreamSynchronize(c->stream);

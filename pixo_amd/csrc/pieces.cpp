@@ -444,7 +444,10 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
                                  (c.last_scan_blocks && static_cast<double>(j.n) * static_cast<double>(c.last_scan_bytes) / static_cast<double>(c.last_scan_blocks) <= kDirectBytes));
         HostTarget target;
         bool direct = false;
-        if (batch == 1 && !j.segmented && (direct_host_stores() || small_file)) {
+        // The one-kernel form (round 5) stores directly at EVERY size: its groups finish one after the other, so the stores of the
+        // early ones cross PCIe while the late ones are still coding — 4096x4096 photo-like content 0.129 -> 0.112 ms, noise
+        // (11 MB, PCIe-bound either way) 0.291 -> 0.283 ms against kernel + copy engine (profiles/r05_whole_file.txt).
+        if (batch == 1 && !j.segmented && (direct_host_stores() || small_file || (fuse_now && !debug().no_direct_small))) {
             pixo_host::file_headers(head, o, j.h); // (the tables are known since scan_lengths)
             if (!dest) {
                 target.grow = true;

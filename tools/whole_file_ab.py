@@ -4,6 +4,7 @@
 `two_kernel_scan`: coefficient kernel + scan_code), interleaved on the same box.  Content: noise (5.3 bit/px), photo
 (synth.photo, ~1.3 bit/px), gradient (0.15 bit/px).
     python tools/whole_file_ab.py                 the A/B table
+    python tools/whole_file_ab.py forms a= b=direct_stores ...   forms named by their PIXO_HIP_DEBUG switches
     python tools/whole_file_ab.py loop <kind> <n> [two]   n calls of one form (for rocprofv3 --kernel-trace --stats)"""
 import os
 import statistics
@@ -38,13 +39,21 @@ def main():
             jpeg.encode_device_into(buf, d, O)
         print("loop", kind, n, "two_kernel_scan" if len(sys.argv) > 4 else "fused")
         return
+    # forms: name=debug switches ("" = the default form); default A/B: the one-kernel form against the two-kernel form
+    forms = {"fused": None, "two_kernel": "two_kernel_scan"}
+    if len(sys.argv) > 1 and sys.argv[1] == "forms":
+        forms = {}
+        for spec in sys.argv[2:]:
+            name, _, sw = spec.partition("=")
+            forms[name] = sw or None
+    names = list(forms)
     for kind in ("noise", "photo", "gradient"):
         d = pixels(kind)
-        res = {"fused": [], "two_kernel": []}
+        res = {f: [] for f in names}
         sizes = {}
         for rep in range(31):
-            for form in ("fused", "two_kernel") if rep % 2 == 0 else ("two_kernel", "fused"):
-                jpeg.debug_configure("two_kernel_scan" if form == "two_kernel" else None)
+            for form in names if rep % 2 == 0 else names[::-1]:
+                jpeg.debug_configure(forms[form])
                 if rep == 0:
                     for _ in range(3):
                         jpeg.encode_device_into(buf, d, O)
@@ -52,15 +61,15 @@ def main():
                 t0 = time.perf_counter()
                 n = jpeg.encode_device_into(buf, d, O)
                 res[form].append((time.perf_counter() - t0) * 1e3)
-                if form in sizes:
-                    assert sizes[form] == bytes(buf[:n].numpy().tobytes()[:4096]) + n.to_bytes(8, "little")
-                sizes[form] = bytes(buf[:n].numpy().tobytes()[:4096]) + n.to_bytes(8, "little")
+                sig = bytes(buf[:n].numpy().tobytes()[:4096]) + n.to_bytes(8, "little")
+                assert sizes.setdefault(form, sig) == sig
         jpeg.debug_configure(None)
-        assert sizes["fused"] == sizes["two_kernel"], "the two forms give different files"
-        n = int.from_bytes(sizes["fused"][-8:], "little")
-        f, t = statistics.median(res["fused"][1:]), statistics.median(res["two_kernel"][1:])
-        print("%-9s file %9d bytes (%.2f bit/px)   fused %.4f ms (min %.4f)   two-kernel %.4f ms (min %.4f)   ratio %.3f"
-              % (kind, n, n * 8 / (W * H), f, min(res["fused"]), t, min(res["two_kernel"]), f / t))
+        assert len(set(sizes.values())) == 1, "the forms give different files"
+        n = int.from_bytes(sizes[names[0]][-8:], "little")
+        med = {f: statistics.median(res[f][1:]) for f in names}
+        print("%-9s file %9d bytes (%.2f bit/px)   " % (kind, n, n * 8 / (W * H))
+              + "   ".join("%s %.4f ms (min %.4f)" % (f, med[f], min(res[f])) for f in names)
+              + "   ratio %.3f" % (med[names[0]] / med[names[-1]]))
 
 
 if __name__ == "__main__":

@@ -150,10 +150,18 @@ struct ProgCode {
     uint32_t nscans;
     uint32_t scan_id[7];      // index into the script: 0..2 DC of Y, Cb, Cr; 3 Y 1..10; 4 Y 11..63; 5 Cb 1..63; 6 Cr 1..63
     uint64_t size[7];         // blocks
-    uint64_t first_group[8];  // first group (of 192 blocks) of scan k; [nscans] = groups in all
+    uint64_t first_group[8];  // scan k's first slot in the per-(scan, group) state arrays (groups of 192 blocks); [nscans] = slots in all
+    // round 5: the WORKGROUPS are per component — group i of component c holds its blocks [192 i, 192 i + 192) and codes them once
+    // per scan of the component (comp_pass[c][0 .. comp_npass[c]): indices k into scan_id / size / first_group, script order)
+    uint64_t comp_first[4];   // first workgroup of the i-th run; [3] = workgroups in all (a component without blocks: none)
+    uint32_t comp_order[3];   // the component whose groups form the i-th run
+    uint64_t comp_blocks[3];
+    uint32_t comp_npass[3];
+    uint32_t comp_pass[3][3];
 };
+void prog_code_plan(ProgCode &a); // comp_* from nscans / scan_id / size (the caller has filled those and first_group)
 size_t prog_code_state_words(uint64_t groups); // u64 words of d_state
-uint64_t prog_groups(uint32_t scan_id, uint64_t blocks); // groups of one scan (192 blocks; a DC scan: 768)
+uint64_t prog_groups(uint32_t scan_id, uint64_t blocks); // state slots of one scan: its component's groups of 192 blocks
 // d_state: zeroed (by the launcher unless state_is_zero); d_stream: scan k at word seg.var_word[k], room for
 // prog_stream_bytes(scan_id, blocks) bytes; d_clear / clear_words, host_totals ([3]: abort flag), spin_budget: as launch_scan_code
 size_t prog_stream_bytes(uint32_t scan_id, uint64_t blocks);

@@ -497,6 +497,58 @@ PIXO_SDEV void band_pack_flat(const uint32_t *w, int ss, int se, const uint32_t 
     *any = seen;
     *ends_zero = run16 != 0u;
 }
+// Round 5: ALL AC scans of a block's component in ONE walk over its 63 positions.  split: the script codes the component in
+// two bands, 1..10 and 11..63 (luminance) — the walk then notes where the first band's bits end (*first_bits), hands out its
+// flags and starts the second band with a fresh zero run, in the same scratch right behind the first band's bits; !split:
+// the one band 1..63 (chrominance; *first_bits = all its bits, the second band's flags are false).
+template <class Sink>
+PIXO_SDEV void bands_pack_flat(const uint32_t *w, bool split, const uint32_t *wtab, FlatPack<Sink> &p, uint32_t *first_bits, bool *any,
+                               bool *ends_zero)
+{
+    const uint32_t zrl = wtab[kWalkZrl];
+    uint32_t run16 = 0;
+    bool seen = false;
+    any[0] = any[1] = ends_zero[0] = ends_zero[1] = false;
+#pragma unroll
+    for (int k = 1; k < 64; k++) {
+        if (k == 11 && split) { // (uniform) the first band ends here
+            any[0] = seen; ends_zero[0] = run16 != 0u;
+            *first_bits = p.word * 32u + p.pending;
+            seen = false; run16 = 0;
+        }
+        const int v = coef_of(w, zigzag(k));
+        const uint64_t nz_lanes = PIXO_BALLOT64(v != 0);
+        if (!nz_lanes) { run16 += 16u; continue; } // (wave-uniform on the device)
+        const bool nz = v != 0;
+        seen = seen || nz;
+        if (k > 16 && __builtin_expect((PIXO_BALLOT64(run16 >= 256u) & nz_lanes) != 0, 0)) { // up to three ZRL codes in front of the symbol
+#pragma unroll
+            for (uint32_t i = 0; i < 3; i++) {
+                const bool on = nz && (run16 >> 8) > i;
+                p.put_left(on ? (zrl & 0xFFFF0000u) : 0u, on ? (zrl & 0xFFu) : 0u);
+            }
+            run16 = nz ? (run16 & 255u) : run16;
+        }
+        const int u = v + (v >> 31);
+        const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u;
+        const uint32_t slot = (k > 16 ? (run16 & 255u) : run16) | (m & 15u);
+        put_symbol(p, wtab[kWalkDc + slot], (uint32_t)u, m);
+        run16 = nz ? 0u : run16 + 16u;
+    }
+    const int last = split ? 1 : 0;
+    any[last] = seen; ends_zero[last] = run16 != 0u;
+    if (!split) *first_bits = p.word * 32u + p.pending;
+}
+// Word j of the `n` bits that begin at bit `from` of a lane's scratch (left-aligned, zero behind the last bit): what the
+// gather of a band ORs into the window.  words: the lane's scratch, `limit` words of it hold bits.
+PIXO_SDEV uint32_t scratch_bits_word(const uint32_t *words, uint32_t limit, uint32_t from, uint32_t n, uint32_t j)
+{
+    const uint32_t at = (from >> 5) + j, sh = from & 31u;
+    const uint32_t a = at < limit ? words[at] : 0u, b = at + 1 < limit ? words[at + 1] : 0u;
+    const uint32_t v = sh ? (a << sh) | (b >> (32u - sh)) : a;
+    const uint32_t have = n > 32u * j ? n - 32u * j : 0u; // bits of this word that belong to the run
+    return have >= 32u ? v : (have ? v & ~(0xFFFFFFFFu >> have) : 0u);
+}
 // the DC symbol of a first DC scan (encode_dc_first, progressive.rs:112-133 with al = 0)
 template <class Sink> PIXO_SDEV void dc_pack_flat(const uint32_t *w, int prev_dc, const uint32_t *wtab, FlatPack<Sink> &p)
 {

@@ -318,158 +318,227 @@ extern "C" __attribute__((visibility("default"))) int pixo_hip_debug_scan_timeli
 //     A descriptors go out right after the walk, before any length is known, so that look-back rarely waits;
 //   * a group may have no bits at all (192 empty blocks): it leaves an aggregate of zero bits in look-back B and a
 //     "transparent" mark in its tail slot (the stream word two groups share is found by a look-back over the tails) and is done.
-// state: [0] abort flag, [1] -, then per group: descriptor A, descriptor B, tail.
-constexpr uint32_t kDcPerLane = 4; // blocks a lane of a DC scan codes (4 x at most 27 bits: inside the lane's scratch)
-constexpr uint32_t kEobSyms = 16; // per class: the packed words of symbols 0x00 .. 0xE0 (end-of-band runs), one spare
+//
+// Round 5: ONE LOAD and ONE WALK of a block serve every scan it takes part in.  A workgroup holds 192 consecutive blocks of ONE
+// component: a lane reads its block once, codes its DC symbol (dc_symbol_bits) and walks its 63 AC positions once
+// (bands_pack_flat: luminance as the bands 1..10 and 11..63 back to back in the lane's scratch, chrominance as 1..63) — and then
+// is a link in the chains of up to THREE scans at the same place (its component's DC scan and AC scans): three bit counts and
+// two run counters published together, the look-backs of the three scans run side by side on the group's three wavefronts,
+// and the scans' bits are placed and written out one after the other through the same LDS window.  (Round 4 gave every scan
+// workgroups of its own: a luminance block was read three times — 110-134 MB of HBM traffic for a 50 MB tuple — and walked
+// twice; a first round-5 version that kept one workgroup per component but ran the scans as passes, one after the other, paid
+// the look-backs' latency once per pass: 85 us where round 4 took 75, the DC pass alone 20 us for 2 % of the bits.)
+// Every wait still points at a lower workgroup id.  The look-back over the bit counts is the reduce-then-scan form in two
+// levels (look_back_blocks) like scan_code's; the run counter's and the shared word's keep the chained form (their sums are
+// not sums).
+// state: [0] abort flag, [1] -, then per (scan, group): descriptor A, descriptor B, tail; then the block sums of the B chains.
+constexpr uint32_t kEobSyms = 16; // the packed words of the class's symbols 0x00 .. 0xE0 (end-of-band runs), one spare
 __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) void prog_code_kernel
-(const ProgCode a, const SegArgs seg, unsigned long long *state, uint32_t *stream, unsigned long long *clear, uint32_t clear_words,
+(const ProgCode a, const SegArgs seg, unsigned long long *state, uint32_t *stream0, unsigned long long *clear, uint32_t clear_words,
  unsigned long long *host_totals, uint32_t spin_budget)
 {
     __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
-    __shared__ uint32_t tab[kWalkWords];
-    __shared__ uint32_t eobs[2 * kEobSyms];
+    __shared__ uint32_t tab[kWalkClassWords];
+    __shared__ uint32_t eobs[kEobSyms];
     __shared__ uint32_t scratch[kGroup * kScratchPitch];
-    __shared__ uint32_t wave_sum[kGroupWaves], wave_long[kGroupWaves], wave_any[kGroupWaves], wave_tail[kGroupWaves];
-    __shared__ unsigned long long s_before, s_in;
-    __shared__ uint32_t s_carry, s_abort;
+    __shared__ uint32_t wave_sum[3][kGroupWaves], wave_long[kGroupWaves], wave_any[2][kGroupWaves], wave_tail[2][kGroupWaves];
+    __shared__ int16_t s_dc[kGroup], s_ext_dc;
+    __shared__ unsigned long long s_before[3], s_in[2];
+    __shared__ uint32_t s_carry, s_abort, s_head[3], s_share[3];
+    __shared__ unsigned long long s_first_word[3];
     const int lane = threadIdx.x, wave = lane >> 6;
-    if (lane == 0) { s_carry = 0; s_abort = 0; s_in = 0; }
-    const uint64_t g = blockIdx.x;
-    uint32_t k = 0; // the scan this group belongs to (wave-uniform)
+    if (lane == 0) s_abort = 0;
+    if (lane < 3) s_share[lane] = 0;
+    uint32_t slot = 0; // which run of workgroups this one belongs to: comp_first[slot] <= id < comp_first[slot + 1]
 #pragma unroll
-    for (uint32_t i = 1; i < 7; i++) k += (i < a.nscans && g >= a.first_group[i]) ? 1u : 0u;
-    const uint32_t scan = a.scan_id[k];
-    const bool dc_scan = scan < 3;
-    // (a lane of a DC scan codes kDcPerLane consecutive blocks — one short symbol each: with one block per lane the three DC
-    // scans were 37 % of the launch's groups for 2 % of its work)
-    const uint32_t group_blocks = dc_scan ? kGroup * kDcPerLane : kGroup;
-    const uint64_t floor_g = a.first_group[k], nblocks_chain = a.size[k], first_in_chain = (g - floor_g) * group_blocks;
+    for (uint32_t i = 1; i < 3; i++) slot += blockIdx.x >= a.comp_first[i] ? 1u : 0u;
+    const uint32_t comp = a.comp_order[slot]; // the component this workgroup's blocks belong to (uniform)
+    const uint64_t local = blockIdx.x - a.comp_first[slot]; // the group's place among the component's groups
+    const uint64_t nblocks_chain = a.comp_blocks[comp];
+    const uint32_t nseg = a.comp_npass[comp]; // scans of the component: 2 (DC, 1..63) or 3 (DC, 1..10, 11..63)
+    const bool split = nseg == 3;
+    const int cls = comp ? 1 : 0;
     const uint64_t ngroups_total = a.first_group[a.nscans];
-    unsigned long long *desc_a = state + 2, *desc = state + 2 + ngroups_total, *tails = state + 2 + 2 * ngroups_total;
+    unsigned long long *const desc_a = state + 2, *const desc = state + 2 + ngroups_total, *const tails = state + 2 + 2 * ngroups_total;
+    unsigned long long *const sup_all = state + 2 + 3 * ngroups_total;
     unsigned long long *const host_abort = host_totals ? host_totals + 3 : nullptr;
-    stream += seg.var_word[k];
-    const int comp = prog_comp((int)scan), cls = comp ? 1 : 0;
-    const int ss = scan == 4 ? 11 : 1, se = scan == 3 ? 10 : 63;
-    const uint64_t my_first = first_in_chain + (uint64_t)lane * (dc_scan ? kDcPerLane : 1u);
+    const uint64_t my_first = local * kGroup + (uint64_t)lane;
     const bool live = my_first < nblocks_chain;
-    const bool last_of_scan = !dc_scan && my_first + 1 == nblocks_chain;
-    uint32_t w[32];
-    int dcs[kDcPerLane + 1]; // DC scans: the predictor and the lane's blocks' first coefficients
-    uint32_t dc_count = 0;
+    const bool last_group = (local + 1) * kGroup >= nblocks_chain;
+    const int16_t *const my_block = (comp == 0 ? a.y : (comp == 1 ? a.cb : a.cr)) + (live ? my_first : 0) * 64;
+    // ---- the block, the tables, the DC predictors (jpeg/mod.rs:1268-1300: the first coefficient of the block before)
+    uint32_t dc_len, first_bits, all_bits;
+    uint32_t dc_left;
+    bool any[2], ends_zero[2];
     {
-        const int16_t *base = comp == 0 ? a.y : (comp == 1 ? a.cb : a.cr);
-        const uint64_t b = live ? my_first : 0;
-        if (dc_scan) { // only the blocks' first coefficients (and the one before them: the predictor, jpeg/mod.rs:1268-1300)
+        uint32_t w[32];
+        const v4u *p4 = reinterpret_cast<const v4u *>(my_block);
 #pragma unroll
-            for (int i = 0; i < 32; i++) w[i] = 0;
-            const uint64_t left = live ? nblocks_chain - my_first : 0;
-            dc_count = left < kDcPerLane ? (uint32_t)left : kDcPerLane;
-            dcs[0] = b ? (int)base[(b - 1) * 64] : 0;
-#pragma unroll
-            for (uint32_t j = 0; j < kDcPerLane; j++) dcs[j + 1] = j < dc_count ? (int)base[(b + j) * 64] : 0;
-        } else {
-            const v4u *p = reinterpret_cast<const v4u *>(base + b * 64);
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const v4u q = p[r];
-                w[4 * r] = q.x; w[4 * r + 1] = q.y; w[4 * r + 2] = q.z; w[4 * r + 3] = q.w;
-            }
+        for (int r = 0; r < 8; r++) {
+            const v4u q = p4[r];
+            w[4 * r] = q.x; w[4 * r + 1] = q.y; w[4 * r + 2] = q.z; w[4 * r + 3] = q.w;
         }
-    }
-    for (int i = lane; i < kWalkWords; i += kGroup) tab[i] = a.tables[kTableWords + i];
-    if (lane < 30) eobs[(lane / 15) * kEobSyms + lane % 15] = a.tables[(lane / 15) * kClassSyms + kDcSyms + ((lane % 15) << 4)];
-    for (uint64_t i = (uint64_t)blockIdx.x * kGroup + lane; i < clear_words; i += (uint64_t)gridDim.x * kGroup) clear[i] = 0;
-    __syncthreads();
-    // ---- the walk: the lane's own symbols into its scratch from bit 0
-    uint32_t own;
-    bool nonempty = false, ends_zero = false;
-    {
+        if (lane == 0) s_ext_dc = my_first ? *(my_block - 64) : (int16_t)0;
+        for (int i = lane; i < kWalkClassWords; i += kGroup) tab[i] = a.tables[kTableWords + cls * kWalkClassWords + i];
+        if (lane < 15) eobs[lane] = a.tables[cls * kClassSyms + kDcSyms + (lane << 4)];
+        for (uint64_t i = (uint64_t)blockIdx.x * kGroup + lane; i < clear_words; i += (uint64_t)gridDim.x * kGroup) clear[i] = 0;
+        const int dc = coef_of(w, 0);
+        s_dc[lane] = (int16_t)dc;
+        __syncthreads();
+        // ---- the walks: the DC symbol (encode_dc_first, progressive.rs:112-133, al = 0) as bits of a word; the AC bands
+        // (progressive.rs:141-210) into the lane's scratch from bit 0
+        const DcBits db = dc_symbol_bits(dc, lane ? (int)s_dc[lane - 1] : (int)s_ext_dc, tab);
+        dc_left = db.left; dc_len = db.len;
         FlatPack<LaneSink> p;
         p.sink = LaneSink{scratch + lane * kScratchPitch};
         p.acc = 0; p.pending = 0; p.word = 0;
-        if (dc_scan) {
-#pragma unroll
-            for (uint32_t j = 0; j < kDcPerLane; j++) { // encode_dc_first (progressive.rs:112-133, al = 0), block after block
-                const bool on = j < dc_count;
-                const int diff = (int)(int16_t)(dcs[j + 1] - dcs[j]);
-                const int u = on ? diff + (diff >> 31) : 0;
-                const uint32_t sb = scan_sign_bits(u), m = sb < 32u ? sb : 32u;
-                put_symbol(p, on ? tab[cls * kWalkClassWords + (m & 15u)] : kWalkNothing, (uint32_t)u, m);
-            }
-        } else band_pack_flat(w, ss, se, tab + cls * kWalkClassWords, p, &nonempty, &ends_zero);
-        own = p.word * 32u + p.pending;
+        bands_pack_flat(w, split, tab, p, &first_bits, any, ends_zero);
+        all_bits = p.word * 32u + p.pending;
         p.finish();
     }
-    if (!live) { own = 0; nonempty = false; ends_zero = false; }
-    // ---- the run counter: what it puts in front of and behind the lane's symbols
-    BandEdge edge;
-    edge.pre.left = edge.pre.len = edge.post.left = edge.post.len = 0;
-    if (!dc_scan) { // (wave-uniform)
-        const uint64_t zmask = PIXO_BALLOT64(nonempty), tmask = PIXO_BALLOT64(ends_zero);
-        const BandCount bc = band_count_in_wave(zmask, tmask, lane & 63);
-        if ((lane & 63) == 0) {
-            bool any; uint32_t tail;
-            band_wave_summary(zmask, tmask, &any, &tail);
-            wave_any[wave] = any ? 1u : 0u;
-            wave_tail[wave] = tail;
+    if (!live) { dc_len = 0; first_bits = all_bits = 0; any[0] = any[1] = ends_zero[0] = ends_zero[1] = false; }
+    const bool long_block = all_bits > kScratchWords * 32u;
+    // what scan S of the component (0: DC, 1: the first AC band, 2: the second) is in the launch
+    auto scan_k = [&](int S) -> uint32_t { return a.comp_pass[comp][S]; };
+    // ---- the run counters of the AC scans: what each puts in front of and behind the lane's symbols.  Band S + 1's ballots, the
+    // wavefronts' summaries, the group's count for the groups behind; its look-back runs on wavefront S
+    BandEdge edge[2];
+    {
+        BandCount bc[2];
+#pragma unroll
+        for (int S = 0; S < 2; S++) {
+            edge[S].pre.left = edge[S].pre.len = edge[S].post.left = edge[S].post.len = 0;
+            if (S == 1 && !split) continue; // (uniform)
+            const uint64_t zmask = PIXO_BALLOT64(any[S]), tmask = PIXO_BALLOT64(ends_zero[S]);
+            bc[S] = band_count_in_wave(zmask, tmask, lane & 63);
+            if ((lane & 63) == 0) {
+                bool wany; uint32_t tail;
+                band_wave_summary(zmask, tmask, &wany, &tail);
+                wave_any[S][wave] = wany ? 1u : 0u;
+                wave_tail[S][wave] = tail;
+            }
         }
         __syncthreads();
-        uint32_t into_wave = 0, group_tail = 0; // counts from the wavefronts before this one / of the whole group, not counting what flows into the group
-        bool wave_open = true, group_open = true; // "no non-empty block so far": what flows into the group is still to be added
+        uint32_t into_wave[2] = {0, 0};
+        bool wave_open[2] = {true, true};
 #pragma unroll
-        for (int i = 0; i < kGroupWaves; i++) {
-            if (i < wave) { if (wave_any[i]) { into_wave = wave_tail[i]; wave_open = false; } else into_wave += wave_tail[i]; }
-            if (wave_any[i]) { group_tail = wave_tail[i]; group_open = false; } else group_tail += wave_tail[i];
-        }
-        if (lane == 0) {
-            if (!group_open) store_relaxed(&desc_a[g], kFlagPrefix | group_tail); // nothing before this group matters behind it
-            else publish_aggregate(desc_a, g, floor_g, group_tail);
-        }
-        if (wave == 0) {
-            const uint64_t sum = look_back(desc_a, g, floor_g, group_tail, state, host_abort, spin_budget);
-            if (lane == 0) {
-                if (sum == kLookBackFailed) s_abort = 1;
-                s_in = sum;
-                if (group_open && g != floor_g && sum != kLookBackFailed) store_relaxed(&desc_a[g], kFlagPrefix | (sum + group_tail));
+        for (int S = 0; S < 2; S++) {
+            if (S == 1 && !split) continue;
+            uint32_t group_tail = 0; // the count behind the group's last non-empty block (all of its t when it holds none), not counting what flows in
+            bool group_open = true;  // "no non-empty block so far": what flows into the group is still to be added
+#pragma unroll
+            for (int i = 0; i < kGroupWaves; i++) {
+                if (i < wave) { if (wave_any[S][i]) { into_wave[S] = wave_tail[S][i]; wave_open[S] = false; } else into_wave[S] += wave_tail[S][i]; }
+                if (wave_any[S][i]) { group_tail = wave_tail[S][i]; group_open = false; } else group_tail += wave_tail[S][i];
+            }
+            if (wave == S) { // (uniform per wavefront)
+                const uint64_t floor_g = a.first_group[scan_k(S + 1)], g = floor_g + local;
+                if ((lane & 63) == 0) {
+                    if (!group_open) store_relaxed(&desc_a[g], kFlagPrefix | group_tail); // nothing before this group matters behind it
+                    else publish_aggregate(desc_a, g, floor_g, group_tail);
+                }
+                const uint64_t sum = look_back(desc_a, g, floor_g, group_tail, state, host_abort, spin_budget);
+                if ((lane & 63) == 0) {
+                    if (sum == kLookBackFailed) s_abort = 1;
+                    s_in[S] = sum;
+                    if (group_open && g != floor_g && sum != kLookBackFailed) store_relaxed(&desc_a[g], kFlagPrefix | (sum + group_tail));
+                }
             }
         }
         __syncthreads();
         if (s_abort) return;
-        const uint32_t C = bc.local + (bc.carried ? into_wave + (wave_open ? (uint32_t)s_in : 0u) : 0u);
-        edge = band_edge(C, live, nonempty, ends_zero, last_of_scan, eobs + cls * kEobSyms);
+#pragma unroll
+        for (int S = 0; S < 2; S++) {
+            if (S == 1 && !split) continue;
+            const uint32_t C = bc[S].local + (bc[S].carried ? into_wave[S] + (wave_open[S] ? (uint32_t)s_in[S] : 0u) : 0u);
+            const bool last_of_scan = my_first + 1 == nblocks_chain;
+            edge[S] = band_edge(C, live, any[S], ends_zero[S], last_of_scan, eobs);
+        }
     }
+    // ---- every scan's bits of the lane, their exclusive prefixes in the group, the group's counts
+    const uint32_t own[3] = {dc_len, first_bits, all_bits - first_bits};
+    const uint32_t len[3] = {dc_len, edge[0].pre.len + own[1] + edge[0].post.len, split ? edge[1].pre.len + own[2] + edge[1].post.len : 0u};
+    uint32_t my_bit[3], group_bits[3];
+    uint32_t group_long = 0;
     {
-        const uint32_t len = edge.pre.len + own + edge.post.len;
-        const bool long_block = own > kScratchWords * 32u;
-        const uint32_t incl = wave_inclusive_scan(len);
-        if ((lane & 63) == 63) wave_sum[wave] = incl;
+        // (the DC scan's lengths — at most 27 bits a lane — ride in the top twelve bits of the first band's scan)
+        const uint32_t incl01 = wave_inclusive_scan((len[0] << 20) | len[1]);
+        const uint32_t incl2 = split ? wave_inclusive_scan(len[2]) : 0u; // (uniform)
+        if ((lane & 63) == 63) { wave_sum[0][wave] = incl01 >> 20; wave_sum[1][wave] = incl01 & 0xFFFFFu; wave_sum[2][wave] = incl2; }
         const bool any_long = PIXO_ANY64(long_block);
         if ((lane & 63) == 0) wave_long[wave] = any_long ? 1u : 0u;
         __syncthreads();
-        uint32_t wave_base = 0, group_bits = 0, group_long = 0;
+        const uint32_t incl[3] = {incl01 >> 20, incl01 & 0xFFFFFu, incl2};
 #pragma unroll
-        for (int i = 0; i < kGroupWaves; i++) {
-            if (i < wave) wave_base += wave_sum[i];
-            group_bits += wave_sum[i];
-            group_long |= wave_long[i];
+        for (int S = 0; S < 3; S++) {
+            uint32_t wave_base = 0;
+            group_bits[S] = 0;
+#pragma unroll
+            for (int i = 0; i < kGroupWaves; i++) {
+                if (i < wave) wave_base += wave_sum[S][i];
+                group_bits[S] += wave_sum[S][i];
+            }
+            my_bit[S] = wave_base + (incl[S] - len[S]);
         }
-        if (lane == 0) publish_aggregate(desc, g, floor_g, group_bits);
-        const bool last_group = first_in_chain + group_blocks >= nblocks_chain;
+#pragma unroll
+        for (int i = 0; i < kGroupWaves; i++) group_long |= wave_long[i];
+    }
+    // ---- where each scan's bits of this group begin: the aggregate out, the look-back — scan S on wavefront S, side by side
+#pragma unroll
+    for (int S = 0; S < 3; S++) {
+        if (wave != S || (uint32_t)S >= nseg) continue; // (uniform per wavefront)
+        const uint32_t k = scan_k(S);
+        const uint64_t floor_g = a.first_group[k], g = floor_g + local;
+        if ((lane & 63) == 0) publish_aggregate(desc, g, floor_g, group_bits[S]);
+        const uint64_t sum = look_back_blocks(desc, sup_all + (floor_g >> 6) + k, g, floor_g, group_bits[S], state, host_abort, spin_budget);
+        if ((lane & 63) == 0) {
+            if (sum == kLookBackFailed) s_abort = 1;
+            s_before[S] = sum;
+            if (last_group && sum != kLookBackFailed) seg.bits[k] = sum + group_bits[S];
+        }
+    }
+    __syncthreads();
+    if (s_abort) return;
+    // ---- place and write out, scan after scan through the same window.  What is left for the end: the word a scan's group
+    // shares with the bits before it (s_head[S], s_first_word[S]; s_share[S]: 0 none, 1 hand the bits on, 2 complete the word)
+    auto place = [&](auto tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(tag)::value;
+        const uint32_t k = scan_k(S);
+        const uint64_t floor_g = a.first_group[k], g = floor_g + local;
+        uint32_t *const stream = stream0 + seg.var_word[k];
+        const uint32_t gbits = group_bits[S];
         // The stream word two groups share travels as the earlier group's `tail`.  A group WITHOUT bits (192 empty blocks) is
         // transparent for it: it says so at once, and the group that needs the word finds the last group with bits by a
         // look-back over the tails (64 per round, kLookBatch = 1) — passing the word on from group to group made one chain of waits out
         // of every run of empty groups (a smooth 4096x4096 image: 1,366 groups in a row, 276 us for the launch).
-        const bool transparent = group_bits == 0 && !last_group;
-        if (transparent) { // nothing to place: its B descriptor stays an aggregate of zero bits, which later groups walk past
+        if (gbits == 0 && !last_group) { // nothing to place: its B descriptor stays an aggregate of zero bits, which later groups walk past
             if (lane == 0) store_relaxed(&tails[g], kFlagAggregate);
             return;
         }
-        const uint32_t my_bit = wave_base + (incl - len);
-        const uint32_t bit_words = (group_bits + 31) >> 5;
-        const uint32_t local_words = bit_words ? bit_words : 1u; // (a group without bits still runs one round: look-back, shared word)
-        uint64_t first_word = 0;
-        uint32_t sh = 0, out_words = 0, pad_word = ~0u, pad_mask = 0;
-        bool tail_partial = false;
+        const BandBits none{0u, 0u};
+        const BandBits pre = S ? edge[S ? S - 1 : 0].pre : none, post = S ? edge[S ? S - 1 : 0].post : none;
+        const uint32_t from = S == 2 ? first_bits : 0u; // where the scan's own bits begin in the lane's scratch
+        const uint32_t bit_words = (gbits + 31) >> 5;
+        const uint32_t local_words = bit_words ? bit_words : 1u; // (a group without bits still runs one round: shared word)
+        const uint64_t start = s_before[S];
+        uint64_t end = start + gbits;
+        uint32_t pad_word = ~0u, pad_mask = 0;
+        if (last_group) { // every scan ends on a byte boundary, padded with 1-bits (BitWriterMsb::finish)
+            const uint32_t n = (uint32_t)((8 - (end & 7)) & 7);
+            if (n) {
+                pad_word = (uint32_t)((end >> 5) - (start >> 5));
+                pad_mask = ((1u << n) - 1u) << (32 - (uint32_t)(end & 31) - n);
+            }
+            end += n;
+        }
+        const uint64_t first_word = start >> 5;
+        const uint32_t sh = (uint32_t)(start & 31);
+        const uint32_t out_words = (uint32_t)((end - (first_word << 5) + 31) >> 5);
+        const bool tail_partial = (end & 31) != 0 && !last_group;
+        // (every group leaves SOMETHING in its tail slot — the look-back over the tails waits for all the slots it reads:
+        // a group whose bits end on a word boundary hands nothing on)
+        if (!tail_partial && lane == 0) store_relaxed(&tails[g], kFlagPrefix);
+        if (lane == 0) s_carry = 0;
         uint32_t head_word = 0;
         for (uint32_t wbase = 0; wbase < local_words; wbase += kWindowWords) {
             const uint32_t wn = local_words - wbase < kWindowWords ? local_words - wbase : kWindowWords;
@@ -484,67 +553,46 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                 (void)__hip_atomic_fetch_or(&buf[(n && d + 1 < wn) ? d + 1 : dummy], bsh ? left << (32 - bsh) : 0u, __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_WORKGROUP);
             };
-            const int64_t rel = (int64_t)my_bit - (int64_t)wbase * 32;  // the lane's first bit
-            const int64_t rel_own = rel + (int64_t)edge.pre.len;          // its own symbols' first bit
-            or_bits(edge.pre.left, edge.pre.len, rel);
-            or_bits(edge.post.left, edge.post.len, rel_own + (int64_t)own);
-            if (!group_long) {
-                const uint32_t nw = (own + 31) >> 5, bsh = (uint32_t)(rel_own & 31);
-                const uint32_t d0 = (uint32_t)(rel_own >> 5);
-#pragma unroll
-                for (uint32_t j = 0; j < kScratchWords; j++) {
-                    if (!PIXO_ANY64(j < nw)) break; // (wave-uniform)
-                    const uint32_t v = j < nw ? scratch[lane * kScratchPitch + j] : 0u;
-                    const uint32_t d = d0 + j;
-                    (void)__hip_atomic_fetch_or(&buf[d < wn ? d : dummy], v >> bsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    (void)__hip_atomic_fetch_or(&buf[d + 1 < wn ? d + 1 : dummy], bsh ? v << (32 - bsh) : 0u, __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 32; i++) asm volatile("" : "+v"(w[i]));
-            if (group_long && PIXO_ANY64(live && rel_own < (int64_t)wn * 32 && rel_own + (int64_t)own > 0)) { // (only AC scans have long blocks)
-                FlatPack<LdsSink> p;
-                p.sink = LdsSink{buf, live ? wn : 0u, dummy};
-                p.acc = 0;
-                p.pending = (uint32_t)(rel_own & 31);
-                p.word = (uint32_t)(rel_own >> 5);
-                bool z2, t2;
-                band_pack_flat(w, ss, se, tab + cls * kWalkClassWords, p, &z2, &t2);
-                p.finish();
-            }
-            if (wbase == 0) {
-                if (wave == 0) {
-                    const uint64_t sum = look_back(desc, g, floor_g, group_bits, state, host_abort, spin_budget);
-                    if (lane == 0) {
-                        if (sum == kLookBackFailed) s_abort = 1;
-                        s_before = sum;
-                        if (g != floor_g) store_relaxed(&desc[g], kFlagPrefix | (sum + group_bits));
-                        if (last_group) seg.bits[k] = sum + group_bits;
-                    }
-                }
-                __syncthreads();
-                if (s_abort) return;
-                const uint64_t start = s_before;
-                uint64_t end = start + group_bits;
-                if (last_group) { // every scan ends on a byte boundary, padded with 1-bits (BitWriterMsb::finish)
-                    const uint32_t n = (uint32_t)((8 - (end & 7)) & 7);
-                    if (n) {
-                        pad_word = (uint32_t)((end >> 5) - (start >> 5));
-                        pad_mask = ((1u << n) - 1u) << (32 - (uint32_t)(end & 31) - n);
-                    }
-                    end += n;
-                }
-                first_word = start >> 5;
-                sh = (uint32_t)(start & 31);
-                out_words = (uint32_t)((end - (first_word << 5) + 31) >> 5);
-                tail_partial = (end & 31) != 0 && !last_group;
-                // (every group leaves SOMETHING in its tail slot — the look-back over the tails waits for all the slots it reads:
-                // a group whose bits end on a word boundary hands nothing on)
-                if (!tail_partial && lane == 0) store_relaxed(&tails[g], kFlagPrefix);
+            const int64_t rel = (int64_t)my_bit[S] - (int64_t)wbase * 32; // the lane's first bit
+            const int64_t rel_own = rel + (int64_t)pre.len;                // its own symbols' first bit
+            if (S == 0) {
+                or_bits(dc_left, dc_len, rel);
             } else {
-                __syncthreads();
+                or_bits(pre.left, pre.len, rel);
+                or_bits(post.left, post.len, rel_own + (int64_t)own[S]);
+                if (!group_long) { // the scan's part of the lane's scratch, word by word (two LDS ORs each)
+                    const uint32_t nw = (own[S] + 31) >> 5, bsh = (uint32_t)(rel_own & 31);
+                    const uint32_t d0 = (uint32_t)(rel_own >> 5);
+#pragma unroll
+                    for (uint32_t j = 0; j < kScratchWords; j++) {
+                        if (!PIXO_ANY64(j < nw)) break; // (wave-uniform)
+                        const uint32_t v = scratch_bits_word(scratch + lane * kScratchPitch, kScratchWords, from, own[S], j);
+                        const uint32_t d = d0 + j;
+                        (void)__hip_atomic_fetch_or(&buf[d < wn ? d : dummy], v >> bsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        (void)__hip_atomic_fetch_or(&buf[d + 1 < wn ? d + 1 : dummy], bsh ? v << (32 - bsh) : 0u, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                } else if (PIXO_ANY64(live && rel_own < (int64_t)wn * 32 && rel_own + (int64_t)own[S] > 0)) {
+                    // a group with a block too long for the scratch (rare: noise at q >= 90): its scans' bits come from a second
+                    // walk of the band straight into the window — the block is read again (L2)
+                    uint32_t w[32];
+                    const v4u *p4 = reinterpret_cast<const v4u *>(my_block);
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        const v4u q = p4[r];
+                        w[4 * r] = q.x; w[4 * r + 1] = q.y; w[4 * r + 2] = q.z; w[4 * r + 3] = q.w;
+                    }
+                    FlatPack<LdsSink> p;
+                    p.sink = LdsSink{buf, live ? wn : 0u, dummy};
+                    p.acc = 0;
+                    p.pending = (uint32_t)(rel_own & 31);
+                    p.word = (uint32_t)(rel_own >> 5);
+                    bool z2, t2;
+                    band_pack_flat(w, S == 2 ? 11 : 1, (S == 1 && split) ? 10 : 63, tab, p, &z2, &t2);
+                    p.finish();
+                }
             }
+            __syncthreads();
             const uint32_t carry = s_carry;
             const bool last_round = wbase + wn == local_words;
             const uint32_t upto = last_round ? out_words - wbase : wn;
@@ -571,14 +619,30 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         // different bits, so the look-back's sum over such slots is their OR — and the group that completes the word finds
         // them, and the tail of the last group that left a word unfinished (a PREFIX), in one look-back: no group waits for
         // another group's look-back (handing the word on from group to group chained every run of small groups).
-        if (sh != 0) {
-            if (tail_partial && out_words == 1) {
-                if (lane == 0) store_relaxed(&tails[g], kFlagAggregate | head_word);
-            } else if (wave == 0) {
-                const uint64_t inherited = look_back(tails, g, floor_g, 0, state, host_abort, spin_budget);
-                if (inherited == kLookBackFailed) return;
-                if (lane == 0) __builtin_nontemporal_store((uint32_t)inherited | head_word, &stream[first_word]);
-            }
+        if (sh != 0 && lane == 0) { // (lane 0 holds word 0 of the first round)
+            s_head[S] = head_word;
+            s_first_word[S] = first_word;
+            s_share[S] = (tail_partial && out_words == 1) ? 1u : 2u;
+        }
+    };
+    place(std::integral_constant<int, 0>{});
+    place(std::integral_constant<int, 1>{});
+    if (split) place(std::integral_constant<int, 2>{});
+    // ---- the shared words: scan S on wavefront S, side by side
+    __syncthreads();
+#pragma unroll
+    for (int S = 0; S < 3; S++) {
+        if (wave != S || (uint32_t)S >= nseg) continue;
+        const uint32_t k = scan_k(S);
+        const uint64_t floor_g = a.first_group[k], g = floor_g + local;
+        const uint32_t hw = s_head[S];
+        const uint32_t how = s_share[S];
+        if (how == 1u) {
+            if ((lane & 63) == 0) store_relaxed(&tails[g], kFlagAggregate | hw);
+        } else if (how == 2u) {
+            const uint64_t inherited = look_back(tails, g, floor_g, 0, state, host_abort, spin_budget);
+            if (inherited != kLookBackFailed && (lane & 63) == 0)
+                __builtin_nontemporal_store((uint32_t)inherited | hw, &(stream0 + seg.var_word[k])[s_first_word[S]]);
         }
     }
 }
@@ -933,29 +997,43 @@ hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool
     return hipGetLastError();
 }
 
-size_t prog_code_state_words(uint64_t groups) { return 2 + 3 * (size_t)groups; }
-uint64_t prog_groups(uint32_t scan_id, uint64_t blocks)
-{
-    const uint64_t per = scan_id < 3 ? (uint64_t)kGroup * kDcPerLane : kGroup;
-    return (blocks + per - 1) / per;
-}
+size_t prog_code_state_words(uint64_t groups) { return 2 + 3 * (size_t)groups + (size_t)(groups >> 6) + 8; } // (+ the B chains' block sums: one word per 64 groups and one per scan)
+uint64_t prog_groups(uint32_t, uint64_t blocks) { return (blocks + kGroup - 1) / kGroup; }
 size_t prog_stream_bytes(uint32_t scan_id, uint64_t blocks)
 { // per block: a DC symbol of at most 16 + 11 bits; a band of n coefficients: n symbols of at most 16 + 10 bits (ZRL codes
   // only where coefficients are missing) + run symbols of at most 30 bits in front and behind; + 64 bytes the kernels read into
     const uint64_t bits = scan_id < 3 ? 27 : ((scan_id == 3 ? 10 : (scan_id == 4 ? 53 : 63)) * 26 + 60);
     return (size_t)((blocks * bits + 7) / 8 + 64 + 15) / 16 * 16;
 }
+void prog_code_plan(ProgCode &a)
+{
+    for (int c = 0; c < 3; c++) { a.comp_blocks[c] = 0; a.comp_npass[c] = 0; }
+    for (uint32_t k = 0; k < a.nscans; k++) {
+        const int sc = (int)a.scan_id[k], c = sc < 3 ? sc : (sc <= 4 ? 0 : sc - 4); // (prog_comp)
+        a.comp_blocks[c] = a.size[k];
+        a.comp_pass[c][a.comp_npass[c]++] = k;
+    }
+    // the workgroups' order: the chrominance components first — their groups serve two scans where a luminance group serves
+    // three, so they leave their slots early (luminance first measured the same within 1 %: profiles/r05_prog_code.txt)
+    const uint32_t order[3] = {1, 2, 0};
+    a.comp_first[0] = 0;
+    for (int i = 0; i < 3; i++) {
+        const uint32_t c = order[i];
+        a.comp_order[i] = c;
+        a.comp_first[i + 1] = a.comp_first[i] + (a.comp_npass[c] ? prog_groups(0, a.comp_blocks[c]) : 0);
+    }
+}
 hipError_t launch_prog_code(const ProgCode &a, const SegArgs &seg, unsigned long long *d_state, bool state_is_zero, uint32_t *d_stream,
                             unsigned long long *d_clear, size_t clear_words, unsigned long long *host_totals, hipStream_t s, uint32_t spin_budget)
 {
-    const uint64_t groups = a.first_group[a.nscans];
+    const uint64_t groups = a.first_group[a.nscans], grid = a.comp_first[3];
     if (host_totals) host_totals[3] = 0;
-    if (groups == 0 || groups > 0x7FFFFFFFull || clear_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (groups == 0 || grid == 0 || grid > 0x7FFFFFFFull || clear_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (!state_is_zero) {
         hipError_t e = hipMemsetAsync(d_state, 0, prog_code_state_words(groups) * 8, s);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(prog_code_kernel, dim3((unsigned)groups), dim3(kGroup), 0, s, a, seg, d_state, d_stream, d_clear,
+    hipLaunchKernelGGL(prog_code_kernel, dim3((unsigned)grid), dim3(kGroup), 0, s, a, seg, d_state, d_stream, d_clear,
                        d_clear ? (uint32_t)clear_words : 0u, host_totals, spin_budget);
     return hipGetLastError();
 }

@@ -158,6 +158,7 @@ static int device_progressive_scans_fused(const int16_t *dy, const int16_t *dcb,
         blocks_all += size[i];
     }
     const uint64_t groups = a.first_group[a.nscans];
+    pd::prog_code_plan(a);
     sg.nsegs = a.nscans;
     sg.var = 1;
     sg.marker_bytes = 10; // room for the next scan's SOS header

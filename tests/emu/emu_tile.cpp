@@ -615,6 +615,117 @@ extern "C" long emu_progressive_flat(const int16_t *y, const int16_t *cb, const 
     return o;
 }
 
+// Round 5's form of the same kernel: a group holds 192 blocks of ONE component and walks each block ONCE — the DC symbol, and
+// all AC bands of the component in one walk into one scratch (bands_pack_flat: luminance 1..10 and 11..63 back to back,
+// chrominance 1..63); every scan's bits are then gathered from its part of the scratch (scratch_bits_word) between what the
+// scan's own run counter adds.  Same output format as emu_progressive.
+extern "C" long emu_progressive_one_walk(const int16_t *y, const int16_t *cb, const int16_t *cr, uint64_t yb, uint64_t cbn,
+                                         const uint32_t *tables, uint8_t *out, long cap, long *seg_len)
+{
+    using namespace pixo_scan;
+    uint32_t wtab[kWalkWords];
+    for (int i = 0; i < kWalkWords; i++) wtab[i] = walk_table_word(tables, i);
+    const int kLanes = 192, kScratch = 64;
+    struct Stream {
+        std::vector<uint32_t> words{0};
+        uint64_t bits = 0;
+        void put(uint32_t left, uint32_t len)
+        {
+            for (uint32_t i = 0; i < len; i++) {
+                if ((bits >> 5) >= words.size()) words.push_back(0);
+                if ((left >> (31 - i)) & 1u) words[bits >> 5] |= 1u << (31 - (bits & 31));
+                bits++;
+            }
+        }
+    } streams[7];
+    for (int comp = 0; comp < 3; comp++) {
+        const int cls = comp ? 1 : 0;
+        const int16_t *base = comp == 0 ? y : (comp == 1 ? cb : cr);
+        const uint64_t nblocks = comp == 0 ? yb : cbn;
+        const bool split = comp == 0;
+        const int dc_scan = comp, band_scan[2] = {comp == 0 ? 3 : 4 + comp, comp == 0 ? 4 : -1};
+        uint32_t eob_syms[15];
+        for (int n = 0; n < 15; n++) eob_syms[n] = tables[cls * kClassSyms + kDcSyms + (n << 4)];
+        uint64_t carry_group[2] = {0, 0};
+        for (uint64_t g0 = 0; g0 < nblocks; g0 += kLanes) {
+            uint32_t scratch[kLanes][kScratch + 1], dcw[kLanes][2];
+            uint32_t dclen[kLanes], first[kLanes], total[kLanes];
+            bool z[2][kLanes], t[2][kLanes], live[kLanes];
+            for (int l = 0; l < kLanes; l++) {
+                const uint64_t b = g0 + l;
+                live[l] = b < nblocks;
+                z[0][l] = z[1][l] = t[0][l] = t[1][l] = false; dclen[l] = first[l] = total[l] = 0;
+                if (!live[l]) continue;
+                uint32_t wds[32];
+                memcpy(wds, base + b * 64, 128);
+                {
+                    FlatPack<EmuLaneSink> p;
+                    p.sink = EmuLaneSink{dcw[l], 1u};
+                    p.acc = 0; p.pending = 0; p.word = 0;
+                    dc_pack_flat(wds, b ? base[(b - 1) * 64] : 0, wtab + cls * kWalkClassWords, p);
+                    dclen[l] = p.word * 32u + p.pending;
+                    p.finish();
+                }
+                FlatPack<EmuLaneSink> p;
+                p.sink = EmuLaneSink{scratch[l], (uint32_t)kScratch};
+                p.acc = 0; p.pending = 0; p.word = 0;
+                bool any[2], ez[2];
+                bands_pack_flat(wds, split, wtab + cls * kWalkClassWords, p, &first[l], any, ez);
+                total[l] = p.word * 32u + p.pending;
+                p.finish();
+                for (int s = 0; s < 2; s++) { z[s][l] = any[s]; t[s][l] = ez[s]; }
+            }
+            for (int l = 0; l < kLanes; l++)
+                if (live[l]) streams[dc_scan].put(dcw[l][0], dclen[l]);
+            for (int s = 0; s < 2; s++) {
+                if (band_scan[s] < 0) continue;
+                Stream &st = streams[band_scan[s]];
+                uint64_t wave_in = carry_group[s];
+                for (int wv = 0; wv < kLanes / 64; wv++) {
+                    uint64_t zmask = 0, tmask = 0;
+                    for (int l = 0; l < 64; l++) {
+                        if (z[s][wv * 64 + l]) zmask |= 1ull << l;
+                        if (t[s][wv * 64 + l] && live[wv * 64 + l]) tmask |= 1ull << l;
+                    }
+                    for (int l = 0; l < 64; l++) {
+                        const int L = wv * 64 + l;
+                        if (!live[L]) continue;
+                        const BandCount c = band_count_in_wave(zmask, tmask, l);
+                        const BandEdge e = band_edge((uint32_t)(c.local + (c.carried ? wave_in : 0)), true, z[s][L], t[s][L], g0 + L + 1 == nblocks, eob_syms);
+                        st.put(e.pre.left, e.pre.len);
+                        const uint32_t from = s ? first[L] : 0u, n = s ? total[L] - first[L] : first[L];
+                        for (uint32_t j = 0; 32u * j < n; j++) st.put(scratch_bits_word(scratch[L], (uint32_t)kScratch, from, n, j), std::min(32u, n - 32u * j));
+                        st.put(e.post.left, e.post.len);
+                    }
+                    bool any; uint32_t tail;
+                    band_wave_summary(zmask, tmask, &any, &tail);
+                    wave_in = any ? tail : wave_in + tail;
+                }
+                carry_group[s] = wave_in;
+            }
+        }
+    }
+    long o = 0;
+    for (int scan = 0; scan < 7; scan++) {
+        Stream &st = streams[scan];
+        const uint64_t blocks = prog_comp(scan) == 0 ? yb : cbn;
+        const long start = o;
+        if (blocks) {
+            const int n = (int)((8 - (st.bits & 7)) & 7);
+            st.put(0xFFFFFFFFu, (uint32_t)n);
+            const uint64_t nbytes = st.bits / 8;
+            for (uint64_t b = 0; b < nbytes; b++) {
+                const uint8_t byte = (uint8_t)(st.words[b >> 2] >> (24 - 8 * (b & 3)));
+                if (o + 2 > cap) return -1;
+                out[o++] = byte;
+                if (byte == 0xFF) out[o++] = 0x00;
+            }
+        }
+        seg_len[scan] = o - start;
+    }
+    return o;
+}
+
 // tables for the progressive coder: like pack_scan_tables, absent symbols = the (0, 4 bits) fallback
 extern "C" void emu_progressive_tables(uint32_t *out /* 536 words */)
 {

@@ -59,6 +59,7 @@ def _check(px, w, h, ct, ss, q):
     assert len(want) == 7
     assert _emu(y, cb, cr) == want
     assert _emu(y, cb, cr, "emu_progressive_flat") == want  # the single-pass form (round 4)
+    assert _emu(y, cb, cr, "emu_progressive_one_walk") == want  # one walk per block for all scans of its component (round 5)
 
 
 @pytest.mark.parametrize("mode", [(2, 1), (2, 0), (0, 0)])
@@ -93,4 +94,5 @@ def test_synthetic_tuples_run_counter_at_every_alignment_of_groups_wavefronts_an
         y, w, h = band_cases.tuple_of(nblocks, where)
         want = _segments(O.encode_from_coeffs(y, empty, empty, O.make_options(w, h, 0, 50, 0, progressive=True)))
         assert _emu(y, empty, empty, "emu_progressive_flat") == want, (nblocks, where[:6])
+        assert _emu(y, empty, empty, "emu_progressive_one_walk") == want, (nblocks, where[:6])
         assert _emu(y, empty, empty) == want, (nblocks, where[:6])

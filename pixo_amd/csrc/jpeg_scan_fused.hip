@@ -349,6 +349,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     const int lane = threadIdx.x, wave = lane >> 6;
     if (lane == 0) s_abort = 0;
     if (lane < 3) s_share[lane] = 0;
+    PIXO_STAMP(0);
     uint32_t slot = 0; // which run of workgroups this one belongs to: comp_first[slot] <= id < comp_first[slot + 1]
 #pragma unroll
     for (uint32_t i = 1; i < 3; i++) slot += blockIdx.x >= a.comp_first[i] ? 1u : 0u;
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const int dc = coef_of(w, 0);
         s_dc[lane] = (int16_t)dc;
         __syncthreads();
+        PIXO_STAMP(1);
         // ---- the walks: the DC symbol (encode_dc_first, progressive.rs:112-133, al = 0) as bits of a word; the AC bands
         // (progressive.rs:141-210) into the lane's scratch from bit 0
         const DcBits db = dc_symbol_bits(dc, lane ? (int)s_dc[lane - 1] : (int)s_ext_dc, tab);
@@ -396,6 +398,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         all_bits = p.word * 32u + p.pending;
         p.finish();
     }
+    PIXO_STAMP(2);
     if (!live) { dc_len = 0; first_bits = all_bits = 0; any[0] = any[1] = ends_zero[0] = ends_zero[1] = false; }
     const bool long_block = all_bits > kScratchWords * 32u;
     // what scan S of the component (0: DC, 1: the first AC band, 2: the second) is in the launch
@@ -446,6 +449,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             }
         }
         __syncthreads();
+        PIXO_STAMP(3);
         if (s_abort) return;
 #pragma unroll
         for (int S = 0; S < 2; S++) {
@@ -498,6 +502,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         }
     }
     __syncthreads();
+    PIXO_STAMP(4);
     if (s_abort) return;
     // ---- place and write out, scan after scan through the same window.  What is left for the end: the word a scan's group
     // shares with the bits before it (s_head[S], s_first_word[S]; s_share[S]: 0 none, 1 hand the bits on, 2 complete the word)
@@ -626,7 +631,9 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         }
     };
     place(std::integral_constant<int, 0>{});
+    PIXO_STAMP(5);
     place(std::integral_constant<int, 1>{});
+    PIXO_STAMP(6);
     if (split) place(std::integral_constant<int, 2>{});
     // ---- the shared words: scan S on wavefront S, side by side
     __syncthreads();
@@ -645,6 +652,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                 __builtin_nontemporal_store((uint32_t)inherited | hw, &(stream0 + seg.var_word[k])[s_first_word[S]]);
         }
     }
+    PIXO_STAMP(7);
 }
 
 // ---- count: symbol statistics for optimised tables (count_block, jpeg/mod.rs:826-860) with the flat walk ---------------

@@ -13,7 +13,9 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "noise"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 px = synth.noise(n, n, 42) if kind == "noise" else (synth.gradient_rgb(n, n) if kind == "gradient" else synth.constant(n, n, 77))
 d = torch.from_numpy(px).to("cuda:0"); torch.cuda.synchronize()
-o = jpeg.JpegOptions.builder(n, n).quality(80).subsampling(jpeg.Subsampling(1)).build()
+prog = len(sys.argv) > 3 and sys.argv[3] == "prog"  # the progressive coder's launch (prog_code_kernel: a group per 192 blocks of a component)
+b = jpeg.JpegOptions.builder(n, n).quality(80).subsampling(jpeg.Subsampling(1))
+o = b.progressive(True).build() if prog else b.build()
 L = ctypes.CDLL(os.environ["PIXO_HIP_LIB"])
 groups = (n // 8) * (n // 8) * 3 // 2 // 192
 for rep in range(6):
@@ -21,6 +23,20 @@ for rep in range(6):
     t = np.zeros(8192 * 8, np.uint64)
     assert L.pixo_hip_debug_scan_timeline(ctypes.c_void_p(t.ctypes.data), ctypes.c_size_t(t.nbytes)) == 0
     if rep < 3: continue
+    if prog:
+        t = t.reshape(8192, 8)[:groups].astype(np.int64)
+        t0 = t[:, 0].min()
+        names = ["entry", "block in", "walks done", "run counters in", "bit counts in", "DC placed", "band 1 placed", "end"]
+        print("progressive %s %dx%d, %d groups, rep %d: kernel span by stamps %.2f us" % (kind, n, n, groups, rep, (t.max() - t0) / 100.0))
+        for part, sel in (("chrominance groups (two scans)", slice(0, groups // 3)), ("luminance groups (three scans)", slice(groups // 3, groups))):
+            tt = t[sel]
+            print("  ", part)
+            for k in range(8):
+                v = (tt[:, k] - t0) / 100.0
+                print("   %-16s min %6.2f  median %6.2f  p90 %6.2f  max %6.2f us" % (names[k], v.min(), np.median(v), np.percentile(v, 90), v.max()))
+            dur = (tt[:, 1:] - tt[:, :-1]) / 100.0
+            print("   phase medians (us):", " ".join("%s %.2f" % (names[k + 1], np.median(dur[:, k])) for k in range(7)), "| whole group %.2f" % np.median((tt[:, 7] - tt[:, 0]) / 100.0))
+        continue
     t = t.reshape(8192, 8)[:groups, :7].astype(np.int64)
     t0 = t[:, 0].min()
     print("%s %dx%d, %d groups, rep %d: kernel span by stamps %.2f us" % (kind, n, n, groups, rep, (t.max() - t0) / 100.0))

@@ -346,9 +346,8 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     __shared__ unsigned long long s_before[3], s_in[2];
     __shared__ uint32_t s_carry, s_abort, s_head[3], s_share[3];
     __shared__ unsigned long long s_first_word[3];
-    const int lane = threadIdx.x, wave = lane >> 6;
-    if (lane == 0) s_abort = 0;
-    if (lane < 3) s_share[lane] = 0;
+    if (threadIdx.x == 0) s_abort = 0;
+    if (threadIdx.x < 3) s_share[threadIdx.x] = 0;
     PIXO_STAMP(0);
     uint32_t slot = 0; // which run of workgroups this one belongs to: comp_first[slot] <= id < comp_first[slot + 1]
 #pragma unroll
@@ -363,15 +362,18 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     unsigned long long *const desc_a = state + 2, *const desc = state + 2 + ngroups_total, *const tails = state + 2 + 2 * ngroups_total;
     unsigned long long *const sup_all = state + 2 + 3 * ngroups_total;
     unsigned long long *const host_abort = host_totals ? host_totals + 3 : nullptr;
-    const uint64_t my_first = local * kGroup + (uint64_t)lane;
-    const bool live = my_first < nblocks_chain;
     const bool last_group = (local + 1) * kGroup >= nblocks_chain;
-    const int16_t *const my_block = (comp == 0 ? a.y : (comp == 1 ? a.cb : a.cr)) + (live ? my_first : 0) * 64;
-    // ---- the block, the tables, the DC predictors (jpeg/mod.rs:1268-1300: the first coefficient of the block before)
-    uint32_t dc_len, first_bits, all_bits;
-    uint32_t dc_left;
+    const int16_t *const comp_base = comp == 0 ? a.y : (comp == 1 ? a.cb : a.cr);
+    // ---- the block, the tables, the DC predictors (jpeg/mod.rs:1268-1300: the first coefficient of the block before); the walk
+    // of the AC bands (progressive.rs:141-210) into the lane's scratch from bit 0.  What the lane knows about itself (its index, its
+    // block's address, whether it has one) is derived HERE for the walk and AGAIN behind it: the walk runs at the kernel's limit of
+    // 80 vector registers, and every value alive across it was spilled to scratch memory (eight dwords a lane: 19 MB of writes a launch).
+    uint32_t first_bits, all_bits;
     bool any[2], ends_zero[2];
     {
+        const int lane = threadIdx.x;
+        const uint64_t my_first = local * kGroup + (uint64_t)lane;
+        const int16_t *const my_block = comp_base + (my_first < nblocks_chain ? my_first : 0) * 64;
         uint32_t w[32];
         const v4u *p4 = reinterpret_cast<const v4u *>(my_block);
 #pragma unroll
@@ -383,14 +385,9 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         for (int i = lane; i < kWalkClassWords; i += kGroup) tab[i] = a.tables[kTableWords + cls * kWalkClassWords + i];
         if (lane < 15) eobs[lane] = a.tables[cls * kClassSyms + kDcSyms + (lane << 4)];
         for (uint64_t i = (uint64_t)blockIdx.x * kGroup + lane; i < clear_words; i += (uint64_t)gridDim.x * kGroup) clear[i] = 0;
-        const int dc = coef_of(w, 0);
-        s_dc[lane] = (int16_t)dc;
+        s_dc[lane] = (int16_t)coef_of(w, 0);
         __syncthreads();
         PIXO_STAMP(1);
-        // ---- the walks: the DC symbol (encode_dc_first, progressive.rs:112-133, al = 0) as bits of a word; the AC bands
-        // (progressive.rs:141-210) into the lane's scratch from bit 0
-        const DcBits db = dc_symbol_bits(dc, lane ? (int)s_dc[lane - 1] : (int)s_ext_dc, tab);
-        dc_left = db.left; dc_len = db.len;
         FlatPack<LaneSink> p;
         p.sink = LaneSink{scratch + lane * kScratchPitch};
         p.acc = 0; p.pending = 0; p.word = 0;
@@ -399,6 +396,18 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         p.finish();
     }
     PIXO_STAMP(2);
+    int lane_behind = threadIdx.x;
+    asm volatile("" : "+v"(lane_behind));
+    const int lane = lane_behind, wave = lane >> 6;
+    const uint64_t my_first = local * kGroup + (uint64_t)lane;
+    const bool live = my_first < nblocks_chain;
+    const int16_t *const my_block = comp_base + (live ? my_first : 0) * 64;
+    // the DC symbol (encode_dc_first, progressive.rs:112-133, al = 0) as bits of a word
+    uint32_t dc_left, dc_len;
+    {
+        const DcBits db = dc_symbol_bits((int)s_dc[lane], lane ? (int)s_dc[lane - 1] : (int)s_ext_dc, tab);
+        dc_left = db.left; dc_len = db.len;
+    }
     if (!live) { dc_len = 0; first_bits = all_bits = 0; any[0] = any[1] = ends_zero[0] = ends_zero[1] = false; }
     const bool long_block = all_bits > kScratchWords * 32u;
     // what scan S of the component (0: DC, 1: the first AC band, 2: the second) is in the launch
@@ -566,12 +575,16 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                 or_bits(pre.left, pre.len, rel);
                 or_bits(post.left, post.len, rel_own + (int64_t)own[S]);
                 if (!group_long) { // the scan's part of the lane's scratch, word by word (two LDS ORs each)
-                    const uint32_t nw = (own[S] + 31) >> 5, bsh = (uint32_t)(rel_own & 31);
+                    // (the length as a value of this round: the twelve words' masks are not computed in front of the rounds' loop and
+                    // kept — eight of them in scratch memory — but where they are used)
+                    uint32_t n_own = own[S];
+                    asm volatile("" : "+v"(n_own));
+                    const uint32_t nw = (n_own + 31) >> 5, bsh = (uint32_t)(rel_own & 31);
                     const uint32_t d0 = (uint32_t)(rel_own >> 5);
 #pragma unroll
                     for (uint32_t j = 0; j < kScratchWords; j++) {
                         if (!PIXO_ANY64(j < nw)) break; // (wave-uniform)
-                        const uint32_t v = scratch_bits_word(scratch + lane * kScratchPitch, kScratchWords, from, own[S], j);
+                        const uint32_t v = scratch_bits_word(scratch + lane * kScratchPitch, kScratchWords, from, n_own, j);
                         const uint32_t d = d0 + j;
                         (void)__hip_atomic_fetch_or(&buf[d < wn ? d : dummy], v >> bsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         (void)__hip_atomic_fetch_or(&buf[d + 1 < wn ? d + 1 : dummy], bsh ? v << (32 - bsh) : 0u, __ATOMIC_RELAXED,

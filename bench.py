@@ -413,6 +413,11 @@ class CoeffWorkload:
             r["copy_frac_of_peak_same_run"] = round(alg / (copy_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
             r["kernel_over_copy_same_run"] = round(kernel_ms / copy_ms, 4)
             r["frac_of_copy_same_run"] = round(copy_ms / kernel_ms, 4)
+            # with the memory system's own ceiling measured in the same run, `bound` compares like with like: the kernel's share of
+            # what a plain copy of its bytes gets against its share of the issue rate (a kernel at 0.99 of the copy and 0.82 of the
+            # issue rate is bound by the memory system, although 0.71 of the 8 TB/s PEAK is the smaller number)
+            r["bound"] = bound_of(copy_ms / kernel_ms, issue)
+            r["bound_rule"] = "larger of frac_of_copy_same_run and frac_issue"
         return r
 
     def copy_step_factory(self):
@@ -697,6 +702,25 @@ def whole_file(job, wl):
                 dev[name] = {"device_us_per_file": round(us, 2), "frac_hbm_pixels_plus_file": round((wl.in_bytes + nb) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                              "kernels": "pixels_code_kernel (one kernel: pixels -> stuffed scan)" if form else "jpeg_coeffs + scan_code + stuff_fused"}
             smooth["device_time"] = dev
+            # the other presets' files: progressive scans (prog_code_kernel: one load and one walk of a block for all
+            # scans of its component) and preset 2 (trellis + progressive + optimised tables), same pixels, same pinned buffer
+            b = lambda: jpeg.JpegOptions.builder(wl.w, wl.h).quality(wl.q).subsampling(jpeg.Subsampling(wl.ss))
+            prog = {}
+            for name, o2, d_img in (("progressive_noise", b().progressive(True).build(), wl.ins[0]),
+                                    ("progressive_photo", b().progressive(True).build(), d_p),
+                                    ("progressive_gradient", b().progressive(True).build(), d_g),
+                                    ("preset2_noise", b().progressive(True).trellis_quant(True).optimize_huffman(True).build(), wl.ins[0]),
+                                    ("preset2_photo", b().progressive(True).trellis_quant(True).optimize_huffman(True).build(), d_p)):
+                for _ in range(3):
+                    nb2 = jpeg.encode_device_into(pinned, d_img, o2)
+                t2 = []
+                for _ in range(11):
+                    t1 = time.perf_counter()
+                    nb2 = jpeg.encode_device_into(pinned, d_img, o2)
+                    t2.append(time.perf_counter() - t1)
+                prog["ms_per_image_" + name] = round(sorted(t2)[5] * 1e3, 3)
+                prog["file_bytes_" + name] = int(nb2)
+            smooth["other_presets"] = prog
             for _ in range(2):
                 jpeg.encode_device_into(pinned, wl.ins[0], opts)
             del d_g, d_p

@@ -65,6 +65,7 @@ int hip_fail(hipError_t e, const char *what); // pixo::Error::CompressionError(S
 struct DebugSwitches {
     bool trace = false, host_entropy = false, multipass_entropy = false, direct_stores = false, one_piece = false;
     bool piece_medium_forced = false, no_bands_upload = false, plain_host = false, no_direct_small = false, two_kernel_scan = false;
+    bool no_side_stats = false; // preset 2 on small images: statistics on the context's stream, in front of the search (round 4's order)
     // host pixels are uploaded in bands from this many MiB of pixels on (bands_upload_min_mb=n), in bands of about
     // bands_upload_mb=n MiB.  A 4096x4096 RGB image (48 MiB) in six bands of 8 MiB: noise 1.18 -> 1.14 ms into caller storage,
     // but a smooth image 0.99 -> 1.10 ms and the malloc'ing entry 1.43 -> 1.55: not below 96 MiB (profiles/r03_host_bands_probe.txt)
@@ -104,6 +105,7 @@ struct Context {
     hipStream_t stream = nullptr;
     hipEvent_t producer_done = nullptr; // orders the context's stream after the caller's (device-pointer entries)
     hipEvent_t stats_done = nullptr;    // preset 2: the symbol counts of the statistics pass have reached the host (progressive.cpp)
+    hipEvent_t side_ready = nullptr;    // preset 2, small images: the second stream may start (the pixels are there)
     void *d_px = nullptr;   size_t px_cap = 0;
     void *d_coef = nullptr; size_t coef_cap = 0;
     void *h_coef = nullptr; size_t hcoef_cap = 0; // pinned
@@ -141,6 +143,7 @@ struct Context {
     size_t code_state_zero_words = 0; // this many words of e_code_state are known to be zero (the stuffing kernel cleans up behind itself)
     Buf p_in, p_out, p_sums, p_scratch; // PNG filter stage
     Buf t_raw, t_trail;                 // progressive + trellis: unquantised DCT blocks (f32), Viterbi back-pointers
+    Buf t_plain;                        // preset 2, small images: the plain quantiser's tuple of the statistics pass on the second stream
     Buf g_flags, g_rank, g_by_rank;     // progressive scans: band flags, rank among non-empty blocks and its inverse
     unsigned long long *h_sums = nullptr; size_t hsums_cap = 0; // pinned
     uint64_t *h_totals = nullptr; // pinned, kTotalsWords words: the kernels' mailbox (4 words per piece of a scan)

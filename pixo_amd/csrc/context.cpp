@@ -67,6 +67,7 @@ DebugSwitches parse_switches(const char *e)
         else if (name == "plain_host") v.plain_host = true;
         else if (name == "no_direct_small") v.no_direct_small = true;
         else if (name == "two_kernel_scan") v.two_kernel_scan = true;
+        else if (name == "no_side_stats") v.no_side_stats = true;
         else if (name == "bands_upload_min_mb" && num > 0) v.bands_upload_min_mb = static_cast<uint32_t>(num);
         else if (name == "bands_upload_mb" && num > 0) v.bands_upload_mb = static_cast<uint32_t>(num);
         else if (name == "piece_groups" && num > 0) v.piece_groups = static_cast<uint64_t>(num);
@@ -176,7 +177,7 @@ template <class F> void each_buf(Context &c, F &&f)
 {
     Context::Buf *bufs[] = {&c.e_tables, &c.e_hist, &c.e_count, &c.e_len, &c.e_off, &c.e_tmp, &c.e_totals, &c.e_stream, &c.e_tile_ff, &c.e_tile_base,
                             &c.e_out, &c.e_seg_bytes, &c.e_seg_off, &c.e_code_state, &c.e_stuff_state, &c.e_pc_state, &c.e_chain, &c.e_segs, &c.e_seams, &c.p_in, &c.p_out,
-                            &c.p_sums, &c.p_scratch, &c.t_raw, &c.t_trail, &c.g_flags, &c.g_rank, &c.g_by_rank};
+                            &c.p_sums, &c.p_scratch, &c.t_raw, &c.t_trail, &c.t_plain, &c.g_flags, &c.g_rank, &c.g_by_rank};
     for (Context::Buf *b : bufs) f(*b);
 }
 } // namespace
@@ -235,7 +236,8 @@ void Context::release()
     if (producer_done) (void)hipEventDestroy(producer_done);
     producer_done = nullptr;
     if (stats_done) (void)hipEventDestroy(stats_done);
-    stats_done = nullptr;
+    if (side_ready) (void)hipEventDestroy(side_ready);
+    stats_done = side_ready = nullptr;
     code_state_zero_words = 0;
     tables_valid = false;
     d_px = d_coef = h_coef = nullptr; px_cap = coef_cap = hcoef_cap = 0;

@@ -320,12 +320,29 @@ int progressive_to_view(const void *d_pixels, const pixo_jpeg_options &o, const 
     const float *qt = qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats;
     pixo_host::HuffSet h;
     const bool need_plain = o.optimize_huffman || !o.trellis_quant;
-    if (need_plain && (rc = coeffs_on_device(c, d_pixels, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
+    const bool late_tables = o.optimize_huffman && o.trellis_quant && !debug().host_entropy;
+    // Round 5, small images (the trellis kernel's wavefronts — 64 blocks each — do not fill the chip's 1,024 SIMDs: up to 1080p):
+    // the statistics run on a SECOND stream beside the raw transform + the search, whose 117 us are the latency of one
+    // wavefront's 63 steps whatever the image's size.  (On large images the search keeps every SIMD issuing and kernels beside
+    // it only take its slots: measured in round 4, not kept.)  The plain tuple then has a buffer of its own — the search
+    // writes the file's tuple while the statistics still read theirs.
+    constexpr size_t kSideStatsBlocks = 65536;
+    const bool side_stats = late_tables && !debug().no_side_stats && g.y_blocks + 2 * g.c_blocks <= kSideStatsBlocks;
+    hipStream_t stats_stream = c.stream;
+    if (side_stats) {
+        if (!c.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+        if (!c.side_ready) HIP_TRY(hipEventCreateWithFlags(&c.side_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c.side_ready, c.stream)); // (the context's stream is ordered behind the pixels' producer)
+        HIP_TRY(hipStreamWaitEvent(c.copy_stream, c.side_ready, 0));
+        stats_stream = c.copy_stream;
+        HIP_TRY(c.t_plain.reserve((g.y_blocks + 2 * g.c_blocks) * 128));
+        dy = c.t_plain.as<int16_t>(); dcb = dy + g.y_blocks * 64; dcr = dcb + g.c_blocks * 64;
+        if ((rc = coeffs_rows(c, d_pixels, o, g, stats_stream, dy, g.gray ? nullptr : dcb, g.gray ? nullptr : dcr, 0, 0))) return rc;
+    } else if (need_plain && (rc = coeffs_on_device(c, d_pixels, o, g, c.stream, &dy, &dcb, &dcr))) return rc;
     // Preset 2 (optimised tables AND trellis): the statistics (plain tuple -> baseline walk -> counts) are enqueued, the counts
     // start their way to a pinned buffer, and the raw transform + trellis search follow on the same stream AT ONCE: the host
     // waits for the counts' event only and builds the tables while the search (0.29 ms for 4096x4096) runs.  Rounds 1-3
     // synchronised, built the tables and only then launched the search: 30 us of idle GPU per file.
-    const bool late_tables = o.optimize_huffman && o.trellis_quant && !debug().host_entropy;
     if (late_tables) {
         pd::ScanArgs a;
         a.y = dy; a.cb = dcb; a.cr = dcr; a.tables = nullptr;
@@ -337,11 +354,11 @@ int progressive_to_view(const void *d_pixels, const pixo_jpeg_options &o, const 
         a.seed_dc[0] = a.seed_dc[1] = a.seed_dc[2] = 0; a.bit_base = 0; a.pad_last = 1;
         HIP_TRY(c.e_hist.reserve(pixo_host::kScanTableWords * 8));
         HIP_TRY(c.e_count.reserve(pd::scan_count_scratch_bytes()));
-        HIP_TRY(pd::launch_scan_count(a, c.e_count.as<uint32_t>(), c.e_hist.as<unsigned long long>(), c.stream));
+        HIP_TRY(pd::launch_scan_count(a, c.e_count.as<uint32_t>(), c.e_hist.as<unsigned long long>(), stats_stream));
         if ((rc = c.reserve_hsegs(pixo_host::kScanTableWords))) return rc;
-        HIP_TRY(hipMemcpyAsync(c.h_segs, c.e_hist.p, pixo_host::kScanTableWords * 8, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipMemcpyAsync(c.h_segs, c.e_hist.p, pixo_host::kScanTableWords * 8, hipMemcpyDeviceToHost, stats_stream));
         if (!c.stats_done) HIP_TRY(hipEventCreateWithFlags(&c.stats_done, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(c.stats_done, c.stream));
+        HIP_TRY(hipEventRecord(c.stats_done, stats_stream));
     } else if ((rc = huffman_for_tuple(dy, dcb, dcr, o, g, c, h))) return rc;
     const size_t blocks = g.y_blocks + 2 * g.c_blocks, coef_bytes = blocks * 128;
     if (o.trellis_quant) {

@@ -821,7 +821,25 @@ __global__ __launch_bounds__(kStuffThreads) __attribute__((amdgpu_waves_per_eu(4
     const uint64_t out_before = out_chain && piece ? out_chain[piece] : 0ull;
     const uint64_t t = tile_offset + blockIdx.x; // one tile per workgroup (the launcher guesses how many there are)
     uint64_t nbytes, ntiles, local_t = t, sidx = 0;
-    if (SEG) {
+    if (SEG && seg.var) {
+        // the scans of a progressive file (at most eight segments of different sizes): every workgroup works the layout out itself
+        // from the segments' bit counts — round 4 ran a one-workgroup kernel (seg_layout) between the coder and this one for it:
+        // 5 us and a launch per file
+        uint64_t first = 0;
+        bool found = false;
+        nbytes = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {
+            if (i >= seg.nsegs) continue; // (uniform)
+            const uint64_t nb = (seg.bits[i] + 7) / 8, tl = (nb + kTileBytes - 1) / kTileBytes;
+            if (!found && t < first + tl) { sidx = i; local_t = t - first; nbytes = nb; found = true; }
+            first += tl;
+        }
+        ntiles = first;
+        if (blockIdx.x == 0 && lane == 0 && tile_offset == 0 && host_totals) host_totals[2] = ntiles; // (the host launches the tiles its guess missed)
+        if (!found) return;
+        stream += seg.var_word[sidx];
+    } else if (SEG) {
         ntiles = seg.layout[0];
         if (t >= ntiles) return;
         uint64_t lo = 0, hi = seg.nsegs; // the segment whose tiles include t: first[lo] <= t < first[lo + 1]

@@ -186,7 +186,7 @@ static int device_progressive_scans_fused(const int16_t *dy, const int16_t *dcb,
     unsigned long long *mailbox = reinterpret_cast<unsigned long long *>(c.h_totals);
     HIP_TRY(pd::launch_prog_code(a, sg, c.e_code_state.as<unsigned long long>(), zero, c.e_stream.as<uint32_t>(),
                                  c.e_stuff_state.as<unsigned long long>(), stuff_words, mailbox, stream, debug().spin_budget));
-    HIP_TRY(pd::launch_seg_layout(sg, const_cast<unsigned long long *>(sg.layout), const_cast<unsigned long long *>(sg.bytes), mailbox, stream));
+    // (the scans' layout — bytes and 16 KiB tiles of each — is worked out by the stuffing kernel's workgroups themselves: seg.var)
     // tiles: a guess of 40 bytes per (scan, block) pair + one partial tile per scan; the layout kernel says how many there are
     uint64_t first_tile = 0, tiles = pd::stuff_tiles(blocks_all * 40 + 4096) + a.nscans;
     size_t want_cap = std::max<size_t>(stream_bytes / 4, 4096);

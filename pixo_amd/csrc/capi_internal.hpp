@@ -138,6 +138,7 @@ struct Context {
     std::vector<hipEvent_t> piece_done, band_up;
     uint32_t tables_held[pixo_scan::kScanTableUpload]; bool tables_valid = false; hipStream_t tables_stream = nullptr; // what e_tables holds (no upload when unchanged)
     uint32_t packed_per_block = 0; // bytes per block of the last whole scan this context coded (0: none yet), see device_entropy_to_pinned
+    uint64_t last_prog_bytes = 0; // the last progressive file's entropy-coded bytes (small: the next one is stored directly)
     uint64_t last_scan_bytes = 0, last_scan_blocks = 0; // ... exactly (a smooth image is below one byte per block): predicts the next file's size
     uint32_t batch_per_block = 0;  // ... of the last batch (1 + bytes per block; 0: none yet): whether sub-batches pay, jpeg_api.cpp
     size_t code_state_zero_words = 0; // this many words of e_code_state are known to be zero (the stuffing kernel cleans up behind itself)

@@ -187,15 +187,40 @@ static int device_progressive_scans_fused(const int16_t *dy, const int16_t *dcb,
     HIP_TRY(pd::launch_prog_code(a, sg, c.e_code_state.as<unsigned long long>(), zero, c.e_stream.as<uint32_t>(),
                                  c.e_stuff_state.as<unsigned long long>(), stuff_words, mailbox, stream, debug().spin_budget));
     // (the scans' layout — bytes and 16 KiB tiles of each — is worked out by the stuffing kernel's workgroups themselves: seg.var)
-    // tiles: a guess of 40 bytes per (scan, block) pair + one partial tile per scan; the layout kernel says how many there are
+    // tiles: a guess of 40 bytes per (scan, block) pair + one partial tile per scan; the stuffing kernel says how many there are
     uint64_t first_tile = 0, tiles = pd::stuff_tiles(blocks_all * 40 + 4096) + a.nscans;
     size_t want_cap = std::max<size_t>(stream_bytes / 4, 4096);
     uint64_t scan_bytes = 0;
+    // Small files (round 5; like the baseline path, pieces.cpp): the stuffing kernel stores the scans straight into host memory the
+    // GPU can write — the caller's pinned storage or the context's pinned file buffer — at their places in the FILE; no copy and no
+    // second wait.  "Small": the last progressive file of this context was (768 KB); all seven scans present (the gaps between
+    // them are then exactly the SOS headers' places).  Too small a destination: the stuffing pass runs again into device memory.
+    constexpr uint64_t kDirectBytes = 768u << 10;
+    const size_t body_at = head.size() + 10; // the first scan's first byte in the file
+    uint8_t *direct_host = nullptr, *direct_dev = nullptr;
+    size_t direct_cap = 0;
+    if (a.nscans == 7 && !debug().no_direct_small && c.last_prog_bytes && c.last_prog_bytes <= kDirectBytes) {
+        const size_t guess = body_at + 2 * static_cast<size_t>(c.last_prog_bytes) + 4096;
+        if (pinned_dest && dest_cap >= guess) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, pinned_dest) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+                direct_host = pinned_dest; direct_dev = static_cast<uint8_t *>(at.devicePointer); direct_cap = dest_cap;
+            } else (void)hipGetLastError();
+        }
+        if (!direct_host) {
+            const int rc_f = c.reserve_hfile(guess);
+            if (rc_f) return rc_f;
+            direct_host = direct_dev = c.h_file; direct_cap = c.hfile_cap;
+        }
+    }
     for (int attempt = 0;; ++attempt) {
-        HIP_TRY(c.e_out.reserve(want_cap));
+        uint8_t *out = nullptr;
+        size_t out_cap = 0;
+        if (direct_host) { out = direct_dev + body_at; out_cap = direct_cap - body_at - 2; }
+        else { HIP_TRY(c.e_out.reserve(want_cap)); out = c.e_out.as<uint8_t>(); out_cap = c.e_out.cap; }
         HIP_TRY(pd::launch_stuff_fused(c.e_stream.as<uint32_t>(), c.e_code_state.as<unsigned long long>(), state_words, 0, false,
                                        stream_bytes + 8 * pd::stuff_tile_bytes(), first_tile, tiles, c.e_stuff_state.as<unsigned long long>(),
-                                       /*state_is_zero=*/attempt == 0, c.e_out.as<uint8_t>(), c.e_out.cap, mailbox, stream, nullptr, 0, &sg,
+                                       /*state_is_zero=*/attempt == 0, out, out_cap, mailbox, stream, nullptr, 0, &sg,
                                        debug().spin_budget));
         c.code_state_zero_words = state_words;
         HIP_TRY(hipStreamSynchronize(stream));
@@ -208,8 +233,9 @@ static int device_progressive_scans_fused(const int16_t *dy, const int16_t *dcb,
             continue;
         }
         scan_bytes = c.h_totals[1];
-        if (scan_bytes > c.e_out.cap) { // (unusually large: grow and repeat the stuffing pass only)
-            if (attempt > 2) return fail(PIXO_ERR_COMPRESSION, "Compression error: stuffed stream larger than announced");
+        if (scan_bytes > out_cap) { // (unusually large: grow and repeat the stuffing pass only — into device memory)
+            if (attempt > 3) return fail(PIXO_ERR_COMPRESSION, "Compression error: stuffed stream larger than announced");
+            direct_host = nullptr;
             want_cap = static_cast<size_t>(scan_bytes);
             first_tile = 0;
             tiles = all_tiles;
@@ -217,9 +243,10 @@ static int device_progressive_scans_fused(const int16_t *dy, const int16_t *dcb,
         }
         break;
     }
-    sw.lap("prog code+layout+stuff");
-    // c.e_out: [scan k0 | 10 | scan k1 | 10 | ...]; c.h_segs[k]: where scan k's bytes end.  The file: head, then per scan of the
-    // script its SOS header and (if it has blocks) its bytes, then EOI.
+    c.last_prog_bytes = scan_bytes;
+    sw.lap("prog code+stuff");
+    // c.e_out (or the file itself): [scan k0 | 10 | scan k1 | 10 | ...]; c.h_segs[k]: where scan k's bytes end.  The file: head, then
+    // per scan of the script its SOS header and (if it has blocks) its bytes, then EOI.
     uint64_t dev_begin[7], dev_end[7];
     for (uint32_t k = 0; k < a.nscans; ++k) {
         dev_end[k] = c.h_segs[k];
@@ -227,6 +254,17 @@ static int device_progressive_scans_fused(const int16_t *dy, const int16_t *dcb,
     }
     const size_t payload = static_cast<size_t>(scan_bytes - static_cast<uint64_t>(sg.marker_bytes) * (a.nscans - 1));
     const size_t total = head.size() + 7 * 10 + payload + 2;
+    if (direct_host) { // the scans already lie in the file: headers into the gaps, EOI behind
+        uint8_t *p = direct_host;
+        std::memcpy(p, head.data(), head.size());
+        sos_of_scan(0, p + head.size());
+        for (uint32_t k = 1; k < 7; ++k) sos_of_scan(static_cast<int>(k), p + body_at + dev_end[k - 1]);
+        p[total - 2] = 0xFF; p[total - 1] = 0xD9;
+        *file = p;
+        *file_len = total;
+        sw.lap("prog headers");
+        return PIXO_OK;
+    }
     uint8_t *p = pinned_dest;
     if (!p || total > dest_cap) {
         const int rc = c.reserve_hfile(total);

@@ -9,7 +9,7 @@ for (w, h) in ((64, 64), (512, 512), (1024, 1024), (1920, 1080)):
         px = synth.noise(w, h, 42) if kind == "noise" else synth.gradient_rgb(w, h)
         row = []
         ref = None
-        for form, sw in (("side stream", None), ("one stream", "no_side_stats")):
+        for form, sw in (("now", None), ("no direct stores", "no_direct_small"), ("one stream", "no_side_stats")):
             jpeg.debug_configure(sw)
             fn = lambda: jpeg.encode_jpeg(px, w, h, 2, 80, 2, True)
             for _ in range(20): r = fn()

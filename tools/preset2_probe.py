@@ -1,6 +1,6 @@
 """N encodes of ONE device-resident 4096x4096 image into pinned storage, for one option set — the loop behind the rocprofv3
 dispatch counts of a progressive / preset-2 file (<= 12 dispatches, no __amd_rocclr_copyBuffer in steady
-state).   python tools/preset2_probe.py <progressive|trellis|preset2|baseline> [n] [noise|gradient]"""
+state).   python tools/preset2_probe.py <progressive|trellis|preset2|baseline> [n] [noise|gradient|photo]"""
 import os, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
@@ -11,7 +11,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "progressive"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 kind = sys.argv[3] if len(sys.argv) > 3 else "noise"
 w = h = 4096
-px = synth.noise(w, h, 42) if kind == "noise" else (synth.gradient_rgb(w, h) if kind == "gradient" else synth.constant(w, h, 77))
+px = synth.noise(w, h, 42) if kind == "noise" else (synth.gradient_rgb(w, h) if kind == "gradient" else (synth.photo(w, h, 42) if kind == "photo" else synth.constant(w, h, 77)))
 d = torch.from_numpy(px).to("cuda:0"); torch.cuda.synchronize()
 b = jpeg.JpegOptions.builder(w, h).quality(80).subsampling(jpeg.Subsampling.S420)
 kw = {"baseline": {}, "progressive": dict(progressive=True), "trellis": dict(progressive=True, trellis_quant=True),

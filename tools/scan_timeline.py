@@ -11,7 +11,7 @@ import synth
 from pixo_amd import jpeg, _lib
 kind = sys.argv[1] if len(sys.argv) > 1 else "noise"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-px = synth.noise(n, n, 42) if kind == "noise" else (synth.gradient_rgb(n, n) if kind == "gradient" else synth.constant(n, n, 77))
+px = synth.noise(n, n, 42) if kind == "noise" else (synth.gradient_rgb(n, n) if kind == "gradient" else (synth.photo(n, n, 42) if kind == "photo" else synth.constant(n, n, 77)))
 d = torch.from_numpy(px).to("cuda:0"); torch.cuda.synchronize()
 prog = len(sys.argv) > 3 and sys.argv[3] == "prog"  # the progressive coder's launch (prog_code_kernel: a group per 192 blocks of a component)
 b = jpeg.JpegOptions.builder(n, n).quality(80).subsampling(jpeg.Subsampling(1))

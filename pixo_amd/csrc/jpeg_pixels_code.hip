@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         uint32_t polls = 0;
         bool gave_up = false;
         while ((d >> 62) == 0) {
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(kPollSleep);
             if (++polls > rest.spin_budget) { gave_up = true; break; }
             d = load_relaxed(src);
         }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                 unsigned long long t = load_relaxed(&tails[g - 1]);
                 uint32_t polls = 0;
                 while (!(t & kTailValid)) {
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(kPollSleep);
                     if (++polls > rest.spin_budget) { raise_abort(a_state, host_abort); s_abort = 1; break; }
                     t = load_relaxed(&tails[g - 1]);
                 }
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                 unsigned long long da = (uint32_t)lane < in_block ? load_relaxed(&desc2[block_first + lane]) : kFlagAggregate;
                 unsigned long long db2 = (uint64_t)lane < kblk ? load_relaxed(&sup2[lane]) : kFlagAggregate;
                 while ((da >> 62) == 0 && !gave_up) {
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(kPollSleep);
                     if (++polls > rest.spin_budget) gave_up = true; else da = load_relaxed(&desc2[block_first + lane]);
                 }
                 uint64_t before2 = 0;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                     if (in_block == 63 && last_round && lane == 0) store_relaxed(&sup2[kblk], kFlagAggregate | ((uint64_t)front + ff_group + round_ff));
                     for (uint64_t base = 0;;) {
                         while ((db2 >> 62) == 0 && !gave_up) {
-                            __builtin_amdgcn_s_sleep(1);
+                            __builtin_amdgcn_s_sleep(kPollSleep);
                             if (++polls > rest.spin_budget) gave_up = true; else db2 = load_relaxed(&sup2[base + lane]);
                         }
                         if (PIXO_ANY64(gave_up)) break;

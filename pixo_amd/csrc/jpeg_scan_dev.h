@@ -63,6 +63,11 @@ __device__ __forceinline__ void store_relaxed(unsigned long long *p, unsigned lo
 #define PIXO_LOOK_BATCH 1 // 64 predecessors per round; 2..32 measured slower (profiles/r04_ab_look_batch.txt)
 #endif
 constexpr int kLookBatch = PIXO_LOOK_BATCH;
+// what a polling wavefront sleeps between two reads of a descriptor that is not there yet (units of 64 cycles)
+#ifndef PIXO_POLL_SLEEP
+#define PIXO_POLL_SLEEP 1
+#endif
+constexpr int kPollSleep = PIXO_POLL_SLEEP;
 // Waiting is BOUNDED: forward progress of these kernels rests on the hardware starting the workgroups of a
 // grid in increasing id order (file header) — observed, not promised by HIP.  Every poll loop gives up after `budget`
 // polls (launch argument; 2^20 polls of >= 64 cycles each = tens of milliseconds, three orders of magnitude beyond any
@@ -102,7 +107,7 @@ __device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t
             const int64_t j = top - lane - 64 * i;
             bool gave_up = false;
             while ((d[i] >> 62) == 0) {
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(kPollSleep);
                 if (++polls > budget) { gave_up = true; break; }
                 d[i] = load_relaxed(&desc[j]);
             }
@@ -149,7 +154,7 @@ __device__ __forceinline__ uint64_t look_back_blocks(unsigned long long *desc, u
     unsigned long long a = (uint32_t)lane < in_block ? load_relaxed(&desc[block_first + lane]) : kFlagAggregate;
     unsigned long long b = (uint64_t)lane < k ? load_relaxed(&sup[lane]) : kFlagAggregate;
     while ((a >> 62) == 0 && !gave_up) {
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(kPollSleep);
         if (++polls > budget) gave_up = true; else a = load_relaxed(&desc[block_first + lane]);
     }
     if (PIXO_ANY64(gave_up)) {
@@ -161,7 +166,7 @@ __device__ __forceinline__ uint64_t look_back_blocks(unsigned long long *desc, u
     uint64_t before = in_front;
     for (uint64_t base = 0;;) { // block sums, 64 per round (one round up to 4096 groups)
         while ((b >> 62) == 0 && !gave_up) {
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(kPollSleep);
             if (++polls > budget) gave_up = true; else b = load_relaxed(&sup[base + lane]);
         }
         if (PIXO_ANY64(gave_up)) {

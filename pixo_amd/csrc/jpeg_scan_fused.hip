@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                 unsigned long long t = load_relaxed(&tails[g - 1]);
                 uint32_t polls = 0;
                 while (!(t & kTailValid)) {
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(kPollSleep);
                     if (++polls > spin_budget) { raise_abort(state, host_abort); return; }
                     t = load_relaxed(&tails[g - 1]);
                 }

@@ -65,6 +65,7 @@ int hip_fail(hipError_t e, const char *what); // pixo::Error::CompressionError(S
 struct DebugSwitches {
     bool trace = false, host_entropy = false, multipass_entropy = false, direct_stores = false, one_piece = false;
     bool piece_medium_forced = false, no_bands_upload = false, plain_host = false, no_direct_small = false, two_kernel_scan = false;
+    int coef_form = 0; // 1 / 2: the coefficient kernel's scalar / packed form whatever the launch size (jpeg_kernels.hpp)
     bool no_side_stats = false; // preset 2 on small images: statistics on the context's stream, in front of the search (round 4's order)
     // host pixels are uploaded in bands from this many MiB of pixels on (bands_upload_min_mb=n), in bands of about
     // bands_upload_mb=n MiB.  A 4096x4096 RGB image (48 MiB) in six bands of 8 MiB: noise 1.18 -> 1.14 ms into caller storage,

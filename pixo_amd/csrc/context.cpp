@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include "capi_internal.hpp"
+#include "jpeg_kernels.hpp"
 
 namespace pixo_capi {
 
@@ -68,6 +69,7 @@ DebugSwitches parse_switches(const char *e)
         else if (name == "no_direct_small") v.no_direct_small = true;
         else if (name == "two_kernel_scan") v.two_kernel_scan = true;
         else if (name == "no_side_stats") v.no_side_stats = true;
+        else if (name == "coef_form") v.coef_form = val == "scalar" ? 1 : (val == "packed" ? 2 : 0);
         else if (name == "bands_upload_min_mb" && num > 0) v.bands_upload_min_mb = static_cast<uint32_t>(num);
         else if (name == "bands_upload_mb" && num > 0) v.bands_upload_mb = static_cast<uint32_t>(num);
         else if (name == "piece_groups" && num > 0) v.piece_groups = static_cast<uint64_t>(num);
@@ -93,7 +95,11 @@ DebugSwitches parse_switches(const char *e)
 }
 DebugSwitches &switches()
 {
-    static DebugSwitches *d = new DebugSwitches(parse_switches(std::getenv("PIXO_HIP_DEBUG")));
+    static DebugSwitches *d = [] {
+        DebugSwitches *p = new DebugSwitches(parse_switches(std::getenv("PIXO_HIP_DEBUG")));
+        pixo_dev::set_coef_form(p->coef_form);
+        return p;
+    }();
     return *d;
 }
 } // namespace
@@ -382,6 +388,7 @@ void *pixo_hip_get_producer_stream(void) { return t_producer; }
 int pixo_hip_debug_configure(const char *switches_or_null)
 { // tests and tools only; not synchronised with calls in flight on other threads
     switches() = parse_switches(switches_or_null ? switches_or_null : std::getenv("PIXO_HIP_DEBUG"));
+    pixo_dev::set_coef_form(switches().coef_form);
     return PIXO_OK;
 }
 

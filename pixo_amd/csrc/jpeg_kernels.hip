@@ -217,6 +217,10 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     }
 }
 
+static int g_coef_form = 0; // (set before any launch, by the debug switches: tools and tests)
+void set_coef_form(int form) { g_coef_form = form; }
+bool packed_launch(uint64_t workgroups) { return g_coef_form == 1 ? false : (g_coef_form == 2 ? true : workgroups > 2048); }
+
 template <int MODE, int LOAD> static hipError_t launch_mode(KArgs &a, hipStream_t s)
 {
     const bool raw = a.ry != nullptr;

@@ -9,7 +9,9 @@ namespace pixo_dev {
 // Which form of the DCT passes and the quantiser a launch of `workgroups` tiles takes (jpeg_tile.h, block_rows): one generation
 // (all workgroups resident at once: 8 per CU x 256 CUs) is latency-bound at its end and runs the scalar forms; several
 // generations are issue-bound and run the packed ones.
-inline bool packed_launch(uint64_t workgroups) { return workgroups > 2048; }
+bool packed_launch(uint64_t workgroups);
+// measurements: 0 = by launch size (above), 1 = always the scalar forms, 2 = always the packed ones (PIXO_HIP_DEBUG coef_form=scalar|packed)
+void set_coef_form(int form);
 
 // Enqueues the fused colour -> DCT -> quantise kernel for `batch` equally sized images on
 // `stream`.  All pointers are device pointers; d_qt points at the 512-float table block of

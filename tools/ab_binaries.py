@@ -36,10 +36,11 @@ def main():
             parity = False
         else:
             n, p = a.split("=", 1)
-            libs.append((n, os.path.join(ROOT, p) if not os.path.isabs(p) else p))
+            p, _, sw = p.partition("@")  # name=path.so@debug switches (a COPY of the library per set of switches: one state per dlopen'ed file)
+            libs.append((n, os.path.join(ROOT, p) if not os.path.isabs(p) else p, sw))
     if not libs:
-        libs = [("r03", os.path.join(ROOT, "pixo_amd/ab_r03.so")), ("r04", os.path.join(ROOT, "pixo_amd/ab_r04.so")),
-                ("r05", os.path.join(ROOT, "pixo_amd/libpixo_hip.so"))]
+        libs = [("r03", os.path.join(ROOT, "pixo_amd/ab_r03.so"), ""), ("r04", os.path.join(ROOT, "pixo_amd/ab_r04.so"), ""),
+                ("r05", os.path.join(ROOT, "pixo_amd/libpixo_hip.so"), "")]
     from pixo_amd import _lib
     _lib._preload_process_hip_runtime()
     W = H = 4096
@@ -55,8 +56,11 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     sp = C.c_void_p(stream) if stream else None
     variants = []
-    for name, path in libs:
+    for name, path, sw in libs:
         L = C.CDLL(path)
+        if sw:
+            L.pixo_hip_debug_configure.argtypes = [C.c_char_p]
+            assert L.pixo_hip_debug_configure(sw.encode()) == 0
         L.pixo_hip_jpeg_coeffs_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint32,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 

@@ -896,3 +896,34 @@ def test_small_file_into_pinned_storage_that_is_too_small_exact_and_roomy(shape)
             n = jpeg.encode_device_into(view, d, o)
             assert n == len(want) and view[:n].numpy().tobytes() == want
         assert bool((buf[cap:] == 0xA5).all()), "bytes behind the buffer's capacity were written (capacity %d)" % cap
+
+
+def test_batch_in_sub_batches_gives_the_same_arena():
+    """Round 5: pixo_hip_jpeg_encode_batch_device_into cuts a large batch into sub-batches (copies under the next one's kernels) —
+    how many, it chooses from the content's bytes per block.  Whatever the count (debug switch batch_parts), the arena, the
+    offsets and the lengths are the same, and the files are the oracle's."""
+    import hashlib
+    import torch
+    w, h, n = 1920, 1080, 40  # (237 MB of pixels: above the 64 MB from which the library considers sub-batches)
+    px = synth.photo(w, h, 5)
+    d = torch.from_numpy(np.ascontiguousarray(px)).cuda().repeat(n).contiguous()
+    d[w * h * 3 * 7: w * h * 3 * 8] ^= 0x10  # (one image of the batch differs)
+    o = jpeg.JpegOptions.builder(w, h).quality(80).subsampling(jpeg.Subsampling.S420).build()
+    arena = torch.empty(n * w * h, dtype=torch.uint8).pin_memory()
+    seen = {}
+    try:
+        for parts in (None, 1, 3, 8, None):
+            jpeg.debug_configure("batch_parts=%d" % parts if parts else None)
+            arena.zero_()
+            offs, lens = jpeg.encode_batch_device_into(arena, d, o, n)
+            end = offs[-1] + lens[-1]
+            seen[parts if parts else 0] = (list(offs), list(lens), hashlib.sha256(arena[:end].numpy().tobytes()).hexdigest())
+    finally:
+        jpeg.debug_configure(None)
+    assert len({repr(v) for v in seen.values()}) == 1, seen.keys()
+    offs, lens, _ = seen[1]
+    want = O.encode(px, O.make_options(w, h, 2, 80, 1))
+    assert arena[offs[0]: offs[0] + lens[0]].numpy().tobytes() == want
+    assert arena[offs[n - 1]: offs[n - 1] + lens[n - 1]].numpy().tobytes() == want
+    other = bytes(d[w * h * 3 * 7: w * h * 3 * 8].cpu().numpy())
+    assert arena[offs[7]: offs[7] + lens[7]].numpy().tobytes() == O.encode(np.frombuffer(other, np.uint8), O.make_options(w, h, 2, 80, 1))

@@ -194,3 +194,35 @@ def test_directed_tuples_for_the_run_counter_on_the_device():
         torch.cuda.synchronize()
         got = jpeg.entropy_encode_device(dy, dy, dy, _opts(w, h, 0, 0, 50, progressive=True))
         assert got == want, (nblocks, where[:6])
+
+
+def test_small_progressive_files_are_stored_straight_into_a_pinned_destination():
+    """Round 5: once a context has seen a small progressive file, the next one's scans are stored by the stuffing kernel at their
+    places in the FILE in pinned memory (caller's storage when it is large enough for the prediction, else the context's buffer).
+    Same bytes as the oracle's either way; nothing behind the file / the capacity is touched; a destination one byte short
+    reports the size needed."""
+    import torch
+    from pixo_amd import error
+    w, h = 320, 200
+    d_cases = []
+    for seed, (trellis, optimize) in ((3, (False, False)), (4, (True, True))):
+        px = synth.noise(w, h, seed)
+        o = _opts(w, h, 2, 1, 80, progressive=True, trellis_quant=trellis, optimize_huffman=optimize)
+        want = O.encode(px, O.make_options(w, h, 2, 80, 1, progressive=True, trellis=trellis, optimize_huffman=optimize))
+        d_cases.append((torch.from_numpy(np.ascontiguousarray(px)).cuda(), o, want))
+    for d, o, want in d_cases:
+        big = torch.full((4 * len(want) + 8192,), 0xA5, dtype=torch.uint8).pin_memory()
+        for _ in range(3):  # (the first call of a context sizes the prediction; from the second on the direct path runs)
+            big.fill_(0xA5)
+            n = jpeg.encode_device_into(big, d, o)
+            assert n == len(want) and big[:n].numpy().tobytes() == want
+            assert bool((big[n:] == 0xA5).all()), "bytes behind the file were written"
+        exact = torch.full((len(want) + 64,), 0xA5, dtype=torch.uint8).pin_memory()
+        n = jpeg.encode_device_into(exact[: len(want)], d, o)
+        assert n == len(want) and exact[:n].numpy().tobytes() == want and bool((exact[n:] == 0xA5).all())
+        short = torch.full((len(want) + 64,), 0xA5, dtype=torch.uint8).pin_memory()
+        with pytest.raises(error.BufferTooSmall) as e:
+            jpeg.encode_device_into(short[: len(want) - 1], d, o)
+        assert e.value.needed == len(want)
+        assert bool((short[len(want) - 1:] == 0xA5).all()), "bytes behind the capacity were written"
+        assert bytes(jpeg.encode_device(d, o)) == want  # (into the context's own buffer)

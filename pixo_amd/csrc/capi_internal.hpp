@@ -65,6 +65,7 @@ int hip_fail(hipError_t e, const char *what); // pixo::Error::CompressionError(S
 struct DebugSwitches {
     bool trace = false, host_entropy = false, multipass_entropy = false, direct_stores = false, one_piece = false;
     bool piece_medium_forced = false, no_bands_upload = false, plain_host = false, no_direct_small = false, two_kernel_scan = false;
+    int trellis_form = 0; // 1 / 2: the trellis search on one / on eight lanes per block whatever the image's size (jpeg_trellis.hpp)
     int coef_form = 0; // 1 / 2: the coefficient kernel's scalar / packed form whatever the launch size (jpeg_kernels.hpp)
     bool no_side_stats = false; // preset 2 on small images: statistics on the context's stream, in front of the search (round 4's order)
     // host pixels are uploaded in bands from this many MiB of pixels on (bands_upload_min_mb=n), in bands of about

@@ -4,6 +4,7 @@
 
 #include "capi_internal.hpp"
 #include "jpeg_kernels.hpp"
+#include "jpeg_trellis.hpp"
 
 namespace pixo_capi {
 
@@ -69,6 +70,7 @@ DebugSwitches parse_switches(const char *e)
         else if (name == "no_direct_small") v.no_direct_small = true;
         else if (name == "two_kernel_scan") v.two_kernel_scan = true;
         else if (name == "no_side_stats") v.no_side_stats = true;
+        else if (name == "trellis_form") v.trellis_form = val == "lane" ? 1 : (val == "group" ? 2 : 0);
         else if (name == "coef_form") v.coef_form = val == "scalar" ? 1 : (val == "packed" ? 2 : 0);
         else if (name == "bands_upload_min_mb" && num > 0) v.bands_upload_min_mb = static_cast<uint32_t>(num);
         else if (name == "bands_upload_mb" && num > 0) v.bands_upload_mb = static_cast<uint32_t>(num);
@@ -98,6 +100,7 @@ DebugSwitches &switches()
     static DebugSwitches *d = [] {
         DebugSwitches *p = new DebugSwitches(parse_switches(std::getenv("PIXO_HIP_DEBUG")));
         pixo_dev::set_coef_form(p->coef_form);
+        pixo_dev::set_trellis_form(p->trellis_form);
         return p;
     }();
     return *d;
@@ -389,6 +392,7 @@ int pixo_hip_debug_configure(const char *switches_or_null)
 { // tests and tools only; not synchronised with calls in flight on other threads
     switches() = parse_switches(switches_or_null ? switches_or_null : std::getenv("PIXO_HIP_DEBUG"));
     pixo_dev::set_coef_form(switches().coef_form);
+    pixo_dev::set_trellis_form(switches().trellis_form);
     return PIXO_OK;
 }
 

@@ -69,16 +69,180 @@ __global__ __launch_bounds__(64) void trellis_kernel(const float *raw, const flo
         if (blk < (int)have) __builtin_nontemporal_store(*reinterpret_cast<const uint32_t *>(s_out + blk * kOutPitch + pair * 2), dst + i);
     }
 }
+
+// ---- the same search on EIGHT LANES per block (round 5; small images) ------------------------------------------------------
+// One lane per block makes a wavefront's 63 steps a chain of ~440 vector instructions each: 117 us whatever the image's size,
+// and an image of up to 65,536 blocks does not even fill the chip's SIMDs with such wavefronts.  Here a block's eight SURVIVORS
+// sit on eight consecutive lanes (a wavefront = eight blocks) and one step is, per lane:
+//   * the three non-zero candidates against ITS parent (three costs), then the first strict minimum over the eight parents by
+//     three DPP exchanges (quad swaps and the half-row mirror) of 64-bit keys (cost bits, parent) — quantize_block_fast's own
+//     v_min_f64 order;
+//   * ITS parent's zero successor (the "first of the run-0 group" rule from a ballot over the group's lanes);
+//   * the reference's stable sort of the eleven entries as a RANK COUNT: the group's eight zero keys pass through LDS, every
+//     lane counts the keys below its own (and, lanes 0..2, below one candidate's) and drops them at their ranks; lane r then
+//     picks up the survivor of rank r.  Keys are quantize_block_fast's (cost bits, slot, run, kind, parent): all distinct, so
+//     the ranks are the sorting network's positions.
+// Back-pointers: a byte per survivor and step in LDS (4 KiB per wavefront); the walk back is a serial chase of 63 LDS bytes,
+// the values are then recomputed eight positions a lane.  Same arithmetic, same order, same ties as jpeg_trellis.h — the two
+// kernels are held to each other on random images at every quality (tests/test_gpu_progressive.py) and both to the oracle.
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+template <int CTRL> __device__ __forceinline__ uint64_t dpp64(uint64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+// the smallest key of the group's eight lanes, in all of them
+__device__ __forceinline__ uint64_t group_min(uint64_t k)
+{
+    k = pixo_trellis::min_key(k, dpp64<0xB1>(k));  // quad_perm [1, 0, 3, 2]
+    k = pixo_trellis::min_key(k, dpp64<0x4E>(k));  // quad_perm [2, 3, 0, 1]
+    k = pixo_trellis::min_key(k, dpp64<0x141>(k)); // row_half_mirror: lane i of eight <- lane 7 - i (the other quad)
+    return k;
+}
+constexpr int kGroupsPerWave = 8;
+__global__ __launch_bounds__(64) void trellis_lanes_kernel(const float *raw, const float *q_luma, const float *q_chroma, int16_t *out,
+                                                           uint64_t nblocks, uint64_t nluma)
+{
+    using namespace pixo_trellis;
+    __shared__ __attribute__((aligned(16))) uint64_t s_z[kGroupsPerWave][8];       // the zero successors' keys, by parent
+    __shared__ __attribute__((aligned(16))) uint64_t s_sorted[kGroupsPerWave][12]; // the eleven keys by rank
+    __shared__ uint8_t s_trail[kGroupsPerWave][64][8];
+    __shared__ __attribute__((aligned(16))) v4u s_pre[kGroupsPerWave][64]; // per position: the three candidates' distortions, the zero candidate's
+    __shared__ uint32_t s_meta[kGroupsPerWave][64];                         // ... and per candidate a byte: size << 4 | kind << 1 | valid
+    __shared__ uint8_t s_kind[kGroupsPerWave][64];
+    __shared__ __attribute__((aligned(16))) int16_t s_res[kGroupsPerWave][64];
+    __shared__ float s_step[128];
+    __shared__ float s_bits[256];
+    const int lane = threadIdx.x, g = lane >> 3, s = lane & 7;
+    const uint64_t first = (uint64_t)blockIdx.x * kGroupsPerWave;
+    const uint64_t have = nblocks - first < (uint64_t)kGroupsPerWave ? nblocks - first : (uint64_t)kGroupsPerWave;
+    s_step[lane] = q_luma[lane];
+    s_step[64 + lane] = q_chroma[lane];
+#pragma unroll
+    for (int i = 0; i < 4; i++) s_bits[i * 64 + lane] = rate_value(i * 64 + lane);
+    __syncthreads();
+    const uint64_t B = first + ((uint64_t)g < have ? (uint64_t)g : have - 1); // (a short last wavefront searches its last block again)
+    const float *col = raw + (B >> 6) * 4096 + (B & 63); // coefficient i (natural order) of the block: col[64 i]
+    const float *steps = s_step + (B < nluma ? 0 : 64);
+    // What a step needs of its coefficient does not depend on the search: the candidates' distortions, size categories, kinds and
+    // valid bits, and the zero candidate's distortion.  All 63 positions are worked out FIRST, eight a lane, side by side (the
+    // divide, the three roundings, the saturating conversions: half of a step's instructions) — the serial loop below only reads them.
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int zz = s + 8 * i, nat = c_zigzag_nat[zz];
+        const float coef = col[nat * 64], qq = steps[nat];
+        const Kinds3 k = candidate_kinds3(coef / qq);
+        uint32_t meta = 0;
+        float dist[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float rec = (float)k.v[j] * qq, d = coef - rec;
+            dist[j] = d * d;
+            meta |= (((uint32_t)size_category(k.v[j]) << 4) | (k.kind[j] << 1) | (k.ok[j] ? 1u : 0u)) << (8 * j);
+        }
+        s_pre[g][zz] = v4u{f2u(dist[0]), f2u(dist[1]), f2u(dist[2]), f2u(coef * coef)};
+        s_meta[g][zz] = meta;
+    }
+    __syncthreads();
+    uint32_t cc = s == 0 ? 0u : kNoState, run6 = 0; // this lane's survivor: cost bits, run << 6
+    for (int zz = 1; zz < 64; zz++) {
+        const v4u pre = s_pre[g][zz];
+        const uint32_t meta = s_meta[g][zz];
+        const float dists[3] = {u2f(pre.x), u2f(pre.y), u2f(pre.z)};
+        uint64_t cand[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t m = meta >> (8 * j), kind = (m >> 1) & 7u;
+            const float rate = s_bits[(run6 >> 2) | ((m >> 4) & 15u)];
+            const float cost = u2f(cc) + rate + 1.0f * dists[j];
+            const uint64_t bestk = group_min(((uint64_t)f2u(cost) << 32) | (uint32_t)s);
+            const uint32_t lo = (uint32_t)bestk | (kind << 28) | (kind << 3);
+            cand[j] = ((uint64_t)sel_u32((m & 1u) != 0, (uint32_t)(bestk >> 32), kNoState) << 32) | lo;
+        }
+        // this parent's zero successor (quantize_block_fast: wire 0 for parent 0, wires 4..10 for parents 1..7)
+        const float dist0 = u2f(pre.w);
+        const bool alive = cc != kNoState, run0 = run6 == 0;
+        const bool over = run6 == (15u << 6);
+        const float cost0 = u2f(cc) + u2f(sel_u32(over, 0x41200000u /* 10.0f */, 0u)) + 1.0f * dist0;
+        const uint64_t r0 = __builtin_amdgcn_ballot_w64(alive && run0);
+        const uint32_t before = (uint32_t)(r0 >> (8 * g)) & ((1u << s) - 1u); // run-0 parents in front of this one
+        const bool ok = alive && !(run0 && before != 0);
+        const uint32_t slot = s == 0 ? 0u : 4u + (uint32_t)s;
+        const uint32_t nrun6 = (run6 + 64u) & (15u << 6);
+        const uint64_t zkey = ((uint64_t)sel_u32(ok, f2u(cost0), kNoState) << 32) | (slot << 28) | nrun6 | (uint32_t)s;
+        s_z[g][s] = zkey;
+        __syncthreads();
+        uint64_t z[8];
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {
+            const v4u q = *reinterpret_cast<const v4u *>(&s_z[g][t]);
+            z[t] = ((uint64_t)q.y << 32) | q.x; z[t + 1] = ((uint64_t)q.w << 32) | q.z;
+        }
+        const uint64_t mine = s == 0 ? cand[0] : (s == 1 ? cand[1] : cand[2]); // (lanes 0..2 place one candidate each)
+        uint32_t rank_z = 0, rank_c = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) { rank_z += z[t] < zkey ? 1u : 0u; rank_c += z[t] < mine ? 1u : 0u; }
+#pragma unroll
+        for (int j = 0; j < 3; j++) { rank_z += cand[j] < zkey ? 1u : 0u; rank_c += cand[j] < mine ? 1u : 0u; }
+        s_sorted[g][rank_z] = zkey;
+        s_sorted[g][s < 3 ? rank_c : 11u] = mine; // (slot 11: nobody's)
+        __syncthreads();
+        const uint64_t e = s_sorted[g][s];
+        cc = (uint32_t)(e >> 32);
+        run6 = (uint32_t)e & (15u << 6);
+        s_trail[g][zz - 1][s] = (uint8_t)e; // (kind, parent) in bits 0..5
+    }
+    // trailing zeros: an EOB will be coded (trellis.rs:172-178); min_by: the first of equal minima
+    float c = u2f(cc);
+    if (run6 > 0) c += 4.0f;
+    int idx = (int)(uint32_t)group_min(((uint64_t)f2u(c) << 32) | (uint32_t)s);
+    __syncthreads();
+    for (int zz = 63; zz >= 1; zz--) { // (every lane of the group walks the same chain)
+        const uint32_t f = s_trail[g][zz - 1][idx] & 63u;
+        if (s == 0) s_kind[g][zz] = (uint8_t)(f >> 3);
+        idx = (int)(f & 7u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; i++) { // the values, eight positions a lane
+        const int zz = s + 8 * i, nat = c_zigzag_nat[zz];
+        const float fq = col[nat * 64] / steps[nat];
+        int v;
+        if (zz == 0) v = to_i16(__builtin_roundf(fq)); // DC: plain rounding (trellis.rs:75)
+        else {
+            const Kinds kk = candidate_kinds(fq);
+            const int kind = (int)s_kind[g][zz];
+            v = 0;
+#pragma unroll
+            for (int j = 1; j < 5; j++) v = kind == j ? kk.v[j] : v;
+        }
+        s_res[g][nat] = (int16_t)v;
+    }
+    __syncthreads();
+    { // a block's 128 bytes by its eight lanes
+        const uint64_t blk = first + (uint64_t)g;
+        if ((uint64_t)g < have) *reinterpret_cast<v4u *>(out + blk * 64 + s * 8) = *reinterpret_cast<const v4u *>(&s_res[g][s * 8]);
+    }
+}
 } // namespace
 
 size_t trellis_scratch_bytes(uint64_t nblocks) { return (size_t)((nblocks + 63) / 64) * 63 * 64 * 8; }
 
+static int g_trellis_form = 0; // (measurements and tests: PIXO_HIP_DEBUG trellis_form=lane|group)
+void set_trellis_form(int form) { g_trellis_form = form; }
 hipError_t launch_trellis(const float *d_raw, const float *d_q_luma, const float *d_q_chroma, int16_t *d_out, uint64_t nblocks,
                           uint64_t nluma, void *d_scratch, hipStream_t s)
 {
     if (nblocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(trellis_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, d_raw, d_q_luma, d_q_chroma, d_out, nblocks,
-                       nluma, static_cast<uint64_t *>(d_scratch));
+    // eight lanes per block while the one-lane form's wavefronts (64 blocks each) would leave SIMDs idle anyway
+    const bool lanes = g_trellis_form == 2 || (g_trellis_form == 0 && nblocks <= kTrellisLanesBlocks);
+    if (lanes)
+        hipLaunchKernelGGL(trellis_lanes_kernel, dim3((unsigned)((nblocks + kGroupsPerWave - 1) / kGroupsPerWave)), dim3(64), 0, s, d_raw, d_q_luma,
+                           d_q_chroma, d_out, nblocks, nluma);
+    else
+        hipLaunchKernelGGL(trellis_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, d_raw, d_q_luma, d_q_chroma, d_out, nblocks,
+                           nluma, static_cast<uint64_t *>(d_scratch));
     return hipGetLastError();
 }
 } // namespace pixo_dev

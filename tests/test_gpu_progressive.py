@@ -226,3 +226,23 @@ def test_small_progressive_files_are_stored_straight_into_a_pinned_destination()
         assert e.value.needed == len(want)
         assert bool((short[len(want) - 1:] == 0xA5).all()), "bytes behind the capacity were written"
         assert bytes(jpeg.encode_device(d, o)) == want  # (into the context's own buffer)
+
+
+def test_trellis_on_eight_lanes_per_block_equals_one_lane_per_block_and_the_oracle():
+    """Round 5: up to 32,768 blocks the trellis search runs with a block's eight survivors on eight lanes (jpeg_trellis.hip,
+    trellis_lanes_kernel), above with one lane per block.  Both forms forced on the same images (debug switch trellis_form):
+    identical files; the small ones are also the oracle's."""
+    cases = [(64, 64, 80, 1, synth.noise(64, 64, 1)), (200, 120, 50, 0, synth.photo(200, 120, 2)), (333, 77, 95, 1, synth.gradient_rgb(333, 77)),
+             (96, 96, 100, 0, synth.checkerboard(96, 96, 3)), (128, 128, 1, 1, synth.noise(128, 128, 3)), (17, 9, 75, 1, synth.noise(17, 9, 4)),
+             (640, 480, 85, 1, synth.photo(640, 480, 5)), (1024, 768, 60, 1, synth.noise(1024, 768, 6)), (8, 8, 90, 0, synth.constant(8, 8, 200))]
+    try:
+        for w, h, q, ss, px in cases:
+            files = {}
+            for form in ("lane", "group"):
+                jpeg.debug_configure("trellis_form=" + form)
+                files[form] = jpeg.encode(px, _opts(w, h, 2, ss, q, progressive=True, trellis_quant=True, optimize_huffman=True))
+            assert files["lane"] == files["group"], (w, h, q, ss)
+            if w * h <= 333 * 120:
+                assert files["group"] == O.encode(px, O.make_options(w, h, 2, q, ss, progressive=True, trellis=True, optimize_huffman=True)), (w, h, q, ss)
+    finally:
+        jpeg.debug_configure(None)

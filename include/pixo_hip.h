@@ -349,7 +349,7 @@ void *pixo_hip_get_producer_stream(void);   /* what the calling thread set (to s
  * image needed (a 16384x16384 image: ~2 GB of HBM, ~0.4 GB pinned) until it calls this. */
 int pixo_hip_trim(void);
 /* Tests and A/B tools only: replaces the debug switches read from the environment variable PIXO_HIP_DEBUG
- * ("name[=value],...": trace, host_entropy, multipass_entropy, direct_stores, one_piece, two_kernel_scan, no_side_stats, coef_form=scalar|packed, batch_parts=n, piece_groups=n, piece_medium=n,
+ * ("name[=value],...": trace, host_entropy, multipass_entropy, direct_stores, one_piece, two_kernel_scan, no_side_stats, coef_form=scalar|packed, trellis_form=lane|group, batch_parts=n, piece_groups=n, piece_medium=n,
  * piece_schedule=a:b:c, copy_threads=n, spin_budget=n, no_bands_upload, bands_upload_min_mb=n, bands_upload_mb=n — pixo_amd/csrc/capi_internal.hpp).  None of
  * them changes the bytes of a file.  NULL = read the environment again.  Not synchronised with calls in flight. */
 int pixo_hip_debug_configure(const char *switches_or_null);

@@ -535,6 +535,7 @@ def run_coeffs(job, args):
     extras = (not args.no_extras) and job.world == 1 and not job.stub and not os.environ.get("PIXO_BENCH_ABLATION")
     if extras and wl.batch == 1 and args.workload in ("c2", "c2_444"):
         line["whole_file"] = whole_file(job, wl)
+        line["small_files"] = small_files(wl)
     if extras and args.workload == "c2":
         others = {}
         del wl.ins, wl.outs
@@ -635,6 +636,42 @@ def batch_whole_files(job, q, n_batches=7):
             "ms_per_batch": round(dt * 1e3, 3), "ms_per_batch_min": round(min(ts) * 1e3, 3), "Mpixels_per_s": round(w * h * n / dt / 1e6, 1),
             "file_bytes_total": int(sum(lens)), "ms_per_batch_as_64_malloced_files": round(sorted(tb)[1] * 1e3, 3),
             "path": "pixo_hip_jpeg_encode_batch_device_into"}
+
+
+def small_files(wl):
+    """Not `value`: the latency of ONE small image, host pixels -> file bytes (pixo_hip_jpeg_encode_jpeg, the wasm entry's shape:
+    src/wasm.rs:113-142), per preset — 0 baseline (one kernel + one wait), 1 optimised tables, 2 trellis (eight lanes per block
+    at these sizes) + progressive + optimised tables.  Median of 100 calls each; the first file of every kind against the oracle."""
+    out = {}
+    try:
+        import numpy as np
+        import oracle_lib as O
+        import synth
+        jpeg = wl.jpeg
+        for (w, h) in ((64, 64), (512, 512)):
+            px = np.ascontiguousarray(synth.noise(w, h, 42)).reshape(-1)
+            row = {}
+            for preset in (0, 1, 2):
+                fn = lambda: jpeg.encode_jpeg(px, w, h, 2, wl.q, preset, True)
+                first = bytes(fn())
+                if first != bytes(O.encode_flat(px, w, h, 2, wl.q, preset, True)):
+                    raise SystemExit("bench: a small preset-%d file differs from the oracle's — refusing to report a number" % preset)
+                for _ in range(10):
+                    fn()
+                ts = []
+                for _ in range(100):
+                    t1 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - t1)
+                row["preset%d_us" % preset] = round(sorted(ts)[50] * 1e6, 1)
+                row["preset%d_bytes" % preset] = len(first)
+            out["%dx%d" % (w, h)] = row
+        out["what"] = "one image, host pixels -> bytes (pixo_hip_jpeg_encode_jpeg), noise, q=%d 4:2:0, median of 100 calls" % wl.q
+    except SystemExit:
+        raise
+    except Exception as ex:  # the metric line must not depend on this extra
+        out = {"error": repr(ex)}
+    return out
 
 
 def whole_file(job, wl):

@@ -138,6 +138,7 @@ struct Context {
     hipStream_t upload_stream = nullptr; // host pixels arrive band by band on this stream while earlier bands are transformed
     struct CopyHelper *helper = nullptr; // ... and a second host thread sends the coded pieces back meanwhile (pieces.cpp; stopped and joined by release())
     std::vector<hipEvent_t> piece_done, band_up;
+    uint32_t *h_tables = nullptr; // pinned staging of tables_held for the upload
     uint32_t tables_held[pixo_scan::kScanTableUpload]; bool tables_valid = false; hipStream_t tables_stream = nullptr; // what e_tables holds (no upload when unchanged)
     uint32_t packed_per_block = 0; // bytes per block of the last whole scan this context coded (0: none yet), see device_entropy_to_pinned
     uint64_t last_prog_bytes = 0; // the last progressive file's entropy-coded bytes (small: the next one is stored directly)

@@ -233,6 +233,8 @@ void Context::release()
     if (h_sums) (void)hipHostFree(h_sums);
     if (h_totals) (void)hipHostFree(h_totals);
     if (h_segs) (void)hipHostFree(h_segs);
+    if (h_tables) (void)hipHostFree(h_tables);
+    h_tables = nullptr; tables_valid = false;
     if (h_file) (void)hipHostFree(h_file);
     if (stream) (void)hipStreamDestroy(stream);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);

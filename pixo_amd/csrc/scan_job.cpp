@@ -97,7 +97,11 @@ int upload_scan_tables(Context &c, const uint32_t (&packed)[pixo_host::kScanTabl
     std::memcpy(c.tables_held, packed, sizeof packed);
     for (int i = 0; i < pixo_scan::kWalkWords; ++i) // the same tables in the form of the flat walk (jpeg_scan_block.h)
         c.tables_held[pixo_scan::kTableWords + i] = pixo_scan::walk_table_word(packed, i);
-    HIP_TRY(hipMemcpyAsync(c.e_tables.p, c.tables_held, sizeof c.tables_held, hipMemcpyHostToDevice, stream));
+    // (from pinned words: the copy is a plain DMA, not the runtime's staging of pageable memory.  The staging words are free again:
+    // every entry point ends with the stream synchronised, and a call uploads its tables once per stream)
+    if (!c.h_tables) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c.h_tables), sizeof c.tables_held, hipHostMallocDefault));
+    std::memcpy(c.h_tables, c.tables_held, sizeof c.tables_held);
+    HIP_TRY(hipMemcpyAsync(c.e_tables.p, c.h_tables, sizeof c.tables_held, hipMemcpyHostToDevice, stream));
     c.tables_valid = true;
     c.tables_stream = stream;
     return PIXO_OK;
@@ -226,8 +230,12 @@ int scan_count(Context &c, ScanJob &j, hipStream_t stream, uint64_t counts[pixo_
 {
     HIP_TRY(c.e_count.reserve(pixo_dev::scan_count_scratch_bytes()));
     HIP_TRY(pixo_dev::launch_scan_count(j.a, c.e_count.as<uint32_t>(), c.e_hist.as<unsigned long long>(), stream));
-    HIP_TRY(hipMemcpyAsync(counts, c.e_hist.p, pixo_host::kScanTableWords * 8, hipMemcpyDeviceToHost, stream));
+    // (into the context's pinned words and from there to the caller's array: a copy to pageable memory goes through the runtime's
+    // staging buffer and costs a small optimised-tables file about ten microseconds)
+    { const int rc = c.reserve_hsegs(pixo_host::kScanTableWords); if (rc) return rc; }
+    HIP_TRY(hipMemcpyAsync(c.h_segs, c.e_hist.p, pixo_host::kScanTableWords * 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    std::memcpy(counts, c.h_segs, pixo_host::kScanTableWords * 8);
     return PIXO_OK;
 }
 

@@ -343,4 +343,86 @@ template <class Env> PIXO_TDEV void quantize_block_fast(Env &env)
 #undef PIXO_CE
 #undef PIXO_CE_LO
 
+// ---- the same search with a block's eight survivors on EIGHT LANES (round 5; jpeg_trellis.hip trellis_lanes_kernel) ----------
+// What ONE LANE (survivor s of its block) does between the group's exchanges; the kernel supplies the exchanges (the minimum over
+// the eight lanes, a ballot, the zero keys through LDS, the scatter by rank), tests/emu runs the same functions lane by lane on
+// the host with arrays in their place.  Keys, costs, slots and ties are quantize_block_fast's.
+struct LanePre { float dist[3]; float dist0; uint32_t meta; }; // one position: the candidates' distortions, the zero candidate's;
+                                                               // per candidate a byte: size << 4 | kind << 1 | valid
+PIXO_TDEV LanePre lanes_prepare(float coef, float qq)
+{ // (does not depend on the search: worked out for all 63 positions up front, side by side)
+    const Kinds3 k = candidate_kinds3(coef / qq);
+    LanePre p;
+    p.meta = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float rec = (float)k.v[j] * qq, d = coef - rec;
+        p.dist[j] = d * d;
+        p.meta |= (((uint32_t)size_category(k.v[j]) << 4) | (k.kind[j] << 1) | (k.ok[j] ? 1u : 0u)) << (8 * j);
+    }
+    p.dist0 = coef * coef;
+    return p;
+}
+// candidate j against THIS lane's parent: (cost bits, parent) — the group's minimum of these is the first strict minimum
+PIXO_TDEV uint64_t lanes_cost_key(uint32_t cc, uint32_t run6, const LanePre &p, int j, int s, const float *rate_table)
+{
+    const uint32_t m = p.meta >> (8 * j);
+    const float rate = rate_table[(run6 >> 2) | ((m >> 4) & 15u)];
+    const float cost = u2f(cc) + rate + 1.0f * p.dist[j];
+    return ((uint64_t)f2u(cost) << 32) | (uint32_t)s;
+}
+// ... and the sort key of the candidate's successor from the group's minimum
+PIXO_TDEV uint64_t lanes_candidate(uint64_t bestk, const LanePre &p, int j)
+{
+    const uint32_t m = p.meta >> (8 * j), kind = (m >> 1) & 7u;
+    const uint32_t lo = (uint32_t)bestk | (kind << 28) | (kind << 3);
+    return ((uint64_t)sel_u32((m & 1u) != 0, (uint32_t)(bestk >> 32), kNoState) << 32) | lo;
+}
+PIXO_TDEV bool lanes_alive_run0(uint32_t cc, uint32_t run6) { return cc != kNoState && run6 == 0; }
+// this lane's parent's zero successor; run0_in_front: some alive parent with run 0 sits on a lower lane of the group
+PIXO_TDEV uint64_t lanes_zero_key(uint32_t cc, uint32_t run6, const LanePre &p, int s, bool run0_in_front)
+{
+    const bool alive = cc != kNoState, run0 = run6 == 0;
+    const bool over = run6 == (15u << 6); // a ZRL symbol will be needed (trellis.rs:117-120)
+    const float cost0 = u2f(cc) + u2f(sel_u32(over, 0x41200000u /* 10.0f */, 0u)) + 1.0f * p.dist0;
+    const bool ok = alive && !(run0 && run0_in_front);
+    const uint32_t slot = s == 0 ? 0u : 4u + (uint32_t)s;
+    const uint32_t nrun6 = (run6 + 64u) & (15u << 6);
+    return ((uint64_t)sel_u32(ok, f2u(cost0), kNoState) << 32) | (slot << 28) | nrun6 | (uint32_t)s;
+}
+// the reference's stable sort as a rank count: how many of the eleven keys lie below this lane's zero key / below `mine`
+PIXO_TDEV void lanes_ranks(const uint64_t z[8], const uint64_t cand[3], uint64_t zkey, uint64_t mine, uint32_t *rank_z, uint32_t *rank_c)
+{
+    uint32_t rz = 0, rc = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) { rz += z[t] < zkey ? 1u : 0u; rc += z[t] < mine ? 1u : 0u; }
+#pragma unroll
+    for (int j = 0; j < 3; j++) { rz += cand[j] < zkey ? 1u : 0u; rc += cand[j] < mine ? 1u : 0u; }
+    *rank_z = rz; *rank_c = rc;
+}
+// the survivor of this lane's rank: its cost, its run, its back-pointer byte ((kind, parent) in bits 0..5)
+PIXO_TDEV void lanes_take(uint64_t e, uint32_t *cc, uint32_t *run6, uint8_t *back)
+{
+    *cc = (uint32_t)(e >> 32);
+    *run6 = (uint32_t)e & (15u << 6);
+    *back = (uint8_t)e;
+}
+// trailing zeros: an EOB will be coded (trellis.rs:172-178); the group's minimum of these keys is min_by's first minimum
+PIXO_TDEV uint64_t lanes_final_key(uint32_t cc, uint32_t run6, int s)
+{
+    float c = u2f(cc);
+    if (run6 > 0) c += 4.0f;
+    return ((uint64_t)f2u(c) << 32) | (uint32_t)s;
+}
+// the value at one position from the kind its back-pointer names (position 0: the DC, plain rounding, trellis.rs:75)
+PIXO_TDEV int lanes_value(float fq, int kind, bool dc)
+{
+    if (dc) return to_i16(__builtin_roundf(fq));
+    const Kinds kk = candidate_kinds(fq);
+    int v = 0;
+#pragma unroll
+    for (int j = 1; j < 5; j++) v = kind == j ? kk.v[j] : v;
+    return v;
+}
+
 } // namespace pixo_trellis

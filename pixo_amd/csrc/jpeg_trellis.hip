@@ -131,46 +131,23 @@ __global__ __launch_bounds__(64) void trellis_lanes_kernel(const float *raw, con
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int zz = s + 8 * i, nat = c_zigzag_nat[zz];
-        const float coef = col[nat * 64], qq = steps[nat];
-        const Kinds3 k = candidate_kinds3(coef / qq);
-        uint32_t meta = 0;
-        float dist[3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const float rec = (float)k.v[j] * qq, d = coef - rec;
-            dist[j] = d * d;
-            meta |= (((uint32_t)size_category(k.v[j]) << 4) | (k.kind[j] << 1) | (k.ok[j] ? 1u : 0u)) << (8 * j);
-        }
-        s_pre[g][zz] = v4u{f2u(dist[0]), f2u(dist[1]), f2u(dist[2]), f2u(coef * coef)};
-        s_meta[g][zz] = meta;
+        const LanePre p = lanes_prepare(col[nat * 64], steps[nat]);
+        s_pre[g][zz] = v4u{f2u(p.dist[0]), f2u(p.dist[1]), f2u(p.dist[2]), f2u(p.dist0)};
+        s_meta[g][zz] = p.meta;
     }
     __syncthreads();
     uint32_t cc = s == 0 ? 0u : kNoState, run6 = 0; // this lane's survivor: cost bits, run << 6
     for (int zz = 1; zz < 64; zz++) {
         const v4u pre = s_pre[g][zz];
-        const uint32_t meta = s_meta[g][zz];
-        const float dists[3] = {u2f(pre.x), u2f(pre.y), u2f(pre.z)};
+        LanePre p;
+        p.dist[0] = u2f(pre.x); p.dist[1] = u2f(pre.y); p.dist[2] = u2f(pre.z); p.dist0 = u2f(pre.w);
+        p.meta = s_meta[g][zz];
         uint64_t cand[3];
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const uint32_t m = meta >> (8 * j), kind = (m >> 1) & 7u;
-            const float rate = s_bits[(run6 >> 2) | ((m >> 4) & 15u)];
-            const float cost = u2f(cc) + rate + 1.0f * dists[j];
-            const uint64_t bestk = group_min(((uint64_t)f2u(cost) << 32) | (uint32_t)s);
-            const uint32_t lo = (uint32_t)bestk | (kind << 28) | (kind << 3);
-            cand[j] = ((uint64_t)sel_u32((m & 1u) != 0, (uint32_t)(bestk >> 32), kNoState) << 32) | lo;
-        }
-        // this parent's zero successor (quantize_block_fast: wire 0 for parent 0, wires 4..10 for parents 1..7)
-        const float dist0 = u2f(pre.w);
-        const bool alive = cc != kNoState, run0 = run6 == 0;
-        const bool over = run6 == (15u << 6);
-        const float cost0 = u2f(cc) + u2f(sel_u32(over, 0x41200000u /* 10.0f */, 0u)) + 1.0f * dist0;
-        const uint64_t r0 = __builtin_amdgcn_ballot_w64(alive && run0);
-        const uint32_t before = (uint32_t)(r0 >> (8 * g)) & ((1u << s) - 1u); // run-0 parents in front of this one
-        const bool ok = alive && !(run0 && before != 0);
-        const uint32_t slot = s == 0 ? 0u : 4u + (uint32_t)s;
-        const uint32_t nrun6 = (run6 + 64u) & (15u << 6);
-        const uint64_t zkey = ((uint64_t)sel_u32(ok, f2u(cost0), kNoState) << 32) | (slot << 28) | nrun6 | (uint32_t)s;
+        for (int j = 0; j < 3; j++) cand[j] = lanes_candidate(group_min(lanes_cost_key(cc, run6, p, j, s, s_bits)), p, j);
+        const uint64_t r0 = __builtin_amdgcn_ballot_w64(lanes_alive_run0(cc, run6));
+        const uint32_t in_front = (uint32_t)(r0 >> (8 * g)) & ((1u << s) - 1u); // run-0 parents on the group's lower lanes
+        const uint64_t zkey = lanes_zero_key(cc, run6, p, s, in_front != 0);
         s_z[g][s] = zkey;
         __syncthreads();
         uint64_t z[8];
@@ -180,23 +157,16 @@ __global__ __launch_bounds__(64) void trellis_lanes_kernel(const float *raw, con
             z[t] = ((uint64_t)q.y << 32) | q.x; z[t + 1] = ((uint64_t)q.w << 32) | q.z;
         }
         const uint64_t mine = s == 0 ? cand[0] : (s == 1 ? cand[1] : cand[2]); // (lanes 0..2 place one candidate each)
-        uint32_t rank_z = 0, rank_c = 0;
-#pragma unroll
-        for (int t = 0; t < 8; t++) { rank_z += z[t] < zkey ? 1u : 0u; rank_c += z[t] < mine ? 1u : 0u; }
-#pragma unroll
-        for (int j = 0; j < 3; j++) { rank_z += cand[j] < zkey ? 1u : 0u; rank_c += cand[j] < mine ? 1u : 0u; }
+        uint32_t rank_z, rank_c;
+        lanes_ranks(z, cand, zkey, mine, &rank_z, &rank_c);
         s_sorted[g][rank_z] = zkey;
         s_sorted[g][s < 3 ? rank_c : 11u] = mine; // (slot 11: nobody's)
         __syncthreads();
-        const uint64_t e = s_sorted[g][s];
-        cc = (uint32_t)(e >> 32);
-        run6 = (uint32_t)e & (15u << 6);
-        s_trail[g][zz - 1][s] = (uint8_t)e; // (kind, parent) in bits 0..5
+        uint8_t back;
+        lanes_take(s_sorted[g][s], &cc, &run6, &back);
+        s_trail[g][zz - 1][s] = back;
     }
-    // trailing zeros: an EOB will be coded (trellis.rs:172-178); min_by: the first of equal minima
-    float c = u2f(cc);
-    if (run6 > 0) c += 4.0f;
-    int idx = (int)(uint32_t)group_min(((uint64_t)f2u(c) << 32) | (uint32_t)s);
+    int idx = (int)(uint32_t)group_min(lanes_final_key(cc, run6, s));
     __syncthreads();
     for (int zz = 63; zz >= 1; zz--) { // (every lane of the group walks the same chain)
         const uint32_t f = s_trail[g][zz - 1][idx] & 63u;
@@ -207,17 +177,7 @@ __global__ __launch_bounds__(64) void trellis_lanes_kernel(const float *raw, con
 #pragma unroll
     for (int i = 0; i < 8; i++) { // the values, eight positions a lane
         const int zz = s + 8 * i, nat = c_zigzag_nat[zz];
-        const float fq = col[nat * 64] / steps[nat];
-        int v;
-        if (zz == 0) v = to_i16(__builtin_roundf(fq)); // DC: plain rounding (trellis.rs:75)
-        else {
-            const Kinds kk = candidate_kinds(fq);
-            const int kind = (int)s_kind[g][zz];
-            v = 0;
-#pragma unroll
-            for (int j = 1; j < 5; j++) v = kind == j ? kk.v[j] : v;
-        }
-        s_res[g][nat] = (int16_t)v;
+        s_res[g][nat] = (int16_t)lanes_value(col[nat * 64] / steps[nat], zz ? (int)s_kind[g][zz] : 0, zz == 0);
     }
     __syncthreads();
     { // a block's 128 bytes by its eight lanes

@@ -453,6 +453,64 @@ extern "C" void emu_trellis_fast(const float *dct, const float *q, long nblocks,
     }
 }
 
+// The eight-lane form of the search (trellis_lanes_kernel, jpeg_trellis.hip): the per-lane functions of jpeg_trellis.h run lane by
+// lane, the group's exchanges — the minimum over the lanes, the ballot, the zero keys through LDS, the scatter by rank — as loops
+// over arrays.
+extern "C" void emu_trellis_lanes(const float *dct, const float *q, long nblocks, int16_t *out)
+{
+    using namespace pixo_trellis;
+    float table[256];
+    for (int rs = 0; rs < 256; rs++) table[rs] = rate_value(rs);
+    for (long b = 0; b < nblocks; b++) {
+        const float *d = dct + b * 64;
+        int16_t *res = out + b * 64;
+        LanePre pre[64];
+        for (int zz = 0; zz < 64; zz++) pre[zz] = lanes_prepare(d[kZigzagNat[zz]], q[kZigzagNat[zz]]);
+        uint32_t cc[8], run6[8];
+        uint8_t trail[63][8];
+        for (int s = 0; s < 8; s++) { cc[s] = s == 0 ? 0u : kNoState; run6[s] = 0; }
+        for (int zz = 1; zz < 64; zz++) {
+            const LanePre &p = pre[zz];
+            uint64_t cand[3];
+            for (int j = 0; j < 3; j++) {
+                uint64_t best = ~0ull;
+                for (int s = 0; s < 8; s++) best = std::min(best, lanes_cost_key(cc[s], run6[s], p, j, s, table));
+                cand[j] = lanes_candidate(best, p, j);
+            }
+            uint64_t z[8];
+            for (int s = 0; s < 8; s++) {
+                bool in_front = false;
+                for (int t = 0; t < s; t++) in_front |= lanes_alive_run0(cc[t], run6[t]);
+                z[s] = lanes_zero_key(cc[s], run6[s], p, s, in_front);
+            }
+            uint64_t sorted[12];
+            for (int i = 0; i < 12; i++) sorted[i] = 0;
+            for (int s = 0; s < 8; s++) {
+                const uint64_t mine = s == 0 ? cand[0] : (s == 1 ? cand[1] : cand[2]);
+                uint32_t rz, rc;
+                lanes_ranks(z, cand, z[s], mine, &rz, &rc);
+                sorted[rz] = z[s];
+                sorted[s < 3 ? rc : 11u] = mine;
+            }
+            for (int s = 0; s < 8; s++) lanes_take(sorted[s], &cc[s], &run6[s], &trail[zz - 1][s]);
+        }
+        uint64_t best = ~0ull;
+        for (int s = 0; s < 8; s++) best = std::min(best, lanes_final_key(cc[s], run6[s], s));
+        int idx = (int)(uint32_t)best;
+        int kind[64];
+        kind[0] = 0;
+        for (int zz = 63; zz >= 1; zz--) {
+            const uint32_t f = trail[zz - 1][idx] & 63u;
+            kind[zz] = (int)(f >> 3);
+            idx = (int)(f & 7u);
+        }
+        for (int zz = 0; zz < 64; zz++) {
+            const int nat = kZigzagNat[zz];
+            res[nat] = (int16_t)lanes_value(d[nat] / q[nat], kind[zz], zz == 0);
+        }
+    }
+}
+
 // (a lane's scratch: the sink of the flat walks in the single-pass kernels)
 struct EmuLaneSink {
     uint32_t *words;

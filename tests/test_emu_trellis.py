@@ -15,11 +15,13 @@ def _both(dct, q):
     L = E.lib()
     got = np.zeros((n, 64), np.int16)
     fast = np.ones((n, 64), np.int16)
-    for fn, dst in ((L.emu_trellis, got), (L.emu_trellis_fast, fast)):
+    lanes = np.full((n, 64), 2, np.int16)
+    for fn, dst in ((L.emu_trellis, got), (L.emu_trellis_fast, fast), (L.emu_trellis_lanes, lanes)):
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         fn.restype = None
         fn(dct.ctypes.data, q.ctypes.data, n, dst.ctypes.data)
     assert np.array_equal(got, fast)  # reference-shaped search == register-resident restatement
+    assert np.array_equal(got, lanes)  # ... == the eight-lane form's per-lane functions (round 5), exchanges as loops
     OL = O.lib()
     OL.po_trellis_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     OL.po_trellis_quantize.restype = None

@@ -418,6 +418,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         if (last_round && tid == 0) store_relaxed(&desc2[g], kFlagAggregate | (uint64_t)(ff_group + round_ff));
         if (wbase == 0) {
             if (wave == 0) { // (look_back_blocks' two levels; the block's sum is published below, when this group's own count is complete)
+                int lane2 = lane; // (a value of this place: see look_back_blocks)
+                asm volatile("" : "+v"(lane2));
+#undef lane
+#define lane lane2
                 const uint64_t rel_g = g, kblk = rel_g >> 6;
                 const uint32_t in_block = (uint32_t)(rel_g & 63);
                 const uint64_t block_first = kblk << 6;
@@ -456,6 +460,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                     s_before = before2;
                     s_front2 = front;
                 }
+#undef lane
+#define lane lane_again
             }
             __syncthreads();
             if (uni(s_abort)) { aborted = true; return; }

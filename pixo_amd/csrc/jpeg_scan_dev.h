@@ -144,7 +144,11 @@ __device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t
 __device__ __forceinline__ uint64_t look_back_blocks(unsigned long long *desc, unsigned long long *sup, uint64_t g, uint64_t floor, uint64_t aggregate,
                                                      unsigned long long *abort_flag, unsigned long long *host_abort, uint32_t budget)
 {
-    const int lane = threadIdx.x & 63;
+    // (the lane as a value of THIS call: the two 64-bit addresses a lane reads from are then computed here — as expressions of the
+    // kernel's lane index they are loop invariants of whatever encloses the call, get hoisted, live across the callers' walks and
+    // end in scratch memory: 7 of the 8 spilled dwords of pixels_code_kernel, 11 MB of scratch writes a launch)
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
     const uint64_t rel = g - floor, k = rel >> 6;
     const uint32_t in_block = (uint32_t)(rel & 63);
     const uint64_t block_first = floor + (k << 6);

@@ -131,6 +131,8 @@ struct Context {
     Buf e_pc_state;                  // the fused pixel -> scan kernel (jpeg_pixels_code.hip): TWO state blocks that alternate — a launch zeroes the
     size_t pc_half_words = 0;        //   block of the launch before it (words per block; 0: nothing is known to be zero)
     int pc_flip = 0;                 //   which block the next launch uses
+    Buf e_pc_spill;                  //   where a group of several 6 KiB rounds parks its quantised blocks between the rounds' walks (a buffer of its
+                                     //   own: growing d_coef here would free the tuple a caller's retry path still points into)
     Buf e_chain;                     // a scan coded in pieces: bits / bytes of the scan before every piece (device_entropy_pieces)
     Buf e_seams;                     // batch files that stay in HBM: their offsets + the header bytes for batch_seams_kernel
     Buf e_segs;                      // segmented scans (batches, restart intervals): per-segment results of the single-pass kernels

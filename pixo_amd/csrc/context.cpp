@@ -185,7 +185,7 @@ namespace {
 template <class F> void each_buf(Context &c, F &&f)
 {
     Context::Buf *bufs[] = {&c.e_tables, &c.e_hist, &c.e_count, &c.e_len, &c.e_off, &c.e_tmp, &c.e_totals, &c.e_stream, &c.e_tile_ff, &c.e_tile_base,
-                            &c.e_out, &c.e_seg_bytes, &c.e_seg_off, &c.e_code_state, &c.e_stuff_state, &c.e_pc_state, &c.e_chain, &c.e_segs, &c.e_seams, &c.p_in, &c.p_out,
+                            &c.e_out, &c.e_seg_bytes, &c.e_seg_off, &c.e_code_state, &c.e_stuff_state, &c.e_pc_state, &c.e_pc_spill, &c.e_chain, &c.e_segs, &c.e_seams, &c.p_in, &c.p_out,
                             &c.p_sums, &c.p_scratch, &c.t_raw, &c.t_trail, &c.t_plain, &c.g_flags, &c.g_rank, &c.g_by_rank};
     for (Context::Buf *b : bufs) f(*b);
 }

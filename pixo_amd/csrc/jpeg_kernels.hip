@@ -7,6 +7,8 @@
 // 4:2:0 image (8 per CU, all resident at once).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 
 #include "jpeg_kernels.hpp"
 #include "jpeg_tile.h"
@@ -217,9 +219,29 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     }
 }
 
-static int g_coef_form = 0; // (set before any launch, by the debug switches: tools and tests)
-void set_coef_form(int form) { g_coef_form = form; }
-bool packed_launch(uint64_t workgroups) { return g_coef_form == 1 ? false : (g_coef_form == 2 ? true : workgroups > 2048); }
+// (a debug switch of tools and tests — pixo_hip_debug_configure may flip it while other threads launch: a relaxed atomic)
+static std::atomic<int> g_coef_form{0};
+void set_coef_form(int form) { g_coef_form.store(form, std::memory_order_relaxed); }
+bool packed_launch(uint64_t workgroups)
+{
+    const int form = g_coef_form.load(std::memory_order_relaxed);
+    return form == 1 ? false : (form == 2 ? true : workgroups > 2048);
+}
+
+// The late start of dispatch numbers 1024..2047 assumes that 2048 workgroups are ONE resident generation: the whole MI355X
+// (256 CUs x 8 workgroups).  A partitioned device (CPX / a compute partition with fewer CUs) holds fewer: no stagger there.
+bool whole_chip_device()
+{
+    static std::atomic<int> cus[64]; // 0: not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = -1;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n == 256;
+}
 
 template <int MODE, int LOAD> static hipError_t launch_mode(KArgs &a, hipStream_t s)
 {
@@ -233,7 +255,7 @@ template <int MODE, int LOAD> static hipError_t launch_mode(KArgs &a, hipStream_
     rest.units_x = a.units_x; rest.units_y = a.units_y; rest.fast = a.fast;
     // tiles_x <= 128 (65535 / 512), tiles_y <= 8192 (65535 / 8)
     // (launches of 1280-1792 workgroups neither gain nor lose with it: tools/shape_timing.py, profiles/r03_stagger_length_ab.txt)
-    const uint32_t a_grid = grid.x | (grid.y << 8) | ((uint64_t)grid.x * grid.y * grid.z >= 2048u ? 0x80000000u : 0u);
+    const uint32_t a_grid = grid.x | (grid.y << 8) | (((uint64_t)grid.x * grid.y * grid.z >= 2048u && whole_chip_device()) ? 0x80000000u : 0u);
     // one generation of workgroups (at most 2048: all resident at once): the scalar forms of the DCT passes and the quantiser;
     // more: the packed forms (jpeg_tile.h, block_rows)
     const bool packed = packed_launch((uint64_t)grid.x * grid.y * grid.z);

@@ -13,6 +13,8 @@
 // ALU work: ~700 VALU instructions per coefficient position.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "jpeg_trellis.h"
 #include "jpeg_trellis.hpp"
 
@@ -189,14 +191,15 @@ __global__ __launch_bounds__(64) void trellis_lanes_kernel(const float *raw, con
 
 size_t trellis_scratch_bytes(uint64_t nblocks) { return (size_t)((nblocks + 63) / 64) * 63 * 64 * 8; }
 
-static int g_trellis_form = 0; // (measurements and tests: PIXO_HIP_DEBUG trellis_form=lane|group)
-void set_trellis_form(int form) { g_trellis_form = form; }
+static std::atomic<int> g_trellis_form{0}; // (measurements and tests: PIXO_HIP_DEBUG trellis_form=lane|group; may be flipped while other threads launch)
+void set_trellis_form(int form) { g_trellis_form.store(form, std::memory_order_relaxed); }
 hipError_t launch_trellis(const float *d_raw, const float *d_q_luma, const float *d_q_chroma, int16_t *d_out, uint64_t nblocks,
                           uint64_t nluma, void *d_scratch, hipStream_t s)
 {
     if (nblocks == 0) return hipSuccess;
     // eight lanes per block while the one-lane form's wavefronts (64 blocks each) would leave SIMDs idle anyway
-    const bool lanes = g_trellis_form == 2 || (g_trellis_form == 0 && nblocks <= kTrellisLanesBlocks);
+    const int form = g_trellis_form.load(std::memory_order_relaxed);
+    const bool lanes = form == 2 || (form == 0 && nblocks <= kTrellisLanesBlocks);
     if (lanes)
         hipLaunchKernelGGL(trellis_lanes_kernel, dim3((unsigned)((nblocks + kGroupsPerWave - 1) / kGroupsPerWave)), dim3(64), 0, s, d_raw, d_q_luma,
                            d_q_chroma, d_out, nblocks, nluma);

@@ -14,6 +14,7 @@
 // written once: no intermediate in HBM.  Byte work bounded by HBM and VALU issue; no MFMA.
 #include <hip/hip_runtime.h>
 
+#include "jpeg_kernels.hpp"
 #include "png_filter.hpp"
 #include "png_filter_math.h"
 
@@ -130,6 +131,7 @@ struct Args {
     int strategy;
     uint32_t stage_bytes; // dynamic LDS for the staged write-out, 0 = rows too long: direct stores
     uint32_t bitmap_off;  // Bigrams: byte offset of the 8 KiB "pair seen" bitmap inside the dynamic LDS
+    uint32_t late_half;   // the second thousand of a launch's workgroups starts late (a whole MI355X holds 2048 at once: launch_png_filter_rows)
 };
 
 // Pass 2 for filter F.  The output row starts at byte y * (n + 1) of the stream — a different
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(KIND == K_REGS512 ? 2 * kThreads : kThreads) void p
     // The chip holds 2048 of these workgroups (8 per CU): the first generation of a tall image loads all at once, scores all
     // at once, stores all at once.  Its second half starts one s_sleep (~3.4 us) late: 42.9 -> 40.8 us for the 4096-row image
     // (two sleeps 41.6, four 43.0, graded quarters 41.6-44.5; profiles/r03_png_stagger_ab.txt).
-    if (KIND == K_REGS && nb >= 2048u && (y >> 10) == 1u) __builtin_amdgcn_s_sleep(127);
+    if (KIND == K_REGS && a.late_half && nb >= 2048u && (y >> 10) == 1u) __builtin_amdgcn_s_sleep(127);
     if (y < full) { const uint32_t xcd = y & 7u, i = y >> 3; y = (((i >> 5) * 8u + xcd) << 5) + (i & 31u); }
     y += a.first_row;
     const int n = (int)a.row_bytes; // < 2^31 (checked by the launcher)
@@ -595,6 +597,7 @@ hipError_t launch_png_filter_rows(const void *d_data, uint32_t width, uint32_t h
     a.stage_bytes = stage <= 48 * 1024 ? (uint32_t)stage : 0u;
     a.bitmap_off = a.stage_bytes;
     a.forced = nullptr; a.winner0 = nullptr; a.first_row = 0;
+    a.late_half = (rows >= 2048u && whole_chip_device()) ? 1u : 0u;
     const bool fast = reinterpret_cast<uintptr_t>(d_data) % 4 == 0 && a.row_bytes % 4 == 0;
     if (strategy == PNG_S_ADAPTIVE_FAST && sequential_fast && height > 1) {
         // sequential AdaptiveFast (filter.rs:147-167): the first row's winner (always Sub, Up or

@@ -345,8 +345,9 @@ int scan_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const p
         c.pc_half_words = words;
         c.pc_flip = 0;
     }
-    // groups of several 6 KiB rounds park their blocks in the space of the tuple this path never writes (jpeg_pixels_code.hip)
-    if ((rc = c.reserve_coef(static_cast<size_t>(groups) * 192 * 128))) return rc;
+    // groups of several 6 KiB rounds park their blocks here (jpeg_pixels_code.hip).  NOT in d_coef: the tuple pointers the caller
+    // derived from it must stay valid for the multi-pass retry, and a hipFree would synchronise the device in the middle of the call
+    HIP_TRY(c.e_pc_spill.reserve(static_cast<size_t>(groups) * 192 * 128));
     size_t want_cap = std::max<size_t>(j.stream_cap / 4, 4096);
     for (int attempt = 0;; ++attempt) {
         uint8_t *out = nullptr;
@@ -370,7 +371,7 @@ int scan_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const p
         c.pc_flip ^= 1;
         HIP_TRY(pd::launch_pixels_code(d_pixels, o.width, o.height, g.s420, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c.e_tables.as<uint32_t>(),
                                        mine, /*state_is_zero=*/true, other, words, out, out_cap, reinterpret_cast<unsigned long long *>(c.h_totals), nullptr, true,
-                                       c.d_coef, stream, debug().spin_budget));
+                                       c.e_pc_spill.p, stream, debug().spin_budget));
         if (!wait) return PIXO_OK;
         HIP_TRY(hipStreamSynchronize(stream));
         if (c.h_totals[3]) { c.pc_half_words = 0; return scan_retry_multipass(c); } // (both blocks are memset before the next use)

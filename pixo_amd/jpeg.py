@@ -409,12 +409,23 @@ def encode_batch_multi(arena, pixels, options: JpegOptions, batch: int, devices)
         ptr, cap = arena.data_ptr(), arena.numel()
     else:
         ptr, cap = arena.ctypes.data, arena.size
+    # (the C entry takes no length: it reads batch * image_bytes from the pointer — whatever carries a size is checked here)
+    bpp = {int(ColorType.Gray): 1, int(ColorType.Rgb): 3}.get(int(options.color_type))
+    need = batch * options.width * options.height * bpp if bpp else None
     if hasattr(pixels, "data_ptr"):
+        have = pixels.numel() * pixels.element_size()
         src = pixels.data_ptr()
     elif isinstance(pixels, np.ndarray):
-        src = _as_u8(pixels).ctypes.data
+        pixels = _as_u8(pixels)
+        have = pixels.size
+        src = pixels.ctypes.data
     else:
+        have = None
         src = int(pixels)
+    if need is not None and have is not None and have != need:
+        raise error.InvalidDataLength("Invalid pixel data length: expected %d bytes, got %d" % (need, have))
+    if len(devices) == 0:
+        raise error.CompressionError("Compression error: encode_batch_multi: no device listed")
     devs = (C.c_int * len(devices))(*[int(d) for d in devices])
     oc = options._c()
     rc = L.pixo_hip_jpeg_encode_batch_multi(src, C.byref(oc), batch, devs, len(devices), ptr, cap, offsets, lens)

@@ -231,6 +231,15 @@ pub mod jpeg {
     pub fn encode_batch_on_devices(images: &[u8], options: &JpegOptions, batch: u32, devices: &[i32]) -> Result<(Vec<u8>, Vec<usize>)> {
         let c = to_c(options);
         let n = batch as usize;
+        // The C entry takes no length (it reads batch * image_bytes from the pointer): check here what `encode` lets the C side
+        // check, so that a safe caller cannot make it read beyond the slice.
+        let image_bytes = options.width as usize * options.height as usize * options.color_type.bytes_per_pixel();
+        if images.len() != n * image_bytes {
+            return Err(Error::InvalidDataLength { expected: n * image_bytes, actual: images.len() });
+        }
+        if devices.is_empty() {
+            return Err(Error::CompressionError("encode_batch_on_devices: no device listed".to_string()));
+        }
         let (mut offsets, mut lens) = (vec![0usize; n], vec![0usize; n]);
         let mut arena = Vec::<u8>::with_capacity(images.len() / 4 + 4096);
         for _ in 0..2 {

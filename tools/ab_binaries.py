@@ -39,7 +39,7 @@ def main():
             p, _, sw = p.partition("@")  # name=path.so@debug switches (a COPY of the library per set of switches: one state per dlopen'ed file)
             libs.append((n, os.path.join(ROOT, p) if not os.path.isabs(p) else p, sw))
     if not libs:
-        libs = [("r03", os.path.join(ROOT, "pixo_amd/ab_r03.so"), ""), ("r04", os.path.join(ROOT, "pixo_amd/ab_r04.so"), ""),
+        libs = [("r03", os.path.join(ROOT, "tools/ab/ab_r03.so"), ""), ("r04", os.path.join(ROOT, "tools/ab/ab_r04.so"), ""),
                 ("r05", os.path.join(ROOT, "pixo_amd/libpixo_hip.so"), "")]
     from pixo_amd import _lib
     _lib._preload_process_hip_runtime()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Device time per baseline file (pixo_hip_debug_scan_device_async: the product's kernels, no waits, no PCIe), 4096x4096 q=80
 4:2:0, for noise / photo / gradient content; HIP events on the launch stream, median of 7 blocks of 50 files.
-    [PIXO_HIP_LIB=pixo_amd/ab_x.so] python tools/device_time.py [two]     (`two`: debug switch two_kernel_scan)"""
+    [PIXO_HIP_LIB=tools/ab/ab_x.so] python tools/device_time.py [two]     (`two`: debug switch two_kernel_scan)"""
 import os
 import statistics
 import sys

@@ -7,7 +7,7 @@
 #   tests [pytest args]       python -m pytest -m gpu -x -q <args or tests/>
 #   bench [bench.py args]     one bench line (summary + the raw line in bench_line.json)
 #   ab <workload> <reps> <variant>...   bench.py --no-extras per variant: "base" = the in-tree library, anything else =
-#                             pixo_amd/ab_<variant>.so (built by tools/ab_build.sh); prints ms_per_step / kernel_us / frac
+#                             tools/ab/ab_<variant>.so (built by tools/ab_build.sh); prints ms_per_step / kernel_us / frac
 #   kstats <name> <cmd...>    rocprofv3 --kernel-trace --stats of <cmd>, the kernel_stats csv copied to <tag>/<name>_kernel_stats.csv
 #   pmc <name> <filter> <cmd...>   separate rocprofv3 --pmc passes (tools/pmc_summary.py on kernels matching <filter>)
 #   issue <name> <filter> <cmd...> one PMC pass -> issue_<name>.json: VALU-busy fraction of the kernel (tools/issue_profile.py)
@@ -40,7 +40,7 @@ recipe_ab() {
   wl="$1"; reps="$2"; shift 2
   for rep in $(seq 1 "$reps"); do
     for v in "$@"; do
-      lib=""; [ "$v" != base ] && lib="$ROOT/pixo_amd/ab_$v.so"
+      lib=""; [ "$v" != base ] && lib="$ROOT/tools/ab/ab_$v.so"
       PIXO_HIP_LIB=$lib timeout 300 python3 bench.py --workload "$wl" --no-cpu-baseline --no-extras 2>/dev/null | grep '^{' | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$wl $v rep$rep ms_per_step', d['ms_per_step'], 'min', d.get('ms_per_step_min'), 'kernel_us', d['roofline']['kernel_us_avg'], 'frac', d['roofline']['frac'])"

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Timeline of ONE dispatch of the coefficient kernel from per-wavefront time stamps (timeline build of the library:
-tools/ab_build.sh probe "-DPIXO_PROBE", selected with PIXO_HIP_LIB=pixo_amd/ab_probe.so; never the shipped library).
+tools/ab_build.sh probe "-DPIXO_PROBE", selected with PIXO_HIP_LIB=tools/ab/ab_probe.so; never the shipped library).
 
 rocprofv3's thread trace (--att) cannot be decoded in this image (no rocprof-trace-decoder library), so the kernel
 stamps the 100 MHz constant clock (s_memrealtime, one counter for all XCDs, 10 ns resolution) at eight points per
 wavefront:  0 wavefront runs | 1 first work item arrived + converted | 2 last item converted | 3 barrier passed |
 4 transform done | 5 quantised (first store next) | 6 last store issued | 7 stores acknowledged.
 
-    PIXO_HIP_LIB=$PWD/pixo_amd/ab_probe.so python tools/probe_timeline.py [workload] [extra kernel variant label]
+    PIXO_HIP_LIB=$PWD/tools/ab/ab_probe.so python tools/probe_timeline.py [workload] [extra kernel variant label]
 """
 import ctypes as C
 import os

@@ -1,4 +1,4 @@
-"""One-off (experiment build -DPIXO_TIMELINE of jpeg_scan_fused.hip, PIXO_HIP_LIB=pixo_amd/ab_timeline.so): where the time of
+"""One-off (experiment build -DPIXO_TIMELINE of jpeg_scan_fused.hip, PIXO_HIP_LIB=tools/ab/ab_timeline.so): where the time of
 one baseline `scan_code` launch goes.  Every group stamps the 100 MHz constant clock at: 0 entry, 1 blocks + tables in (first
 barrier), 2 walk + length scan done (second barrier), 3 bits gathered into the LDS buffer, look-back starts, 4 look-back done
 (barrier), 5 bits written, 6 shared head word resolved.  Printed: per stamp the time since the launch's first stamp, as

@@ -369,6 +369,11 @@ int pixo_hip_debug_stream_copy(const void *d_in, void *d_out, size_t bytes, void
  * two events on `stream` = the device time per file without the call's waits and the file's way over PCIe.  The caller
  * synchronises the stream before it calls anything else of this library on the same thread. */
 int pixo_hip_debug_scan_device_async(const void *d_pixels, const pixo_jpeg_options *options, void *stream, int *form);
+/* ... the same for `batch` equally sized images back to back in device memory (configs[2]: 64 x 1920x1080) — the device work of
+ * pixo_hip_jpeg_encode_batch_device[_into]'s one-pass form, the scans left in the context's device buffer at their files'
+ * spacing: ONE launch of the fused kernel with every image a segment (*form = 1), or coefficient kernel + scan_code + stuffing
+ * kernel over the batch (*form = 0).  batch = 1 is the entry above. */
+int pixo_hip_debug_scan_device_async_batch(const void *d_pixels, const pixo_jpeg_options *options, uint32_t batch, void *stream, int *form);
 /* Releases a buffer the library returned.  Blocks of 24 MiB and more are kept (at most two, 1 GiB) for the next large
  * file instead of going back to the system — their pages are resident, a fresh block of that size costs more than the
  * encode (profiles/r03_fresh_pages.txt); pixo_hip_trim() returns them. */

@@ -256,6 +256,7 @@ struct ScanJob {
     int head_bits = 0;       // band: how many of its first bits share a byte with the band before
     bool fused = false;      // one uninterrupted scan: the two single-pass kernels of jpeg_scan_fused.hip
     bool segmented = false;  // byte-aligned segments (images of a batch, restart intervals) in the single-pass kernels
+    bool pc_seg = false;     // ... coded as segments of the fused pixel -> scan kernel (scan_from_pixels): c.h_segs, seg.marker_bytes as for `segmented`
     pixo_dev::SegArgs seg;   // ... their geometry and per-segment arrays (c.e_segs, c.h_segs)
     uint32_t seg_gap = 0;    // set BEFORE scan_begin: bytes a batch wants left free between its images' scans in c.e_out
                              // (headers + EOI: the whole batch then leaves the device in one copy); honoured only by segmented jobs
@@ -296,7 +297,7 @@ bool pixels_code_usable(const ScanJob &j, const pixo_jpeg_options &o, const pixo
 // that the GPU can write — and j.scan_bytes / j.total_bits / j.nbytes say how long it is.  No tuple, no packed stream is written.
 // wait = false: only enqueued (measurements); the totals are then in c.h_totals[0..2] once the stream has been synchronised.
 int scan_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream, const void *d_pixels,
-                     HostTarget *host, bool wait = true);
+                     HostTarget *host, bool wait = true, uint32_t batch = 1);
 int scan_stuff_fused(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offset, uint32_t *head, int *tail_bits,
                      uint32_t *tail, bool chained = false, HostTarget *host = nullptr);
 int scan_pack(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offset = 0, uint32_t *head = nullptr,

@@ -395,11 +395,12 @@ int batch_on_device(Context &c, const void *d_pixels, const pixo_jpeg_options &o
     const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128 * batch;
     if ((rc = c.reserve_coef(coef_bytes))) return rc;
     int16_t *dy = static_cast<int16_t *>(c.d_coef), *dcb = dy + g.y_blocks * 64 * batch, *dcr = dcb + g.c_blocks * 64 * batch;
-    HIP_TRY(pixo_dev::launch_jpeg_coeffs(d_pixels, o.width, o.height, g.gray, g.s420, batch, dy, g.gray ? nullptr : dcb,
-                                         g.gray ? nullptr : dcr, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c.stream));
+    // (round 6: the entropy stage gets the PIXELS — an RGB batch goes through the fused pixel -> scan kernel, every image a segment,
+    // and never writes the tuple; otherwise the stage launches the coefficient kernel over the batch itself)
+    const PixelSource src{d_pixels, &o, &g, dy, dcb, dcr};
     const uint8_t *unused = nullptr;
     size_t scan_bytes = 0;
-    return device_entropy_to_pinned(c, dy, dcb, dcr, o, g, c.stream, &unused, &scan_bytes, batch, &starts, nullptr, nullptr, 0, nullptr, nullptr, &head,
+    return device_entropy_to_pinned(c, dy, dcb, dcr, o, g, c.stream, &unused, &scan_bytes, batch, &starts, nullptr, nullptr, 0, nullptr, &src, &head,
                                     gap, gaps);
 }
 bool batch_in_one_pass(const pixo_jpeg_options &o, const pixo_host::Geometry &g, uint32_t batch, size_t px_bytes)

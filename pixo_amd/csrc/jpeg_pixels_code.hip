@@ -1,11 +1,20 @@
-// jpeg_pixels_code.hip — pixels -> packed entropy-coded bit stream in ONE kernel (round 5): what the reference's
-// baseline encode_scan does per MCU (src/jpeg/mod.rs:1448-1557: extract -> dct_2d -> quantize_block -> encode_block),
-// without ever materialising the coefficient tuple.  jpeg_coeffs_kernel + scan_code_kernel wrote 3 B/px of coefficients
-// to HBM and read them back; here a tile's quantised blocks go from phase B's registers straight into the flat walk.
+// jpeg_pixels_code.hip — pixels -> the finished, 0xFF-stuffed entropy-coded scan in ONE kernel: what the reference's
+// baseline encode_scan does per MCU (src/jpeg/mod.rs:1408-1563: extract -> dct_2d -> quantize_block -> encode_block ->
+// BitWriterMsb), without ever materialising the coefficient tuple or a packed bit stream in HBM.
 //
 // One 192-thread workgroup = one 512-pixel-wide tile = one GROUP of the scan: 32 MCUs of 4:2:0 (512x16 px) or 64 MCUs of
 // 4:4:4 (512x8 px) — 192 blocks that are CONSECUTIVE in scan order (tiles of a row from left to right, rows from top to
-// bottom; a row's last tile may hold fewer MCUs).  Group id g = tile_y * tiles_x + tile_x.
+// bottom; a row's last tile may hold fewer MCUs).  Grid (tiles_x, tiles_y, images); ticket g = (image * tiles_y + tile_y) *
+// tiles_x + tile_x.
+//
+// SEGMENTS (round 6 — encode_scan's whole surface but gray): a launch codes `images` x `segments per image` byte-aligned scans,
+// each a chain of its own — DC predictors from 0, 1-padded end (BitWriterMsb::flush), look-back floor at its first group:
+//   * the images of a batch (configs[2]): one segment per image, `gap` bytes left free between two scans for EOI + the next
+//     file's headers (the batch then leaves the device in one copy);
+//   * restart intervals that are whole MCU rows (src/jpeg/mod.rs:1423-1445 with interval = k * MCUs per row): a segment per k
+//     tile rows, the two gap bytes receive FF D0+(n & 7) from the segment's last group.
+// Where a segment's bytes begin: a decoupled look-back over the SEGMENTS' byte counts (+ gap), which every segment's last group
+// publishes as soon as it knows its own — before it asks where its segment begins, so that the counts do not wait for each other.
 //
 //   phase A, phase B      exactly jpeg_coeffs_kernel's (jpeg_tile.h): pixels -> planar LDS -> one lane per 8x8 block,
 //                         f32 AAN rows + columns, quantiser -> the block as 32 registers of i16 pairs (natural order)
@@ -17,17 +26,27 @@
 //                         is coded AFTER the walk (dc_symbol_bits) and placed in front of the AC bits when the group's bits
 //                         are gathered: no lane waits for a neighbour tile before its 63-position walk is done
 //   prefix                lengths scattered to scan order in LDS, three wavefront scans, exclusive prefixes gathered back
-//   place + write-out     scan_code_kernel's: group aggregate published, bits OR-ed into the group's LDS window at
-//                         group-relative offsets, two-level reduce-then-scan look-back (look_back_blocks), funnel-shifted
-//                         coalesced stores, the word two groups share handed on through a tail descriptor
+//   place + write-out     the group's bit count published, its bits OR-ed into the group's 6 KiB LDS window at group-relative
+//                         offsets, two-level reduce-then-scan look-back over the bit counts (look_back_blocks) -> the group's
+//                         first bit S; its last seven bits go out for the group behind as soon as the window is complete
+//   stuff + store         the group OWNS the scan's bytes [S / 8, E / 8): aligned words funnelled by S mod 8, 0xFF census,
+//                         wavefront scans, the group's 0xFF count published and a second two-level look-back for the stuffed
+//                         zeros before the group, bytes expanded in LDS (the gaps ARE the stuffed zeros, src/bits.rs:245-253),
+//                         aligned 16-byte stores into the device buffer or straight into the caller's pinned memory
+// (Round 6 built and measured ONE look-back instead of the two: a run of eight 1-bits found at every bit position of the window —
+// three and-shift steps —, counted per position mod 8, every group publishing bit count + 0xFF counts for all eight alignments of
+// its first bit + its first and last seven bits in 24 bytes, blocks of 64 groups their sums for all eight alignments in 40.
+// Byte-identical on the whole GPU suite — and 6-7 us SLOWER per 4096x4096 file: with every group of the launch arriving at its
+// look-back together, the 8 descriptor loads a lane cost more than the second round trip saves:
+// profiles/r06_pixels_code_one_lookback.txt.  The two cheap look-backs stay.)
 //
-// The packed stream, its length (state[1], host_totals[0]) and the abort protocol are scan_code_kernel's, so the stuffing
-// kernel (stuff_fused_kernel) follows unchanged.  LDS: the planar tile (16,896 B) is dead after phase B and becomes
-// scratch (192 x 13 words) + window (1536 + 192 words) = 16,896 B; + 2.2 KiB of tables: 8 workgroups per CU as before.
+// LDS: the planar tile (16,896 B) is dead after phase B and becomes scratch (192 x 13 words) + window (1536 + 192 words)
+// = 16,896 B; + 2.2 KiB of tables: 8 workgroups per CU as before.
 //
-// Serves one whole RGB image, 4:2:0 or 4:4:4, one uninterrupted scan with GIVEN tables (standard ones): gray images,
-// restart intervals, batches, bands and optimised tables (which need the statistics of the tuple first) keep the two-kernel
-// form.  Forward progress: like scan_code_kernel a group waits only for LOWER group ids (file header of
+// Not served: gray images (a gray tile is three block rows — not a run of the scan order), optimised tables (the statistics
+// need the tuple first), restart intervals that are not whole MCU rows, bands of a multi-GPU image (a band's byte alignment
+// is only known after the bit-count exchange between the GPUs: its stuffing cannot be fused with its coding).  Those keep
+// coefficient kernel + scan_code + stuff_fused.  Forward progress: a group waits only for LOWER tickets (file header of
 // jpeg_scan_fused.hip); every wait is bounded and raises the abort flag.
 #include <hip/hip_runtime.h>
 
@@ -52,13 +71,20 @@ static_assert(Geo<M420>::planar <= kFusedLds && Geo<M444>::planar <= kFusedLds, 
 
 // what the kernel needs beyond its first (preloaded) arguments
 struct PRest {
-    size_t px_bytes;
-    unsigned long long *clear; // housekeeping for the stuffing launch that follows (its descriptors must be zero)
+    size_t px_bytes;           // all images
+    size_t px_stride;          // bytes from one image to the next
+    unsigned long long *clear; // housekeeping: the state block of the launch before this one (it must be zero when it is used again)
     uint32_t clear_words;
     unsigned long long *host_totals;
+    unsigned long long *host_segs; // [segments] (pinned, or null): where every segment's bytes end in `out`
     uint32_t spin_budget;
-    uint32_t tiles_x;
-    uint32_t groups;
+    uint32_t tiles_x, tiles_y;
+    uint32_t groups;            // all images
+    uint32_t seg_rows;          // tile rows per segment (tiles_y: an image is one segment)
+    uint32_t segs_per_img;
+    uint32_t seg_blocks64;      // blocks of 64 groups per segment (look-back level two)
+    uint32_t gap;               // bytes left free between two segments' scans
+    uint32_t rst;               // 1: gap == 2 and a segment's last group writes FF D0+(n & 7) there
     int16_t seed_dc[3];
     uint16_t pad_last;
     uint32_t out_skew;  // < 16: the bytes before it are somebody else's (the file headers when `out` is the caller's host buffer)
@@ -108,6 +134,13 @@ __device__ __forceinline__ void phase_a_tab(const TileCtx &c, uint32_t tx, uint3
     }
 }
 
+#ifdef PIXO_TIMELINE // (experiment builds only, tools/pixels_code_timeline.py: where a group's time goes; 100 MHz constant clock)
+__device__ unsigned long long g_pc_timeline[8192 * 16];
+#define PIXO_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 8192) g_pc_timeline[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PIXO_STAMP(k) do { } while (0)
+#endif
+
 template <int MODE, int LOAD, bool PACKED>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void pixels_code_kernel
 (const uint8_t *a_px, uint32_t a_W, uint32_t a_H, const float *a_qt, uint32_t a_units_x, uint32_t a_units_y, const uint32_t *a_tables,
@@ -119,16 +152,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     __shared__ uint32_t s_pos[kGroup];
     __shared__ int16_t s_dc[kGroup];
     __shared__ uint32_t wave_sum[kGroupWaves], wave_long[kGroupWaves];
-    __shared__ unsigned long long s_before;
+    __shared__ unsigned long long s_before, s_segbase;
     __shared__ uint32_t s_carry, s_abort, s_head, s_front2;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    PIXO_STAMP(0);
     __builtin_amdgcn_s_setprio(1); // phase A in front of the older workgroups' phase B (jpeg_kernels.hip)
-    const uint32_t tx = blockIdx.x, ty = blockIdx.y;
+    const uint32_t tx = blockIdx.x, ty = blockIdx.y, img = blockIdx.z;
     TileCtx c;
-    c.px = a_px; c.y = c.cb = c.cr = nullptr; c.qt = a_qt;
+    c.px = a_px + (size_t)img * rest.px_stride; c.y = c.cb = c.cr = nullptr; c.qt = a_qt;
     c.W = a_W; c.H = a_H; c.units_x = a_units_x; c.units_y = a_units_y; c.fast = 1;
     c.px_end = a_px + rest.px_bytes;
-    if (tid == 0) { s_carry = 0; s_abort = 0; s_head = 0; s_front2 = 0; }
+    if (tid == 0) { s_carry = 0; s_abort = 0; s_head = 0; s_front2 = 0; s_segbase = 0; }
     {
         constexpr int base = G::items / kWaves, extra = G::items % kWaves;
         const int first = (extra && wave < extra) ? wave * (base + 1) : extra * (base + 1) + (wave - extra) * base;
@@ -136,6 +170,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         else phase_a_tab<MODE, LOAD, base>(c, tx, ty, first, lane, tid, lds, a_tables + kTableWords, tab);
     }
     lds_only_barrier();
+    PIXO_STAMP(1);
     __builtin_amdgcn_s_setprio(0);
     uint32_t qw[32];
     {
@@ -144,6 +179,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         consumer_cols<PACKED>(v);
         consumer_quant<MODE, PACKED>(wave, lane, a_qt, v, qw);
     }
+    PIXO_STAMP(2);
     // ---- from here on: the group's part of the entropy-coded scan ----------------------------------------------------------
     // (the thread's coordinates again, opaque to the optimiser: whatever the second half derives from them is computed here and
     // does not occupy registers through phase B, which runs at the 80-register limit)
@@ -153,10 +189,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     const int lane_again = tid & 63, wave_again = __builtin_amdgcn_readfirstlane(tid >> 6);
 #define lane lane_again
 #define wave wave_again
-    const uint64_t ngroups = rest.groups, g = (uint64_t)ty * rest.tiles_x + tx;
-    unsigned long long *desc = a_state + 2, *tails = desc + ngroups, *dcw = tails + ngroups, *sup = dcw + 3 * ngroups;
+    // ticket, segment, place in the segment's chain
+    const uint32_t tiles_x = rest.tiles_x, tiles_y = rest.tiles_y;
+    const uint64_t ngroups = rest.groups, g = ((uint64_t)img * tiles_y + ty) * tiles_x + tx;
+    const uint32_t srow = rest.seg_rows >= tiles_y ? 0u : ty / rest.seg_rows;       // (wave-uniform)
+    const uint32_t seg = img * rest.segs_per_img + srow, nsegs = gridDim.z * rest.segs_per_img;
+    const uint32_t row0 = srow * rest.seg_rows;
+    const uint32_t rows_here = tiles_y - row0 < rest.seg_rows ? tiles_y - row0 : rest.seg_rows;
+    const uint32_t rel = (ty - row0) * tiles_x + tx, seg_groups = rows_here * tiles_x;
+    const uint64_t floor = g - rel;
+    const bool last_group = rel + 1 == seg_groups; // of its segment
+    // state: [0] abort flag, [1] total bits; per group: bit-count descriptor, tail, three DC words, 0xFF-count descriptor; per
+    // segment: two rows of block sums (one per 64 groups, + 1) and the segment's byte count / the offset of the next segment
+    const uint64_t sup_words = (uint64_t)nsegs * rest.seg_blocks64 + 1;
+    unsigned long long *desc = a_state + 2, *tails = desc + ngroups, *dcw = tails + ngroups, *desc2 = dcw + 3 * ngroups, *sups = desc2 + ngroups,
+                       *sups2 = sups + sup_words, *segdesc = sups2 + sup_words;
+    unsigned long long *SUP = sups + (uint64_t)seg * rest.seg_blocks64, *SUP2 = sups2 + (uint64_t)seg * rest.seg_blocks64;
     unsigned long long *const host_abort = rest.host_totals ? rest.host_totals + 3 : nullptr;
-    // (housekeeping for the kernel that follows: its descriptors must be zero when it starts — cheaper here than a memset launch)
+    // (housekeeping: the state block of the launch before this one must be zero when it is used again — cheaper here than a memset launch)
     for (uint64_t i = g * kGroup + tid; i < rest.clear_words; i += ngroups * kGroup) rest.clear[i] = 0;
     // which block of the scan this lane holds: MCU m of the tile, component, position among the group's 192 blocks
     const uint32_t u0 = tx * (uint32_t)G::units_x;
@@ -174,16 +224,19 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     const int dc = (int)(int16_t)(uint16_t)(qw[0] & 0xFFFFu);
     s_dc[sidx] = (int16_t)dc;
     // the tile's last block of each component: what the next tile's first block predicts from (jpeg/mod.rs:1417-1419)
-    if (m + 1 == nvalid && last_block_of_mcu_comp) store_relaxed(&dcw[comp * ngroups + g], kDcValid | (uint64_t)(uint16_t)dc);
+    if (m + 1 == nvalid && last_block_of_mcu_comp && !last_group) store_relaxed(&dcw[comp * ngroups + g], kDcValid | (uint64_t)(uint16_t)dc);
     __syncthreads(); // every wavefront has consumed its planar rows (the area becomes scratch + window), s_dc is complete
     // DC predictor: the previous block of the same component.  Inside the tile: from LDS; the tile's first block of a
-    // component: the tile before (after the walk, below), or the seed for the image's first tile
+    // component: the tile before (after the walk, below); a segment's first tile: zero (the launch's first: the seed)
     const bool external = m == 0 && first_of_comp;
     const uint32_t back = MODE == M420 ? (comp == 0 ? (first_of_comp ? 3u : 1u) : 6u) : 3u;
-    int prev_dc = external ? (int)rest.seed_dc[comp] : (int)s_dc[sidx - back];
-    // ---- the walk: 63 AC positions + end-of-block from bit 0 of the lane's scratch; where the packer stands is the length
+    int prev_dc = external ? (seg == 0 ? (int)rest.seed_dc[comp] : 0) : (int)s_dc[sidx - back];
     uint32_t *scratch = reinterpret_cast<uint32_t *>(lds);
     uint32_t *buf = scratch + kGroup * kScratchPitch;
+    // the window, zero: the gather ORs into it (behind the next barrier; the walk only touches the scratch in front of it)
+#pragma unroll
+    for (uint32_t i = 0; i < kWindowWords / kGroup; i++) buf[(uint32_t)tid + kGroup * i] = 0;
+    // ---- the walk: 63 AC positions + end-of-block from bit 0 of the lane's scratch; where the packer stands is the length
     uint32_t len_ac;
     {
         FlatPack<LaneSink> p;
@@ -193,7 +246,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         len_ac = p.word * 32u + p.pending;
         p.finish();
     }
-    if (external && g > 0) { // (at most three lanes of the group)
+    PIXO_STAMP(3);
+    if (external && rel > 0) { // (at most three lanes of the group)
         const unsigned long long *src = &dcw[comp * ngroups + g - 1];
         unsigned long long d = load_relaxed(src);
         uint32_t polls = 0;
@@ -228,23 +282,26 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     }
     group_bits = uni(group_bits); group_long = uni(group_long);
     s_pos[tid] = wave_base + (incl - mine);
-    if (tid == 0) publish_aggregate(desc, g, 0, group_bits);
+    if (tid == 0) publish_aggregate(desc, g, floor, group_bits);
     __syncthreads();
     const uint32_t my_bit = s_pos[sidx];
-    const bool last_group = g + 1 == ngroups;
+    PIXO_STAMP(4);
     // ---- place, stuff, write.  The group's bits go into the LDS window at GROUP-RELATIVE offsets (scan_code_kernel's gather, with
-    // the DC symbol in front of the AC words); a look-back over the groups' bit counts gives the group's first bit S in the
-    // scan; from there on everything is BYTES of the finished scan (round 5: stuff_fused_kernel's work happens here, the packed
-    // stream never exists in HBM):
-    //   * the group OWNS the scan's bytes [S / 8, E / 8) (E = S + its bits; the last group: up to the 1-padded end).  A first
+    // the DC symbol in front of the AC words); a look-back over the groups' bit counts gives the group's first bit S in its
+    // scan; from there on everything is BYTES of the finished scan (stuff_fused_kernel's work happens here, the packed stream
+    // never exists in HBM):
+    //   * the group OWNS the scan's bytes [S / 8, E / 8) (E = S + its bits; a segment's last group: up to the 1-padded end).  A first
     //     byte that began in the group before (S % 8 != 0) arrives as that group's `tail` — its last E' % 8 bits, which it
-    //     publishes as soon as it knows S', before it waits for anything else — and is completed here;
+    //     publishes as soon as its window is complete, before it waits for anything — and is completed here;
     //   * "aligned word" j of the group = its owned bytes 4 j .. 4 j + 3 = the window's words j - 1 and j funnelled by S % 8;
     //     thread (wave v, row k, lane l) takes aligned word 512 v + 64 k + l of the round — 0xFF census per word, wavefront
     //     scans row by row, the group's count published and a second look-back (both two-level, look_back_blocks' form) for
     //     the number of stuffed zeros before the group;
     //   * the bytes are expanded into an LDS stage at the output's 16-byte alignment — each moved up by the 0xFF bytes before
     //     it: the gaps ARE the stuffed zeros (BitWriterMsb, src/bits.rs:245-253) — and stored as aligned 16-byte pieces.
+    // (Round 6 measured ONE look-back instead — every group's 0xFF counts for all eight alignments of its first bit in a 24-byte
+    // descriptor, a predecessor's alignment from the running bit sum: byte-identical, and 6-7 us slower per 4096x4096 file: the
+    // 8 descriptor loads a lane cost more than the second round trip saves, profiles/r06_pixels_code_one_lookback.txt.)
     // The stage is the walk's scratch area (dead after the gather): a group of several rounds, whose later gathers would need the
     // scratch again, packs every round by a second walk straight into the window (the long-block path).
     constexpr uint32_t kWin = kWindowWords - 1; // group words per round: the round's aligned words (one more) are at most 3 x 512
@@ -253,16 +310,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     static_assert(kWindowWords == 3 * 64 * kRows, "three wavefronts x 8 rows of 64 aligned words");
     const uint32_t local_words = (group_bits + 31) >> 5; // >= 1: every block has bits
     const bool walk_into_window = group_long != 0 || local_words > kWin;
-    unsigned long long *desc2 = sup + ((ngroups + 63) >> 6) + 1, *sup2 = desc2 + ngroups;
     uint8_t *stage = lds;
-    uint8_t *const out = a_out; // 16-byte aligned; the scan's first byte goes to out[rest.out_skew]
-    uint64_t S = 0, ff_before_groups = 0;
+    uint8_t *const out = a_out; // 16-byte aligned; the launch's first scan byte goes to out[rest.out_skew]
+    uint64_t S = 0, ff_before_groups = 0, seg_base = 0;
     uint32_t nb_total = 0, sh8 = 0, pad_word = ~0u, pad_mask = 0, ff_group = 0, in_front2 = 0;
     bool aborted = false;
     // MULTI: a group of several rounds / with a very long block (rare: noise at q >= 90): the quantised block stays alive for the
     // second walks.  The common case is its own instantiation, in which the block's registers are dead after the first walk.
-    // (such a group parks its blocks in HBM — a slot per lane in the space reserved for the tuple this kernel never writes — and
-    // loads them again for every round's walk: the 32 registers are not alive through the byte stage of the common path)
+    // (such a group parks its blocks in HBM — a slot per lane — and loads them again for every round's walk: the 32 registers are
+    // not alive through the byte stage of the common path)
     uint32_t *const my_spill = rest.block_spill + ((size_t)g * kGroup + (size_t)tid) * 32u;
     uint32_t park = uni(walk_into_window ? 1u : 0u);
     asm volatile("" : "+s"(park)); // (not recognisable as the condition of the branch below: otherwise this store is moved into that branch
@@ -271,23 +327,30 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
 #pragma unroll
         for (int i = 0; i < 8; i++) *reinterpret_cast<v4u *>(my_spill + 4 * i) = v4u{qw[4 * i], qw[4 * i + 1], qw[4 * i + 2], qw[4 * i + 3]};
     }
+    // A segment's LAST group publishes the segment's byte count before it asks where the segment begins (the segments' counts then
+    // do not wait for each other); a last group of several rounds knows its count only at the end and asks first, like everybody else.
+    const bool seg_late = last_group && !park;
+    const uint32_t kblk = rel >> 6, in_block = rel & 63u; // the group's block of 64 inside its chain, its place in the block
     auto rounds = [&](auto multi_tag) __attribute__((always_inline)) {
     constexpr bool MULTI = decltype(multi_tag)::value;
     for (uint32_t wbase = 0; wbase < (MULTI ? local_words : 1u); wbase += kWin) {
         const uint32_t wn = MULTI ? (local_words - wbase < kWin ? local_words - wbase : kWin) : local_words;
-        for (uint32_t i = tid; i <= wn; i += kGroup) buf[i] = 0; // (word wn: read by the funnel of the round's last aligned word)
-        __syncthreads();
-        const int64_t rel = (int64_t)my_bit - (int64_t)wbase * 32;
+        if (MULTI && wbase) { // (the first round's window was zeroed before the walk)
+#pragma unroll
+            for (uint32_t i = 0; i < kWindowWords / kGroup; i++) buf[(uint32_t)tid + kGroup * i] = 0;
+            __syncthreads();
+        }
+        const int64_t rel_bit = (int64_t)my_bit - (int64_t)wbase * 32;
         const uint32_t dummy = kWindowWords + (uint32_t)tid;
         if (!MULTI) {
             { // the DC symbol (<= 27 bits at the top of db.left)
-                const uint32_t bsh = (uint32_t)(rel & 31), d = (uint32_t)(rel >> 5);
+                const uint32_t bsh = (uint32_t)(rel_bit & 31), d = (uint32_t)(rel_bit >> 5);
                 const uint32_t hi = live ? db.left >> bsh : 0u, lo = (live && bsh) ? db.left << (32 - bsh) : 0u;
                 (void)__hip_atomic_fetch_or(&buf[d < wn ? d : dummy], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 (void)__hip_atomic_fetch_or(&buf[d + 1 < wn ? d + 1 : dummy], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // every word of the lane's scratch, shifted to its place behind the DC symbol (two LDS ORs per word)
-            const int64_t rel_ac = rel + (int64_t)db.len;
+            const int64_t rel_ac = rel_bit + (int64_t)db.len;
             const uint32_t nw = live ? (len_ac + 31) >> 5 : 0u, bsh = (uint32_t)(rel_ac & 31);
             const uint32_t d0 = (uint32_t)(rel_ac >> 5);
 #pragma unroll
@@ -300,25 +363,26 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                                             __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        if (MULTI && PIXO_ANY64(live && rel < (int64_t)wn * 32 && rel + (int64_t)len > 0)) { // (some block of the wavefront lies in the window)
+        if (MULTI && PIXO_ANY64(live && rel_bit < (int64_t)wn * 32 && rel_bit + (int64_t)len > 0)) { // (some block of the wavefront lies in the window)
             uint32_t w[32]; // the lane's block again (its own stores: visible to it)
-            const uint32_t *back = my_spill;
-            asm volatile("" : "+v"(back) : : "memory"); // (a pointer the optimiser cannot see through: no forwarding of the stored registers, which would keep them alive)
+            const uint32_t *back_ptr = my_spill;
+            asm volatile("" : "+v"(back_ptr) : : "memory"); // (a pointer the optimiser cannot see through: no forwarding of the stored registers, which would keep them alive)
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const v4u q = *reinterpret_cast<const v4u *>(back + 4 * i);
+                const v4u q = *reinterpret_cast<const v4u *>(back_ptr + 4 * i);
                 w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
             }
             FlatPack<LdsSink> p;
             p.sink = LdsSink{buf, live ? wn : 0u, dummy};
             p.acc = 0;
-            p.pending = (uint32_t)(rel & 31);
-            p.word = (uint32_t)(rel >> 5);
+            p.pending = (uint32_t)(rel_bit & 31);
+            p.word = (uint32_t)(rel_bit >> 5);
             block_pack_flat(w, prev_dc, wtab, p);
             p.finish();
         }
         const bool last_round = !MULTI || wbase + wn == local_words;
-        __syncthreads(); // the round's window is complete
+        __syncthreads(); // the round's window is complete; the scratch is dead (it becomes the stage)
+        PIXO_STAMP(5);
         // The group's LAST SEVEN BITS for the group behind (its first byte may begin in this group): they do not depend on where
         // this group starts, so they go out at once — the group behind then finds them waiting instead of waiting for them.
         // (>= 12 bits per group: they are this group's own.)
@@ -329,14 +393,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             const uint64_t both = ((uint64_t)lo << 32) | hi;
             store_relaxed(&tails[g], kTailValid | (uint32_t)((both >> (32u - used)) & 0x7Fu));
         }
-        if (wbase == 0) { // where the group starts in the scan
+        if (wbase == 0) { // where the group starts in its scan
             if (wave == 0) {
-                const uint64_t sum = look_back_blocks(desc, sup, g, 0, group_bits, a_state, host_abort, rest.spin_budget);
+                const uint64_t sum = look_back_blocks(desc, SUP, g, floor, group_bits, a_state, host_abort, rest.spin_budget);
                 if (lane == 0) {
                     if (sum == kLookBackFailed) s_abort = 1;
                     s_before = sum;
                 }
-            } else if (tid == 128 && g > 0) { // meanwhile: the seven bits in front of this group (used if it starts inside a byte)
+            } else if (wave == 1 && seg > 0 && !seg_late) { // meanwhile: where this segment's bytes begin — a look-back over the SEGMENTS' byte counts
+                const uint64_t sb = look_back(segdesc, seg, 0, 0, a_state, host_abort, rest.spin_budget);
+                if (lane == 0) {
+                    if (sb == kLookBackFailed) s_abort = 1;
+                    s_segbase = sb;
+                }
+            } else if (tid == 128 && rel > 0) { // meanwhile: the seven bits in front of this group (used if it starts inside a byte)
                 unsigned long long t = load_relaxed(&tails[g - 1]);
                 uint32_t polls = 0;
                 while (!(t & kTailValid)) {
@@ -346,18 +416,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                 }
                 s_head = (uint32_t)t & 0x7Fu;
             }
+            // (the stage, zero — the scratch area is dead: a round that expands all its bytes at once needs no zeroing pass of its own)
+            for (uint32_t i = 16u * tid; i < kStageCap; i += 16u * kGroup) *reinterpret_cast<v4u *>(stage + i) = v4u{0, 0, 0, 0};
             __syncthreads();
+            PIXO_STAMP(6);
             if (uni(s_abort)) { aborted = true; return; }
             S = uni64(s_before);
+            seg_base = uni64(s_segbase);
             sh8 = (uint32_t)(S & 7);
             const uint64_t end_bits = (uint64_t)sh8 + group_bits; // in aligned bits: bit 0 = the first bit of the group's first owned byte
-            nb_total = (uint32_t)(last_group ? (end_bits + 7) >> 3 : end_bits >> 3);
-            if (last_group && (end_bits & 7)) { // BitWriterMsb::flush pads the last byte with 1-bits
+            const bool pad = last_group && rest.pad_last;
+            nb_total = (uint32_t)(pad ? (end_bits + 7) >> 3 : end_bits >> 3);
+            if (pad && (end_bits & 7)) { // BitWriterMsb::flush pads the last byte with 1-bits
                 const uint32_t n = 8u - (uint32_t)(end_bits & 7);
                 pad_word = (uint32_t)(end_bits >> 5);
                 pad_mask = ((1u << n) - 1u) << (32u - (uint32_t)(end_bits & 31) - n);
             }
         } else {
+            for (uint32_t i = 16u * tid; i < kStageCap; i += 16u * kGroup) *reinterpret_cast<v4u *>(stage + i) = v4u{0, 0, 0, 0};
             __syncthreads();
         }
         // ---- the round's aligned words: thread (wave, row k, lane) takes word 512 wave + 64 k + lane
@@ -384,8 +460,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             x[k] = aligned_word(jl, head_now);
             const uint32_t first_byte = 4u * (wbase + jl);
             const uint32_t exist = first_byte < limit ? (limit - first_byte < 4u ? limit - first_byte : 4u) : 0u;
-            const uint32_t m = (zero_byte_mask(~x[k]) >> 7) & 0x01010101u; // bits 24, 16, 8, 0 = bytes 0, 1, 2, 3 of the word (stream order)
-            const uint32_t m4 = ((m * 0x08040201u) >> 24) & ((1u << exist) - 1u);
+            const uint32_t mm = (zero_byte_mask(~x[k]) >> 7) & 0x01010101u; // bits 24, 16, 8, 0 = bytes 0, 1, 2, 3 of the word (stream order)
+            const uint32_t m4 = ((mm * 0x08040201u) >> 24) & ((1u << exist) - 1u);
             flags |= (uint64_t)m4 << (4 * k);
         }
         // 0xFF bytes before every word of the wavefront, in stream order = row by row; two rows share one 32-bit scan
@@ -405,6 +481,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         }
         if (lane == 0) wave_sum[wave] = wave_ff;
         __syncthreads();
+        PIXO_STAMP(7);
         uint32_t wave_base_ff = 0, round_ff = 0;
         uint32_t ff_of_wave[kGroupWaves];
 #pragma unroll
@@ -422,13 +499,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                 asm volatile("" : "+v"(lane2));
 #undef lane
 #define lane lane2
-                const uint64_t rel_g = g, kblk = rel_g >> 6;
-                const uint32_t in_block = (uint32_t)(rel_g & 63);
-                const uint64_t block_first = kblk << 6;
+                const uint64_t block_first = floor + ((uint64_t)kblk << 6);
                 uint32_t polls = 0;
                 bool gave_up = false;
                 unsigned long long da = (uint32_t)lane < in_block ? load_relaxed(&desc2[block_first + lane]) : kFlagAggregate;
-                unsigned long long db2 = (uint64_t)lane < kblk ? load_relaxed(&sup2[lane]) : kFlagAggregate;
+                unsigned long long db2 = (uint32_t)lane < kblk ? load_relaxed(&SUP2[lane]) : kFlagAggregate;
                 while ((da >> 62) == 0 && !gave_up) {
                     __builtin_amdgcn_s_sleep(kPollSleep);
                     if (++polls > rest.spin_budget) gave_up = true; else da = load_relaxed(&desc2[block_first + lane]);
@@ -440,17 +515,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                     before2 = front;
                     // the block's own sum goes out BEFORE waiting for the other blocks' sums (a group of one round knows its count here):
                     // published behind that wait, the blocks' last groups would form one chain of waits through the whole scan
-                    if (in_block == 63 && last_round && lane == 0) store_relaxed(&sup2[kblk], kFlagAggregate | ((uint64_t)front + ff_group + round_ff));
-                    for (uint64_t base = 0;;) {
+                    if (in_block == 63u && last_round && lane == 0) store_relaxed(&SUP2[kblk], kFlagAggregate | ((uint64_t)front + ff_group + round_ff));
+                    for (uint32_t base = 0;;) {
                         while ((db2 >> 62) == 0 && !gave_up) {
                             __builtin_amdgcn_s_sleep(kPollSleep);
-                            if (++polls > rest.spin_budget) gave_up = true; else db2 = load_relaxed(&sup2[base + lane]);
+                            if (++polls > rest.spin_budget) gave_up = true; else db2 = load_relaxed(&SUP2[base + lane]);
                         }
                         if (PIXO_ANY64(gave_up)) break;
                         before2 += (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)(db2 & kValueMask)), 63);
                         base += 64;
                         if (base >= kblk) break;
-                        db2 = base + lane < kblk ? load_relaxed(&sup2[base + lane]) : kFlagAggregate;
+                        db2 = base + lane < kblk ? load_relaxed(&SUP2[base + lane]) : kFlagAggregate;
                     }
                 }
                 if (PIXO_ANY64(gave_up)) {
@@ -464,12 +539,29 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
 #define lane lane_again
             }
             __syncthreads();
+            PIXO_STAMP(8);
             if (uni(s_abort)) { aborted = true; return; }
             ff_before_groups = uni64(s_before);
             in_front2 = uni(s_front2);
+            if (!MULTI && seg_late && nsegs > 1) { // (workgroup-uniform) a segment's last group of one round: the segment's bytes are known — out
+                                                    // they go, and only then: where does the segment begin?
+                if (tid == 0 && seg + 1 < nsegs) publish_aggregate(segdesc, seg, 0, (S >> 3) + nb_total + ff_before_groups + round_ff + rest.gap);
+                if (seg > 0) {
+                    if (wave == 1) {
+                        const uint64_t sb = look_back(segdesc, seg, 0, 0, a_state, host_abort, rest.spin_budget);
+                        if (lane == 0) {
+                            if (sb == kLookBackFailed) s_abort = 1;
+                            s_segbase = sb;
+                        }
+                    }
+                    __syncthreads();
+                    if (uni(s_abort)) { aborted = true; return; }
+                    seg_base = uni64(s_segbase);
+                }
+            }
         }
         // ---- expand + store.  Output offset of the round's first byte (owned byte 4 wbase of the group):
-        const uint64_t dst_round = (uint64_t)rest.out_skew + (S >> 3) + ff_before_groups + round_first + ff_group;
+        const uint64_t dst_round = (uint64_t)rest.out_skew + seg_base + (S >> 3) + ff_before_groups + round_first + ff_group;
         const bool all_at_once = ((uint32_t)dst_round & 15u) + bytes_this + round_ff <= kStageCap;
         for (int turn = 0; turn < (all_at_once ? 1 : kGroupWaves); turn++) { // (wave by wave when a round's bytes + zeros do not fit the stage)
             const uint32_t before_turn = all_at_once ? 0u : (turn == 0 ? 0u : (turn == 1 ? ff_of_wave[0] : ff_of_wave[0] + ff_of_wave[1]));
@@ -478,8 +570,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             const uint32_t turn_bytes = all_at_once ? bytes_this : (bytes_this > 2048u * (uint32_t)turn ? (bytes_this - 2048u * (uint32_t)turn < 2048u ? bytes_this - 2048u * (uint32_t)turn : 2048u) : 0u);
             const uint32_t turn_ff = all_at_once ? round_ff : (turn == 0 ? ff_of_wave[0] : (turn == 1 ? ff_of_wave[1] : ff_of_wave[2]));
             const uint32_t tile_out = turn_bytes + turn_ff;
-            for (uint32_t i = 16u * tid; i < ((skew + tile_out + 15u) & ~15u); i += 16u * kGroup) *reinterpret_cast<v4u *>(stage + i) = v4u{0, 0, 0, 0};
-            __syncthreads();
+            if (turn > 0) { // (the first turn's stage was zeroed on the way here)
+                for (uint32_t i = 16u * tid; i < ((skew + tile_out + 15u) & ~15u); i += 16u * kGroup) *reinterpret_cast<v4u *>(stage + i) = v4u{0, 0, 0, 0};
+                __syncthreads();
+            }
             if (all_at_once || wave == turn) {
                 const uint32_t at0 = skew + (all_at_once ? 2048u * (uint32_t)wave + wave_base_ff : 0u) + 4u * (uint32_t)lane;
 #pragma unroll
@@ -498,6 +592,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                 }
             }
             __syncthreads();
+            PIXO_STAMP(9);
             // out: leading bytes up to the first aligned 16 bytes, aligned 16-byte pieces, trailing bytes — never beyond out_cap
             const uint64_t base = dst0 - skew; // multiple of 16
             const uint32_t end = skew + tile_out;
@@ -514,7 +609,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             } else { // the whole turn lies inside one 16-byte piece
                 if ((uint32_t)tid + skew < end && tid < 16 && base + skew + tid < rest.out_cap) out[base + skew + tid] = stage[skew + tid];
             }
-            __syncthreads();
+            if (MULTI || !all_at_once) __syncthreads();
         }
         ff_group += round_ff;
         if (MULTI) {
@@ -523,15 +618,27 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         }
     }
     };
-    if (walk_into_window) rounds(std::true_type{}); else rounds(std::false_type{});
+    if (park) rounds(std::true_type{}); else rounds(std::false_type{});
+    PIXO_STAMP(10);
     if (aborted) return;
     // the block of 64 groups is complete with its last group: its sum of stuffed zeros for the groups behind
     // (a group of several rounds knows its count only now)
-    if ((g & 63) == 63 && walk_into_window && tid == 0) store_relaxed(&sup2[g >> 6], kFlagAggregate | ((uint64_t)in_front2 + ff_group));
-    if (last_group && tid == 0) { // totals: the scan's length in bits (unpadded), its bytes before and after stuffing
-        const uint64_t bits = S + group_bits, packed = (S >> 3) + nb_total, stuffed = packed + ff_before_groups + ff_group;
-        a_state[1] = bits;
-        if (rest.host_totals) { rest.host_totals[0] = bits; rest.host_totals[1] = stuffed; rest.host_totals[2] = packed; }
+    if (in_block == 63u && park && tid == 0) store_relaxed(&SUP2[kblk], kFlagAggregate | ((uint64_t)in_front2 + ff_group));
+    if (last_group && tid == 0) { // the segment is complete: where the next one begins, where this one ends, the launch's totals
+        const uint64_t packed = (S >> 3) + nb_total, stuffed = packed + ff_before_groups + ff_group, end = seg_base + stuffed;
+        if (seg + 1 < nsegs) {
+            store_relaxed(&segdesc[seg], kFlagPrefix | (end + rest.gap)); // (inclusive prefix: where the next segment begins)
+            if (rest.rst) { // RSTn behind a restart interval while more MCUs follow (jpeg/mod.rs:1431-1445); never stuffed
+                const uint64_t at = (uint64_t)rest.out_skew + end;
+                if (at + 2 <= rest.out_cap) { out[at] = 0xFF; out[at + 1] = (uint8_t)(0xD0u + (srow & 7u)); }
+            }
+        }
+        if (rest.host_segs) rest.host_segs[seg] = end;
+        if (seg + 1 == nsegs) {
+            const uint64_t bits = S + group_bits;
+            a_state[1] = bits;
+            if (rest.host_totals) { rest.host_totals[0] = bits; rest.host_totals[1] = end; rest.host_totals[2] = packed; }
+        }
     }
 #undef tid
 #undef lane
@@ -539,45 +646,65 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
 }
 } // namespace
 
-size_t pixels_code_state_words(uint64_t groups)
-{ // abort flag, total bits; per group: bit-count descriptor, tail, three DC words, 0xFF-count descriptor; per 64 groups: two block sums (+ 1 each)
-    return 2 + 6 * (size_t)groups + 2 * ((size_t)(groups + 63) / 64 + 1);
-}
-
-uint64_t pixels_code_groups(uint32_t W, uint32_t H, bool s420)
+#ifdef PIXO_TIMELINE
+extern "C" __attribute__((visibility("default"))) int pixo_hip_debug_pixels_code_timeline(unsigned long long *out, size_t bytes)
 {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pc_timeline), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+PixelsCodePlan pixels_code_plan(uint32_t W, uint32_t H, bool s420, uint32_t images, uint32_t restart_mcus)
+{
+    PixelsCodePlan p;
     const uint32_t unit = s420 ? 16u : 8u, per_tile = s420 ? 32u : 64u;
-    const uint64_t units_x = (W + unit - 1) / unit, units_y = (H + unit - 1) / unit;
-    return (units_x + per_tile - 1) / per_tile * units_y;
+    p.units_x = (W + unit - 1) / unit; p.units_y = (H + unit - 1) / unit;
+    p.tiles_x = (p.units_x + per_tile - 1) / per_tile; p.tiles_y = p.units_y;
+    p.images = images;
+    p.seg_rows = p.tiles_y;
+    if (restart_mcus && restart_mcus % p.units_x == 0 && restart_mcus / p.units_x < p.tiles_y) p.seg_rows = restart_mcus / p.units_x;
+    p.segs_per_img = (p.tiles_y + p.seg_rows - 1) / p.seg_rows;
+    p.seg_blocks64 = (uint32_t)(((uint64_t)p.seg_rows * p.tiles_x + 63) / 64);
+    p.groups = (uint64_t)p.tiles_x * p.tiles_y * images;
+    p.segments = (uint64_t)p.segs_per_img * images;
+    // abort flag, total bits; per group: bit-count descriptor, tail, three DC words, 0xFF-count descriptor; per segment: two rows of
+    // block sums (+ 1 each), its byte count (+ 1)
+    p.state_words = 2 + 6 * (size_t)p.groups + 2 * ((size_t)p.segments * p.seg_blocks64 + 1) + (size_t)p.segments + 1;
+    return p;
 }
 
-bool pixels_code_supported(uint32_t W, uint32_t H, bool gray)
-{ // vector pixel loads need one whole 4-pixel group per row; a tile row per grid row
-    return !gray && W >= 4 && H >= 1 && (H + 7) / 8 <= 65535u;
+bool pixels_code_supported(uint32_t W, uint32_t H, bool gray, bool s420, uint32_t images, uint32_t restart_mcus)
+{ // vector pixel loads need one whole 4-pixel group per row; a tile row per grid row; restart intervals: whole MCU rows of ONE image
+    if (gray || W < 4 || H < 1 || (H + 7) / 8 > 65535u || images < 1 || images > 65535u) return false;
+    if (restart_mcus) {
+        const uint32_t unit = s420 ? 16u : 8u, units_x = (W + unit - 1) / unit;
+        if (images > 1 || restart_mcus % units_x != 0) return false;
+    }
+    return true;
 }
 
-hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s420, const float *d_qt, const uint32_t *d_tables,
-                              unsigned long long *d_state, bool state_is_zero, unsigned long long *d_clear, size_t clear_words, uint8_t *d_out,
-                              uint64_t out_cap, unsigned long long *host_totals, const int16_t seed_dc[3], bool pad_last, void *d_block_spill, hipStream_t s,
+hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s420, const PixelsCodePlan &p, uint32_t gap, bool rst_markers,
+                              const float *d_qt, const uint32_t *d_tables, unsigned long long *d_state, bool state_is_zero,
+                              unsigned long long *d_clear, size_t clear_words, uint8_t *d_out, uint64_t out_cap, unsigned long long *host_totals,
+                              unsigned long long *host_segs, const int16_t seed_dc[3], bool pad_last, void *d_block_spill, hipStream_t s,
                               uint32_t spin_budget)
 {
-    if (!pixels_code_supported(W, H, false) || clear_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
-    const uint32_t unit = s420 ? 16u : 8u, per_tile = s420 ? 32u : 64u;
-    const uint32_t units_x = (W + unit - 1) / unit, units_y = (H + unit - 1) / unit;
-    const uint32_t tiles_x = (units_x + per_tile - 1) / per_tile, tiles_y = units_y;
-    const uint64_t groups = (uint64_t)tiles_x * tiles_y;
-    if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (!pixels_code_supported(W, H, false, s420, p.images, 0) || clear_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (p.groups > 0x7FFFFFFFull || p.tiles_y > 65535u) return hipErrorInvalidValue;
+    if (rst_markers && gap != 2) return hipErrorInvalidValue;
     if (host_totals) host_totals[3] = 0; // (the kernels' abort flag)
     if (!state_is_zero) {
-        const hipError_t e = hipMemsetAsync(d_state, 0, pixels_code_state_words(groups) * 8, s);
+        const hipError_t e = hipMemsetAsync(d_state, 0, p.state_words * 8, s);
         if (e != hipSuccess) return e;
     }
     PRest rest;
     const size_t row_bytes = (size_t)W * 3;
-    rest.px_bytes = row_bytes * H;
+    rest.px_stride = row_bytes * H;
+    rest.px_bytes = rest.px_stride * p.images;
     rest.clear = d_clear; rest.clear_words = d_clear ? (uint32_t)clear_words : 0u;
-    rest.host_totals = host_totals; rest.spin_budget = spin_budget;
-    rest.tiles_x = tiles_x; rest.groups = (uint32_t)groups;
+    rest.host_totals = host_totals; rest.host_segs = host_segs; rest.spin_budget = spin_budget;
+    rest.tiles_x = p.tiles_x; rest.tiles_y = p.tiles_y; rest.groups = (uint32_t)p.groups;
+    rest.seg_rows = p.seg_rows; rest.segs_per_img = p.segs_per_img; rest.seg_blocks64 = p.seg_blocks64;
+    rest.gap = gap; rest.rst = rst_markers ? 1u : 0u;
     for (int i = 0; i < 3; i++) rest.seed_dc[i] = seed_dc ? seed_dc[i] : (int16_t)0;
     rest.pad_last = pad_last ? 1 : 0;
     // (d_out may start anywhere: the kernel gets the 16-byte boundary below it and the distance)
@@ -585,12 +712,12 @@ hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s42
     uint8_t *out = d_out - rest.out_skew;
     rest.out_cap = out_cap + rest.out_skew;
     rest.block_spill = static_cast<uint32_t *>(d_block_spill);
-    const bool aligned = reinterpret_cast<uintptr_t>(d_px) % 4 == 0 && row_bytes % 4 == 0;
-    const dim3 grid(tiles_x, tiles_y);
+    const bool aligned = reinterpret_cast<uintptr_t>(d_px) % 4 == 0 && row_bytes % 4 == 0 && (p.images == 1 || rest.px_stride % 4 == 0);
+    const dim3 grid(p.tiles_x, p.tiles_y, p.images);
     const uint8_t *px = static_cast<const uint8_t *>(d_px);
-    const bool packed = packed_launch(groups); // (scalar or packed DCT passes and quantiser: jpeg_kernels.hpp)
-#define PIXO_LAUNCH_PC(MODE, LOAD) do { if (packed) hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, true>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, units_x, units_y, d_tables, d_state, out, rest); \
-                                        else hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, false>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, units_x, units_y, d_tables, d_state, out, rest); } while (0)
+    const bool packed = packed_launch(p.groups); // (scalar or packed DCT passes and quantiser: jpeg_kernels.hpp)
+#define PIXO_LAUNCH_PC(MODE, LOAD) do { if (packed) hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, true>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, p.units_x, p.units_y, d_tables, d_state, out, rest); \
+                                        else hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, false>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, p.units_x, p.units_y, d_tables, d_state, out, rest); } while (0)
     if (s420) { if (aligned) PIXO_LAUNCH_PC(M420, L_ALIGNED); else PIXO_LAUNCH_PC(M420, L_FUNNEL); }
     else { if (aligned) PIXO_LAUNCH_PC(M444, L_ALIGNED); else PIXO_LAUNCH_PC(M444, L_FUNNEL); }
 #undef PIXO_LAUNCH_PC

@@ -377,6 +377,7 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
     // first of a medium scan's pieces used to be.  Large scans and host pixels in bands keep the pieces (their PCIe time is
     // what the pieces hide); their bands run coefficient kernel + scan_code as before.
     const bool from_pixels = src && pixels_code_usable(j, o, g, batch);
+    if (from_pixels && batch > 1 && gaps_left) *gaps_left = j.seg_gap == seg_gap && seg_gap != 0; // (the fused kernel leaves any gap between its segments)
     if (j.fused && !j.segmented && batch == 1 && pieces_enabled() && !direct_host_stores() && (large || (medium && !from_pixels) || host_bands) &&
         (!dest || dest_cap >= likely_most) && (host_bands || !(own_malloc && !dest))) {
         PixelSource device_src; // (the same source once the pixels are on the device)
@@ -424,12 +425,17 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
     }
     if ((rc = upload_all())) return rc;
     const bool fuse_now = from_pixels && src; // (src is null once a pieces attempt above has computed the tuple)
-    if (fuse_now) { // pixels -> finished scan in ONE kernel (below); the tuple is never written (a retry with the multi-pass kernels computes it)
+    if (fuse_now) { // pixels -> finished scan(s) in ONE kernel (below); the tuple is never written (a retry with the multi-pass kernels computes it)
     } else {
-        if (src && (rc = coeffs_rows(c, src->d_px, o, g, stream, src->dy, src->dcb, src->dcr, 0, 0))) return rc; // one piece: the whole image first
+        if (src && batch > 1) { // (a batch's tuple: every plane of all images back to back — src->dy / dcb / dcr point into that layout)
+            const float *qt_all = nullptr;
+            if ((rc = device_tables(c.device, &qt_all))) return rc;
+            HIP_TRY(pd::launch_jpeg_coeffs(src->d_px, o.width, o.height, g.gray, g.s420, batch, src->dy, g.gray ? nullptr : src->dcb,
+                                           g.gray ? nullptr : src->dcr, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, stream));
+        } else if (src && (rc = coeffs_rows(c, src->d_px, o, g, stream, src->dy, src->dcb, src->dcr, 0, 0))) return rc; // one piece: the whole image first
         *tuple_done = true;
     }
-    if (j.fused) { // code + stuff back to back, one read-back
+    if (j.fused || fuse_now) { // code + stuff back to back, one read-back
         if ((rc = fuse_now ? scan_tables(c, j, o, g, stream, nullptr) : scan_lengths(c, j, o, g, stream, nullptr, /*wait=*/false))) return rc;
         // One image into host memory the GPU can write — the context's pinned file buffer, or storage of the caller's
         // that is pinned / registered: the stuffing kernel stores straight into it, behind the place of the headers.
@@ -465,7 +471,7 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
                 }
             }
         }
-        if (fuse_now) rc = scan_from_pixels(c, j, o, g, stream, src->d_px, direct ? &target : nullptr);
+        if (fuse_now) rc = scan_from_pixels(c, j, o, g, stream, src->d_px, direct ? &target : nullptr, /*wait=*/true, batch);
         else rc = scan_stuff_fused(c, j, stream, 0, nullptr, nullptr, nullptr, /*chained=*/true, direct ? &target : nullptr);
         if (rc) return rc;
         sw.lap("code+stuff (fused)");
@@ -493,7 +499,7 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
     }
     const uint64_t scan_bytes = j.scan_bytes;
     if (batch == 1 && j.n) { c.packed_per_block = static_cast<uint32_t>(scan_bytes / j.n); c.last_scan_bytes = scan_bytes; c.last_scan_blocks = j.n; }
-    if (batch > 1 && j.segmented) { // the stuffing kernel left every image's end in the pinned mailbox
+    if (batch > 1 && (j.segmented || j.pc_seg)) { // the stuffing kernel / the fused kernel left every image's end in the pinned mailbox
         image_starts->assign(batch + 1, 0); // (h_segs[i]: where image i's bytes end; the next image begins behind the gap)
         for (uint32_t i = 0; i < batch; ++i) (*image_starts)[i + 1] = c.h_segs[i] + (i + 1 < batch ? j.seg.marker_bytes : 0);
     } else if (batch > 1) { // where every image's segment begins in the stuffed stream (reuses the seg_bytes buffer: 8 B/entry)
@@ -508,7 +514,7 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
     pixo_host::file_headers(head, o, j.h);
     const size_t hdr = head.size(), total = hdr + scan_bytes + 2;
     if (head_out) { // the caller delivers the bytes itself from c.e_out (a batch: every file to its final place)
-        if (batch > 1 && !j.segmented) HIP_TRY(hipStreamSynchronize(stream)); // (image_starts is being copied)
+        if (batch > 1 && !j.segmented && !j.pc_seg) HIP_TRY(hipStreamSynchronize(stream)); // (image_starts is being copied)
         *head_out = head;
         *file = nullptr;
         *file_len = static_cast<size_t>(scan_bytes);

@@ -323,21 +323,32 @@ int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_
 }
 
 bool pixels_code_usable(const ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, uint32_t batch)
-{
-    return j.fused && !j.segmented && !j.band && batch == 1 && !g.gray && !o.optimize_huffman && !o.progressive && !debug().two_kernel_scan &&
-           pixo_dev::pixels_code_supported(o.width, o.height, g.gray);
+{ // one uninterrupted RGB scan, the images of a batch, or restart intervals of whole MCU rows — with GIVEN tables.  (Independent of
+  // which tuple kernels scan_begin chose: segments of any size are chains of the fused kernel.)
+    if (j.band || g.gray || o.optimize_huffman || o.progressive || debug().two_kernel_scan || debug().multipass_entropy || t_force_multipass) return false;
+    const uint32_t restart = (batch == 1 && scan_has_restart_markers(o, g)) ? o.restart_interval : 0;
+    return pixo_dev::pixels_code_supported(o.width, o.height, g.gray, g.s420, batch, restart);
 }
 
 int scan_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream, const void *d_pixels,
-                     HostTarget *host, bool wait)
+                     HostTarget *host, bool wait, uint32_t batch)
 {
     namespace pd = pixo_dev;
     int rc = scan_tables(c, j, o, g, stream, nullptr);
     if (rc) return rc;
     const float *qt_all = nullptr;
     if ((rc = device_tables(c.device, &qt_all))) return rc;
-    const uint64_t groups = pd::pixels_code_groups(o.width, o.height, g.s420);
-    const size_t words = pd::pixels_code_state_words(groups);
+    const uint32_t restart = (batch == 1 && scan_has_restart_markers(o, g)) ? o.restart_interval : 0;
+    const pd::PixelsCodePlan plan = pd::pixels_code_plan(o.width, o.height, g.s420, batch, restart);
+    const size_t words = plan.state_words;
+    const bool segs = plan.segments > 1;
+    const uint32_t gap = !segs ? 0u : (restart ? 2u : j.seg_gap); // RSTn, or what a batch wants between its files' scans
+    const bool rst = segs && restart != 0;
+    if (segs) { // (where every segment ends: the kernel's pinned mailbox, like the single-pass tuple kernels')
+        if ((rc = c.reserve_hsegs(plan.segments))) return rc;
+        j.pc_seg = true;
+        j.seg.marker_bytes = gap;
+    }
     // two state blocks: this launch's must be zero, and the launch zeroes the other one (the launch before it used that) on the side
     if (c.e_pc_state.cap < 2 * words * 8 || c.pc_half_words != words) {
         HIP_TRY(c.e_pc_state.reserve(2 * words * 8));
@@ -347,8 +358,8 @@ int scan_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const p
     }
     // groups of several 6 KiB rounds park their blocks here (jpeg_pixels_code.hip).  NOT in d_coef: the tuple pointers the caller
     // derived from it must stay valid for the multi-pass retry, and a hipFree would synchronise the device in the middle of the call
-    HIP_TRY(c.e_pc_spill.reserve(static_cast<size_t>(groups) * 192 * 128));
-    size_t want_cap = std::max<size_t>(j.stream_cap / 4, 4096);
+    HIP_TRY(c.e_pc_spill.reserve(static_cast<size_t>(plan.groups) * 192 * 128));
+    size_t want_cap = std::max<size_t>(j.stream_cap / 4, 4096) + static_cast<size_t>(plan.segments) * gap;
     for (int attempt = 0;; ++attempt) {
         uint8_t *out = nullptr;
         size_t out_cap = 0;
@@ -369,15 +380,16 @@ int scan_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const p
         unsigned long long *mine = c.e_pc_state.as<unsigned long long>() + static_cast<size_t>(c.pc_flip) * words;
         unsigned long long *other = c.e_pc_state.as<unsigned long long>() + static_cast<size_t>(c.pc_flip ^ 1) * words;
         c.pc_flip ^= 1;
-        HIP_TRY(pd::launch_pixels_code(d_pixels, o.width, o.height, g.s420, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c.e_tables.as<uint32_t>(),
-                                       mine, /*state_is_zero=*/true, other, words, out, out_cap, reinterpret_cast<unsigned long long *>(c.h_totals), nullptr, true,
-                                       c.e_pc_spill.p, stream, debug().spin_budget));
+        HIP_TRY(pd::launch_pixels_code(d_pixels, o.width, o.height, g.s420, plan, gap, rst, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats,
+                                       c.e_tables.as<uint32_t>(), mine, /*state_is_zero=*/true, other, words, out, out_cap,
+                                       reinterpret_cast<unsigned long long *>(c.h_totals), segs ? reinterpret_cast<unsigned long long *>(c.h_segs) : nullptr,
+                                       nullptr, true, c.e_pc_spill.p, stream, debug().spin_budget));
         if (!wait) return PIXO_OK;
         HIP_TRY(hipStreamSynchronize(stream));
         if (c.h_totals[3]) { c.pc_half_words = 0; return scan_retry_multipass(c); } // (both blocks are memset before the next use)
         j.total_bits = c.h_totals[0];
         j.scan_bytes = c.h_totals[1];
-        j.nbytes = c.h_totals[2];
+        j.nbytes = segs ? 0 : c.h_totals[2];
         if (j.scan_bytes > out_cap) { // (nothing was stored beyond the capacity: more room, the same kernel again)
             if (host && !host->grow) return PIXO_OK; // (the caller's storage is what it is: the caller reports the size needed)
             if (attempt > 1) return fail(PIXO_ERR_COMPRESSION, "Compression error: scan larger than announced");
@@ -572,7 +584,7 @@ int scan_pack(Context &c, ScanJob &j, hipStream_t stream, uint64_t band_bit_offs
 // time per file without the call's host side (waits, the file's way over PCIe).  The kernels are the product's: the fused
 // pixel -> scan kernel where it serves the job (*form = 1), else coefficient kernel + scan_code + the stuffing kernel on a grid
 // sized like the product's first guess.  Nothing is delivered.
-extern "C" int pixo_hip_debug_scan_device_async(const void *d_pixels, const pixo_jpeg_options *options, void *stream_, int *form)
+extern "C" int pixo_hip_debug_scan_device_async_batch(const void *d_pixels, const pixo_jpeg_options *options, uint32_t batch, void *stream_, int *form)
 {
     using namespace pixo_capi;
     namespace pd = pixo_dev;
@@ -582,21 +594,42 @@ extern "C" int pixo_hip_debug_scan_device_async(const void *d_pixels, const pixo
     int rc = pixo_host::validate(*options, false, 0, msg);
     if (rc) return fail(rc, msg);
     if (options->progressive || options->optimize_huffman) return fail(PIXO_ERR_COMPRESSION, "Compression error: pixo_hip_debug_scan_device_async measures baseline scans with standard tables");
+    if (batch == 0 || batch > 65535) return fail(PIXO_ERR_COMPRESSION, "Compression error: batch must be 1..65535");
     Context *c = nullptr;
     if ((rc = context_on_current_device(&c))) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const pixo_host::Geometry g = pixo_host::geometry(options->width, options->height, options->color_type, options->subsampling);
-    int16_t *dy, *dcb, *dcr;
-    if ((rc = coeffs_reserve(*c, g, &dy, &dcb, &dcr))) return rc;
+    const size_t coef_bytes = (g.y_blocks + 2 * g.c_blocks) * 128 * batch;
+    if ((rc = c->reserve_coef(coef_bytes))) return rc;
+    int16_t *dy = static_cast<int16_t *>(c->d_coef), *dcb = dy + g.y_blocks * 64 * batch, *dcr = dcb + g.c_blocks * 64 * batch;
     ScanJob j;
-    if ((rc = scan_begin(*c, j, dy, dcb, dcr, *options, g, 1, nullptr))) return rc;
-    if (!j.fused || j.segmented) return fail(PIXO_ERR_COMPRESSION, "Compression error: not a single-pass scan");
-    const bool fused = pixels_code_usable(j, *options, g, 1);
+    if (batch > 1) { // (the gap a batch leaves between two scans: EOI + the next file's headers)
+        std::vector<uint8_t> probe_head;
+        pixo_host::file_headers(probe_head, *options, pixo_host::HuffSet::standard());
+        j.seg_gap = static_cast<uint32_t>(probe_head.size() + 2);
+    }
+    if ((rc = scan_begin(*c, j, dy, dcb, dcr, *options, g, batch, nullptr))) return rc;
+    const bool fused = pixels_code_usable(j, *options, g, batch);
+    if (!fused && !j.fused) return fail(PIXO_ERR_COMPRESSION, "Compression error: not a single-pass scan");
     if (form) *form = fused ? 1 : 0;
-    if (fused) return scan_from_pixels(*c, j, *options, g, stream, d_pixels, nullptr, /*wait=*/false); // (ONE kernel: the stuffed scan in c.e_out)
+    if (fused) return scan_from_pixels(*c, j, *options, g, stream, d_pixels, nullptr, /*wait=*/false, batch); // (ONE kernel: the stuffed scans in c.e_out)
     {
-        if ((rc = coeffs_rows(*c, d_pixels, *options, g, stream, dy, dcb, dcr, 0, 0))) return rc;
+        const float *qt_all = nullptr;
+        if ((rc = device_tables(c->device, &qt_all))) return rc;
+        HIP_TRY(pd::launch_jpeg_coeffs(d_pixels, options->width, options->height, g.gray, g.s420, batch, dy, g.gray ? nullptr : dcb,
+                                       g.gray ? nullptr : dcr, qt_all + (options->quality - 1) * pixo_host::kDeviceQtFloats, stream));
         if ((rc = scan_lengths(*c, j, *options, g, stream, nullptr, /*wait=*/false))) return rc;
+    }
+    if (j.segmented) { // (the product's first guess of the stuffing grid: scan_stuff_segmented)
+        const size_t code_words = pd::fused_code_state_words_seg(j.seg.nsegs, j.seg.blocks);
+        const uint64_t per_seg = pd::stuff_tiles(static_cast<uint64_t>(j.seg.blocks) * 64 + 4096);
+        HIP_TRY(c->e_out.reserve(std::max<size_t>(j.stream_cap / 4, 4096)));
+        HIP_TRY(pd::launch_stuff_fused(c->e_stream.as<uint32_t>(), c->e_code_state.as<unsigned long long>(), code_words, 0, false,
+                                       j.stream_cap + j.nseg * pd::stuff_tile_bytes(), 0, per_seg * j.nseg, c->e_stuff_state.as<unsigned long long>(),
+                                       /*state_is_zero=*/true, c->e_out.as<uint8_t>(), c->e_out.cap, reinterpret_cast<unsigned long long *>(c->h_totals), stream,
+                                       nullptr, 0, &j.seg, debug().spin_budget));
+        c->code_state_zero_words = code_words;
+        return PIXO_OK;
     }
     const size_t want_cap = std::max<size_t>(j.stream_cap / 4, 4096);
     HIP_TRY(c->e_out.reserve(want_cap));
@@ -607,4 +640,7 @@ extern "C" int pixo_hip_debug_scan_device_async(const void *d_pixels, const pixo
     c->code_state_zero_words = j.code_state_words;
     return PIXO_OK;
 }
-
+extern "C" int pixo_hip_debug_scan_device_async(const void *d_pixels, const pixo_jpeg_options *options, void *stream_, int *form)
+{
+    return pixo_hip_debug_scan_device_async_batch(d_pixels, options, 1, stream_, form);
+}

@@ -451,12 +451,17 @@ def debug_stream_copy(d_in, d_out, nbytes, stream=0):
         _raise(rc)
 
 
-def debug_scan_device_async(d_pixels, options: JpegOptions, stream=0) -> int:
-    """MEASUREMENT only (`pixo_hip_debug_scan_device_async`): the device kernels of one baseline file enqueued on `stream`,
-    not waited for, nothing delivered.  Returns 1 when the fused pixel -> bit stream kernel ran, 0 for the two-kernel form."""
+def debug_scan_device_async(d_pixels, options: JpegOptions, stream=0, batch=1) -> int:
+    """MEASUREMENT only (`pixo_hip_debug_scan_device_async[_batch]`): the device kernels of one baseline file — or of `batch`
+    equally sized images back to back — enqueued on `stream`, not waited for, nothing delivered.  Returns 1 when the fused
+    pixel -> scan kernel ran, 0 for the two-kernel form."""
     form = C.c_int(0)
     oc = options._c()
-    rc = _lib.load().pixo_hip_debug_scan_device_async(_dev_ptr(d_pixels), C.byref(oc), C.c_void_p(stream) if stream else None, C.byref(form))
+    L = _lib.load()
+    if batch == 1:
+        rc = L.pixo_hip_debug_scan_device_async(_dev_ptr(d_pixels), C.byref(oc), C.c_void_p(stream) if stream else None, C.byref(form))
+    else:
+        rc = L.pixo_hip_debug_scan_device_async_batch(_dev_ptr(d_pixels), C.byref(oc), int(batch), C.c_void_p(stream) if stream else None, C.byref(form))
     if rc:
         _raise(rc)
     return form.value

@@ -98,3 +98,103 @@ def test_pinned_destination_one_byte_short_is_never_written_beyond_its_capacity(
     pinned = torch.full((len(want) + 64,), 0xA5, dtype=torch.uint8).pin_memory()
     n = jpeg.encode_device_into(pinned[: len(want)], d, o)
     assert n == len(want) and pinned[:n].numpy().tobytes() == want and bool((pinned[n:] == 0xA5).all())
+
+
+# ---- round 6: segments — the images of a batch and restart intervals of whole MCU rows go through the fused kernel --------------
+def _form(d, o, batch=1):
+    """1: the fused kernel serves this job, 0: coefficient kernel + scan_code + stuffing kernel"""
+    import torch
+    f = jpeg.debug_scan_device_async(d, o, stream=torch.cuda.current_stream().cuda_stream, batch=batch)
+    torch.cuda.synchronize()
+    return f
+
+
+def _batch_images(w, h, n, seed):
+    gens = [lambda i: synth.noise(w, h, seed + i), lambda i: synth.gradient_rgb(w, h), lambda i: synth.photo(w, h, seed + i),
+            lambda i: synth.flat_blocks(w, h), lambda i: np.tile(np.array([255, 255, 255], np.uint8), w * h),
+            lambda i: synth.extremes(w, h, seed + i)]
+    return [np.ascontiguousarray(gens[i % len(gens)](i)).reshape(-1) for i in range(n)]
+
+
+@pytest.mark.parametrize("w,h,n,ss,q", [(640, 48, 5, 1, 80), (1920, 1080, 3, 1, 80), (96, 64, 70, 1, 75), (16, 16, 300, 1, 90), (1100, 200, 4, 0, 80),
+                                        (520, 24, 9, 0, 50), (2048, 32, 2, 1, 100), (36, 20, 33, 0, 100), (4096, 2048, 2, 1, 80)])
+def test_fused_kernel_batches_every_file_equals_the_oracle(w, h, n, ss, q):
+    """a batch = one launch of the fused kernel with every image a segment (chains of their own, a look-back over the segments'
+    byte counts for where each file begins): host arena, device arena, malloc'd files — all against the oracle, and against the
+    two-kernel form"""
+    import torch
+    imgs = _batch_images(w, h, n, 11)
+    d = torch.from_numpy(np.concatenate(imgs)).cuda()
+    o = _opts(w, h, ss, q)
+    assert _form(d, o, n) == 1, "the batch did not take the fused kernel"
+    want = [O.encode(px, O.make_options(w, h, 2, q, ss)) for px in imgs]
+    total = sum(len(f) for f in want)
+    arena = torch.empty(total + 64, dtype=torch.uint8).pin_memory()
+    for _ in range(2):  # (the context's alternating state blocks: clean after every launch)
+        offs, lens = jpeg.encode_batch_device_into(arena, d, o, n)
+        a = arena.numpy()
+        for i in range(n):
+            assert a[offs[i]: offs[i] + lens[i]].tobytes() == want[i], "file %d of the batch differs from the oracle" % i
+    darena = torch.empty(total + 64, dtype=torch.uint8, device="cuda")
+    offs, lens = jpeg.encode_batch_device_into(darena, d, o, n)
+    a = darena.cpu().numpy()
+    for i in range(n):
+        assert a[offs[i]: offs[i] + lens[i]].tobytes() == want[i]
+    files = jpeg.encode_batch_device(d, o, n)
+    assert [bytes(f) for f in files] == want
+    jpeg.debug_configure("two_kernel_scan")
+    try:
+        if w * h >= 96 * 64:  # (the measuring entry wants a single-pass job: images of 96 blocks and more)
+            assert _form(d, o, n) == 0
+        assert [bytes(f) for f in jpeg.encode_batch_device(d, o, n)] == want
+    finally:
+        jpeg.debug_configure(None)
+    assert jpeg.lookback_fallbacks() == 0
+
+
+@pytest.mark.parametrize("w,h,ss,rows", [(640, 200, 1, 1), (640, 200, 1, 3), (1100, 333, 0, 2), (4096, 512, 1, 1), (513, 100, 1, 7), (200, 4000, 0, 5),
+                                         (64, 64, 1, 1), (2048, 2048, 1, 9)])
+def test_fused_kernel_restart_intervals_of_whole_mcu_rows(w, h, ss, rows):
+    """restart_interval = rows x (MCUs per row): every interval a segment of the fused kernel, RSTn written by the segment's last
+    group (jpeg/mod.rs:1423-1445); an interval that is NOT whole rows keeps the two-kernel form.  (The restart branch is pinned by
+    the oracle only: the reference's wasm entry cannot pass restart_interval.)"""
+    import torch
+    unit = 16 if ss == 1 else 8
+    units_x = (w + unit - 1) // unit
+    px = synth.noise(w, h, 5 + rows) if rows % 2 else synth.photo(w, h, 5 + rows)
+    d = torch.from_numpy(np.ascontiguousarray(px)).cuda()
+    for interval, fused in ((rows * units_x, 1), (rows * units_x + 1, 0)):
+        if interval > 65535:
+            continue
+        o = jpeg.JpegOptions.builder(w, h).color_type(ColorType(2)).quality(80).subsampling(jpeg.Subsampling(ss)).restart_interval(interval).build()
+        units = units_x * ((h + unit - 1) // unit)
+        if interval < units and (fused or interval * (6 if ss else 3) >= 96):
+            assert _form(d, o) == fused
+        want = O.encode(px, O.make_options(w, h, 2, 80, ss, restart=interval))
+        assert jpeg.encode_device(d, o) == want, "restart interval %d: file differs from the oracle" % interval
+        assert jpeg.encode(px, o) == want
+    assert jpeg.lookback_fallbacks() == 0
+
+
+def test_fused_kernel_batch_with_long_groups_and_small_output():
+    """noise at q = 100: groups of several rounds (the blocks parked, walked twice) inside a batch; and an arena that is too small
+    reports the size needed without a byte behind its capacity being written"""
+    import torch
+    from pixo_amd import error
+    w, h, n = 1030, 40, 4
+    imgs = [synth.noise(w, h, 70 + i) for i in range(n)]
+    d = torch.from_numpy(np.concatenate(imgs)).cuda()
+    for ss in (1, 0):
+        o = _opts(w, h, ss, 100)
+        want = [O.encode(px, O.make_options(w, h, 2, 100, ss)) for px in imgs]
+        total = sum(len(f) for f in want)
+        arena = torch.full((total + 64,), 0xA5, dtype=torch.uint8).pin_memory()
+        offs, lens = jpeg.encode_batch_device_into(arena[:total], d, o, n)
+        a = arena.numpy()
+        for i in range(n):
+            assert a[offs[i]: offs[i] + lens[i]].tobytes() == want[i]
+        assert bool((arena[total:] == 0xA5).all())
+        small = torch.full((total,), 0xA5, dtype=torch.uint8).pin_memory()
+        with pytest.raises(error.BufferTooSmall) as e:
+            jpeg.encode_batch_device_into(small[: total - 1], d, o, n)
+        assert e.value.needed == total and int(small[total - 1]) == 0xA5

@@ -297,24 +297,40 @@ def cpu_reference_wasm(w, h, ss, quality):
         return {"error": str(e)}
 
 
-GPU_CLOCK_HZ = 2.4e9  # MI355X peak engine clock (rocminfo clockRate; MI355X_MICROARCH.md): the issue roofline's denominator
+GPU_CLOCK_HZ = 2.4e9  # MI355X peak engine clock (rocminfo clockRate; MI355X_MICROARCH.md): used only for profiles that carry no measured clock
 SIMDS = 1024          # 256 CUs x 4
 
 
+def _profile(kind, name):
+    """A committed counter profile (profiles/<kind>_<name>.json) and whether it still describes the loaded library: the profile
+    records the library version and a hash of the sources its kernel is compiled from (tools/profile_meta.py); counters of another
+    build are STALE — reported as such, never as this run's."""
+    path = os.path.join(ROOT, "profiles", "%s_%s.json" % (kind, name))
+    d = json.load(open(path))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import profile_meta
+    return d, os.path.relpath(path, ROOT), profile_meta.stale_reason(d, name)
+
+
 def issue_of(name, kernel_us):
-    """The VALU-ISSUE roofline of a kernel: vector instructions per launch from the committed PMC profile
-    profiles/issue_<name>.json (rocprofv3 --pmc SQ_INSTS_VALU ..., tools/issue_profile.py) x 4 cycles — the measured average
-    issue cost of this code's instruction mix (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 quad-cycles) — over what 1,024 SIMDs
-    could issue at the peak clock during the kernel time measured IN THIS RUN.  Near 1: only fewer or cheaper vector
-    instructions make the kernel faster, whatever its HBM fraction says."""
-    path = os.path.join(ROOT, "profiles", "issue_%s.json" % name)
+    """The VALU-ISSUE roofline of a kernel: cycles in which a SIMD's vector ALU was issuing, summed over the SIMDs — from the
+    committed PMC profile profiles/issue_<name>.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU ..., tools/issue_profile.py) — over what
+    1,024 SIMDs offer during the kernel time measured IN THIS RUN at the engine clock MEASURED in the profiled launches
+    (GRBM_GUI_ACTIVE / 8 over the dispatch's duration; 2.4 GHz only for profiles that lack it).  Near 1: only fewer or cheaper
+    vector instructions make the kernel faster, whatever its HBM fraction says.  (`valu_busy_under_counters` is the same numerator
+    over the PROFILED launch's own duration, which the counters stretch: 28 us against 18 for the metric's kernel.)"""
     try:
-        d = json.load(open(path))
-        # cycles in which a SIMD's vector ALU was issuing, summed over the SIMDs (SQ_ACTIVE_INST_VALU x 4; older profiles: instructions x 4)
+        d, rel, stale = _profile("issue", name)
+        if stale:
+            return {"frac_issue": None, "counters_stale": True, "counters_stale_reason": stale, "issue_source": "profile: " + rel}
+        # (older profiles: instructions x 4)
         active = d.get("active_valu_cycles_per_launch") or d["insts_valu_per_launch"] * 4.0
-        frac = active / (SIMDS * GPU_CLOCK_HZ * kernel_us * 1e-6)
+        clock = d.get("engine_clock_hz_measured") or GPU_CLOCK_HZ
+        frac = active / (SIMDS * clock * kernel_us * 1e-6)
         return {"frac_issue": round(frac, 4), "valu_insts_per_launch": d["insts_valu_per_launch"], "valu_active_cycles_per_launch": active,
-                "issue_source": "profile: " + os.path.relpath(path, ROOT) + " (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x 2.4 GHz x kernel time of this run))"}
+                "engine_clock_GHz": round(clock / 1e9, 3), "engine_clock_is": "measured in the profiled launches" if d.get("engine_clock_hz_measured") else "assumed (peak)",
+                "valu_busy_under_counters": d.get("valu_busy"), "counters_stale": False,
+                "issue_source": "profile: " + rel + " (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x engine clock x kernel time of this run))"}
     except Exception:
         return {}
 
@@ -322,18 +338,72 @@ def issue_of(name, kernel_us):
 def bound_of(frac_hbm, issue):
     """Which roofline binds: the larger of the two fractions."""
     fi = issue.get("frac_issue")
-    return "valu-issue" if fi is not None and fi > frac_hbm else "hbm"
+    if fi is None:
+        return "hbm (issue counters missing or stale)" if issue.get("counters_stale") else "hbm"
+    return "valu-issue" if fi > frac_hbm else "hbm"
 
 
 def traffic_of(workload):
     """HBM bytes per launch from the committed PMC profile of this workload (separate rocprofv3 --pmc passes,
-    corrected as MI355X_MICROARCH.md prescribes) — read from profiles/, NOT measured in this run."""
-    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    corrected as MI355X_MICROARCH.md prescribes) — read from profiles/, NOT measured in this run; None (and the reason) when the
+    profile was measured on another build of the kernel."""
     try:
-        d = json.load(open(path))
-        return d.get("hbm_bytes_per_launch"), "profile: " + os.path.relpath(path, ROOT)
+        d, rel, stale = _profile("traffic", workload)
+        if stale:
+            return None, "STALE, not reported — %s (profile: %s)" % (stale, rel)
+        return d.get("hbm_bytes_per_launch"), "profile: " + rel
     except Exception:
         return None, None
+
+
+def copy_ceiling(job, in_bytes, out_bytes, steps=200, blocks=5):
+    """What the memory system of THIS box, at THIS moment, gives a plain copy that reads `in_bytes` and writes `out_bytes` in the
+    kernels' launch shape (pixo_hip_debug_stream_io: 192-thread workgroups, every thread R non-temporal 16-byte loads then W
+    stores, R / W in {1, 2, 4, 8, 16}; the side with more bytes gets 8 per thread) — timed by the same block protocol as the
+    kernel beside it.  The copy never moves fewer bytes than asked for (what it moved is reported)."""
+    from pixo_amd import jpeg
+    torch = job.torch
+    piece = 3072
+    big = max(in_bytes, out_bytes)
+    wgs = max(1, -(-big // (8 * piece)))
+
+    def pow2_at_least(x):
+        v = 1
+        while v < x and v < 16:
+            v *= 2
+        return v
+    r, w = pow2_at_least(-(-in_bytes // (wgs * piece))), pow2_at_least(-(-out_bytes // (wgs * piece)))
+    cin, cout = wgs * r * piece, wgs * w * piece
+    nbuf = min(16, max(2, -(-(640 << 20) // (cin + cout))))  # (rotate over more than the 256 MiB Infinity Cache)
+    ins = [torch.empty(cin, dtype=torch.uint8, device=job.dev).random_(0, 256) if i == 0 else torch.empty(cin, dtype=torch.uint8, device=job.dev) for i in range(nbuf)]
+    for t in ins[1:]:
+        t.copy_(ins[0])
+    outs = [torch.empty(cout, dtype=torch.uint8, device=job.dev) for _ in range(nbuf)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        k = i % nbuf
+        jpeg.debug_stream_io(ins[k], outs[k], wgs, r, w, stream=stream)
+    _, evs = job.time_blocks(step, steps, 20, blocks)
+    us = statistics.median(evs) / steps * 1e3
+    del ins, outs
+    torch.cuda.empty_cache()
+    return {"copy_us_same_run": round(us, 3), "copy_bytes_in": cin, "copy_bytes_out": cout, "copy_shape": "%d workgroups x 192 threads, %d loads + %d stores of 16 B" % (wgs, r, w),
+            "copy_GBps_same_run": round((cin + cout) / (us * 1e-6) / 1e9, 1)}
+
+
+def with_copy(job, out, in_bytes, out_bytes, kernel_us, issue, steps=200):
+    """Adds the same-run copy ceiling of a kernel line and lets `bound` compare like with like: the kernel's share of what a plain
+    copy of its bytes gets against its share of the issue rate."""
+    try:
+        c = copy_ceiling(job, in_bytes, out_bytes, steps=steps)
+        out.update(c)
+        out["frac_of_copy_same_run"] = round(c["copy_us_same_run"] / kernel_us, 4)
+        out["bound"] = bound_of(out["frac_of_copy_same_run"], issue)
+        out["bound_rule"] = "larger of frac_of_copy_same_run and frac_issue"
+    except BaseException as ex:  # (the kernel's number stands on its own)
+        out["copy_error"] = repr(ex)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -450,11 +520,15 @@ def quick_kernel(job, name, q, steps=200, blocks=7):
     r = wl.roofline(kernel_ms)
     out = {"workload": wl.label, "kernel_us": r["kernel_us_avg"], "Mpixels_per_s": round(wl.w * wl.h * wl.batch / kernel_ms / 1e3, 1),
            "achieved_GBps": r["achieved"], "frac": r["frac"], "bound": r["bound"], "steps": steps, "blocks": blocks, "settle_ms": QUICK_SETTLE_MS}
-    for key in ("frac_issue", "valu_insts_per_launch", "issue_source"):
+    for key in ("frac_issue", "valu_insts_per_launch", "issue_source", "counters_stale", "counters_stale_reason", "engine_clock_GHz", "valu_busy_under_counters",
+                "traffic", "traffic_source"):
         if key in r:
             out[key] = r[key]
+    in_bytes, out_bytes = wl.in_bytes, wl.out_bytes
     del wl
     job.torch.cuda.empty_cache()
+    # the plain copy of the same bytes (50 -> 100 MB for 4:4:4, 398 -> 401 MB for the batch ...) right behind the kernel's blocks
+    with_copy(job, out, in_bytes, out_bytes, out["kernel_us"], r, steps=max(20, min(steps, int(2e5 / max(out["kernel_us"], 1.0)))))
     return out
 
 
@@ -470,8 +544,12 @@ def quick_png(job, steps=100, blocks=7):
     out = {"workload": "configs[4]: 4096x4096 RGBA8 PNG row filters (Adaptive) + Adler-32 partials", "kernel_us": round(kernel_ms * 1e3, 3),
            "Mpixels_per_s": round(4096 * 4096 / kernel_ms / 1e3, 1), "achieved_GBps": round(alg / (kernel_ms * 1e-3) / 1e9, 1),
            "frac": round(frac, 4), "bound": bound_of(frac, issue), **issue, "steps": steps, "blocks": blocks}
+    traffic, src = traffic_of("c5")
+    out["traffic"], out["traffic_source"] = traffic, src
+    in_bytes, out_bytes = wl.in_bytes, wl.out_bytes
     del wl
     job.torch.cuda.empty_cache()
+    with_copy(job, out, in_bytes, out_bytes, out["kernel_us"], issue, steps=steps)
     return out
 
 
@@ -552,6 +630,10 @@ def run_coeffs(job, args):
         except Exception:
             pass
         try:
+            others["c1"] = config_1(job, args.quality)
+        except BaseException as ex:
+            others["c1"] = {"error": repr(ex)}
+        try:
             others["c3_whole_file"] = batch_whole_files(job, args.quality)
         except BaseException as ex:
             others["c3_whole_file"] = {"error": repr(ex)}
@@ -584,6 +666,45 @@ def run_coeffs(job, args):
         if ref:
             line["cpu_reference"] = ref
     job.finish(line)
+
+
+def config_1(job, q):
+    """configs[0]: a single 512x512 RGB8 image, q=80, 4:2:0 — the reference's own CPU-runnable case ("plumbing, no GPU").  Three
+    numbers side by side: the CPU port of the whole encode (oracle/pixo_oracle.c, one thread, median of 9 files; the checker, used
+    here as the CPU leg only), the GPU library on the same pixels (host pixels -> file bytes, median of 100 calls; compared with
+    the CPU's bytes and with the reference-made golden of SURVEY §8c), and the coefficient kernel alone on that shape."""
+    import numpy as np
+    import oracle_lib as O
+    import synth
+    from pixo_amd import jpeg
+    w = h = 512
+    px = np.ascontiguousarray(synth.noise(w, h, 42)).reshape(-1)
+    oo = O.make_options(w, h, 2, q, 1)
+    want = O.encode(px, oo)
+    tc = []
+    for _ in range(9):
+        t1 = time.perf_counter()
+        O.encode(px, oo)
+        tc.append(time.perf_counter() - t1)
+    opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling.S420).build()
+    got = jpeg.encode(px, opts)
+    if got != want:
+        raise SystemExit("bench: the 512x512 file differs from the oracle's — refusing to report a number")
+    golden = hashlib.sha256(got).hexdigest() == "128275e652c0e640e9bde2360d7a39c58f951f998b00319c07a6209cbe6dd159" if q == 80 else None
+    for _ in range(10):
+        jpeg.encode(px, opts)
+    tg = []
+    for _ in range(100):
+        t1 = time.perf_counter()
+        jpeg.encode(px, opts)
+        tg.append(time.perf_counter() - t1)
+    k = quick_kernel(job, "c1", q, steps=200, blocks=5)
+    cpu_ms, gpu_us = sorted(tc)[4] * 1e3, sorted(tg)[50] * 1e6
+    return {"workload": "configs[0]: single 512x512 RGB8 -> JPEG q=%d 4:2:0 (noise, seed 42)" % q, "file_bytes": len(got),
+            "file_equals_reference_golden_sha256": golden,
+            "cpu_whole_file_ms": round(cpu_ms, 3), "cpu_Mpixels_per_s": round(w * h / cpu_ms / 1e3, 2), "cpu_is": "oracle/pixo_oracle.c (C port of the reference's encode), 1 thread",
+            "gpu_whole_file_us_host_pixels_to_bytes": round(gpu_us, 1), "gpu_Mpixels_per_s_whole_file": round(w * h / gpu_us, 1),
+            "coefficient_kernel": {key: k[key] for key in ("kernel_us", "frac", "Mpixels_per_s", "copy_us_same_run", "frac_of_copy_same_run") if key in k}}
 
 
 def batch_whole_files(job, q, n_batches=7):
@@ -630,9 +751,28 @@ def batch_whole_files(job, q, n_batches=7):
         del dp
     except Exception as ex:
         photo = {"photo_error": repr(ex)}
+    # DEVICE time of the batch (the PCIe-bound 1.7 ms hides the kernels): the product's kernels for the 64 images enqueued back to back
+    # (pixo_hip_debug_scan_device_async_batch: no waits, nothing delivered), HIP events on the launch stream — the default form
+    # (coefficient kernel + scan_code + stuffing kernel over the batch) and the fused pixel -> scan kernel with every image a segment
+    # (debug switch fused_batch; slower on a launch of several generations, which is why it is not the default)
+    device = {}
+    try:
+        stream = torch.cuda.current_stream().cuda_stream
+        for name, sw in (("default_two_kernel_form", None), ("fused_kernel_every_image_a_segment", "fused_batch")):
+            jpeg.debug_configure(sw)
+            form = jpeg.debug_scan_device_async(d, opts, stream=stream, batch=n)
+            job.sync()
+            _, evs = job.time_blocks(lambda i: jpeg.debug_scan_device_async(d, opts, stream=stream, batch=n), 10, 4, 5)
+            us = statistics.median(evs) / 10 * 1e3
+            device[name] = {"device_us_per_batch": round(us, 1), "fused": bool(form),
+                            "frac_hbm_pixels_plus_files": round((n * w * h * 3 + int(sum(lens))) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+        jpeg.debug_configure(None)
+    except Exception as ex:
+        jpeg.debug_configure(None)
+        device = {"error": repr(ex)}
     del d, arena
     torch.cuda.empty_cache()
-    return {**photo, "workload": "configs[2] whole files: 64 x 1920x1080 RGB8 noise, q=%d, 4:2:0 -> 64 files in one pinned arena" % q,
+    return {**photo, "device_time": device, "workload": "configs[2] whole files: 64 x 1920x1080 RGB8 noise, q=%d, 4:2:0 -> 64 files in one pinned arena" % q,
             "ms_per_batch": round(dt * 1e3, 3), "ms_per_batch_min": round(min(ts) * 1e3, 3), "Mpixels_per_s": round(w * h * n / dt / 1e6, 1),
             "file_bytes_total": int(sum(lens)), "ms_per_batch_as_64_malloced_files": round(sorted(tb)[1] * 1e3, 3),
             "path": "pixo_hip_jpeg_encode_batch_device_into"}
@@ -738,6 +878,11 @@ def whole_file(job, wl):
                 us = statistics.median(evs) / 50 * 1e3
                 dev[name] = {"device_us_per_file": round(us, 2), "frac_hbm_pixels_plus_file": round((wl.in_bytes + nb) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                              "kernels": "pixels_code_kernel (one kernel: pixels -> stuffed scan)" if form else "jpeg_coeffs + scan_code + stuff_fused"}
+                issue = issue_of("pixels_code_" + name, us) if form else {}
+                dev[name].update({k: v for k, v in issue.items() if k in ("frac_issue", "valu_insts_per_launch", "counters_stale", "counters_stale_reason", "engine_clock_GHz")})
+                tr, tr_src = traffic_of("pixels_code_" + name)
+                dev[name]["traffic"], dev[name]["traffic_source"] = tr, tr_src
+                with_copy(job, dev[name], wl.in_bytes, int(nb), us, issue, steps=100)
             smooth["device_time"] = dev
             # the other presets' files: progressive scans (prog_code_kernel: one load and one walk of a block for all
             # scans of its component) and preset 2 (trellis + progressive + optimised tables), same pixels, same pinned buffer
@@ -839,6 +984,8 @@ def run_png(job, args):
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": src,
                          **issue_of("c5", kernel_ms * 1e3),
                          "kernel": "png_filter_kernel<4, true>", "algorithmic_bytes_per_launch": alg, "kernel_us_avg": round(kernel_ms * 1e3, 3)}}
+    if job.world == 1 and not args.no_extras:
+        with_copy(job, line["roofline"], wl.in_bytes, wl.out_bytes, kernel_ms * 1e3, line["roofline"], steps=args.steps)
     if not args.no_cpu_baseline and job.world == 1:
         import oracle_lib as O
         rows = 256  # bounded sample: 256 rows of the same image, one thread

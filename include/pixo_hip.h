@@ -349,7 +349,7 @@ void *pixo_hip_get_producer_stream(void);   /* what the calling thread set (to s
  * image needed (a 16384x16384 image: ~2 GB of HBM, ~0.4 GB pinned) until it calls this. */
 int pixo_hip_trim(void);
 /* Tests and A/B tools only: replaces the debug switches read from the environment variable PIXO_HIP_DEBUG
- * ("name[=value],...": trace, host_entropy, multipass_entropy, direct_stores, one_piece, two_kernel_scan, no_side_stats, coef_form=scalar|packed, trellis_form=lane|group, batch_parts=n, piece_groups=n, piece_medium=n,
+ * ("name[=value],...": trace, host_entropy, multipass_entropy, direct_stores, one_piece, two_kernel_scan, fused_batch, no_side_stats, coef_form=scalar|packed, trellis_form=lane|group, batch_parts=n, piece_groups=n, piece_medium=n,
  * piece_schedule=a:b:c, copy_threads=n, spin_budget=n, no_bands_upload, bands_upload_min_mb=n, bands_upload_mb=n — pixo_amd/csrc/capi_internal.hpp).  None of
  * them changes the bytes of a file.  NULL = read the environment again.  Not synchronised with calls in flight. */
 int pixo_hip_debug_configure(const char *switches_or_null);
@@ -362,6 +362,12 @@ uint64_t pixo_hip_debug_lookback_fallbacks(void);
  * memory system of THIS box gives the kernel's 50 MB + 50 MB beside the kernel's own time.  Replaces nothing of the
  * reference.  `bytes` must be a multiple of 24576, the pointers 16-byte aligned; asynchronous on `stream`. */
 int pixo_hip_debug_stream_copy(const void *d_in, void *d_out, size_t bytes, void *stream);
+/* MEASUREMENT only: the same for a kernel that writes more or less than it reads — `workgroups` workgroups of 192 threads, every
+ * thread `loads` non-temporal 16-byte loads, then `stores` non-temporal 16-byte stores (each in {1, 2, 4, 8, 16}): in = workgroups
+ * x loads x 3072 bytes, out = workgroups x stores x 3072 bytes.  The 4:4:4 coefficient kernel is (tiles, 4, 8), the PNG filter
+ * kernel (n, 8, 8), the fused pixel -> scan kernel on noise (tiles, 8, 2).  bench.py reports every kernel line beside it
+ * (`copy_us_same_run`). */
+int pixo_hip_debug_stream_io(const void *d_in, void *d_out, uint32_t workgroups, uint32_t loads, uint32_t stores, void *stream);
 /* MEASUREMENT only: the DEVICE work of one baseline file with standard tables — pixels -> the finished (stuffed, padded) scan in
  * the context's device buffer — enqueued on `stream` and NOT waited for; nothing is delivered.  The kernels are the ones
  * pixo_hip_jpeg_encode_device[_into] runs: the fused pixel -> scan kernel (jpeg_pixels_code.hip: ONE kernel; *form = 1) or

@@ -53,6 +53,8 @@ int hip_fail(hipError_t e, const char *what); // pixo::Error::CompressionError(S
 //   no_direct_small    ... and never, not even for small files (their default since round 4)
 //   one_piece          never code a scan in pieces
 //   two_kernel_scan    never use the fused pixel -> bit stream kernel (jpeg_pixels_code.hip): coefficient kernel + scan_code as in rounds 2-4
+//   fused_batch        batches through the fused kernel as well, every image a segment (round 6; slower than the two-kernel form for
+//                      launches of several generations of workgroups — profiles/r06_batch_device_time.txt — so not the default)
 //   piece_groups=n     equal pieces of n groups of 192 blocks instead of 2048
 //   piece_medium=n     growing pieces from n groups on instead of 1024, whatever the last file's size
 //   piece_schedule=a:b:c   their relative sizes (default 1:3)
@@ -64,7 +66,7 @@ int hip_fail(hipError_t e, const char *what); // pixo::Error::CompressionError(S
 //                      caller's or the library's memory.  Costs what profiles/r03_fresh_pages.txt shows for files of 24 MiB and more.
 struct DebugSwitches {
     bool trace = false, host_entropy = false, multipass_entropy = false, direct_stores = false, one_piece = false;
-    bool piece_medium_forced = false, no_bands_upload = false, plain_host = false, no_direct_small = false, two_kernel_scan = false;
+    bool piece_medium_forced = false, no_bands_upload = false, plain_host = false, no_direct_small = false, two_kernel_scan = false, fused_batch = false;
     int trellis_form = 0; // 1 / 2: the trellis search on one / on eight lanes per block whatever the image's size (jpeg_trellis.hpp)
     int coef_form = 0; // 1 / 2: the coefficient kernel's scalar / packed form whatever the launch size (jpeg_kernels.hpp)
     bool no_side_stats = false; // preset 2 on small images: statistics on the context's stream, in front of the search (round 4's order)

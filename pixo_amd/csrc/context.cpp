@@ -69,6 +69,7 @@ DebugSwitches parse_switches(const char *e)
         else if (name == "plain_host") v.plain_host = true;
         else if (name == "no_direct_small") v.no_direct_small = true;
         else if (name == "two_kernel_scan") v.two_kernel_scan = true;
+        else if (name == "fused_batch") v.fused_batch = true;
         else if (name == "no_side_stats") v.no_side_stats = true;
         else if (name == "trellis_form") v.trellis_form = val == "lane" ? 1 : (val == "group" ? 2 : 0);
         else if (name == "coef_form") v.coef_form = val == "scalar" ? 1 : (val == "packed" ? 2 : 0);

@@ -326,6 +326,11 @@ bool pixels_code_usable(const ScanJob &j, const pixo_jpeg_options &o, const pixo
 { // one uninterrupted RGB scan, the images of a batch, or restart intervals of whole MCU rows — with GIVEN tables.  (Independent of
   // which tuple kernels scan_begin chose: segments of any size are chains of the fused kernel.)
     if (j.band || g.gray || o.optimize_huffman || o.progressive || debug().two_kernel_scan || debug().multipass_entropy || t_force_multipass) return false;
+    // A batch is a launch of SEVERAL generations of workgroups.  The fused kernel's workgroup lives ~40 us, most of it waiting (pixel
+    // loads, two look-backs), and only eight fit a CU (LDS): 64 x 1080p take 434-521 us through it against 306-443 us through
+    // coefficient kernel + scan_code + stuffing kernel, whose workgroups wait for less (profiles/r06_batch_device_time.txt).
+    // One generation (a single image up to 4096x4096) is where the fused kernel wins.  Batches: on request only.
+    if (batch > 1 && !debug().fused_batch) return false;
     const uint32_t restart = (batch == 1 && scan_has_restart_markers(o, g)) ? o.restart_interval : 0;
     return pixo_dev::pixels_code_supported(o.width, o.height, g.gray, g.s420, batch, restart);
 }

@@ -14,6 +14,7 @@
 namespace {
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 constexpr size_t kChunk = 192 * 8 * 16; // bytes per workgroup
+constexpr size_t kPiece = 192 * 16;     // bytes one instruction of a workgroup moves
 
 __global__ __launch_bounds__(192) void stream_copy_kernel(const v4u *in, v4u *out)
 {
@@ -23,6 +24,37 @@ __global__ __launch_bounds__(192) void stream_copy_kernel(const v4u *in, v4u *ou
     for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(in + base + k * 192);
 #pragma unroll
     for (int k = 0; k < 8; k++) __builtin_nontemporal_store(v[k], out + base + k * 192);
+}
+
+// The same shape for a kernel that writes more or less than it reads (4:4:4: 12 KiB of pixels in, 24 KiB of coefficients out per
+// workgroup; the fused pixel -> scan kernel: 24 KiB in, a few KiB out): every workgroup issues R loads and W stores of 16 bytes
+// per thread; what is stored is the loaded data folded together (every byte read is used, no byte is invented).
+template <int R, int W> __global__ __launch_bounds__(192) void stream_io_kernel(const v4u *in, v4u *out)
+{
+    const size_t ib = (size_t)blockIdx.x * (192 * R) + threadIdx.x, ob = (size_t)blockIdx.x * (192 * W) + threadIdx.x;
+    v4u v[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) v[k] = __builtin_nontemporal_load(in + ib + k * 192);
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        v4u o = v[k % R];
+        if (W < R) { // (fewer stores than loads: fold the loads that have no store of their own into this one)
+#pragma unroll
+            for (int j = k + W; j < R; j += W) o ^= v[j];
+        }
+        __builtin_nontemporal_store(o, out + ob + k * 192);
+    }
+}
+template <int R> bool launch_io(int w, unsigned wgs, const v4u *in, v4u *out, hipStream_t s)
+{
+    switch (w) {
+    case 1: hipLaunchKernelGGL((stream_io_kernel<R, 1>), dim3(wgs), dim3(192), 0, s, in, out); return true;
+    case 2: hipLaunchKernelGGL((stream_io_kernel<R, 2>), dim3(wgs), dim3(192), 0, s, in, out); return true;
+    case 4: hipLaunchKernelGGL((stream_io_kernel<R, 4>), dim3(wgs), dim3(192), 0, s, in, out); return true;
+    case 8: hipLaunchKernelGGL((stream_io_kernel<R, 8>), dim3(wgs), dim3(192), 0, s, in, out); return true;
+    case 16: hipLaunchKernelGGL((stream_io_kernel<R, 16>), dim3(wgs), dim3(192), 0, s, in, out); return true;
+    default: return false;
+    }
 }
 } // namespace
 
@@ -35,5 +67,30 @@ extern "C" int pixo_hip_debug_stream_copy(const void *d_in, void *d_out, size_t 
                        static_cast<const v4u *>(d_in), static_cast<v4u *>(d_out));
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return pixo_capi::hip_fail(e, "stream_copy_kernel");
+    return PIXO_OK;
+}
+
+extern "C" int pixo_hip_debug_stream_io(const void *d_in, void *d_out, uint32_t workgroups, uint32_t loads, uint32_t stores, void *stream)
+{
+    auto pow2 = [](uint32_t v) { return v >= 1 && v <= 16 && (v & (v - 1)) == 0; };
+    if (!d_in || !d_out || workgroups == 0 || workgroups > 0x7FFFFFFFu || !pow2(loads) || !pow2(stores) ||
+        (reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) % 16 != 0)
+        return pixo_capi::fail(PIXO_ERR_COMPRESSION, "Compression error: pixo_hip_debug_stream_io wants 16-byte aligned device pointers, loads and stores in {1, 2, 4, 8, 16}");
+    const v4u *in = static_cast<const v4u *>(d_in);
+    v4u *out = static_cast<v4u *>(d_out);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    bool ok = false;
+    switch (loads) {
+    case 1: ok = launch_io<1>((int)stores, workgroups, in, out, s); break;
+    case 2: ok = launch_io<2>((int)stores, workgroups, in, out, s); break;
+    case 4: ok = launch_io<4>((int)stores, workgroups, in, out, s); break;
+    case 8: ok = launch_io<8>((int)stores, workgroups, in, out, s); break;
+    case 16: ok = launch_io<16>((int)stores, workgroups, in, out, s); break;
+    default: break;
+    }
+    if (!ok) return pixo_capi::fail(PIXO_ERR_COMPRESSION, "Compression error: pixo_hip_debug_stream_io: unsupported shape");
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return pixo_capi::hip_fail(e, "stream_io_kernel");
+    (void)kPiece;
     return PIXO_OK;
 }

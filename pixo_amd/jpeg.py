@@ -451,6 +451,15 @@ def debug_stream_copy(d_in, d_out, nbytes, stream=0):
         _raise(rc)
 
 
+def debug_stream_io(d_in, d_out, workgroups, loads, stores, stream=0):
+    """MEASUREMENT only (`pixo_hip_debug_stream_io`): `workgroups` x 192 threads, each `loads` 16-byte loads then `stores` 16-byte stores."""
+    def ptr(x):
+        return x.data_ptr() if hasattr(x, "data_ptr") else int(x)
+    rc = _lib.load().pixo_hip_debug_stream_io(ptr(d_in), ptr(d_out), int(workgroups), int(loads), int(stores), C.c_void_p(stream) if stream else None)
+    if rc:
+        _raise(rc)
+
+
 def debug_scan_device_async(d_pixels, options: JpegOptions, stream=0, batch=1) -> int:
     """MEASUREMENT only (`pixo_hip_debug_scan_device_async[_batch]`): the device kernels of one baseline file — or of `batch`
     equally sized images back to back — enqueued on `stream`, not waited for, nothing delivered.  Returns 1 when the fused

@@ -126,29 +126,31 @@ def test_fused_kernel_batches_every_file_equals_the_oracle(w, h, n, ss, q):
     imgs = _batch_images(w, h, n, 11)
     d = torch.from_numpy(np.concatenate(imgs)).cuda()
     o = _opts(w, h, ss, q)
-    assert _form(d, o, n) == 1, "the batch did not take the fused kernel"
     want = [O.encode(px, O.make_options(w, h, 2, q, ss)) for px in imgs]
     total = sum(len(f) for f in want)
-    arena = torch.empty(total + 64, dtype=torch.uint8).pin_memory()
-    for _ in range(2):  # (the context's alternating state blocks: clean after every launch)
-        offs, lens = jpeg.encode_batch_device_into(arena, d, o, n)
-        a = arena.numpy()
-        for i in range(n):
-            assert a[offs[i]: offs[i] + lens[i]].tobytes() == want[i], "file %d of the batch differs from the oracle" % i
-    darena = torch.empty(total + 64, dtype=torch.uint8, device="cuda")
-    offs, lens = jpeg.encode_batch_device_into(darena, d, o, n)
-    a = darena.cpu().numpy()
-    for i in range(n):
-        assert a[offs[i]: offs[i] + lens[i]].tobytes() == want[i]
-    files = jpeg.encode_batch_device(d, o, n)
-    assert [bytes(f) for f in files] == want
-    jpeg.debug_configure("two_kernel_scan")
+    # (batches take the fused kernel on request only — debug switch fused_batch: a launch of several generations of workgroups
+    # is faster through the two-kernel form, profiles/r06_batch_device_time.txt — so the switch is what this test is about)
+    jpeg.debug_configure("fused_batch")
     try:
-        if w * h >= 96 * 64:  # (the measuring entry wants a single-pass job: images of 96 blocks and more)
-            assert _form(d, o, n) == 0
-        assert [bytes(f) for f in jpeg.encode_batch_device(d, o, n)] == want
+        assert _form(d, o, n) == 1, "the batch did not take the fused kernel"
+        arena = torch.empty(total + 64, dtype=torch.uint8).pin_memory()
+        for _ in range(2):  # (the context's alternating state blocks: clean after every launch)
+            offs, lens = jpeg.encode_batch_device_into(arena, d, o, n)
+            a = arena.numpy()
+            for i in range(n):
+                assert a[offs[i]: offs[i] + lens[i]].tobytes() == want[i], "file %d of the batch differs from the oracle" % i
+        darena = torch.empty(total + 64, dtype=torch.uint8, device="cuda")
+        offs, lens = jpeg.encode_batch_device_into(darena, d, o, n)
+        a = darena.cpu().numpy()
+        for i in range(n):
+            assert a[offs[i]: offs[i] + lens[i]].tobytes() == want[i]
+        files = jpeg.encode_batch_device(d, o, n)
+        assert [bytes(f) for f in files] == want
     finally:
         jpeg.debug_configure(None)
+    if w * h >= 96 * 64:  # (the measuring entry wants a single-pass job: images of 96 blocks and more)
+        assert _form(d, o, n) == 0
+    assert [bytes(f) for f in jpeg.encode_batch_device(d, o, n)] == want
     assert jpeg.lookback_fallbacks() == 0
 
 
@@ -184,6 +186,7 @@ def test_fused_kernel_batch_with_long_groups_and_small_output():
     w, h, n = 1030, 40, 4
     imgs = [synth.noise(w, h, 70 + i) for i in range(n)]
     d = torch.from_numpy(np.concatenate(imgs)).cuda()
+    jpeg.debug_configure("fused_batch")
     for ss in (1, 0):
         o = _opts(w, h, ss, 100)
         want = [O.encode(px, O.make_options(w, h, 2, 100, ss)) for px in imgs]
@@ -198,3 +201,4 @@ def test_fused_kernel_batch_with_long_groups_and_small_output():
         with pytest.raises(error.BufferTooSmall) as e:
             jpeg.encode_batch_device_into(small[: total - 1], d, o, n)
         assert e.value.needed == total and int(small[total - 1]) == 0xA5
+    jpeg.debug_configure(None)

@@ -160,3 +160,22 @@ def test_gpu_filtered_stream_is_a_png_that_pillow_reconstructs(strategy):
             return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
         blob = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, color_type, 0, 0, 0)) + chunk(b"IDAT", z) + chunk(b"IEND", b"")
         assert np.array_equal(np.asarray(Image.open(io.BytesIO(blob))).reshape(-1), px)
+
+
+def test_config_5_full_size_known_answer_of_the_reference():
+    """SURVEY §8c's C5 known answer, made by the reference's own wasm build: 4096x4096 RGBA LCG bytes (seed 42, every 4th byte | 1),
+    FilterStrategy::Adaptive -> filtered stream 67,112,960 B sha256 240e005d..., Adler-32 0x90cc12e3, per-row filter histogram
+    {None 1316, Sub 800, Up 436, Avg 1048, Paeth 496}.  (bench.py refuses to report C5 without it; VERDICT r5 asked for it as a
+    test as well.)  Host pixels and device pixels."""
+    import torch
+    w = h = 4096
+    px = synth.rgba_noise_alpha1(w, h, 42)
+    got, adler = png.apply_filters(px, w, h, 4, png.FilterStrategy.ADAPTIVE)
+    assert got.size == 67112960 and adler == 0x90CC12E3
+    assert hashlib.sha256(got.tobytes()).hexdigest() == "240e005d4da54561ff45b86d92d482cf81b44c78add39fcb6e3f5a600edbd2b0"
+    hist = np.bincount(got.reshape(h, w * 4 + 1)[:, 0], minlength=5)
+    assert hist.tolist() == [1316, 800, 436, 1048, 496]
+    d = torch.from_numpy(px).cuda()
+    out = torch.empty(67112960, dtype=torch.uint8, device="cuda")
+    assert png.apply_filters_device(d, w, h, 4, out, png.FilterStrategy.ADAPTIVE) == 0x90CC12E3
+    assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == "240e005d4da54561ff45b86d92d482cf81b44c78add39fcb6e3f5a600edbd2b0"

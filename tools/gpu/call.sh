@@ -108,6 +108,7 @@ d = {"kernel": kern, "label": sys.argv[4], "hbm_bytes_per_launch": round(rd + wr
      "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (KiB; FETCH_SIZE x 2 on gfx950, MI355X_MICROARCH.md HBM section); raw rows: traffic_%s_raw.csv" % sys.argv[4]}
 json.dump(d, open(sys.argv[2], "w"), indent=1); print(json.dumps(d))
 PY
+  python3 "$ROOT/tools/profile_meta.py" --stamp "$O/traffic_$name.json" > /dev/null   # library version + hash of the kernel's sources (staleness guard of bench.py)
 }
 recipe_py() { timeout 900 python "$@" 2>&1 | tail -60; }
 

@@ -176,7 +176,9 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
     // one s_sleep (8128 clocks, ~3.4 us) late, so that its loads meet the first half's arithmetic and stores: 19.1 ->
     // 18.35 us on one box of the pool, nothing gained or lost (17.4) on a faster one, two sleeps or other halves worse
     // (profiles/r03_stagger_and_occupancy_ab.txt); the 4:4:4 kernel, two generations per 4096x4096 image: 33.8 -> 30.9 us
-    // (profiles/r03_stagger_444.txt).  Later generations are not touched (every odd thousand late: the batch loses 6 %).
+    // (profiles/r03_stagger_444.txt; round 6 tried every odd thousand, halves of 512, graded quarters and two sleeps for 4:4:4 again:
+    // all 1.5-3.5 us slower than this, none at all 0.45 us slower — profiles/r06_ab_444.txt).  Later generations are not touched
+    // (every odd thousand late: the batch loses 6 %).
     // With the grid's shape pre-loaded (below) the gain is 19.9-20.6 -> 18.3 us on a medium box and 21.8 -> 19.1 us on a slow
     // one (profiles/r03_stagger_length_ab.txt); on the fastest kind of box it was within +-1 %.
     // (the grid's shape comes as a preloaded argument — tiles_x | tiles_y << 8 | "2048 workgroups or more" << 31: gridDim

@@ -731,11 +731,20 @@ def batch_whole_files(job, q, n_batches=7):
         offs, lens = jpeg.encode_batch_device_into(arena, d, opts, n)
         ts.append(time.perf_counter() - t1)
     dt = sorted(ts)[len(ts) // 2]
+    # the drop-in shape (a pixo caller's `encode()` per image returns a Vec it owns): `pixo_hip_jpeg_encode_batch_device` hands out 64
+    # blocks the caller owns until pixo_hip_free — timed as a C caller sees it (call + the 64 frees); file 0 checked
+    import ctypes
     tb = []
-    for _ in range(3):
+    for rep in range(6):
         t1 = time.perf_counter()
-        jpeg.encode_batch_device(d, opts, n)
-        tb.append(time.perf_counter() - t1)
+        fp, fl = jpeg.encode_batch_device_raw(d, opts, n)
+        t2 = time.perf_counter()
+        if rep == 0 and ctypes.string_at(fp[0], fl[0]) != first:
+            raise SystemExit("bench: malloc'd batch file 0 differs from the oracle's — refusing to report a number")
+        t3 = time.perf_counter()
+        jpeg.free_files(fp, n)
+        tb.append((t2 - t1) + (time.perf_counter() - t3))
+    tb = tb[1:]  # (the first call allocates the blocks; every later one gets them back from pixo_hip_free)
     # the same batch with photograph-like content (synth.photo, ~1.3 bit/px: the users' case; every image its own copy in HBM)
     photo = {}
     try:
@@ -774,7 +783,8 @@ def batch_whole_files(job, q, n_batches=7):
     torch.cuda.empty_cache()
     return {**photo, "device_time": device, "workload": "configs[2] whole files: 64 x 1920x1080 RGB8 noise, q=%d, 4:2:0 -> 64 files in one pinned arena" % q,
             "ms_per_batch": round(dt * 1e3, 3), "ms_per_batch_min": round(min(ts) * 1e3, 3), "Mpixels_per_s": round(w * h * n / dt / 1e6, 1),
-            "file_bytes_total": int(sum(lens)), "ms_per_batch_as_64_malloced_files": round(sorted(tb)[1] * 1e3, 3),
+            "file_bytes_total": int(sum(lens)), "ms_per_batch_as_64_malloced_files": round(sorted(tb)[len(tb) // 2] * 1e3, 3),
+            "malloced_files_are": "64 blocks from the library's pinned pool, owned by the caller until pixo_hip_free; call + frees timed, steady state (median of 5 after the first)",
             "path": "pixo_hip_jpeg_encode_batch_device_into"}
 
 

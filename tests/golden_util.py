@@ -29,11 +29,22 @@ _GEN = {
     "const255": lambda w, h, seed: synth.constant(w, h, 255),
     "const0_gray": lambda w, h, seed: synth.constant(w, h, 0, 1),
     "primaries": lambda w, h, seed: _primaries(w, h),
+    # photograph-like content (round 6, tests/golden/make_golden_scene.py); gray = the luminance-like mean of the three channels
+    "photo": lambda w, h, seed: synth.photo(w, h, seed),
+    "scene": lambda w, h, seed: synth.scene(w, h, seed),
+    "photo_gray": lambda w, h, seed: (synth.photo(w, h, seed).reshape(-1, 3).astype(np.uint16).sum(axis=1) // 3).astype(np.uint8),
+    "scene_gray": lambda w, h, seed: (synth.scene(w, h, seed).reshape(-1, 3).astype(np.uint16).sum(axis=1) // 3).astype(np.uint8),
 }
 
 
 def load():
     return json.load(open(os.path.join(GOLDEN_DIR, "jpeg_cases.json")))
+
+
+def scene_cases(max_pixels=None, min_pixels=0):
+    """the reference-made vectors on photograph-like content (jpeg_scene_cases.json)"""
+    d = json.load(open(os.path.join(GOLDEN_DIR, "jpeg_scene_cases.json")))
+    return [c for c in d["cases"] if min_pixels <= c["w"] * c["h"] and (max_pixels is None or c["w"] * c["h"] <= max_pixels)]
 
 
 def cases(max_pixels=None, min_pixels=0):

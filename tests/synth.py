@@ -135,3 +135,50 @@ def photo(w: int, h: int, seed: int = 42) -> np.ndarray:
     lum = v.sum(axis=2, keepdims=True) // 3   # correlated colour: mostly luminance, a little chroma
     v = lum + (v - lum) // 3
     return np.clip(v, 0, 255).astype(np.uint8).reshape(-1)
+
+
+def scene(w: int, h: int, seed: int = 42) -> np.ndarray:
+    """A second photograph-like synthetic (round 6), built differently from `photo` (sums of blurred noise): what
+    a camera sees of a man-made scene — FLAT regions with HARD edges (a posterised coarse field picks each pixel's region and the
+    region its colour from a palette that includes saturated primaries), oriented fine TEXTURE inside the regions (hatching whose
+    direction, period and contrast change per region), a smooth illumination gradient across the frame, small SATURATED chroma
+    details (spots of pure red / blue / yellow / green where a mid-scale field peaks) and a little sensor noise.  Integer
+    arithmetic only (box filters by cumulative sums over the lcg bytes): every platform makes the same bytes."""
+    def box(a, k):  # k x k box mean of an int64 plane, edge replicated
+        p = k // 2
+        a = np.pad(a, ((p, p), (p, p)), mode="edge")
+        c = np.cumsum(a, axis=0, dtype=np.int64)
+        a = c[k - 1:] - np.concatenate([np.zeros((1, c.shape[1]), np.int64), c[:-k]], axis=0)
+        c = np.cumsum(a, axis=1, dtype=np.int64)
+        a = c[:, k - 1:] - np.concatenate([np.zeros((c.shape[0], 1), np.int64), c[:, :-k]], axis=1)
+        return a // (k * k)
+    n = lcg_bytes(w * h * 3, seed).reshape(h, w, 3).astype(np.int64)
+    yy, xx = np.arange(h, dtype=np.int64)[:, None], np.arange(w, dtype=np.int64)[None, :]
+    kc = 41 if min(w, h) >= 128 else 9
+    coarse = box(box(n[:, :, 0], kc), kc)                 # ~N(128, small): stretch, then posterise into regions
+    lo, hi = int(coarse.min()), int(coarse.max())
+    region = ((coarse - lo) * 11 // max(hi - lo, 1)).clip(0, 10)   # 11 bands -> contiguous regions with hard borders
+    palette = np.array([[32, 36, 44], [200, 196, 180], [224, 32, 24], [40, 96, 200], [236, 212, 40], [60, 150, 70], [120, 120, 124],
+                        [250, 250, 250], [90, 50, 30], [180, 60, 160], [16, 16, 16]], np.int64)
+    v = palette[region]                                    # (h, w, 3)
+    # oriented texture: per region a direction (a, b), a period and a contrast
+    a = np.array([1, 3, 0, 2, 5, 1, 7, 2, 1, 4, 3], np.int64)[region]
+    b = np.array([0, 1, 1, 5, 2, 6, 1, 3, 1, 1, 4], np.int64)[region]
+    per = np.array([4, 6, 3, 8, 5, 7, 3, 12, 4, 6, 5], np.int64)[region]
+    amp = np.array([10, 18, 6, 24, 12, 30, 4, 8, 20, 14, 3], np.int64)[region]
+    phase = (xx * a + yy * b) % (2 * per)
+    tri = np.where(phase < per, phase, 2 * per - phase)    # triangle wave 0..per
+    v = v + ((tri * 2 - per) * amp // per)[:, :, None]
+    # illumination: darker towards one corner
+    v = v * (160 + (xx * 60) // max(w - 1, 1) + (yy * 36) // max(h - 1, 1))[:, :, None] // 256 + 20
+    # saturated details where a mid-scale field peaks
+    km = 7 if min(w, h) >= 32 else 3
+    mid = box(n[::-1, :, 1], km)
+    top = int(np.sort(mid.reshape(-1))[max(0, mid.size - 1 - mid.size // 40)])   # the highest 2.5 %
+    spots = mid >= top
+    prim = np.array([[255, 0, 0], [0, 0, 255], [255, 255, 0], [0, 255, 0]], np.int64)[(n[:, :, 2] >> 2) & 3]
+    blk = ((xx // 8) + (yy // 8)) % 4                       # (the colour is constant over 8 x 8 cells: spots, not confetti)
+    prim = np.array([[255, 0, 0], [0, 0, 255], [255, 255, 0], [0, 255, 0]], np.int64)[blk + 0 * prim[:, :, 0]]
+    v = np.where(spots[:, :, None], prim, v)
+    v = v + (n - 128) // 24                                # sensor noise
+    return np.clip(v, 0, 255).astype(np.uint8).reshape(-1)

@@ -42,7 +42,15 @@ while time.time() - t0 < budget:
         big = rng.rand() < 0.5
         w = int(rng.randint(4, 4200 if big else 600)); h = int(rng.randint(1, 1200 if big else 300))
         if rng.rand() < 0.3: q = int(rng.randint(90, 101))  # long blocks, groups of several rounds, many 0xFF bytes
-    px = content(w * h * (3 if ct == 2 else 1), int(rng.randint(0, 6)), int(rng.randint(1, 1 << 30)))
+    if fused_only and rng.rand() < 0.35:  # restart intervals of whole MCU rows: segments of the fused kernel (round 6)
+        unit = 16 if ss else 8
+        restart = int(rng.randint(1, 6)) * ((w + unit - 1) // unit)
+        if restart > 65535: restart = None
+    kind = int(rng.randint(0, 8))
+    if ct == 2 and kind >= 6:  # photograph-like content (synth.scene / synth.photo: edges, texture, saturated details)
+        px = synth.scene(w, h, int(rng.randint(1, 1 << 20))) if kind == 6 else synth.photo(w, h, int(rng.randint(1, 1 << 20)))
+    else:
+        px = content(w * h * (3 if ct == 2 else 1), kind % 6, int(rng.randint(1, 1 << 30)))
     b = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss)) \
         .optimize_huffman(flags["optimize_huffman"]).progressive(flags["progressive"]).trellis_quant(flags["trellis"])
     if restart: b = b.restart_interval(restart)

@@ -38,7 +38,9 @@
 // its first bit + its first and last seven bits in 24 bytes, blocks of 64 groups their sums for all eight alignments in 40.
 // Byte-identical on the whole GPU suite — and 6-7 us SLOWER per 4096x4096 file: with every group of the launch arriving at its
 // look-back together, the 8 descriptor loads a lane cost more than the second round trip saves:
-// profiles/r06_pixels_code_one_lookback.txt.  The two cheap look-backs stay.)
+// profiles/r06_pixels_code_one_lookback.txt.  Also measured: the blocks' sums by device-scope ATOMIC ADDS (every group adds its
+// aggregate to its block's word, count in the high bits: a block's sum complete without a reader's round trip) — identical files,
+// 131 / 120 / 112 us instead of 57 / 45 / 40: 4,096 atomics on 64 words cost more than the whole kernel.  The two cheap look-backs stay.)
 //
 // LDS: the planar tile (16,896 B) is dead after phase B and becomes scratch (192 x 13 words) + window (1536 + 192 words)
 // = 16,896 B; + 2.2 KiB of tables: 8 workgroups per CU as before.
@@ -70,9 +72,14 @@ static_assert((kGroup * kScratchPitch + kBufWords) * 4 <= (uint32_t)kFusedLds, "
 static_assert(Geo<M420>::planar <= kFusedLds && Geo<M444>::planar <= kFusedLds, "planar tile");
 
 // what the kernel needs beyond its first (preloaded) arguments
-struct PRest {
+struct PEarly { // what phase A needs
     size_t px_bytes;           // all images
     size_t px_stride;          // bytes from one image to the next
+};
+// ... and what only the entropy-coding half needs.  (Loading these from the kernel-argument segment AFTER phase B instead of with the
+// kernel's first instructions saves 14 of ~200 spilled scalar registers and exposes a scalar load: +0.4 .. 2 us, measured and dropped —
+// profiles/r06_pixels_code_small_variants.txt.)
+struct PRest {
     unsigned long long *clear; // housekeeping: the state block of the launch before this one (it must be zero when it is used again)
     uint32_t clear_words;
     unsigned long long *host_totals;
@@ -141,10 +148,12 @@ __device__ unsigned long long g_pc_timeline[8192 * 16];
 #define PIXO_STAMP(k) do { } while (0)
 #endif
 
-template <int MODE, int LOAD, bool PACKED>
+// SEG = false: ONE image, ONE segment — the shape of the metric's whole-file path: everything about segments folds away (the
+// kernel of round 5: the segment bookkeeping costs ~1 us of a 40-57 us launch in uniform arithmetic and spilled scalar registers).
+template <int MODE, int LOAD, bool PACKED, bool SEG>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void pixels_code_kernel
 (const uint8_t *a_px, uint32_t a_W, uint32_t a_H, const float *a_qt, uint32_t a_units_x, uint32_t a_units_y, const uint32_t *a_tables,
- unsigned long long *a_state, uint8_t *a_out, const PRest rest)
+ unsigned long long *a_state, uint8_t *a_out, const PEarly early, const PRest rest_by_value)
 {
     typedef Geo<MODE> G;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kFusedLds];
@@ -157,11 +166,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     PIXO_STAMP(0);
     __builtin_amdgcn_s_setprio(1); // phase A in front of the older workgroups' phase B (jpeg_kernels.hip)
-    const uint32_t tx = blockIdx.x, ty = blockIdx.y, img = blockIdx.z;
+    const uint32_t tx = blockIdx.x, ty = blockIdx.y, img = SEG ? blockIdx.z : 0u;
     TileCtx c;
-    c.px = a_px + (size_t)img * rest.px_stride; c.y = c.cb = c.cr = nullptr; c.qt = a_qt;
+    c.px = a_px + (size_t)img * early.px_stride; c.y = c.cb = c.cr = nullptr; c.qt = a_qt;
     c.W = a_W; c.H = a_H; c.units_x = a_units_x; c.units_y = a_units_y; c.fast = 1;
-    c.px_end = a_px + rest.px_bytes;
+    c.px_end = a_px + early.px_bytes;
     if (tid == 0) { s_carry = 0; s_abort = 0; s_head = 0; s_front2 = 0; s_segbase = 0; }
     {
         constexpr int base = G::items / kWaves, extra = G::items % kWaves;
@@ -189,13 +198,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     const int lane_again = tid & 63, wave_again = __builtin_amdgcn_readfirstlane(tid >> 6);
 #define lane lane_again
 #define wave wave_again
+    const PRest &rest = rest_by_value;
     // ticket, segment, place in the segment's chain
     const uint32_t tiles_x = rest.tiles_x, tiles_y = rest.tiles_y;
     const uint64_t ngroups = rest.groups, g = ((uint64_t)img * tiles_y + ty) * tiles_x + tx;
-    const uint32_t srow = rest.seg_rows >= tiles_y ? 0u : ty / rest.seg_rows;       // (wave-uniform)
-    const uint32_t seg = img * rest.segs_per_img + srow, nsegs = gridDim.z * rest.segs_per_img;
-    const uint32_t row0 = srow * rest.seg_rows;
-    const uint32_t rows_here = tiles_y - row0 < rest.seg_rows ? tiles_y - row0 : rest.seg_rows;
+    const uint32_t srow = (!SEG || rest.seg_rows >= tiles_y) ? 0u : ty / rest.seg_rows;       // (wave-uniform)
+    const uint32_t seg = SEG ? img * rest.segs_per_img + srow : 0u, nsegs = SEG ? gridDim.z * rest.segs_per_img : 1u;
+    const uint32_t row0 = SEG ? srow * rest.seg_rows : 0u;
+    const uint32_t rows_here = (!SEG || tiles_y - row0 < rest.seg_rows) ? tiles_y - row0 : rest.seg_rows;
     const uint32_t rel = (ty - row0) * tiles_x + tx, seg_groups = rows_here * tiles_x;
     const uint64_t floor = g - rel;
     const bool last_group = rel + 1 == seg_groups; // of its segment
@@ -234,8 +244,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     uint32_t *scratch = reinterpret_cast<uint32_t *>(lds);
     uint32_t *buf = scratch + kGroup * kScratchPitch;
     // the window, zero: the gather ORs into it (behind the next barrier; the walk only touches the scratch in front of it)
+    static_assert(kWindowWords % (4 * kGroup) == 0 && (kGroup * kScratchPitch) % 4 == 0, "the window in whole 16-byte pieces per lane");
 #pragma unroll
-    for (uint32_t i = 0; i < kWindowWords / kGroup; i++) buf[(uint32_t)tid + kGroup * i] = 0;
+    for (uint32_t i = 0; i < kWindowWords / (4 * kGroup); i++) reinterpret_cast<v4u *>(buf)[(uint32_t)tid + kGroup * i] = v4u{0, 0, 0, 0};
     // ---- the walk: 63 AC positions + end-of-block from bit 0 of the lane's scratch; where the packer stands is the length
     uint32_t len_ac;
     {
@@ -416,8 +427,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                 }
                 s_head = (uint32_t)t & 0x7Fu;
             }
-            // (the stage, zero — the scratch area is dead: a round that expands all its bytes at once needs no zeroing pass of its own)
-            for (uint32_t i = 16u * tid; i < kStageCap; i += 16u * kGroup) *reinterpret_cast<v4u *>(stage + i) = v4u{0, 0, 0, 0};
+            // (the stage, zero — the scratch area is dead: a round that expands all its bytes at once needs no zeroing pass of its own.
+            // As far as this round can need it: its bytes, as many stuffed zeros, the 16-byte alignment at both ends)
+            {
+                const uint32_t need = 2u * ((wn < kWin ? wn : kWin) * 4u + 8u) + 32u, upto = need < kStageCap ? need : kStageCap;
+                for (uint32_t i = 16u * tid; i < upto; i += 16u * kGroup) *reinterpret_cast<v4u *>(stage + i) = v4u{0, 0, 0, 0};
+            }
             __syncthreads();
             PIXO_STAMP(6);
             if (uni(s_abort)) { aborted = true; return; }
@@ -697,9 +712,10 @@ hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s42
         if (e != hipSuccess) return e;
     }
     PRest rest;
+    PEarly early;
     const size_t row_bytes = (size_t)W * 3;
-    rest.px_stride = row_bytes * H;
-    rest.px_bytes = rest.px_stride * p.images;
+    early.px_stride = row_bytes * H;
+    early.px_bytes = early.px_stride * p.images;
     rest.clear = d_clear; rest.clear_words = d_clear ? (uint32_t)clear_words : 0u;
     rest.host_totals = host_totals; rest.host_segs = host_segs; rest.spin_budget = spin_budget;
     rest.tiles_x = p.tiles_x; rest.tiles_y = p.tiles_y; rest.groups = (uint32_t)p.groups;
@@ -712,15 +728,18 @@ hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s42
     uint8_t *out = d_out - rest.out_skew;
     rest.out_cap = out_cap + rest.out_skew;
     rest.block_spill = static_cast<uint32_t *>(d_block_spill);
-    const bool aligned = reinterpret_cast<uintptr_t>(d_px) % 4 == 0 && row_bytes % 4 == 0 && (p.images == 1 || rest.px_stride % 4 == 0);
+    const bool aligned = reinterpret_cast<uintptr_t>(d_px) % 4 == 0 && row_bytes % 4 == 0 && (p.images == 1 || early.px_stride % 4 == 0);
     const dim3 grid(p.tiles_x, p.tiles_y, p.images);
     const uint8_t *px = static_cast<const uint8_t *>(d_px);
     const bool packed = packed_launch(p.groups); // (scalar or packed DCT passes and quantiser: jpeg_kernels.hpp)
-#define PIXO_LAUNCH_PC(MODE, LOAD) do { if (packed) hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, true>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, p.units_x, p.units_y, d_tables, d_state, out, rest); \
-                                        else hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, false>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, p.units_x, p.units_y, d_tables, d_state, out, rest); } while (0)
+    const bool segs = p.segments > 1;
+#define PIXO_LAUNCH_PC2(MODE, LOAD, PK) do { if (segs) hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, PK, true>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, p.units_x, p.units_y, d_tables, d_state, out, early, rest); \
+                                             else hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, PK, false>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, p.units_x, p.units_y, d_tables, d_state, out, early, rest); } while (0)
+#define PIXO_LAUNCH_PC(MODE, LOAD) do { if (packed) PIXO_LAUNCH_PC2(MODE, LOAD, true); else PIXO_LAUNCH_PC2(MODE, LOAD, false); } while (0)
     if (s420) { if (aligned) PIXO_LAUNCH_PC(M420, L_ALIGNED); else PIXO_LAUNCH_PC(M420, L_FUNNEL); }
     else { if (aligned) PIXO_LAUNCH_PC(M444, L_ALIGNED); else PIXO_LAUNCH_PC(M444, L_FUNNEL); }
 #undef PIXO_LAUNCH_PC
+#undef PIXO_LAUNCH_PC2
     return hipGetLastError();
 }
 

@@ -297,8 +297,22 @@ def cpu_reference_wasm(w, h, ss, quality):
         return {"error": str(e)}
 
 
-GPU_CLOCK_HZ = 2.4e9  # MI355X peak engine clock (rocminfo clockRate; MI355X_MICROARCH.md): used only for profiles that carry no measured clock
+GPU_CLOCK_HZ = 2.4e9  # MI355X peak engine clock (rocminfo clockRate; MI355X_MICROARCH.md)
 SIMDS = 1024          # 256 CUs x 4
+CLOCK = {"hz": None}  # the engine clock under full vector load MEASURED IN THIS RUN (measure_engine_clock)
+
+
+def measure_engine_clock(job):
+    """pixo_hip_debug_engine_clock: shader-clock ticks over constant-clock ticks while every SIMD issues vector instructions.  The
+    chip clocks down under vector load (2.0-2.4 GHz): the issue roofline's denominator is this clock, not the peak."""
+    if CLOCK["hz"] is None and not job.stub:
+        try:
+            from pixo_amd import jpeg
+            CLOCK["hz"] = jpeg.debug_engine_clock(job.torch.cuda.current_stream().cuda_stream)
+        except Exception as ex:
+            sys.stderr.write("bench: engine clock not measured: %r\n" % (ex,))
+            CLOCK["hz"] = 0.0
+    return CLOCK["hz"] or None
 
 
 def _profile(kind, name):
@@ -315,8 +329,8 @@ def _profile(kind, name):
 def issue_of(name, kernel_us):
     """The VALU-ISSUE roofline of a kernel: cycles in which a SIMD's vector ALU was issuing, summed over the SIMDs — from the
     committed PMC profile profiles/issue_<name>.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU ..., tools/issue_profile.py) — over what
-    1,024 SIMDs offer during the kernel time measured IN THIS RUN at the engine clock MEASURED in the profiled launches
-    (GRBM_GUI_ACTIVE / 8 over the dispatch's duration; 2.4 GHz only for profiles that lack it).  Near 1: only fewer or cheaper
+    1,024 SIMDs offer during the kernel time measured IN THIS RUN at the engine clock MEASURED IN THIS RUN under full vector load
+    (measure_engine_clock; the 2.4 GHz peak only when that failed; `frac_issue_at_peak_clock` beside it).  Near 1: only fewer or cheaper
     vector instructions make the kernel faster, whatever its HBM fraction says.  (`valu_busy_under_counters` is the same numerator
     over the PROFILED launch's own duration, which the counters stretch: 28 us against 18 for the metric's kernel.)"""
     try:
@@ -325,10 +339,12 @@ def issue_of(name, kernel_us):
             return {"frac_issue": None, "counters_stale": True, "counters_stale_reason": stale, "issue_source": "profile: " + rel}
         # (older profiles: instructions x 4)
         active = d.get("active_valu_cycles_per_launch") or d["insts_valu_per_launch"] * 4.0
-        clock = d.get("engine_clock_hz_measured") or GPU_CLOCK_HZ
+        clock = CLOCK["hz"] or GPU_CLOCK_HZ
         frac = active / (SIMDS * clock * kernel_us * 1e-6)
-        return {"frac_issue": round(frac, 4), "valu_insts_per_launch": d["insts_valu_per_launch"], "valu_active_cycles_per_launch": active,
-                "engine_clock_GHz": round(clock / 1e9, 3), "engine_clock_is": "measured in the profiled launches" if d.get("engine_clock_hz_measured") else "assumed (peak)",
+        return {"frac_issue": round(frac, 4), "frac_issue_at_peak_clock": round(active / (SIMDS * GPU_CLOCK_HZ * kernel_us * 1e-6), 4),
+                "valu_insts_per_launch": d["insts_valu_per_launch"], "valu_active_cycles_per_launch": active,
+                "engine_clock_GHz": round(clock / 1e9, 3),
+                "engine_clock_is": "measured in this run under full vector load (pixo_hip_debug_engine_clock)" if CLOCK["hz"] else "assumed (peak)",
                 "valu_busy_under_counters": d.get("valu_busy"), "counters_stale": False,
                 "issue_source": "profile: " + rel + " (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x engine clock x kernel time of this run))"}
     except Exception:
@@ -557,6 +573,8 @@ def run_coeffs(job, args):
     wl = CoeffWorkload(job, args.workload, args.quality)
     settled = job.settle(wl.step, 0 if job.stub else args.settle_ms)
     walls, evs = job.time_blocks(wl.step, args.steps, args.warmup, args.blocks)
+    if job.rank == 0 and job.world == 1:
+        measure_engine_clock(job)
     copy_ms = None
     if job.rank == 0 and not job.stub and job.world == 1 and wl.batch == 1:
         # right behind the metric's blocks, same clocks, same protocol: the plain copy of the kernel's bytes; then the
@@ -971,6 +989,8 @@ def run_png(job, args):
     wl = PngWorkload(job)
     settled = job.settle(wl.step, args.settle_ms)
     walls, evs = job.time_blocks(wl.step, args.steps, args.warmup, args.blocks)
+    if job.rank == 0 and job.world == 1:
+        measure_engine_clock(job)
     if job.rank == 0 and not os.environ.get("PIXO_BENCH_ABLATION"):
         wl.check()
     if job.rank != 0:

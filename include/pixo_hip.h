@@ -368,6 +368,10 @@ int pixo_hip_debug_stream_copy(const void *d_in, void *d_out, size_t bytes, void
  * kernel (n, 8, 8), the fused pixel -> scan kernel on noise (tiles, 8, 2).  bench.py reports every kernel line beside it
  * (`copy_us_same_run`). */
 int pixo_hip_debug_stream_io(const void *d_in, void *d_out, uint32_t workgroups, uint32_t loads, uint32_t stores, void *stream);
+/* MEASUREMENT only: the engine clock in Hz while every SIMD issues vector instructions (four wavefronts each, ~1 ms of v_add_f32
+ * chains; shader-clock ticks over constant-clock ticks).  The chip clocks down under vector load: bench.py puts a kernel's active
+ * vector-ALU cycles over 1,024 SIMDs x THIS clock x the kernel's time (`frac_issue`), not over the 2.4 GHz peak.  Synchronises `stream`. */
+int pixo_hip_debug_engine_clock(void *stream, double *hz);
 /* MEASUREMENT only: the DEVICE work of one baseline file with standard tables — pixels -> the finished (stuffed, padded) scan in
  * the context's device buffer — enqueued on `stream` and NOT waited for; nothing is delivered.  The kernels are the ones
  * pixo_hip_jpeg_encode_device[_into] runs: the fused pixel -> scan kernel (jpeg_pixels_code.hip: ONE kernel; *form = 1) or

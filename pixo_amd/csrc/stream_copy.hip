@@ -56,7 +56,44 @@ template <int R> bool launch_io(int w, unsigned wgs, const v4u *in, v4u *out, hi
     default: return false;
     }
 }
+// The engine clock while every SIMD issues vector instructions (four wavefronts each): shader-clock ticks (s_memtime) over
+// constant-clock ticks (s_memrealtime, 100 MHz) across ~0.5 ms of dependent v_add_f32 chains, read by one thread.  The chip clocks
+// down under vector load (2.0-2.4 GHz measured, tools/ubench/memtime.hip): the issue roofline's denominator is THIS, not the peak.
+__global__ __launch_bounds__(256) void engine_clock_kernel(unsigned long long *out, float *sink, int iters)
+{
+    float a0 = (float)threadIdx.x, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7, b = 1.0f;
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; i++)
+        asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) { out[0] = t1 - t0; out[1] = r1 - r0; }
+    if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == -1.0f) sink[0] = a0; // (never true: keeps the chains alive)
+}
 } // namespace
+
+extern "C" int pixo_hip_debug_engine_clock(void *stream, double *hz)
+{
+    if (!hz) return pixo_capi::fail(PIXO_ERR_COMPRESSION, "Compression error: null argument 'hz'");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned long long *d = nullptr, h[2] = {0, 0};
+    hipError_t e = hipMalloc(&d, 64);
+    if (e != hipSuccess) return pixo_capi::hip_fail(e, "hipMalloc");
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    for (int rep = 0; rep < 2 && e == hipSuccess; rep++) { // (the second launch runs at the clocks the first one settled)
+        hipLaunchKernelGGL(engine_clock_kernel, dim3((unsigned)cus * 4), dim3(256), 0, s, d, reinterpret_cast<float *>(d + 4), 20000);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return pixo_capi::hip_fail(e, "engine_clock_kernel");
+    if (h[1] == 0) return pixo_capi::fail(PIXO_ERR_COMPRESSION, "Compression error: the constant clock did not advance");
+    *hz = (double)h[0] / (double)h[1] * 100e6;
+    return PIXO_OK;
+}
 
 extern "C" int pixo_hip_debug_stream_copy(const void *d_in, void *d_out, size_t bytes, void *stream)
 {

@@ -470,6 +470,15 @@ def debug_stream_copy(d_in, d_out, nbytes, stream=0):
         _raise(rc)
 
 
+def debug_engine_clock(stream=0) -> float:
+    """MEASUREMENT only (`pixo_hip_debug_engine_clock`): the engine clock in Hz under full vector load."""
+    hz = C.c_double(0.0)
+    rc = _lib.load().pixo_hip_debug_engine_clock(C.c_void_p(stream) if stream else None, C.byref(hz))
+    if rc:
+        _raise(rc)
+    return hz.value
+
+
 def debug_stream_io(d_in, d_out, workgroups, loads, stores, stream=0):
     """MEASUREMENT only (`pixo_hip_debug_stream_io`): `workgroups` x 192 threads, each `loads` 16-byte loads then `stores` 16-byte stores."""
     def ptr(x):

@@ -189,7 +189,10 @@ __global__ __launch_bounds__(kThreads) PIXO_WAVES_ATTR void jpeg_coeffs_kernel(c
         if ((lin >> 10) == 1u) __builtin_amdgcn_s_sleep(127); // (a full first generation only; 112..160 units are a plateau, 96 or 200 lose most of it;
                                                                  //  quarters or thirds with graded delays are no better)
     }
-    const TileId id{blockIdx.z, blockIdx.x, blockIdx.y}; // (a 3-D grid: no division on the way to the first load)
+    // (a 3-D grid: no division on the way to the first load.  Rows that are not dword aligned read 9.6 % more from HBM — the line at a
+    // tile's edge is shared with the row's next tile, which round-robin dispatch puts behind another XCD's L2; keeping a row's tiles on
+    // one XCD instead changed nothing in time: profiles/r06_unaligned_rows_per_xcd.txt)
+    const TileId id{blockIdx.z, blockIdx.x, blockIdx.y};
     TileCtx c = ctx_in(a, id.img);
     constexpr int base = G::items / kWaves, extra = G::items % kWaves;
     const int first = (extra && wave < extra) ? wave * (base + 1) : extra * (base + 1) + (wave - extra) * base;

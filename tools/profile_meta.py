@@ -2,7 +2,7 @@
 """What a committed counter profile (profiles/issue_<name>.json, profiles/traffic_<name>.json) was measured ON, so that bench.py can
 tell when it no longer describes the loaded library (the counters in the bench line are read from profiles/, not
 measured in the run): the library's version string and a hash of the SOURCES the profiled kernel is compiled from (the files below
-+ the Makefile's flags).  A profile without these, or with other values than the tree's, is reported as `counters_stale`.
++ the Makefile, comments and layout stripped).  A profile without these, or with other values than the tree's, is reported as `counters_stale`.
 
     python tools/profile_meta.py <name>            prints the meta of profile <name> for the tree as it stands
     python tools/profile_meta.py --stamp f.json    writes it into an existing profile (name = the file's `label`)"""
@@ -33,14 +33,24 @@ def sources_of(name):
     return None
 
 
-def source_hash(name):
+def _code_only(text):
+    """The text without comments and without layout: a reworded comment must not make a profile stale, a changed token must."""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    text = re.sub(r"^\s*#[^\n]*$", lambda m: m.group(0) if not m.group(0).lstrip().startswith("# ") else " ", text, flags=re.M)  # (Makefile comments)
+    return " ".join(text.split())
+
+
+def source_hash(name, root=None):
     files = sources_of(name)
     if files is None:
         return None
     h = hashlib.sha256()
+    base = os.path.join(root, "pixo_amd", "csrc") if root else CSRC
     for f in sorted(files) + ["Makefile"]:
-        with open(os.path.join(CSRC, f), "rb") as fh:
-            h.update(f.encode() + b"\0" + fh.read() + b"\0")
+        with open(os.path.join(base, f), "r", encoding="utf-8", errors="replace") as fh:
+            h.update(f.encode() + b"\0" + _code_only(fh.read()).encode() + b"\0")
     return h.hexdigest()[:16]
 
 

@@ -1,0 +1,268 @@
+"""bench.py's whole-file legs (never `value`): one 4096x4096 file, small files per preset, the 64 x 1080p batch, configs[0]."""
+from .common import *  # noqa: F401,F403
+from .roofline import *  # noqa: F401,F403
+from . import roofline as _roofline  # noqa: F401
+from .kernels import *  # noqa: F401,F403
+from . import kernels as _kernels  # noqa: F401
+
+
+def config_1(job, q):
+    """configs[0]: a single 512x512 RGB8 image, q=80, 4:2:0 — the reference's own CPU-runnable case ("plumbing, no GPU").  Three
+    numbers side by side: the CPU port of the whole encode (oracle/pixo_oracle.c, one thread, median of 9 files; the checker, used
+    here as the CPU leg only), the GPU library on the same pixels (host pixels -> file bytes, median of 100 calls; compared with
+    the CPU's bytes and with the reference-made golden of SURVEY §8c), and the coefficient kernel alone on that shape."""
+    import numpy as np
+    import oracle_lib as O
+    import synth
+    from pixo_amd import jpeg
+    w = h = 512
+    px = np.ascontiguousarray(synth.noise(w, h, 42)).reshape(-1)
+    oo = O.make_options(w, h, 2, q, 1)
+    want = O.encode(px, oo)
+    tc = []
+    for _ in range(9):
+        t1 = time.perf_counter()
+        O.encode(px, oo)
+        tc.append(time.perf_counter() - t1)
+    opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling.S420).build()
+    got = jpeg.encode(px, opts)
+    if got != want:
+        raise SystemExit("bench: the 512x512 file differs from the oracle's — refusing to report a number")
+    golden = hashlib.sha256(got).hexdigest() == "128275e652c0e640e9bde2360d7a39c58f951f998b00319c07a6209cbe6dd159" if q == 80 else None
+    for _ in range(10):
+        jpeg.encode(px, opts)
+    tg = []
+    for _ in range(100):
+        t1 = time.perf_counter()
+        jpeg.encode(px, opts)
+        tg.append(time.perf_counter() - t1)
+    k = quick_kernel(job, "c1", q, steps=200, blocks=5)
+    cpu_ms, gpu_us = sorted(tc)[4] * 1e3, sorted(tg)[50] * 1e6
+    return {"workload": "configs[0]: single 512x512 RGB8 -> JPEG q=%d 4:2:0 (noise, seed 42)" % q, "file_bytes": len(got),
+            "file_equals_reference_golden_sha256": golden,
+            "cpu_whole_file_ms": round(cpu_ms, 3), "cpu_Mpixels_per_s": round(w * h / cpu_ms / 1e3, 2), "cpu_is": "oracle/pixo_oracle.c (C port of the reference's encode), 1 thread",
+            "gpu_whole_file_us_host_pixels_to_bytes": round(gpu_us, 1), "gpu_Mpixels_per_s_whole_file": round(w * h / gpu_us, 1),
+            "coefficient_kernel": {key: k[key] for key in ("kernel_us", "frac", "Mpixels_per_s", "copy_us_same_run", "frac_of_copy_same_run") if key in k}}
+
+
+def batch_whole_files(job, q, n_batches=7):
+    """configs[2] as WHOLE FILES: 64 x 1920x1080 device-resident images -> 64 JPEG files back to back in the caller's pinned
+    arena (pixo_hip_jpeg_encode_batch_device_into): one coefficient launch, the images as segments of the two single-pass
+    entropy kernels, every file copied from the device straight to its final place."""
+    import numpy as np
+    import synth
+    from pixo_amd import jpeg
+    torch = job.torch
+    w, h, n = 1920, 1080, 64
+    base = torch.from_numpy(np.ascontiguousarray(synth.noise(w, h, 42))).to(job.dev)
+    d = torch.cat([base ^ torch.tensor(i, dtype=torch.uint8, device=job.dev) for i in range(n)]).contiguous()
+    opts = jpeg.JpegOptions.builder(w, h).quality(q).subsampling(jpeg.Subsampling.S420).build()
+    arena = torch.empty(n * w * h, dtype=torch.uint8).pin_memory()
+    offs, lens = jpeg.encode_batch_device_into(arena, d, opts, n)
+    import oracle_lib as O
+    first = arena[offs[0]: offs[0] + lens[0]].numpy().tobytes()
+    if first != O.encode(synth.noise(w, h, 42), O.make_options(w, h, 2, q, 1)):
+        raise SystemExit("bench: batch file 0 differs from the oracle's — refusing to report a number")
+    ts = []
+    for _ in range(n_batches):
+        t1 = time.perf_counter()
+        offs, lens = jpeg.encode_batch_device_into(arena, d, opts, n)
+        ts.append(time.perf_counter() - t1)
+    dt = sorted(ts)[len(ts) // 2]
+    # the drop-in shape (a pixo caller's `encode()` per image returns a Vec it owns): `pixo_hip_jpeg_encode_batch_device` hands out 64
+    # blocks the caller owns until pixo_hip_free — timed as a C caller sees it (call + the 64 frees); file 0 checked
+    import ctypes
+    tb = []
+    for rep in range(6):
+        t1 = time.perf_counter()
+        fp, fl = jpeg.encode_batch_device_raw(d, opts, n)
+        t2 = time.perf_counter()
+        if rep == 0 and ctypes.string_at(fp[0], fl[0]) != first:
+            raise SystemExit("bench: malloc'd batch file 0 differs from the oracle's — refusing to report a number")
+        t3 = time.perf_counter()
+        jpeg.free_files(fp, n)
+        tb.append((t2 - t1) + (time.perf_counter() - t3))
+    tb = tb[1:]  # (the first call allocates the blocks; every later one gets them back from pixo_hip_free)
+    # the same batch with photograph-like content (synth.photo, ~1.3 bit/px: the users' case; every image its own copy in HBM)
+    photo = {}
+    try:
+        dp = torch.from_numpy(np.ascontiguousarray(synth.photo(w, h, 42))).to(job.dev).repeat(n).contiguous()
+        for _ in range(2):
+            offs_p, lens_p = jpeg.encode_batch_device_into(arena, dp, opts, n)
+        tp = []
+        for _ in range(n_batches):
+            t1 = time.perf_counter()
+            offs_p, lens_p = jpeg.encode_batch_device_into(arena, dp, opts, n)
+            tp.append(time.perf_counter() - t1)
+        photo = {"ms_per_batch_photo": round(sorted(tp)[len(tp) // 2] * 1e3, 3), "file_bytes_total_photo": int(sum(lens_p))}
+        del dp
+    except Exception as ex:
+        photo = {"photo_error": repr(ex)}
+    # DEVICE time of the batch (the PCIe-bound 1.7 ms hides the kernels): the product's kernels for the 64 images enqueued back to back
+    # (pixo_hip_debug_scan_device_async_batch: no waits, nothing delivered), HIP events on the launch stream — the default form
+    # (coefficient kernel + scan_code + stuffing kernel over the batch) and the fused pixel -> scan kernel with every image a segment
+    # (debug switch fused_batch; slower on a launch of several generations, which is why it is not the default)
+    device = {}
+    try:
+        stream = torch.cuda.current_stream().cuda_stream
+        for name, sw in (("default_two_kernel_form", None), ("fused_kernel_every_image_a_segment", "fused_batch")):
+            jpeg.debug_configure(sw)
+            form = jpeg.debug_scan_device_async(d, opts, stream=stream, batch=n)
+            job.sync()
+            _, evs = job.time_blocks(lambda i: jpeg.debug_scan_device_async(d, opts, stream=stream, batch=n), 10, 4, 5)
+            us = statistics.median(evs) / 10 * 1e3
+            device[name] = {"device_us_per_batch": round(us, 1), "fused": bool(form),
+                            "frac_hbm_pixels_plus_files": round((n * w * h * 3 + int(sum(lens))) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+        jpeg.debug_configure(None)
+    except Exception as ex:
+        jpeg.debug_configure(None)
+        device = {"error": repr(ex)}
+    del d, arena
+    torch.cuda.empty_cache()
+    return {**photo, "device_time": device, "workload": "configs[2] whole files: 64 x 1920x1080 RGB8 noise, q=%d, 4:2:0 -> 64 files in one pinned arena" % q,
+            "ms_per_batch": round(dt * 1e3, 3), "ms_per_batch_min": round(min(ts) * 1e3, 3), "Mpixels_per_s": round(w * h * n / dt / 1e6, 1),
+            "file_bytes_total": int(sum(lens)), "ms_per_batch_as_64_malloced_files": round(sorted(tb)[len(tb) // 2] * 1e3, 3),
+            "malloced_files_are": "64 blocks from the library's pinned pool, owned by the caller until pixo_hip_free; call + frees timed, steady state (median of 5 after the first)",
+            "path": "pixo_hip_jpeg_encode_batch_device_into"}
+
+
+def small_files(wl):
+    """Not `value`: the latency of ONE small image, host pixels -> file bytes (pixo_hip_jpeg_encode_jpeg, the wasm entry's shape:
+    src/wasm.rs:113-142), per preset — 0 baseline (one kernel + one wait), 1 optimised tables, 2 trellis (eight lanes per block
+    at these sizes) + progressive + optimised tables.  Median of 100 calls each; the first file of every kind against the oracle."""
+    out = {}
+    try:
+        import numpy as np
+        import oracle_lib as O
+        import synth
+        jpeg = wl.jpeg
+        for (w, h) in ((64, 64), (512, 512)):
+            px = np.ascontiguousarray(synth.noise(w, h, 42)).reshape(-1)
+            row = {}
+            for preset in (0, 1, 2):
+                fn = lambda: jpeg.encode_jpeg(px, w, h, 2, wl.q, preset, True)
+                first = bytes(fn())
+                if first != bytes(O.encode_flat(px, w, h, 2, wl.q, preset, True)):
+                    raise SystemExit("bench: a small preset-%d file differs from the oracle's — refusing to report a number" % preset)
+                for _ in range(10):
+                    fn()
+                ts = []
+                for _ in range(100):
+                    t1 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - t1)
+                row["preset%d_us" % preset] = round(sorted(ts)[50] * 1e6, 1)
+                row["preset%d_bytes" % preset] = len(first)
+            out["%dx%d" % (w, h)] = row
+        out["what"] = "one image, host pixels -> bytes (pixo_hip_jpeg_encode_jpeg), noise, q=%d 4:2:0, median of 100 calls" % wl.q
+    except SystemExit:
+        raise
+    except Exception as ex:  # the metric line must not depend on this extra
+        out = {"error": repr(ex)}
+    return out
+
+
+def whole_file(job, wl):
+    """Not `value`: the whole file (the fused pixel -> scan kernel + copy of the file to the host) from
+    device-resident pixels, reported beside the kernel-only metric."""
+    torch, jpeg = job.torch, wl.jpeg
+    opts = jpeg.JpegOptions.builder(wl.w, wl.h).quality(wl.q).subsampling(jpeg.Subsampling(wl.ss)).build()
+    try:
+        pinned = torch.empty(wl.in_bytes // 2 + (1 << 16), dtype=torch.uint8).pin_memory()  # (64 B per block + 10 KB or more: the library may write it piece by piece)
+        nbytes = jpeg.encode_device_into(pinned, wl.ins[0], opts)
+        n_files, ts, tb = 15, [], []
+        for i in range(n_files):
+            t1 = time.perf_counter()
+            nbytes = jpeg.encode_device_into(pinned, wl.ins[i % wl.nbuf], opts)
+            ts.append(time.perf_counter() - t1)
+        for i in range(7):
+            t1 = time.perf_counter()
+            jpeg.encode_device(wl.ins[i % wl.nbuf], opts)
+            tb.append(time.perf_counter() - t1)
+        dt, dtb = sorted(ts)[n_files // 2], sorted(tb)[3]
+        host_px = torch.from_numpy(wl.base.copy())  # pageable host pixels, as pixo::jpeg::encode's caller has them
+        th = []
+        for i in range(7):
+            t1 = time.perf_counter()
+            jpeg.encode_into_buffer(pinned.numpy(), host_px.numpy(), opts)
+            th.append(time.perf_counter() - t1)
+        # the same for SMOOTH content (benches/comparison.rs:32 `generate_gradient_image`, SURVEY §8d's secondary input): the file is
+        # 0.3 MB instead of 11 MB, so this is the kernels' and the call's latency, not PCIe
+        smooth = {}
+        try:
+            import synth
+            d_g = torch.from_numpy(synth.gradient_rgb(wl.w, wl.h)).to(job.dev)
+            for _ in range(3):
+                nb_g = jpeg.encode_device_into(pinned, d_g, opts)
+            tg = []
+            for _ in range(15):
+                t1 = time.perf_counter()
+                nb_g = jpeg.encode_device_into(pinned, d_g, opts)
+                tg.append(time.perf_counter() - t1)
+            for _ in range(2):  # (the context predicts the next file's size from the last one: back to the metric's content)
+                jpeg.encode_device_into(pinned, wl.ins[0], opts)
+            smooth = {"ms_per_image_gradient": round(sorted(tg)[7] * 1e3, 3), "file_bytes_gradient": int(nb_g)}
+            # ... and for PHOTOGRAPH-LIKE content (synth.photo: structure at several scales + a little sensor noise, ~1.3 bit/px
+            # at q = 80 — what users encode; noise and the gradient only bracket it)
+            d_p = torch.from_numpy(synth.photo(wl.w, wl.h, 42)).to(job.dev)
+            for _ in range(3):
+                nb_p = jpeg.encode_device_into(pinned, d_p, opts)
+            tp = []
+            for _ in range(15):
+                t1 = time.perf_counter()
+                nb_p = jpeg.encode_device_into(pinned, d_p, opts)
+                tp.append(time.perf_counter() - t1)
+            smooth["ms_per_image_photo"] = round(sorted(tp)[7] * 1e3, 3)
+            smooth["file_bytes_photo"] = int(nb_p)
+            smooth["bits_per_pixel_photo"] = round(nb_p * 8 / (wl.w * wl.h), 3)
+            # the DEVICE time per file (pixo_hip_debug_scan_device_async: the product's kernel for one baseline file — pixels -> the
+            # finished, stuffed scan in ONE kernel — enqueued back to back, HIP events on the launch stream, no waits,
+            # no PCIe): K files between two events, median of the blocks.  frac = (pixels read + file written) / time / 8 TB/s.
+            dev = {}
+            for name, d_img, nb in (("noise", wl.ins[0], nbytes), ("photo", d_p, nb_p), ("gradient", d_g, nb_g)):
+                form = jpeg.debug_scan_device_async(d_img, opts, stream=wl.stream)
+                job.sync()
+                _, evs = job.time_blocks(lambda i, d_img=d_img: jpeg.debug_scan_device_async(d_img, opts, stream=wl.stream), 50, 10, 5)
+                us = statistics.median(evs) / 50 * 1e3
+                dev[name] = {"device_us_per_file": round(us, 2), "frac_hbm_pixels_plus_file": round((wl.in_bytes + nb) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                             "kernels": "pixels_code_kernel (one kernel: pixels -> stuffed scan)" if form else "jpeg_coeffs + scan_code + stuff_fused"}
+                issue = issue_of("pixels_code_" + name, us) if form else {}
+                dev[name].update({k: v for k, v in issue.items() if k in ("frac_issue", "valu_insts_per_launch", "counters_stale", "counters_stale_reason", "engine_clock_GHz")})
+                tr, tr_src = traffic_of("pixels_code_" + name)
+                dev[name]["traffic"], dev[name]["traffic_source"] = tr, tr_src
+                with_copy(job, dev[name], wl.in_bytes, int(nb), us, issue, steps=100)
+            smooth["device_time"] = dev
+            # the other presets' files: progressive scans (prog_code_kernel: one load and one walk of a block for all
+            # scans of its component) and preset 2 (trellis + progressive + optimised tables), same pixels, same pinned buffer
+            b = lambda: jpeg.JpegOptions.builder(wl.w, wl.h).quality(wl.q).subsampling(jpeg.Subsampling(wl.ss))
+            prog = {}
+            for name, o2, d_img in (("progressive_noise", b().progressive(True).build(), wl.ins[0]),
+                                    ("progressive_photo", b().progressive(True).build(), d_p),
+                                    ("progressive_gradient", b().progressive(True).build(), d_g),
+                                    ("preset2_noise", b().progressive(True).trellis_quant(True).optimize_huffman(True).build(), wl.ins[0]),
+                                    ("preset2_photo", b().progressive(True).trellis_quant(True).optimize_huffman(True).build(), d_p)):
+                for _ in range(3):
+                    nb2 = jpeg.encode_device_into(pinned, d_img, o2)
+                t2 = []
+                for _ in range(11):
+                    t1 = time.perf_counter()
+                    nb2 = jpeg.encode_device_into(pinned, d_img, o2)
+                    t2.append(time.perf_counter() - t1)
+                prog["ms_per_image_" + name] = round(sorted(t2)[5] * 1e3, 3)
+                prog["file_bytes_" + name] = int(nb2)
+            smooth["other_presets"] = prog
+            for _ in range(2):
+                jpeg.encode_device_into(pinned, wl.ins[0], opts)
+            del d_g, d_p
+        except Exception as ex:
+            smooth = {"gradient_error": repr(ex)}
+        return {"value": round(wl.w * wl.h / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_image": round(dt * 1e3, 3), **smooth,
+                "whole_file_from_host_ms": round(sorted(th)[3] * 1e3, 3), "whole_file_from_host_min_ms": round(min(th) * 1e3, 3),
+                "ms_per_image_min": round(min(ts) * 1e3, 3), "file_bytes": int(nbytes), "ms_per_image_as_python_bytes": round(dtb * 1e3, 3),
+                "path": "device-resident pixels -> ONE kernel: colour, DCT, quantiser, Huffman walk, bit placement, 0xFF stuffing (no coefficient tuple, no "
+                        "packed stream in HBM) -> file in the caller's pinned host buffer (pixo_hip_jpeg_encode_device_into)"}
+    except Exception as ex:  # the metric line must not depend on this extra
+        return {"error": repr(ex)}
+
+
+__all__ = [n for n in dir() if not n.startswith("__")]

@@ -98,8 +98,9 @@ def test_a_stuck_multi_gpu_leg_cannot_take_the_metric_line_with_it():
 import sys, time
 sys.argv = ["bench.py", "--stub", "--gpus", "1", "--steps", "2", "--warmup", "1", "--blocks", "3", "--no-cpu-baseline"]
 import bench
-bench.MULTI_LEGS_DEADLINE_S = 2.0
-bench.measure_c4 = lambda *a, **k: time.sleep(120)
+import benchlib.multi
+benchlib.multi.MULTI_LEGS_DEADLINE_S = 2.0
+benchlib.multi.measure_c4 = lambda *a, **k: time.sleep(120)
 bench.main()
 '''
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=100)

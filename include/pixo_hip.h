@@ -328,6 +328,9 @@ int pixo_hip_jpeg_encode_multi(const uint8_t *data, size_t data_len, const pixo_
  * copies its run of finished files to their final place in `arena` (host memory, pinned for full speed) over its OWN PCIe
  * link.  offsets / lens / capacity / PIXO_ERR_BUFFER_TOO_SMALL as pixo_hip_jpeg_encode_batch_device_into (a null arena with
  * capacity 0 is a size query); a device may appear more than once.  Byte-identical to that entry on one GPU.
+ * Device pixels: what the caller enqueued on its producer stream (pixo_hip_set_producer_stream; default the NULL stream) is waited
+ * for before the workers read them — `pixels` needs no length argument, so the caller guarantees batch x image bytes behind it
+ * (the Python and Rust mirrors check that).  pixo_hip_trim() also releases the workers' device buffers.
  * Replaces a loop over pixo::jpeg::encode (src/jpeg/mod.rs:88) spread over the GPUs of a node. */
 int pixo_hip_jpeg_encode_batch_multi(const void *pixels, const pixo_jpeg_options *options, uint32_t batch,
                                      const int *devices, uint32_t n_devices, uint8_t *arena, size_t capacity,

@@ -419,6 +419,16 @@ class BandWorkers {
         body_ = nullptr;
         return true;
     }
+    // body(k) on every worker that exists (pixo_hip_trim: their thread-local device buffers); nothing when there are none
+    void run_on_existing(const std::function<void(unsigned)> &body)
+    {
+        unsigned n = 0;
+        {
+            std::lock_guard<std::mutex> turn(turn_);
+            n = static_cast<unsigned>(workers_.size());
+        }
+        if (n) (void)run(n, body);
+    }
   private:
     struct Worker { std::thread thread; int job = -1; };
     void loop(Worker &w)
@@ -597,6 +607,15 @@ struct BatchWorkerBuffers {
 };
 thread_local BatchWorkerBuffers t_batch_buffers;
 } // namespace
+// pixo_hip_trim: the workers' device buffers go back to the driver (each worker frees its own, on its own thread)
+extern "C++" {
+namespace pixo_capi {
+void drop_batch_worker_buffers()
+{
+    band_workers_instance().run_on_existing([](unsigned) { t_batch_buffers.drop(); t_batch_buffers.device = -1; });
+}
+} // namespace pixo_capi
+}
 
 int pixo_hip_jpeg_encode_batch_multi(const void *pixels, const pixo_jpeg_options *options, uint32_t batch, const int *devices, uint32_t n_devices,
                                      uint8_t *arena, size_t capacity, size_t *offsets, size_t *lens)
@@ -622,6 +641,13 @@ int pixo_hip_jpeg_encode_batch_multi(const void *pixels, const pixo_jpeg_options
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, pixels) == hipSuccess && at.type == hipMemoryTypeDevice) src_device = at.device;
         else (void)hipGetLastError(); // (plain host memory is "invalid value" to the runtime: not an error)
+    }
+    // Device pixels may still be being written on the caller's producer stream (pixo_hip_set_producer_stream; default: the NULL
+    // stream).  The work below runs on worker threads with streams of their own: the caller's stream is drained first.
+    if (src_device >= 0) {
+        DeviceScope on(src_device);
+        if (on.err != hipSuccess) return hip_fail(on.err, "hipSetDevice");
+        HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(pixo_hip_get_producer_stream())));
     }
     const uint32_t parts = n_devices;
     struct Share {
@@ -680,7 +706,9 @@ int pixo_hip_jpeg_encode_batch_multi(const void *pixels, const pixo_jpeg_options
                 const int r = pixo_hip_jpeg_encode_batch_device_into(local, options, sh.count, static_cast<uint8_t *>(buf.arena), buf.arena_cap,
                                                                      sh.offs.data(), sh.lens.data());
                 if (r == PIXO_ERR_BUFFER_TOO_SMALL && attempt < 2) { want = sh.offs[sh.count - 1] + sh.lens[sh.count - 1] + 4096; continue; }
-                step(r);
+                if (r == PIXO_ERR_BUFFER_TOO_SMALL) // (the sizes changed between three identical calls: not the CALLER's arena that is too small)
+                    step(fail(PIXO_ERR_COMPRESSION, "Compression error: a batch share's size changed between identical calls"));
+                else step(r);
                 break;
             }
             if (!sh.rc) sh.bytes = sh.offs[sh.count - 1] + sh.lens[sh.count - 1];

@@ -227,6 +227,7 @@ void advise_huge(void *p, size_t n);
 uint8_t *alloc_file(size_t n); // a block for a finished file that the caller will own: large ones come from the blocks pixo_hip_free kept
 void free_file(void *p);       // pixo_hip_free: large blocks are kept (at most two) for the next large file
 void drop_kept_blocks();       // pixo_hip_trim
+void drop_batch_worker_buffers(); // pixo_hip_trim: the device buffers of pixo_hip_jpeg_encode_batch_multi's worker threads (bands.cpp)
 uint8_t *pool_take(size_t n);  // a block of PINNED host memory for a file the caller will own (null: none to be had — malloc instead); back via free_file
 int deliver(const uint8_t *file, size_t n, uint8_t **out, size_t *out_len);   // a fresh malloc block the caller owns
 int hand_over(const std::vector<uint8_t> &v, uint8_t **out, size_t *out_len);

@@ -404,6 +404,7 @@ int pixo_hip_trim(void)
     if (t_slot.c) t_slot.c->release();
     pool().drain();
     drop_kept_blocks();
+    drop_batch_worker_buffers();
     return PIXO_OK;
 }
 

@@ -132,72 +132,108 @@ class SharedFile:
     the others after a barrier with `create=False`).  With it `encode_banded` lets every rank copy its band's body from its
     GPU over its OWN PCIe link straight to the body's final place in the file — no gather to one rank, whose xGMI links
     and single PCIe link would otherwise carry everybody's bytes.  `register()` pins this process's mapping
-    (hipHostRegister) so that the copy is one DMA; without it the copy is staged through the library's pinned buffer."""
+    (hipHostRegister) so that the copy is one DMA; without it the copy is staged through the library's pinned buffer.
+
+    Who made a segment is written INTO it (a 4 KiB header page in front of the file's bytes): magic, the maker's pid,
+    its start time (clock ticks since boot, /proc/<pid>/stat — a reused pid has another) and its PID namespace.  A segment of the
+    same name that exists already is replaced only when its maker is provably gone: same namespace as ours and no live process
+    with that pid AND start time.  A maker in another PID namespace (containers sharing /dev/shm) cannot be judged from here: its
+    segment is left alone.  A header that is still all zero belongs to a maker between shm_open and its first store: waited for
+    briefly.  No companion segment, nothing for the resource tracker to complain about."""
+
+    _HEADER = 4096
+    _MAGIC = b"PIXOSHM2"
 
     def __init__(self, name, size, create):
         from multiprocessing import shared_memory
-        self._owner = None
+        import time
+        total = size + self._HEADER
         try:
-            self.shm = shared_memory.SharedMemory(name=name, create=create, size=size if create else 0)
+            self.shm = shared_memory.SharedMemory(name=name, create=create, size=total if create else 0)
         except FileExistsError:
-            # A segment of that name exists.  Left behind by a run that died: replace it.  In use by a LIVE process (another job
-            # on the node that chose the same name): refuse — unlinking it would take the other job's file away under it
-            # (ADVICE r4).  Who made a segment is written into a small companion segment "<name>.owner" (its pid).
-            owner = self._read_owner(name)
-            if owner is not None and owner != os.getpid() and self._alive(owner):
-                raise FileExistsError("SharedFile %r is in use by live process %d: names must be unique per job" % (name, owner))
-            stale = shared_memory.SharedMemory(name=name, create=False)
-            stale.close()
-            stale.unlink()
-            self.shm = shared_memory.SharedMemory(name=name, create=True, size=size)
-        if create:
-            self._write_owner(name)
-        if not create:  # (Python < 3.13 registers attached segments with the resource tracker too, which then unlinks — or complains
-            try:        # about — a segment this process does not own when the process ends)
-                from multiprocessing import resource_tracker
-                resource_tracker.unregister(self.shm._name, "shared_memory")
-            except Exception:
+            old = shared_memory.SharedMemory(name=name, create=False)
+            self._untrack(old)
+            owner = None
+            for _ in range(50):  # (a maker that has not written its header yet: up to half a second)
+                owner = self._read_header(old.buf)
+                if owner is not None:
+                    break
+                time.sleep(0.01)
+            mine = owner is not None and owner[0] == os.getpid() and owner[1] == self._start_time(os.getpid())
+            if owner is not None and not mine and self._maybe_alive(owner):
+                old.close()
+                raise FileExistsError("SharedFile %r is in use by live process %d: names must be unique per job" % (name, owner[0]))
+            old.close()
+            try:
+                shared_memory.SharedMemory(name=name, create=False).unlink()  # (stale — its maker is gone — or this process's own: replaced)
+            except FileNotFoundError:
                 pass
+            self.shm = shared_memory.SharedMemory(name=name, create=True, size=total)
+        if create:
+            self._write_header(self.shm.buf)
+        else:
+            self._untrack(self.shm)
+            if self.shm.size < total:
+                n = self.shm.size
+                self.shm.close()
+                raise ValueError("SharedFile %r holds %d bytes, %d wanted" % (name, max(0, n - self._HEADER), size))
         self.size = size
         self.registered = False
 
     @staticmethod
-    def _alive(pid):
+    def _untrack(shm):
+        # (Python < 3.13 registers attached segments with the resource tracker too, which then unlinks — or complains about — a
+        # segment this process does not own when the process ends)
+        try:
+            from multiprocessing import resource_tracker
+            resource_tracker.unregister(shm._name, "shared_memory")
+        except Exception:
+            pass
+
+    @staticmethod
+    def _start_time(pid):
+        try:
+            with open("/proc/%d/stat" % pid) as fh:
+                return int(fh.read().rsplit(")", 1)[1].split()[19])  # field 22: starttime
+        except Exception:
+            return 0
+
+    @staticmethod
+    def _pid_namespace():
+        try:
+            return os.stat("/proc/self/ns/pid").st_ino
+        except Exception:
+            return 0
+
+    def _write_header(self, buf):
+        pid = os.getpid()
+        buf[8:32] = pid.to_bytes(8, "little") + self._start_time(pid).to_bytes(8, "little") + self._pid_namespace().to_bytes(8, "little")
+        buf[:8] = self._MAGIC  # (last: a reader that sees the magic sees the fields)
+
+    @classmethod
+    def _read_header(cls, buf):
+        if len(buf) < 32 or bytes(buf[:8]) != cls._MAGIC:
+            return None if len(buf) >= 32 and bytes(buf[:32]) == bytes(32) else (0, 0, 0)  # all zero: being made; anything else: not ours to judge -> stale
+        return tuple(int.from_bytes(bytes(buf[8 + 8 * i: 16 + 8 * i]), "little") for i in range(3))
+
+    @classmethod
+    def _maybe_alive(cls, owner):
+        pid, start, ns = owner
+        if pid == 0:
+            return False  # (a segment without a header: made by an older version, or garbage)
+        if ns != cls._pid_namespace():
+            return True   # (another PID namespace: cannot be judged from here — never unlink somebody else's segment)
         try:
             os.kill(pid, 0)
-            return True
         except ProcessLookupError:
             return False
         except PermissionError:
-            return True
-
-    @staticmethod
-    def _read_owner(name):
-        from multiprocessing import shared_memory
-        try:
-            o = shared_memory.SharedMemory(name=name + ".owner", create=False)
-        except FileNotFoundError:
-            return None  # (made by an older version, or its maker died before writing: treated as stale)
-        try:
-            from multiprocessing import resource_tracker
-            resource_tracker.unregister(o._name, "shared_memory")
-        except Exception:
             pass
-        pid = int.from_bytes(bytes(o.buf[:8]), "little")
-        o.close()
-        return pid or None
-
-    def _write_owner(self, name):
-        from multiprocessing import shared_memory
-        try:
-            o = shared_memory.SharedMemory(name=name + ".owner", create=True, size=8)
-        except FileExistsError:
-            o = shared_memory.SharedMemory(name=name + ".owner", create=False)
-        o.buf[:8] = os.getpid().to_bytes(8, "little")
-        self._owner = o
+        now = cls._start_time(pid)
+        return now == 0 or start == 0 or now == start  # (a reused pid has another start time)
 
     def array(self):
-        return np.ndarray((self.size,), dtype=np.uint8, buffer=self.shm.buf)
+        return np.ndarray((self.size,), dtype=np.uint8, buffer=self.shm.buf, offset=self._HEADER)
 
     def register(self):
         import torch
@@ -213,15 +249,10 @@ class SharedFile:
             self.registered = False
         self.shm.close()
         if unlink:
-            self.shm.unlink()
-        if self._owner is not None:
-            self._owner.close()
-            if unlink:
-                try:
-                    self._owner.unlink()
-                except FileNotFoundError:
-                    pass
-            self._owner = None
+            try:
+                self.shm.unlink()
+            except FileNotFoundError:
+                pass
 
 
 def shared_file_bound(options) -> int:

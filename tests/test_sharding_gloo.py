@@ -488,3 +488,37 @@ def test_shared_file_refuses_a_name_that_a_live_process_holds():
         assert b.array().size == 8192 and int(b.array()[:4].sum()) == 0
     finally:
         b.close(unlink=True)
+
+
+def test_shared_file_header_judges_the_maker_by_pid_start_time_and_namespace():
+    """the maker's identity lives in the segment's own header.  A header naming this very pid with ANOTHER start time
+    (a reused pid) is a dead maker: replaced.  A maker in another PID namespace cannot be judged: refused.  No header at all (an
+    older version's segment): replaced."""
+    from multiprocessing import shared_memory
+    from pixo_amd import sharded
+    SF = sharded.SharedFile
+    name = "pixo_test_hdr_%d" % os.getpid()
+
+    def raw(fill):
+        seg = shared_memory.SharedMemory(name=name, create=True, size=4096 + SF._HEADER)
+        fill(seg.buf)
+        seg.close()
+        SF._untrack(seg)
+
+    def header(buf, pid, start, ns):
+        buf[8:32] = pid.to_bytes(8, "little") + start.to_bytes(8, "little") + ns.to_bytes(8, "little")
+        buf[:8] = SF._MAGIC
+    # a live pid (ours' parent, say pid 1 is always there) whose start time does not match: the pid was reused -> stale
+    raw(lambda b: header(b, 1, SF._start_time(1) + 12345, SF._pid_namespace()))
+    a = SF(name, 4096, create=True)
+    a.close(unlink=True)
+    # another PID namespace: never unlinked
+    raw(lambda b: header(b, 1, 1, SF._pid_namespace() + 1))
+    with pytest.raises(FileExistsError):
+        SF(name, 4096, create=True)
+    shared_memory.SharedMemory(name=name, create=False).unlink()
+    # garbage instead of a header: nobody's -> replaced
+    raw(lambda b: b.__setitem__(slice(0, 8), b"whatever"))
+    c = SF(name, 4096, create=True)
+    assert c.array().size == 4096
+    c.close(unlink=True)

@@ -354,24 +354,27 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         const int64_t rel_bit = (int64_t)my_bit - (int64_t)wbase * 32;
         const uint32_t dummy = kWindowWords + (uint32_t)tid;
         if (!MULTI) {
+            // (No clamping of the word indices: a word behind the group's last one only ever receives ZERO — a block's bits end where
+            // its length says, and the words of a lane without a block are zero — and d + 1 <= local_words + kScratchWords + 1 lies
+            // inside the window + the dummies.  {v, 0} >> s = the part of v that moves into the next word, 0 for s = 0: one alignbit.)
+            static_assert(kWindowWords + kScratchWords + 2 <= kBufWords, "the gather's last word index stays inside the buffer");
             { // the DC symbol (<= 27 bits at the top of db.left)
                 const uint32_t bsh = (uint32_t)(rel_bit & 31), d = (uint32_t)(rel_bit >> 5);
-                const uint32_t hi = live ? db.left >> bsh : 0u, lo = (live && bsh) ? db.left << (32 - bsh) : 0u;
-                (void)__hip_atomic_fetch_or(&buf[d < wn ? d : dummy], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                (void)__hip_atomic_fetch_or(&buf[d + 1 < wn ? d + 1 : dummy], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t left = live ? db.left : 0u;
+                (void)__hip_atomic_fetch_or(&buf[d], left >> bsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_or(&buf[d + 1], __builtin_amdgcn_alignbit(left, 0u, bsh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // every word of the lane's scratch, shifted to its place behind the DC symbol (two LDS ORs per word)
             const int64_t rel_ac = rel_bit + (int64_t)db.len;
             const uint32_t nw = live ? (len_ac + 31) >> 5 : 0u, bsh = (uint32_t)(rel_ac & 31);
-            const uint32_t d0 = (uint32_t)(rel_ac >> 5);
+            const uint32_t d0 = live ? (uint32_t)(rel_ac >> 5) : 0u;
 #pragma unroll
             for (uint32_t j = 0; j < kScratchWords; j++) {
                 if (!PIXO_ANY64(j < nw)) break; // (wave-uniform)
                 const uint32_t v = j < nw ? scratch[tid * kScratchPitch + j] : 0u;
                 const uint32_t d = d0 + j;
-                (void)__hip_atomic_fetch_or(&buf[d < wn ? d : dummy], v >> bsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                (void)__hip_atomic_fetch_or(&buf[d + 1 < wn ? d + 1 : dummy], bsh ? v << (32 - bsh) : 0u, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_or(&buf[d], v >> bsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_or(&buf[d + 1], __builtin_amdgcn_alignbit(v, 0u, bsh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         if (MULTI && PIXO_ANY64(live && rel_bit < (int64_t)wn * 32 && rel_bit + (int64_t)len > 0)) { // (some block of the wavefront lies in the window)
@@ -455,8 +458,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         const uint32_t head = uni(wbase ? s_carry : 0u); // a later round: the previous round's last word is in front of its first aligned word
         uint32_t x[kRows];
         auto aligned_word = [&](uint32_t jl, uint32_t first_prev) -> uint32_t {
-            const uint32_t cur = jl <= wn ? buf[jl] : 0u, prev = jl ? (jl - 1 <= wn ? buf[jl - 1] : 0u) : first_prev;
-            uint32_t v = sh8 ? (prev << (32u - sh8)) | (cur >> sh8) : cur;
+            // (the window is zero behind the round's words — it was zeroed whole — so no index needs clamping; {prev, cur} >> S % 8)
+            const uint32_t cur = buf[jl], prev = jl ? buf[jl - 1] : first_prev;
+            uint32_t v = __builtin_amdgcn_alignbit(prev, cur, sh8);
             v |= wbase + jl == pad_word ? pad_mask : 0u;
             return v;
         };
@@ -577,7 +581,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         }
         // ---- expand + store.  Output offset of the round's first byte (owned byte 4 wbase of the group):
         const uint64_t dst_round = (uint64_t)rest.out_skew + seg_base + (S >> 3) + ff_before_groups + round_first + ff_group;
-        const bool all_at_once = ((uint32_t)dst_round & 15u) + bytes_this + round_ff <= kStageCap;
+        const bool all_at_once = ((uint32_t)dst_round & 15u) + bytes_this + round_ff + 4u <= kStageCap;
         for (int turn = 0; turn < (all_at_once ? 1 : kGroupWaves); turn++) { // (wave by wave when a round's bytes + zeros do not fit the stage)
             const uint32_t before_turn = all_at_once ? 0u : (turn == 0 ? 0u : (turn == 1 ? ff_of_wave[0] : ff_of_wave[0] + ff_of_wave[1]));
             const uint64_t dst0 = dst_round + (all_at_once ? 0u : 2048u * (uint32_t)turn + before_turn);
@@ -595,15 +599,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                 for (int k = 0; k < kRows; k++) {
                     if (4u * (wbase + 512u * (uint32_t)wave + 64u * k) >= limit) continue; // (wave-uniform)
                     const uint32_t first_byte = 4u * (wbase + jl0 + 64u * k);
-                    const uint32_t exist = first_byte < limit ? (limit - first_byte < 4u ? limit - first_byte : 4u) : 0u;
                     const uint32_t m4 = (uint32_t)(flags >> (4 * k)) & 0xFu;
                     const uint32_t to = at0 + 256u * k + before[k];
-#pragma unroll
-                    for (int bb = 0; bb < 4; bb++) {
-                        const uint32_t byte = (x[k] >> (24 - 8 * bb)) & 0xFFu;
-                        const uint32_t moved = (uint32_t)__builtin_popcount(m4 & ((1u << bb) - 1u));
-                        if ((uint32_t)bb < exist) stage[to + bb + moved] = (uint8_t)byte;
+                    // ONE condition per word, not per byte (32 exec masks a round were 64 spilled scalar registers): the word that
+                    // holds the round's last byte writes up to three bytes behind it — into stage bytes nothing reads (the
+                    // stores below stop at the round's end; all_at_once keeps 4 bytes of the stage free for them)
+                    if (first_byte < limit) {
+                        const uint32_t f0 = m4 & 1u, f1 = (m4 >> 1) & 1u, f2 = (m4 >> 2) & 1u;
+                        const uint32_t a1 = to + 1u + f0, a2 = a1 + 1u + f1, a3 = a2 + 1u + f2;
+                        stage[to] = (uint8_t)(x[k] >> 24);
+                        stage[a1] = (uint8_t)(x[k] >> 16);
+                        stage[a2] = (uint8_t)(x[k] >> 8);
+                        stage[a3] = (uint8_t)x[k];
                     }
+                    __builtin_amdgcn_sched_barrier(0); // (row by row: with all 32 addresses computed up front the byte stage spilled vector registers)
                 }
             }
             __syncthreads();

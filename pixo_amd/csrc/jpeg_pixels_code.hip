@@ -111,6 +111,15 @@ __device__ __forceinline__ void lds_only_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// The lane's scratch as the first walk's sink WITHOUT the clamp of LaneSink (jpeg_scan_dev.h): a block longer than its scratch writes
+// on into LDS that belongs to nobody who will read it (see the walk below) — one v_min per position less.  A block has at most 1,665
+// bits = 53 words: the last lane's reach ends inside the window.
+static_assert((kGroup - 1) * kScratchPitch + 54 <= kGroup * kScratchPitch + kBufWords, "a long block's overrun stays inside the LDS area");
+struct LaneSinkOpen {
+    uint32_t *words;
+    __device__ __forceinline__ void or_word(bool, uint32_t word, uint32_t value) { words[word] = value; }
+};
+
 // Phase A of one wavefront (jpeg_kernels.hip phase_a): COUNT items of the tile, HBM -> registers -> planar LDS; all loads are
 // issued before the first conversion.  Behind the pixel loads: this lane's three words of the Huffman tables in the flat
 // walk's form (they arrive with the pixels and go to LDS before the barrier).
@@ -250,10 +259,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     // ---- the walk: 63 AC positions + end-of-block from bit 0 of the lane's scratch; where the packer stands is the length
     uint32_t len_ac;
     {
-        FlatPack<LaneSink> p;
-        p.sink = LaneSink{scratch + tid * kScratchPitch};
+        // (the block in U-FORM from here on — u = v - (v < 0), jpeg_scan_block.h — in place: the walk, the parked copy of a long group
+        // and its second walks all take that form; a block of more than kScratchWords x 32 bits runs over into the scratch of the lanes
+        // behind it and, for the tile's last lanes, into the window: such a group takes the long-block path, which never reads the
+        // scratch and zeroes the window again)
+        block_to_u(qw);
+        FlatPack<LaneSinkOpen> p;
+        p.sink = LaneSinkOpen{scratch + tid * kScratchPitch};
         p.acc = 0; p.pending = 0; p.word = 0;
-        block_pack_flat_ac(qw, wtab, p);
+        block_pack_flat_ac_u(qw, wtab, p);
         len_ac = p.word * 32u + p.pending;
         p.finish();
     }
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     constexpr bool MULTI = decltype(multi_tag)::value;
     for (uint32_t wbase = 0; wbase < (MULTI ? local_words : 1u); wbase += kWin) {
         const uint32_t wn = MULTI ? (local_words - wbase < kWin ? local_words - wbase : kWin) : local_words;
-        if (MULTI && wbase) { // (the first round's window was zeroed before the walk)
+        if (MULTI) { // (also the first round's: the walk of a long block ran over its scratch into the window)
 #pragma unroll
             for (uint32_t i = 0; i < kWindowWords / kGroup; i++) buf[(uint32_t)tid + kGroup * i] = 0;
             __syncthreads();
@@ -391,7 +405,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             p.acc = 0;
             p.pending = (uint32_t)(rel_bit & 31);
             p.word = (uint32_t)(rel_bit >> 5);
-            block_pack_flat(w, prev_dc, wtab, p);
+            block_pack_flat_u(w, prev_dc, wtab, p); // (parked in u-form)
             p.finish();
         }
         const bool last_round = !MULTI || wbase + wn == local_words;

@@ -251,10 +251,29 @@ template <class Sink> PIXO_SDEV void put_symbol(FlatPack<Sink> &p, uint32_t t, u
     p.put_left((t & 0xFFFF0000u) | (value_left >> (t & 0xFFu)), ((t >> 8) & 0xFFu) - m);
 }
 
-// One position of the AC walk, any run length.
-template <class Sink> PIXO_SDEV void walk_position(int k, int v, uint32_t &run16, uint32_t zrl, const uint32_t *wtab, FlatPack<Sink> &p, uint64_t nz_lanes)
+// The U-FORM of a block (round 6): every coefficient v replaced by u = v - (v < 0) — what encode_value writes (huffman.rs:404-418: the
+// low `category` bits of u are the value bits, every bit above them equals the sign; u = 0 only for v = 0, u is never -1).  Two packed
+// 16-bit instructions per PAIR of coefficients in front of the walk instead of two 32-bit ones per coefficient inside it.
+PIXO_SDEV uint32_t pair_to_u(uint32_t w)
 {
-    const bool nz = v != 0;
+#if defined(PIXO_EMU)
+    const int lo = (int16_t)(w & 0xFFFFu), hi = (int16_t)(w >> 16);
+    return ((uint32_t)(uint16_t)(int16_t)(lo - (lo < 0))) | ((uint32_t)(uint16_t)(int16_t)(hi - (hi < 0)) << 16);
+#else
+    typedef short s16pair __attribute__((ext_vector_type(2)));
+    const s16pair v = __builtin_bit_cast(s16pair, w);
+    return __builtin_bit_cast(uint32_t, (s16pair)(v + (v >> 15)));
+#endif
+}
+PIXO_SDEV void block_to_u(uint32_t *w)
+{
+#pragma unroll
+    for (int i = 0; i < 32; i++) w[i] = pair_to_u(w[i]);
+}
+// One position of the AC walk, any run length.  u: the coefficient in u-form.
+template <class Sink> PIXO_SDEV void walk_position_u(int k, int u, uint32_t &run16, uint32_t zrl, const uint32_t *wtab, FlatPack<Sink> &p, uint64_t nz_lanes)
+{
+    const bool nz = u != 0;
     if (k > 16 && __builtin_expect((PIXO_BALLOT64(run16 >= 256u) & nz_lanes) != 0, 0)) { // rare: up to three ZRL codes in front of the symbol
 #pragma unroll
         for (uint32_t i = 0; i < 3; i++) {
@@ -263,28 +282,34 @@ template <class Sink> PIXO_SDEV void walk_position(int k, int v, uint32_t &run16
         }
         run16 = nz ? (run16 & 255u) : run16;
     }
-    const int u = v + (v >> 31);
-    const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u; // v = 0: m = 32, slot 0 of its run = "nothing"
+    const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u; // u = 0: m = 32, slot 0 of its run = "nothing"
     const uint32_t slot = (k > 16 ? (run16 & 255u) : run16) | (m & 15u); // (a lane without a coefficient here may be anywhere in a long run)
     put_symbol(p, wtab[kWalkDc + slot], (uint32_t)u, m);
     run16 = nz ? 0u : run16 + 16u;
 }
-// The AC part of a block (positions 1..63 and the end-of-block code).  `wtab`: this class's kWalkClassWords words.
+// The AC part of a block in u-form (positions 1..63 and the end-of-block code).  `wtab`: this class's kWalkClassWords words.
 // (Round 5 also measured the positions in CHUNKS of 2 / 4 / 8 with the chunk's table words fetched from LDS together: the fused
 // kernel's device time per 4096x4096 file was the same within 1 us for noise, photo and gradient content — the table look-up's
 // latency is not what the walk waits for — profiles/r05_walk_chunks.txt; the simpler form stays.)
-template <class Sink> PIXO_SDEV void block_pack_flat_ac(const uint32_t *w, const uint32_t *wtab, FlatPack<Sink> &p)
+template <class Sink> PIXO_SDEV void block_pack_flat_ac_u(const uint32_t *uw, const uint32_t *wtab, FlatPack<Sink> &p)
 {
     const uint32_t zrl = wtab[kWalkZrl], eob = wtab[kWalkEob];
     uint32_t run16 = 0; // 16 x the zeros since the last non-zero coefficient
 #pragma unroll
     for (int k = 1; k < 64; k++) {
-        const int v = coef_of(w, zigzag(k));
-        const uint64_t nz_lanes = PIXO_BALLOT64(v != 0);
+        const int u = coef_of(uw, zigzag(k));
+        const uint64_t nz_lanes = PIXO_BALLOT64(u != 0);
         if (!nz_lanes) { run16 += 16u; continue; } // (wave-uniform on the device)
-        walk_position(k, v, run16, zrl, wtab, p, nz_lanes);
+        walk_position_u(k, u, run16, zrl, wtab, p, nz_lanes);
     }
     p.put_left(run16 ? (eob & 0xFFFF0000u) : 0u, run16 ? (eob & 0xFFu) : 0u);
+}
+template <class Sink> PIXO_SDEV void block_pack_flat_ac(const uint32_t *w, const uint32_t *wtab, FlatPack<Sink> &p)
+{ // (the same from the block as the quantiser left it: a copy in u-form first — the caller's block is usually dead behind this)
+    uint32_t uw[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) uw[i] = pair_to_u(w[i]);
+    block_pack_flat_ac_u(uw, wtab, p);
 }
 // The DC symbol of a block as bits at the top of a word (encode_block's first step, huffman.rs:430-437): `left` holds the
 // Huffman code followed by the value bits, `len` <= 27 of them.  For a walk whose DC predictor arrives late (the fused
@@ -302,16 +327,24 @@ PIXO_SDEV DcBits dc_symbol_bits(int dc, int prev_dc, const uint32_t *wtab)
     b.len = ((t >> 8) & 0xFFu) - m;
     return b;
 }
-// A whole block: the DC symbol, then the AC part.
-template <class Sink> PIXO_SDEV void block_pack_flat(const uint32_t *w, int prev_dc, const uint32_t *wtab, FlatPack<Sink> &p)
+// A whole block: the DC symbol, then the AC part.  (_u: the block in u-form — its DC is u0 - (u0 >> 31) again)
+template <class Sink> PIXO_SDEV void block_pack_flat_u(const uint32_t *uw, int prev_dc, const uint32_t *wtab, FlatPack<Sink> &p)
 {
     {
-        const int diff = (int)(int16_t)(coef_of(w, 0) - prev_dc); // i16 arithmetic like the reference
+        const int u0 = coef_of(uw, 0), dc = u0 - (u0 >> 31);
+        const int diff = (int)(int16_t)(dc - prev_dc); // i16 arithmetic like the reference
         const int u = diff + (diff >> 31);
         const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u;
         put_symbol(p, wtab[m & 15u], (uint32_t)u, m);
     }
-    block_pack_flat_ac(w, wtab, p);
+    block_pack_flat_ac_u(uw, wtab, p);
+}
+template <class Sink> PIXO_SDEV void block_pack_flat(const uint32_t *w, int prev_dc, const uint32_t *wtab, FlatPack<Sink> &p)
+{
+    uint32_t uw[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) uw[i] = pair_to_u(w[i]);
+    block_pack_flat_u(uw, prev_dc, wtab, p);
 }
 
 // Symbol statistics with the same walk (count_block, jpeg/mod.rs:826-860): `Bump` provides bump(slot, on, amount) —

@@ -232,6 +232,35 @@ def whole_file(job, wl):
                 dev[name]["traffic"], dev[name]["traffic_source"] = tr, tr_src
                 with_copy(job, dev[name], wl.in_bytes, int(nb), us, issue, steps=100)
             smooth["device_time"] = dev
+            # THROUGHPUT with T calling threads (how the reference's rayon users call encode: src/jpeg/mod.rs:88 from a par_iter): every
+            # thread has its own context and stream inside the library, so one file's look-back tail and its way over PCIe run under
+            # another file's kernels.  Device pixels -> each thread's own pinned buffer; wall time over 24 files per thread.
+            try:
+                import threading
+                thr = {}
+                for name, d_img in (("photo", d_p), ("gradient", d_g), ("noise", wl.ins[0])):
+                    row = {}
+                    for T in (1, 2, 4):
+                        bufs = [torch.empty(wl.in_bytes // 2 + (1 << 16), dtype=torch.uint8).pin_memory() for _ in range(T)]
+                        gate = threading.Barrier(T + 1)
+
+                        def work(buf):
+                            jpeg.encode_device_into(buf, d_img, opts)
+                            gate.wait()
+                            for _ in range(24):
+                                jpeg.encode_device_into(buf, d_img, opts)
+                        ths = [threading.Thread(target=work, args=(b,)) for b in bufs]
+                        for t in ths:
+                            t.start()
+                        gate.wait()
+                        t1 = time.perf_counter()
+                        for t in ths:
+                            t.join()
+                        row["us_per_file_%d_threads" % T] = round((time.perf_counter() - t1) / (24 * T) * 1e6, 1)
+                    thr[name] = row
+                smooth["throughput_by_calling_threads"] = thr
+            except Exception as ex:
+                smooth["throughput_by_calling_threads"] = {"error": repr(ex)}
             # the other presets' files: progressive scans (prog_code_kernel: one load and one walk of a block for all
             # scans of its component) and preset 2 (trellis + progressive + optimised tables), same pixels, same pinned buffer
             b = lambda: jpeg.JpegOptions.builder(wl.w, wl.h).quality(wl.q).subsampling(jpeg.Subsampling(wl.ss))

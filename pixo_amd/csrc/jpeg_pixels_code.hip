@@ -90,6 +90,7 @@ struct PRest {
     uint32_t seg_rows;          // tile rows per segment (tiles_y: an image is one segment)
     uint32_t segs_per_img;
     uint32_t seg_blocks64;      // blocks of 64 groups per segment (look-back level two)
+    uint32_t sup_copies, sup_stride; // the block sums exist `sup_copies` times (a power of two), `sup_stride` words apart (look_back_blocks)
     uint32_t gap;               // bytes left free between two segments' scans
     uint32_t rst;               // 1: gap == 2 and a segment's last group writes FF D0+(n & 7) there
     int16_t seed_dc[3];
@@ -220,10 +221,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     const bool last_group = rel + 1 == seg_groups; // of its segment
     // state: [0] abort flag, [1] total bits; per group: bit-count descriptor, tail, three DC words, 0xFF-count descriptor; per
     // segment: two rows of block sums (one per 64 groups, + 1) and the segment's byte count / the offset of the next segment
-    const uint64_t sup_words = (uint64_t)nsegs * rest.seg_blocks64 + 1;
+    const uint32_t sup_copies = rest.sup_copies, sup_stride = rest.sup_stride;
+    const uint64_t sup_words = (uint64_t)sup_copies * sup_stride;
     unsigned long long *desc = a_state + 2, *tails = desc + ngroups, *dcw = tails + ngroups, *desc2 = dcw + 3 * ngroups, *sups = desc2 + ngroups,
                        *sups2 = sups + sup_words, *segdesc = sups2 + sup_words;
-    unsigned long long *SUP = sups + (uint64_t)seg * rest.seg_blocks64, *SUP2 = sups2 + (uint64_t)seg * rest.seg_blocks64;
+    unsigned long long *SUP = sups + (uint64_t)seg * rest.seg_blocks64, *SUP2 = sups2 + (uint64_t)seg * rest.seg_blocks64; // (copy 0)
     unsigned long long *const host_abort = rest.host_totals ? rest.host_totals + 3 : nullptr;
     // (housekeeping: the state block of the launch before this one must be zero when it is used again — cheaper here than a memset launch)
     for (uint64_t i = g * kGroup + tid; i < rest.clear_words; i += ngroups * kGroup) rest.clear[i] = 0;
@@ -256,6 +258,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     static_assert(kWindowWords % (4 * kGroup) == 0 && (kGroup * kScratchPitch) % 4 == 0, "the window in whole 16-byte pieces per lane");
 #pragma unroll
     for (uint32_t i = 0; i < kWindowWords / (4 * kGroup); i++) reinterpret_cast<v4u *>(buf)[(uint32_t)tid + kGroup * i] = v4u{0, 0, 0, 0};
+    // (the predictor from the tile before is ASKED FOR here, in front of the walk, and looked at behind it: the descriptor's way across
+    // the fabric — 0.7-1 us — then lies under the walk instead of between the walk and the group's prefix; one register: flag + value)
+    uint32_t dc_early = 0;
+    if (external && rel > 0) {
+        const unsigned long long d = load_relaxed(&dcw[comp * ngroups + g - 1]);
+        dc_early = (uint32_t)(d >> 32 & 0x40000000u) | (uint32_t)(d & 0xFFFFu);
+    }
     // ---- the walk: 63 AC positions + end-of-block from bit 0 of the lane's scratch; where the packer stands is the length
     uint32_t len_ac;
     {
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     PIXO_STAMP(3);
     if (external && rel > 0) { // (at most three lanes of the group)
         const unsigned long long *src = &dcw[comp * ngroups + g - 1];
-        unsigned long long d = load_relaxed(src);
+        unsigned long long d = (dc_early & 0x40000000u) ? (kDcValid | (dc_early & 0xFFFFu)) : load_relaxed(src);
         uint32_t polls = 0;
         bool gave_up = false;
         while ((d >> 62) == 0) {
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         }
         if (wbase == 0) { // where the group starts in its scan
             if (wave == 0) {
-                const uint64_t sum = look_back_blocks(desc, SUP, g, floor, group_bits, a_state, host_abort, rest.spin_budget);
+                const uint64_t sum = look_back_blocks(desc, SUP, g, floor, group_bits, a_state, host_abort, rest.spin_budget, sup_copies, sup_stride);
                 if (lane == 0) {
                     if (sum == kLookBackFailed) s_abort = 1;
                     s_before = sum;
@@ -535,8 +544,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                 const uint64_t block_first = floor + ((uint64_t)kblk << 6);
                 uint32_t polls = 0;
                 bool gave_up = false;
+                unsigned long long *const SUP2r = SUP2 + (size_t)((uint32_t)g & (sup_copies - 1u)) * sup_stride; // the copy this group reads
                 unsigned long long da = (uint32_t)lane < in_block ? load_relaxed(&desc2[block_first + lane]) : kFlagAggregate;
-                unsigned long long db2 = (uint32_t)lane < kblk ? load_relaxed(&SUP2[lane]) : kFlagAggregate;
+                unsigned long long db2 = (uint32_t)lane < kblk ? load_relaxed(&SUP2r[lane]) : kFlagAggregate;
                 while ((da >> 62) == 0 && !gave_up) {
                     __builtin_amdgcn_s_sleep(kPollSleep);
                     if (++polls > rest.spin_budget) gave_up = true; else da = load_relaxed(&desc2[block_first + lane]);
@@ -548,17 +558,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                     before2 = front;
                     // the block's own sum goes out BEFORE waiting for the other blocks' sums (a group of one round knows its count here):
                     // published behind that wait, the blocks' last groups would form one chain of waits through the whole scan
-                    if (in_block == 63u && last_round && lane == 0) store_relaxed(&SUP2[kblk], kFlagAggregate | ((uint64_t)front + ff_group + round_ff));
+                    if (in_block == 63u && last_round && (uint32_t)lane < sup_copies) store_relaxed(&SUP2[(size_t)lane * sup_stride + kblk], kFlagAggregate | ((uint64_t)front + ff_group + round_ff));
                     for (uint32_t base = 0;;) {
                         while ((db2 >> 62) == 0 && !gave_up) {
                             __builtin_amdgcn_s_sleep(kPollSleep);
-                            if (++polls > rest.spin_budget) gave_up = true; else db2 = load_relaxed(&SUP2[base + lane]);
+                            if (++polls > rest.spin_budget) gave_up = true; else db2 = load_relaxed(&SUP2r[base + lane]);
                         }
                         if (PIXO_ANY64(gave_up)) break;
                         before2 += (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)(db2 & kValueMask)), 63);
                         base += 64;
                         if (base >= kblk) break;
-                        db2 = base + lane < kblk ? load_relaxed(&SUP2[base + lane]) : kFlagAggregate;
+                        db2 = base + lane < kblk ? load_relaxed(&SUP2r[base + lane]) : kFlagAggregate;
                     }
                 }
                 if (PIXO_ANY64(gave_up)) {
@@ -661,7 +671,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     if (aborted) return;
     // the block of 64 groups is complete with its last group: its sum of stuffed zeros for the groups behind
     // (a group of several rounds knows its count only now)
-    if (in_block == 63u && park && tid == 0) store_relaxed(&SUP2[kblk], kFlagAggregate | ((uint64_t)in_front2 + ff_group));
+    if (in_block == 63u && park && (uint32_t)tid < sup_copies) store_relaxed(&SUP2[(size_t)tid * sup_stride + kblk], kFlagAggregate | ((uint64_t)in_front2 + ff_group));
     if (last_group && tid == 0) { // the segment is complete: where the next one begins, where this one ends, the launch's totals
         const uint64_t packed = (S >> 3) + nb_total, stuffed = packed + ff_before_groups + ff_group, end = seg_base + stuffed;
         if (seg + 1 < nsegs) {
@@ -704,9 +714,14 @@ PixelsCodePlan pixels_code_plan(uint32_t W, uint32_t H, bool s420, uint32_t imag
     p.seg_blocks64 = (uint32_t)(((uint64_t)p.seg_rows * p.tiles_x + 63) / 64);
     p.groups = (uint64_t)p.tiles_x * p.tiles_y * images;
     p.segments = (uint64_t)p.segs_per_img * images;
-    // abort flag, total bits; per group: bit-count descriptor, tail, three DC words, 0xFF-count descriptor; per segment: two rows of
-    // block sums (+ 1 each), its byte count (+ 1)
-    p.state_words = 2 + 6 * (size_t)p.groups + 2 * ((size_t)p.segments * p.seg_blocks64 + 1) + (size_t)p.segments + 1;
+    // the block sums in copies (look_back_blocks): a launch of 256 groups or more keeps 16, each 4 KiB + 256 B behind the one before
+    // (or the sums' own size rounded up to 256 B, + 256 B), so that the copies lie in different memory channels
+    const size_t sums = (size_t)p.segments * p.seg_blocks64 + 1;
+    p.sup_copies = p.groups >= 256 ? 16u : 1u;
+    p.sup_stride = (uint32_t)(p.sup_copies == 1 ? sums : (sums <= 512 ? 512 + 32 : ((sums + 31) / 32) * 32 + 32));
+    // abort flag, total bits; per group: bit-count descriptor, tail, three DC words, 0xFF-count descriptor; two rows of block sums
+    // (in copies); per segment its byte count (+ 1)
+    p.state_words = 2 + 6 * (size_t)p.groups + 2 * (size_t)p.sup_copies * p.sup_stride + (size_t)p.segments + 1;
     return p;
 }
 
@@ -743,6 +758,7 @@ hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s42
     rest.host_totals = host_totals; rest.host_segs = host_segs; rest.spin_budget = spin_budget;
     rest.tiles_x = p.tiles_x; rest.tiles_y = p.tiles_y; rest.groups = (uint32_t)p.groups;
     rest.seg_rows = p.seg_rows; rest.segs_per_img = p.segs_per_img; rest.seg_blocks64 = p.seg_blocks64;
+    rest.sup_copies = p.sup_copies; rest.sup_stride = p.sup_stride;
     rest.gap = gap; rest.rst = rst_markers ? 1u : 0u;
     for (int i = 0; i < 3; i++) rest.seed_dc[i] = seed_dc ? seed_dc[i] : (int16_t)0;
     rest.pad_last = pad_last ? 1 : 0;

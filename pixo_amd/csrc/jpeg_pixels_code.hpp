@@ -14,6 +14,7 @@ struct PixelsCodePlan {
     uint32_t tiles_x = 0, tiles_y = 0;
     uint32_t images = 1;
     uint32_t seg_rows = 0, segs_per_img = 1, seg_blocks64 = 0;
+    uint32_t sup_copies = 1, sup_stride = 0; // the look-backs' block sums: copies (a power of two), u64 words from one copy to the next
     uint64_t groups = 0, segments = 0;   // of the whole launch
     size_t state_words = 0;              // u64 words of d_state (zero before the launch)
 };

@@ -48,7 +48,18 @@ PIXO_SDEV int magnitude_bits(int v)
 PIXO_SDEV uint32_t value_bits(int v, int cat) { return (uint32_t)(v < 0 ? v - 1 : v) & ((1u << cat) - 1u); }
 
 // coefficient j (natural order) of a block held as 32 dwords of two i16 each
-PIXO_SDEV int coef_of(const uint32_t *w, int j) { return (int)(int16_t)(w[j >> 1] >> (16 * (j & 1))); }
+PIXO_SDEV int coef_of(const uint32_t *w, int j)
+{
+#if !defined(PIXO_EMU)
+    if ((j & 1) == 0) { // (the low half by ONE bit-field extract: left to itself the compiler tests `w << 16` for zero and shifts that back — three
+                        //  instructions at a position with a coefficient where extract + compare are two)
+        int r;
+        asm("v_bfe_i32 %0, %1, 0, 16" : "=v"(r) : "v"(w[j >> 1]));
+        return r;
+    }
+#endif
+    return (int)(int16_t)(w[j >> 1] >> (16 * (j & 1)));
+}
 
 // Walks one block.  V provides dc(cat, diff), ac(rs, cat, v), zrl(), eob().
 template <class V> PIXO_SDEV void walk_block(const uint32_t *w, int prev_dc, V &vis)
@@ -271,6 +282,9 @@ PIXO_SDEV void block_to_u(uint32_t *w)
     for (int i = 0; i < 32; i++) w[i] = pair_to_u(w[i]);
 }
 // One position of the AC walk, any run length.  u: the coefficient in u-form.
+// (The zero run is counted by the CALLER, behind the join of its wave-uniform "no lane holds a coefficient here" skip: a skip side with
+// code of its own — run16 += 16; continue — made the packer's state a two-sided merge, which the compiler resolved with four register
+// copies per position on BOTH sides; with nothing on the skip side the state is updated in place: 27 -> 23 vector instructions a position.)
 template <class Sink> PIXO_SDEV void walk_position_u(int k, int u, uint32_t &run16, uint32_t zrl, const uint32_t *wtab, FlatPack<Sink> &p, uint64_t nz_lanes)
 {
     const bool nz = u != 0;
@@ -285,7 +299,6 @@ template <class Sink> PIXO_SDEV void walk_position_u(int k, int u, uint32_t &run
     const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u; // u = 0: m = 32, slot 0 of its run = "nothing"
     const uint32_t slot = (k > 16 ? (run16 & 255u) : run16) | (m & 15u); // (a lane without a coefficient here may be anywhere in a long run)
     put_symbol(p, wtab[kWalkDc + slot], (uint32_t)u, m);
-    run16 = nz ? 0u : run16 + 16u;
 }
 // The AC part of a block in u-form (positions 1..63 and the end-of-block code).  `wtab`: this class's kWalkClassWords words.
 // (Round 5 also measured the positions in CHUNKS of 2 / 4 / 8 with the chunk's table words fetched from LDS together: the fused
@@ -299,8 +312,8 @@ template <class Sink> PIXO_SDEV void block_pack_flat_ac_u(const uint32_t *uw, co
     for (int k = 1; k < 64; k++) {
         const int u = coef_of(uw, zigzag(k));
         const uint64_t nz_lanes = PIXO_BALLOT64(u != 0);
-        if (!nz_lanes) { run16 += 16u; continue; } // (wave-uniform on the device)
-        walk_position_u(k, u, run16, zrl, wtab, p, nz_lanes);
+        if (nz_lanes) walk_position_u(k, u, run16, zrl, wtab, p, nz_lanes); // (wave-uniform on the device)
+        run16 = u != 0 ? 0u : run16 + 16u;
     }
     p.put_left(run16 ? (eob & 0xFFFF0000u) : 0u, run16 ? (eob & 0xFFu) : 0u);
 }
@@ -361,14 +374,15 @@ template <class Bump> PIXO_SDEV void block_count_flat(const uint32_t *w, int pre
     for (int k = 1; k < 64; k++) {
         const int v = coef_of(w, zigzag(k));
         const uint64_t nz_lanes = PIXO_BALLOT64(v != 0);
-        if (!nz_lanes) { run16 += 16u; continue; }
         const bool nz = v != 0;
-        if (k > 16 && __builtin_expect((PIXO_BALLOT64(run16 >= 256u) & nz_lanes) != 0, 0)) {
-            h.bump((uint32_t)kWalkZrl, nz && run16 >= 256u, run16 >> 8);
-            run16 = nz ? (run16 & 255u) : run16;
+        if (nz_lanes) { // (wave-uniform on the device; nothing on the other side: walk_position_u)
+            if (k > 16 && __builtin_expect((PIXO_BALLOT64(run16 >= 256u) & nz_lanes) != 0, 0)) {
+                h.bump((uint32_t)kWalkZrl, nz && run16 >= 256u, run16 >> 8);
+                run16 = nz ? (run16 & 255u) : run16;
+            }
+            const uint32_t s = scan_sign_bits(v + (v >> 31)), m = s < 32u ? s : 32u;
+            h.bump((uint32_t)kWalkDc + ((k > 16 ? (run16 & 255u) : run16) | (m & 15u)), nz, 1u);
         }
-        const uint32_t s = scan_sign_bits(v + (v >> 31)), m = s < 32u ? s : 32u;
-        h.bump((uint32_t)kWalkDc + ((k > 16 ? (run16 & 255u) : run16) | (m & 15u)), nz, 1u);
         run16 = nz ? 0u : run16 + 16u;
     }
     h.bump((uint32_t)kWalkEob, run16 != 0u, 1u);
@@ -510,21 +524,22 @@ PIXO_SDEV void band_pack_flat(const uint32_t *w, int ss, int se, const uint32_t 
         if (k < ss || k > se) continue; // (wave-uniform)
         const int v = coef_of(w, zigzag(k));
         const uint64_t nz_lanes = PIXO_BALLOT64(v != 0);
-        if (!nz_lanes) { run16 += 16u; continue; } // (wave-uniform on the device)
         const bool nz = v != 0;
-        seen = seen || nz;
-        if (k > 16 && __builtin_expect((PIXO_BALLOT64(run16 >= 256u) & nz_lanes) != 0, 0)) { // up to three ZRL codes in front of the symbol
+        if (nz_lanes) { // (wave-uniform on the device; nothing on the other side: walk_position_u)
+            seen = seen || nz;
+            if (k > 16 && __builtin_expect((PIXO_BALLOT64(run16 >= 256u) & nz_lanes) != 0, 0)) { // up to three ZRL codes in front of the symbol
 #pragma unroll
-            for (uint32_t i = 0; i < 3; i++) {
-                const bool on = nz && (run16 >> 8) > i;
-                p.put_left(on ? (zrl & 0xFFFF0000u) : 0u, on ? (zrl & 0xFFu) : 0u);
+                for (uint32_t i = 0; i < 3; i++) {
+                    const bool on = nz && (run16 >> 8) > i;
+                    p.put_left(on ? (zrl & 0xFFFF0000u) : 0u, on ? (zrl & 0xFFu) : 0u);
+                }
+                run16 = nz ? (run16 & 255u) : run16;
             }
-            run16 = nz ? (run16 & 255u) : run16;
+            const int u = v + (v >> 31);
+            const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u;
+            const uint32_t slot = (k > 16 ? (run16 & 255u) : run16) | (m & 15u);
+            put_symbol(p, wtab[kWalkDc + slot], (uint32_t)u, m);
         }
-        const int u = v + (v >> 31);
-        const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u;
-        const uint32_t slot = (k > 16 ? (run16 & 255u) : run16) | (m & 15u);
-        put_symbol(p, wtab[kWalkDc + slot], (uint32_t)u, m);
         run16 = nz ? 0u : run16 + 16u;
     }
     *any = seen;
@@ -551,21 +566,22 @@ PIXO_SDEV void bands_pack_flat(const uint32_t *w, bool split, const uint32_t *wt
         }
         const int v = coef_of(w, zigzag(k));
         const uint64_t nz_lanes = PIXO_BALLOT64(v != 0);
-        if (!nz_lanes) { run16 += 16u; continue; } // (wave-uniform on the device)
         const bool nz = v != 0;
-        seen = seen || nz;
-        if (k > 16 && __builtin_expect((PIXO_BALLOT64(run16 >= 256u) & nz_lanes) != 0, 0)) { // up to three ZRL codes in front of the symbol
+        if (nz_lanes) { // (wave-uniform on the device; nothing on the other side: walk_position_u)
+            seen = seen || nz;
+            if (k > 16 && __builtin_expect((PIXO_BALLOT64(run16 >= 256u) & nz_lanes) != 0, 0)) { // up to three ZRL codes in front of the symbol
 #pragma unroll
-            for (uint32_t i = 0; i < 3; i++) {
-                const bool on = nz && (run16 >> 8) > i;
-                p.put_left(on ? (zrl & 0xFFFF0000u) : 0u, on ? (zrl & 0xFFu) : 0u);
+                for (uint32_t i = 0; i < 3; i++) {
+                    const bool on = nz && (run16 >> 8) > i;
+                    p.put_left(on ? (zrl & 0xFFFF0000u) : 0u, on ? (zrl & 0xFFu) : 0u);
+                }
+                run16 = nz ? (run16 & 255u) : run16;
             }
-            run16 = nz ? (run16 & 255u) : run16;
+            const int u = v + (v >> 31);
+            const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u;
+            const uint32_t slot = (k > 16 ? (run16 & 255u) : run16) | (m & 15u);
+            put_symbol(p, wtab[kWalkDc + slot], (uint32_t)u, m);
         }
-        const int u = v + (v >> 31);
-        const uint32_t s = scan_sign_bits(u), m = s < 32u ? s : 32u;
-        const uint32_t slot = (k > 16 ? (run16 & 255u) : run16) | (m & 15u);
-        put_symbol(p, wtab[kWalkDc + slot], (uint32_t)u, m);
         run16 = nz ? 0u : run16 + 16u;
     }
     const int last = split ? 1 : 0;

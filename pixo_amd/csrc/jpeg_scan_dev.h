@@ -141,8 +141,13 @@ __device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t
 // smooth image: 4.5 us median, 8 us for the last groups of 2048; profiles/r04_scan_code_timeline.txt).
 // desc[g] must hold kFlagAggregate | aggregate (publish_aggregate also writes kFlagPrefix for the floor: any flag counts).
 // `sup`: the chain's block sums (zero before the launch).  Every lane returns the sum; kLookBackFailed: gave up waiting.
+// COPIES of the block sums (round 6): every group of a launch reads ALL block sums before it — 2048 groups polling the same two
+// cache lines, which one memory channel serves one request after the other (agent-scope loads are not cached in the XCDs' L2s):
+// the look-back's time followed the number of descriptor bytes, not the number of round trips.  The block's last group therefore
+// stores its sum `copies` times, `stride` words apart (different channels), and a group reads the copy its ticket selects.
 __device__ __forceinline__ uint64_t look_back_blocks(unsigned long long *desc, unsigned long long *sup, uint64_t g, uint64_t floor, uint64_t aggregate,
-                                                     unsigned long long *abort_flag, unsigned long long *host_abort, uint32_t budget)
+                                                     unsigned long long *abort_flag, unsigned long long *host_abort, uint32_t budget,
+                                                     uint32_t copies = 1, uint32_t stride = 0)
 {
     // (the lane as a value of THIS call: the two 64-bit addresses a lane reads from are then computed here — as expressions of the
     // kernel's lane index they are loop invariants of whatever encloses the call, get hoisted, live across the callers' walks and
@@ -154,6 +159,8 @@ __device__ __forceinline__ uint64_t look_back_blocks(unsigned long long *desc, u
     const uint64_t block_first = floor + (k << 6);
     uint32_t polls = 0;
     bool gave_up = false;
+    unsigned long long *const sup_w = sup;                  // copy 0 (the writer's base)
+    sup += (size_t)((uint32_t)g & (copies - 1u)) * stride;  // the copy this group reads
     // (A) the aggregates in front of g inside its block, (B) the first 64 block sums — in flight together
     unsigned long long a = (uint32_t)lane < in_block ? load_relaxed(&desc[block_first + lane]) : kFlagAggregate;
     unsigned long long b = (uint64_t)lane < k ? load_relaxed(&sup[lane]) : kFlagAggregate;
@@ -166,7 +173,7 @@ __device__ __forceinline__ uint64_t look_back_blocks(unsigned long long *desc, u
         return kLookBackFailed;
     }
     const uint32_t in_front = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)(a & kValueMask)), 63); // (< 64 x 2^19)
-    if (in_block == 63 && lane == 0) store_relaxed(&sup[k], kFlagAggregate | ((uint64_t)in_front + aggregate)); // this block's sum, before waiting for the others'
+    if (in_block == 63 && (uint32_t)lane < copies) store_relaxed(&sup_w[(size_t)lane * stride + k], kFlagAggregate | ((uint64_t)in_front + aggregate)); // this block's sum, before waiting for the others'
     uint64_t before = in_front;
     for (uint64_t base = 0;;) { // block sums, 64 per round (one round up to 4096 groups)
         while ((b >> 62) == 0 && !gave_up) {

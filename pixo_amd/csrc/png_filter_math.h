@@ -73,6 +73,10 @@ PIXO_PDEV uint32_t sub4(uint32_t a, uint32_t b)
 { // per-byte a - b (mod 256), no borrow between bytes
     return ((a | kH) - (b & ~kH)) ^ ((a ^ ~b) & kH);
 }
+PIXO_PDEV uint32_t sub4_biased(uint32_t a, uint32_t b)
+{ // (a - b) ^ 0x80 per byte: what the score takes the distance to 0x80 of — the same six operations as sub4, the score's xor saved
+    return ((a | kH) - (b & ~kH)) ^ ((a ^ b) & kH);
+}
 PIXO_PDEV uint32_t avg4(uint32_t a, uint32_t b)
 { // per-byte floor((a + b) / 2)  (fallback.rs:127: u16 sum, / 2): v_lerp_u8 is ((a + b + carry-in bit) >> 1) per byte
     return pixo_lerp_u8(a, b, 0u);
@@ -174,7 +178,17 @@ PIXO_PDEV void score_group(const Raw &r, int k0, int n, uint32_t sc[5])
     group_of<BPP, MASK>(r, k0, n, g);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint32_t m = g.valid[j]; // (all ones without MASK: the ands fold away)
+        if (!MASK) { // a group wholly inside the row: the subtraction leaves its bytes biased by 0x80, the score needs no xor of its own
+            sc[F_SUB] = pixo_sad_u8(sub4_biased(g.cur[j], g.left[j]), kH, sc[F_SUB]);
+            sc[F_UP] = pixo_sad_u8(sub4_biased(g.cur[j], g.up[j]), kH, sc[F_UP]);
+            sc[F_PAETH] = pixo_sad_u8(sub4_biased(g.cur[j], paeth4(g.left[j], g.up[j], g.ul[j])), kH, sc[F_PAETH]);
+            if (!FASTMODE) {
+                sc[F_NONE] = score4(g.cur[j], sc[F_NONE]);
+                sc[F_AVG] = pixo_sad_u8(sub4_biased(g.cur[j], avg4(g.left[j], g.up[j])), kH, sc[F_AVG]);
+            }
+            continue;
+        }
+        const uint32_t m = g.valid[j];
         sc[F_SUB] = score4(filtered(F_SUB, g, j) & m, sc[F_SUB]);
         sc[F_UP] = score4(filtered(F_UP, g, j) & m, sc[F_UP]);
         sc[F_PAETH] = score4(filtered(F_PAETH, g, j) & m, sc[F_PAETH]);

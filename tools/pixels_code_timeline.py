@@ -1,7 +1,7 @@
 """Where the time of one `pixels_code_kernel` launch goes (experiment build: AB_SRC=jpeg_pixels_code.hip tools/ab_build.sh
 timeline -DPIXO_TIMELINE; PIXO_HIP_LIB=tools/ab/ab_timeline.so).  Thread 0 of every group stamps the 100 MHz constant clock at:
 0 entry, 1 phase A done (pixels in LDS), 2 phase B done (quantised), 3 walk done, 4 scan-order prefix done, 5 window gathered,
-6 0xFF counts for all eight alignments done, 7 the look-back done, 8 flags + scans at the group's alignment, 9 expanded, 10 stored
+6 first look-back, 7 census, 8 second look-back, 9 expanded, 10 stored
 (PIXO_TIMELINE_R05=1: the round-5 kernel's stamps — 6 first look-back, 7 census, 8 second look-back, 9 stored).  Printed per stamp: time since the
 launch's first stamp as min / median / p90 / max over groups, and the median duration of every phase.
     python tools/pixels_code_timeline.py [noise|photo|gradient] [size]"""
@@ -20,7 +20,7 @@ from pixo_amd import jpeg
 kinds = sys.argv[1].split(",") if len(sys.argv) > 1 else ["noise", "photo", "gradient"]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 L = ctypes.CDLL(os.environ["PIXO_HIP_LIB"])
-names = ["entry", "phase A", "phase B", "walk", "prefix", "gathered", "census x8", "look-back", "flags+scans", "expanded", "stored"] if not os.environ.get("PIXO_TIMELINE_R05") else ["entry", "phase A", "phase B", "walk", "prefix", "gathered", "look-back 1", "census", "look-back 2", "stored"]
+names = ["entry", "phase A", "phase B", "walk", "prefix", "gathered", "look-back 1", "census", "look-back 2", "expanded", "stored"] if not os.environ.get("PIXO_TIMELINE_R05") else ["entry", "phase A", "phase B", "walk", "prefix", "gathered", "look-back 1", "census", "look-back 2", "stored"]
 NS = len(names)
 o = jpeg.JpegOptions.builder(n, n).quality(80).subsampling(jpeg.Subsampling(1)).build()
 groups = ((n + 511) // 512) * ((n + 15) // 16)

@@ -347,7 +347,7 @@ int pixo_hip_set_producer_stream(void *stream);
 void *pixo_hip_get_producer_stream(void);   /* what the calling thread set (to save and restore it around a call) */
 /* Releases the calling thread's device and pinned buffers AND every context parked by threads that have ended.
  * Buffers only grow while a thread lives; when it ends its context is parked for the next thread (no hipMalloc per
- * request in a thread-per-request server).  Parked contexts are bounded — at most 16 of them and 1 GiB of device +
+ * request in a thread-per-request server).  Parked contexts are bounded — at most 16 of them and 8 GiB of device +
  * pinned memory together, the oldest give their large buffers back first — but a LIVE thread keeps what its largest
  * image needed (a 16384x16384 image: ~2 GB of HBM, ~0.4 GB pinned) until it calls this. */
 int pixo_hip_trim(void);
@@ -359,6 +359,11 @@ int pixo_hip_debug_configure(const char *switches_or_null);
 /* How often a single-pass entropy kernel gave up waiting (its waits on other workgroups are bounded) and the scan was
  * coded again by the multi-pass kernels, in this process.  0 in normal operation. */
 uint64_t pixo_hip_debug_lookback_fallbacks(void);
+/* The dispatch gate of the single-pass kernels (pixo_amd/csrc/dispatch_gate.hpp: calls of several threads are kept from
+ * starting such kernels on an empty device at the same moment — two launches that split the device's workgroup slots wait for
+ * each other until the bounded waits give up): how often a launch found the launch before it, another thread's, not yet fully
+ * dispatched and waited for it (*waits), and how often it stopped waiting after 5 ms (*timeouts).  Either pointer may be NULL. */
+int pixo_hip_debug_dispatch_gate(uint64_t *waits, uint64_t *timeouts);
 /* MEASUREMENT only (bench.py, tools/ab_binaries.py): a plain copy of `bytes` bytes of device memory in the coefficient
  * kernel's launch shape — one generation of 192-thread workgroups, 24 KiB each, 8 non-temporal 16-byte loads then 8
  * non-temporal stores per thread, no arithmetic (pixo_amd/csrc/stream_copy.hip) — so that a run can report what the

@@ -27,7 +27,7 @@ SYMBOLS = [
     "pixo_jpeg_options_from_preset", "pixo_hip_jpeg_encode", "pixo_hip_jpeg_encode_into",
     "pixo_hip_encode_jpeg", "pixo_hip_coeff_geometry", "pixo_hip_jpeg_coeffs",
     "pixo_hip_jpeg_coeffs_device", "pixo_hip_jpeg_coeffs_integer", "pixo_hip_jpeg_coeffs_integer_device", "pixo_hip_jpeg_entropy_encode", "pixo_hip_jpeg_entropy_encode_device",
-    "pixo_hip_jpeg_encode_device", "pixo_hip_jpeg_encode_device_into", "pixo_hip_jpeg_encode_batch_device", "pixo_hip_jpeg_encode_batch_device_into", "pixo_hip_debug_lookback_fallbacks", "pixo_hip_debug_stream_copy", "pixo_hip_debug_stream_io", "pixo_hip_debug_engine_clock", "pixo_hip_debug_scan_device_async", "pixo_hip_debug_scan_device_async_batch", "pixo_hip_png_filter", "pixo_hip_png_filter_device", "pixo_hip_png_filter_async",
+    "pixo_hip_jpeg_encode_device", "pixo_hip_jpeg_encode_device_into", "pixo_hip_jpeg_encode_batch_device", "pixo_hip_jpeg_encode_batch_device_into", "pixo_hip_debug_lookback_fallbacks", "pixo_hip_debug_dispatch_gate", "pixo_hip_debug_stream_copy", "pixo_hip_debug_stream_io", "pixo_hip_debug_engine_clock", "pixo_hip_debug_scan_device_async", "pixo_hip_debug_scan_device_async_batch", "pixo_hip_png_filter", "pixo_hip_png_filter_device", "pixo_hip_png_filter_async",
     "pixo_hip_png_adler32_from_row_sums", "pixo_hip_band",
     "pixo_hip_band_encoder_create", "pixo_hip_band_encoder_destroy", "pixo_hip_band_encoder_rows",
     "pixo_hip_band_encoder_coeffs", "pixo_hip_band_encoder_count", "pixo_hip_band_encoder_lengths",
@@ -94,6 +94,8 @@ def load():
     L.pixo_hip_jpeg_encode_batch_device.argtypes = [C.c_void_p, optp, C.c_uint32, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
     L.pixo_hip_jpeg_encode_batch_device_into.argtypes = [C.c_void_p, optp, C.c_uint32, C.c_void_p, C.c_size_t, szp, szp]
     L.pixo_hip_debug_lookback_fallbacks.restype = C.c_uint64
+    if hasattr(L, "pixo_hip_debug_dispatch_gate"):  # (absent from A/B builds of older trees: tools/ab/)
+        L.pixo_hip_debug_dispatch_gate.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.pixo_hip_debug_stream_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     if hasattr(L, "pixo_hip_debug_engine_clock"):
         L.pixo_hip_debug_engine_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double)]

@@ -271,7 +271,9 @@ void Context::release()
 // re-bound on the adopting thread's hot path: a thread that finds none of its own device makes a new one.  Nothing is
 // destroyed at process exit (the pool is leaked on purpose).
 constexpr size_t kIdleContextsKept = 16;
-constexpr size_t kIdleBytesKept = size_t{1} << 30;    // device + pinned bytes all parked contexts together may keep
+constexpr size_t kIdleBytesKept = size_t{8} << 30;    // device + pinned bytes all parked contexts together may keep (3 % of the 288 GB; round 6: with
+                                                      // 1 GiB four parked contexts of 4096x4096 files shrank — hipFree, a device-wide synchronisation each —
+                                                      // under the feet of the threads that took them over: 217 -> 650-917 us per file, tools/mt_device_files.py)
 constexpr size_t kIdleBufferKept = size_t{64} << 20;  // a parked context that must shrink keeps buffers up to this size
 Context *ContextPool::take(int device)
 {

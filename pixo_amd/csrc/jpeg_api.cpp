@@ -2,6 +2,7 @@
 // usable GPU every compute entry point fails with PIXO_ERR_COMPRESSION and says so.
 #include <algorithm>
 
+#include "dispatch_gate.hpp"
 #include "capi_internal.hpp"
 
 using namespace pixo_capi;
@@ -656,5 +657,13 @@ int pixo_hip_jpeg_encode_batch_device_into(const void *d_pixels, const pixo_jpeg
 }
 
 uint64_t pixo_hip_debug_lookback_fallbacks(void) { return lookback_fallbacks(); }
+int pixo_hip_debug_dispatch_gate(uint64_t *waits, uint64_t *timeouts)
+{
+    unsigned long long w = 0, t = 0;
+    pixo_dev::dispatch_gate_stats(&w, &t);
+    if (waits) *waits = w;
+    if (timeouts) *timeouts = t;
+    return PIXO_OK;
+}
 
 } // extern "C"

@@ -54,6 +54,7 @@
 
 #include <type_traits>
 
+#include "dispatch_gate.hpp"
 #include "jpeg_kernels.hpp"
 #include "jpeg_pixels_code.hpp"
 #include "jpeg_scan_dev.h"
@@ -98,6 +99,8 @@ struct PRest {
     uint32_t out_skew;  // < 16: the bytes before it are somebody else's (the file headers when `out` is the caller's host buffer)
     uint64_t out_cap;   // bytes available from out[0]: nothing is stored beyond (the totals say what was needed)
     uint32_t *block_spill; // groups x 192 x 32 words: where a group of several rounds keeps its quantised blocks between the rounds' walks
+    unsigned long long *gate_slots; // dispatch_gate.hpp: where the launch's last eight workgroups say that they have started
+    unsigned long long gate_seq;
 };
 
 // A value every lane of the wavefront holds alike — read from LDS, say — as the compiler can SEE it: a scalar register.  Branches
@@ -191,6 +194,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     lds_only_barrier();
     PIXO_STAMP(1);
     __builtin_amdgcn_s_setprio(0);
+    if (tid == 0) dispatch_mark(rest_by_value.gate_slots, rest_by_value.gate_seq, ((uint64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
+                                (uint64_t)gridDim.x * gridDim.y * gridDim.z);
     uint32_t qw[32];
     {
         float v[64];
@@ -772,6 +777,8 @@ hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s42
     const uint8_t *px = static_cast<const uint8_t *>(d_px);
     const bool packed = packed_launch(p.groups); // (scalar or packed DCT passes and quantiser: jpeg_kernels.hpp)
     const bool segs = p.segments > 1;
+    const DispatchGate gate(s, p.groups); // (held until the kernel is enqueued)
+    rest.gate_slots = gate.mark().slots; rest.gate_seq = gate.mark().seq;
 #define PIXO_LAUNCH_PC2(MODE, LOAD, PK) do { if (segs) hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, PK, true>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, p.units_x, p.units_y, d_tables, d_state, out, early, rest); \
                                              else hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, PK, false>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, p.units_x, p.units_y, d_tables, d_state, out, early, rest); } while (0)
 #define PIXO_LAUNCH_PC(MODE, LOAD) do { if (packed) PIXO_LAUNCH_PC2(MODE, LOAD, true); else PIXO_LAUNCH_PC2(MODE, LOAD, false); } while (0)

@@ -193,6 +193,17 @@ __device__ __forceinline__ uint64_t look_back_blocks(unsigned long long *desc, u
     return before;
 }
 
+// (one lane of every workgroup, at its start) dispatch_gate.hpp: the launch's last eight workgroups — one per XCD — say that they have
+// started; with fewer than eight workgroups the first one speaks for the missing ones.  lin: the workgroup's linear id, total: all of them.
+__device__ __forceinline__ void dispatch_mark(unsigned long long *slots, unsigned long long seq, uint64_t lin, uint64_t total)
+{
+    if (!slots) return;
+    const uint64_t j = total - 1u - lin;
+    if (j < 8u) __hip_atomic_store(&slots[j], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lin == 0 && total < 8u)
+        for (uint64_t k = total; k < 8u; k++) __hip_atomic_store(&slots[k], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- the LDS bit buffer: sink of block_pack_flat (jpeg_scan_block.h) over a window of words --------------------------
 // Word i of the window is word `first + i` of the stream; every word starts out zero and is only ever OR-ed (LDS
 // atomic without return).  Words outside [0, limit) — a group of very long blocks is written out in more than one

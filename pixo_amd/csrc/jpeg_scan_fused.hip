@@ -32,6 +32,7 @@
 // leave at once — and, if the stream turns out longer, a second launch for the tiles behind the guess.
 #include <hip/hip_runtime.h>
 
+#include "dispatch_gate.hpp"
 #include "jpeg_entropy.hpp"
 #include "jpeg_scan_block.h"
 #include "jpeg_scan_dev.h"
@@ -56,8 +57,9 @@ __device__ unsigned long long g_timeline[8192 * 8];
 template <int MODE, bool SEG>
 __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) void scan_code_kernel
 (const ScanArgs a, unsigned long long *state, uint32_t *stream, unsigned long long *clear, uint32_t clear_words,
- unsigned long long *host_totals, const ScanPiece piece, const SegArgs seg, uint32_t spin_budget)
+ unsigned long long *host_totals, const ScanPiece piece, const SegArgs seg, uint32_t spin_budget, const GateMark gate)
 {
+    if (threadIdx.x == 0) dispatch_mark(gate.slots, gate.seq, blockIdx.x, gridDim.x);
     // state: [0] abort flag, [1] total bits (out), [2 ..] per group: descriptor, then per group: tail
     __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
     __shared__ uint32_t tab[kWalkWords]; // the Huffman tables in the flat walk's form (jpeg_scan_block.h)
@@ -335,8 +337,9 @@ extern "C" __attribute__((visibility("default"))) int pixo_hip_debug_scan_timeli
 constexpr uint32_t kEobSyms = 16; // the packed words of the class's symbols 0x00 .. 0xE0 (end-of-band runs), one spare
 __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) void prog_code_kernel
 (const ProgCode a, const SegArgs seg, unsigned long long *state, uint32_t *stream0, unsigned long long *clear, uint32_t clear_words,
- unsigned long long *host_totals, uint32_t spin_budget)
+ unsigned long long *host_totals, uint32_t spin_budget, const GateMark gate)
 {
+    if (threadIdx.x == 0) dispatch_mark(gate.slots, gate.seq, blockIdx.x, gridDim.x);
     __shared__ __attribute__((aligned(16))) uint32_t buf[kBufWords];
     __shared__ uint32_t tab[kWalkClassWords];
     __shared__ uint32_t eobs[kEobSyms];
@@ -800,8 +803,9 @@ __global__ __launch_bounds__(kStuffThreads) __attribute__((amdgpu_waves_per_eu(4
                                                                    uint8_t *out, uint32_t out_skew, uint64_t out_cap, uint64_t tile_offset,
                                                                    unsigned long long *clear, uint32_t clear_words,
                                                                    unsigned long long *host_totals, unsigned long long *out_chain,
-                                                                   uint32_t piece, const SegArgs seg, uint32_t spin_budget)
+                                                                   uint32_t piece, const SegArgs seg, uint32_t spin_budget, const GateMark gate)
 {
+    if (threadIdx.x == 0) dispatch_mark(gate.slots, gate.seq, blockIdx.x, gridDim.x);
     // The bytes to stuff are the stream's bits from bit `shift` (< 8) on: 0 for a whole image (all bytes, the padded
     // last one included); for a band that starts inside a byte of the scan, its first `shift` bits belong to the byte
     // it shares with the band before, its whole bytes follow, the bits left over are the next band's business.
@@ -1026,7 +1030,9 @@ hipError_t launch_scan_code(const ScanArgs &a, unsigned long long *d_state, bool
     if (ngroups > 0x7FFFFFFFull || clear_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)ngroups;
     const uint32_t cw = d_clear ? (uint32_t)clear_words : 0u;
-#define PIXO_LAUNCH_CODE(MODE, SEG) hipLaunchKernelGGL((scan_code_kernel<MODE, SEG>), dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals, piece, seg, spin_budget)
+    const DispatchGate gate(s, ngroups); // (held until the kernel is enqueued: dispatch_gate.hpp)
+    const GateMark gm = gate.mark();
+#define PIXO_LAUNCH_CODE(MODE, SEG) hipLaunchKernelGGL((scan_code_kernel<MODE, SEG>), dim3(grid), dim3(kGroup), 0, s, a, d_state, d_stream, d_clear, cw, host_totals, piece, seg, spin_budget, gm)
     if (seg_or_null) {
         if (a.mode == 2) PIXO_LAUNCH_CODE(2, true); else if (a.mode == 1) PIXO_LAUNCH_CODE(1, true); else PIXO_LAUNCH_CODE(0, true);
     } else {
@@ -1072,8 +1078,9 @@ hipError_t launch_prog_code(const ProgCode &a, const SegArgs &seg, unsigned long
         hipError_t e = hipMemsetAsync(d_state, 0, prog_code_state_words(groups) * 8, s);
         if (e != hipSuccess) return e;
     }
+    const DispatchGate gate(s, grid); // (held until the kernel is enqueued: dispatch_gate.hpp)
     hipLaunchKernelGGL(prog_code_kernel, dim3((unsigned)grid), dim3(kGroup), 0, s, a, seg, d_state, d_stream, d_clear,
-                       d_clear ? (uint32_t)clear_words : 0u, host_totals, spin_budget);
+                       d_clear ? (uint32_t)clear_words : 0u, host_totals, spin_budget, gate.mark());
     return hipGetLastError();
 }
 
@@ -1137,12 +1144,14 @@ hipError_t launch_stuff_fused(const uint32_t *d_stream, unsigned long long *d_co
     if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (code_state_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const SegArgs seg = seg_or_null ? *seg_or_null : SegArgs{};
+    const DispatchGate gate(s, tiles); // (held until the kernel is enqueued: dispatch_gate.hpp)
+    const GateMark gm = gate.mark();
     if (seg_or_null)
         hipLaunchKernelGGL(stuff_fused_kernel<true>, dim3((unsigned)tiles), dim3(kStuffThreads), 0, s, d_stream, d_code_state, shift, band ? 1u : 0u,
-                           d_state, d_out, out_skew, out_cap, first_tile, d_code_state, (uint32_t)code_state_words, host_totals, d_out_chain, piece, seg, spin_budget);
+                           d_state, d_out, out_skew, out_cap, first_tile, d_code_state, (uint32_t)code_state_words, host_totals, d_out_chain, piece, seg, spin_budget, gm);
     else
         hipLaunchKernelGGL(stuff_fused_kernel<false>, dim3((unsigned)tiles), dim3(kStuffThreads), 0, s, d_stream, d_code_state, shift, band ? 1u : 0u,
-                           d_state, d_out, out_skew, out_cap, first_tile, d_code_state, (uint32_t)code_state_words, host_totals, d_out_chain, piece, seg, spin_budget);
+                           d_state, d_out, out_skew, out_cap, first_tile, d_code_state, (uint32_t)code_state_words, host_totals, d_out_chain, piece, seg, spin_budget, gm);
     return hipGetLastError();
 }
 

@@ -509,6 +509,13 @@ def lookback_fallbacks() -> int:
     return int(_lib.load().pixo_hip_debug_lookback_fallbacks())
 
 
+def dispatch_gate_stats():
+    """(waits, timeouts) of the single-pass kernels' dispatch gate (include/pixo_hip.h pixo_hip_debug_dispatch_gate; tests, tools)."""
+    w, t = C.c_uint64(0), C.c_uint64(0)
+    _lib.load().pixo_hip_debug_dispatch_gate(C.byref(w), C.byref(t))
+    return int(w.value), int(t.value)
+
+
 def band(width, height, color_type, subsampling, parts, index):
     """MCU-row band `index` of `parts`: dict(row_begin,row_end,y_offset,y_blocks,
     c_offset,c_blocks).  Bands are independent sub-images of the same width."""

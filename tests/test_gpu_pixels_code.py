@@ -202,3 +202,41 @@ def test_fused_kernel_batch_with_long_groups_and_small_output():
             jpeg.encode_batch_device_into(small[: total - 1], d, o, n)
         assert e.value.needed == total and int(small[total - 1]) == 0xA5
     jpeg.debug_configure(None)
+
+
+@pytest.mark.parametrize("w,h,threads", [(4096, 4096, 4), (1920, 1080, 6), (640, 480, 8)])
+def test_calling_threads_start_single_pass_kernels_together_without_starving_each_other(w, h, threads):
+    """Several threads, each with a context and a stream of its own, start together (pixo's rayon callers: src/jpeg/mod.rs:88 from a
+    par_iter).  Two single-pass launches that split an empty device's workgroup slots between them wait for each other until the
+    bounded waits give up (0.75 s, then the multi-pass kernels): the dispatch gate (pixo_amd/csrc/dispatch_gate.hpp) keeps ONE
+    such launch at a time in its dispatch phase unless they fit the device together.  Every file = the oracle's, no fallback."""
+    import threading
+    import torch
+    px = synth.photo(w, h, 17)
+    d = torch.from_numpy(np.ascontiguousarray(px)).cuda()
+    o = jpeg.JpegOptions.builder(w, h).color_type(ColorType(2)).quality(80).subsampling(jpeg.Subsampling(1)).build()
+    want = O.encode(px, O.make_options(w, h, 2, 80, 1))
+    fb0 = jpeg.lookback_fallbacks()
+    for two_kernel in (False, True):
+        jpeg.debug_configure("two_kernel_scan" if two_kernel else None)
+        try:
+            for rep in range(3):  # (fresh threads every time: they adopt parked contexts and start at the same moment)
+                gate = threading.Barrier(threads)
+                bad = []
+
+                def work():
+                    gate.wait()
+                    for _ in range(4):
+                        if jpeg.encode_device(d, o) != want:
+                            bad.append(1)
+                ts = [threading.Thread(target=work) for _ in range(threads)]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
+                assert not bad
+        finally:
+            jpeg.debug_configure(None)
+    assert jpeg.lookback_fallbacks() == fb0
+    waits, timeouts = jpeg.dispatch_gate_stats()
+    assert timeouts == 0, (waits, timeouts)

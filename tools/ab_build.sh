@@ -9,7 +9,7 @@ cd "$(dirname "$0")/../pixo_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize"
 OBJ=/tmp/pixo_ab_obj; mkdir -p $OBJ ../../tools/ab
 SRC=${AB_SRC:-jpeg_kernels.hip}; BASE=${SRC%.*}
-for f in jpeg_kernels.hip jpeg_pixels_code.hip jpeg_integer.hip jpeg_entropy.hip jpeg_scan_fused.hip jpeg_trellis.hip png_filter.hip stream_copy.hip context.cpp scan_job.cpp pieces.cpp progressive.cpp jpeg_api.cpp png_api.cpp bands.cpp jpeg_host.cpp; do
+for f in jpeg_kernels.hip jpeg_pixels_code.hip jpeg_integer.hip jpeg_entropy.hip jpeg_scan_fused.hip jpeg_trellis.hip png_filter.hip stream_copy.hip context.cpp dispatch_gate.cpp scan_job.cpp pieces.cpp progressive.cpp jpeg_api.cpp png_api.cpp bands.cpp jpeg_host.cpp; do
   o=$OBJ/${f%.*}.o
   K=""; { [ $f = jpeg_kernels.hip ] || [ $f = jpeg_pixels_code.hip ]; } && K="-mllvm -amdgpu-kernarg-preload-count=14"
   if [ ! -f $o ] || [ $f -nt $o ] || [ -n "$(find . ../../include -name '*.h*' -newer $o | head -1)" ]; then /opt/rocm/bin/hipcc $FLAGS $K -c $f -o $o & fi
@@ -23,7 +23,7 @@ while [ $# -ge 2 ]; do
   /opt/rocm/bin/hipcc $FLAGS $P $2 -c $SRC -o $OBJ/${BASE}_$1.o
   OBJS=""; for b in jpeg_kernels jpeg_pixels_code jpeg_integer jpeg_entropy jpeg_scan_fused jpeg_trellis png_filter stream_copy; do
     if [ $b = $BASE ]; then OBJS="$OBJS $OBJ/${b}_$1.o"; else OBJS="$OBJS $OBJ/$b.o"; fi; done
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../tools/ab/ab_$1.so $OBJS $OBJ/context.o $OBJ/scan_job.o $OBJ/pieces.o $OBJ/progressive.o $OBJ/jpeg_api.o $OBJ/png_api.o $OBJ/bands.o $OBJ/jpeg_host.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../tools/ab/ab_$1.so $OBJS $OBJ/context.o $OBJ/dispatch_gate.o $OBJ/scan_job.o $OBJ/pieces.o $OBJ/progressive.o $OBJ/jpeg_api.o $OBJ/png_api.o $OBJ/bands.o $OBJ/jpeg_host.o
   echo "built ab_$1.so ($2)"
   shift 2
 done

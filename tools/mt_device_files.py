@@ -28,17 +28,20 @@ for kind in kinds:
     px = synth.noise(W, H, 42) if kind == "noise" else (synth.photo(W, H, 42) if kind == "photo" else synth.gradient_rgb(W, H))
     d = torch.from_numpy(np.ascontiguousarray(px)).cuda()
     row = []
-    for T in (1, 2, 3, 4, 8):
+    for T in [int(x) for x in os.environ.get('TS', '1,2,3,4,8').split(',')]:
         bufs = [torch.empty(W * H * 3 // 2 + (1 << 16), dtype=torch.uint8).pin_memory() for _ in range(T)]
         gate = threading.Barrier(T + 1)
         N = 24
+        calls = []
 
         def work(buf):
             jpeg.encode_device_into(buf, d, O)
             jpeg.encode_device_into(buf, d, O)
             gate.wait()
             for _ in range(N):
+                t0 = time.perf_counter()
                 jpeg.encode_device_into(buf, d, O)
+                calls.append((time.perf_counter() - t0) * 1e6)
         ths = [threading.Thread(target=work, args=(b,)) for b in bufs]
         for t in ths:
             t.start()
@@ -46,6 +49,7 @@ for kind in kinds:
         t1 = time.perf_counter()
         for t in ths:
             t.join()
-        row.append("T=%d %.1f" % (T, (time.perf_counter() - t1) / (N * T) * 1e6))
+        cs = sorted(calls)
+        row.append("T=%d %.1f (fb %d; calls median %.0f, three slowest %s)" % (T, (time.perf_counter() - t1) / (N * T) * 1e6, jpeg.lookback_fallbacks(), cs[len(cs) // 2], " ".join("%.0f" % x for x in cs[-3:])))
         del bufs
     print(kind, "switches", sw, "| us per file:", "  ".join(row))

@@ -722,8 +722,9 @@ PixelsCodePlan pixels_code_plan(uint32_t W, uint32_t H, bool s420, uint32_t imag
     // the block sums in copies (look_back_blocks): a launch of 256 groups or more keeps 16, each 4 KiB + 256 B behind the one before
     // (or the sums' own size rounded up to 256 B, + 256 B), so that the copies lie in different memory channels
     const size_t sums = (size_t)p.segments * p.seg_blocks64 + 1;
-    p.sup_copies = p.groups >= 256 ? 16u : 1u;
-    p.sup_stride = (uint32_t)(p.sup_copies == 1 ? sums : (sums <= 512 ? 512 + 32 : ((sums + 31) / 32) * 32 + 32));
+    const SupLayout sl = sup_layout(p.groups, sums);
+    p.sup_copies = sl.copies;
+    p.sup_stride = sl.stride;
     // abort flag, total bits; per group: bit-count descriptor, tail, three DC words, 0xFF-count descriptor; two rows of block sums
     // (in copies); per segment its byte count (+ 1)
     p.state_words = 2 + 6 * (size_t)p.groups + 2 * (size_t)p.sup_copies * p.sup_stride + (size_t)p.segments + 1;

@@ -141,6 +141,14 @@ __device__ __forceinline__ uint64_t look_back(unsigned long long *desc, uint64_t
 // smooth image: 4.5 us median, 8 us for the last groups of 2048; profiles/r04_scan_code_timeline.txt).
 // desc[g] must hold kFlagAggregate | aggregate (publish_aggregate also writes kFlagPrefix for the floor: any flag counts).
 // `sup`: the chain's block sums (zero before the launch).  Every lane returns the sum; kLookBackFailed: gave up waiting.
+// How many copies of its block sums a launch keeps and how far apart (u64 words): launches of 256 groups and more keep 16 copies,
+// each 4 KiB + 256 B behind the one before (or the sums' own size rounded up to 256 B, + 256 B): different memory channels.
+struct SupLayout { uint32_t copies, stride; };
+__host__ __device__ inline SupLayout sup_layout(uint64_t groups, uint64_t sums)
+{
+    if (groups < 256) return SupLayout{1u, (uint32_t)sums};
+    return SupLayout{16u, (uint32_t)(sums <= 512 ? 512 + 32 : ((sums + 31) / 32) * 32 + 32)};
+}
 // COPIES of the block sums (round 6): every group of a launch reads ALL block sums before it — 2048 groups polling the same two
 // cache lines, which one memory channel serves one request after the other (agent-scope loads are not cached in the XCDs' L2s):
 // the look-back's time followed the number of descriptor bytes, not the number of round trips.  The block's last group therefore

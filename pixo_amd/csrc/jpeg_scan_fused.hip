@@ -84,8 +84,10 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     const bool surplus = SEG && first_in_chain >= nblocks_chain; // (the last segment is shorter: its surplus groups only do the housekeeping)
     const uint64_t ngroups_total = SEG ? seg.nsegs * seg.groups : (a.nblocks + kGroup - 1) / kGroup;
     unsigned long long *desc = state + 2, *tails = state + 2 + ngroups_total;
-    // block sums of the two-level look-back: per chain (the scan; a segment) one word per 64 groups, behind the tails
+    // block sums of the two-level look-back: per chain (the scan; a segment) one word per 64 groups, behind the tails — in copies
+    // (sup_layout, jpeg_scan_dev.h: this is copy 0)
     unsigned long long *sup = state + 2 + 2 * ngroups_total + (SEG ? sidx * ((seg.groups + 63) >> 6) : 0);
+    const SupLayout sl = sup_layout(ngroups_total, SEG ? seg.nsegs * ((seg.groups + 63) >> 6) + 1 : ((ngroups_total + 63) >> 6) + 1);
     unsigned long long *const host_abort = host_totals ? host_totals + 3 : nullptr;
     // A scan coded piece by piece (ScanPiece, jpeg_entropy.hpp): the piece's stream is byte-aligned with the SCAN — its
     // first `lead` bits are the end of the piece before — so that the stuffing kernel can work on it without a shift.
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(kGroup) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 #ifdef PIXO_LOOK_CHAINED // (A/B: the chained decoupled look-back of rounds 2-4)
                     const uint64_t sum = look_back(desc, g, floor_g, group_bits, state, host_abort, spin_budget);
 #else
-                    const uint64_t sum = look_back_blocks(desc, sup, g, floor_g, group_bits, state, host_abort, spin_budget);
+                    const uint64_t sum = look_back_blocks(desc, sup, g, floor_g, group_bits, state, host_abort, spin_budget, sl.copies, sl.stride);
 #endif
                     if (lane == 0) {
                         if (sum == kLookBackFailed) s_abort = 1;
@@ -999,12 +1001,14 @@ __global__ __launch_bounds__(kStuffThreads) __attribute__((amdgpu_waves_per_eu(4
 size_t fused_code_state_words(uint64_t nblocks)
 { // abort flag, total bits, per group: descriptor + tail, per 64 groups: block sum (+ 1)
     const size_t groups = (size_t)((nblocks + kGroup - 1) / kGroup);
-    return 2 + 2 * groups + (groups + 63) / 64 + 1;
+    const SupLayout sl = sup_layout(groups, (groups + 63) / 64 + 1);
+    return 2 + 2 * groups + (size_t)sl.copies * sl.stride;
 }
 size_t fused_code_state_words_seg(uint64_t nsegs, uint64_t seg_blocks)
 {
     const size_t per = (size_t)((seg_blocks + kGroup - 1) / kGroup);
-    return 2 + 2 * (size_t)nsegs * per + (size_t)nsegs * ((per + 63) / 64) + 1;
+    const SupLayout sl = sup_layout((uint64_t)nsegs * per, (uint64_t)nsegs * ((per + 63) / 64) + 1);
+    return 2 + 2 * (size_t)nsegs * per + (size_t)sl.copies * sl.stride;
 }
 size_t fused_stuff_state_words(uint64_t max_stream_bytes) { return 3 + (size_t)((max_stream_bytes + kTileBytes - 1) / kTileBytes); }
 uint32_t seg_groups(uint64_t seg_blocks) { return (uint32_t)((seg_blocks + kGroup - 1) / kGroup); }

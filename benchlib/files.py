@@ -100,12 +100,12 @@ def batch_whole_files(job, q, n_batches=7):
         photo = {"photo_error": repr(ex)}
     # DEVICE time of the batch (the PCIe-bound 1.7 ms hides the kernels): the product's kernels for the 64 images enqueued back to back
     # (pixo_hip_debug_scan_device_async_batch: no waits, nothing delivered), HIP events on the launch stream — the default form
-    # (coefficient kernel + scan_code + stuffing kernel over the batch) and the fused pixel -> scan kernel with every image a segment
-    # (debug switch fused_batch; slower on a launch of several generations, which is why it is not the default)
+    # (the fused pixel -> scan kernel with every image a segment, since the second session of round 6) and the two-kernel form it
+    # replaced (coefficient kernel + scan_code + stuffing kernel over the batch; debug switch two_kernel_scan)
     device = {}
     try:
         stream = torch.cuda.current_stream().cuda_stream
-        for name, sw in (("default_two_kernel_form", None), ("fused_kernel_every_image_a_segment", "fused_batch")):
+        for name, sw in (("default_fused_kernel_every_image_a_segment", None), ("two_kernel_form", "two_kernel_scan")):
             jpeg.debug_configure(sw)
             form = jpeg.debug_scan_device_async(d, opts, stream=stream, batch=n)
             job.sync()

@@ -53,8 +53,8 @@ int hip_fail(hipError_t e, const char *what); // pixo::Error::CompressionError(S
 //   no_direct_small    ... and never, not even for small files (their default since round 4)
 //   one_piece          never code a scan in pieces
 //   two_kernel_scan    never use the fused pixel -> bit stream kernel (jpeg_pixels_code.hip): coefficient kernel + scan_code as in rounds 2-4
-//   fused_batch        batches through the fused kernel as well, every image a segment (round 6; slower than the two-kernel form for
-//                      launches of several generations of workgroups — profiles/r06_batch_device_time.txt — so not the default)
+//   fused_batch        batches through the fused kernel whatever the images' width (the default sends batches of images whose 512-pixel
+//                      tiles are at least three quarters full through it, every image a segment: scan_job.cpp pixels_code_usable)
 //   piece_groups=n     equal pieces of n groups of 192 blocks instead of 2048
 //   piece_medium=n     growing pieces from n groups on instead of 1024, whatever the last file's size
 //   piece_schedule=a:b:c   their relative sizes (default 1:3)

@@ -442,12 +442,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                     if (sum == kLookBackFailed) s_abort = 1;
                     s_before = sum;
                 }
-            } else if (wave == 1 && seg > 0 && !seg_late) { // meanwhile: where this segment's bytes begin — a look-back over the SEGMENTS' byte counts
-                const uint64_t sb = look_back(segdesc, seg, 0, 0, a_state, host_abort, rest.spin_budget);
-                if (lane == 0) {
-                    if (sb == kLookBackFailed) s_abort = 1;
-                    s_segbase = sb;
-                }
             } else if (tid == 128 && rel > 0) { // meanwhile: the seven bits in front of this group (used if it starts inside a byte)
                 unsigned long long t = load_relaxed(&tails[g - 1]);
                 uint32_t polls = 0;
@@ -468,7 +462,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             PIXO_STAMP(6);
             if (uni(s_abort)) { aborted = true; return; }
             S = uni64(s_before);
-            seg_base = uni64(s_segbase);
             sh8 = (uint32_t)(S & 7);
             const uint64_t end_bits = (uint64_t)sh8 + group_bits; // in aligned bits: bit 0 = the first bit of the group's first owned byte
             const bool pad = last_group && rest.pad_last;
@@ -585,12 +578,25 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
                 }
 #undef lane
 #define lane lane_again
+            } else if (SEG && wave == 1 && seg > 0 && !seg_late) {
+                // meanwhile: where this segment's bytes begin — a look-back over the SEGMENTS' byte counts.  HERE, behind the group's own
+                // 0xFF count going out, not beside the first look-back: the count of the segment before is known when ITS last group is
+                // through its second look-back, and a group that waited for that in front of its census kept its own count from the
+                // groups behind it — every segment's last group then finished one census + one look-back (6.5 us) behind the last group
+                // of the segment before: a serial chain through all segments (64 x 1080p: 414-453 us; 32 x 4096x512: 216-236 us
+                // against 126-141 us for the same groups in 4 segments, profiles/r06_fused_batches_chain.txt).
+                const uint64_t sb = look_back(segdesc, seg, 0, 0, a_state, host_abort, rest.spin_budget);
+                if (lane == 0) {
+                    if (sb == kLookBackFailed) s_abort = 1;
+                    s_segbase = sb;
+                }
             }
             __syncthreads();
             PIXO_STAMP(8);
             if (uni(s_abort)) { aborted = true; return; }
             ff_before_groups = uni64(s_before);
             in_front2 = uni(s_front2);
+            if (SEG) seg_base = uni64(s_segbase);
             if (!MULTI && seg_late && nsegs > 1) { // (workgroup-uniform) a segment's last group of one round: the segment's bytes are known — out
                                                     // they go, and only then: where does the segment begin?
                 if (tid == 0 && seg + 1 < nsegs) publish_aggregate(segdesc, seg, 0, (S >> 3) + nb_total + ff_before_groups + round_ff + rest.gap);

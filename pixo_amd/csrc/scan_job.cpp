@@ -326,11 +326,17 @@ bool pixels_code_usable(const ScanJob &j, const pixo_jpeg_options &o, const pixo
 { // one uninterrupted RGB scan, the images of a batch, or restart intervals of whole MCU rows — with GIVEN tables.  (Independent of
   // which tuple kernels scan_begin chose: segments of any size are chains of the fused kernel.)
     if (j.band || g.gray || o.optimize_huffman || o.progressive || debug().two_kernel_scan || debug().multipass_entropy || t_force_multipass) return false;
-    // A batch is a launch of SEVERAL generations of workgroups.  The fused kernel's workgroup lives ~40 us, most of it waiting (pixel
-    // loads, two look-backs), and only eight fit a CU (LDS): 64 x 1080p take 434-521 us through it against 306-443 us through
-    // coefficient kernel + scan_code + stuffing kernel, whose workgroups wait for less (profiles/r06_batch_device_time.txt).
-    // One generation (a single image up to 4096x4096) is where the fused kernel wins.  Batches: on request only.
-    if (batch > 1 && !debug().fused_batch) return false;
+    // Batches: every image a segment of ONE launch of the fused kernel — since the segments' byte counts are asked for BEHIND a group's own
+    // 0xFF count (jpeg_pixels_code.hip; in front of it every segment's last group finished 6.5 us behind the one before: 64 x 1080p took
+    // 414-521 us) a batch runs at the rate of one large image: 64 x 1080p 245 / 272 / 340 us (gradient / photo / noise) against 306 / 335 /
+    // 444 us through coefficient kernel + scan_code + stuffing kernel (profiles/r06_fused_batches_chain.txt).  The fused kernel's group is a
+    // 512-pixel TILE: images whose tiles are mostly empty (640 px wide: 62 %) keep the two-kernel form, whose groups are dense
+    // (256 x 640x480: 207-233 against 195-211 us).  debug switch fused_batch: the fused kernel whatever the width.
+    if (batch > 1 && !debug().fused_batch) {
+        const uint32_t unit = g.s420 ? 16u : 8u, per_tile = g.s420 ? 32u : 64u;
+        const uint32_t units_x = (o.width + unit - 1) / unit, tiles_x = (units_x + per_tile - 1) / per_tile;
+        if (static_cast<uint64_t>(units_x) * 4 < static_cast<uint64_t>(tiles_x) * per_tile * 3) return false;
+    }
     const uint32_t restart = (batch == 1 && scan_has_restart_markers(o, g)) ? o.restart_interval : 0;
     return pixo_dev::pixels_code_supported(o.width, o.height, g.gray, g.s420, batch, restart);
 }

@@ -128,8 +128,8 @@ def test_fused_kernel_batches_every_file_equals_the_oracle(w, h, n, ss, q):
     o = _opts(w, h, ss, q)
     want = [O.encode(px, O.make_options(w, h, 2, q, ss)) for px in imgs]
     total = sum(len(f) for f in want)
-    # (batches take the fused kernel on request only — debug switch fused_batch: a launch of several generations of workgroups
-    # is faster through the two-kernel form, profiles/r06_batch_device_time.txt — so the switch is what this test is about)
+    # (switch fused_batch: the fused kernel whatever the width; by default batches of images whose 512-pixel tiles are at least three
+    # quarters full take it — scan_job.cpp pixels_code_usable — and the others coefficient kernel + scan_code + stuffing kernel)
     jpeg.debug_configure("fused_batch")
     try:
         assert _form(d, o, n) == 1, "the batch did not take the fused kernel"
@@ -148,9 +148,18 @@ def test_fused_kernel_batches_every_file_equals_the_oracle(w, h, n, ss, q):
         assert [bytes(f) for f in files] == want
     finally:
         jpeg.debug_configure(None)
-    if w * h >= 96 * 64:  # (the measuring entry wants a single-pass job: images of 96 blocks and more)
-        assert _form(d, o, n) == 0
+    unit, per_tile = (16, 32) if ss == 1 else (8, 64)
+    units_x = (w + unit - 1) // unit
+    tiles_x = (units_x + per_tile - 1) // per_tile
+    by_default = 1 if units_x * 4 >= tiles_x * per_tile * 3 else 0
+    if by_default or w * h >= 96 * 64:  # (the measuring entry wants a single-pass job: images of 96 blocks and more for the tuple kernels)
+        assert _form(d, o, n) == by_default
     assert [bytes(f) for f in jpeg.encode_batch_device(d, o, n)] == want
+    jpeg.debug_configure("two_kernel_scan")
+    try:
+        assert [bytes(f) for f in jpeg.encode_batch_device(d, o, n)] == want
+    finally:
+        jpeg.debug_configure(None)
     assert jpeg.lookback_fallbacks() == 0
 
 

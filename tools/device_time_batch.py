@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Device time of configs[2] — 64 x 1920x1080 RGB8, q=80, 4:2:0, device resident — through pixo_hip_debug_scan_device_async_batch (the
 product's kernels of the one-pass batch, no waits, no PCIe): the fused pixel -> scan kernel with every image a segment against
-coefficient kernel + scan_code + stuffing kernel (the default for batches; the fused form behind debug switch fused_batch) in the same process; HIP events on the launch
+coefficient kernel + scan_code + stuffing kernel (debug switch two_kernel_scan; the fused form is the default for batches of images with well-filled tiles, fused_batch forces it) in the same process; HIP events on the launch
 stream, median of 7 blocks of 10 batches.    python tools/device_time_batch.py [batch] [w] [h]"""
 import os
 import statistics

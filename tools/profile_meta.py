@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pixo_amd", "csrc")
 TILE = ["jpeg_kernels.hip", "jpeg_kernels.hpp", "jpeg_tile.h"]
-SCAN = ["jpeg_scan_block.h", "jpeg_scan_dev.h"]
+SCAN = ["jpeg_scan_block.h", "jpeg_scan_dev.h", "dispatch_gate.hpp"]
 SOURCES = {  # profile name prefix -> the files its kernel is compiled from
     "pixels_code": TILE + SCAN + ["jpeg_pixels_code.hip", "jpeg_pixels_code.hpp"],
     "scan_code": SCAN + ["jpeg_scan_fused.hip", "jpeg_entropy.hpp"],

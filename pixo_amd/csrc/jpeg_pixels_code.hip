@@ -263,13 +263,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     static_assert(kWindowWords % (4 * kGroup) == 0 && (kGroup * kScratchPitch) % 4 == 0, "the window in whole 16-byte pieces per lane");
 #pragma unroll
     for (uint32_t i = 0; i < kWindowWords / (4 * kGroup); i++) reinterpret_cast<v4u *>(buf)[(uint32_t)tid + kGroup * i] = v4u{0, 0, 0, 0};
-    // (the predictor from the tile before is ASKED FOR here, in front of the walk, and looked at behind it: the descriptor's way across
-    // the fabric — 0.7-1 us — then lies under the walk instead of between the walk and the group's prefix; one register: flag + value)
-    uint32_t dc_early = 0;
-    if (external && rel > 0) {
-        const unsigned long long d = load_relaxed(&dcw[comp * ngroups + g - 1]);
-        dc_early = (uint32_t)(d >> 32 & 0x40000000u) | (uint32_t)(d & 0xFFFFu);
-    }
     // ---- the walk: 63 AC positions + end-of-block from bit 0 of the lane's scratch; where the packer stands is the length
     uint32_t len_ac;
     {
@@ -288,7 +281,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     PIXO_STAMP(3);
     if (external && rel > 0) { // (at most three lanes of the group)
         const unsigned long long *src = &dcw[comp * ngroups + g - 1];
-        unsigned long long d = (dc_early & 0x40000000u) ? (kDcValid | (dc_early & 0xFFFFu)) : load_relaxed(src);
+        unsigned long long d = load_relaxed(src);
         uint32_t polls = 0;
         bool gave_up = false;
         while ((d >> 62) == 0) {

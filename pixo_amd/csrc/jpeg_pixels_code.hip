@@ -185,6 +185,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     c.W = a_W; c.H = a_H; c.units_x = a_units_x; c.units_y = a_units_y; c.fast = 1;
     c.px_end = a_px + early.px_bytes;
     if (tid == 0) { s_carry = 0; s_abort = 0; s_head = 0; s_front2 = 0; s_segbase = 0; }
+    if (!SEG) {
+        // dispatch_gate.hpp: the launch's last eight workgroups say that they have started — AT their start (behind phase A it was 8 us
+        // later, which the next thread's launch spent waiting), and found from the preloaded arguments alone: no workgroup waits for
+        // the rest of the kernel-argument segment because of this (a batch, whose grid has a third dimension, marks behind phase A)
+        const uint32_t tiles_x = (a_units_x + (uint32_t)G::units_x - 1u) / (uint32_t)G::units_x, total = tiles_x * a_units_y, lin = blockIdx.y * tiles_x + blockIdx.x;
+        if (lin + 8u >= total || lin == 0u) {
+            if (tid == 0) dispatch_mark(rest_by_value.gate_slots, rest_by_value.gate_seq, lin, total);
+        }
+    }
     {
         constexpr int base = G::items / kWaves, extra = G::items % kWaves;
         const int first = (extra && wave < extra) ? wave * (base + 1) : extra * (base + 1) + (wave - extra) * base;
@@ -194,8 +203,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     lds_only_barrier();
     PIXO_STAMP(1);
     __builtin_amdgcn_s_setprio(0);
-    if (tid == 0) dispatch_mark(rest_by_value.gate_slots, rest_by_value.gate_seq, ((uint64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
-                                (uint64_t)gridDim.x * gridDim.y * gridDim.z);
+    if (SEG && tid == 0) dispatch_mark(rest_by_value.gate_slots, rest_by_value.gate_seq, ((uint64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
+                                       (uint64_t)gridDim.x * gridDim.y * gridDim.z);
     uint32_t qw[32];
     {
         float v[64];

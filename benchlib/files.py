@@ -232,6 +232,19 @@ def whole_file(job, wl):
                 dev[name]["traffic"], dev[name]["traffic_source"] = tr, tr_src
                 with_copy(job, dev[name], wl.in_bytes, int(nb), us, issue, steps=100)
             smooth["device_time"] = dev
+            # the same at 4:4:4 — the reference's DEFAULT subsampling and its Fast / Balanced presets (src/jpeg/mod.rs:142-189): 4096 groups,
+            # two generations of the fused kernel's workgroups
+            try:
+                o444 = jpeg.JpegOptions.builder(wl.w, wl.h).quality(wl.q).subsampling(jpeg.Subsampling(0)).build()
+                dev444 = {}
+                for name, d_img in (("noise", wl.ins[0]), ("photo", d_p), ("gradient", d_g)):
+                    form = jpeg.debug_scan_device_async(d_img, o444, stream=wl.stream)
+                    job.sync()
+                    _, evs = job.time_blocks(lambda i, d_img=d_img: jpeg.debug_scan_device_async(d_img, o444, stream=wl.stream), 30, 6, 5)
+                    dev444[name] = {"device_us_per_file": round(statistics.median(evs) / 30 * 1e3, 2), "fused": bool(form)}
+                smooth["device_time_444"] = dev444
+            except Exception as ex:
+                smooth["device_time_444"] = {"error": repr(ex)}
             # THROUGHPUT with T calling threads (how the reference's rayon users call encode: src/jpeg/mod.rs:88 from a par_iter): every
             # thread has its own context and stream inside the library, so one file's look-back tail and its way over PCIe run under
             # another file's kernels.  Device pixels -> each thread's own pinned buffer; wall time over 24 files per thread.

@@ -352,7 +352,8 @@ def test_restart_intervals_in_the_single_pass_kernels_and_around_their_threshold
     multi-pass kernels: intervals on both sides of the threshold, intervals that divide the image and that do not, a
     last segment of one MCU, an MCU row, images of many tiles per segment; all against the oracle."""
     cases = [(640, 480, 2, 1, (15, 16, 17, 40, 1199, 1200)), (640, 480, 2, 0, (31, 32, 33, 80, 4799)), (512, 384, 0, 0, (95, 96, 97, 3071)),
-             (2048, 2048, 2, 1, (128, 1000, 16383)), (4096, 512, 2, 0, (512, 4097))]
+             (2048, 2048, 2, 1, (128, 1000, 16383)), (4096, 512, 2, 0, (512, 4097)),
+             (2048, 2048, 0, 0, (96,))]  # (683 segments: more block sums than one 4 KiB copy holds — sup_layout's second branch)
     for w, h, ct, ss, intervals in cases:
         px = synth.noise(w, h, w + h) if ct == 2 else synth.noise_gray(w, h, w + h)
         smooth = synth.gradient_rgb(w, h) if ct == 2 else synth.gradient_rgb(w, h).reshape(-1, 3)[:, 1].copy()

@@ -117,7 +117,7 @@ def _batch_images(w, h, n, seed):
 
 
 @pytest.mark.parametrize("w,h,n,ss,q", [(640, 48, 5, 1, 80), (1920, 1080, 3, 1, 80), (96, 64, 70, 1, 75), (16, 16, 300, 1, 90), (1100, 200, 4, 0, 80),
-                                        (520, 24, 9, 0, 50), (2048, 32, 2, 1, 100), (36, 20, 33, 0, 100), (4096, 2048, 2, 1, 80)])
+                                        (520, 24, 9, 0, 50), (2048, 32, 2, 1, 100), (36, 20, 33, 0, 100), (4096, 2048, 2, 1, 80), (16, 16, 600, 1, 85)])
 def test_fused_kernel_batches_every_file_equals_the_oracle(w, h, n, ss, q):
     """a batch = one launch of the fused kernel with every image a segment (chains of their own, a look-back over the segments'
     byte counts for where each file begins): host arena, device arena, malloc'd files — all against the oracle, and against the
@@ -164,7 +164,7 @@ def test_fused_kernel_batches_every_file_equals_the_oracle(w, h, n, ss, q):
 
 
 @pytest.mark.parametrize("w,h,ss,rows", [(640, 200, 1, 1), (640, 200, 1, 3), (1100, 333, 0, 2), (4096, 512, 1, 1), (513, 100, 1, 7), (200, 4000, 0, 5),
-                                         (64, 64, 1, 1), (2048, 2048, 1, 9)])
+                                         (64, 64, 1, 1), (2048, 2048, 1, 9), (64, 8192, 0, 1)])  # (the last: 1024 segments — block sums beyond one 4 KiB copy)
 def test_fused_kernel_restart_intervals_of_whole_mcu_rows(w, h, ss, rows):
     """restart_interval = rows x (MCUs per row): every interval a segment of the fused kernel, RSTn written by the segment's last
     group (jpeg/mod.rs:1423-1445); an interval that is NOT whole rows keeps the two-kernel form.  (The restart branch is pinned by

@@ -15,7 +15,8 @@ import synth
 from pixo_amd import jpeg
 
 W = H = 4096
-O = jpeg.JpegOptions.builder(W, H).quality(80).subsampling(jpeg.Subsampling.S420).build()
+SS = jpeg.Subsampling.S444 if os.environ.get("SS") == "444" else jpeg.Subsampling.S420  # (SS=444: the reference's default subsampling)
+O = jpeg.JpegOptions.builder(W, H).quality(80).subsampling(SS).build()
 if len(sys.argv) > 1 and sys.argv[1] == "two":
     jpeg.debug_configure("two_kernel_scan")
 stream = torch.cuda.current_stream().cuda_stream

@@ -247,6 +247,7 @@ bool scan_has_restart_markers(const pixo_jpeg_options &o, const pixo_host::Geome
 // BAND of a larger image (predictors seeded from the band above, packed at the band's bit offset modulo 8,
 // no final padding).
 struct ScanJob {
+    const void *count_px = nullptr; // optimised tables of a scan the fused kernel codes: the statistics come from these device pixels (scan_tables)
     pixo_dev::ScanArgs a;
     uint64_t n = 0, nseg = 0;
     size_t tmp_blocks = 0, tmp_segs = 0, tmp_tiles = 0;

@@ -705,7 +705,168 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
 #undef lane
 #undef wave
 }
+// ---- statistics for optimised tables FROM PIXELS (second session of round 6) ------------------------------------------------------
+// The reference's optimised-Huffman encode runs its pixel pipeline twice — once to count symbols, once to code
+// (src/jpeg/mod.rs:659-860 count_block over every MCU, then encode_scan) — and so does the fused path now: this kernel is phases
+// A and B of pixels_code_kernel followed by the flat walk as a COUNTER (block_count_flat: LDS counters per workgroup), the tuple is
+// never written.  What crosses workgroups is one thing only — the DC predictor of a tile's first block of each component — and that
+// needs no waiting: every workgroup leaves the DCs of its first and last block per component in HBM, does NOT count its first
+// blocks' DC symbols, and the summing kernel counts those 3 x tiles symbols from the pairs (last of tile t - 1, first of tile t;
+// 0 in front of a restart interval's first tile, src/jpeg/mod.rs:1441-1444).  Counters: one row of 16-bit words per tile (a tile
+// holds at most 192 x 63 symbols), added up by pixels_count_sum_kernel into the [class][12 DC + 256 AC] layout of launch_scan_count.
+struct LdsBumpPc { // (jpeg_scan_fused.hip's LdsBump)
+    uint32_t *hist; // the class's kWalkClassWords counters
+    uint32_t dummy; // index of this lane's dummy counter, relative to hist
+    bool live;
+    __device__ __forceinline__ void bump(uint32_t slot, bool on, uint32_t amount)
+    {
+        (void)__hip_atomic_fetch_add(&hist[on && live ? slot : dummy], amount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+template <int MODE, int LOAD, bool PACKED>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void pixels_count_kernel
+(const uint8_t *a_px, uint32_t a_W, uint32_t a_H, const float *a_qt, uint32_t a_units_x, uint32_t a_units_y, uint16_t *a_slab, int16_t *a_edges,
+ unsigned long long *a_hist, const PEarly early)
+{
+    typedef Geo<MODE> G;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kFusedLds];
+    __shared__ int16_t s_dc[kGroup];
+    static_assert((kWalkWords + kGroup) * 4 <= kFusedLds, "the counters fit the dead planar tile");
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    __builtin_amdgcn_s_setprio(1);
+    const uint32_t tx = blockIdx.x, ty = blockIdx.y;
+    TileCtx c;
+    c.px = a_px; c.y = c.cb = c.cr = nullptr; c.qt = a_qt;
+    c.W = a_W; c.H = a_H; c.units_x = a_units_x; c.units_y = a_units_y; c.fast = 1;
+    c.px_end = a_px + early.px_bytes;
+    {
+        constexpr int base = G::items / kWaves, extra = G::items % kWaves;
+        const int first = (extra && wave < extra) ? wave * (base + 1) : extra * (base + 1) + (wave - extra) * base;
+        const LaneAddr la = lane_addr<MODE>(c, tx, ty, lane);
+        auto run = [&](auto count_tag) __attribute__((always_inline)) {
+            constexpr int COUNT = decltype(count_tag)::value;
+            uint32_t r[COUNT * G::item_regs];
+#pragma unroll
+            for (int j = 0; j < COUNT; j++) producer_load_item<MODE, LOAD>(c, la, tx, ty, first + j, lane, &r[j * G::item_regs]);
+#pragma unroll
+            for (int j = 0; j < COUNT; j++) {
+                producer_fix_item<MODE, LOAD>(c, tx, first + j, lane, &r[j * G::item_regs]);
+                producer_color_item<MODE, true>(first + j, lane, &r[j * G::item_regs], lds);
+            }
+        };
+        if (extra && wave < extra) run(std::integral_constant<int, base + 1>{}); else run(std::integral_constant<int, base>{});
+    }
+    lds_only_barrier();
+    __builtin_amdgcn_s_setprio(0);
+    uint32_t qw[32];
+    {
+        float v[64];
+        consumer_rows<MODE, PACKED>(wave, lane, lds, v);
+        consumer_cols<PACKED>(v);
+        consumer_quant<MODE, PACKED>(wave, lane, a_qt, v, qw);
+    }
+    const uint32_t tiles_x = gridDim.x, g = ty * tiles_x + tx;
+    if (g == 0) // (the sums start from zero: cheaper here than a memset launch — the summing kernel runs behind this one)
+        for (int i = tid; i < kTableWords; i += kGroup) a_hist[i] = 0;
+    const uint32_t u0 = tx * (uint32_t)G::units_x;
+    const uint32_t nvalid = a_units_x - u0 < (uint32_t)G::units_x ? a_units_x - u0 : (uint32_t)G::units_x;
+    uint32_t m, comp, sidx;
+    bool first_of_comp, last_block_of_mcu_comp;
+    if (MODE == M420) {
+        if (wave < 2) { m = (uint32_t)wave * 16u + ((uint32_t)lane >> 2); comp = 0; sidx = 6u * m + ((uint32_t)lane & 3u); first_of_comp = (lane & 3) == 0; last_block_of_mcu_comp = (lane & 3) == 3; }
+        else { m = (uint32_t)lane & 31u; comp = 1u + ((uint32_t)lane >> 5); sidx = 6u * m + 3u + comp; first_of_comp = last_block_of_mcu_comp = true; }
+    } else {
+        m = (uint32_t)lane; comp = (uint32_t)wave; sidx = 3u * m + comp; first_of_comp = last_block_of_mcu_comp = true;
+    }
+    const bool live = m < nvalid;
+    const int dc = (int)(int16_t)(uint16_t)(qw[0] & 0xFFFFu);
+    s_dc[sidx] = (int16_t)dc;
+    const bool external = m == 0 && first_of_comp;
+    // a_edges: [tile][component][0 = the tile's first block's DC, 1 = its last block's]
+    if (external) a_edges[((size_t)g * 3 + comp) * 2] = (int16_t)dc;
+    if (m + 1 == nvalid && last_block_of_mcu_comp) a_edges[((size_t)g * 3 + comp) * 2 + 1] = (int16_t)dc;
+    __syncthreads(); // every wavefront has consumed its planar rows (the area becomes the counters), s_dc is complete
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(lds);
+    for (int i = tid; i < kWalkWords + kGroup; i += kGroup) lhist[i] = 0;
+    const uint32_t back = MODE == M420 ? (comp == 0 ? (first_of_comp ? 3u : 1u) : 6u) : 3u;
+    const int prev_dc = external ? 0 : (int)s_dc[sidx - back];
+    __syncthreads();
+    const uint32_t cls = comp ? 1u : 0u;
+    LdsBumpPc h{lhist + cls * kWalkClassWords, (uint32_t)(kWalkWords + tid) - cls * kWalkClassWords, live};
+    block_count_flat(qw, prev_dc, h, !external);
+    __syncthreads();
+    for (int i = tid; i < kWalkWords; i += kGroup) a_slab[(size_t)g * kWalkWords + i] = (uint16_t)lhist[i];
+}
+
+// blockIdx.x: 64 columns of the slab; blockIdx.y < kPcSumRows: rows blockIdx.y, + kPcSumRows, ... in four phases;
+// the workgroup (0, kPcSumRows): the DC symbols of the tiles' first blocks from the (last, first) pairs
+constexpr uint32_t kPcSumRows = 32;
+__global__ __launch_bounds__(256) void pixels_count_sum_kernel(const uint16_t *slab, const int16_t *edges, uint32_t tiles, uint32_t tiles_x, uint32_t seg_rows,
+                                                               unsigned long long *hist)
+{
+    __shared__ uint32_t part[4][64];
+    __shared__ uint32_t dcs[2][16];
+    if (blockIdx.y == kPcSumRows) {
+        if (blockIdx.x != 0) return;
+        if (threadIdx.x < 32) dcs[threadIdx.x >> 4][threadIdx.x & 15] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < 3u * tiles; i += 256u) {
+            const uint32_t t = i / 3u, comp = i - 3u * t;
+            const bool seg_first = t % (seg_rows * tiles_x) == 0; // (a restart interval's — or the image's — first tile: predictors 0)
+            const int prev = seg_first ? 0 : (int)edges[((size_t)(t - 1) * 3 + comp) * 2 + 1];
+            const int diff = (int)(int16_t)((int)edges[((size_t)t * 3 + comp) * 2] - prev);
+            const uint32_t s = scan_sign_bits(diff + (diff >> 31)), m = s < 32u ? s : 32u;
+            atomicAdd(&dcs[comp ? 1 : 0][m & 15u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int sym = walk_slot_symbol((int)(threadIdx.x & 15));
+            const uint32_t n = dcs[threadIdx.x >> 4][threadIdx.x & 15];
+            if (n && sym >= 0) atomicAdd(&hist[(threadIdx.x >> 4) * kClassSyms + sym], (unsigned long long)n);
+        }
+        return;
+    }
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), phase = threadIdx.x >> 6;
+    uint32_t n = 0;
+    if (col < kWalkWords)
+        for (uint32_t r = blockIdx.y * 4u + (uint32_t)phase; r < tiles; r += 4u * kPcSumRows) n += slab[(size_t)r * kWalkWords + col];
+    part[phase][threadIdx.x & 63] = n;
+    __syncthreads();
+    if (phase == 0 && col < kWalkWords) {
+        const unsigned long long sum = (unsigned long long)part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        const int sym = walk_slot_symbol(col % kWalkClassWords);
+        if (sum && sym >= 0) atomicAdd(&hist[(col / kWalkClassWords) * kClassSyms + sym], sum);
+    }
+}
 } // namespace
+
+size_t pixels_count_scratch_bytes(const PixelsCodePlan &p) { return (size_t)p.groups * kWalkWords * 2 + (size_t)p.groups * 3 * 2 * 2 + 16; }
+
+hipError_t launch_pixels_count(const void *d_px, uint32_t W, uint32_t H, bool s420, const PixelsCodePlan &p, const float *d_qt, void *d_scratch,
+                               unsigned long long *d_hist, hipStream_t s)
+{
+    if (!pixels_code_supported(W, H, false, s420, 1, 0) || p.images != 1 || p.groups > 0x7FFFFFFFull || p.tiles_y > 65535u) return hipErrorInvalidValue;
+    PEarly early;
+    const size_t row_bytes = (size_t)W * 3;
+    early.px_stride = row_bytes * H;
+    early.px_bytes = early.px_stride;
+    uint16_t *slab = static_cast<uint16_t *>(d_scratch);
+    int16_t *edges = reinterpret_cast<int16_t *>(slab + (((size_t)p.groups * kWalkWords + 7) & ~(size_t)7));
+    const bool aligned = reinterpret_cast<uintptr_t>(d_px) % 4 == 0 && row_bytes % 4 == 0;
+    const dim3 grid(p.tiles_x, p.tiles_y, 1);
+    const uint8_t *px = static_cast<const uint8_t *>(d_px);
+    const bool packed = packed_launch(p.groups);
+#define PIXO_LAUNCH_CNT2(MODE, LOAD, PK) hipLaunchKernelGGL((pixels_count_kernel<MODE, LOAD, PK>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, p.units_x, p.units_y, slab, edges, d_hist, early)
+#define PIXO_LAUNCH_CNT(MODE, LOAD) do { if (packed) PIXO_LAUNCH_CNT2(MODE, LOAD, true); else PIXO_LAUNCH_CNT2(MODE, LOAD, false); } while (0)
+    if (s420) { if (aligned) PIXO_LAUNCH_CNT(M420, L_ALIGNED); else PIXO_LAUNCH_CNT(M420, L_FUNNEL); }
+    else { if (aligned) PIXO_LAUNCH_CNT(M444, L_ALIGNED); else PIXO_LAUNCH_CNT(M444, L_FUNNEL); }
+#undef PIXO_LAUNCH_CNT
+#undef PIXO_LAUNCH_CNT2
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pixels_count_sum_kernel, dim3((kWalkWords + 63) / 64, kPcSumRows + 1), dim3(256), 0, s, slab, edges, (uint32_t)p.groups, p.tiles_x, p.seg_rows, d_hist);
+    return hipGetLastError();
+}
 
 #ifdef PIXO_TIMELINE
 extern "C" __attribute__((visibility("default"))) int pixo_hip_debug_pixels_code_timeline(unsigned long long *out, size_t bytes)

@@ -45,4 +45,12 @@ hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s42
                               unsigned long long *host_segs, const int16_t seed_dc[3], bool pad_last, void *d_block_spill, hipStream_t s,
                               uint32_t spin_budget = 1u << 20);
 
+// Symbol statistics for optimised tables straight from the pixels (the reference's optimised-Huffman encode runs its pixel pipeline
+// twice as well: count_block over every MCU, src/jpeg/mod.rs:826-860, then encode_scan): phases A and B of the fused kernel + the flat
+// walk as a counter, ONE image (restart intervals of whole MCU rows as planned by pixels_code_plan), no tuple.  d_hist: kTableWords
+// u64 in launch_scan_count's layout ([class][12 DC + 256 AC]); d_scratch: pixels_count_scratch_bytes(p) bytes.
+size_t pixels_count_scratch_bytes(const PixelsCodePlan &p);
+hipError_t launch_pixels_count(const void *d_px, uint32_t W, uint32_t H, bool s420, const PixelsCodePlan &p, const float *d_qt, void *d_scratch,
+                               unsigned long long *d_hist, hipStream_t s);
+
 } // namespace pixo_dev

@@ -362,12 +362,14 @@ template <class Sink> PIXO_SDEV void block_pack_flat(const uint32_t *w, int prev
 
 // Symbol statistics with the same walk (count_block, jpeg/mod.rs:826-860): `Bump` provides bump(slot, on, amount) —
 // add `amount` to the counter of the walk-table slot `slot` of the block's class when `on`.
-template <class Bump> PIXO_SDEV void block_count_flat(const uint32_t *w, int prev_dc, Bump &h)
+// (count_dc = false: the DC symbol is somebody else's to count — the fused statistics kernel's first block of a tile, whose predictor
+// lives in another workgroup)
+template <class Bump> PIXO_SDEV void block_count_flat(const uint32_t *w, int prev_dc, Bump &h, bool count_dc = true)
 {
     {
         const int diff = (int)(int16_t)(coef_of(w, 0) - prev_dc);
         const uint32_t s = scan_sign_bits(diff + (diff >> 31)), m = s < 32u ? s : 32u;
-        h.bump(m & 15u, true, 1u);
+        h.bump(m & 15u, count_dc, 1u);
     }
     uint32_t run16 = 0;
 #pragma unroll

@@ -378,7 +378,21 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
     // what the pieces hide); their bands run coefficient kernel + scan_code as before.
     const bool from_pixels = src && pixels_code_usable(j, o, g, batch);
     if (from_pixels && batch > 1 && gaps_left) *gaps_left = j.seg_gap == seg_gap && seg_gap != 0; // (the fused kernel leaves any gap between its segments)
-    if (j.fused && !j.segmented && batch == 1 && pieces_enabled() && !direct_host_stores() && (large || (medium && !from_pixels) || host_bands) &&
+    // Second session of round 6: a LARGE scan from device pixels takes the fused kernel too when its stores can go straight to where the file
+    // is wanted (the library's pinned buffer, or storage of the caller's the GPU can write) — one kernel whose groups finish one after
+    // the other IS a pipeline of coding and PCIe: 4096x4096 4:4:4 photo 181 -> 121 us, gradient 144 -> 88, noise 534 -> 498;
+    // 8192x8192 4:2:0 332 -> 261 / 264 -> 152 / 928 -> 916 (tools/large_scan_paths.py, profiles/r06_large_scans_one_kernel.txt).  Plain
+    // malloc'd destinations keep the pieces (their copy engine overlaps the coding), host pixels in bands as well.
+    bool fused_direct_possible = false;
+    if (from_pixels && batch == 1 && large && !host_bands && !debug().no_direct_small) {
+        if (!dest) fused_direct_possible = true;
+        else {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, dest) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) fused_direct_possible = true;
+            else (void)hipGetLastError();
+        }
+    }
+    if (j.fused && !j.segmented && batch == 1 && pieces_enabled() && !direct_host_stores() && ((large && !fused_direct_possible) || (medium && !from_pixels) || host_bands) &&
         (!dest || dest_cap >= likely_most) && (host_bands || !(own_malloc && !dest))) {
         PixelSource device_src; // (the same source once the pixels are on the device)
         if (src && o.optimize_huffman) { // (the statistics need the whole tuple)
@@ -436,6 +450,7 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
         *tuple_done = true;
     }
     if (j.fused || fuse_now) { // code + stuff back to back, one read-back
+        if (fuse_now && o.optimize_huffman) j.count_px = src->d_px; // (optimised tables: the statistics from the pixels as well — scan_tables)
         if ((rc = fuse_now ? scan_tables(c, j, o, g, stream, nullptr) : scan_lengths(c, j, o, g, stream, nullptr, /*wait=*/false))) return rc;
         // One image into host memory the GPU can write — the context's pinned file buffer, or storage of the caller's
         // that is pinned / registered: the stuffing kernel stores straight into it, behind the place of the headers.

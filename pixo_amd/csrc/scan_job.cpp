@@ -239,6 +239,25 @@ int scan_count(Context &c, ScanJob &j, hipStream_t stream, uint64_t counts[pixo_
     return PIXO_OK;
 }
 
+// The same statistics straight from the pixels (launch_pixels_count: the fused kernel's scans never have a tuple).
+int pixels_count(Context &c, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream, const void *d_pixels,
+                 uint64_t counts[pixo_host::kScanTableWords])
+{
+    namespace pd = pixo_dev;
+    const float *qt_all = nullptr;
+    { const int rc = device_tables(c.device, &qt_all); if (rc) return rc; }
+    const uint32_t restart = scan_has_restart_markers(o, g) ? o.restart_interval : 0;
+    const pd::PixelsCodePlan plan = pd::pixels_code_plan(o.width, o.height, g.s420, 1, restart);
+    HIP_TRY(c.e_count.reserve(pd::pixels_count_scratch_bytes(plan)));
+    HIP_TRY(pd::launch_pixels_count(d_pixels, o.width, o.height, g.s420, plan, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c.e_count.p,
+                                    c.e_hist.as<unsigned long long>(), stream));
+    { const int rc = c.reserve_hsegs(pixo_host::kScanTableWords); if (rc) return rc; }
+    HIP_TRY(hipMemcpyAsync(c.h_segs, c.e_hist.p, pixo_host::kScanTableWords * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::memcpy(counts, c.h_segs, pixo_host::kScanTableWords * 8);
+    return PIXO_OK;
+}
+
 // Tables (standard; optimised from `counts`, or from this pass's own statistics when counts == null),
 // block bit lengths and their prefix sum: afterwards j.total_bits is known (one read-back).
 int scan_tables(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, hipStream_t stream,
@@ -248,7 +267,7 @@ int scan_tables(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_h
     if (o.optimize_huffman) { // table construction on the host, exactly like optimized_from_counts
         uint64_t own[pixo_host::kScanTableWords];
         if (!counts) {
-            int rc = scan_count(c, j, stream, own);
+            int rc = j.count_px ? pixels_count(c, o, g, stream, j.count_px, own) : scan_count(c, j, stream, own);
             if (rc) return rc;
             counts = own;
         }
@@ -325,7 +344,8 @@ int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_
 bool pixels_code_usable(const ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, uint32_t batch)
 { // one uninterrupted RGB scan, the images of a batch, or restart intervals of whole MCU rows — with GIVEN tables.  (Independent of
   // which tuple kernels scan_begin chose: segments of any size are chains of the fused kernel.)
-    if (j.band || g.gray || o.optimize_huffman || o.progressive || debug().two_kernel_scan || debug().multipass_entropy || t_force_multipass) return false;
+    if (j.band || g.gray || o.progressive || debug().two_kernel_scan || debug().multipass_entropy || t_force_multipass) return false;
+    if (o.optimize_huffman && batch > 1) return false; // (every file of a batch has tables of its own: not segments of one launch)
     // Batches: every image a segment of ONE launch of the fused kernel — since the segments' byte counts are asked for BEHIND a group's own
     // 0xFF count (jpeg_pixels_code.hip; in front of it every segment's last group finished 6.5 us behind the one before: 64 x 1080p took
     // 414-521 us) a batch runs at the rate of one large image: 64 x 1080p 245 / 272 / 340 us (gradient / photo / noise) against 306 / 335 /
@@ -345,6 +365,7 @@ int scan_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const p
                      HostTarget *host, bool wait, uint32_t batch)
 {
     namespace pd = pixo_dev;
+    if (o.optimize_huffman && !j.tables_ready) j.count_px = d_pixels;
     int rc = scan_tables(c, j, o, g, stream, nullptr);
     if (rc) return rc;
     const float *qt_all = nullptr;

@@ -249,3 +249,30 @@ def test_calling_threads_start_single_pass_kernels_together_without_starving_eac
     assert jpeg.lookback_fallbacks() == fb0
     waits, timeouts = jpeg.dispatch_gate_stats()
     assert timeouts == 0, (waits, timeouts)
+
+
+@pytest.mark.parametrize("w,h,ss,q,rows", [(640, 480, 1, 80, 0), (640, 480, 0, 75, 0), (1030, 37, 1, 90, 0), (20, 20, 0, 50, 0), (4096, 512, 1, 80, 0),
+                                           (2048, 2048, 0, 85, 0), (1100, 333, 0, 80, 2), (640, 200, 1, 80, 3), (4096, 4096, 1, 80, 0), (4094, 1000, 1, 80, 0)])
+def test_optimised_tables_statistics_from_the_pixels(w, h, ss, q, rows):
+    """optimize_huffman through the fused kernel: the statistics come from the pixels as well (launch_pixels_count — the reference runs
+    its pixel pipeline twice for this preset too, src/jpeg/mod.rs:826-860 then :1408-1563), the DC symbols of the tiles' first blocks from
+    the (last DC of the tile before, first DC of this tile) pairs; restart intervals of whole MCU rows reset the predictors.  Files =
+    the oracle's, and = the two-kernel form's, for noise and photograph-like content."""
+    import torch
+    unit = 16 if ss == 1 else 8
+    units_x = (w + unit - 1) // unit
+    for px in (synth.noise(w, h, 31 + w), synth.photo(w, h, 32 + h)):
+        d = torch.from_numpy(np.ascontiguousarray(px)).cuda()
+        b = jpeg.JpegOptions.builder(w, h).color_type(ColorType(2)).quality(q).subsampling(jpeg.Subsampling(ss)).optimize_huffman(True)
+        if rows:
+            b = b.restart_interval(rows * units_x)
+        o = b.build()
+        want = O.encode(px, O.make_options(w, h, 2, q, ss, optimize_huffman=True, restart=rows * units_x if rows else None))
+        assert jpeg.encode_device(d, o) == want, "optimised tables, device pixels: file differs from the oracle"
+        assert jpeg.encode(px, o) == want, "optimised tables, host pixels: file differs from the oracle"
+        jpeg.debug_configure("two_kernel_scan")
+        try:
+            assert jpeg.encode_device(d, o) == want
+        finally:
+            jpeg.debug_configure(None)
+    assert jpeg.lookback_fallbacks() == 0

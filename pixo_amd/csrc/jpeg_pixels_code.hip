@@ -7,7 +7,9 @@
 // bottom; a row's last tile may hold fewer MCUs).  Grid (tiles_x, tiles_y, images); ticket g = (image * tiles_y + tile_y) *
 // tiles_x + tile_x.
 //
-// SEGMENTS (round 6 — encode_scan's whole surface but gray): a launch codes `images` x `segments per image` byte-aligned scans,
+// GRAY images (second session of round 6): tiles of 1536 x 8 pixels = 192 consecutive blocks of one block row (phase_a_gray_row);
+// OPTIMISED TABLES: the statistics come from the pixels as well (pixels_count_kernel below).
+// SEGMENTS (round 6): a launch codes `images` x `segments per image` byte-aligned scans,
 // each a chain of its own — DC predictors from 0, 1-padded end (BitWriterMsb::flush), look-back floor at its first group:
 //   * the images of a batch (configs[2]): one segment per image, `gap` bytes left free between two scans for EOI + the next
 //     file's headers (the batch then leaves the device in one copy);
@@ -45,9 +47,9 @@
 // LDS: the planar tile (16,896 B) is dead after phase B and becomes scratch (192 x 13 words) + window (1536 + 192 words)
 // = 16,896 B; + 2.2 KiB of tables: 8 workgroups per CU as before.
 //
-// Not served: gray images (a gray tile is three block rows — not a run of the scan order), optimised tables (the statistics
-// need the tuple first), restart intervals that are not whole MCU rows, bands of a multi-GPU image (a band's byte alignment
-// is only known after the bit-count exchange between the GPUs: its stuffing cannot be fused with its coding).  Those keep
+// Not served: optimised tables of a batch (every file its own tables), progressive scans, restart intervals that are not whole MCU
+// rows, bands of a multi-GPU image (a band's byte alignment is only known after the bit-count exchange between the GPUs: its
+// stuffing cannot be fused with its coding), batches of images whose tiles are mostly empty.  Those keep
 // coefficient kernel + scan_code + stuff_fused.  Forward progress: a group waits only for LOWER tickets (file header of
 // jpeg_scan_fused.hip); every wait is bounded and raises the abort flag.
 #include <hip/hip_runtime.h>
@@ -154,6 +156,39 @@ __device__ __forceinline__ void phase_a_tab(const TileCtx &c, uint32_t tx, uint3
     }
 }
 
+// GRAY images (second session of round 6): the coefficient kernel's gray tile is 512 x 24 pixels — three block rows, not a run of the
+// scan order.  The fused kernels take a tile of 1536 x 8 pixels instead: 192 CONSECUTIVE blocks of one block row, wavefront w the 64
+// blocks [64 w, 64 w + 64) — in LDS exactly the gray planes phase B of jpeg_tile.h reads (plane w, rows 0..7, pitch kPitch), so only
+// the addresses of phase A differ: item k (48 of 256 bytes each, 16 per wavefront) = row k / 6, sixth k % 6 of the tile row.
+// extract_block's replicate rule (src/jpeg/mod.rs:1565-1606): rows clamped to H - 1, the row's last 4-pixel group read at W - 4 and
+// permuted like producer_fix_item's gray case.
+constexpr int kGrayTileBlocks = 192;
+template <int MODE> constexpr int tile_units() { return MODE == MGRAY ? kGrayTileBlocks : Geo<MODE>::units_x; }
+template <int LOAD>
+__device__ __forceinline__ void phase_a_gray_row(const TileCtx &c, uint32_t tx, uint32_t ty, int wave, int lane, uint8_t *lds)
+{
+    const uint32_t last = c.W - 4u; // (W >= 4: pixels_code_supported)
+    uint32_t r[16], d[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int k = wave * 16 + j, row = k / 6, sixth = k % 6;
+        const uint32_t y0 = ty * 8u + (uint32_t)row, y = y0 < c.H ? y0 : c.H - 1u;
+        const uint32_t x = tx * 1536u + (uint32_t)sixth * 256u + 4u * (uint32_t)lane, xc = x < last ? x : last;
+        const uint8_t *p = c.px + (size_t)y * c.W;
+        if (LOAD == L_ALIGNED) r[j] = PIXO_GLOAD((const uint32_t *)(p + xc));
+        else unaligned_load<1>(p, xc, &r[j]);
+        const uint32_t over = x > last ? x - last : 0u;
+        d[j] = over < 3u ? over : 3u;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int k = wave * 16 + j, row = k / 6, sixth = k % 6;
+        const uint32_t s1 = perm(r[j], r[j], 0x03030201u), s2 = perm(r[j], r[j], 0x03030302u), s3 = perm(r[j], r[j], 0x03030303u);
+        const uint32_t v = d[j] == 0 ? r[j] : (d[j] == 1 ? s1 : (d[j] == 2 ? s2 : s3));
+        *(uint32_t *)(lds + (sixth >> 1) * 4224 + row * kPitch + 4 * ((sixth & 1) * 64 + lane)) = v;
+    }
+}
+
 #ifdef PIXO_TIMELINE // (experiment builds only, tools/pixels_code_timeline.py: where a group's time goes; 100 MHz constant clock)
 __device__ unsigned long long g_pc_timeline[8192 * 16];
 #define PIXO_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 8192) g_pc_timeline[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -189,12 +224,19 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         // dispatch_gate.hpp: the launch's last eight workgroups say that they have started — AT their start (behind phase A it was 8 us
         // later, which the next thread's launch spent waiting), and found from the preloaded arguments alone: no workgroup waits for
         // the rest of the kernel-argument segment because of this (a batch, whose grid has a third dimension, marks behind phase A)
-        const uint32_t tiles_x = (a_units_x + (uint32_t)G::units_x - 1u) / (uint32_t)G::units_x, total = tiles_x * a_units_y, lin = blockIdx.y * tiles_x + blockIdx.x;
+        const uint32_t tiles_x = (a_units_x + (uint32_t)tile_units<MODE>() - 1u) / (uint32_t)tile_units<MODE>(), total = tiles_x * a_units_y, lin = blockIdx.y * tiles_x + blockIdx.x;
         if (lin + 8u >= total || lin == 0u) {
             if (tid == 0) dispatch_mark(rest_by_value.gate_slots, rest_by_value.gate_seq, lin, total);
         }
     }
-    {
+    if constexpr (MODE == MGRAY) {
+        phase_a_gray_row<LOAD>(c, tx, ty, wave, lane, lds);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { // (the flat walk's tables: phase_a_tab's part)
+            const int i = tid + kGroup * k;
+            if (i < kWalkWords) tab[i] = a_tables[kTableWords + i];
+        }
+    } else {
         constexpr int base = G::items / kWaves, extra = G::items % kWaves;
         const int first = (extra && wave < extra) ? wave * (base + 1) : extra * (base + 1) + (wave - extra) * base;
         if (extra && wave < extra) phase_a_tab<MODE, LOAD, base + 1>(c, tx, ty, first, lane, tid, lds, a_tables + kTableWords, tab);
@@ -244,11 +286,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     // (housekeeping: the state block of the launch before this one must be zero when it is used again — cheaper here than a memset launch)
     for (uint64_t i = g * kGroup + tid; i < rest.clear_words; i += ngroups * kGroup) rest.clear[i] = 0;
     // which block of the scan this lane holds: MCU m of the tile, component, position among the group's 192 blocks
-    const uint32_t u0 = tx * (uint32_t)G::units_x;
-    const uint32_t nvalid = a_units_x - u0 < (uint32_t)G::units_x ? a_units_x - u0 : (uint32_t)G::units_x;
+    const uint32_t u0 = tx * (uint32_t)tile_units<MODE>();
+    const uint32_t nvalid = a_units_x - u0 < (uint32_t)tile_units<MODE>() ? a_units_x - u0 : (uint32_t)tile_units<MODE>();
     uint32_t m, comp, sidx;
     bool first_of_comp, last_block_of_mcu_comp; // (the MCU's first / last block of this component)
-    if (MODE == M420) {
+    if (MODE == MGRAY) { // one component, an MCU is a block: the tile's 192 blocks in scan order
+        m = (uint32_t)tid; comp = 0; sidx = m; first_of_comp = last_block_of_mcu_comp = true;
+    } else if (MODE == M420) {
         if (wave < 2) { m = (uint32_t)wave * 16u + ((uint32_t)lane >> 2); comp = 0; sidx = 6u * m + ((uint32_t)lane & 3u); first_of_comp = (lane & 3) == 0; last_block_of_mcu_comp = (lane & 3) == 3; }
         else { m = (uint32_t)lane & 31u; comp = 1u + ((uint32_t)lane >> 5); sidx = 6u * m + 3u + comp; first_of_comp = last_block_of_mcu_comp = true; }
     } else {
@@ -264,7 +308,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     // DC predictor: the previous block of the same component.  Inside the tile: from LDS; the tile's first block of a
     // component: the tile before (after the walk, below); a segment's first tile: zero (the launch's first: the seed)
     const bool external = m == 0 && first_of_comp;
-    const uint32_t back = MODE == M420 ? (comp == 0 ? (first_of_comp ? 3u : 1u) : 6u) : 3u;
+    const uint32_t back = MODE == MGRAY ? 1u : (MODE == M420 ? (comp == 0 ? (first_of_comp ? 3u : 1u) : 6u) : 3u);
     int prev_dc = external ? (seg == 0 ? (int)rest.seed_dc[comp] : 0) : (int)s_dc[sidx - back];
     uint32_t *scratch = reinterpret_cast<uint32_t *>(lds);
     uint32_t *buf = scratch + kGroup * kScratchPitch;
@@ -354,7 +398,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     uint8_t *stage = lds;
     uint8_t *const out = a_out; // 16-byte aligned; the launch's first scan byte goes to out[rest.out_skew]
     uint64_t S = 0, ff_before_groups = 0, seg_base = 0;
-    uint32_t nb_total = 0, sh8 = 0, pad_word = ~0u, pad_mask = 0, ff_group = 0, in_front2 = 0;
+    uint32_t nb_total = 0, sh8 = 0, pad_word = ~0u, pad_mask = 0, ff_group = 0;
     bool aborted = false;
     // MULTI: a group of several rounds / with a very long block (rare: noise at q >= 90): the quantised block stays alive for the
     // second walks.  The common case is its own instantiation, in which the block's registers are dead after the first walk.
@@ -374,6 +418,94 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     const uint32_t kblk = rel >> 6, in_block = rel & 63u; // the group's block of 64 inside its chain, its place in the block
     auto rounds = [&](auto multi_tag) __attribute__((always_inline)) {
     constexpr bool MULTI = decltype(multi_tag)::value;
+    // The second look-back — the number of stuffed zeros before the group — as a step of its own: own_ff = ALL the group's 0xFF bytes (its
+    // count has gone out; the block's sum goes out in here, before the wait for the other blocks' sums).  false: gave up (aborted).
+    auto second_look_back = [&](uint32_t own_ff) __attribute__((always_inline)) -> bool {
+        if (wave == 0) { // (look_back_blocks' two levels; the block's sum is published below, when this group's own count is complete)
+            int lane2 = lane; // (a value of this place: see look_back_blocks)
+            asm volatile("" : "+v"(lane2));
+#undef lane
+#define lane lane2
+            const uint64_t block_first = floor + ((uint64_t)kblk << 6);
+            uint32_t polls = 0;
+            bool gave_up = false;
+            unsigned long long *const SUP2r = SUP2 + (size_t)((uint32_t)g & (sup_copies - 1u)) * sup_stride; // the copy this group reads
+            unsigned long long da = (uint32_t)lane < in_block ? load_relaxed(&desc2[block_first + lane]) : kFlagAggregate;
+            unsigned long long db2 = (uint32_t)lane < kblk ? load_relaxed(&SUP2r[lane]) : kFlagAggregate;
+            while ((da >> 62) == 0 && !gave_up) {
+                __builtin_amdgcn_s_sleep(kPollSleep);
+                if (++polls > rest.spin_budget) gave_up = true; else da = load_relaxed(&desc2[block_first + lane]);
+            }
+            uint64_t before2 = 0;
+            uint32_t front = 0;
+            if (!PIXO_ANY64(gave_up)) {
+                front = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)(da & kValueMask)), 63);
+                before2 = front;
+                // the block's own sum goes out BEFORE waiting for the other blocks' sums (a group of one round knows its count here):
+                // published behind that wait, the blocks' last groups would form one chain of waits through the whole scan
+                if (in_block == 63u && (uint32_t)lane < sup_copies) store_relaxed(&SUP2[(size_t)lane * sup_stride + kblk], kFlagAggregate | ((uint64_t)front + own_ff));
+                for (uint32_t base = 0;;) {
+                    while ((db2 >> 62) == 0 && !gave_up) {
+                        __builtin_amdgcn_s_sleep(kPollSleep);
+                        if (++polls > rest.spin_budget) gave_up = true; else db2 = load_relaxed(&SUP2r[base + lane]);
+                    }
+                    if (PIXO_ANY64(gave_up)) break;
+                    before2 += (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)(db2 & kValueMask)), 63);
+                    base += 64;
+                    if (base >= kblk) break;
+                    db2 = base + lane < kblk ? load_relaxed(&SUP2r[base + lane]) : kFlagAggregate;
+                }
+            }
+            if (PIXO_ANY64(gave_up)) {
+                if (gave_up) raise_abort(a_state, host_abort);
+                if (lane == 0) s_abort = 1;
+            } else if (lane == 0) {
+                s_before = before2;
+            }
+#undef lane
+#define lane lane_again
+        } else if (SEG && wave == 1 && seg > 0 && !seg_late) {
+            // meanwhile: where this segment's bytes begin — a look-back over the SEGMENTS' byte counts.  HERE, behind the group's own
+            // 0xFF count going out, not beside the first look-back: the count of the segment before is known when ITS last group is
+            // through its second look-back, and a group that waited for that in front of its census kept its own count from the
+            // groups behind it — every segment's last group then finished one census + one look-back (6.5 us) behind the last group
+            // of the segment before: a serial chain through all segments (64 x 1080p: 414-453 us; 32 x 4096x512: 216-236 us
+            // against 126-141 us for the same groups in 4 segments, profiles/r06_fused_batches_chain.txt).
+            const uint64_t sb = look_back(segdesc, seg, 0, 0, a_state, host_abort, rest.spin_budget);
+            if (lane == 0) {
+                if (sb == kLookBackFailed) s_abort = 1;
+                s_segbase = sb;
+            }
+        }
+        __syncthreads();
+        PIXO_STAMP(8);
+        if (uni(s_abort)) { aborted = true; return false; }
+        ff_before_groups = uni64(s_before);
+        if (SEG) seg_base = uni64(s_segbase);
+        return true;
+    };
+    for (int pass = 0; pass < (MULTI ? 2 : 1); pass++) {
+    if (MULTI && pass == 1) { // the count is complete: out it goes, then the look-back, then the rounds again — this time for their bytes
+        if (rel > 0 && sh8 != 0) { // (uniform) the group starts inside a byte: the seven bits in front of it, and whether that byte is 0xFF
+            if (tid == 128) {
+                unsigned long long t = load_relaxed(&tails[g - 1]);
+                uint32_t polls = 0;
+                while (!(t & kTailValid)) {
+                    __builtin_amdgcn_s_sleep(kPollSleep);
+                    if (++polls > rest.spin_budget) { raise_abort(a_state, host_abort); s_abort = 1; break; }
+                    t = load_relaxed(&tails[g - 1]);
+                }
+                s_head = (uint32_t)t & 0x7Fu;
+            }
+            __syncthreads();
+            if (uni(s_abort)) { aborted = true; return; }
+            const uint32_t mask = (1u << sh8) - 1u;
+            if (uni(s_front2) && (uni(s_head) & mask) == mask) ff_group += 1u;
+        }
+        if (tid == 0) store_relaxed(&desc2[g], kFlagAggregate | (uint64_t)ff_group);
+        if (!second_look_back(ff_group)) return;
+        ff_group = 0;
+    }
     for (uint32_t wbase = 0; wbase < (MULTI ? local_words : 1u); wbase += kWin) {
         const uint32_t wn = MULTI ? (local_words - wbase < kWin ? local_words - wbase : kWin) : local_words;
         if (MULTI) { // (also the first round's: the walk of a long block ran over its scratch into the window)
@@ -430,21 +562,25 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         // The group's LAST SEVEN BITS for the group behind (its first byte may begin in this group): they do not depend on where
         // this group starts, so they go out at once — the group behind then finds them waiting instead of waiting for them.
         // (>= 12 bits per group: they are this group's own.)
-        if (last_round && !last_group && tid == 64) {
+        // (A group of FEWER than seven bits — one block of a narrow gray image, one MCU under optimised tables with 1-bit codes — has no seven
+        // bits of its own: it first asks for the seven in front of it and hands on theirs + its own, behind the look-back below.)
+        if (last_round && !last_group && tid == 64 && pass == 0 && (group_bits >= 7u || rel == 0)) {
             const uint32_t e = group_bits - wbase * 32u; // the end of the group's bits in this window
             const uint32_t wi = (e - 1u) >> 5, lo = wi ? buf[wi - 1] : (wbase ? s_carry : 0u), hi = buf[wi];
             const uint32_t used = e - wi * 32u; // bits of word wi in use (1..32): the last 7 bits = bits [used - 7, used) of {lo, hi}
             const uint64_t both = ((uint64_t)lo << 32) | hi;
             store_relaxed(&tails[g], kTailValid | (uint32_t)((both >> (32u - used)) & 0x7Fu));
         }
-        if (wbase == 0) { // where the group starts in its scan
+        if (wbase == 0 && pass == 0) { // where the group starts in its scan
             if (wave == 0) {
                 const uint64_t sum = look_back_blocks(desc, SUP, g, floor, group_bits, a_state, host_abort, rest.spin_budget, sup_copies, sup_stride);
                 if (lane == 0) {
                     if (sum == kLookBackFailed) s_abort = 1;
                     s_before = sum;
                 }
-            } else if (tid == 128 && rel > 0) { // meanwhile: the seven bits in front of this group (used if it starts inside a byte)
+            } else if (!MULTI && tid == 128 && rel > 0) { // meanwhile: the seven bits in front of this group (used if it starts inside a byte)
+                // (a group of several rounds asks for them BEHIND its count pass — below: it lets its own last seven bits out in that pass's
+                // last round, and asking first made every such group wait for the whole count pass of the group before it)
                 unsigned long long t = load_relaxed(&tails[g - 1]);
                 uint32_t polls = 0;
                 while (!(t & kTailValid)) {
@@ -463,6 +599,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             __syncthreads();
             PIXO_STAMP(6);
             if (uni(s_abort)) { aborted = true; return; }
+            if (!MULTI && group_bits < 7u && rel > 0 && !last_group && tid == 64) // (see above; every block has at least two bits)
+                store_relaxed(&tails[g], kTailValid | (((s_head << group_bits) | (buf[0] >> (32u - group_bits))) & 0x7Fu));
             S = uni64(s_before);
             sh8 = (uint32_t)(S & 7);
             const uint64_t end_bits = (uint64_t)sh8 + group_bits; // in aligned bits: bit 0 = the first bit of the group's first owned byte
@@ -487,7 +625,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             v |= wbase + jl == pad_word ? pad_mask : 0u;
             return v;
         };
-        const uint32_t head_now = wbase ? head : (uni(s_head) & ((1u << sh8) - 1u)); // the last sh8 of the seven bits in front
+        // the last sh8 of the seven bits in front (a count pass runs without them: its first byte then cannot be 0xFF, and whether it is
+        // is settled behind the pass — s_front2: the group's own part of that byte is all ones)
+        const uint32_t head_now = wbase ? head : ((MULTI && pass == 0) ? 0u : (uni(s_head) & ((1u << sh8) - 1u)));
         // owned bytes of THIS round: up to the group's last one, or (not the last round) up to the round's last complete aligned word
         const uint32_t round_first = 4u * wbase;
         const uint32_t limit = last_round ? nb_total : (nb_total < 4u * (wbase + wn) ? nb_total : 4u * (wbase + wn));
@@ -532,89 +672,38 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             if (k < wave) wave_base_ff += ff_of_wave[k];
             round_ff += ff_of_wave[k];
         }
-        // ---- the number of stuffed zeros before the group: its own count goes out when it is complete (the last round), the
-        // look-back for the groups before it runs in the first round
-        if (last_round && tid == 0) store_relaxed(&desc2[g], kFlagAggregate | (uint64_t)(ff_group + round_ff));
-        if (wbase == 0) {
-            if (wave == 0) { // (look_back_blocks' two levels; the block's sum is published below, when this group's own count is complete)
-                int lane2 = lane; // (a value of this place: see look_back_blocks)
-                asm volatile("" : "+v"(lane2));
-#undef lane
-#define lane lane2
-                const uint64_t block_first = floor + ((uint64_t)kblk << 6);
-                uint32_t polls = 0;
-                bool gave_up = false;
-                unsigned long long *const SUP2r = SUP2 + (size_t)((uint32_t)g & (sup_copies - 1u)) * sup_stride; // the copy this group reads
-                unsigned long long da = (uint32_t)lane < in_block ? load_relaxed(&desc2[block_first + lane]) : kFlagAggregate;
-                unsigned long long db2 = (uint32_t)lane < kblk ? load_relaxed(&SUP2r[lane]) : kFlagAggregate;
-                while ((da >> 62) == 0 && !gave_up) {
-                    __builtin_amdgcn_s_sleep(kPollSleep);
-                    if (++polls > rest.spin_budget) gave_up = true; else da = load_relaxed(&desc2[block_first + lane]);
-                }
-                uint64_t before2 = 0;
-                uint32_t front = 0;
-                if (!PIXO_ANY64(gave_up)) {
-                    front = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)(da & kValueMask)), 63);
-                    before2 = front;
-                    // the block's own sum goes out BEFORE waiting for the other blocks' sums (a group of one round knows its count here):
-                    // published behind that wait, the blocks' last groups would form one chain of waits through the whole scan
-                    if (in_block == 63u && last_round && (uint32_t)lane < sup_copies) store_relaxed(&SUP2[(size_t)lane * sup_stride + kblk], kFlagAggregate | ((uint64_t)front + ff_group + round_ff));
-                    for (uint32_t base = 0;;) {
-                        while ((db2 >> 62) == 0 && !gave_up) {
-                            __builtin_amdgcn_s_sleep(kPollSleep);
-                            if (++polls > rest.spin_budget) gave_up = true; else db2 = load_relaxed(&SUP2r[base + lane]);
-                        }
-                        if (PIXO_ANY64(gave_up)) break;
-                        before2 += (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan((uint32_t)(db2 & kValueMask)), 63);
-                        base += 64;
-                        if (base >= kblk) break;
-                        db2 = base + lane < kblk ? load_relaxed(&SUP2r[base + lane]) : kFlagAggregate;
-                    }
-                }
-                if (PIXO_ANY64(gave_up)) {
-                    if (gave_up) raise_abort(a_state, host_abort);
-                    if (lane == 0) s_abort = 1;
-                } else if (lane == 0) {
-                    s_before = before2;
-                    s_front2 = front;
-                }
-#undef lane
-#define lane lane_again
-            } else if (SEG && wave == 1 && seg > 0 && !seg_late) {
-                // meanwhile: where this segment's bytes begin — a look-back over the SEGMENTS' byte counts.  HERE, behind the group's own
-                // 0xFF count going out, not beside the first look-back: the count of the segment before is known when ITS last group is
-                // through its second look-back, and a group that waited for that in front of its census kept its own count from the
-                // groups behind it — every segment's last group then finished one census + one look-back (6.5 us) behind the last group
-                // of the segment before: a serial chain through all segments (64 x 1080p: 414-453 us; 32 x 4096x512: 216-236 us
-                // against 126-141 us for the same groups in 4 segments, profiles/r06_fused_batches_chain.txt).
-                const uint64_t sb = look_back(segdesc, seg, 0, 0, a_state, host_abort, rest.spin_budget);
-                if (lane == 0) {
-                    if (sb == kLookBackFailed) s_abort = 1;
-                    s_segbase = sb;
-                }
-            }
+        // ---- the number of stuffed zeros before the group.  A group of ONE round: its count goes out here, the look-back follows at once.
+        // A group of SEVERAL rounds (MULTI) COUNTS all its rounds first (pass 0: walk, window, census — nothing is stored), lets its count
+        // out, looks back, and only then walks its rounds again to expand and store them (pass 1).  (Until the second session of round 6
+        // such a group looked back in its first round and let its count out in its last: every group waited for the whole group before
+        // it — noise at q >= 90, photographs at q = 100, gray noise at q = 80 took 24-46 ms per 4096x4096 file instead of 0.1 ms,
+        // profiles/r06_long_groups_chain.txt.)
+        if (MULTI && pass == 0) { // the count pass ends here
+            if (wbase == 0 && tid == 0) s_front2 = (x[0] >> 24) == (0xFFu >> sh8) ? 1u : 0u;
+            ff_group += round_ff;
+            if (tid == 0) s_carry = buf[wn - 1];
             __syncthreads();
-            PIXO_STAMP(8);
-            if (uni(s_abort)) { aborted = true; return; }
-            ff_before_groups = uni64(s_before);
-            in_front2 = uni(s_front2);
-            if (SEG) seg_base = uni64(s_segbase);
-            if (!MULTI && seg_late && nsegs > 1) { // (workgroup-uniform) a segment's last group of one round: the segment's bytes are known — out
-                                                    // they go, and only then: where does the segment begin?
-                if (tid == 0 && seg + 1 < nsegs) publish_aggregate(segdesc, seg, 0, (S >> 3) + nb_total + ff_before_groups + round_ff + rest.gap);
-                if (seg > 0) {
-                    if (wave == 1) {
-                        const uint64_t sb = look_back(segdesc, seg, 0, 0, a_state, host_abort, rest.spin_budget);
-                        if (lane == 0) {
-                            if (sb == kLookBackFailed) s_abort = 1;
-                            s_segbase = sb;
-                        }
+            continue;
+        }
+        if (!MULTI) {
+            if (tid == 0) store_relaxed(&desc2[g], kFlagAggregate | (uint64_t)round_ff);
+            if (!second_look_back(round_ff)) return;
+        if (!MULTI && seg_late && nsegs > 1) { // (workgroup-uniform) a segment's last group of one round: the segment's bytes are known — out
+                                                // they go, and only then: where does the segment begin?
+            if (tid == 0 && seg + 1 < nsegs) publish_aggregate(segdesc, seg, 0, (S >> 3) + nb_total + ff_before_groups + round_ff + rest.gap);
+            if (seg > 0) {
+                if (wave == 1) {
+                    const uint64_t sb = look_back(segdesc, seg, 0, 0, a_state, host_abort, rest.spin_budget);
+                    if (lane == 0) {
+                        if (sb == kLookBackFailed) s_abort = 1;
+                        s_segbase = sb;
                     }
-                    __syncthreads();
-                    if (uni(s_abort)) { aborted = true; return; }
-                    seg_base = uni64(s_segbase);
                 }
+                __syncthreads();
+                if (uni(s_abort)) { aborted = true; return; }
+                seg_base = uni64(s_segbase);
             }
+        }
         }
         // ---- expand + store.  Output offset of the round's first byte (owned byte 4 wbase of the group):
         const uint64_t dst_round = (uint64_t)rest.out_skew + seg_base + (S >> 3) + ff_before_groups + round_first + ff_group;
@@ -678,13 +767,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             __syncthreads();
         }
     }
+    }
     };
     if (park) rounds(std::true_type{}); else rounds(std::false_type{});
     PIXO_STAMP(10);
     if (aborted) return;
-    // the block of 64 groups is complete with its last group: its sum of stuffed zeros for the groups behind
-    // (a group of several rounds knows its count only now)
-    if (in_block == 63u && park && (uint32_t)tid < sup_copies) store_relaxed(&SUP2[(size_t)tid * sup_stride + kblk], kFlagAggregate | ((uint64_t)in_front2 + ff_group));
     if (last_group && tid == 0) { // the segment is complete: where the next one begins, where this one ends, the launch's totals
         const uint64_t packed = (S >> 3) + nb_total, stuffed = packed + ff_before_groups + ff_group, end = seg_base + stuffed;
         if (seg + 1 < nsegs) {
@@ -739,7 +826,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     c.px = a_px; c.y = c.cb = c.cr = nullptr; c.qt = a_qt;
     c.W = a_W; c.H = a_H; c.units_x = a_units_x; c.units_y = a_units_y; c.fast = 1;
     c.px_end = a_px + early.px_bytes;
-    {
+    if constexpr (MODE == MGRAY) {
+        phase_a_gray_row<LOAD>(c, tx, ty, wave, lane, lds);
+    } else {
         constexpr int base = G::items / kWaves, extra = G::items % kWaves;
         const int first = (extra && wave < extra) ? wave * (base + 1) : extra * (base + 1) + (wave - extra) * base;
         const LaneAddr la = lane_addr<MODE>(c, tx, ty, lane);
@@ -768,11 +857,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     const uint32_t tiles_x = gridDim.x, g = ty * tiles_x + tx;
     if (g == 0) // (the sums start from zero: cheaper here than a memset launch — the summing kernel runs behind this one)
         for (int i = tid; i < kTableWords; i += kGroup) a_hist[i] = 0;
-    const uint32_t u0 = tx * (uint32_t)G::units_x;
-    const uint32_t nvalid = a_units_x - u0 < (uint32_t)G::units_x ? a_units_x - u0 : (uint32_t)G::units_x;
+    const uint32_t u0 = tx * (uint32_t)tile_units<MODE>();
+    const uint32_t nvalid = a_units_x - u0 < (uint32_t)tile_units<MODE>() ? a_units_x - u0 : (uint32_t)tile_units<MODE>();
     uint32_t m, comp, sidx;
     bool first_of_comp, last_block_of_mcu_comp;
-    if (MODE == M420) {
+    if (MODE == MGRAY) {
+        m = (uint32_t)tid; comp = 0; sidx = m; first_of_comp = last_block_of_mcu_comp = true;
+    } else if (MODE == M420) {
         if (wave < 2) { m = (uint32_t)wave * 16u + ((uint32_t)lane >> 2); comp = 0; sidx = 6u * m + ((uint32_t)lane & 3u); first_of_comp = (lane & 3) == 0; last_block_of_mcu_comp = (lane & 3) == 3; }
         else { m = (uint32_t)lane & 31u; comp = 1u + ((uint32_t)lane >> 5); sidx = 6u * m + 3u + comp; first_of_comp = last_block_of_mcu_comp = true; }
     } else {
@@ -788,7 +879,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     __syncthreads(); // every wavefront has consumed its planar rows (the area becomes the counters), s_dc is complete
     uint32_t *lhist = reinterpret_cast<uint32_t *>(lds);
     for (int i = tid; i < kWalkWords + kGroup; i += kGroup) lhist[i] = 0;
-    const uint32_t back = MODE == M420 ? (comp == 0 ? (first_of_comp ? 3u : 1u) : 6u) : 3u;
+    const uint32_t back = MODE == MGRAY ? 1u : (MODE == M420 ? (comp == 0 ? (first_of_comp ? 3u : 1u) : 6u) : 3u);
     const int prev_dc = external ? 0 : (int)s_dc[sidx - back];
     __syncthreads();
     const uint32_t cls = comp ? 1u : 0u;
@@ -802,7 +893,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
 // the workgroup (0, kPcSumRows): the DC symbols of the tiles' first blocks from the (last, first) pairs
 constexpr uint32_t kPcSumRows = 32;
 __global__ __launch_bounds__(256) void pixels_count_sum_kernel(const uint16_t *slab, const int16_t *edges, uint32_t tiles, uint32_t tiles_x, uint32_t seg_rows,
-                                                               unsigned long long *hist)
+                                                               uint32_t comps, unsigned long long *hist)
 {
     __shared__ uint32_t part[4][64];
     __shared__ uint32_t dcs[2][16];
@@ -812,6 +903,7 @@ __global__ __launch_bounds__(256) void pixels_count_sum_kernel(const uint16_t *s
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < 3u * tiles; i += 256u) {
             const uint32_t t = i / 3u, comp = i - 3u * t;
+            if (comp >= comps) continue; // (a gray tile has one component)
             const bool seg_first = t % (seg_rows * tiles_x) == 0; // (a restart interval's — or the image's — first tile: predictors 0)
             const int prev = seg_first ? 0 : (int)edges[((size_t)(t - 1) * 3 + comp) * 2 + 1];
             const int diff = (int)(int16_t)((int)edges[((size_t)t * 3 + comp) * 2] - prev);
@@ -842,12 +934,12 @@ __global__ __launch_bounds__(256) void pixels_count_sum_kernel(const uint16_t *s
 
 size_t pixels_count_scratch_bytes(const PixelsCodePlan &p) { return (size_t)p.groups * kWalkWords * 2 + (size_t)p.groups * 3 * 2 * 2 + 16; }
 
-hipError_t launch_pixels_count(const void *d_px, uint32_t W, uint32_t H, bool s420, const PixelsCodePlan &p, const float *d_qt, void *d_scratch,
+hipError_t launch_pixels_count(const void *d_px, uint32_t W, uint32_t H, bool gray, bool s420, const PixelsCodePlan &p, const float *d_qt, void *d_scratch,
                                unsigned long long *d_hist, hipStream_t s)
 {
-    if (!pixels_code_supported(W, H, false, s420, 1, 0) || p.images != 1 || p.groups > 0x7FFFFFFFull || p.tiles_y > 65535u) return hipErrorInvalidValue;
+    if (!pixels_code_supported(W, H, gray, s420, 1, 0) || p.images != 1 || p.groups > 0x7FFFFFFFull || p.tiles_y > 65535u) return hipErrorInvalidValue;
     PEarly early;
-    const size_t row_bytes = (size_t)W * 3;
+    const size_t row_bytes = (size_t)W * (gray ? 1 : 3);
     early.px_stride = row_bytes * H;
     early.px_bytes = early.px_stride;
     uint16_t *slab = static_cast<uint16_t *>(d_scratch);
@@ -858,13 +950,14 @@ hipError_t launch_pixels_count(const void *d_px, uint32_t W, uint32_t H, bool s4
     const bool packed = packed_launch(p.groups);
 #define PIXO_LAUNCH_CNT2(MODE, LOAD, PK) hipLaunchKernelGGL((pixels_count_kernel<MODE, LOAD, PK>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, p.units_x, p.units_y, slab, edges, d_hist, early)
 #define PIXO_LAUNCH_CNT(MODE, LOAD) do { if (packed) PIXO_LAUNCH_CNT2(MODE, LOAD, true); else PIXO_LAUNCH_CNT2(MODE, LOAD, false); } while (0)
-    if (s420) { if (aligned) PIXO_LAUNCH_CNT(M420, L_ALIGNED); else PIXO_LAUNCH_CNT(M420, L_FUNNEL); }
+    if (gray) { if (aligned) PIXO_LAUNCH_CNT(MGRAY, L_ALIGNED); else PIXO_LAUNCH_CNT(MGRAY, L_FUNNEL); }
+    else if (s420) { if (aligned) PIXO_LAUNCH_CNT(M420, L_ALIGNED); else PIXO_LAUNCH_CNT(M420, L_FUNNEL); }
     else { if (aligned) PIXO_LAUNCH_CNT(M444, L_ALIGNED); else PIXO_LAUNCH_CNT(M444, L_FUNNEL); }
 #undef PIXO_LAUNCH_CNT
 #undef PIXO_LAUNCH_CNT2
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(pixels_count_sum_kernel, dim3((kWalkWords + 63) / 64, kPcSumRows + 1), dim3(256), 0, s, slab, edges, (uint32_t)p.groups, p.tiles_x, p.seg_rows, d_hist);
+    hipLaunchKernelGGL(pixels_count_sum_kernel, dim3((kWalkWords + 63) / 64, kPcSumRows + 1), dim3(256), 0, s, slab, edges, (uint32_t)p.groups, p.tiles_x, p.seg_rows, gray ? 1u : 3u, d_hist);
     return hipGetLastError();
 }
 
@@ -875,10 +968,10 @@ extern "C" __attribute__((visibility("default"))) int pixo_hip_debug_pixels_code
 }
 #endif
 
-PixelsCodePlan pixels_code_plan(uint32_t W, uint32_t H, bool s420, uint32_t images, uint32_t restart_mcus)
+PixelsCodePlan pixels_code_plan(uint32_t W, uint32_t H, bool s420, uint32_t images, uint32_t restart_mcus, bool gray)
 {
     PixelsCodePlan p;
-    const uint32_t unit = s420 ? 16u : 8u, per_tile = s420 ? 32u : 64u;
+    const uint32_t unit = (s420 && !gray) ? 16u : 8u, per_tile = gray ? (uint32_t)kGrayTileBlocks : (s420 ? 32u : 64u);
     p.units_x = (W + unit - 1) / unit; p.units_y = (H + unit - 1) / unit;
     p.tiles_x = (p.units_x + per_tile - 1) / per_tile; p.tiles_y = p.units_y;
     p.images = images;
@@ -902,21 +995,21 @@ PixelsCodePlan pixels_code_plan(uint32_t W, uint32_t H, bool s420, uint32_t imag
 
 bool pixels_code_supported(uint32_t W, uint32_t H, bool gray, bool s420, uint32_t images, uint32_t restart_mcus)
 { // vector pixel loads need one whole 4-pixel group per row; a tile row per grid row; restart intervals: whole MCU rows of ONE image
-    if (gray || W < 4 || H < 1 || (H + 7) / 8 > 65535u || images < 1 || images > 65535u) return false;
+    if (W < 4 || H < 1 || (H + 7) / 8 > 65535u || images < 1 || images > 65535u) return false;
     if (restart_mcus) {
-        const uint32_t unit = s420 ? 16u : 8u, units_x = (W + unit - 1) / unit;
+        const uint32_t unit = (s420 && !gray) ? 16u : 8u, units_x = (W + unit - 1) / unit;
         if (images > 1 || restart_mcus % units_x != 0) return false;
     }
     return true;
 }
 
-hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s420, const PixelsCodePlan &p, uint32_t gap, bool rst_markers,
+hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool gray, bool s420, const PixelsCodePlan &p, uint32_t gap, bool rst_markers,
                               const float *d_qt, const uint32_t *d_tables, unsigned long long *d_state, bool state_is_zero,
                               unsigned long long *d_clear, size_t clear_words, uint8_t *d_out, uint64_t out_cap, unsigned long long *host_totals,
                               unsigned long long *host_segs, const int16_t seed_dc[3], bool pad_last, void *d_block_spill, hipStream_t s,
                               uint32_t spin_budget)
 {
-    if (!pixels_code_supported(W, H, false, s420, p.images, 0) || clear_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (!pixels_code_supported(W, H, gray, s420, p.images, 0) || clear_words > 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (p.groups > 0x7FFFFFFFull || p.tiles_y > 65535u) return hipErrorInvalidValue;
     if (rst_markers && gap != 2) return hipErrorInvalidValue;
     if (host_totals) host_totals[3] = 0; // (the kernels' abort flag)
@@ -926,7 +1019,7 @@ hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s42
     }
     PRest rest;
     PEarly early;
-    const size_t row_bytes = (size_t)W * 3;
+    const size_t row_bytes = (size_t)W * (gray ? 1 : 3);
     early.px_stride = row_bytes * H;
     early.px_bytes = early.px_stride * p.images;
     rest.clear = d_clear; rest.clear_words = d_clear ? (uint32_t)clear_words : 0u;
@@ -952,7 +1045,8 @@ hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s42
 #define PIXO_LAUNCH_PC2(MODE, LOAD, PK) do { if (segs) hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, PK, true>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, p.units_x, p.units_y, d_tables, d_state, out, early, rest); \
                                              else hipLaunchKernelGGL((pixels_code_kernel<MODE, LOAD, PK, false>), grid, dim3(kThreads), 0, s, px, W, H, d_qt, p.units_x, p.units_y, d_tables, d_state, out, early, rest); } while (0)
 #define PIXO_LAUNCH_PC(MODE, LOAD) do { if (packed) PIXO_LAUNCH_PC2(MODE, LOAD, true); else PIXO_LAUNCH_PC2(MODE, LOAD, false); } while (0)
-    if (s420) { if (aligned) PIXO_LAUNCH_PC(M420, L_ALIGNED); else PIXO_LAUNCH_PC(M420, L_FUNNEL); }
+    if (gray) { if (aligned) PIXO_LAUNCH_PC(MGRAY, L_ALIGNED); else PIXO_LAUNCH_PC(MGRAY, L_FUNNEL); }
+    else if (s420) { if (aligned) PIXO_LAUNCH_PC(M420, L_ALIGNED); else PIXO_LAUNCH_PC(M420, L_FUNNEL); }
     else { if (aligned) PIXO_LAUNCH_PC(M444, L_ALIGNED); else PIXO_LAUNCH_PC(M444, L_FUNNEL); }
 #undef PIXO_LAUNCH_PC
 #undef PIXO_LAUNCH_PC2

@@ -19,7 +19,7 @@ struct PixelsCodePlan {
     size_t state_words = 0;              // u64 words of d_state (zero before the launch)
 };
 // restart_mcus: JpegOptions::restart_interval if the scan emits RSTn markers (0: none) — must be a multiple of the MCUs per row
-PixelsCodePlan pixels_code_plan(uint32_t W, uint32_t H, bool s420, uint32_t images, uint32_t restart_mcus);
+PixelsCodePlan pixels_code_plan(uint32_t W, uint32_t H, bool s420, uint32_t images, uint32_t restart_mcus, bool gray = false); // gray: tiles of 1536 x 8 pixels (192 blocks of one block row)
 // Does the kernel serve such a scan?  RGB (4:2:0 or 4:4:4), W >= 4, standard or any GIVEN tables; restart intervals only as whole
 // MCU rows of one image.  (Gray images, optimised tables, bands of a multi-GPU image: coefficient kernel + scan_code + stuff_fused.)
 bool pixels_code_supported(uint32_t W, uint32_t H, bool gray, bool s420, uint32_t images, uint32_t restart_mcus);
@@ -39,7 +39,7 @@ bool pixels_code_supported(uint32_t W, uint32_t H, bool gray, bool s420, uint32_
 // not 1-padded (its incomplete byte is not stored: host_totals[0] says how many bits there are).
 // d_block_spill: p.groups x 192 x 128 bytes of device memory (never read by the caller): groups whose bits do not fit one
 // 6 KiB round (noise at q >= 90) park their quantised blocks there between the rounds' walks.
-hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s420, const PixelsCodePlan &p, uint32_t gap, bool rst_markers,
+hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool gray, bool s420, const PixelsCodePlan &p, uint32_t gap, bool rst_markers,
                               const float *d_qt, const uint32_t *d_tables, unsigned long long *d_state, bool state_is_zero,
                               unsigned long long *d_clear, size_t clear_words, uint8_t *d_out, uint64_t out_cap, unsigned long long *host_totals,
                               unsigned long long *host_segs, const int16_t seed_dc[3], bool pad_last, void *d_block_spill, hipStream_t s,
@@ -50,7 +50,7 @@ hipError_t launch_pixels_code(const void *d_px, uint32_t W, uint32_t H, bool s42
 // walk as a counter, ONE image (restart intervals of whole MCU rows as planned by pixels_code_plan), no tuple.  d_hist: kTableWords
 // u64 in launch_scan_count's layout ([class][12 DC + 256 AC]); d_scratch: pixels_count_scratch_bytes(p) bytes.
 size_t pixels_count_scratch_bytes(const PixelsCodePlan &p);
-hipError_t launch_pixels_count(const void *d_px, uint32_t W, uint32_t H, bool s420, const PixelsCodePlan &p, const float *d_qt, void *d_scratch,
+hipError_t launch_pixels_count(const void *d_px, uint32_t W, uint32_t H, bool gray, bool s420, const PixelsCodePlan &p, const float *d_qt, void *d_scratch,
                                unsigned long long *d_hist, hipStream_t s);
 
 } // namespace pixo_dev

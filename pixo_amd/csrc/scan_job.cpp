@@ -247,9 +247,9 @@ int pixels_count(Context &c, const pixo_jpeg_options &o, const pixo_host::Geomet
     const float *qt_all = nullptr;
     { const int rc = device_tables(c.device, &qt_all); if (rc) return rc; }
     const uint32_t restart = scan_has_restart_markers(o, g) ? o.restart_interval : 0;
-    const pd::PixelsCodePlan plan = pd::pixels_code_plan(o.width, o.height, g.s420, 1, restart);
+    const pd::PixelsCodePlan plan = pd::pixels_code_plan(o.width, o.height, g.s420, 1, restart, g.gray);
     HIP_TRY(c.e_count.reserve(pd::pixels_count_scratch_bytes(plan)));
-    HIP_TRY(pd::launch_pixels_count(d_pixels, o.width, o.height, g.s420, plan, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c.e_count.p,
+    HIP_TRY(pd::launch_pixels_count(d_pixels, o.width, o.height, g.gray, g.s420, plan, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats, c.e_count.p,
                                     c.e_hist.as<unsigned long long>(), stream));
     { const int rc = c.reserve_hsegs(pixo_host::kScanTableWords); if (rc) return rc; }
     HIP_TRY(hipMemcpyAsync(c.h_segs, c.e_hist.p, pixo_host::kScanTableWords * 8, hipMemcpyDeviceToHost, stream));
@@ -344,7 +344,7 @@ int scan_lengths(Context &c, ScanJob &j, const pixo_jpeg_options &o, const pixo_
 bool pixels_code_usable(const ScanJob &j, const pixo_jpeg_options &o, const pixo_host::Geometry &g, uint32_t batch)
 { // one uninterrupted RGB scan, the images of a batch, or restart intervals of whole MCU rows — with GIVEN tables.  (Independent of
   // which tuple kernels scan_begin chose: segments of any size are chains of the fused kernel.)
-    if (j.band || g.gray || o.progressive || debug().two_kernel_scan || debug().multipass_entropy || t_force_multipass) return false;
+    if (j.band || o.progressive || debug().two_kernel_scan || debug().multipass_entropy || t_force_multipass) return false;
     if (o.optimize_huffman && batch > 1) return false; // (every file of a batch has tables of its own: not segments of one launch)
     // Batches: every image a segment of ONE launch of the fused kernel — since the segments' byte counts are asked for BEHIND a group's own
     // 0xFF count (jpeg_pixels_code.hip; in front of it every segment's last group finished 6.5 us behind the one before: 64 x 1080p took
@@ -353,7 +353,7 @@ bool pixels_code_usable(const ScanJob &j, const pixo_jpeg_options &o, const pixo
     // 512-pixel TILE: images whose tiles are mostly empty (640 px wide: 62 %) keep the two-kernel form, whose groups are dense
     // (256 x 640x480: 207-233 against 195-211 us).  debug switch fused_batch: the fused kernel whatever the width.
     if (batch > 1 && !debug().fused_batch) {
-        const uint32_t unit = g.s420 ? 16u : 8u, per_tile = g.s420 ? 32u : 64u;
+        const uint32_t unit = g.s420 ? 16u : 8u, per_tile = g.gray ? 192u : (g.s420 ? 32u : 64u);
         const uint32_t units_x = (o.width + unit - 1) / unit, tiles_x = (units_x + per_tile - 1) / per_tile;
         if (static_cast<uint64_t>(units_x) * 4 < static_cast<uint64_t>(tiles_x) * per_tile * 3) return false;
     }
@@ -371,7 +371,7 @@ int scan_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const p
     const float *qt_all = nullptr;
     if ((rc = device_tables(c.device, &qt_all))) return rc;
     const uint32_t restart = (batch == 1 && scan_has_restart_markers(o, g)) ? o.restart_interval : 0;
-    const pd::PixelsCodePlan plan = pd::pixels_code_plan(o.width, o.height, g.s420, batch, restart);
+    const pd::PixelsCodePlan plan = pd::pixels_code_plan(o.width, o.height, g.s420, batch, restart, g.gray);
     const size_t words = plan.state_words;
     const bool segs = plan.segments > 1;
     const uint32_t gap = !segs ? 0u : (restart ? 2u : j.seg_gap); // RSTn, or what a batch wants between its files' scans
@@ -412,7 +412,7 @@ int scan_from_pixels(Context &c, ScanJob &j, const pixo_jpeg_options &o, const p
         unsigned long long *mine = c.e_pc_state.as<unsigned long long>() + static_cast<size_t>(c.pc_flip) * words;
         unsigned long long *other = c.e_pc_state.as<unsigned long long>() + static_cast<size_t>(c.pc_flip ^ 1) * words;
         c.pc_flip ^= 1;
-        HIP_TRY(pd::launch_pixels_code(d_pixels, o.width, o.height, g.s420, plan, gap, rst, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats,
+        HIP_TRY(pd::launch_pixels_code(d_pixels, o.width, o.height, g.gray, g.s420, plan, gap, rst, qt_all + (o.quality - 1) * pixo_host::kDeviceQtFloats,
                                        c.e_tables.as<uint32_t>(), mine, /*state_is_zero=*/true, other, words, out, out_cap,
                                        reinterpret_cast<unsigned long long *>(c.h_totals), segs ? reinterpret_cast<unsigned long long *>(c.h_segs) : nullptr,
                                        nullptr, true, c.e_pc_spill.p, stream, debug().spin_budget));

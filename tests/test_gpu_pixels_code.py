@@ -276,3 +276,70 @@ def test_optimised_tables_statistics_from_the_pixels(w, h, ss, q, rows):
         finally:
             jpeg.debug_configure(None)
     assert jpeg.lookback_fallbacks() == 0
+
+
+@pytest.mark.parametrize("w,h,q", [(1536, 8, 80), (1537, 9, 80), (4, 1, 75), (5, 5, 90), (200, 120, 80), (1535, 64, 50), (3073, 33, 85), (4096, 4096, 80),
+                                   (4094, 515, 80), (1920, 1080, 92), (6150, 24, 100)])
+def test_gray_images_through_the_fused_kernel(w, h, q):
+    """Gray8 (ColorType::Gray, src/jpeg/mod.rs:1448-1470): tiles of 1536 x 8 pixels — 192 consecutive blocks of one block row — through
+    the fused kernel; rows of any alignment, partial last tiles, edge replication (extract_block :1565-1606), standard and optimised
+    tables, restart intervals of whole block rows, a batch.  Files = the oracle's = the two-kernel form's."""
+    import torch
+    units_x = (w + 7) // 8
+    for px in (synth.noise_gray(w, h, 7 + w), synth.photo(w, h, 8 + h).reshape(-1, 3)[:, 1].copy()):
+        d = torch.from_numpy(np.ascontiguousarray(px)).cuda()
+        for opt, rows in ((False, 0), (True, 0), (False, 2), (True, 1)):
+            if rows and rows * units_x > 65535:
+                continue
+            b = jpeg.JpegOptions.builder(w, h).color_type(ColorType(0)).quality(q).optimize_huffman(opt)
+            if rows:
+                b = b.restart_interval(rows * units_x)
+            o = b.build()
+            want = O.encode(px, O.make_options(w, h, 0, q, 0, optimize_huffman=opt, restart=rows * units_x if rows else None))
+            if not opt:
+                assert _form(d, o) == 1, "a gray image did not take the fused kernel"
+            assert jpeg.encode_device(d, o) == want, "gray, device pixels (optimised %s, restart rows %d): file differs from the oracle" % (opt, rows)
+            assert jpeg.encode(px, o) == want
+            jpeg.debug_configure("two_kernel_scan")
+            try:
+                assert jpeg.encode_device(d, o) == want
+            finally:
+                jpeg.debug_configure(None)
+    if w * h <= 1920 * 1080:  # a batch of gray images: every image a segment
+        n = 5
+        imgs = [synth.noise_gray(w, h, 50 + i) for i in range(n)]
+        d = torch.from_numpy(np.concatenate(imgs)).cuda()
+        o = jpeg.JpegOptions.builder(w, h).color_type(ColorType(0)).quality(q).build()
+        want = [O.encode(px, O.make_options(w, h, 0, q, 0)) for px in imgs]
+        jpeg.debug_configure("fused_batch")
+        try:
+            assert [bytes(f) for f in jpeg.encode_batch_device(d, o, n)] == want
+        finally:
+            jpeg.debug_configure(None)
+        assert [bytes(f) for f in jpeg.encode_batch_device(d, o, n)] == want
+    assert jpeg.lookback_fallbacks() == 0
+
+
+@pytest.mark.parametrize("w,h,ct,ss", [(8, 212, 0, 0), (7, 230, 0, 0), (4, 4000, 0, 0), (8, 300, 2, 0), (5, 333, 2, 0), (16, 500, 2, 1), (1537, 100, 0, 0), (520, 90, 2, 0)])
+def test_groups_of_fewer_than_seven_bits_hand_on_the_bits_in_front_of_them(w, h, ct, ss):
+    """A tile with one block (narrow gray images, a row's last tile) under optimised tables whose codes are one bit long codes two or
+    three bits per group: the seven bits a group hands to the group behind it are then not all its own (found by tools/stress_parity.py:
+    gray 8 x 212, optimize_huffman, a slow ramp).  Ramps, flat images and noise; standard and optimised tables; restart rows."""
+    import torch
+    n = w * h * (3 if ct == 2 else 1)
+    unit = 16 if ss == 1 else 8
+    units_x = (w + unit - 1) // unit
+    contents = [((np.arange(n, dtype=np.int64) // 3 // 70) % 256).astype(np.uint8), np.full(n, 200, np.uint8), synth.lcg_bytes(n, 9),
+                ((np.arange(n, dtype=np.int64) // (3 * w)) % 256).astype(np.uint8)]
+    for px in contents:
+        d = torch.from_numpy(px).cuda()
+        for opt in (True, False):
+            for rows in (0, 3):
+                for q in (37, 80):
+                    b = jpeg.JpegOptions.builder(w, h).color_type(ColorType(ct)).quality(q).subsampling(jpeg.Subsampling(ss)).optimize_huffman(opt)
+                    if rows:
+                        b = b.restart_interval(rows * units_x)
+                    o = b.build()
+                    want = O.encode(px, O.make_options(w, h, ct, q, ss, optimize_huffman=opt, restart=rows * units_x if rows else None))
+                    assert jpeg.encode_device(d, o) == want, (w, h, ct, ss, opt, rows, q)
+    assert jpeg.lookback_fallbacks() == 0

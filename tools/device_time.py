@@ -16,13 +16,17 @@ from pixo_amd import jpeg
 
 W = H = 4096
 SS = jpeg.Subsampling.S444 if os.environ.get("SS") == "444" else jpeg.Subsampling.S420  # (SS=444: the reference's default subsampling)
-O = jpeg.JpegOptions.builder(W, H).quality(80).subsampling(SS).build()
+Q = int(os.environ.get("Q", "80"))
+GRAY = os.environ.get("SS") == "gray"  # (SS=gray: Gray8 pixels)
+O = jpeg.JpegOptions.builder(W, H).quality(Q).subsampling(SS).build() if not GRAY else jpeg.JpegOptions.builder(W, H).color_type(jpeg.ColorType(0)).quality(Q).build()
 if len(sys.argv) > 1 and sys.argv[1] == "two":
     jpeg.debug_configure("two_kernel_scan")
 stream = torch.cuda.current_stream().cuda_stream
 out = []
 for kind in ("noise", "photo", "gradient"):
     px = synth.noise(W, H, 42) if kind == "noise" else (synth.photo(W, H, 42) if kind == "photo" else synth.gradient_rgb(W, H))
+    if GRAY:
+        px = px.reshape(-1, 3)[:, 1].copy()
     ds = [torch.from_numpy(np.ascontiguousarray(px)).cuda() for _ in range(4)]  # (rotating copies: 200 MB > one L2, < Infinity Cache; the kernels' traffic is what it is)
     form = jpeg.debug_scan_device_async(ds[0], O, stream=stream)
     torch.cuda.synchronize()

@@ -22,7 +22,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 L = ctypes.CDLL(os.environ["PIXO_HIP_LIB"])
 names = ["entry", "phase A", "phase B", "walk", "prefix", "gathered", "look-back 1", "census", "look-back 2", "expanded", "stored"] if not os.environ.get("PIXO_TIMELINE_R05") else ["entry", "phase A", "phase B", "walk", "prefix", "gathered", "look-back 1", "census", "look-back 2", "stored"]
 NS = len(names)
-o = jpeg.JpegOptions.builder(n, n).quality(80).subsampling(jpeg.Subsampling(1)).build()
+o = jpeg.JpegOptions.builder(n, n).quality(int(os.environ.get("Q", "80"))).subsampling(jpeg.Subsampling(1)).build()
 groups = ((n + 511) // 512) * ((n + 15) // 16)
 stream = torch.cuda.current_stream().cuda_stream
 for kind in kinds:

@@ -376,7 +376,11 @@ static int device_entropy_to_pinned_once(Context &c, const int16_t *dy, const in
     // where that kernel serves the job — one piece: the whole scan is coded ~50 us after the call began, which is where the
     // first of a medium scan's pieces used to be.  Large scans and host pixels in bands keep the pieces (their PCIe time is
     // what the pieces hide); their bands run coefficient kernel + scan_code as before.
-    const bool from_pixels = src && pixels_code_usable(j, o, g, batch);
+    // (A stream of files of more than 30 bytes per block — 4:2:0 above 5.6 bit/px: photographs at q = 100, noise at q >= 90 — would run the
+    // fused kernel's two-pass form for groups of several rounds, 25-50 % behind the two-kernel form: the context's last file decides,
+    // as it does for the pieces.  profiles/r06_long_groups_chain.txt)
+    const bool dense_stream = batch == 1 && c.last_scan_blocks && c.last_scan_bytes > 30 * c.last_scan_blocks && !debug().fused_batch;
+    const bool from_pixels = src && !dense_stream && pixels_code_usable(j, o, g, batch);
     if (from_pixels && batch > 1 && gaps_left) *gaps_left = j.seg_gap == seg_gap && seg_gap != 0; // (the fused kernel leaves any gap between its segments)
     // Second session of round 6: a LARGE scan from device pixels takes the fused kernel too when its stores can go straight to where the file
     // is wanted (the library's pinned buffer, or storage of the caller's the GPU can write) — one kernel whose groups finish one after

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     __shared__ int16_t s_dc[kGroup];
     __shared__ uint32_t wave_sum[kGroupWaves], wave_long[kGroupWaves];
     __shared__ unsigned long long s_before, s_segbase;
-    __shared__ uint32_t s_carry, s_abort, s_head, s_front2;
+    __shared__ uint32_t s_carry, s_abort, s_head, s_first_ones;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     PIXO_STAMP(0);
     __builtin_amdgcn_s_setprio(1); // phase A in front of the older workgroups' phase B (jpeg_kernels.hip)
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
     c.px = a_px + (size_t)img * early.px_stride; c.y = c.cb = c.cr = nullptr; c.qt = a_qt;
     c.W = a_W; c.H = a_H; c.units_x = a_units_x; c.units_y = a_units_y; c.fast = 1;
     c.px_end = a_px + early.px_bytes;
-    if (tid == 0) { s_carry = 0; s_abort = 0; s_head = 0; s_front2 = 0; s_segbase = 0; }
+    if (tid == 0) { s_carry = 0; s_abort = 0; s_head = 0; s_first_ones = 0; s_segbase = 0; }
     if (!SEG) {
         // dispatch_gate.hpp: the launch's last eight workgroups say that they have started — AT their start (behind phase A it was 8 us
         // later, which the next thread's launch spent waiting), and found from the preloaded arguments alone: no workgroup waits for
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             __syncthreads();
             if (uni(s_abort)) { aborted = true; return; }
             const uint32_t mask = (1u << sh8) - 1u;
-            if (uni(s_front2) && (uni(s_head) & mask) == mask) ff_group += 1u;
+            if (uni(s_first_ones) && (uni(s_head) & mask) == mask) ff_group += 1u;
         }
         if (tid == 0) store_relaxed(&desc2[g], kFlagAggregate | (uint64_t)ff_group);
         if (!second_look_back(ff_group)) return;
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
             return v;
         };
         // the last sh8 of the seven bits in front (a count pass runs without them: its first byte then cannot be 0xFF, and whether it is
-        // is settled behind the pass — s_front2: the group's own part of that byte is all ones)
+        // is settled behind the pass — s_first_ones: the group's own part of that byte is all ones)
         const uint32_t head_now = wbase ? head : ((MULTI && pass == 0) ? 0u : (uni(s_head) & ((1u << sh8) - 1u)));
         // owned bytes of THIS round: up to the group's last one, or (not the last round) up to the round's last complete aligned word
         const uint32_t round_first = 4u * wbase;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(6, 6))
         // it — noise at q >= 90, photographs at q = 100, gray noise at q = 80 took 24-46 ms per 4096x4096 file instead of 0.1 ms,
         // profiles/r06_long_groups_chain.txt.)
         if (MULTI && pass == 0) { // the count pass ends here
-            if (wbase == 0 && tid == 0) s_front2 = (x[0] >> 24) == (0xFFu >> sh8) ? 1u : 0u;
+            if (wbase == 0 && tid == 0) s_first_ones = (x[0] >> 24) == (0xFFu >> sh8) ? 1u : 0u;
             ff_group += round_ff;
             if (tid == 0) s_carry = buf[wn - 1];
             __syncthreads();

@@ -343,3 +343,49 @@ def test_groups_of_fewer_than_seven_bits_hand_on_the_bits_in_front_of_them(w, h,
                     want = O.encode(px, O.make_options(w, h, ct, q, ss, optimize_huffman=opt, restart=rows * units_x if rows else None))
                     assert jpeg.encode_device(d, o) == want, (w, h, ct, ss, opt, rows, q)
     assert jpeg.lookback_fallbacks() == 0
+
+
+def test_no_chain_through_all_groups_or_segments_of_a_launch():
+    """Timing with a wide margin, not parity: three times this round a workgroup that WAITED before it let its own value out made
+    every group (or segment) of a launch wait for the whole one before it — milliseconds where the work is tens of microseconds
+    (profiles/r06_fused_batches_chain.txt, r06_long_groups_chain.txt).  Device time by events, best of three, against bounds 8-20 x
+    above what the kernels take: (1) groups of several rounds (noise at q = 95: was 10 us per group), (2) the segments of a batch
+    (was 6.5 us per segment on top), (3) restart rows."""
+    import torch
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def device_us(d, o, batch=1):
+        best = 1e9
+        for _ in range(3):
+            for _ in range(3):
+                jpeg.debug_scan_device_async(d, o, stream=stream, batch=batch)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                jpeg.debug_scan_device_async(d, o, stream=stream, batch=batch)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 5 * 1e3)
+        return best
+
+    w = h = 2048  # 512 groups
+    d = torch.from_numpy(synth.noise(w, h, 3)).cuda()
+    o95 = jpeg.JpegOptions.builder(w, h).color_type(ColorType(2)).quality(95).subsampling(jpeg.Subsampling(1)).build()
+    assert _form(d, o95) == 1
+    t = device_us(d, o95)
+    assert t < 1000, "groups of several rounds: %.0f us for 512 groups (a chain through the groups takes 5000)" % t
+    g = torch.from_numpy(synth.noise_gray(w, h, 4)).cuda()
+    og = jpeg.JpegOptions.builder(w, h).color_type(ColorType(0)).quality(90).build()
+    t = device_us(g, og)
+    assert t < 1000, "gray groups of several rounds: %.0f us" % t
+    n, bw, bh = 128, 1024, 256  # 128 segments of 32 groups
+    imgs = np.concatenate([synth.photo(bw, bh, 60 + i % 4) for i in range(n)])
+    db = torch.from_numpy(imgs).cuda()
+    ob = jpeg.JpegOptions.builder(bw, bh).color_type(ColorType(2)).quality(80).subsampling(jpeg.Subsampling(1)).build()
+    assert _form(db, ob, n) == 1
+    t = device_us(db, ob, n)
+    assert t < 500, "a batch of 128 segments: %.0f us (a chain through the segments adds 800)" % t
+    orst = jpeg.JpegOptions.builder(w, h).color_type(ColorType(2)).quality(80).subsampling(jpeg.Subsampling(1)).restart_interval(w // 16).build()
+    t = device_us(d, orst)
+    assert t < 500, "128 restart rows: %.0f us" % t

@@ -170,7 +170,11 @@ int Context::reserve_hsegs(size_t words)
     if (words > hsegs_cap) {
         if (h_segs) (void)hipHostFree(h_segs);
         h_segs = nullptr; hsegs_cap = 0;
-        const size_t want = words + words / 4 + 16;
+        // (never below 1024 words: the block also receives the 536 symbol counters of an optimised-tables pass, and a job that has handed
+        // the block's address to a kernel — SegArgs::host_out_end — must not see it move when the counters ask for their room: a
+        // standard-tables call followed by an optimised-tables call with restart intervals had the stuffing kernel write the segments'
+        // ends into the freed block — a GPU memory fault, found by tools/stress_parity.py seed 955)
+        const size_t want = (words < 1024 ? 1024 : words) + words / 4 + 16;
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_segs), want * 8, hipHostMallocDefault));
         hsegs_cap = want;
     }

@@ -172,7 +172,7 @@ static int device_progressive_scans_fused(const int16_t *dy, const int16_t *dcb,
     HIP_TRY(c.e_segs.reserve((4 * 8 + 2) * 8));
     unsigned long long *base = c.e_segs.as<unsigned long long>();
     sg.bits = base; sg.layout = base + 8; sg.bytes = base + 2 * 8 + 2; sg.out_end = base + 3 * 8 + 2;
-    { const int rc_s = c.reserve_hsegs(8); if (rc_s) return rc_s; }
+    { const int rc_s = c.reserve_hsegs(pixo_host::kScanTableWords); if (rc_s) return rc_s; } // (8 scan ends; and the counters' room: see scan_begin)
     sg.host_out_end = reinterpret_cast<unsigned long long *>(c.h_segs);
     { const int rc_t = c.ensure_totals(); if (rc_t) return rc_t; }
     uint32_t packed[pixo_host::kScanTableWords];

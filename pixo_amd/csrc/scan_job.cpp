@@ -186,7 +186,8 @@ int scan_begin(Context &c, ScanJob &j, const int16_t *dy, const int16_t *dcb, co
         sg.layout = base + j.nseg;
         sg.bytes = base + 2 * j.nseg + 2;
         sg.out_end = base + 3 * j.nseg + 2;
-        { const int rc_s = c.reserve_hsegs(j.nseg); if (rc_s) return rc_s; }
+        // (room for the optimised-tables counters as well: scan_count / pixels_count reserve theirs AFTER this address has been handed out)
+        { const int rc_s = c.reserve_hsegs(std::max<size_t>(j.nseg, pixo_host::kScanTableWords)); if (rc_s) return rc_s; }
         sg.host_out_end = reinterpret_cast<unsigned long long *>(c.h_segs);
         { const int rc_t = c.ensure_totals(); if (rc_t) return rc_t; }
         a.tables = c.e_tables.as<uint32_t>();

@@ -928,3 +928,21 @@ def test_batch_in_sub_batches_gives_the_same_arena():
     assert arena[offs[n - 1]: offs[n - 1] + lens[n - 1]].numpy().tobytes() == want
     other = bytes(d[w * h * 3 * 7: w * h * 3 * 8].cpu().numpy())
     assert arena[offs[7]: offs[7] + lens[7]].numpy().tobytes() == O.encode(np.frombuffer(other, np.uint8), O.make_options(w, h, 2, 80, 1))
+
+
+def test_optimised_tables_with_restart_intervals_behind_a_standard_tables_call():
+    """Found by tools/stress_parity.py (seed 955, a GPU memory fault): the pinned block that receives the segments' ends also receives the
+    536 symbol counters of an optimised-tables pass, and growing it for the counters moved it under the address a segmented job had already
+    handed to the stuffing kernel — only when an earlier call of the thread had left the block small.  The sequence, several sizes."""
+    for (w, h, ss, restart) in ((95, 260, 0, 35), (95, 260, 0, 36), (640, 480, 1, 17), (333, 222, 0, 100)):
+        n = w * h * 3
+        px = synth.lcg_bytes(n, 1234).copy()
+        px[px < 128] = 0
+        px[px >= 128] = 255
+        jpeg.trim()  # (the thread's buffers start over: the block is small again)
+        for opt, r in ((False, None), (True, restart), (False, restart), (True, restart)):
+            o = _opts(w, h, 2, ss, 77, **({"restart_interval": r} if r else {}), **({"optimize_huffman": True} if opt else {}))
+            kw = dict(optimize_huffman=opt)
+            if r:
+                kw["restart"] = r
+            assert jpeg.encode(px, o) == O.encode(px, O.make_options(w, h, 2, 77, ss, **kw)), (w, h, ss, opt, r)
